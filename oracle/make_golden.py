@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the compiled reference (oracle/_ref/ref_harness).  TEST INFRASTRUCTURE.
+
+Runs only where /root/reference exists (the build container).  For each parameter set it
+  1. creates keys / ciphertexts / plaintexts with the oracle's seeded client-side code,
+  2. feeds them to the *reference itself* (SEAL 2.3.1 Evaluator and the CrCNN Layer classes, compiled in place),
+  3. stores the reference's outputs (and the inputs, so a drifting oracle RNG is detected) as a compressed .npz.
+tests/test_oracle_golden.py then replays the same inputs through the oracle and demands bit equality; the GPU
+parity tests demand the same of the HIP path.
+
+usage:  python oracle/make_golden.py [ops] [layers] [nets] [loader]
+"""
+import hashlib
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import orc  # noqa: E402
+
+HARNESS = os.path.join(HERE, "_ref", "ref_harness")
+GOLD = os.path.join(ROOT, "tests", "golden")
+REF = os.environ.get("CRC_REFERENCE", "/root/reference")
+
+OP_SETS = {
+    # name: (n, q list, t, number of cts, plaintext values)
+    "ops_n256_k2_t20": (256, [0x7fffffff380001, 0x3fffffff000001], 1 << 20, 3, [0.25, -2.5, 1.0, 0.0202090591192245]),
+    "ops_n256_k3_t30": (256, [0x7fffffff380001, 0x7ffffffef00001, 0x3fffffff000001], 1 << 30, 2, [-0.1307, 7.0, 0.3333]),
+    "ops_n256_k1_q60_t30": (256, [0xffffffffffc0001], 1 << 30, 2, [0.5, -1.75]),   # aux base grows by one (baseconverter.cpp:47-56)
+    "ops_n2048_k1_t18": (2048, [0x3fffffff000001], 1 << 18, 1, [0.4242, -3.0]),   # the committed driver's parameters (mainparams.cpp:75-76)
+}
+FLOATS = [0.0, 1.0, -1.0, 0.25, -2.5, 0.5, -0.5, 1.5, 2.5, -0.4242129623889923, 2.8214867115020752, 100.125, -77.0,
+          3.14159, 1e-9, -1e-7, 0.1307, 0.3081, 1.0 / 3.0, 12345.678, 0.020209059119224548, 4.656612873077393e-10]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def run(mode, d):
+    subprocess.check_call([HARNESS, mode, d])
+
+
+def put(d, name, arr, dtype=np.uint64):
+    np.ascontiguousarray(arr, dtype=dtype).tofile(os.path.join(d, name))
+
+
+def get(d, name, shape=None):
+    a = np.fromfile(os.path.join(d, name), dtype=np.uint64)
+    return a.reshape(shape) if shape else a
+
+
+def make_ops(name, n, q, t, nct, vals):
+    O = orc.Oracle(n, q, t)
+    k = O.k
+    sk, pk = O.keygen(1000)
+    evk = O.gen_evk(1001, sk)
+    plains = np.zeros((len(vals), n), dtype=np.uint64)
+    cc = np.zeros(len(vals), dtype=np.uint64)
+    for j, v in enumerate(vals):
+        plains[j], cc[j] = O.encode(np.float32(v) if abs(v) < 1e30 else v)
+    msgs = O.encode_many([0.7071, -1.25, 3.5][:nct])
+    cts = O.encrypt_many(pk, msgs, 2000)
+    with tempfile.TemporaryDirectory() as d:
+        put(d, "params.u64", [n, k, t] + list(q))
+        put(d, "sk.u64", sk); put(d, "pk.u64", pk); put(d, "evk.u64", evk)
+        put(d, "ct_in.u64", cts); put(d, "plains.u64", plains); put(d, "plain_cc.u64", cc)
+        put(d, "floats.f64", FLOATS, dtype=np.float64)
+        run("ops", d)
+        npl = len(vals)
+        g = dict(
+            n=n, q=np.array(q, dtype=np.uint64), t=t, floats=np.array(FLOATS), plain_values=np.array(vals),
+            sk=sk, pk=pk, evk=evk, ct_in=cts, plains=plains, plain_cc=cc, msgs=msgs,
+            ref_consts=get(d, "ref_consts.u64"),
+            ref_root_powers0=get(d, "ref_root_powers0.u64", (2, n)),
+            ref_dec_in=get(d, "ref_dec_in.u64", (nct, n)), ref_budget_in=get(d, "ref_budget_in.u64"),
+            ref_enc=get(d, "ref_enc.u64", (npl, 2, k, n)),
+            ref_sk=get(d, "ref_sk.u64", (k, n)), ref_pk=get(d, "ref_pk.u64", (2, k, n)), ref_evk=get(d, "ref_evk.u64"),
+            ref_enc2=get(d, "ref_enc2.u64", (npl, 2, k, n)), ref_sq2=get(d, "ref_sq2.u64", (npl, 3, k, n)),
+            ref_relin2=get(d, "ref_relin2.u64", (npl, 2, k, n)), ref_dec_relin2=get(d, "ref_dec_relin2.u64", (npl, n)),
+            ref_ct_ntt=get(d, "ref_ct_ntt.u64", (nct, 2, k, n)), ref_plain_ntt=get(d, "ref_plain_ntt.u64", (npl, k, n)),
+            ref_mul_ntt=get(d, "ref_mul_ntt.u64", (nct, npl, 2, k, n)), ref_mul=get(d, "ref_mul.u64", (nct, npl, 2, k, n)),
+            ref_add=get(d, "ref_add.u64", (nct, 2, k, n)), ref_add_plain=get(d, "ref_add_plain.u64", (nct, npl, 2, k, n)),
+            ref_sub_plain=get(d, "ref_sub_plain.u64", (nct, npl, 2, k, n)), ref_mul_plain=get(d, "ref_mul_plain.u64", (nct, npl, 2, k, n)),
+            ref_sq=get(d, "ref_sq.u64", (nct, 3, k, n)), ref_relin=get(d, "ref_relin.u64", (nct, 2, k, n)),
+            ref_budget_relin=get(d, "ref_budget_relin.u64"), ref_dec_relin=get(d, "ref_dec_relin.u64", (nct, n)),
+            ref_enc_floats=get(d, "ref_enc_floats.u64", (len(FLOATS), n)), ref_enc_cc=get(d, "ref_enc_cc.u64"),
+            ref_decode=get(d, "ref_decode.u64").view(np.float64),
+        )
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **g)
+    print("wrote", name, {k_: getattr(v, "shape", v) for k_, v in g.items() if k_.startswith("ref_")})
+
+
+LAYER_SET = dict(n=256, q=[0x7fffffff380001, 0x3fffffff000001], t=1 << 20, zd=2, xd=5, yd=5,
+                 conv=(2, 1, 3, 3, 3), fc_out=4, pool=(2, 1, 2, 2))
+
+
+def make_layers():
+    S = LAYER_SET
+    n, q, t = S["n"], S["q"], S["t"]
+    O = orc.Oracle(n, q, t); k = O.k
+    sk, pk = O.keygen(3000); evk = O.gen_evk(3001, sk)
+    rng = np.random.RandomState(7)
+    zd, xd, yd = S["zd"], S["xd"], S["yd"]
+    img = rng.uniform(-1.5, 2.8, size=(zd, xd, yd)).astype(np.float32)
+    x = O.encrypt_many(pk, O.encode_many(img).reshape(zd, xd, yd, n), 4000)
+    xs, ys, xf, yf, nf = S["conv"]
+    conv_w = rng.normal(0, 0.2, size=(nf, zd, xf, yf)).astype(np.float32); conv_b = rng.normal(0, 0.1, size=nf).astype(np.float32)
+    fc_w = rng.normal(0, 0.2, size=(S["fc_out"], zd * xd * yd)).astype(np.float32); fc_b = rng.normal(0, 0.1, size=S["fc_out"]).astype(np.float32)
+    bn_mean = rng.normal(0, 0.3, size=zd).astype(np.float32); bn_var = rng.uniform(0.5, 2.0, size=zd).astype(np.float32)
+    with tempfile.TemporaryDirectory() as d:
+        put(d, "params.u64", [n, k, t] + list(q)); put(d, "evk.u64", evk)
+        put(d, "layer_dims.u64", [zd, xd, yd, xs, ys, xf, yf, nf, S["fc_out"]] + list(S["pool"]))
+        put(d, "layer_in.u64", x)
+        for nm, a in [("conv_w", conv_w), ("conv_b", conv_b), ("fc_w", fc_w), ("fc_b", fc_b), ("bn_mean", bn_mean), ("bn_var", bn_var)]:
+            put(d, nm + ".f64", a.astype(np.float64), dtype=np.float64)
+        run("layers", d)
+        xo, yo = (xd - xf) // xs + 1, (yd - yf) // ys + 1
+        pxs, pys, pxf, pyf = S["pool"]
+        pxo, pyo = (xd - pxf) // pxs + 1, (yd - pyf) // pys + 1
+        g = dict(n=n, q=np.array(q, dtype=np.uint64), t=t, sk=sk, pk=pk, evk=evk, x=x, img=img,
+                 dims=np.array([zd, xd, yd, xs, ys, xf, yf, nf, S["fc_out"]] + list(S["pool"])),
+                 conv_w=conv_w, conv_b=conv_b, fc_w=fc_w, fc_b=fc_b, bn_mean=bn_mean, bn_var=bn_var,
+                 ref_conv=get(d, "ref_conv.u64", (nf, xo, yo, 2, k, n)), ref_fc=get(d, "ref_fc.u64", (1, S["fc_out"], 1, 2, k, n)),
+                 ref_pool=get(d, "ref_pool.u64", (zd, pxo, pyo, 2, k, n)), ref_avgpool=get(d, "ref_avgpool.u64", (zd, pxo, pyo, 2, k, n)),
+                 ref_bn=get(d, "ref_bn.u64", (zd, xd, yd, 2, k, n)), ref_square=get(d, "ref_square.u64", (zd, xd, yd, 2, k, n)))
+    np.savez_compressed(os.path.join(GOLD, "layers_n256_k2_t20.npz"), **g)
+    print("wrote layers", {k_: v.shape for k_, v in g.items() if k_.startswith("ref_")})
+
+
+# ---- model weights straight from the reference's .h5 files via the image's h5dump (pins the product's own HDF5 reader)
+def h5_dataset(path, name):
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "o.bin")
+        subprocess.check_call(["/opt/conda/bin/h5dump", "-d", "/" + name, "-b", "LE", "-o", out, path], stdout=subprocess.DEVNULL)
+        return np.fromfile(out, dtype="<f4")
+
+
+def h5_names(path):
+    txt = subprocess.check_output(["/opt/conda/bin/h5ls", path]).decode()
+    return [ln.split()[0].replace("\\", "") for ln in txt.splitlines() if ln.strip()]
+
+
+MODELS = ["PlainModelTiny", "ApproxPlainModel", "PlainModelWoPad"]
+
+
+def make_loader():
+    g = {}
+    for m in MODELS:
+        path = os.path.join(REF, "PlainModel", m + ".h5")
+        for nm in h5_names(path):
+            a = h5_dataset(path, nm)
+            g[m + "/" + nm + "/sha256"] = sha(a)
+            g[m + "/" + nm + "/count"] = a.size
+            g[m + "/" + nm + "/head"] = a[:8].copy()
+            g[m + "/" + nm + "/sum64"] = float(a.astype(np.float64).sum())
+    np.savez_compressed(os.path.join(GOLD, "h5_datasets.npz"), **g)
+    print("wrote loader fixture:", len(g) // 4, "datasets")
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["ops", "layers", "loader"]
+    os.makedirs(GOLD, exist_ok=True)
+    if not os.path.exists(HARNESS):
+        subprocess.check_call(["make", "-C", HERE, "ref", "-j8"])
+    if "ops" in what:
+        for nm, (n, q, t, nct, vals) in OP_SETS.items():
+            make_ops(nm, n, q, t, nct, vals)
+    if "layers" in what:
+        make_layers()
+    if "loader" in what:
+        make_loader()
+    if "nets" in what:
+        from oracle import make_golden_nets
+        make_golden_nets.main()
