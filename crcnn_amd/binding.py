@@ -1,0 +1,323 @@
+"""ctypes binding of libcrcnn_hip.so (the C ABI in include/crcnn_hip.h).
+
+This module is plumbing: it loads the in-tree shared library, checks that every symbol the header declares is
+exported, and offers a small `Engine` convenience class (device buffers + numpy round trips) for tests, the bench
+harness and Python users.  There is NO CPU fallback: a missing library or a failing call raises.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcrcnn_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "crcnn_hip.h")
+
+u64 = ctypes.c_uint64
+PU = ctypes.POINTER(u64)
+VP = ctypes.c_void_p
+CI = ctypes.c_int
+SZ = ctypes.c_size_t
+
+COEFF, NTT = 0, 1
+
+
+class CrcError(RuntimeError):
+    def __init__(self, status, what=""):
+        self.status = status
+        super().__init__(f"{what}: {_strerror(status)} (status {status}, hip error {_lib.crc_last_hip_error() if _lib else '?'})")
+
+
+_lib = None
+
+
+def header_symbols():
+    """names of every function declared in include/crcnn_hip.h"""
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(crc_[a-z0-9_]+)\s*\(", txt)))
+
+
+def _strerror(s):
+    return _lib.crc_strerror(s).decode() if _lib else "?"
+
+
+def load():
+    """dlopen the in-tree library; raises if it was not built (run `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: the HIP extension has not been built (no CPU fallback exists)")
+    L = ctypes.CDLL(LIB_PATH)
+    missing = [s for s in header_symbols() if not hasattr(L, s)]
+    if missing:
+        raise ImportError(f"libcrcnn_hip.so does not export: {missing}")
+    L.crc_strerror.restype = ctypes.c_char_p
+    L.crc_strerror.argtypes = [CI]
+    L.crc_ctx_create.argtypes = [CI, PU, CI, u64, CI, ctypes.POINTER(VP)]
+    L.crc_ctx_destroy.argtypes = [VP]
+    L.crc_ctx_destroy.restype = None
+    L.crc_default_coeff_modulus_128.argtypes = [CI, PU, CI]
+    for f in ("crc_ctx_n", "crc_ctx_k", "crc_ctx_kbsk", "crc_ctx_device"):
+        getattr(L, f).argtypes = [VP]
+    L.crc_ct_words.restype = SZ; L.crc_ct_words.argtypes = [VP, CI]
+    L.crc_evk_words.restype = SZ; L.crc_evk_words.argtypes = [VP, CI]
+    L.crc_ctx_table.argtypes = [VP, ctypes.c_char_p, PU, CI]
+    L.crc_malloc.argtypes = [VP, SZ, ctypes.POINTER(VP)]
+    L.crc_free.argtypes = [VP, VP]
+    L.crc_memcpy_h2d.argtypes = [VP, VP, VP, SZ, VP]
+    L.crc_memcpy_d2h.argtypes = [VP, VP, VP, SZ, VP]
+    L.crc_memcpy_d2d.argtypes = [VP, VP, VP, SZ, VP]
+    L.crc_memset.argtypes = [VP, VP, CI, SZ, VP]
+    L.crc_stream_sync.argtypes = [VP, VP]
+    L.crc_encode_f32.argtypes = [VP, ctypes.POINTER(ctypes.c_float), SZ, PU, ctypes.POINTER(ctypes.c_int32)]
+    L.crc_encode_f64.argtypes = [VP, ctypes.POINTER(ctypes.c_double), SZ, PU, ctypes.POINTER(ctypes.c_int32)]
+    L.crc_decode.restype = ctypes.c_double; L.crc_decode.argtypes = [VP, PU]
+    L.crc_bn_invstd_f32.argtypes = [ctypes.POINTER(ctypes.c_float), SZ, ctypes.POINTER(ctypes.c_float)]
+    L.crc_plain_to_ntt.argtypes = [VP, VP, SZ, VP, VP]
+    L.crc_plain_to_delta.argtypes = [VP, VP, SZ, CI, VP, VP]
+    L.crc_ntt_fwd.argtypes = [VP, VP, SZ, CI, VP]
+    L.crc_ntt_inv.argtypes = [VP, VP, SZ, CI, VP]
+    L.crc_ntt_fwd_bsk.argtypes = [VP, VP, SZ, VP]
+    L.crc_ntt_inv_bsk.argtypes = [VP, VP, SZ, VP]
+    L.crc_add.argtypes = [VP, VP, VP, SZ, CI, VP]
+    L.crc_add_plain.argtypes = [VP, VP, VP, SZ, SZ, CI, VP]
+    L.crc_multiply_plain_ntt.argtypes = [VP, VP, VP, SZ, SZ, CI, VP]
+    L.crc_multiply_plain.argtypes = [VP, VP, VP, SZ, SZ, VP]
+    L.crc_conv2d_work_bytes.restype = SZ; L.crc_conv2d_work_bytes.argtypes = [VP] + [CI] * 10
+    L.crc_conv2d.argtypes = [VP, VP, VP, VP] + [CI] * 11 + [VP, VP, VP]
+    L.crc_dense_work_bytes.restype = SZ; L.crc_dense_work_bytes.argtypes = [VP, CI, CI, CI, CI]
+    L.crc_dense.argtypes = [VP, VP, VP, VP, CI, CI, CI, CI, CI, VP, VP, VP]
+    L.crc_pool.argtypes = [VP, VP] + [CI] * 8 + [VP, CI, VP, VP]
+    L.crc_batchnorm.argtypes = [VP, VP, CI, CI, CI, CI, VP, VP, CI, VP]
+    L.crc_square_relin_work_bytes.restype = SZ; L.crc_square_relin_work_bytes.argtypes = [VP, SZ, CI]
+    L.crc_square_relin.argtypes = [VP, VP, SZ, VP, CI, VP, VP, VP]
+    L.crc_square.argtypes = [VP, VP, SZ, VP, VP, VP]
+    L.crc_relinearize.argtypes = [VP, VP, SZ, VP, CI, VP, VP, VP]
+    L.crc_import_seal.argtypes = [VP, PU, CI, PU]
+    L.crc_export_seal.argtypes = [VP, PU, CI, PU]
+    L.crc_h5_dataset_count.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(SZ)]
+    L.crc_h5_read_f32.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float), SZ, ctypes.POINTER(SZ)]
+    L.crc_h5_list.argtypes = [ctypes.c_char_p, ctypes.c_char_p, SZ]
+    L.crc_keygen.argtypes = [VP, u64, PU, PU]
+    L.crc_gen_evk.argtypes = [VP, u64, PU, CI, PU]
+    L.crc_encrypt.argtypes = [VP, PU, PU, SZ, u64, PU]
+    L.crc_decrypt.argtypes = [VP, PU, PU, SZ, CI, PU]
+    L.crc_noise_budget.argtypes = [VP, PU, PU, CI]
+    _lib = L
+    return L
+
+
+def _chk(status, what):
+    if status < 0:
+        raise CrcError(status, what)
+    return status
+
+
+def _pu(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(PU)
+
+
+def default_coeff_modulus_128(n):
+    L = load()
+    buf = (u64 * 16)()
+    cnt = _chk(L.crc_default_coeff_modulus_128(n, buf, 16), "crc_default_coeff_modulus_128")
+    return [int(buf[i]) for i in range(cnt)]
+
+
+def h5_read(path, name):
+    L = load()
+    cnt = SZ(0)
+    _chk(L.crc_h5_dataset_count(path.encode(), name.encode(), ctypes.byref(cnt)), f"crc_h5_dataset_count({name})")
+    out = np.zeros(cnt.value, dtype=np.float32)
+    _chk(L.crc_h5_read_f32(path.encode(), name.encode(), out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), cnt.value, None), "crc_h5_read_f32")
+    return out
+
+
+def h5_list(path):
+    L = load()
+    buf = ctypes.create_string_buffer(1 << 16)
+    _chk(L.crc_h5_list(path.encode(), buf, len(buf)), "crc_h5_list")
+    return [s for s in buf.value.decode().split("\n") if s]
+
+
+class DBuf:
+    """a device allocation owned through crc_malloc/crc_free"""
+
+    def __init__(self, eng, nbytes):
+        self.eng, self.nbytes = eng, int(nbytes)
+        p = VP()
+        _chk(eng.L.crc_malloc(eng.c, max(self.nbytes, 8), ctypes.byref(p)), "crc_malloc")
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr:
+            self.eng.L.crc_free(self.eng.c, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One context = one (n, q[], t) parameter set on one device (device=-1: host-only, for encode/client/tables)."""
+
+    def __init__(self, n, q, t, device=0):
+        self.L = load()
+        self.n, self.k, self.t, self.device = int(n), len(q), int(t), device
+        self.q = np.array(q, dtype=np.uint64)
+        c = VP()
+        _chk(self.L.crc_ctx_create(self.n, _pu(self.q), self.k, self.t, device, ctypes.byref(c)), "crc_ctx_create")
+        self.c = c
+        self.kbsk = self.L.crc_ctx_kbsk(self.c)
+        self.stream = None
+
+    def close(self):
+        if self.c:
+            self.L.crc_ctx_destroy(self.c)
+            self.c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- memory
+    def alloc(self, nbytes):
+        return DBuf(self, nbytes)
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        b = DBuf(self, arr.nbytes)
+        _chk(self.L.crc_memcpy_h2d(self.c, b.ptr, arr.ctypes.data, arr.nbytes, self.stream), "crc_memcpy_h2d")
+        self.sync()
+        return b
+
+    def download(self, buf, shape, dtype=np.uint64):
+        out = np.zeros(shape, dtype=dtype)
+        self.sync()
+        _chk(self.L.crc_memcpy_d2h(self.c, out.ctypes.data, buf.ptr if isinstance(buf, DBuf) else buf, out.nbytes, self.stream), "crc_memcpy_d2h")
+        self.sync()
+        return out
+
+    def sync(self):
+        _chk(self.L.crc_stream_sync(self.c, self.stream), "crc_stream_sync")
+
+    def table(self, name, cap=1 << 16):
+        out = np.zeros(cap, dtype=np.uint64)
+        cnt = _chk(self.L.crc_ctx_table(self.c, name.encode(), _pu(out), cap), f"crc_ctx_table({name})")
+        return out[:cnt].copy()
+
+    # ---- host side: encode / client
+    def encode(self, values, dtype=np.float32):
+        values = np.ascontiguousarray(np.asarray(values, dtype=dtype).reshape(-1))
+        out = np.zeros((values.size, self.n), dtype=np.uint64)
+        cc = np.zeros(values.size, dtype=np.int32)
+        if dtype == np.float32:
+            _chk(self.L.crc_encode_f32(self.c, values.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), values.size, _pu(out), cc.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))), "crc_encode_f32")
+        else:
+            _chk(self.L.crc_encode_f64(self.c, values.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), values.size, _pu(out), cc.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))), "crc_encode_f64")
+        return out, cc
+
+    def decode(self, plain):
+        return self.L.crc_decode(self.c, _pu(np.ascontiguousarray(plain)))
+
+    def keygen(self, seed):
+        sk = np.zeros((self.k, self.n), dtype=np.uint64); pk = np.zeros((2, self.k, self.n), dtype=np.uint64)
+        _chk(self.L.crc_keygen(self.c, seed, _pu(sk), _pu(pk)), "crc_keygen"); return sk, pk
+
+    def gen_evk(self, seed, sk, dbc=16):
+        evk = np.zeros(self.L.crc_evk_words(self.c, dbc), dtype=np.uint64)
+        _chk(self.L.crc_gen_evk(self.c, seed, _pu(sk), dbc, _pu(evk)), "crc_gen_evk"); return evk
+
+    def encrypt(self, pk, plains, seed):
+        plains = np.ascontiguousarray(plains); lead = plains.shape[:-1]
+        cnt = int(np.prod(lead)) if lead else 1
+        ct = np.zeros((cnt, 2, self.k, self.n), dtype=np.uint64)
+        _chk(self.L.crc_encrypt(self.c, _pu(pk), _pu(plains.reshape(cnt, self.n)), cnt, seed, _pu(ct)), "crc_encrypt")
+        return ct.reshape(lead + (2, self.k, self.n))
+
+    def decrypt(self, sk, cts, size=2):
+        cts = np.ascontiguousarray(cts); lead = cts.shape[:-3]
+        cnt = int(np.prod(lead)) if lead else 1
+        out = np.zeros((cnt, self.n), dtype=np.uint64)
+        _chk(self.L.crc_decrypt(self.c, _pu(sk), _pu(cts), cnt, size, _pu(out)), "crc_decrypt")
+        return out.reshape(lead + (self.n,))
+
+    def noise_budget(self, sk, ct):
+        ct = np.ascontiguousarray(ct)
+        return _chk(self.L.crc_noise_budget(self.c, _pu(sk), _pu(ct), ct.shape[-3]), "crc_noise_budget")
+
+    # ---- device ops on DBuf / raw pointers (p(x) accepts DBuf, int, or torch tensor with data_ptr)
+    @staticmethod
+    def p(x):
+        if x is None:
+            return None
+        if isinstance(x, DBuf):
+            return x.ptr
+        if hasattr(x, "data_ptr"):
+            return x.data_ptr()
+        return int(x)
+
+    def plain_to_ntt(self, d_plain, count, d_out):
+        _chk(self.L.crc_plain_to_ntt(self.c, self.p(d_plain), count, self.p(d_out), self.stream), "crc_plain_to_ntt")
+
+    def plain_to_delta(self, d_plain, count, form, d_out):
+        _chk(self.L.crc_plain_to_delta(self.c, self.p(d_plain), count, form, self.p(d_out), self.stream), "crc_plain_to_delta")
+
+    def ntt_fwd(self, d_ct, count, size=2):
+        _chk(self.L.crc_ntt_fwd(self.c, self.p(d_ct), count, size, self.stream), "crc_ntt_fwd")
+
+    def ntt_inv(self, d_ct, count, size=2):
+        _chk(self.L.crc_ntt_inv(self.c, self.p(d_ct), count, size, self.stream), "crc_ntt_inv")
+
+    def add(self, d_acc, d_b, count, size=2):
+        _chk(self.L.crc_add(self.c, self.p(d_acc), self.p(d_b), count, size, self.stream), "crc_add")
+
+    def add_plain(self, d_ct, d_delta, count, group, sign=1):
+        _chk(self.L.crc_add_plain(self.c, self.p(d_ct), self.p(d_delta), count, group, sign, self.stream), "crc_add_plain")
+
+    def multiply_plain_ntt(self, d_ct, d_w, count, group, size=2):
+        _chk(self.L.crc_multiply_plain_ntt(self.c, self.p(d_ct), self.p(d_w), count, group, size, self.stream), "crc_multiply_plain_ntt")
+
+    def multiply_plain(self, d_ct, d_w, count, group):
+        _chk(self.L.crc_multiply_plain(self.c, self.p(d_ct), self.p(d_w), count, group, self.stream), "crc_multiply_plain")
+
+    def conv2d_work_bytes(self, B, zd, xd, yd, xs, ys, xf, yf, nf, in_form):
+        return self.L.crc_conv2d_work_bytes(self.c, B, zd, xd, yd, xs, ys, xf, yf, nf, in_form)
+
+    def conv2d(self, d_x, d_w, d_bias, B, zd, xd, yd, xs, ys, xf, yf, nf, in_form, out_form, d_y, d_work):
+        _chk(self.L.crc_conv2d(self.c, self.p(d_x), self.p(d_w), self.p(d_bias), B, zd, xd, yd, xs, ys, xf, yf, nf, in_form, out_form,
+                               self.p(d_y), self.p(d_work), self.stream), "crc_conv2d")
+
+    def dense_work_bytes(self, B, in_dim, out_dim, in_form):
+        return self.L.crc_dense_work_bytes(self.c, B, in_dim, out_dim, in_form)
+
+    def dense(self, d_x, d_w, d_bias, B, in_dim, out_dim, in_form, out_form, d_y, d_work):
+        _chk(self.L.crc_dense(self.c, self.p(d_x), self.p(d_w), self.p(d_bias), B, in_dim, out_dim, in_form, out_form, self.p(d_y), self.p(d_work),
+                              self.stream), "crc_dense")
+
+    def pool(self, d_x, B, zd, xd, yd, xs, ys, xf, yf, d_div, form, d_y):
+        _chk(self.L.crc_pool(self.c, self.p(d_x), B, zd, xd, yd, xs, ys, xf, yf, self.p(d_div), form, self.p(d_y), self.stream), "crc_pool")
+
+    def batchnorm(self, d_x, B, zd, xd, yd, d_mean, d_invstd, form):
+        _chk(self.L.crc_batchnorm(self.c, self.p(d_x), B, zd, xd, yd, self.p(d_mean), self.p(d_invstd), form, self.stream), "crc_batchnorm")
+
+    def square_relin_work_bytes(self, count, dbc=16):
+        return self.L.crc_square_relin_work_bytes(self.c, count, dbc)
+
+    def square_relin(self, d_x, count, d_evk, d_y, d_work, dbc=16):
+        _chk(self.L.crc_square_relin(self.c, self.p(d_x), count, self.p(d_evk), dbc, self.p(d_y), self.p(d_work), self.stream), "crc_square_relin")
+
+    def square(self, d_x, count, d_y3, d_work):
+        _chk(self.L.crc_square(self.c, self.p(d_x), count, self.p(d_y3), self.p(d_work), self.stream), "crc_square")
+
+    def relinearize(self, d_x3, count, d_evk, d_y, d_work, dbc=16):
+        _chk(self.L.crc_relinearize(self.c, self.p(d_x3), count, self.p(d_evk), dbc, self.p(d_y), self.p(d_work), self.stream), "crc_relinearize")

@@ -1,0 +1,200 @@
+// abi.hip -- extern "C" entry points of include/crcnn_hip.h that drive the kernels (layers and Evaluator ops).
+#include "kernels.h"
+
+#define CHECK_CTX(c) do { if (!(c) || (c)->device < 0) return CRC_ERR_INVALID_ARGUMENT; } while (0)
+#define RUN(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+static inline hipStream_t S(void *s) { return (hipStream_t)s; }
+static inline bool form_ok(int f) { return f == CRC_COEFF || f == CRC_NTT; }
+
+extern "C" int crc_plain_to_ntt(crc_ctx *c, const uint64_t *d_plain, size_t count, uint64_t *d_out, void *stream)
+{
+    CHECK_CTX(c); if (!d_plain || !d_out) return CRC_ERR_INVALID_ARGUMENT;
+    return k_plain_ntt(c, d_plain, count, 1, true, d_out, S(stream));
+}
+extern "C" int crc_plain_to_delta(crc_ctx *c, const uint64_t *d_plain, size_t count, int form, uint64_t *d_out, void *stream)
+{
+    CHECK_CTX(c); if (!d_plain || !d_out || !form_ok(form)) return CRC_ERR_INVALID_ARGUMENT;
+    return k_plain_ntt(c, d_plain, count, 2, form == CRC_NTT, d_out, S(stream));
+}
+
+extern "C" int crc_ntt_fwd(crc_ctx *c, uint64_t *d_ct, size_t count, int size, void *stream)
+{
+    CHECK_CTX(c); if (!d_ct || size < 1) return CRC_ERR_INVALID_ARGUMENT;
+    return k_ntt_ct(c, false, d_ct, d_ct, count, size, false, S(stream), nullptr, 0, 0);
+}
+extern "C" int crc_ntt_inv(crc_ctx *c, uint64_t *d_ct, size_t count, int size, void *stream)
+{
+    CHECK_CTX(c); if (!d_ct || size < 1) return CRC_ERR_INVALID_ARGUMENT;
+    return k_ntt_ct(c, true, d_ct, d_ct, count, size, false, S(stream), nullptr, 0, 0);
+}
+extern "C" int crc_ntt_fwd_bsk(crc_ctx *c, uint64_t *d_rows, size_t count, void *stream)
+{
+    CHECK_CTX(c); if (!d_rows) return CRC_ERR_INVALID_ARGUMENT;
+    return k_ntt_ct(c, false, d_rows, d_rows, count, 1, true, S(stream), nullptr, 0, 0);
+}
+extern "C" int crc_ntt_inv_bsk(crc_ctx *c, uint64_t *d_rows, size_t count, void *stream)
+{
+    CHECK_CTX(c); if (!d_rows) return CRC_ERR_INVALID_ARGUMENT;
+    return k_ntt_ct(c, true, d_rows, d_rows, count, 1, true, S(stream), nullptr, 0, 0);
+}
+
+extern "C" int crc_add(crc_ctx *c, uint64_t *d_acc, const uint64_t *d_b, size_t count, int size, void *stream)
+{
+    CHECK_CTX(c); if (!d_acc || !d_b || size < 1) return CRC_ERR_INVALID_ARGUMENT;
+    return k_rowwise(c, d_acc, d_b, count, size, 0, 1, 1, 0, S(stream));
+}
+extern "C" int crc_add_plain(crc_ctx *c, uint64_t *d_ct, const uint64_t *d_delta, size_t count, size_t group, int sign, void *stream)
+{
+    CHECK_CTX(c); if (!d_ct || !d_delta || (sign != 1 && sign != -1)) return CRC_ERR_INVALID_ARGUMENT;
+    return k_rowwise(c, d_ct, d_delta, count, 2, 1, sign, group, 0, S(stream));
+}
+extern "C" int crc_multiply_plain_ntt(crc_ctx *c, uint64_t *d_ct, const uint64_t *d_w, size_t count, size_t group, int size, void *stream)
+{
+    CHECK_CTX(c); if (!d_ct || !d_w || size < 1) return CRC_ERR_INVALID_ARGUMENT;
+    return k_rowwise(c, d_ct, d_w, count, size, 2, 1, group, 0, S(stream));
+}
+extern "C" int crc_multiply_plain(crc_ctx *c, uint64_t *d_ct, const uint64_t *d_w, size_t count, size_t group, void *stream)
+{
+    CHECK_CTX(c); if (!d_ct || !d_w) return CRC_ERR_INVALID_ARGUMENT;
+    RUN(k_ntt_ct(c, false, d_ct, d_ct, count, 2, false, S(stream), nullptr, 0, 0));
+    RUN(k_rowwise(c, d_ct, d_w, count, 2, 2, 1, group, 0, S(stream)));
+    return k_ntt_ct(c, true, d_ct, d_ct, count, 2, false, S(stream), nullptr, 0, 0);
+}
+
+// ---- convolution / dense ------------------------------------------------------------------------------------------
+static bool conv_shape_ok(int xd, int yd, int xs, int ys, int xf, int yf)
+{
+    if (xd < 1 || yd < 1 || xs < 1 || ys < 1 || xf < 1 || yf < 1 || xf > xd || yf > yd) return false;
+    // the reference iterates i in [0, xd - max(xf,xs) + 1) step xs (Layer::computeBoundaries, layer.cpp:12-26) but sizes
+    // its result (xd-xf)/xs+1: when the stride exceeds the window the two disagree and trailing outputs stay empty
+    // Ciphertexts -- reject those shapes instead of inventing values.
+    const int xl = xd - (xf > xs ? xf : xs) + 1, yl = yd - (yf > ys ? yf : ys) + 1;
+    if (xl < 1 || yl < 1) return false;
+    return (xl + xs - 1) / xs == (xd - xf) / xs + 1 && (yl + ys - 1) / ys == (yd - yf) / ys + 1;
+}
+static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+extern "C" size_t crc_conv2d_work_bytes(const crc_ctx *c, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int in_form)
+{
+    (void)nf;
+    if (!c || !conv_shape_ok(xd, yd, xs, ys, xf, yf)) return 0;
+    const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys + 1;
+    size_t b = align256(sizeof(int) * (size_t)xo * yo) + align256(sizeof(int) * (size_t)zd * xf * yf);
+    if (in_form == CRC_COEFF) b += (size_t)B * zd * xd * yd * crc_ct_words(c, 2) * 8;
+    return b + 256;
+}
+
+extern "C" int crc_conv2d(crc_ctx *c, const uint64_t *d_x, const uint64_t *d_w, const uint64_t *d_bias, int B, int zd, int xd, int yd,
+                          int xs, int ys, int xf, int yf, int nf, int in_form, int out_form, uint64_t *d_y, void *d_work, void *stream)
+{
+    CHECK_CTX(c);
+    if (!d_x || !d_w || !d_y || !d_work || B < 0 || zd < 1 || nf < 1 || !form_ok(in_form) || !form_ok(out_form)) return CRC_ERR_INVALID_ARGUMENT;
+    if (!conv_shape_ok(xd, yd, xs, ys, xf, yf)) return CRC_ERR_INVALID_ARGUMENT;
+    if (B == 0) return CRC_OK;
+    const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys + 1, P = xo * yo, T = zd * xf * yf, in_cts = zd * xd * yd;
+    hipStream_t st = S(stream);
+    char *w = (char *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
+    int *xoff = (int *)w; w += align256(sizeof(int) * (size_t)P);
+    int *toff = (int *)w; w += align256(sizeof(int) * (size_t)T);
+    RUN(k_conv_offsets(xoff, toff, P, T, xd, yd, xs, ys, xf, yf, yo, st));
+    const u64 *xn = d_x;
+    if (in_form == CRC_COEFF) {                   // transform_input_to_ntt, convolutionalLayer.cpp:95-148 (out of place: x is const)
+        u64 *buf = (u64 *)w;
+        RUN(k_ntt_ct(c, false, d_x, buf, (size_t)B * in_cts, 2, false, st, nullptr, 0, 0));
+        xn = buf;
+    }
+    // sum of products in the NTT domain; bias joins here when the output stays NTT-resident
+    RUN(k_mac(c, xn, d_w, d_y, xoff, toff, B, P, nf, T, in_cts, out_form == CRC_NTT ? d_bias : nullptr, st));
+    if (out_form == CRC_COEFF)                    // one inverse NTT per output ciphertext, add_plain(bias) fused into its store
+        RUN(k_ntt_ct(c, true, d_y, d_y, (size_t)B * nf * P, 2, false, st, d_bias, 1, (size_t)P, nf));
+    return CRC_OK;
+}
+
+extern "C" size_t crc_dense_work_bytes(const crc_ctx *c, int B, int in_dim, int out_dim, int in_form)
+{
+    return crc_conv2d_work_bytes(c, B, in_dim, 1, 1, 1, 1, 1, 1, out_dim, in_form);
+}
+extern "C" int crc_dense(crc_ctx *c, const uint64_t *d_x, const uint64_t *d_w, const uint64_t *d_bias, int B, int in_dim, int out_dim,
+                         int in_form, int out_form, uint64_t *d_y, void *d_work, void *stream)
+{
+    // a dense layer is the 1x1 convolution of an in_dim-channel 1x1 image (reshapeInput, fullyConnectedLayer.cpp:38-56,
+    // flattens z,x,y row-major, which is the tensor's memory order)
+    return crc_conv2d(c, d_x, d_w, d_bias, B, in_dim, 1, 1, 1, 1, 1, 1, out_dim, in_form, out_form, d_y, d_work, stream);
+}
+
+// ---- pooling / batch-norm -----------------------------------------------------------------------------------------
+extern "C" int crc_pool(crc_ctx *c, const uint64_t *d_x, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf,
+                        const uint64_t *d_div, int form, uint64_t *d_y, void *stream)
+{
+    CHECK_CTX(c);
+    if (!d_x || !d_y || B < 0 || zd < 1 || !form_ok(form) || !conv_shape_ok(xd, yd, xs, ys, xf, yf)) return CRC_ERR_INVALID_ARGUMENT;
+    if (B == 0) return CRC_OK;
+    hipStream_t st = S(stream);
+    const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys + 1;
+    if (form == CRC_NTT || !d_div) return k_pool(c, d_x, d_y, B, zd, xd, yd, xs, ys, xf, yf, form == CRC_NTT ? d_div : nullptr, st);
+    // coefficient form average pooling: add_many then multiply_plain(div_factor) (avgPoolingLayer.cpp:37-38)
+    RUN(k_pool(c, d_x, d_y, B, zd, xd, yd, xs, ys, xf, yf, nullptr, st));
+    const size_t cnt = (size_t)B * zd * xo * yo;
+    RUN(k_ntt_ct(c, false, d_y, d_y, cnt, 2, false, st, nullptr, 0, 0));
+    RUN(k_rowwise(c, d_y, d_div, cnt, 2, 2, 1, cnt, 0, st));
+    return k_ntt_ct(c, true, d_y, d_y, cnt, 2, false, st, nullptr, 0, 0);
+}
+
+extern "C" int crc_batchnorm(crc_ctx *c, uint64_t *d_x, int B, int zd, int xd, int yd, const uint64_t *d_mean, const uint64_t *d_invstd,
+                             int form, void *stream)
+{
+    CHECK_CTX(c);
+    if (!d_x || !d_mean || !d_invstd || B < 0 || zd < 1 || xd < 1 || yd < 1 || !form_ok(form)) return CRC_ERR_INVALID_ARGUMENT;
+    if (B == 0) return CRC_OK;
+    hipStream_t st = S(stream);
+    const size_t hw = (size_t)xd * yd, cnt = (size_t)B * zd * hw;
+    if (form == CRC_NTT) return k_bn_ntt(c, d_x, B, zd, (int)hw, d_mean, d_invstd, st);
+    // sub_plain(mean[z]) then multiply_plain(var[z])  (batchNormLayer.cpp:36-37)
+    RUN(k_rowwise(c, d_x, d_mean, cnt, 2, 1, -1, hw, (size_t)zd, st));
+    RUN(k_ntt_ct(c, false, d_x, d_x, cnt, 2, false, st, nullptr, 0, 0));
+    RUN(k_rowwise(c, d_x, d_invstd, cnt, 2, 2, 1, hw, (size_t)zd, st));
+    return k_ntt_ct(c, true, d_x, d_x, cnt, 2, false, st, nullptr, 0, 0);
+}
+
+// ---- square + relinearize -----------------------------------------------------------------------------------------
+static const size_t kSquareChunk = 512;           // ciphertexts per internal pass (bounds the scratch footprint)
+
+extern "C" size_t crc_square_relin_work_bytes(const crc_ctx *c, size_t count, int dbc)
+{
+    if (!c) return 0;
+    const size_t ch = count < kSquareChunk ? count : kSquareChunk;
+    const size_t sq = k_square_work_words(c, ch), rl = k_relin_work_words(c, ch, dbc);
+    return 8 * ((sq > rl ? sq : rl) + ch * crc_ct_words(c, 3)) + 256;
+}
+extern "C" int crc_square(crc_ctx *c, const uint64_t *d_x, size_t count, uint64_t *d_y3, void *d_work, void *stream)
+{
+    CHECK_CTX(c); if (!d_x || !d_y3 || !d_work) return CRC_ERR_INVALID_ARGUMENT;
+    u64 *w = (u64 *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
+    for (size_t o = 0; o < count; o += kSquareChunk) {
+        const size_t ch = count - o < kSquareChunk ? count - o : kSquareChunk;
+        RUN(k_square(c, d_x + o * crc_ct_words(c, 2), ch, d_y3 + o * crc_ct_words(c, 3), w, S(stream)));
+    }
+    return CRC_OK;
+}
+extern "C" int crc_relinearize(crc_ctx *c, const uint64_t *d_x3, size_t count, const uint64_t *d_evk, int dbc, uint64_t *d_y, void *d_work, void *stream)
+{
+    CHECK_CTX(c); if (!d_x3 || !d_y || !d_evk || !d_work) return CRC_ERR_INVALID_ARGUMENT;
+    u64 *w = (u64 *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
+    for (size_t o = 0; o < count; o += kSquareChunk) {
+        const size_t ch = count - o < kSquareChunk ? count - o : kSquareChunk;
+        RUN(k_relinearize(c, d_x3 + o * crc_ct_words(c, 3), ch, d_evk, dbc, d_y + o * crc_ct_words(c, 2), w, S(stream)));
+    }
+    return CRC_OK;
+}
+extern "C" int crc_square_relin(crc_ctx *c, const uint64_t *d_x, size_t count, const uint64_t *d_evk, int dbc, uint64_t *d_y, void *d_work, void *stream)
+{
+    CHECK_CTX(c); if (!d_x || !d_y || !d_evk || !d_work) return CRC_ERR_INVALID_ARGUMENT;
+    u64 *w = (u64 *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
+    for (size_t o = 0; o < count; o += kSquareChunk) {
+        const size_t ch = count - o < kSquareChunk ? count - o : kSquareChunk;
+        u64 *y3 = w; u64 *rest = w + ch * crc_ct_words(c, 3);
+        RUN(k_square(c, d_x + o * crc_ct_words(c, 2), ch, y3, rest, S(stream)));
+        RUN(k_relinearize(c, y3, ch, d_evk, dbc, d_y + o * crc_ct_words(c, 2), rest, S(stream)));
+    }
+    return CRC_OK;
+}

@@ -1,0 +1,345 @@
+// ctx.cpp -- builds the context tables on the host and uploads them to HBM.
+#include "ctx.h"
+#include <cstring>
+#include <cstdlib>
+#include <string>
+
+typedef unsigned __int128 u128;
+
+static thread_local int g_last_hip = 0;
+int crc_set_hip_error(hipError_t e) { g_last_hip = (int)e; return CRC_ERR_HIP; }
+
+extern "C" int crc_last_hip_error(void) { return g_last_hip; }
+extern "C" int crc_version(void) { return 100; }
+extern "C" const char *crc_strerror(int s)
+{
+    switch (s) {
+    case CRC_OK: return "ok";
+    case CRC_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case CRC_ERR_PARAMETERS: return "encryption parameters are not set correctly";
+    case CRC_ERR_HIP: return "HIP runtime error";
+    case CRC_ERR_UNSUPPORTED: return "unsupported parameter combination";
+    case CRC_ERR_IO: return "I/O error";
+    case CRC_ERR_NOT_FOUND: return "not found";
+    }
+    return "unknown status";
+}
+
+// ---- small host number theory -------------------------------------------------------------------------------
+u64 h_mulmod(u64 a, u64 b, u64 q) { return (u64)((u128)a * b % q); }
+u64 h_powmod(u64 a, u64 e, u64 q)
+{
+    u64 r = 1 % q; a %= q;
+    for (; e; e >>= 1) { if (e & 1) r = h_mulmod(r, a, q); a = h_mulmod(a, a, q); }
+    return r;
+}
+u64 h_invmod(u64 a, u64 q)
+{
+    __int128 t = 0, nt = 1, r = q, nr = a % q;
+    while (nr) { __int128 d = r / nr, x = t - d * nt; t = nt; nt = x; x = r - d * nr; r = nr; nr = x; }
+    return (u64)(t < 0 ? t + q : t);
+}
+static int sigbits(u64 v) { return v ? 64 - __builtin_clzll(v) : 0; }
+
+ModParams make_mod(u64 q)
+{
+    ModParams m{};
+    u128 all = ~(u128)0, quo = all / q;
+    if (all % q + 1 == q) quo += 1;                // q | 2^128 (m~ = 2^32)
+    m.q = q; m.r0 = (u64)quo; m.r1 = (u64)(quo >> 64); m.two_q = 2 * q; m.bits = (u32)sigbits(q);
+    return m;
+}
+
+int evk_digits(u64 q, int dbc) { int L = 0; while (q) { L++; q >>= dbc; } return L; }
+
+static bool is_prime(u64 n)
+{
+    if (n < 2) return false;
+    for (u64 p : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) { if (n % p == 0) return n == p; }
+    u64 d = n - 1; int s = 0;
+    while (!(d & 1)) { d >>= 1; s++; }
+    for (u64 a : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) {
+        u64 x = h_powmod(a, d, n);
+        if (x == 1 || x == n - 1) continue;
+        bool comp = true;
+        for (int r = 1; r < s; r++) { x = h_mulmod(x, x, n); if (x == n - 1) { comp = false; break; } }
+        if (comp) return false;
+    }
+    return true;
+}
+
+// numerically smallest primitive 2n-th root of unity mod q (what SEAL's try_minimal_primitive_root converges to,
+// util/uintarithsmallmod.cpp:83-108): every primitive root is an odd power of any one of them.
+static u64 minimal_primitive_root(u64 two_n, u64 q)
+{
+    if ((q - 1) % two_n) return 0;
+    u64 e = (q - 1) / two_n, root = 0;
+    for (u64 g = 2; g < 4096 && !root; g++) {
+        u64 c = h_powmod(g, e, q);
+        if (h_powmod(c, two_n >> 1, q) == q - 1) root = c;
+    }
+    if (!root) return 0;
+    u64 sq = h_mulmod(root, root, q), cur = root, best = root;
+    for (u64 i = 0; i < two_n / 2; i++) { if (cur < best) best = cur; cur = h_mulmod(cur, sq, q); }
+    return best;
+}
+
+static u32 bitrev(u32 x, int bits) { u32 r = 0; for (int i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; } return r; }
+
+static bool build_ntt(HostNtt &T, int logn, u64 q)
+{
+    int n = 1 << logn;
+    T.m = make_mod(q);
+    T.root = minimal_primitive_root(2 * (u64)n, q);
+    if (!T.root) return false;
+    u64 iroot = h_invmod(T.root, q);
+    T.inv_n = h_invmod((u64)n, q);
+    T.rp.assign(n, 0); T.srp.assign(n, 0); T.irp2.assign(n, 0); T.sirp2.assign(n, 0);
+    u64 p = 1, ip = 1;
+    for (int i = 0; i < n; i++) {
+        u32 j = bitrev((u32)i, logn);
+        T.rp[j] = p;
+        T.irp2[j] = (ip & 1) ? (u64)(((u128)ip + q) >> 1) : ip >> 1;       // psi^-i / 2 mod q
+        p = h_mulmod(p, T.root, q); ip = h_mulmod(ip, iroot, q);
+    }
+    for (int i = 0; i < n; i++) {
+        T.srp[i] = (u64)(((u128)T.rp[i] << 64) / q);
+        T.sirp2[i] = (u64)(((u128)T.irp2[i] << 64) / q);
+    }
+    return true;
+}
+
+// host reference transforms (client side + table self-checks); same ordering as the device kernels
+void h_ntt_fwd(const HostNtt &T, u64 *a, int n)
+{
+    u64 q = T.m.q;
+    for (int m = 1, t = n >> 1; m < n; m <<= 1, t >>= 1)
+        for (int i = 0; i < m; i++) {
+            u64 w = T.rp[m + i];
+            for (int j = 2 * i * t; j < 2 * i * t + t; j++) {
+                u64 v = h_mulmod(a[j + t], w, q), u = a[j];
+                a[j] = addmod(u, v, q); a[j + t] = submod(u, v, q);
+            }
+        }
+}
+void h_ntt_inv(const HostNtt &T, u64 *a, int n)
+{
+    u64 q = T.m.q;
+    for (int m = n, t = 1; m > 1; m >>= 1, t <<= 1) {
+        int h = m >> 1;
+        for (int i = 0, j1 = 0; i < h; i++, j1 += 2 * t) {
+            u64 w = T.irp2[h + i];
+            for (int j = j1; j < j1 + t; j++) {
+                u64 u = a[j], v = a[j + t];
+                u64 s = addmod(u, v, q);
+                a[j] = (s & 1) ? (u64)(((u128)s + q) >> 1) : s >> 1;
+                a[j + t] = h_mulmod(submod(u, v, q), w, q);
+            }
+        }
+    }
+}
+
+// SEAL's internal BEHZ moduli (util/globals.cpp:321-367): 61-bit primes = 1 mod 2^18
+static const u64 kAuxMods[] = {
+    0x1fffffffffb40001ULL, 0x1fffffffff500001ULL, 0x1fffffffff380001ULL, 0x1fffffffff000001ULL, 0x1ffffffffef00001ULL,
+    0x1ffffffffee80001ULL, 0x1ffffffffeb40001ULL, 0x1ffffffffe780001ULL, 0x1ffffffffe600001ULL, 0x1ffffffffe4c0001ULL };
+static const u64 kMsk = 0x1fffffffffe00001ULL, kMtilde = 1ULL << 32, kGamma = 0x1fffffffffc80001ULL;
+
+static u64 prod_mod(const u64 *v, int cnt, int skip, u64 m)
+{
+    u64 r = 1 % m;
+    for (int j = 0; j < cnt; j++) if (j != skip) r = h_mulmod(r, v[j] % m, m);
+    return r;
+}
+
+extern "C" int crc_default_coeff_modulus_128(int n, uint64_t *q, int cap)
+{
+    static const u64 m1024[] = {0x7e00001}, m2048[] = {0x3fffffff000001}, m4096[] = {0x7fffffff380001, 0x3fffffff000001},
+        m8192[] = {0x7fffffff380001, 0x7ffffffef00001, 0x3fffffff000001, 0x3ffffffef40001},
+        m16384[] = {0x7fffffff380001, 0x7ffffffef00001, 0x7ffffffeac0001, 0x7ffffffe700001, 0x7ffffffe600001, 0x7ffffffe4c0001, 0x3fffffff000001, 0x3ffffffef40001};
+    const u64 *src; int cnt;
+    switch (n) {
+    case 1024: src = m1024; cnt = 1; break;
+    case 2048: src = m2048; cnt = 1; break;
+    case 4096: src = m4096; cnt = 2; break;
+    case 8192: src = m8192; cnt = 4; break;
+    case 16384: src = m16384; cnt = 8; break;
+    default: return CRC_ERR_INVALID_ARGUMENT;
+    }
+    for (int i = 0; i < cnt && i < cap; i++) q[i] = src[i];
+    return cnt;
+}
+
+extern "C" int crc_ctx_create(int n, const uint64_t *q, int k, uint64_t t, int device, crc_ctx **out)
+{
+    if (!out || !q) return CRC_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    // SEALContext::validate, context.cpp:15-169
+    if (k < 1 || k > CRC_MAXK) return CRC_ERR_PARAMETERS;
+    if (n < 64 || n > 32768 || (n & (n - 1))) return CRC_ERR_PARAMETERS;
+    if (t < 2 || (t >> 60)) return CRC_ERR_PARAMETERS;
+    for (int i = 0; i < k; i++) {
+        if (q[i] < 2 || (q[i] >> 60)) return CRC_ERR_PARAMETERS;
+        if (!is_prime(q[i]) || (q[i] - 1) % (2 * (u64)n)) return CRC_ERR_PARAMETERS;      // enable_ntt
+        for (int j = 0; j < i; j++) if (q[i] == q[j]) return CRC_ERR_PARAMETERS;
+        if (t % q[i] == 0) return CRC_ERR_PARAMETERS;
+        if (q[i] <= t) return CRC_ERR_UNSUPPORTED;            // !enable_fast_plain_lift (context.cpp:156-165)
+    }
+    crc_ctx *c = new crc_ctx();
+    c->n = n; c->k = k; c->t = t; c->device = device;
+    c->logn = 0; while ((1 << c->logn) < n) c->logn++;
+    c->q.assign(q, q + k);
+
+    // aux base size rule, baseconverter.cpp:47-56
+    int total = 0; for (int i = 0; i < k; i++) total += sigbits(q[i]);
+    c->ka = k + ((32 + sigbits(t) + total >= 61 * k + 61) ? 1 : 0);
+    c->kb = c->ka + 1;
+    u64 bsk[CRC_MAXB];
+    for (int j = 0; j < c->ka; j++) bsk[j] = kAuxMods[j];
+    bsk[c->ka] = kMsk;
+
+    c->tabs.resize(k + c->kb);
+    for (int i = 0; i < k; i++) if (!build_ntt(c->tabs[i], c->logn, q[i])) { delete c; return CRC_ERR_PARAMETERS; }
+    for (int j = 0; j < c->kb; j++) if (!build_ntt(c->tabs[k + j], c->logn, bsk[j])) { delete c; return CRC_ERR_PARAMETERS; }
+
+    // floor(q/t) mod q_i and (q mod t) mod q_i, evaluator.cpp:66-105 -- long division of the multi-limb q by t
+    {
+        std::vector<u64> big(k, 0); big[0] = 1;
+        for (int i = 0; i < k; i++) { u64 carry = 0; for (int l = 0; l < k; l++) { u128 z = (u128)big[l] * q[i] + carry; big[l] = (u64)z; carry = (u64)(z >> 64); } }
+        c->qbig = big;
+        c->total_bits = 0; for (int l = k - 1; l >= 0; l--) if (big[l]) { c->total_bits = 64 * l + sigbits(big[l]); break; }
+        std::vector<u64> quo(big); u64 rem = 0;
+        for (int l = k - 1; l >= 0; l--) { u128 z = ((u128)rem << 64) | quo[l]; quo[l] = (u64)(z / t); rem = (u64)(z % t); }
+        memset(&c->plain, 0, sizeof c->plain);
+        c->plain.threshold = (t + 1) >> 1;
+        for (int i = 0; i < k; i++) {
+            u64 r = 0; for (int l = k - 1; l >= 0; l--) r = (u64)((((u128)r << 64) | quo[l]) % q[i]);
+            c->plain.delta[i] = r; c->plain.uhi[i] = rem % q[i]; c->plain.inc[i] = q[i] - t;
+        }
+    }
+    // BEHZ tables, baseconverter.cpp:104-353
+    BehzParams &b = c->behz; memset(&b, 0, sizeof b);
+    b.k = k; b.ka = c->ka; b.kb = c->kb; b.t = t; b.m_tilde = kMtilde; b.m_sk = kMsk;
+    for (int i = 0; i < k; i++) {
+        b.inv_qhat[i] = h_invmod(prod_mod(q, k, i, q[i]), q[i]);
+        b.mt_inv_qhat[i] = h_mulmod(b.inv_qhat[i], kMtilde % q[i], q[i]);
+        b.qhat_mod_mt[i] = prod_mod(q, k, i, kMtilde);
+        for (int j = 0; j < c->kb; j++) b.qhat_mod_bsk[j][i] = prod_mod(q, k, i, bsk[j]);
+        for (int j = 0; j < c->ka; j++) b.mhat_mod_q[i][j] = prod_mod(bsk, c->ka, j, q[i]);
+        b.M_mod_q[i] = prod_mod(bsk, c->ka, -1, q[i]);
+    }
+    for (int j = 0; j < c->kb; j++) {
+        b.q_mod_bsk[j] = prod_mod(q, k, -1, bsk[j]);
+        b.inv_q_mod_bsk[j] = h_invmod(b.q_mod_bsk[j], bsk[j]);
+        b.inv_mt_mod_bsk[j] = h_invmod(kMtilde % bsk[j], bsk[j]);
+    }
+    for (int j = 0; j < c->ka; j++) {
+        b.inv_mhat[j] = h_invmod(prod_mod(bsk, c->ka, j, bsk[j]), bsk[j]);
+        b.mhat_mod_msk[j] = prod_mod(bsk, c->ka, j, kMsk);
+    }
+    b.inv_M_mod_msk = h_invmod(prod_mod(bsk, c->ka, -1, kMsk), kMsk);
+    b.inv_q_mod_mt = h_invmod(prod_mod(q, k, -1, kMtilde), kMtilde);
+    // decrypt-only constants
+    c->tmod = make_mod(t); c->gmod = make_mod(kGamma); c->mtmod = make_mod(kMtilde);
+    for (int i = 0; i < k; i++) {
+        c->qhat_mod_tg[0][i] = prod_mod(q, k, i, t); c->qhat_mod_tg[1][i] = prod_mod(q, k, i, kGamma);
+        c->tgamma_mod_q[i] = h_mulmod(t % q[i], kGamma % q[i], q[i]);
+    }
+    c->neg_inv_q_mod_tg[0] = h_invmod(negmod(prod_mod(q, k, -1, t), t), t);
+    c->neg_inv_q_mod_tg[1] = h_invmod(negmod(prod_mod(q, k, -1, kGamma), kGamma), kGamma);
+    c->inv_gamma_mod_t = h_invmod(kGamma % t, t);
+
+    // upload (device < 0: host-only context for encode / client-side use and CPU-only tests of the tables)
+    if (device >= 0) {
+        int rc = CRC_OK;
+        auto fail = [&](hipError_t e) { rc = crc_set_hip_error(e); };
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) { fail(e); delete c; return rc; }
+        int nm = k + c->kb; size_t tw = (size_t)nm * n * 8;
+        std::vector<ModParams> mods(nm);
+        std::vector<u64> rp((size_t)nm * n), srp(rp.size()), irp2(rp.size()), sirp2(rp.size());
+        for (int m = 0; m < nm; m++) {
+            mods[m] = c->tabs[m].m;
+            memcpy(&rp[(size_t)m * n], c->tabs[m].rp.data(), 8 * (size_t)n); memcpy(&srp[(size_t)m * n], c->tabs[m].srp.data(), 8 * (size_t)n);
+            memcpy(&irp2[(size_t)m * n], c->tabs[m].irp2.data(), 8 * (size_t)n); memcpy(&sirp2[(size_t)m * n], c->tabs[m].sirp2.data(), 8 * (size_t)n);
+        }
+        if ((e = hipMalloc(&c->d_mods, sizeof(ModParams) * nm)) != hipSuccess || (e = hipMalloc(&c->d_rp, tw)) != hipSuccess ||
+            (e = hipMalloc(&c->d_srp, tw)) != hipSuccess || (e = hipMalloc(&c->d_irp2, tw)) != hipSuccess ||
+            (e = hipMalloc(&c->d_sirp2, tw)) != hipSuccess || (e = hipMalloc(&c->d_behz, sizeof(BehzParams))) != hipSuccess ||
+            (e = hipMemcpy(c->d_mods, mods.data(), sizeof(ModParams) * nm, hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemcpy(c->d_rp, rp.data(), tw, hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemcpy(c->d_srp, srp.data(), tw, hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemcpy(c->d_irp2, irp2.data(), tw, hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemcpy(c->d_sirp2, sirp2.data(), tw, hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemcpy(c->d_behz, &c->behz, sizeof(BehzParams), hipMemcpyHostToDevice)) != hipSuccess) {
+            fail(e); crc_ctx_destroy(c); return rc;
+        }
+    }
+    *out = c;
+    return CRC_OK;
+}
+
+extern "C" void crc_ctx_destroy(crc_ctx *c)
+{
+    if (!c) return;
+    if (c->device >= 0) {
+        (void)hipFree(c->d_mods); (void)hipFree(c->d_rp); (void)hipFree(c->d_srp); (void)hipFree(c->d_irp2); (void)hipFree(c->d_sirp2); (void)hipFree(c->d_behz);
+    }
+    delete c;
+}
+
+extern "C" int crc_ctx_n(const crc_ctx *c) { return c->n; }
+extern "C" int crc_ctx_k(const crc_ctx *c) { return c->k; }
+extern "C" int crc_ctx_kbsk(const crc_ctx *c) { return c->kb; }
+extern "C" int crc_ctx_device(const crc_ctx *c) { return c->device; }
+extern "C" size_t crc_ct_words(const crc_ctx *c, int size) { return (size_t)size * c->k * c->n; }
+extern "C" size_t crc_evk_words(const crc_ctx *c, int dbc)
+{
+    size_t w = 0;
+    for (int l = 0; l < c->k; l++) w += (size_t)2 * evk_digits(c->q[l], dbc) * c->k * c->n;
+    return w;
+}
+
+extern "C" int crc_ctx_table(const crc_ctx *c, const char *name, uint64_t *out, int cap)
+{
+    std::vector<u64> v; std::string s(name);
+    int k = c->k, kb = c->kb;
+    if (s == "q") for (int i = 0; i < k; i++) v.push_back(c->q[i]);
+    else if (s == "root") for (int i = 0; i < k; i++) v.push_back(c->tabs[i].root);
+    else if (s == "const_ratio") for (int i = 0; i < k; i++) { v.push_back(c->tabs[i].m.r0); v.push_back(c->tabs[i].m.r1); }
+    else if (s == "delta") for (int i = 0; i < k; i++) v.push_back(c->plain.delta[i]);
+    else if (s == "upper_half_increment") for (int i = 0; i < k; i++) v.push_back(c->plain.uhi[i]);
+    else if (s == "bsk") for (int j = 0; j < kb; j++) v.push_back(c->tabs[k + j].m.q);
+    else if (s == "bsk_root") for (int j = 0; j < kb; j++) v.push_back(c->tabs[k + j].root);
+    else if (s.rfind("root_powers:", 0) == 0) { int mi = atoi(name + 12); if (mi < 0 || mi >= k + kb) return CRC_ERR_INVALID_ARGUMENT; v = c->tabs[mi].rp; }
+    else if (s.rfind("inv_root_powers_div_two:", 0) == 0) { int mi = atoi(name + 24); if (mi < 0 || mi >= k + kb) return CRC_ERR_INVALID_ARGUMENT; v = c->tabs[mi].irp2; }
+    else return CRC_ERR_NOT_FOUND;
+    for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = v[i];
+    return (int)v.size();
+}
+
+// ---- device memory helpers ----------------------------------------------------------------------------------
+extern "C" int crc_malloc(crc_ctx *c, size_t bytes, void **p) { HIPCHK(hipSetDevice(c->device)); HIPCHK(hipMalloc(p, bytes)); return CRC_OK; }
+extern "C" int crc_free(crc_ctx *c, void *p) { (void)c; HIPCHK(hipFree(p)); return CRC_OK; }
+extern "C" int crc_memcpy_h2d(crc_ctx *c, void *d, const void *h, size_t b, void *s) { (void)c; HIPCHK(hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice, (hipStream_t)s)); return CRC_OK; }
+extern "C" int crc_memcpy_d2h(crc_ctx *c, void *h, const void *d, size_t b, void *s) { (void)c; HIPCHK(hipMemcpyAsync(h, d, b, hipMemcpyDeviceToHost, (hipStream_t)s)); return CRC_OK; }
+extern "C" int crc_memcpy_d2d(crc_ctx *c, void *d, const void *s0, size_t b, void *s) { (void)c; HIPCHK(hipMemcpyAsync(d, s0, b, hipMemcpyDeviceToDevice, (hipStream_t)s)); return CRC_OK; }
+extern "C" int crc_memset(crc_ctx *c, void *d, int v, size_t b, void *s) { (void)c; HIPCHK(hipMemsetAsync(d, v, b, (hipStream_t)s)); return CRC_OK; }
+extern "C" int crc_stream_sync(crc_ctx *c, void *s) { (void)c; HIPCHK(hipStreamSynchronize((hipStream_t)s)); return CRC_OK; }
+
+extern "C" int crc_import_seal(const crc_ctx *c, const uint64_t *seal, int size, uint64_t *out)
+{
+    for (int r = 0; r < size * c->k; r++) {
+        if (seal[(size_t)r * (c->n + 1) + c->n] != 0) return CRC_ERR_INVALID_ARGUMENT;
+        memcpy(out + (size_t)r * c->n, seal + (size_t)r * (c->n + 1), 8 * (size_t)c->n);
+    }
+    return CRC_OK;
+}
+extern "C" int crc_export_seal(const crc_ctx *c, const uint64_t *in, int size, uint64_t *seal)
+{
+    for (int r = 0; r < size * c->k; r++) {
+        memcpy(seal + (size_t)r * (c->n + 1), in + (size_t)r * c->n, 8 * (size_t)c->n);
+        seal[(size_t)r * (c->n + 1) + c->n] = 0;
+    }
+    return CRC_OK;
+}

@@ -1,0 +1,77 @@
+// ctx.h -- engine context: BFV parameter set, host-side tables, their device copies.
+//
+// Mirrors what the reference spreads over SEALContext (context.cpp:15-169), SmallNTTTables (util/smallntt.cpp:37-92),
+// the Evaluator ctor (evaluator.cpp:19-121) and the BaseConverter ctor (util/baseconverter.cpp:20-353), built
+// MI355X-first: one flat table set in HBM, indexed by "modulus index" mi (0..k-1 = q_i, k..k+kb-1 = Bsk_j).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+#include "modarith.h"
+#include "../../include/crcnn_hip.h"
+
+#define CRC_MAXK 8            // coeff moduli (SEAL's largest default set, n=16384, has 8)
+#define CRC_MAXB (CRC_MAXK + 2)
+
+// constants of add_plain / transform_to_ntt(Plaintext) -- passed to kernels by value
+struct PlainParams {
+    u64 threshold;            // (t+1)>>1                          evaluator.cpp:73
+    u64 inc[CRC_MAXK];        // q_i - t                           evaluator.cpp:80-87
+    u64 delta[CRC_MAXK];      // floor(q/t) mod q_i                evaluator.cpp:66-70,96-100
+    u64 uhi[CRC_MAXK];        // (q mod t) mod q_i                 evaluator.cpp:89-105
+};
+
+// BEHZ constants used by the Square pipeline -- lives in device memory (one copy per context)
+struct BehzParams {
+    int k, ka, kb;
+    u64 t;
+    u64 m_tilde, m_sk;
+    u64 inv_qhat[CRC_MAXK];                  // (q/q_i)^-1 mod q_i
+    u64 mt_inv_qhat[CRC_MAXK];               // m~ (q/q_i)^-1 mod q_i
+    u64 qhat_mod_bsk[CRC_MAXB][CRC_MAXK];    // (q/q_i) mod Bsk_j
+    u64 qhat_mod_mt[CRC_MAXK];               // (q/q_i) mod m~
+    u64 inv_q_mod_mt;                        // q^-1 mod m~
+    u64 q_mod_bsk[CRC_MAXB];                 // q mod Bsk_j
+    u64 inv_mt_mod_bsk[CRC_MAXB];            // m~^-1 mod Bsk_j
+    u64 inv_q_mod_bsk[CRC_MAXB];             // q^-1 mod Bsk_j
+    u64 inv_mhat[CRC_MAXB];                  // (M/m_j)^-1 mod m_j
+    u64 mhat_mod_q[CRC_MAXK][CRC_MAXB];      // (M/m_j) mod q_i
+    u64 mhat_mod_msk[CRC_MAXB];              // (M/m_j) mod m_sk
+    u64 inv_M_mod_msk;                       // M^-1 mod m_sk
+    u64 M_mod_q[CRC_MAXK];                   // M mod q_i
+};
+
+struct HostNtt {               // one modulus
+    ModParams m;
+    u64 root, inv_n;
+    std::vector<u64> rp, srp, irp2, sirp2;   // bit-reversed powers + Shoup companions (layout as SEAL's tables)
+};
+
+struct crc_ctx {
+    int n, logn, k, ka, kb, device;
+    u64 t;
+    int total_bits;
+    std::vector<u64> q;
+    std::vector<HostNtt> tabs;               // k + kb entries
+    PlainParams plain;
+    BehzParams behz;
+    std::vector<u64> qbig;                   // q as little-endian limbs (noise budget)
+    // decrypt-only constants (host client side)
+    ModParams tmod, gmod, mtmod;
+    u64 qhat_mod_tg[2][CRC_MAXK], neg_inv_q_mod_tg[2], inv_gamma_mod_t, tgamma_mod_q[CRC_MAXK];
+    // device copies
+    ModParams *d_mods = nullptr;             // [k+kb]
+    u64 *d_rp = nullptr, *d_srp = nullptr, *d_irp2 = nullptr, *d_sirp2 = nullptr;   // [(k+kb)][n]
+    BehzParams *d_behz = nullptr;
+};
+
+int  crc_set_hip_error(hipError_t e);
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return crc_set_hip_error(e_); } while (0)
+
+// host helpers shared by ctx.cpp / client.cpp / encoder.cpp
+u64  h_mulmod(u64 a, u64 b, u64 q);
+u64  h_powmod(u64 a, u64 e, u64 q);
+u64  h_invmod(u64 a, u64 q);
+void h_ntt_fwd(const HostNtt &T, u64 *a, int n);      // canonical in/out
+void h_ntt_inv(const HostNtt &T, u64 *a, int n);
+ModParams make_mod(u64 q);
+int  evk_digits(u64 q, int dbc);

@@ -1,0 +1,19 @@
+// kernels.h -- launchers implemented in kernels.hip / kernels_square.hip (internal; the public surface is crcnn_hip.h)
+#pragma once
+#include "ctx.h"
+
+int k_ntt_ct(crc_ctx *c, bool inv, const u64 *src, u64 *dst, size_t count, int size, bool bsk, hipStream_t st,
+             const u64 *addend, int add_sign, size_t add_group, int add_mod = 0);
+int k_ntt_ct_addct(crc_ctx *c, const u64 *src, u64 *dst, size_t count, const u64 *addct, int add_size, hipStream_t st);
+int k_spread_ntt(crc_ctx *c, const u64 *src, size_t items, u64 *dst, hipStream_t st);
+int k_plain_ntt(crc_ctx *c, const u64 *d_plain, size_t count, int mode, bool do_ntt, u64 *d_out, hipStream_t st);
+int k_rowwise(crc_ctx *c, u64 *acc, const u64 *b, size_t count, int size, int op, int sign, size_t group, size_t gmod, hipStream_t st);
+int k_pool(crc_ctx *c, const u64 *x, u64 *y, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, const u64 *mul, hipStream_t st);
+int k_bn_ntt(crc_ctx *c, u64 *x, int B, int zd, int hw, const u64 *mean, const u64 *invstd, hipStream_t st);
+int k_mac(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, const int *d_toff, int B, int P, int F, int T, int in_cts,
+          const u64 *bias_ntt, hipStream_t st);
+int k_conv_offsets(int *xoff, int *toff, int P, int T, int xd, int yd, int xs, int ys, int xf, int yf, int yo, hipStream_t st);
+size_t k_square_work_words(const crc_ctx *c, size_t cnt);
+size_t k_relin_work_words(const crc_ctx *c, size_t cnt, int dbc);
+int k_square(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStream_t st);
+int k_relinearize(crc_ctx *c, const u64 *x3, size_t cnt, const u64 *evk, int dbc, u64 *y, u64 *work, hipStream_t st);

@@ -1,0 +1,410 @@
+// kernels.hip -- gfx950 kernels of the encrypted-CNN evaluation path + their launchers.
+//
+// Data model: every tensor is an array of "rows"; a row is one polynomial residue = n uint64 in [0,q_mi).  A size-S
+// ciphertext is S*k consecutive rows ([S][k][n]); row r of a ciphertext array belongs to modulus index r % k.
+// Integer modular arithmetic only -- no MFMA.  Lane <-> coefficient/slot, so every global access is a coalesced
+// 512 B (8 B/lane) or 1 KiB (16 B/lane) wave transaction.
+#include "kernels.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// NTT: one workgroup per row, whole polynomial staged in LDS (32 KiB @ n=4096 ... 128 KiB @ n=16384).
+//   forward = Cooley-Tukey, natural -> bit-reversed, Harvey lazy butterflies   (reference: util/smallntt.cpp:195-273)
+//   inverse = Gentleman-Sande, bit-reversed -> natural, n^-1 folded into the /2 twiddles   (smallntt.cpp:276-375)
+// Output canonical.  Optional fused epilogue for the inverse transform: add/subtract a delta-form plaintext row to
+// poly 0 (the add_plain(bias) of convolution3d, convolutionalLayer.cpp:87) and fused prologue for the forward one:
+// plaintext lift (transform_to_ntt(Plaintext), evaluator.cpp:1465-1486) or delta scaling.
+// ---------------------------------------------------------------------------------------------------------------
+struct NttArgs {
+    const u64 *src; u64 *dst;
+    const ModParams *mods; const u64 *w; const u64 *wp;       // twiddle tables [(k+kb)][n] (forward: rp/srp, inverse: irp2/sirp2)
+    int n, logn;
+    int mod_base, mod_count;                                   // row r -> modulus index mod_base + r % mod_count
+    int src_rows_per_item;                                     // 0: src row = dst row;  >0: plain prologue, src row = r / mod_count
+    int prologue;                                              // 0 none, 1 plain lift, 2 delta scale
+    const u64 *addend; int add_sign; int rows_per_ct; long long add_group;   // epilogue (inverse only)
+    int add_mod;                                               // plaintext index = (ct / add_group) % add_mod (0: no modulo)
+    int add_mode, add_size;                                    // 1: delta plaintext on poly 0 (shared by add_group cts); 2: rows of a size-add_size ct array
+    PlainParams pp;
+};
+
+template <bool INV>
+__global__ void __launch_bounds__(1024) ntt_rows_kernel(NttArgs a)
+{
+    extern __shared__ u64 sm[];
+    const int n = a.n, tid = threadIdx.x, nt = blockDim.x;
+    const size_t row = blockIdx.x;
+    const int mloc = (int)(row % a.mod_count);
+    const int mi = a.mod_base + mloc;
+    const ModParams m = a.mods[mi];
+    const u64 q = m.q, q2 = m.two_q;
+    const u64 *W = a.w + (size_t)mi * n, *Wp = a.wp + (size_t)mi * n;
+    const u64 *src = a.src + (a.src_rows_per_item ? (row / a.mod_count) : row) * (size_t)n;
+    u64 *dst = a.dst + row * (size_t)n;
+
+    for (int s = tid; s < n; s += nt) {
+        u64 v = src[s];
+        if (a.prologue == 1) v = v >= a.pp.threshold ? v + a.pp.inc[mloc] : v;
+        else if (a.prologue == 2) {
+            u64 lo, hi; mul64wide(a.pp.delta[mloc], v, lo, hi);
+            if (v >= a.pp.threshold) { u64 l2 = lo + a.pp.uhi[mloc]; hi += (l2 < lo); lo = l2; }
+            v = barrett128(lo, hi, m);
+        }
+        sm[s] = v;
+    }
+    __syncthreads();
+
+    if (!INV) {
+        int logt = a.logn - 1;
+        for (int mm = 1; mm < n; mm <<= 1, logt--) {
+            const int t = 1 << logt;
+            for (int b = tid; b < (n >> 1); b += nt) {
+                const int i = b >> logt, j = (i << (logt + 1)) + (b & (t - 1));
+                const u64 w = W[mm + i], wp = Wp[mm + i];
+                u64 X = sm[j], Y = sm[j + t];
+                X = X >= q2 ? X - q2 : X;
+                const u64 Q = mulmod_shoup_lazy(Y, w, wp, q);
+                sm[j] = X + Q;
+                sm[j + t] = X + (q2 - Q);
+            }
+            __syncthreads();
+        }
+        for (int s = tid; s < n; s += nt) {
+            u64 v = sm[s];
+            v = v >= q2 ? v - q2 : v;
+            v = v >= q ? v - q : v;
+            dst[s] = v;
+        }
+    } else {
+        int logt = 0;
+        for (int mm = n; mm > 1; mm >>= 1, logt++) {
+            const int t = 1 << logt, h = mm >> 1;
+            for (int b = tid; b < (n >> 1); b += nt) {
+                const int i = b >> logt, j = (i << (logt + 1)) + (b & (t - 1));
+                const u64 w = W[h + i], wp = Wp[h + i];
+                const u64 U = sm[j], V = sm[j + t];
+                const u64 T = q2 - V + U;
+                u64 cu = U + V; cu = cu >= q2 ? cu - q2 : cu;
+                sm[j] = (cu + ((cu & 1) ? q : 0)) >> 1;
+                sm[j + t] = mulmod_shoup_lazy(T, w, wp, q);
+            }
+            __syncthreads();
+        }
+        const u64 *add = nullptr;
+        if (a.addend) {
+            const size_t ct = row / a.rows_per_ct; const int p = (int)((row % a.rows_per_ct) / a.mod_count);
+            if (a.add_mode == 2) add = a.addend + ((ct * a.add_size + p) * a.mod_count + mloc) * (size_t)n;
+            else if (p == 0) { size_t g = ct / a.add_group; if (a.add_mod) g %= a.add_mod; add = a.addend + (g * a.mod_count + mloc) * (size_t)n; }
+        }
+        for (int s = tid; s < n; s += nt) {
+            u64 v = sm[s];
+            v = v >= q2 ? v - q2 : v;
+            v = v >= q ? v - q : v;
+            if (add) v = a.add_sign > 0 ? addmod(v, add[s], q) : submod(v, add[s], q);
+            dst[s] = v;
+        }
+    }
+}
+
+static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t st)
+{
+    if (rows == 0) return CRC_OK;
+    a.mods = c->d_mods; a.n = c->n; a.logn = c->logn;
+    a.w = inv ? c->d_irp2 : c->d_rp; a.wp = inv ? c->d_sirp2 : c->d_srp;
+    int nt = c->n / 8; if (nt < 64) nt = 64; if (nt > 1024) nt = 1024;
+    size_t lds = (size_t)c->n * 8;
+    if (inv) {
+        if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)ntt_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(ntt_rows_kernel<true>, dim3((unsigned)rows), dim3(nt), lds, st, a);
+    } else {
+        if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)ntt_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(ntt_rows_kernel<false>, dim3((unsigned)rows), dim3(nt), lds, st, a);
+    }
+    HIPCHK(hipGetLastError());
+    return CRC_OK;
+}
+
+int k_ntt_ct(crc_ctx *c, bool inv, const u64 *src, u64 *dst, size_t count, int size, bool bsk, hipStream_t st,
+             const u64 *addend, int add_sign, size_t add_group, int add_mod)
+{
+    NttArgs a{};
+    a.src = src; a.dst = dst;
+    a.mod_base = bsk ? c->k : 0; a.mod_count = bsk ? c->kb : c->k;
+    a.addend = addend; a.add_sign = add_sign; a.rows_per_ct = size * a.mod_count; a.add_group = (long long)(add_group ? add_group : 1);
+    a.add_mode = 1; a.add_mod = add_mod;
+    return ntt_launch(c, inv, a, count * size * a.mod_count, st);
+}
+
+// inverse NTT of size-2 ciphertexts src -> dst, adding polys 0,1 of a size-`add_size` ciphertext array (relinearize tail)
+int k_ntt_ct_addct(crc_ctx *c, const u64 *src, u64 *dst, size_t count, const u64 *addct, int add_size, hipStream_t st)
+{
+    NttArgs a{};
+    a.src = src; a.dst = dst; a.mod_base = 0; a.mod_count = c->k;
+    a.addend = addct; a.add_sign = 1; a.rows_per_ct = 2 * c->k; a.add_group = 1; a.add_mode = 2; a.add_size = add_size;
+    return ntt_launch(c, true, a, count * 2 * c->k, st);
+}
+
+// forward NTT of `items` polynomials under every q_j: src [items][n] -> dst [items][k][n]
+int k_spread_ntt(crc_ctx *c, const u64 *src, size_t items, u64 *dst, hipStream_t st)
+{
+    NttArgs a{};
+    a.src = src; a.dst = dst; a.mod_base = 0; a.mod_count = c->k; a.src_rows_per_item = 1; a.prologue = 0;
+    a.rows_per_ct = c->k; a.add_group = 1;
+    return ntt_launch(c, false, a, items * c->k, st);
+}
+
+int k_plain_ntt(crc_ctx *c, const u64 *d_plain, size_t count, int mode, bool do_ntt, u64 *d_out, hipStream_t st);
+
+// plaintext [count][n] -> [count][k][n]: lift (mode 1) or delta-scale (mode 2), then forward NTT (unless !do_ntt)
+__global__ void plain_prep_kernel(const u64 *plain, u64 *out, const ModParams *mods, int n, int k, int mode, PlainParams pp)
+{
+    const size_t row = blockIdx.x; const int i = (int)(row % k);
+    const ModParams m = mods[i];
+    const u64 *src = plain + (row / k) * (size_t)n; u64 *dst = out + row * (size_t)n;
+    for (int s = threadIdx.x; s < n; s += blockDim.x) {
+        u64 v = src[s];
+        if (mode == 1) v = v >= pp.threshold ? v + pp.inc[i] : v;
+        else {
+            u64 lo, hi; mul64wide(pp.delta[i], v, lo, hi);
+            if (v >= pp.threshold) { u64 l2 = lo + pp.uhi[i]; hi += (l2 < lo); lo = l2; }
+            v = barrett128(lo, hi, m);
+        }
+        dst[s] = v;
+    }
+}
+
+int k_plain_ntt(crc_ctx *c, const u64 *d_plain, size_t count, int mode, bool do_ntt, u64 *d_out, hipStream_t st)
+{
+    if (count == 0) return CRC_OK;
+    if (do_ntt) {
+        NttArgs a{};
+        a.src = d_plain; a.dst = d_out; a.mod_base = 0; a.mod_count = c->k; a.src_rows_per_item = 1; a.prologue = mode; a.pp = c->plain;
+        a.rows_per_ct = c->k; a.add_group = 1;
+        return ntt_launch(c, false, a, count * c->k, st);
+    }
+    hipLaunchKernelGGL(plain_prep_kernel, dim3((unsigned)(count * c->k)), dim3(256), 0, st, d_plain, d_out, c->d_mods, c->n, c->k, mode, c->plain);
+    HIPCHK(hipGetLastError());
+    return CRC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// element-wise row kernels (HBM-bound): 16 B per lane
+// ---------------------------------------------------------------------------------------------------------------
+// op 0: acc = acc + b            (Evaluator::add, evaluator.cpp:254-294)
+// op 1: acc = acc +/- plain      (add_plain/sub_plain on poly 0 only; b = delta-form plaintext shared by `group` cts)
+// op 2: acc = acc * w            (multiply_plain_ntt, evaluator.cpp:1541-1585; w shared by `group` cts, both polys)
+__global__ void __launch_bounds__(256) rowwise_kernel(u64 *acc, const u64 *b, const ModParams *mods, int n, int k, int size,
+                                                      int op, int sign, unsigned long long group, unsigned long long gmod)
+{
+    const size_t row = blockIdx.x;
+    const int i = (int)(row % k);
+    const ModParams m = mods[i];
+    const size_t ct = row / ((size_t)size * k);
+    const int p = (int)((row / k) % size);
+    u64 *x = acc + row * (size_t)n;
+    const u64 *y;
+    if (op == 0) y = b + row * (size_t)n;
+    else { if (op == 1 && p != 0) return; size_t g = ct / group; if (gmod) g %= gmod; y = b + (g * k + i) * (size_t)n; }
+    for (int s = threadIdx.x * 2; s < n; s += blockDim.x * 2) {
+        ulonglong2 xv = *reinterpret_cast<const ulonglong2 *>(x + s);
+        const ulonglong2 yv = *reinterpret_cast<const ulonglong2 *>(y + s);
+        if (op == 0 || (op == 1 && sign > 0)) { xv.x = addmod(xv.x, yv.x, m.q); xv.y = addmod(xv.y, yv.y, m.q); }
+        else if (op == 1) { xv.x = submod(xv.x, yv.x, m.q); xv.y = submod(xv.y, yv.y, m.q); }
+        else { xv.x = mulmod(xv.x, yv.x, m); xv.y = mulmod(xv.y, yv.y, m); }
+        *reinterpret_cast<ulonglong2 *>(x + s) = xv;
+    }
+}
+
+int k_rowwise(crc_ctx *c, u64 *acc, const u64 *b, size_t count, int size, int op, int sign, size_t group, size_t gmod, hipStream_t st)
+{
+    if (count == 0) return CRC_OK;
+    size_t rows = count * size * c->k;
+    hipLaunchKernelGGL(rowwise_kernel, dim3((unsigned)rows), dim3(256), 0, st, acc, b, c->d_mods, c->n, c->k, size, op, sign,
+                       (unsigned long long)(group ? group : 1), (unsigned long long)gmod);
+    HIPCHK(hipGetLastError());
+    return CRC_OK;
+}
+
+// window sum (PoolingLayer::forward, poolingLayer.cpp:22-44) with optional dyadic multiply by an NTT-form plaintext
+// (only meaningful when the tensor is NTT-resident) and optional per-channel affine (batch-norm in NTT form).
+__global__ void __launch_bounds__(256) pool_kernel(const u64 *x, u64 *y, const ModParams *mods, int n, int k,
+                                                   int zd, int xd, int yd, int xs, int ys, int xf, int yf, int xo, int yo, const u64 *mul)
+{
+    // one block per output row: row = (((b*zd + z)*xo + ox)*yo + oy)*2k + p*k + i
+    const size_t row = blockIdx.x;
+    const int i = (int)(row % k); const int p = (int)((row / k) % 2);
+    size_t ct = row / (2 * (size_t)k);
+    const int oy = (int)(ct % yo); ct /= yo; const int ox = (int)(ct % xo); ct /= xo;       // ct = b*zd + z
+    const ModParams m = mods[i];
+    const u64 *base = x + ((ct * xd + (size_t)ox * xs) * yd + (size_t)oy * ys) * (2 * (size_t)k * n) + ((size_t)p * k + i) * n;
+    u64 *dst = y + row * (size_t)n;
+    const u64 *w = mul ? mul + (size_t)i * n : nullptr;
+    for (int s = threadIdx.x * 2; s < n; s += blockDim.x * 2) {
+        ulonglong2 acc = make_ulonglong2(0, 0);
+        for (int kx = 0; kx < xf; kx++) for (int ky = 0; ky < yf; ky++) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(base + ((size_t)kx * yd + ky) * (2 * (size_t)k * n) + s);
+            acc.x = addmod(acc.x, v.x, m.q); acc.y = addmod(acc.y, v.y, m.q);
+        }
+        if (w) { const ulonglong2 wv = *reinterpret_cast<const ulonglong2 *>(w + s); acc.x = mulmod(acc.x, wv.x, m); acc.y = mulmod(acc.y, wv.y, m); }
+        *reinterpret_cast<ulonglong2 *>(dst + s) = acc;
+    }
+}
+
+int k_pool(crc_ctx *c, const u64 *x, u64 *y, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, const u64 *mul, hipStream_t st)
+{
+    int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys + 1;
+    size_t rows = (size_t)B * zd * xo * yo * 2 * c->k;
+    if (rows == 0) return CRC_OK;
+    hipLaunchKernelGGL(pool_kernel, dim3((unsigned)rows), dim3(256), 0, st, x, y, c->d_mods, c->n, c->k, zd, xd, yd, xs, ys, xf, yf, xo, yo, mul);
+    HIPCHK(hipGetLastError());
+    return CRC_OK;
+}
+
+// batch-norm on an NTT-resident tensor: x = (x - mean_delta_ntt[z]) * invstd_ntt[z]   (poly 0 gets the subtraction)
+__global__ void __launch_bounds__(256) bn_ntt_kernel(u64 *x, const u64 *mean, const u64 *invstd, const ModParams *mods, int n, int k,
+                                                     int zd, int hw)
+{
+    const size_t row = blockIdx.x;
+    const int i = (int)(row % k); const int p = (int)((row / k) % 2);
+    const size_t ct = row / (2 * (size_t)k);
+    const int z = (int)((ct / hw) % zd);
+    const ModParams m = mods[i];
+    u64 *d = x + row * (size_t)n;
+    const u64 *mu = mean + ((size_t)z * k + i) * n, *w = invstd + ((size_t)z * k + i) * n;
+    for (int s = threadIdx.x * 2; s < n; s += blockDim.x * 2) {
+        ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(d + s);
+        const ulonglong2 wv = *reinterpret_cast<const ulonglong2 *>(w + s);
+        if (p == 0) { const ulonglong2 mv = *reinterpret_cast<const ulonglong2 *>(mu + s); v.x = submod(v.x, mv.x, m.q); v.y = submod(v.y, mv.y, m.q); }
+        v.x = mulmod(v.x, wv.x, m); v.y = mulmod(v.y, wv.y, m);
+        *reinterpret_cast<ulonglong2 *>(d + s) = v;
+    }
+}
+
+int k_bn_ntt(crc_ctx *c, u64 *x, int B, int zd, int hw, const u64 *mean, const u64 *invstd, hipStream_t st)
+{
+    size_t rows = (size_t)B * zd * hw * 2 * c->k;
+    if (rows == 0) return CRC_OK;
+    hipLaunchKernelGGL(bn_ntt_kernel, dim3((unsigned)rows), dim3(256), 0, st, x, mean, invstd, c->d_mods, c->n, c->k, zd, hw);
+    HIPCHK(hipGetLastError());
+    return CRC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ct x pt multiply-accumulate in the NTT domain (the hot loop of convolution3d / FullyConnectedLayer::forward):
+//   y[b][f][p][poly][i][s] = sum_T  x[b][xoff[p] + toff[T]][poly][i][s] * w[f][T][i][s]   (mod q_i)
+// The reference computes INTT(x*w) per product and adds in coefficient form (convolutionalLayer.cpp:73-88); summing
+// in the NTT domain and transforming once is the same element of Z_q[x]/(x^n+1), hence the same bits.
+// One lane = one slot s; a thread keeps a PT x 2(polys) x FT register tile of 128-bit lazy accumulators and does a
+// single Barrett reduction per output (products < 2^120 for T < 2^10..2^18 terms).
+// ---------------------------------------------------------------------------------------------------------------
+// gather tables of a valid-padding strided convolution (device-built: no host data on the launch path)
+__global__ void conv_offsets_kernel(int *xoff, int *toff, int P, int T, int xd, int yd, int xs, int ys, int xf, int yf, int yo)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < P) { const int ox = idx / yo, oy = idx % yo; xoff[idx] = (ox * xs) * yd + oy * ys; }
+    if (idx < T) { const int z = idx / (xf * yf), kx = (idx / yf) % xf, ky = idx % yf; toff[idx] = (z * xd + kx) * yd + ky; }
+}
+int k_conv_offsets(int *xoff, int *toff, int P, int T, int xd, int yd, int xs, int ys, int xf, int yf, int yo, hipStream_t st)
+{
+    const int m = P > T ? P : T;
+    hipLaunchKernelGGL(conv_offsets_kernel, dim3((m + 255) / 256), dim3(256), 0, st, xoff, toff, P, T, xd, yd, xs, ys, xf, yf, yo);
+    HIPCHK(hipGetLastError());
+    return CRC_OK;
+}
+
+struct MacArgs {
+    const u64 *x; const u64 *w; u64 *y; const ModParams *mods;
+    const int *xoff; const int *toff;        // device tables: output pixel -> base ct index, term -> ct offset
+    int n, k, B, P, F, T, in_cts;            // P output pixels per image, in_cts input cts per image
+    const u64 *bias; int bias_sign;          // optional NTT-form delta bias [F][k][n] added to poly 0
+};
+
+template <int PT, int FT>
+__global__ void __launch_bounds__(256) mac_kernel(MacArgs a)
+{
+    const int n = a.n, k = a.k;
+    const int sblocks = n / blockDim.x;
+    const int rs = blockIdx.x % (sblocks * k);
+    const int i = rs / sblocks;                                           // residue
+    const int s = (rs % sblocks) * blockDim.x + threadIdx.x;              // slot
+    const int ptiles = (a.P + PT - 1) / PT;
+    const int bp = blockIdx.x / (sblocks * k);
+    const int b = bp / ptiles, p0 = (bp % ptiles) * PT;
+    const int f0 = blockIdx.y * FT;
+    const ModParams m = a.mods[i];
+    const size_t ctw = 2 * (size_t)k * n, rown = (size_t)i * n + s;
+
+    u64 lo[PT][2][FT], hi[PT][2][FT];
+#pragma unroll
+    for (int pp = 0; pp < PT; pp++)
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int ff = 0; ff < FT; ff++) { lo[pp][c][ff] = 0; hi[pp][c][ff] = 0; }
+
+    const u64 *xb[PT];
+#pragma unroll
+    for (int pp = 0; pp < PT; pp++) {
+        const int p = min(p0 + pp, a.P - 1);
+        xb[pp] = a.x + ((size_t)b * a.in_cts + a.xoff[p]) * ctw + rown;
+    }
+    const u64 *wb = a.w + (size_t)f0 * a.T * k * n + rown;
+    const size_t wstride_f = (size_t)a.T * k * n, wstride_t = (size_t)k * n;
+
+    for (int t = 0; t < a.T; t++) {
+        const size_t to = (size_t)a.toff[t] * ctw;
+        u64 xv[PT][2], wv[FT];
+#pragma unroll
+        for (int pp = 0; pp < PT; pp++) { xv[pp][0] = xb[pp][to]; xv[pp][1] = xb[pp][to + (size_t)k * n]; }
+#pragma unroll
+        for (int ff = 0; ff < FT; ff++) wv[ff] = (f0 + ff < a.F) ? wb[ff * wstride_f + t * wstride_t] : 0;
+#pragma unroll
+        for (int pp = 0; pp < PT; pp++)
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int ff = 0; ff < FT; ff++) {
+                    u64 pl, ph; mul64wide(xv[pp][c], wv[ff], pl, ph);
+                    const u64 nl = lo[pp][c][ff] + pl;
+                    hi[pp][c][ff] += ph + (nl < pl);
+                    lo[pp][c][ff] = nl;
+                }
+    }
+#pragma unroll
+    for (int pp = 0; pp < PT; pp++) {
+        const int p = p0 + pp;
+        if (p >= a.P) continue;
+#pragma unroll
+        for (int ff = 0; ff < FT; ff++) {
+            const int f = f0 + ff;
+            if (f >= a.F) continue;
+            u64 *dst = a.y + (((size_t)b * a.F + f) * a.P + p) * ctw + rown;
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                u64 v = barrett128(lo[pp][c][ff], hi[pp][c][ff], m);
+                if (c == 0 && a.bias) { const u64 bv = a.bias[(size_t)f * k * n + rown]; v = a.bias_sign > 0 ? addmod(v, bv, m.q) : submod(v, bv, m.q); }
+                dst[(size_t)c * k * n] = v;
+            }
+        }
+    }
+}
+
+int k_mac(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, const int *d_toff, int B, int P, int F, int T, int in_cts,
+          const u64 *bias_ntt, hipStream_t st)
+{
+    if (B == 0 || P == 0 || F == 0) return CRC_OK;
+    // 128-bit lazy accumulation bound: T * q^2 < 2^128
+    int maxbits = 0; for (int i = 0; i < c->k; i++) if ((int)c->tabs[i].m.bits > maxbits) maxbits = c->tabs[i].m.bits;
+    int tb = 0; while ((1LL << tb) < T) tb++;
+    if (2 * maxbits + tb > 127) return CRC_ERR_UNSUPPORTED;
+    MacArgs a{};
+    a.x = x; a.w = w; a.y = y; a.mods = c->d_mods; a.xoff = d_xoff; a.toff = d_toff;
+    a.n = c->n; a.k = c->k; a.B = B; a.P = P; a.F = F; a.T = T; a.in_cts = in_cts; a.bias = bias_ntt; a.bias_sign = 1;
+    const int threads = c->n < 256 ? c->n : 256;
+    constexpr int PT = 2, FT = 4;
+    const size_t gx = (size_t)(c->n / threads * c->k) * B * ((P + PT - 1) / PT);
+    if (gx > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
+    dim3 grid((unsigned)gx, (unsigned)((F + FT - 1) / FT));
+    hipLaunchKernelGGL((mac_kernel<PT, FT>), grid, dim3(threads), 0, st, a);
+    HIPCHK(hipGetLastError());
+    return CRC_OK;
+}

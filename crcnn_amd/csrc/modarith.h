@@ -1,0 +1,76 @@
+// modarith.h -- 64-bit modular arithmetic shared by host table builders and gfx950 kernels.
+//
+// Everything in the engine is exact arithmetic in Z_q for word-sized q (54..61 bit), so any exact algorithm produces
+// the reference's bits.  On the device there is no 64x64 multiplier: products are built from
+// 32-bit v_mad_u64_u32 / v_mul_hi_u32 pieces by the compiler (__umul64hi, unsigned __int128 are not used on device).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define CRC_HD __host__ __device__ __forceinline__
+#else
+#define CRC_HD inline
+#endif
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+// per-modulus constants (host builds them, kernels read them from a small device array)
+struct ModParams {
+    u64 q;          // modulus
+    u64 r0, r1;     // floor(2^128 / q) low / high word  (Barrett, same constant SEAL calls const_ratio)
+    u64 two_q;      // 2q
+    u32 bits;       // significant bits of q
+    u32 pad;
+};
+
+CRC_HD u64 mulhi64(u64 a, u64 b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (u64)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+CRC_HD void mul64wide(u64 a, u64 b, u64 &lo, u64 &hi)
+{
+    lo = a * b;
+    hi = mulhi64(a, b);
+}
+
+CRC_HD u64 addmod(u64 a, u64 b, u64 q) { u64 s = a + b; return s >= q ? s - q : s; }
+CRC_HD u64 submod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
+CRC_HD u64 negmod(u64 a, u64 q) { return a ? q - a : 0; }
+
+// x = hi*2^64 + lo  ->  x mod q, canonical.  Exact for any 128-bit x (quotient estimate is off by at most one).
+CRC_HD u64 barrett128(u64 lo, u64 hi, const ModParams &m)
+{
+    // floor(x * r / 2^128) mod 2^64, r = r1*2^64 + r0
+    u64 c = mulhi64(lo, m.r0);
+    u64 t_lo, t_hi;
+    mul64wide(lo, m.r1, t_lo, t_hi);
+    u64 s1 = t_lo + c;
+    u64 acc = t_hi + (s1 < c);
+    mul64wide(hi, m.r0, t_lo, t_hi);
+    u64 s2 = s1 + t_lo;
+    u64 carry = t_hi + (s2 < s1);
+    u64 quot = hi * m.r1 + acc + carry;
+    u64 r = lo - quot * m.q;
+    return r >= m.q ? r - m.q : r;
+}
+
+CRC_HD u64 mulmod(u64 a, u64 b, const ModParams &m)
+{
+    u64 lo, hi;
+    mul64wide(a, b, lo, hi);
+    return barrett128(lo, hi, m);
+}
+
+// Shoup multiplication by a constant w with precomputed wp = floor(w * 2^64 / q):  returns a*w mod q in [0, 2q)
+// for any 64-bit a (lazy), provided q < 2^63.
+CRC_HD u64 mulmod_shoup_lazy(u64 a, u64 w, u64 wp, u64 q)
+{
+    u64 h = mulhi64(wp, a);
+    return a * w - h * q;
+}

@@ -1,0 +1,197 @@
+/*
+ * crcnn_hip.h -- C ABI of the MI355X-native encrypted-CNN evaluation engine (libcrcnn_hip.so).
+ *
+ * Drop-in boundary for the reference's hot path.  The reference (CrCNN) has no FFI layer: its
+ * evaluation path is `Layer::forward(ciphertext3D)` (CrCNN/src/layer.h:10-31) calling ten SEAL 2.3.1 `Evaluator`
+ * methods (SEAL/seal/evaluator.cpp).  Each entry point below names the reference function(s) it replaces.  The C++
+ * classes in crcnn_amd/host/ (Layer, ConvolutionalLayer, ..., Network, CnnBuilder) mirror the reference's interface
+ * one-to-one and are implemented purely on top of this header.
+ *
+ * Conventions
+ *   - plain C types only; every pointer named d_* is a DEVICE pointer (HBM), h_* is a host pointer.
+ *   - a ciphertext of `size` polynomials is uint64[size][k][n], residues canonical in [0,q_i)  (SEAL keeps
+ *     [size][k][n+1] with a dead zero pad word, ciphertext.cpp:103-130: crc_import/export_seal convert).
+ *   - a ciphertext tensor is [B][C][H][W] of ciphertexts, row-major (CrCNN's ciphertext3D is [z][x][y]; B = image batch).
+ *   - plaintext polynomials are uint64[n] coefficient vectors in [0,t); "ntt form" weights are uint64[k][n];
+ *     "delta form" plaintexts (pre-scaled for add_plain/sub_plain) are uint64[k][n].
+ *   - `form` flags say whether a ciphertext tensor is in coefficient form (CRC_COEFF, what the reference's layers
+ *     exchange) or in NTT form (CRC_NTT, SEAL's transform_to_ntt ordering: slot j holds a(psi^(2*bitrev(j)+1))).
+ *   - all functions return 0 on success or a negative crc_status; nothing throws across the ABI.  The reference
+ *     signals errors by C++ exceptions (std::invalid_argument, evaluator.cpp:1549-1556) -- the C++ host classes turn a
+ *     non-zero status back into std::invalid_argument / std::runtime_error.
+ *   - a context is immutable after creation and may be used from several host threads; every launch goes to the HIP
+ *     stream passed in (`stream` is a hipStream_t cast to void*, NULL = default stream).  No entry point allocates,
+ *     frees or synchronises unless its name says so; scratch memory is passed in (`d_work`, sized by *_work_bytes).
+ */
+#ifndef CRCNN_HIP_H
+#define CRCNN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct crc_ctx crc_ctx;
+
+typedef enum {
+    CRC_OK = 0,
+    CRC_ERR_INVALID_ARGUMENT = -1,   /* bad shape / null pointer / unsupported parameter (std::invalid_argument in the reference) */
+    CRC_ERR_PARAMETERS = -2,         /* (n, q[], t) rejected: SEALContext::validate, context.cpp:15-169 */
+    CRC_ERR_HIP = -3,                /* a HIP runtime call failed; crc_last_hip_error() has the code */
+    CRC_ERR_UNSUPPORTED = -4,        /* valid in the reference but not implemented here (e.g. t >= min q_i: slow plain lift) */
+    CRC_ERR_IO = -5,                 /* file could not be read / not an HDF5 file we understand */
+    CRC_ERR_NOT_FOUND = -6           /* dataset name missing in the model file */
+} crc_status;
+
+enum { CRC_COEFF = 0, CRC_NTT = 1 };
+
+const char *crc_strerror(int status);
+int         crc_last_hip_error(void);
+int         crc_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * context   replaces: SEALContext (context.cpp:15-169) + Evaluator ctor tables (evaluator.cpp:19-121) + BaseConverter
+ *           ctor (util/baseconverter.cpp:20-353) + SmallNTTTables (util/smallntt.cpp:37-92) as built by
+ *           CrCNN setParameters (CrCNN/src/globals.cpp:25-56).  q may be any explicit list (coeff_modulus_128(n) or a
+ *           prefix of it, as BASELINE.json's configs ask).
+ * ------------------------------------------------------------------------------------------------------------- */
+int  crc_ctx_create(int n, const uint64_t *q, int k, uint64_t t, int device, crc_ctx **out);
+void crc_ctx_destroy(crc_ctx *ctx);
+/* SEAL's default 128-bit-security moduli (util/globals.cpp:25-90); returns count, copies min(count,cap) */
+int  crc_default_coeff_modulus_128(int n, uint64_t *q, int cap);
+int  crc_ctx_n(const crc_ctx *ctx);
+int  crc_ctx_k(const crc_ctx *ctx);
+int  crc_ctx_kbsk(const crc_ctx *ctx);                 /* |Bsk| */
+int  crc_ctx_device(const crc_ctx *ctx);
+size_t crc_ct_words(const crc_ctx *ctx, int size);     /* size*k*n */
+size_t crc_evk_words(const crc_ctx *ctx, int dbc);     /* words of an evaluation-key blob: sum_l 2*L_l*k*n */
+/* named host-side table read-out (tests): "root","const_ratio","delta","upper_half_increment","bsk","bsk_root",
+ * "root_powers:<i>","inv_root_powers_div_two:<i>"; returns word count */
+int  crc_ctx_table(const crc_ctx *ctx, const char *name, uint64_t *h_out, int cap);
+
+/* thin device-memory helpers so that C / C++ / ctypes callers need not link HIP themselves */
+int crc_malloc(crc_ctx *ctx, size_t bytes, void **d_ptr);
+int crc_free(crc_ctx *ctx, void *d_ptr);
+int crc_memcpy_h2d(crc_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, void *stream);
+int crc_memcpy_d2h(crc_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, void *stream);
+int crc_memcpy_d2d(crc_ctx *ctx, void *d_dst, const void *d_src, size_t bytes, void *stream);
+int crc_memset(crc_ctx *ctx, void *d_dst, int value, size_t bytes, void *stream);
+int crc_stream_sync(crc_ctx *ctx, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * encoding (host)   replaces: FractionalEncoder(t, x^n+1, 64, 32, 3)::encode/decode (encoder.cpp:1013-1076,
+ *           1226-1270; instantiated at CrCNN/src/globals.cpp:52) as used by CnnBuilder::build*Layer (cnnBuilder.cpp:25-105)
+ * ------------------------------------------------------------------------------------------------------------- */
+/* values are widened float32 -> double exactly as `fraencoder->encode(weights[w])` does.  h_coeff_count (optional)
+ * receives SEAL's Plaintext::coeff_count() for each value (needed only for wire-format compatibility). */
+int    crc_encode_f32(const crc_ctx *ctx, const float *h_values, size_t count, uint64_t *h_plain /*[count][n]*/, int32_t *h_coeff_count);
+int    crc_encode_f64(const crc_ctx *ctx, const double *h_values, size_t count, uint64_t *h_plain, int32_t *h_coeff_count);
+double crc_decode(const crc_ctx *ctx, const uint64_t *h_plain /*[n]*/);
+/* batch-norm parameters: invstd = float(1/sqrt(double(var)+0.00001))  (cnnBuilder.cpp:100-102) */
+int    crc_bn_invstd_f32(const float *h_var, size_t count, float *h_invstd);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * plaintext preparation (device)
+ *   crc_plain_to_ntt     replaces Evaluator::transform_to_ntt(Plaintext&) (evaluator.cpp:1418-1493): lift to each q_i
+ *                        (c >= (t+1)/2 ? c + q_i - t : c) and forward NTT.     d_plain [count][n] -> d_out [count][k][n]
+ *   crc_plain_to_delta   the Delta*m term of add_plain/sub_plain (evaluator.cpp:1168-1191): floor(q/t)*c (+ q mod t for
+ *                        "negative" c) mod q_i.  form=CRC_NTT additionally NTTs it (for NTT-resident tensors).
+ * ------------------------------------------------------------------------------------------------------------- */
+int crc_plain_to_ntt(crc_ctx *ctx, const uint64_t *d_plain, size_t count, uint64_t *d_out, void *stream);
+int crc_plain_to_delta(crc_ctx *ctx, const uint64_t *d_plain, size_t count, int form, uint64_t *d_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * NTT   replaces Evaluator::transform_to_ntt(Ciphertext&) / transform_from_ntt (evaluator.cpp:1495-1539) ->
+ *       ntt_negacyclic_harvey / inverse_ntt_negacyclic_harvey (util/smallntt.h:210-258, smallntt.cpp:195-375).
+ *       In place on `count` ciphertexts of `size` polys each; canonical output.
+ * ------------------------------------------------------------------------------------------------------------- */
+int crc_ntt_fwd(crc_ctx *ctx, uint64_t *d_ct, size_t count, int size, void *stream);
+int crc_ntt_inv(crc_ctx *ctx, uint64_t *d_ct, size_t count, int size, void *stream);
+/* same over the Bsk moduli (rows are [count][kbsk][n]); exposed for unit tests of the Square pipeline */
+int crc_ntt_fwd_bsk(crc_ctx *ctx, uint64_t *d_rows, size_t count, void *stream);
+int crc_ntt_inv_bsk(crc_ctx *ctx, uint64_t *d_rows, size_t count, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * element-wise Evaluator ops on `count` size-2 ciphertexts
+ *   crc_add              Evaluator::add (evaluator.cpp:254-294)                      d_acc += d_b
+ *   crc_add_plain        Evaluator::add_plain / sub_plain (:1145-1241) with a pre-scaled delta-form plaintext
+ *                        shared by `group` consecutive ciphertexts (d_delta [count/group][k][n]); sign=+1/-1
+ *   crc_multiply_plain_ntt  Evaluator::multiply_plain_ntt (:1541-1585): NTT-form ct times NTT-form plaintext
+ *   crc_multiply_plain   Evaluator::multiply_plain generic path (:1343-1415): coefficient-form ct in, coefficient-form
+ *                        out, NTT-form plaintext given (the reference re-NTTs it on every call)
+ * ------------------------------------------------------------------------------------------------------------- */
+int crc_add(crc_ctx *ctx, uint64_t *d_acc, const uint64_t *d_b, size_t count, int size, void *stream);
+int crc_add_plain(crc_ctx *ctx, uint64_t *d_ct, const uint64_t *d_delta, size_t count, size_t group, int sign, void *stream);
+int crc_multiply_plain_ntt(crc_ctx *ctx, uint64_t *d_ct, const uint64_t *d_w_ntt, size_t count, size_t group, int size, void *stream);
+int crc_multiply_plain(crc_ctx *ctx, uint64_t *d_ct, const uint64_t *d_w_ntt, size_t count, size_t group, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * layers (batched over B images).  in_form / out_form: CRC_COEFF reproduces the reference layer exactly (coefficient
+ * form in and out); CRC_NTT keeps tensors NTT-resident between layers (bit-identical after the final INTT).
+ *
+ *   crc_conv2d   ConvolutionalLayer::forward / convolution3d (CrCNN/src/convolutionalLayer.cpp:159-197, 56-93):
+ *                y[b][f][i][j] = sum_{z,kx,ky} x[b][z][i*xs+kx][j*ys+ky] (*) w[f][z][kx][ky] + Delta*bias[f],
+ *                valid padding, xo=(xd-xf)/xs+1, yo=(yd-yf)/ys+1.   d_w_ntt [nf][zd][xf][yf][k][n],
+ *                d_bias_delta [nf][k][n] in the form of the OUTPUT (coeff for CRC_COEFF, NTT for CRC_NTT).
+ *   crc_dense    FullyConnectedLayer::forward (fullyConnectedLayer.cpp:113-168) incl. reshapeInput (:38-56):
+ *                x is [B][in_dim] cts in z,x,y row-major order; d_w_ntt [out_dim][in_dim][k][n].
+ *   crc_pool     PoolingLayer::forward (poolingLayer.cpp:22-44) and AvgPoolingLayer::forward (avgPoolingLayer.cpp:16-45):
+ *                window sum; if d_div_ntt != NULL multiply by that NTT-form plaintext (encode(1./(xf*yf))).
+ *   crc_batchnorm BatchNormLayer::forward (batchNormLayer.cpp:29-40): (x - Delta*mean[z]) (*) invstd[z].
+ *                d_mean_delta [C][k][n] in the form of the INPUT, d_invstd_ntt [C][k][n].
+ *   crc_square_relin  SquareLayer::forward (squareLayer.cpp:22-74) = Evaluator::square (evaluator.cpp:702-884) +
+ *                relinearize (:886-1069) with decomposition-bit-count `dbc` keys.  Coefficient form in and out.
+ *                d_evk: for l<k: [2*L_l][k][n] (= evaluation_keys.data()[0][l], pad words dropped), values may be
+ *                SEAL's lazy non-canonical residues.
+ * ------------------------------------------------------------------------------------------------------------- */
+size_t crc_conv2d_work_bytes(const crc_ctx *ctx, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int in_form);
+int crc_conv2d(crc_ctx *ctx, const uint64_t *d_x, const uint64_t *d_w_ntt, const uint64_t *d_bias_delta,
+               int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf,
+               int in_form, int out_form, uint64_t *d_y, void *d_work, void *stream);
+size_t crc_dense_work_bytes(const crc_ctx *ctx, int B, int in_dim, int out_dim, int in_form);
+int crc_dense(crc_ctx *ctx, const uint64_t *d_x, const uint64_t *d_w_ntt, const uint64_t *d_bias_delta,
+              int B, int in_dim, int out_dim, int in_form, int out_form, uint64_t *d_y, void *d_work, void *stream);
+int crc_pool(crc_ctx *ctx, const uint64_t *d_x, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf,
+             const uint64_t *d_div_ntt /* NULL = sum pool */, int form, uint64_t *d_y, void *stream);
+int crc_batchnorm(crc_ctx *ctx, uint64_t *d_x, int B, int zd, int xd, int yd, const uint64_t *d_mean_delta,
+                  const uint64_t *d_invstd_ntt, int form, void *stream);
+size_t crc_square_relin_work_bytes(const crc_ctx *ctx, size_t count, int dbc);
+int crc_square_relin(crc_ctx *ctx, const uint64_t *d_x, size_t count, const uint64_t *d_evk, int dbc,
+                     uint64_t *d_y, void *d_work, void *stream);
+/* the two halves separately (unit tests): square -> size-3 ciphertexts; relinearize -> size 2 */
+int crc_square(crc_ctx *ctx, const uint64_t *d_x, size_t count, uint64_t *d_y3, void *d_work, void *stream);
+int crc_relinearize(crc_ctx *ctx, const uint64_t *d_x3, size_t count, const uint64_t *d_evk, int dbc, uint64_t *d_y,
+                    void *d_work, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * SEAL memory/wire layout <-> engine layout (host)   ciphertext.cpp:103-130 ([size][k][n+1], pad word zero)
+ * ------------------------------------------------------------------------------------------------------------- */
+int crc_import_seal(const crc_ctx *ctx, const uint64_t *h_seal, int size, uint64_t *h_out);
+int crc_export_seal(const crc_ctx *ctx, const uint64_t *h_in, int size, uint64_t *h_seal);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * model loader (host)   replaces LoadH5::getDataVfloat (CrCNN/src/H5Easy.cpp:584-644) as used by
+ *           CnnBuilder::getPretrained (cnnBuilder.cpp:20-23): flat float32 read of dataset `name` (e.g.
+ *           "pool1_features.conv1.weight") from an HDF5 file written by PlainModel/ToH5.py.
+ *           Built-in reader (superblock v0, contiguous little-endian float32 datasets); no libhdf5 needed.
+ * ------------------------------------------------------------------------------------------------------------- */
+int crc_h5_dataset_count(const char *path, const char *name, size_t *count);
+int crc_h5_read_f32(const char *path, const char *name, float *h_out, size_t cap, size_t *count);
+int crc_h5_list(const char *path, char *h_names, size_t cap);   /* newline-separated dataset names */
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * client side (host CPU; SURVEY 8f-2, outside the accelerated path): keygen / encrypt / decrypt so that a user of
+ * CrCNN's globals.cpp (setParameters, encryptImage, decryptImage: globals.cpp:25-56,127-157,207-230) finds them.
+ * Seeded RNG; ciphertexts are valid BFV encryptions but not bit-identical to SEAL's (its RNG is std::random_device).
+ * ------------------------------------------------------------------------------------------------------------- */
+int crc_keygen(const crc_ctx *ctx, uint64_t seed, uint64_t *h_sk_ntt /*[k][n]*/, uint64_t *h_pk /*[2][k][n]*/);
+int crc_gen_evk(const crc_ctx *ctx, uint64_t seed, const uint64_t *h_sk_ntt, int dbc, uint64_t *h_evk);
+int crc_encrypt(const crc_ctx *ctx, const uint64_t *h_pk, const uint64_t *h_plain, size_t count, uint64_t seed, uint64_t *h_ct /*[count][2][k][n]*/);
+int crc_decrypt(const crc_ctx *ctx, const uint64_t *h_sk_ntt, const uint64_t *h_ct, size_t count, int size, uint64_t *h_plain /*[count][n]*/);
+int crc_noise_budget(const crc_ctx *ctx, const uint64_t *h_sk_ntt, const uint64_t *h_ct, int size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,100 @@
+"""CPU-only checks of the product library: it loads, exports every symbol of include/crcnn_hip.h, and its HOST-side
+pieces (context tables, encoder, client-side BFV, HDF5 reader) agree with the reference-pinned goldens.
+No kernel is launched here (device=-1 contexts); GPU parity lives in tests/test_gpu_*.py."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import crcnn_amd as ca
+from crcnn_amd import binding
+from oracle import orc
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+SETS = sorted(glob.glob(os.path.join(GOLD, "ops_*.npz")))
+
+
+def test_library_exports_every_declared_symbol():
+    L = binding.load()
+    syms = binding.header_symbols()
+    assert len(syms) > 40
+    for s in syms:
+        assert hasattr(L, s), s
+
+
+def test_default_moduli():
+    assert ca.default_coeff_modulus_128(4096) == [0x7fffffff380001, 0x3fffffff000001]
+    assert ca.default_coeff_modulus_128(8192)[:3] == [0x7fffffff380001, 0x7ffffffef00001, 0x3fffffff000001]
+    assert len(ca.default_coeff_modulus_128(16384)) == 8
+
+
+def test_invalid_parameters_are_rejected():
+    with pytest.raises(ca.CrcError):
+        ca.Engine(4096, [0x7fffffff380001 + 2], 1 << 20, device=-1)       # not prime / not 1 mod 2n
+    with pytest.raises(ca.CrcError):
+        ca.Engine(4095, [0x7fffffff380001], 1 << 20, device=-1)
+    with pytest.raises(ca.CrcError):
+        ca.Engine(4096, [0x7fffffff380001, 0x7fffffff380001], 1 << 20, device=-1)
+    E = ca.Engine(4096, [0x7fffffff380001], 1 << 20, device=-1)
+    with pytest.raises(ca.CrcError):                                      # device entry point on a host-only context
+        E.ntt_fwd(0, 1)
+
+
+@pytest.mark.parametrize("path", SETS, ids=[os.path.basename(s)[:-4] for s in SETS])
+def test_host_tables_and_encoder_match_reference(path):
+    g = dict(np.load(path))
+    E = ca.Engine(int(g["n"]), [int(x) for x in g["q"]], int(g["t"]), device=-1)
+    k = E.k; c = g["ref_consts"]
+    assert np.array_equal(E.table("root"), c[:k])
+    assert np.array_equal(E.table("const_ratio"), c[k:3 * k])
+    assert np.array_equal(E.table("delta"), c[3 * k:4 * k])
+    assert np.array_equal(E.table("upper_half_increment"), c[4 * k:5 * k])
+    kb = int(c[5 * k]); assert kb == E.kbsk
+    assert np.array_equal(E.table("bsk"), c[5 * k + 1:5 * k + 1 + kb])
+    assert np.array_equal(E.table("bsk_root"), c[5 * k + 1 + kb:5 * k + 1 + 2 * kb])
+    assert np.array_equal(E.table("root_powers:0"), g["ref_root_powers0"][0])
+    assert np.array_equal(E.table("inv_root_powers_div_two:0"), g["ref_root_powers0"][1])
+    enc, cc = E.encode(g["floats"], dtype=np.float64)
+    assert np.array_equal(enc, g["ref_enc_floats"]) and np.array_equal(cc, g["ref_enc_cc"].astype(np.int32))
+    for i in range(len(enc)):
+        assert E.decode(enc[i]) == g["ref_decode"][i]
+
+
+@pytest.mark.parametrize("path", SETS, ids=[os.path.basename(s)[:-4] for s in SETS])
+def test_client_side_interoperates_with_reference(path):
+    """engine decrypts the reference's (SEAL-made) ciphertexts; oracle (pinned to SEAL) decrypts the engine's"""
+    g = dict(np.load(path))
+    n, q, t = int(g["n"]), [int(x) for x in g["q"]], int(g["t"])
+    E = ca.Engine(n, q, t, device=-1); O = orc.Oracle(n, q, t)
+    assert np.array_equal(E.decrypt(g["ref_sk"], g["ref_enc2"]), g["plains"])
+    assert np.array_equal(E.decrypt(g["sk"], g["ref_relin"]), g["ref_dec_relin"])
+    assert np.array_equal(E.decrypt(g["sk"], g["ref_sq"], size=3), g["ref_dec_relin"])
+    for i in range(len(g["ct_in"])):
+        assert E.noise_budget(g["sk"], g["ct_in"][i]) == int(g["ref_budget_in"][i])
+        assert E.noise_budget(g["sk"], g["ref_relin"][i]) == int(g["ref_budget_relin"][i])
+    sk, pk = E.keygen(77)
+    cts = E.encrypt(pk, g["plains"], 5)
+    for j in range(len(cts)):
+        assert np.array_equal(O.decrypt(sk, cts[j]), g["plains"][j])
+        assert O.noise_budget(sk, cts[j]) >= int(g["ref_budget_in"][0]) - 2
+    # evaluation keys made by the engine relinearise correctly under the oracle
+    evk = E.gen_evk(78, sk)
+    r = O.relinearize(O.square(cts[0]), evk)
+    if O.noise_budget(sk, r) >= 10:
+        v = O.decode(g["plains"][0])
+        assert abs(O.decrypt_value(sk, r) - v * v) < 1e-4
+
+
+def test_seal_layout_roundtrip():
+    E = ca.Engine(256, [0x7fffffff380001, 0x3fffffff000001], 1 << 20, device=-1)
+    import ctypes
+    ct = np.arange(2 * 2 * 256, dtype=np.uint64).reshape(2, 2, 256)
+    seal = np.zeros((2, 2, 257), dtype=np.uint64); back = np.zeros_like(ct)
+    PU = ctypes.POINTER(ctypes.c_uint64)
+    assert E.L.crc_export_seal(E.c, ct.ctypes.data_as(PU), 2, seal.ctypes.data_as(PU)) == 0
+    assert np.array_equal(seal[..., :256], ct) and not seal[..., 256].any()
+    assert E.L.crc_import_seal(E.c, seal.ctypes.data_as(PU), 2, back.ctypes.data_as(PU)) == 0
+    assert np.array_equal(back, ct)
+    seal[0, 0, 256] = 1
+    assert E.L.crc_import_seal(E.c, seal.ctypes.data_as(PU), 2, back.ctypes.data_as(PU)) < 0
