@@ -1,0 +1,157 @@
+"""GPU parity, layer level: crc_conv2d / crc_dense / crc_pool / crc_batchnorm / crc_square_relin against the outputs of
+the reference's own Layer::forward (tests/golden/layers_*.npz, CrCNN/src/*Layer.cpp compiled in place) and, for batches
+and NTT-resident chains, against the CPU oracle.  Bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden", "layers_n256_k2_t20.npz")
+
+
+class Net:
+    """helper: uploads encoded parameters the way the C++ host classes do"""
+
+    def __init__(self, E):
+        import crcnn_amd as ca
+        self.E, self.ca = E, ca
+
+    def weights_ntt(self, w):
+        pl, _ = self.E.encode(np.asarray(w, dtype=np.float32))
+        d_p = self.E.upload(pl); d_w = self.E.alloc(len(pl) * self.E.k * self.E.n * 8)
+        self.E.plain_to_ntt(d_p, len(pl), d_w)
+        return d_w
+
+    def delta(self, v, form, dtype=np.float32):
+        pl, _ = self.E.encode(np.asarray(v, dtype=dtype), dtype=dtype)
+        d_p = self.E.upload(pl); d_o = self.E.alloc(len(pl) * self.E.k * self.E.n * 8)
+        self.E.plain_to_delta(d_p, len(pl), form, d_o)
+        return d_o
+
+
+@pytest.fixture(scope="module")
+def gl():
+    import crcnn_amd as ca
+    g = dict(np.load(G))
+    E = ca.Engine(int(g["n"]), [int(x) for x in g["q"]], int(g["t"]), device=0)
+    yield g, E, Net(E)
+    E.close()
+
+
+def ctshape(E, *lead):
+    return tuple(lead) + (2, E.k, E.n)
+
+
+def test_conv2d_matches_reference_layer(gl):
+    g, E, N = gl
+    ca = N.ca
+    zd, xd, yd, xs, ys, xf, yf, nf = [int(v) for v in g["dims"][:8]]
+    xo, yo = (xd - xf) // xs + 1, (yd - yf) // ys + 1
+    d_w = N.weights_ntt(g["conv_w"]); d_b = N.delta(g["conv_b"], ca.COEFF)
+    for B in (1, 3):
+        x = np.ascontiguousarray(np.repeat(g["x"][None], B, axis=0))
+        d_x = E.upload(x); d_y = E.alloc(B * nf * xo * yo * 2 * E.k * E.n * 8)
+        d_work = E.alloc(E.conv2d_work_bytes(B, zd, xd, yd, xs, ys, xf, yf, nf, ca.COEFF))
+        E.conv2d(d_x, d_w, d_b, B, zd, xd, yd, xs, ys, xf, yf, nf, ca.COEFF, ca.COEFF, d_y, d_work)
+        y = E.download(d_y, ctshape(E, B, nf, xo, yo))
+        for b in range(B):
+            assert np.array_equal(y[b], g["ref_conv"])
+        assert np.array_equal(E.download(d_x, x.shape), x)
+
+
+def test_dense_matches_reference_layer(gl):
+    g, E, N = gl
+    ca = N.ca
+    out_dim, in_dim = g["fc_w"].shape
+    d_w = N.weights_ntt(g["fc_w"]); d_b = N.delta(g["fc_b"], ca.COEFF)
+    d_x = E.upload(g["x"]); d_y = E.alloc(out_dim * 2 * E.k * E.n * 8)
+    d_work = E.alloc(E.dense_work_bytes(1, in_dim, out_dim, ca.COEFF))
+    E.dense(d_x, d_w, d_b, 1, in_dim, out_dim, ca.COEFF, ca.COEFF, d_y, d_work)
+    assert np.array_equal(E.download(d_y, ctshape(E, 1, out_dim, 1)), g["ref_fc"])
+
+
+def test_pools_match_reference_layers(gl):
+    g, E, N = gl
+    ca = N.ca
+    zd, xd, yd = [int(v) for v in g["dims"][:3]]
+    pxs, pys, pxf, pyf = [int(v) for v in g["dims"][9:13]]
+    xo, yo = (xd - pxf) // pxs + 1, (yd - pyf) // pys + 1
+    d_x = E.upload(g["x"]); d_y = E.alloc(zd * xo * yo * 2 * E.k * E.n * 8)
+    E.pool(d_x, 1, zd, xd, yd, pxs, pys, pxf, pyf, None, ca.COEFF, d_y)
+    assert np.array_equal(E.download(d_y, ctshape(E, zd, xo, yo)), g["ref_pool"])
+    div = N.weights_ntt(np.array([1.0 / (pxf * pyf)]))          # float32(0.25) == double 0.25: encode(1./(xf*yf)), avgPoolingLayer.cpp:12
+    E.pool(d_x, 1, zd, xd, yd, pxs, pys, pxf, pyf, div, ca.COEFF, d_y)
+    assert np.array_equal(E.download(d_y, ctshape(E, zd, xo, yo)), g["ref_avgpool"])
+
+
+def test_batchnorm_matches_reference_layer(gl):
+    import ctypes
+    g, E, N = gl
+    ca = N.ca
+    zd, xd, yd = [int(v) for v in g["dims"][:3]]
+    var = np.ascontiguousarray(g["bn_var"], dtype=np.float32); invstd = np.zeros_like(var)
+    FP = ctypes.POINTER(ctypes.c_float)
+    assert E.L.crc_bn_invstd_f32(var.ctypes.data_as(FP), var.size, invstd.ctypes.data_as(FP)) == 0
+    d_mean = N.delta(g["bn_mean"], ca.COEFF); d_inv = N.weights_ntt(invstd)
+    d_x = E.upload(g["x"])
+    E.batchnorm(d_x, 1, zd, xd, yd, d_mean, d_inv, ca.COEFF)
+    assert np.array_equal(E.download(d_x, g["x"].shape), g["ref_bn"])
+
+
+def test_square_layer_matches_reference_layer(gl):
+    g, E, N = gl
+    cnt = int(np.prod(g["x"].shape[:3]))
+    d_x = E.upload(g["x"]); d_evk = E.upload(g["evk"]); d_y = E.alloc(g["x"].nbytes); d_w = E.alloc(E.square_relin_work_bytes(cnt))
+    E.square_relin(d_x, cnt, d_evk, d_y, d_w)
+    assert np.array_equal(E.download(d_y, g["x"].shape), g["ref_square"])
+
+
+def test_ntt_resident_chain_equals_reference_order(gl):
+    """conv -> avgpool -> batchnorm -> dense kept in NTT form end to end, one INTT at the very end, must
+    give the bits of the reference's coefficient-form layer sequence (computed here with the oracle's reference-order loops)"""
+    from oracle import orc
+    g, E, N = gl
+    ca = N.ca
+    O = orc.Oracle(E.n, [int(v) for v in E.q], E.t)
+    zd, xd, yd, xs, ys, xf, yf, nf = [int(v) for v in g["dims"][:8]]
+    xo, yo = (xd - xf) // xs + 1, (yd - yf) // ys + 1                # 2 x 3
+    rng = np.random.RandomState(11)
+    mean = rng.normal(0, 0.2, nf).astype(np.float32); var = rng.uniform(0.5, 2, nf).astype(np.float32)
+    invstd = np.float32(1.0 / np.sqrt(var.astype(np.float64) + 0.00001))
+    pxo, pyo = xo - 1, yo - 1                                        # 2x2 window stride 1
+    fcw = rng.normal(0, 0.3, (3, nf * pxo * pyo)).astype(np.float32); fcb = rng.normal(0, 0.1, 3).astype(np.float32)
+    # --- oracle, reference order, coefficient form between layers
+    enc = lambda a: O.encode_many(np.asarray(a, dtype=np.float32)).reshape(np.shape(a) + (O.n,))
+    y = O.conv(g["x"], O.plains_to_ntt(enc(g["conv_w"])), enc(g["conv_b"]), xs, ys)
+    y = O.pool(y, 1, 1, 2, 2, div_plain=O.encode(0.25)[0])
+    y = O.bn(y, enc(mean), enc(invstd))
+    want = O.fc(y, O.plains_to_ntt(enc(fcw)), enc(fcb))
+    # --- engine, NTT resident, batch of 2 identical images
+    B = 2
+    x = np.ascontiguousarray(np.repeat(g["x"][None], B, axis=0))
+    d_x = E.upload(x)
+    d_y1 = E.alloc(B * nf * xo * yo * 2 * E.k * E.n * 8); d_y2 = E.alloc(B * nf * pxo * pyo * 2 * E.k * E.n * 8); d_y3 = E.alloc(B * 3 * 2 * E.k * E.n * 8)
+    d_work = E.alloc(max(E.conv2d_work_bytes(B, zd, xd, yd, xs, ys, xf, yf, nf, ca.COEFF), E.dense_work_bytes(B, nf * pxo * pyo, 3, ca.NTT)))
+    E.conv2d(d_x, N.weights_ntt(g["conv_w"]), N.delta(g["conv_b"], ca.NTT), B, zd, xd, yd, xs, ys, xf, yf, nf, ca.COEFF, ca.NTT, d_y1, d_work)
+    E.pool(d_y1, B, nf, xo, yo, 1, 1, 2, 2, N.weights_ntt(np.array([0.25])), ca.NTT, d_y2)
+    E.batchnorm(d_y2, B, nf, pxo, pyo, N.delta(mean, ca.NTT), N.weights_ntt(invstd), ca.NTT)
+    E.dense(d_y2, N.weights_ntt(fcw), N.delta(fcb, ca.NTT), B, nf * pxo * pyo, 3, ca.NTT, ca.NTT, d_y3, d_work)
+    E.ntt_inv(d_y3, B * 3)
+    got = E.download(d_y3, ctshape(E, B, 1, 3, 1))
+    for b in range(B):
+        assert np.array_equal(got[b], want)
+    vals = [O.decrypt_value(g["sk"], got[0, 0, i, 0]) for i in range(3)]
+    assert all(abs(v) < 50 for v in vals)
+
+
+def test_shape_validation(gl):
+    g, E, N = gl
+    ca = N.ca
+    # stride larger than window with a remainder: the reference leaves empty ciphertexts there -> rejected, not invented
+    assert E.conv2d_work_bytes(1, 1, 5, 5, 3, 3, 2, 2, 1, ca.COEFF) == 0
+    with pytest.raises(ca.CrcError):
+        E.pool(1, 1, 1, 5, 5, 3, 3, 2, 2, None, ca.COEFF, 1)
+    with pytest.raises(ca.CrcError):
+        E.conv2d(1, 1, 1, 1, 1, 2, 2, 1, 1, 3, 3, 1, ca.COEFF, ca.COEFF, 1, 1)     # filter larger than image

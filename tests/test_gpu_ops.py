@@ -1,0 +1,142 @@
+"""GPU parity, op level: every Evaluator-op entry point of the C ABI against (a) outputs of the reference itself
+(tests/golden/ops_*.npz, produced by SEAL 2.3.1 compiled from /root/reference) and (b) the CPU oracle on seeded inputs
+at the BASELINE ring sizes.  Bit-exact (integer arithmetic mod q_i)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+SETS = sorted(glob.glob(os.path.join(GOLD, "ops_*.npz")))
+
+
+@pytest.fixture(scope="module", params=SETS, ids=[os.path.basename(s)[:-4] for s in SETS])
+def gs(request):
+    import crcnn_amd as ca
+    g = dict(np.load(request.param))
+    E = ca.Engine(int(g["n"]), [int(x) for x in g["q"]], int(g["t"]), device=0)
+    yield g, E
+    E.close()
+
+
+def test_ntt_roundtrip_and_golden(gs):
+    g, E = gs
+    cts = g["ct_in"]
+    d = E.upload(cts)
+    E.ntt_fwd(d, len(cts))
+    assert np.array_equal(E.download(d, cts.shape), g["ref_ct_ntt"])
+    E.ntt_inv(d, len(cts))
+    assert np.array_equal(E.download(d, cts.shape), cts)
+
+
+def test_plain_to_ntt(gs):
+    g, E = gs
+    pl = g["plains"]
+    d_p = E.upload(pl); d_o = E.alloc(len(pl) * E.k * E.n * 8)
+    E.plain_to_ntt(d_p, len(pl), d_o)
+    assert np.array_equal(E.download(d_o, (len(pl), E.k, E.n)), g["ref_plain_ntt"])
+
+
+def test_add(gs):
+    g, E = gs
+    cts = g["ct_in"]; nct = len(cts)
+    d_a = E.upload(cts); d_b = E.upload(np.roll(cts, -1, axis=0))
+    E.add(d_a, d_b, nct)
+    assert np.array_equal(E.download(d_a, cts.shape), g["ref_add"])
+
+
+def test_plain_ops(gs):
+    import crcnn_amd as ca
+    g, E = gs
+    cts, pl = g["ct_in"], g["plains"]
+    nct, npl = len(cts), len(pl)
+    d_p = E.upload(pl)
+    d_delta = E.alloc(npl * E.k * E.n * 8); d_w = E.alloc(npl * E.k * E.n * 8)
+    E.plain_to_delta(d_p, npl, ca.COEFF, d_delta); E.plain_to_ntt(d_p, npl, d_w)
+    rep = np.ascontiguousarray(np.repeat(cts[:, None], npl, axis=1))        # [nct][npl] cts; plaintext index = ct % npl -> use group=1 on a transposed view
+    # layout trick: order cts as [npl][nct] so that plaintext j is shared by `nct` consecutive cts (group = nct)
+    byp = np.ascontiguousarray(np.transpose(rep, (1, 0, 2, 3, 4)))
+    for name, fn in (("ref_add_plain", lambda d: E.add_plain(d, d_delta, nct * npl, nct, +1)),
+                     ("ref_sub_plain", lambda d: E.add_plain(d, d_delta, nct * npl, nct, -1)),
+                     ("ref_mul_plain", lambda d: E.multiply_plain(d, d_w, nct * npl, nct))):
+        d = E.upload(byp); fn(d)
+        got = np.transpose(E.download(d, byp.shape), (1, 0, 2, 3, 4))
+        assert np.array_equal(got, g[name]), name
+    # multiply_plain_ntt on NTT-form cts, then transform_from_ntt
+    d = E.upload(byp); E.ntt_fwd(d, nct * npl); E.multiply_plain_ntt(d, d_w, nct * npl, nct)
+    assert np.array_equal(np.transpose(E.download(d, byp.shape), (1, 0, 2, 3, 4)), g["ref_mul_ntt"])
+    E.ntt_inv(d, nct * npl)
+    assert np.array_equal(np.transpose(E.download(d, byp.shape), (1, 0, 2, 3, 4)), g["ref_mul"])
+
+
+def test_square_and_relinearize(gs):
+    g, E = gs
+    cts = g["ct_in"]; nct = len(cts)
+    d_x = E.upload(cts); d_evk = E.upload(g["evk"])
+    d_w = E.alloc(E.square_relin_work_bytes(nct)); d_y3 = E.alloc(nct * 3 * E.k * E.n * 8); d_y = E.alloc(cts.nbytes)
+    E.square(d_x, nct, d_y3, d_w)
+    assert np.array_equal(E.download(d_y3, (nct, 3, E.k, E.n)), g["ref_sq"])
+    E.relinearize(d_y3, nct, d_evk, d_y, d_w)
+    assert np.array_equal(E.download(d_y, cts.shape), g["ref_relin"])
+    d_y2 = E.alloc(cts.nbytes)
+    E.square_relin(d_x, nct, d_evk, d_y2, d_w)
+    assert np.array_equal(E.download(d_y2, cts.shape), g["ref_relin"])
+    assert np.array_equal(E.download(d_x, cts.shape), cts)          # input untouched
+
+
+def test_square_with_seal_made_keys(gs):
+    """SEAL's evaluation keys hold lazy (non-canonical) residues: same bits required"""
+    g, E = gs
+    cts = g["ref_enc2"]; nct = len(cts)
+    d_x = E.upload(cts); d_evk = E.upload(g["ref_evk"]); d_w = E.alloc(E.square_relin_work_bytes(nct)); d_y = E.alloc(cts.nbytes)
+    E.square_relin(d_x, nct, d_evk, d_y, d_w)
+    assert np.array_equal(E.download(d_y, cts.shape), g["ref_relin2"])
+
+
+BIG = [(4096, [0x7fffffff380001, 0x3fffffff000001], 1 << 20),
+       (8192, [0x7fffffff380001, 0x7ffffffef00001, 0x3fffffff000001], 1 << 30),
+       (16384, [0x7fffffff380001, 0x7ffffffef00001, 0x7ffffffeac0001, 0x7ffffffe700001], 1 << 30),
+       (2048, [0x3fffffff000001], 1 << 18)]
+
+
+@pytest.mark.parametrize("n,q,t", BIG, ids=[f"n{p[0]}_k{len(p[1])}" for p in BIG])
+def test_baseline_ring_sizes_vs_oracle(n, q, t):
+    """the BASELINE.json parameter sets (n=4096/k=2, n=8192/k=3, n=16384/k=4): NTT, plain ops, square+relin vs the oracle"""
+    import crcnn_amd as ca
+    from oracle import orc
+    O = orc.Oracle(n, q, t); E = ca.Engine(n, q, t, device=0)
+    sk, pk = O.keygen(5); evk = O.gen_evk(6, sk)
+    vals = np.array([0.5, -1.25, 2.75], dtype=np.float32)
+    cts = O.encrypt_many(pk, O.encode_many(vals), 50)
+    d = E.upload(cts)
+    E.ntt_fwd(d, 3)
+    want_ntt = np.stack([O.ct_to_ntt(c) for c in cts])
+    assert np.array_equal(E.download(d, cts.shape), want_ntt)
+    E.ntt_inv(d, 3)
+    assert np.array_equal(E.download(d, cts.shape), cts)
+    # edge values: all-zero and all-(q-1) polynomials survive the lazy butterflies
+    edge = np.zeros((2, 2, len(q), n), dtype=np.uint64)
+    edge[1] = (np.array(q, dtype=np.uint64) - np.uint64(1))[None, :, None]
+    de = E.upload(edge); E.ntt_fwd(de, 2)
+    assert np.array_equal(E.download(de, edge.shape), np.stack([O.ct_to_ntt(c) for c in edge]))
+    E.ntt_inv(de, 2)
+    assert np.array_equal(E.download(de, edge.shape), edge)
+    pl, _ = E.encode(np.array([0.3333, -7.0], dtype=np.float32))
+    assert np.array_equal(pl, O.encode_many(np.array([0.3333, -7.0], dtype=np.float32)))
+    d_p = E.upload(pl); d_w = E.alloc(2 * len(q) * n * 8); d_dl = E.alloc(2 * len(q) * n * 8)
+    E.plain_to_ntt(d_p, 2, d_w); E.plain_to_delta(d_p, 2, ca.COEFF, d_dl)
+    assert np.array_equal(E.download(d_w, (2, len(q), n)), O.plains_to_ntt(pl))
+    d2 = E.upload(cts[:2]); E.add_plain(d2, d_dl, 2, 1, -1); E.multiply_plain(d2, d_w, 2, 1)
+    want = np.stack([O.multiply_plain(O.sub_plain(cts[i], pl[i]), pl[i]) for i in range(2)])
+    assert np.array_equal(E.download(d2, want.shape), want)
+    d_evk = E.upload(evk); d_work = E.alloc(E.square_relin_work_bytes(3)); d_y = E.alloc(cts.nbytes)
+    E.square_relin(d, 3, d_evk, d_y, d_work)
+    got = E.download(d_y, cts.shape)
+    want = O.square_layer(cts, evk, threads=3)
+    assert np.array_equal(got, want)
+    if O.noise_budget(sk, got[1]) >= 10:
+        assert abs(O.decrypt_value(sk, got[1]) - 1.5625) < 1e-4
+    E.close()
