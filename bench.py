@@ -1,0 +1,297 @@
+#!/usr/bin/env python3
+"""bench.py -- encrypted images/sec of the CrCNN evaluation path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+
+One "step" = one pass of the hot path (Network::forward: conv/pool/[bn/square]/dense over every image) over one batch of
+`--batch` synthetic encrypted MNIST-like images per GPU.  Inputs are encrypted before the timed region and are resident in
+HBM; the encoded (NTT-form) weights are built on rank 0 and broadcast with RCCL; images are sharded across ranks (weak
+scaling, no data-path collective).  Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      achieved HBM GB/s of the dominant kernel (algorithmic bytes / measured duration) vs the 8 TB/s peak
+  cpu_baseline  the CPU oracle executing the reference's own operation order on the host cores, on a bounded sample
+  ms_per_layer  per-image milliseconds per layer (the reference's T_LAYER_i columns, mainparams.cpp:81)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+CONFIGS = {
+    # BASELINE.json configs[1]: PlainModelTiny.h5, n=4096, batch=1024 on one MI355X  (q = coeff_modulus_128(4096), t = 2^20)
+    "tiny4096": dict(model="PlainModelTiny", n=4096, k=2, t=1 << 20, batch=1024, chunk=16),
+    # configs[2]: ApproxPlainModel.h5, n=8192, 3 coeff moduli, batch=1024
+    "approx8192": dict(model="ApproxPlainModel", n=8192, k=3, t=1 << 30, batch=1024, chunk=16),
+    # configs[4]: PlainModelWoPad.h5, n=16384, 4 coeff moduli
+    "wopad16384": dict(model="PlainModelWoPad", n=16384, k=4, t=1 << 30, batch=1024, chunk=4),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--config", default="tiny4096", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None, help="encrypted images per GPU per step (default: the config's)")
+    ap.add_argument("--chunk", type=int, default=None, help="images processed per layer launch")
+    ap.add_argument("--distinct", type=int, default=4, help="distinct encrypted images (tiled to the batch on device)")
+    ap.add_argument("--mode", default="resident", choices=["resident", "layerwise"])
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target size of the CPU-baseline sample (0 = skip)")
+    return ap.parse_args()
+
+
+def plain_forward(model, W, img):
+    """float64 numpy forward of the plaintext network (PlainModel/*.py semantics) for the prediction check"""
+    from crcnn_amd.netrun import TOPOLOGIES
+    x = img.astype(np.float64)[None]
+    for kind, name, a in TOPOLOGIES[model]:
+        if kind == "conv":
+            w = W[name + ".weight"].astype(np.float64).reshape(a["nf"], a["zd"], a["xf"], a["yf"]); b = W[name + ".bias"].astype(np.float64)
+            xo, yo = (a["xd"] - a["xf"]) // a["xs"] + 1, (a["yd"] - a["yf"]) // a["ys"] + 1
+            y = np.zeros((a["nf"], xo, yo))
+            for i in range(xo):
+                for j in range(yo):
+                    patch = x[:, i * a["xs"]:i * a["xs"] + a["xf"], j * a["ys"]:j * a["ys"] + a["yf"]]
+                    y[:, i, j] = (w * patch[None]).sum(axis=(1, 2, 3)) + b
+            x = y
+        elif kind in ("pool", "avgpool"):
+            xo, yo = (a["xd"] - a["xf"]) // a["xs"] + 1, (a["yd"] - a["yf"]) // a["ys"] + 1
+            y = np.zeros((a["zd"], xo, yo))
+            for i in range(xo):
+                for j in range(yo):
+                    y[:, i, j] = x[:, i * a["xs"]:i * a["xs"] + a["xf"], j * a["ys"]:j * a["ys"] + a["yf"]].sum(axis=(1, 2))
+            x = y / (a["xf"] * a["yf"]) if kind == "avgpool" else y
+        elif kind == "bn":
+            mean = W[name + ".running_mean"].astype(np.float64); var = W[name + ".running_var"].astype(np.float64)
+            x = (x - mean[:, None, None]) / np.sqrt(var + 1e-5)[:, None, None]
+        elif kind == "square":
+            x = x * x
+        elif kind == "fc":
+            w = W[name + ".weight"].astype(np.float64).reshape(a["out_dim"], a["in_dim"]); b = W[name + ".bias"].astype(np.float64)
+            x = (w @ x.reshape(-1) + b).reshape(1, a["out_dim"], 1)
+    return x.reshape(-1)
+
+
+def cpu_baseline(cfg, q, W, x0, target_s):
+    """the CPU oracle in the reference's operation order (per-product INTT, convolutionalLayer.cpp:73-88), th_count = host
+    cores, timed on a bounded sample: conv1 restricted to as many filters as fit the time target, plus the first pooling
+    layer; extrapolated to one image by MAC count (images and output channels are independent)."""
+    from crcnn_amd.netrun import TOPOLOGIES, layer_macs
+    from oracle import orc
+    cores = os.cpu_count() or 1
+    O = orc.Oracle(cfg["n"], q, cfg["t"])
+    topo = TOPOLOGIES[cfg["model"]]
+    kind, name, a = topo[0]
+    enc = lambda v: O.encode_many(np.asarray(v, dtype=np.float32)).reshape(np.shape(v) + (O.n,))
+    w = O.plains_to_ntt(enc(W[name + ".weight"].reshape(a["nf"], a["zd"], a["xf"], a["yf"])))
+    b = enc(W[name + ".bias"])
+    # calibrate on one filter with one thread, then size the sample
+    t0 = time.time(); O.conv(x0, w, b, a["xs"], a["ys"], threads=1, f_range=(0, 1)); one = time.time() - t0
+    macs_per_filter = layer_macs(kind, a) // a["nf"]
+    nfil = int(max(1, min(a["nf"], (target_s * cores) // max(one, 1e-6))))
+    nfil = max(min(nfil, a["nf"]), min(cores, a["nf"]))
+    t0 = time.time(); y = O.conv(x0, w, b, a["xs"], a["ys"], threads=cores, f_range=(0, nfil)); t_conv = time.time() - t0
+    mac_rate = nfil * macs_per_filter / t_conv
+    total_macs = sum(layer_macs(k_, a_) for k_, _, a_ in topo)
+    # pooling / bn / square: time the first pooling layer on the channels just computed, extrapolate by ciphertext count
+    pk, pn, pa = topo[1]
+    div = O.encode(1.0 / (pa["xf"] * pa["yf"]))[0] if pk == "avgpool" else None
+    t0 = time.time(); O.pool(y[:nfil], pa["xs"], pa["ys"], pa["xf"], pa["yf"], div_plain=div, threads=cores); t_pool = time.time() - t0
+    xo, yo = (pa["xd"] - pa["xf"]) // pa["xs"] + 1, (pa["yd"] - pa["yf"]) // pa["ys"] + 1
+    pool_rate = nfil * xo * yo / max(t_pool, 1e-9)            # output cts per second (each: window adds + one multiply_plain)
+    other_cts = 0
+    for k_, _, a_ in topo:
+        if k_ in ("pool", "avgpool"):
+            other_cts += a_["zd"] * ((a_["xd"] - a_["xf"]) // a_["xs"] + 1) * ((a_["yd"] - a_["yf"]) // a_["ys"] + 1)
+    t_image = total_macs / mac_rate + (other_cts / pool_rate if pk == "avgpool" else 0.0)
+    return dict(value=1.0 / t_image, unit="encrypted images/sec", cores=cores, kind="port",
+                sample=f"oracle (reference operation order) conv1 filters 0..{nfil - 1} of {a['nf']} + pool1 on image 0: "
+                       f"{nfil * macs_per_filter} ct*pt MACs in {t_conv:.2f}s with {cores} threads; per-image time extrapolated by MAC count "
+                       f"({total_macs} MACs/image){'' if pk == 'avgpool' else '; square/bn layers not sampled'}",
+                mac_per_s=mac_rate)
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import crcnn_amd as ca
+    from crcnn_amd.netrun import Network, TOPOLOGIES, layer_macs
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = dict(CONFIGS[args.config])
+    B = args.batch or cfg["batch"]; C = min(args.chunk or cfg["chunk"], B)
+    q = ca.default_coeff_modulus_128(cfg["n"])[:cfg["k"]]
+    E = ca.Engine(cfg["n"], q, cfg["t"], device=local)
+    E.stream = torch.cuda.current_stream().cuda_stream or None
+    keep = []
+
+    def alloc(nbytes):
+        t = torch.empty((int(nbytes) + 7) // 8, dtype=torch.int64, device=dev); keep.append(t); return t
+
+    model = cfg["model"]
+    h5 = os.path.join(ROOT, "tests", "golden", "models", model + ".h5")
+    W = {nm: ca.h5_read(h5, nm) for nm in ca.h5_list(h5) if not nm.endswith("num_batches_tracked")}
+
+    # ---- keys + encrypted inputs (client side, untimed): `distinct` synthetic images encrypted on the host, tiled on device
+    t_setup = time.time()
+    sk, pk = E.keygen(2024)
+    needs_evk = any(k_ == "square" for k_, _, _ in TOPOLOGIES[model])
+    d_evk = None
+    if needs_evk:
+        evk = E.gen_evk(2025, sk)
+        d_evk = alloc(evk.nbytes); d_evk.copy_(torch.from_numpy(evk.view(np.int64)))
+    from crcnn_amd.synth import normalize, synth_image
+    D = max(1, min(args.distinct, B))
+    imgs = [normalize(synth_image(rank * 100003 + i)) for i in range(D)]
+    ctw = 2 * E.k * E.n
+    src = torch.empty((D, 784 * ctw), dtype=torch.int64, device=dev)
+    for i, im in enumerate(imgs):
+        pl, _ = E.encode(im.reshape(-1))
+        ct = E.encrypt(pk, pl, 7000 + 1000 * i)
+        src[i].copy_(torch.from_numpy(ct.reshape(-1).view(np.int64)))
+    x_all = alloc(B * 784 * ctw * 8).view(B, 784 * ctw)
+    for b0 in range(0, B, D):
+        nb = min(D, B - b0); x_all[b0:b0 + nb].copy_(src[:nb])
+    del src
+
+    # ---- encoded weights: rank 0 encodes + NTTs, RCCL broadcast to the others
+    net = Network(E, model, weights=W, alloc=alloc, resident=(args.mode == "resident"), d_evk=d_evk, materialize=(rank == 0))
+    torch.cuda.synchronize()
+    bcast_s = 0.0
+    if world > 1:
+        dist.barrier(); t0 = time.time()
+        for buf, nbytes in net.param_bufs:
+            flat = buf.view(-1)
+            step = (1 << 30) // 8
+            for o in range(0, flat.numel(), step):
+                dist.broadcast(flat[o:o + step], src=0)
+        torch.cuda.synchronize(); bcast_s = time.time() - t0
+    net.prepare(C)
+    torch.cuda.synchronize()
+    setup_s = time.time() - t_setup
+
+    nl = len(net.plan)
+    out_all = alloc(B * 10 * ctw * 8).view(B, 10 * ctw)
+    lay_ev = []
+
+    def step(record):
+        for c0 in range(0, B, C):
+            cb = min(C, B - c0)
+            evs = []
+
+            def timer(i, name, kind, phase):
+                if record:
+                    e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e)
+            d_out = net.forward(x_all[c0], cb, timer=timer)
+            E.L.crc_memcpy_d2d(E.c, out_all[c0].data_ptr(), E.p(d_out), cb * 10 * ctw * 8, E.stream)
+            if record:
+                lay_ev.append((cb, evs))
+
+    # untimed module-load pass on a single image (not a step)
+    net.forward(x_all[0], 1)
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step(s == args.steps - 1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
+
+    # ---- per-layer times of the last step (HIP events on the launch stream)
+    lay_ms = np.zeros(nl); lay_launch = np.zeros(nl); lay_cnt = np.zeros(nl)
+    for cb, evs in lay_ev:
+        for i in range(nl):
+            ms = evs[2 * i].elapsed_time(evs[2 * i + 1])
+            lay_ms[i] += ms
+            if cb == C:
+                lay_launch[i] += ms; lay_cnt[i] += 1
+    ms_per_layer = {net.plan[i][1]: round(float(lay_ms[i] / B), 4) for i in range(nl)}
+
+    # ---- verification outside the timed region: tiled images give identical outputs; decrypted logits match the plain model
+    ok_tile = all(bool(torch.equal(out_all[b], out_all[b % D])) for b in range(D, B, max(1, (B - D) // 16)))
+    outs = out_all[:D].cpu().numpy().view(np.uint64).reshape(D, 10, 2, E.k, E.n)
+    preds_ok, budgets, max_err = 0, [], 0.0
+    for i in range(D):
+        dec = E.decrypt(sk, outs[i])
+        logits = np.array([E.decode(dec[j]) for j in range(10)])
+        want = plain_forward(model, W, imgs[i])
+        budgets.append(E.noise_budget(sk, outs[i][0]))
+        max_err = max(max_err, float(np.abs(logits - want).max()))
+        preds_ok += int(np.argmax(logits) == np.argmax(want))
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel: algorithmic bytes per launch / measured duration
+    dom = int(np.argmax(lay_launch))
+    kind, name, a, p, ishape, oshape = net.plan[dom]
+    in_cts, out_cts = int(np.prod(ishape)), int(np.prod(oshape))
+    ct_bytes = 8 * E.k * E.n * 2
+    wbytes = layer_macs(kind, a) // max(1, out_cts // (a.get("nf", a.get("out_dim", 1)))) * 8 * E.k * E.n if kind in ("conv", "fc") else 0
+    if kind == "conv":
+        wbytes = a["nf"] * a["zd"] * a["xf"] * a["yf"] * 8 * E.k * E.n
+    elif kind == "fc":
+        wbytes = a["in_dim"] * a["out_dim"] * 8 * E.k * E.n
+    alg_bytes = C * (in_cts + out_cts) * ct_bytes + wbytes
+    dur_ms = lay_launch[dom] / max(1, lay_cnt[dom])
+    achieved = alg_bytes / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
+    macs_launch = layer_macs(kind, a) * C
+    roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
+                    kernel=f"mac_kernel ({name}, {C} images/launch)" if kind in ("conv", "fc") else f"{kind} ({name})",
+                    launch_ms=round(float(dur_ms), 3), algorithmic_bytes_per_launch=int(alg_bytes),
+                    modmul_per_s=round(macs_launch * 2 * E.k * E.n / (dur_ms * 1e-3), 1) if dur_ms > 0 else None)
+
+    cpu = None
+    if args.cpu_seconds > 0:
+        x0 = x_all[0].cpu().numpy().view(np.uint64).reshape(1, 28, 28, 2, E.k, E.n)
+        cpu = cpu_baseline(cfg, q, W, x0, args.cpu_seconds)
+        cpu["value"] = round(cpu["value"], 6); cpu["mac_per_s"] = round(cpu["mac_per_s"], 1)
+
+    total_images = B * world * args.steps
+    value = total_images / elapsed
+    line = {
+        "metric": "encrypted images/sec", "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": f"synthetic ({D} distinct MNIST-like encrypted images per GPU tiled to the batch; trained weights from {model}.h5)",
+        "config": {"workload": f"{model}.h5 n={cfg['n']} k={cfg['k']} t=2^{cfg['t'].bit_length() - 1} batch={B}/GPU chunk={C} ({args.config}, BASELINE configs)",
+                   "mode": args.mode, "parallelism": f"image-sharded x{world}, RCCL weight broadcast"},
+        "ms_per_layer": ms_per_layer, "roofline": roofline, "cpu_baseline": cpu,
+        "check": {"tiled_outputs_identical": bool(ok_tile), "predictions_match_plain_model": f"{preds_ok}/{D}", "max_logit_abs_err": round(max_err, 6),
+                  "noise_budget_bits": budgets},
+        "setup_s": round(setup_s, 1), "weight_broadcast_s": round(bcast_s, 2), "weight_bytes": int(net.weight_bytes),
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,219 @@
+"""Python driver for whole CrCNN networks on the engine (used by bench.py and the tests).
+
+Mirrors CnnBuilder::buildNetwork (CrCNN/src/cnnBuilder.cpp:108-179): the three hard-coded topologies, weights read from
+the HDF5 model by dataset name, every float encoded with the fractional encoder, then `Network::forward`
+(network.cpp:22-47) layer by layer over a batch of encrypted images.  All arithmetic happens in libcrcnn_hip.so; this
+file only sequences C-ABI calls and owns device buffers.  The C++ twin of this logic is crcnn_amd/host/.
+"""
+import numpy as np
+
+from . import binding
+from .binding import COEFF, NTT
+
+# (kind, name, args)  -- argument order as in the reference's build*Layer calls
+TOPOLOGIES = {
+    # cnnBuilder.cpp:157-169
+    "PlainModelTiny": [
+        ("conv", "pool1_features.conv1", dict(xd=28, yd=28, zd=1, xs=1, ys=1, xf=5, yf=5, nf=32)),
+        ("avgpool", "pool1", dict(xd=24, yd=24, zd=32, xs=2, ys=2, xf=2, yf=2)),
+        ("conv", "pool2_features.conv2", dict(xd=12, yd=12, zd=32, xs=1, ys=1, xf=5, yf=5, nf=64)),
+        ("avgpool", "pool2", dict(xd=8, yd=8, zd=64, xs=2, ys=2, xf=2, yf=2)),
+        ("fc", "classifier.fc3", dict(in_dim=1024, out_dim=512)),
+        ("fc", "classifier.fc4", dict(in_dim=512, out_dim=10)),
+    ],
+    # cnnBuilder.cpp:115-134
+    "ApproxPlainModel": [
+        ("conv", "pool1_features.conv1", dict(xd=28, yd=28, zd=1, xs=2, ys=2, xf=5, yf=5, nf=20)),
+        ("avgpool", "pool1", dict(xd=12, yd=12, zd=20, xs=1, ys=1, xf=2, yf=2)),
+        ("bn", "pool1_features.norm1", dict(ch=20)),
+        ("conv", "pool2_features.conv2", dict(xd=11, yd=11, zd=20, xs=2, ys=2, xf=3, yf=3, nf=50)),
+        ("square", "act1", dict()),
+        ("avgpool", "pool2", dict(xd=5, yd=5, zd=50, xs=1, ys=1, xf=2, yf=2)),
+        ("bn", "pool2_features.norm2", dict(ch=50)),
+        ("fc", "classifier.fc3", dict(in_dim=800, out_dim=500)),
+        ("fc", "classifier.fc4", dict(in_dim=500, out_dim=10)),
+    ],
+}
+# cnnBuilder.cpp:136-155: same as Approx with sum pooling
+TOPOLOGIES["PlainModelWoPad"] = [(("pool" if k == "avgpool" else k), n, a) for (k, n, a) in TOPOLOGIES["ApproxPlainModel"]]
+
+
+def out_shape(kind, a, in_shape):
+    if kind == "conv":
+        return (a["nf"], (a["xd"] - a["xf"]) // a["xs"] + 1, (a["yd"] - a["yf"]) // a["ys"] + 1)
+    if kind in ("pool", "avgpool"):
+        return (a["zd"], (a["xd"] - a["xf"]) // a["xs"] + 1, (a["yd"] - a["yf"]) // a["ys"] + 1)
+    if kind == "fc":
+        return (1, a["out_dim"], 1)
+    return in_shape
+
+
+def layer_macs(kind, a):
+    """ct x pt multiply-accumulates per image"""
+    if kind == "conv":
+        xo, yo = (a["xd"] - a["xf"]) // a["xs"] + 1, (a["yd"] - a["yf"]) // a["ys"] + 1
+        return a["nf"] * xo * yo * a["zd"] * a["xf"] * a["yf"]
+    if kind == "fc":
+        return a["in_dim"] * a["out_dim"]
+    return 0
+
+
+class Network:
+    """Encoded network resident in HBM.  `alloc(nbytes)` must return an object Engine.p() understands."""
+
+    def __init__(self, eng, model, h5_path=None, weights=None, alloc=None, resident=True, encode_chunk=2048, dbc=16, d_evk=None, materialize=True):
+        self.E, self.model, self.topo = eng, model, TOPOLOGIES[model]
+        self.alloc = alloc or eng.alloc
+        self.resident = resident            # keep tensors NTT-resident between layers (bit-identical)
+        self.dbc, self.d_evk = dbc, d_evk
+        self.materialize = materialize      # False: only allocate parameter buffers (they are filled by an RCCL broadcast)
+        self.param_bufs = []                # every parameter buffer in a deterministic order: (buffer, nbytes)
+        self.weight_bytes = 0
+        get = (lambda nm: np.asarray(weights[nm], dtype=np.float32)) if weights is not None else (lambda nm: binding.h5_read(h5_path, nm))
+        self._keep = []
+        mid_form = NTT if resident else COEFF
+        shape = (1, 28, 28)
+        form = COEFF
+        self.plan = []
+        for li, (kind, name, a) in enumerate(self.topo):
+            p = {}
+            last = li == len(self.topo) - 1
+            if kind in ("conv", "fc"):
+                out_form = COEFF if (last or not resident) else NTT
+                nxt = self.topo[li + 1][0] if not last else None
+                if nxt == "square":
+                    out_form = COEFF       # Square works on coefficient form (BEHZ base conversions)
+                p["w"] = self._encode_ntt(get(name + ".weight"), encode_chunk)
+                p["b"] = self._delta(get(name + ".bias"), out_form)
+                p["in_form"], p["out_form"] = form, out_form
+                form = out_form
+            elif kind in ("pool", "avgpool"):
+                p["div"] = self._encode_ntt(np.array([1.0 / (a["xf"] * a["yf"])], dtype=np.float64), encode_chunk, dtype=np.float64) if kind == "avgpool" else None
+                p["form"] = form
+            elif kind == "bn":
+                mean = get(name + ".running_mean"); var = get(name + ".running_var")
+                invstd = np.float32(1.0 / np.sqrt(var.astype(np.float64) + 0.00001))       # cnnBuilder.cpp:100-102
+                p["mean"] = self._delta(mean, form); p["invstd"] = self._encode_ntt(invstd, encode_chunk); p["form"] = form
+            elif kind == "square":
+                if form != COEFF:
+                    raise RuntimeError("square needs coefficient form input")
+                p["form"] = COEFF
+                p["to_ntt"] = resident          # go back to NTT residency right after the relinearisation
+                form = NTT if resident else COEFF
+            nshape = out_shape(kind, a, shape)
+            self.plan.append((kind, name, a, p, shape, nshape))
+            shape = nshape
+        self.out_shape = shape
+        self.out_form = form
+
+    # ---- parameter upload
+    def _encode_ntt(self, vals, chunk, dtype=np.float32):
+        E = self.E
+        vals = np.ascontiguousarray(np.asarray(vals, dtype=dtype).reshape(-1))
+        out = self.alloc(vals.size * E.k * E.n * 8)
+        self.weight_bytes += vals.size * E.k * E.n * 8
+        self.param_bufs.append((out, vals.size * E.k * E.n * 8))
+        if not self.materialize:
+            return out
+        stage = self.alloc(min(chunk, vals.size) * E.n * 8)
+        for o in range(0, vals.size, chunk):
+            pl, _ = E.encode(vals[o:o + chunk], dtype=dtype)
+            E.L.crc_memcpy_h2d(E.c, E.p(stage), pl.ctypes.data, pl.nbytes, E.stream)
+            E.plain_to_ntt(stage, len(pl), E.p(out) + o * E.k * E.n * 8)
+            E.sync()
+        return out
+
+    def _delta(self, vals, form):
+        E = self.E
+        pl, _ = E.encode(np.asarray(vals, dtype=np.float32))
+        out = self.alloc(len(pl) * E.k * E.n * 8)
+        self.weight_bytes += len(pl) * E.k * E.n * 8
+        self.param_bufs.append((out, len(pl) * E.k * E.n * 8))
+        if not self.materialize:
+            return out
+        d_p = self.alloc(pl.nbytes)
+        E.L.crc_memcpy_h2d(E.c, E.p(d_p), pl.ctypes.data, pl.nbytes, E.stream)
+        E.plain_to_delta(d_p, len(pl), form, out)
+        E.sync()
+        return out
+
+    # ---- sizes
+    def ct_bytes(self):
+        return 2 * self.E.k * self.E.n * 8
+
+    def activation_cts(self):
+        """ciphertexts per image at every layer boundary"""
+        return [int(np.prod(s)) for (_, _, _, _, s, _) in self.plan] + [int(np.prod(self.out_shape))]
+
+    def scratch_bytes(self, B):
+        E = self.E
+        acts = self.activation_cts()
+        # two ping-pong activation buffers + the largest layer work buffer
+        big = sorted(acts, reverse=True)
+        need_act = (big[0] + big[1]) * B * self.ct_bytes()
+        work = 0
+        for (kind, name, a, p, ishape, oshape) in self.plan:
+            if kind == "conv":
+                work = max(work, E.conv2d_work_bytes(B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"], p["in_form"]))
+            elif kind == "fc":
+                work = max(work, E.dense_work_bytes(B, a["in_dim"], a["out_dim"], p["in_form"]))
+            elif kind == "square":
+                work = max(work, E.square_relin_work_bytes(B * int(np.prod(ishape)), self.dbc))
+        return need_act, work
+
+    def _slots(self):
+        """ping-pong slot of every layer's output (in-place layers keep their input's slot); -1 = caller's input"""
+        slots, cur = [], -1
+        for (kind, *_rest) in self.plan:
+            if kind == "bn" and cur >= 0:
+                slots.append(cur)
+            else:
+                cur = 0 if cur != 0 else 1
+                slots.append(cur)
+        return slots
+
+    def prepare(self, B):
+        """allocate the two ping-pong activation buffers and the work space for chunks of B images"""
+        acts = self.activation_cts()
+        self.B = B
+        self.slots = self._slots()
+        size = [1, 1]
+        for i, sl in enumerate(self.slots):
+            size[sl] = max(size[sl], acts[i + 1])
+        self.buf = [self.alloc(size[0] * B * self.ct_bytes()), self.alloc(size[1] * B * self.ct_bytes())]
+        self.act_bytes = (size[0] + size[1]) * B * self.ct_bytes()
+        _, work = self.scratch_bytes(B)
+        self.work = self.alloc(max(work, 256))
+        self.work_bytes = max(work, 256)
+
+    # ---- forward over one chunk of B images; d_x: [B][1][28][28] cts in coefficient form.  Returns device ptr of the
+    # [B][10] output cts (coefficient form).  `timer(i, name)` (optional) is called around every layer.
+    def forward(self, d_x, B, timer=None):
+        E = self.E
+        cur = d_x
+        for i, (kind, name, a, p, ishape, oshape) in enumerate(self.plan):
+            out = self.buf[self.slots[i]]
+            if timer:
+                timer(i, name, kind, 0)
+            if kind == "conv":
+                E.conv2d(cur, p["w"], p["b"], B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"], p["in_form"], p["out_form"], out, self.work)
+                cur = out
+            elif kind == "fc":
+                E.dense(cur, p["w"], p["b"], B, a["in_dim"], a["out_dim"], p["in_form"], p["out_form"], out, self.work)
+                cur = out
+            elif kind in ("pool", "avgpool"):
+                E.pool(cur, B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], p["div"], p["form"], out)
+                cur = out
+            elif kind == "bn":
+                if E.p(cur) != E.p(out):     # first layer: never modify the caller's input in place
+                    E.L.crc_memcpy_d2d(E.c, E.p(out), E.p(cur), B * int(np.prod(ishape)) * self.ct_bytes(), E.stream)
+                    cur = out
+                E.batchnorm(cur, B, ishape[0], ishape[1], ishape[2], p["mean"], p["invstd"], p["form"])
+            elif kind == "square":
+                E.square_relin(cur, B * int(np.prod(ishape)), self.d_evk, out, self.work, self.dbc)
+                cur = out
+                if p["to_ntt"]:
+                    E.ntt_fwd(cur, B * int(np.prod(ishape)))
+            if timer:
+                timer(i, name, kind, 1)
+        return cur

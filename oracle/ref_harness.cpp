@@ -366,12 +366,19 @@ static int do_net()
     auto evkv = rd("evk.u64", false);
     if (!evkv.empty()) { ev_keys16 = new EvaluationKeys(); load_evk(evkv, 16, *ev_keys16); }
     ifstream topo(DIR + "/topology.txt");
+    struct Sl { string name; int in, out, th, slices; };
+    map<int, Sl> sliced;
     Network net; string kind, name;
     while (topo >> kind >> name) {
         if (kind == "conv") { int xd, yd, zd, xs, ys, xf, yf, nf, th; topo >> xd >> yd >> zd >> xs >> ys >> xf >> yf >> nf >> th;
             net.getLayers().push_back(shared_ptr<Layer>(make_conv(name, xd, yd, zd, xs, ys, xf, yf, nf, th, rdf(name + ".weight.f64"), rdf(name + ".bias.f64")))); }
         else if (kind == "fc") { int in, out, th; topo >> in >> out >> th;
             net.getLayers().push_back(shared_ptr<Layer>(make_fc(name, in, out, th, rdf(name + ".weight.f64"), rdf(name + ".bias.f64")))); }
+        else if (kind == "fcs") {   // the same FullyConnectedLayer, built and run in row slices so that the reference's k*(n+1)-word
+                                    // NTT-form weight Plaintexts (fullyConnectedLayer.cpp:129-131) fit in host RAM; rows are independent
+            int in, out, th, slices; topo >> in >> out >> th >> slices;
+            sliced[(int)net.getLayers().size()] = {name, in, out, th, slices};
+            net.getLayers().push_back(shared_ptr<Layer>(nullptr)); }
         else if (kind == "pool" || kind == "avgpool") { int xd, yd, zd, xs, ys, xf, yf; topo >> xd >> yd >> zd >> xs >> ys >> xf >> yf;
             if (kind == "pool") net.getLayers().push_back(shared_ptr<Layer>(new PoolingLayer(name, xd, yd, zd, xs, ys, xf, yf)));
             else net.getLayers().push_back(shared_ptr<Layer>(new AvgPoolingLayer(name, xd, yd, zd, xs, ys, xf, yf))); }
@@ -386,14 +393,40 @@ static int do_net()
     // Network::forward (network.cpp:22-47) without the client-side refresh (needs the secret key)
     for (int i = 0; i < net.getNumLayers(); i++) {
         auto t0 = chrono::high_resolution_clock::now();
-        t = net.getLayer(i)->forward(t);
+        string lname;
+        if (sliced.count(i)) {
+            const Sl &sl = sliced[i]; lname = sl.name;
+            auto w = rdf(sl.name + ".weight.f64"), b = rdf(sl.name + ".bias.f64");
+            ciphertext3D res(1, ciphertext2D(sl.out, vector<Ciphertext>(1)));
+            int per = (sl.out + sl.slices - 1) / sl.slices;
+            for (int r0 = 0; r0 < sl.out; r0 += per) {
+                int r1 = min(sl.out, r0 + per);
+                vector<double> ws(w.begin() + (size_t)r0 * sl.in, w.begin() + (size_t)r1 * sl.in), bs(b.begin() + r0, b.begin() + r1);
+                unique_ptr<FullyConnectedLayer> l(make_fc(sl.name, sl.in, r1 - r0, min(sl.th, r1 - r0), ws, bs));
+                ciphertext3D part = l->forward(t);
+                for (int r = r0; r < r1; r++) res[0][r][0] = part[0][r - r0][0];
+                fprintf(stderr, "  rows %d..%d done\n", r0, r1);
+            }
+            t = res;
+        } else { lname = net.getLayer(i)->getName(); t = net.getLayer(i)->forward(t); }
         auto t1 = chrono::high_resolution_clock::now();
         string d = digest(t);
-        dg << i << " " << net.getLayer(i)->getName() << " " << t.size() << "x" << t[0].size() << "x" << t[0][0].size() << " " << d << " "
+        dg << i << " " << lname << " " << t.size() << "x" << t[0].size() << "x" << t[0][0].size() << " " << d << " "
            << chrono::duration_cast<chrono::microseconds>(t1 - t0).count() << "us" << endl;
         fprintf(stderr, "layer %d done\n", i);
     }
     vector<u64> out; from_tensor(t, out); wr("ref_net_out.u64", out);
+    auto skv = rd("sk.u64", false);
+    if (!skv.empty()) {      // client side of the reference: decrypt + decode the logits, report the remaining noise budget
+        SecretKey sk = load_sk(skv); Decryptor dec(*context, sk);
+        vector<u64> pl, logits, bud;
+        for (auto &a : t) for (auto &b : a) for (auto &c : b) {
+            Plaintext p; dec.decrypt(c, p); from_plain(p, pl, N);
+            double v = fraencoder->decode(p); u64 bits; memcpy(&bits, &v, 8); logits.push_back(bits);
+            bud.push_back(dec.invariant_noise_budget(c));
+        }
+        wr("ref_net_dec.u64", pl); wr("ref_net_logits.u64", logits); wr("ref_net_budget.u64", bud);
+    }
     return 0;
 }
 

@@ -1,0 +1,58 @@
+"""shared helpers for the whole-network parity tests (oracle side: input generation and the reference-order forward)"""
+import hashlib
+import json
+import os
+
+import numpy as np
+
+from oracle import orc
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load_net_golden(name):
+    return json.load(open(os.path.join(GOLD, f"net_{name}.json")))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def make_inputs(g):
+    """regenerate keys + the encrypted synthetic image exactly as oracle/make_golden_nets.py did"""
+    O = orc.Oracle(g["n"], g["q"], g["t"])
+    sk, pk = O.keygen(g["key_seed"]); evk = O.gen_evk(g["evk_seed"], sk)
+    img = orc.normalize(orc.synth_image(g["image_index"]))
+    x = O.encrypt_many(pk, O.encode_many(img).reshape(1, 28, 28, O.n), g["enc_seed"])
+    assert sha(x) == g["input_sha256"], "oracle input generation drifted from the golden"
+    return O, sk, pk, evk, img, x
+
+
+def model_weights(model):
+    import crcnn_amd as ca
+    path = os.path.join(GOLD, "models", model + ".h5")
+    return {nm: ca.h5_read(path, nm) for nm in ca.h5_list(path) if not nm.endswith("num_batches_tracked")}
+
+
+def oracle_forward(O, model, W, x, evk, threads=8, fast=True):
+    """Network::forward with the oracle's reference-order layer loops; yields (layer index, output tensor)"""
+    from crcnn_amd.netrun import TOPOLOGIES
+    enc = lambda a: O.encode_many(np.asarray(a, dtype=np.float32)).reshape(np.shape(a) + (O.n,))
+    t = x
+    for i, (kind, name, a) in enumerate(TOPOLOGIES[model]):
+        if kind == "conv":
+            w = O.plains_to_ntt(enc(W[name + ".weight"].reshape(a["nf"], a["zd"], a["xf"], a["yf"])))
+            t = O.conv(t, w, enc(W[name + ".bias"]), a["xs"], a["ys"], threads=threads, fast=fast)
+        elif kind == "fc":
+            w = O.plains_to_ntt(enc(W[name + ".weight"].reshape(a["out_dim"], a["in_dim"], 1, 1)))
+            flat = np.ascontiguousarray(t).reshape(a["in_dim"], 1, 1, 2, O.k, O.n)
+            t = O.conv(flat, w, enc(W[name + ".bias"]), 1, 1, threads=threads, fast=fast).reshape(1, a["out_dim"], 1, 2, O.k, O.n)
+        elif kind in ("pool", "avgpool"):
+            div = O.encode(1.0 / (a["xf"] * a["yf"]))[0] if kind == "avgpool" else None
+            t = O.pool(t, a["xs"], a["ys"], a["xf"], a["yf"], div_plain=div, threads=threads)
+        elif kind == "bn":
+            invstd = np.float32(1.0 / np.sqrt(W[name + ".running_var"].astype(np.float64) + 0.00001))
+            t = O.bn(t, enc(W[name + ".running_mean"]), enc(invstd), threads=threads)
+        elif kind == "square":
+            t = O.square_layer(t, evk, threads=threads)
+        yield i, t

@@ -1,0 +1,60 @@
+"""GPU parity, whole networks: the real CrCNN models (real weights from the HDF5 files, one synthetic encrypted image)
+through the engine, per-layer SHA-256 against what the compiled reference's Network::forward produced
+(tests/golden/net_*.json, oracle/make_golden_nets.py) -- at n=256 for all three topologies and at the BASELINE.json
+parameter sets (Tiny n=4096 k=2, Approx n=8192 k=3, WoPad n=16384 k=4) when their goldens are present."""
+import os
+
+import numpy as np
+import pytest
+
+from netcommon import GOLD, load_net_golden, make_inputs, sha
+
+pytestmark = pytest.mark.gpu
+
+NAMES = [n for n in ["tiny256", "approx256", "wopad256", "tiny4096", "approx8192", "wopad16384"]
+         if os.path.exists(os.path.join(GOLD, f"net_{n}.json"))]
+
+
+def run_net(name, resident, batch=1):
+    import crcnn_amd as ca
+    from crcnn_amd.netrun import Network
+    g = load_net_golden(name)
+    O, sk, pk, evk, img, x = make_inputs(g)
+    E = ca.Engine(g["n"], g["q"], g["t"], device=0)
+    d_evk = E.upload(evk)
+    net = Network(E, g["model"], h5_path=os.path.join(GOLD, "models", g["model"] + ".h5"), resident=resident, d_evk=d_evk)
+    net.prepare(batch)
+    xb = np.ascontiguousarray(np.repeat(x[None], batch, axis=0))
+    d_x = E.upload(xb)
+    digests = {}
+
+    def timer(i, lname, kind, phase):
+        if phase == 1 and not resident:      # coefficient form between layers: the reference's own layer boundary
+            oshape = net.plan[i][5]
+            t = E.download(net.buf[net.slots[i]], (batch,) + tuple(oshape) + (2, E.k, E.n))
+            digests[i] = [sha(t[b]) for b in range(batch)]
+
+    d_out = net.forward(d_x, batch, timer=timer)
+    out = E.download(d_out, (batch, 1, 10, 1, 2, E.k, E.n))
+    E.close()
+    return g, O, sk, out, digests
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_layerwise_digests_match_reference(name):
+    """coefficient form in/out of every layer, exactly the reference's Layer::forward contract"""
+    g, O, sk, out, digests = run_net(name, resident=False)
+    for i, L in enumerate(g["layers"]):
+        assert digests[i][0] == L["sha256"], (name, i, L["name"])
+    assert sha(out[0]) == g["out_sha256"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_ntt_resident_network_matches_reference(name):
+    """NTT-resident pipeline (one INTT at the end / around Square), batch of 2: same final ciphertext bits"""
+    g, O, sk, out, _ = run_net(name, resident=True, batch=2)
+    assert sha(out[0]) == g["out_sha256"] and sha(out[1]) == g["out_sha256"]
+    if g["n"] >= 4096:       # real parameter sets: the decrypted logits are the reference's logits
+        got = [O.decrypt_value(sk, out[0, 0, j, 0]) for j in range(10)]
+        assert got == g["logits"]
+        assert [O.noise_budget(sk, out[0, 0, j, 0]) for j in range(3)] == g["budget"][:3]
