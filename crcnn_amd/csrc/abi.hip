@@ -104,7 +104,7 @@ extern "C" int crc_conv2d(crc_ctx *c, const uint64_t *d_x, const uint64_t *d_w, 
         xn = buf;
     }
     // sum of products in the NTT domain; bias joins here when the output stays NTT-resident
-    RUN(k_mac(c, xn, d_w, d_y, xoff, toff, B, P, nf, T, in_cts, out_form == CRC_NTT ? d_bias : nullptr, st));
+    RUN(k_mac2(c, xn, d_w, d_y, xoff, toff, B, P, nf, T, in_cts, out_form == CRC_NTT ? d_bias : nullptr, xd, yd, xf, yf, st));
     if (out_form == CRC_COEFF)                    // one inverse NTT per output ciphertext, add_plain(bias) fused into its store
         RUN(k_ntt_ct(c, true, d_y, d_y, (size_t)B * nf * P, 2, false, st, d_bias, 1, (size_t)P, nf));
     return CRC_OK;

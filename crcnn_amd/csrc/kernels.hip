@@ -316,6 +316,7 @@ struct MacArgs {
     const int *xoff; const int *toff;        // device tables: output pixel -> base ct index, term -> ct offset
     int n, k, B, P, F, T, in_cts;            // P output pixels per image, in_cts input cts per image
     const u64 *bias; int bias_sign;          // optional NTT-form delta bias [F][k][n] added to poly 0
+    int gxd, gyd, gxf, gyf;                  // window geometry: toff[t] = (z*gxd + kx)*gyd + ky for t = (z*gxf + kx)*gyf + ky
 };
 
 template <int PT, int FT>
@@ -407,4 +408,203 @@ int k_mac(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, con
     hipLaunchKernelGGL((mac_kernel<PT, FT>), grid, dim3(threads), 0, st, a);
     HIPCHK(hipGetLastError());
     return CRC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// mac2: the production ct x pt multiply-accumulate kernel (moduli up to 55 bits; wider ones take mac_kernel above).
+//
+// Arithmetic.  gfx950 has no 64x64 multiplier; v_mad_u64_u32 (32x32+64) issues at quarter rate (measured 17.3 T/s,
+// profiles/r01_microbench_valu.txt) and is the roofline of this kernel.  Operands are split into 28-bit limbs
+// x = x1*2^28 + x0 (x1 < 2^27 for q < 2^55) and products are formed Karatsuba-style with THREE mads per MAC:
+//     A0 += x0*w0     A2 += x1*w1     A1 += (x0+x1)*(w0+w1)          (each term < 2^57.2, carry-free for 32 terms)
+// Every 32 terms the top bit of each 64-bit accumulator is moved into a packed overflow counter, so the sum over up to
+// 2^15 terms is exact; one 128-bit recombination  V = A0 + (A1-A0-A2)*2^28 + A2*2^56  and ONE Barrett reduction per
+// output give the canonical residue -- the same element of Z_q as the reference's per-product reductions.
+//
+// Data movement.  A 512-thread workgroup owns 64 consecutive slots of one residue and a (2*PX*WM rows) x (FT*WN filters)
+// output tile; lane = slot, the 8 waves form a WM x WN grid of PX*2 x FT register tiles.  Per reduction step the
+// workgroup needs only 2*PX*WM + FT*WN operand vectors (512 B each); they are fetched once (coalesced 8 B/lane),
+// double-buffered through LDS (S steps per stage, one barrier per stage) and re-read by the waves that share them.
+// Workgroups are numbered so that the 32 CUs of an XCD work on the same slot block and neighbouring tiles at the same
+// time: their shared operands are served by that XCD's L2 instead of HBM.
+// ---------------------------------------------------------------------------------------------------------------
+template <int PX, int FT, int WM, int WN, int S>
+__global__ void __launch_bounds__(64 * WM * WN) mac2_kernel(MacArgs a)
+{
+    constexpr int NW = WM * WN, MT = PX * WM, ROWS = 2 * MT, FW = FT * WN;
+    constexpr int VEC = S * (ROWS + FW), RLOAD = (VEC + NW - 1) / NW;
+    constexpr u64 MASK28 = (1ULL << 28) - 1;
+    extern __shared__ u64 smem[];                     // 2 x [S][ROWS + FW][64]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave / WN, wn = wave % WN;
+    const int n = a.n, k = a.k;
+    const int M = a.B * a.P;
+    const int mtiles = (M + MT - 1) / MT, ftiles = (a.F + FW - 1) / FW, sbt = (n >> 6) * k;
+    // XCD-aware decode: consecutive workgroup ids go to different XCDs (round-robin dispatch), so give every XCD its own
+    // slot blocks and walk (f tile fastest, then m tile) inside one slot block
+    int g = blockIdx.x, sb, tile;
+    if ((sbt & 7) == 0) { const int xcd = g & 7, r = g >> 3, per = sbt >> 3; sb = xcd * per + r / (mtiles * ftiles); tile = r % (mtiles * ftiles); }
+    else { sb = g / (mtiles * ftiles); tile = g % (mtiles * ftiles); }
+    const int ft = tile % ftiles, mt = tile / ftiles;
+    const int i = sb / (n >> 6), s = ((sb % (n >> 6)) << 6) + lane;
+    const int m0 = mt * MT, f0 = ft * FW;
+    const size_t rown = (size_t)i * n + s, kn = (size_t)k * n, ctw = 2 * kn;
+    const ModParams m = a.mods[i];
+
+    // wave-uniform base pointer of every operand vector this wave stages (kept in SGPRs; lanes add (i*n+s)*8)
+    const u64 *vbase[RLOAD]; int vstep[RLOAD]; bool visx[RLOAD];
+#pragma unroll
+    for (int j = 0; j < RLOAD; j++) {
+        const int v = wave + j * NW;
+        const int vv = min(v, VEC - 1);                  // surplus slots (VEC not a multiple of NW) re-load the last vector, never stored
+        const int e = vv % (ROWS + FW);
+        vstep[j] = vv / (ROWS + FW);
+        if (e < ROWS) {
+            const int mm = min(m0 + (e >> 1), M - 1), b = mm / a.P, p = mm % a.P;
+            vbase[j] = a.x + ((size_t)b * a.in_cts + a.xoff[p]) * ctw + (size_t)(e & 1) * kn; visx[j] = true;
+        } else {
+            const int f = min(f0 + (e - ROWS), a.F - 1);     // filters past F are computed on a clamped copy and never stored
+            vbase[j] = a.w + (size_t)f * a.T * kn; visx[j] = false;
+        }
+    }
+
+    u64 A0[PX * 2][FT], A1[PX * 2][FT], A2[PX * 2][FT]; u32 OV[PX * 2][FT];
+#pragma unroll
+    for (int r = 0; r < PX * 2; r++)
+#pragma unroll
+        for (int f = 0; f < FT; f++) { A0[r][f] = 0; A1[r][f] = 0; A2[r][f] = 0; OV[r][f] = 0; }
+
+    const int nstages = (a.T + S - 1) / S;
+    u64 stage_reg[RLOAD];
+    // reduction-term walker, all scalar: (tz, tkx, tky) = coordinates of term st*S; toff derived without touching memory
+    int tz = 0, tkx = 0, tky = 0;
+    auto load_stage = [&](int st) {
+        int toffs[S];
+        {
+            int z = tz, kx = tkx, ky = tky;
+#pragma unroll
+            for (int q = 0; q < S; q++) {
+                toffs[q] = (min(z, a.T / (a.gxf * a.gyf) - 1) * a.gxd + kx) * a.gyd + ky;      // clamped past the end (weights are zeroed there)
+                if (++ky == a.gyf) { ky = 0; if (++kx == a.gxf) { kx = 0; z++; } }
+            }
+            tz = z; tkx = kx; tky = ky;
+        }
+#pragma unroll
+        for (int j = 0; j < RLOAD; j++) {
+            int t = st * S + vstep[j];
+            int to = toffs[0];
+#pragma unroll
+            for (int q = 1; q < S; q++) to = vstep[j] == q ? toffs[q] : to;
+            const bool live = t < a.T;
+            t = live ? t : a.T - 1;
+            const u64 *ptr = visx[j] ? vbase[j] + (size_t)to * ctw : vbase[j] + (size_t)t * kn;
+            stage_reg[j] = ptr[(u32)rown];          // consumed only in store_stage: no wait here, the loads stay in flight during the compute phase
+        }
+    };
+    auto store_stage = [&](int st) {
+        u64 *dst = smem + (size_t)(st & 1) * VEC * 64;
+#pragma unroll
+        for (int j = 0; j < RLOAD; j++) {
+            const int v = wave + j * NW;
+            const bool dead = !visx[j] && st * S + vstep[j] >= a.T;     // weights past the last term are zero (x may be anything valid)
+            if (v < VEC) dst[v * 64 + lane] = dead ? 0 : stage_reg[j];
+        }
+    };
+
+    load_stage(0); store_stage(0);
+    __syncthreads();
+    for (int st = 0; st < nstages; st++) {
+        if (st + 1 < nstages) load_stage(st + 1);
+        const u64 *buf = smem + (size_t)(st & 1) * VEC * 64;
+#pragma unroll 1
+        for (int step = 0; step < S; step++) {
+            const u64 *sv = buf + step * (ROWS + FW) * 64 + lane;
+            u32 w0[FT], w1[FT], ws[FT];
+#pragma unroll
+            for (int f = 0; f < FT; f++) { const u64 wv = sv[(ROWS + wn * FT + f) * 64]; w0[f] = (u32)(wv & MASK28); w1[f] = (u32)(wv >> 28); ws[f] = w0[f] + w1[f]; }
+#pragma unroll
+            for (int r = 0; r < PX * 2; r++) {
+                const u64 xv = sv[(wm * PX * 2 + r) * 64];
+                const u32 x0 = (u32)(xv & MASK28), x1 = (u32)(xv >> 28), xs = x0 + x1;
+#pragma unroll
+                for (int f = 0; f < FT; f++) {
+                    A0[r][f] += (u64)x0 * w0[f];
+                    A2[r][f] += (u64)x1 * w1[f];
+                    A1[r][f] += (u64)xs * ws[f];
+                }
+            }
+        }
+        if ((((st + 1) * S) & 31) < S) {              // every 32 reduction steps: park bit 63 of each accumulator in the overflow word
+#pragma unroll
+            for (int r = 0; r < PX * 2; r++)
+#pragma unroll
+                for (int f = 0; f < FT; f++) {
+                    OV[r][f] += (u32)(A0[r][f] >> 63) + ((u32)(A1[r][f] >> 63) << 10) + ((u32)(A2[r][f] >> 63) << 20);
+                    A0[r][f] &= ~(1ULL << 63); A1[r][f] &= ~(1ULL << 63); A2[r][f] &= ~(1ULL << 63);
+                }
+        }
+        if (st + 1 < nstages) store_stage(st + 1);
+        __syncthreads();
+    }
+
+    // recombine (mod 2^128, exact because the true sum is < 2^128), reduce once, add the bias, store
+#pragma unroll
+    for (int r = 0; r < PX * 2; r++) {
+        const int mm = m0 + wm * PX + (r >> 1), c = r & 1;
+        if (mm >= M) continue;
+        const int b = mm / a.P, p = mm % a.P;
+#pragma unroll
+        for (int f = 0; f < FT; f++) {
+            const int ff = f0 + wn * FT + f;
+            if (ff >= a.F) continue;
+            const u32 ov = OV[r][f];
+            // a_j = A_j + ov_j * 2^63  as (lo, hi)
+            u64 o0 = ov & 1023, o1 = (ov >> 10) & 1023, o2 = (ov >> 20) & 1023;
+            u64 a0l = A0[r][f] + (o0 << 63), a0h = (o0 >> 1) + (a0l < A0[r][f]);
+            u64 a1l = A1[r][f] + (o1 << 63), a1h = (o1 >> 1) + (a1l < A1[r][f]);
+            u64 a2l = A2[r][f] + (o2 << 63), a2h = (o2 >> 1) + (a2l < A2[r][f]);
+            // mid = a1 - a0 - a2
+            u64 ml = a1l - a0l, mh = a1h - a0h - (a1l < a0l);
+            u64 ml2 = ml - a2l; mh = mh - a2h - (ml < a2l); ml = ml2;
+            // V = a0 + mid << 28 + a2 << 56
+            u64 vl = a0l, vh = a0h;
+            u64 tl = ml << 28, th = (mh << 28) | (ml >> 36);
+            u64 nl = vl + tl; vh += th + (nl < vl); vl = nl;
+            tl = a2l << 56; th = (a2h << 56) | (a2l >> 8);
+            nl = vl + tl; vh += th + (nl < vl); vl = nl;
+            u64 v = barrett128(vl, vh, m);
+            if (c == 0 && a.bias) { const u64 bv = a.bias[(size_t)ff * kn + rown]; v = addmod(v, bv, m.q); }
+            a.y[(((size_t)b * a.F + ff) * a.P + p) * ctw + (size_t)c * kn + rown] = v;
+        }
+    }
+}
+
+template <int PX, int FT, int WM, int WN, int S>
+static int mac2_launch(crc_ctx *c, MacArgs &a, hipStream_t st)
+{
+    constexpr int MT = PX * WM, FW = FT * WN, VEC = S * (2 * MT + FW);
+    const int M = a.B * a.P;
+    const size_t grid = (size_t)((M + MT - 1) / MT) * ((a.F + FW - 1) / FW) * (size_t)((c->n >> 6) * c->k);
+    if (grid > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
+    const size_t lds = (size_t)2 * VEC * 64 * 8;
+    auto kern = mac2_kernel<PX, FT, WM, WN, S>;
+    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WM * WN), lds, st, a);
+    HIPCHK(hipGetLastError());
+    return CRC_OK;
+}
+
+int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, const int *d_toff, int B, int P, int F, int T, int in_cts,
+           const u64 *bias_ntt, int gxd, int gyd, int gxf, int gyf, hipStream_t st)
+{
+    if (B == 0 || P == 0 || F == 0) return CRC_OK;
+    int maxbits = 0; for (int i = 0; i < c->k; i++) if ((int)c->tabs[i].m.bits > maxbits) maxbits = c->tabs[i].m.bits;
+    if (maxbits > 55 || T > 32768 || c->n < 64) return k_mac(c, x, w, y, d_xoff, d_toff, B, P, F, T, in_cts, bias_ntt, st);
+    MacArgs a{};
+    a.x = x; a.w = w; a.y = y; a.mods = c->d_mods; a.xoff = d_xoff; a.toff = d_toff;
+    a.n = c->n; a.k = c->k; a.B = B; a.P = P; a.F = F; a.T = T; a.in_cts = in_cts; a.bias = bias_ntt; a.bias_sign = 1;
+    a.gxd = gxd; a.gyd = gyd; a.gxf = gxf; a.gyf = gyf;
+#ifndef MAC2_CFG
+#define MAC2_CFG 3, 4, 2, 4, 2
+#endif
+    return mac2_launch<MAC2_CFG>(c, a, st);
 }

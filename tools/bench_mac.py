@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Time one layer's ct x pt MAC launch on random residues (kernel-only view of the dominant kernel).
+usage: python tools/bench_mac.py [conv2|conv1|fc3] [B] [reps]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import crcnn_amd as ca
+
+layer = sys.argv[1] if len(sys.argv) > 1 else "conv2"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+n, k, t = 4096, 2, 1 << 20
+geo = {"conv2": dict(zd=32, xd=12, yd=12, xs=1, ys=1, xf=5, yf=5, nf=64), "conv1": dict(zd=1, xd=28, yd=28, xs=1, ys=1, xf=5, yf=5, nf=32),
+       "fc3": dict(zd=1024, xd=1, yd=1, xs=1, ys=1, xf=1, yf=1, nf=512), "fc4": dict(zd=512, xd=1, yd=1, xs=1, ys=1, xf=1, yf=1, nf=10)}[layer]
+q = ca.default_coeff_modulus_128(n)[:k]
+E = ca.Engine(n, q, t, device=0)
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev); g.manual_seed(1)
+def rnd(cts_rows):   # rows of n residues, row r mod k -> modulus
+    out = torch.empty((cts_rows, n), dtype=torch.int64, device=dev)
+    for i in range(k):
+        out[i::k] = torch.randint(0, q[i], (len(range(i, cts_rows, k)), n), dtype=torch.int64, device=dev, generator=g)
+    return out
+a = geo
+xo, yo = (a["xd"] - a["xf"]) // a["xs"] + 1, (a["yd"] - a["yf"]) // a["ys"] + 1
+in_cts, out_cts, T = a["zd"] * a["xd"] * a["yd"], a["nf"] * xo * yo, a["zd"] * a["xf"] * a["yf"]
+x = rnd(B * in_cts * 2 * k); w = rnd(a["nf"] * T * k); bias = rnd(a["nf"] * k)
+y = torch.empty((B * out_cts * 2 * k, n), dtype=torch.int64, device=dev)
+work = torch.empty(E.conv2d_work_bytes(B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"], ca.NTT) // 8 + 64, dtype=torch.int64, device=dev)
+def run():
+    E.conv2d(x, w, bias, B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"], ca.NTT, ca.NTT, y, work)
+run(); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps): run()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / reps
+macs = B * out_cts * T
+print(f"{layer} B={B}: {ms:.2f} ms/launch  {macs * 2 * k * n / ms / 1e9:.3f} T modmul/s  ({ms / B:.3f} ms/image)  checksum {int(y.view(-1)[::100003].sum().item()) & 0xffffffff:x}")
