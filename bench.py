@@ -27,7 +27,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 CONFIGS = {
     # BASELINE.json configs[1]: PlainModelTiny.h5, n=4096, batch=1024 on one MI355X  (q = coeff_modulus_128(4096), t = 2^20)
-    "tiny4096": dict(model="PlainModelTiny", n=4096, k=2, t=1 << 20, batch=1024, chunk=16),
+    "tiny4096": dict(model="PlainModelTiny", n=4096, k=2, t=1 << 32, batch=1024, chunk=16),   # t=2^32: exact logits without the client-side refresh
     # configs[2]: ApproxPlainModel.h5, n=8192, 3 coeff moduli, batch=1024
     "approx8192": dict(model="ApproxPlainModel", n=8192, k=3, t=1 << 30, batch=1024, chunk=16),
     # configs[4]: PlainModelWoPad.h5, n=16384, 4 coeff moduli
@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--chunk", type=int, default=None, help="images processed per layer launch")
     ap.add_argument("--distinct", type=int, default=4, help="distinct encrypted images (tiled to the batch on device)")
     ap.add_argument("--mode", default="resident", choices=["resident", "layerwise"])
+    ap.add_argument("--t-bits", type=int, default=None, help="override the plain modulus t = 2^bits")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target size of the CPU-baseline sample (0 = skip)")
     return ap.parse_args()
 
@@ -137,6 +138,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     cfg = dict(CONFIGS[args.config])
+    if args.t_bits:
+        cfg["t"] = 1 << args.t_bits
     B = args.batch or cfg["batch"]; C = min(args.chunk or cfg["chunk"], B)
     q = ca.default_coeff_modulus_128(cfg["n"])[:cfg["k"]]
     E = ca.Engine(cfg["n"], q, cfg["t"], device=local)

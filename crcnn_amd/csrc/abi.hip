@@ -79,7 +79,7 @@ extern "C" size_t crc_conv2d_work_bytes(const crc_ctx *c, int B, int zd, int xd,
     (void)nf;
     if (!c || !conv_shape_ok(xd, yd, xs, ys, xf, yf)) return 0;
     const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys + 1;
-    size_t b = align256(sizeof(int) * (size_t)xo * yo) + align256(sizeof(int) * (size_t)zd * xf * yf);
+    size_t b = align256(sizeof(int) * (size_t)xo * yo) + 2 * align256(sizeof(int) * ((size_t)zd * xf * yf + 8));
     if (in_form == CRC_COEFF) b += (size_t)B * zd * xd * yd * crc_ct_words(c, 2) * 8;
     return b + 256;
 }
@@ -95,8 +95,9 @@ extern "C" int crc_conv2d(crc_ctx *c, const uint64_t *d_x, const uint64_t *d_w, 
     hipStream_t st = S(stream);
     char *w = (char *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
     int *xoff = (int *)w; w += align256(sizeof(int) * (size_t)P);
-    int *toff = (int *)w; w += align256(sizeof(int) * (size_t)T);
-    RUN(k_conv_offsets(xoff, toff, P, T, xd, yd, xs, ys, xf, yf, yo, st));
+    int *toff = (int *)w; w += align256(sizeof(int) * ((size_t)T + 8));
+    unsigned *toffw = (unsigned *)w; w += align256(sizeof(int) * ((size_t)T + 8));
+    RUN(k_conv_offsets(c, xoff, toff, toffw, P, T, in_cts, xd, yd, xs, ys, xf, yf, yo, st));
     const u64 *xn = d_x;
     if (in_form == CRC_COEFF) {                   // transform_input_to_ntt, convolutionalLayer.cpp:95-148 (out of place: x is const)
         u64 *buf = (u64 *)w;
@@ -104,7 +105,7 @@ extern "C" int crc_conv2d(crc_ctx *c, const uint64_t *d_x, const uint64_t *d_w, 
         xn = buf;
     }
     // sum of products in the NTT domain; bias joins here when the output stays NTT-resident
-    RUN(k_mac2(c, xn, d_w, d_y, xoff, toff, B, P, nf, T, in_cts, out_form == CRC_NTT ? d_bias : nullptr, xd, yd, xf, yf, st));
+    RUN(k_mac2(c, xn, d_w, d_y, xoff, toff, B, P, nf, T, in_cts, out_form == CRC_NTT ? d_bias : nullptr, xd, yd, xf, yf, toffw, st));
     if (out_form == CRC_COEFF)                    // one inverse NTT per output ciphertext, add_plain(bias) fused into its store
         RUN(k_ntt_ct(c, true, d_y, d_y, (size_t)B * nf * P, 2, false, st, d_bias, 1, (size_t)P, nf));
     return CRC_OK;

@@ -12,10 +12,10 @@ int k_pool(crc_ctx *c, const u64 *x, u64 *y, int B, int zd, int xd, int yd, int 
 int k_bn_ntt(crc_ctx *c, u64 *x, int B, int zd, int hw, const u64 *mean, const u64 *invstd, hipStream_t st);
 int k_mac(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, const int *d_toff, int B, int P, int F, int T, int in_cts,
           const u64 *bias_ntt, hipStream_t st);
-int k_conv_offsets(int *xoff, int *toff, int P, int T, int xd, int yd, int xs, int ys, int xf, int yf, int yo, hipStream_t st);
+int k_conv_offsets(crc_ctx *c, int *xoff, int *toff, unsigned *toffw, int P, int T, int in_cts, int xd, int yd, int xs, int ys, int xf, int yf, int yo, hipStream_t st);
 size_t k_square_work_words(const crc_ctx *c, size_t cnt);
 size_t k_relin_work_words(const crc_ctx *c, size_t cnt, int dbc);
 int k_square(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStream_t st);
 int k_relinearize(crc_ctx *c, const u64 *x3, size_t cnt, const u64 *evk, int dbc, u64 *y, u64 *work, hipStream_t st);
 int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, const int *d_toff, int B, int P, int F, int T, int in_cts,
-           const u64 *bias_ntt, int gxd, int gyd, int gxf, int gyf, hipStream_t st);
+           const u64 *bias_ntt, int gxd, int gyd, int gxf, int gyf, const unsigned *d_toffw, hipStream_t st);

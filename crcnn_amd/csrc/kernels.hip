@@ -5,6 +5,7 @@
 // Integer modular arithmetic only -- no MFMA.  Lane <-> coefficient/slot, so every global access is a coalesced
 // 512 B (8 B/lane) or 1 KiB (16 B/lane) wave transaction.
 #include "kernels.h"
+#include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------------------------
 // NTT: one workgroup per row, whole polynomial staged in LDS (32 KiB @ n=4096 ... 128 KiB @ n=16384).
@@ -297,16 +298,22 @@ int k_bn_ntt(crc_ctx *c, u64 *x, int B, int zd, int hw, const u64 *mean, const u
 // single Barrett reduction per output (products < 2^120 for T < 2^10..2^18 terms).
 // ---------------------------------------------------------------------------------------------------------------
 // gather tables of a valid-padding strided convolution (device-built: no host data on the launch path)
-__global__ void conv_offsets_kernel(int *xoff, int *toff, int P, int T, int xd, int yd, int xs, int ys, int xf, int yf, int yo)
+__global__ void conv_offsets_kernel(int *xoff, int *toff, unsigned *toffw, unsigned ctw, int P, int T, int xd, int yd, int xs, int ys, int xf, int yf, int yo)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < P) { const int ox = idx / yo, oy = idx % yo; xoff[idx] = (ox * xs) * yd + oy * ys; }
-    if (idx < T) { const int z = idx / (xf * yf), kx = (idx / yf) % xf, ky = idx % yf; toff[idx] = (z * xd + kx) * yd + ky; }
+    if (idx < T + 8) {      // 8 padding entries repeat the last term (the staged weights are zeroed there)
+        const int t = min(idx, T - 1);
+        const int z = t / (xf * yf), kx = (t / yf) % xf, ky = t % yf; const int o = (z * xd + kx) * yd + ky;
+        toff[idx] = o; toffw[idx] = (unsigned)o * ctw;
+    }
 }
-int k_conv_offsets(int *xoff, int *toff, int P, int T, int xd, int yd, int xs, int ys, int xf, int yf, int yo, hipStream_t st)
+int k_conv_offsets(crc_ctx *c, int *xoff, int *toff, unsigned *toffw, int P, int T, int in_cts, int xd, int yd, int xs, int ys, int xf, int yf, int yo, hipStream_t st)
 {
-    const int m = P > T ? P : T;
-    hipLaunchKernelGGL(conv_offsets_kernel, dim3((m + 255) / 256), dim3(256), 0, st, xoff, toff, P, T, xd, yd, xs, ys, xf, yf, yo);
+    const int m = P > T + 8 ? P : T + 8;
+    const size_t ctw = 2 * (size_t)c->k * c->n;
+    if ((size_t)in_cts * ctw > 0xffffffffULL) return CRC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(conv_offsets_kernel, dim3((m + 255) / 256), dim3(256), 0, st, xoff, toff, toffw, (unsigned)ctw, P, T, xd, yd, xs, ys, xf, yf, yo);
     HIPCHK(hipGetLastError());
     return CRC_OK;
 }
@@ -314,8 +321,10 @@ int k_conv_offsets(int *xoff, int *toff, int P, int T, int xd, int yd, int xs, i
 struct MacArgs {
     const u64 *x; const u64 *w; u64 *y; const ModParams *mods;
     const int *xoff; const int *toff;        // device tables: output pixel -> base ct index, term -> ct offset
+    const unsigned *toffw;                   // term -> element offset toff*2kn, padded by 8 entries (mac2)
     int n, k, B, P, F, T, in_cts;            // P output pixels per image, in_cts input cts per image
     const u64 *bias; int bias_sign;          // optional NTT-form delta bias [F][k][n] added to poly 0
+    int dbg;                                 // tuning only: 1 = skip operand staging (timing of the bare MAC loop), 2 = skip barriers too
     int gxd, gyd, gxf, gyf;                  // window geometry: toff[t] = (z*gxd + kx)*gyd + ky for t = (z*gxf + kx)*gyf + ky
 };
 
@@ -473,58 +482,47 @@ __global__ void __launch_bounds__(64 * WM * WN) mac2_kernel(MacArgs a)
 #pragma unroll
         for (int f = 0; f < FT; f++) { A0[r][f] = 0; A1[r][f] = 0; A2[r][f] = 0; OV[r][f] = 0; }
 
-    const int nstages = (a.T + S - 1) / S;
-    u64 stage_reg[RLOAD];
-    // reduction-term walker, all scalar: (tz, tkx, tky) = coordinates of term st*S; toff derived without touching memory
-    int tz = 0, tkx = 0, tky = 0;
-    auto load_stage = [&](int st) {
-        int toffs[S];
-        {
-            int z = tz, kx = tkx, ky = tky;
+    u64 regA[RLOAD], regB[RLOAD];          // two register stages: operand loads run TWO pipeline stages ahead of their use
+    // per-stage x offsets come from the padded toffw table as ONE scalar load (S consecutive entries), fetched a stage ahead
+    unsigned tw_cur[S], tw_nxt[S];
 #pragma unroll
-            for (int q = 0; q < S; q++) {
-                toffs[q] = (min(z, a.T / (a.gxf * a.gyf) - 1) * a.gxd + kx) * a.gyd + ky;      // clamped past the end (weights are zeroed there)
-                if (++ky == a.gyf) { ky = 0; if (++kx == a.gxf) { kx = 0; z++; } }
-            }
-            tz = z; tkx = kx; tky = ky;
-        }
+    for (int q = 0; q < S; q++) { tw_cur[q] = a.toffw[q]; tw_nxt[q] = a.toffw[S + q]; }
+    const u32 kn32 = (u32)kn;
+    auto load_stage = [&](int st, u64 (&reg)[RLOAD]) {          // called with st = 0, 1, 2, ... in order
 #pragma unroll
         for (int j = 0; j < RLOAD; j++) {
-            int t = st * S + vstep[j];
-            int to = toffs[0];
+            u32 off = tw_cur[0];
 #pragma unroll
-            for (int q = 1; q < S; q++) to = vstep[j] == q ? toffs[q] : to;
-            const bool live = t < a.T;
-            t = live ? t : a.T - 1;
-            const u64 *ptr = visx[j] ? vbase[j] + (size_t)to * ctw : vbase[j] + (size_t)t * kn;
-            stage_reg[j] = ptr[(u32)rown];          // consumed only in store_stage: no wait here, the loads stay in flight during the compute phase
+            for (int q = 1; q < S; q++) off = vstep[j] == q ? tw_cur[q] : off;
+            const u32 tclamp = (u32)min(st * S + vstep[j], a.T - 1);
+            off = visx[j] ? off : tclamp * kn32;
+            reg[j] = vbase[j][(size_t)(off + (u32)rown)];      // consumed only in store_stage: the loads stay in flight meanwhile
         }
+#pragma unroll
+        for (int q = 0; q < S; q++) { tw_cur[q] = tw_nxt[q]; tw_nxt[q] = a.toffw[min((st + 2) * S, a.T) + q]; }
     };
-    auto store_stage = [&](int st) {
+    auto store_stage = [&](int st, u64 (&reg)[RLOAD]) {
         u64 *dst = smem + (size_t)(st & 1) * VEC * 64;
 #pragma unroll
         for (int j = 0; j < RLOAD; j++) {
             const int v = wave + j * NW;
             const bool dead = !visx[j] && st * S + vstep[j] >= a.T;     // weights past the last term are zero (x may be anything valid)
-            if (v < VEC) dst[v * 64 + lane] = dead ? 0 : stage_reg[j];
+            const u64 r = dead ? 0 : reg[j];
+            if (v < VEC) dst[v * 64 + lane] = (r & MASK28) | ((r >> 28) << 32);      // pre-split once: low dword = x0 (28 bit), high dword = x1
         }
     };
-
-    load_stage(0); store_stage(0);
-    __syncthreads();
-    for (int st = 0; st < nstages; st++) {
-        if (st + 1 < nstages) load_stage(st + 1);
+    auto compute_stage = [&](int st) {
         const u64 *buf = smem + (size_t)(st & 1) * VEC * 64;
 #pragma unroll 1
         for (int step = 0; step < S; step++) {
             const u64 *sv = buf + step * (ROWS + FW) * 64 + lane;
             u32 w0[FT], w1[FT], ws[FT];
 #pragma unroll
-            for (int f = 0; f < FT; f++) { const u64 wv = sv[(ROWS + wn * FT + f) * 64]; w0[f] = (u32)(wv & MASK28); w1[f] = (u32)(wv >> 28); ws[f] = w0[f] + w1[f]; }
+            for (int f = 0; f < FT; f++) { const u64 wv = sv[(ROWS + wn * FT + f) * 64]; w0[f] = (u32)wv; w1[f] = (u32)(wv >> 32); ws[f] = w0[f] + w1[f]; }
 #pragma unroll
             for (int r = 0; r < PX * 2; r++) {
                 const u64 xv = sv[(wm * PX * 2 + r) * 64];
-                const u32 x0 = (u32)(xv & MASK28), x1 = (u32)(xv >> 28), xs = x0 + x1;
+                const u32 x0 = (u32)xv, x1 = (u32)(xv >> 32), xs = x0 + x1;
 #pragma unroll
                 for (int f = 0; f < FT; f++) {
                     A0[r][f] += (u64)x0 * w0[f];
@@ -542,8 +540,23 @@ __global__ void __launch_bounds__(64 * WM * WN) mac2_kernel(MacArgs a)
                     A0[r][f] &= ~(1ULL << 63); A1[r][f] &= ~(1ULL << 63); A2[r][f] &= ~(1ULL << 63);
                 }
         }
-        if (st + 1 < nstages) store_stage(st + 1);
+    };
+
+    const int nstages = (a.T + S - 1) / S;
+    load_stage(0, regA); store_stage(0, regA);
+    if (nstages > 1) load_stage(1, regA);
+    __syncthreads();
+    for (int st = 0; st < nstages; st += 2) {
+        if (st + 2 < nstages) load_stage(st + 2, regB);
+        compute_stage(st);
+        if (st + 1 < nstages) store_stage(st + 1, regA);
         __syncthreads();
+        if (st + 1 < nstages) {
+            if (st + 3 < nstages) load_stage(st + 3, regA);
+            compute_stage(st + 1);
+            if (st + 2 < nstages) store_stage(st + 2, regB);
+            __syncthreads();
+        }
     }
 
     // recombine (mod 2^128, exact because the true sum is < 2^128), reduce once, add the bias, store
@@ -594,17 +607,27 @@ static int mac2_launch(crc_ctx *c, MacArgs &a, hipStream_t st)
 }
 
 int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, const int *d_toff, int B, int P, int F, int T, int in_cts,
-           const u64 *bias_ntt, int gxd, int gyd, int gxf, int gyf, hipStream_t st)
+           const u64 *bias_ntt, int gxd, int gyd, int gxf, int gyf, const unsigned *d_toffw, hipStream_t st)
 {
     if (B == 0 || P == 0 || F == 0) return CRC_OK;
     int maxbits = 0; for (int i = 0; i < c->k; i++) if ((int)c->tabs[i].m.bits > maxbits) maxbits = c->tabs[i].m.bits;
     if (maxbits > 55 || T > 32768 || c->n < 64) return k_mac(c, x, w, y, d_xoff, d_toff, B, P, F, T, in_cts, bias_ntt, st);
     MacArgs a{};
-    a.x = x; a.w = w; a.y = y; a.mods = c->d_mods; a.xoff = d_xoff; a.toff = d_toff;
+    a.x = x; a.w = w; a.y = y; a.mods = c->d_mods; a.xoff = d_xoff; a.toff = d_toff; a.toffw = d_toffw;
     a.n = c->n; a.k = c->k; a.B = B; a.P = P; a.F = F; a.T = T; a.in_cts = in_cts; a.bias = bias_ntt; a.bias_sign = 1;
     a.gxd = gxd; a.gyd = gyd; a.gxf = gxf; a.gyf = gyf;
-#ifndef MAC2_CFG
-#define MAC2_CFG 3, 4, 2, 4, 2
-#endif
-    return mac2_launch<MAC2_CFG>(c, a, st);
+    { static const int dbg = [] { const char *e = getenv("CRC_MAC2_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
+    // tile configuration <PX, FT, WM, WN, S>; CRC_MAC2_CFG selects an alternative for tuning runs (tools/bench_mac.py)
+    static const int cfg = [] { const char *e = getenv("CRC_MAC2_CFG"); return e ? atoi(e) : 0; }();
+    switch (cfg) {
+    case 1: return mac2_launch<3, 4, 2, 4, 3>(c, a, st);
+    case 2: return mac2_launch<2, 4, 2, 4, 4>(c, a, st);
+    case 3: return mac2_launch<2, 4, 2, 4, 2>(c, a, st);
+    case 4: return mac2_launch<3, 4, 4, 2, 2>(c, a, st);
+    case 5: return mac2_launch<4, 3, 2, 4, 2>(c, a, st);
+    case 6: return mac2_launch<2, 6, 4, 2, 2>(c, a, st);
+    case 7: return mac2_launch<3, 4, 2, 2, 2>(c, a, st);
+    case 8: return mac2_launch<3, 4, 2, 2, 4>(c, a, st);
+    default: return mac2_launch<3, 4, 2, 4, 2>(c, a, st);
+    }
 }
