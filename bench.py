@@ -82,13 +82,26 @@ def plain_forward(model, W, img):
     return x.reshape(-1)
 
 
+def host_cores():
+    """CPU cores this process may really use: scheduler affinity capped by the cgroup CPU quota (a GPU box gives one GPU's
+    share of the host, not all of its hardware threads)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("CRC_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(cfg, q, W, x0, target_s):
     """the CPU oracle in the reference's operation order (per-product INTT, convolutionalLayer.cpp:73-88), th_count = host
     cores, timed on a bounded sample: conv1 restricted to as many filters as fit the time target, plus the first pooling
     layer; extrapolated to one image by MAC count (images and output channels are independent)."""
     from crcnn_amd.netrun import TOPOLOGIES, layer_macs
     from oracle import orc
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     O = orc.Oracle(cfg["n"], q, cfg["t"])
     topo = TOPOLOGIES[cfg["model"]]
     kind, name, a = topo[0]

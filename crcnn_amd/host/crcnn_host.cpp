@@ -1,0 +1,497 @@
+// crcnn_host.cpp -- implementation of the CrCNN-compatible C++ host classes on top of the C ABI (include/crcnn_hip.h).
+#include "crcnn_host.h"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+
+using namespace std;
+
+crc_ctx *context = nullptr;
+vector<uint64_t> secret_key, public_key, ev_keys16_host;
+shared_ptr<DeviceBuffer> ev_keys16;
+uint64_t crcnn_seed = 0x5EA1;
+
+// ---- status -> exception (the reference throws std::invalid_argument from SEAL, evaluator.cpp:1549-1556) ---------------
+static void chk(int status, const char *what)
+{
+    if (status >= 0) return;
+    string msg = string(what) + ": " + crc_strerror(status);
+    if (status == CRC_ERR_INVALID_ARGUMENT || status == CRC_ERR_PARAMETERS) throw invalid_argument(msg);
+    throw runtime_error(msg);
+}
+static crc_ctx *ctx()
+{
+    if (!context) throw logic_error("setParameters() must be called first");
+    return context;
+}
+static int N() { return crc_ctx_n(ctx()); }
+static int K() { return crc_ctx_k(ctx()); }
+static size_t ctBytes() { return crc_ct_words(ctx(), 2) * 8; }
+
+DeviceBuffer::DeviceBuffer(size_t b) : bytes(b) { chk(crc_malloc(ctx(), b ? b : 8, &ptr), "crc_malloc"); }
+DeviceBuffer::~DeviceBuffer() { if (ptr && context) crc_free(context, ptr); }
+
+// ---- Plaintext ------------------------------------------------------------------------------------------------------
+void Plaintext::dense(uint64_t *out, int n) const
+{
+    memset(out, 0, 8 * (size_t)n);
+    for (auto &p : nz) if (p.first < n) out[p.first] = p.second;
+}
+void Plaintext::save(ostream &stream) const
+{
+    int32_t cc = coeff_count_;
+    vector<uint64_t> d((size_t)max(cc, 0), 0);
+    for (auto &p : nz) if (p.first < cc) d[p.first] = p.second;
+    stream.write(reinterpret_cast<const char *>(&cc), sizeof cc);
+    stream.write(reinterpret_cast<const char *>(d.data()), (streamsize)d.size() * 8);
+}
+void Plaintext::load(istream &stream)
+{
+    int32_t cc = 0;
+    stream.read(reinterpret_cast<char *>(&cc), sizeof cc);
+    if (!stream || cc < 0 || cc > N() + 1) throw invalid_argument("plain is not valid for encryption parameters");
+    vector<uint64_t> d((size_t)cc);
+    stream.read(reinterpret_cast<char *>(d.data()), (streamsize)cc * 8);
+    if (!stream) throw invalid_argument("truncated plaintext stream");
+    coeff_count_ = cc; nz.clear();
+    for (int i = 0; i < cc; i++) if (d[i]) nz.emplace_back(i, d[i]);
+}
+static Plaintext fromDense(const uint64_t *co, int n, int cc)
+{
+    Plaintext p; p.coeff_count_ = cc;
+    for (int i = 0; i < n; i++) if (co[i]) p.nz.emplace_back(i, co[i]);
+    return p;
+}
+Plaintext fraencode(double value)
+{
+    vector<uint64_t> co((size_t)N()); int32_t cc = 0;
+    chk(crc_encode_f64(ctx(), &value, 1, co.data(), &cc), "crc_encode_f64");
+    return fromDense(co.data(), N(), cc);
+}
+double fradecode(const vector<uint64_t> &plain) { return crc_decode(ctx(), plain.data()); }
+
+// plaintext list -> device buffer of [count][k][n]: mode 0 = NTT-form weights, 1 = delta coefficient form, 2 = delta NTT form
+static shared_ptr<DeviceBuffer> uploadPlain(const vector<const Plaintext *> &pl, int mode)
+{
+    const int n = N(), k = K();
+    auto out = make_shared<DeviceBuffer>(pl.size() * (size_t)k * n * 8);
+    const size_t chunk = max<size_t>(1, min<size_t>(pl.size(), (64u << 20) / ((size_t)n * 8)));
+    DeviceBuffer stage(chunk * (size_t)n * 8);
+    vector<uint64_t> host(chunk * (size_t)n);
+    for (size_t o = 0; o < pl.size(); o += chunk) {
+        const size_t c = min(chunk, pl.size() - o);
+        for (size_t i = 0; i < c; i++) pl[o + i]->dense(host.data() + i * n, n);
+        chk(crc_memcpy_h2d(ctx(), stage.ptr, host.data(), c * (size_t)n * 8, nullptr), "crc_memcpy_h2d");
+        uint64_t *dst = (uint64_t *)out->ptr + o * (size_t)k * n;
+        if (mode == 0) chk(crc_plain_to_ntt(ctx(), (const uint64_t *)stage.ptr, c, dst, nullptr), "crc_plain_to_ntt");
+        else chk(crc_plain_to_delta(ctx(), (const uint64_t *)stage.ptr, c, mode == 2 ? CRC_NTT : CRC_COEFF, dst, nullptr), "crc_plain_to_delta");
+        chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+    }
+    return out;
+}
+
+// ---- tensors ----------------------------------------------------------------------------------------------------------
+ciphertext3D::ciphertext3D(int B, int zd, int xd, int yd, int form) : B(B), zd(zd), xd(xd), yd(yd), form(form)
+{
+    buf = make_shared<DeviceBuffer>(count() * ctBytes());
+}
+ciphertext3D ciphertext3D::fromHost(const uint64_t *h, int B, int zd, int xd, int yd)
+{
+    ciphertext3D t(B, zd, xd, yd);
+    chk(crc_memcpy_h2d(ctx(), t.buf->ptr, h, t.count() * ctBytes(), nullptr), "crc_memcpy_h2d");
+    chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+    return t;
+}
+vector<uint64_t> ciphertext3D::toHost() const
+{
+    vector<uint64_t> h(count() * ctBytes() / 8);
+    chk(crc_memcpy_d2h(ctx(), h.data(), buf->ptr, h.size() * 8, nullptr), "crc_memcpy_d2h");
+    chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+    return h;
+}
+ciphertext3D stackImages(const vector<ciphertext3D> &images)
+{
+    if (images.empty()) throw invalid_argument("no images");
+    const ciphertext3D &f = images[0];
+    int B = 0; for (auto &im : images) { if (im.zd != f.zd || im.xd != f.xd || im.yd != f.yd || im.form != f.form) throw invalid_argument("image shapes differ"); B += im.B; }
+    ciphertext3D t(B, f.zd, f.xd, f.yd, f.form);
+    size_t off = 0;
+    for (auto &im : images) { chk(crc_memcpy_d2d(ctx(), (char *)t.buf->ptr + off, im.buf->ptr, im.count() * ctBytes(), nullptr), "crc_memcpy_d2d"); off += im.count() * ctBytes(); }
+    chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+    return t;
+}
+ciphertext3D deepCopyImage(const ciphertext3D &image)
+{
+    ciphertext3D t(image.B, image.zd, image.xd, image.yd, image.form);
+    chk(crc_memcpy_d2d(ctx(), t.buf->ptr, image.buf->ptr, image.count() * ctBytes(), nullptr), "crc_memcpy_d2d");
+    return t;
+}
+
+// ---- globals ----------------------------------------------------------------------------------------------------------
+void setParameters(int poly_modulus, uint64_t plain_modulus)
+{
+    uint64_t q[16];
+    int k = crc_default_coeff_modulus_128(poly_modulus, q, 16);            // parms->set_coeff_modulus(coeff_modulus_128(n)), globals.cpp:30
+    if (k < 0) throw invalid_argument("no default coeff_modulus for this poly_modulus");
+    setParameters(poly_modulus, vector<uint64_t>(q, q + k), plain_modulus, 0);
+}
+void setParameters(int poly_modulus, const vector<uint64_t> &coeff_modulus, uint64_t plain_modulus, int device)
+{
+    delParameters();
+    chk(crc_ctx_create(poly_modulus, coeff_modulus.data(), (int)coeff_modulus.size(), plain_modulus, device, &context), "encryption parameters are not set correctly");
+    const int n = N(), k = K();
+    secret_key.assign((size_t)k * n, 0); public_key.assign((size_t)2 * k * n, 0);
+    chk(crc_keygen(context, crcnn_seed, secret_key.data(), public_key.data()), "crc_keygen");
+    ev_keys16_host.assign(crc_evk_words(context, 16), 0);                  // keygen->generate_evaluation_keys(16, *ev_keys16), globals.cpp:54
+    chk(crc_gen_evk(context, crcnn_seed + 1, secret_key.data(), 16, ev_keys16_host.data()), "crc_gen_evk");
+    ev_keys16 = make_shared<DeviceBuffer>(ev_keys16_host.size() * 8);
+    chk(crc_memcpy_h2d(context, ev_keys16->ptr, ev_keys16_host.data(), ev_keys16_host.size() * 8, nullptr), "crc_memcpy_h2d");
+    chk(crc_stream_sync(context, nullptr), "crc_stream_sync");
+}
+void delParameters()
+{
+    ev_keys16.reset();
+    if (context) { crc_ctx_destroy(context); context = nullptr; }
+}
+static uint64_t g_enc_counter = 0;
+ciphertext3D encryptImage(vector<float> image, int zd, int xd, int yd)
+{
+    const int n = N(), k = K();
+    if ((int)image.size() < xd * yd) throw invalid_argument("image too small");
+    // the reference indexes image[i*xd+j] for every z (globals.cpp:133): one plane replicated over zd
+    vector<float> px((size_t)zd * xd * yd);
+    for (int z = 0; z < zd; z++) for (int i = 0; i < xd; i++) for (int j = 0; j < yd; j++) px[((size_t)z * xd + i) * yd + j] = image[(size_t)i * xd + j];
+    vector<uint64_t> pl(px.size() * n), ct(px.size() * 2 * k * n);
+    chk(crc_encode_f32(ctx(), px.data(), px.size(), pl.data(), nullptr), "crc_encode_f32");
+    chk(crc_encrypt(ctx(), public_key.data(), pl.data(), px.size(), crcnn_seed + 1000003 * (++g_enc_counter), ct.data()), "crc_encrypt");
+    return ciphertext3D::fromHost(ct.data(), 1, zd, xd, yd);
+}
+ciphertext3D encryptImage(floatCube image)
+{
+    const int n = N(), k = K();
+    const int zd = (int)image.size(), xd = (int)image[0].size(), yd = (int)image[0][0].size();
+    vector<float> px; px.reserve((size_t)zd * xd * yd);
+    for (auto &a : image) for (auto &b : a) for (float v : b) px.push_back(v);
+    vector<uint64_t> pl(px.size() * n), ct(px.size() * 2 * k * n);
+    chk(crc_encode_f32(ctx(), px.data(), px.size(), pl.data(), nullptr), "crc_encode_f32");
+    chk(crc_encrypt(ctx(), public_key.data(), pl.data(), px.size(), crcnn_seed + 1000003 * (++g_enc_counter), ct.data()), "crc_encrypt");
+    return ciphertext3D::fromHost(ct.data(), 1, zd, xd, yd);
+}
+vector<floatCube> decryptImages(const ciphertext3D &t)
+{
+    const int n = N();
+    if (t.form != CRC_COEFF) throw invalid_argument("tensor is in NTT form");
+    vector<uint64_t> h = t.toHost(), pl(t.count() * n);
+    chk(crc_decrypt(ctx(), secret_key.data(), h.data(), t.count(), 2, pl.data()), "crc_decrypt");
+    vector<floatCube> out(t.B, floatCube(t.zd, vector<vector<float>>(t.xd, vector<float>(t.yd))));
+    size_t i = 0;
+    for (int b = 0; b < t.B; b++) for (int z = 0; z < t.zd; z++) for (int x = 0; x < t.xd; x++) for (int y = 0; y < t.yd; y++, i++)
+        out[b][z][x][y] = (float)crc_decode(ctx(), pl.data() + i * n);
+    return out;
+}
+floatCube decryptImage(const ciphertext3D &t)
+{
+    if (t.B != 1) throw invalid_argument("decryptImage expects a single image; use decryptImages for a batch");
+    return decryptImages(t)[0];
+}
+int noiseBudget(const ciphertext3D &t, size_t index)
+{
+    vector<uint64_t> h(ctBytes() / 8);
+    chk(crc_memcpy_d2h(ctx(), h.data(), (char *)t.buf->ptr + index * ctBytes(), ctBytes(), nullptr), "crc_memcpy_d2h");
+    chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+    return crc_noise_budget(ctx(), secret_key.data(), h.data(), 2);
+}
+
+// ---- Layer ------------------------------------------------------------------------------------------------------------
+void Layer::computeBoundaries(int xd, int yd, int xs, int ys, int xf, int yf, int *xl, int *yl)
+{
+    *xl = xf > xs ? xd - xf + 1 : xd - xs + 1;
+    *yl = yf > ys ? yd - yf + 1 : yd - ys + 1;
+}
+static void checkInput(const ciphertext3D &in, int zd, int xd, int yd, const char *who)
+{
+    if (!in.buf || in.zd != zd || in.xd != xd || in.yd != yd) throw invalid_argument(string(who) + ": input tensor shape does not match the layer");
+}
+static shared_ptr<DeviceBuffer> &ensure(shared_ptr<DeviceBuffer> &b, size_t bytes)
+{
+    if (!b || b->bytes < bytes) b = make_shared<DeviceBuffer>(bytes);
+    return b;
+}
+
+// ---- ConvolutionalLayer -----------------------------------------------------------------------------------------------
+ConvolutionalLayer::ConvolutionalLayer(string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf, int nf, int th_count, plaintext4D &filters, vector<Plaintext> &biases)
+    : Layer(name), xd(xd), yd(yd), zd(zd), xs(xs), ys(ys), xf(xf), yf(yf), nf(nf), th_count(th_count),
+      xo((xd - xf) / xs + 1), yo((yd - yf) / ys + 1), zo(nf), filters(filters), biases(biases) {}
+ConvolutionalLayer::ConvolutionalLayer(string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf, int nf, int th_count, istream *infile)
+    : Layer(name), xd(xd), yd(yd), zd(zd), xs(xs), ys(ys), xf(xf), yf(yf), nf(nf), th_count(th_count),
+      xo((xd - xf) / xs + 1), yo((yd - yf) / ys + 1), zo(nf) { loadPlaintextParameters(infile); }
+void ConvolutionalLayer::upload()
+{
+    if (filters_already_ntt) return;
+    if ((int)filters.size() != nf || (int)biases.size() != nf) throw invalid_argument("conv: filter/bias count mismatch");
+    vector<const Plaintext *> w, b;
+    for (int f = 0; f < nf; f++) {
+        if ((int)filters[f].size() != zd || (int)filters[f][0].size() != xf || (int)filters[f][0][0].size() != yf) throw invalid_argument("conv: kernel shape mismatch");
+        for (int z = 0; z < zd; z++) for (int i = 0; i < xf; i++) for (int j = 0; j < yf; j++) w.push_back(&filters[f][z][i][j]);
+        b.push_back(&biases[f]);
+    }
+    d_w = uploadPlain(w, 0); d_b[0] = uploadPlain(b, 1); d_b[1] = uploadPlain(b, 2);
+    filters_already_ntt = true;            // transform_kernel_to_ntt, convolutionalLayer.cpp:151-156 (done once)
+}
+ciphertext3D ConvolutionalLayer::forward(ciphertext3D input)
+{
+    checkInput(input, zd, xd, yd, "ConvolutionalLayer");
+    upload();
+    ciphertext3D out(input.B, zo, xo, yo, out_form);
+    size_t wb = crc_conv2d_work_bytes(ctx(), input.B, zd, xd, yd, xs, ys, xf, yf, nf, input.form);
+    if (!wb) throw invalid_argument("ConvolutionalLayer: unsupported geometry");
+    ensure(d_work, wb);
+    chk(crc_conv2d(ctx(), input.data(), (const uint64_t *)d_w->ptr, (const uint64_t *)d_b[out_form == CRC_NTT]->ptr, input.B, zd, xd, yd, xs, ys, xf, yf, nf,
+                   input.form, out_form, out.data(), d_work->ptr, nullptr), "crc_conv2d");
+    return out;
+}
+void ConvolutionalLayer::savePlaintextParameters(ostream *outfile)
+{   // order of convolutionalLayer.cpp:213-229
+    for (int n = 0; n < nf; n++) { for (int z = 0; z < zd; z++) for (int i = 0; i < xf; i++) for (int j = 0; j < yf; j++) filters[n][z][i][j].save(*outfile); biases[n].save(*outfile); outfile->flush(); }
+}
+void ConvolutionalLayer::loadPlaintextParameters(istream *infile)
+{
+    filters.assign(nf, plaintext3D(zd, plaintext2D(xf, vector<Plaintext>(yf)))); biases.assign(nf, Plaintext());
+    for (int n = 0; n < nf; n++) { for (int z = 0; z < zd; z++) for (int i = 0; i < xf; i++) for (int j = 0; j < yf; j++) filters[n][z][i][j].load(*infile); biases[n].load(*infile); }
+    filters_already_ntt = false;
+}
+void ConvolutionalLayer::printLayerStructure()
+{
+    cerr << "Convolutional " << name << " : input (" << zd << "," << xd << "," << yd << "); kernel(" << nf << "," << xf << "," << yf << "); stride(" << xs << "," << ys << "); output("
+         << zo << "," << xo << "," << yo << ") " << "run with " << th_count << " threads" << endl;
+}
+
+// ---- FullyConnectedLayer ----------------------------------------------------------------------------------------------
+FullyConnectedLayer::FullyConnectedLayer(string name, int in_dim, int out_dim, int th_count, plaintext2D &weights, vector<Plaintext> &biases)
+    : Layer(name), in_dim(in_dim), out_dim(out_dim), th_count(th_count), weights(weights), biases(biases) {}
+FullyConnectedLayer::FullyConnectedLayer(string name, int in_dim, int out_dim, int th_count, istream *infile)
+    : Layer(name), in_dim(in_dim), out_dim(out_dim), th_count(th_count) { loadPlaintextParameters(infile); }
+void FullyConnectedLayer::upload()
+{
+    if (weights_already_ntt) return;
+    if ((int)weights.size() != out_dim || (int)biases.size() != out_dim) throw invalid_argument("fc: weight/bias count mismatch");
+    vector<const Plaintext *> w, b;
+    for (int i = 0; i < out_dim; i++) { if ((int)weights[i].size() != in_dim) throw invalid_argument("fc: row length mismatch"); for (int j = 0; j < in_dim; j++) w.push_back(&weights[i][j]); b.push_back(&biases[i]); }
+    d_w = uploadPlain(w, 0); d_b[0] = uploadPlain(b, 1); d_b[1] = uploadPlain(b, 2);
+    weights_already_ntt = true;
+}
+ciphertext3D FullyConnectedLayer::forward(ciphertext3D input)
+{
+    if (!input.buf || input.zd * input.xd * input.yd != in_dim) throw invalid_argument("FullyConnectedLayer: input size does not match in_dim");   // reshapeInput, :38-56
+    upload();
+    ciphertext3D out(input.B, 1, out_dim, 1, out_form);
+    ensure(d_work, crc_dense_work_bytes(ctx(), input.B, in_dim, out_dim, input.form));
+    chk(crc_dense(ctx(), input.data(), (const uint64_t *)d_w->ptr, (const uint64_t *)d_b[out_form == CRC_NTT]->ptr, input.B, in_dim, out_dim, input.form, out_form,
+                  out.data(), d_work->ptr, nullptr), "crc_dense");
+    return out;
+}
+void FullyConnectedLayer::savePlaintextParameters(ostream *outfile)
+{
+    for (int i = 0; i < out_dim; i++) { for (int j = 0; j < in_dim; j++) weights[i][j].save(*outfile); biases[i].save(*outfile); outfile->flush(); }
+}
+void FullyConnectedLayer::loadPlaintextParameters(istream *infile)
+{
+    weights.assign(out_dim, vector<Plaintext>(in_dim)); biases.assign(out_dim, Plaintext());
+    for (int i = 0; i < out_dim; i++) { for (int j = 0; j < in_dim; j++) weights[i][j].load(*infile); biases[i].load(*infile); }
+    weights_already_ntt = false;
+}
+void FullyConnectedLayer::printLayerStructure() { cerr << "Fully connected " << name << " : (" << in_dim << " -> " << out_dim << ")" << "run with " << th_count << " threads" << endl; }
+
+// ---- Pooling ----------------------------------------------------------------------------------------------------------
+PoolingLayer::PoolingLayer(string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf)
+    : Layer(name), xd(xd), yd(yd), zd(zd), xs(xs), ys(ys), xf(xf), yf(yf), xo((xd - xf) / xs + 1), yo((yd - yf) / ys + 1), zo(zd) {}
+ciphertext3D PoolingLayer::forward(ciphertext3D input)
+{
+    checkInput(input, zd, xd, yd, "PoolingLayer");
+    ciphertext3D out(input.B, zo, xo, yo, input.form);
+    chk(crc_pool(ctx(), input.data(), input.B, zd, xd, yd, xs, ys, xf, yf, d_div ? (const uint64_t *)d_div->ptr : nullptr, input.form, out.data(), nullptr), "crc_pool");
+    if (out_form != out.form) {      // pooling is form-preserving; convert only if the network asked for the other form
+        if (out_form == CRC_NTT) chk(crc_ntt_fwd(ctx(), out.data(), out.count(), 2, nullptr), "crc_ntt_fwd"); else chk(crc_ntt_inv(ctx(), out.data(), out.count(), 2, nullptr), "crc_ntt_inv");
+        out.form = out_form;
+    }
+    return out;
+}
+void PoolingLayer::printLayerStructure()
+{
+    cerr << "Pooling " << name << " : input (" << zo << "," << xd << "," << yd << "); kernel(" << xf << "," << yf << "); stride(" << xs << "," << ys << "); output(" << zo << "," << xo << "," << yo << ")" << endl;
+}
+AvgPoolingLayer::AvgPoolingLayer(string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf) : PoolingLayer(name, xd, yd, zd, xs, ys, xf, yf)
+{
+    div_factor = fraencode(1. / (xf * yf));                 // avgPoolingLayer.cpp:12
+    d_div = uploadPlain({&div_factor}, 0);
+}
+
+// ---- Square -----------------------------------------------------------------------------------------------------------
+ciphertext3D SquareLayer::forward(ciphertext3D input)
+{
+    if (!input.buf) throw invalid_argument("SquareLayer: empty input");
+    if (input.form != CRC_COEFF) throw invalid_argument("SquareLayer: input must be in coefficient form");
+    if (!ev_keys16) throw invalid_argument("not enough evaluation keys");
+    ciphertext3D out(input.B, input.zd, input.xd, input.yd, CRC_COEFF);
+    ensure(d_work, crc_square_relin_work_bytes(ctx(), input.count(), 16));
+    chk(crc_square_relin(ctx(), input.data(), input.count(), (const uint64_t *)ev_keys16->ptr, 16, out.data(), d_work->ptr, nullptr), "crc_square_relin");
+    if (out_form == CRC_NTT) { chk(crc_ntt_fwd(ctx(), out.data(), out.count(), 2, nullptr), "crc_ntt_fwd"); out.form = CRC_NTT; }
+    return out;
+}
+void SquareLayer::printLayerStructure() { cerr << "Square run with " << th_count << " threads" << endl; }
+
+// ---- BatchNorm --------------------------------------------------------------------------------------------------------
+BatchNormLayer::BatchNormLayer(string name, int num_channels, vector<Plaintext> &mean, vector<Plaintext> &var) : Layer(name), num_channels(num_channels), mean(mean), var(var) {}
+BatchNormLayer::BatchNormLayer(string name, int num_channels, istream *infile) : Layer(name), num_channels(num_channels) { loadPlaintextParameters(infile); }
+void BatchNormLayer::upload()
+{
+    if (d_invstd) return;
+    if ((int)mean.size() != num_channels || (int)var.size() != num_channels) throw invalid_argument("bn: parameter count mismatch");
+    vector<const Plaintext *> m, v;
+    for (int i = 0; i < num_channels; i++) { m.push_back(&mean[i]); v.push_back(&var[i]); }
+    d_mean[0] = uploadPlain(m, 1); d_mean[1] = uploadPlain(m, 2); d_invstd = uploadPlain(v, 0);
+}
+ciphertext3D BatchNormLayer::forward(ciphertext3D input)
+{
+    if (!input.buf || input.zd != num_channels) throw invalid_argument("BatchNormLayer: channel count mismatch");
+    upload();
+    ciphertext3D out = deepCopyImage(input);                // the reference works on its by-value copy (batchNormLayer.cpp:29)
+    chk(crc_batchnorm(ctx(), out.data(), out.B, out.zd, out.xd, out.yd, (const uint64_t *)d_mean[out.form == CRC_NTT]->ptr, (const uint64_t *)d_invstd->ptr, out.form, nullptr), "crc_batchnorm");
+    if (out_form != out.form) {
+        if (out_form == CRC_NTT) chk(crc_ntt_fwd(ctx(), out.data(), out.count(), 2, nullptr), "crc_ntt_fwd"); else chk(crc_ntt_inv(ctx(), out.data(), out.count(), 2, nullptr), "crc_ntt_inv");
+        out.form = out_form;
+    }
+    return out;
+}
+void BatchNormLayer::savePlaintextParameters(ostream *outfile) { for (int i = 0; i < num_channels; i++) { mean[i].save(*outfile); var[i].save(*outfile); outfile->flush(); } }
+void BatchNormLayer::loadPlaintextParameters(istream *infile)
+{
+    mean.assign(num_channels, Plaintext()); var.assign(num_channels, Plaintext());
+    for (int i = 0; i < num_channels; i++) { mean[i].load(*infile); var[i].load(*infile); }
+    d_invstd.reset();
+}
+void BatchNormLayer::printLayerStructure() { cerr << "BatchNormLayer2D " << name << " :num_channels " << num_channels << endl; }
+
+// ---- Network ----------------------------------------------------------------------------------------------------------
+void Network::printNetworkStructure()
+{
+    for (size_t i = 0; i < layers.size(); i++) { cerr << "(" << i << ") : "; layers[i]->printLayerStructure(); cout << endl; }
+}
+ciphertext3D Network::forward(ciphertext3D input)
+{   // network.cpp:22-47
+    const int L = (int)layers.size();
+    // choose the form of every boundary: NTT between linear layers when resident, coefficient form into Square and out of the net
+    for (int i = 0; i < L; i++) {
+        bool coeff = !ntt_resident || i == L - 1 || !layers[i + 1]->linear() || i + 1 == layer_before_reenc;
+        layers[i]->out_form = coeff ? CRC_COEFF : CRC_NTT;
+    }
+    last_layer_ms.assign(L, 0.0);
+    for (int i = 0; i < L; i++) {
+        if (i == layer_before_reenc) {                      // client-side refresh (needs the secret key), network.cpp:30-34
+            vector<floatCube> imgs = decryptImages(input);
+            vector<ciphertext3D> enc; for (auto &im : imgs) enc.push_back(encryptImage(im));
+            input = stackImages(enc);
+        }
+        auto t0 = chrono::high_resolution_clock::now();
+        input = layers[i]->forward(input);
+        chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+        last_layer_ms[i] = chrono::duration<double, milli>(chrono::high_resolution_clock::now() - t0).count();
+    }
+    return input;
+}
+
+// ---- CnnBuilder -------------------------------------------------------------------------------------------------------
+vector<float> CnnBuilder::getPretrained(string var_name)
+{   // LoadH5::getData, cnnBuilder.cpp:20-23
+    size_t cnt = 0;
+    int rc = crc_h5_dataset_count(plain_model_path.c_str(), var_name.c_str(), &cnt);
+    if (rc) throw runtime_error("cannot read dataset " + var_name + " from " + plain_model_path + ": " + crc_strerror(rc));
+    vector<float> v(cnt);
+    chk(crc_h5_read_f32(plain_model_path.c_str(), var_name.c_str(), v.data(), cnt, nullptr), "crc_h5_read_f32");
+    return v;
+}
+static vector<Plaintext> encodeAll(const vector<float> &v)
+{
+    const int n = N();
+    vector<uint64_t> co(v.size() * (size_t)n); vector<int32_t> cc(v.size());
+    chk(crc_encode_f32(ctx(), v.data(), v.size(), co.data(), cc.data()), "crc_encode_f32");
+    vector<Plaintext> out(v.size());
+    for (size_t i = 0; i < v.size(); i++) out[i] = fromDense(co.data() + i * n, n, cc[i]);
+    return out;
+}
+ConvolutionalLayer *CnnBuilder::buildConvolutionalLayer(string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf, int nf, int th_count, istream *infile)
+{   // cnnBuilder.cpp:25-50
+    if (infile != NULL) return new ConvolutionalLayer(name, xd, yd, zd, xs, ys, xf, yf, nf, th_count, infile);
+    vector<float> weights = getPretrained(name + ".weight"), biases = getPretrained(name + ".bias");
+    if ((int)weights.size() != nf * zd * xf * yf || (int)biases.size() != nf) throw invalid_argument("conv: dataset size does not match the layer");
+    vector<Plaintext> ew = encodeAll(weights), eb = encodeAll(biases);
+    plaintext4D encoded_weights(nf, plaintext3D(zd, plaintext2D(xf, vector<Plaintext>(yf))));
+    size_t w = 0;
+    for (int n = 0; n < nf; n++) for (int z = 0; z < zd; z++) for (int i = 0; i < xf; i++) for (int j = 0; j < yf; j++) encoded_weights[n][z][i][j] = ew[w++];
+    return new ConvolutionalLayer(name, xd, yd, zd, xs, ys, xf, yf, nf, th_count, encoded_weights, eb);
+}
+FullyConnectedLayer *CnnBuilder::buildFullyConnectedLayer(string name, int in_dim, int out_dim, int th_count, istream *infile)
+{   // cnnBuilder.cpp:53-76
+    if (infile != NULL) return new FullyConnectedLayer(name, in_dim, out_dim, th_count, infile);
+    vector<float> weights = getPretrained(name + ".weight"), biases = getPretrained(name + ".bias");
+    if ((int)weights.size() != in_dim * out_dim || (int)biases.size() != out_dim) throw invalid_argument("fc: dataset size does not match the layer");
+    vector<Plaintext> ew = encodeAll(weights), eb = encodeAll(biases);
+    plaintext2D encoded_weights(out_dim, vector<Plaintext>(in_dim));
+    size_t w = 0;
+    for (int i = 0; i < out_dim; i++) for (int j = 0; j < in_dim; j++) encoded_weights[i][j] = ew[w++];
+    return new FullyConnectedLayer(name, in_dim, out_dim, th_count, encoded_weights, eb);
+}
+PoolingLayer *CnnBuilder::buildPoolingLayer(string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf) { return new PoolingLayer(name, xd, yd, zd, xs, ys, xf, yf); }
+AvgPoolingLayer *CnnBuilder::buildAvgPoolingLayer(string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf) { return new AvgPoolingLayer(name, xd, yd, zd, xs, ys, xf, yf); }
+SquareLayer *CnnBuilder::buildSquareLayer(string name, int th_count) { return new SquareLayer(name, th_count); }
+BatchNormLayer *CnnBuilder::buildBatchNormLayer(string name, int num_channels, istream *infile)
+{   // cnnBuilder.cpp:89-105
+    if (infile != NULL) return new BatchNormLayer(name, num_channels, infile);
+    vector<float> mean = getPretrained(name + ".running_mean"), var = getPretrained(name + ".running_var");
+    if ((int)mean.size() != num_channels || (int)var.size() != num_channels) throw invalid_argument("bn: dataset size does not match the layer");
+    vector<float> invstd(var.size());
+    chk(crc_bn_invstd_f32(var.data(), var.size(), invstd.data()), "crc_bn_invstd_f32");
+    vector<Plaintext> em = encodeAll(mean), ev = encodeAll(invstd);
+    return new BatchNormLayer(name, num_channels, em, ev);
+}
+Network CnnBuilder::buildNetwork(string file_name) { return buildNetworkByName("PlainModelTiny", file_name); }
+Network CnnBuilder::buildNetworkByName(const string &model, string file_name)
+{
+    int th_count = 40, th_count2 = 50, th_tiny = 32, th_tiny2 = 42;
+    Network net;
+    unique_ptr<ifstream> infile;
+    if (file_name != "") { infile.reset(new ifstream(file_name, ifstream::binary)); if (!*infile) throw runtime_error("cannot open " + file_name); }
+    istream *in = infile.get();
+    auto add = [&](Layer *l) { net.getLayers().push_back(shared_ptr<Layer>(l)); };
+    if (model == "PlainModelTiny") {                         // cnnBuilder.cpp:157-169
+        add(buildConvolutionalLayer("pool1_features.conv1", 28, 28, 1, 1, 1, 5, 5, 32, th_tiny, in));
+        add(buildAvgPoolingLayer("pool1", 24, 24, 32, 2, 2, 2, 2));
+        add(buildConvolutionalLayer("pool2_features.conv2", 12, 12, 32, 1, 1, 5, 5, 64, th_tiny * 2, in));
+        add(buildAvgPoolingLayer("pool2", 8, 8, 64, 2, 2, 2, 2));
+        add(buildFullyConnectedLayer("classifier.fc3", 4 * 4 * 64, 512, th_tiny2, in));
+        add(buildFullyConnectedLayer("classifier.fc4", 512, 10, th_tiny2, in));
+    } else if (model == "ApproxPlainModel" || model == "PlainModelWoPad") {   // cnnBuilder.cpp:115-134 / :136-155
+        const bool avg = model == "ApproxPlainModel";
+        add(buildConvolutionalLayer("pool1_features.conv1", 28, 28, 1, 2, 2, 5, 5, 20, th_count, in));
+        add(avg ? (Layer *)buildAvgPoolingLayer("pool1", 12, 12, 20, 1, 1, 2, 2) : (Layer *)buildPoolingLayer("pool1", 12, 12, 20, 1, 1, 2, 2));
+        add(buildBatchNormLayer("pool1_features.norm1", 20, in));
+        add(buildConvolutionalLayer("pool2_features.conv2", 11, 11, 20, 2, 2, 3, 3, 50, avg ? th_count2 : th_count, in));
+        add(buildSquareLayer("act1", avg ? th_count2 : th_count));
+        add(avg ? (Layer *)buildAvgPoolingLayer("pool2", 5, 5, 50, 1, 1, 2, 2) : (Layer *)buildPoolingLayer("pool2", 5, 5, 50, 1, 1, 2, 2));
+        add(buildBatchNormLayer("pool2_features.norm2", 50, in));
+        add(buildFullyConnectedLayer("classifier.fc3", 4 * 4 * 50, 500, th_count, in));
+        add(buildFullyConnectedLayer("classifier.fc4", 500, 10, avg ? th_count2 : th_count, in));
+    } else throw invalid_argument("unknown model " + model);
+    return net;
+}
+Network CnnBuilder::buildAndSaveNetwork(string file_name)
+{   // cnnBuilder.cpp:181-196
+    ofstream outfile(file_name, ofstream::binary);
+    Network net = buildNetwork();
+    for (int i = 0; i < net.getNumLayers(); i++) net.getLayer(i)->savePlaintextParameters(&outfile);
+    outfile.close();
+    return net;
+}

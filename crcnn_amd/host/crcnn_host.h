@@ -1,0 +1,220 @@
+// crcnn_host.h -- C++ host side of the engine: the reference's layer / network / builder interface, same names, same
+// constructor argument order, same error behaviour (exceptions), implemented purely on the C ABI of include/crcnn_hip.h.
+//
+// What differs from CrCNN by design (MI355X-first):
+//   * `ciphertext3D` is a handle to a device-resident tensor of ciphertexts [B][z][x][y] (B = image batch, 1 for the
+//     reference's single-image calls) instead of nested std::vectors of SEAL objects (CrCNN/src/globals.h:10-16);
+//     copying the handle is cheap, layers never modify their argument.
+//   * `Plaintext` keeps the sparse balanced-ternary coefficients of an encoded weight (<= 96 non-zeros) instead of a dense
+//     n+1 word array; its save/load wire format is SEAL's (plaintext.cpp:346-363) so encoded-model files interchange.
+//   * th_count arguments are accepted and ignored (parallelism is the GPU's).
+#pragma once
+#include <cstdint>
+#include <istream>
+#include <memory>
+#include <ostream>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+#include "../../include/crcnn_hip.h"
+
+// ---- plaintext / tensor types (CrCNN/src/globals.h:10-16) -----------------------------------------------------------
+class Plaintext {
+public:
+    int coeff_count_ = 0;                                   // SEAL's Plaintext::coeff_count()
+    std::vector<std::pair<int, uint64_t>> nz;               // (index, coefficient) for non-zero coefficients
+    int coeff_count() const { return coeff_count_; }
+    bool is_zero() const { return nz.empty(); }
+    void save(std::ostream &stream) const;                  // SEAL wire format: int32 coeff_count, then uint64 coefficients
+    void load(std::istream &stream);
+    void dense(uint64_t *out, int n) const;                 // zero-extended to n coefficients
+};
+typedef std::vector<std::vector<std::vector<Plaintext>>> plaintext3D;
+typedef std::vector<std::vector<Plaintext>> plaintext2D;
+typedef std::vector<std::vector<std::vector<std::vector<Plaintext>>>> plaintext4D;
+typedef std::vector<std::vector<std::vector<std::vector<float>>>> floatHypercube;
+typedef std::vector<std::vector<std::vector<float>>> floatCube;
+
+struct DeviceBuffer { void *ptr = nullptr; size_t bytes = 0; DeviceBuffer(size_t b); ~DeviceBuffer(); DeviceBuffer(const DeviceBuffer &) = delete; DeviceBuffer &operator=(const DeviceBuffer &) = delete; };
+
+class ciphertext3D {          // device tensor of size-2 ciphertexts, [B][zd][xd][yd]
+public:
+    int B = 0, zd = 0, xd = 0, yd = 0, form = CRC_COEFF;
+    std::shared_ptr<DeviceBuffer> buf;
+    ciphertext3D() {}
+    ciphertext3D(int B, int zd, int xd, int yd, int form = CRC_COEFF);
+    size_t count() const { return (size_t)B * zd * xd * yd; }
+    uint64_t *data() const { return buf ? (uint64_t *)buf->ptr : nullptr; }
+    // CrCNN code indexes input[0].size() etc.; the equivalents:
+    int size() const { return zd; }
+    static ciphertext3D fromHost(const uint64_t *h, int B, int zd, int xd, int yd);    // h: [B][zd][xd][yd][2][k][n]
+    std::vector<uint64_t> toHost() const;
+};
+ciphertext3D stackImages(const std::vector<ciphertext3D> &images);      // B=1 tensors -> one batch
+ciphertext3D deepCopyImage(const ciphertext3D &image);                  // globals.cpp:159-171
+
+// ---- process-global crypto context (CrCNN/src/globals.h:18-48) --------------------------------------------------------
+extern crc_ctx *context;                                    // the engine context (SEALContext + Evaluator tables)
+extern std::vector<uint64_t> secret_key, public_key, ev_keys16_host;
+extern std::shared_ptr<DeviceBuffer> ev_keys16;             // evaluation keys, dbc = 16, resident in HBM
+extern uint64_t crcnn_seed;                                 // seed of the client-side RNG (keygen / encryption)
+void setParameters(int poly_modulus = 4096, uint64_t plain_modulus = 1 << 20);          // coeff_modulus_128(poly_modulus)
+void setParameters(int poly_modulus, const std::vector<uint64_t> &coeff_modulus, uint64_t plain_modulus, int device = 0);
+void delParameters();
+Plaintext fraencode(double value);                          // fraencoder->encode(value)
+double fradecode(const std::vector<uint64_t> &plain);
+ciphertext3D encryptImage(std::vector<float> image, int zd, int xd, int yd);             // globals.cpp:127-142
+ciphertext3D encryptImage(floatCube image);                                              // globals.cpp:144-157
+std::vector<floatCube> decryptImages(const ciphertext3D &encrypted);                     // one floatCube per image of the batch
+floatCube decryptImage(const ciphertext3D &encrypted_image);                             // globals.cpp:207-230 (B must be 1)
+int noiseBudget(const ciphertext3D &t, size_t index = 0);
+
+// ---- layers (CrCNN/src/layer.h:10-31) ------------------------------------------------------------------------------
+class Layer {
+public:
+    std::string name;
+    int out_form = CRC_COEFF;                               // CRC_NTT keeps the output NTT-resident (set by Network::forward)
+    Layer() {}
+    Layer(std::string layer_name) : name(layer_name) {}
+    virtual ~Layer() {}
+    std::string getName() { return name; }
+    virtual void printLayerStructure() = 0;
+    virtual ciphertext3D forward(ciphertext3D input) = 0;
+    virtual void savePlaintextParameters(std::ostream *outfile) = 0;
+    virtual void loadPlaintextParameters(std::istream *infile) = 0;
+    virtual bool linear() const { return true; }            // false: needs coefficient-form input (Square)
+    void computeBoundaries(int xd, int yd, int xs, int ys, int xf, int yf, int *xl, int *yl);   // layer.cpp:12-26
+};
+
+class ConvolutionalLayer : public Layer {                   // convolutionalLayer.h:33-34
+public:
+    int xd, yd, zd, xs, ys, xf, yf, nf, th_count;
+    int xo, yo, zo;
+    plaintext4D filters;                                    // nf,zd,xf,yf
+    std::vector<Plaintext> biases;
+    bool filters_already_ntt = false;
+    ConvolutionalLayer(std::string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf, int nf, int th_count, plaintext4D &filters, std::vector<Plaintext> &biases);
+    ConvolutionalLayer(std::string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf, int nf, int th_count, std::istream *infile);
+    ciphertext3D forward(ciphertext3D input) override;
+    plaintext3D getKernel(int kernel_index) { return filters[kernel_index]; }
+    Plaintext getBias(int bias_index) { return biases[bias_index]; }
+    void savePlaintextParameters(std::ostream *outfile) override;
+    void loadPlaintextParameters(std::istream *infile) override;
+    void printLayerStructure() override;
+private:
+    std::shared_ptr<DeviceBuffer> d_w, d_b[2], d_work;      // NTT-form weights, bias delta in coefficient / NTT form
+    void upload();
+};
+
+class FullyConnectedLayer : public Layer {                  // fullyConnectedLayer.h:22-24
+public:
+    int in_dim, out_dim, th_count;
+    plaintext2D weights;
+    std::vector<Plaintext> biases;
+    bool weights_already_ntt = false;
+    FullyConnectedLayer(std::string name, int in_dim, int out_dim, int th_count, plaintext2D &weights, std::vector<Plaintext> &biases);
+    FullyConnectedLayer(std::string name, int in_dim, int out_dim, int th_count, std::istream *infile);
+    ciphertext3D forward(ciphertext3D input) override;
+    Plaintext getWeight(int x_index, int y_index) { return weights[x_index][y_index]; }
+    Plaintext getBias(int x_index) { return biases[x_index]; }
+    void savePlaintextParameters(std::ostream *outfile) override;
+    void loadPlaintextParameters(std::istream *infile) override;
+    void printLayerStructure() override;
+private:
+    std::shared_ptr<DeviceBuffer> d_w, d_b[2], d_work;
+    void upload();
+};
+
+class PoolingLayer : public Layer {                         // poolingLayer.h:15
+public:
+    int xd, yd, zd, xs, ys, xf, yf, xo, yo, zo;
+    PoolingLayer(std::string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf);
+    ciphertext3D forward(ciphertext3D input) override;
+    void savePlaintextParameters(std::ostream *) override {}
+    void loadPlaintextParameters(std::istream *) override {}
+    void printLayerStructure() override;
+protected:
+    std::shared_ptr<DeviceBuffer> d_div;                    // NTT-form divisor (AvgPoolingLayer only)
+};
+
+class AvgPoolingLayer : public PoolingLayer {               // avgPoolingLayer.h:11
+public:
+    Plaintext div_factor;
+    AvgPoolingLayer(std::string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf);
+};
+
+class SquareLayer : public Layer {                          // squareLayer.h:12
+public:
+    int th_count;
+    SquareLayer(std::string name, int th_count) : Layer(name), th_count(th_count) {}
+    ciphertext3D forward(ciphertext3D input) override;
+    void savePlaintextParameters(std::ostream *) override {}
+    void loadPlaintextParameters(std::istream *) override {}
+    void printLayerStructure() override;
+    bool linear() const override { return false; }
+private:
+    std::shared_ptr<DeviceBuffer> d_work;
+};
+
+class BatchNormLayer : public Layer {                       // batchNormLayer.h:18-20
+public:
+    int num_channels;
+    std::vector<Plaintext> mean, var;                       // var already holds encode(1/sqrt(var+1e-5)) (cnnBuilder.cpp:100-102)
+    BatchNormLayer(std::string name, int num_channels, std::vector<Plaintext> &mean, std::vector<Plaintext> &var);
+    BatchNormLayer(std::string name, int num_channels, std::istream *infile);
+    ciphertext3D forward(ciphertext3D input) override;
+    Plaintext getMean(int index) { return mean[index]; }
+    Plaintext getVar(int index) { return var[index]; }
+    void savePlaintextParameters(std::ostream *outfile) override;
+    void loadPlaintextParameters(std::istream *infile) override;
+    void printLayerStructure() override;
+private:
+    std::shared_ptr<DeviceBuffer> d_mean[2], d_invstd;
+    void upload();
+};
+
+// ---- network (CrCNN/src/network.h:11-39) ---------------------------------------------------------------------------
+class OutOfBudgetException : public std::exception {
+public:
+    const int last_layer_computed;
+    std::string msg;
+    OutOfBudgetException(int last_layer_computed) : last_layer_computed(last_layer_computed), msg("OutOfBudgetException at layer " + std::to_string(last_layer_computed)) {}
+    const char *what() const throw() override { return msg.c_str(); }
+};
+
+class Network {
+public:
+    std::vector<std::shared_ptr<Layer>> layers;
+    // network.cpp:23 hard-codes a client-side decrypt/re-encrypt "refresh" before layer 6; it needs the secret key and is off
+    // the accelerated path, so it is a setting here: 6 reproduces the committed reference, -1 (default) never refreshes.
+    int layer_before_reenc = -1;
+    bool ntt_resident = true;                               // keep tensors in NTT form between linear layers (bit-identical)
+    std::vector<double> last_layer_ms;                      // per-layer wall milliseconds of the last forward (T_LAYER_i, mainparams.cpp:81)
+    Network() {}
+    ~Network() {}
+    int getNumLayers() { return (int)layers.size(); }
+    virtual std::shared_ptr<Layer> getLayer(int i) { return layers[i]; }
+    std::vector<std::shared_ptr<Layer>> &getLayers() { return layers; }
+    void printNetworkStructure();
+    ciphertext3D forward(ciphertext3D input);
+};
+
+// ---- model loader + builder (CrCNN/src/cnnBuilder.h:16-44) ----------------------------------------------------------
+class CnnBuilder {
+public:
+    std::string plain_model_path;
+    CnnBuilder(std::string plain_model_path) : plain_model_path(plain_model_path) {}
+    ~CnnBuilder() {}
+    std::vector<float> getPretrained(std::string var_name);
+    ConvolutionalLayer *buildConvolutionalLayer(std::string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf, int nf, int th_count, std::istream *infile);
+    FullyConnectedLayer *buildFullyConnectedLayer(std::string name, int in_dim, int out_dim, int th_count, std::istream *infile);
+    PoolingLayer *buildPoolingLayer(std::string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf);
+    AvgPoolingLayer *buildAvgPoolingLayer(std::string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf);
+    SquareLayer *buildSquareLayer(std::string name, int th_count);
+    BatchNormLayer *buildBatchNormLayer(std::string name, int num_channels, std::istream *infile);
+    // cnnBuilder.cpp:108-179 hard-codes one topology per source edit (Tiny is the committed one); all three are available here
+    Network buildNetwork(std::string file_name = "");                  // PlainModelTiny, as committed (cnnBuilder.cpp:157-169)
+    Network buildNetworkByName(const std::string &model, std::string file_name = "");   // "PlainModelTiny" | "ApproxPlainModel" | "PlainModelWoPad"
+    Network buildAndSaveNetwork(std::string file_name);
+};

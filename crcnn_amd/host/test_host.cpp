@@ -1,0 +1,141 @@
+// test_host.cpp -- driver for the C++ host classes, run by tests/test_gpu_host_cpp.py on the GPU box.
+//   test_host net <model> <h5> <dir> <resident 0|1> <batch>
+//     <dir>/params.u64 (n,k,t,q...), evk.u64, net_in.u64 ([1][1][28][28][2][k][n]) -> writes layer_<i>.u64 (layerwise mode) and out.u64
+//   test_host api <h5> <dir>     exercises save/load of the encoded model, client-side encrypt/decrypt, and error behaviour
+#include "crcnn_host.h"
+#include <cmath>
+#include <cstdio>
+#include <sstream>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+using namespace std;
+typedef uint64_t u64;
+
+static vector<u64> rd(const string &p)
+{
+    ifstream f(p, ios::binary); if (!f) { fprintf(stderr, "missing %s\n", p.c_str()); exit(2); }
+    f.seekg(0, ios::end); size_t sz = f.tellg(); f.seekg(0); vector<u64> v(sz / 8); f.read((char *)v.data(), sz); return v;
+}
+static void wr(const string &p, const vector<u64> &v) { ofstream f(p, ios::binary); f.write((const char *)v.data(), v.size() * 8); }
+
+static void setup(const string &dir)
+{
+    auto p = rd(dir + "/params.u64");
+    int n = (int)p[0], k = (int)p[1]; u64 t = p[2];
+    setParameters(n, vector<u64>(p.begin() + 3, p.begin() + 3 + k), t, 0);
+}
+
+static int do_net(int argc, char **argv)
+{
+    if (argc < 7) return 1;
+    string model = argv[2], h5 = argv[3], dir = argv[4]; bool resident = atoi(argv[5]); int batch = atoi(argv[6]);
+    setup(dir);
+    ifstream evf(dir + "/evk.u64", ios::binary);
+    if (evf) {            // use the caller's evaluation keys (ev_keys16 is a public global in the reference as well, globals.h:26)
+        auto evk = rd(dir + "/evk.u64");
+        ev_keys16 = make_shared<DeviceBuffer>(evk.size() * 8);
+        crc_memcpy_h2d(context, ev_keys16->ptr, evk.data(), evk.size() * 8, nullptr); crc_stream_sync(context, nullptr);
+    }
+    CnnBuilder builder(h5);
+    Network net = builder.buildNetworkByName(model);
+    net.ntt_resident = resident;
+    auto x = rd(dir + "/net_in.u64");
+    vector<ciphertext3D> imgs;
+    for (int b = 0; b < batch; b++) imgs.push_back(ciphertext3D::fromHost(x.data(), 1, 1, 28, 28));
+    ciphertext3D in = stackImages(imgs);
+    if (!resident) {      // layer by layer, coefficient form at every boundary: dump each output for the per-layer digests
+        ciphertext3D t = in;
+        for (int i = 0; i < net.getNumLayers(); i++) {
+            net.getLayer(i)->out_form = CRC_COEFF;
+            t = net.getLayer(i)->forward(t);
+            wr(dir + "/layer_" + to_string(i) + ".u64", t.toHost());
+        }
+        wr(dir + "/out.u64", t.toHost());
+    } else {
+        ciphertext3D out = net.forward(in);
+        wr(dir + "/out.u64", out.toHost());
+        for (double ms : net.last_layer_ms) fprintf(stderr, "%.3f,", ms);
+        fprintf(stderr, "\n");
+    }
+    delParameters();
+    return 0;
+}
+
+#define EXPECT_THROW(stmt, type) do { bool ok_ = false; try { stmt; } catch (const type &) { ok_ = true; } catch (...) {} if (!ok_) { fprintf(stderr, "expected " #type " from: " #stmt "\n"); return 3; } } while (0)
+
+static int do_api(int argc, char **argv)
+{
+    if (argc < 4) return 1;
+    string h5 = argv[2], dir = argv[3];
+    EXPECT_THROW(fraencode(1.0), logic_error);                         // context not set
+    EXPECT_THROW(setParameters(4095, 1 << 20), invalid_argument);      // not a power of two
+    setParameters(1024, {0x7fffffff380001ULL, 0x3fffffff000001ULL}, 1ULL << 20, 0);
+    // client side round trip (encryptImage / decryptImage, globals.cpp:127-157,207-230)
+    vector<float> img(28 * 28); for (int i = 0; i < 784; i++) img[i] = (float)((i % 17) - 8) / 4.0f;
+    ciphertext3D ct = encryptImage(img, 1, 28, 28);
+    floatCube back = decryptImage(ct);
+    for (int i = 0; i < 28; i++) for (int j = 0; j < 28; j++) if (fabs(back[0][i][j] - img[i * 28 + j]) > 1e-6) { fprintf(stderr, "decrypt mismatch\n"); return 4; }
+    if (noiseBudget(ct) < 20) { fprintf(stderr, "budget too small\n"); return 4; }
+    // a tiny layer stack: conv -> avgpool -> square -> fc, resident vs layerwise must give identical ciphertexts
+    vector<float> w(2 * 1 * 3 * 3), b(2), fw(3 * 2 * 6 * 6), fb(3);
+    for (size_t i = 0; i < w.size(); i++) w[i] = 0.05f * (float)((int)(i % 7) - 3);
+    b[0] = 0.1f; b[1] = -0.2f;
+    for (size_t i = 0; i < fw.size(); i++) fw[i] = 0.01f * (float)((int)(i % 11) - 5);
+    fb = {0.5f, -0.25f, 0.125f};
+    auto enc = [&](float v) { return fraencode((double)v); };
+    plaintext4D ew(2, plaintext3D(1, plaintext2D(3, vector<Plaintext>(3)))); vector<Plaintext> eb(2);
+    for (int f = 0; f < 2; f++) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) ew[f][0][i][j] = enc(w[(f * 3 + i) * 3 + j]); eb[f] = enc(b[f]); }
+    plaintext2D efw(3, vector<Plaintext>(72)); vector<Plaintext> efb(3);
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 72; j++) efw[i][j] = enc(fw[i * 72 + j]); efb[i] = enc(fb[i]); }
+    vector<float> small(14 * 14); for (int i = 0; i < 196; i++) small[i] = (float)((i * 7) % 13 - 6) / 8.0f;
+    ciphertext3D x = encryptImage(small, 1, 14, 14);
+    Network net;
+    net.getLayers().push_back(shared_ptr<Layer>(new ConvolutionalLayer("c", 14, 14, 1, 1, 1, 3, 3, 2, 4, ew, eb)));
+    net.getLayers().push_back(shared_ptr<Layer>(new AvgPoolingLayer("p", 12, 12, 2, 2, 2, 2, 2)));
+    net.getLayers().push_back(shared_ptr<Layer>(new SquareLayer("s", 2)));
+    net.getLayers().push_back(shared_ptr<Layer>(new FullyConnectedLayer("f", 72, 3, 2, efw, efb)));
+    net.ntt_resident = true;  vector<u64> r1 = net.forward(x).toHost();
+    net.ntt_resident = false; ciphertext3D o2 = net.forward(x); vector<u64> r2 = o2.toHost();
+    if (r1 != r2) { fprintf(stderr, "resident and layerwise outputs differ\n"); return 5; }
+    // semantic check against float arithmetic
+    floatCube dec = decryptImage(o2);
+    double conv[2][12][12], pool[2][6][6];
+    for (int f = 0; f < 2; f++) for (int i = 0; i < 12; i++) for (int j = 0; j < 12; j++) { double s = b[f]; for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) s += (double)w[(f * 3 + a) * 3 + c] * small[(i + a) * 14 + j + c]; conv[f][i][j] = s; }
+    for (int f = 0; f < 2; f++) for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { double s = (conv[f][2*i][2*j] + conv[f][2*i][2*j+1] + conv[f][2*i+1][2*j] + conv[f][2*i+1][2*j+1]) / 4; pool[f][i][j] = s * s; }
+    for (int o = 0; o < 3; o++) { double s = fb[o]; for (int f = 0; f < 2; f++) for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) s += (double)fw[o * 72 + (f * 6 + i) * 6 + j] * pool[f][i][j];
+        if (fabs(s - dec[0][o][0]) > 1e-4) { fprintf(stderr, "semantic mismatch %d: %f vs %f\n", o, s, dec[0][o][0]); return 6; } }
+    // refresh path (network.cpp:30-34) keeps the result
+    net.layer_before_reenc = 3; floatCube dec2 = decryptImage(net.forward(x)); net.layer_before_reenc = -1;
+    for (int o = 0; o < 3; o++) if (fabs(dec2[0][o][0] - dec[0][o][0]) > 1e-4) { fprintf(stderr, "refresh changed the result\n"); return 7; }
+    // save / load of the encoded parameters in SEAL's Plaintext wire format (savePlaintextParameters / istream ctor)
+    { ofstream f(dir + "/enc_model.bin", ios::binary); for (int i = 0; i < net.getNumLayers(); i++) net.getLayer(i)->savePlaintextParameters(&f); }
+    { ifstream f(dir + "/enc_model.bin", ios::binary);
+      Network n2;
+      n2.getLayers().push_back(shared_ptr<Layer>(new ConvolutionalLayer("c", 14, 14, 1, 1, 1, 3, 3, 2, 4, &f)));
+      n2.getLayers().push_back(shared_ptr<Layer>(new AvgPoolingLayer("p", 12, 12, 2, 2, 2, 2, 2)));
+      n2.getLayers().push_back(shared_ptr<Layer>(new SquareLayer("s", 2)));
+      n2.getLayers().push_back(shared_ptr<Layer>(new FullyConnectedLayer("f", 72, 3, 2, &f)));
+      if (n2.forward(x).toHost() != r1) { fprintf(stderr, "reloaded network differs\n"); return 8; } }
+    // error behaviour mirrors the reference (std::invalid_argument on bad shapes / truncated streams)
+    EXPECT_THROW(net.getLayer(0)->forward(ciphertext3D(1, 1, 10, 10)), invalid_argument);
+    { istringstream empty(""); EXPECT_THROW(FullyConnectedLayer("f", 4, 2, 1, &empty), invalid_argument); }
+    EXPECT_THROW(CnnBuilder("/nonexistent.h5").getPretrained("x"), runtime_error);
+    // HDF5 loader through the builder
+    CnnBuilder builder(h5);
+    if (builder.getPretrained("pool1_features.conv1.weight").size() != 800) return 9;
+    net.printNetworkStructure();
+    delParameters();
+    printf("api ok\n");
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) return 1;
+    try {
+        if (!strcmp(argv[1], "net")) return do_net(argc, argv);
+        if (!strcmp(argv[1], "api")) return do_api(argc, argv);
+    } catch (const exception &e) { fprintf(stderr, "exception: %s\n", e.what()); return 10; }
+    return 1;
+}
