@@ -193,12 +193,9 @@ def main():
     torch.cuda.synchronize()
     bcast_s = 0.0
     if world > 1:
+        from crcnn_amd import shard
         dist.barrier(); t0 = time.time()
-        for buf, nbytes in net.param_bufs:
-            flat = buf.view(-1)
-            step = (1 << 30) // 8
-            for o in range(0, flat.numel(), step):
-                dist.broadcast(flat[o:o + step], src=0)
+        shard.broadcast_buffers([buf for buf, _ in net.param_bufs], src=0, chunk_bytes=1 << 30)      # RCCL over xGMI
         torch.cuda.synchronize(); bcast_s = time.time() - t0
     net.prepare(C)
     torch.cuda.synchronize()
@@ -237,7 +234,8 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
+        from crcnn_amd import shard
+        elapsed = shard.max_over_ranks(elapsed, dev)
 
     # ---- per-layer times of the last step (HIP events on the launch stream)
     lay_ms = np.zeros(nl); lay_launch = np.zeros(nl); lay_cnt = np.zeros(nl)

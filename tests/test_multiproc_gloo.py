@@ -1,0 +1,69 @@
+"""world_size-2 test of the N>1 plumbing on CPU (gloo): shard ranges partition the batch, the weight broadcast delivers
+rank 0's buffers bit-exactly in chunks, timing is the max over ranks.  (The kernels themselves need a GPU; what is multi-
+process about the path is exactly this plumbing -- there is no data-path collective.)"""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    from crcnn_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # weights: rank 0 holds the encoded parameters, the others allocate empty buffers of the same shapes
+        g = torch.Generator().manual_seed(1234)
+        ref = [torch.randint(0, 1 << 62, (n,), dtype=torch.int64, generator=g) for n in (1000, 70001, 3)]
+        bufs = [r.clone() if rank == 0 else torch.zeros_like(r) for r in ref]
+        sent = shard.broadcast_buffers(bufs, src=0, chunk_bytes=64 * 1024)        # forces multi-piece broadcasts
+        ok_bcast = all(torch.equal(a, b) for a, b in zip(bufs, ref)) and sent == sum(r.numel() * 8 for r in ref)
+        # image sharding
+        b, e = shard.shard_range(1027, rank, world)
+        total = shard.gather_counts(e - b, torch.device("cpu"))
+        # timing = max over ranks
+        tmax = shard.max_over_ranks(1.0 + rank, torch.device("cpu"))
+        dist.barrier()
+        out.put((rank, ok_bcast, (b, e), total, tmax))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_process_plumbing():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res)
+    assert res[0][2] == (0, 514) and res[1][2] == (514, 1027)
+    assert all(r[3] == 1027 for r in res)
+    assert all(r[4] == 2.0 for r in res)
+
+
+def test_shard_range_partitions():
+    sys.path.insert(0, ROOT)
+    from crcnn_amd import shard
+    for total in (0, 1, 7, 8, 1024, 8192):
+        for world in (1, 2, 3, 8):
+            ranges = [shard.shard_range(total, r, world) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == total
+            assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+            sizes = [e - b for b, e in ranges]
+            assert max(sizes) - min(sizes) <= 1
