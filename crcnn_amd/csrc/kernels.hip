@@ -437,13 +437,14 @@ int k_mac(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, con
 // Workgroups are numbered so that the 32 CUs of an XCD work on the same slot block and neighbouring tiles at the same
 // time: their shared operands are served by that XCD's L2 instead of HBM.
 // ---------------------------------------------------------------------------------------------------------------
-template <int PX, int FT, int WM, int WN, int S>
+template <int PX, int FT, int WM, int WN, int S, int DEPTH = 2>
 __global__ void __launch_bounds__(64 * WM * WN) mac2_kernel(MacArgs a)
 {
     constexpr int NW = WM * WN, MT = PX * WM, ROWS = 2 * MT, FW = FT * WN;
-    constexpr int VEC = S * (ROWS + FW), RLOAD = (VEC + NW - 1) / NW;
+    constexpr int VEC = S * (ROWS + FW), NPAIR = VEC / 2, RLOAD = 2 * ((NPAIR + NW - 1) / NW);      // operand vectors are staged in (even, odd) pairs
+    static_assert(FT % 2 == 0 && (ROWS + FW) % 2 == 0, "pairs");
     constexpr u64 MASK28 = (1ULL << 28) - 1;
-    extern __shared__ u64 smem[];                     // 2 x [S][ROWS + FW][64]
+    extern __shared__ __attribute__((aligned(16))) u64 smem[];      // 2 x [S][(ROWS + FW)/2 pairs][64 lanes][2]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave / WN, wn = wave % WN;
     const int n = a.n, k = a.k;
     const int M = a.B * a.P;
@@ -463,8 +464,8 @@ __global__ void __launch_bounds__(64 * WM * WN) mac2_kernel(MacArgs a)
     const u64 *vbase[RLOAD]; int vstep[RLOAD]; bool visx[RLOAD];
 #pragma unroll
     for (int j = 0; j < RLOAD; j++) {
-        const int v = wave + j * NW;
-        const int vv = min(v, VEC - 1);                  // surplus slots (VEC not a multiple of NW) re-load the last vector, never stored
+        const int v = 2 * (wave + (j >> 1) * NW) + (j & 1);
+        const int vv = min(v, VEC - 1);                  // surplus slots (NPAIR not a multiple of NW) re-load the last vector, never stored
         const int e = vv % (ROWS + FW);
         vstep[j] = vv / (ROWS + FW);
         if (e < ROWS) {
@@ -483,51 +484,61 @@ __global__ void __launch_bounds__(64 * WM * WN) mac2_kernel(MacArgs a)
         for (int f = 0; f < FT; f++) { A0[r][f] = 0; A1[r][f] = 0; A2[r][f] = 0; OV[r][f] = 0; }
 
     u64 regA[RLOAD], regB[RLOAD];          // two register stages: operand loads run TWO pipeline stages ahead of their use
-    // per-stage x offsets come from the padded toffw table as ONE scalar load (S consecutive entries), fetched a stage ahead
-    unsigned tw_cur[S], tw_nxt[S];
-#pragma unroll
-    for (int q = 0; q < S; q++) { tw_cur[q] = a.toffw[q]; tw_nxt[q] = a.toffw[S + q]; }
+    // per-term x offsets: the padded toffw table is copied into LDS once (scalar loads inside the loop would share lgkmcnt
+    // with the LDS operand reads and stall them); lanes read the same word (broadcast)
+    u32 *tw = reinterpret_cast<u32 *>(smem + (size_t)2 * VEC * 64);
+    for (int t = threadIdx.x; t < a.T + 8; t += blockDim.x) tw[t] = a.toffw[t];
+    __syncthreads();                                 // the table is read by every wave from the first load_stage on
     const u32 kn32 = (u32)kn;
-    auto load_stage = [&](int st, u64 (&reg)[RLOAD]) {          // called with st = 0, 1, 2, ... in order
+    auto load_stage = [&](int st, u64 (&reg)[RLOAD]) {
+        if (st > 1 && (a.dbg == 1 || a.dbg == 2 || a.dbg == 4)) return;
 #pragma unroll
         for (int j = 0; j < RLOAD; j++) {
-            u32 off = tw_cur[0];
-#pragma unroll
-            for (int q = 1; q < S; q++) off = vstep[j] == q ? tw_cur[q] : off;
-            const u32 tclamp = (u32)min(st * S + vstep[j], a.T - 1);
-            off = visx[j] ? off : tclamp * kn32;
+            const int t = min(st * S + vstep[j], a.T - 1);
+            const u32 off = visx[j] ? tw[t] : (u32)t * kn32;
             reg[j] = vbase[j][(size_t)(off + (u32)rown)];      // consumed only in store_stage: the loads stay in flight meanwhile
         }
-#pragma unroll
-        for (int q = 0; q < S; q++) { tw_cur[q] = tw_nxt[q]; tw_nxt[q] = a.toffw[min((st + 2) * S, a.T) + q]; }
     };
     auto store_stage = [&](int st, u64 (&reg)[RLOAD]) {
-        u64 *dst = smem + (size_t)(st & 1) * VEC * 64;
+        if (st > 1 && (a.dbg == 1 || a.dbg == 2 || a.dbg == 3)) return;
+        ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(smem) + (size_t)(st & 1) * NPAIR * 64;
 #pragma unroll
-        for (int j = 0; j < RLOAD; j++) {
-            const int v = wave + j * NW;
-            const bool dead = !visx[j] && st * S + vstep[j] >= a.T;     // weights past the last term are zero (x may be anything valid)
-            const u64 r = dead ? 0 : reg[j];
-            if (v < VEC) dst[v * 64 + lane] = (r & MASK28) | ((r >> 28) << 32);      // pre-split once: low dword = x0 (28 bit), high dword = x1
+        for (int jj = 0; jj < RLOAD / 2; jj++) {
+            const int pr = wave + jj * NW;
+            ulonglong2 v;
+            {   const bool dead = !visx[2 * jj] && st * S + vstep[2 * jj] >= a.T;         // weights past the last term are zero (x may be anything valid)
+                const u64 r = dead ? 0 : reg[2 * jj]; v.x = (r & MASK28) | ((r >> 28) << 32); }     // pre-split once: low dword = x0 (28 bit), high dword = x1
+            {   const bool dead = !visx[2 * jj + 1] && st * S + vstep[2 * jj + 1] >= a.T;
+                const u64 r = dead ? 0 : reg[2 * jj + 1]; v.y = (r & MASK28) | ((r >> 28) << 32); }
+            if (pr < NPAIR) dst[pr * 64 + lane] = v;                                        // one ds_write_b128 per operand pair
         }
     };
     auto compute_stage = [&](int st) {
-        const u64 *buf = smem + (size_t)(st & 1) * VEC * 64;
+        const ulonglong2 *buf = reinterpret_cast<const ulonglong2 *>(smem) + (size_t)(st & 1) * NPAIR * 64;
 #pragma unroll 1
         for (int step = 0; step < S; step++) {
-            const u64 *sv = buf + step * (ROWS + FW) * 64 + lane;
+            const ulonglong2 *sv = buf + step * ((ROWS + FW) / 2) * 64 + lane;
             u32 w0[FT], w1[FT], ws[FT];
 #pragma unroll
-            for (int f = 0; f < FT; f++) { const u64 wv = sv[(ROWS + wn * FT + f) * 64]; w0[f] = (u32)wv; w1[f] = (u32)(wv >> 32); ws[f] = w0[f] + w1[f]; }
+            for (int f = 0; f < FT; f += 2) {
+                const ulonglong2 wv = sv[(ROWS / 2 + (wn * FT + f) / 2) * 64];
+                w0[f] = (u32)wv.x; w1[f] = (u32)(wv.x >> 32); ws[f] = w0[f] + w1[f];
+                w0[f + 1] = (u32)wv.y; w1[f + 1] = (u32)(wv.y >> 32); ws[f + 1] = w0[f + 1] + w1[f + 1];
+            }
 #pragma unroll
-            for (int r = 0; r < PX * 2; r++) {
-                const u64 xv = sv[(wm * PX * 2 + r) * 64];
-                const u32 x0 = (u32)xv, x1 = (u32)(xv >> 32), xs = x0 + x1;
+            for (int px = 0; px < PX; px++) {
+                const ulonglong2 xv = sv[(wm * PX + px) * 64];            // both polys of one pixel
 #pragma unroll
-                for (int f = 0; f < FT; f++) {
-                    A0[r][f] += (u64)x0 * w0[f];
-                    A2[r][f] += (u64)x1 * w1[f];
-                    A1[r][f] += (u64)xs * ws[f];
+                for (int c = 0; c < 2; c++) {
+                    const u64 xc = c ? xv.y : xv.x;
+                    const u32 x0 = (u32)xc, x1 = (u32)(xc >> 32), xs = x0 + x1;
+                    const int r = px * 2 + c;
+#pragma unroll
+                    for (int f = 0; f < FT; f++) {
+                        A0[r][f] += (u64)x0 * w0[f];
+                        A2[r][f] += (u64)x1 * w1[f];
+                        A1[r][f] += (u64)xs * ws[f];
+                    }
                 }
             }
         }
@@ -544,17 +555,27 @@ __global__ void __launch_bounds__(64 * WM * WN) mac2_kernel(MacArgs a)
 
     const int nstages = (a.T + S - 1) / S;
     load_stage(0, regA); store_stage(0, regA);
-    if (nstages > 1) load_stage(1, regA);
-    __syncthreads();
-    for (int st = 0; st < nstages; st += 2) {
-        if (st + 2 < nstages) load_stage(st + 2, regB);
-        compute_stage(st);
-        if (st + 1 < nstages) store_stage(st + 1, regA);
+    if (DEPTH == 2) {
+        if (nstages > 1) load_stage(1, regA);
         __syncthreads();
-        if (st + 1 < nstages) {
-            if (st + 3 < nstages) load_stage(st + 3, regA);
-            compute_stage(st + 1);
-            if (st + 2 < nstages) store_stage(st + 2, regB);
+        for (int st = 0; st < nstages; st += 2) {
+            if (st + 2 < nstages) load_stage(st + 2, regB);
+            compute_stage(st);
+            if (st + 1 < nstages) store_stage(st + 1, regA);
+            __syncthreads();
+            if (st + 1 < nstages) {
+                if (st + 3 < nstages) load_stage(st + 3, regA);
+                compute_stage(st + 1);
+                if (st + 2 < nstages) store_stage(st + 2, regB);
+                __syncthreads();
+            }
+        }
+    } else {
+        __syncthreads();
+        for (int st = 0; st < nstages; st++) {
+            if (st + 1 < nstages) load_stage(st + 1, regA);
+            compute_stage(st);
+            if (st + 1 < nstages) store_stage(st + 1, regA);
             __syncthreads();
         }
     }
@@ -591,15 +612,16 @@ __global__ void __launch_bounds__(64 * WM * WN) mac2_kernel(MacArgs a)
     }
 }
 
-template <int PX, int FT, int WM, int WN, int S>
+template <int PX, int FT, int WM, int WN, int S, int DEPTH = 2>
 static int mac2_launch(crc_ctx *c, MacArgs &a, hipStream_t st)
 {
     constexpr int MT = PX * WM, FW = FT * WN, VEC = S * (2 * MT + FW);
     const int M = a.B * a.P;
     const size_t grid = (size_t)((M + MT - 1) / MT) * ((a.F + FW - 1) / FW) * (size_t)((c->n >> 6) * c->k);
     if (grid > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
-    const size_t lds = (size_t)2 * VEC * 64 * 8;
-    auto kern = mac2_kernel<PX, FT, WM, WN, S>;
+    if (a.T + 8 > 16384) return CRC_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)2 * VEC * 64 * 8 + (size_t)(a.T + 8) * 4;
+    auto kern = mac2_kernel<PX, FT, WM, WN, S, DEPTH>;
     if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WM * WN), lds, st, a);
     HIPCHK(hipGetLastError());
@@ -611,7 +633,7 @@ int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, co
 {
     if (B == 0 || P == 0 || F == 0) return CRC_OK;
     int maxbits = 0; for (int i = 0; i < c->k; i++) if ((int)c->tabs[i].m.bits > maxbits) maxbits = c->tabs[i].m.bits;
-    if (maxbits > 55 || T > 32768 || c->n < 64) return k_mac(c, x, w, y, d_xoff, d_toff, B, P, F, T, in_cts, bias_ntt, st);
+    if (maxbits > 55 || T > 16000 || c->n < 64) return k_mac(c, x, w, y, d_xoff, d_toff, B, P, F, T, in_cts, bias_ntt, st);
     MacArgs a{};
     a.x = x; a.w = w; a.y = y; a.mods = c->d_mods; a.xoff = d_xoff; a.toff = d_toff; a.toffw = d_toffw;
     a.n = c->n; a.k = c->k; a.B = B; a.P = P; a.F = F; a.T = T; a.in_cts = in_cts; a.bias = bias_ntt; a.bias_sign = 1;
@@ -620,14 +642,11 @@ int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, co
     // tile configuration <PX, FT, WM, WN, S>; CRC_MAC2_CFG selects an alternative for tuning runs (tools/bench_mac.py)
     static const int cfg = [] { const char *e = getenv("CRC_MAC2_CFG"); return e ? atoi(e) : 0; }();
     switch (cfg) {
-    case 1: return mac2_launch<3, 4, 2, 4, 3>(c, a, st);
-    case 2: return mac2_launch<2, 4, 2, 4, 4>(c, a, st);
-    case 3: return mac2_launch<2, 4, 2, 4, 2>(c, a, st);
-    case 4: return mac2_launch<3, 4, 4, 2, 2>(c, a, st);
-    case 5: return mac2_launch<4, 3, 2, 4, 2>(c, a, st);
-    case 6: return mac2_launch<2, 6, 4, 2, 2>(c, a, st);
     case 7: return mac2_launch<3, 4, 2, 2, 2>(c, a, st);
-    case 8: return mac2_launch<3, 4, 2, 2, 4>(c, a, st);
+    case 8: return mac2_launch<3, 4, 2, 4, 4, 1>(c, a, st);
+    case 9: return mac2_launch<3, 4, 2, 4, 2, 1>(c, a, st);
+    case 10: return mac2_launch<3, 4, 2, 4, 5, 1>(c, a, st);
+    case 11: return mac2_launch<3, 4, 2, 4, 3, 2>(c, a, st);
     default: return mac2_launch<3, 4, 2, 4, 2>(c, a, st);
     }
 }
