@@ -255,22 +255,21 @@ extern "C" int crc_ctx_create(int n, const uint64_t *q, int k, uint64_t t, int d
         auto fail = [&](hipError_t e) { rc = crc_set_hip_error(e); };
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) { fail(e); delete c; return rc; }
-        int nm = k + c->kb; size_t tw = (size_t)nm * n * 8;
+        int nm = k + c->kb; size_t tw = (size_t)nm * n * 16;      // {twiddle, Shoup companion} interleaved: one 16-byte load per butterfly
         std::vector<ModParams> mods(nm);
-        std::vector<u64> rp((size_t)nm * n), srp(rp.size()), irp2(rp.size()), sirp2(rp.size());
+        std::vector<u64> rp((size_t)nm * n * 2), irp2(rp.size());
         for (int m = 0; m < nm; m++) {
             mods[m] = c->tabs[m].m;
-            memcpy(&rp[(size_t)m * n], c->tabs[m].rp.data(), 8 * (size_t)n); memcpy(&srp[(size_t)m * n], c->tabs[m].srp.data(), 8 * (size_t)n);
-            memcpy(&irp2[(size_t)m * n], c->tabs[m].irp2.data(), 8 * (size_t)n); memcpy(&sirp2[(size_t)m * n], c->tabs[m].sirp2.data(), 8 * (size_t)n);
+            for (int i = 0; i < n; i++) {
+                rp[((size_t)m * n + i) * 2] = c->tabs[m].rp[i]; rp[((size_t)m * n + i) * 2 + 1] = c->tabs[m].srp[i];
+                irp2[((size_t)m * n + i) * 2] = c->tabs[m].irp2[i]; irp2[((size_t)m * n + i) * 2 + 1] = c->tabs[m].sirp2[i];
+            }
         }
         if ((e = hipMalloc(&c->d_mods, sizeof(ModParams) * nm)) != hipSuccess || (e = hipMalloc(&c->d_rp, tw)) != hipSuccess ||
-            (e = hipMalloc(&c->d_srp, tw)) != hipSuccess || (e = hipMalloc(&c->d_irp2, tw)) != hipSuccess ||
-            (e = hipMalloc(&c->d_sirp2, tw)) != hipSuccess || (e = hipMalloc(&c->d_behz, sizeof(BehzParams))) != hipSuccess ||
+            (e = hipMalloc(&c->d_irp2, tw)) != hipSuccess || (e = hipMalloc(&c->d_behz, sizeof(BehzParams))) != hipSuccess ||
             (e = hipMemcpy(c->d_mods, mods.data(), sizeof(ModParams) * nm, hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(c->d_rp, rp.data(), tw, hipMemcpyHostToDevice)) != hipSuccess ||
-            (e = hipMemcpy(c->d_srp, srp.data(), tw, hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(c->d_irp2, irp2.data(), tw, hipMemcpyHostToDevice)) != hipSuccess ||
-            (e = hipMemcpy(c->d_sirp2, sirp2.data(), tw, hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(c->d_behz, &c->behz, sizeof(BehzParams), hipMemcpyHostToDevice)) != hipSuccess) {
             fail(e); crc_ctx_destroy(c); return rc;
         }
@@ -283,7 +282,7 @@ extern "C" void crc_ctx_destroy(crc_ctx *c)
 {
     if (!c) return;
     if (c->device >= 0) {
-        (void)hipFree(c->d_mods); (void)hipFree(c->d_rp); (void)hipFree(c->d_srp); (void)hipFree(c->d_irp2); (void)hipFree(c->d_sirp2); (void)hipFree(c->d_behz);
+        (void)hipFree(c->d_mods); (void)hipFree(c->d_rp); (void)hipFree(c->d_irp2); (void)hipFree(c->d_behz);
     }
     delete c;
 }

@@ -60,7 +60,7 @@ struct crc_ctx {
     u64 qhat_mod_tg[2][CRC_MAXK], neg_inv_q_mod_tg[2], inv_gamma_mod_t, tgamma_mod_q[CRC_MAXK];
     // device copies
     ModParams *d_mods = nullptr;             // [k+kb]
-    u64 *d_rp = nullptr, *d_srp = nullptr, *d_irp2 = nullptr, *d_sirp2 = nullptr;   // [(k+kb)][n]
+    u64 *d_rp = nullptr, *d_irp2 = nullptr;   // [(k+kb)][n][2]: {bit-reversed root power, its Shoup companion} (forward / inverse-div-2)
     BehzParams *d_behz = nullptr;
 };
 

@@ -17,7 +17,7 @@
 // ---------------------------------------------------------------------------------------------------------------
 struct NttArgs {
     const u64 *src; u64 *dst;
-    const ModParams *mods; const u64 *w; const u64 *wp;       // twiddle tables [(k+kb)][n] (forward: rp/srp, inverse: irp2/sirp2)
+    const ModParams *mods; const ulonglong2 *w;               // twiddle table [(k+kb)][n] of {w, Shoup(w)} (forward: root powers, inverse: psi^-i / 2)
     int n, logn;
     int mod_base, mod_count;                                   // row r -> modulus index mod_base + r % mod_count
     int src_rows_per_item;                                     // 0: src row = dst row;  >0: plain prologue, src row = r / mod_count
@@ -28,17 +28,79 @@ struct NttArgs {
     PlainParams pp;
 };
 
+// LDS index padding: one extra word every 8 keeps the strided register-tile accesses of the late passes bank-conflict free
+__device__ __forceinline__ int lpad(int i) { return i + (i >> 3); }
+
+// R butterfly stages on 2^R register-resident values.  Forward (Cooley-Tukey): first stage pairs c with c + 2^(R-1);
+// inverse (Gentleman-Sande): first stage pairs c with c + 1.
+template <int R>
+__device__ __forceinline__ void fwd_stages(u64 (&v)[1 << R], const ulonglong2 *W, int m, int blk, u64 q, u64 q2)
+{
+#pragma unroll
+    for (int st = 0; st < R; st++) {
+        const int half = 1 << (R - 1 - st);
+#pragma unroll
+        for (int c = 0; c < (1 << R); c++) {
+            if (c & half) continue;
+            const int wi = (m << st) + (blk << st) + (c >> (R - st));
+            const ulonglong2 tw = W[wi]; const u64 w = tw.x, wp = tw.y;
+            u64 X = v[c]; const u64 Y = v[c + half];
+            X = X >= q2 ? X - q2 : X;
+            const u64 Q = mulmod_shoup_lazy(Y, w, wp, q);
+            v[c] = X + Q;
+            v[c + half] = X + (q2 - Q);
+        }
+    }
+}
+template <int R>
+__device__ __forceinline__ void inv_stages(u64 (&v)[1 << R], const ulonglong2 *W, int h, int blk, u64 q, u64 q2)
+{
+#pragma unroll
+    for (int st = 0; st < R; st++) {
+        const int half = 1 << st;
+#pragma unroll
+        for (int c = 0; c < (1 << R); c++) {
+            if (c & half) continue;
+            const int wi = (h >> st) + (blk << (R - 1 - st)) + (c >> (st + 1));
+            const ulonglong2 tw = W[wi]; const u64 w = tw.x, wp = tw.y;
+            const u64 U = v[c], V = v[c + half];
+            const u64 T = q2 - V + U;
+            u64 cu = U + V; cu = cu >= q2 ? cu - q2 : cu;
+            v[c] = (cu + ((cu & 1) ? q : 0)) >> 1;
+            v[c + half] = mulmod_shoup_lazy(T, w, wp, q);
+        }
+    }
+}
+
+// one pass over the whole row: every thread takes groups of 2^R values that interact in the next R stages
+template <bool INV, int R>
+__device__ __forceinline__ void ntt_pass(u64 *sm, const ulonglong2 *W, int n, int s /*element stride inside a group*/, int tabidx, u64 q, u64 q2)
+{
+    const int groups = n >> R;
+    for (int g = threadIdx.x; g < groups; g += blockDim.x) {
+        const int blk = g / s, l = g - blk * s;
+        const int base = blk * (s << R) + l;
+        u64 v[1 << R];
+#pragma unroll
+        for (int c = 0; c < (1 << R); c++) v[c] = sm[lpad(base + c * s)];
+        if (INV) inv_stages<R>(v, W, tabidx, blk, q, q2); else fwd_stages<R>(v, W, tabidx, blk, q, q2);
+#pragma unroll
+        for (int c = 0; c < (1 << R); c++) sm[lpad(base + c * s)] = v[c];
+    }
+    __syncthreads();
+}
+
 template <bool INV>
 __global__ void __launch_bounds__(1024) ntt_rows_kernel(NttArgs a)
 {
     extern __shared__ u64 sm[];
-    const int n = a.n, tid = threadIdx.x, nt = blockDim.x;
+    const int n = a.n, logn = a.logn, tid = threadIdx.x, nt = blockDim.x;
     const size_t row = blockIdx.x;
     const int mloc = (int)(row % a.mod_count);
     const int mi = a.mod_base + mloc;
     const ModParams m = a.mods[mi];
     const u64 q = m.q, q2 = m.two_q;
-    const u64 *W = a.w + (size_t)mi * n, *Wp = a.wp + (size_t)mi * n;
+    const ulonglong2 *W = a.w + (size_t)mi * n;
     const u64 *src = a.src + (a.src_rows_per_item ? (row / a.mod_count) : row) * (size_t)n;
     u64 *dst = a.dst + row * (size_t)n;
 
@@ -50,46 +112,29 @@ __global__ void __launch_bounds__(1024) ntt_rows_kernel(NttArgs a)
             if (v >= a.pp.threshold) { u64 l2 = lo + a.pp.uhi[mloc]; hi += (l2 < lo); lo = l2; }
             v = barrett128(lo, hi, m);
         }
-        sm[s] = v;
+        sm[lpad(s)] = v;
     }
     __syncthreads();
 
+    const int full = logn / 3, rem = logn - 3 * full;
     if (!INV) {
-        int logt = a.logn - 1;
-        for (int mm = 1; mm < n; mm <<= 1, logt--) {
-            const int t = 1 << logt;
-            for (int b = tid; b < (n >> 1); b += nt) {
-                const int i = b >> logt, j = (i << (logt + 1)) + (b & (t - 1));
-                const u64 w = W[mm + i], wp = Wp[mm + i];
-                u64 X = sm[j], Y = sm[j + t];
-                X = X >= q2 ? X - q2 : X;
-                const u64 Q = mulmod_shoup_lazy(Y, w, wp, q);
-                sm[j] = X + Q;
-                sm[j + t] = X + (q2 - Q);
-            }
-            __syncthreads();
-        }
+        // gaps n/2, n/4, ...: radix-8 passes first, a radix-4 / radix-2 pass finishes when log2(n) is not a multiple of 3
+        int t = n >> 1;
+        for (int p = 0; p < full; p++, t >>= 3) ntt_pass<false, 3>(sm, W, n, t >> 2, n / (2 * t), q, q2);
+        if (rem == 2) ntt_pass<false, 2>(sm, W, n, t >> 1, n / (2 * t), q, q2);
+        else if (rem == 1) ntt_pass<false, 1>(sm, W, n, t, n / (2 * t), q, q2);
         for (int s = tid; s < n; s += nt) {
-            u64 v = sm[s];
+            u64 v = sm[lpad(s)];
             v = v >= q2 ? v - q2 : v;
             v = v >= q ? v - q : v;
             dst[s] = v;
         }
     } else {
-        int logt = 0;
-        for (int mm = n; mm > 1; mm >>= 1, logt++) {
-            const int t = 1 << logt, h = mm >> 1;
-            for (int b = tid; b < (n >> 1); b += nt) {
-                const int i = b >> logt, j = (i << (logt + 1)) + (b & (t - 1));
-                const u64 w = W[h + i], wp = Wp[h + i];
-                const u64 U = sm[j], V = sm[j + t];
-                const u64 T = q2 - V + U;
-                u64 cu = U + V; cu = cu >= q2 ? cu - q2 : cu;
-                sm[j] = (cu + ((cu & 1) ? q : 0)) >> 1;
-                sm[j + t] = mulmod_shoup_lazy(T, w, wp, q);
-            }
-            __syncthreads();
-        }
+        // gaps 1, 2, 4, ...
+        int t = 1;
+        for (int p = 0; p < full; p++, t <<= 3) ntt_pass<true, 3>(sm, W, n, t, n / (2 * t), q, q2);
+        if (rem == 2) ntt_pass<true, 2>(sm, W, n, t, n / (2 * t), q, q2);
+        else if (rem == 1) ntt_pass<true, 1>(sm, W, n, t, n / (2 * t), q, q2);
         const u64 *add = nullptr;
         if (a.addend) {
             const size_t ct = row / a.rows_per_ct; const int p = (int)((row % a.rows_per_ct) / a.mod_count);
@@ -97,7 +142,7 @@ __global__ void __launch_bounds__(1024) ntt_rows_kernel(NttArgs a)
             else if (p == 0) { size_t g = ct / a.add_group; if (a.add_mod) g %= a.add_mod; add = a.addend + (g * a.mod_count + mloc) * (size_t)n; }
         }
         for (int s = tid; s < n; s += nt) {
-            u64 v = sm[s];
+            u64 v = sm[lpad(s)];
             v = v >= q2 ? v - q2 : v;
             v = v >= q ? v - q : v;
             if (add) v = a.add_sign > 0 ? addmod(v, add[s], q) : submod(v, add[s], q);
@@ -110,9 +155,9 @@ static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t
 {
     if (rows == 0) return CRC_OK;
     a.mods = c->d_mods; a.n = c->n; a.logn = c->logn;
-    a.w = inv ? c->d_irp2 : c->d_rp; a.wp = inv ? c->d_sirp2 : c->d_srp;
+    a.w = reinterpret_cast<const ulonglong2 *>(inv ? c->d_irp2 : c->d_rp);
     int nt = c->n / 8; if (nt < 64) nt = 64; if (nt > 1024) nt = 1024;
-    size_t lds = (size_t)c->n * 8;
+    size_t lds = ((size_t)c->n + (c->n >> 3)) * 8;
     if (inv) {
         if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)ntt_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(ntt_rows_kernel<true>, dim3((unsigned)rows), dim3(nt), lds, st, a);
