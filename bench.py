@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--chunk", type=int, default=None, help="images processed per layer launch")
     ap.add_argument("--distinct", type=int, default=4, help="distinct encrypted images (tiled to the batch on device)")
     ap.add_argument("--mode", default="resident", choices=["resident", "layerwise"])
+    ap.add_argument("--no-fuse", action="store_true", help="do not fold pooling layers into the preceding convolution")
+    ap.add_argument("--unfused-images", type=int, default=128, help="images of the extra, untimed-for-`value` pass with every reference layer run separately")
     ap.add_argument("--t-bits", type=int, default=None, help="override the plain modulus t = 2^bits")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target size of the CPU-baseline sample (0 = skip)")
     return ap.parse_args()
@@ -189,7 +191,7 @@ def main():
     del src
 
     # ---- encoded weights: rank 0 encodes + NTTs, RCCL broadcast to the others
-    net = Network(E, model, weights=W, alloc=alloc, resident=(args.mode == "resident"), d_evk=d_evk, materialize=(rank == 0))
+    net = Network(E, model, weights=W, alloc=alloc, resident=(args.mode == "resident"), d_evk=d_evk, materialize=(rank == 0), fuse_pool=False)
     torch.cuda.synchronize()
     bcast_s = 0.0
     if world > 1:
@@ -197,12 +199,33 @@ def main():
         dist.barrier(); t0 = time.time()
         shard.broadcast_buffers([buf for buf, _ in net.param_bufs], src=0, chunk_bytes=1 << 30)      # RCCL over xGMI
         torch.cuda.synchronize(); bcast_s = time.time() - t0
+    out_all = alloc(B * 10 * ctw * 8).view(B, 10 * ctw)
+    # ---- reference layer structure first (every CrCNN layer run as its own kernel sequence, NTT-resident): a short pass
+    unfused = None
+    want_fuse = args.mode == "resident" and not args.no_fuse
+    if want_fuse and args.unfused_images > 0:
+        nu = min(B, max(C, args.unfused_images // C * C))
+        net.prepare(C)
+        net.forward(x_all[0], 1); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for c0 in range(0, nu, C):
+            d_out = net.forward(x_all[c0], min(C, nu - c0))
+            E.L.crc_memcpy_d2d(E.c, out_all[c0].data_ptr(), E.p(d_out), min(C, nu - c0) * 10 * ctw * 8, E.stream)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        unfused = dict(images=nu, images_per_s=round(nu / dt, 3), ms_per_image=round(dt / nu * 1e3, 3), first_outputs=out_all[:min(D, nu)].clone(),
+                       layers=[pl[1] for pl in net.plan])
+        for t_ in list(net.buf) + [net.work]:          # give the large unfused activation buffers back before the main pass
+            keep[:] = [k_ for k_ in keep if k_ is not t_]
+        del net.buf, net.work, t_
+        torch.cuda.empty_cache()
+    if want_fuse:
+        net.fuse()            # fold avg/sum pooling into the preceding convolution where that removes MACs (exact)
     net.prepare(C)
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
 
     nl = len(net.plan)
-    out_all = alloc(B * 10 * ctw * 8).view(B, 10 * ctw)
     lay_ev = []
 
     def step(record):
@@ -249,6 +272,9 @@ def main():
 
     # ---- verification outside the timed region: tiled images give identical outputs; decrypted logits match the plain model
     ok_tile = all(bool(torch.equal(out_all[b], out_all[b % D])) for b in range(D, B, max(1, (B - D) // 16)))
+    if unfused is not None:     # folding pooling into the convolution must not change a single output bit
+        fo = unfused.pop("first_outputs")
+        unfused["outputs_identical_to_fused"] = bool(torch.equal(fo, out_all[:fo.shape[0]]))
     outs = out_all[:D].cpu().numpy().view(np.uint64).reshape(D, 10, 2, E.k, E.n)
     preds_ok, budgets, max_err = 0, [], 0.0
     for i in range(D):
@@ -296,8 +322,8 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": f"synthetic ({D} distinct MNIST-like encrypted images per GPU tiled to the batch; trained weights from {model}.h5)",
         "config": {"workload": f"{model}.h5 n={cfg['n']} k={cfg['k']} t=2^{cfg['t'].bit_length() - 1} batch={B}/GPU chunk={C} ({args.config}, BASELINE configs)",
-                   "mode": args.mode, "parallelism": f"image-sharded x{world}, RCCL weight broadcast"},
-        "ms_per_layer": ms_per_layer, "roofline": roofline, "cpu_baseline": cpu,
+                   "mode": args.mode + ("+conv/pool folding" if want_fuse else ""), "parallelism": f"image-sharded x{world}, RCCL weight broadcast"},
+        "ms_per_layer": ms_per_layer, "reference_layer_structure": unfused, "roofline": roofline, "cpu_baseline": cpu,
         "check": {"tiled_outputs_identical": bool(ok_tile), "predictions_match_plain_model": f"{preds_ok}/{D}", "max_logit_abs_err": round(max_err, 6),
                   "noise_budget_bits": budgets},
         "setup_s": round(setup_s, 1), "weight_broadcast_s": round(bcast_s, 2), "weight_bytes": int(net.weight_bytes),

@@ -88,6 +88,7 @@ def load():
     L.crc_multiply_plain.argtypes = [VP, VP, VP, SZ, SZ, VP]
     L.crc_conv2d_work_bytes.restype = SZ; L.crc_conv2d_work_bytes.argtypes = [VP] + [CI] * 10
     L.crc_conv2d.argtypes = [VP, VP, VP, VP] + [CI] * 11 + [VP, VP, VP]
+    L.crc_conv2d_fold_pool.argtypes = [VP, VP, VP, VP] + [CI] * 8 + [VP, VP, VP]
     L.crc_dense_work_bytes.restype = SZ; L.crc_dense_work_bytes.argtypes = [VP, CI, CI, CI, CI]
     L.crc_dense.argtypes = [VP, VP, VP, VP, CI, CI, CI, CI, CI, VP, VP, VP]
     L.crc_pool.argtypes = [VP, VP] + [CI] * 8 + [VP, CI, VP, VP]
@@ -296,6 +297,10 @@ class Engine:
     def conv2d(self, d_x, d_w, d_bias, B, zd, xd, yd, xs, ys, xf, yf, nf, in_form, out_form, d_y, d_work):
         _chk(self.L.crc_conv2d(self.c, self.p(d_x), self.p(d_w), self.p(d_bias), B, zd, xd, yd, xs, ys, xf, yf, nf, in_form, out_form,
                                self.p(d_y), self.p(d_work), self.stream), "crc_conv2d")
+
+    def conv2d_fold_pool(self, d_w, d_bias_ntt, d_div_ntt, nf, zd, xf, yf, cxs, cys, pxf, pyf, d_w_out, d_bias_out):
+        _chk(self.L.crc_conv2d_fold_pool(self.c, self.p(d_w), self.p(d_bias_ntt), self.p(d_div_ntt), nf, zd, xf, yf, cxs, cys, pxf, pyf,
+                                         self.p(d_w_out), self.p(d_bias_out), self.stream), "crc_conv2d_fold_pool")
 
     def dense_work_bytes(self, B, in_dim, out_dim, in_form):
         return self.L.crc_dense_work_bytes(self.c, B, in_dim, out_dim, in_form)

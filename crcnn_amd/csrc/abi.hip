@@ -123,6 +123,14 @@ extern "C" int crc_dense(crc_ctx *c, const uint64_t *d_x, const uint64_t *d_w, c
     return crc_conv2d(c, d_x, d_w, d_bias, B, in_dim, 1, 1, 1, 1, 1, 1, out_dim, in_form, out_form, d_y, d_work, stream);
 }
 
+extern "C" int crc_conv2d_fold_pool(crc_ctx *c, const uint64_t *d_w, const uint64_t *d_bias_ntt, const uint64_t *d_div_ntt, int nf, int zd, int xf, int yf,
+                                    int cxs, int cys, int pxf, int pyf, uint64_t *d_w_out, uint64_t *d_bias_out, void *stream)
+{
+    CHECK_CTX(c);
+    if (!d_w || !d_bias_ntt || !d_w_out || !d_bias_out || nf < 1 || zd < 1 || xf < 1 || yf < 1 || cxs < 1 || cys < 1 || pxf < 1 || pyf < 1) return CRC_ERR_INVALID_ARGUMENT;
+    return k_fold_pool(c, d_w, d_bias_ntt, d_div_ntt, d_w_out, d_bias_out, nf, zd, xf, yf, cxs, cys, pxf, pyf, S(stream));
+}
+
 // ---- pooling / batch-norm -----------------------------------------------------------------------------------------
 extern "C" int crc_pool(crc_ctx *c, const uint64_t *d_x, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf,
                         const uint64_t *d_div, int form, uint64_t *d_y, void *stream)

@@ -482,13 +482,20 @@ int k_mac(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, con
 // Workgroups are numbered so that the 32 CUs of an XCD work on the same slot block and neighbouring tiles at the same
 // time: their shared operands are served by that XCD's L2 instead of HBM.
 // ---------------------------------------------------------------------------------------------------------------
+// x (< 2^56) -> {low dword = x & (2^28-1), high dword = x >> 28}: two 32-bit VALU ops (64-bit shifts are slow on gfx950)
+__device__ __forceinline__ u64 split28(u64 r)
+{
+    const u32 lo = (u32)r, hi = (u32)(r >> 32);
+    const u32 x0 = lo & 0x0fffffffu, x1 = __builtin_amdgcn_alignbit(hi, lo, 28);
+    return (u64)x0 | ((u64)x1 << 32);
+}
+
 template <int PX, int FT, int WM, int WN, int S, int DEPTH = 2>
 __global__ void __launch_bounds__(64 * WM * WN) mac2_kernel(MacArgs a)
 {
     constexpr int NW = WM * WN, MT = PX * WM, ROWS = 2 * MT, FW = FT * WN;
     constexpr int VEC = S * (ROWS + FW), NPAIR = VEC / 2, RLOAD = 2 * ((NPAIR + NW - 1) / NW);      // operand vectors are staged in (even, odd) pairs
     static_assert(FT % 2 == 0 && (ROWS + FW) % 2 == 0, "pairs");
-    constexpr u64 MASK28 = (1ULL << 28) - 1;
     extern __shared__ __attribute__((aligned(16))) u64 smem[];      // 2 x [S][(ROWS + FW)/2 pairs][64 lanes][2]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave / WN, wn = wave % WN;
     const int n = a.n, k = a.k;
@@ -535,28 +542,30 @@ __global__ void __launch_bounds__(64 * WM * WN) mac2_kernel(MacArgs a)
     for (int t = threadIdx.x; t < a.T + 8; t += blockDim.x) tw[t] = a.toffw[t];
     __syncthreads();                                 // the table is read by every wave from the first load_stage on
     const u32 kn32 = (u32)kn;
+    auto load_one = [&](int st, int j, u64 (&reg)[RLOAD]) {
+        const int t = min(st * S + vstep[j], a.T - 1);
+        const u32 off = visx[j] ? tw[t] : (u32)t * kn32;
+        reg[j] = *reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(vbase[j]) + (size_t)((off + (u32)rown) << 3));   // uniform base + 32-bit lane offset; consumed only by store_pair
+    };
+    auto store_pair = [&](int st, int jj, u64 (&reg)[RLOAD]) {
+        ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(smem) + (size_t)(st & 1) * NPAIR * 64;
+        const int pr = wave + jj * NW;
+        ulonglong2 v;
+        {   const bool dead = !visx[2 * jj] && st * S + vstep[2 * jj] >= a.T;             // weights past the last term are zero (x may be anything valid)
+            const u64 r = dead ? 0 : reg[2 * jj]; v.x = split28(r); }         // pre-split once: low dword = x0 (28 bit), high dword = x1
+        {   const bool dead = !visx[2 * jj + 1] && st * S + vstep[2 * jj + 1] >= a.T;
+            const u64 r = dead ? 0 : reg[2 * jj + 1]; v.y = split28(r); }
+        if (pr < NPAIR) dst[pr * 64 + lane] = v;                                            // one ds_write_b128 per operand pair
+    };
     auto load_stage = [&](int st, u64 (&reg)[RLOAD]) {
         if (st > 1 && (a.dbg == 1 || a.dbg == 2 || a.dbg == 4)) return;
 #pragma unroll
-        for (int j = 0; j < RLOAD; j++) {
-            const int t = min(st * S + vstep[j], a.T - 1);
-            const u32 off = visx[j] ? tw[t] : (u32)t * kn32;
-            reg[j] = vbase[j][(size_t)(off + (u32)rown)];      // consumed only in store_stage: the loads stay in flight meanwhile
-        }
+        for (int j = 0; j < RLOAD; j++) { if (a.dbg == 7 && st > 1 && (j & 1)) continue; load_one(st, j, reg); }
     };
     auto store_stage = [&](int st, u64 (&reg)[RLOAD]) {
         if (st > 1 && (a.dbg == 1 || a.dbg == 2 || a.dbg == 3)) return;
-        ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(smem) + (size_t)(st & 1) * NPAIR * 64;
 #pragma unroll
-        for (int jj = 0; jj < RLOAD / 2; jj++) {
-            const int pr = wave + jj * NW;
-            ulonglong2 v;
-            {   const bool dead = !visx[2 * jj] && st * S + vstep[2 * jj] >= a.T;         // weights past the last term are zero (x may be anything valid)
-                const u64 r = dead ? 0 : reg[2 * jj]; v.x = (r & MASK28) | ((r >> 28) << 32); }     // pre-split once: low dword = x0 (28 bit), high dword = x1
-            {   const bool dead = !visx[2 * jj + 1] && st * S + vstep[2 * jj + 1] >= a.T;
-                const u64 r = dead ? 0 : reg[2 * jj + 1]; v.y = (r & MASK28) | ((r >> 28) << 32); }
-            if (pr < NPAIR) dst[pr * 64 + lane] = v;                                        // one ds_write_b128 per operand pair
-        }
+        for (int jj = 0; jj < RLOAD / 2; jj++) store_pair(st, jj, reg);
     };
     auto compute_stage = [&](int st) {
         const ulonglong2 *buf = reinterpret_cast<const ulonglong2 *>(smem) + (size_t)(st & 1) * NPAIR * 64;
@@ -694,4 +703,52 @@ int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, co
     case 11: return mac2_launch<3, 4, 2, 4, 3, 2>(c, a, st);
     default: return mac2_launch<3, 4, 2, 4, 2>(c, a, st);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Algebraic fusion conv -> sum/avg pool (both linear over Z_q, so this is exact): pool(conv_w(x) + b) == conv_w'(x) + b'
+// with the pooled kernel  w'[f][z][u][v] = div * sum_{a<pxf, b<pyf} w[f][z][u - a*cxs][v - b*cys]   (indices in range),
+// b' = div * (pxf*pyf) * b, window xf' = (pxf-1)*cxs + xf, stride cxs*pxs.  For a decimating pool (stride = window) the
+// fused layer has (xf'*yf')/(xf*yf) more terms but pxs*pys fewer outputs: 2.8x fewer MACs for CrCNN's 5x5 conv + 2x2/2 pool.
+// All inputs/outputs in NTT form.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fold_pool_kernel(const u64 *w, const u64 *bias, const u64 *div, u64 *wout, u64 *bout, const ModParams *mods, int n, int k,
+                                                        int nf, int zd, int xf, int yf, int cxs, int cys, int pxf, int pyf, int xf2, int yf2)
+{
+    // rows: first nf*zd*xf2*yf2*k weight rows, then nf*k bias rows
+    const size_t row = blockIdx.x;
+    const size_t wrows = (size_t)nf * zd * xf2 * yf2 * k;
+    const int i = (int)(row % k);
+    const ModParams m = mods[i];
+    const u64 *dv = div ? div + (size_t)i * n : nullptr;
+    if (row < wrows) {
+        size_t e = row / k;
+        const int v = (int)(e % yf2); e /= yf2; const int u = (int)(e % xf2); e /= xf2;     // e = f*zd + z
+        u64 *dst = wout + row * (size_t)n;
+        for (int s = threadIdx.x; s < n; s += blockDim.x) {
+            u64 acc = 0;
+            for (int a = 0; a < pxf; a++) { const int kx = u - a * cxs; if (kx < 0 || kx >= xf) continue;
+                for (int b = 0; b < pyf; b++) { const int ky = v - b * cys; if (ky < 0 || ky >= yf) continue;
+                    acc = addmod(acc, w[(((e * xf + kx) * yf + ky) * k + i) * (size_t)n + s], m.q); } }
+            dst[s] = dv ? mulmod(acc, dv[s], m) : acc;
+        }
+    } else {
+        const size_t br = row - wrows;                   // f*k + i
+        const u64 *src = bias + br * (size_t)n; u64 *dst = bout + br * (size_t)n;
+        const u64 cnt = (u64)(pxf * pyf) % m.q;
+        for (int s = threadIdx.x; s < n; s += blockDim.x) {
+            u64 x = mulmod(src[s], cnt, m);
+            dst[s] = dv ? mulmod(x, dv[s], m) : x;
+        }
+    }
+}
+
+int k_fold_pool(crc_ctx *c, const u64 *w, const u64 *bias, const u64 *div, u64 *wout, u64 *bout, int nf, int zd, int xf, int yf, int cxs, int cys,
+                int pxf, int pyf, hipStream_t st)
+{
+    const int xf2 = (pxf - 1) * cxs + xf, yf2 = (pyf - 1) * cys + yf;
+    const size_t rows = ((size_t)nf * zd * xf2 * yf2 + nf) * c->k;
+    hipLaunchKernelGGL(fold_pool_kernel, dim3((unsigned)rows), dim3(256), 0, st, w, bias, div, wout, bout, c->d_mods, c->n, c->k, nf, zd, xf, yf, cxs, cys, pxf, pyf, xf2, yf2);
+    HIPCHK(hipGetLastError());
+    return CRC_OK;
 }

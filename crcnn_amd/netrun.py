@@ -61,11 +61,14 @@ def layer_macs(kind, a):
 class Network:
     """Encoded network resident in HBM.  `alloc(nbytes)` must return an object Engine.p() understands."""
 
-    def __init__(self, eng, model, h5_path=None, weights=None, alloc=None, resident=True, encode_chunk=2048, dbc=16, d_evk=None, materialize=True):
+    def __init__(self, eng, model, h5_path=None, weights=None, alloc=None, resident=True, encode_chunk=2048, dbc=16, d_evk=None, materialize=True, fuse_pool=None):
         self.E, self.model, self.topo = eng, model, TOPOLOGIES[model]
         self.alloc = alloc or eng.alloc
         self.resident = resident            # keep tensors NTT-resident between layers (bit-identical, SURVEY 8f-1)
         self.dbc, self.d_evk = dbc, d_evk
+        # fold a (sum/avg) pooling layer into the convolution in front of it when that reduces the MAC count (exact, SURVEY 8f-1+);
+        # only in NTT-resident mode, where the intermediate tensor is not observable
+        self.fuse_pool = resident if fuse_pool is None else (fuse_pool and resident)
         self.materialize = materialize      # False: only allocate parameter buffers (they are filled by an RCCL broadcast)
         self.param_bufs = []                # every parameter buffer in a deterministic order: (buffer, nbytes)
         self.weight_bytes = 0
@@ -105,6 +108,43 @@ class Network:
             shape = nshape
         self.out_shape = shape
         self.out_form = form
+        if self.fuse_pool:
+            self.fuse()
+
+    # ---- conv + pool fusion (crc_conv2d_fold_pool)
+    def fuse(self):
+        """fold pooling layers into the convolutions in front of them (exact); call prepare() again afterwards"""
+        E = self.E
+        plan, i = [], 0
+        while i < len(self.plan):
+            kind, name, a, p, ishape, oshape = self.plan[i]
+            nxt = self.plan[i + 1] if i + 1 < len(self.plan) else None
+            if kind == "conv" and nxt and nxt[0] in ("pool", "avgpool") and p["out_form"] == NTT and nxt[3]["form"] == NTT:
+                pa = nxt[2]
+                xf2, yf2 = (pa["xf"] - 1) * a["xs"] + a["xf"], (pa["yf"] - 1) * a["ys"] + a["yf"]
+                xs2, ys2 = a["xs"] * pa["xs"], a["ys"] * pa["ys"]
+                xo2, yo2 = (a["xd"] - xf2) // xs2 + 1, (a["yd"] - yf2) // ys2 + 1
+                macs_sep = layer_macs("conv", a)
+                macs_fused = a["nf"] * xo2 * yo2 * a["zd"] * xf2 * yf2
+                same_shape = (a["nf"], xo2, yo2) == tuple(nxt[5])
+                if same_shape and macs_fused < macs_sep:
+                    cnt = a["nf"] * a["zd"] * xf2 * yf2
+                    w2 = self.alloc(cnt * E.k * E.n * 8); b2 = self.alloc(a["nf"] * E.k * E.n * 8)
+                    if self.materialize:
+                        E.conv2d_fold_pool(p["w"], p["b"], nxt[3]["div"], a["nf"], a["zd"], a["xf"], a["yf"], a["xs"], a["ys"], pa["xf"], pa["yf"], w2, b2)
+                        E.sync()
+                    # the fused parameters replace the originals in the broadcast list
+                    self.param_bufs = [(b_, n_) for (b_, n_) in self.param_bufs if b_ is not p["w"] and b_ is not p["b"]]
+                    self.param_bufs += [(w2, cnt * E.k * E.n * 8), (b2, a["nf"] * E.k * E.n * 8)]
+                    self.weight_bytes += (cnt - a["nf"] * a["zd"] * a["xf"] * a["yf"]) * E.k * E.n * 8
+                    a2 = dict(a, xs=xs2, ys=ys2, xf=xf2, yf=yf2)
+                    p2 = dict(p, w=w2, b=b2, fused=(name, nxt[1]), macs_separate=macs_sep, macs=macs_fused)
+                    p["w"] = p["b"] = None            # drop the unfused copies
+                    plan.append(("conv", name + "+" + nxt[1], a2, p2, ishape, nxt[5]))
+                    i += 2
+                    continue
+            plan.append(self.plan[i]); i += 1
+        self.plan = plan
 
     # ---- parameter upload
     def _encode_ntt(self, vals, chunk, dtype=np.float32):

@@ -149,6 +149,14 @@ size_t crc_conv2d_work_bytes(const crc_ctx *ctx, int B, int zd, int xd, int yd, 
 int crc_conv2d(crc_ctx *ctx, const uint64_t *d_x, const uint64_t *d_w_ntt, const uint64_t *d_bias_delta,
                int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf,
                int in_form, int out_form, uint64_t *d_y, void *d_work, void *stream);
+/* Algebraic fusion of a convolution with the sum/average pooling that follows it (ConvolutionalLayer + PoolingLayer /
+ * AvgPoolingLayer, convolutionalLayer.cpp:159-197 + poolingLayer.cpp:22-44 / avgPoolingLayer.cpp:16-45): both are linear over Z_q,
+ * so pool(conv_w(x) + b) = conv_w'(x) + b' exactly, with w'[f][z][u][v] = div * sum_{a,b} w[f][z][u-a*cxs][v-b*cys], b' = div*pxf*pyf*b.
+ * Produces the pooled kernel [nf][zd][xf'][yf'][k][n] (xf' = (pxf-1)*cxs + xf) and bias [nf][k][n], all in NTT form; run it with
+ * crc_conv2d(..., xs = cxs*pxs, ys = cys*pys, xf', yf', out_form = CRC_NTT).  The final network output is bit-identical; only the
+ * (unobservable in NTT-resident mode) intermediate tensor disappears.  d_div_ntt = NULL for sum pooling. */
+int crc_conv2d_fold_pool(crc_ctx *ctx, const uint64_t *d_w_ntt, const uint64_t *d_bias_delta_ntt, const uint64_t *d_div_ntt, int nf, int zd, int xf, int yf,
+                         int cxs, int cys, int pxf, int pyf, uint64_t *d_w_out, uint64_t *d_bias_out, void *stream);
 size_t crc_dense_work_bytes(const crc_ctx *ctx, int B, int in_dim, int out_dim, int in_form);
 int crc_dense(crc_ctx *ctx, const uint64_t *d_x, const uint64_t *d_w_ntt, const uint64_t *d_bias_delta,
               int B, int in_dim, int out_dim, int in_form, int out_form, uint64_t *d_y, void *d_work, void *stream);

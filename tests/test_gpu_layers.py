@@ -146,6 +146,35 @@ def test_ntt_resident_chain_equals_reference_order(gl):
     assert all(abs(v) < 50 for v in vals)
 
 
+def test_conv_pool_fusion_is_exact(gl):
+    """crc_conv2d_fold_pool: pool(conv(x)+b) computed as ONE convolution with the pooled kernel equals the reference's
+    conv layer followed by its (avg / sum) pooling layer, bit for bit (both are linear over Z_q)"""
+    from oracle import orc
+    g, E, N = gl
+    ca = N.ca
+    O = orc.Oracle(E.n, [int(v) for v in E.q], E.t)
+    zd, xd, yd, xs, ys, xf, yf, nf = [int(v) for v in g["dims"][:8]]
+    xo, yo = (xd - xf) // xs + 1, (yd - yf) // ys + 1
+    for avg in (True, False):
+        pxf, pyf, pxs, pys = 2, 2, 1, 1
+        want = O.pool(g["ref_conv"], pxs, pys, pxf, pyf, div_plain=O.encode(0.25)[0] if avg else None)
+        d_w = N.weights_ntt(g["conv_w"]); d_b = N.delta(g["conv_b"], ca.NTT)
+        d_div = N.weights_ntt(np.array([0.25])) if avg else None
+        xf2, yf2 = (pxf - 1) * xs + xf, (pyf - 1) * ys + yf
+        d_w2 = E.alloc(nf * zd * xf2 * yf2 * E.k * E.n * 8); d_b2 = E.alloc(nf * E.k * E.n * 8)
+        E.conv2d_fold_pool(d_w, d_b, d_div, nf, zd, xf, yf, xs, ys, pxf, pyf, d_w2, d_b2)
+        pxo, pyo = (xo - pxf) // pxs + 1, (yo - pyf) // pys + 1
+        assert ((xd - xf2) // (xs * pxs) + 1, (yd - yf2) // (ys * pys) + 1) == (pxo, pyo)
+        B = 2
+        x = np.ascontiguousarray(np.repeat(g["x"][None], B, axis=0))
+        d_x = E.upload(x); d_y = E.alloc(B * nf * pxo * pyo * 2 * E.k * E.n * 8)
+        d_work = E.alloc(E.conv2d_work_bytes(B, zd, xd, yd, xs * pxs, ys * pys, xf2, yf2, nf, ca.COEFF))
+        E.conv2d(d_x, d_w2, d_b2, B, zd, xd, yd, xs * pxs, ys * pys, xf2, yf2, nf, ca.COEFF, ca.NTT, d_y, d_work)
+        E.ntt_inv(d_y, B * nf * pxo * pyo)
+        got = E.download(d_y, ctshape(E, B, nf, pxo, pyo))
+        assert np.array_equal(got[0], want) and np.array_equal(got[1], want)
+
+
 def test_shape_validation(gl):
     g, E, N = gl
     ca = N.ca
