@@ -27,11 +27,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 CONFIGS = {
     # BASELINE.json configs[1]: PlainModelTiny.h5, n=4096, batch=1024 on one MI355X  (q = coeff_modulus_128(4096), t = 2^20)
-    "tiny4096": dict(model="PlainModelTiny", n=4096, k=2, t=1 << 32, batch=1024, chunk=16),   # t=2^32: exact logits without the client-side refresh
+    "tiny4096": dict(model="PlainModelTiny", n=4096, k=2, t=1 << 32, batch=1024, chunk=24),   # t=2^32: exact logits without the client-side refresh
     # configs[2]: ApproxPlainModel.h5, n=8192, 3 coeff moduli, batch=1024
-    "approx8192": dict(model="ApproxPlainModel", n=8192, k=3, t=1 << 42, batch=1024, chunk=16),   # t=2^42: exact logits, 19 bits of budget left
+    "approx8192": dict(model="ApproxPlainModel", n=8192, k=3, t=1 << 42, batch=1024, chunk=24),   # t=2^42: exact logits, 19 bits of budget left
     # configs[4]: PlainModelWoPad.h5, n=16384, 4 coeff moduli
-    "wopad16384": dict(model="PlainModelWoPad", n=16384, k=4, t=1 << 44, batch=1024, chunk=4),
+    "wopad16384": dict(model="PlainModelWoPad", n=16384, k=4, t=1 << 44, batch=1024, chunk=6),
 }
 
 
@@ -146,11 +146,17 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    ndev = torch.cuda.device_count()
+    local = local % max(1, ndev)                     # (rehearsals with more ranks than GPUs share a device; the driver uses one rank per GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("CRC_DIST_BACKEND", "nccl")           # "nccl" is RCCL on ROCm; "gloo" only for single-GPU rehearsals of this code path
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     cfg = dict(CONFIGS[args.config])
     if args.t_bits:
@@ -158,6 +164,7 @@ def main():
     B = args.batch or cfg["batch"]; C = min(args.chunk or cfg["chunk"], B)
     q = ca.default_coeff_modulus_128(cfg["n"])[:cfg["k"]]
     E = ca.Engine(cfg["n"], q, cfg["t"], device=local)
+    local_rank_env = int(os.environ.get("LOCAL_RANK", "0"))
     E.stream = torch.cuda.current_stream().cuda_stream or None
     keep = []
 
@@ -199,6 +206,7 @@ def main():
         dist.barrier(); t0 = time.time()
         shard.broadcast_buffers([buf for buf, _ in net.param_bufs], src=0, chunk_bytes=1 << 30)      # RCCL over xGMI
         torch.cuda.synchronize(); bcast_s = time.time() - t0
+    net.materialize = True                       # every rank now holds the encoded parameters (needed by fuse())
     out_all = alloc(B * 10 * ctw * 8).view(B, 10 * ctw)
     # ---- reference layer structure first (every CrCNN layer run as its own kernel sequence, NTT-resident): a short pass
     unfused = None
@@ -285,9 +293,13 @@ def main():
         max_err = max(max_err, float(np.abs(logits - want).max()))
         preds_ok += int(np.argmax(logits) == np.argmax(want))
 
+    if world > 1:           # every rank must have verified its own outputs
+        from crcnn_amd import shard
+        all_ok = shard.gather_counts(int(ok_tile and preds_ok == D and (unfused is None or unfused["outputs_identical_to_fused"])), dev)
+    else:
+        all_ok = int(ok_tile and preds_ok == D)
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     # ---- roofline of the dominant kernel: algorithmic bytes per launch / measured duration
@@ -325,7 +337,7 @@ def main():
                    "mode": args.mode + ("+conv/pool folding" if want_fuse else ""), "parallelism": f"image-sharded x{world}, RCCL weight broadcast"},
         "ms_per_layer": ms_per_layer, "reference_layer_structure": unfused, "roofline": roofline, "cpu_baseline": cpu,
         "check": {"tiled_outputs_identical": bool(ok_tile), "predictions_match_plain_model": f"{preds_ok}/{D}", "max_logit_abs_err": round(max_err, 6),
-                  "noise_budget_bits": budgets},
+                  "noise_budget_bits": budgets, "ranks_verified": f"{all_ok}/{world}"},
         "setup_s": round(setup_s, 1), "weight_broadcast_s": round(bcast_s, 2), "weight_bytes": int(net.weight_bytes),
     }
     print(json.dumps(line))
