@@ -28,8 +28,10 @@ struct NttArgs {
     PlainParams pp;
 };
 
-// LDS index padding: one extra word every 8 keeps the strided register-tile accesses of the late passes bank-conflict free
-__device__ __forceinline__ int lpad(int i) { return i + (i >> 3); }
+// LDS index swizzle (XOR, no padding): conflict-free ds_read/write_b64 for the contiguous staging accesses AND for every strided
+// register-tile pattern of the radix-8 passes at n = 4096 (at most 2-way in the short tail pass of n = 8192 / 16384); found by
+// enumerating the access patterns (bank = index mod 32 per 32-lane group)
+__device__ __forceinline__ int lpad(int i) { return i ^ ((i >> 3) & 7) ^ (((i >> 6) & 3) << 3); }
 
 // R butterfly stages on 2^R register-resident values.  Forward (Cooley-Tukey): first stage pairs c with c + 2^(R-1);
 // inverse (Gentleman-Sande): first stage pairs c with c + 1.
@@ -157,7 +159,7 @@ static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t
     a.mods = c->d_mods; a.n = c->n; a.logn = c->logn;
     a.w = reinterpret_cast<const ulonglong2 *>(inv ? c->d_irp2 : c->d_rp);
     int nt = c->n / 8; if (nt < 64) nt = 64; if (nt > 1024) nt = 1024;
-    size_t lds = ((size_t)c->n + (c->n >> 3)) * 8;
+    size_t lds = (size_t)c->n * 8;
     if (inv) {
         if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)ntt_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(ntt_rows_kernel<true>, dim3((unsigned)rows), dim3(nt), lds, st, a);
