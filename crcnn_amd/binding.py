@@ -99,6 +99,18 @@ def load():
     L.crc_relinearize.argtypes = [VP, VP, SZ, VP, CI, VP, VP, VP]
     L.crc_import_seal.argtypes = [VP, PU, CI, PU]
     L.crc_export_seal.argtypes = [VP, PU, CI, PU]
+    L.crc_params_hash.argtypes = [VP, PU]
+    for f_ in ("ct", "evk", "pk", "sk"):
+        getattr(L, f"crc_seal_{f_}_bytes").restype = SZ
+    L.crc_seal_ct_bytes.argtypes = [VP, CI]; L.crc_seal_evk_bytes.argtypes = [VP, CI]; L.crc_seal_pk_bytes.argtypes = [VP]; L.crc_seal_sk_bytes.argtypes = [VP]
+    L.crc_seal_ct_save.argtypes = [VP, PU, CI, VP, SZ, ctypes.POINTER(SZ)]
+    L.crc_seal_ct_load.argtypes = [VP, VP, SZ, PU, CI, ctypes.POINTER(CI), ctypes.POINTER(SZ)]
+    L.crc_seal_evk_save.argtypes = [VP, PU, CI, VP, SZ, ctypes.POINTER(SZ)]
+    L.crc_seal_evk_load.argtypes = [VP, VP, SZ, PU, ctypes.POINTER(CI)]
+    L.crc_seal_pk_save.argtypes = [VP, PU, VP, SZ, ctypes.POINTER(SZ)]
+    L.crc_seal_pk_load.argtypes = [VP, VP, SZ, PU]
+    L.crc_seal_sk_save.argtypes = [VP, PU, VP, SZ, ctypes.POINTER(SZ)]
+    L.crc_seal_sk_load.argtypes = [VP, VP, SZ, PU]
     L.crc_h5_dataset_count.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(SZ)]
     L.crc_h5_read_f32.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float), SZ, ctypes.POINTER(SZ)]
     L.crc_h5_list.argtypes = [ctypes.c_char_p, ctypes.c_char_p, SZ]

@@ -156,6 +156,51 @@ void delParameters()
     ev_keys16.reset();
     if (context) { crc_ctx_destroy(context); context = nullptr; }
 }
+static void writeFile(const string &path, const vector<uint8_t> &b) { ofstream f(path, ofstream::binary); if (!f) throw runtime_error("cannot write " + path); f.write((const char *)b.data(), (streamsize)b.size()); }
+static vector<uint8_t> readFile(const string &path)
+{
+    ifstream f(path, ifstream::binary); if (!f) throw runtime_error("cannot open " + path);
+    f.seekg(0, ios::end); size_t sz = (size_t)f.tellg(); f.seekg(0); vector<uint8_t> b(sz); f.read((char *)b.data(), (streamsize)sz); return b;
+}
+void setAndSaveParameters(string public_key_path, string secret_key_path, string evaluation_key_path, int poly_modulus, uint64_t plain_modulus)
+{   // globals.cpp:58-74
+    setParameters(poly_modulus, plain_modulus);
+    size_t w = 0;
+    vector<uint8_t> b(crc_seal_pk_bytes(context)); chk(crc_seal_pk_save(context, public_key.data(), b.data(), b.size(), &w), "crc_seal_pk_save"); writeFile(public_key_path, b);
+    b.assign(crc_seal_sk_bytes(context), 0); chk(crc_seal_sk_save(context, secret_key.data(), b.data(), b.size(), &w), "crc_seal_sk_save"); writeFile(secret_key_path, b);
+    b.assign(crc_seal_evk_bytes(context, 16), 0); chk(crc_seal_evk_save(context, ev_keys16_host.data(), 16, b.data(), b.size(), &w), "crc_seal_evk_save"); writeFile(evaluation_key_path, b);
+}
+void initFromKeys(string public_key_path, string secret_key_path, string evaluation_key_path, int poly_modulus, uint64_t plain_modulus)
+{   // globals.cpp:77-111
+    setParameters(poly_modulus, plain_modulus);
+    vector<uint8_t> b = readFile(public_key_path); chk(crc_seal_pk_load(context, b.data(), b.size(), public_key.data()), "public_key is not valid for encryption parameters");
+    b = readFile(secret_key_path); chk(crc_seal_sk_load(context, b.data(), b.size(), secret_key.data()), "secret_key is not valid for encryption parameters");
+    b = readFile(evaluation_key_path); int dbc = 0;
+    chk(crc_seal_evk_load(context, b.data(), b.size(), ev_keys16_host.data(), &dbc), "evaluation_keys is not valid for encryption parameters");
+    if (dbc != 16) throw invalid_argument("evaluation keys must have decomposition_bit_count 16");
+    chk(crc_memcpy_h2d(context, ev_keys16->ptr, ev_keys16_host.data(), ev_keys16_host.size() * 8, nullptr), "crc_memcpy_h2d");
+    chk(crc_stream_sync(context, nullptr), "crc_stream_sync");
+}
+ciphertext3D encryptAndSaveImage(vector<float> image, int zd, int xd, int yd, string file_name)
+{   // globals.cpp:174-190: the ciphertexts back to back in Ciphertext::save format
+    ciphertext3D t = encryptImage(image, zd, xd, yd);
+    vector<uint64_t> h = t.toHost();
+    const size_t one = crc_seal_ct_bytes(ctx(), 2), ctw = crc_ct_words(ctx(), 2);
+    vector<uint8_t> b(one * t.count()); size_t w = 0;
+    for (size_t i = 0; i < t.count(); i++) chk(crc_seal_ct_save(ctx(), h.data() + i * ctw, 2, b.data() + i * one, one, &w), "crc_seal_ct_save");
+    writeFile(file_name, b);
+    return t;
+}
+ciphertext3D loadEncryptedImage(int zd, int xd, int yd, string file_name)
+{   // globals.cpp:193-205
+    vector<uint8_t> b = readFile(file_name);
+    const size_t cnt = (size_t)zd * xd * yd, ctw = crc_ct_words(ctx(), 2);
+    vector<uint64_t> h(cnt * ctw); size_t off = 0;
+    for (size_t i = 0; i < cnt; i++) { int size = 0; size_t used = 0;
+        chk(crc_seal_ct_load(ctx(), b.data() + off, b.size() - off, h.data() + i * ctw, 2, &size, &used), "encrypted is not valid for encryption parameters");
+        if (size != 2) throw invalid_argument("expected size-2 ciphertexts"); off += used; }
+    return ciphertext3D::fromHost(h.data(), 1, zd, xd, yd);
+}
 static uint64_t g_enc_counter = 0;
 ciphertext3D encryptImage(vector<float> image, int zd, int xd, int yd)
 {

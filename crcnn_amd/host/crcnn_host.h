@@ -62,6 +62,11 @@ extern uint64_t crcnn_seed;                                 // seed of the clien
 void setParameters(int poly_modulus = 4096, uint64_t plain_modulus = 1 << 20);          // coeff_modulus_128(poly_modulus)
 void setParameters(int poly_modulus, const std::vector<uint64_t> &coeff_modulus, uint64_t plain_modulus, int device = 0);
 void delParameters();
+// key / ciphertext files in SEAL's wire formats, interchangeable with CrCNN's (globals.cpp:58-111, 174-205)
+void setAndSaveParameters(std::string public_key_path, std::string secret_key_path, std::string evaluation_key_path, int poly_modulus, uint64_t plain_modulus);
+void initFromKeys(std::string public_key_path, std::string secret_key_path, std::string evaluation_key_path, int poly_modulus, uint64_t plain_modulus);
+ciphertext3D encryptAndSaveImage(std::vector<float> image, int zd, int xd, int yd, std::string file_name);
+ciphertext3D loadEncryptedImage(int zd, int xd, int yd, std::string file_name);
 Plaintext fraencode(double value);                          // fraencoder->encode(value)
 double fradecode(const std::vector<uint64_t> &plain);
 ciphertext3D encryptImage(std::vector<float> image, int zd, int xd, int yd);             // globals.cpp:127-142

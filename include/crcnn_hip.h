@@ -177,6 +177,23 @@ int crc_relinearize(crc_ctx *ctx, const uint64_t *d_x3, size_t count, const uint
  * ------------------------------------------------------------------------------------------------------------- */
 int crc_import_seal(const crc_ctx *ctx, const uint64_t *h_seal, int size, uint64_t *h_out);
 int crc_export_seal(const crc_ctx *ctx, const uint64_t *h_in, int size, uint64_t *h_seal);
+/* SEAL 2.3.1 wire formats (byte-compatible with Ciphertext::save ciphertext.cpp:103-113, EvaluationKeys::save
+ * evaluationkeys.cpp:8-39, PublicKey/SecretKey::save publickey.h:81-98 / secretkey.h:86-107), incl. the 32-byte SHA3-256
+ * parameter hash (encryptionparams.cpp:69-100) that SEAL checks on every object.  *_load rejects a wrong hash / shape with
+ * CRC_ERR_INVALID_ARGUMENT ("not valid for encryption parameters").  Buffers are host memory. */
+int    crc_params_hash(const crc_ctx *ctx, uint64_t out[4]);
+size_t crc_seal_ct_bytes(const crc_ctx *ctx, int size);
+size_t crc_seal_evk_bytes(const crc_ctx *ctx, int dbc);
+size_t crc_seal_pk_bytes(const crc_ctx *ctx);
+size_t crc_seal_sk_bytes(const crc_ctx *ctx);
+int crc_seal_ct_save(const crc_ctx *ctx, const uint64_t *h_ct, int size, void *buf, size_t cap, size_t *written);
+int crc_seal_ct_load(const crc_ctx *ctx, const void *buf, size_t bytes, uint64_t *h_ct, int max_size, int *size, size_t *consumed);
+int crc_seal_evk_save(const crc_ctx *ctx, const uint64_t *h_evk, int dbc, void *buf, size_t cap, size_t *written);
+int crc_seal_evk_load(const crc_ctx *ctx, const void *buf, size_t bytes, uint64_t *h_evk, int *dbc);
+int crc_seal_pk_save(const crc_ctx *ctx, const uint64_t *h_pk, void *buf, size_t cap, size_t *written);
+int crc_seal_pk_load(const crc_ctx *ctx, const void *buf, size_t bytes, uint64_t *h_pk);
+int crc_seal_sk_save(const crc_ctx *ctx, const uint64_t *h_sk_ntt, void *buf, size_t cap, size_t *written);
+int crc_seal_sk_load(const crc_ctx *ctx, const void *buf, size_t bytes, uint64_t *h_sk_ntt);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * model loader (host)   replaces LoadH5::getDataVfloat (CrCNN/src/H5Easy.cpp:584-644) as used by

@@ -76,7 +76,8 @@ def make_ops(name, n, q, t, nct, vals):
         g = dict(
             n=n, q=np.array(q, dtype=np.uint64), t=t, floats=np.array(FLOATS), plain_values=np.array(vals),
             sk=sk, pk=pk, evk=evk, ct_in=cts, plains=plains, plain_cc=cc, msgs=msgs,
-            ref_consts=get(d, "ref_consts.u64"),
+            ref_consts=get(d, "ref_consts.u64"), ref_params_hash=get(d, "ref_params_hash.u64"),
+            **({nm: np.fromfile(os.path.join(d, nm + ".bin"), dtype=np.uint8) for nm in ("ref_wire_ct", "ref_wire_evk", "ref_wire_pk", "ref_wire_sk")} if n <= 256 else {}),
             ref_root_powers0=get(d, "ref_root_powers0.u64", (2, n)),
             ref_dec_in=get(d, "ref_dec_in.u64", (nct, n)), ref_budget_in=get(d, "ref_budget_in.u64"),
             ref_enc=get(d, "ref_enc.u64", (npl, 2, k, n)),

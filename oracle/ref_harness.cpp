@@ -194,6 +194,15 @@ static int do_ops()
         for (int i = 0; i < N; i++) rp.push_back(context->small_ntt_tables_[0].get_from_inv_root_powers_div_two(i));
         wr("ref_root_powers0.u64", rp);
     }
+    // (0) SEAL's own wire bytes of these objects (ciphertext / evaluation keys / public key / secret key), incl. the parameter hash
+    {
+        auto dump = [&](const string &name, const string &bytes) { ofstream f(DIR + "/" + name, ios::binary); f.write(bytes.data(), bytes.size()); };
+        { ostringstream o; to_ct(&cts[0], 2).save(o); dump("ref_wire_ct.bin", o.str()); }
+        { ostringstream o; ek.save(o); dump("ref_wire_evk.bin", o.str()); }
+        { ostringstream o; pk.save(o); dump("ref_wire_pk.bin", o.str()); }
+        { ostringstream o; sk.save(o); dump("ref_wire_sk.bin", o.str()); }
+        vector<u64> h(parms->hash_block().begin(), parms->hash_block().end()); wr("ref_params_hash.u64", h);
+    }
     // (1) the reference decrypts the oracle's ciphertexts under the oracle's secret key
     {
         vector<u64> out, bud;
