@@ -198,7 +198,8 @@ ciphertext3D loadEncryptedImage(int zd, int xd, int yd, string file_name)
     vector<uint64_t> h(cnt * ctw); size_t off = 0;
     for (size_t i = 0; i < cnt; i++) { int size = 0; size_t used = 0;
         chk(crc_seal_ct_load(ctx(), b.data() + off, b.size() - off, h.data() + i * ctw, 2, &size, &used), "encrypted is not valid for encryption parameters");
-        if (size != 2) throw invalid_argument("expected size-2 ciphertexts"); off += used; }
+        if (size != 2) throw invalid_argument("expected size-2 ciphertexts");
+        off += used; }
     return ciphertext3D::fromHost(h.data(), 1, zd, xd, yd);
 }
 static uint64_t g_enc_counter = 0;

@@ -124,16 +124,16 @@ static int do_api(int argc, char **argv)
     // key / image files in SEAL's wire formats (setAndSaveParameters / initFromKeys / encryptAndSaveImage / loadEncryptedImage)
     {
         crcnn_seed = 777;
-        setAndSaveParameters(dir + "/pk.bin", dir + "/sk.bin", dir + "/evk.bin", 1024, 1ULL << 20);
+        setAndSaveParameters(dir + "/pk.bin", dir + "/sk.bin", dir + "/evk.bin", 2048, 1ULL << 16);
         ciphertext3D saved = encryptAndSaveImage(small, 1, 14, 14, dir + "/img.bin");
         vector<u64> before = saved.toHost();
         crcnn_seed = 999;                                    // a different key pair would be generated ...
-        initFromKeys(dir + "/pk.bin", dir + "/sk.bin", dir + "/evk.bin", 1024, 1ULL << 20);       // ... but the files restore the first one
+        initFromKeys(dir + "/pk.bin", dir + "/sk.bin", dir + "/evk.bin", 2048, 1ULL << 16);       // ... but the files restore the first one
         ciphertext3D loaded = loadEncryptedImage(1, 14, 14, dir + "/img.bin");
         if (loaded.toHost() != before) { fprintf(stderr, "image file round trip differs\n"); return 11; }
         floatCube d3 = decryptImage(loaded);
         for (int i = 0; i < 196; i++) if (fabs(d3[0][i / 14][i % 14] - small[i]) > 1e-6) { fprintf(stderr, "decrypt after initFromKeys failed\n"); return 12; }
-        EXPECT_THROW(initFromKeys(dir + "/pk.bin", dir + "/sk.bin", dir + "/evk.bin", 1024, 1ULL << 21), invalid_argument);   // hash mismatch
+        EXPECT_THROW(initFromKeys(dir + "/pk.bin", dir + "/sk.bin", dir + "/evk.bin", 2048, 1ULL << 17), invalid_argument);   // hash mismatch
         setParameters(1024, {0x7fffffff380001ULL, 0x3fffffff000001ULL}, 1ULL << 20, 0);
     }
     // HDF5 loader through the builder
