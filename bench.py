@@ -230,9 +230,19 @@ def main():
         pl, _ = E.encode(im.reshape(-1))
         ct = E.encrypt(pk, pl, 7000 + 1000 * i)
         src[i].copy_(torch.from_numpy(ct.reshape(-1).view(np.int64)))
-    x_all = alloc(B * 784 * ctw * 8).view(B, 784 * ctw)
-    for b0 in range(0, B, D):
-        nb = min(D, B - b0); x_all[b0:b0 + nb].copy_(src[:nb])
+    # the batch is `D` distinct encrypted images tiled B/D times.  It is materialised in HBM when it fits beside the weights
+    # (Tiny: 98 GiB); for the bigger rings (1024 x 784 cts is 294 GiB at n=8192) a window of whole chunks is kept instead and
+    # chunk c reads window position c mod window -- the same tiling, the same bytes per image
+    img_bytes = 784 * ctw * 8
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    from crcnn_amd.netrun import TOPOLOGIES as _T
+    est_weights = sum((a_.get("nf", 0) * a_.get("zd", 0) * a_.get("xf", 0) * a_.get("yf", 0) + a_.get("in_dim", 0) * a_.get("out_dim", 0)) for _, _, a_ in _T[model]) * E.k * E.n * 8
+    budget = max(img_bytes * C, int(0.45 * (free_b - 1.25 * est_weights)))
+    step_w = C * D // np.gcd(C, D)                      # window must be a multiple of the chunk and of the tiling period
+    window = min(B, max(step_w, (budget // img_bytes) // step_w * step_w)) if budget // img_bytes < B else B
+    x_all = alloc(window * img_bytes).view(window, 784 * ctw)
+    for b0 in range(0, window, D):
+        nb = min(D, window - b0); x_all[b0:b0 + nb].copy_(src[:nb])
     del src
 
     # ---- encoded weights: rank 0 encodes + NTTs, RCCL broadcast to the others
@@ -255,7 +265,7 @@ def main():
         net.forward(x_all[0], 1); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for c0 in range(0, nu, C):
-            d_out = net.forward(x_all[c0], min(C, nu - c0))
+            d_out = net.forward(x_all[c0 % window], min(C, nu - c0))
             E.L.crc_memcpy_d2d(E.c, out_all[c0].data_ptr(), E.p(d_out), min(C, nu - c0) * 10 * ctw * 8, E.stream)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -282,7 +292,7 @@ def main():
             def timer(i, name, kind, phase):
                 if record:
                     e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e)
-            d_out = net.forward(x_all[c0], cb, timer=timer)
+            d_out = net.forward(x_all[c0 % window], cb, timer=timer)
             E.L.crc_memcpy_d2d(E.c, out_all[c0].data_ptr(), E.p(d_out), cb * 10 * ctw * 8, E.stream)
             if record:
                 lay_ev.append((cb, evs))
@@ -370,7 +380,7 @@ def main():
     line = {
         "metric": "encrypted images/sec", "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u64", "data": f"synthetic ({D} distinct MNIST-like encrypted images per GPU tiled to the batch; trained weights from {model}.h5)",
+        "dtype": "u64", "data": f"synthetic ({D} distinct MNIST-like encrypted images per GPU tiled to the batch" + ("" if window == B else f", resident as a {window}-image window") + f"; trained weights from {model}.h5)",
         "config": {"workload": f"{model}.h5 n={cfg['n']} k={cfg['k']} t=2^{cfg['t'].bit_length() - 1} batch={B}/GPU chunk={C} ({args.config}, BASELINE configs)",
                    "mode": args.mode + ("+conv/pool folding" if want_fuse else ""), "parallelism": f"image-sharded x{world}, RCCL weight broadcast"},
         "ms_per_layer": ms_per_layer, "reference_layer_structure": unfused, "roofline": roofline, "cpu_baseline": cpu,

@@ -698,6 +698,9 @@ int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, co
     // tile configuration <PX, FT, WM, WN, S>; CRC_MAC2_CFG selects an alternative for tuning runs (tools/bench_mac.py)
     static const int cfg = [] { const char *e = getenv("CRC_MAC2_CFG"); return e ? atoi(e) : 0; }();
     switch (cfg) {
+    case 1: return mac2_launch<2, 4, 3, 4, 2, 2>(c, a, st);
+    case 2: return mac2_launch<2, 4, 4, 4, 2, 2>(c, a, st);
+    case 3: return mac2_launch<2, 4, 3, 4, 2, 1>(c, a, st);
     case 7: return mac2_launch<3, 4, 2, 2, 2>(c, a, st);
     case 8: return mac2_launch<3, 4, 2, 4, 4, 1>(c, a, st);
     case 9: return mac2_launch<3, 4, 2, 4, 2, 1>(c, a, st);
