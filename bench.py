@@ -364,7 +364,17 @@ def main():
     dur_ms = lay_launch[dom] / max(1, lay_cnt[dom])
     achieved = alg_bytes / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
     macs_launch = layer_macs(kind, a) * C
-    roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
+    # HBM traffic of that launch from rocprofv3 PMC passes (FETCH_SIZE corrected x2 for gfx950, WRITE_SIZE), collected offline with
+    # tools/bench_mac.py and committed under profiles/ -- bench.py cannot run the profiler on itself
+    traffic = None
+    kernel_label = f"mac2_kernel ({name}, {C} images/launch)" if kind in ("conv", "fc") else f"{kind} ({name})"
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))).get(args.config)
+        if pm and pm["kernel"] == kernel_label:
+            traffic = int(pm["traffic_bytes"])
+    except Exception:
+        pass
+    roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                     kernel=f"mac_kernel ({name}, {C} images/launch)" if kind in ("conv", "fc") else f"{kind} ({name})",
                     launch_ms=round(float(dur_ms), 3), algorithmic_bytes_per_launch=int(alg_bytes),
                     modmul_per_s=round(macs_launch * 2 * E.k * E.n / (dur_ms * 1e-3), 1) if dur_ms > 0 else None)

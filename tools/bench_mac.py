@@ -12,6 +12,7 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 n, k, t = 4096, 2, 1 << 20
 geo = {"conv2": dict(zd=32, xd=12, yd=12, xs=1, ys=1, xf=5, yf=5, nf=64), "conv1": dict(zd=1, xd=28, yd=28, xs=1, ys=1, xf=5, yf=5, nf=32),
+       "conv2p": dict(zd=32, xd=12, yd=12, xs=2, ys=2, xf=6, yf=6, nf=64), "conv1p": dict(zd=1, xd=28, yd=28, xs=2, ys=2, xf=6, yf=6, nf=32),
        "fc3": dict(zd=1024, xd=1, yd=1, xs=1, ys=1, xf=1, yf=1, nf=512), "fc4": dict(zd=512, xd=1, yd=1, xs=1, ys=1, xf=1, yf=1, nf=10)}[layer]
 q = ca.default_coeff_modulus_128(n)[:k]
 E = ca.Engine(n, q, t, device=0)
