@@ -531,70 +531,68 @@ __global__ void __launch_bounds__(64 * WM * WN) mac2_kernel(MacArgs a)
         }
     }
 
+    // wide staging loads: ONE global_load_dwordx4 fetches two vectors of a pair -- lanes 0..31 take slots (2l, 2l+1) of the even
+    // vector, lanes 32..63 the same slots of the odd one (the cost of staging is per memory INSTRUCTION, see DESIGN.md ablation)
+    const int half = lane >> 5, l2 = (lane & 31) * 2;
+    const u32 rown2 = (u32)((size_t)i * n + (s - lane) + l2);
+    const u32 hmask = half ? 0xffffffffu : 0u;
+    u32 vdelta[RLOAD / 2];                                   // element distance even -> odd vector of a pair (wave-uniform)
+#pragma unroll
+    for (int jj = 0; jj < RLOAD / 2; jj++) vdelta[jj] = (u32)(vbase[2 * jj + 1] - vbase[2 * jj]);
+
     u64 A0[PX * 2][FT], A1[PX * 2][FT], A2[PX * 2][FT]; u32 OV[PX * 2][FT];
 #pragma unroll
     for (int r = 0; r < PX * 2; r++)
 #pragma unroll
         for (int f = 0; f < FT; f++) { A0[r][f] = 0; A1[r][f] = 0; A2[r][f] = 0; OV[r][f] = 0; }
 
-    u64 regA[RLOAD], regB[RLOAD];          // two register stages: operand loads run TWO pipeline stages ahead of their use
+    ulonglong2 regA[RLOAD / 2], regB[RLOAD / 2];    // two register stages: operand loads run TWO pipeline stages ahead of their use
     // per-term x offsets: the padded toffw table is copied into LDS once (scalar loads inside the loop would share lgkmcnt
     // with the LDS operand reads and stall them); lanes read the same word (broadcast)
     u32 *tw = reinterpret_cast<u32 *>(smem + (size_t)2 * VEC * 64);
     for (int t = threadIdx.x; t < a.T + 8; t += blockDim.x) tw[t] = a.toffw[t];
     __syncthreads();                                 // the table is read by every wave from the first load_stage on
     const u32 kn32 = (u32)kn;
-    auto load_one = [&](int st, int j, u64 (&reg)[RLOAD]) {
-        const int t = min(st * S + vstep[j], a.T - 1);
-        const u32 off = visx[j] ? tw[t] : (u32)t * kn32;
-        reg[j] = *reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(vbase[j]) + (size_t)((off + (u32)rown) << 3));   // uniform base + 32-bit lane offset; consumed only by store_pair
+    auto load_one = [&](int st, int jj, ulonglong2 (&reg)[RLOAD / 2]) {
+        const int t = min(st * S + vstep[2 * jj], a.T - 1);
+        const u32 off = visx[2 * jj] ? tw[t] : (u32)t * kn32;
+        reg[jj] = *reinterpret_cast<const ulonglong2 *>(reinterpret_cast<const char *>(vbase[2 * jj]) + (size_t)((off + rown2 + (hmask & vdelta[jj])) << 3));   // consumed only by store_pair
     };
-    auto store_pair = [&](int st, int jj, u64 (&reg)[RLOAD]) {
-        ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(smem) + (size_t)(st & 1) * NPAIR * 64;
+    auto store_pair = [&](int st, int jj, ulonglong2 (&reg)[RLOAD / 2]) {
+        u64 *dst = smem + (size_t)(st & 1) * VEC * 64;
         const int pr = wave + jj * NW;
+        const bool dead = !visx[2 * jj] && st * S + vstep[2 * jj] >= a.T;                 // weights past the last term are zero (x may be anything valid)
         ulonglong2 v;
-        {   const bool dead = !visx[2 * jj] && st * S + vstep[2 * jj] >= a.T;             // weights past the last term are zero (x may be anything valid)
-            const u64 r = dead ? 0 : reg[2 * jj]; v.x = split28(r); }         // pre-split once: low dword = x0 (28 bit), high dword = x1
-        {   const bool dead = !visx[2 * jj + 1] && st * S + vstep[2 * jj + 1] >= a.T;
-            const u64 r = dead ? 0 : reg[2 * jj + 1]; v.y = split28(r); }
-        if (pr < NPAIR) dst[pr * 64 + lane] = v;                                            // one ds_write_b128 per operand pair
+        v.x = split28(dead ? 0 : reg[jj].x); v.y = split28(dead ? 0 : reg[jj].y);        // pre-split once: low dword = x0 (28 bit), high dword = x1
+        if (pr < NPAIR) *reinterpret_cast<ulonglong2 *>(dst + (2 * pr + half) * 64 + l2) = v;     // one ds_write_b128: two adjacent slots of one vector
     };
-    auto load_stage = [&](int st, u64 (&reg)[RLOAD]) {
+    auto load_stage = [&](int st, ulonglong2 (&reg)[RLOAD / 2]) {
         if (st > 1 && (a.dbg == 1 || a.dbg == 2 || a.dbg == 4)) return;
 #pragma unroll
-        for (int j = 0; j < RLOAD; j++) { if (a.dbg == 7 && st > 1 && (j & 1)) continue; load_one(st, j, reg); }
+        for (int jj = 0; jj < RLOAD / 2; jj++) { if (a.dbg == 7 && st > 1 && (jj & 1)) continue; load_one(st, jj, reg); }
     };
-    auto store_stage = [&](int st, u64 (&reg)[RLOAD]) {
+    auto store_stage = [&](int st, ulonglong2 (&reg)[RLOAD / 2]) {
         if (st > 1 && (a.dbg == 1 || a.dbg == 2 || a.dbg == 3)) return;
 #pragma unroll
         for (int jj = 0; jj < RLOAD / 2; jj++) store_pair(st, jj, reg);
     };
     auto compute_stage = [&](int st) {
-        const ulonglong2 *buf = reinterpret_cast<const ulonglong2 *>(smem) + (size_t)(st & 1) * NPAIR * 64;
+        const u64 *buf = smem + (size_t)(st & 1) * VEC * 64;
 #pragma unroll 1
         for (int step = 0; step < S; step++) {
-            const ulonglong2 *sv = buf + step * ((ROWS + FW) / 2) * 64 + lane;
+            const u64 *sv = buf + step * (ROWS + FW) * 64 + lane;
             u32 w0[FT], w1[FT], ws[FT];
 #pragma unroll
-            for (int f = 0; f < FT; f += 2) {
-                const ulonglong2 wv = sv[(ROWS / 2 + (wn * FT + f) / 2) * 64];
-                w0[f] = (u32)wv.x; w1[f] = (u32)(wv.x >> 32); ws[f] = w0[f] + w1[f];
-                w0[f + 1] = (u32)wv.y; w1[f + 1] = (u32)(wv.y >> 32); ws[f + 1] = w0[f + 1] + w1[f + 1];
-            }
+            for (int f = 0; f < FT; f++) { const u64 wv = sv[(ROWS + wn * FT + f) * 64]; w0[f] = (u32)wv; w1[f] = (u32)(wv >> 32); ws[f] = w0[f] + w1[f]; }
 #pragma unroll
-            for (int px = 0; px < PX; px++) {
-                const ulonglong2 xv = sv[(wm * PX + px) * 64];            // both polys of one pixel
+            for (int r = 0; r < PX * 2; r++) {
+                const u64 xv = sv[(wm * PX * 2 + r) * 64];
+                const u32 x0 = (u32)xv, x1 = (u32)(xv >> 32), xs = x0 + x1;
 #pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    const u64 xc = c ? xv.y : xv.x;
-                    const u32 x0 = (u32)xc, x1 = (u32)(xc >> 32), xs = x0 + x1;
-                    const int r = px * 2 + c;
-#pragma unroll
-                    for (int f = 0; f < FT; f++) {
-                        A0[r][f] += (u64)x0 * w0[f];
-                        A2[r][f] += (u64)x1 * w1[f];
-                        A1[r][f] += (u64)xs * ws[f];
-                    }
+                for (int f = 0; f < FT; f++) {
+                    A0[r][f] += (u64)x0 * w0[f];
+                    A2[r][f] += (u64)x1 * w1[f];
+                    A1[r][f] += (u64)xs * ws[f];
                 }
             }
         }
@@ -689,7 +687,10 @@ int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, co
 {
     if (B == 0 || P == 0 || F == 0) return CRC_OK;
     int maxbits = 0; for (int i = 0; i < c->k; i++) if ((int)c->tabs[i].m.bits > maxbits) maxbits = c->tabs[i].m.bits;
-    if (maxbits > 55 || T > 16000 || c->n < 64) return k_mac(c, x, w, y, d_xoff, d_toff, B, P, F, T, in_cts, bias_ntt, st);
+    // mac2 addresses operands as wave-uniform base + 32-bit byte offset (term offset + half-wave pair offset + slot)
+    const size_t kn8 = (size_t)c->k * c->n * 8;
+    const bool off32 = ((size_t)2 * T + 3) * kn8 < (1ull << 32) && ((size_t)2 * in_cts + 3) * kn8 < (1ull << 32);
+    if (maxbits > 55 || T > 16000 || c->n < 64 || !off32) return k_mac(c, x, w, y, d_xoff, d_toff, B, P, F, T, in_cts, bias_ntt, st);
     MacArgs a{};
     a.x = x; a.w = w; a.y = y; a.mods = c->d_mods; a.xoff = d_xoff; a.toff = d_toff; a.toffw = d_toffw;
     a.n = c->n; a.k = c->k; a.B = B; a.P = P; a.F = F; a.T = T; a.in_cts = in_cts; a.bias = bias_ntt; a.bias_sign = 1;
