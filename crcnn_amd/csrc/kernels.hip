@@ -576,10 +576,16 @@ __global__ void __launch_bounds__(64 * WM * WN) mac2_kernel(MacArgs a)
 #pragma unroll
         for (int jj = 0; jj < RLOAD / 2; jj++) store_pair(st, jj, reg);
     };
-    auto compute_stage = [&](int st) {
+    // the staging traffic of a stage (LDS writes of stage st+1, global loads of stage st+2) is issued INSIDE the compute of stage
+    // st, at a different reduction step in the two waves that share a SIMD (waves w and w+4): while one wave issues its memory
+    // instructions the other one has multiply-adds to issue, instead of all eight waves staging at the same moment
+    const int io_sel = a.dbg == 8 ? (wave & 1) : a.dbg == 9 ? 0 : ((wave >> 2) & 1);     // dbg 8/9: tuning controls (tools/bench_mac.py)
+    const int io_step = io_sel ? S / 2 : 0;
+    auto compute_stage = [&](int st, auto &&io) {
         const u64 *buf = smem + (size_t)(st & 1) * VEC * 64;
 #pragma unroll 1
         for (int step = 0; step < S; step++) {
+            if (step == io_step) io();
             const u64 *sv = buf + step * (ROWS + FW) * 64 + lane;
             u32 w0[FT], w1[FT], ws[FT];
 #pragma unroll
@@ -613,14 +619,10 @@ __global__ void __launch_bounds__(64 * WM * WN) mac2_kernel(MacArgs a)
         if (nstages > 1) load_stage(1, regA);
         __syncthreads();
         for (int st = 0; st < nstages; st += 2) {
-            if (st + 2 < nstages) load_stage(st + 2, regB);
-            compute_stage(st);
-            if (st + 1 < nstages) store_stage(st + 1, regA);
+            compute_stage(st, [&] { if (st + 1 < nstages) store_stage(st + 1, regA); if (st + 2 < nstages) load_stage(st + 2, regB); });
             __syncthreads();
             if (st + 1 < nstages) {
-                if (st + 3 < nstages) load_stage(st + 3, regA);
-                compute_stage(st + 1);
-                if (st + 2 < nstages) store_stage(st + 2, regB);
+                compute_stage(st + 1, [&] { if (st + 2 < nstages) store_stage(st + 2, regB); if (st + 3 < nstages) load_stage(st + 3, regA); });
                 __syncthreads();
             }
         }
@@ -628,7 +630,7 @@ __global__ void __launch_bounds__(64 * WM * WN) mac2_kernel(MacArgs a)
         __syncthreads();
         for (int st = 0; st < nstages; st++) {
             if (st + 1 < nstages) load_stage(st + 1, regA);
-            compute_stage(st);
+            compute_stage(st, [] {});
             if (st + 1 < nstages) store_stage(st + 1, regA);
             __syncthreads();
         }
