@@ -698,17 +698,20 @@ int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, co
     a.n = c->n; a.k = c->k; a.B = B; a.P = P; a.F = F; a.T = T; a.in_cts = in_cts; a.bias = bias_ntt; a.bias_sign = 1;
     a.gxd = gxd; a.gyd = gyd; a.gxf = gxf; a.gyf = gyf;
     { static const int dbg = [] { const char *e = getenv("CRC_MAC2_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
-    // tile configuration <PX, FT, WM, WN, S>; CRC_MAC2_CFG selects an alternative for tuning runs (tools/bench_mac.py)
+    // tile configuration <PX, FT, WM, WN, S>: a workgroup covers PX*WM pixels x FT*WN filters (6 x 16 or 12 x 8), 24 accumulators
+    // per wave either way; pick the shape that wastes fewer multiply-adds on filter/pixel padding (F = 50 -> 56 instead of 64,
+    // F = 20 -> 24 instead of 32; measured equal on full tiles).  CRC_MAC2_CFG forces one (tools/bench_mac.py)
     static const int cfg = [] { const char *e = getenv("CRC_MAC2_CFG"); return e ? atoi(e) : 0; }();
-    switch (cfg) {
-    case 1: return mac2_launch<2, 4, 3, 4, 2, 2>(c, a, st);
-    case 2: return mac2_launch<2, 4, 4, 4, 2, 2>(c, a, st);
+    int pick = cfg;
+    if (pick == 0) {
+        const long long M = (long long)B * P;
+        auto padded = [&](int mt, int fw) { return ((M + mt - 1) / mt * mt) * (((long long)F + fw - 1) / fw * fw); };
+        pick = padded(12, 8) * 100 < padded(6, 16) * 98 ? 8 : 16;
+    }
+    switch (pick) {
     case 3: return mac2_launch<2, 4, 3, 4, 2, 1>(c, a, st);
-    case 7: return mac2_launch<3, 4, 2, 2, 2>(c, a, st);
-    case 8: return mac2_launch<3, 4, 2, 4, 4, 1>(c, a, st);
     case 9: return mac2_launch<3, 4, 2, 4, 2, 1>(c, a, st);
-    case 10: return mac2_launch<3, 4, 2, 4, 5, 1>(c, a, st);
-    case 11: return mac2_launch<3, 4, 2, 4, 3, 2>(c, a, st);
+    case 8: return mac2_launch<3, 4, 4, 2, 2>(c, a, st);
     default: return mac2_launch<3, 4, 2, 4, 2>(c, a, st);
     }
 }

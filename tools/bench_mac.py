@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time one layer's ct x pt MAC launch on random residues (kernel-only view of the dominant kernel).
-usage: python tools/bench_mac.py [conv2|conv1|fc3] [B] [reps]"""
+usage: python tools/bench_mac.py [conv2|conv1|fc3|conv1p|conv2p|aconv1|aconv2|afc3|f5] [B] [reps]   (a*: ApproxPlainModel shapes; CRC_MAC2_CFG=16|8 forces a tile shape)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,6 +13,8 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 n, k, t = 4096, 2, 1 << 20
 geo = {"conv2": dict(zd=32, xd=12, yd=12, xs=1, ys=1, xf=5, yf=5, nf=64), "conv1": dict(zd=1, xd=28, yd=28, xs=1, ys=1, xf=5, yf=5, nf=32),
        "conv2p": dict(zd=32, xd=12, yd=12, xs=2, ys=2, xf=6, yf=6, nf=64), "conv1p": dict(zd=1, xd=28, yd=28, xs=2, ys=2, xf=6, yf=6, nf=32),
+       "aconv1": dict(zd=1, xd=28, yd=28, xs=2, ys=2, xf=5, yf=5, nf=20), "aconv2": dict(zd=20, xd=11, yd=11, xs=2, ys=2, xf=3, yf=3, nf=50),
+       "afc3": dict(zd=800, xd=1, yd=1, xs=1, ys=1, xf=1, yf=1, nf=500), "f5": dict(zd=4, xd=28, yd=28, xs=1, ys=1, xf=5, yf=5, nf=5),
        "fc3": dict(zd=1024, xd=1, yd=1, xs=1, ys=1, xf=1, yf=1, nf=512), "fc4": dict(zd=512, xd=1, yd=1, xs=1, ys=1, xf=1, yf=1, nf=10)}[layer]
 q = ca.default_coeff_modulus_128(n)[:k]
 E = ca.Engine(n, q, t, device=0)
