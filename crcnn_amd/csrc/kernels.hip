@@ -493,7 +493,7 @@ __device__ __forceinline__ u64 split28(u64 r)
 }
 
 template <int PX, int FT, int WM, int WN, int S, int DEPTH = 2>
-__global__ void __launch_bounds__(64 * WM * WN) mac2_kernel(MacArgs a)
+__global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2))) mac2_kernel(MacArgs a)
 {
     constexpr int NW = WM * WN, MT = PX * WM, ROWS = 2 * MT, FW = FT * WN;
     constexpr int VEC = S * (ROWS + FW), NPAIR = VEC / 2, RLOAD = 2 * ((NPAIR + NW - 1) / NW);      // operand vectors are staged in (even, odd) pairs
@@ -712,6 +712,8 @@ int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, co
     case 3: return mac2_launch<2, 4, 3, 4, 2, 1>(c, a, st);
     case 9: return mac2_launch<3, 4, 2, 4, 2, 1>(c, a, st);
     case 8: return mac2_launch<3, 4, 4, 2, 2>(c, a, st);
+    case 4: return mac2_launch<3, 4, 2, 2, 2>(c, a, st);
+    case 5: return mac2_launch<3, 4, 1, 4, 2>(c, a, st);
     default: return mac2_launch<3, 4, 2, 4, 2>(c, a, st);
     }
 }
