@@ -33,11 +33,32 @@ struct NttArgs {
 // enumerating the access patterns (bank = index mod 32 per 32-lane group)
 __device__ __forceinline__ int lpad(int i) { return i ^ ((i >> 3) & 7) ^ (((i >> 6) & 3) << 3); }
 
+// Lazy variant (LAZY = true, moduli of at most 57 bits): there are 7+ spare bits above q in a 64-bit word, so butterflies never
+// correct their inputs and use a 3-product estimate of the Shoup quotient (result in [0, 4q) instead of [0, 2q)); the forward
+// transform lets values grow by 4q per stage (<= (1 + 4*14) q < 2^63), the inverse one stays below 11q because every stage halves.
+// One float-estimated reduction per coefficient at the end makes the output canonical, so the bits are the reference's.
+__device__ __forceinline__ u64 shoup_lazy4(u64 a, u64 w, u64 wp, u64 q)
+{
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), p0 = (u32)wp, p1 = (u32)(wp >> 32);
+    const u64 h = (u64)a1 * p1 + __umulhi(a1, p0) + __umulhi(a0, p1);          // floor(a*wp / 2^64) - {0,1,2}
+    return a * w - h * q;
+}
+// v < 128 q  ->  v mod q.  rq = 1 / float((q >> 32) + 1): the quotient estimate never exceeds floor(v/q) and is at most 2 short.
+__device__ __forceinline__ u64 reduce_small(u64 v, u64 q, u64 q2, float rq)
+{
+    u32 est = (u32)((float)(u32)(v >> 32) * rq);
+    est = est ? est - 1 : 0;
+    v -= (u64)est * q;
+    v = v >= q2 ? v - q2 : v;
+    return v >= q ? v - q : v;
+}
+
 // R butterfly stages on 2^R register-resident values.  Forward (Cooley-Tukey): first stage pairs c with c + 2^(R-1);
 // inverse (Gentleman-Sande): first stage pairs c with c + 1.
-template <int R>
+template <int R, bool LAZY>
 __device__ __forceinline__ void fwd_stages(u64 (&v)[1 << R], const ulonglong2 *W, int m, int blk, u64 q, u64 q2)
 {
+    const u64 q4 = q2 + q2;
 #pragma unroll
     for (int st = 0; st < R; st++) {
         const int half = 1 << (R - 1 - st);
@@ -47,16 +68,23 @@ __device__ __forceinline__ void fwd_stages(u64 (&v)[1 << R], const ulonglong2 *W
             const int wi = (m << st) + (blk << st) + (c >> (R - st));
             const ulonglong2 tw = W[wi]; const u64 w = tw.x, wp = tw.y;
             u64 X = v[c]; const u64 Y = v[c + half];
-            X = X >= q2 ? X - q2 : X;
-            const u64 Q = mulmod_shoup_lazy(Y, w, wp, q);
-            v[c] = X + Q;
-            v[c + half] = X + (q2 - Q);
+            if (LAZY) {
+                const u64 Q = shoup_lazy4(Y, w, wp, q);
+                v[c] = X + Q;
+                v[c + half] = X + (q4 - Q);
+            } else {
+                X = X >= q2 ? X - q2 : X;
+                const u64 Q = mulmod_shoup_lazy(Y, w, wp, q);
+                v[c] = X + Q;
+                v[c + half] = X + (q2 - Q);
+            }
         }
     }
 }
-template <int R>
+template <int R, bool LAZY>
 __device__ __forceinline__ void inv_stages(u64 (&v)[1 << R], const ulonglong2 *W, int h, int blk, u64 q, u64 q2)
 {
+    const u64 q16 = q2 << 3;
 #pragma unroll
     for (int st = 0; st < R; st++) {
         const int half = 1 << st;
@@ -66,16 +94,23 @@ __device__ __forceinline__ void inv_stages(u64 (&v)[1 << R], const ulonglong2 *W
             const int wi = (h >> st) + (blk << (R - 1 - st)) + (c >> (st + 1));
             const ulonglong2 tw = W[wi]; const u64 w = tw.x, wp = tw.y;
             const u64 U = v[c], V = v[c + half];
-            const u64 T = q2 - V + U;
-            u64 cu = U + V; cu = cu >= q2 ? cu - q2 : cu;
-            v[c] = (cu + ((cu & 1) ? q : 0)) >> 1;
-            v[c + half] = mulmod_shoup_lazy(T, w, wp, q);
+            if (LAZY) {                                  // U, V < Bq  ->  U' < (B + 1/2) q, V' < 4q: never above (4 + 13/2) q < 16q
+                const u64 T = q16 - V + U;
+                const u64 cu = U + V;
+                v[c] = (cu + ((cu & 1) ? q : 0)) >> 1;
+                v[c + half] = shoup_lazy4(T, w, wp, q);
+            } else {
+                const u64 T = q2 - V + U;
+                u64 cu = U + V; cu = cu >= q2 ? cu - q2 : cu;
+                v[c] = (cu + ((cu & 1) ? q : 0)) >> 1;
+                v[c + half] = mulmod_shoup_lazy(T, w, wp, q);
+            }
         }
     }
 }
 
 // one pass over the whole row: every thread takes groups of 2^R values that interact in the next R stages
-template <bool INV, int R>
+template <bool INV, int R, bool LAZY>
 __device__ __forceinline__ void ntt_pass(u64 *sm, const ulonglong2 *W, int n, int s /*element stride inside a group*/, int tabidx, u64 q, u64 q2)
 {
     const int groups = n >> R;
@@ -85,14 +120,14 @@ __device__ __forceinline__ void ntt_pass(u64 *sm, const ulonglong2 *W, int n, in
         u64 v[1 << R];
 #pragma unroll
         for (int c = 0; c < (1 << R); c++) v[c] = sm[lpad(base + c * s)];
-        if (INV) inv_stages<R>(v, W, tabidx, blk, q, q2); else fwd_stages<R>(v, W, tabidx, blk, q, q2);
+        if (INV) inv_stages<R, LAZY>(v, W, tabidx, blk, q, q2); else fwd_stages<R, LAZY>(v, W, tabidx, blk, q, q2);
 #pragma unroll
         for (int c = 0; c < (1 << R); c++) sm[lpad(base + c * s)] = v[c];
     }
     __syncthreads();
 }
 
-template <bool INV>
+template <bool INV, bool LAZY>
 __global__ void __launch_bounds__(1024) ntt_rows_kernel(NttArgs a)
 {
     extern __shared__ u64 sm[];
@@ -102,6 +137,7 @@ __global__ void __launch_bounds__(1024) ntt_rows_kernel(NttArgs a)
     const int mi = a.mod_base + mloc;
     const ModParams m = a.mods[mi];
     const u64 q = m.q, q2 = m.two_q;
+    const float rq = 1.0f / (float)((u32)(q >> 32) + 1);
     const ulonglong2 *W = a.w + (size_t)mi * n;
     const u64 *src = a.src + (a.src_rows_per_item ? (row / a.mod_count) : row) * (size_t)n;
     u64 *dst = a.dst + row * (size_t)n;
@@ -122,21 +158,21 @@ __global__ void __launch_bounds__(1024) ntt_rows_kernel(NttArgs a)
     if (!INV) {
         // gaps n/2, n/4, ...: radix-8 passes first, a radix-4 / radix-2 pass finishes when log2(n) is not a multiple of 3
         int t = n >> 1;
-        for (int p = 0; p < full; p++, t >>= 3) ntt_pass<false, 3>(sm, W, n, t >> 2, n / (2 * t), q, q2);
-        if (rem == 2) ntt_pass<false, 2>(sm, W, n, t >> 1, n / (2 * t), q, q2);
-        else if (rem == 1) ntt_pass<false, 1>(sm, W, n, t, n / (2 * t), q, q2);
+        for (int p = 0; p < full; p++, t >>= 3) ntt_pass<false, 3, LAZY>(sm, W, n, t >> 2, n / (2 * t), q, q2);
+        if (rem == 2) ntt_pass<false, 2, LAZY>(sm, W, n, t >> 1, n / (2 * t), q, q2);
+        else if (rem == 1) ntt_pass<false, 1, LAZY>(sm, W, n, t, n / (2 * t), q, q2);
         for (int s = tid; s < n; s += nt) {
             u64 v = sm[lpad(s)];
-            v = v >= q2 ? v - q2 : v;
-            v = v >= q ? v - q : v;
+            if (LAZY) v = reduce_small(v, q, q2, rq);
+            else { v = v >= q2 ? v - q2 : v; v = v >= q ? v - q : v; }
             dst[s] = v;
         }
     } else {
         // gaps 1, 2, 4, ...
         int t = 1;
-        for (int p = 0; p < full; p++, t <<= 3) ntt_pass<true, 3>(sm, W, n, t, n / (2 * t), q, q2);
-        if (rem == 2) ntt_pass<true, 2>(sm, W, n, t, n / (2 * t), q, q2);
-        else if (rem == 1) ntt_pass<true, 1>(sm, W, n, t, n / (2 * t), q, q2);
+        for (int p = 0; p < full; p++, t <<= 3) ntt_pass<true, 3, LAZY>(sm, W, n, t, n / (2 * t), q, q2);
+        if (rem == 2) ntt_pass<true, 2, LAZY>(sm, W, n, t, n / (2 * t), q, q2);
+        else if (rem == 1) ntt_pass<true, 1, LAZY>(sm, W, n, t, n / (2 * t), q, q2);
         const u64 *add = nullptr;
         if (a.addend) {
             const size_t ct = row / a.rows_per_ct; const int p = (int)((row % a.rows_per_ct) / a.mod_count);
@@ -145,8 +181,8 @@ __global__ void __launch_bounds__(1024) ntt_rows_kernel(NttArgs a)
         }
         for (int s = tid; s < n; s += nt) {
             u64 v = sm[lpad(s)];
-            v = v >= q2 ? v - q2 : v;
-            v = v >= q ? v - q : v;
+            if (LAZY) v = reduce_small(v, q, q2, rq);
+            else { v = v >= q2 ? v - q2 : v; v = v >= q ? v - q : v; }
             if (add) v = a.add_sign > 0 ? addmod(v, add[s], q) : submod(v, add[s], q);
             dst[s] = v;
         }
@@ -160,13 +196,13 @@ static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t
     a.w = reinterpret_cast<const ulonglong2 *>(inv ? c->d_irp2 : c->d_rp);
     int nt = c->n / 8; if (nt < 64) nt = 64; if (nt > 1024) nt = 1024;
     size_t lds = (size_t)c->n * 8;
-    if (inv) {
-        if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)ntt_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(ntt_rows_kernel<true>, dim3((unsigned)rows), dim3(nt), lds, st, a);
-    } else {
-        if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)ntt_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(ntt_rows_kernel<false>, dim3((unsigned)rows), dim3(nt), lds, st, a);
-    }
+    // lazy butterflies need (1 + 4 log2 n) q < 2^64 (and the float quotient estimate a q of 45+ bits): every coefficient modulus of the
+    // reference's parameter sets qualifies (54..55 bits), the 61-bit auxiliary base of Square does not
+    bool lazy = true;
+    for (int i = a.mod_base; i < a.mod_base + a.mod_count; i++) if (c->tabs[i].m.bits > 57 || c->tabs[i].m.bits < 45) lazy = false;
+    auto kern = inv ? (lazy ? ntt_rows_kernel<true, true> : ntt_rows_kernel<true, false>) : (lazy ? ntt_rows_kernel<false, true> : ntt_rows_kernel<false, false>);
+    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)rows), dim3(nt), lds, st, a);
     HIPCHK(hipGetLastError());
     return CRC_OK;
 }
