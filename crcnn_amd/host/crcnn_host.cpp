@@ -435,6 +435,27 @@ ciphertext3D Network::forward(ciphertext3D input)
         layers[i]->out_form = coeff ? CRC_COEFF : CRC_NTT;
     }
     last_layer_ms.assign(L, 0.0);
+    if (max_num_of_reencryptions >= 0) {                    // network.cpp:52-96
+        int refreshes_left = max_num_of_reencryptions;
+        for (int i = 0; i < L; i++) {
+            layers[i]->out_form = CRC_COEFF;
+            auto t0 = chrono::high_resolution_clock::now();
+            ciphertext3D output = layers[i]->forward(input);
+            chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+            last_layer_ms[i] += chrono::duration<double, milli>(chrono::high_resolution_clock::now() - t0).count();
+            if (noiseBudget(output) <= 5) {
+                if (refreshes_left <= 0) throw OutOfBudgetException(i - 1);
+                vector<floatCube> imgs = decryptImages(input);
+                vector<ciphertext3D> enc; for (auto &im : imgs) enc.push_back(encryptImage(im));
+                input = stackImages(enc);
+                refreshes_left--;
+                i--;
+                continue;
+            }
+            input = output;
+        }
+        return input;
+    }
     for (int i = 0; i < L; i++) {
         if (i == layer_before_reenc) {                      // client-side refresh (needs the secret key), network.cpp:30-34
             vector<floatCube> imgs = decryptImages(input);

@@ -195,6 +195,10 @@ public:
     // the accelerated path, so it is a setting here: 6 reproduces the committed reference, -1 (default) never refreshes.
     int layer_before_reenc = -1;
     bool ntt_resident = true;                               // keep tensors in NTT form between linear layers (bit-identical)
+    // >= 0 selects the budget-checking forward the reference keeps for its parameter search (network.cpp:52-96): after every layer the
+    // noise budget of output[0][0][0] is measured (secret key, coefficient form at every boundary); at <= 5 bits the layer's input is
+    // refreshed and the layer repeated while refreshes are left, then OutOfBudgetException(i - 1) is thrown.  -1: plain forward.
+    int max_num_of_reencryptions = -1;
     std::vector<double> last_layer_ms;                      // per-layer wall milliseconds of the last forward (T_LAYER_i, mainparams.cpp:81)
     Network() {}
     ~Network() {}

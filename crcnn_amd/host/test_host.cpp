@@ -2,7 +2,13 @@
 //   test_host net <model> <h5> <dir> <resident 0|1> <batch>
 //     <dir>/params.u64 (n,k,t,q...), evk.u64, net_in.u64 ([1][1][28][28][2][k][n]) -> writes layer_<i>.u64 (layerwise mode) and out.u64
 //   test_host api <h5> <dir>     exercises save/load of the encoded model, client-side encrypt/decrypt, and error behaviour
+//   test_host searchlogic <min> <max> <first_good> <last_good> <min_q>
+//     the plain-modulus search on a synthetic predicate (t < first_good: MISPREDICTED, t > last_good: OUT_OF_BUDGET); no GPU work.
+//     prints "found <t>" and one "tried <t> <status>" line per test
+//   test_host search <model> <h5> <images.f32> <n> <min> <max> <num_images> <seed> [q0 q1 ...]   (no q: coeff_modulus_128(n))
+//     the real search: images.f32 = N x 784 normalised float32 pixels, labels from the float model; prints found / tried lines
 #include "crcnn_host.h"
+#include "plain_modulus_search.h"
 #include <cmath>
 #include <cstdio>
 #include <sstream>
@@ -59,6 +65,42 @@ static int do_net(int argc, char **argv)
         fprintf(stderr, "\n");
     }
     delParameters();
+    return 0;
+}
+
+static const char *status_name(exit_status_forward s) { return s == SUCCESS ? "SUCCESS" : s == OUT_OF_BUDGET ? "OUT_OF_BUDGET" : "MISPREDICTED"; }
+
+static int do_searchlogic(int argc, char **argv)
+{
+    if (argc < 7) return 1;
+    const u64 lo = strtoull(argv[2], 0, 0), hi = strtoull(argv[3], 0, 0), first_good = strtoull(argv[4], 0, 0), last_good = strtoull(argv[5], 0, 0), min_q = strtoull(argv[6], 0, 0);
+    vector<pair<u64, exit_status_forward>> tried;
+    auto pred = [&](u64 t) { exit_status_forward s = t < first_good ? MISPREDICTED : t > last_good ? OUT_OF_BUDGET : SUCCESS; tried.emplace_back(t, s); return s; };
+    const u64 found = plainModulusBinarySearch(pred, lo, hi, min_q);
+    printf("found %llu\n", (unsigned long long)found);
+    for (auto &p : tried) printf("tried %llu %s\n", (unsigned long long)p.first, status_name(p.second));
+    return 0;
+}
+
+static int do_search(int argc, char **argv)
+{
+    if (argc < 10) return 1;
+    PlainModulusSearch s;
+    s.model = argv[2];
+    const string h5 = argv[3], images = argv[4];
+    s.max_poly_modulus = atoi(argv[5]);
+    const u64 lo = strtoull(argv[6], 0, 0), hi = strtoull(argv[7], 0, 0);
+    const int num_images = atoi(argv[8]); s.seed = (unsigned)strtoul(argv[9], 0, 0);
+    for (int i = 10; i < argc; i++) s.coeff_modulus.push_back(strtoull(argv[i], 0, 0));
+    ifstream f(images, ios::binary); if (!f) { fprintf(stderr, "missing %s\n", images.c_str()); return 2; }
+    f.seekg(0, ios::end); const size_t cnt = (size_t)f.tellg() / (784 * 4); f.seekg(0);
+    s.test_set.assign(cnt, vector<float>(784));
+    for (auto &im : s.test_set) f.read((char *)im.data(), 784 * 4);
+    s.predictWithPlainModel(h5);
+    for (size_t i = 0; i < cnt; i++) printf("label %zu %d\n", i, (int)s.predicted_labels[i]);
+    const u64 found = s.run(num_images, lo, hi, h5);
+    printf("found %llu\n", (unsigned long long)found);
+    for (size_t i = 0; i < s.tried.size(); i++) printf("tried %llu %s %.2f\n", (unsigned long long)s.tried[i].first, status_name(s.tried[i].second), s.test_seconds[i]);
     return 0;
 }
 
@@ -151,6 +193,8 @@ int main(int argc, char **argv)
     try {
         if (!strcmp(argv[1], "net")) return do_net(argc, argv);
         if (!strcmp(argv[1], "api")) return do_api(argc, argv);
+        if (!strcmp(argv[1], "searchlogic")) return do_searchlogic(argc, argv);
+        if (!strcmp(argv[1], "search")) return do_search(argc, argv);
     } catch (const exception &e) { fprintf(stderr, "exception: %s\n", e.what()); return 10; }
     return 1;
 }

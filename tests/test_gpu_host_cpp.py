@@ -48,3 +48,38 @@ def test_cpp_api_behaviour():
     out = subprocess.run([DRIVER, "api", h5, d], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "api ok" in out.stdout
+
+
+def test_cpp_plain_modulus_search():
+    """the reference's plain-modulus binary search (optimalParametersChooser.cpp) driven by the GPU engine through
+    the C++ host classes: setParameters / buildNetwork / encryptImage / Network::forward with budget check / decryptImage per
+    candidate.  The run must be consistent with the reference's recursion replayed over the verdicts it observed, the modulus
+    found must have succeeded, and the plaintext labels must be those of the float model."""
+    from crcnn_amd import synth
+    from oracle import search_ref as ref
+    import bench
+    d = tempfile.mkdtemp()
+    n, q = 4096, [0x7fffffff380001, 0x3fffffff000001]        # coeff_modulus_128(4096); the encoder needs this much room for a 6-layer net
+    imgs = np.stack([synth.normalize(synth.synth_image(i)).reshape(-1) for i in range(4)]).astype(np.float32)
+    imgs.tofile(os.path.join(d, "images.f32"))
+    h5 = os.path.join(GOLD, "models", "PlainModelTiny.h5")
+    lo, hi = 1 << 22, 1 << 26
+    out = subprocess.check_output([DRIVER, "search", "PlainModelTiny", h5, os.path.join(d, "images.f32"), str(n), str(lo), str(hi), "2", "7"], text=True).split("\n")
+    labels = [int(l.split()[2]) for l in out if l.startswith("label")]
+    found = int([l for l in out if l.startswith("found")][0].split()[1])
+    tried = [(int(l.split()[1]), l.split()[2]) for l in out if l.startswith("tried")]
+    # plaintext labels = argmax of the float forward
+    from crcnn_amd import binding
+    W = {nm: binding.h5_read(h5, nm) for nm in binding.h5_list(h5)}
+    assert labels == [int(np.argmax(bench.plain_forward("PlainModelTiny", W, im.reshape(28, 28)))) for im in imgs]
+    # replay the reference's control flow over the observed verdicts: same sequence of candidates, same result
+    table = dict(tried)
+    seen = []
+    def pred(t):
+        seen.append((t, table[t])); return table[t]
+    assert ref.search(pred, lo, hi, min(q)) == found
+    assert seen == tried
+    assert found > 0 and table[found] == "SUCCESS"
+    assert all(s != "SUCCESS" for t, s in tried if t < found)
+    # the verdicts have the expected shape: too-small moduli mispredict, too-large ones run out of budget
+    assert any(s == "MISPREDICTED" for t, s in tried if t < found) or found == lo
