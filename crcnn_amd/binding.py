@@ -117,6 +117,8 @@ def load():
     L.crc_keygen.argtypes = [VP, u64, PU, PU]
     L.crc_gen_evk.argtypes = [VP, u64, PU, CI, PU]
     L.crc_encrypt.argtypes = [VP, PU, PU, SZ, u64, PU]
+    L.crc_encrypt_dev_work_bytes.restype = SZ; L.crc_encrypt_dev_work_bytes.argtypes = [VP, SZ]
+    L.crc_encrypt_dev.argtypes = [VP, VP, VP, SZ, u64, VP, VP, VP]
     L.crc_decrypt.argtypes = [VP, PU, PU, SZ, CI, PU]
     L.crc_noise_budget.argtypes = [VP, PU, PU, CI]
     _lib = L
@@ -332,6 +334,12 @@ class Engine:
 
     def square_relin(self, d_x, count, d_evk, d_y, d_work, dbc=16):
         _chk(self.L.crc_square_relin(self.c, self.p(d_x), count, self.p(d_evk), dbc, self.p(d_y), self.p(d_work), self.stream), "crc_square_relin")
+
+    def encrypt_dev_work_bytes(self, count):
+        return self.L.crc_encrypt_dev_work_bytes(self.c, count)
+
+    def encrypt_dev(self, d_pk, d_plain, count, seed, d_ct, d_work):
+        _chk(self.L.crc_encrypt_dev(self.c, self.p(d_pk), self.p(d_plain), count, seed, self.p(d_ct), self.p(d_work), self.stream), "crc_encrypt_dev")
 
     def square(self, d_x, count, d_y3, d_work):
         _chk(self.L.crc_square(self.c, self.p(d_x), count, self.p(d_y3), self.p(d_work), self.stream), "crc_square")

@@ -203,28 +203,35 @@ ciphertext3D loadEncryptedImage(int zd, int xd, int yd, string file_name)
     return ciphertext3D::fromHost(h.data(), 1, zd, xd, yd);
 }
 static uint64_t g_enc_counter = 0;
+// encode on the host, encrypt on the device (crc_encrypt_dev: Encryptor::encrypt, encryptor.cpp:71-134)
+static ciphertext3D encryptPixels(const vector<float> &px, int zd, int xd, int yd)
+{
+    const int n = N();
+    vector<uint64_t> pl(px.size() * n);
+    chk(crc_encode_f32(ctx(), px.data(), px.size(), pl.data(), nullptr), "crc_encode_f32");
+    DeviceBuffer d_pl(pl.size() * 8), d_pk(public_key.size() * 8), d_work(crc_encrypt_dev_work_bytes(ctx(), px.size()));
+    chk(crc_memcpy_h2d(ctx(), d_pl.ptr, pl.data(), pl.size() * 8, nullptr), "crc_memcpy_h2d");
+    chk(crc_memcpy_h2d(ctx(), d_pk.ptr, public_key.data(), public_key.size() * 8, nullptr), "crc_memcpy_h2d");
+    ciphertext3D out(1, zd, xd, yd, CRC_COEFF);
+    chk(crc_encrypt_dev(ctx(), (const uint64_t *)d_pk.ptr, (const uint64_t *)d_pl.ptr, px.size(), crcnn_seed + 1000003 * (++g_enc_counter),
+                        (uint64_t *)out.buf->ptr, d_work.ptr, nullptr), "crc_encrypt_dev");
+    chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+    return out;
+}
 ciphertext3D encryptImage(vector<float> image, int zd, int xd, int yd)
 {
-    const int n = N(), k = K();
     if ((int)image.size() < xd * yd) throw invalid_argument("image too small");
     // the reference indexes image[i*xd+j] for every z (globals.cpp:133): one plane replicated over zd
     vector<float> px((size_t)zd * xd * yd);
     for (int z = 0; z < zd; z++) for (int i = 0; i < xd; i++) for (int j = 0; j < yd; j++) px[((size_t)z * xd + i) * yd + j] = image[(size_t)i * xd + j];
-    vector<uint64_t> pl(px.size() * n), ct(px.size() * 2 * k * n);
-    chk(crc_encode_f32(ctx(), px.data(), px.size(), pl.data(), nullptr), "crc_encode_f32");
-    chk(crc_encrypt(ctx(), public_key.data(), pl.data(), px.size(), crcnn_seed + 1000003 * (++g_enc_counter), ct.data()), "crc_encrypt");
-    return ciphertext3D::fromHost(ct.data(), 1, zd, xd, yd);
+    return encryptPixels(px, zd, xd, yd);
 }
 ciphertext3D encryptImage(floatCube image)
 {
-    const int n = N(), k = K();
     const int zd = (int)image.size(), xd = (int)image[0].size(), yd = (int)image[0][0].size();
     vector<float> px; px.reserve((size_t)zd * xd * yd);
     for (auto &a : image) for (auto &b : a) for (float v : b) px.push_back(v);
-    vector<uint64_t> pl(px.size() * n), ct(px.size() * 2 * k * n);
-    chk(crc_encode_f32(ctx(), px.data(), px.size(), pl.data(), nullptr), "crc_encode_f32");
-    chk(crc_encrypt(ctx(), public_key.data(), pl.data(), px.size(), crcnn_seed + 1000003 * (++g_enc_counter), ct.data()), "crc_encrypt");
-    return ciphertext3D::fromHost(ct.data(), 1, zd, xd, yd);
+    return encryptPixels(px, zd, xd, yd);
 }
 vector<floatCube> decryptImages(const ciphertext3D &t)
 {

@@ -216,6 +216,14 @@ int crc_encrypt(const crc_ctx *ctx, const uint64_t *h_pk, const uint64_t *h_plai
 int crc_decrypt(const crc_ctx *ctx, const uint64_t *h_sk_ntt, const uint64_t *h_ct, size_t count, int size, uint64_t *h_plain /*[count][n]*/);
 int crc_noise_budget(const crc_ctx *ctx, const uint64_t *h_sk_ntt, const uint64_t *h_ct, int size);
 
+/* Encryptor::encrypt (encryptor.cpp:71-134) on the device, for the 784 encryptions per image that dominate the client's
+ * latency in the reference: d_pk = the public key of crc_keygen copied to the device ([2][k][n], NTT form), d_plain =
+ * [count][n] plaintext coefficients (< t), d_ct = [count][2][k][n] coefficient form.  Sampling (ternary u, clipped-normal
+ * e1/e2) is a counter-based generator keyed by (seed, ciphertext, coefficient): deterministic per seed, same laws as
+ * crc_encrypt, different bits.  d_work: crc_encrypt_dev_work_bytes(count). */
+size_t crc_encrypt_dev_work_bytes(const crc_ctx *ctx, size_t count);
+int crc_encrypt_dev(crc_ctx *ctx, const uint64_t *d_pk, const uint64_t *d_plain, size_t count, uint64_t seed, uint64_t *d_ct, void *d_work, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

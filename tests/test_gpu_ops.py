@@ -140,3 +140,33 @@ def test_baseline_ring_sizes_vs_oracle(n, q, t):
     if O.noise_budget(sk, got[1]) >= 10:
         assert abs(O.decrypt_value(sk, got[1]) - 1.5625) < 1e-4
     E.close()
+
+
+@pytest.mark.parametrize("n,k,t", [(4096, 2, 1 << 20), (8192, 3, 1 << 30), (1024, 2, 1 << 16)])
+def test_device_encryptor(n, k, t):
+    """SURVEY 8f-2: Encryptor::encrypt on the device.  The reference samples from std::random_device, so the check is semantic:
+    every ciphertext decrypts (CPU client, secret key) to its plaintext, the noise budget is that of the CPU encryptor's
+    ciphertexts (same sampling laws), and the stream is a function of (seed, ciphertext index)."""
+    import crcnn_amd as ca
+    q = ca.default_coeff_modulus_128(8192)[:k] if n != 4096 else ca.default_coeff_modulus_128(4096)
+    E = ca.Engine(n, q, t, device=0)
+    sk, pk = E.keygen(11)
+    rng = np.random.default_rng(5)
+    cnt = 24
+    plains = rng.integers(0, t, size=(cnt, n), dtype=np.uint64)
+    plains[0] = 0; plains[1] = t - 1
+    d_pk = E.upload(pk); d_pl = E.upload(plains)
+    d_ct = E.alloc(cnt * 2 * k * n * 8); d_w = E.alloc(E.encrypt_dev_work_bytes(cnt))
+    E.encrypt_dev(d_pk, d_pl, cnt, 77, d_ct, d_w)
+    ct = E.download(d_ct, (cnt, 2, k, n))
+    assert np.array_equal(E.decrypt(sk, ct), plains)
+    ref = E.encrypt(pk, plains[:4], 3)
+    b_dev = [E.noise_budget(sk, ct[i]) for i in range(4)]; b_cpu = [E.noise_budget(sk, ref[i]) for i in range(4)]
+    assert min(b_dev) >= min(b_cpu) - 2 and max(b_dev) <= max(b_cpu) + 2, (b_dev, b_cpu)
+    # deterministic per seed, different across seeds and across ciphertexts
+    E.encrypt_dev(d_pk, d_pl, cnt, 77, d_ct, d_w)
+    assert np.array_equal(E.download(d_ct, (cnt, 2, k, n)), ct)
+    E.encrypt_dev(d_pk, d_pl, cnt, 78, d_ct, d_w)
+    assert not np.array_equal(E.download(d_ct, (cnt, 2, k, n))[:, 1], ct[:, 1])
+    assert not np.array_equal(ct[2, 1], ct[3, 1])
+    E.close()
