@@ -95,6 +95,7 @@ def load():
     L.crc_batchnorm.argtypes = [VP, VP, CI, CI, CI, CI, VP, VP, CI, VP]
     L.crc_square_relin_work_bytes.restype = SZ; L.crc_square_relin_work_bytes.argtypes = [VP, SZ, CI]
     L.crc_square_relin.argtypes = [VP, VP, SZ, VP, CI, VP, VP, VP]
+    L.crc_square_relin_forms.argtypes = [VP, VP, CI, SZ, VP, CI, VP, CI, VP, VP]
     L.crc_square.argtypes = [VP, VP, SZ, VP, VP, VP]
     L.crc_relinearize.argtypes = [VP, VP, SZ, VP, CI, VP, VP, VP]
     L.crc_import_seal.argtypes = [VP, PU, CI, PU]
@@ -332,8 +333,8 @@ class Engine:
     def square_relin_work_bytes(self, count, dbc=16):
         return self.L.crc_square_relin_work_bytes(self.c, count, dbc)
 
-    def square_relin(self, d_x, count, d_evk, d_y, d_work, dbc=16):
-        _chk(self.L.crc_square_relin(self.c, self.p(d_x), count, self.p(d_evk), dbc, self.p(d_y), self.p(d_work), self.stream), "crc_square_relin")
+    def square_relin(self, d_x, count, d_evk, d_y, d_work, dbc=16, in_form=COEFF, out_form=COEFF):
+        _chk(self.L.crc_square_relin_forms(self.c, self.p(d_x), in_form, count, self.p(d_evk), dbc, self.p(d_y), out_form, self.p(d_work), self.stream), "crc_square_relin_forms")
 
     def encrypt_dev_work_bytes(self, count):
         return self.L.crc_encrypt_dev_work_bytes(self.c, count)

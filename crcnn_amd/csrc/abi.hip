@@ -202,15 +202,20 @@ extern "C" int crc_relinearize(crc_ctx *c, const uint64_t *d_x3, size_t count, c
     }
     return CRC_OK;
 }
-extern "C" int crc_square_relin(crc_ctx *c, const uint64_t *d_x, size_t count, const uint64_t *d_evk, int dbc, uint64_t *d_y, void *d_work, void *stream)
+extern "C" int crc_square_relin_forms(crc_ctx *c, const uint64_t *d_x, int in_form, size_t count, const uint64_t *d_evk, int dbc, uint64_t *d_y, int out_form,
+                                      void *d_work, void *stream)
 {
-    CHECK_CTX(c); if (!d_x || !d_y || !d_evk || !d_work) return CRC_ERR_INVALID_ARGUMENT;
+    CHECK_CTX(c); if (!d_x || !d_y || !d_evk || !d_work || !form_ok(in_form) || !form_ok(out_form)) return CRC_ERR_INVALID_ARGUMENT;
     u64 *w = (u64 *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
     for (size_t o = 0; o < count; o += kSquareChunk) {
         const size_t ch = count - o < kSquareChunk ? count - o : kSquareChunk;
         u64 *y3 = w; u64 *rest = w + ch * crc_ct_words(c, 3);
-        RUN(k_square(c, d_x + o * crc_ct_words(c, 2), ch, y3, rest, S(stream)));
-        RUN(k_relinearize(c, y3, ch, d_evk, dbc, d_y + o * crc_ct_words(c, 2), rest, S(stream)));
+        RUN(k_square(c, d_x + o * crc_ct_words(c, 2), ch, y3, rest, S(stream), in_form == CRC_NTT));
+        RUN(k_relinearize(c, y3, ch, d_evk, dbc, d_y + o * crc_ct_words(c, 2), rest, S(stream), out_form == CRC_NTT));
     }
     return CRC_OK;
+}
+extern "C" int crc_square_relin(crc_ctx *c, const uint64_t *d_x, size_t count, const uint64_t *d_evk, int dbc, uint64_t *d_y, void *d_work, void *stream)
+{
+    return crc_square_relin_forms(c, d_x, CRC_COEFF, count, d_evk, dbc, d_y, CRC_COEFF, d_work, stream);
 }

@@ -21,6 +21,7 @@ struct NttArgs {
     int n, logn;
     int mod_base, mod_count;                                   // row r -> modulus index mod_base + r % mod_count
     int src_rows_per_item;                                     // 0: src row = dst row;  >0: plain prologue, src row = r / mod_count
+    int src_ct_rows, dst_ct_rows;                              // both > 0: dst row r = (ct, j < dst_ct_rows) reads src row ct*src_ct_rows + j (leading polys of wider cts)
     int prologue;                                              // 0 none, 1 plain lift, 2 delta scale
     const u64 *addend; int add_sign; int rows_per_ct; long long add_group;   // epilogue (inverse only)
     int add_mod;                                               // plaintext index = (ct / add_group) % add_mod (0: no modulo)
@@ -139,7 +140,8 @@ __global__ void __launch_bounds__(1024) ntt_rows_kernel(NttArgs a)
     const u64 q = m.q, q2 = m.two_q;
     const float rq = 1.0f / (float)((u32)(q >> 32) + 1);
     const ulonglong2 *W = a.w + (size_t)mi * n;
-    const u64 *src = a.src + (a.src_rows_per_item ? (row / a.mod_count) : row) * (size_t)n;
+    const size_t srow = a.dst_ct_rows ? (row / a.dst_ct_rows) * a.src_ct_rows + row % a.dst_ct_rows : (a.src_rows_per_item ? (row / a.mod_count) : row);
+    const u64 *src = a.src + srow * (size_t)n;
     u64 *dst = a.dst + row * (size_t)n;
 
     for (int s = tid; s < n; s += nt) {
@@ -161,10 +163,12 @@ __global__ void __launch_bounds__(1024) ntt_rows_kernel(NttArgs a)
         for (int p = 0; p < full; p++, t >>= 3) ntt_pass<false, 3, LAZY>(sm, W, n, t >> 2, n / (2 * t), q, q2);
         if (rem == 2) ntt_pass<false, 2, LAZY>(sm, W, n, t >> 1, n / (2 * t), q, q2);
         else if (rem == 1) ntt_pass<false, 1, LAZY>(sm, W, n, t, n / (2 * t), q, q2);
+        const u64 *add = a.addend ? a.addend + row * (size_t)n : nullptr;      // forward epilogue: + an NTT-form row of the same index
         for (int s = tid; s < n; s += nt) {
             u64 v = sm[lpad(s)];
             if (LAZY) v = reduce_small(v, q, q2, rq);
             else { v = v >= q2 ? v - q2 : v; v = v >= q ? v - q : v; }
+            if (add) v = addmod(v, add[s], q);
             dst[s] = v;
         }
     } else {
@@ -225,6 +229,17 @@ int k_ntt_ct_addct(crc_ctx *c, const u64 *src, u64 *dst, size_t count, const u64
     a.src = src; a.dst = dst; a.mod_base = 0; a.mod_count = c->k;
     a.addend = addct; a.add_sign = 1; a.rows_per_ct = 2 * c->k; a.add_group = 1; a.add_mode = 2; a.add_size = add_size;
     return ntt_launch(c, true, a, count * 2 * c->k, st);
+}
+
+// forward NTT of polys 0,1 of size-`src_size` ciphertexts src -> size-2 dst, adding the NTT-form rows `addrows` ([count][2][k][n])
+// (relinearize tail when the result stays in NTT form: NTT(c0, c1) + key-switched c2)
+int k_ntt_ct_head_add(crc_ctx *c, const u64 *src, int src_size, u64 *dst, size_t count, const u64 *addrows, hipStream_t st)
+{
+    NttArgs a{};
+    a.src = src; a.dst = dst; a.mod_base = 0; a.mod_count = c->k;
+    a.src_ct_rows = src_size * c->k; a.dst_ct_rows = 2 * c->k;
+    a.addend = addrows; a.add_sign = 1; a.rows_per_ct = 2 * c->k; a.add_group = 1;
+    return ntt_launch(c, false, a, count * 2 * c->k, st);
 }
 
 // forward NTT of `items` polynomials under every q_j: src [items][n] -> dst [items][k][n]

@@ -161,18 +161,22 @@ size_t k_relin_work_words(const crc_ctx *c, size_t cnt, int dbc)
     return cnt * n * (D + D * k + 2 * k);
 }
 
-int k_square(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStream_t st)
+int k_square(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStream_t st, bool in_ntt)
 {
     if (cnt == 0) return CRC_OK;
     const size_t n = c->n, k = c->k, kb = c->kb;
     u64 *QN = work, *BS = QN + cnt * 2 * k * n, *DQ = BS + cnt * 2 * kb * n, *DB = DQ + cnt * 3 * k * n;
     const int threads = c->n < 256 ? c->n : 256, sblocks = c->n / threads;
-    hipLaunchKernelGGL(sq_lift_kernel, dim3((unsigned)(cnt * 2 * sblocks)), dim3(threads), 0, st, x, BS, c->d_mods, c->d_behz, c->n);
-    HIPCHK(hipGetLastError());
     int rc;
-    if ((rc = k_ntt_ct(c, false, x, QN, cnt, 2, false, st, nullptr, 0, 0, 0))) return rc;
+    // the square needs x in both forms: coefficients for the base extension, NTT values (base q) for the products.  An NTT-resident
+    // caller hands over the latter, so one inverse transform replaces the forward one (and the caller's own conversion disappears)
+    const u64 *xc = x, *xn = QN;
+    if (in_ntt) { if ((rc = k_ntt_ct(c, true, x, QN, cnt, 2, false, st, nullptr, 0, 0, 0))) return rc; xc = QN; xn = x; }
+    hipLaunchKernelGGL(sq_lift_kernel, dim3((unsigned)(cnt * 2 * sblocks)), dim3(threads), 0, st, xc, BS, c->d_mods, c->d_behz, c->n);
+    HIPCHK(hipGetLastError());
+    if (!in_ntt && (rc = k_ntt_ct(c, false, x, QN, cnt, 2, false, st, nullptr, 0, 0, 0))) return rc;
     if ((rc = k_ntt_ct(c, false, BS, BS, cnt, 2, true, st, nullptr, 0, 0, 0))) return rc;
-    hipLaunchKernelGGL(sq_dyadic_kernel, dim3((unsigned)(cnt * k)), dim3(256), 0, st, QN, DQ, c->d_mods, c->n, (int)k, 0);
+    hipLaunchKernelGGL(sq_dyadic_kernel, dim3((unsigned)(cnt * k)), dim3(256), 0, st, xn, DQ, c->d_mods, c->n, (int)k, 0);
     hipLaunchKernelGGL(sq_dyadic_kernel, dim3((unsigned)(cnt * kb)), dim3(256), 0, st, BS, DB, c->d_mods, c->n, (int)kb, (int)k);
     HIPCHK(hipGetLastError());
     if ((rc = k_ntt_ct(c, true, DQ, DQ, cnt, 3, false, st, nullptr, 0, 0, 0))) return rc;
@@ -182,7 +186,7 @@ int k_square(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStream
     return CRC_OK;
 }
 
-int k_relinearize(crc_ctx *c, const u64 *x3, size_t cnt, const u64 *evk, int dbc, u64 *y, u64 *work, hipStream_t st)
+int k_relinearize(crc_ctx *c, const u64 *x3, size_t cnt, const u64 *evk, int dbc, u64 *y, u64 *work, hipStream_t st, bool out_ntt)
 {
     if (cnt == 0) return CRC_OK;
     if (dbc < 1 || dbc > 60) return CRC_ERR_INVALID_ARGUMENT;
@@ -203,6 +207,8 @@ int k_relinearize(crc_ctx *c, const u64 *x3, size_t cnt, const u64 *evk, int dbc
     const int threads = c->n < 256 ? c->n : 256, sblocks = c->n / threads;
     hipLaunchKernelGGL(relin_mac_kernel, dim3((unsigned)(cnt * k * sblocks)), dim3(threads), 0, st, E, evk, R, c->d_mods, c->n, c->k, D, tab);
     HIPCHK(hipGetLastError());
-    // INTT and add (c0, c1) of the size-3 input   (evaluator.cpp:1041-1068)
+    // INTT and add (c0, c1) of the size-3 input   (evaluator.cpp:1041-1068); for an NTT-form result the sum is formed on the other
+    // side of the (linear) transform: NTT(c0, c1) + R
+    if (out_ntt) return k_ntt_ct_head_add(c, x3, 3, y, cnt, R, st);
     return k_ntt_ct_addct(c, R, y, cnt, x3, 3, st);
 }

@@ -386,12 +386,12 @@ AvgPoolingLayer::AvgPoolingLayer(string name, int xd, int yd, int zd, int xs, in
 ciphertext3D SquareLayer::forward(ciphertext3D input)
 {
     if (!input.buf) throw invalid_argument("SquareLayer: empty input");
-    if (input.form != CRC_COEFF) throw invalid_argument("SquareLayer: input must be in coefficient form");
     if (!ev_keys16) throw invalid_argument("not enough evaluation keys");
-    ciphertext3D out(input.B, input.zd, input.xd, input.yd, CRC_COEFF);
+    // either form in, the requested form out: crc_square_relin_forms keeps an NTT-resident network resident
+    ciphertext3D out(input.B, input.zd, input.xd, input.yd, out_form);
     ensure(d_work, crc_square_relin_work_bytes(ctx(), input.count(), 16));
-    chk(crc_square_relin(ctx(), input.data(), input.count(), (const uint64_t *)ev_keys16->ptr, 16, out.data(), d_work->ptr, nullptr), "crc_square_relin");
-    if (out_form == CRC_NTT) { chk(crc_ntt_fwd(ctx(), out.data(), out.count(), 2, nullptr), "crc_ntt_fwd"); out.form = CRC_NTT; }
+    chk(crc_square_relin_forms(ctx(), input.data(), input.form, input.count(), (const uint64_t *)ev_keys16->ptr, 16, out.data(), out_form, d_work->ptr, nullptr),
+        "crc_square_relin_forms");
     return out;
 }
 void SquareLayer::printLayerStructure() { cerr << "Square run with " << th_count << " threads" << endl; }
@@ -438,7 +438,7 @@ ciphertext3D Network::forward(ciphertext3D input)
     const int L = (int)layers.size();
     // choose the form of every boundary: NTT between linear layers when resident, coefficient form into Square and out of the net
     for (int i = 0; i < L; i++) {
-        bool coeff = !ntt_resident || i == L - 1 || !layers[i + 1]->linear() || i + 1 == layer_before_reenc;
+        bool coeff = !ntt_resident || i == L - 1 || i + 1 == layer_before_reenc;
         layers[i]->out_form = coeff ? CRC_COEFF : CRC_NTT;
     }
     last_layer_ms.assign(L, 0.0);

@@ -88,7 +88,6 @@ public:
     virtual ciphertext3D forward(ciphertext3D input) = 0;
     virtual void savePlaintextParameters(std::ostream *outfile) = 0;
     virtual void loadPlaintextParameters(std::istream *infile) = 0;
-    virtual bool linear() const { return true; }            // false: needs coefficient-form input (Square)
     void computeBoundaries(int xd, int yd, int xs, int ys, int xf, int yf, int *xl, int *yl);   // layer.cpp:12-26
 };
 
@@ -157,7 +156,6 @@ public:
     void savePlaintextParameters(std::ostream *) override {}
     void loadPlaintextParameters(std::istream *) override {}
     void printLayerStructure() override;
-    bool linear() const override { return false; }
 private:
     std::shared_ptr<DeviceBuffer> d_work;
 };

@@ -83,9 +83,6 @@ class Network:
             last = li == len(self.topo) - 1
             if kind in ("conv", "fc"):
                 out_form = COEFF if (last or not resident) else NTT
-                nxt = self.topo[li + 1][0] if not last else None
-                if nxt == "square":
-                    out_form = COEFF       # Square works on coefficient form (BEHZ base conversions)
                 p["w"] = self._encode_ntt(get(name + ".weight"), encode_chunk)
                 p["b"] = self._delta(get(name + ".bias"), out_form)
                 p["in_form"], p["out_form"] = form, out_form
@@ -98,11 +95,10 @@ class Network:
                 invstd = np.float32(1.0 / np.sqrt(var.astype(np.float64) + 0.00001))       # cnnBuilder.cpp:100-102
                 p["mean"] = self._delta(mean, form); p["invstd"] = self._encode_ntt(invstd, encode_chunk); p["form"] = form
             elif kind == "square":
-                if form != COEFF:
-                    raise RuntimeError("square needs coefficient form input")
-                p["form"] = COEFF
-                p["to_ntt"] = resident          # go back to NTT residency right after the relinearisation
-                form = NTT if resident else COEFF
+                # crc_square_relin_forms takes and leaves NTT-resident tensors (one INTT inside feeds the BEHZ base extension)
+                p["in_form"] = form
+                p["out_form"] = COEFF if (last or not resident) else NTT
+                form = p["out_form"]
             nshape = out_shape(kind, a, shape)
             self.plan.append((kind, name, a, p, shape, nshape))
             shape = nshape
@@ -250,10 +246,8 @@ class Network:
                     cur = out
                 E.batchnorm(cur, B, ishape[0], ishape[1], ishape[2], p["mean"], p["invstd"], p["form"])
             elif kind == "square":
-                E.square_relin(cur, B * int(np.prod(ishape)), self.d_evk, out, self.work, self.dbc)
+                E.square_relin(cur, B * int(np.prod(ishape)), self.d_evk, out, self.work, self.dbc, p["in_form"], p["out_form"])
                 cur = out
-                if p["to_ntt"]:
-                    E.ntt_fwd(cur, B * int(np.prod(ishape)))
             if timer:
                 timer(i, name, kind, 1)
         return cur

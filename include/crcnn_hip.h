@@ -167,6 +167,12 @@ int crc_batchnorm(crc_ctx *ctx, uint64_t *d_x, int B, int zd, int xd, int yd, co
 size_t crc_square_relin_work_bytes(const crc_ctx *ctx, size_t count, int dbc);
 int crc_square_relin(crc_ctx *ctx, const uint64_t *d_x, size_t count, const uint64_t *d_evk, int dbc,
                      uint64_t *d_y, void *d_work, void *stream);
+/* the same layer between NTT-resident neighbours: with in_form = CRC_NTT the given NTT values feed the products
+ * and one inverse transform supplies the coefficients for the base extension; with out_form = CRC_NTT the tail adds
+ * NTT(c0, c1) to the key-switched c2 instead of transforming back.  Identical ciphertexts in the requested form; 4k row
+ * transforms fewer per ciphertext than converting outside. */
+int crc_square_relin_forms(crc_ctx *ctx, const uint64_t *d_x, int in_form, size_t count, const uint64_t *d_evk, int dbc,
+                           uint64_t *d_y, int out_form, void *d_work, void *stream);
 /* the two halves separately (unit tests): square -> size-3 ciphertexts; relinearize -> size 2 */
 int crc_square(crc_ctx *ctx, const uint64_t *d_x, size_t count, uint64_t *d_y3, void *d_work, void *stream);
 int crc_relinearize(crc_ctx *ctx, const uint64_t *d_x3, size_t count, const uint64_t *d_evk, int dbc, uint64_t *d_y,

@@ -85,6 +85,15 @@ def test_square_and_relinearize(gs):
     E.square_relin(d_x, nct, d_evk, d_y2, d_w)
     assert np.array_equal(E.download(d_y2, cts.shape), g["ref_relin"])
     assert np.array_equal(E.download(d_x, cts.shape), cts)          # input untouched
+    # between NTT-resident neighbours (crc_square_relin_forms): NTT in and/or out, same ciphertexts in the requested form
+    import crcnn_amd as ca
+    d_xn = E.upload(cts); E.ntt_fwd(d_xn, nct); xn = E.download(d_xn, cts.shape)
+    for fin, fout in [(ca.NTT, ca.NTT), (ca.NTT, ca.COEFF), (ca.COEFF, ca.NTT)]:
+        E.square_relin(d_xn if fin == ca.NTT else d_x, nct, d_evk, d_y2, d_w, in_form=fin, out_form=fout)
+        if fout == ca.NTT:
+            E.ntt_inv(d_y2, nct)
+        assert np.array_equal(E.download(d_y2, cts.shape), g["ref_relin"]), (fin, fout)
+    assert np.array_equal(E.download(d_xn, cts.shape), xn)
 
 
 def test_square_with_seal_made_keys(gs):
