@@ -29,104 +29,7 @@ struct NttArgs {
     PlainParams pp;
 };
 
-// LDS index swizzle (XOR, no padding): conflict-free ds_read/write_b64 for the contiguous staging accesses AND for every strided
-// register-tile pattern of the radix-8 passes at n = 4096 (at most 2-way in the short tail pass of n = 8192 / 16384); found by
-// enumerating the access patterns (bank = index mod 32 per 32-lane group)
-__device__ __forceinline__ int lpad(int i) { return i ^ ((i >> 3) & 7) ^ (((i >> 6) & 3) << 3); }
-
-// Lazy variant (LAZY = true, moduli of at most 57 bits): there are 7+ spare bits above q in a 64-bit word, so butterflies never
-// correct their inputs and use a 3-product estimate of the Shoup quotient (result in [0, 4q) instead of [0, 2q)); the forward
-// transform lets values grow by 4q per stage (<= (1 + 4*14) q < 2^63), the inverse one stays below 11q because every stage halves.
-// One float-estimated reduction per coefficient at the end makes the output canonical, so the bits are the reference's.
-__device__ __forceinline__ u64 shoup_lazy4(u64 a, u64 w, u64 wp, u64 q)
-{
-    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), p0 = (u32)wp, p1 = (u32)(wp >> 32);
-    const u64 h = (u64)a1 * p1 + __umulhi(a1, p0) + __umulhi(a0, p1);          // floor(a*wp / 2^64) - {0,1,2}
-    return a * w - h * q;
-}
-// v < 128 q  ->  v mod q.  rq = 1 / float((q >> 32) + 1): the quotient estimate never exceeds floor(v/q) and is at most 2 short.
-__device__ __forceinline__ u64 reduce_small(u64 v, u64 q, u64 q2, float rq)
-{
-    u32 est = (u32)((float)(u32)(v >> 32) * rq);
-    est = est ? est - 1 : 0;
-    v -= (u64)est * q;
-    v = v >= q2 ? v - q2 : v;
-    return v >= q ? v - q : v;
-}
-
-// R butterfly stages on 2^R register-resident values.  Forward (Cooley-Tukey): first stage pairs c with c + 2^(R-1);
-// inverse (Gentleman-Sande): first stage pairs c with c + 1.
-template <int R, bool LAZY>
-__device__ __forceinline__ void fwd_stages(u64 (&v)[1 << R], const ulonglong2 *W, int m, int blk, u64 q, u64 q2)
-{
-    const u64 q4 = q2 + q2;
-#pragma unroll
-    for (int st = 0; st < R; st++) {
-        const int half = 1 << (R - 1 - st);
-#pragma unroll
-        for (int c = 0; c < (1 << R); c++) {
-            if (c & half) continue;
-            const int wi = (m << st) + (blk << st) + (c >> (R - st));
-            const ulonglong2 tw = W[wi]; const u64 w = tw.x, wp = tw.y;
-            u64 X = v[c]; const u64 Y = v[c + half];
-            if (LAZY) {
-                const u64 Q = shoup_lazy4(Y, w, wp, q);
-                v[c] = X + Q;
-                v[c + half] = X + (q4 - Q);
-            } else {
-                X = X >= q2 ? X - q2 : X;
-                const u64 Q = mulmod_shoup_lazy(Y, w, wp, q);
-                v[c] = X + Q;
-                v[c + half] = X + (q2 - Q);
-            }
-        }
-    }
-}
-template <int R, bool LAZY>
-__device__ __forceinline__ void inv_stages(u64 (&v)[1 << R], const ulonglong2 *W, int h, int blk, u64 q, u64 q2)
-{
-    const u64 q16 = q2 << 3;
-#pragma unroll
-    for (int st = 0; st < R; st++) {
-        const int half = 1 << st;
-#pragma unroll
-        for (int c = 0; c < (1 << R); c++) {
-            if (c & half) continue;
-            const int wi = (h >> st) + (blk << (R - 1 - st)) + (c >> (st + 1));
-            const ulonglong2 tw = W[wi]; const u64 w = tw.x, wp = tw.y;
-            const u64 U = v[c], V = v[c + half];
-            if (LAZY) {                                  // U, V < Bq  ->  U' < (B + 1/2) q, V' < 4q: never above (4 + 13/2) q < 16q
-                const u64 T = q16 - V + U;
-                const u64 cu = U + V;
-                v[c] = (cu + ((cu & 1) ? q : 0)) >> 1;
-                v[c + half] = shoup_lazy4(T, w, wp, q);
-            } else {
-                const u64 T = q2 - V + U;
-                u64 cu = U + V; cu = cu >= q2 ? cu - q2 : cu;
-                v[c] = (cu + ((cu & 1) ? q : 0)) >> 1;
-                v[c + half] = mulmod_shoup_lazy(T, w, wp, q);
-            }
-        }
-    }
-}
-
-// one pass over the whole row: every thread takes groups of 2^R values that interact in the next R stages
-template <bool INV, int R, bool LAZY>
-__device__ __forceinline__ void ntt_pass(u64 *sm, const ulonglong2 *W, int n, int s /*element stride inside a group*/, int tabidx, u64 q, u64 q2)
-{
-    const int groups = n >> R;
-    for (int g = threadIdx.x; g < groups; g += blockDim.x) {
-        const int blk = g / s, l = g - blk * s;
-        const int base = blk * (s << R) + l;
-        u64 v[1 << R];
-#pragma unroll
-        for (int c = 0; c < (1 << R); c++) v[c] = sm[lpad(base + c * s)];
-        if (INV) inv_stages<R, LAZY>(v, W, tabidx, blk, q, q2); else fwd_stages<R, LAZY>(v, W, tabidx, blk, q, q2);
-#pragma unroll
-        for (int c = 0; c < (1 << R); c++) sm[lpad(base + c * s)] = v[c];
-    }
-    __syncthreads();
-}
+#include "ntt_device.h"  // lpad, shoup_lazy4, reduce_small, fwd_stages / inv_stages, ntt_pass
 
 template <bool INV, bool LAZY>
 __global__ void __launch_bounds__(1024) ntt_rows_kernel(NttArgs a)
