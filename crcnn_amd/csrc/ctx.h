@@ -38,6 +38,13 @@ struct BehzParams {
     u64 mhat_mod_msk[CRC_MAXB];              // (M/m_j) mod m_sk
     u64 inv_M_mod_msk;                       // M^-1 mod m_sk
     u64 M_mod_q[CRC_MAXK];                   // M mod q_i
+    // Shoup companions floor(c 2^64 / modulus) of the per-modulus constants the base-conversion kernels multiply by, and the two
+    // products that fold consecutive constant multiplications of the reference into one (same residue)
+    u64 mt_inv_qhat_s[CRC_MAXK];
+    u64 t_inv_qhat[CRC_MAXK], t_inv_qhat_s[CRC_MAXK];          // t (q/q_i)^-1 mod q_i   (evaluator.cpp:856-871 then baseconverter.cpp:413-423)
+    u64 t_mod_bsk[CRC_MAXB], t_mod_bsk_s[CRC_MAXB];            // t mod Bsk_j
+    u64 inv_mt_mod_bsk_s[CRC_MAXB], inv_q_mod_bsk_s[CRC_MAXB], inv_mhat_s[CRC_MAXB];
+    u64 inv_M_mod_msk_s;
 };
 
 struct HostNtt {               // one modulus

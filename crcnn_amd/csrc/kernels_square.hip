@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(256) sq_lift_kernel(const u64 *x, u64 *out, co
     const int s = (blockIdx.x % sblocks) * blockDim.x + threadIdx.x;
     const u64 *src = x + poly * (size_t)k * n + s;
     u64 tr[CRC_MAXK];
-    for (int i = 0; i < k; i++) tr[i] = mulmod(src[(size_t)i * n], b.mt_inv_qhat[i], mods[i]);      // baseconverter.cpp:686-696
+    for (int i = 0; i < k; i++) tr[i] = mulmod_shoup(src[(size_t)i * n], b.mt_inv_qhat[i], b.mt_inv_qhat_s[i], mods[i].q);      // baseconverter.cpp:686-696
     // residue mod m~ = 2^32 (:720-741) and r = -(x_m~ q^-1) mod m~ (mont_rq :604-612)
     u64 xm = 0;
     for (int i = 0; i < k; i++) xm += tr[i] * b.qhat_mod_mt[i];
@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(256) sq_lift_kernel(const u64 *x, u64 *out, co
         for (int i = 0; i < k; i++) acc_mad(a, tr[i], b.qhat_mod_bsk[j][i]);                        // :698-718
         acc_mad(a, b.q_mod_bsk[j], r);                                                              // mont_rq :614-618 (sum stays < 2^128)
         const u64 v = barrett128(a.lo, a.hi, mj);
-        dst[(size_t)j * n] = mulmod(v, b.inv_mt_mod_bsk[j], mj);                                    // :619
+        dst[(size_t)j * n] = mulmod_shoup(v, b.inv_mt_mod_bsk[j], b.inv_mt_mod_bsk_s[j], mj.q);     // :619
     }
 }
 
@@ -76,27 +76,25 @@ __global__ void __launch_bounds__(256) sq_floor_kernel(const u64 *dq, const u64 
     const int s = (blockIdx.x % sblocks) * blockDim.x + threadIdx.x;
     const u64 *xq = dq + poly * (size_t)k * n + s, *xb = db + poly * (size_t)kb * n + s;
     u64 tr[CRC_MAXK];
-    for (int i = 0; i < k; i++) {
-        const u64 v = mulmod(xq[(size_t)i * n], b.t, mods[i]);                                      // evaluator.cpp:856-871
-        tr[i] = mulmod(v, b.inv_qhat[i], mods[i]);                                                  // fastbconv :413-423
-    }
+    // x t (evaluator.cpp:856-871) and the (q/q_i)^-1 of fastbconv (:413-423) are one constant
+    for (int i = 0; i < k; i++) tr[i] = mulmod_shoup(xq[(size_t)i * n], b.t_inv_qhat[i], b.t_inv_qhat_s[i], mods[i].q);
     u64 fl[CRC_MAXB];
     for (int j = 0; j < kb; j++) {
         const ModParams mj = mods[k + j];
         acc128 a{0, 0};
         for (int i = 0; i < k; i++) acc_mad(a, tr[i], b.qhat_mod_bsk[j][i]);                        // :425-445
         const u64 conv = barrett128(a.lo, a.hi, mj);
-        const u64 xv = mulmod(xb[(size_t)j * n], b.t, mj);
-        fl[j] = mulmod(xv + mj.q - conv, b.inv_q_mod_bsk[j], mj);                                   // fast_floor :646-660
+        const u64 xv = mulmod_shoup(xb[(size_t)j * n], b.t_mod_bsk[j], b.t_mod_bsk_s[j], mj.q);
+        fl[j] = mulmod_shoup(xv + mj.q - conv, b.inv_q_mod_bsk[j], b.inv_q_mod_bsk_s[j], mj.q);    // fast_floor :646-660
     }
     // fastbconv_sk :448-579
     u64 z[CRC_MAXB];
-    for (int j = 0; j < ka; j++) z[j] = mulmod(fl[j], b.inv_mhat[j], mods[k + j]);
+    for (int j = 0; j < ka; j++) z[j] = mulmod_shoup(fl[j], b.inv_mhat[j], b.inv_mhat_s[j], mods[k + j].q);
     const ModParams msk = mods[k + ka];
     acc128 as{0, 0};
     for (int j = 0; j < ka; j++) acc_mad(as, z[j], b.mhat_mod_msk[j]);
     const u64 vsk = barrett128(as.lo, as.hi, msk);
-    const u64 alpha = mulmod(vsk + (b.m_sk - fl[ka]), b.inv_M_mod_msk, msk);
+    const u64 alpha = mulmod_shoup(vsk + (b.m_sk - fl[ka]), b.inv_M_mod_msk, b.inv_M_mod_msk_s, msk.q);
     const bool neg = alpha > (b.m_sk >> 1);
     u64 *dst = y3 + poly * (size_t)k * n + s;
     for (int i = 0; i < k; i++) {

@@ -60,6 +60,13 @@ CRC_HD u64 barrett128(u64 lo, u64 hi, const ModParams &m)
     return r >= m.q ? r - m.q : r;
 }
 
+// a*w mod q, canonical, for a constant w with its exact Shoup companion wp = floor(w 2^64 / q); any 64-bit a, q < 2^63
+CRC_HD u64 mulmod_shoup(u64 a, u64 w, u64 wp, u64 q)
+{
+    const u64 r = a * w - mulhi64(a, wp) * q;
+    return r >= q ? r - q : r;
+}
+
 CRC_HD u64 mulmod(u64 a, u64 b, const ModParams &m)
 {
     u64 lo, hi;
