@@ -141,6 +141,53 @@ class Network:
                     continue
             plan.append(self.plan[i]); i += 1
         self.plan = plan
+        self._fold_batchnorm()
+
+    # ---- batch-norm folding: bn (per-channel  s (*) (x - M), M on poly 0 only) followed by a conv / dense layer is that layer with
+    # weights w (*) s[channel] and bias  B - sum_taps w (*) s (*) M  -- ring-linear over Z_q, so the ciphertexts are identical
+    def _fold_batchnorm(self):
+        E = self.E
+        plan, i = [], 0
+        rowb = E.k * E.n * 8
+        while i < len(self.plan):
+            kind, name, a, p, ishape, oshape = self.plan[i]
+            nxt = self.plan[i + 1] if i + 1 < len(self.plan) else None
+            if kind == "bn" and nxt and nxt[0] in ("conv", "fc") and p["form"] == NTT and nxt[3]["out_form"] == NTT and "fused" not in nxt[3]:
+                nk, nname, na, np_, nish, nosh = nxt
+                ch = ishape[0]
+                if nk == "conv":
+                    F, per_ch, T = na["nf"], na["xf"] * na["yf"], na["zd"] * na["xf"] * na["yf"]
+                else:
+                    F, per_ch, T = na["out_dim"], ishape[1] * ishape[2], na["in_dim"]
+                assert T == ch * per_ch
+                if self.materialize:
+                    # w'[f][z][tap] = w (*) s[z]: one multiply_plain_ntt per output row (plaintext index = tap / per_ch)
+                    for f in range(F):
+                        E.L.crc_multiply_plain_ntt(E.c, E.p(np_["w"]) + f * T * rowb, E.p(p["invstd"]), T, per_ch, 1, E.stream)
+                    # correction[f] = sum_t w'[f][t] (*) M[z(t)]: the dense kernel on one pseudo-image whose "ciphertexts" are (M[z(t)], 0)
+                    fake = self.alloc(T * 2 * rowb); outc = self.alloc(F * 2 * rowb)
+                    E.L.crc_memset(E.c, E.p(fake), 0, T * 2 * rowb, E.stream)
+                    for z in range(ch):
+                        for t in range(per_ch):
+                            E.L.crc_memcpy_d2d(E.c, E.p(fake) + (z * per_ch + t) * 2 * rowb, E.p(p["mean"]) + z * rowb, rowb, E.stream)
+                    wk = self.alloc(max(E.dense_work_bytes(1, T, F, NTT), 256))
+                    E.dense(fake, np_["w"], None, 1, T, F, NTT, NTT, outc, wk)
+                    E.sync()
+                    corr = E.download(E.p(outc), (F, 2, E.k, E.n))[:, 0]
+                    bias = E.download(E.p(np_["b"]), (F, E.k, E.n))
+                    qv = np.array(E.q, dtype=np.uint64).reshape(1, E.k, 1)
+                    newb = np.ascontiguousarray((bias + (qv - corr)) % qv)
+                    E.L.crc_memcpy_h2d(E.c, E.p(np_["b"]), newb.ctypes.data, newb.nbytes, E.stream)
+                    E.sync()
+                    self._keep.append(newb)
+                self.param_bufs = [(b_, n_) for (b_, n_) in self.param_bufs if b_ is not p["mean"] and b_ is not p["invstd"]]
+                self.weight_bytes -= 2 * ch * rowb
+                p2 = dict(np_, folded_bn=name)
+                plan.append((nk, name + "+" + nname, na, p2, ishape, nosh))
+                i += 2
+                continue
+            plan.append(self.plan[i]); i += 1
+        self.plan = plan
 
     # ---- parameter upload
     def _encode_ntt(self, vals, chunk, dtype=np.float32):
