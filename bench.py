@@ -375,7 +375,7 @@ def main():
     except Exception:
         pass
     roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
-                    kernel=f"mac_kernel ({name}, {C} images/launch)" if kind in ("conv", "fc") else f"{kind} ({name})",
+                    kernel=kernel_label if kind in ("conv", "fc") else f"{kind} ({name})",
                     launch_ms=round(float(dur_ms), 3), algorithmic_bytes_per_launch=int(alg_bytes),
                     modmul_per_s=round(macs_launch * 2 * E.k * E.n / (dur_ms * 1e-3), 1) if dur_ms > 0 else None)
 
