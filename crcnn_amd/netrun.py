@@ -123,7 +123,14 @@ class Network:
                 macs_sep = layer_macs("conv", a)
                 macs_fused = a["nf"] * xo2 * yo2 * a["zd"] * xf2 * yf2
                 same_shape = (a["nf"], xo2, yo2) == tuple(nxt[5])
-                if same_shape and macs_fused < macs_sep:
+                # cost in units of one MAC term per output ciphertext: the MAC kernel pays ~24 terms of prologue/epilogue per output tile
+                #  and filters in multiples of 8; a pooling pass moves (window + 1) ciphertexts per output at HBM rate,
+                # ~10 term-times each.  Folding wins whenever it removes MACs (decimating pools) and narrowly for CrCNN's stride-1 pools.
+                fpad = -(-a["nf"] // 8) * 8
+                cost_sep = fpad * (macs_sep // a["nf"] // (a["zd"] * a["xf"] * a["yf"])) * (a["zd"] * a["xf"] * a["yf"] + 24) \
+                    + a["nf"] * xo2 * yo2 * 10 * (pa["xf"] * pa["yf"] + 1)
+                cost_fused = fpad * xo2 * yo2 * (a["zd"] * xf2 * yf2 + 24)
+                if same_shape and cost_fused < cost_sep:
                     cnt = a["nf"] * a["zd"] * xf2 * yf2
                     w2 = self.alloc(cnt * E.k * E.n * 8); b2 = self.alloc(a["nf"] * E.k * E.n * 8)
                     if self.materialize:
