@@ -184,3 +184,54 @@ def test_shape_validation(gl):
         E.pool(1, 1, 1, 5, 5, 3, 3, 2, 2, None, ca.COEFF, 1)
     with pytest.raises(ca.CrcError):
         E.conv2d(1, 1, 1, 1, 1, 2, 2, 1, 1, 3, 3, 1, ca.COEFF, ca.COEFF, 1, 1)     # filter larger than image
+
+
+RAGGED = [
+    # zd, xd, yd, xs, ys, xf, yf, nf, B      (T = zd*xf*yf reduction terms, M = B*xo*yo pixels)
+    (1, 5, 5, 1, 1, 3, 3, 1, 1),             # T=9 (odd: half-filled last stage), one filter
+    (3, 7, 6, 2, 1, 3, 2, 5, 2),             # T=18, F=5 (one partial filter tile), M=2*3*5=30
+    (7, 4, 4, 1, 1, 2, 2, 17, 3),            # T=28, F=17 (12x8 shape: 24, 6x16: 32), M=27
+    (11, 3, 3, 1, 1, 3, 3, 20, 1),           # T=99 > 64: overflow parking of the lazy accumulators, M=1
+    (70, 1, 1, 1, 1, 1, 1, 50, 7),           # dense-shaped, T=70, F=50, M=7
+    (2, 6, 6, 3, 3, 3, 3, 9, 0),             # empty batch
+]
+
+
+@pytest.mark.parametrize("geo", RAGGED, ids=[f"z{g[0]}_{g[1]}x{g[2]}_s{g[3]}{g[4]}_f{g[5]}x{g[6]}_nf{g[7]}_B{g[8]}" for g in RAGGED])
+def test_mac_ragged_geometries_exact(geo):
+    """crc_conv2d on NTT-form operands is, per slot, y[b,f,i,j] = sum_{z,u,v} x[b,z,i*xs+u,j*ys+v] * w[f,z,u,v] + bias[f] (poly 0)
+    mod q_i (convolutionalLayer.cpp:56-93 with multiply_plain_ntt, evaluator.cpp:1541-1585): checked against exact integer
+    arithmetic on random residues for shapes that leave partial pixel / filter tiles, odd reduction lengths, sums past
+    2^64 per limb, and an empty batch."""
+    import crcnn_amd as ca
+    zd, xd, yd, xs, ys, xf, yf, nf, B = geo
+    n, q = 128, ca.default_coeff_modulus_128(4096)
+    E = ca.Engine(n, q, 1 << 20, device=0)
+    k = E.k
+    rng = np.random.default_rng(abs(hash(geo)) % (1 << 32))
+    qa = np.array(q, dtype=np.uint64).reshape(1, k, 1)
+    def rnd(*lead):
+        hi = rng.integers(0, 1 << 62, size=lead + (k, n), dtype=np.uint64)
+        return hi % qa
+    xo, yo = (xd - xf) // xs + 1, (yd - yf) // ys + 1
+    x = rnd(max(B, 1), zd, xd, yd, 2)[:B]; w = rnd(nf, zd, xf, yf); bias = rnd(nf)
+    d_x = E.upload(x) if B else E.alloc(64); d_w = E.upload(w); d_b = E.upload(bias)
+    d_y = E.alloc(max(B, 1) * nf * xo * yo * 2 * k * n * 8)
+    d_work = E.alloc(E.conv2d_work_bytes(max(B, 1), zd, xd, yd, xs, ys, xf, yf, nf, ca.NTT))
+    E.conv2d(d_x, d_w, d_b, B, zd, xd, yd, xs, ys, xf, yf, nf, ca.NTT, ca.NTT, d_y, d_work)
+    E.sync()
+    if B == 0:
+        E.close(); return
+    y = E.download(d_y, (B, nf, xo, yo, 2, k, n))
+    xo_ = x.astype(object); wo = w.astype(object); qo = [int(v) for v in q]
+    for b in range(B):
+        for i in range(xo):
+            for j in range(yo):
+                patch = xo_[b, :, i * xs:i * xs + xf, j * ys:j * ys + yf]                 # [zd][xf][yf][2][k][n]
+                for f in range(nf):
+                    acc = (patch * wo[f][:, :, :, None]).sum(axis=(0, 1, 2))               # [2][k][n] exact integers
+                    acc[0] = acc[0] + bias[f].astype(object)
+                    for m in range(k):
+                        exp = np.array([int(v) % qo[m] for v in acc[:, m].reshape(-1)], dtype=np.uint64).reshape(2, n)
+                        assert np.array_equal(y[b, f, i, j, :, m], exp), (geo, b, f, i, j, m)
+    E.close()
