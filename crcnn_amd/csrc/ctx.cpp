@@ -278,6 +278,7 @@ extern "C" int crc_ctx_create(int n, const uint64_t *q, int k, uint64_t t, int d
         }
         if ((e = hipMalloc(&c->d_mods, sizeof(ModParams) * nm)) != hipSuccess || (e = hipMalloc(&c->d_rp, tw)) != hipSuccess ||
             (e = hipMalloc(&c->d_irp2, tw)) != hipSuccess || (e = hipMalloc(&c->d_behz, sizeof(BehzParams))) != hipSuccess ||
+            (e = hipMalloc(&c->d_zero, 4096)) != hipSuccess || (e = hipMemset(c->d_zero, 0, 4096)) != hipSuccess ||
             (e = hipMemcpy(c->d_mods, mods.data(), sizeof(ModParams) * nm, hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(c->d_rp, rp.data(), tw, hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(c->d_irp2, irp2.data(), tw, hipMemcpyHostToDevice)) != hipSuccess ||
@@ -293,7 +294,7 @@ extern "C" void crc_ctx_destroy(crc_ctx *c)
 {
     if (!c) return;
     if (c->device >= 0) {
-        (void)hipFree(c->d_mods); (void)hipFree(c->d_rp); (void)hipFree(c->d_irp2); (void)hipFree(c->d_behz);
+        (void)hipFree(c->d_mods); (void)hipFree(c->d_rp); (void)hipFree(c->d_irp2); (void)hipFree(c->d_behz); (void)hipFree(c->d_zero);
     }
     delete c;
 }

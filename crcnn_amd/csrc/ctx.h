@@ -69,6 +69,7 @@ struct crc_ctx {
     ModParams *d_mods = nullptr;             // [k+kb]
     u64 *d_rp = nullptr, *d_irp2 = nullptr;   // [(k+kb)][n][2]: {bit-reversed root power, its Shoup companion} (forward / inverse-div-2)
     BehzParams *d_behz = nullptr;
+    u64 *d_zero = nullptr;                   // 4 KiB of zeros (source row of reduction terms past T in mac3_kernel)
 };
 
 int  crc_set_hip_error(hipError_t e);

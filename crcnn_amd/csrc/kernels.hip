@@ -326,6 +326,7 @@ struct MacArgs {
     int n, k, B, P, F, T, in_cts;            // P output pixels per image, in_cts input cts per image
     const u64 *bias; int bias_sign;          // optional NTT-form delta bias [F][k][n] added to poly 0
     int dbg;                                 // tuning only: 1 = skip operand staging (timing of the bare MAC loop), 2 = skip barriers too
+    const u64 *zero;                         // >= 1 KiB of zeros (mac3: source of the terms past T)
     int gxd, gyd, gxf, gyf;                  // window geometry: toff[t] = (z*gxd + kx)*gyd + ky for t = (z*gxf + kx)*gyf + ky
 };
 
@@ -622,6 +623,182 @@ __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_
     }
 }
 
+// mac3_kernel (the default): mac2_kernel with the operand staging done by LDS-DMA (global_load_lds_dwordx4: global -> LDS, no VGPR
+// hop, no ds_write).  The LDS image holds the raw residues (the 28-bit split moves to the consumer side); the ~45 VGPRs this frees
+// pay for longer stages: S = 4 reduction steps per stage in two LDS buffers (115-128 KiB), i.e. half the barriers per MAC, with the
+// loads of stage st+1 in flight during stage st.  A wave waits for its own loads (s_waitcnt vmcnt(0)) before the one barrier per
+// stage.  Terms past T read a row of zeros.  Same arithmetic, same output as mac2_kernel; +7 % on the large layers.
+template <int PX, int FT, int WM, int WN, int S>
+__global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2))) mac3_kernel(MacArgs a)
+{
+    constexpr int NW = WM * WN, MT = PX * WM, ROWS = 2 * MT, FW = FT * WN;
+    constexpr int VEC = S * (ROWS + FW), NPAIR = VEC / 2, RLOAD = 2 * ((NPAIR + NW - 1) / NW);      // operand vectors are staged in (even, odd) pairs
+    static_assert(FT % 2 == 0 && (ROWS + FW) % 2 == 0, "pairs");
+    extern __shared__ __attribute__((aligned(16))) u64 smem[];      // 2 x [S][ROWS + FW vectors][64 slots] raw residues, then the term table, then 1 KiB dump
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave / WN, wn = wave % WN;
+    const int n = a.n, k = a.k;
+    const int M = a.B * a.P;
+    const int mtiles = (M + MT - 1) / MT, ftiles = (a.F + FW - 1) / FW, sbt = (n >> 6) * k;
+    // XCD-aware decode: consecutive workgroup ids go to different XCDs (round-robin dispatch), so give every XCD its own
+    // slot blocks and walk (f tile fastest, then m tile) inside one slot block
+    int g = blockIdx.x, sb, tile;
+    if ((sbt & 7) == 0) { const int xcd = g & 7, r = g >> 3, per = sbt >> 3; sb = xcd * per + r / (mtiles * ftiles); tile = r % (mtiles * ftiles); }
+    else { sb = g / (mtiles * ftiles); tile = g % (mtiles * ftiles); }
+    const int ft = tile % ftiles, mt = tile / ftiles;
+    const int i = sb / (n >> 6), s = ((sb % (n >> 6)) << 6) + lane;
+    const int m0 = mt * MT, f0 = ft * FW;
+    const size_t rown = (size_t)i * n + s, kn = (size_t)k * n, ctw = 2 * kn;
+    const ModParams m = a.mods[i];
+
+    // wave-uniform base pointer of every operand vector this wave stages (kept in SGPRs; lanes add (i*n+s)*8)
+    const u64 *vbase[RLOAD]; int vstep[RLOAD]; bool visx[RLOAD];
+#pragma unroll
+    for (int j = 0; j < RLOAD; j++) {
+        const int v = 2 * (wave + (j >> 1) * NW) + (j & 1);
+        const int vv = min(v, VEC - 1);                  // surplus slots (NPAIR not a multiple of NW) re-load the last vector, never stored
+        const int e = vv % (ROWS + FW);
+        vstep[j] = vv / (ROWS + FW);
+        if (e < ROWS) {
+            const int mm = min(m0 + (e >> 1), M - 1), b = mm / a.P, p = mm % a.P;
+            vbase[j] = a.x + ((size_t)b * a.in_cts + a.xoff[p]) * ctw + (size_t)(e & 1) * kn; visx[j] = true;
+        } else {
+            const int f = min(f0 + (e - ROWS), a.F - 1);     // filters past F are computed on a clamped copy and never stored
+            vbase[j] = a.w + (size_t)f * a.T * kn; visx[j] = false;
+        }
+    }
+
+    // wide staging loads: ONE global_load_dwordx4 fetches two vectors of a pair -- lanes 0..31 take slots (2l, 2l+1) of the even
+    // vector, lanes 32..63 the same slots of the odd one (the cost of staging is per memory INSTRUCTION, see DESIGN.md ablation)
+    const int half = lane >> 5, l2 = (lane & 31) * 2;
+    const u32 rown2 = (u32)((size_t)i * n + (s - lane) + l2);
+    const u32 hmask = half ? 0xffffffffu : 0u;
+    u32 vdelta[RLOAD / 2];                                   // element distance even -> odd vector of a pair (wave-uniform)
+#pragma unroll
+    for (int jj = 0; jj < RLOAD / 2; jj++) vdelta[jj] = (u32)(vbase[2 * jj + 1] - vbase[2 * jj]);
+
+    u64 A0[PX * 2][FT], A1[PX * 2][FT], A2[PX * 2][FT]; u32 OV[PX * 2][FT];
+#pragma unroll
+    for (int r = 0; r < PX * 2; r++)
+#pragma unroll
+        for (int f = 0; f < FT; f++) { A0[r][f] = 0; A1[r][f] = 0; A2[r][f] = 0; OV[r][f] = 0; }
+
+    constexpr int NBUF = 2, NLD = RLOAD / 2;                                 // every wave issues NLD loads per stage (surplus ones land in the dump)
+    // per-term x offsets: the padded toffw table is copied into LDS once (scalar loads inside the loop would share lgkmcnt
+    // with the LDS operand reads and stall them); lanes read the same word (broadcast)
+    u32 *tw = reinterpret_cast<u32 *>(smem + (size_t)NBUF * VEC * 64);
+    for (int t = threadIdx.x; t < a.T + 8; t += blockDim.x) tw[t] = a.toffw[t];
+    u64 *dump = smem + (size_t)NBUF * VEC * 64 + ((a.T + 8 + 3) / 4) * 2;
+    __syncthreads();                                 // the table is read by every wave from the first issue on
+    const u32 kn32 = (u32)kn;
+    const char *zrow = reinterpret_cast<const char *>(a.zero) + lane * 16;
+    auto issue_one = [&](int st, int jj) {
+        const int t = min(st * S + vstep[2 * jj], a.T - 1);
+        const u32 off = visx[2 * jj] ? tw[t] : (u32)t * kn32;
+        const bool dead = !visx[2 * jj] && st * S + vstep[2 * jj] >= a.T;                 // weights past the last term are zero (x may be anything valid)
+        const char *src = dead ? zrow : reinterpret_cast<const char *>(vbase[2 * jj]) + (size_t)((off + rown2 + (hmask & vdelta[jj])) << 3);
+        const int pr = wave + jj * NW;
+        u64 *dst = pr < NPAIR ? smem + ((size_t)(st % NBUF) * VEC + 2 * pr) * 64 : dump;  // lanes 0..31 -> vector 2pr, lanes 32..63 -> vector 2pr+1
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    };
+    auto issue_stage = [&](int st) {
+#pragma unroll
+        for (int jj = 0; jj < NLD; jj++) issue_one(st, jj);
+    };
+    // the staging traffic of a stage (LDS writes of stage st+1, global loads of stage st+2) is issued INSIDE the compute of stage
+    // st, at a different reduction step in the two waves that share a SIMD (waves w and w+4): while one wave issues its memory
+    // instructions the other one has multiply-adds to issue, instead of all eight waves staging at the same moment
+    const int io_sel = (wave >> 2) & 1;
+    const int io_step = io_sel ? S / 2 : 0;
+    auto compute_stage = [&](int st, auto &&io) {
+        const u64 *buf = smem + (size_t)(st % NBUF) * VEC * 64;
+#pragma unroll
+        for (int step = 0; step < S; step++) {
+            if (step == io_step) io();
+            const u64 *sv = buf + step * (ROWS + FW) * 64 + lane;
+            u32 w0[FT], w1[FT], ws[FT];
+#pragma unroll
+            for (int f = 0; f < FT; f++) { const u64 wv = split28(sv[(ROWS + wn * FT + f) * 64]); w0[f] = (u32)wv; w1[f] = (u32)(wv >> 32); ws[f] = w0[f] + w1[f]; }
+#pragma unroll
+            for (int r = 0; r < PX * 2; r++) {
+                const u64 xv = split28(sv[(wm * PX * 2 + r) * 64]);
+                const u32 x0 = (u32)xv, x1 = (u32)(xv >> 32), xs = x0 + x1;
+#pragma unroll
+                for (int f = 0; f < FT; f++) {
+                    A0[r][f] += (u64)x0 * w0[f];
+                    A2[r][f] += (u64)x1 * w1[f];
+                    A1[r][f] += (u64)xs * ws[f];
+                }
+            }
+        }
+        if ((st + 1) % (32 / S) == 0) {               // at most every 32 reduction steps: park bit 63 of each accumulator in the overflow word
+#pragma unroll
+            for (int r = 0; r < PX * 2; r++)
+#pragma unroll
+                for (int f = 0; f < FT; f++) {
+                    OV[r][f] += (u32)(A0[r][f] >> 63) + ((u32)(A1[r][f] >> 63) << 10) + ((u32)(A2[r][f] >> 63) << 20);
+                    A0[r][f] &= ~(1ULL << 63); A1[r][f] &= ~(1ULL << 63); A2[r][f] &= ~(1ULL << 63);
+                }
+        }
+    };
+
+    const int nstages = (a.T + S - 1) / S;
+    constexpr int WAIT_VM0 = (7 << 4) | (15 << 8);  // s_waitcnt vmcnt(0) only (gfx9 encoding: expcnt / lgkmcnt unconstrained)
+    issue_stage(0);
+    for (int st = 0; st < nstages; st++) {
+        __builtin_amdgcn_s_waitcnt(WAIT_VM0);        // this wave's loads for stage st have landed ...
+        __builtin_amdgcn_s_barrier();                // ... and everybody else's; all waves are also done reading the other buffer
+        compute_stage(st, [&] { if (st + 1 < nstages) issue_stage(st + 1); });
+    }
+
+    // recombine (mod 2^128, exact because the true sum is < 2^128), reduce once, add the bias, store
+#pragma unroll
+    for (int r = 0; r < PX * 2; r++) {
+        const int mm = m0 + wm * PX + (r >> 1), c = r & 1;
+        if (mm >= M) continue;
+        const int b = mm / a.P, p = mm % a.P;
+#pragma unroll
+        for (int f = 0; f < FT; f++) {
+            const int ff = f0 + wn * FT + f;
+            if (ff >= a.F) continue;
+            const u32 ov = OV[r][f];
+            // a_j = A_j + ov_j * 2^63  as (lo, hi)
+            u64 o0 = ov & 1023, o1 = (ov >> 10) & 1023, o2 = (ov >> 20) & 1023;
+            u64 a0l = A0[r][f] + (o0 << 63), a0h = (o0 >> 1) + (a0l < A0[r][f]);
+            u64 a1l = A1[r][f] + (o1 << 63), a1h = (o1 >> 1) + (a1l < A1[r][f]);
+            u64 a2l = A2[r][f] + (o2 << 63), a2h = (o2 >> 1) + (a2l < A2[r][f]);
+            // mid = a1 - a0 - a2
+            u64 ml = a1l - a0l, mh = a1h - a0h - (a1l < a0l);
+            u64 ml2 = ml - a2l; mh = mh - a2h - (ml < a2l); ml = ml2;
+            // V = a0 + mid << 28 + a2 << 56
+            u64 vl = a0l, vh = a0h;
+            u64 tl = ml << 28, th = (mh << 28) | (ml >> 36);
+            u64 nl = vl + tl; vh += th + (nl < vl); vl = nl;
+            tl = a2l << 56; th = (a2h << 56) | (a2l >> 8);
+            nl = vl + tl; vh += th + (nl < vl); vl = nl;
+            u64 v = barrett128(vl, vh, m);
+            if (c == 0 && a.bias) { const u64 bv = a.bias[(size_t)ff * kn + rown]; v = addmod(v, bv, m.q); }
+            a.y[(((size_t)b * a.F + ff) * a.P + p) * ctw + (size_t)c * kn + rown] = v;
+        }
+    }
+}
+
+template <int PX, int FT, int WM, int WN, int S>
+static int mac3_launch(crc_ctx *c, MacArgs &a, hipStream_t st)
+{
+    constexpr int MT = PX * WM, FW = FT * WN, VEC = S * (2 * MT + FW);
+    const int M = a.B * a.P;
+    const size_t grid = (size_t)((M + MT - 1) / MT) * ((a.F + FW - 1) / FW) * (size_t)((c->n >> 6) * c->k);
+    if (grid > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
+    if (a.T + 8 > 16384) return CRC_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)2 * VEC * 64 * 8 + (size_t)((a.T + 8 + 3) / 4) * 16 + 1024;
+    if (lds > 160 * 1024) return CRC_ERR_UNSUPPORTED;
+    auto kern = mac3_kernel<PX, FT, WM, WN, S>;
+    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WM * WN), lds, st, a);
+    HIPCHK(hipGetLastError());
+    return CRC_OK;
+}
+
 template <int PX, int FT, int WM, int WN, int S, int DEPTH = 2>
 static int mac2_launch(crc_ctx *c, MacArgs &a, hipStream_t st)
 {
@@ -661,6 +838,16 @@ int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, co
         const long long M = (long long)B * P;
         auto padded = [&](int mt, int fw) { return ((M + mt - 1) / mt * mt) * (((long long)F + fw - 1) / fw * fw); };
         pick = padded(12, 8) * 100 < padded(6, 16) * 98 ? 8 : 16;
+    }
+    a.zero = c->d_zero;
+    // default: LDS-DMA staging with 4-step stages; the register-staged mac2_kernel remains for reductions whose term table does not
+    // fit beside the two stage buffers (T > ~7000) and as the tuning reference (CRC_MAC_REGSTAGE=1, CRC_MAC2_CFG)
+    static const int regstage = [] { const char *e = getenv("CRC_MAC_REGSTAGE"); return e ? atoi(e) : 0; }();
+    // short reductions that are not a multiple of 4 lose more to the padded last stage than LDS-DMA gains (T = 25: 28 steps instead of 26)
+    const bool short_odd = ((T + 3) / 4 * 4 - (T + 1) / 2 * 2) * 20 > T;
+    if (!regstage && !cfg && !short_odd) {
+        const int rc = pick == 8 ? mac3_launch<3, 4, 4, 2, 4>(c, a, st) : mac3_launch<3, 4, 2, 4, 4>(c, a, st);
+        if (rc != CRC_ERR_UNSUPPORTED) return rc;
     }
     switch (pick) {
     case 3: return mac2_launch<2, 4, 3, 4, 2, 1>(c, a, st);
