@@ -367,7 +367,7 @@ def main():
     # HBM traffic of that launch from rocprofv3 PMC passes (FETCH_SIZE corrected x2 for gfx950, WRITE_SIZE), collected offline with
     # tools/bench_mac.py and committed under profiles/ -- bench.py cannot run the profiler on itself
     traffic = None
-    kernel_label = f"mac2_kernel ({name}, {C} images/launch)" if kind in ("conv", "fc") else f"{kind} ({name})"
+    kernel_label = f"mac3_kernel ({name}, {C} images/launch)" if kind in ("conv", "fc") else f"{kind} ({name})"
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))).get(args.config)
         if pm and pm["kernel"] == kernel_label:
