@@ -477,6 +477,92 @@ ciphertext3D Network::forward(ciphertext3D input)
     return input;
 }
 
+int Network::fuse()
+{
+    const int n = N(), k = K();
+    const size_t rowb = (size_t)k * n * 8;
+    int removed = 0;
+    auto inttCopy = [&](const shared_ptr<DeviceBuffer> &ntt_rows, size_t rows) {       // coefficient-form twin of NTT-form delta rows
+        auto out = make_shared<DeviceBuffer>(rows * rowb);
+        chk(crc_memcpy_d2d(ctx(), out->ptr, ntt_rows->ptr, rows * rowb, nullptr), "crc_memcpy_d2d");
+        chk(crc_ntt_inv(ctx(), (uint64_t *)out->ptr, rows, 1, nullptr), "crc_ntt_inv");
+        return out;
+    };
+    // 1. conv + pool
+    for (size_t i = 0; i + 1 < layers.size(); i++) {
+        auto conv = dynamic_pointer_cast<ConvolutionalLayer>(layers[i]);
+        auto pool = dynamic_pointer_cast<PoolingLayer>(layers[i + 1]);
+        if (!conv || !pool || (int)i + 1 == layer_before_reenc) continue;
+        if (pool->zd != conv->nf || pool->xd != conv->xo || pool->yd != conv->yo) continue;
+        const int xf2 = (pool->xf - 1) * conv->xs + conv->xf, yf2 = (pool->yf - 1) * conv->ys + conv->yf;
+        const int xs2 = conv->xs * pool->xs, ys2 = conv->ys * pool->ys;
+        if (xf2 > conv->xd || yf2 > conv->yd) continue;
+        const int xo2 = (conv->xd - xf2) / xs2 + 1, yo2 = (conv->yd - yf2) / ys2 + 1;
+        if (xo2 != pool->xo || yo2 != pool->yo) continue;
+        // cost in MAC terms per output ciphertext (the MAC kernel pays ~24 terms of prologue/epilogue per output, filters come in
+        // multiples of 8; a pooling pass moves window+1 ciphertexts per output at HBM rate, ~10 term-times each)
+        const long long fpad = (conv->nf + 7) / 8 * 8, T1 = (long long)conv->zd * conv->xf * conv->yf, T2 = (long long)conv->zd * xf2 * yf2;
+        const long long cost_sep = fpad * conv->xo * conv->yo * (T1 + 24) + (long long)conv->nf * xo2 * yo2 * 10 * (pool->xf * pool->yf + 1);
+        const long long cost_fused = fpad * xo2 * yo2 * (T2 + 24);
+        if (cost_fused >= cost_sep) continue;
+        conv->upload();
+        vector<Plaintext> nob; plaintext4D nof;
+        auto fused = make_shared<ConvolutionalLayer>(conv->name + "+" + pool->name, conv->xd, conv->yd, conv->zd, xs2, ys2, xf2, yf2, conv->nf, conv->th_count, nof, nob);
+        fused->d_w = make_shared<DeviceBuffer>((size_t)conv->nf * T2 * rowb);
+        fused->d_b[1] = make_shared<DeviceBuffer>((size_t)conv->nf * rowb);
+        chk(crc_conv2d_fold_pool(ctx(), (const uint64_t *)conv->d_w->ptr, (const uint64_t *)conv->d_b[1]->ptr, pool->d_div ? (const uint64_t *)pool->d_div->ptr : nullptr,
+                                 conv->nf, conv->zd, conv->xf, conv->yf, conv->xs, conv->ys, pool->xf, pool->yf, (uint64_t *)fused->d_w->ptr, (uint64_t *)fused->d_b[1]->ptr, nullptr),
+            "crc_conv2d_fold_pool");
+        fused->d_b[0] = inttCopy(fused->d_b[1], conv->nf);
+        fused->filters_already_ntt = true;
+        layers[i] = fused;
+        layers.erase(layers.begin() + i + 1);
+        removed++;
+    }
+    // 2. batch-norm + conv / dense
+    for (size_t i = 0; i + 1 < layers.size(); i++) {
+        auto bn = dynamic_pointer_cast<BatchNormLayer>(layers[i]);
+        if (!bn || (int)i + 1 == layer_before_reenc) continue;
+        auto conv = dynamic_pointer_cast<ConvolutionalLayer>(layers[i + 1]);
+        auto fc = dynamic_pointer_cast<FullyConnectedLayer>(layers[i + 1]);
+        if (!conv && !fc) continue;
+        const int ch = bn->num_channels;
+        int F, per_ch, T;
+        if (conv) { if (conv->zd != ch) continue; F = conv->nf; per_ch = conv->xf * conv->yf; T = conv->zd * per_ch; conv->upload(); }
+        else { if (fc->in_dim % ch) continue; F = fc->out_dim; per_ch = fc->in_dim / ch; T = fc->in_dim; fc->upload(); }
+        bn->upload();
+        shared_ptr<DeviceBuffer> &dw = conv ? conv->d_w : fc->d_w;
+        shared_ptr<DeviceBuffer> *db = conv ? conv->d_b : fc->d_b;
+        // w'[f][z][tap] = w (*) s[z]
+        for (int f = 0; f < F; f++)
+            chk(crc_multiply_plain_ntt(ctx(), (uint64_t *)dw->ptr + (size_t)f * T * k * n, (const uint64_t *)bn->d_invstd->ptr, T, per_ch, 1, nullptr), "crc_multiply_plain_ntt");
+        // correction[f] = sum_t w'[f][t] (*) M[z(t)]: the dense kernel on one pseudo-image whose ciphertexts are (M[z(t)], 0)
+        DeviceBuffer fake((size_t)T * 2 * rowb), outc((size_t)F * 2 * rowb), wk(max<size_t>(crc_dense_work_bytes(ctx(), 1, T, F, CRC_NTT), 256));
+        chk(crc_memset(ctx(), fake.ptr, 0, (size_t)T * 2 * rowb, nullptr), "crc_memset");
+        for (int z = 0; z < ch; z++) for (int t = 0; t < per_ch; t++)
+            chk(crc_memcpy_d2d(ctx(), (char *)fake.ptr + ((size_t)z * per_ch + t) * 2 * rowb, (char *)bn->d_mean[1]->ptr + (size_t)z * rowb, rowb, nullptr), "crc_memcpy_d2d");
+        chk(crc_dense(ctx(), (const uint64_t *)fake.ptr, (const uint64_t *)dw->ptr, nullptr, 1, T, F, CRC_NTT, CRC_NTT, (uint64_t *)outc.ptr, wk.ptr, nullptr), "crc_dense");
+        vector<uint64_t> corr((size_t)F * 2 * k * n), bias((size_t)F * k * n), q(k);
+        chk(crc_memcpy_d2h(ctx(), corr.data(), outc.ptr, corr.size() * 8, nullptr), "crc_memcpy_d2h");
+        chk(crc_memcpy_d2h(ctx(), bias.data(), db[1]->ptr, bias.size() * 8, nullptr), "crc_memcpy_d2h");
+        chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+        chk(crc_ctx_table(ctx(), "q", q.data(), k) < 0 ? CRC_ERR_INVALID_ARGUMENT : CRC_OK, "crc_ctx_table");
+        for (int f = 0; f < F; f++) for (int m = 0; m < k; m++) for (int s2 = 0; s2 < n; s2++) {
+            uint64_t &b = bias[((size_t)f * k + m) * n + s2]; const uint64_t c = corr[(((size_t)f * 2) * k + m) * n + s2];
+            b = b >= c ? b - c : b + q[m] - c;
+        }
+        db[1] = make_shared<DeviceBuffer>(bias.size() * 8);
+        chk(crc_memcpy_h2d(ctx(), db[1]->ptr, bias.data(), bias.size() * 8, nullptr), "crc_memcpy_h2d");
+        chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+        db[0] = inttCopy(db[1], F);
+        layers[i + 1]->name = bn->name + "+" + layers[i + 1]->name;
+        layers.erase(layers.begin() + i);
+        removed++;
+    }
+    chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+    return removed;
+}
+
 // ---- CnnBuilder -------------------------------------------------------------------------------------------------------
 vector<float> CnnBuilder::getPretrained(string var_name)
 {   // LoadH5::getData, cnnBuilder.cpp:20-23

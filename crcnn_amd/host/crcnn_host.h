@@ -93,6 +93,7 @@ public:
 
 class ConvolutionalLayer : public Layer {                   // convolutionalLayer.h:33-34
 public:
+    friend class Network;
     int xd, yd, zd, xs, ys, xf, yf, nf, th_count;
     int xo, yo, zo;
     plaintext4D filters;                                    // nf,zd,xf,yf
@@ -113,6 +114,7 @@ private:
 
 class FullyConnectedLayer : public Layer {                  // fullyConnectedLayer.h:22-24
 public:
+    friend class Network;
     int in_dim, out_dim, th_count;
     plaintext2D weights;
     std::vector<Plaintext> biases;
@@ -132,6 +134,7 @@ private:
 
 class PoolingLayer : public Layer {                         // poolingLayer.h:15
 public:
+    friend class Network;
     int xd, yd, zd, xs, ys, xf, yf, xo, yo, zo;
     PoolingLayer(std::string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf);
     ciphertext3D forward(ciphertext3D input) override;
@@ -162,6 +165,7 @@ private:
 
 class BatchNormLayer : public Layer {                       // batchNormLayer.h:18-20
 public:
+    friend class Network;
     int num_channels;
     std::vector<Plaintext> mean, var;                       // var already holds encode(1/sqrt(var+1e-5)) (cnnBuilder.cpp:100-102)
     BatchNormLayer(std::string name, int num_channels, std::vector<Plaintext> &mean, std::vector<Plaintext> &var);
@@ -205,6 +209,12 @@ public:
     std::vector<std::shared_ptr<Layer>> &getLayers() { return layers; }
     void printNetworkStructure();
     ciphertext3D forward(ciphertext3D input);
+    // Exact layer folding (ring algebra over Z_q), done once on the device-resident parameters: a sum/avg pooling
+    // layer is folded into the convolution in front of it (pooled kernel, xf' = (pxf-1)*cxs + xf, stride cxs*pxs) when that is
+    // estimated to be cheaper, a batch-norm layer into the conv / dense layer behind it (w' = w (*) s[channel],
+    // b' = b - sum_taps w' (*) mean[channel]).  The network's output ciphertexts stay bit-identical; only the folded layers'
+    // intermediate tensors disappear (their plaintext parameters can no longer be saved).  Returns the number of layers removed.
+    int fuse();
 };
 
 // ---- model loader + builder (CrCNN/src/cnnBuilder.h:16-44) ----------------------------------------------------------

@@ -1,5 +1,5 @@
 // test_host.cpp -- driver for the C++ host classes, run by tests/test_gpu_host_cpp.py on the GPU box.
-//   test_host net <model> <h5> <dir> <resident 0|1> <batch>
+//   test_host net <model> <h5> <dir> <resident 0|1> <batch> [fuse 0|1]      (fuse: Network::fuse() before the resident forward)
 //     <dir>/params.u64 (n,k,t,q...), evk.u64, net_in.u64 ([1][1][28][28][2][k][n]) -> writes layer_<i>.u64 (layerwise mode) and out.u64
 //   test_host api <h5> <dir>     exercises save/load of the encoded model, client-side encrypt/decrypt, and error behaviour
 //   test_host searchlogic <min> <max> <first_good> <last_good> <min_q>
@@ -46,6 +46,7 @@ static int do_net(int argc, char **argv)
     CnnBuilder builder(h5);
     Network net = builder.buildNetworkByName(model);
     net.ntt_resident = resident;
+    if (argc > 7 && atoi(argv[7])) { const int removed = net.fuse(); fprintf(stderr, "fused: %d layers removed, %d left\n", removed, net.getNumLayers()); }
     auto x = rd(dir + "/net_in.u64");
     vector<ciphertext3D> imgs;
     for (int b = 0; b < batch; b++) imgs.push_back(ciphertext3D::fromHost(x.data(), 1, 1, 28, 28));

@@ -15,14 +15,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DRIVER = os.path.join(ROOT, "crcnn_amd", "lib", "test_host")
 
 
-def run_driver(name, resident, batch=1):
+def run_driver(name, resident, batch=1, fuse=False):
     g = load_net_golden(name)
     O, sk, pk, evk, img, x = make_inputs(g)
     d = tempfile.mkdtemp()
     np.array([g["n"], len(g["q"]), g["t"]] + g["q"], dtype=np.uint64).tofile(os.path.join(d, "params.u64"))
     evk.tofile(os.path.join(d, "evk.u64")); x.tofile(os.path.join(d, "net_in.u64"))
     h5 = os.path.join(GOLD, "models", g["model"] + ".h5")
-    subprocess.check_call([DRIVER, "net", g["model"], h5, d, "1" if resident else "0", str(batch)])
+    subprocess.check_call([DRIVER, "net", g["model"], h5, d, "1" if resident else "0", str(batch), "1" if fuse else "0"])
     return g, O, d
 
 
@@ -83,3 +83,12 @@ def test_cpp_plain_modulus_search():
     assert all(s != "SUCCESS" for t, s in tried if t < found)
     # the verdicts have the expected shape: too-small moduli mispredict, too-large ones run out of budget
     assert any(s == "MISPREDICTED" for t, s in tried if t < found) or found == lo
+
+
+@pytest.mark.parametrize("name", ["tiny256", "approx256", "wopad256"])
+def test_cpp_network_fused_equals_reference(name):
+    """Network::fuse() (conv+pool folding, batch-norm folding) must leave the network's output ciphertexts bit-identical to the
+    compiled reference's"""
+    g, O, d = run_driver(name, resident=True, batch=2, fuse=True)
+    out = np.fromfile(os.path.join(d, "out.u64"), dtype=np.uint64).reshape(2, -1)
+    assert sha(out[0]) == g["out_sha256"] and sha(out[1]) == g["out_sha256"]
