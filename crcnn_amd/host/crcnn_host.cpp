@@ -308,6 +308,7 @@ ciphertext3D ConvolutionalLayer::forward(ciphertext3D input)
 }
 void ConvolutionalLayer::savePlaintextParameters(ostream *outfile)
 {   // order of convolutionalLayer.cpp:213-229
+    if ((int)filters.size() != nf) throw logic_error("ConvolutionalLayer " + name + ": a folded layer has no plaintext parameters to save (save before Network::fuse())");
     for (int n = 0; n < nf; n++) { for (int z = 0; z < zd; z++) for (int i = 0; i < xf; i++) for (int j = 0; j < yf; j++) filters[n][z][i][j].save(*outfile); biases[n].save(*outfile); outfile->flush(); }
 }
 void ConvolutionalLayer::loadPlaintextParameters(istream *infile)
