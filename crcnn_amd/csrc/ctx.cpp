@@ -47,6 +47,7 @@ ModParams make_mod(u64 q)
     u128 all = ~(u128)0, quo = all / q;
     if (all % q + 1 == q) quo += 1;                // q | 2^128 (m~ = 2^32)
     m.q = q; m.r0 = (u64)quo; m.r1 = (u64)(quo >> 64); m.two_q = 2 * q; m.bits = (u32)sigbits(q);
+    { const u64 d = m.bits >= 40 && m.bits <= 62 ? ((u64)1 << m.bits) - q : 0; m.fold = d && d < (1u << 26) && !getenv("CRC_NO_FOLD") ? (u32)d : 0; }
     return m;
 }
 

@@ -21,7 +21,7 @@ struct ModParams {
     u64 r0, r1;     // floor(2^128 / q) low / high word  (Barrett, same constant SEAL calls const_ratio)
     u64 two_q;      // 2q
     u32 bits;       // significant bits of q
-    u32 pad;
+    u32 fold;       // 2^bits - q when that is below 2^26 (every prime SEAL ships: 2^b - c 2^s + 1), else 0
 };
 
 CRC_HD u64 mulhi64(u64 a, u64 b)
@@ -43,9 +43,30 @@ CRC_HD u64 addmod(u64 a, u64 b, u64 q) { u64 s = a + b; return s >= q ? s - q : 
 CRC_HD u64 submod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
 CRC_HD u64 negmod(u64 a, u64 q) { return a ? q - a : 0; }
 
+// x = hi*2^64 + lo  ->  x mod q, canonical, for q = 2^b - d with a small d (m.fold): 2^b = d (mod q), so the part of x above bit b
+// folds down as (x >> b) d + (x mod 2^b).  Three folds take any 128-bit x below 2^b + 2^44 < 2q; 6 word multiplies instead of the
+// 18 of the generic Barrett reduction below.  Requires 40 <= b <= 62, d < 2^26.
+CRC_HD u64 fold128(u64 lo, u64 hi, const ModParams &m)
+{
+    const u32 b = m.bits; const u64 d = m.fold, mask = ((u64)1 << b) - 1;
+    // fold 1: h1 = x >> b (up to 128 - b <= 88 bits), x1 = h1 d + (x mod 2^b) < 2^114 + 2^b
+    const u64 h1l = (lo >> b) | (hi << (64 - b)), h1h = hi >> b;
+    u64 pl, ph; mul64wide(h1l, d, pl, ph);
+    u64 x1l = pl + (lo & mask); u64 x1h = ph + h1h * d + (x1l < pl);
+    // fold 2: h2 = x1 >> b (<= 60 bits)
+    const u64 h2 = (x1l >> b) | (x1h << (64 - b));
+    mul64wide(h2, d, pl, ph);
+    u64 x2l = pl + (x1l & mask); u64 x2h = ph + (x2l < pl);
+    // fold 3: h3 = x2 >> b (<= 24 bits), x3 = h3 d + (x2 mod 2^b) < 2^50 + 2^b
+    const u64 h3 = (x2l >> b) | (x2h << (64 - b));
+    u64 r = h3 * d + (x2l & mask);
+    return r >= m.q ? r - m.q : r;
+}
+
 // x = hi*2^64 + lo  ->  x mod q, canonical.  Exact for any 128-bit x (quotient estimate is off by at most one).
 CRC_HD u64 barrett128(u64 lo, u64 hi, const ModParams &m)
 {
+    if (m.fold) return fold128(lo, hi, m);
     // floor(x * r / 2^128) mod 2^64, r = r1*2^64 + r0
     u64 c = mulhi64(lo, m.r0);
     u64 t_lo, t_hi;
