@@ -1,0 +1,41 @@
+// Host-side check of crcnn_amd/csrc/modarith.h (shared by the host table builders and the gfx950 kernels): barrett128 / fold128 /
+// mulmod / Shoup multiplications against unsigned __int128 arithmetic for every prime the reference's parameter sets use
+// (coeff_modulus_128, SEAL util/globals.cpp:25-90; auxiliary 61-bit primes :321-367) plus a prime without the 2^b - d form.
+#include "modarith.h"
+#include <cstdio>
+typedef unsigned __int128 u128;
+static ModParams make(u64 q, bool allow_fold)
+{
+    ModParams m{}; u128 all = ~(u128)0, quo = all / q;
+    m.q = q; m.r0 = (u64)quo; m.r1 = (u64)(quo >> 64); m.two_q = 2 * q; m.bits = 64 - __builtin_clzll(q);
+    const u64 d = ((u64)1 << m.bits) - q; m.fold = allow_fold && m.bits >= 40 && m.bits <= 62 && d < (1u << 26) ? (u32)d : 0;
+    return m;
+}
+int main()
+{
+    const u64 qs[] = {0x7fffffff380001ULL, 0x3fffffff000001ULL, 0x7ffffffef00001ULL, 0x3ffffffef40001ULL, 0x7ffffffeac0001ULL, 0x7ffffffe700001ULL,
+                      0x7ffffffe600001ULL, 0x7ffffffe4c0001ULL, 0x1fffffffffe00001ULL, 0x1fffffffffc80001ULL, 0x1fffffffffb40001ULL, 0x1fffffffff500001ULL,
+                      1152921504606584833ULL /* 2^60 - 2^18 + 1 */, 4611686018326724609ULL /* 62 bits */};
+    u64 x = 88172645463325252ULL; auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    long checked = 0;
+    for (u64 q : qs) for (int fold = 0; fold < 2; fold++) {
+        const ModParams m = make(q, fold);
+        if (fold && !m.fold) continue;
+        const u128 qq = (u128)q * q - 1;
+        for (long it = 0; it < 400000; it++) {
+            u64 lo = rnd(), hi = rnd();
+            if (it % 7 == 0) hi = ~0ULL; if (it % 11 == 0) lo = ~0ULL; if (it % 13 == 0) hi = 0; if (it % 17 == 0) { hi = (u64)(qq >> 64); lo = (u64)qq; } if (it % 19 == 0) { hi = 0; lo = q - 1 + (it & 1); }
+            const u64 e = (u64)(((((u128)hi) << 64) | lo) % q);
+            if (barrett128(lo, hi, m) != e) { printf("barrett128 mismatch q=%llx fold=%d hi=%llx lo=%llx\n", (unsigned long long)q, fold, (unsigned long long)hi, (unsigned long long)lo); return 1; }
+            const u64 a = rnd() % q, b = rnd() % q, wp = (u64)(((u128)b << 64) / q);
+            if (mulmod(a, b, m) != (u64)((u128)a * b % q)) { printf("mulmod mismatch q=%llx\n", (unsigned long long)q); return 1; }
+            const u64 any = rnd();
+            if (mulmod_shoup(any, b, wp, q) != (u64)((u128)any * b % q)) { printf("mulmod_shoup mismatch q=%llx\n", (unsigned long long)q); return 1; }
+            const u64 lz = mulmod_shoup_lazy(any, b, wp, q);
+            if (lz >= 2 * q || lz % q != (u64)((u128)any * b % q)) { printf("mulmod_shoup_lazy mismatch q=%llx\n", (unsigned long long)q); return 1; }
+            checked++;
+        }
+    }
+    printf("ok %ld\n", checked);
+    return 0;
+}

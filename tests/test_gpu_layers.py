@@ -194,6 +194,8 @@ RAGGED = [
     (11, 3, 3, 1, 1, 3, 3, 20, 1),           # T=99 > 64: overflow parking of the lazy accumulators, M=1
     (70, 1, 1, 1, 1, 1, 1, 50, 7),           # dense-shaped, T=70, F=50, M=7
     (2, 6, 6, 3, 3, 3, 3, 9, 0),             # empty batch
+    (12001, 1, 1, 1, 1, 1, 1, 2, 1),         # T=12001: term table no longer fits beside mac3's stage buffers -> register-staged mac2
+    (16500, 1, 1, 1, 1, 1, 1, 2, 1),         # T=16500: past the LDS term table altogether -> mac_kernel (v1)
 ]
 
 

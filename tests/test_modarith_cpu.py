@@ -1,0 +1,16 @@
+"""Host logic: the modular-arithmetic header shared by the host table builders and the kernels (crcnn_amd/csrc/modarith.h) against
+unsigned __int128 arithmetic -- Barrett (SEAL uintarithsmallmod.h:137-176 semantics), the folding reduction for 2^b - d primes, Shoup
+multiplication -- for every prime of the reference's parameter sets.  Compiled with g++ on the spot; no GPU."""
+import os
+import subprocess
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_modarith_header_against_int128():
+    exe = os.path.join(tempfile.mkdtemp(), "modarith_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "crcnn_amd", "csrc"), os.path.join(ROOT, "tests", "cpp", "modarith_check.cpp"), "-o", exe])
+    out = subprocess.check_output([exe], text=True)
+    assert out.startswith("ok "), out
+    assert int(out.split()[1]) > 5_000_000
