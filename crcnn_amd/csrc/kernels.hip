@@ -511,7 +511,7 @@ __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_
     auto load_one = [&](int st, int jj, ulonglong2 (&reg)[RLOAD / 2]) {
         const int t = min(st * S + vstep[2 * jj], a.T - 1);
         const u32 off = visx[2 * jj] ? tw[t] : (u32)t * kn32;
-        reg[jj] = *reinterpret_cast<const ulonglong2 *>(reinterpret_cast<const char *>(vbase[2 * jj]) + (size_t)((off + rown2 + (hmask & vdelta[jj])) << 3));   // consumed only by store_pair
+        reg[jj] = *reinterpret_cast<const ulonglong2 *>(reinterpret_cast<const char *>(vbase[2 * jj]) + ((size_t)(off + rown2 + (hmask & vdelta[jj])) << 3));   // consumed only by store_pair
     };
     auto store_pair = [&](int st, int jj, ulonglong2 (&reg)[RLOAD / 2]) {
         u64 *dst = smem + (size_t)(st & 1) * VEC * 64;
@@ -695,7 +695,7 @@ __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_
         const int t = min(st * S + vstep[2 * jj], a.T - 1);
         const u32 off = visx[2 * jj] ? tw[t] : (u32)t * kn32;
         const bool dead = !visx[2 * jj] && st * S + vstep[2 * jj] >= a.T;                 // weights past the last term are zero (x may be anything valid)
-        const char *src = dead ? zrow : reinterpret_cast<const char *>(vbase[2 * jj]) + (size_t)((off + rown2 + (hmask & vdelta[jj])) << 3);
+        const char *src = dead ? zrow : reinterpret_cast<const char *>(vbase[2 * jj]) + ((size_t)(off + rown2 + (hmask & vdelta[jj])) << 3);
         const int pr = wave + jj * NW;
         u64 *dst = pr < NPAIR ? smem + ((size_t)(st % NBUF) * VEC + 2 * pr) * 64 : dump;  // lanes 0..31 -> vector 2pr, lanes 32..63 -> vector 2pr+1
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
@@ -820,9 +820,9 @@ int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, co
 {
     if (B == 0 || P == 0 || F == 0) return CRC_OK;
     int maxbits = 0; for (int i = 0; i < c->k; i++) if ((int)c->tabs[i].m.bits > maxbits) maxbits = c->tabs[i].m.bits;
-    // mac2 addresses operands as wave-uniform base + 32-bit byte offset (term offset + half-wave pair offset + slot)
-    const size_t kn8 = (size_t)c->k * c->n * 8;
-    const bool off32 = ((size_t)2 * T + 3) * kn8 < (1ull << 32) && ((size_t)2 * in_cts + 3) * kn8 < (1ull << 32);
+    // operands are addressed as wave-uniform base + 32-bit ELEMENT offset (term offset + half-wave pair offset + slot), widened to bytes per lane
+    const size_t kn1 = (size_t)c->k * c->n;
+    const bool off32 = ((size_t)2 * T + 3) * kn1 < (1ull << 32) && ((size_t)2 * in_cts + 3) * kn1 < (1ull << 32);
     if (maxbits > 55 || T > 16000 || c->n < 64 || !off32) return k_mac(c, x, w, y, d_xoff, d_toff, B, P, F, T, in_cts, bias_ntt, st);
     MacArgs a{};
     a.x = x; a.w = w; a.y = y; a.mods = c->d_mods; a.xoff = d_xoff; a.toff = d_toff; a.toffw = d_toffw;

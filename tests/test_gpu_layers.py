@@ -237,3 +237,43 @@ def test_mac_ragged_geometries_exact(geo):
                         exp = np.array([int(v) % qo[m] for v in acc[:, m].reshape(-1)], dtype=np.uint64).reshape(2, n)
                         assert np.array_equal(y[b, f, i, j, :, m], exp), (geo, b, f, i, j, m)
     E.close()
+
+
+def test_mac_operand_offsets_past_4GiB():
+    """an input tensor larger than 4 GiB (40 channels of 32x32 ciphertexts at n=4096, k=2 = 5.4 GB): operand byte offsets no longer fit
+    32 bits; spot-check output pixels against exact integer arithmetic.  The input is filled by the device encryptor (any residues do)."""
+    import crcnn_amd as ca
+    n, q = 4096, ca.default_coeff_modulus_128(4096)
+    E = ca.Engine(n, q, 1 << 20, device=0)
+    k = E.k
+    zd, xd, yd, nf = 40, 32, 32, 2
+    ctb = 2 * k * n * 8
+    cts = zd * xd * yd
+    assert cts * ctb > (1 << 32)
+    sk, pk = E.keygen(5)
+    d_pk = E.upload(pk)
+    chunk = 4096
+    d_pl = E.upload(np.zeros((chunk, n), dtype=np.uint64)); d_w8 = E.alloc(E.encrypt_dev_work_bytes(chunk))
+    d_x = E.alloc(cts * ctb)
+    for o in range(0, cts, chunk):
+        E.encrypt_dev(d_pk, d_pl, chunk, 1000 + o, E.p(d_x) + o * ctb, d_w8)
+    rng = np.random.default_rng(9)
+    qa = np.array(q, dtype=np.uint64).reshape(1, k, 1)
+    w = rng.integers(0, 1 << 62, size=(nf * zd, k, n), dtype=np.uint64) % qa
+    bias = rng.integers(0, 1 << 62, size=(nf, k, n), dtype=np.uint64) % qa
+    d_w = E.upload(w); d_b = E.upload(bias)
+    d_y = E.alloc(nf * xd * yd * ctb)
+    d_work = E.alloc(E.conv2d_work_bytes(1, zd, xd, yd, 1, 1, 1, 1, nf, ca.NTT))
+    E.conv2d(d_x, d_w, d_b, 1, zd, xd, yd, 1, 1, 1, 1, nf, ca.NTT, ca.NTT, d_y, d_work)
+    E.sync()
+    wv = w.reshape(nf, zd, k, n).astype(object)
+    for (i, j) in [(0, 0), (31, 31), (17, 5), (31, 0)]:
+        px = np.stack([E.download(E.p(d_x) + ((z * xd + i) * yd + j) * ctb, (2, k, n)) for z in range(zd)]).astype(object)       # [zd][2][k][n]
+        for f in range(nf):
+            acc = (px * wv[f][:, None]).sum(axis=0)                                          # [2][k][n]
+            acc[0] = acc[0] + bias[f].astype(object)
+            got = E.download(E.p(d_y) + ((f * xd + i) * yd + j) * ctb, (2, k, n))
+            for m in range(k):
+                exp = np.array([int(v) % int(q[m]) for v in acc[:, m].reshape(-1)], dtype=np.uint64).reshape(2, n)
+                assert np.array_equal(got[:, m], exp), (i, j, f, m)
+    E.close()
