@@ -50,6 +50,12 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: the HIP extension has not been built (no CPU fallback exists)")
+    try:
+        # torch ships its own libamdhip64: load it first so that this library binds to the same HIP runtime (two runtimes in one
+        # process cannot both own the device: whichever initialises second sees "no HIP GPUs")
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     missing = [s for s in header_symbols() if not hasattr(L, s)]
     if missing:
