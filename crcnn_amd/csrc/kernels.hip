@@ -325,6 +325,7 @@ struct MacArgs {
     const unsigned *toffw;                   // term -> element offset toff*2kn, padded by 8 entries (mac2)
     int n, k, B, P, F, T, in_cts;            // P output pixels per image, in_cts input cts per image
     const u64 *bias; int bias_sign;          // optional NTT-form delta bias [F][k][n] added to poly 0
+    int mt_fastest;                          // tile walk order (see the kernels)
     int dbg;                                 // tuning only: 1 = skip operand staging (timing of the bare MAC loop), 2 = skip barriers too
     const u64 *zero;                         // >= 1 KiB of zeros (mac3: source of the terms past T)
     int gxd, gyd, gxf, gyf;                  // window geometry: toff[t] = (z*gxd + kx)*gyd + ky for t = (z*gxf + kx)*gyf + ky
@@ -463,7 +464,9 @@ __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_
     int g = blockIdx.x, sb, tile;
     if ((sbt & 7) == 0) { const int xcd = g & 7, r = g >> 3, per = sbt >> 3; sb = xcd * per + r / (mtiles * ftiles); tile = r % (mtiles * ftiles); }
     else { sb = g / (mtiles * ftiles); tile = g % (mtiles * ftiles); }
-    const int ft = tile % ftiles, mt = tile / ftiles;
+    // walk order inside a slot block: filter tiles fastest (neighbouring workgroups share the pixel tile's x rows) or, for layers with
+    // few pixel tiles (dense), pixel tiles fastest (neighbours share the filter tile's weight rows, which are then read from HBM once)
+    const int ft = a.mt_fastest ? tile / mtiles : tile % ftiles, mt = a.mt_fastest ? tile % mtiles : tile / ftiles;
     const int i = sb / (n >> 6), s = ((sb % (n >> 6)) << 6) + lane;
     const int m0 = mt * MT, f0 = ft * FW;
     const size_t rown = (size_t)i * n + s, kn = (size_t)k * n, ctw = 2 * kn;
@@ -644,7 +647,9 @@ __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_
     int g = blockIdx.x, sb, tile;
     if ((sbt & 7) == 0) { const int xcd = g & 7, r = g >> 3, per = sbt >> 3; sb = xcd * per + r / (mtiles * ftiles); tile = r % (mtiles * ftiles); }
     else { sb = g / (mtiles * ftiles); tile = g % (mtiles * ftiles); }
-    const int ft = tile % ftiles, mt = tile / ftiles;
+    // walk order inside a slot block: filter tiles fastest (neighbouring workgroups share the pixel tile's x rows) or, for layers with
+    // few pixel tiles (dense), pixel tiles fastest (neighbours share the filter tile's weight rows, which are then read from HBM once)
+    const int ft = a.mt_fastest ? tile / mtiles : tile % ftiles, mt = a.mt_fastest ? tile % mtiles : tile / ftiles;
     const int i = sb / (n >> 6), s = ((sb % (n >> 6)) << 6) + lane;
     const int m0 = mt * MT, f0 = ft * FW;
     const size_t rown = (size_t)i * n + s, kn = (size_t)k * n, ctw = 2 * kn;
@@ -840,6 +845,9 @@ int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, co
         pick = padded(12, 8) * 100 < padded(6, 16) * 98 ? 8 : 16;
     }
     a.zero = c->d_zero;
+    { static const int ord = [] { const char *e = getenv("CRC_MAC_ORDER"); return e ? atoi(e) : -1; }();
+      const long long mtl = ((long long)B * P + 5) / 6;
+      a.mt_fastest = ord >= 0 ? ord : (mtl <= 16); }
     // default: LDS-DMA staging with 4-step stages; the register-staged mac2_kernel remains for reductions whose term table does not
     // fit beside the two stage buffers (T > ~7000) and as the tuning reference (CRC_MAC_REGSTAGE=1, CRC_MAC2_CFG)
     static const int regstage = [] { const char *e = getenv("CRC_MAC_REGSTAGE"); return e ? atoi(e) : 0; }();
