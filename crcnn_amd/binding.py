@@ -20,7 +20,7 @@ VP = ctypes.c_void_p
 CI = ctypes.c_int
 SZ = ctypes.c_size_t
 
-COEFF, NTT = 0, 1
+COEFF, NTT, NTTP = 0, 1, 2
 
 
 class CrcError(RuntimeError):
@@ -102,6 +102,9 @@ def load():
     L.crc_square_relin_work_bytes.restype = SZ; L.crc_square_relin_work_bytes.argtypes = [VP, SZ, CI]
     L.crc_square_relin.argtypes = [VP, VP, SZ, VP, CI, VP, VP, VP]
     L.crc_square_relin_forms.argtypes = [VP, VP, CI, SZ, VP, CI, VP, CI, VP, VP]
+    L.crc_conv2d_forms.argtypes = [VP, VP, VP, CI, VP] + [CI] * 9 + [CI, CI, VP, VP, VP]
+    L.crc_dense_forms.argtypes = [VP, VP, VP, CI, VP, CI, CI, CI, CI, CI, VP, VP, VP]
+    L.crc_pack28.argtypes = [VP, VP, SZ, CI, VP]
     L.crc_square.argtypes = [VP, VP, SZ, VP, VP, VP]
     L.crc_relinearize.argtypes = [VP, VP, SZ, VP, CI, VP, VP, VP]
     L.crc_import_seal.argtypes = [VP, PU, CI, PU]
@@ -315,9 +318,16 @@ class Engine:
     def conv2d_work_bytes(self, B, zd, xd, yd, xs, ys, xf, yf, nf, in_form):
         return self.L.crc_conv2d_work_bytes(self.c, B, zd, xd, yd, xs, ys, xf, yf, nf, in_form)
 
-    def conv2d(self, d_x, d_w, d_bias, B, zd, xd, yd, xs, ys, xf, yf, nf, in_form, out_form, d_y, d_work):
-        _chk(self.L.crc_conv2d(self.c, self.p(d_x), self.p(d_w), self.p(d_bias), B, zd, xd, yd, xs, ys, xf, yf, nf, in_form, out_form,
-                               self.p(d_y), self.p(d_work), self.stream), "crc_conv2d")
+    def conv2d(self, d_x, d_w, d_bias, B, zd, xd, yd, xs, ys, xf, yf, nf, in_form, out_form, d_y, d_work, w_form=NTT):
+        if w_form == NTT and in_form != NTTP and out_form != NTTP:
+            _chk(self.L.crc_conv2d(self.c, self.p(d_x), self.p(d_w), self.p(d_bias), B, zd, xd, yd, xs, ys, xf, yf, nf, in_form, out_form,
+                                   self.p(d_y), self.p(d_work), self.stream), "crc_conv2d")
+        else:
+            _chk(self.L.crc_conv2d_forms(self.c, self.p(d_x), self.p(d_w), w_form, self.p(d_bias), B, zd, xd, yd, xs, ys, xf, yf, nf, in_form, out_form,
+                                         self.p(d_y), self.p(d_work), self.stream), "crc_conv2d_forms")
+
+    def pack28(self, d_rows, rows, unpack=False):
+        _chk(self.L.crc_pack28(self.c, self.p(d_rows), rows, 1 if unpack else 0, self.stream), "crc_pack28")
 
     def conv2d_fold_pool(self, d_w, d_bias_ntt, d_div_ntt, nf, zd, xf, yf, cxs, cys, pxf, pyf, d_w_out, d_bias_out):
         _chk(self.L.crc_conv2d_fold_pool(self.c, self.p(d_w), self.p(d_bias_ntt), self.p(d_div_ntt), nf, zd, xf, yf, cxs, cys, pxf, pyf,
@@ -326,9 +336,13 @@ class Engine:
     def dense_work_bytes(self, B, in_dim, out_dim, in_form):
         return self.L.crc_dense_work_bytes(self.c, B, in_dim, out_dim, in_form)
 
-    def dense(self, d_x, d_w, d_bias, B, in_dim, out_dim, in_form, out_form, d_y, d_work):
-        _chk(self.L.crc_dense(self.c, self.p(d_x), self.p(d_w), self.p(d_bias), B, in_dim, out_dim, in_form, out_form, self.p(d_y), self.p(d_work),
-                              self.stream), "crc_dense")
+    def dense(self, d_x, d_w, d_bias, B, in_dim, out_dim, in_form, out_form, d_y, d_work, w_form=NTT):
+        if w_form == NTT and in_form != NTTP and out_form != NTTP:
+            _chk(self.L.crc_dense(self.c, self.p(d_x), self.p(d_w), self.p(d_bias), B, in_dim, out_dim, in_form, out_form, self.p(d_y), self.p(d_work),
+                                  self.stream), "crc_dense")
+        else:
+            _chk(self.L.crc_dense_forms(self.c, self.p(d_x), self.p(d_w), w_form, self.p(d_bias), B, in_dim, out_dim, in_form, out_form, self.p(d_y),
+                                        self.p(d_work), self.stream), "crc_dense_forms")
 
     def pool(self, d_x, B, zd, xd, yd, xs, ys, xf, yf, d_div, form, d_y):
         _chk(self.L.crc_pool(self.c, self.p(d_x), B, zd, xd, yd, xs, ys, xf, yf, self.p(d_div), form, self.p(d_y), self.stream), "crc_pool")

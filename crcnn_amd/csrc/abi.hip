@@ -84,11 +84,13 @@ extern "C" size_t crc_conv2d_work_bytes(const crc_ctx *c, int B, int zd, int xd,
     return b + 256;
 }
 
-extern "C" int crc_conv2d(crc_ctx *c, const uint64_t *d_x, const uint64_t *d_w, const uint64_t *d_bias, int B, int zd, int xd, int yd,
-                          int xs, int ys, int xf, int yf, int nf, int in_form, int out_form, uint64_t *d_y, void *d_work, void *stream)
+static inline bool nform_ok(int f) { return f == CRC_COEFF || f == CRC_NTT || f == CRC_NTTP; }
+extern "C" int crc_conv2d_forms(crc_ctx *c, const uint64_t *d_x, const uint64_t *d_w, int w_form, const uint64_t *d_bias, int B, int zd, int xd, int yd,
+                                int xs, int ys, int xf, int yf, int nf, int in_form, int out_form, uint64_t *d_y, void *d_work, void *stream)
 {
     CHECK_CTX(c);
-    if (!d_x || !d_w || !d_y || !d_work || B < 0 || zd < 1 || nf < 1 || !form_ok(in_form) || !form_ok(out_form)) return CRC_ERR_INVALID_ARGUMENT;
+    if (!d_x || !d_w || !d_y || !d_work || B < 0 || zd < 1 || nf < 1 || !nform_ok(in_form) || !nform_ok(out_form) || (w_form != CRC_NTT && w_form != CRC_NTTP))
+        return CRC_ERR_INVALID_ARGUMENT;
     if (!conv_shape_ok(xd, yd, xs, ys, xf, yf)) return CRC_ERR_INVALID_ARGUMENT;
     if (B == 0) return CRC_OK;
     const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys + 1, P = xo * yo, T = zd * xf * yf, in_cts = zd * xd * yd;
@@ -99,16 +101,35 @@ extern "C" int crc_conv2d(crc_ctx *c, const uint64_t *d_x, const uint64_t *d_w, 
     unsigned *toffw = (unsigned *)w; w += align256(sizeof(int) * ((size_t)T + 8));
     RUN(k_conv_offsets(c, xoff, toff, toffw, P, T, in_cts, xd, yd, xs, ys, xf, yf, yo, st));
     const u64 *xn = d_x;
+    int xp = in_form == CRC_NTTP;
     if (in_form == CRC_COEFF) {                   // transform_input_to_ntt, convolutionalLayer.cpp:95-148 (out of place: x is const)
         u64 *buf = (u64 *)w;
-        RUN(k_ntt_ct(c, false, d_x, buf, (size_t)B * in_cts, 2, false, st, nullptr, 0, 0));
+        int maxbits = 0; for (int i = 0; i < c->k; i++) if ((int)c->tabs[i].m.bits > maxbits) maxbits = c->tabs[i].m.bits;
+        xp = maxbits <= 55;                       // the private copy goes straight into the MAC kernels' operand form
+        RUN(k_ntt_ct(c, false, d_x, buf, (size_t)B * in_cts, 2, false, st, nullptr, 0, 0, 0, xp));
         xn = buf;
     }
     // sum of products in the NTT domain; bias joins here when the output stays NTT-resident
-    RUN(k_mac2(c, xn, d_w, d_y, xoff, toff, B, P, nf, T, in_cts, out_form == CRC_NTT ? d_bias : nullptr, xd, yd, xf, yf, toffw, st));
+    RUN(k_mac2(c, xn, d_w, d_y, xoff, toff, B, P, nf, T, in_cts, out_form != CRC_COEFF ? d_bias : nullptr, xd, yd, xf, yf, toffw, st, xp, w_form == CRC_NTTP, out_form == CRC_NTTP));
     if (out_form == CRC_COEFF)                    // one inverse NTT per output ciphertext, add_plain(bias) fused into its store
         RUN(k_ntt_ct(c, true, d_y, d_y, (size_t)B * nf * P, 2, false, st, d_bias, 1, (size_t)P, nf));
     return CRC_OK;
+}
+extern "C" int crc_conv2d(crc_ctx *c, const uint64_t *d_x, const uint64_t *d_w, const uint64_t *d_bias, int B, int zd, int xd, int yd,
+                          int xs, int ys, int xf, int yf, int nf, int in_form, int out_form, uint64_t *d_y, void *d_work, void *stream)
+{
+    if (!form_ok(in_form) || !form_ok(out_form)) return CRC_ERR_INVALID_ARGUMENT;
+    return crc_conv2d_forms(c, d_x, d_w, CRC_NTT, d_bias, B, zd, xd, yd, xs, ys, xf, yf, nf, in_form, out_form, d_y, d_work, stream);
+}
+extern "C" int crc_dense_forms(crc_ctx *c, const uint64_t *d_x, const uint64_t *d_w, int w_form, const uint64_t *d_bias, int B, int in_dim, int out_dim,
+                               int in_form, int out_form, uint64_t *d_y, void *d_work, void *stream)
+{
+    return crc_conv2d_forms(c, d_x, d_w, w_form, d_bias, B, in_dim, 1, 1, 1, 1, 1, 1, out_dim, in_form, out_form, d_y, d_work, stream);
+}
+extern "C" int crc_pack28(crc_ctx *c, uint64_t *d_rows, size_t rows, int unpack, void *stream)
+{
+    CHECK_CTX(c); if (!d_rows) return CRC_ERR_INVALID_ARGUMENT;
+    return k_pack28(c, d_rows, rows, unpack != 0, S(stream));
 }
 
 extern "C" size_t crc_dense_work_bytes(const crc_ctx *c, int B, int in_dim, int out_dim, int in_form)

@@ -3,7 +3,7 @@
 #include "ctx.h"
 
 int k_ntt_ct(crc_ctx *c, bool inv, const u64 *src, u64 *dst, size_t count, int size, bool bsk, hipStream_t st,
-             const u64 *addend, int add_sign, size_t add_group, int add_mod = 0);
+             const u64 *addend, int add_sign, size_t add_group, int add_mod = 0, int pack_out = 0);
 int k_ntt_ct_addct(crc_ctx *c, const u64 *src, u64 *dst, size_t count, const u64 *addct, int add_size, hipStream_t st);
 int k_ntt_ct_head_add(crc_ctx *c, const u64 *src, int src_size, u64 *dst, size_t count, const u64 *addrows, hipStream_t st);
 int k_spread_ntt(crc_ctx *c, const u64 *src, size_t items, u64 *dst, hipStream_t st);
@@ -12,14 +12,15 @@ int k_rowwise(crc_ctx *c, u64 *acc, const u64 *b, size_t count, int size, int op
 int k_pool(crc_ctx *c, const u64 *x, u64 *y, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, const u64 *mul, hipStream_t st);
 int k_bn_ntt(crc_ctx *c, u64 *x, int B, int zd, int hw, const u64 *mean, const u64 *invstd, hipStream_t st);
 int k_mac(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, const int *d_toff, int B, int P, int F, int T, int in_cts,
-          const u64 *bias_ntt, hipStream_t st);
+          const u64 *bias_ntt, hipStream_t st, int xp = 0, int wp = 0, int yp = 0);
+int k_pack28(crc_ctx *c, u64 *rows, size_t nrows, bool unpack, hipStream_t st);
 int k_conv_offsets(crc_ctx *c, int *xoff, int *toff, unsigned *toffw, int P, int T, int in_cts, int xd, int yd, int xs, int ys, int xf, int yf, int yo, hipStream_t st);
 size_t k_square_work_words(const crc_ctx *c, size_t cnt);
 size_t k_relin_work_words(const crc_ctx *c, size_t cnt, int dbc);
 int k_square(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStream_t st, bool in_ntt = false);
 int k_relinearize(crc_ctx *c, const u64 *x3, size_t cnt, const u64 *evk, int dbc, u64 *y, u64 *work, hipStream_t st, bool out_ntt = false);
 int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, const int *d_toff, int B, int P, int F, int T, int in_cts,
-           const u64 *bias_ntt, int gxd, int gyd, int gxf, int gyf, const unsigned *d_toffw, hipStream_t st);
+           const u64 *bias_ntt, int gxd, int gyd, int gxf, int gyf, const unsigned *d_toffw, hipStream_t st, int xp = 0, int wp = 0, int yp = 0);
 int k_fold_pool(crc_ctx *c, const u64 *w, const u64 *bias, const u64 *div, u64 *wout, u64 *bout, int nf, int zd, int xf, int yf, int cxs, int cys,
                 int pxf, int pyf, hipStream_t st);
 size_t k_encrypt_work_words(const crc_ctx *c, size_t cnt);

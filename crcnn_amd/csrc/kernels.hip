@@ -21,6 +21,7 @@ struct NttArgs {
     int n, logn;
     int mod_base, mod_count;                                   // row r -> modulus index mod_base + r % mod_count
     int src_rows_per_item;                                     // 0: src row = dst row;  >0: plain prologue, src row = r / mod_count
+    int pack_out;                                              // forward only: store the result as 28-bit limb pairs (operand form of the MAC kernels)
     int src_ct_rows, dst_ct_rows;                              // both > 0: dst row r = (ct, j < dst_ct_rows) reads src row ct*src_ct_rows + j (leading polys of wider cts)
     int prologue;                                              // 0 none, 1 plain lift, 2 delta scale
     const u64 *addend; int add_sign; int rows_per_ct; long long add_group;   // epilogue (inverse only)
@@ -30,6 +31,7 @@ struct NttArgs {
 };
 
 #include "ntt_device.h"  // lpad, shoup_lazy4, reduce_small, fwd_stages / inv_stages, ntt_pass
+__device__ __forceinline__ u64 split28v(u64 v) { return (v & 0x0fffffffULL) | ((v >> 28) << 32); }      // = split28 further down
 
 template <bool INV, bool LAZY>
 __global__ void __launch_bounds__(1024) ntt_rows_kernel(NttArgs a)
@@ -72,7 +74,7 @@ __global__ void __launch_bounds__(1024) ntt_rows_kernel(NttArgs a)
             if (LAZY) v = reduce_small(v, q, q2, rq);
             else { v = v >= q2 ? v - q2 : v; v = v >= q ? v - q : v; }
             if (add) v = addmod(v, add[s], q);
-            dst[s] = v;
+            dst[s] = a.pack_out ? split28v(v) : v;
         }
     } else {
         // gaps 1, 2, 4, ...
@@ -115,9 +117,10 @@ static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t
 }
 
 int k_ntt_ct(crc_ctx *c, bool inv, const u64 *src, u64 *dst, size_t count, int size, bool bsk, hipStream_t st,
-             const u64 *addend, int add_sign, size_t add_group, int add_mod)
+             const u64 *addend, int add_sign, size_t add_group, int add_mod, int pack_out)
 {
     NttArgs a{};
+    a.pack_out = inv ? 0 : pack_out;
     a.src = src; a.dst = dst;
     a.mod_base = bsk ? c->k : 0; a.mod_count = bsk ? c->kb : c->k;
     a.addend = addend; a.add_sign = add_sign; a.rows_per_ct = size * a.mod_count; a.add_group = (long long)(add_group ? add_group : 1);
@@ -214,6 +217,28 @@ __global__ void __launch_bounds__(256) rowwise_kernel(u64 *acc, const u64 *b, co
         else { xv.x = mulmod(xv.x, yv.x, m); xv.y = mulmod(xv.y, yv.y, m); }
         *reinterpret_cast<ulonglong2 *>(x + s) = xv;
     }
+}
+
+// in-place conversion of NTT-form rows between canonical residues and 28-bit limb pairs
+__global__ void __launch_bounds__(256) pack28_kernel(u64 *rows, size_t words, int unpack)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 2;             // grid-stride: weight tensors exceed 2^32 threads' worth of words
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < words; i += stride) {
+        ulonglong2 v = *reinterpret_cast<ulonglong2 *>(rows + i);
+        if (unpack) { v.x = (v.x & 0xffffffffULL) | ((v.x >> 32) << 28); v.y = (v.y & 0xffffffffULL) | ((v.y >> 32) << 28); }
+        else { v.x = (v.x & 0x0fffffffULL) | ((v.x >> 28) << 32); v.y = (v.y & 0x0fffffffULL) | ((v.y >> 28) << 32); }
+        *reinterpret_cast<ulonglong2 *>(rows + i) = v;
+    }
+}
+int k_pack28(crc_ctx *c, u64 *rows, size_t nrows, bool unpack, hipStream_t st)
+{
+    if (nrows == 0) return CRC_OK;
+    for (int i = 0; i < c->k; i++) if (c->tabs[i].m.bits > 56) return CRC_ERR_UNSUPPORTED;
+    const size_t words = nrows * (size_t)c->n;
+    size_t blocks = (words / 2 + 255) / 256; if (blocks > (1u << 20)) blocks = 1u << 20;
+    hipLaunchKernelGGL(pack28_kernel, dim3((unsigned)blocks), dim3(256), 0, st, rows, words, unpack ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    return CRC_OK;
 }
 
 int k_rowwise(crc_ctx *c, u64 *acc, const u64 *b, size_t count, int size, int op, int sign, size_t group, size_t gmod, hipStream_t st)
@@ -326,10 +351,22 @@ struct MacArgs {
     int n, k, B, P, F, T, in_cts;            // P output pixels per image, in_cts input cts per image
     const u64 *bias; int bias_sign;          // optional NTT-form delta bias [F][k][n] added to poly 0
     int mt_fastest;                          // tile walk order (see the kernels)
+    int xp, wp, yp;                          // x / w arrive packed (28-bit limb pairs), y leaves packed
     int dbg;                                 // tuning only: 1 = skip operand staging (timing of the bare MAC loop), 2 = skip barriers too
     const u64 *zero;                         // >= 1 KiB of zeros (mac3: source of the terms past T)
     int gxd, gyd, gxf, gyf;                  // window geometry: toff[t] = (z*gxd + kx)*gyd + ky for t = (z*gxf + kx)*gyf + ky
 };
+
+// x (< 2^56) -> {low dword = x & (2^28-1), high dword = x >> 28}: two 32-bit VALU ops (64-bit shifts are slow on gfx950)
+__device__ __forceinline__ u64 split28(u64 r)
+{
+    const u32 lo = (u32)r, hi = (u32)(r >> 32);
+    const u32 x0 = lo & 0x0fffffffu, x1 = __builtin_amdgcn_alignbit(hi, lo, 28);
+    return (u64)x0 | ((u64)x1 << 32);
+}
+// inverse: the canonical residue of a packed value.  "Packed" (CRC_NTTP) is how the MAC kernels want their operands: weights and the
+// NTT-resident tensors that travel from one conv / dense layer to the next are kept in this form so that nobody has to split them again
+__device__ __forceinline__ u64 unsplit28(u64 p) { return (p & 0xffffffffULL) | ((p >> 32) << 28); }
 
 template <int PT, int FT>
 __global__ void __launch_bounds__(256) mac_kernel(MacArgs a)
@@ -367,9 +404,9 @@ __global__ void __launch_bounds__(256) mac_kernel(MacArgs a)
         const size_t to = (size_t)a.toff[t] * ctw;
         u64 xv[PT][2], wv[FT];
 #pragma unroll
-        for (int pp = 0; pp < PT; pp++) { xv[pp][0] = xb[pp][to]; xv[pp][1] = xb[pp][to + (size_t)k * n]; }
+        for (int pp = 0; pp < PT; pp++) { xv[pp][0] = xb[pp][to]; xv[pp][1] = xb[pp][to + (size_t)k * n]; if (a.xp) { xv[pp][0] = unsplit28(xv[pp][0]); xv[pp][1] = unsplit28(xv[pp][1]); } }
 #pragma unroll
-        for (int ff = 0; ff < FT; ff++) wv[ff] = (f0 + ff < a.F) ? wb[ff * wstride_f + t * wstride_t] : 0;
+        for (int ff = 0; ff < FT; ff++) { wv[ff] = (f0 + ff < a.F) ? wb[ff * wstride_f + t * wstride_t] : 0; if (a.wp) wv[ff] = unsplit28(wv[ff]); }
 #pragma unroll
         for (int pp = 0; pp < PT; pp++)
 #pragma unroll
@@ -395,14 +432,14 @@ __global__ void __launch_bounds__(256) mac_kernel(MacArgs a)
             for (int c = 0; c < 2; c++) {
                 u64 v = barrett128(lo[pp][c][ff], hi[pp][c][ff], m);
                 if (c == 0 && a.bias) { const u64 bv = a.bias[(size_t)f * k * n + rown]; v = a.bias_sign > 0 ? addmod(v, bv, m.q) : submod(v, bv, m.q); }
-                dst[(size_t)c * k * n] = v;
+                dst[(size_t)c * k * n] = a.yp ? split28(v) : v;
             }
         }
     }
 }
 
 int k_mac(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, const int *d_toff, int B, int P, int F, int T, int in_cts,
-          const u64 *bias_ntt, hipStream_t st)
+          const u64 *bias_ntt, hipStream_t st, int xp, int wp, int yp)
 {
     if (B == 0 || P == 0 || F == 0) return CRC_OK;
     // 128-bit lazy accumulation bound: T * q^2 < 2^128
@@ -411,7 +448,7 @@ int k_mac(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, con
     if (2 * maxbits + tb > 127) return CRC_ERR_UNSUPPORTED;
     MacArgs a{};
     a.x = x; a.w = w; a.y = y; a.mods = c->d_mods; a.xoff = d_xoff; a.toff = d_toff;
-    a.n = c->n; a.k = c->k; a.B = B; a.P = P; a.F = F; a.T = T; a.in_cts = in_cts; a.bias = bias_ntt; a.bias_sign = 1;
+    a.n = c->n; a.k = c->k; a.B = B; a.P = P; a.F = F; a.T = T; a.in_cts = in_cts; a.bias = bias_ntt; a.bias_sign = 1; a.xp = xp; a.wp = wp; a.yp = yp;
     const int threads = c->n < 256 ? c->n : 256;
     constexpr int PT = 2, FT = 4;
     const size_t gx = (size_t)(c->n / threads * c->k) * B * ((P + PT - 1) / PT);
@@ -440,13 +477,6 @@ int k_mac(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, con
 // Workgroups are numbered so that the 32 CUs of an XCD work on the same slot block and neighbouring tiles at the same
 // time: their shared operands are served by that XCD's L2 instead of HBM.
 // ---------------------------------------------------------------------------------------------------------------
-// x (< 2^56) -> {low dword = x & (2^28-1), high dword = x >> 28}: two 32-bit VALU ops (64-bit shifts are slow on gfx950)
-__device__ __forceinline__ u64 split28(u64 r)
-{
-    const u32 lo = (u32)r, hi = (u32)(r >> 32);
-    const u32 x0 = lo & 0x0fffffffu, x1 = __builtin_amdgcn_alignbit(hi, lo, 28);
-    return (u64)x0 | ((u64)x1 << 32);
-}
 
 template <int PX, int FT, int WM, int WN, int S, int DEPTH = 2>
 __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2))) mac2_kernel(MacArgs a)
@@ -521,7 +551,9 @@ __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_
         const int pr = wave + jj * NW;
         const bool dead = !visx[2 * jj] && st * S + vstep[2 * jj] >= a.T;                 // weights past the last term are zero (x may be anything valid)
         ulonglong2 v;
-        v.x = split28(dead ? 0 : reg[jj].x); v.y = split28(dead ? 0 : reg[jj].y);        // pre-split once: low dword = x0 (28 bit), high dword = x1
+        const bool packed = visx[2 * jj] ? a.xp : a.wp;                                  // operands that arrive packed are already split
+        v.x = dead ? 0 : reg[jj].x; v.y = dead ? 0 : reg[jj].y;
+        if (!packed) { v.x = split28(v.x); v.y = split28(v.y); }                          // pre-split once: low dword = x0 (28 bit), high dword = x1
         if (pr < NPAIR) *reinterpret_cast<ulonglong2 *>(dst + (2 * pr + half) * 64 + l2) = v;     // one ds_write_b128: two adjacent slots of one vector
     };
     auto load_stage = [&](int st, ulonglong2 (&reg)[RLOAD / 2]) {
@@ -621,7 +653,7 @@ __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_
             nl = vl + tl; vh += th + (nl < vl); vl = nl;
             u64 v = barrett128(vl, vh, m);
             if (c == 0 && a.bias) { const u64 bv = a.bias[(size_t)ff * kn + rown]; v = addmod(v, bv, m.q); }
-            a.y[(((size_t)b * a.F + ff) * a.P + p) * ctw + (size_t)c * kn + rown] = v;
+            a.y[(((size_t)b * a.F + ff) * a.P + p) * ctw + (size_t)c * kn + rown] = a.yp ? split28(v) : v;
         }
     }
 }
@@ -631,7 +663,7 @@ __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_
 // pay for longer stages: S = 4 reduction steps per stage in two LDS buffers (115-128 KiB), i.e. half the barriers per MAC, with the
 // loads of stage st+1 in flight during stage st.  A wave waits for its own loads (s_waitcnt vmcnt(0)) before the one barrier per
 // stage.  Terms past T read a row of zeros.  Same arithmetic, same output as mac2_kernel; +7 % on the large layers.
-template <int PX, int FT, int WM, int WN, int S>
+template <int PX, int FT, int WM, int WN, int S, bool XP, bool WP>
 __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2))) mac3_kernel(MacArgs a)
 {
     constexpr int NW = WM * WN, MT = PX * WM, ROWS = 2 * MT, FW = FT * WN;
@@ -722,10 +754,10 @@ __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_
             const u64 *sv = buf + step * (ROWS + FW) * 64 + lane;
             u32 w0[FT], w1[FT], ws[FT];
 #pragma unroll
-            for (int f = 0; f < FT; f++) { const u64 wv = split28(sv[(ROWS + wn * FT + f) * 64]); w0[f] = (u32)wv; w1[f] = (u32)(wv >> 32); ws[f] = w0[f] + w1[f]; }
+            for (int f = 0; f < FT; f++) { const u64 wr = sv[(ROWS + wn * FT + f) * 64]; const u64 wv = WP ? wr : split28(wr); w0[f] = (u32)wv; w1[f] = (u32)(wv >> 32); ws[f] = w0[f] + w1[f]; }
 #pragma unroll
             for (int r = 0; r < PX * 2; r++) {
-                const u64 xv = split28(sv[(wm * PX * 2 + r) * 64]);
+                const u64 xr = sv[(wm * PX * 2 + r) * 64]; const u64 xv = XP ? xr : split28(xr);
                 const u32 x0 = (u32)xv, x1 = (u32)(xv >> 32), xs = x0 + x1;
 #pragma unroll
                 for (int f = 0; f < FT; f++) {
@@ -782,12 +814,12 @@ __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_
             nl = vl + tl; vh += th + (nl < vl); vl = nl;
             u64 v = barrett128(vl, vh, m);
             if (c == 0 && a.bias) { const u64 bv = a.bias[(size_t)ff * kn + rown]; v = addmod(v, bv, m.q); }
-            a.y[(((size_t)b * a.F + ff) * a.P + p) * ctw + (size_t)c * kn + rown] = v;
+            a.y[(((size_t)b * a.F + ff) * a.P + p) * ctw + (size_t)c * kn + rown] = a.yp ? split28(v) : v;
         }
     }
 }
 
-template <int PX, int FT, int WM, int WN, int S>
+template <int PX, int FT, int WM, int WN, int S, bool XP, bool WP>
 static int mac3_launch(crc_ctx *c, MacArgs &a, hipStream_t st)
 {
     constexpr int MT = PX * WM, FW = FT * WN, VEC = S * (2 * MT + FW);
@@ -797,7 +829,7 @@ static int mac3_launch(crc_ctx *c, MacArgs &a, hipStream_t st)
     if (a.T + 8 > 16384) return CRC_ERR_UNSUPPORTED;
     const size_t lds = (size_t)2 * VEC * 64 * 8 + (size_t)((a.T + 8 + 3) / 4) * 16 + 1024;
     if (lds > 160 * 1024) return CRC_ERR_UNSUPPORTED;
-    auto kern = mac3_kernel<PX, FT, WM, WN, S>;
+    auto kern = mac3_kernel<PX, FT, WM, WN, S, XP, WP>;
     if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WM * WN), lds, st, a);
     HIPCHK(hipGetLastError());
@@ -821,18 +853,18 @@ static int mac2_launch(crc_ctx *c, MacArgs &a, hipStream_t st)
 }
 
 int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, const int *d_toff, int B, int P, int F, int T, int in_cts,
-           const u64 *bias_ntt, int gxd, int gyd, int gxf, int gyf, const unsigned *d_toffw, hipStream_t st)
+           const u64 *bias_ntt, int gxd, int gyd, int gxf, int gyf, const unsigned *d_toffw, hipStream_t st, int xp, int wp, int yp)
 {
     if (B == 0 || P == 0 || F == 0) return CRC_OK;
     int maxbits = 0; for (int i = 0; i < c->k; i++) if ((int)c->tabs[i].m.bits > maxbits) maxbits = c->tabs[i].m.bits;
     // operands are addressed as wave-uniform base + 32-bit ELEMENT offset (term offset + half-wave pair offset + slot), widened to bytes per lane
     const size_t kn1 = (size_t)c->k * c->n;
     const bool off32 = ((size_t)2 * T + 3) * kn1 < (1ull << 32) && ((size_t)2 * in_cts + 3) * kn1 < (1ull << 32);
-    if (maxbits > 55 || T > 16000 || c->n < 64 || !off32) return k_mac(c, x, w, y, d_xoff, d_toff, B, P, F, T, in_cts, bias_ntt, st);
+    if (maxbits > 55 || T > 16000 || c->n < 64 || !off32) return k_mac(c, x, w, y, d_xoff, d_toff, B, P, F, T, in_cts, bias_ntt, st, xp, wp, yp);
     MacArgs a{};
     a.x = x; a.w = w; a.y = y; a.mods = c->d_mods; a.xoff = d_xoff; a.toff = d_toff; a.toffw = d_toffw;
     a.n = c->n; a.k = c->k; a.B = B; a.P = P; a.F = F; a.T = T; a.in_cts = in_cts; a.bias = bias_ntt; a.bias_sign = 1;
-    a.gxd = gxd; a.gyd = gyd; a.gxf = gxf; a.gyf = gyf;
+    a.gxd = gxd; a.gyd = gyd; a.gxf = gxf; a.gyf = gyf; a.xp = xp; a.wp = wp; a.yp = yp;
     { static const int dbg = [] { const char *e = getenv("CRC_MAC2_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
     // tile configuration <PX, FT, WM, WN, S>: a workgroup covers PX*WM pixels x FT*WN filters (6 x 16 or 12 x 8), 24 accumulators
     // per wave either way; pick the shape that wastes fewer multiply-adds on filter/pixel padding (F = 50 -> 56 instead of 64,
@@ -854,7 +886,10 @@ int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, co
     // short reductions that are not a multiple of 4 lose more to the padded last stage than LDS-DMA gains (T = 25: 28 steps instead of 26)
     const bool short_odd = ((T + 3) / 4 * 4 - (T + 1) / 2 * 2) * 20 > T;
     if (!regstage && !cfg && !short_odd) {
-        const int rc = pick == 8 ? mac3_launch<3, 4, 4, 2, 4>(c, a, st) : mac3_launch<3, 4, 2, 4, 4>(c, a, st);
+        int rc;
+#define MAC3_GO(XPV, WPV) (pick == 8 ? mac3_launch<3, 4, 4, 2, 4, XPV, WPV>(c, a, st) : mac3_launch<3, 4, 2, 4, 4, XPV, WPV>(c, a, st))
+        if (a.xp && a.wp) rc = MAC3_GO(true, true); else if (a.xp) rc = MAC3_GO(true, false); else if (a.wp) rc = MAC3_GO(false, true); else rc = MAC3_GO(false, false);
+#undef MAC3_GO
         if (rc != CRC_ERR_UNSUPPORTED) return rc;
     }
     switch (pick) {

@@ -104,13 +104,38 @@ class Network:
             shape = nshape
         self.out_shape = shape
         self.out_form = form
+        self._packed = False
         if self.fuse_pool:
             self.fuse()
+
+    # ---- operand form of the MAC kernels (CRC_NTTP: 28-bit limb pairs): weights are packed once, and a conv / dense layer that feeds
+    # another one hands its output over packed, so that no kernel has to split a residue again (+12 % on the conv / dense layers)
+    def _pack_operands(self, unpack=False):
+        """called by prepare() (pack) and by fuse() (unpack: the folding kernels work on canonical residues)"""
+        E = self.E
+        if max(int(q).bit_length() for q in E.q) > 55 or self._packed == (not unpack):
+            return
+        for idx, (kind, name, a, p, ishape, oshape) in enumerate(self.plan):
+            if kind not in ("conv", "fc"):
+                continue
+            rows = (a["nf"] * a["zd"] * a["xf"] * a["yf"] if kind == "conv" else a["in_dim"] * a["out_dim"]) * E.k
+            E.pack28(p["w"], rows, unpack=unpack)
+            p["w_form"] = NTT if unpack else binding.NTTP
+            nxt = self.plan[idx + 1] if idx + 1 < len(self.plan) else None
+            if nxt and nxt[0] in ("conv", "fc"):
+                if not unpack and p["out_form"] == NTT and nxt[3]["in_form"] == NTT:
+                    p["out_form"] = nxt[3]["in_form"] = binding.NTTP
+                elif unpack and p["out_form"] == binding.NTTP:
+                    p["out_form"] = nxt[3]["in_form"] = NTT
+        E.sync()
+        self._packed = not unpack
 
     # ---- conv + pool fusion (crc_conv2d_fold_pool)
     def fuse(self):
         """fold pooling layers into the convolutions in front of them (exact); call prepare() again afterwards"""
         E = self.E
+        if self.materialize:
+            self._pack_operands(unpack=True)
         plan, i = [], 0
         while i < len(self.plan):
             kind, name, a, p, ishape, oshape = self.plan[i]
@@ -263,7 +288,9 @@ class Network:
         return slots
 
     def prepare(self, B):
-        """allocate the two ping-pong activation buffers and the work space for chunks of B images"""
+        """allocate the two ping-pong activation buffers and the work space for chunks of B images; put the MAC operands into packed form"""
+        if self.materialize:
+            self._pack_operands()
         acts = self.activation_cts()
         self.B = B
         self.slots = self._slots()
@@ -286,10 +313,11 @@ class Network:
             if timer:
                 timer(i, name, kind, 0)
             if kind == "conv":
-                E.conv2d(cur, p["w"], p["b"], B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"], p["in_form"], p["out_form"], out, self.work)
+                E.conv2d(cur, p["w"], p["b"], B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"], p["in_form"], p["out_form"], out, self.work,
+                         w_form=p.get("w_form", NTT))
                 cur = out
             elif kind == "fc":
-                E.dense(cur, p["w"], p["b"], B, a["in_dim"], a["out_dim"], p["in_form"], p["out_form"], out, self.work)
+                E.dense(cur, p["w"], p["b"], B, a["in_dim"], a["out_dim"], p["in_form"], p["out_form"], out, self.work, w_form=p.get("w_form", NTT))
                 cur = out
             elif kind in ("pool", "avgpool"):
                 E.pool(cur, B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], p["div"], p["form"], out)

@@ -44,7 +44,12 @@ typedef enum {
     CRC_ERR_NOT_FOUND = -6           /* dataset name missing in the model file */
 } crc_status;
 
-enum { CRC_COEFF = 0, CRC_NTT = 1 };
+enum { CRC_COEFF = 0, CRC_NTT = 1,
+       /* NTT form with every residue stored as its two 28-bit limbs (lo | hi << 32): the operand form of the multiply-accumulate
+        * kernels (no 64x64 multiplier on gfx950; 3 v_mad_u64_u32 per product on 28-bit limbs).  Only crc_conv2d_forms /
+        * crc_dense_forms take or produce it (weights and the tensors that travel between conv / dense layers); crc_pack28 converts.
+        * Needs coefficient moduli below 2^56. */
+       CRC_NTTP = 2 };
 
 const char *crc_strerror(int status);
 int         crc_last_hip_error(void);
@@ -157,6 +162,15 @@ int crc_conv2d(crc_ctx *ctx, const uint64_t *d_x, const uint64_t *d_w_ntt, const
  * (unobservable in NTT-resident mode) intermediate tensor disappears.  d_div_ntt = NULL for sum pooling. */
 int crc_conv2d_fold_pool(crc_ctx *ctx, const uint64_t *d_w_ntt, const uint64_t *d_bias_delta_ntt, const uint64_t *d_div_ntt, int nf, int zd, int xf, int yf,
                          int cxs, int cys, int pxf, int pyf, uint64_t *d_w_out, uint64_t *d_bias_out, void *stream);
+/* the same two layers with the packed operand form: in_form / out_form may also be CRC_NTTP, w_form says how d_w_ntt is stored
+ * (CRC_NTT canonical, CRC_NTTP packed by crc_pack28).  Same ciphertexts; nothing is re-split inside the kernels. */
+int crc_conv2d_forms(crc_ctx *ctx, const uint64_t *d_x, const uint64_t *d_w_ntt, int w_form, const uint64_t *d_bias_delta,
+                     int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf,
+                     int in_form, int out_form, uint64_t *d_y, void *d_work, void *stream);
+int crc_dense_forms(crc_ctx *ctx, const uint64_t *d_x, const uint64_t *d_w_ntt, int w_form, const uint64_t *d_bias_delta,
+                    int B, int in_dim, int out_dim, int in_form, int out_form, uint64_t *d_y, void *d_work, void *stream);
+/* in-place CRC_NTT <-> CRC_NTTP conversion of `rows` residue rows (unpack = 0: pack, 1: unpack) */
+int crc_pack28(crc_ctx *ctx, uint64_t *d_rows, size_t rows, int unpack, void *stream);
 size_t crc_dense_work_bytes(const crc_ctx *ctx, int B, int in_dim, int out_dim, int in_form);
 int crc_dense(crc_ctx *ctx, const uint64_t *d_x, const uint64_t *d_w_ntt, const uint64_t *d_bias_delta,
               int B, int in_dim, int out_dim, int in_form, int out_form, uint64_t *d_y, void *d_work, void *stream);

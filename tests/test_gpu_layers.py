@@ -277,3 +277,39 @@ def test_mac_operand_offsets_past_4GiB():
                 exp = np.array([int(v) % int(q[m]) for v in acc[:, m].reshape(-1)], dtype=np.uint64).reshape(2, n)
                 assert np.array_equal(got[:, m], exp), (i, j, f, m)
     E.close()
+
+
+def test_packed_operand_forms(gl):
+    """CRC_NTTP (28-bit limb pairs, the MAC kernels' operand form) in any position -- input, weights, output -- gives the ciphertexts
+    of the canonical NTT path; crc_pack28 round-trips"""
+    g, E, N = gl
+    ca = N.ca
+    zd, xd, yd, xs, ys, xf, yf, nf = [int(v) for v in g["dims"][:8]]
+    xo, yo = (xd - xf) // xs + 1, (yd - yf) // ys + 1
+    d_w = N.weights_ntt(g["conv_w"]); d_b = N.delta(g["conv_b"], ca.NTT)
+    B = 3
+    x = np.ascontiguousarray(np.repeat(g["x"][None], B, axis=0))
+    d_x = E.upload(x); E.ntt_fwd(d_x, B * zd * xd * yd)
+    rows_x, rows_w, rows_y = B * zd * xd * yd * 2 * E.k, nf * zd * xf * yf * E.k, B * nf * xo * yo * 2 * E.k
+    d_y = E.alloc(rows_y * E.n * 8); d_work = E.alloc(E.conv2d_work_bytes(B, zd, xd, yd, xs, ys, xf, yf, nf, ca.COEFF))
+    E.conv2d(d_x, d_w, d_b, B, zd, xd, yd, xs, ys, xf, yf, nf, ca.NTT, ca.NTT, d_y, d_work)
+    want = E.download(d_y, (rows_y, E.n))
+    xn = E.download(d_x, (rows_x, E.n)); wn = E.download(d_w, (rows_w, E.n))
+    d_xp = E.upload(xn); E.pack28(d_xp, rows_x); d_wp = E.upload(wn); E.pack28(d_wp, rows_w)
+    packed = E.download(d_xp, (rows_x, E.n))
+    assert np.array_equal(packed & np.uint64(0xffffffff), xn & np.uint64(0x0fffffff)) and np.array_equal(packed >> np.uint64(32), xn >> np.uint64(28))
+    for fin, fw, fout in [(ca.NTTP, ca.NTTP, ca.NTTP), (ca.NTT, ca.NTTP, ca.NTT), (ca.NTTP, ca.NTT, ca.NTT), (ca.NTT, ca.NTT, ca.NTTP), (ca.NTTP, ca.NTTP, ca.COEFF)]:
+        E.conv2d(d_xp if fin == ca.NTTP else d_x, d_wp if fw == ca.NTTP else d_w, d_b if fout != ca.COEFF else N.delta(g["conv_b"], ca.COEFF), B, zd, xd, yd, xs, ys, xf, yf, nf,
+                 fin, fout, d_y, d_work, w_form=fw)
+        if fout == ca.NTTP:
+            E.pack28(d_y, rows_y, unpack=True)
+        if fout == ca.COEFF:
+            E.ntt_fwd(d_y, B * nf * xo * yo)
+        assert np.array_equal(E.download(d_y, (rows_y, E.n)), want), (fin, fw, fout)
+    E.pack28(d_xp, rows_x, unpack=True)
+    assert np.array_equal(E.download(d_xp, (rows_x, E.n)), xn)
+    # coefficient-form input (the private NTT copy is written packed) still gives the reference layer's ciphertexts
+    E.conv2d(E.upload(x), d_wp, N.delta(g["conv_b"], ca.COEFF), B, zd, xd, yd, xs, ys, xf, yf, nf, ca.COEFF, ca.COEFF, d_y, d_work, w_form=ca.NTTP)
+    y = E.download(d_y, (B, nf, xo, yo, 2, E.k, E.n))
+    for b in range(B):
+        assert np.array_equal(y[b], g["ref_conv"])

@@ -31,8 +31,13 @@ in_cts, out_cts, T = a["zd"] * a["xd"] * a["yd"], a["nf"] * xo * yo, a["zd"] * a
 x = rnd(B * in_cts * 2 * k); w = rnd(a["nf"] * T * k); bias = rnd(a["nf"] * k)
 y = torch.empty((B * out_cts * 2 * k, n), dtype=torch.int64, device=dev)
 work = torch.empty(E.conv2d_work_bytes(B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"], ca.NTT) // 8 + 64, dtype=torch.int64, device=dev)
+PACKED = os.environ.get("CRC_BENCH_PACKED") == "1"       # operands and result in the packed 28-bit limb form (CRC_NTTP)
+if PACKED:
+    E.stream = torch.cuda.current_stream().cuda_stream or None
+    E.pack28(x, x.shape[0]); E.pack28(w, w.shape[0])
+F_IO = ca.NTTP if PACKED else ca.NTT
 def run():
-    E.conv2d(x, w, bias, B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"], ca.NTT, ca.NTT, y, work)
+    E.conv2d(x, w, bias, B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"], F_IO, F_IO, y, work, w_form=F_IO)
 run(); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
@@ -40,4 +45,6 @@ for _ in range(reps): run()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
 macs = B * out_cts * T
-print(f"{layer} B={B}: {ms:.2f} ms/launch  {macs * 2 * k * n / ms / 1e9:.3f} T modmul/s  ({ms / B:.3f} ms/image)  checksum {int(y.view(-1)[::100003].sum().item()) & 0xffffffff:x}")
+if PACKED:
+    E.pack28(y, y.shape[0], unpack=True); torch.cuda.synchronize()
+print(f"{layer} B={B}{' packed' if PACKED else ''}: {ms:.2f} ms/launch  {macs * 2 * k * n / ms / 1e9:.3f} T modmul/s  ({ms / B:.3f} ms/image)  checksum {int(y.view(-1)[::100003].sum().item()) & 0xffffffff:x}")
