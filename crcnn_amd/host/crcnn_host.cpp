@@ -294,6 +294,13 @@ void ConvolutionalLayer::upload()
     d_w = uploadPlain(w, 0); d_b[0] = uploadPlain(b, 1); d_b[1] = uploadPlain(b, 2);
     filters_already_ntt = true;            // transform_kernel_to_ntt, convolutionalLayer.cpp:151-156 (done once)
 }
+void ConvolutionalLayer::packWeights(bool unpack)
+{
+    upload();
+    if ((w_form == CRC_NTTP) == !unpack) return;
+    chk(crc_pack28(ctx(), (uint64_t *)d_w->ptr, (size_t)nf * zd * xf * yf * K(), unpack ? 1 : 0, nullptr), "crc_pack28");
+    w_form = unpack ? CRC_NTT : CRC_NTTP;
+}
 ciphertext3D ConvolutionalLayer::forward(ciphertext3D input)
 {
     checkInput(input, zd, xd, yd, "ConvolutionalLayer");
@@ -302,8 +309,8 @@ ciphertext3D ConvolutionalLayer::forward(ciphertext3D input)
     size_t wb = crc_conv2d_work_bytes(ctx(), input.B, zd, xd, yd, xs, ys, xf, yf, nf, input.form);
     if (!wb) throw invalid_argument("ConvolutionalLayer: unsupported geometry");
     ensure(d_work, wb);
-    chk(crc_conv2d(ctx(), input.data(), (const uint64_t *)d_w->ptr, (const uint64_t *)d_b[out_form == CRC_NTT]->ptr, input.B, zd, xd, yd, xs, ys, xf, yf, nf,
-                   input.form, out_form, out.data(), d_work->ptr, nullptr), "crc_conv2d");
+    chk(crc_conv2d_forms(ctx(), input.data(), (const uint64_t *)d_w->ptr, w_form, (const uint64_t *)d_b[out_form != CRC_COEFF]->ptr, input.B, zd, xd, yd, xs, ys, xf, yf, nf,
+                         input.form, out_form, out.data(), d_work->ptr, nullptr), "crc_conv2d_forms");
     return out;
 }
 void ConvolutionalLayer::savePlaintextParameters(ostream *outfile)
@@ -337,14 +344,21 @@ void FullyConnectedLayer::upload()
     d_w = uploadPlain(w, 0); d_b[0] = uploadPlain(b, 1); d_b[1] = uploadPlain(b, 2);
     weights_already_ntt = true;
 }
+void FullyConnectedLayer::packWeights(bool unpack)
+{
+    upload();
+    if ((w_form == CRC_NTTP) == !unpack) return;
+    chk(crc_pack28(ctx(), (uint64_t *)d_w->ptr, (size_t)in_dim * out_dim * K(), unpack ? 1 : 0, nullptr), "crc_pack28");
+    w_form = unpack ? CRC_NTT : CRC_NTTP;
+}
 ciphertext3D FullyConnectedLayer::forward(ciphertext3D input)
 {
     if (!input.buf || input.zd * input.xd * input.yd != in_dim) throw invalid_argument("FullyConnectedLayer: input size does not match in_dim");   // reshapeInput, :38-56
     upload();
     ciphertext3D out(input.B, 1, out_dim, 1, out_form);
     ensure(d_work, crc_dense_work_bytes(ctx(), input.B, in_dim, out_dim, input.form));
-    chk(crc_dense(ctx(), input.data(), (const uint64_t *)d_w->ptr, (const uint64_t *)d_b[out_form == CRC_NTT]->ptr, input.B, in_dim, out_dim, input.form, out_form,
-                  out.data(), d_work->ptr, nullptr), "crc_dense");
+    chk(crc_dense_forms(ctx(), input.data(), (const uint64_t *)d_w->ptr, w_form, (const uint64_t *)d_b[out_form != CRC_COEFF]->ptr, input.B, in_dim, out_dim, input.form, out_form,
+                        out.data(), d_work->ptr, nullptr), "crc_dense_forms");
     return out;
 }
 void FullyConnectedLayer::savePlaintextParameters(ostream *outfile)
@@ -438,9 +452,19 @@ ciphertext3D Network::forward(ciphertext3D input)
 {   // network.cpp:22-47
     const int L = (int)layers.size();
     // choose the form of every boundary: NTT between linear layers when resident, coefficient form into Square and out of the net
+    // conv / dense weights go into the MAC kernels' operand form (28-bit limb pairs) once; moduli above 55 bits cannot be packed
+    bool packable = true;
+    { vector<uint64_t> q(K()); crc_ctx_table(ctx(), "q", q.data(), K()); for (uint64_t v : q) if (v >> 55) packable = false; }
+    auto isMac = [&](int i) { return i >= 0 && i < L && (dynamic_pointer_cast<ConvolutionalLayer>(layers[i]) || dynamic_pointer_cast<FullyConnectedLayer>(layers[i])); };
+    if (packable)
+        for (int i = 0; i < L; i++) {
+            if (auto c = dynamic_pointer_cast<ConvolutionalLayer>(layers[i])) c->packWeights(false);
+            else if (auto f = dynamic_pointer_cast<FullyConnectedLayer>(layers[i])) f->packWeights(false);
+        }
     for (int i = 0; i < L; i++) {
         bool coeff = !ntt_resident || i == L - 1 || i + 1 == layer_before_reenc;
-        layers[i]->out_form = coeff ? CRC_COEFF : CRC_NTT;
+        // a conv / dense layer feeding another one hands its tensor over packed as well
+        layers[i]->out_form = coeff ? CRC_COEFF : (packable && max_num_of_reencryptions < 0 && isMac(i) && isMac(i + 1) ? CRC_NTTP : CRC_NTT);
     }
     last_layer_ms.assign(L, 0.0);
     if (max_num_of_reencryptions >= 0) {                    // network.cpp:52-96
@@ -483,6 +507,10 @@ int Network::fuse()
     const int n = N(), k = K();
     const size_t rowb = (size_t)k * n * 8;
     int removed = 0;
+    for (auto &l : layers) {                                // the folding kernels work on canonical residues
+        if (auto c = dynamic_pointer_cast<ConvolutionalLayer>(l)) { if (c->w_form == CRC_NTTP) c->packWeights(true); }
+        else if (auto f = dynamic_pointer_cast<FullyConnectedLayer>(l)) { if (f->w_form == CRC_NTTP) f->packWeights(true); }
+    }
     auto inttCopy = [&](const shared_ptr<DeviceBuffer> &ntt_rows, size_t rows) {       // coefficient-form twin of NTT-form delta rows
         auto out = make_shared<DeviceBuffer>(rows * rowb);
         chk(crc_memcpy_d2d(ctx(), out->ptr, ntt_rows->ptr, rows * rowb, nullptr), "crc_memcpy_d2d");

@@ -109,7 +109,9 @@ public:
     void printLayerStructure() override;
 private:
     std::shared_ptr<DeviceBuffer> d_w, d_b[2], d_work;      // NTT-form weights, bias delta in coefficient / NTT form
+    int w_form = CRC_NTT;                                   // CRC_NTTP once Network::forward has put the weights into the MAC kernels' operand form
     void upload();
+    void packWeights(bool unpack);
 };
 
 class FullyConnectedLayer : public Layer {                  // fullyConnectedLayer.h:22-24
@@ -129,7 +131,9 @@ public:
     void printLayerStructure() override;
 private:
     std::shared_ptr<DeviceBuffer> d_w, d_b[2], d_work;
+    int w_form = CRC_NTT;
     void upload();
+    void packWeights(bool unpack);
 };
 
 class PoolingLayer : public Layer {                         // poolingLayer.h:15
