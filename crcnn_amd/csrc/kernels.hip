@@ -881,11 +881,10 @@ int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, co
       const long long mtl = ((long long)B * P + 5) / 6;
       a.mt_fastest = ord >= 0 ? ord : (mtl <= 16); }
     // default: LDS-DMA staging with 4-step stages; the register-staged mac2_kernel remains for reductions whose term table does not
-    // fit beside the two stage buffers (T > ~7000) and as the tuning reference (CRC_MAC_REGSTAGE=1, CRC_MAC2_CFG)
+    // fit beside the two stage buffers (T > ~7000) and as the tuning reference (CRC_MAC_REGSTAGE=1, CRC_MAC2_CFG).  (Short reductions
+    // that are not a multiple of 4 pay a padded last stage, T = 25: 28 steps; with packed operands mac3 still wins.)
     static const int regstage = [] { const char *e = getenv("CRC_MAC_REGSTAGE"); return e ? atoi(e) : 0; }();
-    // short reductions that are not a multiple of 4 lose more to the padded last stage than LDS-DMA gains (T = 25: 28 steps instead of 26)
-    const bool short_odd = ((T + 3) / 4 * 4 - (T + 1) / 2 * 2) * 20 > T;
-    if (!regstage && !cfg && !short_odd) {
+    if (!regstage && !cfg) {
         int rc;
 #define MAC3_GO(XPV, WPV) (pick == 8 ? mac3_launch<3, 4, 4, 2, 4, XPV, WPV>(c, a, st) : mac3_launch<3, 4, 2, 4, 4, XPV, WPV>(c, a, st))
         if (a.xp && a.wp) rc = MAC3_GO(true, true); else if (a.xp) rc = MAC3_GO(true, false); else if (a.wp) rc = MAC3_GO(false, true); else rc = MAC3_GO(false, false);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time one layer's ct x pt MAC launch on random residues (kernel-only view of the dominant kernel).
-usage: python tools/bench_mac.py [conv2|conv1|fc3|conv1p|conv2p|aconv1|aconv2|afc3|f5] [B] [reps]   (a*: ApproxPlainModel shapes; CRC_MAC2_CFG=16|8 forces a tile shape)"""
+usage: python tools/bench_mac.py [conv2|conv1|fc3|conv1p|conv2p|aconv1|aconv2|afc3|f5] [B] [reps] [packed]   (a*: ApproxPlainModel shapes; CRC_MAC2_CFG=16|8 forces a tile shape)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -31,7 +31,7 @@ in_cts, out_cts, T = a["zd"] * a["xd"] * a["yd"], a["nf"] * xo * yo, a["zd"] * a
 x = rnd(B * in_cts * 2 * k); w = rnd(a["nf"] * T * k); bias = rnd(a["nf"] * k)
 y = torch.empty((B * out_cts * 2 * k, n), dtype=torch.int64, device=dev)
 work = torch.empty(E.conv2d_work_bytes(B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"], ca.NTT) // 8 + 64, dtype=torch.int64, device=dev)
-PACKED = os.environ.get("CRC_BENCH_PACKED") == "1"       # operands and result in the packed 28-bit limb form (CRC_NTTP)
+PACKED = os.environ.get("CRC_BENCH_PACKED") == "1" or (len(sys.argv) > 4 and sys.argv[4] == "packed")       # operands and result in the packed 28-bit limb form (CRC_NTTP)
 if PACKED:
     E.stream = torch.cuda.current_stream().cuda_stream or None
     E.pack28(x, x.shape[0]); E.pack28(w, w.shape[0])

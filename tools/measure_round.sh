@@ -6,9 +6,10 @@ timeout -k 10 500 python bench.py --config approx8192 > $O/bench_approx8192.json
 timeout -k 10 500 python bench.py --config wopad16384 --batch 96 > $O/bench_wopad16384_b96.json 2> $O/bench_wopad.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_tiny -o tiny -- python3 bench.py --cpu-seconds 0 --unfused-images 48 > $O/prof_tiny.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_approx -o approx -- python3 bench.py --config approx8192 --batch 96 --cpu-seconds 0 --unfused-images 0 > $O/prof_approx.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 tools/bench_mac.py conv2p 24 1 > $O/pmc_fetch.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 tools/bench_mac.py conv2p 24 1 > $O/pmc_write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 tools/bench_mac.py conv2p 24 1 packed > $O/pmc_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 tools/bench_mac.py conv2p 24 1 packed > $O/pmc_write.log 2>&1
 (python tools/bench_ntt.py 4096 2 8192; python tools/bench_ntt.py 8192 3 4096; python tools/bench_ntt.py 16384 4 1024) > $O/ntt_elementwise.txt 2>&1
 (python tools/bench_square.py 8192 3 1250; python tools/bench_square.py 16384 4 512; python tools/bench_square.py 8192 3 1250 0 0) > $O/square.txt 2>&1
-for g in conv1 conv1p conv2 conv2p fc3 aconv1 aconv2 afc3; do python tools/bench_mac.py $g 24 2 2>&1 | grep -v amdgpu >> $O/mac_geometries.txt; done
+rm -f $O/mac_geometries.txt
+for g in conv1 conv1p conv2 conv2p fc3 aconv1 aconv2 afc3; do python tools/bench_mac.py $g 24 2 2>&1 | grep -v amdgpu >> $O/mac_geometries.txt; python tools/bench_mac.py $g 24 2 packed 2>&1 | grep -v amdgpu >> $O/mac_geometries.txt; done
 ls $O
