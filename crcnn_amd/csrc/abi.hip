@@ -5,6 +5,7 @@
 #define RUN(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 static inline hipStream_t S(void *s) { return (hipStream_t)s; }
 static inline bool form_ok(int f) { return f == CRC_COEFF || f == CRC_NTT; }
+static inline bool nform_ok(int f) { return f == CRC_COEFF || f == CRC_NTT || f == CRC_NTTP; }
 
 extern "C" int crc_plain_to_ntt(crc_ctx *c, const uint64_t *d_plain, size_t count, uint64_t *d_out, void *stream)
 {
@@ -84,7 +85,6 @@ extern "C" size_t crc_conv2d_work_bytes(const crc_ctx *c, int B, int zd, int xd,
     return b + 256;
 }
 
-static inline bool nform_ok(int f) { return f == CRC_COEFF || f == CRC_NTT || f == CRC_NTTP; }
 extern "C" int crc_conv2d_forms(crc_ctx *c, const uint64_t *d_x, const uint64_t *d_w, int w_form, const uint64_t *d_bias, int B, int zd, int xd, int yd,
                                 int xs, int ys, int xf, int yf, int nf, int in_form, int out_form, uint64_t *d_y, void *d_work, void *stream)
 {
@@ -156,11 +156,13 @@ extern "C" int crc_conv2d_fold_pool(crc_ctx *c, const uint64_t *d_w, const uint6
 extern "C" int crc_pool(crc_ctx *c, const uint64_t *d_x, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf,
                         const uint64_t *d_div, int form, uint64_t *d_y, void *stream)
 {
+    // form = CRC_NTTP: NTT-form input, result written in the MAC kernels' operand form (the layer behind is a conv / dense layer)
     CHECK_CTX(c);
-    if (!d_x || !d_y || B < 0 || zd < 1 || !form_ok(form) || !conv_shape_ok(xd, yd, xs, ys, xf, yf)) return CRC_ERR_INVALID_ARGUMENT;
+    if (!d_x || !d_y || B < 0 || zd < 1 || !nform_ok(form) || !conv_shape_ok(xd, yd, xs, ys, xf, yf)) return CRC_ERR_INVALID_ARGUMENT;
     if (B == 0) return CRC_OK;
     hipStream_t st = S(stream);
     const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys + 1;
+    if (form == CRC_NTTP) return k_pool(c, d_x, d_y, B, zd, xd, yd, xs, ys, xf, yf, d_div, st, 1);
     if (form == CRC_NTT || !d_div) return k_pool(c, d_x, d_y, B, zd, xd, yd, xs, ys, xf, yf, form == CRC_NTT ? d_div : nullptr, st);
     // coefficient form average pooling: add_many then multiply_plain(div_factor) (avgPoolingLayer.cpp:37-38)
     RUN(k_pool(c, d_x, d_y, B, zd, xd, yd, xs, ys, xf, yf, nullptr, st));

@@ -254,7 +254,7 @@ int k_rowwise(crc_ctx *c, u64 *acc, const u64 *b, size_t count, int size, int op
 // window sum (PoolingLayer::forward, poolingLayer.cpp:22-44) with optional dyadic multiply by an NTT-form plaintext
 // (only meaningful when the tensor is NTT-resident) and optional per-channel affine (batch-norm in NTT form).
 __global__ void __launch_bounds__(256) pool_kernel(const u64 *x, u64 *y, const ModParams *mods, int n, int k,
-                                                   int zd, int xd, int yd, int xs, int ys, int xf, int yf, int xo, int yo, const u64 *mul)
+                                                   int zd, int xd, int yd, int xs, int ys, int xf, int yf, int xo, int yo, const u64 *mul, int pack_out)
 {
     // one block per output row: row = (((b*zd + z)*xo + ox)*yo + oy)*2k + p*k + i
     const size_t row = blockIdx.x;
@@ -272,16 +272,17 @@ __global__ void __launch_bounds__(256) pool_kernel(const u64 *x, u64 *y, const M
             acc.x = addmod(acc.x, v.x, m.q); acc.y = addmod(acc.y, v.y, m.q);
         }
         if (w) { const ulonglong2 wv = *reinterpret_cast<const ulonglong2 *>(w + s); acc.x = mulmod(acc.x, wv.x, m); acc.y = mulmod(acc.y, wv.y, m); }
+        if (pack_out) { acc.x = split28v(acc.x); acc.y = split28v(acc.y); }          // hand-over to a conv / dense layer in its operand form
         *reinterpret_cast<ulonglong2 *>(dst + s) = acc;
     }
 }
 
-int k_pool(crc_ctx *c, const u64 *x, u64 *y, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, const u64 *mul, hipStream_t st)
+int k_pool(crc_ctx *c, const u64 *x, u64 *y, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, const u64 *mul, hipStream_t st, int pack_out)
 {
     int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys + 1;
     size_t rows = (size_t)B * zd * xo * yo * 2 * c->k;
     if (rows == 0) return CRC_OK;
-    hipLaunchKernelGGL(pool_kernel, dim3((unsigned)rows), dim3(256), 0, st, x, y, c->d_mods, c->n, c->k, zd, xd, yd, xs, ys, xf, yf, xo, yo, mul);
+    hipLaunchKernelGGL(pool_kernel, dim3((unsigned)rows), dim3(256), 0, st, x, y, c->d_mods, c->n, c->k, zd, xd, yd, xs, ys, xf, yf, xo, yo, mul, pack_out);
     HIPCHK(hipGetLastError());
     return CRC_OK;
 }

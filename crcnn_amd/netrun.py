@@ -116,6 +116,14 @@ class Network:
         if max(int(q).bit_length() for q in E.q) > 55 or self._packed == (not unpack):
             return
         for idx, (kind, name, a, p, ishape, oshape) in enumerate(self.plan):
+            if kind in ("pool", "avgpool"):               # a pooling layer in front of a conv / dense layer writes the packed form too
+                nxt = self.plan[idx + 1] if idx + 1 < len(self.plan) else None
+                if nxt and nxt[0] in ("conv", "fc"):
+                    if not unpack and p["form"] == NTT and nxt[3]["in_form"] == NTT:
+                        p["form"] = nxt[3]["in_form"] = binding.NTTP
+                    elif unpack and p["form"] == binding.NTTP:
+                        p["form"] = nxt[3]["in_form"] = NTT
+                continue
             if kind not in ("conv", "fc"):
                 continue
             rows = (a["nf"] * a["zd"] * a["xf"] * a["yf"] if kind == "conv" else a["in_dim"] * a["out_dim"]) * E.k

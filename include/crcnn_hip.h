@@ -143,6 +143,7 @@ int crc_multiply_plain(crc_ctx *ctx, uint64_t *d_ct, const uint64_t *d_w_ntt, si
  *                x is [B][in_dim] cts in z,x,y row-major order; d_w_ntt [out_dim][in_dim][k][n].
  *   crc_pool     PoolingLayer::forward (poolingLayer.cpp:22-44) and AvgPoolingLayer::forward (avgPoolingLayer.cpp:16-45):
  *                window sum; if d_div_ntt != NULL multiply by that NTT-form plaintext (encode(1./(xf*yf))).
+ *                form = CRC_NTTP: NTT-form input, output in the packed operand form (hand-over to a conv / dense layer).
  *   crc_batchnorm BatchNormLayer::forward (batchNormLayer.cpp:29-40): (x - Delta*mean[z]) (*) invstd[z].
  *                d_mean_delta [C][k][n] in the form of the INPUT, d_invstd_ntt [C][k][n].
  *   crc_square_relin  SquareLayer::forward (squareLayer.cpp:22-74) = Evaluator::square (evaluator.cpp:702-884) +
