@@ -893,11 +893,7 @@ int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, co
         if (rc != CRC_ERR_UNSUPPORTED) return rc;
     }
     switch (pick) {
-    case 3: return mac2_launch<2, 4, 3, 4, 2, 1>(c, a, st);
-    case 9: return mac2_launch<3, 4, 2, 4, 2, 1>(c, a, st);
     case 8: return mac2_launch<3, 4, 4, 2, 2>(c, a, st);
-    case 4: return mac2_launch<3, 4, 2, 2, 2>(c, a, st);
-    case 5: return mac2_launch<3, 4, 1, 4, 2>(c, a, st);
     default: return mac2_launch<3, 4, 2, 4, 2>(c, a, st);
     }
 }
