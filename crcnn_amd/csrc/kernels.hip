@@ -638,6 +638,8 @@ __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_
             const int ff = f0 + wn * FT + f;
             if (ff >= a.F) continue;
             const u32 ov = OV[r][f];
+            u64 v;
+            {
             // a_j = A_j + ov_j * 2^63  as (lo, hi)
             u64 o0 = ov & 1023, o1 = (ov >> 10) & 1023, o2 = (ov >> 20) & 1023;
             u64 a0l = A0[r][f] + (o0 << 63), a0h = (o0 >> 1) + (a0l < A0[r][f]);
@@ -652,7 +654,8 @@ __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_
             u64 nl = vl + tl; vh += th + (nl < vl); vl = nl;
             tl = a2l << 56; th = (a2h << 56) | (a2l >> 8);
             nl = vl + tl; vh += th + (nl < vl); vl = nl;
-            u64 v = barrett128(vl, vh, m);
+            v = barrett128(vl, vh, m);
+            }
             if (c == 0 && a.bias) { const u64 bv = a.bias[(size_t)ff * kn + rown]; v = addmod(v, bv, m.q); }
             a.y[(((size_t)b * a.F + ff) * a.P + p) * ctw + (size_t)c * kn + rown] = a.yp ? split28(v) : v;
         }
@@ -799,21 +802,8 @@ __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_
             const int ff = f0 + wn * FT + f;
             if (ff >= a.F) continue;
             const u32 ov = OV[r][f];
-            // a_j = A_j + ov_j * 2^63  as (lo, hi)
-            u64 o0 = ov & 1023, o1 = (ov >> 10) & 1023, o2 = (ov >> 20) & 1023;
-            u64 a0l = A0[r][f] + (o0 << 63), a0h = (o0 >> 1) + (a0l < A0[r][f]);
-            u64 a1l = A1[r][f] + (o1 << 63), a1h = (o1 >> 1) + (a1l < A1[r][f]);
-            u64 a2l = A2[r][f] + (o2 << 63), a2h = (o2 >> 1) + (a2l < A2[r][f]);
-            // mid = a1 - a0 - a2
-            u64 ml = a1l - a0l, mh = a1h - a0h - (a1l < a0l);
-            u64 ml2 = ml - a2l; mh = mh - a2h - (ml < a2l); ml = ml2;
-            // V = a0 + mid << 28 + a2 << 56
-            u64 vl = a0l, vh = a0h;
-            u64 tl = ml << 28, th = (mh << 28) | (ml >> 36);
-            u64 nl = vl + tl; vh += th + (nl < vl); vl = nl;
-            tl = a2l << 56; th = (a2h << 56) | (a2l >> 8);
-            nl = vl + tl; vh += th + (nl < vl); vl = nl;
-            u64 v = barrett128(vl, vh, m);
+            // every modulus this kernel is launched for has the form 2^b - d (k_mac2 checks): fold every limb sum first (modarith.h)
+            u64 v = mac_reduce_fold(A0[r][f], A1[r][f], A2[r][f], ov, m);
             if (c == 0 && a.bias) { const u64 bv = a.bias[(size_t)ff * kn + rown]; v = addmod(v, bv, m.q); }
             a.y[(((size_t)b * a.F + ff) * a.P + p) * ctw + (size_t)c * kn + rown] = a.yp ? split28(v) : v;
         }
@@ -885,7 +875,9 @@ int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, co
     // fit beside the two stage buffers (T > ~7000) and as the tuning reference (CRC_MAC_REGSTAGE=1, CRC_MAC2_CFG).  (Short reductions
     // that are not a multiple of 4 pay a padded last stage, T = 25: 28 steps; with packed operands mac3 still wins.)
     static const int regstage = [] { const char *e = getenv("CRC_MAC_REGSTAGE"); return e ? atoi(e) : 0; }();
-    if (!regstage && !cfg) {
+    bool foldable = true;                          // mac3's epilogue is the folding reduction: needs q = 2^b - d, 50 <= b <= 55
+    for (int i = 0; i < c->k; i++) if (!c->tabs[i].m.fold || c->tabs[i].m.bits < 50 || c->tabs[i].m.bits > 55) foldable = false;
+    if (!regstage && !cfg && foldable) {
         int rc;
 #define MAC3_GO(XPV, WPV) (pick == 8 ? mac3_launch<3, 4, 4, 2, 4, XPV, WPV>(c, a, st) : mac3_launch<3, 4, 2, 4, 4, XPV, WPV>(c, a, st))
         if (a.xp && a.wp) rc = MAC3_GO(true, true); else if (a.xp) rc = MAC3_GO(true, false); else if (a.wp) rc = MAC3_GO(false, true); else rc = MAC3_GO(false, false);

@@ -63,6 +63,37 @@ CRC_HD u64 fold128(u64 lo, u64 hi, const ModParams &m)
     return r >= m.q ? r - m.q : r;
 }
 
+// The MAC kernels' epilogue for q = 2^b - d (m.fold, 50 <= b <= 55):  a0 + (a1 - a0 - a2) 2^28 + a2 2^56  mod q  from the three lazy limb
+// accumulators a_j = A_j + o_j 2^63 (o_j < 1024 packed in ov as 3 x 10 bits), canonical.  Every accumulator is folded below 2^b + 2^50
+// first (one word multiply each), so the 2^28 / 2^56 weights never need 128-bit arithmetic: 9 word multiplies in all, about a third of
+// the instructions of recombining into 128 bits and reducing that.
+CRC_HD u64 mac_reduce_fold(u64 A0, u64 A1, u64 A2, u32 ov, const ModParams &m)
+{
+    const u32 b = m.bits, d = m.fold;
+    const u64 mask = ((u64)1 << b) - 1;
+    const u32 os = 63 - b;
+    // a_j = (A_j >> b) 2^b + (A_j mod 2^b) + o_j 2^(63-b) 2^b  ==  h_j d + l_j,   h_j < 2^24
+    const u32 h0 = (u32)(A0 >> b) + ((ov & 1023u) << os), h1 = (u32)(A1 >> b) + (((ov >> 10) & 1023u) << os), h2 = (u32)(A2 >> b) + (((ov >> 20) & 1023u) << os);
+    const u64 a0 = (u64)h0 * d + (A0 & mask), a1 = (u64)h1 * d + (A1 & mask);
+    u64 a2 = (u64)h2 * d + (A2 & mask);                                   // each < 2^b + 2^50
+    // mid = a1 - a0 - a2 + 8q  in (0, 2^(b+3.2)), folded once: < 2^b + 2^30
+    u64 mid = a1 + (m.q << 3) - a0 - a2;
+    mid = (u64)(u32)(mid >> b) * d + (mid & mask);
+    // mid 2^28  ==  (mid >> (b-28)) d + (mid mod 2^(b-28)) 2^28
+    const u32 lb = b - 28;
+    const u64 M = (u64)(u32)(mid >> lb) * d + ((mid & (((u64)1 << lb) - 1)) << 28);          // < 2^54.1 + 2^b
+    // a2 2^56  ==  a2 c,  c = d 2^(56-b) < 2^32,  a2 first brought below 2^b
+    a2 = (a2 >> b) ? (a2 & mask) + d : a2;
+    const u32 c = d << (56 - b);
+    const u64 p0 = (u64)(u32)a2 * c, p1 = (u64)(u32)(a2 >> 32) * c;
+    const u64 t = p1 + (p0 >> 32);                                        // a2 c = t 2^32 + lo32(p0) < 2^(b+32)
+    const u32 hb = b - 32;
+    const u64 N = (u64)(u32)(t >> hb) * d + (((t & (((u64)1 << hb) - 1)) << 32) | (u32)p0);  // < 2^58 + 2^b
+    const u64 sum = a0 + M + N;                                           // < 2^58.3
+    const u64 r = (u64)(u32)(sum >> b) * d + (sum & mask);                // < 2^b + 2^35 < 2q
+    return r >= m.q ? r - m.q : r;
+}
+
 // x = hi*2^64 + lo  ->  x mod q, canonical.  Exact for any 128-bit x (quotient estimate is off by at most one).
 CRC_HD u64 barrett128(u64 lo, u64 hi, const ModParams &m)
 {

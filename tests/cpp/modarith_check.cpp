@@ -33,6 +33,15 @@ int main()
             if (mulmod_shoup(any, b, wp, q) != (u64)((u128)any * b % q)) { printf("mulmod_shoup mismatch q=%llx\n", (unsigned long long)q); return 1; }
             const u64 lz = mulmod_shoup_lazy(any, b, wp, q);
             if (lz >= 2 * q || lz % q != (u64)((u128)any * b % q)) { printf("mulmod_shoup_lazy mismatch q=%llx\n", (unsigned long long)q); return 1; }
+            if (m.fold && m.bits >= 50 && m.bits <= 55) {                  // the MAC epilogue: limbs up to their lazy bounds, overflow counters up to 1023
+                u64 A0 = rnd(), A1 = rnd(), A2 = rnd(); u32 ov = (u32)rnd() & 0x3fffffffu;
+                if (it % 5 == 0) { A0 = ~0ULL; A1 = ~0ULL; A2 = ~0ULL; ov = 0x3fffffffu; } if (it % 9 == 0) { A0 = A1 = A2 = 0; } if (it % 3 == 0) ov = 0;
+                const u128 a0 = (u128)A0 + ((u128)(ov & 1023) << 63), a1 = (u128)A1 + ((u128)((ov >> 10) & 1023) << 63), a2 = (u128)A2 + ((u128)((ov >> 20) & 1023) << 63);
+                const u64 r0 = (u64)(a0 % q), r1 = (u64)(a1 % q), r2 = (u64)(a2 % q);
+                const u64 midv = (u64)(((u128)r1 + 2 * (u128)q - r0 - r2) % q);
+                const u64 want = (u64)(((u128)r0 + (u128)midv * (u64)(((u128)1 << 28) % q) % q + (u128)r2 * (u64)(((u128)1 << 56) % q) % q) % q);
+                if (mac_reduce_fold(A0, A1, A2, ov, m) != want) { printf("mac_reduce_fold mismatch q=%llx A=%llx %llx %llx ov=%x\n", (unsigned long long)q, (unsigned long long)A0, (unsigned long long)A1, (unsigned long long)A2, ov); return 1; }
+            }
             checked++;
         }
     }
