@@ -92,3 +92,19 @@ def test_cpp_network_fused_equals_reference(name):
     g, O, d = run_driver(name, resident=True, batch=2, fuse=True)
     out = np.fromfile(os.path.join(d, "out.u64"), dtype=np.uint64).reshape(2, -1)
     assert sha(out[0]) == g["out_sha256"] and sha(out[1]) == g["out_sha256"]
+
+
+def test_cpp_example_driver():
+    """crcnn_amd/host/example_main.cpp: the reference's timed test driver (mainparams.cpp:64-116) written against the host classes --
+    encrypt, Network::forward (with and without Network::fuse), decrypt, arg-max equal to the float model's"""
+    from crcnn_amd import synth
+    d = tempfile.mkdtemp()
+    imgs = np.stack([synth.normalize(synth.synth_image(i)).reshape(-1) for i in range(2)]).astype(np.float32)
+    imgs.tofile(os.path.join(d, "images.f32"))
+    exe = os.path.join(ROOT, "crcnn_amd", "lib", "example_main")
+    h5 = os.path.join(GOLD, "models", "PlainModelTiny.h5")
+    for fuse in ("0", "1"):
+        out = subprocess.check_output([exe, "PlainModelTiny", h5, os.path.join(d, "images.f32"), "4096", str(1 << 32), "2", fuse], text=True)
+        lines = [l for l in out.split("\n") if l.startswith("OUTPUT:")]
+        assert len(lines) == 2 and all(l.endswith("Success") for l in lines), out
+        assert "SUMMARY: 2 of 2" in out
