@@ -21,6 +21,7 @@ struct NttArgs {
     int n, logn;
     int mod_base, mod_count;                                   // row r -> modulus index mod_base + r % mod_count
     int src_rows_per_item;                                     // 0: src row = dst row;  >0: plain prologue, src row = r / mod_count
+    size_t rows;                                               // total rows of the launch (prefetch variant)
     int pack_out;                                              // forward only: store the result as 28-bit limb pairs (operand form of the MAC kernels)
     int src_ct_rows, dst_ct_rows;                              // both > 0: dst row r = (ct, j < dst_ct_rows) reads src row ct*src_ct_rows + j (leading polys of wider cts)
     int prologue;                                              // 0 none, 1 plain lift, 2 delta scale
@@ -98,6 +99,71 @@ __global__ void __launch_bounds__(1024) ntt_rows_kernel(NttArgs a)
     }
 }
 
+// n = 16384: 128 KiB of LDS per row leaves ONE resident workgroup per CU, so the HBM read of a row sits exposed in front of its butterfly
+// passes.  This variant keeps the workgroup resident over rows blockIdx, blockIdx + gridDim, ... and fetches the next row into registers
+// (16 coefficients per thread) while the passes of the current one run: +5 % at n = 16384.  (At n <= 8192 the extra registers cost a
+// resident workgroup and the plain kernel above is faster -- profiles/r01_ntt_experiments.txt.)
+template <bool INV, bool LAZY>
+__global__ void __launch_bounds__(1024) ntt_rows_prefetch_kernel(NttArgs a)
+{
+    constexpr int PF = 16;
+    extern __shared__ u64 sm[];
+    const int n = a.n, logn = a.logn, tid = threadIdx.x, nt = blockDim.x;
+    auto src_of = [&](size_t row) {
+        const size_t srow = a.dst_ct_rows ? (row / a.dst_ct_rows) * a.src_ct_rows + row % a.dst_ct_rows : (a.src_rows_per_item ? (row / a.mod_count) : row);
+        return a.src + srow * (size_t)n;
+    };
+    u64 pre[PF];
+    {
+        const u64 *src = src_of(blockIdx.x);
+#pragma unroll
+        for (int j = 0; j < PF; j++) pre[j] = src[tid + j * nt];
+    }
+    for (size_t row = blockIdx.x; row < a.rows; row += gridDim.x) {
+        const int mloc = (int)(row % a.mod_count);
+        const int mi = a.mod_base + mloc;
+        const ModParams m = a.mods[mi];
+        const u64 q = m.q, q2 = m.two_q;
+        const float rq = 1.0f / (float)((u32)(q >> 32) + 1);
+        const ulonglong2 *W = a.w + (size_t)mi * n;
+        u64 *dst = a.dst + row * (size_t)n;
+#pragma unroll
+        for (int j = 0; j < PF; j++) {
+            u64 v = pre[j];
+            if (a.prologue == 1) v = v >= a.pp.threshold ? v + a.pp.inc[mloc] : v;
+            else if (a.prologue == 2) {
+                u64 lo, hi; mul64wide(a.pp.delta[mloc], v, lo, hi);
+                if (v >= a.pp.threshold) { u64 l2 = lo + a.pp.uhi[mloc]; hi += (l2 < lo); lo = l2; }
+                v = barrett128(lo, hi, m);
+            }
+            sm[lpad(tid + j * nt)] = v;
+        }
+        if (row + gridDim.x < a.rows) {
+            const u64 *nsrc = src_of(row + gridDim.x);
+#pragma unroll
+            for (int j = 0; j < PF; j++) pre[j] = nsrc[tid + j * nt];
+        }
+        __syncthreads();
+        ntt_row_passes<INV, LAZY>(sm, W, n, logn, q, q2);
+        const u64 *add = nullptr;
+        if (INV) {
+            if (a.addend) {
+                const size_t ct = row / a.rows_per_ct; const int p = (int)((row % a.rows_per_ct) / a.mod_count);
+                if (a.add_mode == 2) add = a.addend + ((ct * a.add_size + p) * a.mod_count + mloc) * (size_t)n;
+                else if (p == 0) { size_t g = ct / a.add_group; if (a.add_mod) g %= a.add_mod; add = a.addend + (g * a.mod_count + mloc) * (size_t)n; }
+            }
+        } else if (a.addend) add = a.addend + row * (size_t)n;
+        for (int s = tid; s < n; s += nt) {
+            u64 v = sm[lpad(s)];
+            if (LAZY) v = reduce_small(v, q, q2, rq);
+            else { v = v >= q2 ? v - q2 : v; v = v >= q ? v - q : v; }
+            if (add) v = (INV && a.add_sign < 0) ? submod(v, add[s], q) : addmod(v, add[s], q);
+            dst[s] = (!INV && a.pack_out) ? split28v(v) : v;
+        }
+        __syncthreads();                             // the next row's staging overwrites the LDS image
+    }
+}
+
 static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t st)
 {
     if (rows == 0) return CRC_OK;
@@ -109,6 +175,15 @@ static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t
     // reference's parameter sets qualifies (54..55 bits), the 61-bit auxiliary base of Square does not
     bool lazy = true;
     for (int i = a.mod_base; i < a.mod_base + a.mod_count; i++) if (c->tabs[i].m.bits > 57 || c->tabs[i].m.bits < 45) lazy = false;
+    static const int cus = [] { int dev = 0, v = 256; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 256; return v > 0 ? v : 256; }();
+    if (c->n / nt == 16 && rows > (size_t)cus) {     // n = 16384: one resident workgroup per CU, prefetching the next row
+        a.rows = rows;
+        auto pk = inv ? (lazy ? ntt_rows_prefetch_kernel<true, true> : ntt_rows_prefetch_kernel<true, false>) : (lazy ? ntt_rows_prefetch_kernel<false, true> : ntt_rows_prefetch_kernel<false, false>);
+        HIPCHK(hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(pk, dim3((unsigned)cus), dim3(nt), lds, st, a);
+        HIPCHK(hipGetLastError());
+        return CRC_OK;
+    }
     auto kern = inv ? (lazy ? ntt_rows_kernel<true, true> : ntt_rows_kernel<true, false>) : (lazy ? ntt_rows_kernel<false, true> : ntt_rows_kernel<false, false>);
     if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)rows), dim3(nt), lds, st, a);
