@@ -35,6 +35,8 @@ CONFIGS = {
     # the coefficient modulus CrCNN itself would run at n=8192 (all four primes of coeff_modulus_128(8192)); at n=16384 the
     # eight default primes would need 424 GB for PlainModelWoPad's encoded weights alone (> HBM), so that one stays at k=4
     "approx8192k4": dict(model="ApproxPlainModel", n=8192, k=4, t=1 << 42, batch=1024, chunk=16),
+    # small ring for the tests of this script and single-GPU rehearsals of the multi-rank path (golden: net_tiny1024_eng.json)
+    "tiny1024": dict(model="PlainModelTiny", n=1024, k=2, q=[0x7fffffff380001, 0x3fffffff000001], t=1 << 32, batch=48, chunk=24),
 }
 
 
@@ -52,7 +54,55 @@ def parse():
     ap.add_argument("--unfused-images", type=int, default=128, help="images of the extra, untimed-for-`value` pass with every reference layer run separately")
     ap.add_argument("--t-bits", type=int, default=None, help="override the plain modulus t = 2^bits")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target size of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--also", default="auto", help="a second workload measured in the same invocation and reported under \"also\" (auto: approx8192 = BASELINE "
+                    "configs[2]/[3] beside the tiny4096 headline; none: skip)")
+    ap.add_argument("--also-steps", type=int, default=2)
+    ap.add_argument("--also-batch", type=int, default=None)
+    ap.add_argument("--launch-check", action="store_true", help="only start the ranks, rendezvous (gloo, no GPU call) and report: CPU test of the self-launch path")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks (torch.distributed.run, one per GPU) as a CHILD process -- this
+    parent has made no GPU call and never execs -- relay rank 0's JSON line, and exit non-zero if any rank does."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC (RCCL across processes)
+    env["CRC_SELF_LAUNCHED"] = "1"
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith("{"):
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks finished without a result line\n"); rc = 1
+    return rc
+
+
+def launch_check(args):
+    """ranks rendezvous over gloo and count themselves; nothing touches a GPU (tests/test_multiproc_gloo.py)"""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    seen = world
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        t = torch.tensor([1], dtype=torch.int64); dist.all_reduce(t); seen = int(t.item())
+        dist.barrier(); dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": seen, "self_launched": bool(os.environ.get("CRC_SELF_LAUNCHED"))}), flush=True)
+    return 0 if seen == args.gpus else 1
 
 
 def plain_forward(model, W, img):
@@ -177,35 +227,97 @@ def cpu_baseline(cfg, q, W, x0, target_s):
                 mac_per_s=mac_rate)
 
 
-def main():
-    args = parse()
+# golden fixtures (tests/golden/net_*.json, produced by the compiled reference: oracle/make_golden_nets.py) whose encrypted input is what
+# this script generates for image 0 of rank 0 -- same parameter set, same seeded client side
+GOLDEN_FOR = {"tiny4096": "tiny4096_t32", "approx8192": "approx8192_t42", "approx8192k4": "approx8192k4_t42", "wopad16384": "wopad16384_t44", "tiny1024": "tiny1024_eng"}
+KEY_SEED, EVK_SEED, ENC_SEED = 2024, 2025, 7000
+
+
+def golden_check(cfg_name, cfg, q, rank, x0_sha, out0_sha):
+    """True / False when a reference-made golden exists for exactly these parameters and inputs, else None"""
+    path = os.path.join(ROOT, "tests", "golden", f"net_{GOLDEN_FOR.get(cfg_name, '')}.json")
+    if rank != 0 or not os.path.exists(path):
+        return None, None
+    g = json.load(open(path))
+    same = (g.get("input_gen") == "engine" and g["model"] == cfg["model"] and g["n"] == cfg["n"] and g["t"] == cfg["t"] and [int(v) for v in g["q"]] == [int(v) for v in q]
+            and (g["key_seed"], g["evk_seed"], g["enc_seed"], g["image_index"]) == (KEY_SEED, EVK_SEED, ENC_SEED, 0))
+    if not same:
+        return None, None
+    return bool(g["input_sha256"] == x0_sha and g["out_sha256"] == out0_sha), os.path.basename(path)
+
+
+class Dist:
+    """rank bookkeeping + the two kinds of collective this script needs: the weight broadcast (RCCL through the engine's own C ABI,
+    crc_comm_* / crc_broadcast_weights) and tiny host-side reductions (timing, verification counts)"""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0")); self.world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus and self.world > 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        ndev = torch.cuda.device_count()
+        self.backend = os.environ.get("CRC_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm; "gloo" only for single-GPU rehearsals of this code path
+        if self.world > 1 and self.backend == "nccl" and ndev < self.world:
+            raise SystemExit(f"--gpus {self.world} needs {self.world} GPUs, {ndev} visible (CRC_DIST_BACKEND=gloo rehearses the multi-rank path on fewer)")
+        self.local = local % max(1, ndev)                # (rehearsals with more ranks than GPUs share a device; the driver uses one rank per GPU)
+        torch.cuda.set_device(self.local)
+        self.dev = torch.device("cuda", self.local)
+        self.comm = None
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend)
+
+    def make_comm(self, E):
+        """RCCL communicator of the engine (C ABI); the 128-byte rendezvous id travels over the torch.distributed store"""
+        if self.world == 1 or self.backend != "nccl":
+            return None
+        obj = [E.comm_unique_id() if self.rank == 0 else None]
+        self.dist.broadcast_object_list(obj, src=0)
+        return E.comm_create(self.world, self.rank, obj[0])
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max(self, v):
+        if self.world == 1:
+            return v
+        from crcnn_amd import shard
+        return shard.max_over_ranks(v, self.dev)
+
+    def sum(self, v):
+        if self.world == 1:
+            return v
+        from crcnn_amd import shard
+        return shard.gather_counts(v, self.dev)
+
+    def gather(self, obj):
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+
+def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=True):
+    """one workload: setup (keys, encrypted inputs, encoded weights + broadcast), `warmup` + `steps` timed passes, verification.
+    full=False: the secondary workload (no reference-layer-structure pass, no CPU baseline).  Returns (result dict on rank 0, all checks ok)"""
     import torch
-    import torch.distributed as dist
     import crcnn_amd as ca
     from crcnn_amd.netrun import Network, TOPOLOGIES, layer_macs
+    rank, world, dev = D_.rank, D_.world, D_.dev
 
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    ndev = torch.cuda.device_count()
-    local = local % max(1, ndev)                     # (rehearsals with more ranks than GPUs share a device; the driver uses one rank per GPU)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("CRC_DIST_BACKEND", "nccl")           # "nccl" is RCCL on ROCm; "gloo" only for single-GPU rehearsals of this code path
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-
-    cfg = dict(CONFIGS[args.config])
-    if args.t_bits:
+    cfg = dict(CONFIGS[cfg_name])
+    if args.t_bits and full:
         cfg["t"] = 1 << args.t_bits
-    B = args.batch or cfg["batch"]; C = min(args.chunk or cfg["chunk"], B)
-    q = ca.default_coeff_modulus_128(cfg["n"])[:cfg["k"]]
-    E = ca.Engine(cfg["n"], q, cfg["t"], device=local)
-    local_rank_env = int(os.environ.get("LOCAL_RANK", "0"))
+    B = batch or cfg["batch"]; C = min(chunk or cfg["chunk"], B)
+    q = cfg.get("q") or ca.default_coeff_modulus_128(cfg["n"])[:cfg["k"]]
+    E = ca.Engine(cfg["n"], q, cfg["t"], device=D_.local)
     E.stream = torch.cuda.current_stream().cuda_stream or None
     keep = []
 
@@ -216,30 +328,34 @@ def main():
     h5 = os.path.join(ROOT, "tests", "golden", "models", model + ".h5")
     W = {nm: ca.h5_read(h5, nm) for nm in ca.h5_list(h5) if not nm.endswith("num_batches_tracked")}
 
-    # ---- keys + encrypted inputs (client side, untimed): `distinct` synthetic images encrypted on the host, tiled on device
+    # ---- keys + encrypted inputs (client side, untimed): `distinct` synthetic images encrypted on the host, tiled on device.
+    # Seeded (deterministic, NOT secure) on purpose: image 0 of rank 0 is the input of the reference-made golden (GOLDEN_FOR)
     t_setup = time.time()
-    sk, pk = E.keygen(2024)
+    sk, pk = E.keygen(KEY_SEED)
     needs_evk = any(k_ == "square" for k_, _, _ in TOPOLOGIES[model])
     d_evk = None
     if needs_evk:
-        evk = E.gen_evk(2025, sk)
+        evk = E.gen_evk(EVK_SEED, sk)
         d_evk = alloc(evk.nbytes); d_evk.copy_(torch.from_numpy(evk.view(np.int64)))
     from crcnn_amd.synth import normalize, synth_image
     D = max(1, min(args.distinct, B))
     imgs = [normalize(synth_image(rank * 100003 + i)) for i in range(D)]
     ctw = 2 * E.k * E.n
     src = torch.empty((D, 784 * ctw), dtype=torch.int64, device=dev)
+    x0_sha = None
     for i, im in enumerate(imgs):
         pl, _ = E.encode(im.reshape(-1))
-        ct = E.encrypt(pk, pl, 7000 + 1000 * i)
+        ct = E.encrypt(pk, pl, ENC_SEED + 1000 * i)
+        if i == 0:
+            import hashlib
+            x0_sha = hashlib.sha256(np.ascontiguousarray(ct).tobytes()).hexdigest()
         src[i].copy_(torch.from_numpy(ct.reshape(-1).view(np.int64)))
     # the batch is `D` distinct encrypted images tiled B/D times.  It is materialised in HBM when it fits beside the weights
     # (Tiny: 98 GiB); for the bigger rings (1024 x 784 cts is 294 GiB at n=8192) a window of whole chunks is kept instead and
     # chunk c reads window position c mod window -- the same tiling, the same bytes per image
     img_bytes = 784 * ctw * 8
     free_b, total_b = torch.cuda.mem_get_info(dev)
-    from crcnn_amd.netrun import TOPOLOGIES as _T
-    est_weights = sum((a_.get("nf", 0) * a_.get("zd", 0) * a_.get("xf", 0) * a_.get("yf", 0) + a_.get("in_dim", 0) * a_.get("out_dim", 0)) for _, _, a_ in _T[model]) * E.k * E.n * 8
+    est_weights = sum((a_.get("nf", 0) * a_.get("zd", 0) * a_.get("xf", 0) * a_.get("yf", 0) + a_.get("in_dim", 0) * a_.get("out_dim", 0)) for _, _, a_ in TOPOLOGIES[model]) * E.k * E.n * 8
     budget = max(img_bytes * C, int(0.45 * (free_b - 1.25 * est_weights)))
     step_w = C * D // np.gcd(C, D)                      # window must be a multiple of the chunk and of the tiling period
     window = min(B, max(step_w, (budget // img_bytes) // step_w * step_w)) if budget // img_bytes < B else B
@@ -248,21 +364,41 @@ def main():
         nb = min(D, window - b0); x_all[b0:b0 + nb].copy_(src[:nb])
     del src
 
-    # ---- encoded weights: rank 0 encodes + NTTs, RCCL broadcast to the others
+    # ---- encoded weights: rank 0 encodes + NTTs, RCCL broadcast to the others, every rank checksums what it holds
     net = Network(E, model, weights=W, alloc=alloc, resident=(args.mode == "resident"), d_evk=d_evk, materialize=(rank == 0), fuse_pool=False)
     torch.cuda.synchronize()
-    bcast_s = 0.0
+    bcast = None
     if world > 1:
-        from crcnn_amd import shard
-        dist.barrier(); t0 = time.time()
-        shard.broadcast_buffers([buf for buf, _ in net.param_bufs], src=0, chunk_bytes=1 << 30)      # RCCL over xGMI
-        torch.cuda.synchronize(); bcast_s = time.time() - t0
+        bufs = list(net.param_bufs) + ([(d_evk, d_evk.numel() * 8)] if d_evk is not None else [])
+        nbytes = sum(n_ for _, n_ in bufs)
+        comm = D_.make_comm(E)
+        D_.barrier(); t0 = time.time()
+        if comm is not None:
+            for buf, n_ in bufs:
+                E.broadcast_weights(comm, buf, (n_ + 7) // 8 * 8, root=0)          # crc_broadcast_weights: ncclBroadcast over xGMI, <= 1 GiB pieces
+            via = "crc_broadcast_weights (RCCL through the engine's C ABI)"
+        else:
+            from crcnn_amd import shard
+            shard.broadcast_buffers([buf for buf, _ in bufs], src=0, chunk_bytes=1 << 30)
+            via = f"torch.distributed ({D_.backend}) -- rehearsal backend"
+        torch.cuda.synchronize(); D_.barrier(); bcast_s = time.time() - t0
+        cs = [0, 0]
+        for buf, n_ in bufs:
+            x_, s_ = E.checksum64(buf, n_ // 8 * 8)
+            cs[0] ^= x_; cs[1] = (cs[1] * 0x9E3779B97F4A7C15 + s_) & ((1 << 64) - 1)
+        if comm is not None:
+            allcs = [tuple(int(v) for v in row) for row in E.allgather_u64(comm, cs)]
+            E.comm_destroy(comm)
+        else:
+            allcs = [tuple(c_) for c_ in D_.gather(cs)]
+        bcast = dict(seconds=round(bcast_s, 3), bytes=int(nbytes), GBps=round(nbytes / bcast_s / 1e9, 2), via=via,
+                     xgmi_link_peak_GBps=153.0, checksums_match=f"{sum(1 for c_ in allcs if c_ == allcs[0])}/{world}", checksum=f"{allcs[0][0]:016x}:{allcs[0][1]:016x}")
     net.materialize = True                       # every rank now holds the encoded parameters (needed by fuse())
     out_all = alloc(B * 10 * ctw * 8).view(B, 10 * ctw)
     # ---- reference layer structure first (every CrCNN layer run as its own kernel sequence, NTT-resident): a short pass
     unfused = None
     want_fuse = args.mode == "resident" and not args.no_fuse
-    if want_fuse and args.unfused_images > 0:
+    if want_fuse and full and args.unfused_images > 0:
         nu = min(B, max(C, args.unfused_images // C * C))
         net.prepare(C)
         net.forward(x_all[0], 1); torch.cuda.synchronize()
@@ -303,21 +439,16 @@ def main():
     # untimed module-load pass on a single image (not a step)
     net.forward(x_all[0], 1)
     torch.cuda.synchronize()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step(False)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    D_.barrier()
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        step(s == args.steps - 1)
+    for s in range(steps):
+        step(s == steps - 1)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        from crcnn_amd import shard
-        elapsed = shard.max_over_ranks(elapsed, dev)
+    D_.barrier()
+    elapsed = D_.max(time.perf_counter() - t0)
 
     # ---- per-layer times of the last step (HIP events on the launch stream)
     lay_ms = np.zeros(nl); lay_launch = np.zeros(nl); lay_cnt = np.zeros(nl)
@@ -329,12 +460,16 @@ def main():
                 lay_launch[i] += ms; lay_cnt[i] += 1
     ms_per_layer = {net.plan[i][1]: round(float(lay_ms[i] / B), 4) for i in range(nl)}
 
-    # ---- verification outside the timed region: tiled images give identical outputs; decrypted logits match the plain model
+    # ---- verification outside the timed region: tiled images give identical outputs; decrypted logits match the plain model;
+    # the output ciphertexts of image 0 are, bit for bit, the compiled reference's (golden fixture)
     ok_tile = all(bool(torch.equal(out_all[b], out_all[b % D])) for b in range(D, B, max(1, (B - D) // 16)))
+    ok_fused = True
     if unfused is not None:     # folding pooling into the convolution must not change a single output bit
         fo = unfused.pop("first_outputs")
-        unfused["outputs_identical_to_fused"] = bool(torch.equal(fo, out_all[:fo.shape[0]]))
+        ok_fused = unfused["outputs_identical_to_fused"] = bool(torch.equal(fo, out_all[:fo.shape[0]]))
     outs = out_all[:D].cpu().numpy().view(np.uint64).reshape(D, 10, 2, E.k, E.n)
+    import hashlib
+    gold_ok, gold_name = golden_check(cfg_name, cfg, q, rank, x0_sha, hashlib.sha256(np.ascontiguousarray(outs[0]).tobytes()).hexdigest())
     preds_ok, budgets, max_err = 0, [], 0.0
     for i in range(D):
         dec = E.decrypt(sk, outs[i])
@@ -343,67 +478,91 @@ def main():
         budgets.append(E.noise_budget(sk, outs[i][0]))
         max_err = max(max_err, float(np.abs(logits - want).max()))
         preds_ok += int(np.argmax(logits) == np.argmax(want))
+    mine_ok = bool(ok_tile and ok_fused and preds_ok == D and gold_ok is not False)
+    ranks_ok = D_.sum(int(mine_ok))               # every rank must have verified its own outputs
+    all_ok = ranks_ok == world and (bcast is None or bcast["checksums_match"] == f"{world}/{world}")
 
-    if world > 1:           # every rank must have verified its own outputs
-        from crcnn_amd import shard
-        all_ok = shard.gather_counts(int(ok_tile and preds_ok == D and (unfused is None or unfused["outputs_identical_to_fused"])), dev)
-    else:
-        all_ok = int(ok_tile and preds_ok == D)
-    if rank != 0:
-        dist.destroy_process_group()
-        return
+    result = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: algorithmic bytes per launch / measured duration
+        dom = int(np.argmax(lay_launch))
+        kind, name, a, p, ishape, oshape = net.plan[dom]
+        in_cts, out_cts = int(np.prod(ishape)), int(np.prod(oshape))
+        ct_bytes = 8 * E.k * E.n * 2
+        wbytes = 0
+        if kind == "conv":
+            wbytes = a["nf"] * a["zd"] * a["xf"] * a["yf"] * 8 * E.k * E.n
+        elif kind == "fc":
+            wbytes = a["in_dim"] * a["out_dim"] * 8 * E.k * E.n
+        alg_bytes = C * (in_cts + out_cts) * ct_bytes + wbytes
+        dur_ms = lay_launch[dom] / max(1, lay_cnt[dom])
+        achieved = alg_bytes / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
+        macs_launch = layer_macs(kind, a) * C
+        # HBM traffic of that launch: rocprofv3 PMC passes (FETCH_SIZE corrected x2 for gfx950, WRITE_SIZE) collected OFFLINE with
+        # tools/bench_mac.py and committed under profiles/ -- bench.py cannot run the profiler on itself, so this is not measured in this run
+        traffic, traffic_source = None, None
+        kernel_label = f"mac3_kernel ({name}, {C} images/launch)" if kind in ("conv", "fc") else f"{kind} ({name})"
+        for pf in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", pf))).get(cfg_name)
+                if pm and pm["kernel"] == kernel_label:
+                    traffic = int(pm["traffic_bytes"]); traffic_source = f"profiles/{pf}, offline rocprofv3 --pmc passes of the same launch (not measured in this run)"
+                    break
+            except Exception:
+                pass
+        roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
+                        traffic_source=traffic_source, kernel=kernel_label, launch_ms=round(float(dur_ms), 3), algorithmic_bytes_per_launch=int(alg_bytes),
+                        modmul_per_s=round(macs_launch * 2 * E.k * E.n / (dur_ms * 1e-3), 1) if dur_ms > 0 and macs_launch else None)
+        cpu = None
+        if full and args.cpu_seconds > 0:
+            x0 = x_all[0].cpu().numpy().view(np.uint64).reshape(1, 28, 28, 2, E.k, E.n)
+            cpu = cpu_baseline_reference(cfg, q, W, x0, host_cores()) or cpu_baseline(cfg, q, W, x0, args.cpu_seconds)
+            cpu["value"] = round(cpu["value"], 6); cpu["mac_per_s"] = round(cpu["mac_per_s"], 1)
+        value = B * world * steps / elapsed
+        result = {
+            "metric": "encrypted images/sec", "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": f"synthetic ({D} distinct MNIST-like encrypted images per GPU tiled to the batch" + ("" if window == B else f", resident as a {window}-image window") + f"; trained weights from {model}.h5)",
+            "config": {"workload": f"{model}.h5 n={cfg['n']} k={cfg['k']} t=2^{cfg['t'].bit_length() - 1} batch={B}/GPU chunk={C} ({cfg_name}, BASELINE configs)",
+                       "mode": args.mode + ("+conv/pool folding" if want_fuse else ""), "parallelism": f"image-sharded x{world}, RCCL weight broadcast"},
+            "ms_per_layer": ms_per_layer, "reference_layer_structure": unfused, "roofline": roofline, "cpu_baseline": cpu,
+            "check": {"tiled_outputs_identical": bool(ok_tile), "predictions_match_plain_model": f"{preds_ok}/{D}", "max_logit_abs_err": round(max_err, 6),
+                      "noise_budget_bits": budgets, "ranks_verified": f"{ranks_ok}/{world}", "golden_match": gold_ok, "golden": gold_name, "all_ok": bool(all_ok)},
+            "setup_s": round(setup_s, 1), "weight_broadcast": bcast, "weight_broadcast_s": bcast["seconds"] if bcast else 0.0, "weight_bytes": int(net.weight_bytes),
+        }
+    # give everything back before a second workload
+    del net, x_all, out_all, outs, keep[:]
+    E.sync(); E.close()
+    torch.cuda.empty_cache()
+    return result, bool(all_ok)
 
-    # ---- roofline of the dominant kernel: algorithmic bytes per launch / measured duration
-    dom = int(np.argmax(lay_launch))
-    kind, name, a, p, ishape, oshape = net.plan[dom]
-    in_cts, out_cts = int(np.prod(ishape)), int(np.prod(oshape))
-    ct_bytes = 8 * E.k * E.n * 2
-    wbytes = layer_macs(kind, a) // max(1, out_cts // (a.get("nf", a.get("out_dim", 1)))) * 8 * E.k * E.n if kind in ("conv", "fc") else 0
-    if kind == "conv":
-        wbytes = a["nf"] * a["zd"] * a["xf"] * a["yf"] * 8 * E.k * E.n
-    elif kind == "fc":
-        wbytes = a["in_dim"] * a["out_dim"] * 8 * E.k * E.n
-    alg_bytes = C * (in_cts + out_cts) * ct_bytes + wbytes
-    dur_ms = lay_launch[dom] / max(1, lay_cnt[dom])
-    achieved = alg_bytes / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
-    macs_launch = layer_macs(kind, a) * C
-    # HBM traffic of that launch from rocprofv3 PMC passes (FETCH_SIZE corrected x2 for gfx950, WRITE_SIZE), collected offline with
-    # tools/bench_mac.py and committed under profiles/ -- bench.py cannot run the profiler on itself
-    traffic = None
-    kernel_label = f"mac3_kernel ({name}, {C} images/launch)" if kind in ("conv", "fc") else f"{kind} ({name})"
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))).get(args.config)
-        if pm and pm["kernel"] == kernel_label:
-            traffic = int(pm["traffic_bytes"])
-    except Exception:
-        pass
-    roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
-                    kernel=kernel_label if kind in ("conv", "fc") else f"{kind} ({name})",
-                    launch_ms=round(float(dur_ms), 3), algorithmic_bytes_per_launch=int(alg_bytes),
-                    modmul_per_s=round(macs_launch * 2 * E.k * E.n / (dur_ms * 1e-3), 1) if dur_ms > 0 else None)
 
-    cpu = None
-    if args.cpu_seconds > 0:
-        x0 = x_all[0].cpu().numpy().view(np.uint64).reshape(1, 28, 28, 2, E.k, E.n)
-        cpu = cpu_baseline_reference(cfg, q, W, x0, host_cores()) or cpu_baseline(cfg, q, W, x0, args.cpu_seconds)
-        cpu["value"] = round(cpu["value"], 6); cpu["mac_per_s"] = round(cpu["mac_per_s"], 1)
-
-    total_images = B * world * args.steps
-    value = total_images / elapsed
-    line = {
-        "metric": "encrypted images/sec", "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u64", "data": f"synthetic ({D} distinct MNIST-like encrypted images per GPU tiled to the batch" + ("" if window == B else f", resident as a {window}-image window") + f"; trained weights from {model}.h5)",
-        "config": {"workload": f"{model}.h5 n={cfg['n']} k={cfg['k']} t=2^{cfg['t'].bit_length() - 1} batch={B}/GPU chunk={C} ({args.config}, BASELINE configs)",
-                   "mode": args.mode + ("+conv/pool folding" if want_fuse else ""), "parallelism": f"image-sharded x{world}, RCCL weight broadcast"},
-        "ms_per_layer": ms_per_layer, "reference_layer_structure": unfused, "roofline": roofline, "cpu_baseline": cpu,
-        "check": {"tiled_outputs_identical": bool(ok_tile), "predictions_match_plain_model": f"{preds_ok}/{D}", "max_logit_abs_err": round(max_err, 6),
-                  "noise_budget_bits": budgets, "ranks_verified": f"{all_ok}/{world}"},
-        "setup_s": round(setup_s, 1), "weight_broadcast_s": round(bcast_s, 2), "weight_bytes": int(net.weight_bytes),
-    }
-    print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+def main():
+    args = parse()
+    if args.launch_check:
+        if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+            sys.exit(self_launch(args))
+        sys.exit(launch_check(args))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # plain `python bench.py --gpus N`: start the ranks ourselves
+        sys.exit(self_launch(args))
+    D_ = Dist(args)
+    line, ok = run_config(args, D_, args.config, args.steps, args.warmup, batch=args.batch, chunk=args.chunk, full=True)
+    also = args.also
+    if also == "auto":
+        also = "approx8192" if args.config == "tiny4096" and args.batch is None else "none"
+    if also != "none":
+        second, ok2 = run_config(args, D_, also, args.also_steps, 0, batch=args.also_batch, full=False)
+        ok = ok and ok2
+        if line is not None:
+            line["also"] = [{k_: second[k_] for k_ in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "config", "data", "ms_per_layer", "roofline", "check", "setup_s",
+                                                       "weight_broadcast", "weight_bytes")}]
+    if line is not None:
+        print(json.dumps(line), flush=True)
+    if D_.world > 1:
+        D_.dist.destroy_process_group()
+    if not ok:
+        sys.stderr.write("bench.py: a self-check FAILED (see \"check\"): the reported value is not a valid measurement\n")
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -129,6 +129,22 @@ def load():
     L.crc_encrypt.argtypes = [VP, PU, PU, SZ, u64, PU]
     L.crc_encrypt_dev_work_bytes.restype = SZ; L.crc_encrypt_dev_work_bytes.argtypes = [VP, SZ]
     L.crc_encrypt_dev.argtypes = [VP, VP, VP, SZ, u64, VP, VP, VP]
+    PB = ctypes.POINTER(ctypes.c_uint8)
+    L.crc_random_key.argtypes = [PB]
+    L.crc_chacha20_block.argtypes = [PB, ctypes.c_uint32, PB, PB]
+    L.crc_keygen_key.argtypes = [VP, PB, PU, PU]
+    L.crc_gen_evk_key.argtypes = [VP, PB, PU, CI, PU]
+    L.crc_encrypt_key.argtypes = [VP, PU, PU, SZ, PB, u64, PU]
+    L.crc_encrypt_dev_key.argtypes = [VP, VP, VP, SZ, PB, u64, VP, VP, VP]
+    L.crc_comm_unique_id.argtypes = [PB]
+    L.crc_comm_create.argtypes = [VP, CI, CI, PB, ctypes.POINTER(VP)]
+    L.crc_comm_create_all.argtypes = [ctypes.POINTER(VP), CI, ctypes.POINTER(VP)]
+    L.crc_comm_destroy.argtypes = [VP]; L.crc_comm_destroy.restype = None
+    L.crc_comm_rank.argtypes = [VP]; L.crc_comm_world.argtypes = [VP]
+    L.crc_broadcast_weights.argtypes = [VP, VP, SZ, CI, VP]
+    L.crc_broadcast_weights_all.argtypes = [ctypes.POINTER(VP), CI, ctypes.POINTER(VP), SZ, CI, ctypes.POINTER(VP)]
+    L.crc_comm_allgather_u64.argtypes = [VP, PU, SZ, PU, VP]
+    L.crc_checksum64.argtypes = [VP, VP, SZ, PU, VP]
     L.crc_decrypt.argtypes = [VP, PU, PU, SZ, CI, PU]
     L.crc_noise_budget.argtypes = [VP, PU, PU, CI]
     _lib = L
@@ -269,6 +285,32 @@ class Engine:
         _chk(self.L.crc_encrypt(self.c, _pu(pk), _pu(plains.reshape(cnt, self.n)), cnt, seed, _pu(ct)), "crc_encrypt")
         return ct.reshape(lead + (2, self.k, self.n))
 
+    # key-based client side (ChaCha20 under a 256-bit key; `key` = 32 bytes, random_key() draws it from the OS)
+    @staticmethod
+    def _key(key):
+        key = bytes(key)
+        assert len(key) == 32
+        return (ctypes.c_uint8 * 32).from_buffer_copy(key)
+
+    def random_key(self):
+        buf = (ctypes.c_uint8 * 32)()
+        _chk(self.L.crc_random_key(buf), "crc_random_key"); return bytes(buf)
+
+    def keygen_key(self, key):
+        sk = np.zeros((self.k, self.n), dtype=np.uint64); pk = np.zeros((2, self.k, self.n), dtype=np.uint64)
+        _chk(self.L.crc_keygen_key(self.c, self._key(key), _pu(sk), _pu(pk)), "crc_keygen_key"); return sk, pk
+
+    def gen_evk_key(self, key, sk, dbc=16):
+        evk = np.zeros(self.L.crc_evk_words(self.c, dbc), dtype=np.uint64)
+        _chk(self.L.crc_gen_evk_key(self.c, self._key(key), _pu(sk), dbc, _pu(evk)), "crc_gen_evk_key"); return evk
+
+    def encrypt_key(self, pk, plains, key, stream_base=0):
+        plains = np.ascontiguousarray(plains); lead = plains.shape[:-1]
+        cnt = int(np.prod(lead)) if lead else 1
+        ct = np.zeros((cnt, 2, self.k, self.n), dtype=np.uint64)
+        _chk(self.L.crc_encrypt_key(self.c, _pu(pk), _pu(plains.reshape(cnt, self.n)), cnt, self._key(key), stream_base, _pu(ct)), "crc_encrypt_key")
+        return ct.reshape(lead + (2, self.k, self.n))
+
     def decrypt(self, sk, cts, size=2):
         cts = np.ascontiguousarray(cts); lead = cts.shape[:-3]
         cnt = int(np.prod(lead)) if lead else 1
@@ -361,6 +403,38 @@ class Engine:
 
     def encrypt_dev(self, d_pk, d_plain, count, seed, d_ct, d_work):
         _chk(self.L.crc_encrypt_dev(self.c, self.p(d_pk), self.p(d_plain), count, seed, self.p(d_ct), self.p(d_work), self.stream), "crc_encrypt_dev")
+
+    def encrypt_dev_key(self, d_pk, d_plain, count, key, stream_base, d_ct, d_work):
+        _chk(self.L.crc_encrypt_dev_key(self.c, self.p(d_pk), self.p(d_plain), count, self._key(key), stream_base, self.p(d_ct), self.p(d_work), self.stream), "crc_encrypt_dev_key")
+
+    # ---- multi-GPU: RCCL communicator bound to this context's device
+    def comm_unique_id(self):
+        buf = (ctypes.c_uint8 * 128)()
+        _chk(self.L.crc_comm_unique_id(buf), "crc_comm_unique_id"); return bytes(buf)
+
+    def comm_create(self, world, rank, uid):
+        assert len(uid) == 128
+        out = VP()
+        _chk(self.L.crc_comm_create(self.c, world, rank, (ctypes.c_uint8 * 128).from_buffer_copy(bytes(uid)), ctypes.byref(out)), "crc_comm_create")
+        return out
+
+    def comm_destroy(self, comm):
+        self.L.crc_comm_destroy(comm)
+
+    def broadcast_weights(self, comm, d_w, nbytes, root=0):
+        assert nbytes % 8 == 0
+        _chk(self.L.crc_broadcast_weights(comm, self.p(d_w), nbytes // 8, root, self.stream), "crc_broadcast_weights")
+
+    def allgather_u64(self, comm, values):
+        v = np.ascontiguousarray(values, dtype=np.uint64)
+        out = np.zeros((self.L.crc_comm_world(comm), v.size), dtype=np.uint64)
+        _chk(self.L.crc_comm_allgather_u64(comm, _pu(v), v.size, _pu(out), self.stream), "crc_comm_allgather_u64")
+        return out
+
+    def checksum64(self, d_words, nbytes):
+        out = np.zeros(2, dtype=np.uint64)
+        _chk(self.L.crc_checksum64(self.c, self.p(d_words), nbytes // 8, _pu(out), self.stream), "crc_checksum64")
+        return int(out[0]), int(out[1])
 
     def square(self, d_x, count, d_y3, d_work):
         _chk(self.L.crc_square(self.c, self.p(d_x), count, self.p(d_y3), self.p(d_work), self.stream), "crc_square")

@@ -1,5 +1,6 @@
 // abi.hip -- extern "C" entry points of include/crcnn_hip.h that drive the kernels (layers and Evaluator ops).
 #include "kernels.h"
+#include "chacha.h"
 
 #define CHECK_CTX(c) do { if (!(c) || (c)->device < 0) return CRC_ERR_INVALID_ARGUMENT; } while (0)
 #define RUN(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
@@ -199,11 +200,18 @@ extern "C" size_t crc_square_relin_work_bytes(const crc_ctx *c, size_t count, in
     return 8 * ((sq > rl ? sq : rl) + ch * crc_ct_words(c, 3)) + 256;
 }
 extern "C" size_t crc_encrypt_dev_work_bytes(const crc_ctx *c, size_t count) { return c ? 8 * k_encrypt_work_words(c, count) + 256 : 0; }
+extern "C" int crc_encrypt_dev_key(crc_ctx *c, const uint64_t *d_pk, const uint64_t *d_plain, size_t count, const uint8_t *key, uint64_t stream_base,
+                                   uint64_t *d_ct, void *d_work, void *stream)
+{
+    CHECK_CTX(c); if (!d_pk || !d_plain || !d_ct || !d_work || !key) return CRC_ERR_INVALID_ARGUMENT;
+    u64 *w = (u64 *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
+    return k_encrypt(c, d_pk, d_plain, count, chacha_load_key(key), stream_base, d_ct, w, S(stream));
+}
 extern "C" int crc_encrypt_dev(crc_ctx *c, const uint64_t *d_pk, const uint64_t *d_plain, size_t count, uint64_t seed, uint64_t *d_ct, void *d_work, void *stream)
 {
     CHECK_CTX(c); if (!d_pk || !d_plain || !d_ct || !d_work) return CRC_ERR_INVALID_ARGUMENT;
     u64 *w = (u64 *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
-    return k_encrypt(c, d_pk, d_plain, count, seed, d_ct, w, S(stream));
+    return k_encrypt(c, d_pk, d_plain, count, chacha_seed_key(seed), 0, d_ct, w, S(stream));
 }
 extern "C" int crc_square(crc_ctx *c, const uint64_t *d_x, size_t count, uint64_t *d_y3, void *d_work, void *stream)
 {

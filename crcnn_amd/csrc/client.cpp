@@ -3,22 +3,23 @@
 // Outside the accelerated path (needs the secret key) but part of what a CrCNN user calls around it:
 // setParameters / encryptImage / decryptImage (CrCNN/src/globals.cpp:25-56,127-157,207-230) over SEAL's KeyGenerator
 // (keygenerator.cpp:96-282), Encryptor (encryptor.cpp:71-134) and Decryptor (decryptor.cpp:107-236, BEHZ gamma rounding).
-// Randomness: seeded xoshiro256** (SEAL uses std::random_device, so no bit pattern is defined by the reference).
+// Randomness: ChaCha20 keystreams (chacha.h) under a 256-bit key -- crc_random_key() draws it from the OS (getrandom(2)); the
+// uint64 "seed" entry points expand a public seed and exist for tests / bench / goldens only.  SEAL draws from std::random_device,
+// so the reference defines sampling laws, not bits.
 #include "ctx.h"
+#include "chacha.h"
 #include <cmath>
 #include <cstring>
 #include <vector>
+#include <cerrno>
+#include <sys/random.h>
 
 typedef unsigned __int128 u128;
 
 namespace {
-struct Rng {
-    u64 s[4];
-    explicit Rng(u64 seed) { for (auto &x : s) { seed += 0x9E3779B97F4A7C15ULL; u64 z = seed; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; x = z ^ (z >> 31); } }
-    static u64 rotl(u64 x, int k) { return (x << k) | (x >> (64 - k)); }
-    u64 next() { u64 r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17; s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45); return r; }
-    double unit() { return ((double)(next() >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
-};
+typedef ChaChaStream Rng;                                 // 64-bit words of a ChaCha20 keystream (chacha.h)
+ChaChaKey load_key(const uint8_t *key) { return chacha_load_key(key); }
+ChaChaKey seed_key(u64 seed) { return chacha_seed_key(seed); }
 
 void ternary(const crc_ctx *c, Rng &r, u64 *p)            // uniform over {-1,0,1}^n in RNS form
 {
@@ -67,11 +68,33 @@ void dot_secret(const crc_ctx *c, const u64 *sk, const u64 *ct, int size, u64 *v
 }
 }  // namespace
 
-extern "C" int crc_keygen(const crc_ctx *c, uint64_t seed, uint64_t *sk, uint64_t *pk)
+// known-answer access to the generator (RFC 8439 section 2.3.2 test vector; tests/test_client_rng.py)
+extern "C" int crc_chacha20_block(const uint8_t *key, uint32_t counter, const uint8_t *nonce, uint8_t *out)
 {
-    if (!c || !sk || !pk) return CRC_ERR_INVALID_ARGUMENT;
+    if (!key || !nonce || !out) return CRC_ERR_INVALID_ARGUMENT;
+    u32 nw[3], o[16];
+    for (int i = 0; i < 3; i++) nw[i] = (u32)nonce[4 * i] | ((u32)nonce[4 * i + 1] << 8) | ((u32)nonce[4 * i + 2] << 16) | ((u32)nonce[4 * i + 3] << 24);
+    chacha20_block(load_key(key), counter, nw[0], nw[1], nw[2], o);
+    for (int i = 0; i < 16; i++) { out[4 * i] = (uint8_t)o[i]; out[4 * i + 1] = (uint8_t)(o[i] >> 8); out[4 * i + 2] = (uint8_t)(o[i] >> 16); out[4 * i + 3] = (uint8_t)(o[i] >> 24); }
+    return CRC_OK;
+}
+
+extern "C" int crc_random_key(uint8_t *key)
+{
+    if (!key) return CRC_ERR_INVALID_ARGUMENT;
+    size_t got = 0;
+    while (got < CRC_KEY_BYTES) {
+        const ssize_t r = getrandom(key + got, CRC_KEY_BYTES - got, 0);
+        if (r < 0) { if (errno == EINTR) continue; return CRC_ERR_IO; }
+        got += (size_t)r;
+    }
+    return CRC_OK;
+}
+
+static int keygen_impl(const crc_ctx *c, const ChaChaKey &key, uint64_t *sk, uint64_t *pk)
+{
     const int n = c->n, k = c->k;
-    Rng r(seed);
+    Rng r(key, 0, 0, (u32)CHACHA_DOM_KEYGEN << 24);
     std::vector<u64> e((size_t)k * n);
     ternary(c, r, sk); uniform(c, r, pk + (size_t)k * n); gauss(c, r, e.data());
     for (int i = 0; i < k; i++) {
@@ -84,12 +107,22 @@ extern "C" int crc_keygen(const crc_ctx *c, uint64_t seed, uint64_t *sk, uint64_
     }
     return CRC_OK;
 }
-
-extern "C" int crc_gen_evk(const crc_ctx *c, uint64_t seed, const uint64_t *sk, int dbc, uint64_t *evk)
+extern "C" int crc_keygen_key(const crc_ctx *c, const uint8_t *key, uint64_t *sk, uint64_t *pk)
 {
-    if (!c || !sk || !evk || dbc < 1 || dbc > 60) return CRC_ERR_INVALID_ARGUMENT;
+    if (!c || !key || !sk || !pk) return CRC_ERR_INVALID_ARGUMENT;
+    return keygen_impl(c, load_key(key), sk, pk);
+}
+extern "C" int crc_keygen(const crc_ctx *c, uint64_t seed, uint64_t *sk, uint64_t *pk)
+{
+    if (!c || !sk || !pk) return CRC_ERR_INVALID_ARGUMENT;
+    return keygen_impl(c, seed_key(seed), sk, pk);
+}
+
+static int gen_evk_impl(const crc_ctx *c, const ChaChaKey &ckey, const uint64_t *sk, int dbc, uint64_t *evk)
+{
+    if (dbc < 1 || dbc > 60) return CRC_ERR_INVALID_ARGUMENT;
     const int n = c->n, k = c->k;
-    Rng r(seed ^ 0x5851F42D4C957F2DULL);
+    Rng r(ckey, 0, 0, (u32)CHACHA_DOM_EVK << 24);
     std::vector<u64> s2((size_t)k * n), e((size_t)k * n);
     for (int j = 0; j < k; j++) for (int s = 0; s < n; s++) { const size_t o = (size_t)j * n + s; s2[o] = h_mulmod(sk[o], sk[o], c->q[j]); }
     u64 *key = evk;
@@ -116,14 +149,24 @@ extern "C" int crc_gen_evk(const crc_ctx *c, uint64_t seed, const uint64_t *sk, 
     }
     return CRC_OK;
 }
-
-extern "C" int crc_encrypt(const crc_ctx *c, const uint64_t *pk, const uint64_t *plain, size_t count, uint64_t seed, uint64_t *ct)
+extern "C" int crc_gen_evk_key(const crc_ctx *c, const uint8_t *key, const uint64_t *sk, int dbc, uint64_t *evk)
 {
-    if (!c || !pk || !plain || !ct) return CRC_ERR_INVALID_ARGUMENT;
+    if (!c || !key || !sk || !evk) return CRC_ERR_INVALID_ARGUMENT;
+    return gen_evk_impl(c, load_key(key), sk, dbc, evk);
+}
+extern "C" int crc_gen_evk(const crc_ctx *c, uint64_t seed, const uint64_t *sk, int dbc, uint64_t *evk)
+{
+    if (!c || !sk || !evk) return CRC_ERR_INVALID_ARGUMENT;
+    return gen_evk_impl(c, seed_key(seed), sk, dbc, evk);
+}
+
+static int encrypt_impl(const crc_ctx *c, const uint64_t *pk, const uint64_t *plain, size_t count, const ChaChaKey &key, uint64_t stream_base, uint64_t *ct)
+{
     const int n = c->n, k = c->k;
     std::vector<u64> u((size_t)k * n), e((size_t)k * n);
     for (size_t m = 0; m < count; m++) {
-        Rng r(seed + m * 0x9E3779B97F4A7C15ULL);
+        const u64 sid = stream_base + m;                  // one keystream per ciphertext
+        Rng r(key, (u32)sid, (u32)(sid >> 32), (u32)CHACHA_DOM_ENC_HOST << 24);
         u64 *o = ct + m * 2 * (size_t)k * n; const u64 *pl = plain + m * (size_t)n;
         ternary(c, r, u.data());
         for (int i = 0; i < k; i++) {
@@ -142,6 +185,16 @@ extern "C" int crc_encrypt(const crc_ctx *c, const uint64_t *pk, const uint64_t 
         }
     }
     return CRC_OK;
+}
+extern "C" int crc_encrypt_key(const crc_ctx *c, const uint64_t *pk, const uint64_t *plain, size_t count, const uint8_t *key, uint64_t stream_base, uint64_t *ct)
+{
+    if (!c || !pk || !plain || !ct || !key) return CRC_ERR_INVALID_ARGUMENT;
+    return encrypt_impl(c, pk, plain, count, load_key(key), stream_base, ct);
+}
+extern "C" int crc_encrypt(const crc_ctx *c, const uint64_t *pk, const uint64_t *plain, size_t count, uint64_t seed, uint64_t *ct)
+{
+    if (!c || !pk || !plain || !ct) return CRC_ERR_INVALID_ARGUMENT;
+    return encrypt_impl(c, pk, plain, count, seed_key(seed), 0, ct);
 }
 
 extern "C" int crc_decrypt(const crc_ctx *c, const uint64_t *sk, const uint64_t *ct, size_t count, int size, uint64_t *plain)

@@ -1,0 +1,154 @@
+// comm.hip -- the one collective of the evaluation path: start-up broadcast of the encoded (NTT-form) weights and the
+// evaluation keys over RCCL (xGMI inside a node), plus the small helpers a multi-GPU driver needs to verify it.
+//
+// images are independent, so a batch shards over the GPUs with no data-path collective.  Rank `root` encodes the
+// model once (lift + NTT of ~0.5 M plaintexts, 35-200 GiB), everybody else receives it with ncclBroadcast.  xGMI is
+// point-to-point (7 links x ~153 GB/s per GPU) and RCCL's broadcast is a ring/tree of per-link transfers, so a few large
+// messages are what we want: pieces of 1 GiB keep RCCL's staging small and its pipelining busy.  The reference has no
+// analogue (its only parallelism is the std::thread fan-out of convolutionalLayer.cpp:177-191).
+#include "kernels.h"
+#include <rccl/rccl.h>
+#include <cstring>
+#include <vector>
+
+struct crc_comm {
+    ncclComm_t comm = nullptr;
+    int world = 1, rank = 0, device = 0;
+    u64 *d_scratch = nullptr;                     // [kScratchWords * (world + 1)]: all-gather send + receive staging
+};
+
+static const size_t kPieceWords = (size_t)1 << 27;     // 1 GiB
+static const size_t kScratchWords = 64;                // per-rank payload limit of crc_comm_allgather_u64
+
+static thread_local int g_last_nccl = 0;
+extern "C" int crc_last_comm_error(void) { return g_last_nccl; }
+#define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { g_last_nccl = (int)r_; return CRC_ERR_COMM; } } while (0)
+
+static_assert(sizeof(ncclUniqueId) == CRC_COMM_ID_BYTES, "rendezvous id size");
+
+extern "C" int crc_comm_unique_id(uint8_t *h_id)
+{
+    if (!h_id) return CRC_ERR_INVALID_ARGUMENT;
+    ncclUniqueId id;
+    NCCLCHK(ncclGetUniqueId(&id));
+    std::memcpy(h_id, &id, sizeof id);
+    return CRC_OK;
+}
+
+static int comm_finish(crc_comm *cm)
+{
+    HIPCHK(hipSetDevice(cm->device));
+    HIPCHK(hipMalloc((void **)&cm->d_scratch, kScratchWords * (size_t)(cm->world + 1) * 8));
+    return CRC_OK;
+}
+
+extern "C" int crc_comm_create(crc_ctx *c, int world, int rank, const uint8_t *h_id, crc_comm **out)
+{
+    if (!c || c->device < 0 || !h_id || !out || world < 1 || rank < 0 || rank >= world) return CRC_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(c->device));
+    ncclUniqueId id; std::memcpy(&id, h_id, sizeof id);
+    crc_comm *cm = new crc_comm(); cm->world = world; cm->rank = rank; cm->device = c->device;
+    ncclResult_t r = ncclCommInitRank(&cm->comm, world, id, rank);
+    if (r != ncclSuccess) { g_last_nccl = (int)r; delete cm; return CRC_ERR_COMM; }
+    const int rc = comm_finish(cm);
+    if (rc) { crc_comm_destroy(cm); return rc; }
+    *out = cm;
+    return CRC_OK;
+}
+
+extern "C" int crc_comm_create_all(crc_ctx *const *ctxs, int ndev, crc_comm **out)
+{
+    if (!ctxs || !out || ndev < 1) return CRC_ERR_INVALID_ARGUMENT;
+    std::vector<int> devs(ndev);
+    for (int i = 0; i < ndev; i++) {
+        if (!ctxs[i] || ctxs[i]->device < 0) return CRC_ERR_INVALID_ARGUMENT;
+        devs[i] = ctxs[i]->device;
+        for (int j = 0; j < i; j++) if (devs[j] == devs[i]) return CRC_ERR_INVALID_ARGUMENT;      // one rank per GPU
+    }
+    std::vector<ncclComm_t> comms(ndev);
+    NCCLCHK(ncclCommInitAll(comms.data(), ndev, devs.data()));
+    for (int i = 0; i < ndev; i++) {
+        crc_comm *cm = new crc_comm(); cm->comm = comms[i]; cm->world = ndev; cm->rank = i; cm->device = devs[i];
+        out[i] = cm;
+        const int rc = comm_finish(cm);
+        if (rc) { for (int j = 0; j <= i; j++) { crc_comm_destroy(out[j]); out[j] = nullptr; } for (int j = i + 1; j < ndev; j++) ncclCommDestroy(comms[j]); return rc; }
+    }
+    return CRC_OK;
+}
+
+extern "C" void crc_comm_destroy(crc_comm *cm)
+{
+    if (!cm) return;
+    (void)hipSetDevice(cm->device);
+    if (cm->d_scratch) (void)hipFree(cm->d_scratch);
+    if (cm->comm) ncclCommDestroy(cm->comm);
+    delete cm;
+}
+extern "C" int crc_comm_rank(const crc_comm *cm) { return cm ? cm->rank : CRC_ERR_INVALID_ARGUMENT; }
+extern "C" int crc_comm_world(const crc_comm *cm) { return cm ? cm->world : CRC_ERR_INVALID_ARGUMENT; }
+
+extern "C" int crc_broadcast_weights(crc_comm *cm, uint64_t *d_w, size_t words, int root, void *stream)
+{
+    if (!cm || (!d_w && words) || root < 0 || root >= cm->world) return CRC_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(cm->device));
+    for (size_t o = 0; o < words; o += kPieceWords) {
+        const size_t cnt = words - o < kPieceWords ? words - o : kPieceWords;
+        NCCLCHK(ncclBroadcast(d_w + o, d_w + o, cnt, ncclUint64, root, cm->comm, (hipStream_t)stream));
+    }
+    return CRC_OK;
+}
+
+extern "C" int crc_broadcast_weights_all(crc_comm *const *comms, int ndev, uint64_t *const *d_w, size_t words, int root, void *const *streams)
+{
+    if (!comms || !d_w || ndev < 1 || root < 0 || root >= ndev) return CRC_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < ndev; i++) if (!comms[i] || comms[i]->world != ndev || (!d_w[i] && words)) return CRC_ERR_INVALID_ARGUMENT;
+    for (size_t o = 0; o < words; o += kPieceWords) {
+        const size_t cnt = words - o < kPieceWords ? words - o : kPieceWords;
+        NCCLCHK(ncclGroupStart());                 // one thread drives every rank: the calls of a piece must be grouped
+        for (int i = 0; i < ndev; i++) {
+            ncclResult_t r = ncclBroadcast(d_w[i] + o, d_w[i] + o, cnt, ncclUint64, root, comms[i]->comm, streams ? (hipStream_t)streams[i] : nullptr);
+            if (r != ncclSuccess) { g_last_nccl = (int)r; ncclGroupEnd(); return CRC_ERR_COMM; }
+        }
+        NCCLCHK(ncclGroupEnd());
+    }
+    return CRC_OK;
+}
+
+extern "C" int crc_comm_allgather_u64(crc_comm *cm, const uint64_t *h_in, size_t words, uint64_t *h_out, void *stream)
+{
+    if (!cm || !h_in || !h_out || words == 0 || words > kScratchWords) return CRC_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(cm->device));
+    hipStream_t st = (hipStream_t)stream;
+    u64 *send = cm->d_scratch, *recv = cm->d_scratch + kScratchWords;
+    HIPCHK(hipMemcpyAsync(send, h_in, words * 8, hipMemcpyHostToDevice, st));
+    NCCLCHK(ncclAllGather(send, recv, words, ncclUint64, cm->comm, st));
+    HIPCHK(hipMemcpyAsync(h_out, recv, words * 8 * (size_t)cm->world, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return CRC_OK;
+}
+
+// ---- checksum of a device buffer (what a receiving rank compares with the root's) -------------------------------------
+__global__ void __launch_bounds__(256) checksum_kernel(const u64 *w, size_t words, u64 *out)
+{
+    u64 x = 0, s = 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += stride) { const u64 v = w[i]; x ^= v; s += v * (2 * (u64)i + 1); }
+    for (int off = 32; off > 0; off >>= 1) { x ^= __shfl_down(x, off, 64); s += __shfl_down(s, off, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicXor((unsigned long long *)&out[0], (unsigned long long)x); atomicAdd((unsigned long long *)&out[1], (unsigned long long)s); }
+}
+
+extern "C" int crc_checksum64(crc_ctx *c, const uint64_t *d_words, size_t words, uint64_t *h_out, void *stream)
+{
+    if (!c || c->device < 0 || !h_out || (!d_words && words)) return CRC_ERR_INVALID_ARGUMENT;
+    hipStream_t st = (hipStream_t)stream;
+    u64 *acc = c->d_scratch;                       // context scratch: one checksum at a time per context
+    HIPCHK(hipMemsetAsync(acc, 0, 16, st));
+    if (words) {
+        size_t blocks = (words + 255) / 256; if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(checksum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_words, words, acc);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpyAsync(h_out, acc, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return CRC_OK;
+}

@@ -21,6 +21,7 @@ extern "C" const char *crc_strerror(int s)
     case CRC_ERR_UNSUPPORTED: return "unsupported parameter combination";
     case CRC_ERR_IO: return "I/O error";
     case CRC_ERR_NOT_FOUND: return "not found";
+    case CRC_ERR_COMM: return "RCCL error";
     }
     return "unknown status";
 }
@@ -47,7 +48,7 @@ ModParams make_mod(u64 q)
     u128 all = ~(u128)0, quo = all / q;
     if (all % q + 1 == q) quo += 1;                // q | 2^128 (m~ = 2^32)
     m.q = q; m.r0 = (u64)quo; m.r1 = (u64)(quo >> 64); m.two_q = 2 * q; m.bits = (u32)sigbits(q);
-    { const u64 d = m.bits >= 40 && m.bits <= 62 ? ((u64)1 << m.bits) - q : 0; m.fold = d && d < (1u << 26) && !getenv("CRC_NO_FOLD") ? (u32)d : 0; }
+    m.fold = getenv("CRC_NO_FOLD") ? 0 : fold_constant(q, m.bits);
     return m;
 }
 
@@ -279,13 +280,16 @@ extern "C" int crc_ctx_create(int n, const uint64_t *q, int k, uint64_t t, int d
         }
         if ((e = hipMalloc(&c->d_mods, sizeof(ModParams) * nm)) != hipSuccess || (e = hipMalloc(&c->d_rp, tw)) != hipSuccess ||
             (e = hipMalloc(&c->d_irp2, tw)) != hipSuccess || (e = hipMalloc(&c->d_behz, sizeof(BehzParams))) != hipSuccess ||
-            (e = hipMalloc(&c->d_zero, 4096)) != hipSuccess || (e = hipMemset(c->d_zero, 0, 4096)) != hipSuccess ||
+            (e = hipMalloc(&c->d_zero, 8192)) != hipSuccess || (e = hipMemset(c->d_zero, 0, 8192)) != hipSuccess ||
             (e = hipMemcpy(c->d_mods, mods.data(), sizeof(ModParams) * nm, hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(c->d_rp, rp.data(), tw, hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(c->d_irp2, irp2.data(), tw, hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(c->d_behz, &c->behz, sizeof(BehzParams), hipMemcpyHostToDevice)) != hipSuccess) {
             fail(e); crc_ctx_destroy(c); return rc;
         }
+        c->d_scratch = c->d_zero + 512;
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->cus = cus;
     }
     *out = c;
     return CRC_OK;
@@ -298,6 +302,18 @@ extern "C" void crc_ctx_destroy(crc_ctx *c)
         (void)hipFree(c->d_mods); (void)hipFree(c->d_rp); (void)hipFree(c->d_irp2); (void)hipFree(c->d_behz); (void)hipFree(c->d_zero);
     }
     delete c;
+}
+
+// raise a kernel's dynamic-LDS limit (needed above 64 KiB) once per (context = device, kernel)
+int crc_ctx_ensure_lds(crc_ctx *c, const void *kernel, size_t lds_bytes)
+{
+    if (lds_bytes <= 64 * 1024) return CRC_OK;
+    std::lock_guard<std::mutex> g(c->attr_mu);
+    auto it = c->lds_attr.find(kernel);
+    if (it != c->lds_attr.end() && it->second >= lds_bytes) return CRC_OK;
+    HIPCHK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    c->lds_attr[kernel] = lds_bytes;
+    return CRC_OK;
 }
 
 extern "C" int crc_ctx_n(const crc_ctx *c) { return c->n; }

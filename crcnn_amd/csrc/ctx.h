@@ -5,6 +5,8 @@
 // MI355X-first: one flat table set in HBM, indexed by "modulus index" mi (0..k-1 = q_i, k..k+kb-1 = Bsk_j).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 #include "modarith.h"
 #include "../../include/crcnn_hip.h"
@@ -69,8 +71,14 @@ struct crc_ctx {
     ModParams *d_mods = nullptr;             // [k+kb]
     u64 *d_rp = nullptr, *d_irp2 = nullptr;   // [(k+kb)][n][2]: {bit-reversed root power, its Shoup companion} (forward / inverse-div-2)
     BehzParams *d_behz = nullptr;
-    u64 *d_zero = nullptr;                   // 4 KiB of zeros (source row of reduction terms past T in mac3_kernel)
+    u64 *d_zero = nullptr;                   // 4 KiB of zeros (source row of reduction terms past T in mac3_kernel) + 4 KiB context scratch
+    u64 *d_scratch = nullptr;                // = d_zero + 512 words (crc_checksum64 accumulators)
+    int cus = 256;                           // compute units of THIS context's device
+    // kernels whose dynamic-LDS limit has been raised on this context's device (hipFuncSetAttribute is a driver call: once, not per launch)
+    std::mutex attr_mu;
+    std::unordered_map<const void *, size_t> lds_attr;
 };
+int crc_ctx_ensure_lds(crc_ctx *c, const void *kernel, size_t lds_bytes);
 
 int  crc_set_hip_error(hipError_t e);
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return crc_set_hip_error(e_); } while (0)

@@ -24,4 +24,5 @@ int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, co
 int k_fold_pool(crc_ctx *c, const u64 *w, const u64 *bias, const u64 *div, u64 *wout, u64 *bout, int nf, int zd, int xf, int yf, int cxs, int cys,
                 int pxf, int pyf, hipStream_t st);
 size_t k_encrypt_work_words(const crc_ctx *c, size_t cnt);
-int k_encrypt(crc_ctx *c, const u64 *pk, const u64 *plain, size_t cnt, u64 seed, u64 *ct, u64 *work, hipStream_t st);
+struct ChaChaKey;
+int k_encrypt(crc_ctx *c, const u64 *pk, const u64 *plain, size_t cnt, const ChaChaKey &key, u64 stream_base, u64 *ct, u64 *work, hipStream_t st);

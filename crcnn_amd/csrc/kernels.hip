@@ -175,17 +175,17 @@ static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t
     // reference's parameter sets qualifies (54..55 bits), the 61-bit auxiliary base of Square does not
     bool lazy = true;
     for (int i = a.mod_base; i < a.mod_base + a.mod_count; i++) if (c->tabs[i].m.bits > 57 || c->tabs[i].m.bits < 45) lazy = false;
-    static const int cus = [] { int dev = 0, v = 256; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 256; return v > 0 ? v : 256; }();
+    const int cus = c->cus;
     if (c->n / nt == 16 && rows > (size_t)cus) {     // n = 16384: one resident workgroup per CU, prefetching the next row
         a.rows = rows;
         auto pk = inv ? (lazy ? ntt_rows_prefetch_kernel<true, true> : ntt_rows_prefetch_kernel<true, false>) : (lazy ? ntt_rows_prefetch_kernel<false, true> : ntt_rows_prefetch_kernel<false, false>);
-        HIPCHK(hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { const int rc = crc_ctx_ensure_lds(c, (const void *)pk, lds); if (rc) return rc; }
         hipLaunchKernelGGL(pk, dim3((unsigned)cus), dim3(nt), lds, st, a);
         HIPCHK(hipGetLastError());
         return CRC_OK;
     }
     auto kern = inv ? (lazy ? ntt_rows_kernel<true, true> : ntt_rows_kernel<true, false>) : (lazy ? ntt_rows_kernel<false, true> : ntt_rows_kernel<false, false>);
-    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { const int rc = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (rc) return rc; }
     hipLaunchKernelGGL(kern, dim3((unsigned)rows), dim3(nt), lds, st, a);
     HIPCHK(hipGetLastError());
     return CRC_OK;
@@ -428,7 +428,10 @@ struct MacArgs {
     const u64 *bias; int bias_sign;          // optional NTT-form delta bias [F][k][n] added to poly 0
     int mt_fastest;                          // tile walk order (see the kernels)
     int xp, wp, yp;                          // x / w arrive packed (28-bit limb pairs), y leaves packed
-    int dbg;                                 // tuning only: 1 = skip operand staging (timing of the bare MAC loop), 2 = skip barriers too
+#ifdef CRC_TUNING
+    int dbg;                                 // -DCRC_TUNING builds only (make tuning; tools/bench_mac.py): ablation switches of mac2_kernel that give
+                                             // WRONG results (1 = skip operand staging, 2 = skip barriers too, ...).  The shipped library has none.
+#endif
     const u64 *zero;                         // >= 1 KiB of zeros (mac3: source of the terms past T)
     int gxd, gyd, gxf, gyf;                  // window geometry: toff[t] = (z*gxd + kx)*gyd + ky for t = (z*gxf + kx)*gyf + ky
 };
@@ -443,6 +446,12 @@ __device__ __forceinline__ u64 split28(u64 r)
 // inverse: the canonical residue of a packed value.  "Packed" (CRC_NTTP) is how the MAC kernels want their operands: weights and the
 // NTT-resident tensors that travel from one conv / dense layer to the next are kept in this form so that nobody has to split them again
 __device__ __forceinline__ u64 unsplit28(u64 p) { return (p & 0xffffffffULL) | ((p >> 32) << 28); }
+
+#ifdef CRC_TUNING
+#define MAC_DBG (a.dbg)
+#else
+#define MAC_DBG 0
+#endif
 
 template <int PT, int FT>
 __global__ void __launch_bounds__(256) mac_kernel(MacArgs a)
@@ -633,19 +642,19 @@ __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_
         if (pr < NPAIR) *reinterpret_cast<ulonglong2 *>(dst + (2 * pr + half) * 64 + l2) = v;     // one ds_write_b128: two adjacent slots of one vector
     };
     auto load_stage = [&](int st, ulonglong2 (&reg)[RLOAD / 2]) {
-        if (st > 1 && (a.dbg == 1 || a.dbg == 2 || a.dbg == 4)) return;
+        if (st > 1 && (MAC_DBG == 1 || MAC_DBG == 2 || MAC_DBG == 4)) return;
 #pragma unroll
-        for (int jj = 0; jj < RLOAD / 2; jj++) { if (a.dbg == 7 && st > 1 && (jj & 1)) continue; load_one(st, jj, reg); }
+        for (int jj = 0; jj < RLOAD / 2; jj++) { if (MAC_DBG == 7 && st > 1 && (jj & 1)) continue; load_one(st, jj, reg); }
     };
     auto store_stage = [&](int st, ulonglong2 (&reg)[RLOAD / 2]) {
-        if (st > 1 && (a.dbg == 1 || a.dbg == 2 || a.dbg == 3)) return;
+        if (st > 1 && (MAC_DBG == 1 || MAC_DBG == 2 || MAC_DBG == 3)) return;
 #pragma unroll
         for (int jj = 0; jj < RLOAD / 2; jj++) store_pair(st, jj, reg);
     };
     // the staging traffic of a stage (LDS writes of stage st+1, global loads of stage st+2) is issued INSIDE the compute of stage
     // st, at a different reduction step in the two waves that share a SIMD (waves w and w+4): while one wave issues its memory
     // instructions the other one has multiply-adds to issue, instead of all eight waves staging at the same moment
-    const int io_sel = a.dbg == 8 ? (wave & 1) : a.dbg == 9 ? 0 : ((wave >> 2) & 1);     // dbg 8/9: tuning controls (tools/bench_mac.py)
+    const int io_sel = MAC_DBG == 8 ? (wave & 1) : MAC_DBG == 9 ? 0 : ((wave >> 2) & 1);     // dbg 8/9: tuning controls (tools/bench_mac.py)
     const int io_step = io_sel ? S / 2 : 0;
     auto compute_stage = [&](int st, auto &&io) {
         const u64 *buf = smem + (size_t)(st & 1) * VEC * 64;
@@ -896,7 +905,7 @@ static int mac3_launch(crc_ctx *c, MacArgs &a, hipStream_t st)
     const size_t lds = (size_t)2 * VEC * 64 * 8 + (size_t)((a.T + 8 + 3) / 4) * 16 + 1024;
     if (lds > 160 * 1024) return CRC_ERR_UNSUPPORTED;
     auto kern = mac3_kernel<PX, FT, WM, WN, S, XP, WP>;
-    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { const int rc = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (rc) return rc; }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WM * WN), lds, st, a);
     HIPCHK(hipGetLastError());
     return CRC_OK;
@@ -912,7 +921,7 @@ static int mac2_launch(crc_ctx *c, MacArgs &a, hipStream_t st)
     if (a.T + 8 > 16384) return CRC_ERR_UNSUPPORTED;
     const size_t lds = (size_t)2 * VEC * 64 * 8 + (size_t)(a.T + 8) * 4;
     auto kern = mac2_kernel<PX, FT, WM, WN, S, DEPTH>;
-    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { const int rc = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (rc) return rc; }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WM * WN), lds, st, a);
     HIPCHK(hipGetLastError());
     return CRC_OK;
@@ -931,7 +940,9 @@ int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, co
     a.x = x; a.w = w; a.y = y; a.mods = c->d_mods; a.xoff = d_xoff; a.toff = d_toff; a.toffw = d_toffw;
     a.n = c->n; a.k = c->k; a.B = B; a.P = P; a.F = F; a.T = T; a.in_cts = in_cts; a.bias = bias_ntt; a.bias_sign = 1;
     a.gxd = gxd; a.gyd = gyd; a.gxf = gxf; a.gyf = gyf; a.xp = xp; a.wp = wp; a.yp = yp;
+#ifdef CRC_TUNING
     { static const int dbg = [] { const char *e = getenv("CRC_MAC2_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
+#endif
     // tile configuration <PX, FT, WM, WN, S>: a workgroup covers PX*WM pixels x FT*WN filters (6 x 16 or 12 x 8), 24 accumulators
     // per wave either way; pick the shape that wastes fewer multiply-adds on filter/pixel padding (F = 50 -> 56 instead of 64,
     // F = 20 -> 24 instead of 32; measured equal on full tiles).  CRC_MAC2_CFG forces one (tools/bench_mac.py)

@@ -21,8 +21,19 @@ struct ModParams {
     u64 r0, r1;     // floor(2^128 / q) low / high word  (Barrett, same constant SEAL calls const_ratio)
     u64 two_q;      // 2q
     u32 bits;       // significant bits of q
-    u32 fold;       // 2^bits - q when that is below 2^26 (every prime SEAL ships: 2^b - c 2^s + 1), else 0
+    u32 fold;       // fold_constant(q, bits): 2^bits - q when the folding reduction is valid for this modulus, else 0
 };
+
+// The folding reduction fold128 below is exact for ANY 128-bit input only when q = 2^b - d with 52 <= b <= 62 and d < 2^26: after three
+// folds the value is below 2^(206-3b) + 2^b, which must stay under 2q (b >= 52), and the intermediate high parts must fit a word
+// (b >= 48).  Every coefficient modulus SEAL's default sets use (54-55 bits) and the 61-bit auxiliary primes qualify; smaller primes of
+// the same shape (SEAL's small_mods_40bit / 50bit) take the generic Barrett path.
+CRC_HD u32 fold_constant(u64 q, u32 bits)
+{
+    if (bits < 52 || bits > 62) return 0;
+    const u64 d = ((u64)1 << bits) - q;
+    return d && d < ((u64)1 << 26) ? (u32)d : 0;
+}
 
 CRC_HD u64 mulhi64(u64 a, u64 b)
 {
@@ -44,20 +55,20 @@ CRC_HD u64 submod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
 CRC_HD u64 negmod(u64 a, u64 q) { return a ? q - a : 0; }
 
 // x = hi*2^64 + lo  ->  x mod q, canonical, for q = 2^b - d with a small d (m.fold): 2^b = d (mod q), so the part of x above bit b
-// folds down as (x >> b) d + (x mod 2^b).  Three folds take any 128-bit x below 2^b + 2^44 < 2q; 6 word multiplies instead of the
-// 18 of the generic Barrett reduction below.  Requires 40 <= b <= 62, d < 2^26.
+// folds down as (x >> b) d + (x mod 2^b).  Three folds take any 128-bit x below 2^b + 2^(206-3b) < 2q; 6 word multiplies instead of the
+// 18 of the generic Barrett reduction below.  Requires 52 <= b <= 62, d < 2^26 (fold_constant above; m.fold is 0 otherwise).
 CRC_HD u64 fold128(u64 lo, u64 hi, const ModParams &m)
 {
     const u32 b = m.bits; const u64 d = m.fold, mask = ((u64)1 << b) - 1;
-    // fold 1: h1 = x >> b (up to 128 - b <= 88 bits), x1 = h1 d + (x mod 2^b) < 2^114 + 2^b
+    // fold 1: h1 = x >> b (up to 128 - b <= 76 bits), x1 = h1 d + (x mod 2^b) < 2^102 + 2^b
     const u64 h1l = (lo >> b) | (hi << (64 - b)), h1h = hi >> b;
     u64 pl, ph; mul64wide(h1l, d, pl, ph);
     u64 x1l = pl + (lo & mask); u64 x1h = ph + h1h * d + (x1l < pl);
-    // fold 2: h2 = x1 >> b (<= 60 bits)
+    // fold 2: h2 = x1 >> b (<= 154 - 2b <= 50 bits)
     const u64 h2 = (x1l >> b) | (x1h << (64 - b));
     mul64wide(h2, d, pl, ph);
     u64 x2l = pl + (x1l & mask); u64 x2h = ph + (x2l < pl);
-    // fold 3: h3 = x2 >> b (<= 24 bits), x3 = h3 d + (x2 mod 2^b) < 2^50 + 2^b
+    // fold 3: h3 = x2 >> b (<= 180 - 3b <= 24 bits), x3 = h3 d + (x2 mod 2^b) < 2^50 + 2^b
     const u64 h3 = (x2l >> b) | (x2h << (64 - b));
     u64 r = h3 * d + (x2l & mask);
     return r >= m.q ? r - m.q : r;

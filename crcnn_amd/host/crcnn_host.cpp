@@ -12,7 +12,12 @@ using namespace std;
 crc_ctx *context = nullptr;
 vector<uint64_t> secret_key, public_key, ev_keys16_host;
 shared_ptr<DeviceBuffer> ev_keys16;
-uint64_t crcnn_seed = 0x5EA1;
+static bool g_det = false;                                  // setDeterministicSeed(): tests / bench only
+static uint64_t g_det_seed = 0;
+static uint8_t g_master_key[CRC_KEY_BYTES];                 // fresh from the OS on every setParameters()
+static uint64_t g_enc_counter = 0;                          // ciphertexts encrypted under g_master_key so far (= next keystream id)
+void setDeterministicSeed(uint64_t seed) { g_det = true; g_det_seed = seed; }
+void clearDeterministicSeed() { g_det = false; }
 
 // ---- status -> exception (the reference throws std::invalid_argument from SEAL, evaluator.cpp:1549-1556) ---------------
 static void chk(int status, const char *what)
@@ -144,9 +149,16 @@ void setParameters(int poly_modulus, const vector<uint64_t> &coeff_modulus, uint
     chk(crc_ctx_create(poly_modulus, coeff_modulus.data(), (int)coeff_modulus.size(), plain_modulus, device, &context), "encryption parameters are not set correctly");
     const int n = N(), k = K();
     secret_key.assign((size_t)k * n, 0); public_key.assign((size_t)2 * k * n, 0);
-    chk(crc_keygen(context, crcnn_seed, secret_key.data(), public_key.data()), "crc_keygen");
     ev_keys16_host.assign(crc_evk_words(context, 16), 0);                  // keygen->generate_evaluation_keys(16, *ev_keys16), globals.cpp:54
-    chk(crc_gen_evk(context, crcnn_seed + 1, secret_key.data(), 16, ev_keys16_host.data()), "crc_gen_evk");
+    g_enc_counter = 0;
+    if (g_det) {
+        chk(crc_keygen(context, g_det_seed, secret_key.data(), public_key.data()), "crc_keygen");
+        chk(crc_gen_evk(context, g_det_seed + 1, secret_key.data(), 16, ev_keys16_host.data()), "crc_gen_evk");
+    } else {
+        chk(crc_random_key(g_master_key), "crc_random_key");
+        chk(crc_keygen_key(context, g_master_key, secret_key.data(), public_key.data()), "crc_keygen_key");
+        chk(crc_gen_evk_key(context, g_master_key, secret_key.data(), 16, ev_keys16_host.data()), "crc_gen_evk_key");
+    }
     ev_keys16 = make_shared<DeviceBuffer>(ev_keys16_host.size() * 8);
     chk(crc_memcpy_h2d(context, ev_keys16->ptr, ev_keys16_host.data(), ev_keys16_host.size() * 8, nullptr), "crc_memcpy_h2d");
     chk(crc_stream_sync(context, nullptr), "crc_stream_sync");
@@ -202,7 +214,6 @@ ciphertext3D loadEncryptedImage(int zd, int xd, int yd, string file_name)
         off += used; }
     return ciphertext3D::fromHost(h.data(), 1, zd, xd, yd);
 }
-static uint64_t g_enc_counter = 0;
 // encode on the host, encrypt on the device (crc_encrypt_dev: Encryptor::encrypt, encryptor.cpp:71-134)
 static ciphertext3D encryptPixels(const vector<float> &px, int zd, int xd, int yd)
 {
@@ -213,8 +224,13 @@ static ciphertext3D encryptPixels(const vector<float> &px, int zd, int xd, int y
     chk(crc_memcpy_h2d(ctx(), d_pl.ptr, pl.data(), pl.size() * 8, nullptr), "crc_memcpy_h2d");
     chk(crc_memcpy_h2d(ctx(), d_pk.ptr, public_key.data(), public_key.size() * 8, nullptr), "crc_memcpy_h2d");
     ciphertext3D out(1, zd, xd, yd, CRC_COEFF);
-    chk(crc_encrypt_dev(ctx(), (const uint64_t *)d_pk.ptr, (const uint64_t *)d_pl.ptr, px.size(), crcnn_seed + 1000003 * (++g_enc_counter),
-                        (uint64_t *)out.buf->ptr, d_work.ptr, nullptr), "crc_encrypt_dev");
+    if (g_det)
+        chk(crc_encrypt_dev(ctx(), (const uint64_t *)d_pk.ptr, (const uint64_t *)d_pl.ptr, px.size(), g_det_seed + 1000003 * (g_enc_counter + 1),
+                            (uint64_t *)out.buf->ptr, d_work.ptr, nullptr), "crc_encrypt_dev");
+    else                                                    // one keystream per ciphertext, never reused under this key
+        chk(crc_encrypt_dev_key(ctx(), (const uint64_t *)d_pk.ptr, (const uint64_t *)d_pl.ptr, px.size(), g_master_key, g_enc_counter,
+                                (uint64_t *)out.buf->ptr, d_work.ptr, nullptr), "crc_encrypt_dev_key");
+    g_enc_counter += px.size();
     chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
     return out;
 }
@@ -294,6 +310,16 @@ void ConvolutionalLayer::upload()
     d_w = uploadPlain(w, 0); d_b[0] = uploadPlain(b, 1); d_b[1] = uploadPlain(b, 2);
     filters_already_ntt = true;            // transform_kernel_to_ntt, convolutionalLayer.cpp:151-156 (done once)
 }
+void ConvolutionalLayer::deviceParameters(vector<shared_ptr<DeviceBuffer>> &out, bool allocate_only)
+{
+    if (allocate_only && !filters_already_ntt) {
+        const size_t rowb = (size_t)K() * N() * 8;
+        d_w = make_shared<DeviceBuffer>((size_t)nf * zd * xf * yf * rowb); d_b[0] = make_shared<DeviceBuffer>(nf * rowb); d_b[1] = make_shared<DeviceBuffer>(nf * rowb);
+        filters_already_ntt = true;
+    }
+    packWeights(true);                                      // canonical residues on the wire (uploads first if needed)
+    out.push_back(d_w); out.push_back(d_b[0]); out.push_back(d_b[1]);
+}
 void ConvolutionalLayer::packWeights(bool unpack)
 {
     upload();
@@ -343,6 +369,16 @@ void FullyConnectedLayer::upload()
     for (int i = 0; i < out_dim; i++) { if ((int)weights[i].size() != in_dim) throw invalid_argument("fc: row length mismatch"); for (int j = 0; j < in_dim; j++) w.push_back(&weights[i][j]); b.push_back(&biases[i]); }
     d_w = uploadPlain(w, 0); d_b[0] = uploadPlain(b, 1); d_b[1] = uploadPlain(b, 2);
     weights_already_ntt = true;
+}
+void FullyConnectedLayer::deviceParameters(vector<shared_ptr<DeviceBuffer>> &out, bool allocate_only)
+{
+    if (allocate_only && !weights_already_ntt) {
+        const size_t rowb = (size_t)K() * N() * 8;
+        d_w = make_shared<DeviceBuffer>((size_t)in_dim * out_dim * rowb); d_b[0] = make_shared<DeviceBuffer>(out_dim * rowb); d_b[1] = make_shared<DeviceBuffer>(out_dim * rowb);
+        weights_already_ntt = true;
+    }
+    packWeights(true);
+    out.push_back(d_w); out.push_back(d_b[0]); out.push_back(d_b[1]);
 }
 void FullyConnectedLayer::packWeights(bool unpack)
 {
@@ -422,6 +458,15 @@ void BatchNormLayer::upload()
     for (int i = 0; i < num_channels; i++) { m.push_back(&mean[i]); v.push_back(&var[i]); }
     d_mean[0] = uploadPlain(m, 1); d_mean[1] = uploadPlain(m, 2); d_invstd = uploadPlain(v, 0);
 }
+void BatchNormLayer::deviceParameters(vector<shared_ptr<DeviceBuffer>> &out, bool allocate_only)
+{
+    if (allocate_only && !d_invstd) {
+        const size_t rowb = (size_t)K() * N() * 8;
+        d_mean[0] = make_shared<DeviceBuffer>(num_channels * rowb); d_mean[1] = make_shared<DeviceBuffer>(num_channels * rowb); d_invstd = make_shared<DeviceBuffer>(num_channels * rowb);
+    }
+    upload();
+    out.push_back(d_mean[0]); out.push_back(d_mean[1]); out.push_back(d_invstd);
+}
 ciphertext3D BatchNormLayer::forward(ciphertext3D input)
 {
     if (!input.buf || input.zd != num_channels) throw invalid_argument("BatchNormLayer: channel count mismatch");
@@ -500,6 +545,37 @@ ciphertext3D Network::forward(ciphertext3D input)
         last_layer_ms[i] = chrono::duration<double, milli>(chrono::high_resolution_clock::now() - t0).count();
     }
     return input;
+}
+
+size_t Network::broadcastParameters(crc_comm *comm, int root)
+{
+    if (!comm) throw invalid_argument("broadcastParameters: no communicator");
+    const int rank = crc_comm_rank(comm), world = crc_comm_world(comm);
+    if (root < 0 || root >= world) throw invalid_argument("broadcastParameters: bad root");
+    vector<shared_ptr<DeviceBuffer>> bufs;
+    for (auto &l : layers) l->deviceParameters(bufs, rank != root);
+    if (!ev_keys16) throw logic_error("setParameters() must be called first");
+    bufs.push_back(ev_keys16);                              // the evaluation keys come from the client through the root
+    size_t bytes = 0;
+    uint64_t mine[2] = {0, 0};
+    for (auto &b : bufs) {
+        const size_t words = b->bytes / 8;
+        chk(crc_broadcast_weights(comm, (uint64_t *)b->ptr, words, root, nullptr), "crc_broadcast_weights");
+        uint64_t cs[2];
+        chk(crc_checksum64(ctx(), (const uint64_t *)b->ptr, words, cs, nullptr), "crc_checksum64");
+        mine[0] ^= cs[0]; mine[1] = mine[1] * 0x9E3779B97F4A7C15ULL + cs[1];
+        bytes += b->bytes;
+    }
+    vector<uint64_t> all((size_t)2 * world);
+    chk(crc_comm_allgather_u64(comm, mine, 2, all.data(), nullptr), "crc_comm_allgather_u64");
+    for (int r = 0; r < world; r++)
+        if (all[2 * r] != all[2 * root] || all[2 * r + 1] != all[2 * root + 1])
+            throw runtime_error("broadcastParameters: rank " + to_string(r) + " holds different parameter bytes than the root");
+    if (rank != root) {                                     // host copy of the keys follows the device copy
+        chk(crc_memcpy_d2h(ctx(), ev_keys16_host.data(), ev_keys16->ptr, ev_keys16_host.size() * 8, nullptr), "crc_memcpy_d2h");
+        chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+    }
+    return bytes;
 }
 
 int Network::fuse()

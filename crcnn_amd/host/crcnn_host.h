@@ -58,7 +58,12 @@ ciphertext3D deepCopyImage(const ciphertext3D &image);                  // globa
 extern crc_ctx *context;                                    // the engine context (SEALContext + Evaluator tables)
 extern std::vector<uint64_t> secret_key, public_key, ev_keys16_host;
 extern std::shared_ptr<DeviceBuffer> ev_keys16;             // evaluation keys, dbc = 16, resident in HBM
-extern uint64_t crcnn_seed;                                 // seed of the client-side RNG (keygen / encryption)
+// Client-side randomness (secret key, evaluation keys, every encryption).  The reference draws from std::random_device (SEAL 2.3.1
+// randomgen.cpp:7); here setParameters() draws a fresh 256-bit ChaCha20 key from the OS (crc_random_key -> getrandom(2)) on every
+// call and each encryption uses its own keystream under it.  setDeterministicSeed() replaces that by a PUBLIC 64-bit seed so that
+// tests, benchmarks and golden vectors are reproducible -- a seeded run is NOT secure (anyone who knows the seed can decrypt).
+void setDeterministicSeed(uint64_t seed);                   // tests / bench only; takes effect at the next setParameters()
+void clearDeterministicSeed();                              // back to OS entropy (the default)
 void setParameters(int poly_modulus = 4096, uint64_t plain_modulus = 1 << 20);          // coeff_modulus_128(poly_modulus)
 void setParameters(int poly_modulus, const std::vector<uint64_t> &coeff_modulus, uint64_t plain_modulus, int device = 0);
 void delParameters();
@@ -89,6 +94,9 @@ public:
     virtual void savePlaintextParameters(std::ostream *outfile) = 0;
     virtual void loadPlaintextParameters(std::istream *infile) = 0;
     void computeBoundaries(int xd, int yd, int xs, int ys, int xf, int yf, int *xl, int *yl);   // layer.cpp:12-26
+    // device-resident encoded parameters of this layer, in a fixed order (Network::broadcastParameters).  allocate_only: a receiving
+    // rank sizes the buffers without encoding anything; otherwise the plaintext parameters are lifted + NTT'd into them first.
+    virtual void deviceParameters(std::vector<std::shared_ptr<DeviceBuffer>> &out, bool allocate_only) { (void)out; (void)allocate_only; }
 };
 
 class ConvolutionalLayer : public Layer {                   // convolutionalLayer.h:33-34
@@ -112,6 +120,8 @@ private:
     int w_form = CRC_NTT;                                   // CRC_NTTP once Network::forward has put the weights into the MAC kernels' operand form
     void upload();
     void packWeights(bool unpack);
+public:
+    void deviceParameters(std::vector<std::shared_ptr<DeviceBuffer>> &out, bool allocate_only) override;
 };
 
 class FullyConnectedLayer : public Layer {                  // fullyConnectedLayer.h:22-24
@@ -134,6 +144,8 @@ private:
     int w_form = CRC_NTT;
     void upload();
     void packWeights(bool unpack);
+public:
+    void deviceParameters(std::vector<std::shared_ptr<DeviceBuffer>> &out, bool allocate_only) override;
 };
 
 class PoolingLayer : public Layer {                         // poolingLayer.h:15
@@ -183,6 +195,8 @@ public:
 private:
     std::shared_ptr<DeviceBuffer> d_mean[2], d_invstd;
     void upload();
+public:
+    void deviceParameters(std::vector<std::shared_ptr<DeviceBuffer>> &out, bool allocate_only) override;
 };
 
 // ---- network (CrCNN/src/network.h:11-39) ---------------------------------------------------------------------------
@@ -219,6 +233,13 @@ public:
     // b' = b - sum_taps w' (*) mean[channel]).  The network's output ciphertexts stay bit-identical; only the folded layers'
     // intermediate tensors disappear (their plaintext parameters can no longer be saved).  Returns the number of layers removed.
     int fuse();
+    // Multi-GPU start-up (no analogue in the reference): one process (or host thread) per GPU, images sharded across them
+    // with no data-path collective.  Rank `root` holds the encoded model -- this call lifts + NTTs its plaintext parameters if that has
+    // not happened yet -- and every other rank receives the NTT-form weights / bias / batch-norm rows and the evaluation keys over RCCL
+    // (crc_broadcast_weights: ncclBroadcast in <= 1 GiB pieces), without encoding anything.  Every rank then checksums what it holds
+    // (crc_checksum64) and the sums are compared with the root's; a mismatch throws std::runtime_error.  Call it before fuse() and
+    // before the first forward() on the receiving ranks.  Returns the bytes received per rank.
+    size_t broadcastParameters(crc_comm *comm, int root = 0);
 };
 
 // ---- model loader + builder (CrCNN/src/cnnBuilder.h:16-44) ----------------------------------------------------------

@@ -160,17 +160,29 @@ static int do_api(int argc, char **argv)
       n2.getLayers().push_back(shared_ptr<Layer>(new SquareLayer("s", 2)));
       n2.getLayers().push_back(shared_ptr<Layer>(new FullyConnectedLayer("f", 72, 3, 2, &f)));
       if (n2.forward(x).toHost() != r1) { fprintf(stderr, "reloaded network differs\n"); return 8; } }
+    // multi-GPU start-up path (Network::broadcastParameters over crc_comm / RCCL) on a one-rank communicator: the weights are unpacked,
+    // "broadcast", checksummed and compared, and the network must still produce the same ciphertexts
+    {
+        uint8_t id[CRC_COMM_ID_BYTES]; crc_comm *comm = nullptr;
+        if (crc_comm_unique_id(id) || crc_comm_create(context, 1, 0, id, &comm)) { fprintf(stderr, "crc_comm_create failed (rccl error %d)\n", crc_last_comm_error()); return 13; }
+        const size_t bytes = net.broadcastParameters(comm, 0);
+        fprintf(stderr, "broadcastParameters: %zu bytes on %d rank(s)\n", bytes, crc_comm_world(comm));
+        net.ntt_resident = true;
+        if (bytes == 0 || net.forward(x).toHost() != r1) { fprintf(stderr, "network differs after broadcastParameters\n"); return 13; }
+        EXPECT_THROW(net.broadcastParameters(comm, 1), invalid_argument);
+        crc_comm_destroy(comm);
+    }
     // error behaviour mirrors the reference (std::invalid_argument on bad shapes / truncated streams)
     EXPECT_THROW(net.getLayer(0)->forward(ciphertext3D(1, 1, 10, 10)), invalid_argument);
     { istringstream empty(""); EXPECT_THROW(FullyConnectedLayer("f", 4, 2, 1, &empty), invalid_argument); }
     EXPECT_THROW(CnnBuilder("/nonexistent.h5").getPretrained("x"), runtime_error);
     // key / image files in SEAL's wire formats (setAndSaveParameters / initFromKeys / encryptAndSaveImage / loadEncryptedImage)
     {
-        crcnn_seed = 777;
+        setDeterministicSeed(777);
         setAndSaveParameters(dir + "/pk.bin", dir + "/sk.bin", dir + "/evk.bin", 2048, 1ULL << 16);
         ciphertext3D saved = encryptAndSaveImage(small, 1, 14, 14, dir + "/img.bin");
         vector<u64> before = saved.toHost();
-        crcnn_seed = 999;                                    // a different key pair would be generated ...
+        setDeterministicSeed(999);                                    // a different key pair would be generated ...
         initFromKeys(dir + "/pk.bin", dir + "/sk.bin", dir + "/evk.bin", 2048, 1ULL << 16);       // ... but the files restore the first one
         ciphertext3D loaded = loadEncryptedImage(1, 14, 14, dir + "/img.bin");
         if (loaded.toHost() != before) { fprintf(stderr, "image file round trip differs\n"); return 11; }

@@ -41,7 +41,8 @@ typedef enum {
     CRC_ERR_HIP = -3,                /* a HIP runtime call failed; crc_last_hip_error() has the code */
     CRC_ERR_UNSUPPORTED = -4,        /* valid in the reference but not implemented here (e.g. t >= min q_i: slow plain lift) */
     CRC_ERR_IO = -5,                 /* file could not be read / not an HDF5 file we understand */
-    CRC_ERR_NOT_FOUND = -6           /* dataset name missing in the model file */
+    CRC_ERR_NOT_FOUND = -6,          /* dataset name missing in the model file */
+    CRC_ERR_COMM = -7                /* an RCCL call failed; crc_last_comm_error() has the ncclResult_t */
 } crc_status;
 
 enum { CRC_COEFF = 0, CRC_NTT = 1,
@@ -229,8 +230,25 @@ int crc_h5_list(const char *path, char *h_names, size_t cap);   /* newline-separ
 /* ---------------------------------------------------------------------------------------------------------------
  * client side (host CPU; SURVEY 8f-2, outside the accelerated path): keygen / encrypt / decrypt so that a user of
  * CrCNN's globals.cpp (setParameters, encryptImage, decryptImage: globals.cpp:25-56,127-157,207-230) finds them.
- * Seeded RNG; ciphertexts are valid BFV encryptions but not bit-identical to SEAL's (its RNG is std::random_device).
+ *
+ * Randomness.  SEAL 2.3.1 draws from std::random_device (randomgen.cpp:7), so the reference fixes sampling LAWS (uniform
+ * ternary secret / encryption sample, clipped normal sigma 3.19 cut at 6 sigma: util/globals.cpp:13-15), not bits.  Here every
+ * sample comes from ChaCha20 keystreams under a 256-bit key:
+ *   *_key entry points   take the key (CRC_KEY_BYTES bytes).  Draw it with crc_random_key (getrandom(2)) -- that is the
+ *                        secure way and what the C++ host classes do on every setParameters().  One key may serve keygen,
+ *                        evaluation keys and any number of encryptions: each use has its own stream (domain, `stream_base` +
+ *                        ciphertext index, coefficient).  NEVER encrypt two different batches under the same (key, stream_base).
+ *   uint64 seed variants expand a PUBLIC 64-bit seed into the key.  Deterministic by design: tests, bench, golden vectors.
+ *                        NOT SECURE -- anyone who knows the seed can decrypt.
  * ------------------------------------------------------------------------------------------------------------- */
+#define CRC_KEY_BYTES 32
+int crc_random_key(uint8_t *h_key /*[CRC_KEY_BYTES]*/);
+/* one ChaCha20 block (RFC 8439: 32-byte key, 32-bit block counter, 12-byte nonce -> 64 bytes): known-answer access to the generator */
+int crc_chacha20_block(const uint8_t *h_key, uint32_t counter, const uint8_t *h_nonce /*[12]*/, uint8_t *h_out /*[64]*/);
+int crc_keygen_key(const crc_ctx *ctx, const uint8_t *h_key, uint64_t *h_sk_ntt /*[k][n]*/, uint64_t *h_pk /*[2][k][n]*/);
+int crc_gen_evk_key(const crc_ctx *ctx, const uint8_t *h_key, const uint64_t *h_sk_ntt, int dbc, uint64_t *h_evk);
+int crc_encrypt_key(const crc_ctx *ctx, const uint64_t *h_pk, const uint64_t *h_plain, size_t count, const uint8_t *h_key, uint64_t stream_base,
+                    uint64_t *h_ct /*[count][2][k][n]*/);
 int crc_keygen(const crc_ctx *ctx, uint64_t seed, uint64_t *h_sk_ntt /*[k][n]*/, uint64_t *h_pk /*[2][k][n]*/);
 int crc_gen_evk(const crc_ctx *ctx, uint64_t seed, const uint64_t *h_sk_ntt, int dbc, uint64_t *h_evk);
 int crc_encrypt(const crc_ctx *ctx, const uint64_t *h_pk, const uint64_t *h_plain, size_t count, uint64_t seed, uint64_t *h_ct /*[count][2][k][n]*/);
@@ -240,10 +258,44 @@ int crc_noise_budget(const crc_ctx *ctx, const uint64_t *h_sk_ntt, const uint64_
 /* Encryptor::encrypt (encryptor.cpp:71-134) on the device, for the 784 encryptions per image that dominate the client's
  * latency in the reference: d_pk = the public key of crc_keygen copied to the device ([2][k][n], NTT form), d_plain =
  * [count][n] plaintext coefficients (< t), d_ct = [count][2][k][n] coefficient form.  Sampling (ternary u, clipped-normal
- * e1/e2) is a counter-based generator keyed by (seed, ciphertext, coefficient): deterministic per seed, same laws as
- * crc_encrypt, different bits.  d_work: crc_encrypt_dev_work_bytes(count). */
+ * e1/e2) is ChaCha20 in counter mode, one stream per (ciphertext, coefficient): same laws as crc_encrypt, different bits.
+ * d_work: crc_encrypt_dev_work_bytes(count). */
 size_t crc_encrypt_dev_work_bytes(const crc_ctx *ctx, size_t count);
+int crc_encrypt_dev_key(crc_ctx *ctx, const uint64_t *d_pk, const uint64_t *d_plain, size_t count, const uint8_t *h_key, uint64_t stream_base,
+                        uint64_t *d_ct, void *d_work, void *stream);
 int crc_encrypt_dev(crc_ctx *ctx, const uint64_t *d_pk, const uint64_t *d_plain, size_t count, uint64_t seed, uint64_t *d_ct, void *d_work, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * multi-GPU (SURVEY 8e / 8b `crc_broadcast_weights`).  The reference has no analogue: its only parallelism is the
+ * std::thread fan-out inside a layer (convolutionalLayer.cpp:177-191).  Here a batch of encrypted images shards over the
+ * GPUs of a node with NO data-path collective; the ONE collective is the start-up broadcast of the encoded (NTT-form)
+ * weights and evaluation keys from the rank that built them, over RCCL (ncclBroadcast; xGMI inside a node).
+ *
+ *   crc_comm_unique_id    the root makes the 128-byte rendezvous id and hands it to the other ranks out of band
+ *                         (file, socket, MPI, torch.distributed ...)
+ *   crc_comm_create       one communicator per (process, GPU): rank `rank` of `world` on the context's device
+ *   crc_comm_create_all   single-process alternative: one communicator per context / device (ncclCommInitAll); use the
+ *                         *_all broadcast below, or one host thread per communicator
+ *   crc_broadcast_weights in-place broadcast of `words` uint64 from `root` in <= 1 GiB pieces on `stream` (asynchronous:
+ *                         ordered with the kernels of that stream, no host sync)
+ *   crc_comm_allgather_u64  small host-to-host all-gather (per-rank checksums, timings); synchronises `stream`
+ *   crc_checksum64        position-sensitive checksum of a device buffer: h_out[0] = xor of all words, h_out[1] =
+ *                         sum_i w_i * (2i+1) mod 2^64; synchronises `stream`.  Every rank checks what it received against the
+ *                         root's pair.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct crc_comm crc_comm;
+#define CRC_COMM_ID_BYTES 128
+int  crc_comm_unique_id(uint8_t *h_id /*[CRC_COMM_ID_BYTES]*/);
+int  crc_comm_create(crc_ctx *ctx, int world, int rank, const uint8_t *h_id, crc_comm **out);
+int  crc_comm_create_all(crc_ctx *const *ctxs, int ndev, crc_comm **out /*[ndev]*/);
+void crc_comm_destroy(crc_comm *comm);
+int  crc_comm_rank(const crc_comm *comm);
+int  crc_comm_world(const crc_comm *comm);
+int  crc_last_comm_error(void);                        /* the ncclResult_t of the last failed RCCL call (CRC_ERR_COMM) */
+int  crc_broadcast_weights(crc_comm *comm, uint64_t *d_w, size_t words, int root, void *stream);
+int  crc_broadcast_weights_all(crc_comm *const *comms, int ndev, uint64_t *const *d_w, size_t words, int root, void *const *streams);
+int  crc_comm_allgather_u64(crc_comm *comm, const uint64_t *h_in, size_t words, uint64_t *h_out /*[world][words]*/, void *stream);
+int  crc_checksum64(crc_ctx *ctx, const uint64_t *d_words, size_t words, uint64_t *h_out /*[2]*/, void *stream);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,9 @@ OP_SETS = {
     "ops_n256_k3_t30": (256, [0x7fffffff380001, 0x7ffffffef00001, 0x3fffffff000001], 1 << 30, 2, [-0.1307, 7.0, 0.3333]),
     "ops_n256_k1_q60_t30": (256, [0xffffffffffc0001], 1 << 30, 2, [0.5, -1.75]),   # aux base grows by one (baseconverter.cpp:47-56)
     "ops_n2048_k1_t18": (2048, [0x3fffffff000001], 1 << 18, 1, [0.4242, -3.0]),   # the committed driver's parameters (mainparams.cpp:75-76)
+    # SEAL's small_mods_40bit (util/globals.cpp): 2^40 - c 2^s + 1 primes BELOW the folding reduction's validity bound (modarith.h
+    # fold_constant): every 128-bit reduction of the Square pipeline must take the generic Barrett path here
+    "ops_n256_k2_q40_t16": (256, [0xffffe80001, 0xffffc40001], 1 << 16, 2, [0.5, -1.75]),
 }
 FLOATS = [0.0, 1.0, -1.0, 0.25, -2.5, 0.5, -0.5, 1.5, 2.5, -0.4242129623889923, 2.8214867115020752, 100.125, -77.0,
           3.14159, 1e-9, -1e-7, 0.1307, 0.3081, 1.0 / 3.0, 12345.678, 0.020209059119224548, 4.656612873077393e-10]

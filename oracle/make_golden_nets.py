@@ -31,8 +31,20 @@ NETS = {
     "tiny4096": ("PlainModelTiny", 4096, orc.COEFF_MODULUS_128[4096], 1 << 20, 2),                      # BASELINE configs[0..1]
     "approx8192": ("ApproxPlainModel", 8192, Q8192[:3], 1 << 30, 10),                                   # configs[2..3]
     "wopad16384": ("PlainModelWoPad", 16384, Q16384[:4], 1 << 30, 25),                                  # configs[4]
+    # the plain moduli bench.py actually runs (exact logits without the client-side refresh), and the
+    # coefficient modulus CrCNN's own setParameters would pick at n=8192 (all four primes of coeff_modulus_128(8192))
+    "tiny4096_t32": ("PlainModelTiny", 4096, orc.COEFF_MODULUS_128[4096], 1 << 32, 2),
+    "approx8192_t42": ("ApproxPlainModel", 8192, Q8192[:3], 1 << 42, 10),
+    "approx8192k4_t42": ("ApproxPlainModel", 8192, Q8192[:4], 1 << 42, 10),
+    "wopad16384_t44": ("PlainModelWoPad", 16384, Q16384[:4], 1 << 44, 25),
 }
 KEY_SEED, EVK_SEED, ENC_SEED, IMAGE_INDEX = 9000, 9001, 100000, 0
+# The bench-parameter sets take their keys and encrypted input image from the ENGINE's seeded client side (crc_keygen / crc_gen_evk /
+# crc_encrypt on the host, no GPU) with exactly the seeds bench.py uses for image 0 of rank 0: the product can then reproduce the golden
+# input without touching anything under oracle/, and bench.py compares its output digest with the reference's (`golden_match`).
+ENGINE_INPUTS = {"tiny4096_t32", "approx8192_t42", "approx8192k4_t42", "wopad16384_t44", "tiny1024_eng"}
+ENG_KEY_SEED, ENG_EVK_SEED, ENG_ENC_SEED = 2024, 2025, 7000
+NETS["tiny1024_eng"] = ("PlainModelTiny", 1024, [0x7fffffff380001, 0x3fffffff000001], 1 << 32, 1)     # n = 1024: smallest ring in which the fractional encoding survives the four multiplicative levels
 
 
 def topology(model, slices, th=8):
@@ -64,8 +76,19 @@ def net_input(O, pk):
 def make(name):
     model, n, q, t, slices = NETS[name]
     O = orc.Oracle(n, q, t)
-    sk, pk = O.keygen(KEY_SEED); evk = O.gen_evk(EVK_SEED, sk)
-    img, x = net_input(O, pk)
+    seeds = dict(key_seed=KEY_SEED, evk_seed=EVK_SEED, enc_seed=ENC_SEED, input_gen="oracle")
+    if name in ENGINE_INPUTS:
+        import crcnn_amd as ca
+        from crcnn_amd import synth
+        E = ca.Engine(n, q, t, device=-1)
+        sk, pk = E.keygen(ENG_KEY_SEED); evk = E.gen_evk(ENG_EVK_SEED, sk)
+        img = synth.normalize(synth.synth_image(IMAGE_INDEX))
+        pl, _ = E.encode(img.reshape(-1))
+        x = E.encrypt(pk, pl, ENG_ENC_SEED).reshape(1, 28, 28, 2, O.k, n)
+        seeds = dict(key_seed=ENG_KEY_SEED, evk_seed=ENG_EVK_SEED, enc_seed=ENG_ENC_SEED, input_gen="engine")
+    else:
+        sk, pk = O.keygen(KEY_SEED); evk = O.gen_evk(EVK_SEED, sk)
+        img, x = net_input(O, pk)
     path = os.path.join(REF, "PlainModel", model + ".h5")
     from crcnn_amd.netrun import TOPOLOGIES
     t0 = time.time()
@@ -79,7 +102,7 @@ def make(name):
         subprocess.check_call([HARNESS, "net", d])
         digests = [ln.split() for ln in open(os.path.join(d, "ref_digests.txt")).read().splitlines()]
         out = get(d, "ref_net_out.u64", (1, 10, 1, 2, O.k, n))
-        g = dict(model=model, n=n, q=[int(v) for v in q], t=t, key_seed=KEY_SEED, evk_seed=EVK_SEED, enc_seed=ENC_SEED, image_index=IMAGE_INDEX,
+        g = dict(model=model, n=n, q=[int(v) for v in q], t=t, **seeds, image_index=IMAGE_INDEX,
                  input_sha256=hashlib.sha256(x.tobytes()).hexdigest(),
                  layers=[dict(index=int(r[0]), name=r[1], shape=r[2], sha256=r[3], ref_time=r[4]) for r in digests],
                  logits=[float(v) for v in get(d, "ref_net_logits.u64").view(np.float64)],

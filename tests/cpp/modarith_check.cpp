@@ -8,25 +8,34 @@ static ModParams make(u64 q, bool allow_fold)
 {
     ModParams m{}; u128 all = ~(u128)0, quo = all / q;
     m.q = q; m.r0 = (u64)quo; m.r1 = (u64)(quo >> 64); m.two_q = 2 * q; m.bits = 64 - __builtin_clzll(q);
-    const u64 d = ((u64)1 << m.bits) - q; m.fold = allow_fold && m.bits >= 40 && m.bits <= 62 && d < (1u << 26) ? (u32)d : 0;
+    m.fold = allow_fold ? fold_constant(q, m.bits) : 0;        // the product's own rule (ctx.cpp make_mod)
     return m;
 }
 int main()
 {
     const u64 qs[] = {0x7fffffff380001ULL, 0x3fffffff000001ULL, 0x7ffffffef00001ULL, 0x3ffffffef40001ULL, 0x7ffffffeac0001ULL, 0x7ffffffe700001ULL,
                       0x7ffffffe600001ULL, 0x7ffffffe4c0001ULL, 0x1fffffffffe00001ULL, 0x1fffffffffc80001ULL, 0x1fffffffffb40001ULL, 0x1fffffffff500001ULL,
-                      1152921504606584833ULL /* 2^60 - 2^18 + 1 */, 4611686018326724609ULL /* 62 bits */};
+                      1152921504606584833ULL /* 2^60 - 2^18 + 1 */, 4611686018326724609ULL /* 62 bits */,
+                      // primes of the same 2^b - c 2^s + 1 shape below the folding bound: SEAL's small_mods_40bit (util/globals.cpp) and 45..53-bit ones.
+                      // Below 52 bits fold_constant must refuse them (three folds no longer reach [0, 2q)) and the generic Barrett path must be exact
+                      0xffffe80001ULL, 0xffffc40001ULL, 0x1fffff980001ULL, 0xfffffff00001ULL, 0x3ffffffb80001ULL, 0x3fffffec80001ULL, 0x7ffffff9c0001ULL,
+                      0xffffffff00001ULL, 0xfffffffe40001ULL, 0x1fffffffd80001ULL};
     u64 x = 88172645463325252ULL; auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
     long checked = 0;
     for (u64 q : qs) for (int fold = 0; fold < 2; fold++) {
         const ModParams m = make(q, fold);
         if (fold && !m.fold) continue;
+        if (m.fold && m.bits < 52) { printf("fold enabled for a %u-bit modulus\n", m.bits); return 1; }
         const u128 qq = (u128)q * q - 1;
         for (long it = 0; it < 400000; it++) {
             u64 lo = rnd(), hi = rnd();
             if (it % 7 == 0) hi = ~0ULL; if (it % 11 == 0) lo = ~0ULL; if (it % 13 == 0) hi = 0; if (it % 17 == 0) { hi = (u64)(qq >> 64); lo = (u64)qq; } if (it % 19 == 0) { hi = 0; lo = q - 1 + (it & 1); }
             const u64 e = (u64)(((((u128)hi) << 64) | lo) % q);
             if (barrett128(lo, hi, m) != e) { printf("barrett128 mismatch q=%llx fold=%d hi=%llx lo=%llx\n", (unsigned long long)q, fold, (unsigned long long)hi, (unsigned long long)lo); return 1; }
+            {   // what sq_floor / sq_lift feed it: sums of k products of a 61-bit value and a residue of this modulus
+                u128 acc = 0; for (int j = 0; j < 3; j++) acc += (u128)(rnd() >> 3) * (rnd() % q);
+                if (barrett128((u64)acc, (u64)(acc >> 64), m) != (u64)(acc % q)) { printf("barrett128 (sum of products) mismatch q=%llx fold=%d\n", (unsigned long long)q, fold); return 1; }
+            }
             const u64 a = rnd() % q, b = rnd() % q, wp = (u64)(((u128)b << 64) / q);
             if (mulmod(a, b, m) != (u64)((u128)a * b % q)) { printf("mulmod mismatch q=%llx\n", (unsigned long long)q); return 1; }
             const u64 any = rnd();

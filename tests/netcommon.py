@@ -21,10 +21,20 @@ def sha(a):
 def make_inputs(g):
     """regenerate keys + the encrypted synthetic image exactly as oracle/make_golden_nets.py did"""
     O = orc.Oracle(g["n"], g["q"], g["t"])
-    sk, pk = O.keygen(g["key_seed"]); evk = O.gen_evk(g["evk_seed"], sk)
     img = orc.normalize(orc.synth_image(g["image_index"]))
-    x = O.encrypt_many(pk, O.encode_many(img).reshape(1, 28, 28, O.n), g["enc_seed"])
-    assert sha(x) == g["input_sha256"], "oracle input generation drifted from the golden"
+    if g.get("input_gen") == "engine":
+        # goldens at the parameter sets bench.py runs: keys and the encrypted image come from the ENGINE's seeded host-side client
+        # (crc_keygen / crc_gen_evk / crc_encrypt; no GPU), so that bench.py can reproduce them without touching oracle/
+        import crcnn_amd as ca
+        E = ca.Engine(g["n"], g["q"], g["t"], device=-1)
+        sk, pk = E.keygen(g["key_seed"]); evk = E.gen_evk(g["evk_seed"], sk)
+        pl, _ = E.encode(img.reshape(-1))
+        x = E.encrypt(pk, pl, g["enc_seed"]).reshape(1, 28, 28, 2, O.k, O.n)
+        E.close()
+    else:
+        sk, pk = O.keygen(g["key_seed"]); evk = O.gen_evk(g["evk_seed"], sk)
+        x = O.encrypt_many(pk, O.encode_many(img).reshape(1, 28, 28, O.n), g["enc_seed"])
+    assert sha(x) == g["input_sha256"], "input generation drifted from the golden"
     return O, sk, pk, evk, img, x
 
 

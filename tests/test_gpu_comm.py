@@ -1,0 +1,68 @@
+"""GPU tests of the multi-GPU start-up path: the engine's RCCL communicator behind the C ABI (crc_comm_*,
+crc_broadcast_weights, crc_checksum64) on the one GPU of the test box, and bench.py's multi-rank path end to end (two ranks sharing
+the device over the gloo rehearsal backend -- RCCL itself refuses two ranks on one GPU; the 8-GPU run is the driver's)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MASK = (1 << 64) - 1
+
+
+def test_comm_one_rank_broadcast_and_checksum():
+    import crcnn_amd as ca
+    E = ca.Engine(1024, [0x7fffffff380001, 0x3fffffff000001], 1 << 20, device=0)
+    rng = np.random.default_rng(7)
+    for words in (1, 63, 4096, (1 << 20) + 17):
+        w = rng.integers(0, 1 << 63, size=words, dtype=np.uint64)
+        d = E.upload(w)
+        x, s = E.checksum64(d, words * 8)
+        wx = int(np.bitwise_xor.reduce(w))
+        ws = int(np.sum(w * (2 * np.arange(words, dtype=np.uint64) + 1), dtype=np.uint64))      # wraps mod 2^64
+        assert (x, s) == (wx, ws)
+    comm = E.comm_create(1, 0, E.comm_unique_id())
+    assert E.L.crc_comm_world(comm) == 1 and E.L.crc_comm_rank(comm) == 0
+    E.broadcast_weights(comm, d, words * 8, root=0)
+    E.sync()
+    assert np.array_equal(E.download(d, (words,)), w)
+    got = E.allgather_u64(comm, [x, s, 5])
+    assert got.shape == (1, 3) and [int(v) for v in got[0]] == [x, s, 5]
+    with pytest.raises(ca.CrcError):
+        E.broadcast_weights(comm, d, words * 8, root=1)
+    E.comm_destroy(comm)
+    E.close()
+
+
+def _run_bench(extra, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "tiny1024", "--steps", "1", "--cpu-seconds", "0", "--also", "none"] + extra,
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_small_workload_matches_reference_golden():
+    """bench.py's own output ciphertexts for image 0 are, bit for bit, what the compiled reference computed from the same encrypted
+    input (tests/golden/net_tiny1024_eng.json), with and without the layer folding"""
+    line = _run_bench(["--gpus", "1", "--unfused-images", "24"])
+    c = line["check"]
+    assert line["n_gpus"] == 1 and c["golden_match"] is True and c["golden"] == "net_tiny1024_eng.json" and c["all_ok"] is True
+    assert c["tiled_outputs_identical"] and c["predictions_match_plain_model"] == "4/4"
+    assert line["reference_layer_structure"]["outputs_identical_to_fused"] is True
+    assert line["roofline"]["frac"] > 0 and line["roofline"]["traffic_source"] is None
+
+
+def test_bench_two_ranks_end_to_end_on_one_device():
+    """plain `python bench.py --gpus 2` (self-launch), weights built on rank 0 only, broadcast, per-rank checksums, every rank verified"""
+    line = _run_bench(["--gpus", "2", "--unfused-images", "0"], {"CRC_DIST_BACKEND": "gloo"})
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    c = line["check"]
+    assert c["ranks_verified"] == "2/2" and c["golden_match"] is True and c["all_ok"] is True
+    b = line["weight_broadcast"]
+    assert b["checksums_match"] == "2/2" and b["bytes"] > 0 and b["seconds"] > 0 and b["via"].startswith("torch.distributed (gloo)")

@@ -85,6 +85,22 @@ def test_cpp_plain_modulus_search():
     assert any(s == "MISPREDICTED" for t, s in tried if t < found) or found == lo
 
 
+FULL = [n for n in ["tiny4096_t32", "approx8192_t42", "wopad16384_t44"] if os.path.exists(os.path.join(GOLD, f"net_{n}.json"))]
+
+
+@pytest.mark.parametrize("name", FULL)
+@pytest.mark.parametrize("fuse", [False, True], ids=["unfused", "fused"])
+def test_cpp_network_full_size_equals_reference(name, fuse):
+    """the drop-in itself (C++ Layer / Network / CnnBuilder) at the BASELINE ring sizes and the plain moduli bench.py runs at:
+    CnnBuilder reads the real model, Network::forward (NTT-resident, with and without Network::fuse) must produce the compiled
+    reference's output ciphertexts bit for bit"""
+    g, O, d = run_driver(name, resident=True, batch=1, fuse=fuse)
+    out = np.fromfile(os.path.join(d, "out.u64"), dtype=np.uint64)
+    assert sha(out) == g["out_sha256"]
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
+
+
 @pytest.mark.parametrize("name", ["tiny256", "approx256", "wopad256"])
 def test_cpp_network_fused_equals_reference(name):
     """Network::fuse() (conv+pool folding, batch-norm folding) must leave the network's output ciphertexts bit-identical to the

@@ -11,7 +11,10 @@ from netcommon import GOLD, load_net_golden, make_inputs, sha
 
 pytestmark = pytest.mark.gpu
 
-NAMES = [n for n in ["tiny256", "approx256", "wopad256", "tiny4096", "approx8192", "wopad16384"]
+# *_t32 / _t42 / _t44: the plain moduli bench.py runs at (exact logits without the client-side refresh); approx8192k4: all four primes of
+# coeff_modulus_128(8192), the coefficient modulus CrCNN's own setParameters picks; tiny1024_eng: the small workload of the bench tests
+NAMES = [n for n in ["tiny256", "approx256", "wopad256", "tiny1024_eng", "tiny4096", "approx8192", "wopad16384",
+                     "tiny4096_t32", "approx8192_t42", "approx8192k4_t42", "wopad16384_t44"]
          if os.path.exists(os.path.join(GOLD, f"net_{n}.json"))]
 
 
@@ -54,7 +57,7 @@ def test_ntt_resident_network_matches_reference(name):
     """NTT-resident pipeline (one INTT at the end / around Square), batch of 2: same final ciphertext bits"""
     g, O, sk, out, _ = run_net(name, resident=True, batch=2)
     assert sha(out[0]) == g["out_sha256"] and sha(out[1]) == g["out_sha256"]
-    if g["n"] >= 4096:       # real parameter sets: the decrypted logits are the reference's logits
+    if g["n"] >= 1024:       # real parameter sets: the decrypted logits are the reference's logits
         got = [O.decrypt_value(sk, out[0, 0, j, 0]) for j in range(10)]
         assert got == g["logits"]
         assert [O.noise_budget(sk, out[0, 0, j, 0]) for j in range(3)] == g["budget"][:3]

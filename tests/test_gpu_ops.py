@@ -153,12 +153,15 @@ def test_baseline_ring_sizes_vs_oracle(n, q, t):
 
 @pytest.mark.parametrize("n,k,t", [(4096, 2, 1 << 20), (8192, 3, 1 << 30), (1024, 2, 1 << 16)])
 def test_device_encryptor(n, k, t):
-    """SURVEY 8f-2: Encryptor::encrypt on the device.  The reference samples from std::random_device, so the check is semantic:
-    every ciphertext decrypts (CPU client, secret key) to its plaintext, the noise budget is that of the CPU encryptor's
-    ciphertexts (same sampling laws), and the stream is a function of (seed, ciphertext index)."""
+    """SURVEY 8f-2: Encryptor::encrypt on the device.  The reference samples from std::random_device, so the check is semantic, and
+    the checker is the ORACLE (pinned to SEAL's Decryptor by tests/test_oracle_golden.py), not the product's own client code: every
+    ciphertext decrypts under the oracle to its plaintext, its oracle-measured noise budget is that of ciphertexts the oracle's own
+    Encryptor restatement makes (same sampling laws), and the stream is a function of (seed / key, ciphertext index)."""
     import crcnn_amd as ca
+    from oracle import orc
     q = ca.default_coeff_modulus_128(8192)[:k] if n != 4096 else ca.default_coeff_modulus_128(4096)
     E = ca.Engine(n, q, t, device=0)
+    O = orc.Oracle(n, q, t)
     sk, pk = E.keygen(11)
     rng = np.random.default_rng(5)
     cnt = 24
@@ -168,10 +171,22 @@ def test_device_encryptor(n, k, t):
     d_ct = E.alloc(cnt * 2 * k * n * 8); d_w = E.alloc(E.encrypt_dev_work_bytes(cnt))
     E.encrypt_dev(d_pk, d_pl, cnt, 77, d_ct, d_w)
     ct = E.download(d_ct, (cnt, 2, k, n))
-    assert np.array_equal(E.decrypt(sk, ct), plains)
-    ref = E.encrypt(pk, plains[:4], 3)
-    b_dev = [E.noise_budget(sk, ct[i]) for i in range(4)]; b_cpu = [E.noise_budget(sk, ref[i]) for i in range(4)]
+    assert np.array_equal(np.stack([O.decrypt(sk, ct[i]) for i in range(cnt)]), plains)
+    ref = O.encrypt_many(pk, plains[:4], 3)
+    assert np.array_equal(np.stack([O.decrypt(sk, ref[i]) for i in range(4)]), plains[:4])
+    b_dev = [O.noise_budget(sk, ct[i]) for i in range(cnt)]; b_cpu = [O.noise_budget(sk, ref[i]) for i in range(4)]
     assert min(b_dev) >= min(b_cpu) - 2 and max(b_dev) <= max(b_cpu) + 2, (b_dev, b_cpu)
+    # sampling laws of the device generator (ChaCha20 streams): c1 - pk1*u = e2 is not observable without u, but c0 + c1 s = Delta m + v with
+    # v = e1 + e2 s - e u: centred, small; its size is what the budget above measures.  Key-based entry point: fresh key, distinct streams
+    key = E.random_key()
+    E.encrypt_dev_key(d_pk, d_pl, cnt, key, 1000, d_ct, d_w)
+    ck = E.download(d_ct, (cnt, 2, k, n))
+    assert np.array_equal(np.stack([O.decrypt(sk, ck[i]) for i in range(cnt)]), plains)
+    E.encrypt_dev_key(d_pk, d_pl, cnt, key, 1001, d_ct, d_w)         # stream_base + 1: ciphertext i now uses the stream ciphertext i+1 used before
+    ck2 = E.download(d_ct, (cnt, 2, k, n))
+    assert not np.array_equal(ck2[:, 1], ck[:, 1])
+    u_same = (ck2[0, 1].astype(object) - ck[1, 1].astype(object))      # same stream => same u and e2 => identical c1 (c1 does not depend on the plaintext)
+    assert not np.any(u_same)
     # deterministic per seed, different across seeds and across ciphertexts
     E.encrypt_dev(d_pk, d_pl, cnt, 77, d_ct, d_w)
     assert np.array_equal(E.download(d_ct, (cnt, 2, k, n)), ct)

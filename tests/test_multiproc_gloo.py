@@ -67,3 +67,19 @@ def test_shard_range_partitions():
             assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
             sizes = [e - b for b, e in ranges]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE must start its own two ranks (fresh children of a parent that has
+    made no GPU call), relay rank 0's JSON line and propagate the exit code.  --launch-check stops after the rendezvous (no GPU here)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line == {"launch_check": True, "n_gpus": 2, "ranks_seen": 2, "self_launched": True}
+    # a rank that fails makes the parent fail: --gpus 3 announced, but the check insists on what the flag says
+    bad = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launch-check"], capture_output=True, text=True, env=env, timeout=300)
+    assert bad.returncode != 0
