@@ -243,12 +243,20 @@ extern "C" int crc_ctx_create(int n, const uint64_t *q, int k, uint64_t t, int d
     b.inv_q_mod_mt = h_invmod(prod_mod(q, k, -1, kMtilde), kMtilde);
     auto shoup = [](u64 w, u64 m) { return (u64)(((u128)w << 64) / m); };
     for (int i = 0; i < k; i++) {
-        b.mt_inv_qhat_s[i] = shoup(b.mt_inv_qhat[i], q[i]);
+        b.mt_inv_qhat_s[i] = shoup(b.mt_inv_qhat[i], q[i]); b.inv_qhat_s[i] = shoup(b.inv_qhat[i], q[i]);
         b.t_inv_qhat[i] = h_mulmod(t % q[i], b.inv_qhat[i], q[i]); b.t_inv_qhat_s[i] = shoup(b.t_inv_qhat[i], q[i]);
     }
     for (int j = 0; j < c->kb; j++) {
         b.t_mod_bsk[j] = t % bsk[j]; b.t_mod_bsk_s[j] = shoup(b.t_mod_bsk[j], bsk[j]);
         b.inv_mt_mod_bsk_s[j] = shoup(b.inv_mt_mod_bsk[j], bsk[j]); b.inv_q_mod_bsk_s[j] = shoup(b.inv_q_mod_bsk[j], bsk[j]);
+    }
+    for (int j = 0; j < c->kb; j++) {
+        b.lift_r[j] = h_mulmod(b.q_mod_bsk[j], b.inv_mt_mod_bsk[j], bsk[j]);
+        b.floor_x[j] = h_mulmod(b.t_mod_bsk[j], b.inv_q_mod_bsk[j], bsk[j]);
+        for (int i = 0; i < k; i++) {
+            b.lift_c[j][i] = h_mulmod(b.qhat_mod_bsk[j][i], b.inv_mt_mod_bsk[j], bsk[j]);
+            b.floor_c[j][i] = negmod(h_mulmod(b.qhat_mod_bsk[j][i], b.inv_q_mod_bsk[j], bsk[j]), bsk[j]);
+        }
     }
     for (int j = 0; j < c->ka; j++) b.inv_mhat_s[j] = shoup(b.inv_mhat[j], bsk[j]);
     b.inv_M_mod_msk_s = shoup(b.inv_M_mod_msk, kMsk);

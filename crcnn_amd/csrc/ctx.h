@@ -47,6 +47,13 @@ struct BehzParams {
     u64 t_mod_bsk[CRC_MAXB], t_mod_bsk_s[CRC_MAXB];            // t mod Bsk_j
     u64 inv_mt_mod_bsk_s[CRC_MAXB], inv_q_mod_bsk_s[CRC_MAXB], inv_mhat_s[CRC_MAXB];
     u64 inv_M_mod_msk_s;
+    // products of consecutive constant multiplications inside one modulus, so that a base conversion is ONE lazy 128-bit sum and ONE reduction
+    // per target residue (same residue, hence the same bits):
+    u64 lift_c[CRC_MAXB][CRC_MAXK];          // (q/q_i) m~^-1 mod Bsk_j          fastbconv_mtilde then mont_rq's final multiply (baseconverter.cpp:698-718, 619)
+    u64 lift_r[CRC_MAXB];                    // q m~^-1 mod Bsk_j                 the r q term of mont_rq (:614-618)
+    u64 floor_x[CRC_MAXB];                   // t q^-1 mod Bsk_j                  x t (evaluator.cpp:856-871) then fast_floor's q^-1 (:646-660)
+    u64 floor_c[CRC_MAXB][CRC_MAXK];         // -(q/q_i) q^-1 mod Bsk_j           minus fastbconv(x) times q^-1
+    u64 inv_qhat_s[CRC_MAXK];                // Shoup companion of inv_qhat (relinearisation digits are cut out of c2 (q/q_i)^-1, evaluator.cpp:984-985)
 };
 
 struct HostNtt {               // one modulus

@@ -7,6 +7,9 @@ int k_ntt_ct(crc_ctx *c, bool inv, const u64 *src, u64 *dst, size_t count, int s
 int k_ntt_ct_addct(crc_ctx *c, const u64 *src, u64 *dst, size_t count, const u64 *addct, int add_size, hipStream_t st);
 int k_ntt_ct_head_add(crc_ctx *c, const u64 *src, int src_size, u64 *dst, size_t count, const u64 *addrows, hipStream_t st);
 int k_spread_ntt(crc_ctx *c, const u64 *src, size_t items, u64 *dst, hipStream_t st);
+int k_digit_ntt(crc_ctx *c, const u64 *src, int src_size, int src_poly, size_t count, int D, const unsigned char *dig_i, const unsigned char *dig_shift, int dbc,
+                u64 *dst, hipStream_t st, int pack_out = 0);
+int k_square_intt(crc_ctx *c, const u64 *src, u64 *dst, size_t count, bool bsk, hipStream_t st);
 int k_plain_ntt(crc_ctx *c, const u64 *d_plain, size_t count, int mode, bool do_ntt, u64 *d_out, hipStream_t st);
 int k_rowwise(crc_ctx *c, u64 *acc, const u64 *b, size_t count, int size, int op, int sign, size_t group, size_t gmod, hipStream_t st);
 int k_pool(crc_ctx *c, const u64 *x, u64 *y, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, const u64 *mul, hipStream_t st, int pack_out = 0);
@@ -17,8 +20,9 @@ int k_pack28(crc_ctx *c, u64 *rows, size_t nrows, bool unpack, hipStream_t st);
 int k_conv_offsets(crc_ctx *c, int *xoff, int *toff, unsigned *toffw, int P, int T, int in_cts, int xd, int yd, int xs, int ys, int xf, int yf, int yo, hipStream_t st);
 size_t k_square_work_words(const crc_ctx *c, size_t cnt);
 size_t k_relin_work_words(const crc_ctx *c, size_t cnt, int dbc);
-int k_square(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStream_t st, bool in_ntt = false);
-int k_relinearize(crc_ctx *c, const u64 *x3, size_t cnt, const u64 *evk, int dbc, u64 *y, u64 *work, hipStream_t st, bool out_ntt = false);
+int k_square(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStream_t st, bool in_ntt = false, bool premul_c2 = false);
+int k_relinearize(crc_ctx *c, const u64 *x3, size_t cnt, const u64 *evk, int dbc, u64 *y, u64 *work, u64 *kp, hipStream_t st, bool out_ntt = false,
+                  bool c2_premul = false, bool keys_ready = false);
 int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, const int *d_toff, int B, int P, int F, int T, int in_cts,
            const u64 *bias_ntt, int gxd, int gyd, int gxf, int gyf, const unsigned *d_toffw, hipStream_t st, int xp = 0, int wp = 0, int yp = 0);
 int k_fold_pool(crc_ctx *c, const u64 *w, const u64 *bias, const u64 *div, u64 *wout, u64 *bout, int nf, int zd, int xf, int yf, int cxs, int cys,

@@ -24,7 +24,14 @@ struct NttArgs {
     size_t rows;                                               // total rows of the launch (prefetch variant)
     int pack_out;                                              // forward only: store the result as 28-bit limb pairs (operand form of the MAC kernels)
     int src_ct_rows, dst_ct_rows;                              // both > 0: dst row r = (ct, j < dst_ct_rows) reads src row ct*src_ct_rows + j (leading polys of wider cts)
-    int prologue;                                              // 0 none, 1 plain lift, 2 delta scale
+    int prologue;                                              // 0 none, 1 plain lift, 2 delta scale, 3 relinearisation digit, 4 square products
+    // prologue 3 (forward): row = ((ct*D + g)*k + j); the source row is the premultiplied third polynomial c2 (q/q_i)^-1 mod q_i of ciphertext ct under
+    //   modulus i = dig_i[g] (src = size-`src_size` ciphertexts, poly `src_poly`); the value fed to the transform is its digit (v >> dig_shift[g]) & dig_mask
+    //   (relinearize_one_step, evaluator.cpp:984-1001) -- the digit polynomials never exist in memory
+    // prologue 4 (inverse): row = ((ct*3 + p)*mod_count + j); sources are the NTT-form rows a, b of polys 0 and 1 of ciphertext ct in `src` ([ct][2][mod_count][n]);
+    //   the value fed to the transform is a^2, 2ab or b^2 (Evaluator::square's dyadic products, evaluator.cpp:798-852)
+    int D, src_size, src_poly; unsigned long long dig_mask;
+    unsigned char dig_i[48], dig_shift[48];
     const u64 *addend; int add_sign; int rows_per_ct; long long add_group;   // epilogue (inverse only)
     int add_mod;                                               // plaintext index = (ct / add_group) % add_mod (0: no modulo)
     int add_mode, add_size;                                    // 1: delta plaintext on poly 0 (shared by add_group cts); 2: rows of a size-add_size ct array
@@ -34,8 +41,10 @@ struct NttArgs {
 #include "ntt_device.h"  // lpad, shoup_lazy4, reduce_small, fwd_stages / inv_stages, ntt_pass
 __device__ __forceinline__ u64 split28v(u64 v) { return (v & 0x0fffffffULL) | ((v >> 28) << 32); }      // = split28 further down
 
-template <bool INV, bool LAZY>
-__global__ void __launch_bounds__(1024) ntt_rows_kernel(NttArgs a)
+// PRO: load prologue compiled into this instance -- 0: a.prologue in {0 none, 1 plain lift, 2 delta scale}; 3: relinearisation digit; 4: square products
+// (separate instances keep every variant at <= 64 VGPRs = two resident 1024-thread workgroups per CU at n = 8192)
+template <bool INV, bool LAZY, int PRO>
+__device__ __forceinline__ void ntt_rows_body(const NttArgs &a)
 {
     extern __shared__ u64 sm[];
     const int n = a.n, logn = a.logn, tid = threadIdx.x, nt = blockDim.x;
@@ -46,19 +55,34 @@ __global__ void __launch_bounds__(1024) ntt_rows_kernel(NttArgs a)
     const u64 q = m.q, q2 = m.two_q;
     const float rq = 1.0f / (float)((u32)(q >> 32) + 1);
     const ulonglong2 *W = a.w + (size_t)mi * n;
-    const size_t srow = a.dst_ct_rows ? (row / a.dst_ct_rows) * a.src_ct_rows + row % a.dst_ct_rows : (a.src_rows_per_item ? (row / a.mod_count) : row);
-    const u64 *src = a.src + srow * (size_t)n;
     u64 *dst = a.dst + row * (size_t)n;
-
-    for (int s = tid; s < n; s += nt) {
-        u64 v = src[s];
-        if (a.prologue == 1) v = v >= a.pp.threshold ? v + a.pp.inc[mloc] : v;
-        else if (a.prologue == 2) {
-            u64 lo, hi; mul64wide(a.pp.delta[mloc], v, lo, hi);
-            if (v >= a.pp.threshold) { u64 l2 = lo + a.pp.uhi[mloc]; hi += (l2 < lo); lo = l2; }
-            v = barrett128(lo, hi, m);
+    if (INV && PRO == 4) {
+        const size_t ct = row / (3 * (size_t)a.mod_count); const int p = (int)((row / a.mod_count) % 3);
+        const u64 *pa = a.src + ((ct * 2 + (p == 2 ? 1 : 0)) * a.mod_count + mloc) * (size_t)n;
+        const u64 *pb = a.src + ((ct * 2 + (p == 0 ? 0 : 1)) * a.mod_count + mloc) * (size_t)n;
+        for (int s = tid; s < n; s += nt) {
+            u64 v = mulmod(pa[s], pb[s], m);
+            if (p == 1) v = addmod(v, v, q);
+            sm[lpad(s)] = v;
         }
-        sm[lpad(s)] = v;
+    } else if (!INV && PRO == 3) {
+        const size_t item = row / a.mod_count, ct = item / a.D; const int g = (int)(item % a.D);
+        const u64 *src = a.src + ((ct * a.src_size + a.src_poly) * a.mod_count + a.dig_i[g]) * (size_t)n;
+        const int sh = a.dig_shift[g];
+        for (int s = tid; s < n; s += nt) sm[lpad(s)] = (src[s] >> sh) & a.dig_mask;
+    } else {
+        const size_t srow = a.dst_ct_rows ? (row / a.dst_ct_rows) * a.src_ct_rows + row % a.dst_ct_rows : (a.src_rows_per_item ? (row / a.mod_count) : row);
+        const u64 *src = a.src + srow * (size_t)n;
+        for (int s = tid; s < n; s += nt) {
+            u64 v = src[s];
+            if (a.prologue == 1) v = v >= a.pp.threshold ? v + a.pp.inc[mloc] : v;
+            else if (a.prologue == 2) {
+                u64 lo, hi; mul64wide(a.pp.delta[mloc], v, lo, hi);
+                if (v >= a.pp.threshold) { u64 l2 = lo + a.pp.uhi[mloc]; hi += (l2 < lo); lo = l2; }
+                v = barrett128(lo, hi, m);
+            }
+            sm[lpad(s)] = v;
+        }
     }
     __syncthreads();
 
@@ -98,6 +122,13 @@ __global__ void __launch_bounds__(1024) ntt_rows_kernel(NttArgs a)
         }
     }
 }
+
+template <bool INV, bool LAZY, int PRO>
+__global__ void __launch_bounds__(1024) ntt_rows_kernel(NttArgs a) { ntt_rows_body<INV, LAZY, PRO>(a); }
+// the inverse transform over the 61-bit auxiliary base (Harvey form, full 64 x 64 high products) allocates 68 VGPRs on its own: one 1024-thread workgroup
+// per CU at n = 8192.  Held to 64 (8 waves per SIMD = two workgroups per CU) it spills five dwords outside the butterfly loops and runs faster.
+template <int PRO>
+__global__ void __launch_bounds__(1024, 8) ntt_rows_inv61_kernel(NttArgs a) { ntt_rows_body<true, false, PRO>(a); }
 
 // n = 16384: 128 KiB of LDS per row leaves ONE resident workgroup per CU, so the HBM read of a row sits exposed in front of its butterfly
 // passes.  This variant keeps the workgroup resident over rows blockIdx, blockIdx + gridDim, ... and fetches the next row into registers
@@ -176,7 +207,7 @@ static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t
     bool lazy = true;
     for (int i = a.mod_base; i < a.mod_base + a.mod_count; i++) if (c->tabs[i].m.bits > 57 || c->tabs[i].m.bits < 45) lazy = false;
     const int cus = c->cus;
-    if (c->n / nt == 16 && rows > (size_t)cus) {     // n = 16384: one resident workgroup per CU, prefetching the next row
+    if (c->n / nt == 16 && rows > (size_t)cus && a.prologue < 3) {     // n = 16384: one resident workgroup per CU, prefetching the next row
         a.rows = rows;
         auto pk = inv ? (lazy ? ntt_rows_prefetch_kernel<true, true> : ntt_rows_prefetch_kernel<true, false>) : (lazy ? ntt_rows_prefetch_kernel<false, true> : ntt_rows_prefetch_kernel<false, false>);
         { const int rc = crc_ctx_ensure_lds(c, (const void *)pk, lds); if (rc) return rc; }
@@ -184,7 +215,11 @@ static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t
         HIPCHK(hipGetLastError());
         return CRC_OK;
     }
-    auto kern = inv ? (lazy ? ntt_rows_kernel<true, true> : ntt_rows_kernel<true, false>) : (lazy ? ntt_rows_kernel<false, true> : ntt_rows_kernel<false, false>);
+    if ((a.prologue == 3 && inv) || (a.prologue == 4 && !inv)) return CRC_ERR_INVALID_ARGUMENT;
+    static const bool strict61 = !getenv("CRC_NTT_INV61_LOOSE");
+    auto kern = a.prologue == 4 ? (lazy ? ntt_rows_kernel<true, true, 4> : strict61 ? ntt_rows_inv61_kernel<4> : ntt_rows_kernel<true, false, 4>)
+              : a.prologue == 3 ? (lazy ? ntt_rows_kernel<false, true, 3> : ntt_rows_kernel<false, false, 3>)
+              : inv ? (lazy ? ntt_rows_kernel<true, true, 0> : strict61 ? ntt_rows_inv61_kernel<0> : ntt_rows_kernel<true, false, 0>) : (lazy ? ntt_rows_kernel<false, true, 0> : ntt_rows_kernel<false, false, 0>);
     { const int rc = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (rc) return rc; }
     hipLaunchKernelGGL(kern, dim3((unsigned)rows), dim3(nt), lds, st, a);
     HIPCHK(hipGetLastError());
@@ -230,6 +265,30 @@ int k_spread_ntt(crc_ctx *c, const u64 *src, size_t items, u64 *dst, hipStream_t
     a.src = src; a.dst = dst; a.mod_base = 0; a.mod_count = c->k; a.src_rows_per_item = 1; a.prologue = 0;
     a.rows_per_ct = c->k; a.add_group = 1;
     return ntt_launch(c, false, a, items * c->k, st);
+}
+
+// relinearisation digits: forward NTT of digit g of c2 (premultiplied by (q/q_i)^-1, poly `src_poly` of the size-`src_size` ciphertexts `src`) under every q_j:
+// dst [count][D][k][n]; the digit is cut out of the source word while the row is loaded (NttArgs prologue 3)
+int k_digit_ntt(crc_ctx *c, const u64 *src, int src_size, int src_poly, size_t count, int D, const unsigned char *dig_i, const unsigned char *dig_shift, int dbc,
+                u64 *dst, hipStream_t st, int pack_out)
+{
+    if (D > 48) return CRC_ERR_UNSUPPORTED;
+    NttArgs a{};
+    a.src = src; a.dst = dst; a.mod_base = 0; a.mod_count = c->k; a.prologue = 3; a.pack_out = pack_out;
+    a.D = D; a.src_size = src_size; a.src_poly = src_poly; a.dig_mask = (1ULL << dbc) - 1;
+    for (int g = 0; g < D; g++) { a.dig_i[g] = dig_i[g]; a.dig_shift[g] = dig_shift[g]; }
+    a.rows_per_ct = c->k; a.add_group = 1;
+    return ntt_launch(c, false, a, count * D * c->k, st);
+}
+
+// inverse NTT of the three dyadic products (a^2, 2ab, b^2) of size-2 NTT-form ciphertexts src [count][2][K][n] -> dst [count][3][K][n] (coefficient form),
+// K = k moduli of q or kb moduli of Bsk; the products are formed while the row is loaded (NttArgs prologue 4)
+int k_square_intt(crc_ctx *c, const u64 *src, u64 *dst, size_t count, bool bsk, hipStream_t st)
+{
+    NttArgs a{};
+    a.src = src; a.dst = dst; a.mod_base = bsk ? c->k : 0; a.mod_count = bsk ? c->kb : c->k; a.prologue = 4;
+    a.rows_per_ct = 3 * a.mod_count; a.add_group = 1;
+    return ntt_launch(c, true, a, count * 3 * a.mod_count, st);
 }
 
 int k_plain_ntt(crc_ctx *c, const u64 *d_plain, size_t count, int mode, bool do_ntt, u64 *d_out, hipStream_t st);

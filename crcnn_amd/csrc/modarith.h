@@ -35,10 +35,22 @@ CRC_HD u32 fold_constant(u64 q, u32 bits)
     return d && d < ((u64)1 << 26) ? (u32)d : 0;
 }
 
+// 64 x 64 -> 128 from four 32 x 32 + 64 multiply-adds (v_mad_u64_u32 on gfx950: there is no wider multiplier, and the compiler's
+// expansion of __umul64hi next to a separate a*b costs about twice as many multiplies).  No step can overflow: (2^32-1)^2 + 2 (2^32-1) < 2^64.
+CRC_HD void mul64wide_mad(u64 a, u64 b, u64 &lo, u64 &hi)
+{
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 p00 = (u64)a0 * b0;
+    const u64 p01 = (u64)a0 * b1 + (p00 >> 32);
+    const u64 p10 = (u64)a1 * b0 + (u32)p01;
+    hi = (u64)a1 * b1 + (p01 >> 32) + (p10 >> 32);
+    lo = (u64)(u32)p00 | (p10 << 32);
+}
+
 CRC_HD u64 mulhi64(u64 a, u64 b)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __umul64hi(a, b);
+#if defined(__HIP_DEVICE_COMPILE__) || defined(CRC_FORCE_MAD_MUL)
+    u64 lo, hi; mul64wide_mad(a, b, lo, hi); return hi;
 #else
     return (u64)(((unsigned __int128)a * b) >> 64);
 #endif
@@ -46,8 +58,12 @@ CRC_HD u64 mulhi64(u64 a, u64 b)
 
 CRC_HD void mul64wide(u64 a, u64 b, u64 &lo, u64 &hi)
 {
+#if defined(__HIP_DEVICE_COMPILE__) || defined(CRC_FORCE_MAD_MUL)
+    mul64wide_mad(a, b, lo, hi);
+#else
     lo = a * b;
     hi = mulhi64(a, b);
+#endif
 }
 
 CRC_HD u64 addmod(u64 a, u64 b, u64 q) { u64 s = a + b; return s >= q ? s - q : s; }

@@ -8,9 +8,14 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_modarith_header_against_int128():
+import pytest
+
+
+@pytest.mark.parametrize("flags", [[], ["-DCRC_FORCE_MAD_MUL"]], ids=["int128", "device-multiply"])
+def test_modarith_header_against_int128(flags):
+    """-DCRC_FORCE_MAD_MUL compiles the DEVICE form of the 64 x 64 -> 128 multiply (four 32-bit multiply-adds) on the host"""
     exe = os.path.join(tempfile.mkdtemp(), "modarith_check")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "crcnn_amd", "csrc"), os.path.join(ROOT, "tests", "cpp", "modarith_check.cpp"), "-o", exe])
+    subprocess.check_call(["g++", "-O2", "-std=c++17"] + flags + ["-I", os.path.join(ROOT, "crcnn_amd", "csrc"), os.path.join(ROOT, "tests", "cpp", "modarith_check.cpp"), "-o", exe])
     out = subprocess.check_output([exe], text=True)
     assert out.startswith("ok "), out
     assert int(out.split()[1]) > 5_000_000
