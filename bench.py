@@ -366,6 +366,10 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
 
     # ---- encoded weights: rank 0 encodes + NTTs, RCCL broadcast to the others, every rank checksums what it holds
     net = Network(E, model, weights=W, alloc=alloc, resident=(args.mode == "resident"), d_evk=d_evk, materialize=(rank == 0), fuse_pool=False)
+
+    def release(buf):
+        keep[:] = [k_ for k_ in keep if k_ is not buf]
+    net.release = release
     torch.cuda.synchronize()
     bcast = None
     if world > 1:
@@ -400,7 +404,7 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
     want_fuse = args.mode == "resident" and not args.no_fuse
     if want_fuse and full and args.unfused_images > 0:
         nu = min(B, max(C, args.unfused_images // C * C))
-        net.prepare(C)
+        net.prepare(C, limb=False)                     # (the limb conversion drops the canonical weights fuse() needs; it happens in the final prepare)
         net.forward(x_all[0], 1); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for c0 in range(0, nu, C):
@@ -501,7 +505,8 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
         # HBM traffic of that launch: rocprofv3 PMC passes (FETCH_SIZE corrected x2 for gfx950, WRITE_SIZE) collected OFFLINE with
         # tools/bench_mac.py and committed under profiles/ -- bench.py cannot run the profiler on itself, so this is not measured in this run
         traffic, traffic_source = None, None
-        kernel_label = f"mac3_kernel ({name}, {C} images/launch)" if kind in ("conv", "fc") else f"{kind} ({name})"
+        kname = "mfma_mac_kernel" if p.get("w_form") == ca.NTTL else "mac3_kernel"
+        kernel_label = f"{kname} ({name}, {C} images/launch)" if kind in ("conv", "fc") else f"{kind} ({name})"
         for pf in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", pf))).get(cfg_name)
@@ -525,7 +530,10 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
             "dtype": "u64", "data": f"synthetic ({D} distinct MNIST-like encrypted images per GPU tiled to the batch" + ("" if window == B else f", resident as a {window}-image window") + f"; trained weights from {model}.h5)",
             "config": {"workload": f"{model}.h5 n={cfg['n']} k={cfg['k']} t=2^{cfg['t'].bit_length() - 1} batch={B}/GPU chunk={C} ({cfg_name}, BASELINE configs)",
                        "mode": args.mode + ("+conv/pool folding" if want_fuse else ""), "parallelism": f"image-sharded x{world}, RCCL weight broadcast"},
-            "ms_per_layer": ms_per_layer, "reference_layer_structure": unfused, "roofline": roofline, "cpu_baseline": cpu,
+            "ms_per_layer": ms_per_layer,
+            "mac_kernel_per_layer": {pl[1]: ("mfma_mac_kernel (int8 limb GEMM, CRC_NTTL)" if pl[3].get("w_form") == ca.NTTL else "mac3_kernel (v_mad_u64_u32, CRC_NTTP)")
+                                     for pl in net.plan if pl[0] in ("conv", "fc")},
+            "reference_layer_structure": unfused, "roofline": roofline, "cpu_baseline": cpu,
             "check": {"tiled_outputs_identical": bool(ok_tile), "predictions_match_plain_model": f"{preds_ok}/{D}", "max_logit_abs_err": round(max_err, 6),
                       "noise_budget_bits": budgets, "ranks_verified": f"{ranks_ok}/{world}", "golden_match": gold_ok, "golden": gold_name, "all_ok": bool(all_ok)},
             "setup_s": round(setup_s, 1), "weight_broadcast": bcast, "weight_broadcast_s": bcast["seconds"] if bcast else 0.0, "weight_bytes": int(net.weight_bytes),

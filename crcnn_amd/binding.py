@@ -20,7 +20,7 @@ VP = ctypes.c_void_p
 CI = ctypes.c_int
 SZ = ctypes.c_size_t
 
-COEFF, NTT, NTTP = 0, 1, 2
+COEFF, NTT, NTTP, NTTL = 0, 1, 2, 3
 
 
 class CrcError(RuntimeError):
@@ -71,6 +71,7 @@ def load():
     L.crc_ct_words.restype = SZ; L.crc_ct_words.argtypes = [VP, CI]
     L.crc_evk_words.restype = SZ; L.crc_evk_words.argtypes = [VP, CI]
     L.crc_ctx_table.argtypes = [VP, ctypes.c_char_p, PU, CI]
+    L.crc_mem_info.argtypes = [VP, ctypes.POINTER(SZ), ctypes.POINTER(SZ)]
     L.crc_malloc.argtypes = [VP, SZ, ctypes.POINTER(VP)]
     L.crc_free.argtypes = [VP, VP]
     L.crc_memcpy_h2d.argtypes = [VP, VP, VP, SZ, VP]
@@ -105,6 +106,11 @@ def load():
     L.crc_conv2d_forms.argtypes = [VP, VP, VP, CI, VP] + [CI] * 9 + [CI, CI, VP, VP, VP]
     L.crc_dense_forms.argtypes = [VP, VP, VP, CI, VP, CI, CI, CI, CI, CI, VP, VP, VP]
     L.crc_pack28.argtypes = [VP, VP, SZ, CI, VP]
+    L.crc_limb_supported.argtypes = [VP, CI, CI, CI]
+    L.crc_limb_tensor_bytes.restype = SZ; L.crc_limb_tensor_bytes.argtypes = [VP, CI, CI, CI, CI]
+    L.crc_limb_weights_bytes.restype = SZ; L.crc_limb_weights_bytes.argtypes = [VP, CI, CI, CI, CI]
+    L.crc_limb_pack_weights.argtypes = [VP, VP, CI, CI, CI, CI, VP, VP]
+    L.crc_conv2d_forms_work_bytes.restype = SZ; L.crc_conv2d_forms_work_bytes.argtypes = [VP] + [CI] * 12
     L.crc_square.argtypes = [VP, VP, SZ, VP, VP, VP]
     L.crc_relinearize.argtypes = [VP, VP, SZ, VP, CI, VP, VP, VP]
     L.crc_import_seal.argtypes = [VP, PU, CI, PU]
@@ -231,6 +237,11 @@ class Engine:
             pass
 
     # ---- memory
+    def mem_info(self):
+        f, t = SZ(0), SZ(0)
+        _chk(self.L.crc_mem_info(self.c, ctypes.byref(f), ctypes.byref(t)), "crc_mem_info")
+        return f.value, t.value
+
     def alloc(self, nbytes):
         return DBuf(self, nbytes)
 
@@ -367,6 +378,22 @@ class Engine:
         else:
             _chk(self.L.crc_conv2d_forms(self.c, self.p(d_x), self.p(d_w), w_form, self.p(d_bias), B, zd, xd, yd, xs, ys, xf, yf, nf, in_form, out_form,
                                          self.p(d_y), self.p(d_work), self.stream), "crc_conv2d_forms")
+
+    # ---- limb form (CRC_NTTL): conv / dense on the matrix cores
+    def limb_supported(self, zd, xf=1, yf=1):
+        return bool(self.L.crc_limb_supported(self.c, zd, xf, yf))
+
+    def limb_tensor_bytes(self, B, zd, xd=1, yd=1):
+        return self.L.crc_limb_tensor_bytes(self.c, B, zd, xd, yd)
+
+    def limb_weights_bytes(self, nf, zd, xf=1, yf=1):
+        return self.L.crc_limb_weights_bytes(self.c, nf, zd, xf, yf)
+
+    def limb_pack_weights(self, d_w_ntt, nf, zd, xf, yf, d_wl):
+        _chk(self.L.crc_limb_pack_weights(self.c, self.p(d_w_ntt), nf, zd, xf, yf, self.p(d_wl), self.stream), "crc_limb_pack_weights")
+
+    def conv2d_forms_work_bytes(self, B, zd, xd, yd, xs, ys, xf, yf, nf, in_form, w_form, out_form):
+        return self.L.crc_conv2d_forms_work_bytes(self.c, B, zd, xd, yd, xs, ys, xf, yf, nf, in_form, w_form, out_form)
 
     def pack28(self, d_rows, rows, unpack=False):
         _chk(self.L.crc_pack28(self.c, self.p(d_rows), rows, 1 if unpack else 0, self.stream), "crc_pack28")

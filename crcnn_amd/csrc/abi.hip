@@ -7,6 +7,7 @@
 static inline hipStream_t S(void *s) { return (hipStream_t)s; }
 static inline bool form_ok(int f) { return f == CRC_COEFF || f == CRC_NTT; }
 static inline bool nform_ok(int f) { return f == CRC_COEFF || f == CRC_NTT || f == CRC_NTTP; }
+static inline bool lform_ok(int f) { return nform_ok(f) || f == CRC_NTTL; }
 
 extern "C" int crc_plain_to_ntt(crc_ctx *c, const uint64_t *d_plain, size_t count, uint64_t *d_out, void *stream)
 {
@@ -86,10 +87,63 @@ extern "C" size_t crc_conv2d_work_bytes(const crc_ctx *c, int B, int zd, int xd,
     return b + 256;
 }
 
+// ---- limb form (CRC_NTTL): the layer on the matrix cores (kernels_mfma.hip) ------------------------------------------------------------
+extern "C" int crc_limb_supported(const crc_ctx *c, int zd, int xf, int yf)
+{
+    if (!c || zd < 1 || xf < 1 || yf < 1) return 0;
+    return k_limb_supported(c, ((zd + 31) / 32) * 32 * xf * yf) ? 1 : 0;
+}
+extern "C" size_t crc_limb_tensor_bytes(const crc_ctx *c, int B, int zd, int xd, int yd) { return c ? k_limb_tensor_bytes(c, B, zd, xd * yd) : 0; }
+extern "C" size_t crc_limb_weights_bytes(const crc_ctx *c, int nf, int zd, int xf, int yf) { return c ? k_limb_weights_bytes(c, nf, zd, xf * yf) : 0; }
+extern "C" int crc_limb_pack_weights(crc_ctx *c, const uint64_t *d_w_ntt, int nf, int zd, int xf, int yf, void *d_wl, void *stream)
+{
+    CHECK_CTX(c); if (!d_w_ntt || !d_wl || nf < 1 || zd < 1 || xf < 1 || yf < 1) return CRC_ERR_INVALID_ARGUMENT;
+    if (!crc_limb_supported(c, zd, xf, yf)) return CRC_ERR_UNSUPPORTED;
+    return k_limb_pack_weights(c, d_w_ntt, (signed char *)d_wl, nf, zd, xf * yf, S(stream));
+}
+extern "C" size_t crc_conv2d_forms_work_bytes(const crc_ctx *c, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int in_form, int w_form, int out_form)
+{
+    if (w_form != CRC_NTTL) return crc_conv2d_work_bytes(c, B, zd, xd, yd, xs, ys, xf, yf, nf, in_form);
+    if (!c || !conv_shape_ok(xd, yd, xs, ys, xf, yf)) return 0;
+    (void)out_form;
+    const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys + 1;
+    size_t b = align256(8 * k_limb_result_words(c, B, nf, xo * yo));                                   // Ys
+    if (in_form != CRC_NTTL) b += align256(k_limb_tensor_bytes(c, B, zd, xd * yd));                      // Xl
+    if (in_form == CRC_COEFF) b += align256((size_t)B * zd * xd * yd * crc_ct_words(c, 2) * 8);          // NTT copy of the input
+    return b + 256;
+}
+static int conv2d_limb(crc_ctx *c, const uint64_t *d_x, const void *d_wl, const uint64_t *d_bias, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf,
+                       int in_form, int out_form, uint64_t *d_y, void *d_work, hipStream_t st)
+{
+    if (!crc_limb_supported(c, zd, xf, yf)) return CRC_ERR_UNSUPPORTED;
+    const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys + 1, P = xo * yo, in_cts = zd * xd * yd;
+    char *w = (char *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
+    u64 *Ys = (u64 *)w; w += align256(8 * k_limb_result_words(c, B, nf, P));
+    const signed char *xl = (const signed char *)d_x;
+    if (in_form != CRC_NTTL) {
+        signed char *Xl = (signed char *)w; w += align256(k_limb_tensor_bytes(c, B, zd, xd * yd));
+        const u64 *xn = d_x; bool packed = in_form == CRC_NTTP;
+        if (in_form == CRC_COEFF) { u64 *buf = (u64 *)w; RUN(k_ntt_ct(c, false, d_x, buf, (size_t)B * in_cts, 2, false, st, nullptr, 0, 0, 0, 0)); xn = buf; packed = false; }
+        RUN(k_limb_pack_tensor(c, xn, Xl, B, zd, xd * yd, packed, st));
+        xl = Xl;
+    }
+    // bias joins in the NTT domain unless the result goes back to coefficient form (then add_plain(bias) rides on the inverse transform's store)
+    RUN(k_limb_mac(c, xl, (const signed char *)d_wl, Ys, out_form != CRC_COEFF ? d_bias : nullptr, B, zd, xd, yd, xs, ys, xf, yf, nf, st));
+    if (out_form == CRC_NTTL) return k_limb_result_to_limb(c, Ys, (signed char *)d_y, B, nf * P, st);     // hand-over to a dense layer: channels = (f, px, py) flattened
+    RUN(k_limb_result_to_rows(c, Ys, d_y, (size_t)B * nf * P * 2, out_form == CRC_NTTP, st));
+    if (out_form == CRC_COEFF) RUN(k_ntt_ct(c, true, d_y, d_y, (size_t)B * nf * P, 2, false, st, d_bias, 1, (size_t)P, nf));
+    return CRC_OK;
+}
+
 extern "C" int crc_conv2d_forms(crc_ctx *c, const uint64_t *d_x, const uint64_t *d_w, int w_form, const uint64_t *d_bias, int B, int zd, int xd, int yd,
                                 int xs, int ys, int xf, int yf, int nf, int in_form, int out_form, uint64_t *d_y, void *d_work, void *stream)
 {
     CHECK_CTX(c);
+    if (w_form == CRC_NTTL) {
+        if (!d_x || !d_w || !d_y || !d_work || B < 0 || zd < 1 || nf < 1 || !lform_ok(in_form) || !lform_ok(out_form) || !conv_shape_ok(xd, yd, xs, ys, xf, yf)) return CRC_ERR_INVALID_ARGUMENT;
+        if (B == 0) return CRC_OK;
+        return conv2d_limb(c, d_x, d_w, d_bias, B, zd, xd, yd, xs, ys, xf, yf, nf, in_form, out_form, d_y, d_work, S(stream));
+    }
     if (!d_x || !d_w || !d_y || !d_work || B < 0 || zd < 1 || nf < 1 || !nform_ok(in_form) || !nform_ok(out_form) || (w_form != CRC_NTT && w_form != CRC_NTTP))
         return CRC_ERR_INVALID_ARGUMENT;
     if (!conv_shape_ok(xd, yd, xs, ys, xf, yf)) return CRC_ERR_INVALID_ARGUMENT;

@@ -30,3 +30,15 @@ int k_fold_pool(crc_ctx *c, const u64 *w, const u64 *bias, const u64 *div, u64 *
 size_t k_encrypt_work_words(const crc_ctx *c, size_t cnt);
 struct ChaChaKey;
 int k_encrypt(crc_ctx *c, const u64 *pk, const u64 *plain, size_t cnt, const ChaChaKey &key, u64 stream_base, u64 *ct, u64 *work, hipStream_t st);
+
+// kernels_mfma.hip: conv / dense multiply-accumulate as an int8 limb GEMM on the matrix cores (operand form CRC_NTTL)
+bool   k_limb_supported(const crc_ctx *c, int T);
+size_t k_limb_tensor_bytes(const crc_ctx *c, int B, int zd, int npos);
+size_t k_limb_weights_bytes(const crc_ctx *c, int nf, int zd, int taps);
+size_t k_limb_result_words(const crc_ctx *c, int B, int nf, int P);
+int k_limb_pack_tensor(crc_ctx *c, const u64 *x, signed char *xl, int B, int zd, int npos, bool packed, hipStream_t st);
+int k_limb_pack_weights(crc_ctx *c, const u64 *w, signed char *wl, int nf, int zd, int taps, hipStream_t st);
+int k_limb_result_to_rows(crc_ctx *c, const u64 *ys, u64 *y, size_t rows, bool pack_out, hipStream_t st);
+int k_limb_result_to_limb(crc_ctx *c, const u64 *ys, signed char *xl, int B, int zd, hipStream_t st);
+int k_limb_mac(crc_ctx *c, const signed char *xl, const signed char *wl, u64 *ys, const u64 *bias_ntt, int B, int zd, int xd, int yd, int xs, int ys_, int xf, int yf, int nf,
+               hipStream_t st);

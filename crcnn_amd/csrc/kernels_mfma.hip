@@ -1,0 +1,345 @@
+// kernels_mfma.hip -- the ct x pt multiply-accumulate of convolution / dense layers as an int8 limb GEMM on the matrix cores.
+//
+// Why.  mac3_kernel (kernels.hip) sits at 88 % of the v_mad_u64_u32 rate: gfx950 has no 64 x 64 multiplier and the vector ALU gives 5.7 T modular
+// multiply-adds per second, 3.5 % of what HBM could feed.  Per residue i and slot s a layer is a GEMM over Z_q,
+//       Y[m][f] = sum_t A[m][t] W[t][f]        m = (image, output pixel, poly),  t = (tap, channel),
+// and the integer MFMA unit does exact int8 x int8 -> int32 dot products 49x faster than that.  Every residue r < q < 2^55 is written as its centred
+// representative r' in (-q/2, q/2] (same class mod q) in balanced base 256,  r' = sum_{l<7} d_l 256^l, d_l in [-128, 127] (|d_6| <= 64).  Then
+// x w = sum_{l,m} a_l b_m 256^(l+m): 49 limb products on 13 diagonals l+m.  One v_mfma_i32_32x32x32_i8 forms a 32 x 32 tile of 32-term dot products
+// of one (l, m) pair into diagonal l+m's int32 accumulator -- exact while T 7 128^2 < 2^31 (T <= 18 000).  After the reduction loop
+// V = sum_d D_d 2^(8d) is reduced mod q ONCE per output.  Exact integer arithmetic, the same element of Z_q, hence the same bits as the reference
+// (convolutionalLayer.cpp:56-93 / fullyConnectedLayer.cpp:113-168) and as mac3_kernel; measured 4x faster on CrCNN's conv2+pool2 (profiles/r02_*).
+//
+// Layouts (CRC_NTTL, "limb form"; slot = i*n + s).  The GEMMs of different slots share nothing, so operands are SLOT-MAJOR here (the rest of the engine
+// is slot-minor: one row = n slots of one residue):
+//     tensor   Xl [slot][B][7 planes][positions][2 polys][zdp]          int8, zdp = channels rounded up to 32 (zero padded)
+//     weights  Wl [slot][reduction step = (tap, 32-channel block)][7 planes][Fp][32]   int8, Fp = filters rounded up to 64 (zero padded)
+//     result   Ys [slot][B][F][P][2] u64 canonical (internal), then transposed to the slot-minor tensor layout or re-limbed for a dense consumer
+// Workgroup = one slot, 64 rows x 64 filters: 4 waves (one per SIMD), a 32 x 32 tile and 13 x 16 int32 accumulators (208 AGPRs) each.  Per reduction
+// step the workgroup stages 64 x 32 B x 7 planes of A -- implicit im2col: each lane's LDS-DMA piece reads its own (pixel + tap) address, no patch
+// matrix exists -- and as much of W (contiguous) into a 4-slot LDS ring (112 KiB), three steps ahead of use; 49 MFMAs per wave and step.
+#include "kernels.h"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef signed char i8;
+
+#define NPL 7                                    // limb planes
+#define TILE_B (NPL * 64 * 32)                   // 14336: one operand tile of a reduction step (A: 64 rows, W: 64 filters), [plane][row][32 B]
+
+struct MfmaArgs {
+    const i8 *xl; const i8 *wl; u64 *ys; const ModParams *mods; const u64 *bias;     // bias: NTT-form delta rows [F][k][n] added to poly 0, or null
+    int n, k, B, zdp, npos, yd, xs, ys_, yf, yo, P, F, Fp, zblks, ksteps, M, mtiles, ntiles;
+    unsigned img_bytes; unsigned long long wslot_bytes;
+};
+
+// canonical residue -> 7 balanced base-256 digits of its centred representative
+__device__ __forceinline__ void limb_digits(u64 r, u64 q, int (&d)[NPL])
+{
+    long long v = r > (q >> 1) ? (long long)r - (long long)q : (long long)r;
+#pragma unroll
+    for (int l = 0; l < NPL; l++) { d[l] = (int)(signed char)(v & 0xff); v = (v - d[l]) >> 8; }
+}
+
+// V = sum_d D_d 2^(8d) (signed, |V| < 2^125)  ->  V mod q, canonical
+__device__ __forceinline__ u64 limb_reduce(const int (&D)[13], const ModParams &m)
+{
+    long long G[4];                                   // G_g = D_4g + D_4g+1 2^8 + D_4g+2 2^16 + D_4g+3 2^24   (|G| < 2^56)
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        long long a = D[4 * g];
+        if (4 * g + 1 < 13) a += (long long)D[4 * g + 1] * 256;
+        if (4 * g + 2 < 13) a += (long long)D[4 * g + 2] * 65536;
+        if (4 * g + 3 < 13) a += (long long)D[4 * g + 3] * 16777216;
+        G[g] = a;
+    }
+    // V = G0 + G1 2^32 + G2 2^64 + G3 2^96 in two's complement, plus q 2^(126 - bits) (a multiple of q in (2^125, 2^126): the sum is positive)
+    u64 lo = (u64)G[0], hi = (u64)(G[0] >> 63);
+    { const u64 t = (u64)G[1] << 32; const u64 nl = lo + t; hi += (u64)(G[1] >> 32) + (nl < lo); lo = nl; }
+    hi += (u64)G[2] + ((u64)G[3] << 32);
+    hi += m.q << (62 - m.bits);
+    return barrett128(lo, hi, m);
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) mfma_mac_kernel(MfmaArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) i8 lds[];                  // ring of 4 x (A tile | W tile)
+    constexpr int NST = 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 1, wn = wave & 1;
+    const int slots = a.n * a.k, per = a.mtiles * a.ntiles;
+    // XCD-aware decode (workgroups are dealt round-robin over the 8 XCDs): the tiles of one slot run on one XCD at about the same time, so what they share
+    // (the slot's weight limbs across row tiles, its rows across filter tiles) is fetched from HBM once and then served by that XCD's L2
+    int g = blockIdx.x, slot, tile;
+    if ((slots & 7) == 0) { const int xcd = g & 7, r = g >> 3; slot = xcd * (slots >> 3) + r / per; tile = r % per; }
+    else { slot = g / per; tile = g % per; }
+    const int mt = tile / a.ntiles, nt = tile % a.ntiles;
+    const int i = slot / a.n, s = slot % a.n;
+    const int m0 = mt * 64, f0 = nt * 64;
+    const ModParams m = a.mods[i];
+    const i8 *xs = a.xl + (size_t)slot * a.B * a.img_bytes;
+    const i8 *ws = a.wl + (size_t)slot * a.wslot_bytes + (size_t)f0 * 32;
+
+    // staging: 28 LDS-DMA pieces of 1 KiB per step (pieces 0..13 of A, 14..27 of W), 7 per wave (pieces wave, wave+4, ...); a piece = 64 lanes x 16 B,
+    // landing lane-linear.  A piece chunk c16 (0..895) -> (plane, row, half); row -> (image, pixel, poly)
+    u32 src_off[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+        const int pc = wave + 4 * j;
+        if (pc < 14) {
+            const int c16 = pc * 64 + lane;
+            const int plane = c16 >> 7, row = (c16 >> 1) & 63, half = c16 & 1;
+            const int mm = min(m0 + row, a.M - 1);                           // rows past M re-read the last one and are never stored
+            const int b = mm / (2 * a.P), p = (mm >> 1) % a.P, c = mm & 1;
+            const int ox = p / a.yo, oy = p % a.yo;
+            src_off[j] = (u32)b * a.img_bytes + (u32)(plane * (a.npos * 2 * a.zdp) + (((ox * a.xs) * a.yd + oy * a.ys_) * 2 + c) * a.zdp + half * 16);
+        } else src_off[j] = (u32)(((pc - 14) >> 1) * (a.Fp * 32) + ((pc - 14) & 1) * 1024 + lane * 16);
+    }
+    auto issue = [&](int ks) {
+        const int tap = ks / a.zblks, zb = ks - tap * a.zblks;
+        const int kx = tap / a.yf, ky = tap - kx * a.yf;
+        const u32 delta = (u32)((kx * a.yd + ky) * 2 * a.zdp + zb * 32);
+        i8 *dst = lds + (ks % NST) * (2 * TILE_B);
+        const i8 *wt = ws + (size_t)ks * (NPL * a.Fp * 32);
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const int pc = wave + 4 * j;
+            const i8 *src = pc < 14 ? xs + src_off[j] + delta : wt + src_off[j];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)(dst + pc * 1024), 16, 0, 0);
+        }
+    };
+
+    v16i acc[13];
+#pragma unroll
+    for (int d = 0; d < 13; d++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[d][e] = 0;
+
+    const int K = a.ksteps;
+    issue(0); if (K > 1) issue(1); if (K > 2) issue(2);
+    const int fragA = (wm * 32 + (lane & 31)) * 32 + (lane >> 5) * 16, fragW = (wn * 32 + (lane & 31)) * 32 + (lane >> 5) * 16;
+    for (int ks = 0; ks < K; ks++) {
+        // this wave's pieces of step ks have landed (up to two younger steps = 14 loads may still be in flight) ...
+        if (ks + 2 < K) __builtin_amdgcn_s_waitcnt(14 | (7 << 4) | (15 << 8));
+        else if (ks + 1 < K) __builtin_amdgcn_s_waitcnt(7 | (7 << 4) | (15 << 8));
+        else __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
+        __syncthreads();                                          // ... and everybody's; ring slot (ks + 3) % 4, read in step ks - 1, is free
+        if (ks + 3 < K) issue(ks + 3);
+        const i8 *tA = lds + (ks % NST) * (2 * TILE_B), *tW = tA + TILE_B;
+        v4i w[NPL];
+#pragma unroll
+        for (int l = 0; l < NPL; l++) w[l] = *reinterpret_cast<const v4i *>(tW + l * (64 * 32) + fragW);
+        // 49 limb products; the seven MFMAs of one A plane go to seven different diagonals (no back-to-back dependent accumulators)
+#pragma unroll
+        for (int l = 0; l < NPL; l++) {
+            const v4i av = *reinterpret_cast<const v4i *>(tA + l * (64 * 32) + fragA);
+#pragma unroll
+            for (int mm = 0; mm < NPL; mm++)
+                acc[l + mm] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, w[mm], acc[l + mm], 0, 0, 0);
+        }
+    }
+
+    // epilogue: C/D layout of a 32 x 32 tile: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    const int f = f0 + wn * 32 + (lane & 31);
+    const u64 bv = (a.bias && f < a.F) ? a.bias[((size_t)f * a.k + i) * a.n + s] : 0;
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+        const int mm = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        int D[13];
+#pragma unroll
+        for (int d = 0; d < 13; d++) D[d] = acc[d][reg];
+        u64 v = limb_reduce(D, m);
+        if (mm < a.M && f < a.F) {
+            const int b = mm / (2 * a.P), p = (mm >> 1) % a.P, c = mm & 1;
+            if (c == 0 && a.bias) v = addmod(v, bv, m.q);
+            a.ys[(((size_t)slot * a.B + b) * a.F + f) * (2 * a.P) + p * 2 + c] = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);                 // one output at a time: sixteen interleaved reductions would spill
+    }
+}
+
+// ---- layout conversions ------------------------------------------------------------------------------------------------------------------
+// slot-minor NTT-form tensor x [B][zd*npos cts][2][k][n] (canonical residues, or 28-bit limb pairs when `packed`) -> Xl.  One thread per (slot, image,
+// position, poly, 32-channel block); lanes run over 64 consecutive slots, so every read is a coalesced 512-B row segment
+__global__ void __launch_bounds__(64) limb_pack_tensor_kernel(const u64 *x, i8 *xl, const ModParams *mods, int n, int k, int B, int zd, int zdp, int npos, int packed)
+{
+    const int sblocks = n / 64;
+    const int sb = blockIdx.x % (sblocks * k), i = sb / sblocks, s = (sb % sblocks) * 64 + threadIdx.x;
+    size_t r = blockIdx.x / (sblocks * k);                       // ((b*npos + pos)*2 + c)*zblks + zb
+    const int zblks = zdp / 32;
+    const int zb = (int)(r % zblks); r /= zblks; const int c = (int)(r % 2); r /= 2; const int pos = (int)(r % npos); const int b = (int)(r / npos);
+    const u64 q = mods[i].q;
+    u32 pl[NPL][8];
+#pragma unroll
+    for (int l = 0; l < NPL; l++)
+#pragma unroll
+        for (int wv = 0; wv < 8; wv++) pl[l][wv] = 0;
+#pragma unroll
+    for (int z = 0; z < 32; z++) {
+        const int zz = zb * 32 + z;
+        if (zz < zd) {
+            u64 v = x[((((size_t)b * zd * npos + (size_t)zz * npos + pos) * 2 + c) * k + i) * (size_t)n + s];
+            if (packed) v = (v & 0xffffffffULL) | ((v >> 32) << 28);
+            int d[NPL]; limb_digits(v, q, d);
+#pragma unroll
+            for (int l = 0; l < NPL; l++) pl[l][z >> 2] |= (u32)(d[l] & 0xff) << (8 * (z & 3));
+        }
+    }
+    i8 *dst = xl + (((size_t)i * n + s) * B + b) * ((size_t)NPL * npos * 2 * zdp) + ((size_t)pos * 2 + c) * zdp + zb * 32;
+#pragma unroll
+    for (int l = 0; l < NPL; l++) {
+        uint4 *o = reinterpret_cast<uint4 *>(dst + (size_t)l * npos * 2 * zdp);
+        o[0] = make_uint4(pl[l][0], pl[l][1], pl[l][2], pl[l][3]); o[1] = make_uint4(pl[l][4], pl[l][5], pl[l][6], pl[l][7]);
+    }
+}
+// NTT-form weights w [F][zd][taps][k][n] (canonical) -> Wl (pre-zeroed: channel / filter padding).  One thread per (slot, filter, tap, channel block)
+__global__ void __launch_bounds__(64) limb_pack_weights_kernel(const u64 *w, i8 *wl, const ModParams *mods, int n, int k, int F, int Fp, int zd, int zblks, int taps)
+{
+    const int sblocks = n / 64;
+    const int sb = blockIdx.x % (sblocks * k), i = sb / sblocks, s = (sb % sblocks) * 64 + threadIdx.x;
+    size_t r = blockIdx.x / (sblocks * k);                       // (f*taps + tap)*zblks + zb
+    const int zb = (int)(r % zblks); r /= zblks; const int tap = (int)(r % taps); const int f = (int)(r / taps);
+    const u64 q = mods[i].q;
+    u32 pl[NPL][8];
+#pragma unroll
+    for (int l = 0; l < NPL; l++)
+#pragma unroll
+        for (int wv = 0; wv < 8; wv++) pl[l][wv] = 0;
+#pragma unroll
+    for (int z = 0; z < 32; z++) {
+        const int zz = zb * 32 + z;
+        if (zz < zd) {
+            const u64 v = w[((((size_t)f * zd + zz) * taps + tap) * k + i) * (size_t)n + s];
+            int d[NPL]; limb_digits(v, q, d);
+#pragma unroll
+            for (int l = 0; l < NPL; l++) pl[l][z >> 2] |= (u32)(d[l] & 0xff) << (8 * (z & 3));
+        }
+    }
+    i8 *dst = wl + ((size_t)i * n + s) * ((size_t)taps * zblks * NPL * Fp * 32) + ((size_t)tap * zblks + zb) * (NPL * Fp * 32) + (size_t)f * 32;
+#pragma unroll
+    for (int l = 0; l < NPL; l++) {
+        uint4 *o = reinterpret_cast<uint4 *>(dst + (size_t)l * Fp * 32);
+        o[0] = make_uint4(pl[l][0], pl[l][1], pl[l][2], pl[l][3]); o[1] = make_uint4(pl[l][4], pl[l][5], pl[l][6], pl[l][7]);
+    }
+}
+// Ys [slot][rows] (rows = B*F*P*2 canonical u64, slot-major) -> y [rows][k][n] (the engine's slot-minor tensor layout): 64 x 64 tile transpose through LDS
+__global__ void __launch_bounds__(256) slotmajor_to_rows_kernel(const u64 *ys, u64 *y, int n, int k, size_t rows, int pack_out)
+{
+    __shared__ u64 tile[64][65];
+    const int sblocks = n / 64;
+    const int sb = blockIdx.x % (sblocks * k), i = sb / sblocks, s0 = (sb % sblocks) * 64;
+    const size_t e0 = (size_t)(blockIdx.x / (sblocks * k)) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int sl = r * 4 + ty;
+        const size_t e = e0 + tx;
+        tile[sl][tx] = e < rows ? ys[((size_t)i * n + s0 + sl) * rows + e] : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int el = r * 4 + ty;
+        const size_t e = e0 + el;
+        if (e < rows) { u64 v = tile[tx][el]; if (pack_out) v = (v & 0x0fffffffULL) | ((v >> 28) << 32); y[(e * k + i) * (size_t)n + s0 + tx] = v; }
+    }
+}
+// Ys [slot][B][zd'*2] (zd' = F*P flattened channels, poly innermost) -> Xl' [slot][B][7][1][2][zdp'] for a dense consumer.  One thread per 16 channels.
+__global__ void __launch_bounds__(256) slotmajor_to_limb_kernel(const u64 *ys, i8 *xl, const ModParams *mods, int n, int B, int zd, int zdp, size_t total)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;              // ((slot*B + b)*2 + c)*(zdp/16) + zg
+    if (t >= total) return;
+    const int zgs = zdp / 16;
+    const int zg = (int)(t % zgs); size_t r = t / zgs; const int c = (int)(r % 2); r /= 2; const int b = (int)(r % B); const size_t slot = r / B;
+    const u64 q = mods[slot / n].q;
+    u32 pl[NPL][4];
+#pragma unroll
+    for (int l = 0; l < NPL; l++)
+#pragma unroll
+        for (int wv = 0; wv < 4; wv++) pl[l][wv] = 0;
+    const u64 *src = ys + (slot * B + b) * (size_t)zd * 2 + c;
+#pragma unroll
+    for (int z = 0; z < 16; z++) {
+        const int zz = zg * 16 + z;
+        if (zz < zd) {
+            int d[NPL]; limb_digits(src[(size_t)zz * 2], q, d);
+#pragma unroll
+            for (int l = 0; l < NPL; l++) pl[l][z >> 2] |= (u32)(d[l] & 0xff) << (8 * (z & 3));
+        }
+    }
+    i8 *dst = xl + (slot * B + b) * ((size_t)NPL * 2 * zdp) + (size_t)c * zdp + zg * 16;
+#pragma unroll
+    for (int l = 0; l < NPL; l++) *reinterpret_cast<uint4 *>(dst + (size_t)l * 2 * zdp) = make_uint4(pl[l][0], pl[l][1], pl[l][2], pl[l][3]);
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------------------------------------------
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+bool k_limb_supported(const crc_ctx *c, int T)
+{
+    if (c->n < 64 || T > 18000) return false;
+    for (int i = 0; i < c->k; i++) if (c->tabs[i].m.bits > 55) return false;          // 7 balanced bytes hold |r'| < 2^54
+    return true;
+}
+size_t k_limb_tensor_bytes(const crc_ctx *c, int B, int zd, int npos) { return (size_t)c->n * c->k * B * NPL * npos * 2 * round_up(zd, 32); }
+size_t k_limb_weights_bytes(const crc_ctx *c, int nf, int zd, int taps) { return (size_t)c->n * c->k * taps * (round_up(zd, 32) / 32) * NPL * round_up(nf, 64) * 32; }
+size_t k_limb_result_words(const crc_ctx *c, int B, int nf, int P) { return (size_t)c->n * c->k * B * nf * P * 2; }
+
+int k_limb_pack_tensor(crc_ctx *c, const u64 *x, i8 *xl, int B, int zd, int npos, bool packed, hipStream_t st)
+{
+    const int zdp = round_up(zd, 32);
+    const size_t blocks = (size_t)(c->n / 64) * c->k * B * npos * 2 * (zdp / 32);
+    if (blocks == 0) return CRC_OK;
+    if (blocks > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(limb_pack_tensor_kernel, dim3((unsigned)blocks), dim3(64), 0, st, x, xl, c->d_mods, c->n, c->k, B, zd, zdp, npos, packed ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    return CRC_OK;
+}
+int k_limb_pack_weights(crc_ctx *c, const u64 *w, i8 *wl, int nf, int zd, int taps, hipStream_t st)
+{
+    const int zblks = round_up(zd, 32) / 32, Fp = round_up(nf, 64);
+    HIPCHK(hipMemsetAsync(wl, 0, k_limb_weights_bytes(c, nf, zd, taps), st));
+    const size_t blocks = (size_t)(c->n / 64) * c->k * nf * taps * zblks;
+    if (blocks > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(limb_pack_weights_kernel, dim3((unsigned)blocks), dim3(64), 0, st, w, wl, c->d_mods, c->n, c->k, nf, Fp, zd, zblks, taps);
+    HIPCHK(hipGetLastError());
+    return CRC_OK;
+}
+int k_limb_result_to_rows(crc_ctx *c, const u64 *ys, u64 *y, size_t rows, bool pack_out, hipStream_t st)
+{
+    const size_t blocks = (size_t)(c->n / 64) * c->k * ((rows + 63) / 64);
+    if (blocks == 0) return CRC_OK;
+    if (blocks > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(slotmajor_to_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ys, y, c->n, c->k, rows, pack_out ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    return CRC_OK;
+}
+int k_limb_result_to_limb(crc_ctx *c, const u64 *ys, i8 *xl, int B, int zd, hipStream_t st)
+{
+    const int zdp = round_up(zd, 32);
+    const size_t total = (size_t)c->n * c->k * B * 2 * (zdp / 16);
+    if (total == 0) return CRC_OK;
+    hipLaunchKernelGGL(slotmajor_to_limb_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ys, xl, c->d_mods, c->n, B, zd, zdp, total);
+    HIPCHK(hipGetLastError());
+    return CRC_OK;
+}
+// the layer: Xl (B images of zd x xd x yd) * Wl -> Ys [slot][B][nf][P][2], + NTT-form bias on poly 0
+int k_limb_mac(crc_ctx *c, const i8 *xl, const i8 *wl, u64 *ys, const u64 *bias_ntt, int B, int zd, int xd, int yd, int xs, int ys_, int xf, int yf, int nf, hipStream_t st)
+{
+    if (B == 0) return CRC_OK;
+    const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys_ + 1;
+    MfmaArgs a{};
+    a.xl = xl; a.wl = wl; a.ys = ys; a.mods = c->d_mods; a.bias = bias_ntt;
+    a.n = c->n; a.k = c->k; a.B = B; a.zdp = round_up(zd, 32); a.npos = xd * yd; a.yd = yd; a.xs = xs; a.ys_ = ys_; a.yf = yf; a.yo = yo; a.P = xo * yo;
+    a.F = nf; a.Fp = round_up(nf, 64); a.zblks = a.zdp / 32; a.ksteps = xf * yf * a.zblks; a.M = B * a.P * 2;
+    a.mtiles = (a.M + 63) / 64; a.ntiles = a.Fp / 64;
+    const size_t img = (size_t)NPL * a.npos * 2 * a.zdp;
+    if (img * B > 0xffffffffULL || !k_limb_supported(c, a.ksteps * 32)) return CRC_ERR_UNSUPPORTED;
+    a.img_bytes = (unsigned)img; a.wslot_bytes = (unsigned long long)a.ksteps * NPL * a.Fp * 32;
+    const size_t grid = (size_t)c->n * c->k * a.mtiles * a.ntiles;
+    if (grid > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
+    const size_t lds = 8 * TILE_B;
+    auto kern = mfma_mac_kernel;
+    { const int rc = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (rc) return rc; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);
+    HIPCHK(hipGetLastError());
+    return CRC_OK;
+}

@@ -61,8 +61,13 @@ def layer_macs(kind, a):
 class Network:
     """Encoded network resident in HBM.  `alloc(nbytes)` must return an object Engine.p() understands."""
 
-    def __init__(self, eng, model, h5_path=None, weights=None, alloc=None, resident=True, encode_chunk=2048, dbc=16, d_evk=None, materialize=True, fuse_pool=None):
+    def __init__(self, eng, model, h5_path=None, weights=None, alloc=None, resident=True, encode_chunk=2048, dbc=16, d_evk=None, materialize=True, fuse_pool=None, limb=None):
         self.E, self.model, self.topo = eng, model, TOPOLOGIES[model]
+        # conv / dense layers with long reductions run on the matrix cores (operand form CRC_NTTL, kernels_mfma.hip) unless CRC_MFMA=0
+        import os
+        self.limb = (os.environ.get("CRC_MFMA", "1") != "0") if limb is None else limb
+        self._limbed = False
+        self.limb_reserve = 24 << 30          # HBM to leave free when a limb copy of the weights is made (activations + work space come later)
         self.alloc = alloc or eng.alloc
         self.resident = resident            # keep tensors NTT-resident between layers (bit-identical, SURVEY 8f-1)
         self.dbc, self.d_evk = dbc, d_evk
@@ -110,9 +115,57 @@ class Network:
 
     # ---- operand form of the MAC kernels (CRC_NTTP: 28-bit limb pairs): weights are packed once, and a conv / dense layer that feeds
     # another one hands its output over packed, so that no kernel has to split a residue again (+12 % on the conv / dense layers)
+    def limb_eligible(self, kind, a):
+        """long reductions go to the matrix-core kernel: at least 16 reduction steps of 32 channels (below that its fixed costs per output tile -- ring fill,
+        13-diagonal reduction, layout conversions -- and the channel padding eat the gain: ApproxPlainModel's conv2, 9 steps of 20/32 channels, ties mac3_kernel)"""
+        if kind == "conv":
+            zd, xf, yf = a["zd"], a["xf"], a["yf"]
+        elif kind == "fc":
+            zd, xf, yf = a["in_dim"], 1, 1
+        else:
+            return False
+        return self.limb and zd >= 16 and -(-zd // 32) * xf * yf >= 16 and self.E.limb_supported(zd, xf, yf)
+
+    def _limb_operands(self):
+        """conv / dense weights of the eligible layers -> limb form (the canonical copy is dropped: call after fuse()); a limb layer that feeds a dense
+        limb layer hands its tensor over in limb form"""
+        E = self.E
+        if self._limbed or not self.limb:
+            return
+        assert not self._packed
+        for idx, (kind, name, a, p, ishape, oshape) in enumerate(self.plan):
+            if not self.limb_eligible(kind, a):
+                continue
+            nf, zd, xf, yf = (a["nf"], a["zd"], a["xf"], a["yf"]) if kind == "conv" else (a["out_dim"], a["in_dim"], 1, 1)
+            nbytes = E.limb_weights_bytes(nf, zd, xf, yf)
+            # the limb copy is built beside the canonical one: a layer whose two copies do not fit in HBM stays on the vector-ALU kernel
+            if E.mem_info()[0] < nbytes + self.limb_reserve:
+                continue
+            wl = self.alloc(nbytes)
+            E.limb_pack_weights(p["w"], nf, zd, xf, yf, wl)
+            E.sync()
+            self.weight_bytes += nbytes - nf * zd * xf * yf * E.k * E.n * 8
+            self._free(p["w"])
+            p["w"], p["w_form"] = wl, binding.NTTL
+        for idx, (kind, name, a, p, ishape, oshape) in enumerate(self.plan):
+            nxt = self.plan[idx + 1] if idx + 1 < len(self.plan) else None
+            if p.get("w_form") == binding.NTTL and nxt and nxt[0] == "fc" and nxt[3].get("w_form") == binding.NTTL and p["out_form"] == NTT and nxt[3]["in_form"] == NTT:
+                p["out_form"] = nxt[3]["in_form"] = binding.NTTL
+        self._limbed = True
+
+    def _free(self, buf):
+        """give a parameter buffer back (torch tensors handed out by bench.py's allocator are dropped from its keep list through `release`)"""
+        self.param_bufs = [(b_, n_) for (b_, n_) in self.param_bufs if b_ is not buf]
+        if getattr(self, "release", None):
+            self.release(buf)
+        elif hasattr(buf, "free"):
+            buf.free()
+
     def _pack_operands(self, unpack=False):
         """called by prepare() (pack) and by fuse() (unpack: the folding kernels work on canonical residues)"""
         E = self.E
+        if unpack:
+            assert not self._limbed, "fuse() must run before the weights are converted to limb form"
         if max(int(q).bit_length() for q in E.q) > 55 or self._packed == (not unpack):
             return
         for idx, (kind, name, a, p, ishape, oshape) in enumerate(self.plan):
@@ -126,9 +179,10 @@ class Network:
                 continue
             if kind not in ("conv", "fc"):
                 continue
-            rows = (a["nf"] * a["zd"] * a["xf"] * a["yf"] if kind == "conv" else a["in_dim"] * a["out_dim"]) * E.k
-            E.pack28(p["w"], rows, unpack=unpack)
-            p["w_form"] = NTT if unpack else binding.NTTP
+            if p.get("w_form") != binding.NTTL:
+                rows = (a["nf"] * a["zd"] * a["xf"] * a["yf"] if kind == "conv" else a["in_dim"] * a["out_dim"]) * E.k
+                E.pack28(p["w"], rows, unpack=unpack)
+                p["w_form"] = NTT if unpack else binding.NTTP
             nxt = self.plan[idx + 1] if idx + 1 < len(self.plan) else None
             if nxt and nxt[0] in ("conv", "fc"):
                 if not unpack and p["out_form"] == NTT and nxt[3]["in_form"] == NTT:
@@ -277,9 +331,9 @@ class Network:
         work = 0
         for (kind, name, a, p, ishape, oshape) in self.plan:
             if kind == "conv":
-                work = max(work, E.conv2d_work_bytes(B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"], p["in_form"]))
+                work = max(work, E.conv2d_forms_work_bytes(B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"], p["in_form"], p.get("w_form", NTT), p["out_form"]))
             elif kind == "fc":
-                work = max(work, E.dense_work_bytes(B, a["in_dim"], a["out_dim"], p["in_form"]))
+                work = max(work, E.conv2d_forms_work_bytes(B, a["in_dim"], 1, 1, 1, 1, 1, 1, a["out_dim"], p["in_form"], p.get("w_form", NTT), p["out_form"]))
             elif kind == "square":
                 work = max(work, E.square_relin_work_bytes(B * int(np.prod(ishape)), self.dbc))
         return need_act, work
@@ -295,9 +349,12 @@ class Network:
                 slots.append(cur)
         return slots
 
-    def prepare(self, B):
-        """allocate the two ping-pong activation buffers and the work space for chunks of B images; put the MAC operands into packed form"""
+    def prepare(self, B, limb=True):
+        """allocate the two ping-pong activation buffers and the work space for chunks of B images; put the MAC operands into their kernel's operand form
+        (limb=False keeps every layer on the vector-ALU kernel: needed while fuse() is still to come)"""
         if self.materialize:
+            if limb:
+                self._limb_operands()
             self._pack_operands()
         acts = self.activation_cts()
         self.B = B

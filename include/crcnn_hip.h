@@ -50,7 +50,15 @@ enum { CRC_COEFF = 0, CRC_NTT = 1,
         * kernels (no 64x64 multiplier on gfx950; 3 v_mad_u64_u32 per product on 28-bit limbs).  Only crc_conv2d_forms /
         * crc_dense_forms take or produce it (weights and the tensors that travel between conv / dense layers); crc_pack28 converts.
         * Needs coefficient moduli below 2^56. */
-       CRC_NTTP = 2 };
+       CRC_NTTP = 2,
+       /* "limb form": the operand form of the matrix-core multiply-accumulate (kernels_mfma.hip).  Every residue as the seven balanced base-256 digits of
+        * its centred representative (int8), SLOT-MAJOR: tensors [k][n][B][7][positions][2 polys][channels rounded up to 32], weights
+        * [k][n][tap][channel block][7][filters rounded up to 64][32].  Exact integer arithmetic on v_mfma_i32_32x32x32_i8 (49 limb products per modular
+        * multiply, int32 accumulators, one reduction per output): the same ciphertexts as every other form, about 4x the throughput of the vector-ALU
+        * kernel on long reductions.  crc_limb_pack_weights makes the weights; crc_conv2d_forms / crc_dense_forms take w_form = CRC_NTTL, convert a
+        * CRC_COEFF / CRC_NTT / CRC_NTTP input themselves and produce any form (out_form = CRC_NTTL hands the tensor to a DENSE layer: channels =
+        * (filter, x, y) flattened, 1 x 1 positions).  Needs coefficient moduli below 2^56 and reductions of at most 18 000 terms. */
+       CRC_NTTL = 3 };
 
 const char *crc_strerror(int status);
 int         crc_last_hip_error(void);
@@ -77,6 +85,7 @@ size_t crc_evk_words(const crc_ctx *ctx, int dbc);     /* words of an evaluation
 int  crc_ctx_table(const crc_ctx *ctx, const char *name, uint64_t *h_out, int cap);
 
 /* thin device-memory helpers so that C / C++ / ctypes callers need not link HIP themselves */
+int crc_mem_info(crc_ctx *ctx, size_t *free_bytes, size_t *total_bytes);      /* hipMemGetInfo of the context's device */
 int crc_malloc(crc_ctx *ctx, size_t bytes, void **d_ptr);
 int crc_free(crc_ctx *ctx, void *d_ptr);
 int crc_memcpy_h2d(crc_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, void *stream);
@@ -171,6 +180,13 @@ int crc_conv2d_forms(crc_ctx *ctx, const uint64_t *d_x, const uint64_t *d_w_ntt,
                      int in_form, int out_form, uint64_t *d_y, void *d_work, void *stream);
 int crc_dense_forms(crc_ctx *ctx, const uint64_t *d_x, const uint64_t *d_w_ntt, int w_form, const uint64_t *d_bias_delta,
                     int B, int in_dim, int out_dim, int in_form, int out_form, uint64_t *d_y, void *d_work, void *stream);
+/* limb form (CRC_NTTL): sizes, weight conversion (from CRC_NTT canonical weights; d_wl: crc_limb_weights_bytes), and the work space of
+ * crc_conv2d_forms / crc_dense_forms when w_form = CRC_NTTL (crc_conv2d_work_bytes covers the other weight forms) */
+int    crc_limb_supported(const crc_ctx *ctx, int zd, int xf, int yf);
+size_t crc_limb_tensor_bytes(const crc_ctx *ctx, int B, int zd, int xd, int yd);
+size_t crc_limb_weights_bytes(const crc_ctx *ctx, int nf, int zd, int xf, int yf);
+int    crc_limb_pack_weights(crc_ctx *ctx, const uint64_t *d_w_ntt, int nf, int zd, int xf, int yf, void *d_wl, void *stream);
+size_t crc_conv2d_forms_work_bytes(const crc_ctx *ctx, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int in_form, int w_form, int out_form);
 /* in-place CRC_NTT <-> CRC_NTTP conversion of `rows` residue rows (unpack = 0: pack, 1: unpack) */
 int crc_pack28(crc_ctx *ctx, uint64_t *d_rows, size_t rows, int unpack, void *stream);
 size_t crc_dense_work_bytes(const crc_ctx *ctx, int B, int in_dim, int out_dim, int in_form);
