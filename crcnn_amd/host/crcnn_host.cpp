@@ -290,6 +290,23 @@ static shared_ptr<DeviceBuffer> &ensure(shared_ptr<DeviceBuffer> &b, size_t byte
     return b;
 }
 
+// canonical NTT-form weights -> limb form (CRC_NTTL) when the reduction is long enough for the matrix-core kernel to pay (same rule as netrun.py) and the
+// second copy fits beside the first; the canonical copy is dropped
+static bool toLimb(shared_ptr<DeviceBuffer> &d_w, int &w_form, int nf, int zd, int xf, int yf)
+{
+    if (w_form == CRC_NTTL) return true;
+    if (zd < 16 || (zd + 31) / 32 * xf * yf < 16 || !crc_limb_supported(ctx(), zd, xf, yf)) return false;
+    const size_t nbytes = crc_limb_weights_bytes(ctx(), nf, zd, xf, yf);
+    size_t free_b = 0, total_b = 0;
+    chk(crc_mem_info(ctx(), &free_b, &total_b), "crc_mem_info");
+    if (free_b < nbytes + ((size_t)24 << 30)) return false;
+    auto wl = make_shared<DeviceBuffer>(nbytes);
+    chk(crc_limb_pack_weights(ctx(), (const uint64_t *)d_w->ptr, nf, zd, xf, yf, wl->ptr, nullptr), "crc_limb_pack_weights");
+    chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+    d_w = wl; w_form = CRC_NTTL;
+    return true;
+}
+
 // ---- ConvolutionalLayer -----------------------------------------------------------------------------------------------
 ConvolutionalLayer::ConvolutionalLayer(string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf, int nf, int th_count, plaintext4D &filters, vector<Plaintext> &biases)
     : Layer(name), xd(xd), yd(yd), zd(zd), xs(xs), ys(ys), xf(xf), yf(yf), nf(nf), th_count(th_count),
@@ -320,9 +337,11 @@ void ConvolutionalLayer::deviceParameters(vector<shared_ptr<DeviceBuffer>> &out,
     packWeights(true);                                      // canonical residues on the wire (uploads first if needed)
     out.push_back(d_w); out.push_back(d_b[0]); out.push_back(d_b[1]);
 }
+bool ConvolutionalLayer::limbWeights() { upload(); if (w_form == CRC_NTTP) packWeights(true); return toLimb(d_w, w_form, nf, zd, xf, yf); }
 void ConvolutionalLayer::packWeights(bool unpack)
 {
     upload();
+    if (w_form == CRC_NTTL) { if (unpack) throw logic_error("ConvolutionalLayer " + name + ": weights are in limb form (fuse() / broadcastParameters() must precede the first forward())"); return; }
     if ((w_form == CRC_NTTP) == !unpack) return;
     chk(crc_pack28(ctx(), (uint64_t *)d_w->ptr, (size_t)nf * zd * xf * yf * K(), unpack ? 1 : 0, nullptr), "crc_pack28");
     w_form = unpack ? CRC_NTT : CRC_NTTP;
@@ -332,7 +351,7 @@ ciphertext3D ConvolutionalLayer::forward(ciphertext3D input)
     checkInput(input, zd, xd, yd, "ConvolutionalLayer");
     upload();
     ciphertext3D out(input.B, zo, xo, yo, out_form);
-    size_t wb = crc_conv2d_work_bytes(ctx(), input.B, zd, xd, yd, xs, ys, xf, yf, nf, input.form);
+    size_t wb = crc_conv2d_forms_work_bytes(ctx(), input.B, zd, xd, yd, xs, ys, xf, yf, nf, input.form, w_form, out_form);
     if (!wb) throw invalid_argument("ConvolutionalLayer: unsupported geometry");
     ensure(d_work, wb);
     chk(crc_conv2d_forms(ctx(), input.data(), (const uint64_t *)d_w->ptr, w_form, (const uint64_t *)d_b[out_form != CRC_COEFF]->ptr, input.B, zd, xd, yd, xs, ys, xf, yf, nf,
@@ -380,9 +399,11 @@ void FullyConnectedLayer::deviceParameters(vector<shared_ptr<DeviceBuffer>> &out
     packWeights(true);
     out.push_back(d_w); out.push_back(d_b[0]); out.push_back(d_b[1]);
 }
+bool FullyConnectedLayer::limbWeights() { upload(); if (w_form == CRC_NTTP) packWeights(true); return toLimb(d_w, w_form, out_dim, in_dim, 1, 1); }
 void FullyConnectedLayer::packWeights(bool unpack)
 {
     upload();
+    if (w_form == CRC_NTTL) { if (unpack) throw logic_error("FullyConnectedLayer " + name + ": weights are in limb form (fuse() / broadcastParameters() must precede the first forward())"); return; }
     if ((w_form == CRC_NTTP) == !unpack) return;
     chk(crc_pack28(ctx(), (uint64_t *)d_w->ptr, (size_t)in_dim * out_dim * K(), unpack ? 1 : 0, nullptr), "crc_pack28");
     w_form = unpack ? CRC_NTT : CRC_NTTP;
@@ -392,7 +413,7 @@ ciphertext3D FullyConnectedLayer::forward(ciphertext3D input)
     if (!input.buf || input.zd * input.xd * input.yd != in_dim) throw invalid_argument("FullyConnectedLayer: input size does not match in_dim");   // reshapeInput, :38-56
     upload();
     ciphertext3D out(input.B, 1, out_dim, 1, out_form);
-    ensure(d_work, crc_dense_work_bytes(ctx(), input.B, in_dim, out_dim, input.form));
+    ensure(d_work, crc_conv2d_forms_work_bytes(ctx(), input.B, in_dim, 1, 1, 1, 1, 1, 1, out_dim, input.form, w_form, out_form));
     chk(crc_dense_forms(ctx(), input.data(), (const uint64_t *)d_w->ptr, w_form, (const uint64_t *)d_b[out_form != CRC_COEFF]->ptr, input.B, in_dim, out_dim, input.form, out_form,
                         out.data(), d_work->ptr, nullptr), "crc_dense_forms");
     return out;
@@ -501,15 +522,19 @@ ciphertext3D Network::forward(ciphertext3D input)
     bool packable = true;
     { vector<uint64_t> q(K()); crc_ctx_table(ctx(), "q", q.data(), K()); for (uint64_t v : q) if (v >> 55) packable = false; }
     auto isMac = [&](int i) { return i >= 0 && i < L && (dynamic_pointer_cast<ConvolutionalLayer>(layers[i]) || dynamic_pointer_cast<FullyConnectedLayer>(layers[i])); };
+    vector<char> limb(L, 0);
     if (packable)
         for (int i = 0; i < L; i++) {
-            if (auto c = dynamic_pointer_cast<ConvolutionalLayer>(layers[i])) c->packWeights(false);
-            else if (auto f = dynamic_pointer_cast<FullyConnectedLayer>(layers[i])) f->packWeights(false);
+            if (auto c = dynamic_pointer_cast<ConvolutionalLayer>(layers[i])) { limb[i] = matrix_cores && c->limbWeights(); if (!limb[i]) c->packWeights(false); }
+            else if (auto f = dynamic_pointer_cast<FullyConnectedLayer>(layers[i])) { limb[i] = matrix_cores && f->limbWeights(); if (!limb[i]) f->packWeights(false); }
         }
     for (int i = 0; i < L; i++) {
         bool coeff = !ntt_resident || i == L - 1 || i + 1 == layer_before_reenc;
         // a conv / dense layer feeding another one hands its tensor over packed as well
-        layers[i]->out_form = coeff ? CRC_COEFF : (packable && max_num_of_reencryptions < 0 && isMac(i) && isMac(i + 1) ? CRC_NTTP : CRC_NTT);
+        // ... and a limb layer feeding a DENSE limb layer hands it over in limb form
+        const bool to_dense_limb = i + 1 < L && limb[i] && limb[i + 1] && dynamic_pointer_cast<FullyConnectedLayer>(layers[i + 1]);
+        layers[i]->out_form = coeff ? CRC_COEFF : to_dense_limb && max_num_of_reencryptions < 0 ? CRC_NTTL
+                            : (packable && max_num_of_reencryptions < 0 && isMac(i) && isMac(i + 1) ? CRC_NTTP : CRC_NTT);
     }
     last_layer_ms.assign(L, 0.0);
     if (max_num_of_reencryptions >= 0) {                    // network.cpp:52-96

@@ -117,9 +117,10 @@ public:
     void printLayerStructure() override;
 private:
     std::shared_ptr<DeviceBuffer> d_w, d_b[2], d_work;      // NTT-form weights, bias delta in coefficient / NTT form
-    int w_form = CRC_NTT;                                   // CRC_NTTP once Network::forward has put the weights into the MAC kernels' operand form
+    int w_form = CRC_NTT;                                   // CRC_NTTP / CRC_NTTL once Network::forward has put the weights into their MAC kernel's operand form
     void upload();
     void packWeights(bool unpack);
+    bool limbWeights();                                     // -> CRC_NTTL (matrix-core kernel) when the layer qualifies and HBM has room for the second copy
 public:
     void deviceParameters(std::vector<std::shared_ptr<DeviceBuffer>> &out, bool allocate_only) override;
 };
@@ -144,6 +145,7 @@ private:
     int w_form = CRC_NTT;
     void upload();
     void packWeights(bool unpack);
+    bool limbWeights();
 public:
     void deviceParameters(std::vector<std::shared_ptr<DeviceBuffer>> &out, bool allocate_only) override;
 };
@@ -215,6 +217,10 @@ public:
     // the accelerated path, so it is a setting here: 6 reproduces the committed reference, -1 (default) never refreshes.
     int layer_before_reenc = -1;
     bool ntt_resident = true;                               // keep tensors in NTT form between linear layers (bit-identical)
+    // conv / dense layers with long reductions (>= 16 steps of 32 channels) run as an int8 limb GEMM on the matrix cores (CRC_NTTL, kernels_mfma.hip):
+    // exact integer arithmetic, identical ciphertexts, about 4x the vector-ALU kernel.  The conversion of a layer's weights drops their canonical copy,
+    // so fuse() and broadcastParameters() must come before the first forward().
+    bool matrix_cores = true;
     // >= 0 selects the budget-checking forward the reference keeps for its parameter search (network.cpp:52-96): after every layer the
     // noise budget of output[0][0][0] is measured (secret key, coefficient form at every boundary); at <= 5 bits the layer's input is
     // refreshed and the layer repeated while refreshes are left, then OutOfBudgetException(i - 1) is thrown.  -1: plain forward.
