@@ -27,9 +27,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 CONFIGS = {
     # BASELINE.json configs[1]: PlainModelTiny.h5, n=4096, batch=1024 on one MI355X  (q = coeff_modulus_128(4096), t = 2^20)
-    "tiny4096": dict(model="PlainModelTiny", n=4096, k=2, t=1 << 32, batch=1024, chunk=24),   # t=2^32: exact logits without the client-side refresh
+    "tiny4096": dict(model="PlainModelTiny", n=4096, k=2, t=1 << 32, batch=1024, chunk=32),   # t=2^32: exact logits without the client-side refresh
     # configs[2]: ApproxPlainModel.h5, n=8192, 3 coeff moduli, batch=1024
-    "approx8192": dict(model="ApproxPlainModel", n=8192, k=3, t=1 << 42, batch=1024, chunk=24),   # t=2^42: exact logits, 19 bits of budget left
+    "approx8192": dict(model="ApproxPlainModel", n=8192, k=3, t=1 << 42, batch=1024, chunk=32),   # t=2^42: exact logits, 19 bits of budget left
     # configs[4]: PlainModelWoPad.h5, n=16384, 4 coeff moduli
     "wopad16384": dict(model="PlainModelWoPad", n=16384, k=4, t=1 << 44, batch=1024, chunk=6),
     # the coefficient modulus CrCNN itself would run at n=8192 (all four primes of coeff_modulus_128(8192)); at n=16384 the

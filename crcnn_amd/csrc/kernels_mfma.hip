@@ -19,6 +19,7 @@
 // step the workgroup stages 64 x 32 B x 7 planes of A -- implicit im2col: each lane's LDS-DMA piece reads its own (pixel + tap) address, no patch
 // matrix exists -- and as much of W (contiguous) into a 4-slot LDS ring (112 KiB), three steps ahead of use; 49 MFMAs per wave and step.
 #include "kernels.h"
+#include <cstdlib>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -61,10 +62,10 @@ __device__ __forceinline__ u64 limb_reduce(const int (&D)[13], const ModParams &
     return barrett128(lo, hi, m);
 }
 
+template <int NST>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) mfma_mac_kernel(MfmaArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) i8 lds[];                  // ring of 4 x (A tile | W tile)
-    constexpr int NST = 4;
+    extern __shared__ __attribute__((aligned(16))) i8 lds[];                  // ring of NST x (A tile | W tile): the loads run NST - 1 reduction steps ahead
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 1, wn = wave & 1;
     const int slots = a.n * a.k, per = a.mtiles * a.ntiles;
     // XCD-aware decode (workgroups are dealt round-robin over the 8 XCDs): the tiles of one slot run on one XCD at about the same time, so what they share
@@ -94,18 +95,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             src_off[j] = (u32)b * a.img_bytes + (u32)(plane * (a.npos * 2 * a.zdp) + (((ox * a.xs) * a.yd + oy * a.ys_) * 2 + c) * a.zdp + half * 16);
         } else src_off[j] = (u32)(((pc - 14) >> 1) * (a.Fp * 32) + ((pc - 14) & 1) * 1024 + lane * 16);
     }
-    auto issue = [&](int ks) {
+    // the step's wave-uniform terms (tap offset inside an image block, ring slot, weight tile), then one piece (j = 0..6: this wave's j-th piece)
+    struct StepAddr { u32 delta; i8 *dst; const i8 *wt; };
+    auto step_addr = [&](int ks) {
         const int tap = ks / a.zblks, zb = ks - tap * a.zblks;
         const int kx = tap / a.yf, ky = tap - kx * a.yf;
-        const u32 delta = (u32)((kx * a.yd + ky) * 2 * a.zdp + zb * 32);
-        i8 *dst = lds + (ks % NST) * (2 * TILE_B);
-        const i8 *wt = ws + (size_t)ks * (NPL * a.Fp * 32);
+        return StepAddr{(u32)((kx * a.yd + ky) * 2 * a.zdp + zb * 32), lds + (ks % NST) * (2 * TILE_B), ws + (size_t)ks * (NPL * a.Fp * 32)};
+    };
+    auto issue_one = [&](const StepAddr &sa, int j) {
+        const int pc = wave + 4 * j;
+        const i8 *src = pc < 14 ? xs + src_off[j] + sa.delta : sa.wt + src_off[j];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)(sa.dst + pc * 1024), 16, 0, 0);
+    };
+    auto issue = [&](int ks) {
+        const StepAddr sa = step_addr(ks);
 #pragma unroll
-        for (int j = 0; j < 7; j++) {
-            const int pc = wave + 4 * j;
-            const i8 *src = pc < 14 ? xs + src_off[j] + delta : wt + src_off[j];
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)(dst + pc * 1024), 16, 0, 0);
-        }
+        for (int j = 0; j < 7; j++) issue_one(sa, j);
     };
 
     v16i acc[13];
@@ -115,15 +120,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         for (int e = 0; e < 16; e++) acc[d][e] = 0;
 
     const int K = a.ksteps;
-    issue(0); if (K > 1) issue(1); if (K > 2) issue(2);
+#pragma unroll
+    for (int j = 0; j < NST - 1; j++) if (j < K) issue(j);
     const int fragA = (wm * 32 + (lane & 31)) * 32 + (lane >> 5) * 16, fragW = (wn * 32 + (lane & 31)) * 32 + (lane >> 5) * 16;
     for (int ks = 0; ks < K; ks++) {
-        // this wave's pieces of step ks have landed (up to two younger steps = 14 loads may still be in flight) ...
-        if (ks + 2 < K) __builtin_amdgcn_s_waitcnt(14 | (7 << 4) | (15 << 8));
-        else if (ks + 1 < K) __builtin_amdgcn_s_waitcnt(7 | (7 << 4) | (15 << 8));
+        // this wave's pieces of step ks have landed (up to NST - 2 younger steps of 7 loads each may still be in flight) ...
+        const int younger = min(NST - 2, K - 1 - ks);
+        if (younger >= 3) __builtin_amdgcn_s_waitcnt(21 | (7 << 4) | (15 << 8));
+        else if (younger == 2) __builtin_amdgcn_s_waitcnt(14 | (7 << 4) | (15 << 8));
+        else if (younger == 1) __builtin_amdgcn_s_waitcnt(7 | (7 << 4) | (15 << 8));
         else __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
-        __syncthreads();                                          // ... and everybody's; ring slot (ks + 3) % 4, read in step ks - 1, is free
-        if (ks + 3 < K) issue(ks + 3);
+        __syncthreads();                                          // ... and everybody's; ring slot (ks - 1) % NST, read in step ks - 1, is free
+        if (ks + NST - 1 < K) issue(ks + NST - 1);                // (as one block: spreading the pieces between the MFMA groups below measured 5 % slower)
         const i8 *tA = lds + (ks % NST) * (2 * TILE_B), *tW = tA + TILE_B;
         v4i w[NPL];
 #pragma unroll
@@ -336,8 +344,9 @@ int k_limb_mac(crc_ctx *c, const i8 *xl, const i8 *wl, u64 *ys, const u64 *bias_
     a.img_bytes = (unsigned)img; a.wslot_bytes = (unsigned long long)a.ksteps * NPL * a.Fp * 32;
     const size_t grid = (size_t)c->n * c->k * a.mtiles * a.ntiles;
     if (grid > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
-    const size_t lds = 8 * TILE_B;
-    auto kern = mfma_mac_kernel;
+    static const int ring = [] { const char *e = getenv("CRC_MFMA_RING"); const int v = e ? atoi(e) : 4; return v == 3 || v == 5 ? v : 4; }();     // tuning (tools/)
+    const size_t lds = (size_t)ring * 2 * TILE_B;
+    auto kern = ring == 5 ? mfma_mac_kernel<5> : ring == 3 ? mfma_mac_kernel<3> : mfma_mac_kernel<4>;
     { const int rc = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (rc) return rc; }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);
     HIPCHK(hipGetLastError());
