@@ -185,7 +185,6 @@ extern "C" int crc_ctx_create(int n, const uint64_t *q, int k, uint64_t t, int d
         if (!is_prime(q[i]) || (q[i] - 1) % (2 * (u64)n)) return CRC_ERR_PARAMETERS;      // enable_ntt
         for (int j = 0; j < i; j++) if (q[i] == q[j]) return CRC_ERR_PARAMETERS;
         if (t % q[i] == 0) return CRC_ERR_PARAMETERS;
-        if (q[i] <= t) return CRC_ERR_UNSUPPORTED;            // !enable_fast_plain_lift (context.cpp:156-165)
     }
     crc_ctx *c = new crc_ctx();
     c->n = n; c->k = k; c->t = t; c->device = device;
@@ -214,9 +213,10 @@ extern "C" int crc_ctx_create(int n, const uint64_t *q, int k, uint64_t t, int d
         for (int l = k - 1; l >= 0; l--) { u128 z = ((u128)rem << 64) | quo[l]; quo[l] = (u64)(z / t); rem = (u64)(z % t); }
         memset(&c->plain, 0, sizeof c->plain);
         c->plain.threshold = (t + 1) >> 1;
+        c->plain.fast = 1; for (int i = 0; i < k; i++) if (q[i] <= t) c->plain.fast = 0;
         for (int i = 0; i < k; i++) {
             u64 r = 0; for (int l = k - 1; l >= 0; l--) r = (u64)((((u128)r << 64) | quo[l]) % q[i]);
-            c->plain.delta[i] = r; c->plain.uhi[i] = rem % q[i]; c->plain.inc[i] = q[i] - t;
+            c->plain.delta[i] = r; c->plain.uhi[i] = rem % q[i]; c->plain.inc[i] = q[i] - t % q[i];
         }
     }
     // BEHZ tables, baseconverter.cpp:104-353

@@ -17,7 +17,9 @@
 // constants of add_plain / transform_to_ntt(Plaintext) -- passed to kernels by value
 struct PlainParams {
     u64 threshold;            // (t+1)>>1                          evaluator.cpp:73
-    u64 inc[CRC_MAXK];        // q_i - t                           evaluator.cpp:80-87
+    u64 inc[CRC_MAXK];        // (q - t) mod q_i = q_i - (t mod q_i); = q_i - t when q_i > t          evaluator.cpp:74-87
+    int fast;                 // every q_i > t: c + inc needs no reduction (enable_fast_plain_lift, context.cpp:156-165); otherwise the lift of
+                              // evaluator.cpp:1447-1463 (multi-word c + (q - t), then decompose) is computed as (c mod q_i) + inc mod q_i
     u64 delta[CRC_MAXK];      // floor(q/t) mod q_i                evaluator.cpp:66-70,96-100
     u64 uhi[CRC_MAXK];        // (q mod t) mod q_i                 evaluator.cpp:89-105
 };

@@ -38,6 +38,16 @@ struct NttArgs {
     PlainParams pp;
 };
 
+// transform_to_ntt(Plaintext)'s lift of a plaintext coefficient c < t to its residue mod q_i (evaluator.cpp:1447-1486): c, or c + (q - t) for the "negative"
+// upper half.  With every q_i > t that is c + (q_i - t) without reduction (the fast branch); otherwise the reference adds the multi-word q - t and decomposes,
+// i.e. (c mod q_i) + ((q - t) mod q_i) mod q_i -- the same residue
+__device__ __forceinline__ u64 plain_lift(u64 c, const PlainParams &pp, int i, const ModParams &m)
+{
+    if (pp.fast) return c >= pp.threshold ? c + pp.inc[i] : c;
+    const u64 r = barrett128(c, 0, m);
+    return c >= pp.threshold ? addmod(r, pp.inc[i], m.q) : r;
+}
+
 #include "ntt_device.h"  // lpad, shoup_lazy4, reduce_small, fwd_stages / inv_stages, ntt_pass
 __device__ __forceinline__ u64 split28v(u64 v) { return (v & 0x0fffffffULL) | ((v >> 28) << 32); }      // = split28 further down
 
@@ -75,7 +85,7 @@ __device__ __forceinline__ void ntt_rows_body(const NttArgs &a)
         const u64 *src = a.src + srow * (size_t)n;
         for (int s = tid; s < n; s += nt) {
             u64 v = src[s];
-            if (a.prologue == 1) v = v >= a.pp.threshold ? v + a.pp.inc[mloc] : v;
+            if (a.prologue == 1) v = plain_lift(v, a.pp, mloc, m);
             else if (a.prologue == 2) {
                 u64 lo, hi; mul64wide(a.pp.delta[mloc], v, lo, hi);
                 if (v >= a.pp.threshold) { u64 l2 = lo + a.pp.uhi[mloc]; hi += (l2 < lo); lo = l2; }
@@ -161,7 +171,7 @@ __global__ void __launch_bounds__(1024) ntt_rows_prefetch_kernel(NttArgs a)
 #pragma unroll
         for (int j = 0; j < PF; j++) {
             u64 v = pre[j];
-            if (a.prologue == 1) v = v >= a.pp.threshold ? v + a.pp.inc[mloc] : v;
+            if (a.prologue == 1) v = plain_lift(v, a.pp, mloc, m);
             else if (a.prologue == 2) {
                 u64 lo, hi; mul64wide(a.pp.delta[mloc], v, lo, hi);
                 if (v >= a.pp.threshold) { u64 l2 = lo + a.pp.uhi[mloc]; hi += (l2 < lo); lo = l2; }
@@ -301,7 +311,7 @@ __global__ void plain_prep_kernel(const u64 *plain, u64 *out, const ModParams *m
     const u64 *src = plain + (row / k) * (size_t)n; u64 *dst = out + row * (size_t)n;
     for (int s = threadIdx.x; s < n; s += blockDim.x) {
         u64 v = src[s];
-        if (mode == 1) v = v >= pp.threshold ? v + pp.inc[i] : v;
+        if (mode == 1) v = plain_lift(v, pp, i, m);
         else {
             u64 lo, hi; mul64wide(pp.delta[i], v, lo, hi);
             if (v >= pp.threshold) { u64 l2 = lo + pp.uhi[i]; hi += (l2 < lo); lo = l2; }

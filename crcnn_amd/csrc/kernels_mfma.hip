@@ -168,35 +168,40 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 // ---- layout conversions ------------------------------------------------------------------------------------------------------------------
 // slot-minor NTT-form tensor x [B][zd*npos cts][2][k][n] (canonical residues, or 28-bit limb pairs when `packed`) -> Xl.  One thread per (slot, image,
 // position, poly, 32-channel block); lanes run over 64 consecutive slots, so every read is a coalesced 512-B row segment
-__global__ void __launch_bounds__(64) limb_pack_tensor_kernel(const u64 *x, i8 *xl, const ModParams *mods, int n, int k, int B, int zd, int zdp, int npos, int packed)
+__global__ void __launch_bounds__(64) limb_pack_tensor_kernel(const u64 *x, i8 *xl, const ModParams *mods, int n, int k, int B, int zd, int zdp, int npos, int packed, int group)
 {
     const int sblocks = n / 64;
     const int sb = blockIdx.x % (sblocks * k), i = sb / sblocks, s = (sb % sblocks) * 64 + threadIdx.x;
-    size_t r = blockIdx.x / (sblocks * k);                       // ((b*npos + pos)*2 + c)*zblks + zb
     const int zblks = zdp / 32;
-    const int zb = (int)(r % zblks); r /= zblks; const int c = (int)(r % 2); r /= 2; const int pos = (int)(r % npos); const int b = (int)(r / npos);
+    const size_t items = (size_t)B * npos * 2 * zblks;           // item = ((b*npos + pos)*2 + c)*zblks + zb
     const u64 q = mods[i].q;
-    u32 pl[NPL][8];
+    // `group` consecutive items per thread: with one channel block they are adjacent 32-B pieces of the same slot block, written back to back so that
+    // the L2 can merge them into whole lines before they go to HBM
+    for (size_t r0 = (size_t)(blockIdx.x / (sblocks * k)) * group, u = 0; u < (size_t)group && r0 + u < items; u++) {
+        size_t r = r0 + u;
+        const int zb = (int)(r % zblks); r /= zblks; const int c = (int)(r % 2); r /= 2; const int pos = (int)(r % npos); const int b = (int)(r / npos);
+        u32 pl[NPL][8];
 #pragma unroll
-    for (int l = 0; l < NPL; l++)
+        for (int l = 0; l < NPL; l++)
 #pragma unroll
-        for (int wv = 0; wv < 8; wv++) pl[l][wv] = 0;
+            for (int wv = 0; wv < 8; wv++) pl[l][wv] = 0;
 #pragma unroll
-    for (int z = 0; z < 32; z++) {
-        const int zz = zb * 32 + z;
-        if (zz < zd) {
-            u64 v = x[((((size_t)b * zd * npos + (size_t)zz * npos + pos) * 2 + c) * k + i) * (size_t)n + s];
-            if (packed) v = (v & 0xffffffffULL) | ((v >> 32) << 28);
-            int d[NPL]; limb_digits(v, q, d);
+        for (int z = 0; z < 32; z++) {
+            const int zz = zb * 32 + z;
+            if (zz < zd) {
+                u64 v = x[((((size_t)b * zd * npos + (size_t)zz * npos + pos) * 2 + c) * k + i) * (size_t)n + s];
+                if (packed) v = (v & 0xffffffffULL) | ((v >> 32) << 28);
+                int d[NPL]; limb_digits(v, q, d);
 #pragma unroll
-            for (int l = 0; l < NPL; l++) pl[l][z >> 2] |= (u32)(d[l] & 0xff) << (8 * (z & 3));
+                for (int l = 0; l < NPL; l++) pl[l][z >> 2] |= (u32)(d[l] & 0xff) << (8 * (z & 3));
+            }
         }
-    }
-    i8 *dst = xl + (((size_t)i * n + s) * B + b) * ((size_t)NPL * npos * 2 * zdp) + ((size_t)pos * 2 + c) * zdp + zb * 32;
+        i8 *dst = xl + (((size_t)i * n + s) * B + b) * ((size_t)NPL * npos * 2 * zdp) + ((size_t)pos * 2 + c) * zdp + zb * 32;
 #pragma unroll
-    for (int l = 0; l < NPL; l++) {
-        uint4 *o = reinterpret_cast<uint4 *>(dst + (size_t)l * npos * 2 * zdp);
-        o[0] = make_uint4(pl[l][0], pl[l][1], pl[l][2], pl[l][3]); o[1] = make_uint4(pl[l][4], pl[l][5], pl[l][6], pl[l][7]);
+        for (int l = 0; l < NPL; l++) {
+            uint4 *o = reinterpret_cast<uint4 *>(dst + (size_t)l * npos * 2 * zdp);
+            o[0] = make_uint4(pl[l][0], pl[l][1], pl[l][2], pl[l][3]); o[1] = make_uint4(pl[l][4], pl[l][5], pl[l][6], pl[l][7]);
+        }
     }
 }
 // NTT-form weights w [F][zd][taps][k][n] (canonical) -> Wl (pre-zeroed: channel / filter padding).  One thread per (slot, filter, tap, channel block)
@@ -294,10 +299,12 @@ size_t k_limb_result_words(const crc_ctx *c, int B, int nf, int P) { return (siz
 int k_limb_pack_tensor(crc_ctx *c, const u64 *x, i8 *xl, int B, int zd, int npos, bool packed, hipStream_t st)
 {
     const int zdp = round_up(zd, 32);
-    const size_t blocks = (size_t)(c->n / 64) * c->k * B * npos * 2 * (zdp / 32);
+    static const int group = [] { const char *e = getenv("CRC_LIMB_PACK_GROUP"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();     // (4 and 8 adjacent pieces per thread measured 3-7 % slower)
+    const size_t items = (size_t)B * npos * 2 * (zdp / 32);
+    const size_t blocks = (size_t)(c->n / 64) * c->k * ((items + group - 1) / group);
     if (blocks == 0) return CRC_OK;
     if (blocks > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(limb_pack_tensor_kernel, dim3((unsigned)blocks), dim3(64), 0, st, x, xl, c->d_mods, c->n, c->k, B, zd, zdp, npos, packed ? 1 : 0);
+    hipLaunchKernelGGL(limb_pack_tensor_kernel, dim3((unsigned)blocks), dim3(64), 0, st, x, xl, c->d_mods, c->n, c->k, B, zd, zdp, npos, packed ? 1 : 0, group);
     HIPCHK(hipGetLastError());
     return CRC_OK;
 }

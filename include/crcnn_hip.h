@@ -39,7 +39,7 @@ typedef enum {
     CRC_ERR_INVALID_ARGUMENT = -1,   /* bad shape / null pointer / unsupported parameter (std::invalid_argument in the reference) */
     CRC_ERR_PARAMETERS = -2,         /* (n, q[], t) rejected: SEALContext::validate, context.cpp:15-169 */
     CRC_ERR_HIP = -3,                /* a HIP runtime call failed; crc_last_hip_error() has the code */
-    CRC_ERR_UNSUPPORTED = -4,        /* valid in the reference but not implemented here (e.g. t >= min q_i: slow plain lift) */
+    CRC_ERR_UNSUPPORTED = -4,        /* valid in the reference but not implemented here (e.g. more than 48 relinearisation digits) */
     CRC_ERR_IO = -5,                 /* file could not be read / not an HDF5 file we understand */
     CRC_ERR_NOT_FOUND = -6,          /* dataset name missing in the model file */
     CRC_ERR_COMM = -7                /* an RCCL call failed; crc_last_comm_error() has the ncclResult_t */

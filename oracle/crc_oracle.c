@@ -244,7 +244,9 @@ struct orc_ctx {
     /* Evaluator ctor constants, evaluator.cpp:66-105 */
     u64 delta[MAXK];      /* floor(q/t) mod q_i           coeff_div_plain_modulus_        */
     u64 uhi[MAXK];        /* (q - t*floor(q/t)) mod q_i   upper_half_increment_           */
-    u64 inc[MAXK];        /* q_i - t                      plain_upper_half_increment_array_ */
+    u64 inc[MAXK];        /* q_i - t                      plain_upper_half_increment_array_ (fast plain lift only) */
+    int fast_lift;        /* every q_i > t                context.cpp:156-165 */
+    u64 inc_big[MAXK];    /* q - t, multi-word            plain_upper_half_increment_ (evaluator.cpp:74-77) */
     u64 threshold;        /* (t+1)>>1 */
     int total_bits;       /* significant bits of q */
     u64 qbig[MAXK];       /* q as little-endian limbs */
@@ -325,7 +327,6 @@ orc_ctx *orc_ctx_create(int n, const u64 *q, int k, u64 t)
     c->n = n; c->k = k; c->t = t; c->t_bits = sig_bits(t);
     while ((1 << c->logn) < n) c->logn++;
     for (int i = 0; i < k; i++) {
-        if (q[i] <= t) { free(c); return NULL; }          /* enable_fast_plain_lift required: context.cpp:156-165 */
         if (ntt_make(&c->qn[i], c->logn, q[i])) { free(c); return NULL; }
     }
     /* q, floor(q/t), q mod t  -- evaluator.cpp:66-105 */
@@ -339,8 +340,11 @@ orc_ctx *orc_ctx_create(int n, const u64 *q, int k, u64 t)
     for (int i = 0; i < k; i++) {
         c->delta[i] = big_mod_u64(quo, k, q[i]);
         c->uhi[i] = q_mod_t % q[i];
-        c->inc[i] = q[i] - t;
+        c->inc[i] = q[i] - t;                              /* only meaningful (and only used) when q_i > t */
     }
+    c->fast_lift = 1;
+    for (int i = 0; i < k; i++) if (q[i] <= t) c->fast_lift = 0;                        /* context.cpp:156-165 */
+    { u64 tb[MAXK] = {0}; tb[0] = t; memcpy(c->inc_big, big, sizeof big); big_sub(c->inc_big, tb, k); }     /* evaluator.cpp:74-77 */
     c->threshold = (t + 1) >> 1;
 
     /* BaseConverter ctor -- baseconverter.cpp:20-353 */
@@ -541,7 +545,14 @@ void orc_plain_to_ntt(const orc_ctx *c, const u64 *plain, u64 *out)
 {
     for (int i = 0; i < c->k; i++) {
         u64 *o = out + i * PN(c);
-        for (int s = 0; s < c->n; s++) o[s] = plain[s] >= c->threshold ? plain[s] + c->inc[i] : plain[s];
+        if (c->fast_lift)
+            for (int s = 0; s < c->n; s++) o[s] = plain[s] >= c->threshold ? plain[s] + c->inc[i] : plain[s];
+        else                                               /* !enable_fast_plain_lift, evaluator.cpp:1447-1463: multi-word add of q - t, then decompose */
+            for (int s = 0; s < c->n; s++) {
+                u64 wide[MAXK] = {0}; wide[0] = plain[s];
+                if (plain[s] >= c->threshold) big_add(wide, c->inc_big, c->k);
+                o[s] = big_mod_u64(wide, c->k, c->qn[i].m.q);
+            }
         ntt_fwd(o, &c->qn[i]);
     }
 }

@@ -36,6 +36,9 @@ OP_SETS = {
     # SEAL's small_mods_40bit (util/globals.cpp): 2^40 - c 2^s + 1 primes BELOW the folding reduction's validity bound (modarith.h
     # fold_constant): every 128-bit reduction of the Square pipeline must take the generic Barrett path here
     "ops_n256_k2_q40_t16": (256, [0xffffe80001, 0xffffc40001], 1 << 16, 2, [0.5, -1.75]),
+    # plain modulus ABOVE the coefficient primes (t = 2^41 > q_i ~ 2^40, t < q): SEAL's !enable_fast_plain_lift branches (context.cpp:156-165,
+    # evaluator.cpp:1447-1463) -- the boundary the second phase of CrCNN's plain-modulus search walks along (optimalParametersChooser.cpp:44-58)
+    "ops_n256_k2_q40_t41": (256, [0xffffe80001, 0xffffc40001], 1 << 41, 2, [0.5, -1.75]),
 }
 FLOATS = [0.0, 1.0, -1.0, 0.25, -2.5, 0.5, -0.5, 1.5, 2.5, -0.4242129623889923, 2.8214867115020752, 100.125, -77.0,
           3.14159, 1e-9, -1e-7, 0.1307, 0.3081, 1.0 / 3.0, 12345.678, 0.020209059119224548, 4.656612873077393e-10]
