@@ -2,6 +2,9 @@
 //   test_host net <model> <h5> <dir> <resident 0|1> <batch> [fuse 0|1]      (fuse: Network::fuse() before the resident forward)
 //     <dir>/params.u64 (n,k,t,q...), evk.u64, net_in.u64 ([1][1][28][28][2][k][n]) -> writes layer_<i>.u64 (layerwise mode) and out.u64
 //   test_host api <h5> <dir>     exercises save/load of the encoded model, client-side encrypt/decrypt, and error behaviour
+//   test_host files <dir>        CrCNN's own files: loads the encoded-model stream and the cipher_image file the REFERENCE wrote (<dir>/ref_encoded_layers.bin,
+//     ref_cipher_image.bin; cnnBuilder.cpp:181-196, globals.cpp:174-205), runs conv -> bn -> dense on them (out_from_ref_files.u64), then writes the same two
+//     files itself (our_encoded_layers.bin, our_cipher_image.bin) and runs those (out_from_our_files.u64)
 //   test_host searchlogic <min> <max> <first_good> <last_good> <min_q>
 //     the plain-modulus search on a synthetic predicate (t < first_good: MISPREDICTED, t > last_good: OUT_OF_BUDGET); no GPU work.
 //     prints "found <t>" and one "tried <t> <status>" line per test
@@ -66,6 +69,53 @@ static int do_net(int argc, char **argv)
         fprintf(stderr, "\n");
     }
     delParameters();
+    return 0;
+}
+
+static vector<double> rdf(const string &p)
+{
+    ifstream f(p, ios::binary); if (!f) { fprintf(stderr, "missing %s\n", p.c_str()); exit(2); }
+    f.seekg(0, ios::end); size_t sz = f.tellg(); f.seekg(0); vector<double> v(sz / 8); f.read((char *)v.data(), sz); return v;
+}
+static int do_files(int argc, char **argv)
+{
+    if (argc < 3) return 1;
+    const string dir = argv[2];
+    setup(dir);
+    secret_key = rd(dir + "/sk.u64"); public_key = rd(dir + "/pk.u64");            // the fixture's key pair (globals are public, as in the reference)
+    auto dims = rd(dir + "/layer_dims.u64");
+    const int zd = (int)dims[0], xd = (int)dims[1], yd = (int)dims[2], xs = (int)dims[3], ys = (int)dims[4], xf = (int)dims[5], yf = (int)dims[6], nf = (int)dims[7], od = (int)dims[8];
+    const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys + 1;
+    auto run = [&](Layer &c, Layer &b, Layer &f, const ciphertext3D &x, const string &out) {
+        c.out_form = b.out_form = f.out_form = CRC_COEFF;
+        wr(dir + "/" + out, f.forward(b.forward(c.forward(x))).toHost());
+    };
+    {   // what the reference wrote
+        ifstream in(dir + "/ref_encoded_layers.bin", ios::binary); if (!in) { fprintf(stderr, "missing ref_encoded_layers.bin\n"); return 2; }
+        ConvolutionalLayer c("conv", xd, yd, zd, xs, ys, xf, yf, nf, 2, &in);
+        BatchNormLayer b("bn", nf, &in);
+        FullyConnectedLayer f("fc", nf * xo * yo, od, 2, &in);
+        if (in.peek() != EOF) { fprintf(stderr, "encoded-model stream not consumed exactly\n"); return 3; }
+        run(c, b, f, loadEncryptedImage(zd, xd, yd, dir + "/ref_cipher_image.bin"), "out_from_ref_files.u64");
+    }
+    {   // the same files written by the host classes (encoding as CnnBuilder::build*Layer: float32 widened to double)
+        auto enc = [&](const vector<double> &v) { vector<Plaintext> o; for (double d : v) o.push_back(fraencode((double)(float)d)); return o; };
+        auto fw = enc(rdf(dir + "/conv_w.f64")), fb = enc(rdf(dir + "/conv_b.f64")), bm = enc(rdf(dir + "/bn_mean.f64")), dw = enc(rdf(dir + "/fc_w.f64")), db = enc(rdf(dir + "/fc_b.f64"));
+        vector<Plaintext> bv; for (double d : rdf(dir + "/bn_var.f64")) { float v = (float)d; v = 1 / sqrt(v + 0.00001); bv.push_back(fraencode((double)v)); }   // cnnBuilder.cpp:100-102
+        plaintext4D ew(nf, plaintext3D(zd, plaintext2D(xf, vector<Plaintext>(yf)))); size_t w = 0;
+        for (int n = 0; n < nf; n++) for (int z = 0; z < zd; z++) for (int i = 0; i < xf; i++) for (int j = 0; j < yf; j++) ew[n][z][i][j] = fw[w++];
+        plaintext2D ed(od, vector<Plaintext>(nf * xo * yo)); w = 0;
+        for (int i = 0; i < od; i++) for (int j = 0; j < nf * xo * yo; j++) ed[i][j] = dw[w++];
+        ConvolutionalLayer c("conv", xd, yd, zd, xs, ys, xf, yf, nf, 2, ew, fb);
+        BatchNormLayer b("bn", nf, bm, bv);
+        FullyConnectedLayer f("fc", nf * xo * yo, od, 2, ed, db);
+        { ofstream o(dir + "/our_encoded_layers.bin", ios::binary); c.savePlaintextParameters(&o); b.savePlaintextParameters(&o); f.savePlaintextParameters(&o); }
+        vector<float> image; for (double d : rdf(dir + "/image.f64")) image.push_back((float)d);
+        ciphertext3D x = encryptAndSaveImage(image, zd, xd, yd, dir + "/our_cipher_image.bin");
+        run(c, b, f, x, "out_from_our_files.u64");
+    }
+    delParameters();
+    printf("files ok\n");
     return 0;
 }
 
@@ -206,6 +256,7 @@ int main(int argc, char **argv)
     try {
         if (!strcmp(argv[1], "net")) return do_net(argc, argv);
         if (!strcmp(argv[1], "api")) return do_api(argc, argv);
+        if (!strcmp(argv[1], "files")) return do_files(argc, argv);
         if (!strcmp(argv[1], "searchlogic")) return do_searchlogic(argc, argv);
         if (!strcmp(argv[1], "search")) return do_search(argc, argv);
     } catch (const exception &e) { fprintf(stderr, "exception: %s\n", e.what()); return 10; }

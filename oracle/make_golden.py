@@ -170,6 +170,68 @@ def make_loader():
     print("wrote loader fixture:", len(g) // 4, "datasets")
 
 
+def make_files():
+    """CrCNN's own file formats written BY THE REFERENCE (ref_harness files): an encoded-model stream (conv + batch-norm + dense parameters through
+    savePlaintextParameters, cnnBuilder.cpp:181-196) and a cipher_image file (encryptAndSaveImage, globals.cpp:174-190), with the reference's outputs
+    of those layers on that image.  tests/test_gpu_host_cpp.py has the C++ host classes load them, and the reference load what those write."""
+    n, q, t = 256, [0x7fffffff380001, 0x3fffffff000001], 1 << 20
+    O = orc.Oracle(n, q, t)
+    sk, pk = O.keygen(4000)
+    d = os.path.join(GOLD, "files_n256")
+    os.makedirs(d, exist_ok=True)
+    rng = np.random.RandomState(12)
+    zd, xd, yd, xs, ys, xf, yf, nf, od = 1, 4, 4, 1, 1, 3, 3, 2, 3
+    xo, yo = (xd - xf) // xs + 1, (yd - yf) // ys + 1
+    put(d, "params.u64", [n, len(q), t] + q); put(d, "sk.u64", sk); put(d, "pk.u64", pk)
+    put(d, "layer_dims.u64", [zd, xd, yd, xs, ys, xf, yf, nf, od])
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    put(d, "conv_w.f64", f32(rng.normal(0, 0.4, nf * zd * xf * yf)), dtype=np.float64); put(d, "conv_b.f64", f32(rng.normal(0, 0.2, nf)), dtype=np.float64)
+    put(d, "bn_mean.f64", f32(rng.normal(0, 0.3, nf)), dtype=np.float64); put(d, "bn_var.f64", f32(rng.uniform(0.5, 2.0, nf)), dtype=np.float64)
+    put(d, "fc_w.f64", f32(rng.normal(0, 0.3, od * nf * xo * yo)), dtype=np.float64); put(d, "fc_b.f64", f32(rng.normal(0, 0.1, od)), dtype=np.float64)
+    put(d, "image.f64", f32(rng.uniform(-1, 1, zd * xd * yd)), dtype=np.float64)
+    for stale in ("our_encoded_layers.bin", "our_cipher_image.bin"):
+        if os.path.exists(os.path.join(d, stale)):
+            os.remove(os.path.join(d, stale))
+    run("files", d)
+    print("wrote files_n256:", sorted(os.listdir(d)))
+
+
+def search_cases():
+    """(lo, hi, pow, first_good, last_good): the synthetic verdict tables of tests/test_search_logic.py, both phases of the reference's search"""
+    q1 = 18014398492704769
+    cases = []
+    for lo_e, hi_e in [(16, 34), (24, 34), (20, 21), (20, 20), (10, 40), (1, 62)]:
+        for fg_e in range(lo_e - 1, hi_e + 3, 3):
+            for lg_e in (fg_e - 1, fg_e, fg_e + 2, hi_e + 1):
+                cases.append((1 << lo_e, 1 << hi_e, 1, (1 << fg_e) + (fg_e % 2), (1 << max(lg_e, 0)) + 5))
+    cases = cases[::3]
+    # second phase (optimalParametersChooser.cpp:44-58): integers of [2^floor(log2 q), q - 1] for a small "smallest prime" q, and for the real one
+    q = (1 << 20) + 7
+    for fg, lg in [((1 << 20) + 3, 1 << 30), (1 << 20, 1 << 30), ((1 << 21) + 1, 1 << 30), (1 << 22, 1 << 21), ((1 << 20) + 6, 1 << 30), ((1 << 20) + 7, 1 << 30)]:
+        cases.append((1 << 16, 1 << 34, 1, fg, lg))
+        cases.append((1 << 20, q - 1, 0, fg, lg))
+    cases.append((1 << 53, q1 - 1, 0, (1 << 53) + 12345, 1 << 60))
+    return cases
+
+
+def make_search():
+    """candidate sequences of the REFERENCE's plainModulusBinarySearchInternal (oracle/_ref/search_harness) -> tests/golden/search_sequences.json"""
+    import json
+    harness = os.path.join(HERE, "_ref", "search_harness")
+    if not os.path.exists(harness):
+        subprocess.check_call(["make", "-C", HERE, "ref", "-j8"])
+    out = []
+    for lo, hi, pw, fg, lg in search_cases():
+        r = subprocess.run([harness, str(lo), str(hi), str(pw), str(fg), str(lg)], capture_output=True, text=True, check=True)
+        lines = r.stderr.splitlines()
+        tried = [[int(l.split()[1]), l.split()[2]] for l in lines if l.startswith("tried")]
+        found = int([l for l in lines if l.startswith("found")][0].split()[1])
+        out.append(dict(lo=lo, hi=hi, pow=pw, first_good=fg, last_good=lg, tried=tried, found=found))
+    json.dump(dict(source="CrCNN/src/optimalParametersChooser.cpp:84-181 (plainModulusBinarySearchInternal) compiled in place, predicate = table", cases=out),
+              open(os.path.join(GOLD, "search_sequences.json"), "w"), indent=0)
+    print("wrote search_sequences.json:", len(out), "cases")
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["ops", "layers", "loader"]
     os.makedirs(GOLD, exist_ok=True)
@@ -182,6 +244,10 @@ if __name__ == "__main__":
         make_layers()
     if "loader" in what:
         make_loader()
+    if "files" in what:
+        make_files()
+    if "search" in what:
+        make_search()
     if "nets" in what:
         from oracle import make_golden_nets
         make_golden_nets.main()

@@ -7,6 +7,10 @@
 //   ref_harness ops <dir>    op-level vectors (+ two-way key/ciphertext compatibility checks)
 //   ref_harness layers <dir> CrCNN layer-level vectors on a small tensor
 //   ref_harness net <dir>    a whole CrCNN network (topology + float weights from <dir>), SHA-256 per layer
+//   ref_harness files <dir>  CrCNN's own file formats: the reference WRITES an encoded-model stream (savePlaintextParameters of a conv, a batch-norm
+//                            and a dense layer back to back: cnnBuilder.cpp:181-196) and a cipher_image file (encryptAndSaveImage, globals.cpp:174-190),
+//                            runs the layers on that image, and -- if <dir> holds our_encoded_layers.bin / our_cipher_image.bin written by the
+//                            product -- LOADS those with its istream constructors / loadEncryptedImage (globals.cpp:193-205) and runs them too
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -336,6 +340,45 @@ static int do_layers()
     return 0;
 }
 
+static int do_files()
+{
+    setup();
+    auto pkv = rd("pk.u64"), skv = rd("sk.u64");
+    PublicKey pk = load_pk(pkv); SecretKey sk = load_sk(skv);
+    encryptor = new Encryptor(*context, pk); decryptor = new Decryptor(*context, sk);
+    auto dims = rd("layer_dims.u64");   // zd xd yd | conv: xs ys xf yf nf | fc: out_dim
+    const int zd = dims[0], xd = dims[1], yd = dims[2], nf = dims[7];
+    const int xo = (xd - (int)dims[5]) / (int)dims[3] + 1, yo = (yd - (int)dims[6]) / (int)dims[4] + 1;
+    auto fw = rdf("conv_w.f64"), fb = rdf("conv_b.f64"), bm = rdf("bn_mean.f64"), bv = rdf("bn_var.f64"), dw = rdf("fc_w.f64"), db = rdf("fc_b.f64");
+    auto imgd = rdf("image.f64");
+    vector<float> image(imgd.begin(), imgd.end());
+    auto run = [&](ConvolutionalLayer *c, BatchNormLayer *b, FullyConnectedLayer *f, ciphertext3D x, const string &tag) {
+        vector<u64> out; ciphertext3D y = f->forward(b->forward(c->forward(x)));
+        from_tensor(y, out); wr("ref_files_out_" + tag + ".u64", out);
+        vector<double> dec; floatCube img = decryptImage(y);
+        for (auto &a : img) for (auto &r : a) for (float v : r) dec.push_back(v);
+        ofstream o(DIR + "/ref_files_dec_" + tag + ".f64", ios::binary); o.write((const char *)dec.data(), dec.size() * 8);
+    };
+    {   // the reference writes ...
+        ConvolutionalLayer *c = make_conv("conv", xd, yd, zd, dims[3], dims[4], dims[5], dims[6], nf, 2, fw, fb);
+        BatchNormLayer *b = make_bn("bn", nf, bm, bv);
+        FullyConnectedLayer *f = make_fc("fc", nf * xo * yo, dims[8], 2, dw, db);
+        { ofstream o(DIR + "/ref_encoded_layers.bin", ofstream::binary); c->savePlaintextParameters(&o); b->savePlaintextParameters(&o); f->savePlaintextParameters(&o); }
+        ciphertext3D x = encryptAndSaveImage(image, zd, xd, yd, DIR + "/ref_cipher_image.bin");
+        run(c, b, f, x, "own");
+        delete c; delete b; delete f;
+    }
+    ifstream ours(DIR + "/our_encoded_layers.bin", ifstream::binary);
+    if (ours) {   // ... and reads what the product wrote
+        ConvolutionalLayer c("conv", xd, yd, zd, dims[3], dims[4], dims[5], dims[6], nf, 2, &ours);
+        BatchNormLayer b("bn", nf, &ours);
+        FullyConnectedLayer f("fc", nf * xo * yo, dims[8], 2, &ours);
+        ciphertext3D x = loadEncryptedImage(zd, xd, yd, DIR + "/our_cipher_image.bin");
+        run(&c, &b, &f, x, "ours");
+    }
+    return 0;
+}
+
 // ---- SHA-256 (FIPS 180-4), for per-layer digests of full networks ----
 struct Sha256 {
     uint32_t h[8]; uint8_t buf[64]; size_t fill = 0; uint64_t total = 0;
@@ -448,6 +491,7 @@ int main(int argc, char **argv)
         if (mode == "ops") return do_ops();
         if (mode == "layers") return do_layers();
         if (mode == "net") return do_net();
+        if (mode == "files") return do_files();
     } catch (const exception &e) { fprintf(stderr, "reference threw: %s\n", e.what()); return 6; }
     return 1;
 }

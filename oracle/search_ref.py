@@ -1,8 +1,9 @@
 """TEST INFRASTRUCTURE ONLY (see oracle/crc_oracle.h): restatement of the control flow of the reference's plain-modulus
 binary search, used to pin crcnn_amd/host/plain_modulus_search.cpp.  Follows CrCNN/src/optimalParametersChooser.cpp
 statement by statement (line numbers below), including its conversions through log2() truncated to an integer.
-The reference has no test or fixture for this tool and its predicate needs MNIST images that are absent here, so the
-pin is control flow only: same moduli tested in the same order, same return value, for a synthetic predicate."""
+Pinned itself: tests/test_search_logic.py demands that `internal` reproduce every candidate sequence recorded from the REFERENCE's
+compiled plainModulusBinarySearchInternal (tests/golden/search_sequences.json <- oracle/_ref/search_harness).  Its remaining use is to replay
+the recursion over verdicts observed on the GPU (tests/test_gpu_host_cpp.py), which no pre-recorded table can anticipate."""
 import math
 
 SUCCESS, OUT_OF_BUDGET, MISPREDICTED = "SUCCESS", "OUT_OF_BUDGET", "MISPREDICTED"

@@ -124,3 +124,29 @@ def test_cpp_example_driver():
         lines = [l for l in out.split("\n") if l.startswith("OUTPUT:")]
         assert len(lines) == 2 and all(l.endswith("Success") for l in lines), out
         assert "SUMMARY: 2 of 2" in out
+
+
+def test_cpp_crcnn_files_interchange_with_the_reference():
+    """CrCNN's own files (not just SEAL's object formats): the encoded-model stream -- savePlaintextParameters of consecutive layers, cnnBuilder.cpp:181-196 --
+    and a cipher_image file (encryptAndSaveImage / loadEncryptedImage, globals.cpp:174-205).  tests/golden/files_n256 holds both as WRITTEN BY THE COMPILED
+    REFERENCE (oracle/make_golden.py files) with the reference's layer outputs on them.  The C++ host classes must (a) load them and reproduce those outputs
+    bit for bit, (b) write an encoded-model stream that is byte-identical to the reference's, and (c) write a cipher_image file the reference loads
+    (checked with the prebuilt reference harness when it is present: it runs the same layers on OUR files and must land on OUR output bits)."""
+    import shutil
+    src = os.path.join(GOLD, "files_n256")
+    d = tempfile.mkdtemp()
+    for f in os.listdir(src):
+        shutil.copy(os.path.join(src, f), d)
+    out = subprocess.run([DRIVER, "files", d], capture_output=True, text=True)
+    assert out.returncode == 0 and "files ok" in out.stdout, out.stderr[-2000:]
+    rd = lambda nm: np.fromfile(os.path.join(d, nm), dtype=np.uint64)
+    assert np.array_equal(rd("out_from_ref_files.u64"), rd("ref_files_out_own.u64"))                              # (a)
+    assert open(os.path.join(d, "our_encoded_layers.bin"), "rb").read() == open(os.path.join(d, "ref_encoded_layers.bin"), "rb").read()     # (b)
+    assert os.path.getsize(os.path.join(d, "our_cipher_image.bin")) == os.path.getsize(os.path.join(d, "ref_cipher_image.bin"))
+    harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    if os.path.exists(harness):                                                                                     # (c)
+        subprocess.check_call([harness, "files", d], stdout=subprocess.DEVNULL)
+        assert np.array_equal(rd("ref_files_out_ours.u64"), rd("out_from_our_files.u64"))
+        dec = np.fromfile(os.path.join(d, "ref_files_dec_ours.f64")); want = np.fromfile(os.path.join(src, "ref_files_dec_own.f64"))
+        assert np.allclose(dec, want, atol=1e-4)          # same image, same layers, different encryption randomness
+    shutil.rmtree(d, ignore_errors=True)
