@@ -110,6 +110,7 @@ def load():
     L.crc_limb_tensor_bytes.restype = SZ; L.crc_limb_tensor_bytes.argtypes = [VP, CI, CI, CI, CI]
     L.crc_limb_weights_bytes.restype = SZ; L.crc_limb_weights_bytes.argtypes = [VP, CI, CI, CI, CI]
     L.crc_limb_pack_weights.argtypes = [VP, VP, CI, CI, CI, CI, VP, VP]
+    L.crc_limb_pack_tensor.argtypes = [VP, VP, CI, CI, CI, CI, CI, VP, VP]
     L.crc_conv2d_forms_work_bytes.restype = SZ; L.crc_conv2d_forms_work_bytes.argtypes = [VP] + [CI] * 12
     L.crc_square.argtypes = [VP, VP, SZ, VP, VP, VP]
     L.crc_relinearize.argtypes = [VP, VP, SZ, VP, CI, VP, VP, VP]
@@ -391,6 +392,9 @@ class Engine:
 
     def limb_pack_weights(self, d_w_ntt, nf, zd, xf, yf, d_wl):
         _chk(self.L.crc_limb_pack_weights(self.c, self.p(d_w_ntt), nf, zd, xf, yf, self.p(d_wl), self.stream), "crc_limb_pack_weights")
+
+    def limb_pack_tensor(self, d_x, in_form, B, zd, xd, yd, d_xl):
+        _chk(self.L.crc_limb_pack_tensor(self.c, self.p(d_x), in_form, B, zd, xd, yd, self.p(d_xl), self.stream), "crc_limb_pack_tensor")
 
     def conv2d_forms_work_bytes(self, B, zd, xd, yd, xs, ys, xf, yf, nf, in_form, w_form, out_form):
         return self.L.crc_conv2d_forms_work_bytes(self.c, B, zd, xd, yd, xs, ys, xf, yf, nf, in_form, w_form, out_form)

@@ -101,6 +101,12 @@ extern "C" int crc_limb_pack_weights(crc_ctx *c, const uint64_t *d_w_ntt, int nf
     if (!crc_limb_supported(c, zd, xf, yf)) return CRC_ERR_UNSUPPORTED;
     return k_limb_pack_weights(c, d_w_ntt, (signed char *)d_wl, nf, zd, xf * yf, S(stream));
 }
+extern "C" int crc_limb_pack_tensor(crc_ctx *c, const uint64_t *d_x, int in_form, int B, int zd, int xd, int yd, void *d_xl, void *stream)
+{
+    CHECK_CTX(c); if (!d_x || !d_xl || B < 0 || zd < 1 || xd < 1 || yd < 1 || (in_form != CRC_NTT && in_form != CRC_NTTP)) return CRC_ERR_INVALID_ARGUMENT;
+    if (!crc_limb_supported(c, zd, 1, 1)) return CRC_ERR_UNSUPPORTED;
+    return k_limb_pack_tensor(c, d_x, (signed char *)d_xl, B, zd, xd * yd, in_form == CRC_NTTP, S(stream));
+}
 extern "C" size_t crc_conv2d_forms_work_bytes(const crc_ctx *c, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int in_form, int w_form, int out_form)
 {
     if (w_form != CRC_NTTL) return crc_conv2d_work_bytes(c, B, zd, xd, yd, xs, ys, xf, yf, nf, in_form);

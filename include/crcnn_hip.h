@@ -186,6 +186,9 @@ int    crc_limb_supported(const crc_ctx *ctx, int zd, int xf, int yf);
 size_t crc_limb_tensor_bytes(const crc_ctx *ctx, int B, int zd, int xd, int yd);
 size_t crc_limb_weights_bytes(const crc_ctx *ctx, int nf, int zd, int xf, int yf);
 int    crc_limb_pack_weights(crc_ctx *ctx, const uint64_t *d_w_ntt, int nf, int zd, int xf, int yf, void *d_wl, void *stream);
+/* an NTT-form tensor (CRC_NTT canonical or CRC_NTTP) -> limb form; crc_conv2d_forms does this itself for such inputs, the separate entry point lets a
+ * caller convert once and reuse (d_xl: crc_limb_tensor_bytes) */
+int    crc_limb_pack_tensor(crc_ctx *ctx, const uint64_t *d_x, int in_form, int B, int zd, int xd, int yd, void *d_xl, void *stream);
 size_t crc_conv2d_forms_work_bytes(const crc_ctx *ctx, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int in_form, int w_form, int out_form);
 /* in-place CRC_NTT <-> CRC_NTTP conversion of `rows` residue rows (unpack = 0: pack, 1: unpack) */
 int crc_pack28(crc_ctx *ctx, uint64_t *d_rows, size_t rows, int unpack, void *stream);

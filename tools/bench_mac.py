@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Time one layer's ct x pt MAC launch on random residues (kernel-only view of the dominant kernel).
-usage: python tools/bench_mac.py [conv2|conv1|fc3|conv1p|conv2p|aconv1|aconv2|afc3|f5] [B] [reps] [packed]   (a*: ApproxPlainModel shapes; CRC_MAC2_CFG=16|8 forces a tile shape)"""
+usage: python tools/bench_mac.py [conv2|conv1|fc3|conv1p|conv2p|aconv1|aconv2|afc3|f5] [B] [reps] [packed|limb|limbk]   (a*: ApproxPlainModel shapes; CRC_MAC2_CFG=16|8 forces a tile shape)
+packed: CRC_NTTP operands on mac3_kernel; limb: the matrix-core path as a layer call (CRC_NTTP tensor in -> limb_pack_tensor + mfma_mac_kernel + result conversion -> CRC_NTT);
+limbk: the same on a pre-converted limb tensor with a limb-form result (mfma_mac_kernel + slotmajor_to_limb only)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -31,13 +33,28 @@ in_cts, out_cts, T = a["zd"] * a["xd"] * a["yd"], a["nf"] * xo * yo, a["zd"] * a
 x = rnd(B * in_cts * 2 * k); w = rnd(a["nf"] * T * k); bias = rnd(a["nf"] * k)
 y = torch.empty((B * out_cts * 2 * k, n), dtype=torch.int64, device=dev)
 work = torch.empty(E.conv2d_work_bytes(B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"], ca.NTT) // 8 + 64, dtype=torch.int64, device=dev)
-PACKED = os.environ.get("CRC_BENCH_PACKED") == "1" or (len(sys.argv) > 4 and sys.argv[4] == "packed")       # operands and result in the packed 28-bit limb form (CRC_NTTP)
+MODE = sys.argv[4] if len(sys.argv) > 4 else ""
+LIMB = MODE in ("limb", "limbk")
+PACKED = os.environ.get("CRC_BENCH_PACKED") == "1" or MODE == "packed" or LIMB       # operands in the packed 28-bit limb form (CRC_NTTP)
 if PACKED:
     E.stream = torch.cuda.current_stream().cuda_stream or None
     E.pack28(x, x.shape[0]); E.pack28(w, w.shape[0])
 F_IO = ca.NTTP if PACKED else ca.NTT
+if LIMB:
+    E.pack28(w, w.shape[0], unpack=True)
+    wl = torch.empty(E.limb_weights_bytes(a["nf"], a["zd"], a["xf"], a["yf"]), dtype=torch.int8, device=dev)
+    E.limb_pack_weights(w, a["nf"], a["zd"], a["xf"], a["yf"], wl)
+    work = torch.empty(E.conv2d_forms_work_bytes(B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"], ca.NTTP, ca.NTTL, ca.NTT) // 8 + 64, dtype=torch.int64, device=dev)
+    if MODE == "limbk":
+        xl = torch.empty(E.limb_tensor_bytes(B, a["zd"], a["xd"], a["yd"]), dtype=torch.int8, device=dev)
+        E.limb_pack_tensor(x, ca.NTTP, B, a["zd"], a["xd"], a["yd"], xl)
 def run():
-    E.conv2d(x, w, bias, B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"], F_IO, F_IO, y, work, w_form=F_IO)
+    if MODE == "limbk":
+        E.conv2d(xl, wl, bias, B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"], ca.NTTL, ca.NTTL, y, work, w_form=ca.NTTL)
+    elif LIMB:
+        E.conv2d(x, wl, bias, B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"], ca.NTTP, ca.NTT, y, work, w_form=ca.NTTL)
+    else:
+        E.conv2d(x, w, bias, B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"], F_IO, F_IO, y, work, w_form=F_IO)
 run(); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
@@ -45,6 +62,6 @@ for _ in range(reps): run()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
 macs = B * out_cts * T
-if PACKED:
+if PACKED and not LIMB:
     E.pack28(y, y.shape[0], unpack=True); torch.cuda.synchronize()
-print(f"{layer} B={B}{' packed' if PACKED else ''}: {ms:.2f} ms/launch  {macs * 2 * k * n / ms / 1e9:.3f} T modmul/s  ({ms / B:.3f} ms/image)  checksum {int(y.view(-1)[::100003].sum().item()) & 0xffffffff:x}")
+print(f"{layer} B={B}{' ' + (MODE or 'packed') if PACKED else ''}: {ms:.2f} ms/launch  {macs * 2 * k * n / ms / 1e9:.3f} T modmul/s  ({ms / B:.3f} ms/image)  checksum {int(y.view(-1)[::100003].sum().item()) & 0xffffffff:x}")

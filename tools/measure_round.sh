@@ -1,15 +1,26 @@
 set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/final; mkdir -p $O
-timeout -k 10 400 python bench.py > $O/bench_tiny4096.json 2> $O/bench_tiny4096.err
-timeout -k 10 500 python bench.py --config approx8192 > $O/bench_approx8192.json 2> $O/bench_approx8192.err
-timeout -k 10 500 python bench.py --config wopad16384 --batch 96 > $O/bench_wopad16384_b96.json 2> $O/bench_wopad.err
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_tiny -o tiny -- python3 bench.py --cpu-seconds 0 --unfused-images 48 > $O/prof_tiny.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_approx -o approx -- python3 bench.py --config approx8192 --batch 96 --cpu-seconds 0 --unfused-images 0 > $O/prof_approx.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 tools/bench_mac.py conv2p 24 1 packed > $O/pmc_fetch.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 tools/bench_mac.py conv2p 24 1 packed > $O/pmc_write.log 2>&1
+P=${1:-all}
+if [ $P = all ] || [ $P = bench ]; then
+timeout -k 10 500 python bench.py --steps 5 --warmup 1 > $O/bench_tiny4096.json 2> $O/bench_tiny4096.err
+timeout -k 10 500 python bench.py --config approx8192 --also none --steps 2 > $O/bench_approx8192.json 2> $O/bench_approx8192.err
+timeout -k 10 500 python bench.py --config approx8192k4 --also none --steps 1 --batch 256 > $O/bench_approx8192k4_b256.json 2> $O/bench_approx8192k4.err
+timeout -k 10 500 python bench.py --config wopad16384 --also none --steps 1 --batch 96 > $O/bench_wopad16384_b96.json 2> $O/bench_wopad.err
+fi
+if [ $P = all ] || [ $P = prof ]; then
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_tiny -o tiny -- python3 bench.py --cpu-seconds 0 --unfused-images 0 --also none --batch 256 > $O/prof_tiny.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_approx -o approx -- python3 bench.py --config approx8192 --batch 96 --cpu-seconds 0 --unfused-images 0 --also none > $O/prof_approx.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_sq -o sq -- python3 tools/bench_square.py 8192 3 1250 > $O/prof_sq.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 tools/bench_mac.py conv2p 32 1 limbk > $O/pmc_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 tools/bench_mac.py conv2p 32 1 limbk > $O/pmc_write.log 2>&1
+fi
+if [ $P = all ] || [ $P = micro ]; then
 (python tools/bench_ntt.py 4096 2 8192; python tools/bench_ntt.py 8192 3 4096; python tools/bench_ntt.py 16384 4 1024) > $O/ntt_elementwise.txt 2>&1
-(python tools/bench_square.py 8192 3 1250; python tools/bench_square.py 16384 4 512; python tools/bench_square.py 8192 3 1250 0 0) > $O/square.txt 2>&1
+(python tools/bench_square.py 8192 3 1250; python tools/bench_square.py 16384 4 512; python tools/bench_square.py 8192 3 1250 0 0; python tools/bench_square.py 8192 4 1250) > $O/square.txt 2>&1
 rm -f $O/mac_geometries.txt
-for g in conv1 conv1p conv2 conv2p fc3 aconv1 aconv2 afc3; do python tools/bench_mac.py $g 24 2 2>&1 | grep -v amdgpu >> $O/mac_geometries.txt; python tools/bench_mac.py $g 24 2 packed 2>&1 | grep -v amdgpu >> $O/mac_geometries.txt; done
+for g in conv1 conv1p conv2 conv2p fc3 aconv1 aconv2 afc3; do python tools/bench_mac.py $g 32 2 packed 2>&1 | grep -v amdgpu >> $O/mac_geometries.txt; done
+for g in conv2p fc3 aconv2 afc3; do python tools/bench_mac.py $g 32 2 limb 2>&1 | grep -v amdgpu >> $O/mac_geometries.txt; python tools/bench_mac.py $g 32 2 limbk 2>&1 | grep -v amdgpu >> $O/mac_geometries.txt; done
+python tools/bench_mfma.py 4096 2 24 > $O/mfma_proto.txt 2>&1
+fi
 ls $O
