@@ -35,6 +35,9 @@ CONFIGS = {
     # the coefficient modulus CrCNN itself would run at n=8192 (all four primes of coeff_modulus_128(8192)); at n=16384 the
     # eight default primes would need 424 GB for PlainModelWoPad's encoded weights alone (> HBM), so that one stays at k=4
     "approx8192k4": dict(model="ApproxPlainModel", n=8192, k=4, t=1 << 42, batch=1024, chunk=16),
+    # every prime of coeff_modulus_128(16384), the coefficient modulus CrCNN's own setParameters(16384, t) picks: 424 GB of NTT-form weights -- fc3 keeps
+    # coefficient-form plaintexts in HBM and is lifted + transformed a filter tile at a time inside every forward (netrun: streamed layers)
+    "wopad16384k8": dict(model="PlainModelWoPad", n=16384, k=8, t=1 << 44, batch=96, chunk=6),
     # small ring for the tests of this script and single-GPU rehearsals of the multi-rank path (golden: net_tiny1024_eng.json)
     "tiny1024": dict(model="PlainModelTiny", n=1024, k=2, q=[0x7fffffff380001, 0x3fffffff000001], t=1 << 32, batch=48, chunk=24),
 }
@@ -229,7 +232,7 @@ def cpu_baseline(cfg, q, W, x0, target_s):
 
 # golden fixtures (tests/golden/net_*.json, produced by the compiled reference: oracle/make_golden_nets.py) whose encrypted input is what
 # this script generates for image 0 of rank 0 -- same parameter set, same seeded client side
-GOLDEN_FOR = {"tiny4096": "tiny4096_t32", "approx8192": "approx8192_t42", "approx8192k4": "approx8192k4_t42", "wopad16384": "wopad16384_t44", "tiny1024": "tiny1024_eng"}
+GOLDEN_FOR = {"tiny4096": "tiny4096_t32", "approx8192": "approx8192_t42", "approx8192k4": "approx8192k4_t42", "wopad16384": "wopad16384_t44", "wopad16384k8": "wopad16384k8_t44", "tiny1024": "tiny1024_eng"}
 KEY_SEED, EVK_SEED, ENC_SEED = 2024, 2025, 7000
 
 

@@ -58,6 +58,10 @@ def layer_macs(kind, a):
     return 0
 
 
+def E_k_n_8(eng):
+    return eng.k * eng.n * 8
+
+
 class Network:
     """Encoded network resident in HBM.  `alloc(nbytes)` must return an object Engine.p() understands."""
 
@@ -67,6 +71,10 @@ class Network:
         import os
         self.limb = (os.environ.get("CRC_MFMA", "1") != "0") if limb is None else limb
         self._limbed = False
+        # a conv / dense layer whose NTT-form weights (k rows per weight) would take more than this share of HBM keeps its weights as coefficient-form plaintexts
+        # (ONE row per weight) and lifts + NTTs them a filter tile at a time inside every forward (SURVEY section 7's fall-back: PlainModelWoPad's fc3 at n = 16384,
+        # k = 8 is 419 GB in NTT form, 52 GB as plaintexts).  Same ciphertexts; the price is k row transforms per weight and chunk.
+        self.stream_share = float(os.environ.get("CRC_STREAM_SHARE", "0.45"))
         self.limb_reserve = 24 << 30          # HBM to leave free when a limb copy of the weights is made (activations + work space come later)
         self.alloc = alloc or eng.alloc
         self.resident = resident            # keep tensors NTT-resident between layers (bit-identical)
@@ -88,7 +96,12 @@ class Network:
             last = li == len(self.topo) - 1
             if kind in ("conv", "fc"):
                 out_form = COEFF if (last or not resident) else NTT
-                p["w"] = self._encode_ntt(get(name + ".weight"), encode_chunk)
+                wv = get(name + ".weight")
+                if eng.device >= 0 and wv.size * E_k_n_8(eng) > self.stream_share * eng.mem_info()[1]:
+                    p["w"] = None; p["streamed"] = True
+                    p["plain"] = self._encode_plain(wv, encode_chunk)
+                else:
+                    p["w"] = self._encode_ntt(wv, encode_chunk)
                 p["b"] = self._delta(get(name + ".bias"), out_form)
                 p["in_form"], p["out_form"] = form, out_form
                 form = out_form
@@ -134,7 +147,7 @@ class Network:
             return
         assert not self._packed
         for idx, (kind, name, a, p, ishape, oshape) in enumerate(self.plan):
-            if not self.limb_eligible(kind, a):
+            if not self.limb_eligible(kind, a) or p.get("streamed"):
                 continue
             nf, zd, xf, yf = (a["nf"], a["zd"], a["xf"], a["yf"]) if kind == "conv" else (a["out_dim"], a["in_dim"], 1, 1)
             nbytes = E.limb_weights_bytes(nf, zd, xf, yf)
@@ -179,7 +192,7 @@ class Network:
                 continue
             if kind not in ("conv", "fc"):
                 continue
-            if p.get("w_form") != binding.NTTL:
+            if p.get("w_form") != binding.NTTL and not p.get("streamed"):
                 rows = (a["nf"] * a["zd"] * a["xf"] * a["yf"] if kind == "conv" else a["in_dim"] * a["out_dim"]) * E.k
                 E.pack28(p["w"], rows, unpack=unpack)
                 p["w_form"] = NTT if unpack else binding.NTTP
@@ -202,7 +215,7 @@ class Network:
         while i < len(self.plan):
             kind, name, a, p, ishape, oshape = self.plan[i]
             nxt = self.plan[i + 1] if i + 1 < len(self.plan) else None
-            if kind == "conv" and nxt and nxt[0] in ("pool", "avgpool") and p["out_form"] == NTT and nxt[3]["form"] == NTT:
+            if kind == "conv" and not p.get("streamed") and nxt and nxt[0] in ("pool", "avgpool") and p["out_form"] == NTT and nxt[3]["form"] == NTT:
                 pa = nxt[2]
                 xf2, yf2 = (pa["xf"] - 1) * a["xs"] + a["xf"], (pa["yf"] - 1) * a["ys"] + a["yf"]
                 xs2, ys2 = a["xs"] * pa["xs"], a["ys"] * pa["ys"]
@@ -246,7 +259,7 @@ class Network:
         while i < len(self.plan):
             kind, name, a, p, ishape, oshape = self.plan[i]
             nxt = self.plan[i + 1] if i + 1 < len(self.plan) else None
-            if kind == "bn" and nxt and nxt[0] in ("conv", "fc") and p["form"] == NTT and nxt[3]["out_form"] == NTT and "fused" not in nxt[3]:
+            if kind == "bn" and nxt and nxt[0] in ("conv", "fc") and p["form"] == NTT and nxt[3]["out_form"] == NTT and "fused" not in nxt[3] and not nxt[3].get("streamed"):
                 nk, nname, na, np_, nish, nosh = nxt
                 ch = ishape[0]
                 if nk == "conv":
@@ -300,6 +313,21 @@ class Network:
             E.sync()
         return out
 
+    def _encode_plain(self, vals, chunk, dtype=np.float32):
+        """coefficient-form plaintexts [count][n] resident in HBM (streamed layers)"""
+        E = self.E
+        vals = np.ascontiguousarray(np.asarray(vals, dtype=dtype).reshape(-1))
+        out = self.alloc(vals.size * E.n * 8)
+        self.weight_bytes += vals.size * E.n * 8
+        self.param_bufs.append((out, vals.size * E.n * 8))
+        if not self.materialize:
+            return out
+        for o in range(0, vals.size, chunk):
+            pl, _ = E.encode(vals[o:o + chunk], dtype=dtype)
+            E.L.crc_memcpy_h2d(E.c, E.p(out) + o * E.n * 8, pl.ctypes.data, pl.nbytes, E.stream)
+            E.sync()
+        return out
+
     def _delta(self, vals, form):
         E = self.E
         pl, _ = E.encode(np.asarray(vals, dtype=np.float32))
@@ -330,6 +358,10 @@ class Network:
         need_act = (big[0] + big[1]) * B * self.ct_bytes()
         work = 0
         for (kind, name, a, p, ishape, oshape) in self.plan:
+            if p.get("streamed"):
+                g = self._stream_geometry(kind, a)
+                work = max(work, E.conv2d_forms_work_bytes(B, g["zd"], g["xd"], g["yd"], g["xs"], g["ys"], g["xf"], g["yf"], g["ft"], p["in_form"], NTT, p["out_form"]))
+                continue
             if kind == "conv":
                 work = max(work, E.conv2d_forms_work_bytes(B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"], p["in_form"], p.get("w_form", NTT), p["out_form"]))
             elif kind == "fc":
@@ -337,6 +369,30 @@ class Network:
             elif kind == "square":
                 work = max(work, E.square_relin_work_bytes(B * int(np.prod(ishape)), self.dbc))
         return need_act, work
+
+    def _stream_geometry(self, kind, a):
+        """a streamed layer as a convolution + the filter tile: as many filters as make ~2 GiB of NTT-form weights"""
+        g = dict(zd=a["zd"], xd=a["xd"], yd=a["yd"], xs=a["xs"], ys=a["ys"], xf=a["xf"], yf=a["yf"], nf=a["nf"]) if kind == "conv" else \
+            dict(zd=a["in_dim"], xd=1, yd=1, xs=1, ys=1, xf=1, yf=1, nf=a["out_dim"])
+        T = g["zd"] * g["xf"] * g["yf"]
+        g["T"] = T
+        g["ft"] = max(1, min(g["nf"], (2 << 30) // (T * self.E.k * self.E.n * 8)))
+        g["P"] = ((g["xd"] - g["xf"]) // g["xs"] + 1) * ((g["yd"] - g["yf"]) // g["ys"] + 1)
+        return g
+
+    def _forward_streamed(self, kind, a, p, cur, B, out):
+        """lift + NTT a tile of filters, run the layer on the tile, scatter the tile's output channels into the [B][F][P] tensor"""
+        E = self.E
+        g = self._stream_geometry(kind, a)
+        rowb = E.k * E.n * 8; ctb = self.ct_bytes()
+        coeff_out = p["out_form"] == COEFF
+        for f0 in range(0, g["nf"], g["ft"]):
+            ft = min(g["ft"], g["nf"] - f0)
+            E.plain_to_ntt(E.p(p["plain"]) + f0 * g["T"] * E.n * 8, ft * g["T"], self.wtile)
+            bias = E.p(p["b"]) + f0 * rowb
+            E.conv2d(cur, self.wtile, bias, B, g["zd"], g["xd"], g["yd"], g["xs"], g["ys"], g["xf"], g["yf"], ft, p["in_form"], p["out_form"], self.ytile, self.work)
+            for b in range(B):
+                E.L.crc_memcpy_d2d(E.c, E.p(out) + (b * g["nf"] + f0) * g["P"] * ctb, E.p(self.ytile) + b * ft * g["P"] * ctb, ft * g["P"] * ctb, E.stream)
 
     def _slots(self):
         """ping-pong slot of every layer's output (in-place layers keep their input's slot); -1 = caller's input"""
@@ -367,6 +423,15 @@ class Network:
         _, work = self.scratch_bytes(B)
         self.work = self.alloc(max(work, 256))
         self.work_bytes = max(work, 256)
+        self.wtile = self.ytile = None
+        for (kind, name, a, p, ishape, oshape) in self.plan:
+            if p.get("streamed"):
+                g = self._stream_geometry(kind, a)
+                wt, yt = g["ft"] * g["T"] * self.E.k * self.E.n * 8, B * g["ft"] * g["P"] * self.ct_bytes()
+                if self.wtile is None or self._wtile_bytes < wt:
+                    self.wtile, self._wtile_bytes = self.alloc(wt), wt
+                if self.ytile is None or self._ytile_bytes < yt:
+                    self.ytile, self._ytile_bytes = self.alloc(yt), yt
 
     # ---- forward over one chunk of B images; d_x: [B][1][28][28] cts in coefficient form.  Returns device ptr of the
     # [B][10] output cts (coefficient form).  `timer(i, name)` (optional) is called around every layer.
@@ -377,7 +442,10 @@ class Network:
             out = self.buf[self.slots[i]]
             if timer:
                 timer(i, name, kind, 0)
-            if kind == "conv":
+            if p.get("streamed"):
+                self._forward_streamed(kind, a, p, cur, B, out)
+                cur = out
+            elif kind == "conv":
                 E.conv2d(cur, p["w"], p["b"], B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"], p["in_form"], p["out_form"], out, self.work,
                          w_form=p.get("w_form", NTT))
                 cur = out

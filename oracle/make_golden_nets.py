@@ -37,12 +37,14 @@ NETS = {
     "approx8192_t42": ("ApproxPlainModel", 8192, Q8192[:3], 1 << 42, 10),
     "approx8192k4_t42": ("ApproxPlainModel", 8192, Q8192[:4], 1 << 42, 10),
     "wopad16384_t44": ("PlainModelWoPad", 16384, Q16384[:4], 1 << 44, 25),
+    # all eight primes of coeff_modulus_128(16384): what CrCNN's own setParameters(16384, t) picks.  424 GB of NTT-form weights: the engine streams them
+    "wopad16384k8_t44": ("PlainModelWoPad", 16384, Q16384[:8], 1 << 44, 50),
 }
 KEY_SEED, EVK_SEED, ENC_SEED, IMAGE_INDEX = 9000, 9001, 100000, 0
 # The bench-parameter sets take their keys and encrypted input image from the ENGINE's seeded client side (crc_keygen / crc_gen_evk /
 # crc_encrypt on the host, no GPU) with exactly the seeds bench.py uses for image 0 of rank 0: the product can then reproduce the golden
 # input without touching anything under oracle/, and bench.py compares its output digest with the reference's (`golden_match`).
-ENGINE_INPUTS = {"tiny4096_t32", "approx8192_t42", "approx8192k4_t42", "wopad16384_t44", "tiny1024_eng"}
+ENGINE_INPUTS = {"tiny4096_t32", "approx8192_t42", "approx8192k4_t42", "wopad16384_t44", "wopad16384k8_t44", "tiny1024_eng"}
 ENG_KEY_SEED, ENG_EVK_SEED, ENG_ENC_SEED = 2024, 2025, 7000
 NETS["tiny1024_eng"] = ("PlainModelTiny", 1024, [0x7fffffff380001, 0x3fffffff000001], 1 << 32, 1)     # n = 1024: smallest ring in which the fractional encoding survives the four multiplicative levels
 

@@ -61,3 +61,15 @@ def test_ntt_resident_network_matches_reference(name):
         got = [O.decrypt_value(sk, out[0, 0, j, 0]) for j in range(10)]
         assert got == g["logits"]
         assert [O.noise_budget(sk, out[0, 0, j, 0]) for j in range(3)] == g["budget"][:3]
+
+
+@pytest.mark.parametrize("name", ["tiny256", "wopad256", "tiny1024_eng"])
+def test_streamed_weights_match_reference(name, monkeypatch):
+    """layers whose NTT-form weights would not fit in HBM (PlainModelWoPad at n = 16384 with all eight primes: 424 GB) keep coefficient-form plaintexts and lift + NTT
+    a filter tile at a time inside every forward (netrun.Network.stream_share).  Forced here on small rings: every conv / dense layer streams; same reference digests"""
+    monkeypatch.setenv("CRC_STREAM_SHARE", "1e-9")
+    g, O, sk, out, digests = run_net(name, resident=False)
+    for i, L in enumerate(g["layers"]):
+        assert digests[i][0] == L["sha256"], (name, i, L["name"])
+    g, O, sk, out, _ = run_net(name, resident=True, batch=2)
+    assert sha(out[0]) == g["out_sha256"] and sha(out[1]) == g["out_sha256"]

@@ -45,3 +45,42 @@ def test_errors():
         ca.h5_read(os.path.join(GOLD, "h5_datasets.npz"), "x")      # not an HDF5 file
     with pytest.raises(ca.CrcError):
         ca.h5_read("/nonexistent/file.h5", "x")
+
+
+def test_malformed_files_fail_cleanly():
+    """message bodies, dimension products and base-relative addresses are bounds-checked -- truncated or mutated files give CRC_ERR_IO / not-found /
+    a clean read, never an out-of-bounds access.  Run in a child process so that a crash cannot take the test session down."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+import crcnn_amd as ca
+src = open(%r, "rb").read()
+rng = np.random.default_rng(3)
+tmp = %r
+names = ["pool1_features.conv1.weight", "classifier.fc3.bias"]
+bad = 0
+for it in range(300):
+    b = bytearray(src)
+    if it %% 3 == 0:
+        b = b[: int(rng.integers(8, len(b)))]                       # truncation
+    else:
+        for _ in range(int(rng.integers(1, 6))):                      # header mutations: superblock, B-tree, heap, object headers live in the first pages
+            pos = int(rng.integers(0, min(len(b), 8192)))
+            b[pos] = int(rng.integers(0, 256)) if it %% 3 == 1 else 0xff
+    open(tmp, "wb").write(bytes(b))
+    for nm in names:
+        try:
+            ca.h5_read(tmp, nm)
+        except ca.CrcError:
+            bad += 1
+    try:
+        ca.h5_list(tmp)
+    except ca.CrcError:
+        bad += 1
+print("survived", bad)
+''' % (os.path.dirname(GOLD.rstrip("/")) + "/..", os.path.join(GOLD, "models", "PlainModelTiny.h5"), os.path.join(os.environ.get("TMPDIR", "/tmp"), "crc_fuzz.h5"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "survived" in out.stdout, (out.returncode, out.stderr[-1500:])
+    assert int(out.stdout.split()[-1]) > 50          # most mutations must have been detected as errors
