@@ -292,9 +292,10 @@ static shared_ptr<DeviceBuffer> &ensure(shared_ptr<DeviceBuffer> &b, size_t byte
 
 // canonical NTT-form weights -> limb form (CRC_NTTL) when the reduction is long enough for the matrix-core kernel to pay (same rule as netrun.py) and the
 // second copy fits beside the first; the canonical copy is dropped
-static bool toLimb(shared_ptr<DeviceBuffer> &d_w, int &w_form, int nf, int zd, int xf, int yf)
+static bool toLimb(shared_ptr<DeviceBuffer> &d_w, int &w_form, int nf, int zd, int xf, int yf, long rows)
 {
     if (w_form == CRC_NTTL) return true;
+    if (rows < 32) return false;                            // less than half a 64-row tile per launch: mostly padding, the vector-ALU kernel is faster
     if (zd < 16 || (zd + 31) / 32 * xf * yf < 16 || !crc_limb_supported(ctx(), zd, xf, yf)) return false;
     const size_t nbytes = crc_limb_weights_bytes(ctx(), nf, zd, xf, yf);
     size_t free_b = 0, total_b = 0;
@@ -337,7 +338,7 @@ void ConvolutionalLayer::deviceParameters(vector<shared_ptr<DeviceBuffer>> &out,
     packWeights(true);                                      // canonical residues on the wire (uploads first if needed)
     out.push_back(d_w); out.push_back(d_b[0]); out.push_back(d_b[1]);
 }
-bool ConvolutionalLayer::limbWeights() { upload(); if (w_form == CRC_NTTP) packWeights(true); return toLimb(d_w, w_form, nf, zd, xf, yf); }
+bool ConvolutionalLayer::limbWeights(int B) { upload(); if (w_form == CRC_NTTL) return true; if (w_form == CRC_NTTP) packWeights(true); return toLimb(d_w, w_form, nf, zd, xf, yf, (long)B * 2 * xo * yo); }
 void ConvolutionalLayer::packWeights(bool unpack)
 {
     upload();
@@ -399,7 +400,7 @@ void FullyConnectedLayer::deviceParameters(vector<shared_ptr<DeviceBuffer>> &out
     packWeights(true);
     out.push_back(d_w); out.push_back(d_b[0]); out.push_back(d_b[1]);
 }
-bool FullyConnectedLayer::limbWeights() { upload(); if (w_form == CRC_NTTP) packWeights(true); return toLimb(d_w, w_form, out_dim, in_dim, 1, 1); }
+bool FullyConnectedLayer::limbWeights(int B) { upload(); if (w_form == CRC_NTTL) return true; if (w_form == CRC_NTTP) packWeights(true); return toLimb(d_w, w_form, out_dim, in_dim, 1, 1, (long)B * 2); }
 void FullyConnectedLayer::packWeights(bool unpack)
 {
     upload();
@@ -525,8 +526,8 @@ ciphertext3D Network::forward(ciphertext3D input)
     vector<char> limb(L, 0);
     if (packable)
         for (int i = 0; i < L; i++) {
-            if (auto c = dynamic_pointer_cast<ConvolutionalLayer>(layers[i])) { limb[i] = matrix_cores && c->limbWeights(); if (!limb[i]) c->packWeights(false); }
-            else if (auto f = dynamic_pointer_cast<FullyConnectedLayer>(layers[i])) { limb[i] = matrix_cores && f->limbWeights(); if (!limb[i]) f->packWeights(false); }
+            if (auto c = dynamic_pointer_cast<ConvolutionalLayer>(layers[i])) { limb[i] = matrix_cores && c->limbWeights(input.B); if (!limb[i]) c->packWeights(false); }
+            else if (auto f = dynamic_pointer_cast<FullyConnectedLayer>(layers[i])) { limb[i] = matrix_cores && f->limbWeights(input.B); if (!limb[i]) f->packWeights(false); }
         }
     for (int i = 0; i < L; i++) {
         bool coeff = !ntt_resident || i == L - 1 || i + 1 == layer_before_reenc;

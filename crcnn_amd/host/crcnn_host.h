@@ -120,7 +120,7 @@ private:
     int w_form = CRC_NTT;                                   // CRC_NTTP / CRC_NTTL once Network::forward has put the weights into their MAC kernel's operand form
     void upload();
     void packWeights(bool unpack);
-    bool limbWeights();                                     // -> CRC_NTTL (matrix-core kernel) when the layer qualifies and HBM has room for the second copy
+    bool limbWeights(int B);                                // -> CRC_NTTL (matrix-core kernel) when the layer qualifies (for batches of B) and HBM has room for the second copy
 public:
     void deviceParameters(std::vector<std::shared_ptr<DeviceBuffer>> &out, bool allocate_only) override;
 };
@@ -145,7 +145,7 @@ private:
     int w_form = CRC_NTT;
     void upload();
     void packWeights(bool unpack);
-    bool limbWeights();
+    bool limbWeights(int B);
 public:
     void deviceParameters(std::vector<std::shared_ptr<DeviceBuffer>> &out, bool allocate_only) override;
 };

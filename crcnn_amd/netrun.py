@@ -139,7 +139,7 @@ class Network:
             return False
         return self.limb and zd >= 16 and -(-zd // 32) * xf * yf >= 16 and self.E.limb_supported(zd, xf, yf)
 
-    def _limb_operands(self):
+    def _limb_operands(self, B=None):
         """conv / dense weights of the eligible layers -> limb form (the canonical copy is dropped: call after fuse()); a limb layer that feeds a dense
         limb layer hands its tensor over in limb form"""
         E = self.E
@@ -148,6 +148,10 @@ class Network:
         assert not self._packed
         for idx, (kind, name, a, p, ishape, oshape) in enumerate(self.plan):
             if not self.limb_eligible(kind, a) or p.get("streamed"):
+                continue
+            # a workgroup covers 64 rows = (image, pixel, poly): with fewer than half a tile of rows per launch (dense layers at small chunks) most of every MFMA is
+            # padding and every slot's weights are streamed for a handful of rows -- mac3_kernel is faster there (PlainModelWoPad at chunk 6: fc4 0.23 vs 1.59 ms/image)
+            if B is not None and B * 2 * int(np.prod(oshape[1:])) < 32:
                 continue
             nf, zd, xf, yf = (a["nf"], a["zd"], a["xf"], a["yf"]) if kind == "conv" else (a["out_dim"], a["in_dim"], 1, 1)
             nbytes = E.limb_weights_bytes(nf, zd, xf, yf)
@@ -410,7 +414,7 @@ class Network:
         (limb=False keeps every layer on the vector-ALU kernel: needed while fuse() is still to come)"""
         if self.materialize:
             if limb:
-                self._limb_operands()
+                self._limb_operands(B)
             self._pack_operands()
         acts = self.activation_cts()
         self.B = B

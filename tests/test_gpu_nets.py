@@ -73,3 +73,21 @@ def test_streamed_weights_match_reference(name, monkeypatch):
         assert digests[i][0] == L["sha256"], (name, i, L["name"])
     g, O, sk, out, _ = run_net(name, resident=True, batch=2)
     assert sha(out[0]) == g["out_sha256"] and sha(out[1]) == g["out_sha256"]
+
+
+def test_matrix_core_dense_layers_match_reference():
+    """with at least half a 64-row tile per launch (16 images x 2 polys) the dense layers run on the matrix-core kernel too, and conv2 hands its tensor to fc3 in limb
+    form (CRC_NTTL): every image of the batch must still come out as the compiled reference's ciphertexts"""
+    import crcnn_amd as ca
+    from crcnn_amd.netrun import Network
+    g = load_net_golden("tiny1024_eng")
+    O, sk, pk, evk, img, x = make_inputs(g)
+    E = ca.Engine(g["n"], g["q"], g["t"], device=0)
+    net = Network(E, g["model"], h5_path=os.path.join(GOLD, "models", g["model"] + ".h5"), resident=True)
+    net.fuse(); net.prepare(16)
+    forms = {pl[1]: pl[3].get("w_form") for pl in net.plan if pl[0] in ("conv", "fc")}
+    assert forms["classifier.fc3"] == ca.NTTL and forms["classifier.fc4"] == ca.NTTL and [pl[3]["in_form"] for pl in net.plan if pl[1] == "classifier.fc3"] == [ca.NTTL]
+    d_x = E.upload(np.ascontiguousarray(np.repeat(x[None], 16, axis=0)))
+    out = E.download(net.forward(d_x, 16), (16, 1, 10, 1, 2, E.k, E.n))
+    E.close()
+    assert all(sha(out[b]) == g["out_sha256"] for b in range(16))
