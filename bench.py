@@ -278,10 +278,21 @@ class Dist:
     def make_comm(self, E):
         """RCCL communicator of the engine (C ABI); the 128-byte rendezvous id travels over the torch.distributed store"""
         if self.world == 1 or self.backend != "nccl":
-            return None
-        obj = [E.comm_unique_id() if self.rank == 0 else None]
-        self.dist.broadcast_object_list(obj, src=0)
-        return E.comm_create(self.world, self.rank, obj[0])
+            return None, None
+        comm, err = None, None
+        try:
+            obj = [E.comm_unique_id() if self.rank == 0 else None]
+            self.dist.broadcast_object_list(obj, src=0)
+            comm = E.comm_create(self.world, self.rank, obj[0])
+        except Exception as ex:                                   # a rank without its communicator must not leave the others waiting inside ncclBroadcast:
+            err = f"{type(ex).__name__}: {ex}"                    # every rank learns whether ALL have one, otherwise all use the torch.distributed (RCCL) broadcast
+        have = self.sum(int(comm is not None))
+        if have != self.world:
+            if comm is not None:
+                E.comm_destroy(comm)
+            errs = [e_ for e_ in self.gather(err) if e_]
+            return None, (errs[0] if errs else "communicator missing on some rank")
+        return comm, None
 
     def barrier(self):
         if self.world > 1:
@@ -378,7 +389,7 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
     if world > 1:
         bufs = list(net.param_bufs) + ([(d_evk, d_evk.numel() * 8)] if d_evk is not None else [])
         nbytes = sum(n_ for _, n_ in bufs)
-        comm = D_.make_comm(E)
+        comm, comm_err = D_.make_comm(E)
         D_.barrier(); t0 = time.time()
         if comm is not None:
             for buf, n_ in bufs:
@@ -387,7 +398,7 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
         else:
             from crcnn_amd import shard
             shard.broadcast_buffers([buf for buf, _ in bufs], src=0, chunk_bytes=1 << 30)
-            via = f"torch.distributed ({D_.backend}) -- rehearsal backend"
+            via = f"torch.distributed ({D_.backend})" + (" -- rehearsal backend" if D_.backend != "nccl" else f" -- FALLBACK, crc_comm_create failed: {comm_err}")
         torch.cuda.synchronize(); D_.barrier(); bcast_s = time.time() - t0
         cs = [0, 0]
         for buf, n_ in bufs:
