@@ -71,10 +71,21 @@ t_px = timed(lambda: ck(M.mm_pack_x(VP(x.data_ptr()), VP(xp.data_ptr()), n, k, B
 conv = lambda mode=0: ck(M.mm_conv(VP(xp.data_ptr()), VP(wp.data_ptr()), VP(ys.data_ptr()), n, k, B, VP(mods.data_ptr()), mode), "conv")
 abl = ""
 if os.environ.get("MM_ABLATE"):
-    abl = f" | ablation: no loads {timed(lambda: conv(1)):.2f} ms, no MFMA {timed(lambda: conv(2)):.2f} ms"
+    abl = f" | ablation: no loads {timed(lambda: conv(1)):.2f} ms, no MFMA {timed(lambda: conv(2)):.2f} ms, no epilogue reduction {timed(lambda: conv(3)):.2f} ms"
 t_mm = timed(conv)
+if os.environ.get("MM_ZERO"):          # data dependence of the clock the chip holds (power): the same launch on all-zero limb tensors
+    xp.zero_(); wp.zero_(); torch.cuda.synchronize()
+    abl += f" | all-zero operands {timed(conv):.2f} ms"
+    ck(M.mm_pack_w(VP(w.data_ptr()), VP(wp.data_ptr()), qa, n, k, VP(mods.data_ptr())), "pack_w")
+    ck(M.mm_pack_x(VP(x.data_ptr()), VP(xp.data_ptr()), n, k, B, VP(mods.data_ptr())), "pack_x"); conv(); torch.cuda.synchronize()
 ck(M.mm_unpack_y(VP(ys.data_ptr()), VP(y.data_ptr()), n, k, B), "unpack_y")
 torch.cuda.synchronize()
+if os.environ.get("MM_RESIDENT"):
+    t_res = timed(lambda: conv(4))
+    y2 = torch.empty_like(y_ref)
+    ck(M.mm_unpack_y(VP(ys.data_ptr()), VP(y2.data_ptr()), n, k, B), "unpack_y"); torch.cuda.synchronize()
+    abl += f" | A-resident variant {t_res:.2f} ms, bit-identical: {bool(torch.equal(y2, y_ref))}"
+    conv(0); torch.cuda.synchronize()
 same = bool(torch.equal(y, y_ref))
 bad = int((y != y_ref).sum().item()) if not same else 0
 modmul = B * P * NF * T * 2 * k * n

@@ -118,7 +118,7 @@ __device__ __forceinline__ u64 reduce_diagonals(const i32 (&D)[13], const Mod &m
 }
 
 // grid: one workgroup per (residue, slot, image pair); 256 threads = 4 waves (wm, wn) in a 2 x 2 arrangement of 32 x 32 tiles
-// MODE (ablation, wrong results): 1 = no operand loads after the first three steps, 2 = no MFMAs
+// MODE (ablation, wrong results): 1 = no operand loads after the first three steps, 2 = no MFMAs, 3 = no reduction mod q in the epilogue
 template <int MODE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 mfma_conv_kernel(const signed char *xp, const signed char *wp, u64 *ys, const Mod *mods, int n, int k, int B)
@@ -205,8 +205,80 @@ mfma_conv_kernel(const signed char *xp, const signed char *wp, u64 *ys, const Mo
         i32 D[13];
 #pragma unroll
         for (int d = 0; d < 13; d++) D[d] = acc[d][reg];
-        dst[row] = reduce_diagonals(D, m);
+        if (mode == 3) { u64 sum = 0; for (int d = 0; d < 13; d++) sum += (u64)(u32)D[d] << d; dst[row] = sum; }     // keeps every accumulator alive, drops the reduction
+        else dst[row] = reduce_diagonals(D, m);
         __builtin_amdgcn_sched_barrier(0);                 // one output at a time: sixteen interleaved reductions would spill
+    }
+}
+
+// Variant with the workgroup's two image blocks RESIDENT in LDS (129 KiB) and only the weight tile streamed (2-slot ring, 28 KiB): every A byte crosses L2 -> LDS once
+// instead of once per tap that touches it (~9x), halving the per-step LDS-DMA fill that bounds the streaming kernel.  A fragments are gathered from the resident blocks.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+mfma_conv_resident_kernel(const signed char *xp, const signed char *wp, u64 *ys, const Mod *mods, int n, int k, int B)
+{
+    extern __shared__ __attribute__((aligned(16))) signed char lds[];          // [2 image blocks][2 x W tile]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 1, wn = wave & 1;
+    const int pairs = B / 2, slots = n * k;
+    int g = blockIdx.x, slot, bp;
+    if ((slots & 7) == 0) { const int xcd = g & 7, r = g >> 3; slot = xcd * (slots >> 3) + r / pairs; bp = r % pairs; }
+    else { slot = g / pairs; bp = g % pairs; }
+    const int i = slot / n;
+    const Mod m = mods[i];
+    const signed char *ximg = xp + ((size_t)slot * B + 2 * bp) * IMG_BYTES;
+    const signed char *wsl = wp + (size_t)slot * WSLOT_BYTES;
+    signed char *ldsW = lds + 2 * IMG_BYTES;
+    constexpr int APIECES = 2 * IMG_BYTES / 1024;            // 126
+    // W pieces of a step: 14, waves take pieces wave, wave + 4, ... (4, 4, 3, 3)
+    auto issue_w = [&](int tap) {
+        signed char *dst = ldsW + (tap & 1) * TILE_BYTES;
+        const signed char *wt = wsl + (size_t)tap * TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int pc = wave + 4 * j;
+            if (pc < 14)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wt + pc * 1024 + lane * 16), (__attribute__((address_space(3))) void *)(dst + pc * 1024), 16, 0, 0);
+        }
+    };
+    for (int pc = wave; pc < APIECES; pc += 4)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ximg + pc * 1024 + lane * 16), (__attribute__((address_space(3))) void *)(lds + pc * 1024), 16, 0, 0);
+    issue_w(0);
+
+    v16i acc[13];
+#pragma unroll
+    for (int d = 0; d < 13; d++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[d][e] = 0;
+
+    const int r = lane & 31, p = r >> 1, c = r & 1, ox = p >> 2, oy = p & 3;
+    const int fragA = wm * IMG_BYTES + (((ox * STR) * XD + oy * STR) * 2 + c) * ZD + (lane >> 5) * 16;
+    const int fragW = (wn * 32 + (lane & 31)) * ZD + (lane >> 5) * 16;
+    for (int tap = 0; tap < TAPS; tap++) {
+        __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));    // this wave's pieces of step `tap` (and, at tap 0, of the image blocks) have landed ...
+        __syncthreads();                                          // ... and everybody's; the other W slot, read in step tap - 1, is free
+        if (tap + 1 < TAPS) issue_w(tap + 1);
+        const int kx = tap / WF, ky = tap % WF;
+        const signed char *tA = lds + fragA + (kx * XD + ky) * 2 * ZD, *tW = ldsW + (tap & 1) * TILE_BYTES;
+        v4i w[NPL];
+#pragma unroll
+        for (int l = 0; l < NPL; l++) w[l] = *reinterpret_cast<const v4i *>(tW + l * (64 * ZD) + fragW);
+#pragma unroll
+        for (int l = 0; l < NPL; l++) {
+            const v4i a = *reinterpret_cast<const v4i *>(tA + l * (NPOS * 2 * ZD));
+#pragma unroll
+            for (int mm = 0; mm < NPL; mm++)
+                acc[l + mm] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, w[mm], acc[l + mm], 0, 0, 0);
+        }
+    }
+    const int f = wn * 32 + (lane & 31);
+    u64 *dst = ys + ((size_t)slot * B + 2 * bp + wm) * (NF * 32) + (size_t)f * 32;
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        i32 D[13];
+#pragma unroll
+        for (int d = 0; d < 13; d++) D[d] = acc[d][reg];
+        dst[row] = reduce_diagonals(D, m);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -241,8 +313,14 @@ extern "C" int mm_pack_x(const u64 *x, signed char *xp, int n, int k, int B, voi
 extern "C" int mm_conv(const signed char *xp, const signed char *wp, u64 *ys, int n, int k, int B, void *d_mods, int mode)
 {
     if (B % 2) return -3;
+    if (mode == 4) {
+        const size_t ldsr = 2 * IMG_BYTES + 2 * TILE_BYTES;
+        if (hipFuncSetAttribute((const void *)mfma_conv_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr) != hipSuccess) return -4;
+        hipLaunchKernelGGL(mfma_conv_resident_kernel, dim3((unsigned)((size_t)n * k * (B / 2))), dim3(256), ldsr, 0, xp, wp, ys, (const Mod *)d_mods, n, k, B);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     const size_t lds = 8 * TILE_BYTES;                    // 4-slot ring of (A tile | W tile): 112 KiB
-    auto kern = mode == 1 ? mfma_conv_kernel<1> : mode == 2 ? mfma_conv_kernel<2> : mfma_conv_kernel<0>;
+    auto kern = mode == 1 ? mfma_conv_kernel<1> : mode == 2 ? mfma_conv_kernel<2> : mode == 3 ? mfma_conv_kernel<3> : mfma_conv_kernel<0>;
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -4;
     const size_t grid = (size_t)n * k * (B / 2);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, 0, xp, wp, ys, (const Mod *)d_mods, n, k, B);
