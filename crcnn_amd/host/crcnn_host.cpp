@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -78,10 +79,11 @@ Plaintext fraencode(double value)
 }
 double fradecode(const vector<uint64_t> &plain) { return crc_decode(ctx(), plain.data()); }
 
-// plaintext list -> device buffer of [count][k][n]: mode 0 = NTT-form weights, 1 = delta coefficient form, 2 = delta NTT form
+// plaintext list -> device buffer of [count][k][n]: mode 0 = NTT-form weights, 1 = delta coefficient form, 2 = delta NTT form; mode 3 = the plaintext coefficients
+// themselves, [count][n] (streamed layers)
 static shared_ptr<DeviceBuffer> uploadPlain(const vector<const Plaintext *> &pl, int mode)
 {
-    const int n = N(), k = K();
+    const int n = N(), k = mode == 3 ? 1 : K();
     auto out = make_shared<DeviceBuffer>(pl.size() * (size_t)k * n * 8);
     const size_t chunk = max<size_t>(1, min<size_t>(pl.size(), (64u << 20) / ((size_t)n * 8)));
     DeviceBuffer stage(chunk * (size_t)n * 8);
@@ -91,7 +93,8 @@ static shared_ptr<DeviceBuffer> uploadPlain(const vector<const Plaintext *> &pl,
         for (size_t i = 0; i < c; i++) pl[o + i]->dense(host.data() + i * n, n);
         chk(crc_memcpy_h2d(ctx(), stage.ptr, host.data(), c * (size_t)n * 8, nullptr), "crc_memcpy_h2d");
         uint64_t *dst = (uint64_t *)out->ptr + o * (size_t)k * n;
-        if (mode == 0) chk(crc_plain_to_ntt(ctx(), (const uint64_t *)stage.ptr, c, dst, nullptr), "crc_plain_to_ntt");
+        if (mode == 3) chk(crc_memcpy_d2d(ctx(), dst, stage.ptr, c * (size_t)n * 8, nullptr), "crc_memcpy_d2d");
+        else if (mode == 0) chk(crc_plain_to_ntt(ctx(), (const uint64_t *)stage.ptr, c, dst, nullptr), "crc_plain_to_ntt");
         else chk(crc_plain_to_delta(ctx(), (const uint64_t *)stage.ptr, c, mode == 2 ? CRC_NTT : CRC_COEFF, dst, nullptr), "crc_plain_to_delta");
         chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
     }
@@ -290,6 +293,35 @@ static shared_ptr<DeviceBuffer> &ensure(shared_ptr<DeviceBuffer> &b, size_t byte
     return b;
 }
 
+static bool tooLargeForHbm(size_t weights)
+{
+    size_t free_b = 0, total_b = 0;
+    chk(crc_mem_info(ctx(), &free_b, &total_b), "crc_mem_info");
+    const char *e = getenv("CRC_STREAM_SHARE");                 // (tests force streaming on small rings with a tiny share, as netrun.py does)
+    const double share = e ? atof(e) : 0.45;
+    return (double)weights * K() * N() * 8 > share * (double)total_b;
+}
+// a streamed layer: lift + NTT a tile of filters, run the layer on the tile, scatter the tile's output channels into the [B][F][P] tensor
+static void forwardStreamed(const ciphertext3D &input, ciphertext3D &out, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int out_form,
+                            shared_ptr<DeviceBuffer> &d_plain, shared_ptr<DeviceBuffer> *d_b, shared_ptr<DeviceBuffer> &d_wtile, shared_ptr<DeviceBuffer> &d_ytile, shared_ptr<DeviceBuffer> &d_work)
+{
+    const size_t n = N(), k = K(), rowb = k * n * 8, ctb = ctBytes();
+    const size_t T = (size_t)zd * xf * yf, P = (size_t)((xd - xf) / xs + 1) * ((yd - yf) / ys + 1);
+    const int ft_max = (int)max<size_t>(1, min<size_t>(nf, ((size_t)2 << 30) / (T * rowb)));
+    if (!d_wtile || d_wtile->bytes < ft_max * T * rowb) d_wtile = make_shared<DeviceBuffer>(ft_max * T * rowb);
+    if (!d_ytile || d_ytile->bytes < (size_t)input.B * ft_max * P * ctb) d_ytile = make_shared<DeviceBuffer>((size_t)input.B * ft_max * P * ctb);
+    size_t wb = crc_conv2d_forms_work_bytes(ctx(), input.B, zd, xd, yd, xs, ys, xf, yf, ft_max, input.form, CRC_NTT, out_form);
+    if (!d_work || d_work->bytes < wb) d_work = make_shared<DeviceBuffer>(wb);
+    for (int f0 = 0; f0 < nf; f0 += ft_max) {
+        const int ft = min(ft_max, nf - f0);
+        chk(crc_plain_to_ntt(ctx(), (const uint64_t *)d_plain->ptr + (size_t)f0 * T * n, (size_t)ft * T, (uint64_t *)d_wtile->ptr, nullptr), "crc_plain_to_ntt");
+        chk(crc_conv2d_forms(ctx(), input.data(), (const uint64_t *)d_wtile->ptr, CRC_NTT, (const uint64_t *)((const char *)d_b[out_form != CRC_COEFF]->ptr + (size_t)f0 * rowb), input.B,
+                             zd, xd, yd, xs, ys, xf, yf, ft, input.form, out_form, (uint64_t *)d_ytile->ptr, d_work->ptr, nullptr), "crc_conv2d_forms");
+        for (int b = 0; b < input.B; b++)
+            chk(crc_memcpy_d2d(ctx(), (char *)out.buf->ptr + ((size_t)b * nf + f0) * P * ctb, (const char *)d_ytile->ptr + (size_t)b * ft * P * ctb, (size_t)ft * P * ctb, nullptr), "crc_memcpy_d2d");
+    }
+}
+
 // canonical NTT-form weights -> limb form (CRC_NTTL) when the reduction is long enough for the matrix-core kernel to pay (same rule as netrun.py) and the
 // second copy fits beside the first; the canonical copy is dropped
 static bool toLimb(shared_ptr<DeviceBuffer> &d_w, int &w_form, int nf, int zd, int xf, int yf, long rows)
@@ -325,23 +357,29 @@ void ConvolutionalLayer::upload()
         for (int z = 0; z < zd; z++) for (int i = 0; i < xf; i++) for (int j = 0; j < yf; j++) w.push_back(&filters[f][z][i][j]);
         b.push_back(&biases[f]);
     }
-    d_w = uploadPlain(w, 0); d_b[0] = uploadPlain(b, 1); d_b[1] = uploadPlain(b, 2);
+    streamed = tooLargeForHbm(w.size());
+    if (streamed) d_plain = uploadPlain(w, 3); else d_w = uploadPlain(w, 0);
+    d_b[0] = uploadPlain(b, 1); d_b[1] = uploadPlain(b, 2);
     filters_already_ntt = true;            // transform_kernel_to_ntt, convolutionalLayer.cpp:151-156 (done once)
 }
 void ConvolutionalLayer::deviceParameters(vector<shared_ptr<DeviceBuffer>> &out, bool allocate_only)
 {
     if (allocate_only && !filters_already_ntt) {
         const size_t rowb = (size_t)K() * N() * 8;
-        d_w = make_shared<DeviceBuffer>((size_t)nf * zd * xf * yf * rowb); d_b[0] = make_shared<DeviceBuffer>(nf * rowb); d_b[1] = make_shared<DeviceBuffer>(nf * rowb);
+        streamed = tooLargeForHbm((size_t)nf * zd * xf * yf);
+        if (!streamed) d_w = make_shared<DeviceBuffer>((size_t)nf * zd * xf * yf * rowb);
+        d_b[0] = make_shared<DeviceBuffer>(nf * rowb); d_b[1] = make_shared<DeviceBuffer>(nf * rowb);
         filters_already_ntt = true;
     }
     packWeights(true);                                      // canonical residues on the wire (uploads first if needed)
-    out.push_back(d_w); out.push_back(d_b[0]); out.push_back(d_b[1]);
+    if (streamed && !d_plain) d_plain = make_shared<DeviceBuffer>((size_t)nf * zd * xf * yf * N() * 8);
+    out.push_back(streamed ? d_plain : d_w); out.push_back(d_b[0]); out.push_back(d_b[1]);
 }
-bool ConvolutionalLayer::limbWeights(int B) { upload(); if (w_form == CRC_NTTL) return true; if (w_form == CRC_NTTP) packWeights(true); return toLimb(d_w, w_form, nf, zd, xf, yf, (long)B * 2 * xo * yo); }
+bool ConvolutionalLayer::limbWeights(int B) { upload(); if (streamed) return false; if (w_form == CRC_NTTL) return true; if (w_form == CRC_NTTP) packWeights(true); return toLimb(d_w, w_form, nf, zd, xf, yf, (long)B * 2 * xo * yo); }
 void ConvolutionalLayer::packWeights(bool unpack)
 {
     upload();
+    if (streamed) return;
     if (w_form == CRC_NTTL) { if (unpack) throw logic_error("ConvolutionalLayer " + name + ": weights are in limb form (fuse() / broadcastParameters() must precede the first forward())"); return; }
     if ((w_form == CRC_NTTP) == !unpack) return;
     chk(crc_pack28(ctx(), (uint64_t *)d_w->ptr, (size_t)nf * zd * xf * yf * K(), unpack ? 1 : 0, nullptr), "crc_pack28");
@@ -352,6 +390,7 @@ ciphertext3D ConvolutionalLayer::forward(ciphertext3D input)
     checkInput(input, zd, xd, yd, "ConvolutionalLayer");
     upload();
     ciphertext3D out(input.B, zo, xo, yo, out_form);
+    if (streamed) { forwardStreamed(input, out, zd, xd, yd, xs, ys, xf, yf, nf, out_form, d_plain, d_b, d_wtile, d_ytile, d_work); return out; }
     size_t wb = crc_conv2d_forms_work_bytes(ctx(), input.B, zd, xd, yd, xs, ys, xf, yf, nf, input.form, w_form, out_form);
     if (!wb) throw invalid_argument("ConvolutionalLayer: unsupported geometry");
     ensure(d_work, wb);
@@ -387,23 +426,29 @@ void FullyConnectedLayer::upload()
     if ((int)weights.size() != out_dim || (int)biases.size() != out_dim) throw invalid_argument("fc: weight/bias count mismatch");
     vector<const Plaintext *> w, b;
     for (int i = 0; i < out_dim; i++) { if ((int)weights[i].size() != in_dim) throw invalid_argument("fc: row length mismatch"); for (int j = 0; j < in_dim; j++) w.push_back(&weights[i][j]); b.push_back(&biases[i]); }
-    d_w = uploadPlain(w, 0); d_b[0] = uploadPlain(b, 1); d_b[1] = uploadPlain(b, 2);
+    streamed = tooLargeForHbm(w.size());
+    if (streamed) d_plain = uploadPlain(w, 3); else d_w = uploadPlain(w, 0);
+    d_b[0] = uploadPlain(b, 1); d_b[1] = uploadPlain(b, 2);
     weights_already_ntt = true;
 }
 void FullyConnectedLayer::deviceParameters(vector<shared_ptr<DeviceBuffer>> &out, bool allocate_only)
 {
     if (allocate_only && !weights_already_ntt) {
         const size_t rowb = (size_t)K() * N() * 8;
-        d_w = make_shared<DeviceBuffer>((size_t)in_dim * out_dim * rowb); d_b[0] = make_shared<DeviceBuffer>(out_dim * rowb); d_b[1] = make_shared<DeviceBuffer>(out_dim * rowb);
+        streamed = tooLargeForHbm((size_t)in_dim * out_dim);
+        if (!streamed) d_w = make_shared<DeviceBuffer>((size_t)in_dim * out_dim * rowb);
+        d_b[0] = make_shared<DeviceBuffer>(out_dim * rowb); d_b[1] = make_shared<DeviceBuffer>(out_dim * rowb);
         weights_already_ntt = true;
     }
     packWeights(true);
-    out.push_back(d_w); out.push_back(d_b[0]); out.push_back(d_b[1]);
+    if (streamed && !d_plain) d_plain = make_shared<DeviceBuffer>((size_t)in_dim * out_dim * N() * 8);
+    out.push_back(streamed ? d_plain : d_w); out.push_back(d_b[0]); out.push_back(d_b[1]);
 }
-bool FullyConnectedLayer::limbWeights(int B) { upload(); if (w_form == CRC_NTTL) return true; if (w_form == CRC_NTTP) packWeights(true); return toLimb(d_w, w_form, out_dim, in_dim, 1, 1, (long)B * 2); }
+bool FullyConnectedLayer::limbWeights(int B) { upload(); if (streamed) return false; if (w_form == CRC_NTTL) return true; if (w_form == CRC_NTTP) packWeights(true); return toLimb(d_w, w_form, out_dim, in_dim, 1, 1, (long)B * 2); }
 void FullyConnectedLayer::packWeights(bool unpack)
 {
     upload();
+    if (streamed) return;
     if (w_form == CRC_NTTL) { if (unpack) throw logic_error("FullyConnectedLayer " + name + ": weights are in limb form (fuse() / broadcastParameters() must precede the first forward())"); return; }
     if ((w_form == CRC_NTTP) == !unpack) return;
     chk(crc_pack28(ctx(), (uint64_t *)d_w->ptr, (size_t)in_dim * out_dim * K(), unpack ? 1 : 0, nullptr), "crc_pack28");
@@ -414,6 +459,7 @@ ciphertext3D FullyConnectedLayer::forward(ciphertext3D input)
     if (!input.buf || input.zd * input.xd * input.yd != in_dim) throw invalid_argument("FullyConnectedLayer: input size does not match in_dim");   // reshapeInput, :38-56
     upload();
     ciphertext3D out(input.B, 1, out_dim, 1, out_form);
+    if (streamed) { forwardStreamed(input, out, in_dim, 1, 1, 1, 1, 1, 1, out_dim, out_form, d_plain, d_b, d_wtile, d_ytile, d_work); return out; }
     ensure(d_work, crc_conv2d_forms_work_bytes(ctx(), input.B, in_dim, 1, 1, 1, 1, 1, 1, out_dim, input.form, w_form, out_form));
     chk(crc_dense_forms(ctx(), input.data(), (const uint64_t *)d_w->ptr, w_form, (const uint64_t *)d_b[out_form != CRC_COEFF]->ptr, input.B, in_dim, out_dim, input.form, out_form,
                         out.data(), d_work->ptr, nullptr), "crc_dense_forms");
@@ -624,6 +670,8 @@ int Network::fuse()
         auto conv = dynamic_pointer_cast<ConvolutionalLayer>(layers[i]);
         auto pool = dynamic_pointer_cast<PoolingLayer>(layers[i + 1]);
         if (!conv || !pool || (int)i + 1 == layer_before_reenc) continue;
+        conv->upload();
+        if (conv->streamed) continue;
         if (pool->zd != conv->nf || pool->xd != conv->xo || pool->yd != conv->yo) continue;
         const int xf2 = (pool->xf - 1) * conv->xs + conv->xf, yf2 = (pool->yf - 1) * conv->ys + conv->yf;
         const int xs2 = conv->xs * pool->xs, ys2 = conv->ys * pool->ys;
@@ -659,8 +707,8 @@ int Network::fuse()
         if (!conv && !fc) continue;
         const int ch = bn->num_channels;
         int F, per_ch, T;
-        if (conv) { if (conv->zd != ch) continue; F = conv->nf; per_ch = conv->xf * conv->yf; T = conv->zd * per_ch; conv->upload(); }
-        else { if (fc->in_dim % ch) continue; F = fc->out_dim; per_ch = fc->in_dim / ch; T = fc->in_dim; fc->upload(); }
+        if (conv) { if (conv->zd != ch) continue; F = conv->nf; per_ch = conv->xf * conv->yf; T = conv->zd * per_ch; conv->upload(); if (conv->streamed) continue; }
+        else { if (fc->in_dim % ch) continue; F = fc->out_dim; per_ch = fc->in_dim / ch; T = fc->in_dim; fc->upload(); if (fc->streamed) continue; }
         bn->upload();
         shared_ptr<DeviceBuffer> &dw = conv ? conv->d_w : fc->d_w;
         shared_ptr<DeviceBuffer> *db = conv ? conv->d_b : fc->d_b;

@@ -49,7 +49,7 @@ ENG_KEY_SEED, ENG_EVK_SEED, ENG_ENC_SEED = 2024, 2025, 7000
 NETS["tiny1024_eng"] = ("PlainModelTiny", 1024, [0x7fffffff380001, 0x3fffffff000001], 1 << 32, 1)     # n = 1024: smallest ring in which the fractional encoding survives the four multiplicative levels
 
 
-def topology(model, slices, th=8):
+def topology(model, slices, th=int(os.environ.get("CRC_REF_THREADS", "8"))):
     """reference topology lines (cnnBuilder.cpp:115-169) for ref_harness; thread counts only affect speed"""
     from crcnn_amd.netrun import TOPOLOGIES
     lines = []

@@ -150,3 +150,17 @@ def test_cpp_crcnn_files_interchange_with_the_reference():
         dec = np.fromfile(os.path.join(d, "ref_files_dec_ours.f64")); want = np.fromfile(os.path.join(src, "ref_files_dec_own.f64"))
         assert np.allclose(dec, want, atol=1e-4)          # same image, same layers, different encryption randomness
     shutil.rmtree(d, ignore_errors=True)
+
+
+@pytest.mark.parametrize("name", ["tiny256", "wopad256"])
+def test_cpp_network_streamed_weights_equal_reference(name):
+    """the C++ classes' fall-back for layers whose NTT-form weights exceed HBM (every prime of coeff_modulus_128(16384) with PlainModelWoPad: 424 GB): coefficient-form
+    plaintexts resident, lift + NTT of a filter tile inside every forward.  Forced on a small ring through CRC_STREAM_SHARE; resident and fused runs stay bit-identical"""
+    os.environ["CRC_STREAM_SHARE"] = "1e-9"
+    try:
+        for fuse in (False, True):
+            g, O, d = run_driver(name, resident=True, batch=2, fuse=fuse)
+            out = np.fromfile(os.path.join(d, "out.u64"), dtype=np.uint64).reshape(2, -1)
+            assert sha(out[0]) == g["out_sha256"] and sha(out[1]) == g["out_sha256"]
+    finally:
+        del os.environ["CRC_STREAM_SHARE"]
