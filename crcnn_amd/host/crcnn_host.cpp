@@ -307,7 +307,12 @@ static void forwardStreamed(const ciphertext3D &input, ciphertext3D &out, int zd
 {
     const size_t n = N(), k = K(), rowb = k * n * 8, ctb = ctBytes();
     const size_t T = (size_t)zd * xf * yf, P = (size_t)((xd - xf) / xs + 1) * ((yd - yf) / ys + 1);
-    const int ft_max = (int)max<size_t>(1, min<size_t>(nf, ((size_t)2 << 30) / (T * rowb)));
+    // tile: as many filters (a multiple of 8, the MAC kernel's filter granule) as make 2-16 GiB of NTT-form weights, by what HBM has left
+    size_t free_b = 0, total_b = 0;
+    chk(crc_mem_info(ctx(), &free_b, &total_b), "crc_mem_info");
+    const size_t tile_bytes = d_wtile ? d_wtile->bytes : max<size_t>((size_t)2 << 30, min<size_t>((size_t)16 << 30, free_b / 8));
+    size_t ftv = tile_bytes / (T * rowb); if (ftv >= 8) ftv = ftv / 8 * 8;
+    const int ft_max = (int)max<size_t>(1, min<size_t>(nf, ftv));
     if (!d_wtile || d_wtile->bytes < ft_max * T * rowb) d_wtile = make_shared<DeviceBuffer>(ft_max * T * rowb);
     if (!d_ytile || d_ytile->bytes < (size_t)input.B * ft_max * P * ctb) d_ytile = make_shared<DeviceBuffer>((size_t)input.B * ft_max * P * ctb);
     size_t wb = crc_conv2d_forms_work_bytes(ctx(), input.B, zd, xd, yd, xs, ys, xf, yf, ft_max, input.form, CRC_NTT, out_form);

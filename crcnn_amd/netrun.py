@@ -375,12 +375,16 @@ class Network:
         return need_act, work
 
     def _stream_geometry(self, kind, a):
-        """a streamed layer as a convolution + the filter tile: as many filters as make ~2 GiB of NTT-form weights"""
+        """a streamed layer as a convolution + the filter tile: as many filters (a multiple of 8, the MAC kernel's filter granule) as make 2-16 GiB of NTT-form
+        weights, by what HBM has left (a tile of 2 filters runs the MAC kernel at a quarter of its rate and costs 250 launches per chunk)"""
         g = dict(zd=a["zd"], xd=a["xd"], yd=a["yd"], xs=a["xs"], ys=a["ys"], xf=a["xf"], yf=a["yf"], nf=a["nf"]) if kind == "conv" else \
             dict(zd=a["in_dim"], xd=1, yd=1, xs=1, ys=1, xf=1, yf=1, nf=a["out_dim"])
         T = g["zd"] * g["xf"] * g["yf"]
         g["T"] = T
-        g["ft"] = max(1, min(g["nf"], (2 << 30) // (T * self.E.k * self.E.n * 8)))
+        if not hasattr(self, "_stream_tile_bytes"):
+            self._stream_tile_bytes = max(2 << 30, min(16 << 30, self.E.mem_info()[0] // 8))
+        ft = self._stream_tile_bytes // (T * self.E.k * self.E.n * 8)
+        g["ft"] = max(1, min(g["nf"], ft // 8 * 8 if ft >= 8 else ft))
         g["P"] = ((g["xd"] - g["xf"]) // g["xs"] + 1) * ((g["yd"] - g["yf"]) // g["ys"] + 1)
         return g
 
