@@ -5,6 +5,6 @@ in crcnn_amd/host/ that mirror CrCNN's Layer / Network / CnnBuilder interface.  
 ctypes plumbing used by the tests and bench.py.  Importing it loads the HIP library and fails if it is missing.
 """
 from . import binding
-from .binding import COEFF, NTT, NTTP, NTTL, CrcError, Engine, default_coeff_modulus_128, h5_list, h5_read, load  # noqa: F401
+from .binding import COEFF, NTT, NTTP, NTTL, NTTL1, NTTLC, CrcError, Engine, default_coeff_modulus_128, h5_list, h5_read, load  # noqa: F401
 
 load()

@@ -20,7 +20,7 @@ VP = ctypes.c_void_p
 CI = ctypes.c_int
 SZ = ctypes.c_size_t
 
-COEFF, NTT, NTTP, NTTL = 0, 1, 2, 3
+COEFF, NTT, NTTP, NTTL, NTTL1, NTTLC = 0, 1, 2, 3, 4, 5
 
 
 class CrcError(RuntimeError):
@@ -111,6 +111,9 @@ def load():
     L.crc_limb_weights_bytes.restype = SZ; L.crc_limb_weights_bytes.argtypes = [VP, CI, CI, CI, CI]
     L.crc_limb_pack_weights.argtypes = [VP, VP, CI, CI, CI, CI, VP, VP]
     L.crc_limb_pack_tensor.argtypes = [VP, VP, CI, CI, CI, CI, CI, VP, VP]
+    L.crc_limb_conv1_supported.argtypes = [VP] + [CI] * 8
+    L.crc_limb_conv1_weights_bytes.restype = SZ; L.crc_limb_conv1_weights_bytes.argtypes = [VP]
+    L.crc_limb_conv1_pack_weights.argtypes = [VP, VP, CI, CI, CI, VP, VP]
     L.crc_conv2d_forms_work_bytes.restype = SZ; L.crc_conv2d_forms_work_bytes.argtypes = [VP] + [CI] * 12
     L.crc_square.argtypes = [VP, VP, SZ, VP, VP, VP]
     L.crc_relinearize.argtypes = [VP, VP, SZ, VP, CI, VP, VP, VP]
@@ -395,6 +398,16 @@ class Engine:
 
     def limb_pack_tensor(self, d_x, in_form, B, zd, xd, yd, d_xl):
         _chk(self.L.crc_limb_pack_tensor(self.c, self.p(d_x), in_form, B, zd, xd, yd, self.p(d_xl), self.stream), "crc_limb_pack_tensor")
+
+    # ---- one-channel convolutions on the matrix cores (weight form CRC_NTTL1)
+    def limb_conv1_supported(self, zd, xd, yd, xs, ys, xf, yf, nf):
+        return bool(self.L.crc_limb_conv1_supported(self.c, zd, xd, yd, xs, ys, xf, yf, nf))
+
+    def limb_conv1_weights_bytes(self):
+        return self.L.crc_limb_conv1_weights_bytes(self.c)
+
+    def limb_conv1_pack_weights(self, d_w_ntt, nf, xf, yf, d_wl):
+        _chk(self.L.crc_limb_conv1_pack_weights(self.c, self.p(d_w_ntt), nf, xf, yf, self.p(d_wl), self.stream), "crc_limb_conv1_pack_weights")
 
     def conv2d_forms_work_bytes(self, B, zd, xd, yd, xs, ys, xf, yf, nf, in_form, w_form, out_form):
         return self.L.crc_conv2d_forms_work_bytes(self.c, B, zd, xd, yd, xs, ys, xf, yf, nf, in_form, w_form, out_form)

@@ -1,4 +1,5 @@
 // abi.hip -- extern "C" entry points of include/crcnn_hip.h that drive the kernels (layers and Evaluator ops).
+#include <cstdlib>
 #include "kernels.h"
 #include "chacha.h"
 
@@ -107,8 +108,65 @@ extern "C" int crc_limb_pack_tensor(crc_ctx *c, const uint64_t *d_x, int in_form
     if (!crc_limb_supported(c, zd, 1, 1)) return CRC_ERR_UNSUPPORTED;
     return k_limb_pack_tensor(c, d_x, (signed char *)d_xl, B, zd, xd * yd, in_form == CRC_NTTP, S(stream));
 }
+// one-channel convolutions (CRC_NTTL1, kernels_mfma1.hip)
+extern "C" int crc_limb_conv1_supported(const crc_ctx *c, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf)
+{
+    if (!c || nf < 1 || !conv_shape_ok(xd, yd, xs, ys, xf, yf)) return 0;
+    return k_limb_conv1_shape(c, zd, xd, yd, xs, ys, xf, yf, nf) ? 1 : 0;
+}
+extern "C" size_t crc_limb_conv1_weights_bytes(const crc_ctx *c) { return c ? k_limb_conv1_weights_bytes(c) : 0; }
+extern "C" int crc_limb_conv1_pack_weights(crc_ctx *c, const uint64_t *d_w_ntt, int nf, int xf, int yf, void *d_wl, void *stream)
+{
+    CHECK_CTX(c); if (!d_w_ntt || !d_wl || nf < 1 || nf > 32 || xf < 1 || yf < 1 || xf > 8 || yf > 8) return CRC_ERR_INVALID_ARGUMENT;
+    if (!k_limb_supported(c, 64)) return CRC_ERR_UNSUPPORTED;
+    return k_limb_conv1_pack_weights(c, d_w_ntt, (signed char *)d_wl, nf, xf, yf, S(stream));
+}
+// images per internal pass: the y-expanded limb images and the slot-major result of a pass stay below ~16 GiB of work space (a dense consumer's flattened
+// limb tensor is converted from the whole batch's result at once: no sub-batching there)
+static int conv1_sub_batch(const crc_ctx *c, int B, int xd, int yo, int nf, int P, int out_form)
+{
+    if (out_form == CRC_NTTL || B <= 1) return B;
+    const size_t per = k_limb_conv1_image_bytes(c, 1, xd) + (out_form == CRC_NTTLC ? 0 : 8 * k_limb_result_words(c, 1, nf, P));
+    const char *e = getenv("CRC_CONV1_PASS_BYTES");                  // (the tests shrink it to cover the multi-pass path at small sizes)
+    const long long ev = e ? atoll(e) : 0;
+    const size_t cap = ev > 0 ? (size_t)ev : (size_t)16 << 30;
+    const size_t fit = cap / (per ? per : 1);
+    return (int)(fit < 1 ? 1 : fit > (size_t)B ? (size_t)B : fit);
+}
+static int conv2d_limb1(crc_ctx *c, const uint64_t *d_x, const void *d_wl, const uint64_t *d_bias, int B, int xd, int yd, int xs, int ys, int xf, int yf, int nf,
+                        int in_form, int out_form, uint64_t *d_y, void *d_work, hipStream_t st)
+{
+    const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys + 1, P = xo * yo, in_cts = xd * yd;
+    const int Bs = conv1_sub_batch(c, B, xd, yo, nf, P, out_form);
+    const size_t ctw = crc_ct_words(c, 2);
+    char *w = (char *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
+    signed char *Xr = (signed char *)w; w += align256(k_limb_conv1_image_bytes(c, Bs, xd));
+    u64 *Ys = nullptr;
+    if (out_form != CRC_NTTLC) { Ys = (u64 *)w; w += align256(8 * k_limb_result_words(c, Bs, nf, P)); }
+    u64 *buf = (u64 *)w;                                           // NTT copy of a coefficient-form sub-batch
+    for (int b0 = 0; b0 < B; b0 += Bs) {
+        const int Bn = B - b0 < Bs ? B - b0 : Bs;
+        const u64 *xn = d_x + (size_t)b0 * in_cts * ctw; bool packed = in_form == CRC_NTTP;
+        if (in_form == CRC_COEFF) { RUN(k_ntt_ct(c, false, xn, buf, (size_t)Bn * in_cts, 2, false, st, nullptr, 0, 0, 0, 0)); xn = buf; packed = false; }
+        RUN(k_limb_conv1(c, xn, packed, Xr, (const signed char *)d_wl, Ys, out_form == CRC_NTTLC ? (signed char *)d_y : nullptr, B, b0, out_form != CRC_COEFF ? d_bias : nullptr,
+                         Bn, xd, yd, xs, ys, xf, yf, nf, st));
+        if (out_form == CRC_NTTLC) continue;
+        if (out_form == CRC_NTTL) return k_limb_result_to_limb(c, Ys, (signed char *)d_y, B, nf * P, st);     // (Bs == B)
+        RUN(k_limb_result_to_rows(c, Ys, d_y + (size_t)b0 * nf * P * ctw, (size_t)Bn * nf * P * 2, out_form == CRC_NTTP, st));
+    }
+    if (out_form == CRC_COEFF) RUN(k_ntt_ct(c, true, d_y, d_y, (size_t)B * nf * P, 2, false, st, d_bias, 1, (size_t)P, nf));
+    return CRC_OK;
+}
 extern "C" size_t crc_conv2d_forms_work_bytes(const crc_ctx *c, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int in_form, int w_form, int out_form)
 {
+    if (w_form == CRC_NTTL1) {
+        if (!c || !conv_shape_ok(xd, yd, xs, ys, xf, yf)) return 0;
+        const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys + 1, Bs = conv1_sub_batch(c, B, xd, yo, nf, xo * yo, out_form);
+        size_t b = align256(k_limb_conv1_image_bytes(c, Bs, xd));
+        if (out_form != CRC_NTTLC) b += align256(8 * k_limb_result_words(c, Bs, nf, xo * yo));
+        if (in_form == CRC_COEFF) b += align256((size_t)Bs * xd * yd * crc_ct_words(c, 2) * 8);
+        return b + 256;
+    }
     if (w_form != CRC_NTTL) return crc_conv2d_work_bytes(c, B, zd, xd, yd, xs, ys, xf, yf, nf, in_form);
     if (!c || !conv_shape_ok(xd, yd, xs, ys, xf, yf)) return 0;
     (void)out_form;
@@ -145,6 +203,13 @@ extern "C" int crc_conv2d_forms(crc_ctx *c, const uint64_t *d_x, const uint64_t 
                                 int xs, int ys, int xf, int yf, int nf, int in_form, int out_form, uint64_t *d_y, void *d_work, void *stream)
 {
     CHECK_CTX(c);
+    if (w_form == CRC_NTTL1) {
+        if (!d_x || !d_w || !d_y || !d_work || B < 0 || nf < 1 || !nform_ok(in_form) || !(lform_ok(out_form) || out_form == CRC_NTTLC) || !conv_shape_ok(xd, yd, xs, ys, xf, yf))
+            return CRC_ERR_INVALID_ARGUMENT;
+        if (!k_limb_conv1_shape(c, zd, xd, yd, xs, ys, xf, yf, nf)) return CRC_ERR_UNSUPPORTED;
+        if (B == 0) return CRC_OK;
+        return conv2d_limb1(c, d_x, d_w, d_bias, B, xd, yd, xs, ys, xf, yf, nf, in_form, out_form, d_y, d_work, S(stream));
+    }
     if (w_form == CRC_NTTL) {
         if (!d_x || !d_w || !d_y || !d_work || B < 0 || zd < 1 || nf < 1 || !lform_ok(in_form) || !lform_ok(out_form) || !conv_shape_ok(xd, yd, xs, ys, xf, yf)) return CRC_ERR_INVALID_ARGUMENT;
         if (B == 0) return CRC_OK;

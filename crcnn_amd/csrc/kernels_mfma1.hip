@@ -1,0 +1,287 @@
+// kernels_mfma1.hip -- one-channel convolutions (CrCNN's conv1, alone or fused with its pooling layer: 6 x 6 / 7 x 7 windows over the 28 x 28 encrypted image,
+// 32 / 20 filters) on the matrix cores.
+//
+// With one input channel the reduction is xf*yf = 36..49 terms.  As a generic limb GEMM (kernels_mfma.hip) that is two reduction steps per output tile and the
+// per-output work -- recombining 13 diagonals and reducing mod q -- dominates; on the vector ALU (mac3_kernel) the layer runs at 3.5 T modmul/s and, once conv2
+// and fc3 moved to the matrix cores, is a third of PlainModelTiny.  This kernel is built around the two things such a layer offers:
+//   reuse     per slot the window taps are K = 8 rows x 8 columns = 64 (zero weights beyond the window): ONE v_mfma_i32_16x16x64_i8 per limb pair covers the
+//             whole reduction.  The 7 weight fragments of a wave's 16 filters live in registers for the whole workgroup, and a workgroup walks ALL images of
+//             the chunk for its slot (image b+1 arrives by LDS-DMA while image b is multiplied);
+//   a cheap   the accumulators start at per-diagonal biases B_d (so every diagonal stays in [0, 2^24) and their sum is a multiple of q: no signs, no
+//   epilogue  correction term), pairs of diagonals pack into 32-bit words without carries, the 128-bit value is two word vectors added once, and a Montgomery
+//             step (weights carry the factor 2^64) replaces the 128-bit Barrett / folding reduction: ~90 VALU operations per output instead of ~340.
+// 8 or 12 waves per workgroup (2-3 per SIMD: one wave's epilogue overlaps another's MFMAs); a wave owns 16 filters and every (waves/2)-th 16-row tile.
+//   per image   the limb image [plane][poly][row][32 columns] (12.5 KiB for 28 x 28) in LDS, double-buffered; a lane's A fragment is two 8-byte LDS reads per
+//               plane (window rows kx, kx+1): the three words around byte offset oy * stride, byte-aligned in registers;
+//   output      either the limb tensor of a following convolution, staged in LDS as [plane][pixel][poly][32 channels] and written out as one contiguous block
+//               (no limb_pack_tensor pass in front of conv2), or slot-major u64 for the generic conversions.
+// Exact integer arithmetic throughout: the same element of Z_q, hence the same bits, as mac3_kernel and the reference (convolutionalLayer.cpp:56-93).
+#include "kernels.h"
+#include <cstdlib>
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef signed char i8;
+#define NPL 7
+#define MAXK 8                                   // coefficient moduli (kernel argument tables)
+
+struct Conv1Args {
+    const i8 *xr; const i8 *wl; u64 *ys; i8 *xl_out; const ModParams *mods; const u64 *bias;
+    int n, k, B, Bout, b0, xd, yo, xs, ystr, P, F, mtiles;   // B images in this launch; the limb result is image b0 + b of Bout
+    unsigned img_stride, plane_bytes, poly_bytes;      // per (slot, image): 7 planes x 2 polys x xd rows x 32 bytes (+ 8: the last window may read past its row), rounded up to 1 KiB
+    unsigned out_img_bytes;                            // 7 * P * 2 * 32 (limb output)
+    int acc0[MAXK][13];                                // initial value of the 13 diagonal accumulators, per modulus (conv1_tables)
+    u64 qinv[MAXK];                                    // q^-1 mod 2^64
+};
+
+// canonical residue -> 7 balanced base-256 digits of its centred representative
+__device__ __forceinline__ void limb_digits1(u64 r, u64 q, int (&d)[NPL])
+{
+    long long v = r > (q >> 1) ? (long long)r - (long long)q : (long long)r;
+#pragma unroll
+    for (int l = 0; l < NPL; l++) { d[l] = (int)(signed char)(v & 0xff); v = (v - d[l]) >> 8; }
+}
+
+// The 13 diagonals D'_d = B_d + D_d, all in [0, 2^24) with D'_odd < 0.94 2^24 (conv1_tables), hold U = sum_d D'_d 2^(8d) = V + K*, K* a multiple of q,
+// 0 <= U < 2^115.6.  Returns U 2^-64 mod q, canonical (the weights carry the factor 2^64: that is V's residue).
+__device__ __forceinline__ u64 diag_reduce_mont(const int (&D)[13], u64 q, u64 qinv)
+{
+    // pairs of diagonals: P_j = D'_2j + D'_2j+1 2^8 < 2^32, sitting at bit 16 j.  Even pairs are the words of one 128-bit number, odd pairs of another, 16 bits up
+    u32 P[7];
+#pragma unroll
+    for (int j = 0; j < 6; j++) P[j] = (u32)D[2 * j] + ((u32)D[2 * j + 1] << 8);
+    P[6] = (u32)D[12];
+    const u32 o0 = P[1] << 16, o1 = __builtin_amdgcn_alignbit(P[3], P[1], 16), o2 = __builtin_amdgcn_alignbit(P[5], P[3], 16), o3 = P[5] >> 16;
+    const u64 elo = ((u64)P[2] << 32) | P[0], ehi = ((u64)P[6] << 32) | P[4], olo = ((u64)o1 << 32) | o0, ohi = ((u64)o3 << 32) | o2;
+    const u64 ulo = elo + olo, uhi = ehi + ohi + (ulo < elo);
+    // Montgomery step, subtractive form: m = U_lo q^-1 mod 2^64 makes U - m q divisible by 2^64, and t = (U - m q) / 2^64 = U_hi - hi64(m q) exactly
+    // (the low words cancel: no borrow).  t in (U 2^-64 - q, U 2^-64] = (-q, 2^51.6]: one conditional add
+    const u64 m = ulo * qinv;
+    const long long t = (long long)(uhi - __umul64hi(m, q));
+    return (u64)(t + ((t >> 63) & (long long)q));
+}
+
+__global__ void __launch_bounds__(768) mfma_conv1_kernel(Conv1Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) i8 lds[];                  // [2 image buffers][output staging]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+    const int slot = blockIdx.x, i = slot / a.n, s = slot % a.n;
+    const ModParams m = a.mods[i];
+    const u64 qinv = a.qinv[i];
+    const int nt = wave & 1, col = nt * 16 + (lane & 15), g = lane >> 4;      // this wave's 16 filters; this lane's filter and K group (window rows 2g, 2g+1)
+    // the weight fragments of this lane's filter, resident for the whole workgroup
+    v4i wv[NPL];
+    {
+        const i8 *ws = a.wl + (size_t)slot * (NPL * 32 * 64) + col * 64 + g * 16;
+#pragma unroll
+        for (int l = 0; l < NPL; l++) wv[l] = *reinterpret_cast<const v4i *>(ws + l * (32 * 64));
+    }
+    int acc0[13];
+#pragma unroll
+    for (int d = 0; d < 13; d++) acc0[d] = a.acc0[i][d];
+    const u64 bv = (a.bias && col < a.F) ? a.bias[((size_t)col * a.k + i) * a.n + s] : 0;
+    i8 *stage = lds + 2 * (size_t)a.img_stride;
+    const i8 *ximg = a.xr + (size_t)slot * a.B * a.img_stride;
+    const int pieces = a.img_stride / 1024;
+    auto issue_img = [&](int b) {
+        i8 *dst = lds + (b & 1) * (size_t)a.img_stride;
+        const i8 *src = ximg + (size_t)b * a.img_stride + lane * 16;
+        for (int pc = wave; pc < pieces; pc += nwaves)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + pc * 1024), (__attribute__((address_space(3))) void *)(dst + pc * 1024), 16, 0, 0);
+    };
+    issue_img(0);
+    for (int b = 0; b < a.B; b++) {
+        __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));    // this wave's pieces of image b have landed (and its stores of image b-1's staging copy have left) ...
+        __syncthreads();                                          // ... everybody's; the other image buffer and the staging area are free
+        if (b + 1 < a.B) issue_img(b + 1);
+        const i8 *img = lds + (b & 1) * (size_t)a.img_stride;
+        for (int mt = wave >> 1; mt < a.mtiles; mt += nwaves >> 1) {
+            v4i acc[13];
+#pragma unroll
+            for (int d = 0; d < 13; d++) acc[d] = v4i{acc0[d], acc0[d], acc0[d], acc0[d]};
+            // this lane's A row: output pixel p, poly c (rows past 2P re-read the last one and are never stored)
+            const int mrow = min(mt * 16 + (lane & 15), 2 * a.P - 1), p = mrow >> 1, c = mrow & 1, ox = p / a.yo, oy = p - ox * a.yo;
+            // k = 16 g + j  <->  window row kx = 2 g + (j >> 3), window column ky = j & 7: per row the three words around the window's first column, cut to its
+            // 8 bytes with a byte alignment (rows clamped, and columns past the window may belong to the next row: their weights are zero)
+            const int r0 = min(ox * a.xs + 2 * g, a.xd - 1), r1 = min(ox * a.xs + 2 * g + 1, a.xd - 1);
+            const int off = oy * a.ystr, sh = off & 3;
+            const i8 *p0 = img + c * a.poly_bytes + (off & ~3) + r0 * 32, *p1 = img + c * a.poly_bytes + (off & ~3) + r1 * 32;
+#pragma unroll
+            for (int l = 0; l < NPL; l++) {
+                const u32 *q0 = reinterpret_cast<const u32 *>(p0 + l * a.plane_bytes), *q1 = reinterpret_cast<const u32 *>(p1 + l * a.plane_bytes);
+                const u32 a0 = q0[0], a1 = q0[1], a2 = q0[2], b0 = q1[0], b1 = q1[1], b2 = q1[2];
+                int2 lo, hi;
+                lo.x = (int)__builtin_amdgcn_alignbyte(a1, a0, sh); lo.y = (int)__builtin_amdgcn_alignbyte(a2, a1, sh);
+                hi.x = (int)__builtin_amdgcn_alignbyte(b1, b0, sh); hi.y = (int)__builtin_amdgcn_alignbyte(b2, b1, sh);
+                const v4i av = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+                for (int mm = 0; mm < NPL; mm++)
+                    acc[l + mm] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, wv[mm], acc[l + mm], 0, 0, 0);
+            }
+            // epilogue: C/D layout of a 16 x 16 tile: col = lane & 15, row = 4 (lane >> 4) + reg
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int mm = mt * 16 + 4 * g + reg;
+                int D[13];
+#pragma unroll
+                for (int d = 0; d < 13; d++) D[d] = acc[d][reg];
+                u64 v = diag_reduce_mont(D, m.q, qinv);
+                if ((reg & 1) == 0) v = addmod(v, bv, m.q);       // rows alternate poly 0 / poly 1 (16 | tile base, 4 | lane base): the bias joins poly 0
+                if (mm < 2 * a.P) {
+                    if (a.xl_out) {               // limb tensor of the next convolution: [plane][pixel][poly][32 channels], channels past F stay zero
+                        // balanced digits of the centred representative cv: the bytes of cv + 0x80...80, each with its top bit flipped
+                        const long long cv = (col < a.F) ? (v > (m.q >> 1) ? (long long)(v - m.q) : (long long)v) : 0;
+                        const u64 dg = ((u64)cv + 0x0080808080808080ULL) ^ 0x0080808080808080ULL;
+                        i8 *sp = stage + mm * 32 + col;
+#pragma unroll
+                        for (int l = 0; l < NPL; l++) sp[(size_t)l * (a.P * 2 * 32)] = (i8)(dg >> (8 * l));
+                    } else if (col < a.F)
+                        a.ys[(((size_t)slot * a.B + b) * a.F + col) * (2 * a.P) + mm] = v;
+                }
+            }
+        }
+        if (a.xl_out) {
+            __syncthreads();
+            i8 *dst = a.xl_out + ((size_t)slot * a.Bout + a.b0 + b) * a.out_img_bytes;
+            for (unsigned o = threadIdx.x * 16; o < a.out_img_bytes; o += blockDim.x * 16) *reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(stage + o);
+        }
+    }
+}
+
+// ---- operand preparation -----------------------------------------------------------------------------------------------------------------
+// NTT-form image x [B][xd*yd cts][2][k][n] (one channel; canonical or 28-bit packed) -> Xr [slot][B][plane][poly][row][32 columns] (yd <= 32, zero padded).  One thread
+// per (slot, image, poly, group of RG rows); lanes run over 64 consecutive slots (coalesced 512-B row segments); a row is 32 contiguous bytes per plane, written as
+// two adjacent 16-byte stores
+#define RG 4
+__global__ void __launch_bounds__(64) limb_pack_rows1_kernel(const u64 *x, i8 *xr, const ModParams *mods, int n, int k, int B, int xd, int yd, int packed,
+                                                             unsigned img_stride, unsigned plane_bytes, unsigned poly_bytes)
+{
+    const int sblocks = n / 64;
+    const int sb = blockIdx.x % (sblocks * k), i = sb / sblocks, s = (sb % sblocks) * 64 + threadIdx.x;
+    const int rgs = (xd + RG - 1) / RG;
+    size_t r = blockIdx.x / (sblocks * k);                       // (b*2 + c)*rgs + row group
+    const int rg = (int)(r % rgs); r /= rgs; const int c = (int)(r % 2); const int b = (int)(r / 2);
+    const u64 q = mods[i].q;
+    i8 *dimg = xr + (((size_t)i * n + s) * B + b) * img_stride + (size_t)c * poly_bytes;
+    for (int row = rg * RG; row < min(xd, rg * RG + RG); row++) {
+        u32 pl[NPL][8];
+#pragma unroll
+        for (int l = 0; l < NPL; l++)
+#pragma unroll
+            for (int wv = 0; wv < 8; wv++) pl[l][wv] = 0;
+        const u64 *src = x + ((((size_t)b * xd * yd + (size_t)row * yd) * 2 + c) * k + i) * (size_t)n + s;
+#pragma unroll
+        for (int colx = 0; colx < 32; colx++)
+            if (colx < yd) {
+                u64 v = src[(size_t)colx * 2 * k * n];
+                if (packed) v = (v & 0xffffffffULL) | ((v >> 32) << 28);
+                const long long cv = v > (q >> 1) ? (long long)(v - q) : (long long)v;
+                const u64 dg = ((u64)cv + 0x0080808080808080ULL) ^ 0x0080808080808080ULL;         // the 7 balanced digits, one per byte
+#pragma unroll
+                for (int l = 0; l < NPL; l++) pl[l][colx >> 2] |= (u32)((dg >> (8 * l)) & 0xff) << (8 * (colx & 3));
+            }
+        i8 *drow = dimg + (size_t)row * 32;
+#pragma unroll
+        for (int l = 0; l < NPL; l++) {
+            uint4 *o = reinterpret_cast<uint4 *>(drow + (size_t)l * plane_bytes);
+            o[0] = make_uint4(pl[l][0], pl[l][1], pl[l][2], pl[l][3]); o[1] = make_uint4(pl[l][4], pl[l][5], pl[l][6], pl[l][7]);
+        }
+    }
+}
+// NTT-form weights w [F][1][xf][yf][k][n] -> Wl1 [slot][7 planes][32 filters][64 taps], tap = kx*8 + ky (pre-zeroed), each weight times 2^64 mod q (the Montgomery factor the
+// kernel's reduction divides out)
+__global__ void __launch_bounds__(64) limb_pack_w1_kernel(const u64 *w, i8 *wl, const ModParams *mods, int n, int k, int F, int xf, int yf)
+{
+    const int sblocks = n / 64;
+    const int sb = blockIdx.x % (sblocks * k), i = sb / sblocks, s = (sb % sblocks) * 64 + threadIdx.x;
+    size_t r = blockIdx.x / (sblocks * k);                       // (f*xf + kx)*yf + ky
+    const int ky = (int)(r % yf); r /= yf; const int kx = (int)(r % xf); const int f = (int)(r / xf);
+    const ModParams m = mods[i];
+    const u64 R = barrett128(0, 1, m);                           // 2^64 mod q
+    int d[NPL]; limb_digits1(mulmod(w[((((size_t)f * xf + kx) * yf + ky) * k + i) * (size_t)n + s], R, m), m.q, d);
+    i8 *dst = wl + ((size_t)i * n + s) * (NPL * 32 * 64) + f * 64 + kx * 8 + ky;
+#pragma unroll
+    for (int l = 0; l < NPL; l++) dst[(size_t)l * (32 * 64)] = (i8)d[l];
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------------------------------------------
+static inline unsigned conv1_img_stride(int xd) { const unsigned b = NPL * 2 * (unsigned)xd * 32 + 8; return (b + 1023) / 1024 * 1024; }
+bool k_limb_conv1_shape(const crc_ctx *c, int zd, int xd, int yd, int xs, int ys_, int xf, int yf, int nf)
+{
+    if (zd != 1 || xf > 8 || yf > 8 || nf > 32 || yd > 32 || c->n < 64 || c->k > MAXK) return false;
+    // the epilogue's bounds (conv1_tables): a Montgomery quotient in (-q, 2^51.6] needs q > 2^52; 7 balanced digits with |top digit| <= 64 need q < 2^55
+    for (int i = 0; i < c->k; i++) if (c->tabs[i].m.bits > 55 || c->tabs[i].m.bits < 53) return false;
+    const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys_ + 1;
+    // two image buffers + the staging area of a limb result must fit the 160 KiB of LDS
+    return 2 * (size_t)conv1_img_stride(xd) + (size_t)NPL * xo * yo * 2 * 32 <= 160 * 1024;
+}
+size_t k_limb_conv1_weights_bytes(const crc_ctx *c) { return (size_t)c->n * c->k * NPL * 32 * 64; }
+size_t k_limb_conv1_image_bytes(const crc_ctx *c, int B, int xd) { return (size_t)c->n * c->k * B * conv1_img_stride(xd); }
+
+// Initial accumulator values.  Diagonal d collects the products a_l b_m with l + m = d of K = 64 terms; digits are in [-128, 127], the top ones (l, m = 6) in
+// [-64, 64] because |centred residue| < 2^54:  |D_d| <= 64 * 7 * 2^14 < 0.877 2^23 (d <= 10), |D_11| <= 2^20, |D_12| <= 2^18.  Base values B0 = 2^23 (d <= 10),
+// 2^21, 2^19 keep every D'_d = B_d + D_d inside (0, 0.94 2^24) -- unsigned, and a pair D'_2j + D'_2j+1 2^8 never carries out of 32 bits.  Their weighted sum
+// K0 = sum B0_d 2^(8d) ~ 2^115.02 exceeds |V| <= 64 (q/2)^2 <= 2^114; it is moved to the nearest multiple K* of q by adding the balanced digits of K* - K0
+// (|.| <= q/2 < 2^54: seven digits of at most 128) to B0_0..6.  Then U = V + K* == V (mod q) and 0 < U < 2^115.6.
+static void conv1_tables(const crc_ctx *c, Conv1Args &a)
+{
+    typedef unsigned __int128 u128;
+    for (int i = 0; i < c->k; i++) {
+        const u64 q = c->tabs[i].m.q;
+        long long B0[13];
+        u128 K0 = 0;
+        for (int d = 0; d < 13; d++) { B0[d] = d <= 10 ? 1 << 23 : d == 11 ? 1 << 21 : 1 << 19; K0 += (u128)B0[d] << (8 * d); }
+        const u128 rem = K0 % q;
+        long long delta = rem > q / 2 ? (long long)(q - (u64)rem) : -(long long)(u64)rem;        // K* - K0
+        for (int d = 0; d < 7; d++) { const long long dg = (long long)(signed char)(delta & 0xff); B0[d] += dg; delta = (delta - dg) >> 8; }
+        for (int d = 0; d < 13; d++) a.acc0[i][d] = (int)B0[d];
+        u64 inv = q;                                             // Newton: q odd, q q = 1 (mod 8); each step doubles the correct bits
+        for (int it = 0; it < 6; it++) inv *= 2 - q * inv;
+        a.qinv[i] = inv;
+    }
+}
+
+int k_limb_conv1_pack_weights(crc_ctx *c, const u64 *w, i8 *wl, int nf, int xf, int yf, hipStream_t st)
+{
+    HIPCHK(hipMemsetAsync(wl, 0, k_limb_conv1_weights_bytes(c), st));
+    const size_t blocks = (size_t)(c->n / 64) * c->k * nf * xf * yf;
+    hipLaunchKernelGGL(limb_pack_w1_kernel, dim3((unsigned)blocks), dim3(64), 0, st, w, wl, c->d_mods, c->n, c->k, nf, xf, yf);
+    HIPCHK(hipGetLastError());
+    return CRC_OK;
+}
+// x: B NTT-form one-channel images; xr: k_limb_conv1_image_bytes of scratch; result either images b0 .. b0 + B of a limb tensor of Bout images (xl_out,
+// [slot][Bout][7][P][2][32]) or slot-major u64 (ys, [slot][B][F][P][2])
+int k_limb_conv1(crc_ctx *c, const u64 *x, bool packed, i8 *xr, const i8 *wl, u64 *ys, i8 *xl_out, int Bout, int b0, const u64 *bias_ntt, int B, int xd, int yd, int xs, int ys_,
+                 int xf, int yf, int nf, hipStream_t st)
+{
+    if (B == 0) return CRC_OK;
+    if (!k_limb_conv1_shape(c, 1, xd, yd, xs, ys_, xf, yf, nf)) return CRC_ERR_UNSUPPORTED;
+    const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys_ + 1;
+    Conv1Args a{};
+    a.xr = xr; a.wl = wl; a.ys = ys; a.xl_out = xl_out; a.mods = c->d_mods; a.bias = bias_ntt;
+    a.n = c->n; a.k = c->k; a.B = B; a.Bout = Bout; a.b0 = b0; a.xd = xd; a.yo = yo; a.xs = xs; a.ystr = ys_; a.P = xo * yo; a.F = nf; a.mtiles = (2 * a.P + 15) / 16;
+    a.poly_bytes = (unsigned)xd * 32; a.plane_bytes = 2 * a.poly_bytes; a.img_stride = conv1_img_stride(xd);
+    a.out_img_bytes = (unsigned)(NPL * a.P * 2 * 32);
+    conv1_tables(c, a);
+    {
+        const size_t blocks = (size_t)(c->n / 64) * c->k * B * 2 * ((xd + RG - 1) / RG);
+        if (blocks > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
+        hipLaunchKernelGGL(limb_pack_rows1_kernel, dim3((unsigned)blocks), dim3(64), 0, st, x, xr, c->d_mods, c->n, c->k, B, xd, yd, packed ? 1 : 0, a.img_stride, a.plane_bytes,
+                           a.poly_bytes);
+        HIPCHK(hipGetLastError());
+    }
+    // waves per workgroup (8 or 12; wave w runs on SIMD w % 4 and takes row tiles w/2, w/2 + waves/2, ...): the count that loads the busiest SIMD least, 12 on a tie
+    // (a third wave per SIMD hides more of the epilogue behind the other waves' MFMAs)
+    auto busiest = [&](int nw) {
+        int load[4] = {0, 0, 0, 0}, worst = 0;
+        for (int w = 0; w < nw; w++) load[w & 3] += (a.mtiles - (w >> 1) + nw / 2 - 1) / (nw / 2);
+        for (int sd = 0; sd < 4; sd++) worst = load[sd] > worst ? load[sd] : worst;
+        return worst;
+    };
+    static const int forced = [] { const char *e = getenv("CRC_CONV1_WAVES"); const int v = e ? atoi(e) : 0; return v == 8 || v == 12 ? v : 0; }();     // tuning (tools/)
+    const int nwaves = forced ? forced : busiest(12) <= busiest(8) ? 12 : 8;
+    const size_t lds = 2 * (size_t)a.img_stride + (xl_out ? a.out_img_bytes : 0);
+    { const int rc = crc_ctx_ensure_lds(c, (const void *)mfma_conv1_kernel, lds); if (rc) return rc; }
+    hipLaunchKernelGGL(mfma_conv1_kernel, dim3((unsigned)(c->n * c->k)), dim3(64 * nwaves), lds, st, a);
+    HIPCHK(hipGetLastError());
+    return CRC_OK;
+}

@@ -104,7 +104,9 @@ static shared_ptr<DeviceBuffer> uploadPlain(const vector<const Plaintext *> &pl,
 // ---- tensors ----------------------------------------------------------------------------------------------------------
 ciphertext3D::ciphertext3D(int B, int zd, int xd, int yd, int form) : B(B), zd(zd), xd(xd), yd(yd), form(form)
 {
-    buf = make_shared<DeviceBuffer>(count() * ctBytes());
+    size_t bytes = count() * ctBytes();
+    if (form == CRC_NTTLC) { const size_t lb = crc_limb_tensor_bytes(ctx(), B, zd, xd, yd); if (lb > bytes) bytes = lb; }      // channels padded to 32
+    buf = make_shared<DeviceBuffer>(bytes);
 }
 ciphertext3D ciphertext3D::fromHost(const uint64_t *h, int B, int zd, int xd, int yd)
 {
@@ -380,12 +382,26 @@ void ConvolutionalLayer::deviceParameters(vector<shared_ptr<DeviceBuffer>> &out,
     if (streamed && !d_plain) d_plain = make_shared<DeviceBuffer>((size_t)nf * zd * xf * yf * N() * 8);
     out.push_back(streamed ? d_plain : d_w); out.push_back(d_b[0]); out.push_back(d_b[1]);
 }
-bool ConvolutionalLayer::limbWeights(int B) { upload(); if (streamed) return false; if (w_form == CRC_NTTL) return true; if (w_form == CRC_NTTP) packWeights(true); return toLimb(d_w, w_form, nf, zd, xf, yf, (long)B * 2 * xo * yo); }
+bool ConvolutionalLayer::limbWeights(int B)
+{
+    upload();
+    if (streamed) return false;
+    if (w_form == CRC_NTTL || w_form == CRC_NTTL1) return true;
+    if (w_form == CRC_NTTP) packWeights(true);
+    if (crc_limb_conv1_supported(ctx(), zd, xd, yd, xs, ys, xf, yf, nf)) {          // one-channel convolutions have their own matrix-core kernel (kernels_mfma1.hip)
+        auto wl = make_shared<DeviceBuffer>(crc_limb_conv1_weights_bytes(ctx()));
+        chk(crc_limb_conv1_pack_weights(ctx(), (const uint64_t *)d_w->ptr, nf, xf, yf, wl->ptr, nullptr), "crc_limb_conv1_pack_weights");
+        chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+        d_w = wl; w_form = CRC_NTTL1;
+        return true;
+    }
+    return toLimb(d_w, w_form, nf, zd, xf, yf, (long)B * 2 * xo * yo);
+}
 void ConvolutionalLayer::packWeights(bool unpack)
 {
     upload();
     if (streamed) return;
-    if (w_form == CRC_NTTL) { if (unpack) throw logic_error("ConvolutionalLayer " + name + ": weights are in limb form (fuse() / broadcastParameters() must precede the first forward())"); return; }
+    if (w_form == CRC_NTTL || w_form == CRC_NTTL1) { if (unpack) throw logic_error("ConvolutionalLayer " + name + ": weights are in limb form (fuse() / broadcastParameters() must precede the first forward())"); return; }
     if ((w_form == CRC_NTTP) == !unpack) return;
     chk(crc_pack28(ctx(), (uint64_t *)d_w->ptr, (size_t)nf * zd * xf * yf * K(), unpack ? 1 : 0, nullptr), "crc_pack28");
     w_form = unpack ? CRC_NTT : CRC_NTTP;
@@ -401,6 +417,7 @@ ciphertext3D ConvolutionalLayer::forward(ciphertext3D input)
     ensure(d_work, wb);
     chk(crc_conv2d_forms(ctx(), input.data(), (const uint64_t *)d_w->ptr, w_form, (const uint64_t *)d_b[out_form != CRC_COEFF]->ptr, input.B, zd, xd, yd, xs, ys, xf, yf, nf,
                          input.form, out_form, out.data(), d_work->ptr, nullptr), "crc_conv2d_forms");
+    if (out_form == CRC_NTTLC) out.form = CRC_NTTL;         // what the convolution behind reads as its limb-form input
     return out;
 }
 void ConvolutionalLayer::savePlaintextParameters(ostream *outfile)
@@ -585,7 +602,11 @@ ciphertext3D Network::forward(ciphertext3D input)
         // a conv / dense layer feeding another one hands its tensor over packed as well
         // ... and a limb layer feeding a DENSE limb layer hands it over in limb form
         const bool to_dense_limb = i + 1 < L && limb[i] && limb[i + 1] && dynamic_pointer_cast<FullyConnectedLayer>(layers[i + 1]);
-        layers[i]->out_form = coeff ? CRC_COEFF : to_dense_limb && max_num_of_reencryptions < 0 ? CRC_NTTL
+        // ... and a one-channel convolution writes the limb tensor of a matrix-core CONVOLUTION behind it itself
+        auto ci = dynamic_pointer_cast<ConvolutionalLayer>(layers[i]);
+        auto cn = i + 1 < L ? dynamic_pointer_cast<ConvolutionalLayer>(layers[i + 1]) : nullptr;
+        const bool to_conv_limb = ci && cn && ci->w_form == CRC_NTTL1 && cn->w_form == CRC_NTTL;
+        layers[i]->out_form = coeff ? CRC_COEFF : to_dense_limb && max_num_of_reencryptions < 0 ? CRC_NTTL : to_conv_limb && max_num_of_reencryptions < 0 ? CRC_NTTLC
                             : (packable && max_num_of_reencryptions < 0 && isMac(i) && isMac(i + 1) ? CRC_NTTP : CRC_NTT);
     }
     last_layer_ms.assign(L, 0.0);

@@ -5,6 +5,8 @@ the HDF5 model by dataset name, every float encoded with the fractional encoder,
 (network.cpp:22-47) layer by layer over a batch of encrypted images.  All arithmetic happens in libcrcnn_hip.so; this
 file only sequences C-ABI calls and owns device buffers.  The C++ twin of this logic is crcnn_amd/host/.
 """
+import os
+
 import numpy as np
 
 from . import binding
@@ -68,7 +70,6 @@ class Network:
     def __init__(self, eng, model, h5_path=None, weights=None, alloc=None, resident=True, encode_chunk=2048, dbc=16, d_evk=None, materialize=True, fuse_pool=None, limb=None):
         self.E, self.model, self.topo = eng, model, TOPOLOGIES[model]
         # conv / dense layers with long reductions run on the matrix cores (operand form CRC_NTTL, kernels_mfma.hip) unless CRC_MFMA=0
-        import os
         self.limb = (os.environ.get("CRC_MFMA", "1") != "0") if limb is None else limb
         self._limbed = False
         # a conv / dense layer whose NTT-form weights (k rows per weight) would take more than this share of HBM keeps its weights as coefficient-form plaintexts
@@ -139,6 +140,10 @@ class Network:
             return False
         return self.limb and zd >= 16 and -(-zd // 32) * xf * yf >= 16 and self.E.limb_supported(zd, xf, yf)
 
+    def conv1_eligible(self, kind, a):
+        """one-channel convolutions (conv1, alone or with its pooling layer folded in) have their own matrix-core kernel (kernels_mfma1.hip)"""
+        return self.limb and kind == "conv" and a["zd"] == 1 and self.E.limb_conv1_supported(1, a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"])
+
     def _limb_operands(self, B=None):
         """conv / dense weights of the eligible layers -> limb form (the canonical copy is dropped: call after fuse()); a limb layer that feeds a dense
         limb layer hands its tensor over in limb form"""
@@ -147,6 +152,15 @@ class Network:
             return
         assert not self._packed
         for idx, (kind, name, a, p, ishape, oshape) in enumerate(self.plan):
+            if self.conv1_eligible(kind, a) and not p.get("streamed") and os.environ.get("CRC_MFMA_CONV1", "1") != "0":
+                nbytes = E.limb_conv1_weights_bytes()
+                wl = self.alloc(nbytes)
+                E.limb_conv1_pack_weights(p["w"], a["nf"], a["xf"], a["yf"], wl)
+                E.sync()
+                self.weight_bytes += nbytes - a["nf"] * a["xf"] * a["yf"] * E.k * E.n * 8
+                self._free(p["w"])
+                p["w"], p["w_form"] = wl, binding.NTTL1
+                continue
             if not self.limb_eligible(kind, a) or p.get("streamed"):
                 continue
             # a workgroup covers 64 rows = (image, pixel, poly): with fewer than half a tile of rows per launch (dense layers at small chunks) most of every MFMA is
@@ -168,6 +182,9 @@ class Network:
             nxt = self.plan[idx + 1] if idx + 1 < len(self.plan) else None
             if p.get("w_form") == binding.NTTL and nxt and nxt[0] == "fc" and nxt[3].get("w_form") == binding.NTTL and p["out_form"] == NTT and nxt[3]["in_form"] == NTT:
                 p["out_form"] = nxt[3]["in_form"] = binding.NTTL
+            # a one-channel convolution in front of a matrix-core convolution writes that layer's limb tensor itself
+            if p.get("w_form") == binding.NTTL1 and nxt and nxt[0] == "conv" and nxt[3].get("w_form") == binding.NTTL and p["out_form"] == NTT and nxt[3]["in_form"] == NTT:
+                p["out_form"], nxt[3]["in_form"] = binding.NTTLC, binding.NTTL
         self._limbed = True
 
     def _free(self, buf):
@@ -196,7 +213,7 @@ class Network:
                 continue
             if kind not in ("conv", "fc"):
                 continue
-            if p.get("w_form") != binding.NTTL and not p.get("streamed"):
+            if p.get("w_form") not in (binding.NTTL, binding.NTTL1) and not p.get("streamed"):
                 rows = (a["nf"] * a["zd"] * a["xf"] * a["yf"] if kind == "conv" else a["in_dim"] * a["out_dim"]) * E.k
                 E.pack28(p["w"], rows, unpack=unpack)
                 p["w_form"] = NTT if unpack else binding.NTTP
@@ -425,9 +442,12 @@ class Network:
         self.slots = self._slots()
         size = [1, 1]
         for i, sl in enumerate(self.slots):
-            size[sl] = max(size[sl], acts[i + 1])
-        self.buf = [self.alloc(size[0] * B * self.ct_bytes()), self.alloc(size[1] * B * self.ct_bytes())]
-        self.act_bytes = (size[0] + size[1]) * B * self.ct_bytes()
+            size[sl] = max(size[sl], acts[i + 1] * B * self.ct_bytes())
+            if self.plan[i][3].get("out_form") == binding.NTTLC:          # a limb tensor pads the channels to 32 (7 bytes per residue instead of 8)
+                nf, xo, yo = self.plan[i][5]
+                size[sl] = max(size[sl], self.E.limb_tensor_bytes(B, nf, xo, yo))
+        self.buf = [self.alloc(size[0]), self.alloc(size[1])]
+        self.act_bytes = size[0] + size[1]
         _, work = self.scratch_bytes(B)
         self.work = self.alloc(max(work, 256))
         self.work_bytes = max(work, 256)

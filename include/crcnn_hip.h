@@ -58,7 +58,13 @@ enum { CRC_COEFF = 0, CRC_NTT = 1,
         * kernel on long reductions.  crc_limb_pack_weights makes the weights; crc_conv2d_forms / crc_dense_forms take w_form = CRC_NTTL, convert a
         * CRC_COEFF / CRC_NTT / CRC_NTTP input themselves and produce any form (out_form = CRC_NTTL hands the tensor to a DENSE layer: channels =
         * (filter, x, y) flattened, 1 x 1 positions).  Needs coefficient moduli below 2^56 and reductions of at most 18 000 terms. */
-       CRC_NTTL = 3 };
+       CRC_NTTL = 3,
+       /* weights of a ONE-CHANNEL convolution (CrCNN's conv1, alone or fused with its pooling layer: window <= 8 x 8, <= 32 filters) for the matrix-core
+        * kernel specialised for it (kernels_mfma1.hip): [k][n][2][7][32 filters][32 window taps], tap = 8 kx + ky.  w_form only (crc_limb_conv1_*). */
+       CRC_NTTL1 = 4,
+       /* out_form only, with w_form = CRC_NTTL1: the result as the limb tensor a CONVOLUTION reads with in_form = CRC_NTTL
+        * ([k][n][B][7][xo*yo][2][32 channels]; CRC_NTTL as out_form flattens for a dense consumer instead) */
+       CRC_NTTLC = 5 };
 
 const char *crc_strerror(int status);
 int         crc_last_hip_error(void);
@@ -189,6 +195,10 @@ int    crc_limb_pack_weights(crc_ctx *ctx, const uint64_t *d_w_ntt, int nf, int 
 /* an NTT-form tensor (CRC_NTT canonical or CRC_NTTP) -> limb form; crc_conv2d_forms does this itself for such inputs, the separate entry point lets a
  * caller convert once and reuse (d_xl: crc_limb_tensor_bytes) */
 int    crc_limb_pack_tensor(crc_ctx *ctx, const uint64_t *d_x, int in_form, int B, int zd, int xd, int yd, void *d_xl, void *stream);
+/* one-channel convolutions on the matrix cores (w_form = CRC_NTTL1): eligibility of a shape, size of the weights, conversion from CRC_NTT weights */
+int    crc_limb_conv1_supported(const crc_ctx *ctx, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf);
+size_t crc_limb_conv1_weights_bytes(const crc_ctx *ctx);
+int    crc_limb_conv1_pack_weights(crc_ctx *ctx, const uint64_t *d_w_ntt, int nf, int xf, int yf, void *d_wl, void *stream);
 size_t crc_conv2d_forms_work_bytes(const crc_ctx *ctx, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int in_form, int w_form, int out_form);
 /* in-place CRC_NTT <-> CRC_NTTP conversion of `rows` residue rows (unpack = 0: pack, 1: unpack) */
 int crc_pack28(crc_ctx *ctx, uint64_t *d_rows, size_t rows, int unpack, void *stream);

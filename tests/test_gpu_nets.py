@@ -91,3 +91,13 @@ def test_matrix_core_dense_layers_match_reference():
     out = E.download(net.forward(d_x, 16), (16, 1, 10, 1, 2, E.k, E.n))
     E.close()
     assert all(sha(out[b]) == g["out_sha256"] for b in range(16))
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, "net_tiny4096_t32.json")), reason="needs the n=4096 golden")
+def test_bench_chunk_matches_reference():
+    """PlainModelTiny at the BASELINE parameters and bench.py's chunk (32 images per layer launch): conv1+pool1 on its own matrix-core kernel writing conv2's limb tensor,
+    conv2 / fc3 / fc4 as limb GEMMs -- every image of the chunk is the compiled reference's ciphertext"""
+    import crcnn_amd as ca
+    g, O, sk, out, _ = run_net("tiny4096_t32", resident=True, batch=32)
+    bad = [b for b in range(32) if sha(out[b]) != g["out_sha256"]]
+    assert not bad, bad
