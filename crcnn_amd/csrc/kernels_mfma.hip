@@ -30,8 +30,10 @@ typedef signed char i8;
 
 struct MfmaArgs {
     const i8 *xl; const i8 *wl; u64 *ys; const ModParams *mods; const u64 *bias;     // bias: NTT-form delta rows [F][k][n] added to poly 0, or null
-    int n, k, B, zdp, npos, yd, xs, ys_, yf, yo, P, F, Fp, zblks, ksteps, M, mtiles, ntiles;
-    unsigned img_bytes; unsigned long long wslot_bytes;
+    int n, k, B, zdp, npos, yd, xs, ys_, yf, yo, P, F, Fp, zblks, ksteps, M, mtiles, ntiles;      // ksteps: rounded up to even (the weights carry a zero step)
+    unsigned img_bytes; unsigned long long wslot_bytes; int ksteps_real;
+    int acc0[8][13];                                   // initial value of the 13 diagonal accumulators, per modulus (limb_tables)
+    u64 qinv[8];                                       // q^-1 mod 2^64
 };
 
 // canonical residue -> 7 balanced base-256 digits of its centred representative
@@ -42,34 +44,38 @@ __device__ __forceinline__ void limb_digits(u64 r, u64 q, int (&d)[NPL])
     for (int l = 0; l < NPL; l++) { d[l] = (int)(signed char)(v & 0xff); v = (v - d[l]) >> 8; }
 }
 
-// V = sum_d D_d 2^(8d) (signed, |V| < 2^125)  ->  V mod q, canonical
-__device__ __forceinline__ u64 limb_reduce(const int (&D)[13], const ModParams &m)
+// The 13 diagonals D'_d = B_d + D_d (any 32-bit words; the accumulators start at B_d, limb_tables) hold U = sum_d D'_d 2^(8d) = V + K*, K* a multiple of q,
+// 0 <= U < 2^127.  Returns U 2^-64 mod q, canonical: the weights carry the factor 2^64, so that is V's residue.  The diagonals d = r (mod 4) are the words of one
+// number each (no overlap); U is their sum at byte offsets 0..3.  One Montgomery step (subtractive form: m = U_lo q^-1 mod 2^64 makes U - m q divisible by 2^64, the
+// low halves cancel without a borrow) leaves t = U_hi - hi64(m q) in (-q, 2^63); t + q < 2^64 is then folded (q = 2^b - f) or Barrett-reduced.  ~80 VALU operations
+// per output where recombining into 128 bits with signs and reducing that took ~340.
+__device__ __forceinline__ u64 diag_reduce(const int (&D)[13], const ModParams &m, u64 qinv)
 {
-    long long G[4];                                   // G_g = D_4g + D_4g+1 2^8 + D_4g+2 2^16 + D_4g+3 2^24   (|G| < 2^56)
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        long long a = D[4 * g];
-        if (4 * g + 1 < 13) a += (long long)D[4 * g + 1] * 256;
-        if (4 * g + 2 < 13) a += (long long)D[4 * g + 2] * 65536;
-        if (4 * g + 3 < 13) a += (long long)D[4 * g + 3] * 16777216;
-        G[g] = a;
+    typedef unsigned __int128 u128;
+    const u128 s0 = ((u128)(((u64)(u32)D[12] << 32) | (u32)D[8]) << 64) | (((u64)(u32)D[4] << 32) | (u32)D[0]);
+    const u128 s1 = ((u128)(u32)D[9] << 64) | (((u64)(u32)D[5] << 32) | (u32)D[1]);
+    const u128 s2 = ((u128)(u32)D[10] << 64) | (((u64)(u32)D[6] << 32) | (u32)D[2]);
+    const u128 s3 = ((u128)(u32)D[11] << 64) | (((u64)(u32)D[7] << 32) | (u32)D[3]);
+    const u128 U = s0 + (s1 << 8) + (s2 << 16) + (s3 << 24);
+    const u64 ulo = (u64)U, uhi = (u64)(U >> 64);
+    const u64 mq = ulo * qinv;
+    const u64 t = uhi - __umul64hi(mq, m.q) + m.q;               // in (0, 2^63 + q)
+    if (m.fold) {                                                 // 2^b = f (mod q): (t >> b) < 2^12, f < 2^26
+        const u64 r = (t & (((u64)1 << m.bits) - 1)) + (u64)(u32)(t >> m.bits) * (u32)m.fold;        // one 32 x 32 multiply
+        return r >= m.q ? r - m.q : r;
     }
-    // V = G0 + G1 2^32 + G2 2^64 + G3 2^96 in two's complement, plus q 2^(126 - bits) (a multiple of q in (2^125, 2^126): the sum is positive)
-    u64 lo = (u64)G[0], hi = (u64)(G[0] >> 63);
-    { const u64 t = (u64)G[1] << 32; const u64 nl = lo + t; hi += (u64)(G[1] >> 32) + (nl < lo); lo = nl; }
-    hi += (u64)G[2] + ((u64)G[3] << 32);
-    hi += m.q << (62 - m.bits);
-    return barrett128(lo, hi, m);
+    return barrett128(t, 0, m);
 }
 
+// The same layer on v_mfma_i32_16x16x64_i8: a wave's 32 x 32 tile as 2 x 2 sub-tiles, two 32-term reduction steps per instruction.  Same cycles per product as the
+// 32x32x32 form, but the chip holds a higher clock on this shape under random operands (tools/mfma_shape.hip: 3.8 vs 3.5 Pop/s in a bare loop), and twice the work between
+// barriers.  A K group g = lane / 16 of an operand fragment is half (g & 1) of ring slot 2d + (g >> 1): the staging is the 32x32x32 kernel's, one slot per 32-term step.
 template <int NST>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) mfma_mac_kernel(MfmaArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) i8 lds[];                  // ring of NST x (A tile | W tile): the loads run NST - 1 reduction steps ahead
+    extern __shared__ __attribute__((aligned(16))) i8 lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 1, wn = wave & 1;
     const int slots = a.n * a.k, per = a.mtiles * a.ntiles;
-    // XCD-aware decode (workgroups are dealt round-robin over the 8 XCDs): the tiles of one slot run on one XCD at about the same time, so what they share
-    // (the slot's weight limbs across row tiles, its rows across filter tiles) is fetched from HBM once and then served by that XCD's L2
     int g = blockIdx.x, slot, tile;
     if ((slots & 7) == 0) { const int xcd = g & 7, r = g >> 3; slot = xcd * (slots >> 3) + r / per; tile = r % per; }
     else { slot = g / per; tile = g % per; }
@@ -77,11 +83,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const int i = slot / a.n, s = slot % a.n;
     const int m0 = mt * 64, f0 = nt * 64;
     const ModParams m = a.mods[i];
+    const u64 qinv = a.qinv[i];
     const i8 *xs = a.xl + (size_t)slot * a.B * a.img_bytes;
     const i8 *ws = a.wl + (size_t)slot * a.wslot_bytes + (size_t)f0 * 32;
-
-    // staging: 28 LDS-DMA pieces of 1 KiB per step (pieces 0..13 of A, 14..27 of W), 7 per wave (pieces wave, wave+4, ...); a piece = 64 lanes x 16 B,
-    // landing lane-linear.  A piece chunk c16 (0..895) -> (plane, row, half); row -> (image, pixel, poly)
     u32 src_off[7];
 #pragma unroll
     for (int j = 0; j < 7; j++) {
@@ -89,79 +93,87 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         if (pc < 14) {
             const int c16 = pc * 64 + lane;
             const int plane = c16 >> 7, row = (c16 >> 1) & 63, half = c16 & 1;
-            const int mm = min(m0 + row, a.M - 1);                           // rows past M re-read the last one and are never stored
+            const int mm = min(m0 + row, a.M - 1);
             const int b = mm / (2 * a.P), p = (mm >> 1) % a.P, c = mm & 1;
             const int ox = p / a.yo, oy = p % a.yo;
             src_off[j] = (u32)b * a.img_bytes + (u32)(plane * (a.npos * 2 * a.zdp) + (((ox * a.xs) * a.yd + oy * a.ys_) * 2 + c) * a.zdp + half * 16);
         } else src_off[j] = (u32)(((pc - 14) >> 1) * (a.Fp * 32) + ((pc - 14) & 1) * 1024 + lane * 16);
     }
-    // the step's wave-uniform terms (tap offset inside an image block, ring slot, weight tile), then one piece (j = 0..6: this wave's j-th piece)
-    struct StepAddr { u32 delta; i8 *dst; const i8 *wt; };
-    auto step_addr = [&](int ks) {
-        const int tap = ks / a.zblks, zb = ks - tap * a.zblks;
-        const int kx = tap / a.yf, ky = tap - kx * a.yf;
-        return StepAddr{(u32)((kx * a.yd + ky) * 2 * a.zdp + zb * 32), lds + (ks % NST) * (2 * TILE_B), ws + (size_t)ks * (NPL * a.Fp * 32)};
-    };
-    auto issue_one = [&](const StepAddr &sa, int j) {
-        const int pc = wave + 4 * j;
-        const i8 *src = pc < 14 ? xs + src_off[j] + sa.delta : sa.wt + src_off[j];
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)(sa.dst + pc * 1024), 16, 0, 0);
-    };
+    const int kreal = a.ksteps_real;
     auto issue = [&](int ks) {
-        const StepAddr sa = step_addr(ks);
+        const int ka = min(ks, kreal - 1);                        // the padding step multiplies by zero weights: any valid rows will do
+        const int tap = ka / a.zblks, zb = ka - tap * a.zblks;
+        const int kx = tap / a.yf, ky = tap - kx * a.yf;
+        const u32 delta = (u32)((kx * a.yd + ky) * 2 * a.zdp + zb * 32);
+        i8 *dst = lds + (ks % NST) * (2 * TILE_B);
+        const i8 *wt = ws + (size_t)ks * (NPL * a.Fp * 32);
 #pragma unroll
-        for (int j = 0; j < 7; j++) issue_one(sa, j);
+        for (int j = 0; j < 7; j++) {
+            const int pc = wave + 4 * j;
+            const i8 *src = pc < 14 ? xs + src_off[j] + delta : wt + src_off[j];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)(dst + pc * 1024), 16, 0, 0);
+        }
     };
-
-    v16i acc[13];
+    v4i acc[2][2][13];
 #pragma unroll
-    for (int d = 0; d < 13; d++)
+    for (int rs = 0; rs < 2; rs++)
 #pragma unroll
-        for (int e = 0; e < 16; e++) acc[d][e] = 0;
-
-    const int K = a.ksteps;
+        for (int cs = 0; cs < 2; cs++)
 #pragma unroll
-    for (int j = 0; j < NST - 1; j++) if (j < K) issue(j);
-    const int fragA = (wm * 32 + (lane & 31)) * 32 + (lane >> 5) * 16, fragW = (wn * 32 + (lane & 31)) * 32 + (lane >> 5) * 16;
-    for (int ks = 0; ks < K; ks++) {
-        // this wave's pieces of step ks have landed (up to NST - 2 younger steps of 7 loads each may still be in flight) ...
-        const int younger = min(NST - 2, K - 1 - ks);
-        if (younger >= 3) __builtin_amdgcn_s_waitcnt(21 | (7 << 4) | (15 << 8));
-        else if (younger == 2) __builtin_amdgcn_s_waitcnt(14 | (7 << 4) | (15 << 8));
-        else if (younger == 1) __builtin_amdgcn_s_waitcnt(7 | (7 << 4) | (15 << 8));
+            for (int d = 0; d < 13; d++) { const int b0 = a.acc0[i][d]; acc[rs][cs][d] = v4i{b0, b0, b0, b0}; }
+    const int K = a.ksteps;                                       // even
+#pragma unroll
+    for (int j = 0; j < NST - 2; j++) if (j < K) issue(j);
+    const int kg = lane >> 4, r16 = lane & 15;
+    const int fragA = (wm * 32 + r16) * 32 + (kg & 1) * 16, fragW = (wn * 32 + r16) * 32 + (kg & 1) * 16;
+    for (int ks = 0; ks < K; ks += 2) {
+        // steps ks, ks + 1 have landed; up to NST - 4 younger steps (7 loads each) may still be in flight
+        const int younger = min(NST - 4, K - 2 - ks);
+        if (younger >= 1) __builtin_amdgcn_s_waitcnt(7 | (7 << 4) | (15 << 8));
         else __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
-        __syncthreads();                                          // ... and everybody's; ring slot (ks - 1) % NST, read in step ks - 1, is free
-        if (ks + NST - 1 < K) issue(ks + NST - 1);                // (as one block: spreading the pieces between the MFMA groups below measured 5 % slower)
-        const i8 *tA = lds + (ks % NST) * (2 * TILE_B), *tW = tA + TILE_B;
-        v4i w[NPL];
+        __syncthreads();
+        if (ks + NST - 2 < K) { issue(ks + NST - 2); if (ks + NST - 1 < K) issue(ks + NST - 1); }
+        const i8 *tA = lds + ((ks + (kg >> 1)) % NST) * (2 * TILE_B), *tW = tA + TILE_B;
+        v4i w[2][NPL];
 #pragma unroll
-        for (int l = 0; l < NPL; l++) w[l] = *reinterpret_cast<const v4i *>(tW + l * (64 * 32) + fragW);
-        // 49 limb products; the seven MFMAs of one A plane go to seven different diagonals (no back-to-back dependent accumulators)
+        for (int cs = 0; cs < 2; cs++)
 #pragma unroll
-        for (int l = 0; l < NPL; l++) {
-            const v4i av = *reinterpret_cast<const v4i *>(tA + l * (64 * 32) + fragA);
+            for (int l = 0; l < NPL; l++) w[cs][l] = *reinterpret_cast<const v4i *>(tW + l * (64 * 32) + fragW + cs * (16 * 32));
 #pragma unroll
-            for (int mm = 0; mm < NPL; mm++)
-                acc[l + mm] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, w[mm], acc[l + mm], 0, 0, 0);
-        }
+        for (int rs = 0; rs < 2; rs++)
+#pragma unroll
+            for (int l = 0; l < NPL; l++) {
+                const v4i av = *reinterpret_cast<const v4i *>(tA + l * (64 * 32) + fragA + rs * (16 * 32));
+#pragma unroll
+                for (int cs = 0; cs < 2; cs++)
+#pragma unroll
+                    for (int mm = 0; mm < NPL; mm++)
+                        acc[rs][cs][l + mm] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, w[cs][mm], acc[rs][cs][l + mm], 0, 0, 0);
+            }
     }
-
-    // epilogue: C/D layout of a 32 x 32 tile: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-    const int f = f0 + wn * 32 + (lane & 31);
-    const u64 bv = (a.bias && f < a.F) ? a.bias[((size_t)f * a.k + i) * a.n + s] : 0;
+    // epilogue: C/D layout of a 16 x 16 tile: col = lane & 15, row = 4 (lane >> 4) + reg.  Row mm = image b, pixel p, poly c (= reg & 1: the row bases are multiples
+    // of 4) lands at Ys[((slot B + b) F + f) 2P + (mm - b 2P)] = Ys[slot B F 2P + b (F - 1) 2P + f 2P + mm]: one division per group of four rows
+    u64 *yslot = a.ys + (size_t)slot * a.B * a.F * (2 * a.P);
+    const u32 P2 = 2 * a.P;
 #pragma unroll
-    for (int reg = 0; reg < 16; reg++) {
-        const int mm = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        int D[13];
+    for (int rs = 0; rs < 2; rs++) {
+        const u32 mbase = m0 + wm * 32 + rs * 16 + 4 * kg, bb = mbase / P2, rem = mbase - bb * P2;
 #pragma unroll
-        for (int d = 0; d < 13; d++) D[d] = acc[d][reg];
-        u64 v = limb_reduce(D, m);
-        if (mm < a.M && f < a.F) {
-            const int b = mm / (2 * a.P), p = (mm >> 1) % a.P, c = mm & 1;
-            if (c == 0 && a.bias) v = addmod(v, bv, m.q);
-            a.ys[(((size_t)slot * a.B + b) * a.F + f) * (2 * a.P) + p * 2 + c] = v;
+        for (int cs = 0; cs < 2; cs++) {
+            const int f = f0 + wn * 32 + cs * 16 + r16;
+            const u64 bv = (a.bias && f < a.F) ? a.bias[((size_t)f * a.k + i) * a.n + s] : 0;
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                int D[13];
+#pragma unroll
+                for (int d = 0; d < 13; d++) D[d] = acc[rs][cs][d][reg];
+                u64 v = diag_reduce(D, m, qinv);
+                if ((reg & 1) == 0) v = addmod(v, bv, m.q);
+                const u32 r = rem + reg, b = bb + (r >= P2) + (r >= 2 * P2);
+                if (mbase + reg < (u32)a.M && f < a.F) yslot[b * (u32)(a.F - 1) * P2 + (u32)f * P2 + mbase + reg] = v;
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);                 // one output at a time: sixteen interleaved reductions would spill
     }
 }
 
@@ -213,7 +225,8 @@ __global__ void __launch_bounds__(64) limb_pack_weights_kernel(const u64 *w, i8 
     const int sb = blockIdx.x % (sblocks * k), i = sb / sblocks, s = (sb % sblocks) * 64 + threadIdx.x;
     size_t r = blockIdx.x / (sblocks * k);                       // (f*taps + tap)*zblks + zb
     const int zb = (int)(r % zblks); r /= zblks; const int tap = (int)(r % taps); const int f = (int)(r / taps);
-    const u64 q = mods[i].q;
+    const ModParams m = mods[i];
+    const u64 R = barrett128(0, 1, m);                           // 2^64 mod q: the factor the kernel's Montgomery reduction divides out
     u32 pl[NPL][8];
 #pragma unroll
     for (int l = 0; l < NPL; l++)
@@ -223,13 +236,13 @@ __global__ void __launch_bounds__(64) limb_pack_weights_kernel(const u64 *w, i8 
     for (int z = 0; z < 32; z++) {
         const int zz = zb * 32 + z;
         if (zz < zd) {
-            const u64 v = w[((((size_t)f * zd + zz) * taps + tap) * k + i) * (size_t)n + s];
-            int d[NPL]; limb_digits(v, q, d);
+            const u64 v = mulmod(w[((((size_t)f * zd + zz) * taps + tap) * k + i) * (size_t)n + s], R, m);
+            int d[NPL]; limb_digits(v, m.q, d);
 #pragma unroll
             for (int l = 0; l < NPL; l++) pl[l][z >> 2] |= (u32)(d[l] & 0xff) << (8 * (z & 3));
         }
     }
-    i8 *dst = wl + ((size_t)i * n + s) * ((size_t)taps * zblks * NPL * Fp * 32) + ((size_t)tap * zblks + zb) * (NPL * Fp * 32) + (size_t)f * 32;
+    i8 *dst = wl + ((size_t)i * n + s) * ((size_t)((taps * zblks + 1) & ~1) * NPL * Fp * 32) + ((size_t)tap * zblks + zb) * (NPL * Fp * 32) + (size_t)f * 32;
 #pragma unroll
     for (int l = 0; l < NPL; l++) {
         uint4 *o = reinterpret_cast<uint4 *>(dst + (size_t)l * Fp * 32);
@@ -286,6 +299,31 @@ __global__ void __launch_bounds__(256) slotmajor_to_limb_kernel(const u64 *ys, i
     for (int l = 0; l < NPL; l++) *reinterpret_cast<uint4 *>(dst + (size_t)l * 2 * zdp) = make_uint4(pl[l][0], pl[l][1], pl[l][2], pl[l][3]);
 }
 
+// Initial accumulator values for reductions of T terms.  Diagonal d collects the np_d = min(d, 12 - d) + 1 products a_l b_m with l + m = d of every term:
+// |D_d| <= T np_d 2^14.  B_d = the power of two above that bound (+ 256) keeps D'_d = B_d + D_d positive; K0 = sum B_d 2^(8d) is moved to the nearest multiple K* of q
+// by adding the balanced digits of K* - K0 (|.| <= q/2: seven digits of at most 128) to B_0..6.  Then U = sum D'_d 2^(8d) = V + K* == V (mod q), U > 0.
+static void limb_tables(const crc_ctx *c, int T, int (*acc0)[13], u64 *qinv)
+{
+    typedef unsigned __int128 u128;
+    for (int i = 0; i < c->k; i++) {
+        const u64 q = c->tabs[i].m.q;
+        long long B0[13];
+        u128 K0 = 0;
+        for (int d = 0; d < 13; d++) {
+            const u64 bound = (u64)T * (u64)((d < 12 - d ? d : 12 - d) + 1) * 16384 + 256;
+            u64 b = 1; while (b < bound) b <<= 1;
+            B0[d] = (long long)b; K0 += (u128)b << (8 * d);
+        }
+        const u128 rem = K0 % q;
+        long long delta = rem > q / 2 ? (long long)(q - (u64)rem) : -(long long)(u64)rem;        // K* - K0
+        for (int d = 0; d < 7; d++) { const long long dg = (long long)(signed char)(delta & 0xff); B0[d] += dg; delta = (delta - dg) >> 8; }
+        for (int d = 0; d < 13; d++) acc0[i][d] = (int)(u32)(u64)B0[d];                           // (B_d up to 2^31: the accumulators are words mod 2^32)
+        u64 inv = q;                                             // Newton: q odd, q q = 1 (mod 8); each step doubles the correct bits
+        for (int it = 0; it < 6; it++) inv *= 2 - q * inv;
+        qinv[i] = inv;
+    }
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------------------------------------------
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 bool k_limb_supported(const crc_ctx *c, int T)
@@ -295,7 +333,7 @@ bool k_limb_supported(const crc_ctx *c, int T)
     return true;
 }
 size_t k_limb_tensor_bytes(const crc_ctx *c, int B, int zd, int npos) { return (size_t)c->n * c->k * B * NPL * npos * 2 * round_up(zd, 32); }
-size_t k_limb_weights_bytes(const crc_ctx *c, int nf, int zd, int taps) { return (size_t)c->n * c->k * taps * (round_up(zd, 32) / 32) * NPL * round_up(nf, 64) * 32; }
+size_t k_limb_weights_bytes(const crc_ctx *c, int nf, int zd, int taps) { return (size_t)c->n * c->k * round_up(taps * (round_up(zd, 32) / 32), 2) * NPL * round_up(nf, 64) * 32; }      // (an odd number of reduction steps gets a zero step)
 size_t k_limb_result_words(const crc_ctx *c, int B, int nf, int P) { return (size_t)c->n * c->k * B * nf * P * 2; }
 
 int k_limb_pack_tensor(crc_ctx *c, const u64 *x, i8 *xl, int B, int zd, int npos, bool packed, hipStream_t st)
@@ -346,16 +384,20 @@ int k_limb_mac(crc_ctx *c, const i8 *xl, const i8 *wl, u64 *ys, const u64 *bias_
     MfmaArgs a{};
     a.xl = xl; a.wl = wl; a.ys = ys; a.mods = c->d_mods; a.bias = bias_ntt;
     a.n = c->n; a.k = c->k; a.B = B; a.zdp = round_up(zd, 32); a.npos = xd * yd; a.yd = yd; a.xs = xs; a.ys_ = ys_; a.yf = yf; a.yo = yo; a.P = xo * yo;
-    a.F = nf; a.Fp = round_up(nf, 64); a.zblks = a.zdp / 32; a.ksteps = xf * yf * a.zblks; a.M = B * a.P * 2;
+    a.F = nf; a.Fp = round_up(nf, 64); a.zblks = a.zdp / 32; a.ksteps_real = xf * yf * a.zblks; a.M = B * a.P * 2;
     a.mtiles = (a.M + 63) / 64; a.ntiles = a.Fp / 64;
     const size_t img = (size_t)NPL * a.npos * 2 * a.zdp;
-    if (img * B > 0xffffffffULL || !k_limb_supported(c, a.ksteps * 32)) return CRC_ERR_UNSUPPORTED;
-    a.img_bytes = (unsigned)img; a.wslot_bytes = (unsigned long long)a.ksteps * NPL * a.Fp * 32;
+    if (img * B > 0xffffffffULL || !k_limb_supported(c, a.ksteps_real * 32)) return CRC_ERR_UNSUPPORTED;
+    a.img_bytes = (unsigned)img; a.wslot_bytes = (unsigned long long)round_up(a.ksteps_real, 2) * NPL * a.Fp * 32;
     const size_t grid = (size_t)c->n * c->k * a.mtiles * a.ntiles;
     if (grid > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
-    static const int ring = [] { const char *e = getenv("CRC_MFMA_RING"); const int v = e ? atoi(e) : 4; return v == 3 || v == 5 ? v : 4; }();     // tuning (tools/)
-    const size_t lds = (size_t)ring * 2 * TILE_B;
-    auto kern = ring == 5 ? mfma_mac_kernel<5> : ring == 3 ? mfma_mac_kernel<3> : mfma_mac_kernel<4>;
+    if (c->k > 8) return CRC_ERR_UNSUPPORTED;
+    limb_tables(c, a.ksteps_real * 32, a.acc0, a.qinv);
+    static const int ring = [] { const char *e = getenv("CRC_MFMA_RING"); const int v = e ? atoi(e) : 0; return v >= 3 && v <= 5 ? v : 0; }();     // tuning (tools/)
+    a.ksteps = round_up(a.ksteps_real, 2);
+    const int nst = ring == 4 ? 4 : 5;
+    const size_t lds = (size_t)nst * 2 * TILE_B;
+    auto kern = nst == 4 ? mfma_mac_kernel<4> : mfma_mac_kernel<5>;
     { const int rc = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (rc) return rc; }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);
     HIPCHK(hipGetLastError());

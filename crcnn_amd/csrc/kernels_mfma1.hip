@@ -13,7 +13,7 @@
 // 8 or 12 waves per workgroup (2-3 per SIMD: one wave's epilogue overlaps another's MFMAs); a wave owns 16 filters and every (waves/2)-th 16-row tile.
 //   per image   the limb image [plane][poly][row][32 columns] (12.5 KiB for 28 x 28) in LDS, double-buffered; a lane's A fragment is two 8-byte LDS reads per
 //               plane (window rows kx, kx+1): the three words around byte offset oy * stride, byte-aligned in registers;
-//   output      either the limb tensor of a following convolution, staged in LDS as [plane][pixel][poly][32 channels] and written out as one contiguous block
+//   output      either the limb tensor of a following convolution, staged in LDS and written out as one contiguous [plane][pixel][poly][32 channels] block
 //               (no limb_pack_tensor pass in front of conv2), or slot-major u64 for the generic conversions.
 // Exact integer arithmetic throughout: the same element of Z_q, hence the same bits, as mac3_kernel and the reference (convolutionalLayer.cpp:56-93).
 #include "kernels.h"
@@ -60,13 +60,12 @@ __device__ __forceinline__ u64 diag_reduce_mont(const int (&D)[13], u64 q, u64 q
     return (u64)(t + ((t >> 63) & (long long)q));
 }
 
-__global__ void __launch_bounds__(768) mfma_conv1_kernel(Conv1Args a)
+__global__ void __launch_bounds__(1024) mfma_conv1_kernel(Conv1Args a)
 {
     extern __shared__ __attribute__((aligned(16))) i8 lds[];                  // [2 image buffers][output staging]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
     const int slot = blockIdx.x, i = slot / a.n, s = slot % a.n;
-    const ModParams m = a.mods[i];
-    const u64 qinv = a.qinv[i];
+    const u64 q = a.mods[i].q, qinv = a.qinv[i];
     const int nt = wave & 1, col = nt * 16 + (lane & 15), g = lane >> 4;      // this wave's 16 filters; this lane's filter and K group (window rows 2g, 2g+1)
     // the weight fragments of this lane's filter, resident for the whole workgroup
     v4i wv[NPL];
@@ -124,16 +123,16 @@ __global__ void __launch_bounds__(768) mfma_conv1_kernel(Conv1Args a)
                 int D[13];
 #pragma unroll
                 for (int d = 0; d < 13; d++) D[d] = acc[d][reg];
-                u64 v = diag_reduce_mont(D, m.q, qinv);
-                if ((reg & 1) == 0) v = addmod(v, bv, m.q);       // rows alternate poly 0 / poly 1 (16 | tile base, 4 | lane base): the bias joins poly 0
+                u64 v = diag_reduce_mont(D, q, qinv);
+                if ((reg & 1) == 0) v = addmod(v, bv, q);       // rows alternate poly 0 / poly 1 (16 | tile base, 4 | lane base): the bias joins poly 0
                 if (mm < 2 * a.P) {
                     if (a.xl_out) {               // limb tensor of the next convolution: [plane][pixel][poly][32 channels], channels past F stay zero
                         // balanced digits of the centred representative cv: the bytes of cv + 0x80...80, each with its top bit flipped
-                        const long long cv = (col < a.F) ? (v > (m.q >> 1) ? (long long)(v - m.q) : (long long)v) : 0;
+                        const long long cv = (col < a.F) ? (v > (q >> 1) ? (long long)(v - q) : (long long)v) : 0;
                         const u64 dg = ((u64)cv + 0x0080808080808080ULL) ^ 0x0080808080808080ULL;
-                        i8 *sp = stage + mm * 32 + col;
+                        i8 *sp = stage + mm * (NPL * 32) + col;            // staged [row][plane][32 channels]: the seven stores share one address
 #pragma unroll
-                        for (int l = 0; l < NPL; l++) sp[(size_t)l * (a.P * 2 * 32)] = (i8)(dg >> (8 * l));
+                        for (int l = 0; l < NPL; l++) sp[l * 32] = (i8)(dg >> (8 * l));
                     } else if (col < a.F)
                         a.ys[(((size_t)slot * a.B + b) * a.F + col) * (2 * a.P) + mm] = v;
                 }
@@ -142,7 +141,11 @@ __global__ void __launch_bounds__(768) mfma_conv1_kernel(Conv1Args a)
         if (a.xl_out) {
             __syncthreads();
             i8 *dst = a.xl_out + ((size_t)slot * a.Bout + a.b0 + b) * a.out_img_bytes;
-            for (unsigned o = threadIdx.x * 16; o < a.out_img_bytes; o += blockDim.x * 16) *reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(stage + o);
+            const unsigned per_plane = a.out_img_bytes / (NPL * 16);      // 16-byte pieces of one plane: (row, half)
+            for (unsigned o = threadIdx.x; o < NPL * per_plane; o += blockDim.x) {
+                const unsigned l = o / per_plane, rem = o - l * per_plane;
+                *reinterpret_cast<uint4 *>(dst + (size_t)o * 16) = *reinterpret_cast<const uint4 *>(stage + (rem >> 1) * (NPL * 32) + l * 32 + (rem & 1) * 16);
+            }
         }
     }
 }
@@ -277,7 +280,7 @@ int k_limb_conv1(crc_ctx *c, const u64 *x, bool packed, i8 *xr, const i8 *wl, u6
         for (int sd = 0; sd < 4; sd++) worst = load[sd] > worst ? load[sd] : worst;
         return worst;
     };
-    static const int forced = [] { const char *e = getenv("CRC_CONV1_WAVES"); const int v = e ? atoi(e) : 0; return v == 8 || v == 12 ? v : 0; }();     // tuning (tools/)
+    static const int forced = [] { const char *e = getenv("CRC_CONV1_WAVES"); const int v = e ? atoi(e) : 0; return v == 8 || v == 12 || v == 16 ? v : 0; }();     // tuning (tools/)
     const int nwaves = forced ? forced : busiest(12) <= busiest(8) ? 12 : 8;
     const size_t lds = 2 * (size_t)a.img_stride + (xl_out ? a.out_img_bytes : 0);
     { const int rc = crc_ctx_ensure_lds(c, (const void *)mfma_conv1_kernel, lds); if (rc) return rc; }
