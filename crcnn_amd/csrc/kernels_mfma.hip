@@ -134,22 +134,28 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         __syncthreads();
         if (ks + NST - 2 < K) { issue(ks + NST - 2); if (ks + NST - 1 < K) issue(ks + NST - 1); }
         const i8 *tA = lds + ((ks + (kg >> 1)) % NST) * (2 * TILE_B), *tW = tA + TILE_B;
-        v4i w[2][NPL];
+        // the weight fragments and the first two A fragments are requested up front, then A fragment g + 2 behind the MFMAs of fragment g: a read has two groups of
+        // 14 MFMAs to land (read just in time, each fragment's LDS latency sat exposed in front of its MFMAs; all 28 up front overflow the 4-bit lgkm counter and the
+        // compiler waits for everything).  The scheduling barriers pin this order.
+        v4i w[2][NPL], av[2 * NPL];
+        auto read_a = [&](int gi) { return *reinterpret_cast<const v4i *>(tA + (gi % NPL) * (64 * 32) + fragA + (gi / NPL) * (16 * 32)); };
 #pragma unroll
         for (int cs = 0; cs < 2; cs++)
 #pragma unroll
             for (int l = 0; l < NPL; l++) w[cs][l] = *reinterpret_cast<const v4i *>(tW + l * (64 * 32) + fragW + cs * (16 * 32));
+        av[0] = read_a(0); av[1] = read_a(1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int rs = 0; rs < 2; rs++)
+        for (int gi = 0; gi < 2 * NPL; gi++) {
+            const int rs = gi / NPL, l = gi % NPL;
 #pragma unroll
-            for (int l = 0; l < NPL; l++) {
-                const v4i av = *reinterpret_cast<const v4i *>(tA + l * (64 * 32) + fragA + rs * (16 * 32));
+            for (int cs = 0; cs < 2; cs++)
 #pragma unroll
-                for (int cs = 0; cs < 2; cs++)
-#pragma unroll
-                    for (int mm = 0; mm < NPL; mm++)
-                        acc[rs][cs][l + mm] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, w[cs][mm], acc[rs][cs][l + mm], 0, 0, 0);
-            }
+                for (int mm = 0; mm < NPL; mm++)
+                    acc[rs][cs][l + mm] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[gi], w[cs][mm], acc[rs][cs][l + mm], 0, 0, 0);
+            if (gi + 2 < 2 * NPL) av[gi + 2] = read_a(gi + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     // epilogue: C/D layout of a 16 x 16 tile: col = lane & 15, row = 4 (lane >> 4) + reg.  Row mm = image b, pixel p, poly c (= reg & 1: the row bases are multiples
     // of 4) lands at Ys[((slot B + b) F + f) 2P + (mm - b 2P)] = Ys[slot B F 2P + b (F - 1) 2P + f 2P + mm]: one division per group of four rows
