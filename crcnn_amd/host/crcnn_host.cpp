@@ -392,7 +392,7 @@ bool ConvolutionalLayer::limbWeights(int B)
         auto wl = make_shared<DeviceBuffer>(crc_limb_conv1_weights_bytes(ctx()));
         chk(crc_limb_conv1_pack_weights(ctx(), (const uint64_t *)d_w->ptr, nf, xf, yf, wl->ptr, nullptr), "crc_limb_conv1_pack_weights");
         chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
-        d_w = wl; w_form = CRC_NTTL1;
+        d_w_canon = d_w; d_w = wl; w_form = CRC_NTTL1;         // (the canonical copy of a one-channel layer is small: kept, so that the weights can go back on the wire)
         return true;
     }
     return toLimb(d_w, w_form, nf, zd, xf, yf, (long)B * 2 * xo * yo);
@@ -401,6 +401,7 @@ void ConvolutionalLayer::packWeights(bool unpack)
 {
     upload();
     if (streamed) return;
+    if (w_form == CRC_NTTL1 && unpack) { d_w = d_w_canon; d_w_canon.reset(); w_form = CRC_NTT; return; }
     if (w_form == CRC_NTTL || w_form == CRC_NTTL1) { if (unpack) throw logic_error("ConvolutionalLayer " + name + ": weights are in limb form (fuse() / broadcastParameters() must precede the first forward())"); return; }
     if ((w_form == CRC_NTTP) == !unpack) return;
     chk(crc_pack28(ctx(), (uint64_t *)d_w->ptr, (size_t)nf * zd * xf * yf * K(), unpack ? 1 : 0, nullptr), "crc_pack28");

@@ -121,7 +121,8 @@ private:
     // ~2-GiB filter tile at a time inside every forward (SURVEY section 7's fall-back; PlainModelWoPad's fc3 with all eight primes of n = 16384 is 419 GB)
     bool streamed = false;
     std::shared_ptr<DeviceBuffer> d_plain, d_wtile, d_ytile;
-    int w_form = CRC_NTT;                                   // CRC_NTTP / CRC_NTTL once Network::forward has put the weights into their MAC kernel's operand form
+    int w_form = CRC_NTT;                                   // CRC_NTTP / CRC_NTTL / CRC_NTTL1 once Network::forward has put the weights into their MAC kernel's operand form
+    std::shared_ptr<DeviceBuffer> d_w_canon;                // CRC_NTTL1 only: the canonical NTT-form weights
     void upload();
     void packWeights(bool unpack);
     bool limbWeights(int B);                                // -> CRC_NTTL (matrix-core kernel) when the layer qualifies (for batches of B) and HBM has room for the second copy
