@@ -101,3 +101,12 @@ def test_bench_chunk_matches_reference():
     g, O, sk, out, _ = run_net("tiny4096_t32", resident=True, batch=32)
     bad = [b for b in range(32) if sha(out[b]) != g["out_sha256"]]
     assert not bad, bad
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, "net_wopad16384k8_t44.json")), reason="needs the n=16384 k=8 golden")
+def test_all_eight_primes_match_reference():
+    """PlainModelWoPad at n = 16384 with all EIGHT primes of coeff_modulus_128(16384) -- the coefficient modulus CrCNN's own setParameters picks (globals.cpp) -- and
+    t = 2^44 >= q_i / 2^11 (the slow plain lift).  fc3's NTT-form weights (419 GB) do not fit: the layer streams coefficient-form plaintexts (netrun stream_share).
+    One image, NTT-resident: the compiled reference's ciphertext (an hour of CPU time in oracle/make_golden_nets.py)"""
+    g, O, sk, out, _ = run_net("wopad16384k8_t44", resident=True, batch=1)
+    assert sha(out[0]) == g["out_sha256"]
