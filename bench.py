@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+INT8_PEAK_TOPS = 5000.0        # dense int8 MFMA peak: 2x the ~2.5 PF bf16 rate per clock (MI355X_MICROARCH.md, matrix cores; no sparsity)
 
 CONFIGS = {
     # BASELINE.json configs[1]: PlainModelTiny.h5, n=4096, batch=1024 on one MI355X  (q = coeff_modulus_128(4096), t = 2^20)
@@ -552,12 +553,14 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
                                f"(limb_pack_tensor + mfma_mac_kernel + conversion) takes {layer_ms:.2f} ms inside the timed region")
             except Exception as ex:          # keep the layer-level figure
                 kernel_note = f"kernel-only timing failed ({type(ex).__name__}); launch_ms is the whole layer call"
+        if kernel_note is None and p.get("w_form") == ca.NTTL:
+            kernel_note = "HIP events around the layer call inside the timed region: mfma_mac_kernel + the slot-major -> next-layer conversion of its result (about 3 % of the call); the input arrives in limb form from the layer in front"
         achieved = alg_bytes / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
         macs_launch = layer_macs(kind, a) * C
         # HBM traffic of that launch: rocprofv3 PMC passes (FETCH_SIZE corrected x2 for gfx950, WRITE_SIZE) collected OFFLINE with
         # tools/bench_mac.py and committed under profiles/ -- bench.py cannot run the profiler on itself, so this is not measured in this run
         traffic, traffic_source = None, None
-        kname = "mfma_mac_kernel" if p.get("w_form") == ca.NTTL else "mac3_kernel"
+        kname = "mfma_mac_kernel" if p.get("w_form") == ca.NTTL else "mfma_conv1_kernel" if p.get("w_form") == ca.NTTL1 else "mac3_kernel"
         kernel_label = f"{kname} ({name}, {C} images/launch)" if kind in ("conv", "fc") else f"{kind} ({name})"
         for pf in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
@@ -567,10 +570,18 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
                     break
             except Exception:
                 pass
-        roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
-                        traffic_source=traffic_source, kernel=kernel_label, kernel_timing=kernel_note, launch_ms=round(float(dur_ms), 3), layer_call_ms=round(float(layer_ms), 3),
-                        algorithmic_bytes_per_launch=int(alg_bytes),
-                        modmul_per_s=round(macs_launch * 2 * E.k * E.n / (dur_ms * 1e-3), 1) if dur_ms > 0 and macs_launch else None)
+        modmul_s = macs_launch * 2 * E.k * E.n / (dur_ms * 1e-3) if dur_ms > 0 and macs_launch else None
+        if kname == "mfma_mac_kernel" and modmul_s:
+            # the matrix-core kernel is bound by the int8 MFMA rate, not by HBM: 49 limb products (98 int8 operations) per modular multiply-add, against the dense
+            # int8 peak (2x the bf16 rate per clock: MI355X_MICROARCH.md, matrix cores).  The HBM view of the same launch stays beside it
+            tops = modmul_s * 98 / 1e12
+            roofline = dict(bound="mfma", achieved=round(tops, 1), peak=INT8_PEAK_TOPS, unit="TFLOP/s", frac=round(tops / INT8_PEAK_TOPS, 5), traffic=traffic,
+                            ops="int8 multiply and add, 98 per modular multiply-add (7 x 7 balanced base-256 limb products); algorithmic = the layer's ct x pt multiply-adds x 2 polys x k n",
+                            hbm_achieved_GBps=round(achieved, 2), hbm_frac=round(achieved / HBM_PEAK_GBS, 5))
+        else:
+            roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic)
+        roofline.update(traffic_source=traffic_source, kernel=kernel_label, kernel_timing=kernel_note, launch_ms=round(float(dur_ms), 3), layer_call_ms=round(float(layer_ms), 3),
+                        algorithmic_bytes_per_launch=int(alg_bytes), modmul_per_s=round(modmul_s, 1) if modmul_s else None)
         cpu = None
         if full and args.cpu_seconds > 0:
             x0 = x_all[0].cpu().numpy().view(np.uint64).reshape(1, 28, 28, 2, E.k, E.n)
@@ -591,8 +602,9 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
             "config": {"workload": f"{model}.h5 n={cfg['n']} k={cfg['k']} t=2^{cfg['t'].bit_length() - 1} batch={B}/GPU chunk={C} ({cfg_name}, BASELINE configs)",
                        "mode": args.mode + ("+conv/pool folding" if want_fuse else ""), "parallelism": f"image-sharded x{world}, RCCL weight broadcast"},
             "ms_per_layer": ms_per_layer,
-            "mac_kernel_per_layer": {pl[1]: ("mfma_mac_kernel (int8 limb GEMM, CRC_NTTL)" if pl[3].get("w_form") == ca.NTTL else "mac3_kernel (v_mad_u64_u32, CRC_NTTP)")
-                                     for pl in net.plan if pl[0] in ("conv", "fc")},
+            "mac_kernel_per_layer": {pl[1]: ("mfma_mac_kernel (int8 limb GEMM, CRC_NTTL)" if pl[3].get("w_form") == ca.NTTL else
+                                             "mfma_conv1_kernel (one-channel convolution on the matrix cores, CRC_NTTL1)" if pl[3].get("w_form") == ca.NTTL1 else
+                                             "mac3_kernel (v_mad_u64_u32, CRC_NTTP)") for pl in net.plan if pl[0] in ("conv", "fc")},
             "reference_layer_structure": unfused, "roofline": roofline, "cpu_baseline": cpu,
             "check": {"tiled_outputs_identical": bool(ok_tile), "predictions_match_plain_model": f"{preds_ok}/{D}", "max_logit_abs_err": round(max_err, 6),
                       "noise_budget_bits": budgets, "ranks_verified": f"{ranks_ok}/{world}", "golden_match": gold_ok, "golden": gold_name, "c1_images_match_reference": c1_ok, "all_ok": bool(all_ok)},

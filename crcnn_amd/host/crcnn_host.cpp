@@ -335,7 +335,7 @@ static bool toLimb(shared_ptr<DeviceBuffer> &d_w, int &w_form, int nf, int zd, i
 {
     if (w_form == CRC_NTTL) return true;
     if (rows < 32) return false;                            // less than half a 64-row tile per launch: mostly padding, the vector-ALU kernel is faster
-    if (zd < 16 || (zd + 31) / 32 * xf * yf < 16 || !crc_limb_supported(ctx(), zd, xf, yf)) return false;
+    if (zd < 16 || (zd + 31) / 32 * xf * yf < 8 || !crc_limb_supported(ctx(), zd, xf, yf)) return false;
     const size_t nbytes = crc_limb_weights_bytes(ctx(), nf, zd, xf, yf);
     size_t free_b = 0, total_b = 0;
     chk(crc_mem_info(ctx(), &free_b, &total_b), "crc_mem_info");

@@ -224,7 +224,7 @@ public:
     // the accelerated path, so it is a setting here: 6 reproduces the committed reference, -1 (default) never refreshes.
     int layer_before_reenc = -1;
     bool ntt_resident = true;                               // keep tensors in NTT form between linear layers (bit-identical)
-    // conv / dense layers with long reductions (>= 16 steps of 32 channels) run as an int8 limb GEMM on the matrix cores (CRC_NTTL, kernels_mfma.hip):
+    // conv / dense layers with long reductions (>= 8 steps of 32 channels) run as an int8 limb GEMM on the matrix cores (CRC_NTTL, kernels_mfma.hip):
     // exact integer arithmetic, identical ciphertexts, about 4x the vector-ALU kernel.  The conversion of a layer's weights drops their canonical copy,
     // so fuse() and broadcastParameters() must come before the first forward().
     bool matrix_cores = true;

@@ -130,15 +130,16 @@ class Network:
     # ---- operand form of the MAC kernels (CRC_NTTP: 28-bit limb pairs): weights are packed once, and a conv / dense layer that feeds
     # another one hands its output over packed, so that no kernel has to split a residue again (+12 % on the conv / dense layers)
     def limb_eligible(self, kind, a):
-        """long reductions go to the matrix-core kernel: at least 16 reduction steps of 32 channels (below that its fixed costs per output tile -- ring fill,
-        13-diagonal reduction, layout conversions -- and the channel padding eat the gain: ApproxPlainModel's conv2, 9 steps of 20/32 channels, ties mac3_kernel)"""
+        """reductions of at least 8 steps of 32 channels go to the matrix-core kernel (below that its fixed costs per output tile -- ring fill, the reduction of 13
+        diagonals, layout conversions -- and the channel padding eat the gain).  ApproxPlainModel's conv2, 9 steps of 20/32 channels and 50/64 filters, runs 1.6x
+        faster there than on mac3_kernel once conv1 hands it the limb tensor (1.58 vs 2.57 ms per image at n = 8192, k = 3)"""
         if kind == "conv":
             zd, xf, yf = a["zd"], a["xf"], a["yf"]
         elif kind == "fc":
             zd, xf, yf = a["in_dim"], 1, 1
         else:
             return False
-        return self.limb and zd >= 16 and -(-zd // 32) * xf * yf >= 16 and self.E.limb_supported(zd, xf, yf)
+        return self.limb and zd >= 16 and -(-zd // 32) * xf * yf >= int(os.environ.get("CRC_MFMA_MIN_STEPS", "8")) and self.E.limb_supported(zd, xf, yf)
 
     def conv1_eligible(self, kind, a):
         """one-channel convolutions (conv1, alone or with its pooling layer folded in) have their own matrix-core kernel (kernels_mfma1.hip)"""

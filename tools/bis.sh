@@ -1,10 +1,11 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python bench.py --config wopad16384k8 --also none --steps 1 --batch 32 --cpu-seconds 0 > gpurun_out/bench_k8.json 2> gpurun_out/bench_k8.err
+for ms in 16 8; do
+CRC_MFMA_MIN_STEPS=$ms timeout -k 10 400 python bench.py --config approx8192 --also none --cpu-seconds 0 --unfused-images 0 --batch 256 > gpurun_out/bis_a$ms.json 2> gpurun_out/bis_a$ms.err
 python - <<PY
 import json
-for l in open('gpurun_out/bench_k8.json'):
+for l in open('gpurun_out/bis_a$ms.json'):
     if l.startswith('{'):
-        d=json.loads(l); print('k8', d['value'], d['check'], d['ms_per_layer'], d['config'])
+        d=json.loads(l); print('$ms', d['value'], d['check']['all_ok'], d['check']['golden_match'], d['ms_per_layer'])
 PY
-tail -3 gpurun_out/bench_k8.err
-timeout -k 10 900 python -m pytest tests/test_gpu_nets.py -x -q -k eight_primes 2>&1 | tail -3
+tail -2 gpurun_out/bis_a$ms.err
+done
