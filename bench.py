@@ -371,7 +371,7 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
     img_bytes = 784 * ctw * 8
     free_b, total_b = torch.cuda.mem_get_info(dev)
     est_weights = sum((a_.get("nf", 0) * a_.get("zd", 0) * a_.get("xf", 0) * a_.get("yf", 0) + a_.get("in_dim", 0) * a_.get("out_dim", 0)) for _, _, a_ in TOPOLOGIES[model]) * E.k * E.n * 8
-    budget = max(img_bytes * C, int(0.45 * (free_b - 1.25 * est_weights)))
+    budget = max(img_bytes * C, int(0.45 * (free_b - 2.3 * est_weights)))          # (2.3: the limb copy of the weights is built beside the canonical one)
     step_w = C * D // np.gcd(C, D)                      # window must be a multiple of the chunk and of the tiling period
     window = min(B, max(step_w, (budget // img_bytes) // step_w * step_w)) if budget // img_bytes < B else B
     x_all = alloc(window * img_bytes).view(window, 784 * ctw)
@@ -604,7 +604,8 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
             "ms_per_layer": ms_per_layer,
             "mac_kernel_per_layer": {pl[1]: ("mfma_mac_kernel (int8 limb GEMM, CRC_NTTL)" if pl[3].get("w_form") == ca.NTTL else
                                              "mfma_conv1_kernel (one-channel convolution on the matrix cores, CRC_NTTL1)" if pl[3].get("w_form") == ca.NTTL1 else
-                                             "mac3_kernel (v_mad_u64_u32, CRC_NTTP)") for pl in net.plan if pl[0] in ("conv", "fc")},
+                                             "mac3_kernel (v_mad_u64_u32, CRC_NTTP)" + (", streamed weights" if pl[3].get("streamed") else "") +
+                                             (f" [{pl[3]['limb_skipped']}]" if pl[3].get("limb_skipped") else "")) for pl in net.plan if pl[0] in ("conv", "fc")},
             "reference_layer_structure": unfused, "roofline": roofline, "cpu_baseline": cpu,
             "check": {"tiled_outputs_identical": bool(ok_tile), "predictions_match_plain_model": f"{preds_ok}/{D}", "max_logit_abs_err": round(max_err, 6),
                       "noise_budget_bits": budgets, "ranks_verified": f"{ranks_ok}/{world}", "golden_match": gold_ok, "golden": gold_name, "c1_images_match_reference": c1_ok, "all_ok": bool(all_ok)},

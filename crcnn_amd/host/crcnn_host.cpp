@@ -300,7 +300,7 @@ static bool tooLargeForHbm(size_t weights)
     size_t free_b = 0, total_b = 0;
     chk(crc_mem_info(ctx(), &free_b, &total_b), "crc_mem_info");
     const char *e = getenv("CRC_STREAM_SHARE");                 // (tests force streaming on small rings with a tiny share, as netrun.py does)
-    const double share = e ? atof(e) : 0.45;
+    const double share = e ? atof(e) : 0.75;
     return (double)weights * K() * N() * 8 > share * (double)total_b;
 }
 // a streamed layer: lift + NTT a tile of filters, run the layer on the tile, scatter the tile's output channels into the [B][F][P] tensor

@@ -117,7 +117,7 @@ public:
     void printLayerStructure() override;
 private:
     std::shared_ptr<DeviceBuffer> d_w, d_b[2], d_work;      // NTT-form weights, bias delta in coefficient / NTT form
-    // weights whose NTT form (k rows each) would take more than 45 % of HBM stay coefficient-form plaintexts (ONE row each) and are lifted + transformed a
+    // weights whose NTT form (k rows each) would take more than 75 % of HBM stay coefficient-form plaintexts (ONE row each) and are lifted + transformed a
     // ~2-GiB filter tile at a time inside every forward (SURVEY section 7's fall-back; PlainModelWoPad's fc3 with all eight primes of n = 16384 is 419 GB)
     bool streamed = false;
     std::shared_ptr<DeviceBuffer> d_plain, d_wtile, d_ytile;

@@ -75,7 +75,7 @@ class Network:
         # a conv / dense layer whose NTT-form weights (k rows per weight) would take more than this share of HBM keeps its weights as coefficient-form plaintexts
         # (ONE row per weight) and lifts + NTTs them a filter tile at a time inside every forward (SURVEY section 7's fall-back: PlainModelWoPad's fc3 at n = 16384,
         # k = 8 is 419 GB in NTT form, 52 GB as plaintexts).  Same ciphertexts; the price is k row transforms per weight and chunk.
-        self.stream_share = float(os.environ.get("CRC_STREAM_SHARE", "0.45"))
+        self.stream_share = float(os.environ.get("CRC_STREAM_SHARE", "0.75"))
         self.limb_reserve = 24 << 30          # HBM to leave free when a limb copy of the weights is made (activations + work space come later)
         self.alloc = alloc or eng.alloc
         self.resident = resident            # keep tensors NTT-resident between layers (bit-identical)
@@ -172,6 +172,7 @@ class Network:
             nbytes = E.limb_weights_bytes(nf, zd, xf, yf)
             # the limb copy is built beside the canonical one: a layer whose two copies do not fit in HBM stays on the vector-ALU kernel
             if E.mem_info()[0] < nbytes + self.limb_reserve:
+                p["limb_skipped"] = f"limb copy of {nbytes >> 30} GiB + {self.limb_reserve >> 30} GiB reserve > {E.mem_info()[0] >> 30} GiB free"
                 continue
             wl = self.alloc(nbytes)
             E.limb_pack_weights(p["w"], nf, zd, xf, yf, wl)

@@ -1,11 +1,11 @@
 cd $GRAFT_REPO_ROOT
-for ms in 16 8; do
-CRC_MFMA_MIN_STEPS=$ms timeout -k 10 400 python bench.py --config approx8192 --also none --cpu-seconds 0 --unfused-images 0 --batch 256 > gpurun_out/bis_a$ms.json 2> gpurun_out/bis_a$ms.err
+timeout -k 10 500 python bench.py --config approx8192 --also none --steps 2 --cpu-seconds 0 > gpurun_out/bis_a.json 2> gpurun_out/bis_a.err
+timeout -k 10 500 python bench.py --config wopad16384 --also none --steps 1 --batch 96 --cpu-seconds 0 > gpurun_out/bis_w.json 2> gpurun_out/bis_w.err
 python - <<PY
 import json
-for l in open('gpurun_out/bis_a$ms.json'):
+for f in ('a','w'):
+  for l in open('gpurun_out/bis_%s.json'%f):
     if l.startswith('{'):
-        d=json.loads(l); print('$ms', d['value'], d['check']['all_ok'], d['check']['golden_match'], d['ms_per_layer'])
+        d=json.loads(l); print(f, d['value'], d['check']['all_ok'], d['check']['golden_match'], d['ms_per_layer'], d['mac_kernel_per_layer'])
 PY
-tail -2 gpurun_out/bis_a$ms.err
-done
+tail -n 2 gpurun_out/bis_a.err gpurun_out/bis_w.err
