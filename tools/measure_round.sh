@@ -7,11 +7,17 @@ timeout -k 10 500 python bench.py --steps 5 --warmup 1 > $O/bench_tiny4096.json 
 timeout -k 10 500 python bench.py --config approx8192 --also none --steps 2 > $O/bench_approx8192.json 2> $O/bench_approx8192.err
 timeout -k 10 500 python bench.py --config approx8192k4 --also none --steps 1 --batch 256 > $O/bench_approx8192k4_b256.json 2> $O/bench_approx8192k4.err
 timeout -k 10 500 python bench.py --config wopad16384 --also none --steps 1 --batch 96 > $O/bench_wopad16384_b96.json 2> $O/bench_wopad.err
+timeout -k 10 500 python bench.py --config wopad16384k8 --also none --steps 1 --batch 32 --cpu-seconds 0 > $O/bench_wopad16384k8_b32.json 2> $O/bench_wopadk8.err
 fi
 if [ $P = all ] || [ $P = prof ]; then
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_tiny -o tiny -- python3 bench.py --cpu-seconds 0 --unfused-images 0 --also none --batch 256 > $O/prof_tiny.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_approx -o approx -- python3 bench.py --config approx8192 --batch 96 --cpu-seconds 0 --unfused-images 0 --also none > $O/prof_approx.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_sq -o sq -- python3 tools/bench_square.py 8192 3 1250 > $O/prof_sq.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c1 -o c1 -- python3 tools/check_conv1.py 4096 2 32 tiny > $O/prof_c1.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_c1_fetch -o f -- python3 tools/check_conv1.py 4096 2 32 tiny > $O/pmc_c1_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_c1_write -o w -- python3 tools/check_conv1.py 4096 2 32 tiny > $O/pmc_c1_write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq -o s -- python3 tools/bench_mac.py conv2p 32 1 limbk > $O/pmc_sq.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_grbm -o g -- python3 tools/bench_mac.py conv2p 32 1 limbk > $O/pmc_grbm.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 tools/bench_mac.py conv2p 32 1 limbk > $O/pmc_fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 tools/bench_mac.py conv2p 32 1 limbk > $O/pmc_write.log 2>&1
 fi
@@ -20,7 +26,8 @@ if [ $P = all ] || [ $P = micro ]; then
 (python tools/bench_square.py 8192 3 1250; python tools/bench_square.py 16384 4 512; python tools/bench_square.py 8192 3 1250 0 0; python tools/bench_square.py 8192 4 1250) > $O/square.txt 2>&1
 rm -f $O/mac_geometries.txt
 for g in conv1 conv1p conv2 conv2p fc3 aconv1 aconv2 afc3; do python tools/bench_mac.py $g 32 2 packed 2>&1 | grep -v amdgpu >> $O/mac_geometries.txt; done
+(python tools/check_conv1.py 4096 2 32 tiny; python tools/check_conv1.py 8192 3 16 approx) 2>&1 | grep -v "amdgpu\|^[EW]2" > $O/conv1.txt
+(timeout -k 10 120 ./tools/mfma_shape; timeout -k 10 120 ./tools/mfma_shape zeros) > $O/mfma_shape.txt 2>&1
 for g in conv2p fc3 aconv2 afc3; do python tools/bench_mac.py $g 32 2 limb 2>&1 | grep -v amdgpu >> $O/mac_geometries.txt; python tools/bench_mac.py $g 32 2 limbk 2>&1 | grep -v amdgpu >> $O/mac_geometries.txt; done
-python tools/bench_mfma.py 4096 2 24 > $O/mfma_proto.txt 2>&1
 fi
 ls $O
