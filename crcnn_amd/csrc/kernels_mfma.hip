@@ -5,19 +5,21 @@
 //       Y[m][f] = sum_t A[m][t] W[t][f]        m = (image, output pixel, poly),  t = (tap, channel),
 // and the integer MFMA unit does exact int8 x int8 -> int32 dot products 49x faster than that.  Every residue r < q < 2^55 is written as its centred
 // representative r' in (-q/2, q/2] (same class mod q) in balanced base 256,  r' = sum_{l<7} d_l 256^l, d_l in [-128, 127] (|d_6| <= 64).  Then
-// x w = sum_{l,m} a_l b_m 256^(l+m): 49 limb products on 13 diagonals l+m.  One v_mfma_i32_32x32x32_i8 forms a 32 x 32 tile of 32-term dot products
+// x w = sum_{l,m} a_l b_m 256^(l+m): 49 limb products on 13 diagonals l+m.  One v_mfma_i32_16x16x64_i8 forms a 16 x 16 tile of 64-term dot products
 // of one (l, m) pair into diagonal l+m's int32 accumulator -- exact while T 7 128^2 < 2^31 (T <= 18 000).  After the reduction loop
-// V = sum_d D_d 2^(8d) is reduced mod q ONCE per output.  Exact integer arithmetic, the same element of Z_q, hence the same bits as the reference
-// (convolutionalLayer.cpp:56-93 / fullyConnectedLayer.cpp:113-168) and as mac3_kernel; measured 4x faster on CrCNN's conv2+pool2 (profiles/r02_*).
+// V = sum_d D_d 2^(8d) is reduced mod q ONCE per output (diag_reduce: biased accumulators, one Montgomery step; the weights carry 2^64 mod q).  Exact integer
+// arithmetic, the same element of Z_q, hence the same bits as the reference (convolutionalLayer.cpp:56-93 / fullyConnectedLayer.cpp:113-168) and as mac3_kernel;
+// measured 4x faster on CrCNN's conv2+pool2 (profiles/r02_*).
 //
 // Layouts (CRC_NTTL, "limb form"; slot = i*n + s).  The GEMMs of different slots share nothing, so operands are SLOT-MAJOR here (the rest of the engine
 // is slot-minor: one row = n slots of one residue):
 //     tensor   Xl [slot][B][7 planes][positions][2 polys][zdp]          int8, zdp = channels rounded up to 32 (zero padded)
-//     weights  Wl [slot][reduction step = (tap, 32-channel block)][7 planes][Fp][32]   int8, Fp = filters rounded up to 64 (zero padded)
+//     weights  Wl [slot][reduction step = (tap, 32-channel block)][7 planes][Fp][32]   int8, Fp = filters rounded up to 64 (zero padded), an odd number of
+//                 steps rounded up to even with a zero step; every weight times 2^64 mod q
 //     result   Ys [slot][B][F][P][2] u64 canonical (internal), then transposed to the slot-minor tensor layout or re-limbed for a dense consumer
-// Workgroup = one slot, 64 rows x 64 filters: 4 waves (one per SIMD), a 32 x 32 tile and 13 x 16 int32 accumulators (208 AGPRs) each.  Per reduction
-// step the workgroup stages 64 x 32 B x 7 planes of A -- implicit im2col: each lane's LDS-DMA piece reads its own (pixel + tap) address, no patch
-// matrix exists -- and as much of W (contiguous) into a 4-slot LDS ring (112 KiB), three steps ahead of use; 49 MFMAs per wave and step.
+// Workgroup = one slot, 64 rows x 64 filters: 4 waves (one per SIMD), a 32 x 32 tile = 2 x 2 sub-tiles x 13 diagonals x 4 int32 accumulators (208 AGPRs) each.
+// Per 32-term reduction step the workgroup stages 64 x 32 B x 7 planes of A -- implicit im2col: each lane's LDS-DMA piece reads its own (pixel + tap) address, no
+// patch matrix exists -- and as much of W (contiguous) into a 5-slot LDS ring (140 KiB), three steps ahead of use; an MFMA spans two steps: 196 per wave and barrier.
 #include "kernels.h"
 #include <cstdlib>
 
@@ -67,9 +69,10 @@ __device__ __forceinline__ u64 diag_reduce(const int (&D)[13], const ModParams &
     return barrett128(t, 0, m);
 }
 
-// The same layer on v_mfma_i32_16x16x64_i8: a wave's 32 x 32 tile as 2 x 2 sub-tiles, two 32-term reduction steps per instruction.  Same cycles per product as the
-// 32x32x32 form, but the chip holds a higher clock on this shape under random operands (tools/mfma_shape.hip: 3.8 vs 3.5 Pop/s in a bare loop), and twice the work between
-// barriers.  A K group g = lane / 16 of an operand fragment is half (g & 1) of ring slot 2d + (g >> 1): the staging is the 32x32x32 kernel's, one slot per 32-term step.
+// v_mfma_i32_16x16x64_i8: a wave's 32 x 32 tile as 2 x 2 sub-tiles, two 32-term reduction steps per instruction.  Same cycles per product as v_mfma_i32_32x32x32_i8
+// (this kernel's first form: tools/mfma_mac.hip), but the chip holds a higher clock on this shape under random operands (tools/mfma_shape.hip: 3.6 vs 3.3 Pop/s in a
+// bare loop), and there is twice the work between barriers.  A K group g = lane / 16 of an operand fragment is half (g & 1) of ring slot 2d + (g >> 1): staging stays
+// one slot per 32-term step.
 template <int NST>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) mfma_mac_kernel(MfmaArgs a)
 {
