@@ -1,10 +1,20 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 500 python bench.py --config approx8192 --also none --steps 2 --cpu-seconds 0 > gpurun_out/bis_a.json 2> gpurun_out/bis_a.err
+for ch in 32 64 128; do
+timeout -k 10 400 python bench.py --cpu-seconds 0 --also none --unfused-images 0 --chunk $ch --steps 3 > gpurun_out/bis_$ch.json 2> gpurun_out/bis_$ch.err
 python - <<PY
 import json
-for f in ('a',):
-  for l in open('gpurun_out/bis_%s.json'%f):
+for l in open('gpurun_out/bis_$ch.json'):
     if l.startswith('{'):
-        d=json.loads(l); print(f, d['value'], d['check']['all_ok'], d['check']['golden_match'], d['ms_per_layer'], d['mac_kernel_per_layer'], d['data'])
+        d=json.loads(l); print('$ch', d['value'], d['check']['all_ok'], d['ms_per_layer'])
 PY
-tail -n 2 gpurun_out/bis_a.err
+done
+for ch in 64; do
+timeout -k 10 400 python bench.py --config approx8192 --cpu-seconds 0 --also none --unfused-images 0 --chunk $ch --steps 1 > gpurun_out/bis_a$ch.json 2> gpurun_out/bis_a$ch.err
+python - <<PY
+import json
+for l in open('gpurun_out/bis_a$ch.json'):
+    if l.startswith('{'):
+        d=json.loads(l); print('approx $ch', d['value'], d['check']['all_ok'], d['ms_per_layer'])
+PY
+tail -n 2 gpurun_out/bis_a$ch.err
+done

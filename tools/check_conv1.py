@@ -18,9 +18,12 @@ def rows(r):
     return out
 xo, yo = (xd - xf) // xs + 1, (yd - yf) // ys + 1
 x1 = rows(xd * yd * 2)
-x = np.ascontiguousarray(np.broadcast_to(x1[None], (B,) + x1.shape)).reshape(-1, E.k, E.n)
 w = rows(nf * xf * yf); b = rows(nf)
-d_x, d_w, d_b = E.upload(x), E.upload(w), E.upload(b)
+d_x1, d_w, d_b = E.upload(x1), E.upload(w), E.upload(b)
+d_x = E.alloc(B * x1.nbytes)                      # the same image B times (replicated on the device)
+for bb in range(B):
+    E.L.crc_memcpy_d2d(E.c, E.p(d_x) + bb * x1.nbytes, E.p(d_x1), x1.nbytes, E.stream)
+E.sync()
 rows_y = B * nf * xo * yo * 2 * E.k
 d_y0 = E.alloc(rows_y * E.n * 8)
 d_work = E.alloc(E.conv2d_work_bytes(B, 1, xd, yd, xs, ys, xf, yf, nf, ca.NTT))

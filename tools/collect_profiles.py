@@ -17,7 +17,7 @@ for c in ("tiny4096", "approx8192", "approx8192k4_b256", "wopad16384_b96", "wopa
 cp("prof_tiny/tiny_kernel_stats.csv", "bench_tiny4096_b256_kernel_stats.csv")
 cp("prof_approx/approx_kernel_stats.csv", "bench_approx8192_b96_kernel_stats.csv")
 cp("prof_sq/sq_kernel_stats.csv", "square_relin_8192k3_kernel_stats.csv")
-cp("prof_c1/c1_kernel_stats.csv", "conv1_4096k2_b32_kernel_stats.csv")
+cp("prof_c1/c1_kernel_stats.csv", "conv1_4096k2_b128_kernel_stats.csv")
 for src, dst in (("ntt_elementwise.txt", "ntt_elementwise_kernels.txt"), ("mac_geometries.txt", "mac_geometries.txt"), ("conv1.txt", "conv1_kernel.txt"), ("mfma_shape.txt", "mfma_shape.txt"),
                  ("square.txt", "square_relin_raw.txt")):
     if os.path.exists(os.path.join(F, src)):
@@ -43,19 +43,19 @@ try:
         w, _ = tot(os.path.join(F, "pmc_write/w_counter_collection.csv"), "WRITE_SIZE", kern)
         d[kern] = dict(fetch_bytes=f * 2048, write_bytes=w * 1024, traffic_bytes=f * 2048 + w * 1024, launch_ms_under_pmc=round(ms, 3))
     m = d["mfma_mac_kernel"]
-    out["tiny4096"] = {"kernel": "mfma_mac_kernel (pool2_features.conv2+pool2, 32 images/launch)", **m, "other_kernels_of_the_layer_call": {k: v for k, v in d.items() if k != "mfma_mac_kernel"},
-                       "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/measure_round.sh prof) on `tools/bench_mac.py conv2p 32 1 limbk` = the conv2+pool2 launch "
-                               "of the bench at chunk 32 on a limb-form input; counters are KiB; FETCH_SIZE doubled (gfx950 reports half the bytes of coalesced 16-B-per-lane reads, "
-                               "global_load and LDS-DMA alike: MI355X_MICROARCH.md).  Algorithmic bytes of the launch in limb form: 16.9 GB tensor + 4.2 GB weights + 4.3 GB result = 25.4 GB"}
-    # the same for the one-channel convolution (tools/check_conv1.py: last launches = the limb-tensor output of 32 images) and the issue / wait split of mfma_mac_kernel
+    out["tiny4096"] = {"kernel": "mfma_mac_kernel (pool2_features.conv2+pool2, 128 images/launch)", **m, "other_kernels_of_the_layer_call": {k: v for k, v in d.items() if k != "mfma_mac_kernel"},
+                       "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/measure_round.sh prof) on `tools/bench_mac.py conv2p 128 1 limbk` = the conv2+pool2 launch "
+                               "of the bench at chunk 128 on a limb-form input; counters are KiB; FETCH_SIZE doubled (gfx950 reports half the bytes of coalesced 16-B-per-lane reads, "
+                               "global_load and LDS-DMA alike: MI355X_MICROARCH.md).  Algorithmic bytes of the launch in limb form: 67.6 GB tensor + 4.2 GB weights + 17.2 GB result = 89 GB"}
+    # the same for the one-channel convolution (tools/check_conv1.py: last launches = the limb-tensor output of 128 images) and the issue / wait split of mfma_mac_kernel
     try:
         c1 = {}
         for kern in ("mfma_conv1_kernel", "limb_pack_rows1_kernel"):
             f, ms = tot(os.path.join(F, "pmc_c1_fetch/f_counter_collection.csv"), "FETCH_SIZE", kern)
             w, _ = tot(os.path.join(F, "pmc_c1_write/w_counter_collection.csv"), "WRITE_SIZE", kern)
             c1[kern] = dict(fetch_bytes=f * 2048, write_bytes=w * 1024, traffic_bytes=f * 2048 + w * 1024, launch_ms_under_pmc=round(ms, 3))
-        out["tiny4096_conv1"] = {"kernel": "mfma_conv1_kernel (pool1_features.conv1+pool1, 32 images/launch, limb-tensor output)", **c1["mfma_conv1_kernel"], "limb_pack_rows1_kernel": c1["limb_pack_rows1_kernel"],
-                                 "note": "algorithmic: 3.3 GB limb images in, 16.9 GB limb tensor out (mfma_conv1_kernel); 3.3 GB NTT-form images in, 3.3 GB limb images out (limb_pack_rows1_kernel)"}
+        out["tiny4096_conv1"] = {"kernel": "mfma_conv1_kernel (pool1_features.conv1+pool1, 128 images/launch, limb-tensor output)", **c1["mfma_conv1_kernel"], "limb_pack_rows1_kernel": c1["limb_pack_rows1_kernel"],
+                                 "note": "algorithmic: 13.2 GB limb images in, 67.6 GB limb tensor out (mfma_conv1_kernel); 13.2 GB NTT-form images in, 13.2 GB limb images out (limb_pack_rows1_kernel)"}
         sq = {}
         for cn in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_BUSY_CYCLES"):
             sq[cn], ms = tot(os.path.join(F, "pmc_sq/s_counter_collection.csv"), cn, "mfma_mac_kernel")

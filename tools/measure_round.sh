@@ -13,13 +13,13 @@ if [ $P = all ] || [ $P = prof ]; then
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_tiny -o tiny -- python3 bench.py --cpu-seconds 0 --unfused-images 0 --also none --batch 256 > $O/prof_tiny.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_approx -o approx -- python3 bench.py --config approx8192 --batch 96 --cpu-seconds 0 --unfused-images 0 --also none > $O/prof_approx.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_sq -o sq -- python3 tools/bench_square.py 8192 3 1250 > $O/prof_sq.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c1 -o c1 -- python3 tools/check_conv1.py 4096 2 32 tiny > $O/prof_c1.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_c1_fetch -o f -- python3 tools/check_conv1.py 4096 2 32 tiny > $O/pmc_c1_fetch.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_c1_write -o w -- python3 tools/check_conv1.py 4096 2 32 tiny > $O/pmc_c1_write.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq -o s -- python3 tools/bench_mac.py conv2p 32 1 limbk > $O/pmc_sq.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_grbm -o g -- python3 tools/bench_mac.py conv2p 32 1 limbk > $O/pmc_grbm.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 tools/bench_mac.py conv2p 32 1 limbk > $O/pmc_fetch.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 tools/bench_mac.py conv2p 32 1 limbk > $O/pmc_write.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c1 -o c1 -- python3 tools/check_conv1.py 4096 2 128 tiny > $O/prof_c1.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_c1_fetch -o f -- python3 tools/check_conv1.py 4096 2 128 tiny > $O/pmc_c1_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_c1_write -o w -- python3 tools/check_conv1.py 4096 2 128 tiny > $O/pmc_c1_write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq -o s -- python3 tools/bench_mac.py conv2p 128 1 limbk > $O/pmc_sq.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_grbm -o g -- python3 tools/bench_mac.py conv2p 128 1 limbk > $O/pmc_grbm.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 tools/bench_mac.py conv2p 128 1 limbk > $O/pmc_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 tools/bench_mac.py conv2p 128 1 limbk > $O/pmc_write.log 2>&1
 fi
 if [ $P = all ] || [ $P = micro ]; then
 (python tools/bench_ntt.py 4096 2 8192; python tools/bench_ntt.py 8192 3 4096; python tools/bench_ntt.py 16384 4 1024) > $O/ntt_elementwise.txt 2>&1
