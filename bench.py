@@ -418,13 +418,14 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
     unfused = None
     want_fuse = args.mode == "resident" and not args.no_fuse
     if want_fuse and full and args.unfused_images > 0:
-        nu = min(B, max(C, args.unfused_images // C * C))
-        net.prepare(C, limb=False)                     # (the limb conversion drops the canonical weights fuse() needs; it happens in the final prepare)
+        Cu = min(C, 32)                                # the unfused conv1 output is 18 432 ciphertexts per image (Tiny): a smaller chunk than the main pass
+        nu = min(B, max(Cu, args.unfused_images // Cu * Cu))
+        net.prepare(Cu, limb=False)                    # (the limb conversion drops the canonical weights fuse() needs; it happens in the final prepare)
         net.forward(x_all[0], 1); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for c0 in range(0, nu, C):
-            d_out = net.forward(x_all[c0 % window], min(C, nu - c0))
-            E.L.crc_memcpy_d2d(E.c, out_all[c0].data_ptr(), E.p(d_out), min(C, nu - c0) * 10 * ctw * 8, E.stream)
+        for c0 in range(0, nu, Cu):
+            d_out = net.forward(x_all[c0 % window], min(Cu, nu - c0))
+            E.L.crc_memcpy_d2d(E.c, out_all[c0].data_ptr(), E.p(d_out), min(Cu, nu - c0) * 10 * ctw * 8, E.stream)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         unfused = dict(images=nu, images_per_s=round(nu / dt, 3), ms_per_image=round(dt / nu * 1e3, 3), first_outputs=out_all[:min(D, nu)].clone(),

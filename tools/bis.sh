@@ -1,20 +1,11 @@
-cd $GRAFT_REPO_ROOT
-for ch in 32 64 128; do
-timeout -k 10 400 python bench.py --cpu-seconds 0 --also none --unfused-images 0 --chunk $ch --steps 3 > gpurun_out/bis_$ch.json 2> gpurun_out/bis_$ch.err
-python - <<PY
+cd $GRAFT_REPO_ROOT; O=gpurun_out/final; mkdir -p $O
+timeout -k 10 500 python bench.py --steps 5 --warmup 1 > $O/bench_tiny4096.json 2> $O/bench_tiny4096.err
+timeout -k 10 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python3 - <<PY
 import json
-for l in open('gpurun_out/bis_$ch.json'):
-    if l.startswith('{'):
-        d=json.loads(l); print('$ch', d['value'], d['check']['all_ok'], d['ms_per_layer'])
+for f in ("bench_tiny4096","bench_default"):
+    for l in open("gpurun_out/final/%s.json"%f):
+        if l.startswith("{"):
+            d=json.loads(l); print(f, d["value"], d["check"], d["ms_per_layer"], d["roofline"]); print("also", d["also"][0]["value"], d["also"][0]["check"]["all_ok"]); print(d["cpu_baseline"])
 PY
-done
-for ch in 64; do
-timeout -k 10 400 python bench.py --config approx8192 --cpu-seconds 0 --also none --unfused-images 0 --chunk $ch --steps 1 > gpurun_out/bis_a$ch.json 2> gpurun_out/bis_a$ch.err
-python - <<PY
-import json
-for l in open('gpurun_out/bis_a$ch.json'):
-    if l.startswith('{'):
-        d=json.loads(l); print('approx $ch', d['value'], d['check']['all_ok'], d['ms_per_layer'])
-PY
-tail -n 2 gpurun_out/bis_a$ch.err
-done
+tail -n 2 $O/bench_default.err
