@@ -192,8 +192,10 @@ static int conv2d_limb(crc_ctx *c, const uint64_t *d_x, const void *d_wl, const 
         xl = Xl;
     }
     // bias joins in the NTT domain unless the result goes back to coefficient form (then add_plain(bias) rides on the inverse transform's store)
-    RUN(k_limb_mac(c, xl, (const signed char *)d_wl, Ys, out_form != CRC_COEFF ? d_bias : nullptr, B, zd, xd, yd, xs, ys, xf, yf, nf, st));
-    if (out_form == CRC_NTTL) return k_limb_result_to_limb(c, Ys, (signed char *)d_y, B, nf * P, st);     // hand-over to a dense layer: channels = (f, px, py) flattened
+    if (out_form == CRC_NTTL && k_limb_direct_dense(P))         // hand-over to a dense layer (channels = (f, px, py) flattened), written by the kernel itself
+        return k_limb_mac(c, xl, (const signed char *)d_wl, Ys, (signed char *)d_y, d_bias, B, zd, xd, yd, xs, ys, xf, yf, nf, st);
+    RUN(k_limb_mac(c, xl, (const signed char *)d_wl, Ys, nullptr, out_form != CRC_COEFF ? d_bias : nullptr, B, zd, xd, yd, xs, ys, xf, yf, nf, st));
+    if (out_form == CRC_NTTL) return k_limb_result_to_limb(c, Ys, (signed char *)d_y, B, nf * P, st);     // ... or re-limbed from the slot-major result
     RUN(k_limb_result_to_rows(c, Ys, d_y, (size_t)B * nf * P * 2, out_form == CRC_NTTP, st));
     if (out_form == CRC_COEFF) RUN(k_ntt_ct(c, true, d_y, d_y, (size_t)B * nf * P, 2, false, st, d_bias, 1, (size_t)P, nf));
     return CRC_OK;

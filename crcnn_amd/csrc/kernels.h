@@ -40,7 +40,8 @@ int k_limb_pack_tensor(crc_ctx *c, const u64 *x, signed char *xl, int B, int zd,
 int k_limb_pack_weights(crc_ctx *c, const u64 *w, signed char *wl, int nf, int zd, int taps, hipStream_t st);
 int k_limb_result_to_rows(crc_ctx *c, const u64 *ys, u64 *y, size_t rows, bool pack_out, hipStream_t st);
 int k_limb_result_to_limb(crc_ctx *c, const u64 *ys, signed char *xl, int B, int zd, hipStream_t st);
-int k_limb_mac(crc_ctx *c, const signed char *xl, const signed char *wl, u64 *ys, const u64 *bias_ntt, int B, int zd, int xd, int yd, int xs, int ys_, int xf, int yf, int nf,
+bool k_limb_direct_dense(int P);
+int k_limb_mac(crc_ctx *c, const signed char *xl, const signed char *wl, u64 *ys, signed char *xl_out, const u64 *bias_ntt, int B, int zd, int xd, int yd, int xs, int ys_, int xf, int yf, int nf,
                hipStream_t st);
 // kernels_mfma1.hip: one-channel convolutions (conv1 [+ pool1]) on the matrix cores (weight form CRC_NTTL1)
 bool   k_limb_conv1_shape(const crc_ctx *c, int zd, int xd, int yd, int xs, int ys_, int xf, int yf, int nf);

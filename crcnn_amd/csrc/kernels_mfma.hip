@@ -32,6 +32,7 @@ typedef signed char i8;
 
 struct MfmaArgs {
     const i8 *xl; const i8 *wl; u64 *ys; const ModParams *mods; const u64 *bias;     // bias: NTT-form delta rows [F][k][n] added to poly 0, or null
+    i8 *xl_out; int lp2; unsigned zdp_out;             // direct limb result for a dense consumer (2P = 2^lp2 divides 64): [slot][B][7][2][zdp_out], channel = f P + p
     int n, k, B, zdp, npos, yd, xs, ys_, yf, yo, P, F, Fp, zblks, ksteps, M, mtiles, ntiles;      // ksteps: rounded up to even (the weights carry a zero step)
     unsigned img_bytes; unsigned long long wslot_bytes; int ksteps_real;
     int acc0[8][13];                                   // initial value of the 13 diagonal accumulators, per modulus (limb_tables)
@@ -161,15 +162,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         }
     }
     // epilogue: C/D layout of a 16 x 16 tile: col = lane & 15, row = 4 (lane >> 4) + reg.  Row mm = image b, pixel p, poly c (= reg & 1: the row bases are multiples
-    // of 4) lands at Ys[((slot B + b) F + f) 2P + (mm - b 2P)] = Ys[slot B F 2P + b (F - 1) 2P + f 2P + mm]: one division per group of four rows
+    // of 4) lands at Ys[((slot B + b) F + f) 2P + (mm - b 2P)] = Ys[slot B F 2P + b (F - 1) 2P + f 2P + mm]: one division per group of four rows.
+    // With a dense consumer behind (xl_out; 2P = 2^lp2 divides 64, so the tile is 64 / 2P whole images) the balanced digits go straight into that layer's limb tensor
+    // -- channel = f P + p: per image, plane and poly the tile owns one run of 64 P bytes -- staged in the (now idle) ring as [image][plane][poly][64 P] and copied out
+    // in 16-byte pieces: no slot-major u64 result, no conversion kernel (9 % of the conv2+pool2 layer call)
     u64 *yslot = a.ys + (size_t)slot * a.B * a.F * (2 * a.P);
     const u32 P2 = 2 * a.P;
+    const u32 RL = 64 * a.P;                                      // bytes of one run
+    if (a.xl_out) __syncthreads();                                // everybody has read its last fragments: the ring becomes the staging area
 #pragma unroll
     for (int rs = 0; rs < 2; rs++) {
         const u32 mbase = m0 + wm * 32 + rs * 16 + 4 * kg, bb = mbase / P2, rem = mbase - bb * P2;
 #pragma unroll
         for (int cs = 0; cs < 2; cs++) {
-            const int f = f0 + wn * 32 + cs * 16 + r16;
+            const int fl = wn * 32 + cs * 16 + r16, f = f0 + fl;
             const u64 bv = (a.bias && f < a.F) ? a.bias[((size_t)f * a.k + i) * a.n + s] : 0;
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
@@ -178,10 +184,30 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 for (int d = 0; d < 13; d++) D[d] = acc[rs][cs][d][reg];
                 u64 v = diag_reduce(D, m, qinv);
                 if ((reg & 1) == 0) v = addmod(v, bv, m.q);
-                const u32 r = rem + reg, b = bb + (r >= P2) + (r >= 2 * P2);
-                if (mbase + reg < (u32)a.M && f < a.F) yslot[b * (u32)(a.F - 1) * P2 + (u32)f * P2 + mbase + reg] = v;
+                if (a.xl_out) {
+                    const u32 rt = wm * 32 + rs * 16 + 4 * kg + reg, bl = rt >> a.lp2, qq = rt & (P2 - 1);        // row in the tile -> image in the tile, (pixel, poly)
+                    const long long cv = (f < a.F) ? (v > (m.q >> 1) ? (long long)(v - m.q) : (long long)v) : 0;   // filters past F: zero padding of the consumer's channels
+                    const u64 dg = ((u64)cv + 0x0080808080808080ULL) ^ 0x0080808080808080ULL;                     // the 7 balanced digits, one per byte
+                    i8 *sp = lds + (size_t)bl * (NPL * 2 * RL) + (qq & 1) * RL + fl * a.P + (qq >> 1);
+#pragma unroll
+                    for (int l = 0; l < NPL; l++) sp[(size_t)l * (2 * RL)] = (i8)(dg >> (8 * l));
+                } else {
+                    const u32 r = rem + reg, b = bb + (r >= P2) + (r >= 2 * P2);
+                    if (mbase + reg < (u32)a.M && f < a.F) yslot[b * (u32)(a.F - 1) * P2 + (u32)f * P2 + mbase + reg] = v;
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
+    }
+    if (a.xl_out) {
+        __syncthreads();
+        const u32 imgs = 64 >> a.lp2, b0 = (u32)m0 >> a.lp2, per_run = RL / 16, pieces = imgs * NPL * 2 * per_run;
+        const u32 ch0 = (u32)f0 * a.P;                            // first channel of this tile's runs
+        for (u32 o = threadIdx.x; o < pieces; o += 256) {
+            const u32 run = o / per_run, off = (o - run * per_run) * 16, bl = run / (NPL * 2), lc = run - bl * (NPL * 2);       // lc = plane * 2 + poly
+            if (b0 + bl < (u32)a.B && ch0 + off < a.zdp_out)
+                *reinterpret_cast<uint4 *>(a.xl_out + ((size_t)slot * a.B + b0 + bl) * ((size_t)NPL * 2 * a.zdp_out) + (size_t)lc * a.zdp_out + ch0 + off) =
+                    *reinterpret_cast<const uint4 *>(lds + (size_t)run * RL + off);
         }
     }
 }
@@ -386,17 +412,25 @@ int k_limb_result_to_limb(crc_ctx *c, const u64 *ys, i8 *xl, int B, int zd, hipS
     return CRC_OK;
 }
 // the layer: Xl (B images of zd x xd x yd) * Wl -> Ys [slot][B][nf][P][2], + NTT-form bias on poly 0
-int k_limb_mac(crc_ctx *c, const i8 *xl, const i8 *wl, u64 *ys, const u64 *bias_ntt, int B, int zd, int xd, int yd, int xs, int ys_, int xf, int yf, int nf, hipStream_t st)
+// can the layer write a dense consumer's limb tensor itself?  (the output tile must be whole images: 2P a power of two dividing 64)
+bool k_limb_direct_dense(int P) { const int p2 = 2 * P; return p2 <= 64 && (p2 & (p2 - 1)) == 0; }
+int k_limb_mac(crc_ctx *c, const i8 *xl, const i8 *wl, u64 *ys, i8 *xl_out, const u64 *bias_ntt, int B, int zd, int xd, int yd, int xs, int ys_, int xf, int yf, int nf, hipStream_t st)
 {
     if (B == 0) return CRC_OK;
     const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys_ + 1;
     MfmaArgs a{};
     a.xl = xl; a.wl = wl; a.ys = ys; a.mods = c->d_mods; a.bias = bias_ntt;
+    a.xl_out = nullptr; a.lp2 = -1; a.zdp_out = 0;
     a.n = c->n; a.k = c->k; a.B = B; a.zdp = round_up(zd, 32); a.npos = xd * yd; a.yd = yd; a.xs = xs; a.ys_ = ys_; a.yf = yf; a.yo = yo; a.P = xo * yo;
     a.F = nf; a.Fp = round_up(nf, 64); a.zblks = a.zdp / 32; a.ksteps_real = xf * yf * a.zblks; a.M = B * a.P * 2;
     a.mtiles = (a.M + 63) / 64; a.ntiles = a.Fp / 64;
     const size_t img = (size_t)NPL * a.npos * 2 * a.zdp;
     if (img * B > 0xffffffffULL || !k_limb_supported(c, a.ksteps_real * 32)) return CRC_ERR_UNSUPPORTED;
+    if (xl_out) {
+        if (!k_limb_direct_dense(a.P)) return CRC_ERR_INVALID_ARGUMENT;
+        a.xl_out = xl_out; a.zdp_out = (unsigned)round_up(nf * a.P, 32);
+        for (a.lp2 = 0; (1 << a.lp2) < 2 * a.P; a.lp2++) {}
+    }
     a.img_bytes = (unsigned)img; a.wslot_bytes = (unsigned long long)round_up(a.ksteps_real, 2) * NPL * a.Fp * 32;
     const size_t grid = (size_t)c->n * c->k * a.mtiles * a.ntiles;
     if (grid > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;

@@ -154,3 +154,32 @@ def test_limb_gemm_kernel(eng, shape):
             E.pack28(d_y, rows_y, unpack=True)
         E.sync()
         assert np.array_equal(E.download(d_y, (rows_y, E.n)), want), (shape, fin, fout)
+
+
+DENSE_HANDOVER_SHAPES = [
+    # zd, xd, yd, xs, ys, xf, yf, nf, B      the layer's result goes to a dense layer in limb form (out_form = CRC_NTTL), written by the GEMM kernel itself when 2P | 64
+    (32, 6, 6, 1, 1, 3, 3, 64, 3),          # 4 x 4 pixels (PlainModelTiny's conv2+pool2 shape): a tile = two images, the last tile ragged
+    (32, 5, 5, 1, 1, 2, 2, 50, 2),          # 50 filters: the tile's filters past 50 are zero padding of the consumer's channels
+    (70, 1, 1, 1, 1, 1, 1, 10, 9),          # dense -> dense: 32 images per tile, 10 of 32 padded channels
+    (32, 5, 5, 1, 1, 3, 3, 64, 2),          # 3 x 3 pixels: 2P = 18 does not divide 64 -> slot-major result + conversion kernel
+]
+
+
+@pytest.mark.parametrize("shape", DENSE_HANDOVER_SHAPES)
+def test_limb_gemm_hands_over_to_dense(eng, shape):
+    E, ca = eng
+    zd, xd, yd, xs, ys, xf, yf, nf, B = shape
+    rng = np.random.default_rng(zd * 7 + nf)
+    xo, yo = (xd - xf) // xs + 1, (yd - yf) // ys + 1
+    x = rand_rows(rng, E, B * zd * xd * yd * 2); w = rand_rows(rng, E, nf * zd * xf * yf); b = rand_rows(rng, E, nf)
+    d_x, d_w, d_b = E.upload(x), E.upload(w), E.upload(b)
+    want = vector_alu_conv(E, ca, d_x, d_w, d_b, B, zd, xd, yd, xs, ys, xf, yf, nf)
+    d_wl = E.alloc(E.limb_weights_bytes(nf, zd, xf, yf)); E.limb_pack_weights(d_w, nf, zd, xf, yf, d_wl)
+    nb = E.limb_tensor_bytes(B, nf * xo * yo)          # the consumer's tensor: nf * P channels, one position
+    d_y = E.alloc(nb); E.L.crc_memset(E.c, E.p(d_y), 0x55, nb, E.stream)
+    d_work = E.alloc(E.conv2d_forms_work_bytes(B, zd, xd, yd, xs, ys, xf, yf, nf, ca.NTT, ca.NTTL, ca.NTTL))
+    E.conv2d(d_x, d_wl, d_b, B, zd, xd, yd, xs, ys, xf, yf, nf, ca.NTT, ca.NTTL, d_y, d_work, w_form=ca.NTTL)
+    d_ref = E.alloc(nb); E.L.crc_memset(E.c, E.p(d_ref), 0, nb, E.stream)
+    E.limb_pack_tensor(E.upload(want.reshape(-1)), ca.NTT, B, nf * xo * yo, 1, 1, d_ref)
+    E.sync()
+    assert np.array_equal(E.download(d_y, (nb // 8,)), E.download(d_ref, (nb // 8,))), shape
