@@ -555,7 +555,8 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
             except Exception as ex:          # keep the layer-level figure
                 kernel_note = f"kernel-only timing failed ({type(ex).__name__}); launch_ms is the whole layer call"
         if kernel_note is None and p.get("w_form") == ca.NTTL:
-            kernel_note = "HIP events around the layer call inside the timed region: mfma_mac_kernel + the slot-major -> next-layer conversion of its result (about 3 % of the call); the input arrives in limb form from the layer in front"
+            kernel_note = ("HIP events around the layer call inside the timed region; the input arrives in limb form from the layer in front and the call is " +
+                           ("mfma_mac_kernel alone (it writes the next dense layer's limb tensor itself)" if p["out_form"] == ca.NTTL else "mfma_mac_kernel + the conversion of its slot-major result (3-9 % of the call)"))
         achieved = alg_bytes / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
         macs_launch = layer_macs(kind, a) * C
         # HBM traffic of that launch: rocprofv3 PMC passes (FETCH_SIZE corrected x2 for gfx950, WRITE_SIZE) collected OFFLINE with
