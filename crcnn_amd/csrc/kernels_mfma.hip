@@ -21,6 +21,7 @@
 // Per 32-term reduction step the workgroup stages 64 x 32 B x 7 planes of A -- implicit im2col: each lane's LDS-DMA piece reads its own (pixel + tap) address, no
 // patch matrix exists -- and as much of W (contiguous) into a 5-slot LDS ring (140 KiB), three steps ahead of use; an MFMA spans two steps: 196 per wave and barrier.
 #include "kernels.h"
+#include "limbred.h"
 #include <cstdlib>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -45,29 +46,6 @@ __device__ __forceinline__ void limb_digits(u64 r, u64 q, int (&d)[NPL])
     long long v = r > (q >> 1) ? (long long)r - (long long)q : (long long)r;
 #pragma unroll
     for (int l = 0; l < NPL; l++) { d[l] = (int)(signed char)(v & 0xff); v = (v - d[l]) >> 8; }
-}
-
-// The 13 diagonals D'_d = B_d + D_d (any 32-bit words; the accumulators start at B_d, limb_tables) hold U = sum_d D'_d 2^(8d) = V + K*, K* a multiple of q,
-// 0 <= U < 2^127.  Returns U 2^-64 mod q, canonical: the weights carry the factor 2^64, so that is V's residue.  The diagonals d = r (mod 4) are the words of one
-// number each (no overlap); U is their sum at byte offsets 0..3.  One Montgomery step (subtractive form: m = U_lo q^-1 mod 2^64 makes U - m q divisible by 2^64, the
-// low halves cancel without a borrow) leaves t = U_hi - hi64(m q) in (-q, 2^63); t + q < 2^64 is then folded (q = 2^b - f) or Barrett-reduced.  ~80 VALU operations
-// per output where recombining into 128 bits with signs and reducing that took ~340.
-__device__ __forceinline__ u64 diag_reduce(const int (&D)[13], const ModParams &m, u64 qinv)
-{
-    typedef unsigned __int128 u128;
-    const u128 s0 = ((u128)(((u64)(u32)D[12] << 32) | (u32)D[8]) << 64) | (((u64)(u32)D[4] << 32) | (u32)D[0]);
-    const u128 s1 = ((u128)(u32)D[9] << 64) | (((u64)(u32)D[5] << 32) | (u32)D[1]);
-    const u128 s2 = ((u128)(u32)D[10] << 64) | (((u64)(u32)D[6] << 32) | (u32)D[2]);
-    const u128 s3 = ((u128)(u32)D[11] << 64) | (((u64)(u32)D[7] << 32) | (u32)D[3]);
-    const u128 U = s0 + (s1 << 8) + (s2 << 16) + (s3 << 24);
-    const u64 ulo = (u64)U, uhi = (u64)(U >> 64);
-    const u64 mq = ulo * qinv;
-    const u64 t = uhi - __umul64hi(mq, m.q) + m.q;               // in (0, 2^63 + q)
-    if (m.fold) {                                                 // 2^b = f (mod q): (t >> b) < 2^12, f < 2^26
-        const u64 r = (t & (((u64)1 << m.bits) - 1)) + (u64)(u32)(t >> m.bits) * (u32)m.fold;        // one 32 x 32 multiply
-        return r >= m.q ? r - m.q : r;
-    }
-    return barrett128(t, 0, m);
 }
 
 // v_mfma_i32_16x16x64_i8: a wave's 32 x 32 tile as 2 x 2 sub-tiles, two 32-term reduction steps per instruction.  Same cycles per product as v_mfma_i32_32x32x32_i8
@@ -186,8 +164,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 if ((reg & 1) == 0) v = addmod(v, bv, m.q);
                 if (a.xl_out) {
                     const u32 rt = wm * 32 + rs * 16 + 4 * kg + reg, bl = rt >> a.lp2, qq = rt & (P2 - 1);        // row in the tile -> image in the tile, (pixel, poly)
-                    const long long cv = (f < a.F) ? (v > (m.q >> 1) ? (long long)(v - m.q) : (long long)v) : 0;   // filters past F: zero padding of the consumer's channels
-                    const u64 dg = ((u64)cv + 0x0080808080808080ULL) ^ 0x0080808080808080ULL;                     // the 7 balanced digits, one per byte
+                    const u64 dg = f < a.F ? balanced_digit_bytes(v, m.q) : 0;          // the 7 balanced digits, one per byte; filters past F: zero padding of the consumer's channels
                     i8 *sp = lds + (size_t)bl * (NPL * 2 * RL) + (qq & 1) * RL + fl * a.P + (qq >> 1);
 #pragma unroll
                     for (int l = 0; l < NPL; l++) sp[(size_t)l * (2 * RL)] = (i8)(dg >> (8 * l));
@@ -334,29 +311,9 @@ __global__ void __launch_bounds__(256) slotmajor_to_limb_kernel(const u64 *ys, i
     for (int l = 0; l < NPL; l++) *reinterpret_cast<uint4 *>(dst + (size_t)l * 2 * zdp) = make_uint4(pl[l][0], pl[l][1], pl[l][2], pl[l][3]);
 }
 
-// Initial accumulator values for reductions of T terms.  Diagonal d collects the np_d = min(d, 12 - d) + 1 products a_l b_m with l + m = d of every term:
-// |D_d| <= T np_d 2^14.  B_d = the power of two above that bound (+ 256) keeps D'_d = B_d + D_d positive; K0 = sum B_d 2^(8d) is moved to the nearest multiple K* of q
-// by adding the balanced digits of K* - K0 (|.| <= q/2: seven digits of at most 128) to B_0..6.  Then U = sum D'_d 2^(8d) = V + K* == V (mod q), U > 0.
-static void limb_tables(const crc_ctx *c, int T, int (*acc0)[13], u64 *qinv)
+static void limb_tables(const crc_ctx *c, int T, int (*acc0)[13], u64 *qinv)      // limbred.h: accumulator biases and q^-1 mod 2^64 per modulus
 {
-    typedef unsigned __int128 u128;
-    for (int i = 0; i < c->k; i++) {
-        const u64 q = c->tabs[i].m.q;
-        long long B0[13];
-        u128 K0 = 0;
-        for (int d = 0; d < 13; d++) {
-            const u64 bound = (u64)T * (u64)((d < 12 - d ? d : 12 - d) + 1) * 16384 + 256;
-            u64 b = 1; while (b < bound) b <<= 1;
-            B0[d] = (long long)b; K0 += (u128)b << (8 * d);
-        }
-        const u128 rem = K0 % q;
-        long long delta = rem > q / 2 ? (long long)(q - (u64)rem) : -(long long)(u64)rem;        // K* - K0
-        for (int d = 0; d < 7; d++) { const long long dg = (long long)(signed char)(delta & 0xff); B0[d] += dg; delta = (delta - dg) >> 8; }
-        for (int d = 0; d < 13; d++) acc0[i][d] = (int)(u32)(u64)B0[d];                           // (B_d up to 2^31: the accumulators are words mod 2^32)
-        u64 inv = q;                                             // Newton: q odd, q q = 1 (mod 8); each step doubles the correct bits
-        for (int it = 0; it < 6; it++) inv *= 2 - q * inv;
-        qinv[i] = inv;
-    }
+    for (int i = 0; i < c->k; i++) { limb_bias_table(c->tabs[i].m.q, T, acc0[i]); qinv[i] = inverse_mod_2_64(c->tabs[i].m.q); }
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------------------------------

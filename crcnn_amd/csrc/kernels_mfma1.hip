@@ -17,6 +17,7 @@
 //               (no limb_pack_tensor pass in front of conv2), or slot-major u64 for the generic conversions.
 // Exact integer arithmetic throughout: the same element of Z_q, hence the same bits, as mac3_kernel and the reference (convolutionalLayer.cpp:56-93).
 #include "kernels.h"
+#include "limbred.h"
 #include <cstdlib>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -39,25 +40,6 @@ __device__ __forceinline__ void limb_digits1(u64 r, u64 q, int (&d)[NPL])
     long long v = r > (q >> 1) ? (long long)r - (long long)q : (long long)r;
 #pragma unroll
     for (int l = 0; l < NPL; l++) { d[l] = (int)(signed char)(v & 0xff); v = (v - d[l]) >> 8; }
-}
-
-// The 13 diagonals D'_d = B_d + D_d, all in [0, 2^24) with D'_odd < 0.94 2^24 (conv1_tables), hold U = sum_d D'_d 2^(8d) = V + K*, K* a multiple of q,
-// 0 <= U < 2^115.6.  Returns U 2^-64 mod q, canonical (the weights carry the factor 2^64: that is V's residue).
-__device__ __forceinline__ u64 diag_reduce_mont(const int (&D)[13], u64 q, u64 qinv)
-{
-    // pairs of diagonals: P_j = D'_2j + D'_2j+1 2^8 < 2^32, sitting at bit 16 j.  Even pairs are the words of one 128-bit number, odd pairs of another, 16 bits up
-    u32 P[7];
-#pragma unroll
-    for (int j = 0; j < 6; j++) P[j] = (u32)D[2 * j] + ((u32)D[2 * j + 1] << 8);
-    P[6] = (u32)D[12];
-    const u32 o0 = P[1] << 16, o1 = __builtin_amdgcn_alignbit(P[3], P[1], 16), o2 = __builtin_amdgcn_alignbit(P[5], P[3], 16), o3 = P[5] >> 16;
-    const u64 elo = ((u64)P[2] << 32) | P[0], ehi = ((u64)P[6] << 32) | P[4], olo = ((u64)o1 << 32) | o0, ohi = ((u64)o3 << 32) | o2;
-    const u64 ulo = elo + olo, uhi = ehi + ohi + (ulo < elo);
-    // Montgomery step, subtractive form: m = U_lo q^-1 mod 2^64 makes U - m q divisible by 2^64, and t = (U - m q) / 2^64 = U_hi - hi64(m q) exactly
-    // (the low words cancel: no borrow).  t in (U 2^-64 - q, U 2^-64] = (-q, 2^51.6]: one conditional add
-    const u64 m = ulo * qinv;
-    const long long t = (long long)(uhi - __umul64hi(m, q));
-    return (u64)(t + ((t >> 63) & (long long)q));
 }
 
 __global__ void __launch_bounds__(1024) mfma_conv1_kernel(Conv1Args a)
@@ -123,13 +105,12 @@ __global__ void __launch_bounds__(1024) mfma_conv1_kernel(Conv1Args a)
                 int D[13];
 #pragma unroll
                 for (int d = 0; d < 13; d++) D[d] = acc[d][reg];
-                u64 v = diag_reduce_mont(D, q, qinv);
+                u64 v = diag_reduce_short(D, q, qinv);
                 if ((reg & 1) == 0) v = addmod(v, bv, q);       // rows alternate poly 0 / poly 1 (16 | tile base, 4 | lane base): the bias joins poly 0
                 if (mm < 2 * a.P) {
                     if (a.xl_out) {               // limb tensor of the next convolution: [plane][pixel][poly][32 channels], channels past F stay zero
                         // balanced digits of the centred representative cv: the bytes of cv + 0x80...80, each with its top bit flipped
-                        const long long cv = (col < a.F) ? (v > (q >> 1) ? (long long)(v - q) : (long long)v) : 0;
-                        const u64 dg = ((u64)cv + 0x0080808080808080ULL) ^ 0x0080808080808080ULL;
+                        const u64 dg = col < a.F ? balanced_digit_bytes(v, q) : 0;
                         i8 *sp = stage + mm * (NPL * 32) + col;            // staged [row][plane][32 channels]: the seven stores share one address
 #pragma unroll
                         for (int l = 0; l < NPL; l++) sp[l * 32] = (i8)(dg >> (8 * l));
@@ -177,8 +158,7 @@ __global__ void __launch_bounds__(64) limb_pack_rows1_kernel(const u64 *x, i8 *x
             if (colx < yd) {
                 u64 v = src[(size_t)colx * 2 * k * n];
                 if (packed) v = (v & 0xffffffffULL) | ((v >> 32) << 28);
-                const long long cv = v > (q >> 1) ? (long long)(v - q) : (long long)v;
-                const u64 dg = ((u64)cv + 0x0080808080808080ULL) ^ 0x0080808080808080ULL;         // the 7 balanced digits, one per byte
+                const u64 dg = balanced_digit_bytes(v, q);         // the 7 balanced digits, one per byte
 #pragma unroll
                 for (int l = 0; l < NPL; l++) pl[l][colx >> 2] |= (u32)((dg >> (8 * l)) & 0xff) << (8 * (colx & 3));
             }
@@ -220,27 +200,9 @@ bool k_limb_conv1_shape(const crc_ctx *c, int zd, int xd, int yd, int xs, int ys
 size_t k_limb_conv1_weights_bytes(const crc_ctx *c) { return (size_t)c->n * c->k * NPL * 32 * 64; }
 size_t k_limb_conv1_image_bytes(const crc_ctx *c, int B, int xd) { return (size_t)c->n * c->k * B * conv1_img_stride(xd); }
 
-// Initial accumulator values.  Diagonal d collects the products a_l b_m with l + m = d of K = 64 terms; digits are in [-128, 127], the top ones (l, m = 6) in
-// [-64, 64] because |centred residue| < 2^54:  |D_d| <= 64 * 7 * 2^14 < 0.877 2^23 (d <= 10), |D_11| <= 2^20, |D_12| <= 2^18.  Base values B0 = 2^23 (d <= 10),
-// 2^21, 2^19 keep every D'_d = B_d + D_d inside (0, 0.94 2^24) -- unsigned, and a pair D'_2j + D'_2j+1 2^8 never carries out of 32 bits.  Their weighted sum
-// K0 = sum B0_d 2^(8d) ~ 2^115.02 exceeds |V| <= 64 (q/2)^2 <= 2^114; it is moved to the nearest multiple K* of q by adding the balanced digits of K* - K0
-// (|.| <= q/2 < 2^54: seven digits of at most 128) to B0_0..6.  Then U = V + K* == V (mod q) and 0 < U < 2^115.6.
-static void conv1_tables(const crc_ctx *c, Conv1Args &a)
+static void conv1_tables(const crc_ctx *c, Conv1Args &a)      // limbred.h: accumulator biases and q^-1 mod 2^64 per modulus
 {
-    typedef unsigned __int128 u128;
-    for (int i = 0; i < c->k; i++) {
-        const u64 q = c->tabs[i].m.q;
-        long long B0[13];
-        u128 K0 = 0;
-        for (int d = 0; d < 13; d++) { B0[d] = d <= 10 ? 1 << 23 : d == 11 ? 1 << 21 : 1 << 19; K0 += (u128)B0[d] << (8 * d); }
-        const u128 rem = K0 % q;
-        long long delta = rem > q / 2 ? (long long)(q - (u64)rem) : -(long long)(u64)rem;        // K* - K0
-        for (int d = 0; d < 7; d++) { const long long dg = (long long)(signed char)(delta & 0xff); B0[d] += dg; delta = (delta - dg) >> 8; }
-        for (int d = 0; d < 13; d++) a.acc0[i][d] = (int)B0[d];
-        u64 inv = q;                                             // Newton: q odd, q q = 1 (mod 8); each step doubles the correct bits
-        for (int it = 0; it < 6; it++) inv *= 2 - q * inv;
-        a.qinv[i] = inv;
-    }
+    for (int i = 0; i < c->k; i++) { conv1_bias_table(c->tabs[i].m.q, a.acc0[i]); a.qinv[i] = inverse_mod_2_64(c->tabs[i].m.q); }
 }
 
 int k_limb_conv1_pack_weights(crc_ctx *c, const u64 *w, i8 *wl, int nf, int xf, int yf, hipStream_t st)

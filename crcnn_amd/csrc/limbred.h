@@ -1,0 +1,92 @@
+// limbred.h -- the once-per-output reduction of the matrix-core kernels (kernels_mfma.hip, kernels_mfma1.hip) and the tables it needs; host + device, so that
+// tests/cpp/limbred_check.cpp can run the very same code against 128-bit integer arithmetic on the CPU.
+//
+// A modular multiply-add chain  V = sum_t x_t w_t  over centred representatives in balanced base 256 arrives as 13 int32 diagonals D_d = sum_t sum_{l+m=d} a_l b_m,
+// V = sum_d D_d 2^(8d).  The kernels start every accumulator at a bias B_d instead of 0:
+//   * B_d > max |D_d|, so D'_d = B_d + D_d is a NON-NEGATIVE word and U = sum_d D'_d 2^(8d) can be assembled as unsigned multi-word numbers (no sign handling);
+//   * K* = sum_d B_d 2^(8d) is a multiple of q (the low digits of B are adjusted by the balanced digits of the distance to the nearest multiple), so U == V (mod q)
+//     without a correction term.
+// The weights carry the factor 2^64 mod q; one Montgomery step in its subtractive form -- m = U_lo q^-1 mod 2^64 makes U - m q divisible by 2^64, the low halves cancel
+// without a borrow, t = U_hi - hi64(m q) in (U 2^-64 - q, U 2^-64] -- divides it out again.
+#pragma once
+#include "modarith.h"
+
+// generic form: any 32-bit D'_d (reductions of up to 18 000 terms), 0 < U < 2^127.  The diagonals d = r (mod 4) are the words of one number each (no overlap); U is
+// their sum at byte offsets 0..3.  After the Montgomery step t + q is in (0, 2^63 + q): folded (q = 2^b - f) or Barrett-reduced to the canonical residue.
+CRC_HD u64 diag_reduce(const int (&D)[13], const ModParams &m, u64 qinv)
+{
+    typedef unsigned __int128 u128;
+    const u128 s0 = ((u128)(((u64)(u32)D[12] << 32) | (u32)D[8]) << 64) | (((u64)(u32)D[4] << 32) | (u32)D[0]);
+    const u128 s1 = ((u128)(u32)D[9] << 64) | (((u64)(u32)D[5] << 32) | (u32)D[1]);
+    const u128 s2 = ((u128)(u32)D[10] << 64) | (((u64)(u32)D[6] << 32) | (u32)D[2]);
+    const u128 s3 = ((u128)(u32)D[11] << 64) | (((u64)(u32)D[7] << 32) | (u32)D[3]);
+    const u128 U = s0 + (s1 << 8) + (s2 << 16) + (s3 << 24);
+    const u64 ulo = (u64)U, uhi = (u64)(U >> 64);
+    const u64 mq = ulo * qinv;
+    const u64 t = uhi - mulhi64(mq, m.q) + m.q;                  // in (0, 2^63 + q)
+    if (m.fold) {                                                 // 2^b = f (mod q): (t >> b) < 2^12, f < 2^26
+        const u64 r = (t & (((u64)1 << m.bits) - 1)) + (u64)(u32)(t >> m.bits) * (u32)m.fold;        // one 32 x 32 multiply
+        return r >= m.q ? r - m.q : r;
+    }
+    return barrett128(t, 0, m);
+}
+
+// short form (kernels_mfma1.hip: 64-term reductions, 2^52 < q < 2^55): all D'_d < 2^24 with D'_odd < 0.94 2^24, 0 < U < 2^115.6.  PAIRS of diagonals
+// P_j = D'_2j + D'_2j+1 2^8 < 2^32 sit at bit 16 j: even pairs are the words of one 128-bit number, odd pairs of another, 16 bits up.  t in (-q, 2^51.6]: one
+// conditional add, no second reduction.
+CRC_HD u64 diag_reduce_short(const int (&D)[13], u64 q, u64 qinv)
+{
+    u32 P[7];
+    for (int j = 0; j < 6; j++) P[j] = (u32)D[2 * j] + ((u32)D[2 * j + 1] << 8);
+    P[6] = (u32)D[12];
+    const u32 o0 = P[1] << 16, o1 = (P[3] << 16) | (P[1] >> 16), o2 = (P[5] << 16) | (P[3] >> 16), o3 = P[5] >> 16;          // (v_alignbit_b32)
+    const u64 elo = ((u64)P[2] << 32) | P[0], ehi = ((u64)P[6] << 32) | P[4], olo = ((u64)o1 << 32) | o0, ohi = ((u64)o3 << 32) | o2;
+    const u64 ulo = elo + olo, uhi = ehi + ohi + (ulo < elo);
+    const u64 mq = ulo * qinv;
+    const long long t = (long long)(uhi - mulhi64(mq, q));
+    return (u64)(t + ((t >> 63) & (long long)q));
+}
+
+// the 7 balanced base-256 digits of a canonical residue's centred representative, one per byte: the bytes of (centred value + 0x80...80) with their top bits flipped
+CRC_HD u64 balanced_digit_bytes(u64 r, u64 q)
+{
+    const long long cv = r > (q >> 1) ? (long long)(r - q) : (long long)r;
+    return ((u64)cv + 0x0080808080808080ULL) ^ 0x0080808080808080ULL;
+}
+
+// ---- tables (host) ------------------------------------------------------------------------------------------------------------------------------------------
+inline u64 inverse_mod_2_64(u64 q) { u64 inv = q; for (int it = 0; it < 6; it++) inv *= 2 - q * inv; return inv; }      // Newton: q odd, q q = 1 (mod 8)
+
+// move K0 = sum B_d 2^(8d) to the nearest multiple of q by adding the balanced digits of the distance (|.| <= q/2 < 2^62: at most 8 digits of at most 128) to B_0..7
+inline void bias_to_multiple(u64 q, long long (&B)[13])
+{
+    typedef unsigned __int128 u128;
+    u128 K0 = 0;
+    for (int d = 0; d < 13; d++) K0 += (u128)(u64)B[d] << (8 * d);
+    const u64 rem = (u64)(K0 % q);
+    long long delta = rem > q / 2 ? (long long)(q - rem) : -(long long)rem;
+    for (int d = 0; d < 8 && delta; d++) { const long long dg = (long long)(signed char)(delta & 0xff); B[d] += dg; delta = (delta - dg) >> 8; }
+}
+// generic form, reductions of T terms: diagonal d collects np_d = min(d, 12 - d) + 1 products of every term, |D_d| <= T np_d 2^14; B_d = the power of two above that
+// bound (+ 256: room for the digit adjustment) keeps D'_d positive and below 2^32 for T <= 18 000
+inline void limb_bias_table(u64 q, int T, int (&out)[13])
+{
+    long long B[13];
+    for (int d = 0; d < 13; d++) {
+        const u64 bound = (u64)T * (u64)((d < 12 - d ? d : 12 - d) + 1) * 16384 + 256;
+        u64 b = 1; while (b < bound) b <<= 1;
+        B[d] = (long long)b;
+    }
+    bias_to_multiple(q, B);
+    for (int d = 0; d < 13; d++) out[d] = (int)(u32)(u64)B[d];                                   // (B_d up to 2^31: the accumulators are words mod 2^32)
+}
+// short form, 64 terms: digits are in [-128, 127], the top ones (l, m = 6) in [-64, 64] because |centred residue| < 2^54:  |D_d| <= 64 * 7 * 2^14 < 0.877 2^23
+// (d <= 10), |D_11| <= 2^20, |D_12| <= 2^18.  B = 2^23 (d <= 10), 2^21, 2^19 keep every D'_d inside (0, 0.94 2^24) and a pair D'_2j + D'_2j+1 2^8 inside 32 bits;
+// K0 ~ 2^115.02 exceeds |V| <= 64 (q/2)^2 <= 2^114, so U > 0, and U < 2^115.6
+inline void conv1_bias_table(u64 q, int (&out)[13])
+{
+    long long B[13];
+    for (int d = 0; d < 13; d++) B[d] = d <= 10 ? 1 << 23 : d == 11 ? 1 << 21 : 1 << 19;
+    bias_to_multiple(q, B);
+    for (int d = 0; d < 13; d++) out[d] = (int)B[d];
+}

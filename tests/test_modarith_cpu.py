@@ -19,3 +19,14 @@ def test_modarith_header_against_int128(flags):
     out = subprocess.check_output([exe], text=True)
     assert out.startswith("ok "), out
     assert int(out.split()[1]) > 5_000_000
+
+
+@pytest.mark.parametrize("flags", [[], ["-DCRC_FORCE_MAD_MUL"]], ids=["int128", "device-multiply"])
+def test_matrix_core_reduction_against_int128(flags):
+    """crcnn_amd/csrc/limbred.h (the once-per-output reduction of kernels_mfma.hip / kernels_mfma1.hip and its bias tables) on the CPU: digit products accumulated in 32-bit
+    words from the bias table, reduced, compared with sum x w mod q in 128-bit arithmetic -- random, extreme-digit and edge residues, T = 64 .. 18 000 terms, 40..55-bit moduli"""
+    exe = os.path.join(tempfile.mkdtemp(), "limbred_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17"] + flags + ["-I", os.path.join(ROOT, "crcnn_amd", "csrc"), os.path.join(ROOT, "tests", "cpp", "limbred_check.cpp"), "-o", exe])
+    out = subprocess.check_output([exe], text=True)
+    assert out.startswith("ok "), out
+    assert int(out.split()[1]) > 20_000
