@@ -189,6 +189,143 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
 }
 
+// Two workgroups per CU.  With one workgroup per CU and one wave per SIMD (above) nothing overlaps a workgroup's start-up, its barrier skew or its epilogue: the matrix
+// pipe idles for half of the cycles.  Here a wave's tile is 32 rows x 16 filters (2 x 13 x 4 = 104 accumulators), a workgroup's 64 x 32, the weight fragments come
+// straight from L2 into registers (a lane's fragment is 16 contiguous bytes of Wl; they are prefetched one double step ahead) and only A goes through LDS: 5 x 14 KiB per
+// workgroup, <= 256 registers per wave, so TWO workgroups share a CU and one's stalls are the other's issue slots.
+#define TILE_A (NPL * 64 * 32)
+template <int NST>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) mfma_mac2w_kernel(MfmaArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) i8 lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 1, wn = wave & 1;
+    const int ntiles2 = a.Fp / 32, slots = a.n * a.k, per = a.mtiles * ntiles2;
+    int g = blockIdx.x, slot, tile;
+    if ((slots & 7) == 0) { const int xcd = g & 7, r = g >> 3; slot = xcd * (slots >> 3) + r / per; tile = r % per; }
+    else { slot = g / per; tile = g % per; }
+    const int mt = tile / ntiles2, nt = tile % ntiles2;
+    const int i = slot / a.n, s = slot % a.n;
+    const int m0 = mt * 64, f0 = nt * 32;
+    const ModParams m = a.mods[i];
+    const u64 qinv = a.qinv[i];
+    const i8 *xs = a.xl + (size_t)slot * a.B * a.img_bytes;
+    const int kg = lane >> 4, r16 = lane & 15;
+    // this lane's weight fragment: filter f0 + 16 wn + r16, K group kg = half (kg & 1) of step ks + (kg >> 1)
+    const i8 *wlane = a.wl + (size_t)slot * a.wslot_bytes + (size_t)(f0 + wn * 16 + r16) * 32 + (kg & 1) * 16 + (size_t)(kg >> 1) * (NPL * a.Fp * 32);
+    const int wplane = a.Fp * 32, wstep = NPL * a.Fp * 32;
+    // A staging: 14 LDS-DMA pieces of 1 KiB per 32-term step, pieces wave, wave + 4, ...; waves 2 and 3 load pieces 10 / 11 twice so that every wave issues four
+    // loads per step (uniform counts: the waits below are immediates)
+    u32 src_off[4]; int pcs[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int pc = wave + 4 * j < 14 ? wave + 4 * j : wave + 8, c16 = pc * 64 + lane;
+        pcs[j] = pc;
+        const int plane = c16 >> 7, row = (c16 >> 1) & 63, half = c16 & 1;
+        const int mm = min(m0 + row, a.M - 1);
+        const int b = mm / (2 * a.P), p = (mm >> 1) % a.P, c = mm & 1;
+        const int ox = p / a.yo, oy = p % a.yo;
+        src_off[j] = (u32)b * a.img_bytes + (u32)(plane * (a.npos * 2 * a.zdp) + (((ox * a.xs) * a.yd + oy * a.ys_) * 2 + c) * a.zdp + half * 16);
+    }
+    const int kreal = a.ksteps_real;
+    auto issue_a = [&](int ks) {
+        const int ka = min(ks, kreal - 1);
+        const int tap = ka / a.zblks, zb = ka - tap * a.zblks;
+        const int kx = tap / a.yf, ky = tap - kx * a.yf;
+        const u32 delta = (u32)((kx * a.yd + ky) * 2 * a.zdp + zb * 32);
+        i8 *dst = lds + (ks % NST) * TILE_A;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xs + src_off[j] + delta), (__attribute__((address_space(3))) void *)(dst + pcs[j] * 1024), 16, 0, 0);
+    };
+    auto load_w = [&](int ks, v4i (&w)[NPL]) {
+        const i8 *pw = wlane + (size_t)ks * wstep;
+#pragma unroll
+        for (int l = 0; l < NPL; l++) w[l] = *reinterpret_cast<const v4i *>(pw + (size_t)l * wplane);
+    };
+    v4i acc[2][13];
+#pragma unroll
+    for (int rs = 0; rs < 2; rs++)
+#pragma unroll
+        for (int d = 0; d < 13; d++) { const int b0 = a.acc0[i][d]; acc[rs][d] = v4i{b0, b0, b0, b0}; }
+    const int K = a.ksteps;                                       // even
+    const int fragA = (wm * 32 + r16) * 32 + (kg & 1) * 16;
+    // one double step: steps ks, ks + 1 of A and the weights `wuse` (double step ks) have landed.  Issue order inside a double step: A(ks + 3), W(ks + 4) -> wload,
+    // A(ks + 4); at the top of the next one everything up to A(ks + 3) is needed, so 7 + 4 loads may stay in flight: the weights are fetched TWO double steps ahead
+    // (dense layers stream them from HBM), A three steps ahead.  Three weight buffers rotate through a loop unrolled by three (no register copies).
+    auto dstep = [&](int ks, v4i (&wuse)[NPL], v4i (&wload)[NPL]) {
+        if (ks + 2 < K) __builtin_amdgcn_s_waitcnt(11 | (7 << 4) | (15 << 8));
+        else __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
+        __syncthreads();
+        if (ks + 3 < K) issue_a(ks + 3);
+        if (ks + 4 < K) { load_w(ks + 4, wload); issue_a(ks + 4); }
+        const i8 *tA = lds + ((ks + (kg >> 1)) % NST) * TILE_A;
+        v4i av[2 * NPL];
+        auto read_a = [&](int gi) { return *reinterpret_cast<const v4i *>(tA + (gi % NPL) * (64 * 32) + fragA + (gi / NPL) * (16 * 32)); };
+        av[0] = read_a(0); av[1] = read_a(1); av[2] = read_a(2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int gi = 0; gi < 2 * NPL; gi++) {
+            const int rs = gi / NPL, l = gi % NPL;
+#pragma unroll
+            for (int mm = 0; mm < NPL; mm++)
+                acc[rs][l + mm] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[gi], wuse[mm], acc[rs][l + mm], 0, 0, 0);
+            if (gi + 3 < 2 * NPL) av[gi + 3] = read_a(gi + 3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    v4i w0[NPL], w1[NPL], w2[NPL];
+    // prologue in the steady-state order: A(0), A(1), W(0), A(2), W(2)  -- the first wait leaves W(2) + A(2)'s four pieces ... at most 11 loads in flight
+    issue_a(0); if (1 < K) issue_a(1);
+    load_w(0, w0);
+    if (2 < K) { issue_a(2); load_w(2, w1); }
+    for (int ks = 0; ks < K; ks += 6) {
+        dstep(ks, w0, w2);
+        if (ks + 2 < K) dstep(ks + 2, w1, w0);
+        if (ks + 4 < K) dstep(ks + 4, w2, w1);
+    }
+    // epilogue as in mfma_mac_kernel: 8 outputs per lane
+    u64 *yslot = a.ys + (size_t)slot * a.B * a.F * (2 * a.P);
+    const u32 P2 = 2 * a.P;
+    const u32 RL = 32 * a.P;                                      // bytes of one run of a direct limb result (this tile's 32 filters)
+    if (a.xl_out) __syncthreads();
+    const int fl = wn * 16 + r16, f = f0 + fl;
+    const u64 bv = (a.bias && f < a.F) ? a.bias[((size_t)f * a.k + i) * a.n + s] : 0;
+#pragma unroll
+    for (int rs = 0; rs < 2; rs++) {
+        const u32 mbase = m0 + wm * 32 + rs * 16 + 4 * kg, bb = mbase / P2, rem = mbase - bb * P2;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            int D[13];
+#pragma unroll
+            for (int d = 0; d < 13; d++) D[d] = acc[rs][d][reg];
+            u64 v = diag_reduce(D, m, qinv);
+            if ((reg & 1) == 0) v = addmod(v, bv, m.q);
+            if (a.xl_out) {
+                const u32 rt = wm * 32 + rs * 16 + 4 * kg + reg, bl = rt >> a.lp2, qq = rt & (P2 - 1);
+                const u64 dg = f < a.F ? balanced_digit_bytes(v, m.q) : 0;
+                i8 *sp = lds + (size_t)bl * (NPL * 2 * RL) + (qq & 1) * RL + fl * a.P + (qq >> 1);
+#pragma unroll
+                for (int l = 0; l < NPL; l++) sp[(size_t)l * (2 * RL)] = (i8)(dg >> (8 * l));
+            } else {
+                const u32 r = rem + reg, b = bb + (r >= P2) + (r >= 2 * P2);
+                if (mbase + reg < (u32)a.M && f < a.F) yslot[b * (u32)(a.F - 1) * P2 + (u32)f * P2 + mbase + reg] = v;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (a.xl_out) {
+        __syncthreads();
+        const u32 imgs = 64 >> a.lp2, b0 = (u32)m0 >> a.lp2, per_run = RL / 16, pieces = imgs * NPL * 2 * per_run;
+        const u32 ch0 = (u32)f0 * a.P;
+        for (u32 o = threadIdx.x; o < pieces; o += 256) {
+            const u32 run = o / per_run, off = (o - run * per_run) * 16, bl = run / (NPL * 2), lc = run - bl * (NPL * 2);
+            if (b0 + bl < (u32)a.B && ch0 + off < a.zdp_out)
+                *reinterpret_cast<uint4 *>(a.xl_out + ((size_t)slot * a.B + b0 + bl) * ((size_t)NPL * 2 * a.zdp_out) + (size_t)lc * a.zdp_out + ch0 + off) =
+                    *reinterpret_cast<const uint4 *>(lds + (size_t)run * RL + off);
+        }
+    }
+}
+
 // ---- layout conversions ------------------------------------------------------------------------------------------------------------------
 // slot-minor NTT-form tensor x [B][zd*npos cts][2][k][n] (canonical residues, or 28-bit limb pairs when `packed`) -> Xl.  One thread per (slot, image,
 // position, poly, 32-channel block); lanes run over 64 consecutive slots, so every read is a coalesced 512-B row segment; every lane writes 7 x 32 B into its
@@ -395,6 +532,16 @@ int k_limb_mac(crc_ctx *c, const i8 *xl, const i8 *wl, u64 *ys, i8 *xl_out, cons
     limb_tables(c, a.ksteps_real * 32, a.acc0, a.qinv);
     static const int ring = [] { const char *e = getenv("CRC_MFMA_RING"); const int v = e ? atoi(e) : 0; return v >= 3 && v <= 5 ? v : 0; }();     // tuning (tools/)
     a.ksteps = round_up(a.ksteps_real, 2);
+    static const int variant = [] { const char *e = getenv("CRC_MFMA_VARIANT"); return e ? atoi(e) : 2; }();          // 2 (default): two workgroups per CU (mfma_mac2w_kernel); 1: mfma_mac_kernel
+    if (variant == 2) {
+        const size_t grid2 = (size_t)c->n * c->k * a.mtiles * (a.Fp / 32);
+        if (grid2 > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
+        const size_t lds = (size_t)5 * TILE_A;
+        { const int rc = crc_ctx_ensure_lds(c, (const void *)mfma_mac2w_kernel<5>, lds); if (rc) return rc; }
+        hipLaunchKernelGGL(mfma_mac2w_kernel<5>, dim3((unsigned)grid2), dim3(256), lds, st, a);
+        HIPCHK(hipGetLastError());
+        return CRC_OK;
+    }
     const int nst = ring == 4 ? 4 : 5;
     const size_t lds = (size_t)nst * 2 * TILE_B;
     auto kern = nst == 4 ? mfma_mac_kernel<4> : mfma_mac_kernel<5>;
