@@ -550,19 +550,19 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
                     run_k()
                 e1.record(); torch.cuda.synchronize()
                 dur_ms = e0.elapsed_time(e1) / 5
-                kernel_note = (f"mfma_mac_kernel timed on its own (+ the 3 % slotmajor_to_limb conversion behind it): 5 launches on the limb-form input of one chunk; the whole layer call "
-                               f"(limb_pack_tensor + mfma_mac_kernel + conversion) takes {layer_ms:.2f} ms inside the timed region")
+                kernel_note = (f"mfma_mac2w_kernel timed on its own (+ the 3 % slotmajor_to_limb conversion behind it): 5 launches on the limb-form input of one chunk; the whole layer call "
+                               f"(limb_pack_tensor + mfma_mac2w_kernel + conversion) takes {layer_ms:.2f} ms inside the timed region")
             except Exception as ex:          # keep the layer-level figure
                 kernel_note = f"kernel-only timing failed ({type(ex).__name__}); launch_ms is the whole layer call"
         if kernel_note is None and p.get("w_form") == ca.NTTL:
             kernel_note = ("HIP events around the layer call inside the timed region; the input arrives in limb form from the layer in front and the call is " +
-                           ("mfma_mac_kernel alone (it writes the next dense layer's limb tensor itself)" if p["out_form"] == ca.NTTL else "mfma_mac_kernel + the conversion of its slot-major result (3-9 % of the call)"))
+                           ("mfma_mac2w_kernel alone (it writes the next dense layer's limb tensor itself)" if p["out_form"] == ca.NTTL else "mfma_mac2w_kernel + the conversion of its slot-major result (3-9 % of the call)"))
         achieved = alg_bytes / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
         macs_launch = layer_macs(kind, a) * C
         # HBM traffic of that launch: rocprofv3 PMC passes (FETCH_SIZE corrected x2 for gfx950, WRITE_SIZE) collected OFFLINE with
         # tools/bench_mac.py and committed under profiles/ -- bench.py cannot run the profiler on itself, so this is not measured in this run
         traffic, traffic_source = None, None
-        kname = "mfma_mac_kernel" if p.get("w_form") == ca.NTTL else "mfma_conv1_kernel" if p.get("w_form") == ca.NTTL1 else "mac3_kernel"
+        kname = "mfma_mac2w_kernel" if p.get("w_form") == ca.NTTL else "mfma_conv1_kernel" if p.get("w_form") == ca.NTTL1 else "mac3_kernel"
         kernel_label = f"{kname} ({name}, {C} images/launch)" if kind in ("conv", "fc") else f"{kind} ({name})"
         for pf in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
@@ -573,7 +573,7 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
             except Exception:
                 pass
         modmul_s = macs_launch * 2 * E.k * E.n / (dur_ms * 1e-3) if dur_ms > 0 and macs_launch else None
-        if kname == "mfma_mac_kernel" and modmul_s:
+        if kname == "mfma_mac2w_kernel" and modmul_s:
             # the matrix-core kernel is bound by the int8 MFMA rate, not by HBM: 49 limb products (98 int8 operations) per modular multiply-add, against the dense
             # int8 peak (2x the bf16 rate per clock: MI355X_MICROARCH.md, matrix cores).  The HBM view of the same launch stays beside it
             tops = modmul_s * 98 / 1e12
@@ -604,7 +604,7 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
             "config": {"workload": f"{model}.h5 n={cfg['n']} k={cfg['k']} t=2^{cfg['t'].bit_length() - 1} batch={B}/GPU chunk={C} ({cfg_name}, BASELINE configs)",
                        "mode": args.mode + ("+conv/pool folding" if want_fuse else ""), "parallelism": f"image-sharded x{world}, RCCL weight broadcast"},
             "ms_per_layer": ms_per_layer,
-            "mac_kernel_per_layer": {pl[1]: ("mfma_mac_kernel (int8 limb GEMM, CRC_NTTL)" if pl[3].get("w_form") == ca.NTTL else
+            "mac_kernel_per_layer": {pl[1]: ("mfma_mac2w_kernel (int8 limb GEMM, CRC_NTTL)" if pl[3].get("w_form") == ca.NTTL else
                                              "mfma_conv1_kernel (one-channel convolution on the matrix cores, CRC_NTTL1)" if pl[3].get("w_form") == ca.NTTL1 else
                                              "mac3_kernel (v_mad_u64_u32, CRC_NTTP)" + (", streamed weights" if pl[3].get("streamed") else "") +
                                              (f" [{pl[3]['limb_skipped']}]" if pl[3].get("limb_skipped") else "")) for pl in net.plan if pl[0] in ("conv", "fc")},

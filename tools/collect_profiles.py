@@ -38,15 +38,18 @@ def tot(path, counter, kernel):
 out = {}
 try:
     d = {}
-    for kern in ("mfma_mac_kernel", "limb_pack_tensor_kernel", "slotmajor_to_limb_kernel"):
-        f, ms = tot(os.path.join(F, "pmc_fetch/f_counter_collection.csv"), "FETCH_SIZE", kern)
-        w, _ = tot(os.path.join(F, "pmc_write/w_counter_collection.csv"), "WRITE_SIZE", kern)
+    for kern in ("mfma_mac2w_kernel", "limb_pack_tensor_kernel", "slotmajor_to_limb_kernel"):
+        try:
+            f, ms = tot(os.path.join(F, "pmc_fetch/f_counter_collection.csv"), "FETCH_SIZE", kern)
+            w, _ = tot(os.path.join(F, "pmc_write/w_counter_collection.csv"), "WRITE_SIZE", kern)
+        except IndexError:            # not launched (the GEMM writes a dense consumer's limb tensor itself: no conversion kernel)
+            continue
         d[kern] = dict(fetch_bytes=f * 2048, write_bytes=w * 1024, traffic_bytes=f * 2048 + w * 1024, launch_ms_under_pmc=round(ms, 3))
-    m = d["mfma_mac_kernel"]
-    out["tiny4096"] = {"kernel": "mfma_mac_kernel (pool2_features.conv2+pool2, 128 images/launch)", **m, "other_kernels_of_the_layer_call": {k: v for k, v in d.items() if k != "mfma_mac_kernel"},
+    m = d["mfma_mac2w_kernel"]
+    out["tiny4096"] = {"kernel": "mfma_mac2w_kernel (pool2_features.conv2+pool2, 128 images/launch)", **m, "other_kernels_of_the_layer_call": {k: v for k, v in d.items() if k != "mfma_mac2w_kernel"},
                        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/measure_round.sh prof) on `tools/bench_mac.py conv2p 128 1 limbk` = the conv2+pool2 launch "
                                "of the bench at chunk 128 on a limb-form input; counters are KiB; FETCH_SIZE doubled (gfx950 reports half the bytes of coalesced 16-B-per-lane reads, "
-                               "global_load and LDS-DMA alike: MI355X_MICROARCH.md).  Algorithmic bytes of the launch in limb form: 67.6 GB tensor + 4.2 GB weights + 17.2 GB result = 89 GB"}
+                               "global_load and LDS-DMA alike: MI355X_MICROARCH.md).  Algorithmic bytes of the launch in limb form: 67.6 GB tensor + 4.2 GB weights + 15.0 GB result (fc3's limb tensor, written by the kernel itself) = 86.8 GB"}
     # the same for the one-channel convolution (tools/check_conv1.py: last launches = the limb-tensor output of 128 images) and the issue / wait split of mfma_mac_kernel
     try:
         c1 = {}
@@ -58,8 +61,8 @@ try:
                                  "note": "algorithmic: 13.2 GB limb images in, 67.6 GB limb tensor out (mfma_conv1_kernel); 13.2 GB NTT-form images in, 13.2 GB limb images out (limb_pack_rows1_kernel)"}
         sq = {}
         for cn in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_BUSY_CYCLES"):
-            sq[cn], ms = tot(os.path.join(F, "pmc_sq/s_counter_collection.csv"), cn, "mfma_mac_kernel")
-        g, msg = tot(os.path.join(F, "pmc_grbm/g_counter_collection.csv"), "GRBM_GUI_ACTIVE", "mfma_mac_kernel")
+            sq[cn], ms = tot(os.path.join(F, "pmc_sq/s_counter_collection.csv"), cn, "mfma_mac2w_kernel")
+        g, msg = tot(os.path.join(F, "pmc_grbm/g_counter_collection.csv"), "GRBM_GUI_ACTIVE", "mfma_mac2w_kernel")
         out["tiny4096"]["issue_split"] = {**{k_: v_ for k_, v_ in sq.items()}, "launch_ms_under_pmc": round(ms, 3), "GRBM_GUI_ACTIVE": g, "effective_clock_GHz": round(g / 8 / (msg * 1e-3) / 1e9, 3),
                                           "note": "wave-parked (s_waitcnt / barrier) = SQ_WAIT_ANY / SQ_WAVE_CYCLES, issue stall (MFMA pipe / dependency) = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES"}
     except Exception as e:
