@@ -532,7 +532,8 @@ int k_limb_mac(crc_ctx *c, const i8 *xl, const i8 *wl, u64 *ys, i8 *xl_out, cons
     limb_tables(c, a.ksteps_real * 32, a.acc0, a.qinv);
     static const int ring = [] { const char *e = getenv("CRC_MFMA_RING"); const int v = e ? atoi(e) : 0; return v >= 3 && v <= 5 ? v : 0; }();     // tuning (tools/)
     a.ksteps = round_up(a.ksteps_real, 2);
-    static const int variant = [] { const char *e = getenv("CRC_MFMA_VARIANT"); return e ? atoi(e) : 2; }();          // 2 (default): two workgroups per CU (mfma_mac2w_kernel); 1: mfma_mac_kernel
+    const char *ev = getenv("CRC_MFMA_VARIANT");                 // 2 (default): two workgroups per CU (mfma_mac2w_kernel); 1: mfma_mac_kernel (read per call: the tests run both)
+    const int variant = ev ? atoi(ev) : 2;
     if (variant == 2) {
         const size_t grid2 = (size_t)c->n * c->k * a.mtiles * (a.Fp / 32);
         if (grid2 > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;

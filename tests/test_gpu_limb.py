@@ -134,8 +134,10 @@ GEMM_SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("variant", ["2", "1"], ids=["two-workgroups-per-CU", "one-workgroup-per-CU"])
 @pytest.mark.parametrize("shape", GEMM_SHAPES)
-def test_limb_gemm_kernel(eng, shape):
+def test_limb_gemm_kernel(eng, shape, variant, monkeypatch):
+    monkeypatch.setenv("CRC_MFMA_VARIANT", variant)
     E, ca = eng
     zd, xd, yd, xs, ys, xf, yf, nf, B = shape
     rng = np.random.default_rng(zd * 100 + nf)
@@ -165,8 +167,10 @@ DENSE_HANDOVER_SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("variant", ["2", "1"], ids=["two-workgroups-per-CU", "one-workgroup-per-CU"])
 @pytest.mark.parametrize("shape", DENSE_HANDOVER_SHAPES)
-def test_limb_gemm_hands_over_to_dense(eng, shape):
+def test_limb_gemm_hands_over_to_dense(eng, shape, variant, monkeypatch):
+    monkeypatch.setenv("CRC_MFMA_VARIANT", variant)
     E, ca = eng
     zd, xd, yd, xs, ys, xf, yf, nf, B = shape
     rng = np.random.default_rng(zd * 7 + nf)
