@@ -95,8 +95,9 @@ def test_matrix_core_dense_layers_match_reference():
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, "net_tiny4096_t32.json")), reason="needs the n=4096 golden")
 def test_bench_chunk_matches_reference():
-    """PlainModelTiny at the BASELINE parameters and bench.py's chunk (32 images per layer launch): conv1+pool1 on its own matrix-core kernel writing conv2's limb tensor,
-    conv2 / fc3 / fc4 as limb GEMMs -- every image of the chunk is the compiled reference's ciphertext"""
+    """PlainModelTiny at the BASELINE parameters and a bench-sized chunk (32 images per layer launch; bench.py itself verifies its 128-image chunks against the same
+    golden): conv1+pool1 on its own matrix-core kernel writing conv2's limb tensor, conv2 / fc3 / fc4 as limb GEMMs handing their tensors on in limb form -- every image
+    of the chunk is the compiled reference's ciphertext"""
     import crcnn_amd as ca
     g, O, sk, out, _ = run_net("tiny4096_t32", resident=True, batch=32)
     bad = [b for b in range(32) if sha(out[b]) != g["out_sha256"]]
