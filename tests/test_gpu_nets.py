@@ -111,3 +111,36 @@ def test_all_eight_primes_match_reference():
     One image, NTT-resident: the compiled reference's ciphertext (an hour of CPU time in oracle/make_golden_nets.py)"""
     g, O, sk, out, _ = run_net("wopad16384k8_t44", resident=True, batch=1)
     assert sha(out[0]) == g["out_sha256"]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, "c1_tiny4096_t32.json")), reason="needs the configs[0] fixture")
+def test_baseline_configs0_in_full():
+    """BASELINE configs[0]: PlainModelTiny.h5 on 32 encrypted MNIST-like images at n = 4096.  The compiled reference ran all 32 (tests/golden/c1_tiny4096_t32.json,
+    oracle/make_c1.py: 3.5 hours of CPU); the engine runs them as ONE chunk.  Same input ciphertexts (seeded client), same 10 output ciphertexts per image bit for bit,
+    same predictions"""
+    import hashlib
+    import json
+    import crcnn_amd as ca
+    from crcnn_amd import synth
+    from crcnn_amd.netrun import Network
+    c1 = json.load(open(os.path.join(GOLD, "c1_tiny4096_t32.json")))
+    assert len(c1["images"]) == 32
+    E = ca.Engine(c1["n"], c1["q"], c1["t"], device=0)
+    sk, pk = E.keygen(c1["key_seed"])
+    xs = []
+    for i in range(32):
+        pl, _ = E.encode(synth.normalize(synth.synth_image(i)).reshape(-1))
+        x = E.encrypt(pk, pl, c1["enc_seed_base"] + c1["enc_seed_stride"] * i)
+        assert hashlib.sha256(np.ascontiguousarray(x).tobytes()).hexdigest() == c1["images"][str(i)]["input_sha256"], i
+        xs.append(x.reshape(28 * 28, 2, E.k, E.n))
+    net = Network(E, "PlainModelTiny", h5_path=os.path.join(GOLD, "models", "PlainModelTiny.h5"), resident=True)
+    net.prepare(32)
+    out = E.download(net.forward(E.upload(np.ascontiguousarray(np.stack(xs))), 32), (32, 10, 2, E.k, E.n))
+    bad = [i for i in range(32) if hashlib.sha256(np.ascontiguousarray(out[i]).tobytes()).hexdigest() != c1["images"][str(i)]["out_sha256"]]
+    assert not bad, bad
+    from oracle import orc
+    O = orc.Oracle(c1["n"], c1["q"], c1["t"])
+    for i in (0, 13, 31):
+        logits = [O.decrypt_value(sk, out[i, j]) for j in range(10)]
+        assert int(np.argmax(logits)) == c1["images"][str(i)]["prediction"] and np.allclose(logits, c1["images"][str(i)]["logits"], atol=1e-9)
+    E.close()
