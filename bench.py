@@ -585,7 +585,7 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
         roofline.update(traffic_source=traffic_source, kernel=kernel_label, kernel_timing=kernel_note, launch_ms=round(float(dur_ms), 3), layer_call_ms=round(float(layer_ms), 3),
                         algorithmic_bytes_per_launch=int(alg_bytes), modmul_per_s=round(modmul_s, 1) if modmul_s else None)
         cpu = None
-        if full and args.cpu_seconds > 0:
+        if full and args.cpu_seconds > 0 and world == 1:      # (the CPU leg runs at N = 1 only: at N > 1 the host cores are busy driving N ranks)
             x0 = x_all[0].cpu().numpy().view(np.uint64).reshape(1, 28, 28, 2, E.k, E.n)
             cpu = cpu_baseline_reference(cfg, q, W, x0, host_cores()) or cpu_baseline(cfg, q, W, x0, args.cpu_seconds)
             cpu["value"] = round(cpu["value"], 6); cpu["mac_per_s"] = round(cpu["mac_per_s"], 1)
