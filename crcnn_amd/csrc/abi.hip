@@ -137,6 +137,7 @@ static int conv2d_limb1(crc_ctx *c, const uint64_t *d_x, const void *d_wl, const
                         int in_form, int out_form, uint64_t *d_y, void *d_work, hipStream_t st)
 {
     const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys + 1, P = xo * yo, in_cts = xd * yd;
+    if (out_form == CRC_NTTLC && P == 1) out_form = CRC_NTTL;   // a 1 x 1 result is a dense layer's input: the K-blocked form (kernels_mfma.hip), made from the slot-major result
     const int Bs = conv1_sub_batch(c, B, xd, yo, nf, P, out_form);
     const size_t ctw = crc_ct_words(c, 2);
     char *w = (char *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
@@ -161,7 +162,9 @@ extern "C" size_t crc_conv2d_forms_work_bytes(const crc_ctx *c, int B, int zd, i
 {
     if (w_form == CRC_NTTL1) {
         if (!c || !conv_shape_ok(xd, yd, xs, ys, xf, yf)) return 0;
-        const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys + 1, Bs = conv1_sub_batch(c, B, xd, yo, nf, xo * yo, out_form);
+        const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys + 1;
+        if (out_form == CRC_NTTLC && xo * yo == 1) out_form = CRC_NTTL;
+        const int Bs = conv1_sub_batch(c, B, xd, yo, nf, xo * yo, out_form);
         size_t b = align256(k_limb_conv1_image_bytes(c, Bs, xd));
         if (out_form != CRC_NTTLC) b += align256(8 * k_limb_result_words(c, Bs, nf, xo * yo));
         if (in_form == CRC_COEFF) b += align256((size_t)Bs * xd * yd * crc_ct_words(c, 2) * 8);

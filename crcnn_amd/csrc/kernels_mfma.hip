@@ -13,7 +13,9 @@
 //
 // Layouts (CRC_NTTL, "limb form"; slot = i*n + s).  The GEMMs of different slots share nothing, so operands are SLOT-MAJOR here (the rest of the engine
 // is slot-minor: one row = n slots of one residue):
-//     tensor   Xl [slot][B][7 planes][positions][2 polys][zdp]          int8, zdp = channels rounded up to 32 (zero padded)
+//     tensor   Xl [slot][B][7 planes][positions][2 polys][zdp]          int8, zdp = channels rounded up to 32 (zero padded); a DENSE layer's input (one position) is
+//                 K-blocked instead: [slot][7 planes][zdp / 32][B * 2 rows = (image, poly)][32], so that a reduction step's 64 rows are 2 KiB contiguous per plane
+//                 (channel-innermost rows 1 KiB apart filled a quarter of every cache line the LDS-DMA touched: fc3 ran 20 % below the convolution's rate)
 //     weights  Wl [slot][reduction step = (tap, 32-channel block)][7 planes][Fp][32]   int8, Fp = filters rounded up to 64 (zero padded), an odd number of
 //                 steps rounded up to even with a zero step; every weight times 2^64 mod q
 //     result   Ys [slot][B][F][P][2] u64 canonical (internal), then transposed to the slot-minor tensor layout or re-limbed for a dense consumer
@@ -33,6 +35,7 @@ typedef signed char i8;
 
 struct MfmaArgs {
     const i8 *xl; const i8 *wl; u64 *ys; const ModParams *mods; const u64 *bias;     // bias: NTT-form delta rows [F][k][n] added to poly 0, or null
+    int mfast;                                         // tile order inside a slot: row tiles fastest (neighbouring workgroups share the weight tile) instead of filter tiles fastest
     i8 *xl_out; int lp2; unsigned zdp_out;             // direct limb result for a dense consumer (2P = 2^lp2 divides 64): [slot][B][7][2][zdp_out], channel = f P + p
     int n, k, B, zdp, npos, yd, xs, ys_, yf, yo, P, F, Fp, zblks, ksteps, M, mtiles, ntiles;      // ksteps: rounded up to even (the weights carry a zero step)
     unsigned img_bytes; unsigned long long wslot_bytes; int ksteps_real;
@@ -61,7 +64,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     int g = blockIdx.x, slot, tile;
     if ((slots & 7) == 0) { const int xcd = g & 7, r = g >> 3; slot = xcd * (slots >> 3) + r / per; tile = r % per; }
     else { slot = g / per; tile = g % per; }
-    const int mt = tile / a.ntiles, nt = tile % a.ntiles;
+    const int mt = a.mfast ? tile % a.mtiles : tile / a.ntiles, nt = a.mfast ? tile / a.mtiles : tile % a.ntiles;
     const int i = slot / a.n, s = slot % a.n;
     const int m0 = mt * 64, f0 = nt * 64;
     const ModParams m = a.mods[i];
@@ -78,7 +81,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             const int mm = min(m0 + row, a.M - 1);
             const int b = mm / (2 * a.P), p = (mm >> 1) % a.P, c = mm & 1;
             const int ox = p / a.yo, oy = p % a.yo;
-            src_off[j] = (u32)b * a.img_bytes + (u32)(plane * (a.npos * 2 * a.zdp) + (((ox * a.xs) * a.yd + oy * a.ys_) * 2 + c) * a.zdp + half * 16);
+            src_off[j] = a.npos == 1 ? (u32)(plane * a.zblks * (2 * a.B) + mm) * 32 + half * 16        // dense input: K-blocked rows (mm = image * 2 + poly)
+                                     : (u32)b * a.img_bytes + (u32)(plane * (a.npos * 2 * a.zdp) + (((ox * a.xs) * a.yd + oy * a.ys_) * 2 + c) * a.zdp + half * 16);
         } else src_off[j] = (u32)(((pc - 14) >> 1) * (a.Fp * 32) + ((pc - 14) & 1) * 1024 + lane * 16);
     }
     const int kreal = a.ksteps_real;
@@ -86,7 +90,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         const int ka = min(ks, kreal - 1);                        // the padding step multiplies by zero weights: any valid rows will do
         const int tap = ka / a.zblks, zb = ka - tap * a.zblks;
         const int kx = tap / a.yf, ky = tap - kx * a.yf;
-        const u32 delta = (u32)((kx * a.yd + ky) * 2 * a.zdp + zb * 32);
+        const u32 delta = a.npos == 1 ? (u32)zb * (2 * a.B) * 32 : (u32)((kx * a.yd + ky) * 2 * a.zdp + zb * 32);
         i8 *dst = lds + (ks % NST) * (2 * TILE_B);
         const i8 *wt = ws + (size_t)ks * (NPL * a.Fp * 32);
 #pragma unroll
@@ -182,8 +186,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         const u32 ch0 = (u32)f0 * a.P;                            // first channel of this tile's runs
         for (u32 o = threadIdx.x; o < pieces; o += 256) {
             const u32 run = o / per_run, off = (o - run * per_run) * 16, bl = run / (NPL * 2), lc = run - bl * (NPL * 2);       // lc = plane * 2 + poly
-            if (b0 + bl < (u32)a.B && ch0 + off < a.zdp_out)
-                *reinterpret_cast<uint4 *>(a.xl_out + ((size_t)slot * a.B + b0 + bl) * ((size_t)NPL * 2 * a.zdp_out) + (size_t)lc * a.zdp_out + ch0 + off) =
+            const u32 ch = ch0 + off;                                 // consumer layout: [plane][channel block][row = image * 2 + poly][32]
+            if (b0 + bl < (u32)a.B && ch < a.zdp_out)
+                *reinterpret_cast<uint4 *>(a.xl_out + (size_t)slot * ((size_t)NPL * 2 * a.B * a.zdp_out)
+                                           + ((size_t)((lc >> 1) * (a.zdp_out / 32) + (ch >> 5)) * (2 * a.B) + (b0 + bl) * 2 + (lc & 1)) * 32 + (ch & 31)) =
                     *reinterpret_cast<const uint4 *>(lds + (size_t)run * RL + off);
         }
     }
@@ -203,7 +209,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     int g = blockIdx.x, slot, tile;
     if ((slots & 7) == 0) { const int xcd = g & 7, r = g >> 3; slot = xcd * (slots >> 3) + r / per; tile = r % per; }
     else { slot = g / per; tile = g % per; }
-    const int mt = tile / ntiles2, nt = tile % ntiles2;
+    const int mt = a.mfast ? tile % a.mtiles : tile / ntiles2, nt = a.mfast ? tile / a.mtiles : tile % ntiles2;
     const int i = slot / a.n, s = slot % a.n;
     const int m0 = mt * 64, f0 = nt * 32;
     const ModParams m = a.mods[i];
@@ -224,14 +230,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         const int mm = min(m0 + row, a.M - 1);
         const int b = mm / (2 * a.P), p = (mm >> 1) % a.P, c = mm & 1;
         const int ox = p / a.yo, oy = p % a.yo;
-        src_off[j] = (u32)b * a.img_bytes + (u32)(plane * (a.npos * 2 * a.zdp) + (((ox * a.xs) * a.yd + oy * a.ys_) * 2 + c) * a.zdp + half * 16);
+        src_off[j] = a.npos == 1 ? (u32)(plane * a.zblks * (2 * a.B) + mm) * 32 + half * 16
+                                 : (u32)b * a.img_bytes + (u32)(plane * (a.npos * 2 * a.zdp) + (((ox * a.xs) * a.yd + oy * a.ys_) * 2 + c) * a.zdp + half * 16);
     }
     const int kreal = a.ksteps_real;
     auto issue_a = [&](int ks) {
         const int ka = min(ks, kreal - 1);
         const int tap = ka / a.zblks, zb = ka - tap * a.zblks;
         const int kx = tap / a.yf, ky = tap - kx * a.yf;
-        const u32 delta = (u32)((kx * a.yd + ky) * 2 * a.zdp + zb * 32);
+        const u32 delta = a.npos == 1 ? (u32)zb * (2 * a.B) * 32 : (u32)((kx * a.yd + ky) * 2 * a.zdp + zb * 32);
         i8 *dst = lds + (ks % NST) * TILE_A;
 #pragma unroll
         for (int j = 0; j < 4; j++)
@@ -319,8 +326,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         const u32 ch0 = (u32)f0 * a.P;
         for (u32 o = threadIdx.x; o < pieces; o += 256) {
             const u32 run = o / per_run, off = (o - run * per_run) * 16, bl = run / (NPL * 2), lc = run - bl * (NPL * 2);
-            if (b0 + bl < (u32)a.B && ch0 + off < a.zdp_out)
-                *reinterpret_cast<uint4 *>(a.xl_out + ((size_t)slot * a.B + b0 + bl) * ((size_t)NPL * 2 * a.zdp_out) + (size_t)lc * a.zdp_out + ch0 + off) =
+            const u32 ch = ch0 + off;                                 // consumer layout: [plane][channel block][row = image * 2 + poly][32]
+            if (b0 + bl < (u32)a.B && ch < a.zdp_out)
+                *reinterpret_cast<uint4 *>(a.xl_out + (size_t)slot * ((size_t)NPL * 2 * a.B * a.zdp_out)
+                                           + ((size_t)((lc >> 1) * (a.zdp_out / 32) + (ch >> 5)) * (2 * a.B) + (b0 + bl) * 2 + (lc & 1)) * 32 + (ch & 31)) =
                     *reinterpret_cast<const uint4 *>(lds + (size_t)run * RL + off);
         }
     }
@@ -359,10 +368,13 @@ __global__ void __launch_bounds__(64) limb_pack_tensor_kernel(const u64 *x, i8 *
                 for (int l = 0; l < NPL; l++) pl[l][z >> 2] |= (u32)(d[l] & 0xff) << (8 * (z & 3));
             }
         }
-        i8 *dst = xl + (((size_t)i * n + s) * B + b) * ((size_t)NPL * npos * 2 * zdp) + ((size_t)pos * 2 + c) * zdp + zb * 32;
+        // one position (a dense layer's input): K-blocked [plane][channel block][row = image * 2 + poly][32]
+        i8 *dst = npos == 1 ? xl + ((size_t)i * n + s) * ((size_t)NPL * 2 * B * zdp) + ((size_t)zb * (2 * B) + b * 2 + c) * 32
+                            : xl + (((size_t)i * n + s) * B + b) * ((size_t)NPL * npos * 2 * zdp) + ((size_t)pos * 2 + c) * zdp + zb * 32;
+        const size_t plane_stride = npos == 1 ? (size_t)zblks * (2 * B) * 32 : (size_t)npos * 2 * zdp;
 #pragma unroll
         for (int l = 0; l < NPL; l++) {
-            uint4 *o = reinterpret_cast<uint4 *>(dst + (size_t)l * npos * 2 * zdp);
+            uint4 *o = reinterpret_cast<uint4 *>(dst + (size_t)l * plane_stride);
             o[0] = make_uint4(pl[l][0], pl[l][1], pl[l][2], pl[l][3]); o[1] = make_uint4(pl[l][4], pl[l][5], pl[l][6], pl[l][7]);
         }
     }
@@ -420,7 +432,7 @@ __global__ void __launch_bounds__(256) slotmajor_to_rows_kernel(const u64 *ys, u
         if (e < rows) { u64 v = tile[tx][el]; if (pack_out) v = (v & 0x0fffffffULL) | ((v >> 28) << 32); y[(e * k + i) * (size_t)n + s0 + tx] = v; }
     }
 }
-// Ys [slot][B][zd'*2] (zd' = F*P flattened channels, poly innermost) -> Xl' [slot][B][7][1][2][zdp'] for a dense consumer.  One thread per 16 channels.
+// Ys [slot][B][zd'*2] (zd' = F*P flattened channels, poly innermost) -> Xl' [slot][7][zdp'/32][B*2][32] for a dense consumer.  One thread per 16 channels.
 __global__ void __launch_bounds__(256) slotmajor_to_limb_kernel(const u64 *ys, i8 *xl, const ModParams *mods, int n, int B, int zd, int zdp, size_t total)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;              // ((slot*B + b)*2 + c)*(zdp/16) + zg
@@ -443,9 +455,9 @@ __global__ void __launch_bounds__(256) slotmajor_to_limb_kernel(const u64 *ys, i
             for (int l = 0; l < NPL; l++) pl[l][z >> 2] |= (u32)(d[l] & 0xff) << (8 * (z & 3));
         }
     }
-    i8 *dst = xl + (slot * B + b) * ((size_t)NPL * 2 * zdp) + (size_t)c * zdp + zg * 16;
+    i8 *dst = xl + slot * ((size_t)NPL * 2 * B * zdp) + ((size_t)(zg >> 1) * (2 * B) + b * 2 + c) * 32 + (zg & 1) * 16;      // K-blocked dense input (header)
 #pragma unroll
-    for (int l = 0; l < NPL; l++) *reinterpret_cast<uint4 *>(dst + (size_t)l * 2 * zdp) = make_uint4(pl[l][0], pl[l][1], pl[l][2], pl[l][3]);
+    for (int l = 0; l < NPL; l++) *reinterpret_cast<uint4 *>(dst + (size_t)l * (zdp / 32) * (2 * B) * 32) = make_uint4(pl[l][0], pl[l][1], pl[l][2], pl[l][3]);
 }
 
 static void limb_tables(const crc_ctx *c, int T, int (*acc0)[13], u64 *qinv)      // limbred.h: accumulator biases and q^-1 mod 2^64 per modulus
@@ -514,7 +526,7 @@ int k_limb_mac(crc_ctx *c, const i8 *xl, const i8 *wl, u64 *ys, i8 *xl_out, cons
     const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys_ + 1;
     MfmaArgs a{};
     a.xl = xl; a.wl = wl; a.ys = ys; a.mods = c->d_mods; a.bias = bias_ntt;
-    a.xl_out = nullptr; a.lp2 = -1; a.zdp_out = 0;
+    a.xl_out = nullptr; a.lp2 = -1; a.zdp_out = 0; a.mfast = 0;
     a.n = c->n; a.k = c->k; a.B = B; a.zdp = round_up(zd, 32); a.npos = xd * yd; a.yd = yd; a.xs = xs; a.ys_ = ys_; a.yf = yf; a.yo = yo; a.P = xo * yo;
     a.F = nf; a.Fp = round_up(nf, 64); a.zblks = a.zdp / 32; a.ksteps_real = xf * yf * a.zblks; a.M = B * a.P * 2;
     a.mtiles = (a.M + 63) / 64; a.ntiles = a.Fp / 64;
@@ -532,6 +544,9 @@ int k_limb_mac(crc_ctx *c, const i8 *xl, const i8 *wl, u64 *ys, i8 *xl_out, cons
     limb_tables(c, a.ksteps_real * 32, a.acc0, a.qinv);
     static const int ring = [] { const char *e = getenv("CRC_MFMA_RING"); const int v = e ? atoi(e) : 0; return v >= 3 && v <= 5 ? v : 0; }();     // tuning (tools/)
     a.ksteps = round_up(a.ksteps_real, 2);
+    // layers with few row tiles and many filter tiles (dense layers) stream their weights: walk the row tiles of one filter tile back to back, so that the weight tile is
+    // fetched from HBM once and the (small) tensor stays in L2; convolutions keep filter tiles fastest (the big tensor tile is shared, the weights sit in L2)
+    { const char *eo = getenv("CRC_MFMA_ORDER"); a.mfast = eo ? atoi(eo) : (a.mtiles < a.Fp / 32 ? 1 : 0); }
     const char *ev = getenv("CRC_MFMA_VARIANT");                 // 2 (default): two workgroups per CU (mfma_mac2w_kernel); 1: mfma_mac_kernel (read per call: the tests run both)
     const int variant = ev ? atoi(ev) : 2;
     if (variant == 2) {

@@ -52,7 +52,8 @@ enum { CRC_COEFF = 0, CRC_NTT = 1,
         * Needs coefficient moduli below 2^56. */
        CRC_NTTP = 2,
        /* "limb form": the operand form of the matrix-core multiply-accumulate (kernels_mfma.hip).  Every residue as the seven balanced base-256 digits of
-        * its centred representative (int8), SLOT-MAJOR: tensors [k][n][B][7][positions][2 polys][channels rounded up to 32], weights
+        * its centred representative (int8), SLOT-MAJOR: tensors [k][n][B][7][positions][2 polys][channels rounded up to 32] (a dense layer's input, one position, is
+        * K-blocked instead: [k][n][7][channels / 32][B * 2 rows = (image, poly)][32]), weights
         * [k][n][tap][channel block][7][filters rounded up to 64][32] (times 2^64 mod q: the kernel's Montgomery reduction divides it out).  Exact integer arithmetic on v_mfma_i32_16x16x64_i8 (49 limb products per modular
         * multiply, int32 accumulators, one reduction per output): the same ciphertexts as every other form, about 4x the throughput of the vector-ALU
         * kernel on long reductions.  crc_limb_pack_weights makes the weights; crc_conv2d_forms / crc_dense_forms take w_form = CRC_NTTL, convert a
