@@ -60,6 +60,7 @@ __global__ void __launch_bounds__(1024) mfma_conv1_kernel(Conv1Args a)
 #pragma unroll
     for (int d = 0; d < 13; d++) acc0[d] = a.acc0[i][d];
     const u64 bv = (a.bias && col < a.F) ? a.bias[((size_t)col * a.k + i) * a.n + s] : 0;
+    const long long bvc = bv > (q >> 1) ? (long long)(bv - q) : (long long)bv;        // the bias, centred
     i8 *stage = lds + 2 * (size_t)a.img_stride;
     const i8 *ximg = a.xr + (size_t)slot * a.B * a.img_stride;
     const int pieces = a.img_stride / 1024;
@@ -105,17 +106,16 @@ __global__ void __launch_bounds__(1024) mfma_conv1_kernel(Conv1Args a)
                 int D[13];
 #pragma unroll
                 for (int d = 0; d < 13; d++) D[d] = acc[d][reg];
-                u64 v = diag_reduce_short(D, q, qinv);
-                if ((reg & 1) == 0) v = addmod(v, bv, q);       // rows alternate poly 0 / poly 1 (16 | tile base, 4 | lane base): the bias joins poly 0
+                // rows alternate poly 0 / poly 1 (16 | tile base, 4 | lane base): the bias joins poly 0.  One pass from the diagonals to the centred representative
+                const long long cv = (reg & 1) == 0 ? diag_reduce_short_centred<true>(D, q, qinv, bvc) : diag_reduce_short_centred<false>(D, q, qinv, 0);
                 if (mm < 2 * a.P) {
                     if (a.xl_out) {               // limb tensor of the next convolution: [plane][pixel][poly][32 channels], channels past F stay zero
-                        // balanced digits of the centred representative cv: the bytes of cv + 0x80...80, each with its top bit flipped
-                        const u64 dg = col < a.F ? balanced_digit_bytes(v, q) : 0;
+                        const u64 dg = col < a.F ? centred_digit_bytes(cv) : 0;     // the seven balanced digits, one per byte
                         i8 *sp = stage + mm * (NPL * 32) + col;            // staged [row][plane][32 channels]: the seven stores share one address
 #pragma unroll
                         for (int l = 0; l < NPL; l++) sp[l * 32] = (i8)(dg >> (8 * l));
                     } else if (col < a.F)
-                        a.ys[(((size_t)slot * a.B + b) * a.F + col) * (2 * a.P) + mm] = v;
+                        a.ys[(((size_t)slot * a.B + b) * a.F + col) * (2 * a.P) + mm] = (u64)(cv + ((cv >> 63) & (long long)q));       // canonical
                 }
             }
         }

@@ -47,6 +47,29 @@ CRC_HD u64 diag_reduce_short(const int (&D)[13], u64 q, u64 qinv)
     return (u64)(t + ((t >> 63) & (long long)q));
 }
 
+// the same, returning the CENTRED representative of (U 2^-64 + bias) mod q in [-(q-1)/2, (q-1)/2] -- what the limb form of the next layer is made of -- in one pass:
+// t in (-q, 2^51.6] plus a centred bias in [-(q-1)/2, (q-1)/2] lies in (-1.5 q, q), so one conditional +q and (only when a bias was added) one conditional -q
+// replace the three corrections of canonicalise / add the bias mod q / centre
+template <bool HAS_BIAS>
+CRC_HD long long diag_reduce_short_centred(const int (&D)[13], u64 q, u64 qinv, long long bias_centred)
+{
+    typedef unsigned __int128 u128;
+    u32 P[7];
+    for (int j = 0; j < 6; j++) P[j] = (u32)D[2 * j] + ((u32)D[2 * j + 1] << 8);
+    P[6] = (u32)D[12];
+    const u128 E = ((u128)(((u64)P[6] << 32) | P[4]) << 64) | (((u64)P[2] << 32) | P[0]);
+    const u128 O = ((u128)P[5] << 64) | (((u64)P[3] << 32) | P[1]);
+    const u128 U = E + (O << 16);
+    const u64 mq = (u64)U * qinv;
+    long long t = (long long)((u64)(U >> 64) - mulhi64(mq, q));
+    const long long h = (long long)(q >> 1);
+    if (HAS_BIAS) t += bias_centred;
+    t += t < -h ? (long long)q : 0;
+    if (HAS_BIAS) t -= t > h ? (long long)q : 0;
+    return t;
+}
+CRC_HD u64 centred_digit_bytes(long long cv) { return ((u64)cv + 0x0080808080808080ULL) ^ 0x0080808080808080ULL; }
+
 // the 7 balanced base-256 digits of a canonical residue's centred representative, one per byte: the bytes of (centred value + 0x80...80) with their top bits flipped
 CRC_HD u64 balanced_digit_bytes(u64 r, u64 q)
 {

@@ -67,6 +67,14 @@ int main()
                 if (shortform) {
                     for (int d = 0; d < 13; d++) if (D[d] >= (1u << 24)) { printf("short form: diagonal %d out of range q=%llx\n", d, (unsigned long long)q); return 1; }
                     if (diag_reduce_short(Ds, q, qinv) != expect) { printf("diag_reduce_short mismatch q=%llx mode=%d\n", (unsigned long long)q, mode); return 1; }
+                    // the one-pass centred form, without and with a bias
+                    const long long hq = (long long)(q >> 1);
+                    auto centre = [&](u64 r) { return r > (q >> 1) ? (long long)(r - q) : (long long)r; };
+                    if (diag_reduce_short_centred<false>(Ds, q, qinv, 0) != centre(expect)) { printf("diag_reduce_short_centred mismatch q=%llx mode=%d\n", (unsigned long long)q, mode); return 1; }
+                    const u64 bias = mode == 4 ? edge[rnd() % 9] : rnd() % q;
+                    const long long got = diag_reduce_short_centred<true>(Ds, q, qinv, centre(bias));
+                    if (got != centre((u64)(((u128)expect + bias) % q)) || got < -hq || got > hq) { printf("diag_reduce_short_centred (bias) mismatch q=%llx mode=%d\n", (unsigned long long)q, mode); return 1; }
+                    if (centred_digit_bytes(got) != balanced_digit_bytes((u64)(((u128)expect + bias) % q), q)) { printf("centred_digit_bytes mismatch\n"); return 1; }
                 }
                 {
                     if (shortform) { int Bg[13]; limb_bias_table(q, T, Bg); for (int d = 0; d < 13; d++) Ds[d] = (int)(D[d] - (u32)B[d] + (u32)Bg[d]); }
