@@ -13,6 +13,7 @@ scaling, no data-path collective).  Rank 0 prints ONE JSON line.  Besides the co
   ms_per_layer  per-image milliseconds per layer (the reference's T_LAYER_i columns, mainparams.cpp:81)
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -272,21 +273,32 @@ class Dist:
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if self.backend == "nccl":
-                dist.init_process_group("nccl", device_id=self.dev)
+                dist.init_process_group("nccl", device_id=self.dev, timeout=datetime.timedelta(minutes=10))      # a collective nobody else joins ends the job, not hangs it
             else:
-                dist.init_process_group(self.backend)
+                dist.init_process_group(self.backend, timeout=datetime.timedelta(minutes=10))
 
     def make_comm(self, E):
         """RCCL communicator of the engine (C ABI); the 128-byte rendezvous id travels over the torch.distributed store"""
         if self.world == 1 or self.backend != "nccl":
             return None, None
         comm, err = None, None
-        try:
-            obj = [E.comm_unique_id() if self.rank == 0 else None]
-            self.dist.broadcast_object_list(obj, src=0)
-            comm = E.comm_create(self.world, self.rank, obj[0])
-        except Exception as ex:                                   # a rank without its communicator must not leave the others waiting inside ncclBroadcast:
-            err = f"{type(ex).__name__}: {ex}"                    # every rank learns whether ALL have one, otherwise all use the torch.distributed (RCCL) broadcast
+        # every rank runs the SAME sequence of torch.distributed collectives whatever fails: rank 0 always broadcasts (id or None, error), every rank skips
+        # crc_comm_create when there is no id, and the all-reduce afterwards tells everybody whether ALL ranks hold a communicator (otherwise all of them use
+        # the torch.distributed broadcast).  A rank that dies inside ncclCommInitRank is caught by the process group's timeout (init_process_group above).
+        obj = [None, None]
+        if self.rank == 0:
+            try:
+                obj = [E.comm_unique_id(), None]
+            except Exception as ex:
+                obj = [None, f"{type(ex).__name__}: {ex}"]
+        self.dist.broadcast_object_list(obj, src=0)
+        if obj[0] is None:
+            err = obj[1] or "rank 0 could not make a rendezvous id"
+        else:
+            try:
+                comm = E.comm_create(self.world, self.rank, obj[0])
+            except Exception as ex:
+                err = f"{type(ex).__name__}: {ex}"
         have = self.sum(int(comm is not None))
         if have != self.world:
             if comm is not None:

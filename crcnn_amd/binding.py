@@ -71,6 +71,7 @@ def load():
     L.crc_ct_words.restype = SZ; L.crc_ct_words.argtypes = [VP, CI]
     L.crc_evk_words.restype = SZ; L.crc_evk_words.argtypes = [VP, CI]
     L.crc_ctx_table.argtypes = [VP, ctypes.c_char_p, PU, CI]
+    L.crc_ctx_set_tuning.argtypes = [VP, ctypes.c_char_p, ctypes.c_longlong]
     L.crc_mem_info.argtypes = [VP, ctypes.POINTER(SZ), ctypes.POINTER(SZ)]
     L.crc_malloc.argtypes = [VP, SZ, ctypes.POINTER(VP)]
     L.crc_free.argtypes = [VP, VP]
@@ -265,6 +266,11 @@ class Engine:
 
     def sync(self):
         _chk(self.L.crc_stream_sync(self.c, self.stream), "crc_stream_sync")
+
+    def set_tuning(self, name, value):
+        """tools / tests only: change one tuning switch of this (quiescent) context (the environment is read once, at creation)"""
+        self.sync()
+        _chk(self.L.crc_ctx_set_tuning(self.c, name.encode(), int(value)), f"crc_ctx_set_tuning({name})")
 
     def table(self, name, cap=1 << 16):
         out = np.zeros(cap, dtype=np.uint64)

@@ -3,7 +3,10 @@
 #include "kernels.h"
 #include "chacha.h"
 
-#define CHECK_CTX(c) do { if (!(c) || (c)->device < 0) return CRC_ERR_INVALID_ARGUMENT; } while (0)
+// every device entry point makes its context's GPU current for the calling thread (a no-op in the one-process-per-GPU flow; in a one-process, many-GPU
+// application the launch must not land on whatever device the thread used last)
+#define CHECK_CTX(c) do { if (!(c) || (c)->device < 0) return CRC_ERR_INVALID_ARGUMENT; \
+        int dev_ = -1; if (hipGetDevice(&dev_) != hipSuccess || dev_ != (c)->device) HIPCHK(hipSetDevice((c)->device)); } while (0)
 #define RUN(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 static inline hipStream_t S(void *s) { return (hipStream_t)s; }
 static inline bool form_ok(int f) { return f == CRC_COEFF || f == CRC_NTT; }
@@ -127,8 +130,7 @@ static int conv1_sub_batch(const crc_ctx *c, int B, int xd, int yo, int nf, int 
 {
     if (out_form == CRC_NTTL || B <= 1) return B;
     const size_t per = k_limb_conv1_image_bytes(c, 1, xd) + (out_form == CRC_NTTLC ? 0 : 8 * k_limb_result_words(c, 1, nf, P));
-    const char *e = getenv("CRC_CONV1_PASS_BYTES");                  // (the tests shrink it to cover the multi-pass path at small sizes)
-    const long long ev = e ? atoll(e) : 0;
+    const long long ev = c->tune.conv1_pass_bytes;                   // (the tests shrink it to cover the multi-pass path at small sizes: crc_ctx_set_tuning)
     const size_t cap = ev > 0 ? (size_t)ev : (size_t)16 << 30;
     const size_t fit = cap / (per ? per : 1);
     return (int)(fit < 1 ? 1 : fit > (size_t)B ? (size_t)B : fit);

@@ -26,6 +26,15 @@ extern "C" int crc_last_comm_error(void) { return g_last_nccl; }
 
 static_assert(sizeof(ncclUniqueId) == CRC_COMM_ID_BYTES, "rendezvous id size");
 
+// makes `device` current for the calling thread and puts the caller's device back on scope exit: in the one-process, many-GPU flow (crc_comm_create_all /
+// crc_broadcast_weights_all) a comm call must not leave the thread on the last communicator's GPU, or the next kernel call for another context runs there
+struct DeviceGuard {
+    int prev = -1; bool ok = true;
+    explicit DeviceGuard(int device) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != device) ok = hipSetDevice(device) == hipSuccess; }
+    ~DeviceGuard() { int cur = -1; if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev); }
+};
+#define GUARD(dev) DeviceGuard guard_(dev); if (!guard_.ok) return crc_set_hip_error(hipErrorInvalidDevice)
+
 extern "C" int crc_comm_unique_id(uint8_t *h_id)
 {
     if (!h_id) return CRC_ERR_INVALID_ARGUMENT;
@@ -37,7 +46,7 @@ extern "C" int crc_comm_unique_id(uint8_t *h_id)
 
 static int comm_finish(crc_comm *cm)
 {
-    HIPCHK(hipSetDevice(cm->device));
+    GUARD(cm->device);
     HIPCHK(hipMalloc((void **)&cm->d_scratch, kScratchWords * (size_t)(cm->world + 1) * 8));
     return CRC_OK;
 }
@@ -45,7 +54,7 @@ static int comm_finish(crc_comm *cm)
 extern "C" int crc_comm_create(crc_ctx *c, int world, int rank, const uint8_t *h_id, crc_comm **out)
 {
     if (!c || c->device < 0 || !h_id || !out || world < 1 || rank < 0 || rank >= world) return CRC_ERR_INVALID_ARGUMENT;
-    HIPCHK(hipSetDevice(c->device));
+    GUARD(c->device);
     ncclUniqueId id; std::memcpy(&id, h_id, sizeof id);
     crc_comm *cm = new crc_comm(); cm->world = world; cm->rank = rank; cm->device = c->device;
     ncclResult_t r = ncclCommInitRank(&cm->comm, world, id, rank);
@@ -66,6 +75,7 @@ extern "C" int crc_comm_create_all(crc_ctx *const *ctxs, int ndev, crc_comm **ou
         for (int j = 0; j < i; j++) if (devs[j] == devs[i]) return CRC_ERR_INVALID_ARGUMENT;      // one rank per GPU
     }
     std::vector<ncclComm_t> comms(ndev);
+    GUARD(devs[0]);                                      // ncclCommInitAll walks the devices: the guard puts the caller's back
     NCCLCHK(ncclCommInitAll(comms.data(), ndev, devs.data()));
     for (int i = 0; i < ndev; i++) {
         crc_comm *cm = new crc_comm(); cm->comm = comms[i]; cm->world = ndev; cm->rank = i; cm->device = devs[i];
@@ -79,7 +89,7 @@ extern "C" int crc_comm_create_all(crc_ctx *const *ctxs, int ndev, crc_comm **ou
 extern "C" void crc_comm_destroy(crc_comm *cm)
 {
     if (!cm) return;
-    (void)hipSetDevice(cm->device);
+    DeviceGuard guard_(cm->device);
     if (cm->d_scratch) (void)hipFree(cm->d_scratch);
     if (cm->comm) ncclCommDestroy(cm->comm);
     delete cm;
@@ -90,7 +100,7 @@ extern "C" int crc_comm_world(const crc_comm *cm) { return cm ? cm->world : CRC_
 extern "C" int crc_broadcast_weights(crc_comm *cm, uint64_t *d_w, size_t words, int root, void *stream)
 {
     if (!cm || (!d_w && words) || root < 0 || root >= cm->world) return CRC_ERR_INVALID_ARGUMENT;
-    HIPCHK(hipSetDevice(cm->device));
+    GUARD(cm->device);
     for (size_t o = 0; o < words; o += kPieceWords) {
         const size_t cnt = words - o < kPieceWords ? words - o : kPieceWords;
         NCCLCHK(ncclBroadcast(d_w + o, d_w + o, cnt, ncclUint64, root, cm->comm, (hipStream_t)stream));
@@ -102,6 +112,7 @@ extern "C" int crc_broadcast_weights_all(crc_comm *const *comms, int ndev, uint6
 {
     if (!comms || !d_w || ndev < 1 || root < 0 || root >= ndev) return CRC_ERR_INVALID_ARGUMENT;
     for (int i = 0; i < ndev; i++) if (!comms[i] || comms[i]->world != ndev || (!d_w[i] && words)) return CRC_ERR_INVALID_ARGUMENT;
+    GUARD(comms[0]->device);                             // RCCL switches devices inside the group: the caller's comes back on exit
     for (size_t o = 0; o < words; o += kPieceWords) {
         const size_t cnt = words - o < kPieceWords ? words - o : kPieceWords;
         NCCLCHK(ncclGroupStart());                 // one thread drives every rank: the calls of a piece must be grouped
@@ -117,7 +128,7 @@ extern "C" int crc_broadcast_weights_all(crc_comm *const *comms, int ndev, uint6
 extern "C" int crc_comm_allgather_u64(crc_comm *cm, const uint64_t *h_in, size_t words, uint64_t *h_out, void *stream)
 {
     if (!cm || !h_in || !h_out || words == 0 || words > kScratchWords) return CRC_ERR_INVALID_ARGUMENT;
-    HIPCHK(hipSetDevice(cm->device));
+    GUARD(cm->device);
     hipStream_t st = (hipStream_t)stream;
     u64 *send = cm->d_scratch, *recv = cm->d_scratch + kScratchWords;
     HIPCHK(hipMemcpyAsync(send, h_in, words * 8, hipMemcpyHostToDevice, st));
@@ -140,6 +151,7 @@ __global__ void __launch_bounds__(256) checksum_kernel(const u64 *w, size_t word
 extern "C" int crc_checksum64(crc_ctx *c, const uint64_t *d_words, size_t words, uint64_t *h_out, void *stream)
 {
     if (!c || c->device < 0 || !h_out || (!d_words && words)) return CRC_ERR_INVALID_ARGUMENT;
+    GUARD(c->device);                                    // the kernel and the copies below belong to THIS context's GPU, whatever the thread's current device is
     hipStream_t st = (hipStream_t)stream;
     u64 *acc = c->d_scratch;                       // context scratch: one checksum at a time per context
     HIPCHK(hipMemsetAsync(acc, 0, 16, st));

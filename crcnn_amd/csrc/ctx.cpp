@@ -42,13 +42,13 @@ u64 h_invmod(u64 a, u64 q)
 }
 static int sigbits(u64 v) { return v ? 64 - __builtin_clzll(v) : 0; }
 
-ModParams make_mod(u64 q)
+ModParams make_mod(u64 q, bool no_fold)
 {
     ModParams m{};
     u128 all = ~(u128)0, quo = all / q;
     if (all % q + 1 == q) quo += 1;                // q | 2^128 (m~ = 2^32)
     m.q = q; m.r0 = (u64)quo; m.r1 = (u64)(quo >> 64); m.two_q = 2 * q; m.bits = (u32)sigbits(q);
-    m.fold = getenv("CRC_NO_FOLD") ? 0 : fold_constant(q, m.bits);
+    m.fold = no_fold ? 0 : fold_constant(q, m.bits);
     return m;
 }
 
@@ -88,10 +88,10 @@ static u64 minimal_primitive_root(u64 two_n, u64 q)
 
 static u32 bitrev(u32 x, int bits) { u32 r = 0; for (int i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; } return r; }
 
-static bool build_ntt(HostNtt &T, int logn, u64 q)
+static bool build_ntt(HostNtt &T, int logn, u64 q, bool no_fold)
 {
     int n = 1 << logn;
-    T.m = make_mod(q);
+    T.m = make_mod(q, no_fold);
     T.root = minimal_primitive_root(2 * (u64)n, q);
     if (!T.root) return false;
     u64 iroot = h_invmod(T.root, q);
@@ -154,6 +154,44 @@ static u64 prod_mod(const u64 *v, int cnt, int skip, u64 m)
     return r;
 }
 
+// the only place the engine reads its environment: once per context, before any kernel can be launched on it
+static void read_tuning(CrcTuning &t)
+{
+    auto geti = [](const char *name, long long dflt) { const char *e = getenv(name); return e && *e ? atoll(e) : dflt; };
+    t.no_fold = getenv("CRC_NO_FOLD") ? 1 : 0;
+    t.ntt_inv61_loose = getenv("CRC_NTT_INV61_LOOSE") ? 1 : 0;
+    t.mfma_order = (int)geti("CRC_MFMA_ORDER", -1);
+    t.mfma_variant = (int)geti("CRC_MFMA_VARIANT", 2);
+    { const int v = (int)geti("CRC_MFMA_RING", 0); t.mfma_ring = v >= 3 && v <= 5 ? v : 0; }
+    { const int v = (int)geti("CRC_CONV1_WAVES", 0); t.conv1_waves = v == 8 || v == 12 || v == 16 ? v : 0; }
+    { const long long v = geti("CRC_CONV1_PASS_BYTES", 0); t.conv1_pass_bytes = v > 0 ? v : 0; }
+    { const int v = (int)geti("CRC_LIMB_PACK_GROUP", 1); t.limb_pack_group = v > 0 ? v : 1; }
+    t.mac2_cfg = (int)geti("CRC_MAC2_CFG", 0);
+    t.mac_order = (int)geti("CRC_MAC_ORDER", -1);
+    t.mac_regstage = (int)geti("CRC_MAC_REGSTAGE", 0);
+    t.mac2_dbg = (int)geti("CRC_MAC2_DBG", 0);
+    t.relin_path = (int)geti("CRC_RELIN_PATH", 0);
+}
+extern "C" int crc_ctx_set_tuning(crc_ctx *c, const char *name, long long value)
+{
+    if (!c || !name) return CRC_ERR_INVALID_ARGUMENT;
+    const std::string s(name);
+    CrcTuning &t = c->tune;
+    if (s == "mfma_order") t.mfma_order = (int)value;
+    else if (s == "mfma_variant") t.mfma_variant = (int)value;
+    else if (s == "mfma_ring") t.mfma_ring = value >= 3 && value <= 5 ? (int)value : 0;
+    else if (s == "conv1_waves") t.conv1_waves = value == 8 || value == 12 || value == 16 ? (int)value : 0;
+    else if (s == "conv1_pass_bytes") t.conv1_pass_bytes = value > 0 ? value : 0;
+    else if (s == "limb_pack_group") t.limb_pack_group = value > 0 ? (int)value : 1;
+    else if (s == "mac2_cfg") t.mac2_cfg = (int)value;
+    else if (s == "mac_order") t.mac_order = (int)value;
+    else if (s == "mac_regstage") t.mac_regstage = (int)value;
+    else if (s == "ntt_inv61_loose") t.ntt_inv61_loose = value ? 1 : 0;
+    else if (s == "relin_path") t.relin_path = (int)value;
+    else return CRC_ERR_NOT_FOUND;             // (no_fold is baked into the tables at creation)
+    return CRC_OK;
+}
+
 extern "C" int crc_default_coeff_modulus_128(int n, uint64_t *q, int cap)
 {
     static const u64 m1024[] = {0x7e00001}, m2048[] = {0x3fffffff000001}, m4096[] = {0x7fffffff380001, 0x3fffffff000001},
@@ -199,9 +237,10 @@ extern "C" int crc_ctx_create(int n, const uint64_t *q, int k, uint64_t t, int d
     for (int j = 0; j < c->ka; j++) bsk[j] = kAuxMods[j];
     bsk[c->ka] = kMsk;
 
+    read_tuning(c->tune);
     c->tabs.resize(k + c->kb);
-    for (int i = 0; i < k; i++) if (!build_ntt(c->tabs[i], c->logn, q[i])) { delete c; return CRC_ERR_PARAMETERS; }
-    for (int j = 0; j < c->kb; j++) if (!build_ntt(c->tabs[k + j], c->logn, bsk[j])) { delete c; return CRC_ERR_PARAMETERS; }
+    for (int i = 0; i < k; i++) if (!build_ntt(c->tabs[i], c->logn, q[i], c->tune.no_fold)) { delete c; return CRC_ERR_PARAMETERS; }
+    for (int j = 0; j < c->kb; j++) if (!build_ntt(c->tabs[k + j], c->logn, bsk[j], c->tune.no_fold)) { delete c; return CRC_ERR_PARAMETERS; }
 
     // floor(q/t) mod q_i and (q mod t) mod q_i, evaluator.cpp:66-105 -- long division of the multi-limb q by t
     {

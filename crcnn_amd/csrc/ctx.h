@@ -64,8 +64,27 @@ struct HostNtt {               // one modulus
     std::vector<u64> rp, srp, irp2, sirp2;   // bit-reversed powers + Shoup companions (layout as SEAL's tables)
 };
 
+// Tuning switches of tools/ and the tests.  The environment is read ONCE, inside crc_ctx_create (a host application that calls setenv from another thread
+// cannot race a launch); crc_ctx_set_tuning changes one value on a quiescent context.  None is needed for normal use.
+struct CrcTuning {
+    int no_fold = 0;              // CRC_NO_FOLD=1: generic Barrett reduction instead of the folding one
+    int ntt_inv61_loose = 0;      // CRC_NTT_INV61_LOOSE=1: do not hold the 61-bit inverse transform to 64 VGPRs
+    int mfma_order = -1;          // CRC_MFMA_ORDER=0|1: force the tile walk order of the limb GEMM (-1: by shape)
+    int mfma_variant = 2;         // CRC_MFMA_VARIANT=2: two workgroups per CU (mfma_mac2w_kernel), 1: mfma_mac_kernel
+    int mfma_ring = 0;            // CRC_MFMA_RING=4|5: LDS ring slots of mfma_mac_kernel
+    int conv1_waves = 0;          // CRC_CONV1_WAVES=8|12|16
+    long long conv1_pass_bytes = 0;   // CRC_CONV1_PASS_BYTES: work-space cap per internal pass of a one-channel convolution (0: 16 GiB)
+    int limb_pack_group = 1;      // CRC_LIMB_PACK_GROUP
+    int mac2_cfg = 0;             // CRC_MAC2_CFG=16|8: force a tile shape (mac2_kernel)
+    int mac_order = -1;           // CRC_MAC_ORDER=0|1
+    int mac_regstage = 0;         // CRC_MAC_REGSTAGE=1: register-staged mac2_kernel instead of the LDS-DMA mac3_kernel
+    int mac2_dbg = 0;             // CRC_MAC2_DBG (only in -DCRC_TUNING builds)
+    int relin_path = 0;           // CRC_RELIN_PATH=0: by parameters, 1: key switching over the coefficient moduli (round-2 path), 2: over the two fp64 primes
+};
+
 struct crc_ctx {
     int n, logn, k, ka, kb, device;
+    CrcTuning tune;
     u64 t;
     int total_bits;
     std::vector<u64> q;
@@ -98,5 +117,5 @@ u64  h_powmod(u64 a, u64 e, u64 q);
 u64  h_invmod(u64 a, u64 q);
 void h_ntt_fwd(const HostNtt &T, u64 *a, int n);      // canonical in/out
 void h_ntt_inv(const HostNtt &T, u64 *a, int n);
-ModParams make_mod(u64 q);
+ModParams make_mod(u64 q, bool no_fold = false);
 int  evk_digits(u64 q, int dbc);

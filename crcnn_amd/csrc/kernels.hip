@@ -226,7 +226,7 @@ static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t
         return CRC_OK;
     }
     if ((a.prologue == 3 && inv) || (a.prologue == 4 && !inv)) return CRC_ERR_INVALID_ARGUMENT;
-    static const bool strict61 = !getenv("CRC_NTT_INV61_LOOSE");
+    const bool strict61 = !c->tune.ntt_inv61_loose;
     auto kern = a.prologue == 4 ? (lazy ? ntt_rows_kernel<true, true, 4> : strict61 ? ntt_rows_inv61_kernel<4> : ntt_rows_kernel<true, false, 4>)
               : a.prologue == 3 ? (lazy ? ntt_rows_kernel<false, true, 3> : ntt_rows_kernel<false, false, 3>)
               : inv ? (lazy ? ntt_rows_kernel<true, true, 0> : strict61 ? ntt_rows_inv61_kernel<0> : ntt_rows_kernel<true, false, 0>) : (lazy ? ntt_rows_kernel<false, true, 0> : ntt_rows_kernel<false, false, 0>);
@@ -1010,12 +1010,12 @@ int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, co
     a.n = c->n; a.k = c->k; a.B = B; a.P = P; a.F = F; a.T = T; a.in_cts = in_cts; a.bias = bias_ntt; a.bias_sign = 1;
     a.gxd = gxd; a.gyd = gyd; a.gxf = gxf; a.gyf = gyf; a.xp = xp; a.wp = wp; a.yp = yp;
 #ifdef CRC_TUNING
-    { static const int dbg = [] { const char *e = getenv("CRC_MAC2_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
+    a.dbg = c->tune.mac2_dbg;
 #endif
     // tile configuration <PX, FT, WM, WN, S>: a workgroup covers PX*WM pixels x FT*WN filters (6 x 16 or 12 x 8), 24 accumulators
     // per wave either way; pick the shape that wastes fewer multiply-adds on filter/pixel padding (F = 50 -> 56 instead of 64,
     // F = 20 -> 24 instead of 32; measured equal on full tiles).  CRC_MAC2_CFG forces one (tools/bench_mac.py)
-    static const int cfg = [] { const char *e = getenv("CRC_MAC2_CFG"); return e ? atoi(e) : 0; }();
+    const int cfg = c->tune.mac2_cfg;
     int pick = cfg;
     if (pick == 0) {
         const long long M = (long long)B * P;
@@ -1023,13 +1023,13 @@ int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, co
         pick = padded(12, 8) * 100 < padded(6, 16) * 98 ? 8 : 16;
     }
     a.zero = c->d_zero;
-    { static const int ord = [] { const char *e = getenv("CRC_MAC_ORDER"); return e ? atoi(e) : -1; }();
+    { const int ord = c->tune.mac_order;
       const long long mtl = ((long long)B * P + 5) / 6;
       a.mt_fastest = ord >= 0 ? ord : (mtl <= 16); }
     // default: LDS-DMA staging with 4-step stages; the register-staged mac2_kernel remains for reductions whose term table does not
     // fit beside the two stage buffers (T > ~7000) and as the tuning reference (CRC_MAC_REGSTAGE=1, CRC_MAC2_CFG).  (Short reductions
     // that are not a multiple of 4 pay a padded last stage, T = 25: 28 steps; with packed operands mac3 still wins.)
-    static const int regstage = [] { const char *e = getenv("CRC_MAC_REGSTAGE"); return e ? atoi(e) : 0; }();
+    const int regstage = c->tune.mac_regstage;
     bool foldable = true;                          // mac3's epilogue is the folding reduction: needs q = 2^b - d, 50 <= b <= 55
     for (int i = 0; i < c->k; i++) if (!c->tabs[i].m.fold || c->tabs[i].m.bits < 50 || c->tabs[i].m.bits > 55) foldable = false;
     if (!regstage && !cfg && foldable) {

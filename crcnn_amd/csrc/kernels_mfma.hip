@@ -118,7 +118,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         if (younger >= 1) __builtin_amdgcn_s_waitcnt(7 | (7 << 4) | (15 << 8));
         else __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
         __syncthreads();
-        if (ks + NST - 2 < K) { issue(ks + NST - 2); if (ks + NST - 1 < K) issue(ks + NST - 1); }
+        __builtin_amdgcn_sched_barrier(0);                       // (the wait immediates count loads in issue order: keep the two steps' pieces apart and in order)
+        if (ks + NST - 2 < K) { issue(ks + NST - 2); __builtin_amdgcn_sched_barrier(0); if (ks + NST - 1 < K) issue(ks + NST - 1); }
+        __builtin_amdgcn_sched_barrier(0);
         const i8 *tA = lds + ((ks + (kg >> 1)) % NST) * (2 * TILE_B), *tW = tA + TILE_B;
         // the weight fragments and the first two A fragments are requested up front, then A fragment g + 2 behind the MFMAs of fragment g: a read has two groups of
         // 14 MFMAs to land (read just in time, each fragment's LDS latency sat exposed in front of its MFMAs; all 28 up front overflow the 4-bit lgkm counter and the
@@ -263,8 +265,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         if (ks + 2 < K) __builtin_amdgcn_s_waitcnt(11 | (7 << 4) | (15 << 8));
         else __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
         __syncthreads();
+        // the immediates above count loads in ISSUE order: the scheduling barriers pin A(ks + 3), W(ks + 4), A(ks + 4) (LDS-DMA writes do not alias the register loads,
+        // so nothing else stops the compiler from permuting them -- a permutation would let A(ks + 3) still be in flight when it is read)
+        __builtin_amdgcn_sched_barrier(0);
         if (ks + 3 < K) issue_a(ks + 3);
-        if (ks + 4 < K) { load_w(ks + 4, wload); issue_a(ks + 4); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 4 < K) { load_w(ks + 4, wload); __builtin_amdgcn_sched_barrier(0); issue_a(ks + 4); }
+        __builtin_amdgcn_sched_barrier(0);
         const i8 *tA = lds + ((ks + (kg >> 1)) % NST) * TILE_A;
         v4i av[2 * NPL];
         auto read_a = [&](int gi) { return *reinterpret_cast<const v4i *>(tA + (gi % NPL) * (64 * 32) + fragA + (gi / NPL) * (16 * 32)); };
@@ -283,8 +290,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     v4i w0[NPL], w1[NPL], w2[NPL];
     // prologue in the steady-state order: A(0), A(1), W(0), A(2), W(2)  -- the first wait leaves W(2) + A(2)'s four pieces ... at most 11 loads in flight
     issue_a(0); if (1 < K) issue_a(1);
+    __builtin_amdgcn_sched_barrier(0);
     load_w(0, w0);
-    if (2 < K) { issue_a(2); load_w(2, w1); }
+    __builtin_amdgcn_sched_barrier(0);
+    if (2 < K) { issue_a(2); __builtin_amdgcn_sched_barrier(0); load_w(2, w1); }
+    __builtin_amdgcn_sched_barrier(0);
     for (int ks = 0; ks < K; ks += 6) {
         dstep(ks, w0, w2);
         if (ks + 2 < K) dstep(ks + 2, w1, w0);
@@ -480,7 +490,7 @@ size_t k_limb_result_words(const crc_ctx *c, int B, int nf, int P) { return (siz
 int k_limb_pack_tensor(crc_ctx *c, const u64 *x, i8 *xl, int B, int zd, int npos, bool packed, hipStream_t st)
 {
     const int zdp = round_up(zd, 32);
-    static const int group = [] { const char *e = getenv("CRC_LIMB_PACK_GROUP"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();     // (4 and 8 adjacent pieces per thread measured 3-7 % slower)
+    const int group = c->tune.limb_pack_group;     // (4 and 8 adjacent pieces per thread measured 3-7 % slower)
     const size_t items = (size_t)B * npos * 2 * (zdp / 32);
     const size_t blocks = (size_t)(c->n / 64) * c->k * ((items + group - 1) / group);
     if (blocks == 0) return CRC_OK;
@@ -542,13 +552,12 @@ int k_limb_mac(crc_ctx *c, const i8 *xl, const i8 *wl, u64 *ys, i8 *xl_out, cons
     if (grid > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
     if (c->k > 8) return CRC_ERR_UNSUPPORTED;
     limb_tables(c, a.ksteps_real * 32, a.acc0, a.qinv);
-    static const int ring = [] { const char *e = getenv("CRC_MFMA_RING"); const int v = e ? atoi(e) : 0; return v >= 3 && v <= 5 ? v : 0; }();     // tuning (tools/)
+    const int ring = c->tune.mfma_ring;     // tuning (tools/)
     a.ksteps = round_up(a.ksteps_real, 2);
     // layers with few row tiles and many filter tiles (dense layers) stream their weights: walk the row tiles of one filter tile back to back, so that the weight tile is
     // fetched from HBM once and the (small) tensor stays in L2; convolutions keep filter tiles fastest (the big tensor tile is shared, the weights sit in L2)
-    { const char *eo = getenv("CRC_MFMA_ORDER"); a.mfast = eo ? atoi(eo) : (a.mtiles < a.Fp / 32 ? 1 : 0); }
-    const char *ev = getenv("CRC_MFMA_VARIANT");                 // 2 (default): two workgroups per CU (mfma_mac2w_kernel); 1: mfma_mac_kernel (read per call: the tests run both)
-    const int variant = ev ? atoi(ev) : 2;
+    a.mfast = c->tune.mfma_order >= 0 ? c->tune.mfma_order : (a.mtiles < a.Fp / 32 ? 1 : 0);
+    const int variant = c->tune.mfma_variant;                    // 2 (default): two workgroups per CU (mfma_mac2w_kernel); 1: mfma_mac_kernel (the tests run both: crc_ctx_set_tuning)
     if (variant == 2) {
         const size_t grid2 = (size_t)c->n * c->k * a.mtiles * (a.Fp / 32);
         if (grid2 > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;

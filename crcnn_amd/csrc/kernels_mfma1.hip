@@ -242,7 +242,7 @@ int k_limb_conv1(crc_ctx *c, const u64 *x, bool packed, i8 *xr, const i8 *wl, u6
         for (int sd = 0; sd < 4; sd++) worst = load[sd] > worst ? load[sd] : worst;
         return worst;
     };
-    static const int forced = [] { const char *e = getenv("CRC_CONV1_WAVES"); const int v = e ? atoi(e) : 0; return v == 8 || v == 12 || v == 16 ? v : 0; }();     // tuning (tools/)
+    const int forced = c->tune.conv1_waves;     // tuning (tools/)
     const int nwaves = forced ? forced : busiest(12) <= busiest(8) ? 12 : 8;
     const size_t lds = 2 * (size_t)a.img_stride + (xl_out ? a.out_img_bytes : 0);
     { const int rc = crc_ctx_ensure_lds(c, (const void *)mfma_conv1_kernel, lds); if (rc) return rc; }

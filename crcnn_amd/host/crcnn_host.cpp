@@ -106,6 +106,8 @@ ciphertext3D::ciphertext3D(int B, int zd, int xd, int yd, int form) : B(B), zd(z
 {
     size_t bytes = count() * ctBytes();
     if (form == CRC_NTTLC) { const size_t lb = crc_limb_tensor_bytes(ctx(), B, zd, xd, yd); if (lb > bytes) bytes = lb; }      // channels padded to 32
+    // a dense consumer's limb tensor: every output a channel of ONE position, rounded up to 32 (7 bytes per residue: larger than the ciphertexts below 217 channels)
+    if (form == CRC_NTTL) { const size_t lb = crc_limb_tensor_bytes(ctx(), B, zd * xd * yd, 1, 1); if (lb > bytes) bytes = lb; }
     buf = make_shared<DeviceBuffer>(bytes);
 }
 ciphertext3D ciphertext3D::fromHost(const uint64_t *h, int B, int zd, int xd, int yd)

@@ -166,7 +166,9 @@ class Network:
                 continue
             # a workgroup covers 64 rows = (image, pixel, poly): with fewer than half a tile of rows per launch (dense layers at small chunks) most of every MFMA is
             # padding and every slot's weights are streamed for a handful of rows -- mac3_kernel is faster there (PlainModelWoPad at chunk 6: fc4 0.23 vs 1.59 ms/image)
-            if B is not None and B * 2 * int(np.prod(oshape[1:])) < 32:
+            # (rows = images x 2 polys x output PIXELS: one for a dense layer, whose oshape is (1, out_dim, 1))
+            if B is not None and B * 2 * (1 if kind == "fc" else int(np.prod(oshape[1:]))) < 32:
+                p["limb_skipped"] = "fewer than 32 rows per launch"
                 continue
             nf, zd, xf, yf = (a["nf"], a["zd"], a["xf"], a["yf"]) if kind == "conv" else (a["out_dim"], a["in_dim"], 1, 1)
             nbytes = E.limb_weights_bytes(nf, zd, xf, yf)
@@ -445,9 +447,12 @@ class Network:
         size = [1, 1]
         for i, sl in enumerate(self.slots):
             size[sl] = max(size[sl], acts[i + 1] * B * self.ct_bytes())
-            if self.plan[i][3].get("out_form") == binding.NTTLC:          # a limb tensor pads the channels to 32 (7 bytes per residue instead of 8)
+            of = self.plan[i][3].get("out_form")
+            if of == binding.NTTLC:          # a limb tensor pads the channels to 32 (7 bytes per residue instead of 8)
                 nf, xo, yo = self.plan[i][5]
                 size[sl] = max(size[sl], self.E.limb_tensor_bytes(B, nf, xo, yo))
+            elif of == binding.NTTL:         # a dense consumer's tensor: all of the layer's outputs as channels of one position, rounded up to 32 (larger than the
+                size[sl] = max(size[sl], self.E.limb_tensor_bytes(B, acts[i + 1], 1, 1))      # ciphertexts themselves below 217 channels)
         self.buf = [self.alloc(size[0]), self.alloc(size[1])]
         self.act_bytes = size[0] + size[1]
         _, work = self.scratch_bytes(B)

@@ -58,7 +58,8 @@ enum { CRC_COEFF = 0, CRC_NTT = 1,
         * multiply, int32 accumulators, one reduction per output): the same ciphertexts as every other form, about 4x the throughput of the vector-ALU
         * kernel on long reductions.  crc_limb_pack_weights makes the weights; crc_conv2d_forms / crc_dense_forms take w_form = CRC_NTTL, convert a
         * CRC_COEFF / CRC_NTT / CRC_NTTP input themselves and produce any form (out_form = CRC_NTTL hands the tensor to a DENSE layer: channels =
-        * (filter, x, y) flattened, 1 x 1 positions).  Needs coefficient moduli below 2^56 and reductions of at most 18 000 terms. */
+        * (filter, x, y) flattened, 1 x 1 positions).  Needs coefficient moduli below 2^55 (at most 55 significant bits: |centred residue| < 2^54 fits seven balanced
+        * bytes) and reductions of at most 18 000 terms; crc_limb_supported answers for a context and shape. */
        CRC_NTTL = 3,
        /* weights of a ONE-CHANNEL convolution (CrCNN's conv1, alone or fused with its pooling layer: window <= 8 x 8, <= 32 filters) for the matrix-core
         * kernel specialised for it (kernels_mfma1.hip): [k][n][2][7][32 filters][32 window taps], tap = 8 kx + ky.  w_form only (crc_limb_conv1_*). */
@@ -90,6 +91,10 @@ size_t crc_evk_words(const crc_ctx *ctx, int dbc);     /* words of an evaluation
 /* named host-side table read-out (tests): "root","const_ratio","delta","upper_half_increment","bsk","bsk_root",
  * "root_powers:<i>","inv_root_powers_div_two:<i>"; returns word count */
 int  crc_ctx_table(const crc_ctx *ctx, const char *name, uint64_t *h_out, int cap);
+/* Tuning switches of tools/ and the tests (none is needed for normal use).  The engine reads its environment (CRC_MFMA_VARIANT, CRC_CONV1_PASS_BYTES, ...) exactly
+ * once, inside crc_ctx_create; this call changes one switch of a context nobody is launching on: "mfma_variant", "mfma_order", "mfma_ring", "conv1_waves",
+ * "conv1_pass_bytes", "limb_pack_group", "mac2_cfg", "mac_order", "mac_regstage", "ntt_inv61_loose", "relin_path".  CRC_ERR_NOT_FOUND for anything else. */
+int  crc_ctx_set_tuning(crc_ctx *ctx, const char *name, long long value);
 
 /* thin device-memory helpers so that C / C++ / ctypes callers need not link HIP themselves */
 int crc_mem_info(crc_ctx *ctx, size_t *free_bytes, size_t *total_bytes);      /* hipMemGetInfo of the context's device */

@@ -222,7 +222,9 @@ def make_search():
         subprocess.check_call(["make", "-C", HERE, "ref", "-j8"])
     out = []
     for lo, hi, pw, fg, lg in search_cases():
-        r = subprocess.run([harness, str(lo), str(hi), str(pw), str(fg), str(lg)], capture_output=True, text=True, check=True)
+        # (linked against the image's libhdf5: _ref/h5libs holds symlinks to exactly those two libraries, oracle/Makefile)
+        r = subprocess.run([harness, str(lo), str(hi), str(pw), str(fg), str(lg)], capture_output=True, text=True, check=True,
+                           env=dict(os.environ, LD_LIBRARY_PATH=os.path.join(HERE, "_ref", "h5libs")))
         lines = r.stderr.splitlines()
         tried = [[int(l.split()[1]), l.split()[2]] for l in lines if l.startswith("tried")]
         found = int([l for l in lines if l.startswith("found")][0].split()[1])

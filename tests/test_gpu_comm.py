@@ -38,6 +38,45 @@ def test_comm_one_rank_broadcast_and_checksum():
     E.close()
 
 
+def test_comm_one_process_all_devices():
+    """the one-process, many-GPU entry points (crc_comm_create_all / crc_broadcast_weights_all): one context per visible GPU (one on the test box, the same
+    code with 8 on a node), broadcast from the last device, every context's checksum equals the root's, and the calling thread's device is left alone"""
+    import ctypes
+    import torch
+    import crcnn_amd as ca
+    ndev = min(torch.cuda.device_count(), 8)
+    assert ndev >= 1
+    engs = [ca.Engine(1024, [0x7fffffff380001, 0x3fffffff000001], 1 << 20, device=d) for d in range(ndev)]
+    L = engs[0].L
+    VP = ctypes.c_void_p
+    ctxs = (VP * ndev)(*[e.c for e in engs]); comms = (VP * ndev)()
+    torch.cuda.set_device(0)
+    assert L.crc_comm_create_all(ctxs, ndev, comms) == 0
+    assert torch.cuda.current_device() == 0
+    words = (1 << 18) + 5
+    rng = np.random.default_rng(11)
+    root = ndev - 1
+    bufs = []
+    for d, e in enumerate(engs):
+        w = rng.integers(0, 1 << 63, size=words, dtype=np.uint64)
+        if d == root:
+            want = w
+        bufs.append(e.upload(w))
+    ptrs = (VP * ndev)(*[engs[d].p(bufs[d]) for d in range(ndev)])
+    assert L.crc_broadcast_weights_all(comms, ndev, ctypes.cast(ptrs, ctypes.POINTER(VP)), words, root, None) == 0
+    assert torch.cuda.current_device() == 0
+    wx = int(np.bitwise_xor.reduce(want)); ws = int(np.sum(want * (2 * np.arange(words, dtype=np.uint64) + 1), dtype=np.uint64))
+    for d in reversed(range(ndev)):                  # checksum of context d from a thread whose current device is 0
+        engs[d].sync()
+        assert engs[d].checksum64(bufs[d], words * 8) == (wx, ws), d
+        assert np.array_equal(engs[d].download(bufs[d], (words,)), want)
+    for d in range(ndev):
+        L.crc_comm_destroy(comms[d])
+    assert torch.cuda.current_device() == 0
+    for e in engs:
+        e.close()
+
+
 def _run_bench(extra, env_extra=None):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     env.update(env_extra or {})

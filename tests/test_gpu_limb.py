@@ -86,7 +86,7 @@ def test_conv1_matrix_core_kernel(eng, shape, edge):
     assert np.array_equal(E.download(d_y, (rows_y, E.n)), want), (shape, "coeff in")
 
 
-def test_conv1_multi_pass(eng, monkeypatch):
+def test_conv1_multi_pass(eng, request):
     """a batch whose work space would exceed the per-pass cap is processed in sub-batches: same ciphertexts, same limb tensor"""
     E, ca = eng
     xd, yd, xs, ys, xf, yf, nf, B = 28, 28, 2, 2, 6, 6, 32, 5
@@ -100,7 +100,8 @@ def test_conv1_multi_pass(eng, monkeypatch):
     nb = E.limb_tensor_bytes(B, nf, xo, yo)
     d_y = E.alloc(max(rows_y * E.n * 8, nb))
     whole = E.conv2d_forms_work_bytes(B, 1, xd, yd, xs, ys, xf, yf, nf, ca.COEFF, ca.NTTL1, ca.NTT)
-    monkeypatch.setenv("CRC_CONV1_PASS_BYTES", str(whole // 3))          # a third of the whole: one or two images per pass
+    E.set_tuning("conv1_pass_bytes", whole // 3)          # a third of the whole: one or two images per pass
+    request.addfinalizer(lambda: E.set_tuning("conv1_pass_bytes", 0))
     assert E.conv2d_forms_work_bytes(B, 1, xd, yd, xs, ys, xf, yf, nf, ca.COEFF, ca.NTTL1, ca.NTT) < whole // 2
     d_xc = E.upload(x); E.ntt_inv(d_xc, B * xd * yd)
     d_work = E.alloc(E.conv2d_forms_work_bytes(B, 1, xd, yd, xs, ys, xf, yf, nf, ca.COEFF, ca.NTTL1, ca.NTT))
@@ -136,9 +137,9 @@ GEMM_SHAPES = [
 
 @pytest.mark.parametrize("variant", ["2", "1"], ids=["two-workgroups-per-CU", "one-workgroup-per-CU"])
 @pytest.mark.parametrize("shape", GEMM_SHAPES)
-def test_limb_gemm_kernel(eng, shape, variant, monkeypatch):
-    monkeypatch.setenv("CRC_MFMA_VARIANT", variant)
+def test_limb_gemm_kernel(eng, shape, variant, request):
     E, ca = eng
+    E.set_tuning("mfma_variant", int(variant)); request.addfinalizer(lambda: E.set_tuning("mfma_variant", 2))
     zd, xd, yd, xs, ys, xf, yf, nf, B = shape
     rng = np.random.default_rng(zd * 100 + nf)
     xo, yo = (xd - xf) // xs + 1, (yd - yf) // ys + 1
@@ -169,9 +170,9 @@ DENSE_HANDOVER_SHAPES = [
 
 @pytest.mark.parametrize("variant", ["2", "1"], ids=["two-workgroups-per-CU", "one-workgroup-per-CU"])
 @pytest.mark.parametrize("shape", DENSE_HANDOVER_SHAPES)
-def test_limb_gemm_hands_over_to_dense(eng, shape, variant, monkeypatch):
-    monkeypatch.setenv("CRC_MFMA_VARIANT", variant)
+def test_limb_gemm_hands_over_to_dense(eng, shape, variant, request):
     E, ca = eng
+    E.set_tuning("mfma_variant", int(variant)); request.addfinalizer(lambda: E.set_tuning("mfma_variant", 2))
     zd, xd, yd, xs, ys, xf, yf, nf, B = shape
     rng = np.random.default_rng(zd * 7 + nf)
     xo, yo = (xd - xf) // xs + 1, (yd - yf) // ys + 1

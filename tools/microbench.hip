@@ -25,6 +25,18 @@ template <int OP> __global__ void __launch_bounds__(256) probe(u64 *out, u32 a0,
             if (OP == 6) acc[i] = (u64)((u32)acc[i] + a + i);                             // v_add_u32 / v_add3
             if (OP == 7) { u64 x = acc[i]; acc[i] = __umul64hi(x, ((u64)a << 32) | b) + x * (((u64)b << 32) | a); }   // full 64x64 hi + lo
             if (OP == 8) { u64 x = acc[i]; acc[i] = x * ((((u64)a << 32) | b) + i); }    // 64x64 low
+            if (OP == 9) dacc[i] = __builtin_rint(dacc[i] * da) + db;                     // v_mul_f64 + v_rndne_f64 + v_add_f64
+            if (OP == 10) {                                                               // fp64 modular multiplication by a constant (6 flops): exact for p < 2^50
+                const double w = 123456789012345.0 + i, wq = w / 140737488355333.0, P = 140737488355333.0, y = dacc[i];
+                const double h = w * y, l = __builtin_fma(w, y, -h), c = __builtin_rint(y * wq);
+                dacc[i] = __builtin_fma(-c, P, h) + l;
+            }
+            if (OP == 11) {                                                               // the row NTT's lazy 64-bit Shoup product (3-product quotient estimate)
+                const u64 w = (((u64)a << 23) | b) + i, wp = ~w, q = 0x7fffffff380001ULL, y = acc[i];
+                const u32 y0 = (u32)y, y1 = (u32)(y >> 32), p0 = (u32)wp, p1 = (u32)(wp >> 32);
+                const u64 hq = (u64)y1 * p1 + __umulhi(y1, p0) + __umulhi(y0, p1);
+                acc[i] = y * w - hq * q;
+            }
         }
     }
     u64 s = 0; for (int i = 0; i < NACC; i++) s += acc[i] + (u64)dacc[i];
@@ -55,5 +67,6 @@ int main()
     printf("device %s  CUs %d  clock %d kHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate);
     run<0>("mad_u64_u32", 1); run<1>("mul_lo_u32(+add)", 1); run<2>("mul_hi_u32(+add)", 1); run<3>("mul_u32_u24(+add)", 1);
     run<4>("fma_f64", 1); run<5>("add_u64", 1); run<6>("add_u32", 1); run<7>("umul64hi + mul64lo", 1); run<8>("mul64 lo", 1);
+    run<9>("mul+rndne+add f64", 3); run<10>("fp64 modmul (6 flops) as 1", 1); run<11>("u64 lazy Shoup modmul as 1", 1);
     return 0;
 }
