@@ -107,8 +107,13 @@ LAYER_SET = dict(n=256, q=[0x7fffffff380001, 0x3fffffff000001], t=1 << 20, zd=2,
                  conv=(2, 1, 3, 3, 3), fc_out=4, pool=(2, 1, 2, 2))
 
 
-def make_layers():
-    S = LAYER_SET
+# a ONE-channel convolution (CrCNN's conv1 shape class: what the engine's CRC_NTTL1 matrix-core kernel takes), through the reference's own ConvolutionalLayer
+LAYER_SET1 = dict(n=256, q=[0x7fffffff380001, 0x3fffffff000001], t=1 << 20, zd=1, xd=9, yd=10,
+                  conv=(2, 1, 4, 3, 5), fc_out=4, pool=(2, 1, 2, 2))
+
+
+def make_layers(S=None, out_name="layers_n256_k2_t20.npz", conv_only=False):
+    S = S or LAYER_SET
     n, q, t = S["n"], S["q"], S["t"]
     O = orc.Oracle(n, q, t); k = O.k
     sk, pk = O.keygen(3000); evk = O.gen_evk(3001, sk)
@@ -122,7 +127,7 @@ def make_layers():
     bn_mean = rng.normal(0, 0.3, size=zd).astype(np.float32); bn_var = rng.uniform(0.5, 2.0, size=zd).astype(np.float32)
     with tempfile.TemporaryDirectory() as d:
         put(d, "params.u64", [n, k, t] + list(q)); put(d, "evk.u64", evk)
-        put(d, "layer_dims.u64", [zd, xd, yd, xs, ys, xf, yf, nf, S["fc_out"]] + list(S["pool"]))
+        put(d, "layer_dims.u64", [zd, xd, yd, xs, ys, xf, yf, nf, S["fc_out"]] + list(S["pool"]) + [1 if conv_only else 0])
         put(d, "layer_in.u64", x)
         for nm, a in [("conv_w", conv_w), ("conv_b", conv_b), ("fc_w", fc_w), ("fc_b", fc_b), ("bn_mean", bn_mean), ("bn_var", bn_var)]:
             put(d, nm + ".f64", a.astype(np.float64), dtype=np.float64)
@@ -133,11 +138,15 @@ def make_layers():
         g = dict(n=n, q=np.array(q, dtype=np.uint64), t=t, sk=sk, pk=pk, evk=evk, x=x, img=img,
                  dims=np.array([zd, xd, yd, xs, ys, xf, yf, nf, S["fc_out"]] + list(S["pool"])),
                  conv_w=conv_w, conv_b=conv_b, fc_w=fc_w, fc_b=fc_b, bn_mean=bn_mean, bn_var=bn_var,
-                 ref_conv=get(d, "ref_conv.u64", (nf, xo, yo, 2, k, n)), ref_fc=get(d, "ref_fc.u64", (1, S["fc_out"], 1, 2, k, n)),
-                 ref_pool=get(d, "ref_pool.u64", (zd, pxo, pyo, 2, k, n)), ref_avgpool=get(d, "ref_avgpool.u64", (zd, pxo, pyo, 2, k, n)),
-                 ref_bn=get(d, "ref_bn.u64", (zd, xd, yd, 2, k, n)), ref_square=get(d, "ref_square.u64", (zd, xd, yd, 2, k, n)))
-    np.savez_compressed(os.path.join(GOLD, "layers_n256_k2_t20.npz"), **g)
-    print("wrote layers", {k_: v.shape for k_, v in g.items() if k_.startswith("ref_")})
+                 ref_conv=get(d, "ref_conv.u64", (nf, xo, yo, 2, k, n)))
+        if not conv_only:
+            g.update(ref_fc=get(d, "ref_fc.u64", (1, S["fc_out"], 1, 2, k, n)),
+                     ref_pool=get(d, "ref_pool.u64", (zd, pxo, pyo, 2, k, n)), ref_avgpool=get(d, "ref_avgpool.u64", (zd, pxo, pyo, 2, k, n)),
+                     ref_bn=get(d, "ref_bn.u64", (zd, xd, yd, 2, k, n)), ref_square=get(d, "ref_square.u64", (zd, xd, yd, 2, k, n)))
+    if conv_only:
+        g = {k_: v for k_, v in g.items() if k_ in ("n", "q", "t", "x", "img", "dims", "conv_w", "conv_b", "ref_conv", "sk")}
+    np.savez_compressed(os.path.join(GOLD, out_name), **g)
+    print("wrote", out_name, {k_: v.shape for k_, v in g.items() if k_.startswith("ref_")})
 
 
 # ---- model weights straight from the reference's .h5 files via the image's h5dump (pins the product's own HDF5 reader)
@@ -244,6 +253,8 @@ if __name__ == "__main__":
             make_ops(nm, n, q, t, nct, vals)
     if "layers" in what:
         make_layers()
+    if "layers1" in what:
+        make_layers(LAYER_SET1, "layers1_n256_k2_t20.npz", conv_only=True)
     if "loader" in what:
         make_loader()
     if "files" in what:

@@ -325,6 +325,7 @@ static int do_layers()
     vector<u64> out;
     {   ConvolutionalLayer *l = make_conv("conv", xd, yd, zd, dims[3], dims[4], dims[5], dims[6], dims[7], 2, fw, fb);
         out.clear(); from_tensor(l->forward(to_tensor(x, zd, xd, yd)), out); wr("ref_conv.u64", out); delete l; }
+    if (dims.size() > 13 && dims[13]) return 0;          // convolution only (one-channel set: the reference's dense layer does not survive zd = 1 with two threads)
     {   auto w = rdf("fc_w.f64"), b = rdf("fc_b.f64"); int od = dims[8];
         FullyConnectedLayer *l = make_fc("fc", zd * xd * yd, od, 2, w, b);
         out.clear(); from_tensor(l->forward(to_tensor(x, zd, xd, yd)), out); wr("ref_fc.u64", out); delete l; }

@@ -89,14 +89,16 @@ FULL = [n for n in ["tiny4096_t32", "approx8192_t42", "wopad16384_t44"] if os.pa
 
 
 @pytest.mark.parametrize("name", FULL)
-@pytest.mark.parametrize("fuse", [False, True], ids=["unfused", "fused"])
-def test_cpp_network_full_size_equals_reference(name, fuse):
+@pytest.mark.parametrize("fuse,batch", [(False, 1), (True, 1), (True, 16)], ids=["unfused", "fused", "fused-batch16"])
+def test_cpp_network_full_size_equals_reference(name, fuse, batch):
     """the drop-in itself (C++ Layer / Network / CnnBuilder) at the BASELINE ring sizes and the plain moduli bench.py runs at:
     CnnBuilder reads the real model, Network::forward (NTT-resident, with and without Network::fuse) must produce the compiled
-    reference's output ciphertexts bit for bit"""
-    g, O, d = run_driver(name, resident=True, batch=1, fuse=fuse)
-    out = np.fromfile(os.path.join(d, "out.u64"), dtype=np.uint64)
-    assert sha(out) == g["out_sha256"]
+    reference's output ciphertexts bit for bit.  Batch 16 gives a dense layer 32 rows = (image, poly): the C++ classes' dense limb path (a batch-1 dense layer
+    stays on the vector-ALU kernel) and the limb hand-overs conv -> dense, dense -> dense are golden-checked at BASELINE sizes too"""
+    g, O, d = run_driver(name, resident=True, batch=batch, fuse=fuse)
+    out = np.fromfile(os.path.join(d, "out.u64"), dtype=np.uint64).reshape(batch, -1)
+    for b in range(batch):
+        assert sha(out[b]) == g["out_sha256"], (name, b)
     import shutil
     shutil.rmtree(d, ignore_errors=True)
 

@@ -1,6 +1,11 @@
-"""GPU parity, layer level, of the matrix-core kernels (kernels_mfma.hip / kernels_mfma1.hip) against the vector-ALU kernel of the same layer, which
-tests/test_gpu_layers.py pins to the reference's own Layer::forward outputs.  Random full-range residues (the worst case for the limb split: digits at
-both ends of [-128, 127]), every operand / result form, ragged shapes.  Bit-exact."""
+"""GPU parity, layer level, of the matrix-core kernels (kernels_mfma.hip / kernels_mfma1.hip):
+  * DIRECTLY against the CPU oracle's convolution (oracle/crc_oracle.c conv_run = convolution3d, convolutionalLayer.cpp:56-93) on the same operands -- random
+    full-range residues and extreme-digit residues (the worst cases for the balanced-limb split: digits at both ends of [-128, 127]) as the NTT-domain values --
+    for every weight form (CRC_NTTL, CRC_NTTL1), the coefficient-form layer contract, NTT residency, and the limb hand-overs (CRC_NTTLC, CRC_NTTL), whose
+    expected tensors are built here in numpy from the oracle's result;
+  * against the reference's own ConvolutionalLayer / FullyConnectedLayer outputs (tests/golden/layers*_n256_k2_t20.npz) with the weights in limb form;
+  * against the vector-ALU kernel of the same layer for the remaining operand / result forms, ragged shapes and multi-pass runs.
+Bit-exact."""
 import numpy as np
 import pytest
 
@@ -36,6 +41,209 @@ def vector_alu_conv(E, ca, d_x, d_w, d_b, B, zd, xd, yd, xs, ys, xf, yf, nf):
     E.conv2d(d_x, d_w, d_b, B, zd, xd, yd, xs, ys, xf, yf, nf, ca.NTT, ca.NTT, d_y, d_work)
     E.sync()
     return E.download(d_y, (B * nf * xo * yo * 2 * E.k, E.n))
+
+
+# ---- the oracle as the direct checker -----------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def O():
+    from oracle import orc
+    return orc.Oracle(N, Q, 1 << 20)
+
+
+def oracle_layer(O, x_ntt, w_ntt, bias_vals, B, zd, xd, yd, xs, ys, xf, yf, nf):
+    """the reference's convolution (oracle restatement) on operands whose NTT-DOMAIN values are the given rows: the input ciphertexts are the oracle's own inverse
+    transforms of x_ntt, so that the products inside are exactly x_ntt * w_ntt.  Returns (coefficient-form inputs, coefficient-form result, NTT-form result)."""
+    k, n = O.k, O.n
+    xc = np.empty((B * zd * xd * yd, 2, k, n), dtype=np.uint64)
+    for i, ct in enumerate(x_ntt.reshape(-1, 2, k, n)):
+        xc[i] = O.ct_from_ntt(ct)
+    xc = xc.reshape(B, zd, xd, yd, 2, k, n)
+    w = np.ascontiguousarray(w_ntt.reshape(nf, zd, xf, yf, k, n))
+    bp = O.encode_many(bias_vals)
+    macs = nf * ((xd - xf) // xs + 1) * ((yd - yf) // ys + 1) * zd * xf * yf
+    # reference operation order (one inverse transform per product) where that takes seconds, NTT-domain accumulation of the same oracle primitives otherwise
+    # (bit-identical: tests/test_oracle_layers.py::test_conv)
+    want = np.stack([O.conv(xc[b], w, bp, xs, ys, threads=8, fast=macs > 20000) for b in range(B)])
+    want_ntt = np.empty_like(want)
+    flat, flat_n = want.reshape(-1, 2, k, n), want_ntt.reshape(-1, 2, k, n)
+    for i in range(flat.shape[0]):
+        flat_n[i] = O.ct_to_ntt(flat[i])
+    return xc, want, want_ntt
+
+
+def np_limb_tensor(y_ntt, q, dense):
+    """numpy statement of the limb operand form (include/crcnn_hip.h CRC_NTTL): y_ntt [B][C][P][2][k][n] canonical residues -> int8 balanced base-256 digits of the
+    centred representatives; conv consumer [k][n][B][7][P][2][C^32], dense consumer (all C * P outputs as channels of one position) [k][n][7][ch/32][B*2][32]"""
+    B, C, P = y_ntt.shape[:3]
+    k, n = y_ntt.shape[-2:]
+    qv = np.array(q, dtype=np.int64).reshape(1, 1, 1, 1, k, 1)
+    v = y_ntt.astype(np.int64)
+    v = np.where(v > (qv >> 1), v - qv, v)
+    digs = []
+    for _ in range(7):
+        d = ((v + 128) & 255) - 128
+        digs.append(d.astype(np.int8)); v = (v - d) >> 8
+    assert not v.any()
+    dg = np.stack(digs)                                   # [7][B][C][P][2][k][n]
+    if not dense:
+        Cp = -(-C // 32) * 32
+        out = np.zeros((k, n, B, 7, P, 2, Cp), dtype=np.int8)
+        out[..., :C] = dg.transpose(5, 6, 1, 0, 3, 4, 2)
+        return out
+    ch = C * P; chp = -(-ch // 32) * 32
+    flat = np.zeros((7, B, chp, 2, k, n), dtype=np.int8)
+    flat[:, :, :ch] = dg.reshape(7, B, ch, 2, k, n)
+    # [k][n][7][chp/32][B][2][32]
+    return np.ascontiguousarray(flat.reshape(7, B, chp // 32, 32, 2, k, n).transpose(5, 6, 0, 2, 1, 4, 3))
+
+
+def gpu_bias(E, ca, bias_vals, form):
+    pl, _ = E.encode(np.asarray(bias_vals, dtype=np.float32))
+    d_b = E.alloc(len(pl) * E.k * E.n * 8)
+    E.plain_to_delta(E.upload(pl), len(pl), form, d_b)
+    return d_b
+
+
+ORACLE_CONV1_SHAPES = [
+    # xd, yd, xs, ys, xf, yf, nf, B        (zd = 1)
+    (28, 28, 2, 2, 6, 6, 32, 1),           # PlainModelTiny conv1 + pool1
+    (28, 28, 2, 2, 7, 7, 20, 1),           # ApproxPlainModel / PlainModelWoPad conv1 + pool1
+    (9, 11, 1, 2, 3, 4, 5, 2),             # ragged
+    (8, 8, 1, 1, 8, 8, 1, 3),              # a single output pixel and filter
+]
+
+
+@pytest.mark.parametrize("shape", ORACLE_CONV1_SHAPES)
+@pytest.mark.parametrize("edge", [False, True])
+def test_conv1_kernel_equals_oracle(eng, O, shape, edge):
+    E, ca = eng
+    xd, yd, xs, ys, xf, yf, nf, B = shape
+    rng = np.random.default_rng(xd * 999 + yf * 13 + nf + 7 * edge)
+    xo, yo = (xd - xf) // xs + 1, (yd - yf) // ys + 1
+    x = rand_rows(rng, E, B * xd * yd * 2, edge); w = rand_rows(rng, E, nf * xf * yf, edge)
+    bv = rng.normal(0, 0.3, nf).astype(np.float32)
+    xc, want, want_ntt = oracle_layer(O, x, w, bv, B, 1, xd, yd, xs, ys, xf, yf, nf)
+    d_w = E.upload(w)
+    d_wl = E.alloc(E.limb_conv1_weights_bytes()); E.limb_conv1_pack_weights(d_w, nf, xf, yf, d_wl)
+    rows_y = B * nf * xo * yo * 2 * E.k
+    d_y = E.alloc(max(rows_y * E.n * 8, E.limb_tensor_bytes(B, nf, xo, yo)))
+    # the layer as the reference calls it: coefficient form in and out
+    d_work = E.alloc(E.conv2d_forms_work_bytes(B, 1, xd, yd, xs, ys, xf, yf, nf, ca.COEFF, ca.NTTL1, ca.COEFF))
+    E.conv2d(E.upload(xc), d_wl, gpu_bias(E, ca, bv, ca.COEFF), B, 1, xd, yd, xs, ys, xf, yf, nf, ca.COEFF, ca.COEFF, d_y, d_work, w_form=ca.NTTL1)
+    E.sync()
+    assert np.array_equal(E.download(d_y, want.shape), want), (shape, edge, "coefficient form")
+    # NTT-resident
+    d_bn = gpu_bias(E, ca, bv, ca.NTT)
+    d_work = E.alloc(E.conv2d_forms_work_bytes(B, 1, xd, yd, xs, ys, xf, yf, nf, ca.NTT, ca.NTTL1, ca.NTT))
+    E.conv2d(E.upload(x), d_wl, d_bn, B, 1, xd, yd, xs, ys, xf, yf, nf, ca.NTT, ca.NTT, d_y, d_work, w_form=ca.NTTL1)
+    E.sync()
+    assert np.array_equal(E.download(d_y, want.shape), want_ntt), (shape, edge, "NTT form")
+    # hand-over to a matrix-core convolution: the limb tensor, built here from the oracle's result
+    if xo * yo > 1:
+        nb = E.limb_tensor_bytes(B, nf, xo, yo)
+        E.L.crc_memset(E.c, E.p(d_y), 0, nb, E.stream)
+        d_work = E.alloc(E.conv2d_forms_work_bytes(B, 1, xd, yd, xs, ys, xf, yf, nf, ca.NTT, ca.NTTL1, ca.NTTLC))
+        E.conv2d(E.upload(x), d_wl, d_bn, B, 1, xd, yd, xs, ys, xf, yf, nf, ca.NTT, ca.NTTLC, d_y, d_work, w_form=ca.NTTL1)
+        E.sync()
+        exp = np_limb_tensor(want_ntt.reshape(B, nf, xo * yo, 2, E.k, E.n), E.q, dense=False)
+        assert np.array_equal(E.download(d_y, exp.shape, dtype=np.int8), exp), (shape, edge, "limb tensor")
+
+
+ORACLE_GEMM_SHAPES = [
+    # zd, xd, yd, xs, ys, xf, yf, nf, B
+    (32, 6, 6, 1, 1, 3, 3, 64, 2),          # 4 x 4 pixels: direct dense hand-over (2P | 64)
+    (20, 5, 7, 2, 1, 3, 2, 50, 1),          # channel and filter padding, ragged rows; 2P = 24: slot-major result + conversion kernel
+    (70, 1, 1, 1, 1, 1, 1, 10, 9),          # a dense layer (dense -> dense hand-over)
+]
+
+
+@pytest.mark.parametrize("variant", [2, 1], ids=["two-workgroups-per-CU", "one-workgroup-per-CU"])
+@pytest.mark.parametrize("shape", ORACLE_GEMM_SHAPES)
+@pytest.mark.parametrize("edge", [False, True])
+def test_limb_gemm_equals_oracle(eng, O, shape, edge, variant, request):
+    E, ca = eng
+    E.set_tuning("mfma_variant", variant); request.addfinalizer(lambda: E.set_tuning("mfma_variant", 2))
+    zd, xd, yd, xs, ys, xf, yf, nf, B = shape
+    rng = np.random.default_rng(zd * 101 + nf + 5 * edge)
+    xo, yo = (xd - xf) // xs + 1, (yd - yf) // ys + 1
+    x = rand_rows(rng, E, B * zd * xd * yd * 2, edge); w = rand_rows(rng, E, nf * zd * xf * yf, edge)
+    bv = rng.normal(0, 0.3, nf).astype(np.float32)
+    xc, want, want_ntt = oracle_layer(O, x, w, bv, B, zd, xd, yd, xs, ys, xf, yf, nf)
+    d_wl = E.alloc(E.limb_weights_bytes(nf, zd, xf, yf)); E.limb_pack_weights(E.upload(w), nf, zd, xf, yf, d_wl)
+    d_y = E.alloc(max(want.nbytes, E.limb_tensor_bytes(B, nf * xo * yo)))
+    # coefficient form in and out
+    d_work = E.alloc(E.conv2d_forms_work_bytes(B, zd, xd, yd, xs, ys, xf, yf, nf, ca.COEFF, ca.NTTL, ca.COEFF))
+    E.conv2d(E.upload(xc), d_wl, gpu_bias(E, ca, bv, ca.COEFF), B, zd, xd, yd, xs, ys, xf, yf, nf, ca.COEFF, ca.COEFF, d_y, d_work, w_form=ca.NTTL)
+    E.sync()
+    assert np.array_equal(E.download(d_y, want.shape), want), (shape, edge, "coefficient form")
+    # limb tensor in (made in numpy from the same rows: pins crc_limb_pack_tensor's layout too), NTT form out
+    d_bn = gpu_bias(E, ca, bv, ca.NTT)
+    xl = np_limb_tensor(x.reshape(B, zd, xd * yd, 2, E.k, E.n), E.q, dense=(xd * yd == 1))
+    d_xl = E.alloc(E.limb_tensor_bytes(B, zd, xd, yd)); E.limb_pack_tensor(E.upload(x), ca.NTT, B, zd, xd, yd, d_xl); E.sync()
+    assert np.array_equal(E.download(d_xl, xl.shape, dtype=np.int8), xl), (shape, edge, "crc_limb_pack_tensor")
+    d_work = E.alloc(E.conv2d_forms_work_bytes(B, zd, xd, yd, xs, ys, xf, yf, nf, ca.NTTL, ca.NTTL, ca.NTT))
+    E.conv2d(E.upload(xl), d_wl, d_bn, B, zd, xd, yd, xs, ys, xf, yf, nf, ca.NTTL, ca.NTT, d_y, d_work, w_form=ca.NTTL)
+    E.sync()
+    assert np.array_equal(E.download(d_y, want.shape), want_ntt), (shape, edge, "limb in, NTT out")
+    # hand-over to a dense matrix-core layer
+    nb = E.limb_tensor_bytes(B, nf * xo * yo)
+    E.L.crc_memset(E.c, E.p(d_y), 0x55, nb, E.stream)
+    d_work = E.alloc(E.conv2d_forms_work_bytes(B, zd, xd, yd, xs, ys, xf, yf, nf, ca.NTT, ca.NTTL, ca.NTTL))
+    E.conv2d(E.upload(x), d_wl, d_bn, B, zd, xd, yd, xs, ys, xf, yf, nf, ca.NTT, ca.NTTL, d_y, d_work, w_form=ca.NTTL)
+    E.sync()
+    exp = np_limb_tensor(want_ntt.reshape(B, nf, xo * yo, 2, E.k, E.n), E.q, dense=True)
+    assert np.array_equal(E.download(d_y, exp.shape, dtype=np.int8), exp), (shape, edge, "dense hand-over")
+
+
+def test_reference_layer_outputs_with_limb_weights():
+    """CrCNN's own ConvolutionalLayer / FullyConnectedLayer outputs (tests/golden/layers_n256_k2_t20.npz, layers1_...: compiled reference) reproduced with the
+    weights in the matrix-core forms: CRC_NTTL for the two-channel convolution and the dense layer, CRC_NTTL1 for the one-channel convolution"""
+    import os
+    import crcnn_amd as ca
+    gd = os.path.join(os.path.dirname(__file__), "golden")
+    g = dict(np.load(os.path.join(gd, "layers_n256_k2_t20.npz")))
+    E = ca.Engine(int(g["n"]), [int(v) for v in g["q"]], int(g["t"]), device=0)
+
+    def weights(wv):
+        pl, _ = E.encode(np.asarray(wv, dtype=np.float32)); d_w = E.alloc(len(pl) * E.k * E.n * 8)
+        E.plain_to_ntt(E.upload(pl), len(pl), d_w); return d_w
+
+    zd, xd, yd, xs, ys, xf, yf, nf = [int(v) for v in g["dims"][:8]]
+    xo, yo = (xd - xf) // xs + 1, (yd - yf) // ys + 1
+    for variant in (2, 1):
+        E.set_tuning("mfma_variant", variant)
+        assert E.limb_supported(zd, xf, yf)
+        d_wl = E.alloc(E.limb_weights_bytes(nf, zd, xf, yf)); E.limb_pack_weights(weights(g["conv_w"]), nf, zd, xf, yf, d_wl)
+        for B in (1, 3):
+            x = np.ascontiguousarray(np.repeat(g["x"][None], B, axis=0))
+            d_y = E.alloc(B * nf * xo * yo * 2 * E.k * E.n * 8)
+            d_work = E.alloc(E.conv2d_forms_work_bytes(B, zd, xd, yd, xs, ys, xf, yf, nf, ca.COEFF, ca.NTTL, ca.COEFF))
+            E.conv2d(E.upload(x), d_wl, gpu_bias(E, ca, g["conv_b"], ca.COEFF), B, zd, xd, yd, xs, ys, xf, yf, nf, ca.COEFF, ca.COEFF, d_y, d_work, w_form=ca.NTTL)
+            y = E.download(d_y, (B, nf, xo, yo, 2, E.k, E.n))
+            for b in range(B):
+                assert np.array_equal(y[b], g["ref_conv"]), ("conv", variant, B)
+        out_dim, in_dim = g["fc_w"].shape
+        assert E.limb_supported(in_dim, 1, 1)
+        d_wl = E.alloc(E.limb_weights_bytes(out_dim, in_dim, 1, 1)); E.limb_pack_weights(weights(g["fc_w"]), out_dim, in_dim, 1, 1, d_wl)
+        d_y = E.alloc(out_dim * 2 * E.k * E.n * 8)
+        d_work = E.alloc(E.conv2d_forms_work_bytes(1, in_dim, 1, 1, 1, 1, 1, 1, out_dim, ca.COEFF, ca.NTTL, ca.COEFF))
+        E.dense(E.upload(g["x"]), d_wl, gpu_bias(E, ca, g["fc_b"], ca.COEFF), 1, in_dim, out_dim, ca.COEFF, ca.COEFF, d_y, d_work, w_form=ca.NTTL)
+        assert np.array_equal(E.download(d_y, (1, out_dim, 1, 2, E.k, E.n)), g["ref_fc"]), ("fc", variant)
+    E.set_tuning("mfma_variant", 2)
+    g1 = dict(np.load(os.path.join(gd, "layers1_n256_k2_t20.npz")))
+    zd, xd, yd, xs, ys, xf, yf, nf = [int(v) for v in g1["dims"][:8]]
+    xo, yo = (xd - xf) // xs + 1, (yd - yf) // ys + 1
+    assert zd == 1 and E.limb_conv1_supported(1, xd, yd, xs, ys, xf, yf, nf)
+    d_wl = E.alloc(E.limb_conv1_weights_bytes()); E.limb_conv1_pack_weights(weights(g1["conv_w"]), nf, xf, yf, d_wl)
+    for B in (1, 2):
+        x = np.ascontiguousarray(np.repeat(g1["x"][None], B, axis=0))
+        d_y = E.alloc(B * nf * xo * yo * 2 * E.k * E.n * 8)
+        d_work = E.alloc(E.conv2d_forms_work_bytes(B, 1, xd, yd, xs, ys, xf, yf, nf, ca.COEFF, ca.NTTL1, ca.COEFF))
+        E.conv2d(E.upload(x), d_wl, gpu_bias(E, ca, g1["conv_b"], ca.COEFF), B, 1, xd, yd, xs, ys, xf, yf, nf, ca.COEFF, ca.COEFF, d_y, d_work, w_form=ca.NTTL1)
+        y = E.download(d_y, (B, nf, xo, yo, 2, E.k, E.n))
+        for b in range(B):
+            assert np.array_equal(y[b], g1["ref_conv"]), ("one-channel conv", B)
+    E.close()
 
 
 CONV1_SHAPES = [

@@ -44,6 +44,17 @@ def test_conv(gl):
         assert abs(O.decrypt_value(g["sk"], y[f, 0, 0]) - want) < 1e-5
 
 
+def test_one_channel_conv_matches_reference_layer():
+    """the reference's ConvolutionalLayer on a ONE-channel input (conv1's shape class; tests/golden/layers1_n256_k2_t20.npz): oracle, both operation orders"""
+    g = dict(np.load(os.path.join(os.path.dirname(G), "layers1_n256_k2_t20.npz")))
+    O = orc.Oracle(int(g["n"]), [int(x) for x in g["q"]], int(g["t"]))
+    zd, xd, yd, xs, ys, xf, yf, nf = [int(v) for v in g["dims"][:8]]
+    assert zd == 1
+    w = enc_w(O, g["conv_w"]); b = O.encode_many(g["conv_b"])
+    assert np.array_equal(O.conv(g["x"], w, b, xs, ys, threads=2), g["ref_conv"])
+    assert np.array_equal(O.conv(g["x"], w, b, xs, ys, fast=True), g["ref_conv"])
+
+
 def test_fc(gl):
     g, O = gl
     w = enc_w(O, g["fc_w"]); b = O.encode_many(g["fc_b"])
