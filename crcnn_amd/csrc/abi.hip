@@ -330,7 +330,7 @@ extern "C" size_t crc_square_relin_work_bytes(const crc_ctx *c, size_t count, in
     const size_t ch = count < kSquareChunk ? count : kSquareChunk;
     const size_t sq = k_square_work_words(c, ch), rl = k_relin_work_words(c, ch, dbc);
     // [packed keys][size-3 intermediates of one pass][scratch of the square, then of the relinearisation]
-    return 8 * (crc_evk_words(c, dbc) + (sq > rl ? sq : rl) + ch * crc_ct_words(c, 3)) + 256;
+    return 8 * (k_relin_keys_words(c, dbc) + (sq > rl ? sq : rl) + ch * crc_ct_words(c, 3)) + 256;
 }
 extern "C" size_t crc_encrypt_dev_work_bytes(const crc_ctx *c, size_t count) { return c ? 8 * k_encrypt_work_words(c, count) + 256 : 0; }
 extern "C" int crc_encrypt_dev_key(crc_ctx *c, const uint64_t *d_pk, const uint64_t *d_plain, size_t count, const uint8_t *key, uint64_t stream_base,
@@ -362,7 +362,7 @@ extern "C" int crc_relinearize(crc_ctx *c, const uint64_t *d_x3, size_t count, c
     u64 *w = (u64 *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
     for (size_t o = 0; o < count; o += kSquareChunk) {
         const size_t ch = count - o < kSquareChunk ? count - o : kSquareChunk;
-        RUN(k_relinearize(c, d_x3 + o * crc_ct_words(c, 3), ch, d_evk, dbc, d_y + o * crc_ct_words(c, 2), w + crc_evk_words(c, dbc), w, S(stream), false, false, o != 0));
+        RUN(k_relinearize(c, d_x3 + o * crc_ct_words(c, 3), ch, d_evk, dbc, d_y + o * crc_ct_words(c, 2), w + k_relin_keys_words(c, dbc), w, S(stream), false, false, o != 0));
     }
     return CRC_OK;
 }
@@ -375,7 +375,7 @@ extern "C" int crc_square_relin_forms(crc_ctx *c, const uint64_t *d_x, int in_fo
     for (size_t o = 0; o < count; o += kSquareChunk) {
         const size_t ch = count - o < kSquareChunk ? count - o : kSquareChunk;
         // [packed keys (filled by pass 0)][size-3 intermediates][scratch]
-        u64 *kp = w, *y3 = kp + crc_evk_words(c, dbc), *rest = y3 + ch0 * crc_ct_words(c, 3);
+        u64 *kp = w, *y3 = kp + k_relin_keys_words(c, dbc), *rest = y3 + ch0 * crc_ct_words(c, 3);
         RUN(k_square(c, d_x + o * crc_ct_words(c, 2), ch, y3, rest, S(stream), in_form == CRC_NTT, true));
         RUN(k_relinearize(c, y3, ch, d_evk, dbc, d_y + o * crc_ct_words(c, 2), rest, kp, S(stream), out_form == CRC_NTT, true, o != 0));
     }

@@ -309,6 +309,37 @@ extern "C" int crc_ctx_create(int n, const uint64_t *q, int k, uint64_t t, int d
     c->neg_inv_q_mod_tg[1] = h_invmod(negmod(prod_mod(q, k, -1, kGamma), kGamma), kGamma);
     c->inv_gamma_mod_t = h_invmod(kGamma % t, t);
 
+    // fp64 NTT primes: the largest primes below 2^47 that are 1 mod 2^16 (so that every ring degree up to 32768 has its 2n-th roots)
+    std::vector<std::vector<double>> f64rp(CRC_NF64), f64irp(CRC_NF64);
+    {
+        int found = 0;
+        for (u64 cand = ((u64)1 << CRC_F64_PRIME_BITS) - 65536 + 1; found < CRC_NF64; cand -= 65536) if (is_prime(cand)) c->f64_primes[found++] = cand;
+        F64Params &f = c->f64; memset(&f, 0, sizeof f);
+        auto centred = [](u64 v, u64 p) { return v > p / 2 ? (double)((long long)v - (long long)p) : (double)v; };
+        auto quot = [](double w, u64 p) { return (double)((long double)w / (long double)p); };
+        for (int m = 0; m < CRC_NF64; m++) {
+            const u64 p = c->f64_primes[m];
+            f.m[m].p = (double)p; f.m[m].pinv = 1.0 / (double)p;
+            f.ninv[m] = centred(h_invmod((u64)n, p), p); f.ninv_q[m] = quot(f.ninv[m], p);
+            if (device >= 0) {
+                const u64 psi = minimal_primitive_root(2 * (u64)n, p), ipsi = h_invmod(psi, p);
+                if (!psi) { delete c; return CRC_ERR_PARAMETERS; }
+                f64rp[m].assign((size_t)2 * n, 0.0); f64irp[m].assign((size_t)2 * n, 0.0);
+                u64 a = 1, b = 1;
+                for (int i = 0; i < n; i++) {
+                    const u32 j = bitrev((u32)i, c->logn);
+                    const double wa = centred(a, p), wb = centred(b, p);
+                    f64rp[m][2 * j] = wa; f64rp[m][2 * j + 1] = quot(wa, p);
+                    f64irp[m][2 * j] = wb; f64irp[m][2 * j + 1] = quot(wb, p);
+                    a = h_mulmod(a, psi, p); b = h_mulmod(b, ipsi, p);
+                }
+            }
+        }
+        f.inv_p0_p1 = centred(h_invmod(c->f64_primes[0] % c->f64_primes[1], c->f64_primes[1]), c->f64_primes[1]);
+        f.inv_p0_p1_q = quot(f.inv_p0_p1, c->f64_primes[1]);
+        for (int i = 0; i < k; i++) f.p0_mod_q[i] = c->f64_primes[0] % q[i];
+    }
+
     // upload (device < 0: host-only context for encode / client-side use and CPU-only tests of the tables)
     if (device >= 0) {
         int rc = CRC_OK;
@@ -334,6 +365,11 @@ extern "C" int crc_ctx_create(int n, const uint64_t *q, int k, uint64_t t, int d
             (e = hipMemcpy(c->d_behz, &c->behz, sizeof(BehzParams), hipMemcpyHostToDevice)) != hipSuccess) {
             fail(e); crc_ctx_destroy(c); return rc;
         }
+        const size_t ftw = (size_t)n * 16;
+        if ((e = hipMalloc(&c->d_f64_rp, ftw * CRC_NF64)) != hipSuccess || (e = hipMalloc(&c->d_f64_irp, ftw * CRC_NF64)) != hipSuccess) { fail(e); crc_ctx_destroy(c); return rc; }
+        for (int m = 0; m < CRC_NF64; m++)
+            if ((e = hipMemcpy((char *)c->d_f64_rp + m * ftw, f64rp[m].data(), ftw, hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemcpy((char *)c->d_f64_irp + m * ftw, f64irp[m].data(), ftw, hipMemcpyHostToDevice)) != hipSuccess) { fail(e); crc_ctx_destroy(c); return rc; }
         c->d_scratch = c->d_zero + 512;
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->cus = cus;
@@ -347,6 +383,7 @@ extern "C" void crc_ctx_destroy(crc_ctx *c)
     if (!c) return;
     if (c->device >= 0) {
         (void)hipFree(c->d_mods); (void)hipFree(c->d_rp); (void)hipFree(c->d_irp2); (void)hipFree(c->d_behz); (void)hipFree(c->d_zero);
+        (void)hipFree(c->d_f64_rp); (void)hipFree(c->d_f64_irp);
     }
     delete c;
 }
@@ -386,6 +423,7 @@ extern "C" int crc_ctx_table(const crc_ctx *c, const char *name, uint64_t *out, 
     else if (s == "upper_half_increment") for (int i = 0; i < k; i++) v.push_back(c->plain.uhi[i]);
     else if (s == "bsk") for (int j = 0; j < kb; j++) v.push_back(c->tabs[k + j].m.q);
     else if (s == "bsk_root") for (int j = 0; j < kb; j++) v.push_back(c->tabs[k + j].root);
+    else if (s == "f64_primes") for (int m = 0; m < CRC_NF64; m++) v.push_back(c->f64_primes[m]);
     else if (s.rfind("root_powers:", 0) == 0) { int mi = atoi(name + 12); if (mi < 0 || mi >= k + kb) return CRC_ERR_INVALID_ARGUMENT; v = c->tabs[mi].rp; }
     else if (s.rfind("inv_root_powers_div_two:", 0) == 0) { int mi = atoi(name + 24); if (mi < 0 || mi >= k + kb) return CRC_ERR_INVALID_ARGUMENT; v = c->tabs[mi].irp2; }
     else return CRC_ERR_NOT_FOUND;

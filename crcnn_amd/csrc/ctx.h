@@ -9,6 +9,7 @@
 #include <unordered_map>
 #include <vector>
 #include "modarith.h"
+#include "f64mod.h"
 #include "../../include/crcnn_hip.h"
 
 #define CRC_MAXK 8            // coeff moduli (SEAL's largest default set, n=16384, has 8)
@@ -58,6 +59,16 @@ struct BehzParams {
     u64 inv_qhat_s[CRC_MAXK];                // Shoup companion of inv_qhat (relinearisation digits are cut out of c2 (q/q_i)^-1, evaluator.cpp:984-985)
 };
 
+// The engine's own fp64 NTT primes (f64mod.h): the largest primes below 2^47 that are 1 mod 2^16.  Relinearisation's key-switching inner products
+// sum_g digit_g (*) key_g are computed modulo these two and lifted by CRT (kernels_relin64.hip) -- passed to kernels by value
+#define CRC_NF64 2
+struct F64Params {
+    F64Mod m[CRC_NF64];
+    double inv_p0_p1, inv_p0_p1_q;                // p_0^-1 mod p_1 (centred) and its quotient companion (f64_mulmod_const)
+    double ninv[CRC_NF64], ninv_q[CRC_NF64];      // n^-1 mod p_m (centred) + companion: folded into the keys, so the inverse transforms do not scale
+    u64 p0_mod_q[CRC_MAXK];                       // p_0 mod q_j
+};
+
 struct HostNtt {               // one modulus
     ModParams m;
     u64 root, inv_n;
@@ -99,6 +110,9 @@ struct crc_ctx {
     ModParams *d_mods = nullptr;             // [k+kb]
     u64 *d_rp = nullptr, *d_irp2 = nullptr;   // [(k+kb)][n][2]: {bit-reversed root power, its Shoup companion} (forward / inverse-div-2)
     BehzParams *d_behz = nullptr;
+    u64 f64_primes[CRC_NF64] = {0, 0};
+    F64Params f64;
+    double *d_f64_rp = nullptr, *d_f64_irp = nullptr;   // [CRC_NF64][n][2]: {bit-reversed power of psi_m (centred), that / p_m} forward; psi_m^-1 powers inverse
     u64 *d_zero = nullptr;                   // 4 KiB of zeros (source row of reduction terms past T in mac3_kernel) + 4 KiB context scratch
     u64 *d_scratch = nullptr;                // = d_zero + 512 words (crc_checksum64 accumulators)
     int cus = 256;                           // compute units of THIS context's device

@@ -20,6 +20,14 @@ int k_pack28(crc_ctx *c, u64 *rows, size_t nrows, bool unpack, hipStream_t st);
 int k_conv_offsets(crc_ctx *c, int *xoff, int *toff, unsigned *toffw, int P, int T, int in_cts, int xd, int yd, int xs, int ys, int xf, int yf, int yo, hipStream_t st);
 size_t k_square_work_words(const crc_ctx *c, size_t cnt);
 size_t k_relin_work_words(const crc_ctx *c, size_t cnt, int dbc);
+size_t k_relin_keys_words(const crc_ctx *c, int dbc);
+// kernels_relin64.hip: key switching over the two fp64 primes
+bool   k_relin64_supported(const crc_ctx *c, int dbc);
+size_t k_relin64_keys_words(const crc_ctx *c, int dbc);
+size_t k_relin64_work_words(const crc_ctx *c, size_t cnt, int dbc);
+int k_relin64_prepare_keys(crc_ctx *c, const u64 *evk, int dbc, u64 *kp, u64 *scratch, hipStream_t st);
+int k_relinearize64(crc_ctx *c, const u64 *src, int src_size, int src_poly, const u64 *x3, int add_size, size_t cnt, int dbc, u64 *y, u64 *work, const u64 *kp,
+                    hipStream_t st, bool out_ntt);
 int k_square(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStream_t st, bool in_ntt = false, bool premul_c2 = false);
 int k_relinearize(crc_ctx *c, const u64 *x3, size_t cnt, const u64 *evk, int dbc, u64 *y, u64 *work, u64 *kp, hipStream_t st, bool out_ntt = false,
                   bool c2_premul = false, bool keys_ready = false);

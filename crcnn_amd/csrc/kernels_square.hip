@@ -210,9 +210,11 @@ size_t k_relin_work_words(const crc_ctx *c, size_t cnt, int dbc)
 {
     const size_t n = c->n, k = c->k;
     size_t D = 0; for (int i = 0; i < c->k; i++) D += evk_digits(c->q[i], dbc);
-    // PM[k] E[D*k] R[2k]   (the packed keys live in front of the caller's work space: crc_evk_words more)
-    return cnt * n * (k + D * k + 2 * k);
+    // PM[k] E[D*k] R[2k]   (the prepared keys live in front of the caller's work space: k_relin_keys_words more); either path must fit
+    const size_t a = cnt * n * (k + D * k + 2 * k), b = k_relin64_work_words(c, cnt, dbc);
+    return a > b ? a : b;
 }
+size_t k_relin_keys_words(const crc_ctx *c, int dbc) { return k_relin64_keys_words(c, dbc); }      // (>= crc_evk_words: the 28-bit packed keys of the other path fit too)
 
 int k_square(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStream_t st, bool in_ntt, bool premul_c2)
 {
@@ -258,6 +260,19 @@ int k_relinearize(crc_ctx *c, const u64 *x3, size_t cnt, const u64 *evk, int dbc
     if (cnt == 0) return CRC_OK;
     if (dbc < 1 || dbc > 60) return CRC_ERR_INVALID_ARGUMENT;
     const size_t n = c->n, k = c->k;
+    // key switching over the context's two fp64 primes (kernels_relin64.hip) whenever the inner products fit below p_0 p_1 / 4 -- every parameter set of the reference
+    // with 16-bit digits does; tune.relin_path = 1 keeps the transforms over the coefficient moduli (the round-2 path below)
+    if (c->tune.relin_path != 1 && k_relin64_supported(c, dbc)) {
+        int rc;
+        if (!keys_ready && (rc = k_relin64_prepare_keys(c, evk, dbc, kp, work, st))) return rc;        // (borrows the scratch: before anything else is put there)
+        const u64 *src = x3; int src_size = 3, src_poly = 2;
+        if (!c2_premul) {
+            hipLaunchKernelGGL(relin_premul_kernel, dim3((unsigned)(cnt * k)), dim3(256), 0, st, x3, work, c->d_mods, c->d_behz, c->n, c->k);
+            HIPCHK(hipGetLastError());
+            src = work; src_size = 1; src_poly = 0;
+        }
+        return k_relinearize64(c, src, src_size, src_poly, x3, 3, cnt, dbc, y, c2_premul ? work : work + cnt * k * n, kp, st, out_ntt);
+    }
     RelinTab tab{};
     int D = 0; long long off = 0;
     for (int i = 0; i < c->k; i++) {

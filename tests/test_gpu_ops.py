@@ -151,6 +151,71 @@ def test_baseline_ring_sizes_vs_oracle(n, q, t):
     E.close()
 
 
+RELIN_SETS = [(256, 1, 1), (1024, 2, 3), (4096, 2, 3), (8192, 4, 2), (16384, 8, 2)]
+
+
+@pytest.mark.parametrize("n,k,cnt", RELIN_SETS, ids=[f"n{p[0]}_k{p[1]}" for p in RELIN_SETS])
+def test_relinearise_over_fp64_primes_equals_reference_arithmetic(n, k, cnt):
+    """Evaluator::relinearize (evaluator.cpp:934-1069) two ways on the same size-3 inputs: key switching over the two fp64 primes + CRT (kernels_relin64.hip, the
+    default) and over the coefficient moduli (the round-2 kernels, which follow the reference transform by transform), plus the CPU oracle.  Inputs are the worst
+    cases for the integer bound of the fp64 path: random full-range residues and c2 polynomials whose every digit is 0xffff / whose residues are all q - 1, under
+    random full-range key material (a key is any element of R_q as far as the arithmetic is concerned).  Every form of crc_square_relin_forms as well."""
+    import crcnn_amd as ca
+    from oracle import orc
+    q = ca.default_coeff_modulus_128(n)[:k] if n >= 4096 else [0x7fffffff380001, 0x3fffffff000001][:k]
+    t = 1 << 30
+    E = ca.Engine(n, q, t, device=0)
+    rng = np.random.default_rng(n + k)
+    qa = np.array(q, dtype=np.uint64)
+    x3 = np.empty((cnt + 2, 3, k, n), dtype=np.uint64)
+    for i in range(k):
+        x3[:, :, i] = rng.integers(0, q[i], size=(cnt + 2, 3, n), dtype=np.uint64)
+    x3[cnt, 2] = (qa - np.uint64(1))[:, None]                        # c2 = q - 1 everywhere
+    # ... and the c2 whose premultiplied form c2 (q/q_i)^-1 mod q_i -- what the digits are cut from -- has its three low 16-bit digits at 0xffff in every coefficient
+    for i in range(k):
+        v = (q[i] - 1) | 0xffffffffffff
+        if v >= q[i]:
+            v = (((q[i] >> 48) - 1) << 48) | 0xffffffffffff
+        qhat = 1
+        for l in range(k):
+            if l != i:
+                qhat = qhat * q[l] % q[i]
+        x3[cnt + 1, 2, i] = np.uint64(v * qhat % q[i])
+    evk_words = E.L.crc_evk_words(E.c, 16)
+    evk = np.empty(evk_words, dtype=np.uint64)
+    rows = evk.reshape(-1, k, n)
+    for i in range(k):
+        rows[:, i] = rng.integers(0, q[i], size=(rows.shape[0], n), dtype=np.uint64)
+    O = orc.Oracle(n, q, t) if n <= 4096 else None
+    d_x3 = E.upload(x3); d_evk = E.upload(evk)
+    d_w = E.alloc(E.square_relin_work_bytes(cnt + 2))
+    outs = {}
+    for path in (1, 0):
+        E.set_tuning("relin_path", path)
+        d_y = E.alloc((cnt + 2) * 2 * k * n * 8)
+        E.relinearize(d_x3, cnt + 2, d_evk, d_y, d_w)
+        outs[path] = E.download(d_y, (cnt + 2, 2, k, n))
+    assert np.array_equal(outs[0], outs[1]), "fp64-prime key switching differs from the transforms over the coefficient moduli"
+    if O is not None:
+        for i in range(cnt + 2):
+            assert np.array_equal(outs[0][i], O.relinearize(x3[i], evk)), ("oracle", i)
+    # square + relinearise, all form combinations, both paths (valid ciphertext-shaped inputs: any residues)
+    x = np.ascontiguousarray(x3[:, :2])
+    d_x = E.upload(x)
+    res = {}
+    for path in (1, 0):
+        E.set_tuning("relin_path", path)
+        for fin, fout in [(ca.COEFF, ca.COEFF), (ca.NTT, ca.NTT), (ca.COEFF, ca.NTT), (ca.NTT, ca.COEFF)]:
+            d_y = E.alloc(x.nbytes)
+            E.square_relin(d_x, cnt + 2, d_evk, d_y, d_w, in_form=fin, out_form=fout)
+            res[(path, fin, fout)] = E.download(d_y, x.shape)
+    for key, v in res.items():
+        if key[0] == 0:
+            assert np.array_equal(v, res[(1,) + key[1:]]), key
+    E.set_tuning("relin_path", 0)
+    E.close()
+
+
 @pytest.mark.parametrize("n,k,t", [(4096, 2, 1 << 20), (8192, 3, 1 << 30), (1024, 2, 1 << 16)])
 def test_device_encryptor(n, k, t):
     """SURVEY 8f-2: Encryptor::encrypt on the device.  The reference samples from std::random_device, so the check is semantic, and

@@ -30,3 +30,18 @@ def test_matrix_core_reduction_against_int128(flags):
     out = subprocess.check_output([exe], text=True)
     assert out.startswith("ok "), out
     assert int(out.split()[1]) > 20_000
+
+
+def test_fp64_modular_arithmetic_against_int128():
+    """crcnn_amd/csrc/f64mod.h (exact modular arithmetic on integers held in doubles: the arithmetic of relinearisation's fp64-prime NTTs) on the CPU: the stated bounds
+    on random and extreme operands, the centring reduction at its boundaries, integer -> residue conversion, and a lazy forward / inverse transform pair against an
+    O(n^2) evaluation in integers; also pins the primes the engine picks (the largest below 2^47 that are 1 mod 2^16)"""
+    exe = os.path.join(tempfile.mkdtemp(), "f64mod_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "crcnn_amd", "csrc"), os.path.join(ROOT, "tests", "cpp", "f64mod_check.cpp"), "-o", exe])
+    out = subprocess.check_output([exe], text=True).split()
+    assert out[0] == "ok" and int(out[1]) > 5_000_000
+    import crcnn_amd as ca
+    E = ca.Engine(4096, [0x7fffffff380001, 0x3fffffff000001], 1 << 20, device=-1)
+    assert [int(v) for v in E.table("f64_primes")] == [int(v) for v in out[3:5]]
+    for p in E.table("f64_primes"):
+        assert int(p) % 65536 == 1 and int(p) < (1 << 47)
