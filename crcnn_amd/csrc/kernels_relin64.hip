@@ -19,8 +19,26 @@ typedef double2 d2;
 
 // ---- fp64 butterflies (the index arithmetic of ntt_device.h's fwd_stages / inv_stages; arithmetic of f64mod.h) ---------------------------------------------------
 // forward: values grow by at most 0.875 p per stage: 16-bit inputs stay below 14 p < 2^51 through 15 stages -- no reduction anywhere
+// The 2^R - 1 twiddles of a thread's R stages are fetched up front (tw[(1 << st) - 1 + j] = twiddle j of stage st), in front of the LDS reads of the pass: one
+// exposed memory latency per pass instead of one per stage (the compiler keeps loads where they are written and waits right in front of the first use)
 template <int R>
-__device__ __forceinline__ void fwd_stages_f64(double (&v)[1 << R], const d2 *W, int m, int blk, double p)
+__device__ __forceinline__ void load_tw_fwd(d2 (&tw)[(1 << R) - 1], const d2 *W, int m, int blk)
+{
+#pragma unroll
+    for (int st = 0; st < R; st++)
+#pragma unroll
+        for (int j = 0; j < (1 << st); j++) tw[(1 << st) - 1 + j] = W[(m << st) + (blk << st) + j];
+}
+template <int R>
+__device__ __forceinline__ void load_tw_inv(d2 (&tw)[(1 << R) - 1], const d2 *W, int h, int blk)
+{
+#pragma unroll
+    for (int st = 0; st < R; st++)
+#pragma unroll
+        for (int j = 0; j < (1 << (R - 1 - st)); j++) tw[(1 << R) - (1 << (R - st)) + j] = W[(h >> st) + (blk << (R - 1 - st)) + j];
+}
+template <int R>
+__device__ __forceinline__ void fwd_stages_f64(double (&v)[1 << R], const d2 (&tw)[(1 << R) - 1], double p)
 {
 #pragma unroll
     for (int st = 0; st < R; st++) {
@@ -28,15 +46,15 @@ __device__ __forceinline__ void fwd_stages_f64(double (&v)[1 << R], const d2 *W,
 #pragma unroll
         for (int c = 0; c < (1 << R); c++) {
             if (c & half) continue;
-            const d2 tw = W[(m << st) + (blk << st) + (c >> (R - st))];
-            const double X = v[c], T = f64_mulmod_const(v[c + half], tw.x, tw.y, p);
+            const d2 t2 = tw[(1 << st) - 1 + (c >> (R - st))];
+            const double X = v[c], T = f64_mulmod_const(v[c + half], t2.x, t2.y, p);
             v[c] = X + T; v[c + half] = X - T;
         }
     }
 }
 // inverse (Gentleman-Sande, no halving: n^-1 sits in the keys): sums double per stage, so a pass starts from reduced values (|x| <= p/2 -> below 4 p after three stages)
 template <int R>
-__device__ __forceinline__ void inv_stages_f64(double (&v)[1 << R], const d2 *W, int h, int blk, double p)
+__device__ __forceinline__ void inv_stages_f64(double (&v)[1 << R], const d2 (&tw)[(1 << R) - 1], double p)
 {
 #pragma unroll
     for (int st = 0; st < R; st++) {
@@ -44,44 +62,57 @@ __device__ __forceinline__ void inv_stages_f64(double (&v)[1 << R], const d2 *W,
 #pragma unroll
         for (int c = 0; c < (1 << R); c++) {
             if (c & half) continue;
-            const d2 tw = W[(h >> st) + (blk << (R - 1 - st)) + (c >> (st + 1))];
+            const d2 t2 = tw[(1 << R) - (1 << (R - st)) + (c >> (st + 1))];
             const double U = v[c], V = v[c + half];
-            v[c] = U + V; v[c + half] = f64_mulmod_const(U - V, tw.x, tw.y, p);
+            v[c] = U + V; v[c + half] = f64_mulmod_const(U - V, t2.x, t2.y, p);
         }
     }
 }
-template <bool INV, int R>
-__device__ __forceinline__ void ntt_pass_f64(double *sm, const d2 *W, int n, int s, int tabidx, const F64Mod md, bool reduce_in)
+// s = 2^ls: element stride inside a group.  The swizzles are XORs of shifted index bits, i.e. linear over GF(2), and (c << ls) occupies bits that are zero in
+// `base`: swz(base + c s) = swz(base) ^ swz(c s) -- one vector XOR per element against a wave-uniform constant instead of the whole index arithmetic
+template <bool INV, int R, int RB>
+__device__ __forceinline__ void ntt_pass_f64(double *sm, const d2 *W, int n, int ls, int tabidx, const F64Mod md, bool reduce_in)
 {
-    const int groups = n >> R;
-    for (int g = threadIdx.x; g < groups; g += blockDim.x) {
-        const int blk = g / s, l = g - blk * s;
-        const int base = blk * (s << R) + l;
+    const unsigned groups = (unsigned)n >> R;
+    for (unsigned g = threadIdx.x; g < groups; g += blockDim.x) {
+        const unsigned blk = g >> ls, l = g & ((1u << ls) - 1);
+        const int a0 = swz<RB>((int)((blk << (ls + R)) + l));
+        d2 tw[(1 << R) - 1];
+        if (INV) load_tw_inv<R>(tw, W, tabidx, (int)blk); else load_tw_fwd<R>(tw, W, tabidx, (int)blk);
         double v[1 << R];
 #pragma unroll
-        for (int c = 0; c < (1 << R); c++) { v[c] = sm[lpad(base + c * s)]; if (INV && reduce_in) v[c] = f64_reduce(v[c], md); }
-        if (INV) inv_stages_f64<R>(v, W, tabidx, blk, md.p); else fwd_stages_f64<R>(v, W, tabidx, blk, md.p);
+        for (int c = 0; c < (1 << R); c++) { v[c] = sm[a0 ^ swz<RB>(c << ls)]; if (INV && reduce_in) v[c] = f64_reduce(v[c], md); }
+        if (INV) inv_stages_f64<R>(v, tw, md.p); else fwd_stages_f64<R>(v, tw, md.p);
 #pragma unroll
-        for (int c = 0; c < (1 << R); c++) sm[lpad(base + c * s)] = v[c];
+        for (int c = 0; c < (1 << R); c++) sm[a0 ^ swz<RB>(c << ls)] = v[c];
     }
     __syncthreads();
 }
+template <bool INV, int RB>
+__device__ __forceinline__ void ntt_tail_pass_f64(int rem, double *sm, const d2 *W, int n, int ls, int tabidx, const F64Mod md)
+{
+    if (rem == 1) ntt_pass_f64<INV, 1, RB>(sm, W, n, ls, tabidx, md, INV);
+    else if (rem == 2) ntt_pass_f64<INV, 2, RB>(sm, W, n, ls, tabidx, md, INV);
+    else if (RB > 3 && rem == 3) ntt_pass_f64<INV, 3, RB>(sm, W, n, ls, tabidx, md, INV);
+    else if (RB > 4 && rem == 4) ntt_pass_f64<INV, 4, RB>(sm, W, n, ls, tabidx, md, INV);
+}
 // all passes of one row on the LDS image (lpad-swizzled); caller has synchronised after filling it, returns synchronised.  Inverse: the image holds values below
 // 2^52 (lazy sums of up to 48 products); every pass reduces on load.
-template <bool INV>
+// (RB = stages per pass: 2^RB values per thread in registers between two LDS round trips.  The fp64 butterfly is a third of the 64-bit integer one's issue cycles, so
+// the LDS passes, their barriers and the twiddle loads weigh more here than in ntt_device.h: fewer, wider passes)
+template <bool INV, int RB>
 __device__ __forceinline__ void ntt_row_passes_f64(double *sm, const d2 *W, int n, int logn, const F64Mod md)
 {
-    const int full = logn / 3, rem = logn - 3 * full;
+    const int full = logn / RB, rem = logn - RB * full;
     if (!INV) {
-        int t = n >> 1;
-        for (int p = 0; p < full; p++, t >>= 3) ntt_pass_f64<false, 3>(sm, W, n, t >> 2, n / (2 * t), md, false);
-        if (rem == 2) ntt_pass_f64<false, 2>(sm, W, n, t >> 1, n / (2 * t), md, false);
-        else if (rem == 1) ntt_pass_f64<false, 1>(sm, W, n, t, n / (2 * t), md, false);
+        // gaps n/2, n/4, ...: a pass of R stages starting at gap 2^lt works on groups of stride 2^(lt - R + 1); twiddle block index n / 2^(lt + 1)
+        int lt = logn - 1;
+        for (int p = 0; p < full; p++, lt -= RB) ntt_pass_f64<false, RB, RB>(sm, W, n, lt - RB + 1, n >> (lt + 1), md, false);
+        if (rem) ntt_tail_pass_f64<false, RB>(rem, sm, W, n, lt - rem + 1, n >> (lt + 1), md);
     } else {
-        int t = 1;
-        for (int p = 0; p < full; p++, t <<= 3) ntt_pass_f64<true, 3>(sm, W, n, t, n / (2 * t), md, true);
-        if (rem == 2) ntt_pass_f64<true, 2>(sm, W, n, t, n / (2 * t), md, true);
-        else if (rem == 1) ntt_pass_f64<true, 1>(sm, W, n, t, n / (2 * t), md, true);
+        int lt = 0;
+        for (int p = 0; p < full; p++, lt += RB) ntt_pass_f64<true, RB, RB>(sm, W, n, lt, n >> (lt + 1), md, true);
+        if (rem) ntt_tail_pass_f64<true, RB>(rem, sm, W, n, lt, n >> (lt + 1), md);
     }
 }
 
@@ -97,7 +128,8 @@ __global__ void __launch_bounds__(256) evk_canon_kernel(const u64 *evk, u64 *out
     for (int s = threadIdx.x; s < n; s += blockDim.x) dst[s] = barrett128(src[s], 0, m);
 }
 // kc: the keys in coefficient form over q_j, rows [2 g + poly][j] (blob order)  ->  Kf [g][poly k + j][m][n]: centred residue mod p_m, forward transform, times n^-1
-__global__ void __launch_bounds__(1024) relin_keys_f64_kernel(const u64 *kc, double *Kf, const ModParams *mods, const d2 *Wf, F64Params fp, int n, int logn, int k)
+template <int RB>
+__global__ void __launch_bounds__(RB == 5 ? 512 : 1024) relin_keys_f64_kernel(const u64 *kc, double *Kf, const ModParams *mods, const d2 *Wf, F64Params fp, int n, int logn, int k)
 {
     extern __shared__ double smd[];
     const int m = blockIdx.x % CRC_NF64; const size_t row = blockIdx.x / CRC_NF64;       // row = (2 g + poly) k + j
@@ -107,17 +139,18 @@ __global__ void __launch_bounds__(1024) relin_keys_f64_kernel(const u64 *kc, dou
     const u64 *src = kc + row * (size_t)n;
     for (int s = threadIdx.x; s < n; s += blockDim.x) {
         const u64 v = src[s];
-        smd[lpad(s)] = f64_from_i64(v > (q >> 1) ? (long long)v - (long long)q : (long long)v, md);
+        smd[swz<RB>(s)] = f64_from_i64(v > (q >> 1) ? (long long)v - (long long)q : (long long)v, md);
     }
     __syncthreads();
-    ntt_row_passes_f64<false>(smd, Wf + (size_t)m * n, n, logn, md);
+    ntt_row_passes_f64<false, RB>(smd, Wf + (size_t)m * n, n, logn, md);
     double *dst = Kf + (((g * 2 * k + (size_t)poly * k + j) * CRC_NF64) + m) * (size_t)n;
-    for (int s = threadIdx.x; s < n; s += blockDim.x) dst[s] = f64_reduce(f64_mulmod_const(smd[lpad(s)], fp.ninv[m], fp.ninv_q[m], md.p), md);
+    for (int s = threadIdx.x; s < n; s += blockDim.x) dst[s] = f64_reduce(f64_mulmod_const(smd[swz<RB>(s)], fp.ninv[m], fp.ninv_q[m], md.p), md);
 }
 
 // ---- K1: digits of c2' under both primes ---------------------------------------------------------------------------------------------------------------------------
 // src: size-`src_size` ciphertexts, poly `src_poly` = c2 (q/q_i)^-1 mod q_i (evaluator.cpp:984-985); E [ct][g][m][n], unreduced (|.| < 14 p)
-__global__ void __launch_bounds__(1024) relin_digits_f64_kernel(const u64 *src, int src_size, int src_poly, double *E, const d2 *Wf, F64Params fp, int n, int logn, int k, int D,
+template <int RB>
+__global__ void __launch_bounds__(RB == 5 ? 512 : 1024) relin_digits_f64_kernel(const u64 *src, int src_size, int src_poly, double *E, const d2 *Wf, F64Params fp, int n, int logn, int k, int D,
                                                                 int dbc, Relin64Tab tab)
 {
     extern __shared__ double smd[];
@@ -128,11 +161,11 @@ __global__ void __launch_bounds__(1024) relin_digits_f64_kernel(const u64 *src, 
     for (int d = 0; d < L; d++) {
         const int sh = d * dbc;
         for (int m = 0; m < CRC_NF64; m++) {
-            for (int s = threadIdx.x; s < n; s += blockDim.x) smd[lpad(s)] = (double)(u32)((row[s] >> sh) & mask);
+            for (int s = threadIdx.x; s < n; s += blockDim.x) smd[swz<RB>(s)] = (double)(u32)((row[s] >> sh) & mask);
             __syncthreads();
-            ntt_row_passes_f64<false>(smd, Wf + (size_t)m * n, n, logn, fp.m[m]);
+            ntt_row_passes_f64<false, RB>(smd, Wf + (size_t)m * n, n, logn, fp.m[m]);
             double *dst = E + ((ct * D + g0 + d) * CRC_NF64 + m) * (size_t)n;
-            for (int s = threadIdx.x; s < n; s += blockDim.x) dst[s] = smd[lpad(s)];
+            for (int s = threadIdx.x; s < n; s += blockDim.x) dst[s] = smd[swz<RB>(s)];
             __syncthreads();
         }
     }
@@ -141,27 +174,32 @@ __global__ void __launch_bounds__(1024) relin_digits_f64_kernel(const u64 *src, 
 // ---- K2: slot-wise inner products ------------------------------------------------------------------------------------------------------------------------------------
 // A[ct][pj][m][s] = sum_g Kf[g][pj][m][s] E[ct][g][m][s]: every product reduced below 0.875 p, the sum of D <= 48 of them stays below 2^53 (exact); CT ciphertexts share
 // every key value a thread loads
-template <int K, int CT>
+// A thread owns one slot of one prime for CT ciphertexts x PJ of the 2k key columns (PJS = 2k / PJ thread groups share the E values through L2): per digit CT + PJ
+// loads feed CT PJ products -- the kernel is bound by L2 bandwidth on the key and digit values, not by the 7 flops per product
+template <int K, int CT, int PJ>
 __global__ void __launch_bounds__(256) relin_mac_f64_kernel(const double *E, const double *Kf, double *A, F64Params fp, int n, int D, size_t cnt)
 {
+    constexpr int PJS = 2 * K / PJ;
     const int sblocks = n / blockDim.x;
-    const int s = (blockIdx.x % sblocks) * blockDim.x + threadIdx.x;
-    const int m = (blockIdx.x / sblocks) % CRC_NF64;
-    const size_t ct0 = (size_t)(blockIdx.x / (sblocks * CRC_NF64)) * CT;
+    unsigned b = blockIdx.x;
+    const int s = (b % sblocks) * blockDim.x + threadIdx.x; b /= sblocks;
+    const int pj0 = (b % PJS) * PJ; b /= PJS;
+    const int m = b % CRC_NF64;
+    const size_t ct0 = (size_t)(b / CRC_NF64) * CT;
     const F64Mod md = fp.m[m];
-    double acc[CT][2 * K];
+    double acc[CT][PJ];
 #pragma unroll
     for (int c = 0; c < CT; c++)
 #pragma unroll
-        for (int pj = 0; pj < 2 * K; pj++) acc[c][pj] = 0.0;
+        for (int pj = 0; pj < PJ; pj++) acc[c][pj] = 0.0;
     const size_t nn = (size_t)n;
     for (int g = 0; g < D; g++) {
         double e[CT];
 #pragma unroll
         for (int c = 0; c < CT; c++) e[c] = ct0 + c < cnt ? E[(((ct0 + c) * D + g) * CRC_NF64 + m) * nn + s] : 0.0;
-        const double *kr = Kf + (((size_t)g * 2 * K) * CRC_NF64 + m) * nn + s;
+        const double *kr = Kf + (((size_t)g * 2 * K + pj0) * CRC_NF64 + m) * nn + s;
 #pragma unroll
-        for (int pj = 0; pj < 2 * K; pj++) {
+        for (int pj = 0; pj < PJ; pj++) {
             const double kv = kr[(size_t)pj * CRC_NF64 * nn];
 #pragma unroll
             for (int c = 0; c < CT; c++) acc[c][pj] += f64_mulmod(kv, e[c], md);
@@ -171,29 +209,27 @@ __global__ void __launch_bounds__(256) relin_mac_f64_kernel(const double *E, con
     for (int c = 0; c < CT; c++)
         if (ct0 + c < cnt)
 #pragma unroll
-            for (int pj = 0; pj < 2 * K; pj++) A[(((ct0 + c) * 2 * K + pj) * CRC_NF64 + m) * nn + s] = acc[c][pj];
+            for (int pj = 0; pj < PJ; pj++) A[(((ct0 + c) * 2 * K + pj0 + pj) * CRC_NF64 + m) * nn + s] = acc[c][pj];
 }
 
 // ---- K3: inverse transforms, CRT lift, mod q_j, + (c0, c1) -------------------------------------------------------------------------------------------------------------
-// A [ct][poly k + j][m][n]; x3: size-`add_size` ciphertexts whose polys 0, 1 are added (coefficient form); y [ct][2][k][n].
-// NPT = n / blockDim.x values per thread keep the first prime's result in registers while the LDS image serves the second transform.
-template <int NPT, bool OUT_NTT, bool LAZY>
-__global__ void __launch_bounds__(1024) relin_inv_crt_kernel(const double *A, const u64 *x3, int add_size, u64 *y, const ModParams *mods, const d2 *Wi, const ulonglong2 *Wq, F64Params fp,
-                                                             int n, int logn, int k)
+// A [ct][poly k + j][m][n] (overwritten: the first prime's result is parked in its own row -- L2-hot when it is read back -- while the LDS image serves the second
+// transform); x3: size-`add_size` ciphertexts whose polys 0, 1 are added (coefficient form); y [ct][2][k][n].
+template <int RB, bool OUT_NTT, bool LAZY>
+__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 ? 8 : 4) relin_inv_crt_kernel(double *A, const u64 *x3, int add_size, u64 *y, const ModParams *mods, const d2 *Wi, const ulonglong2 *Wq, F64Params fp,
+                                                                             int n, int logn, int k)
 {
     extern __shared__ double smd[];
     const size_t ct = blockIdx.x / (2 * k); const int pj = blockIdx.x % (2 * k), poly = pj / k, j = pj % k;
     const int tid = threadIdx.x, nt = blockDim.x;
-    double r0[NPT];
+    double *a0row = A + ((ct * 2 * k + pj) * CRC_NF64) * (size_t)n;
     for (int m = 0; m < CRC_NF64; m++) {
-        const double *src = A + ((ct * 2 * k + pj) * CRC_NF64 + m) * (size_t)n;
-#pragma unroll
-        for (int u = 0; u < NPT; u++) smd[lpad(tid + u * nt)] = src[tid + u * nt];
+        const double *src = a0row + (size_t)m * n;
+        for (int s = tid; s < n; s += nt) smd[swz<RB>(s)] = src[s];
         __syncthreads();
-        ntt_row_passes_f64<true>(smd, Wi + (size_t)m * n, n, logn, fp.m[m]);
+        ntt_row_passes_f64<true, RB>(smd, Wi + (size_t)m * n, n, logn, fp.m[m]);
         if (m == 0) {
-#pragma unroll
-            for (int u = 0; u < NPT; u++) r0[u] = f64_reduce(smd[lpad(tid + u * nt)], fp.m[0]);
+            for (int s = tid; s < n; s += nt) a0row[s] = f64_reduce(smd[swz<RB>(s)], fp.m[0]);
             __syncthreads();
         }
     }
@@ -203,12 +239,11 @@ __global__ void __launch_bounds__(1024) relin_inv_crt_kernel(const double *A, co
     const u64 *add = x3 + ((ct * add_size + poly) * k + j) * (size_t)n;
     u64 *dst = y + ((ct * 2 + poly) * k + j) * (size_t)n;
     u64 *sm = reinterpret_cast<u64 *>(smd);           // (a thread reads and rewrites only its own positions of the image here: no barrier in between)
-#pragma unroll
-    for (int u = 0; u < NPT; u++) {
-        const int s = tid + u * nt;
-        const double a1 = f64_reduce(smd[lpad(s)], fp.m[1]);
-        const double t = f64_reduce(f64_mulmod_const(a1 - r0[u], fp.inv_p0_p1, fp.inv_p0_p1_q, fp.m[1].p), fp.m[1]);
-        const long long ti = (long long)t, a0i = (long long)r0[u];
+    for (int s = tid; s < n; s += nt) {
+        const double a0 = a0row[s];                   // (written by this very thread above)
+        const double a1 = f64_reduce(smd[swz<RB>(s)], fp.m[1]);
+        const double t = f64_reduce(f64_mulmod_const(a1 - a0, fp.inv_p0_p1, fp.inv_p0_p1_q, fp.m[1].p), fp.m[1]);
+        const long long ti = (long long)t, a0i = (long long)a0;
         u64 lo, hi; mul64wide((u64)(ti < 0 ? -ti : ti), p0q, lo, hi);
         u64 r = barrett128(lo, hi, mq);
         if (ti < 0) r = negmod(r, q);
@@ -216,19 +251,18 @@ __global__ void __launch_bounds__(1024) relin_inv_crt_kernel(const double *A, co
         if (a0m >= q) a0m = barrett128(a0m, 0, mq);
         r = addmod(r, a0i < 0 ? negmod(a0m, q) : a0m, q);
         r = addmod(r, add[s], q);
-        if (OUT_NTT) sm[lpad(s)] = r; else dst[s] = r;
+        if (OUT_NTT) sm[swz<RB>(s)] = r; else dst[s] = r;
     }
     if (!OUT_NTT) return;
-    // NTT-resident result: forward transform over q_j of (c_poly + R) in the same LDS image (ntt_device.h)
+    // NTT-resident result: forward transform over q_j of (c_poly + R) in the same LDS image, same layout (ntt_device.h's radix-8 passes on the fp64 image's swizzle)
     __syncthreads();
-    ntt_row_passes<false, LAZY>(sm, Wq + (size_t)j * n, n, logn, q, mq.two_q);
+    ntt_row_passes<false, LAZY, RB>(sm, Wq + (size_t)j * n, n, logn, q, mq.two_q);
     const float rq = 1.0f / (float)((u32)(q >> 32) + 1);
-#pragma unroll
-    for (int u = 0; u < NPT; u++) {
-        u64 v = sm[lpad(tid + u * nt)];
+    for (int s = tid; s < n; s += nt) {
+        u64 v = sm[swz<RB>(s)];
         if (LAZY) v = reduce_small(v, q, mq.two_q, rq);
         else { v = v >= mq.two_q ? v - mq.two_q : v; v = v >= q ? v - q : v; }
-        dst[tid + u * nt] = v;
+        dst[s] = v;
     }
 }
 
@@ -255,6 +289,12 @@ size_t k_relin64_work_words(const crc_ctx *c, size_t cnt, int dbc)
     return run > prep ? run : prep;
 }
 
+// threads per workgroup for passes of 2^RB values per thread
+static int f64_threads(const crc_ctx *c, int RB) { int nt = c->n >> RB; if (nt < 64) nt = 64; if (nt > (RB == 5 ? 512 : 1024)) nt = RB == 5 ? 512 : 1024; return nt; }
+// 3 stages (8 values per thread) per LDS pass by default: measured on (8192, 3) the digit kernel runs 0.90 / 1.08 / 1.34 us per ciphertext with 3 / 4 / 5 -- the wider
+// passes save LDS round trips and barriers but cost occupancy (76 / 134 registers), and the kernel is bound by instruction issue, not by LDS (profiles/r03_square_relin.txt)
+static int f64_radix(const crc_ctx *c) { const int r = c->tune.f64_radix; return r >= 3 && r <= 5 ? r : 3; }
+
 // kp: k_relin64_keys_words; scratch: crc_evk_words (k_relin64_work_words covers it)
 int k_relin64_prepare_keys(crc_ctx *c, const u64 *evk, int dbc, u64 *kp, u64 *scratch, hipStream_t st)
 {
@@ -265,10 +305,11 @@ int k_relin64_prepare_keys(crc_ctx *c, const u64 *evk, int dbc, u64 *kp, u64 *sc
     HIPCHK(hipGetLastError());
     int rc;
     if ((rc = k_ntt_ct(c, true, scratch, scratch, rows / c->k, 1, false, st, nullptr, 0, 0, 0))) return rc;
-    int nt = c->n / 8; if (nt < 64) nt = 64; if (nt > 1024) nt = 1024;
     const size_t lds = (size_t)c->n * 8;
-    { const int r2 = crc_ctx_ensure_lds(c, (const void *)relin_keys_f64_kernel, lds); if (r2) return r2; }
-    hipLaunchKernelGGL(relin_keys_f64_kernel, dim3((unsigned)(rows * CRC_NF64)), dim3(nt), lds, st, scratch, Kf, c->d_mods, reinterpret_cast<const d2 *>(c->d_f64_rp), c->f64, c->n, c->logn, c->k);
+    const int RB = f64_radix(c);
+    auto kern = RB == 3 ? relin_keys_f64_kernel<3> : RB == 4 ? relin_keys_f64_kernel<4> : relin_keys_f64_kernel<5>;
+    { const int r2 = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (r2) return r2; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(rows * CRC_NF64)), dim3(f64_threads(c, RB)), lds, st, scratch, Kf, c->d_mods, reinterpret_cast<const d2 *>(c->d_f64_rp), c->f64, c->n, c->logn, c->k);
     HIPCHK(hipGetLastError());
     return CRC_OK;
 }
@@ -276,24 +317,25 @@ int k_relin64_prepare_keys(crc_ctx *c, const u64 *evk, int dbc, u64 *kp, u64 *sc
 template <int K>
 static int relin64_mac(crc_ctx *c, const double *E, const double *Kf, double *A, int D, size_t cnt, hipStream_t st)
 {
-    constexpr int CT = K <= 2 ? 4 : K <= 4 ? 2 : 1;
+    // accumulators: CT x PJ doubles per thread (32..48)
+    constexpr int PJ = 2 * K <= 8 ? 2 * K : (2 * K) % 8 == 0 ? 8 : (2 * K) % 6 == 0 ? 6 : (2 * K) % 5 == 0 ? 5 : 7, CT = PJ <= 4 ? 8 : PJ <= 6 ? 6 : 4, PJS = 2 * K / PJ;
+    static_assert(PJ * PJS == 2 * K, "key columns must split evenly");
     const int threads = c->n < 256 ? c->n : 256, sblocks = c->n / threads;
     const size_t groups = (cnt + CT - 1) / CT;
-    hipLaunchKernelGGL((relin_mac_f64_kernel<K, CT>), dim3((unsigned)(groups * CRC_NF64 * sblocks)), dim3(threads), 0, st, E, Kf, A, c->f64, c->n, D, cnt);
+    hipLaunchKernelGGL((relin_mac_f64_kernel<K, CT, PJ>), dim3((unsigned)(groups * CRC_NF64 * PJS * sblocks)), dim3(threads), 0, st, E, Kf, A, c->f64, c->n, D, cnt);
     HIPCHK(hipGetLastError());
     return CRC_OK;
 }
 
-template <int NPT>
-static int relin64_tail(crc_ctx *c, const double *A, const u64 *x3, int add_size, u64 *y, size_t cnt, bool out_ntt, hipStream_t st)
+template <int RB>
+static int relin64_tail(crc_ctx *c, double *A, const u64 *x3, int add_size, u64 *y, size_t cnt, bool out_ntt, hipStream_t st)
 {
     bool lazy = true;
     for (int i = 0; i < c->k; i++) if (c->tabs[i].m.bits > 57 || c->tabs[i].m.bits < 45) lazy = false;
-    const int nt = c->n / NPT;
     const size_t lds = (size_t)c->n * 8;
-    auto kern = !out_ntt ? relin_inv_crt_kernel<NPT, false, false> : lazy ? relin_inv_crt_kernel<NPT, true, true> : relin_inv_crt_kernel<NPT, true, false>;
+    auto kern = !out_ntt ? relin_inv_crt_kernel<RB, false, false> : lazy ? relin_inv_crt_kernel<RB, true, true> : relin_inv_crt_kernel<RB, true, false>;
     { const int rc = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (rc) return rc; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * 2 * c->k)), dim3(nt), lds, st, A, x3, add_size, y, c->d_mods, reinterpret_cast<const d2 *>(c->d_f64_irp),
+    hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * 2 * c->k)), dim3(f64_threads(c, RB)), lds, st, A, x3, add_size, y, c->d_mods, reinterpret_cast<const d2 *>(c->d_f64_irp),
                        reinterpret_cast<const ulonglong2 *>(c->d_rp), c->f64, c->n, c->logn, c->k);
     HIPCHK(hipGetLastError());
     return CRC_OK;
@@ -313,12 +355,15 @@ int k_relinearize64(crc_ctx *c, const u64 *src, int src_size, int src_poly, cons
     const double *Kf = reinterpret_cast<const double *>(kp);
     int rc;
     double *E = reinterpret_cast<double *>(work), *A = E + cnt * D * CRC_NF64 * n;
-    int nt = c->n / 8; if (nt < 64) nt = 64; if (nt > 1024) nt = 1024;
     const size_t lds = n * 8;
-    { const int r2 = crc_ctx_ensure_lds(c, (const void *)relin_digits_f64_kernel, lds); if (r2) return r2; }
-    hipLaunchKernelGGL(relin_digits_f64_kernel, dim3((unsigned)(cnt * k)), dim3(nt), lds, st, src, src_size, src_poly, E, reinterpret_cast<const d2 *>(c->d_f64_rp), c->f64, c->n, c->logn,
-                       c->k, D, dbc, tab);
-    HIPCHK(hipGetLastError());
+    const int RB = f64_radix(c);
+    {
+        auto kern = RB == 3 ? relin_digits_f64_kernel<3> : RB == 4 ? relin_digits_f64_kernel<4> : relin_digits_f64_kernel<5>;
+        const int r2 = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (r2) return r2;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * k)), dim3(f64_threads(c, RB)), lds, st, src, src_size, src_poly, E, reinterpret_cast<const d2 *>(c->d_f64_rp), c->f64, c->n, c->logn,
+                           c->k, D, dbc, tab);
+        HIPCHK(hipGetLastError());
+    }
     switch (c->k) {
 #define MACK(KV) case KV: rc = relin64_mac<KV>(c, E, Kf, A, D, cnt, st); break;
     MACK(1) MACK(2) MACK(3) MACK(4) MACK(5) MACK(6) MACK(7) MACK(8)
@@ -326,12 +371,6 @@ int k_relinearize64(crc_ctx *c, const u64 *src, int src_size, int src_poly, cons
     default: return CRC_ERR_UNSUPPORTED;
     }
     if (rc) return rc;
-    switch (c->n / nt) {
-    case 1: return relin64_tail<1>(c, A, x3, add_size, y, cnt, out_ntt, st);
-    case 2: return relin64_tail<2>(c, A, x3, add_size, y, cnt, out_ntt, st);
-    case 4: return relin64_tail<4>(c, A, x3, add_size, y, cnt, out_ntt, st);
-    case 8: return relin64_tail<8>(c, A, x3, add_size, y, cnt, out_ntt, st);
-    case 16: return relin64_tail<16>(c, A, x3, add_size, y, cnt, out_ntt, st);
-    }
-    return CRC_ERR_UNSUPPORTED;
+    return RB == 3 ? relin64_tail<3>(c, A, x3, add_size, y, cnt, out_ntt, st) : RB == 4 ? relin64_tail<4>(c, A, x3, add_size, y, cnt, out_ntt, st)
+                                                                                          : relin64_tail<5>(c, A, x3, add_size, y, cnt, out_ntt, st);
 }

@@ -8,6 +8,13 @@
 // register-tile pattern of the radix-8 passes at n = 4096 (at most 2-way in the short tail pass of n = 8192 / 16384); found by
 // enumerating the access patterns (bank = index mod 32 per 32-lane group)
 __device__ __forceinline__ int lpad(int i) { return i ^ ((i >> 3) & 7) ^ (((i >> 6) & 3) << 3); }
+// the same idea for passes of 16 / 32 values per thread (the fp64 transforms of kernels_relin64.hip): XOR of higher index bits into the low four = the sixteen 8-byte
+// slots of a 128-byte LDS row; found by enumerating every pass's access pattern in groups of 16 lanes (forward and inverse, n = 4096 / 8192 / 16384): conflict-free for
+// their own radix, at most 2-way in one pass of the radix-8 transforms below when those run on an image laid out this way
+template <int SW> __device__ __forceinline__ int swz(int i);
+template <> __device__ __forceinline__ int swz<3>(int i) { return lpad(i); }
+template <> __device__ __forceinline__ int swz<4>(int i) { return i ^ ((i >> 2) & 1) ^ ((i >> 4) & 15); }
+template <> __device__ __forceinline__ int swz<5>(int i) { return i ^ ((i >> 4) & 15) ^ ((i >> 5) & 15); }
 
 // Lazy variant (LAZY = true, moduli of at most 57 bits): there are 7+ spare bits above q in a 64-bit word, so butterflies never
 // correct their inputs and use a 3-product estimate of the Shoup quotient (result in [0, 4q) instead of [0, 2q)); the forward
@@ -86,7 +93,7 @@ __device__ __forceinline__ void inv_stages(u64 (&v)[1 << R], const ulonglong2 *W
 }
 
 // one pass over the whole row: every thread takes groups of 2^R values that interact in the next R stages
-template <bool INV, int R, bool LAZY>
+template <bool INV, int R, bool LAZY, int SW = 3>
 __device__ __forceinline__ void ntt_pass(u64 *sm, const ulonglong2 *W, int n, int s /*element stride inside a group*/, int tabidx, u64 q, u64 q2)
 {
     const int groups = n >> R;
@@ -95,10 +102,10 @@ __device__ __forceinline__ void ntt_pass(u64 *sm, const ulonglong2 *W, int n, in
         const int base = blk * (s << R) + l;
         u64 v[1 << R];
 #pragma unroll
-        for (int c = 0; c < (1 << R); c++) v[c] = sm[lpad(base + c * s)];
+        for (int c = 0; c < (1 << R); c++) v[c] = sm[swz<SW>(base + c * s)];
         if (INV) inv_stages<R, LAZY>(v, W, tabidx, blk, q, q2); else fwd_stages<R, LAZY>(v, W, tabidx, blk, q, q2);
 #pragma unroll
-        for (int c = 0; c < (1 << R); c++) sm[lpad(base + c * s)] = v[c];
+        for (int c = 0; c < (1 << R); c++) sm[swz<SW>(base + c * s)] = v[c];
     }
     __syncthreads();
 }
@@ -107,19 +114,19 @@ __device__ __forceinline__ void ntt_pass(u64 *sm, const ulonglong2 *W, int n, in
 // all passes of one row transform on the LDS image `sm` (n values, lpad-swizzled); the caller has synchronised after filling it and
 // the function returns synchronised.  Forward: gaps n/2, n/4, ... (radix-8 passes, then a radix-4 / radix-2 pass when log2 n is not
 // a multiple of 3); inverse: gaps 1, 2, 4, ...
-template <bool INV, bool LAZY>
+template <bool INV, bool LAZY, int SW = 3>
 __device__ __forceinline__ void ntt_row_passes(u64 *sm, const ulonglong2 *W, int n, int logn, u64 q, u64 q2)
 {
     const int full = logn / 3, rem = logn - 3 * full;
     if (!INV) {
         int t = n >> 1;
-        for (int p = 0; p < full; p++, t >>= 3) ntt_pass<false, 3, LAZY>(sm, W, n, t >> 2, n / (2 * t), q, q2);
-        if (rem == 2) ntt_pass<false, 2, LAZY>(sm, W, n, t >> 1, n / (2 * t), q, q2);
-        else if (rem == 1) ntt_pass<false, 1, LAZY>(sm, W, n, t, n / (2 * t), q, q2);
+        for (int p = 0; p < full; p++, t >>= 3) ntt_pass<false, 3, LAZY, SW>(sm, W, n, t >> 2, n / (2 * t), q, q2);
+        if (rem == 2) ntt_pass<false, 2, LAZY, SW>(sm, W, n, t >> 1, n / (2 * t), q, q2);
+        else if (rem == 1) ntt_pass<false, 1, LAZY, SW>(sm, W, n, t, n / (2 * t), q, q2);
     } else {
         int t = 1;
-        for (int p = 0; p < full; p++, t <<= 3) ntt_pass<true, 3, LAZY>(sm, W, n, t, n / (2 * t), q, q2);
-        if (rem == 2) ntt_pass<true, 2, LAZY>(sm, W, n, t, n / (2 * t), q, q2);
-        else if (rem == 1) ntt_pass<true, 1, LAZY>(sm, W, n, t, n / (2 * t), q, q2);
+        for (int p = 0; p < full; p++, t <<= 3) ntt_pass<true, 3, LAZY, SW>(sm, W, n, t, n / (2 * t), q, q2);
+        if (rem == 2) ntt_pass<true, 2, LAZY, SW>(sm, W, n, t, n / (2 * t), q, q2);
+        else if (rem == 1) ntt_pass<true, 1, LAZY, SW>(sm, W, n, t, n / (2 * t), q, q2);
     }
 }

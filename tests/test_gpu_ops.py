@@ -212,7 +212,17 @@ def test_relinearise_over_fp64_primes_equals_reference_arithmetic(n, k, cnt):
     for key, v in res.items():
         if key[0] == 0:
             assert np.array_equal(v, res[(1,) + key[1:]]), key
+    # the wider LDS passes of the fp64 transforms (tuning variants: 16 / 32 values per thread, their own LDS swizzles)
     E.set_tuning("relin_path", 0)
+    for radix in (4, 5):
+        E.set_tuning("f64_radix", radix)
+        d_y = E.alloc((cnt + 2) * 2 * k * n * 8)
+        E.relinearize(d_x3, cnt + 2, d_evk, d_y, d_w)
+        assert np.array_equal(E.download(d_y, (cnt + 2, 2, k, n)), outs[1]), ("radix", radix)
+        d_y = E.alloc(x.nbytes)
+        E.square_relin(d_x, cnt + 2, d_evk, d_y, d_w, in_form=ca.NTT, out_form=ca.NTT)
+        assert np.array_equal(E.download(d_y, x.shape), res[(1, ca.NTT, ca.NTT)]), ("radix", radix, "forms")
+    E.set_tuning("f64_radix", 0)
     E.close()
 
 
