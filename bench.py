@@ -33,13 +33,14 @@ CONFIGS = {
     # configs[2]: ApproxPlainModel.h5, n=8192, 3 coeff moduli, batch=1024
     "approx8192": dict(model="ApproxPlainModel", n=8192, k=3, t=1 << 42, batch=1024, chunk=32),   # t=2^42: exact logits, 19 bits of budget left
     # configs[4]: PlainModelWoPad.h5, n=16384, 4 coeff moduli
-    "wopad16384": dict(model="PlainModelWoPad", n=16384, k=4, t=1 << 44, batch=1024, chunk=6),
+    # (tail=4: the dense layers run once per 4 chunks = 24 images -- two-level chunking, netrun.prepare: fc3 streams 177 GiB of limb-form weights per launch)
+    "wopad16384": dict(model="PlainModelWoPad", n=16384, k=4, t=1 << 44, batch=1024, chunk=6, tail=4),
     # the coefficient modulus CrCNN itself would run at n=8192 (all four primes of coeff_modulus_128(8192)); at n=16384 the
     # eight default primes would need 424 GB for PlainModelWoPad's encoded weights alone (> HBM), so that one stays at k=4
     "approx8192k4": dict(model="ApproxPlainModel", n=8192, k=4, t=1 << 42, batch=1024, chunk=16),
     # every prime of coeff_modulus_128(16384), the coefficient modulus CrCNN's own setParameters(16384, t) picks: 424 GB of NTT-form weights -- fc3 keeps
     # coefficient-form plaintexts in HBM and is lifted + transformed a filter tile at a time inside every forward (netrun: streamed layers)
-    "wopad16384k8": dict(model="PlainModelWoPad", n=16384, k=8, t=1 << 44, batch=96, chunk=8),
+    "wopad16384k8": dict(model="PlainModelWoPad", n=16384, k=8, t=1 << 44, batch=96, chunk=8, tail=4),
     # small ring for the tests of this script and single-GPU rehearsals of the multi-rank path (golden: net_tiny1024_eng.json)
     "tiny1024": dict(model="PlainModelTiny", n=1024, k=2, q=[0x7fffffff380001, 0x3fffffff000001], t=1 << 32, batch=48, chunk=24),
 }
@@ -53,6 +54,7 @@ def parse():
     ap.add_argument("--config", default="tiny4096", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="encrypted images per GPU per step (default: the config's)")
     ap.add_argument("--chunk", type=int, default=None, help="images processed per layer launch")
+    ap.add_argument("--tail", type=int, default=None, help="chunks per launch of the dense layers (two-level chunking; default: the config's)")
     ap.add_argument("--distinct", type=int, default=4, help="distinct encrypted images (tiled to the batch on device)")
     ap.add_argument("--mode", default="resident", choices=["resident", "layerwise"])
     ap.add_argument("--no-fuse", action="store_true", help="do not fold pooling layers into the preceding convolution")
@@ -343,6 +345,7 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
     if args.t_bits and full:
         cfg["t"] = 1 << args.t_bits
     B = batch or cfg["batch"]; C = min(chunk or cfg["chunk"], B)
+    G = max(1, min(int(args.tail or cfg.get("tail", 1)), B // C))       # chunks per run of the dense layers (two-level chunking)
     q = cfg.get("q") or ca.default_coeff_modulus_128(cfg["n"])[:cfg["k"]]
     E = ca.Engine(cfg["n"], q, cfg["t"], device=D_.local)
     E.stream = torch.cuda.current_stream().cuda_stream or None
@@ -429,7 +432,8 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
     # ---- reference layer structure first (every CrCNN layer run as its own kernel sequence, NTT-resident): a short pass
     unfused = None
     want_fuse = args.mode == "resident" and not args.no_fuse
-    if want_fuse and full and args.unfused_images > 0:
+    tilewise = any(pl[3].get("tilewise") for pl in net.plan)       # (their limb weights would have to be built twice, before and after the folding: skipped)
+    if want_fuse and full and args.unfused_images > 0 and not tilewise:
         Cu = min(C, 32)                                # the unfused conv1 output is 18 432 ciphertexts per image (Tiny): a smaller chunk than the main pass
         nu = min(B, max(Cu, args.unfused_images // Cu * Cu))
         net.prepare(Cu, limb=False)                    # (the limb conversion drops the canonical weights fuse() needs; it happens in the final prepare)
@@ -448,28 +452,34 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
         torch.cuda.empty_cache()
     if want_fuse:
         net.fuse()            # fold avg/sum pooling into the preceding convolution where that removes MACs (exact)
-    net.prepare(C)
+    net.prepare(C, tail_group=G)
+    G = net.G
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
 
     nl = len(net.plan)
     lay_ev = []
+    # groups of up to G full chunks (the dense layers run once per group); a ragged last chunk is a group of its own
+    groups, c0 = [], 0
+    while c0 < B:
+        cb = min(C, B - c0)
+        ng = min(G, (B - c0) // C) if cb == C else 1
+        groups.append((c0, cb, max(1, ng))); c0 += cb * max(1, ng)
 
     def step(record):
-        for c0 in range(0, B, C):
-            cb = min(C, B - c0)
+        for (c0, cb, ng) in groups:
             evs = []
 
             def timer(i, name, kind, phase):
                 if record:
-                    e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e)
-            d_out = net.forward(x_all[c0 % window], cb, timer=timer)
-            E.L.crc_memcpy_d2d(E.c, out_all[c0].data_ptr(), E.p(d_out), cb * 10 * ctw * 8, E.stream)
+                    e = torch.cuda.Event(enable_timing=True); e.record(); evs.append((i, e))
+            d_out = net.forward_group([x_all[(c0 + j * cb) % window] for j in range(ng)], cb, timer=timer)
+            E.L.crc_memcpy_d2d(E.c, out_all[c0].data_ptr(), E.p(d_out), ng * cb * 10 * ctw * 8, E.stream)
             if record:
-                lay_ev.append((cb, evs))
+                lay_ev.append((cb, ng, evs))
 
     # untimed module-load pass on a single image (not a step)
-    net.forward(x_all[0], 1)
+    net.forward_group([x_all[0]], 1)
     torch.cuda.synchronize()
     for _ in range(warmup):
         step(False)
@@ -484,11 +494,11 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
 
     # ---- per-layer times of the last step (HIP events on the launch stream)
     lay_ms = np.zeros(nl); lay_launch = np.zeros(nl); lay_cnt = np.zeros(nl)
-    for cb, evs in lay_ev:
-        for i in range(nl):
-            ms = evs[2 * i].elapsed_time(evs[2 * i + 1])
+    for cb, ng, evs in lay_ev:
+        for j in range(0, len(evs), 2):                  # (layer i, start), (layer i, end) -- a head layer once per chunk of the group, a dense layer once per group
+            i = evs[j][0]; ms = evs[j][1].elapsed_time(evs[j + 1][1])
             lay_ms[i] += ms
-            if cb == C:
+            if cb == C and (i < net.split or ng == G):
                 lay_launch[i] += ms; lay_cnt[i] += 1
     ms_per_layer = {net.plan[i][1]: round(float(lay_ms[i] / B), 4) for i in range(nl)}
 
@@ -535,7 +545,8 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
             wbytes = a["nf"] * a["zd"] * a["xf"] * a["yf"] * 8 * E.k * E.n
         elif kind == "fc":
             wbytes = a["in_dim"] * a["out_dim"] * 8 * E.k * E.n
-        alg_bytes = C * (in_cts + out_cts) * ct_bytes + wbytes
+        CL = C * G if dom >= net.split else C           # images per launch of that layer
+        alg_bytes = CL * (in_cts + out_cts) * ct_bytes + wbytes
         dur_ms = lay_launch[dom] / max(1, lay_cnt[dom])
         layer_ms = dur_ms
         kernel_note = None
@@ -570,12 +581,12 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
             kernel_note = ("HIP events around the layer call inside the timed region; the input arrives in limb form from the layer in front and the call is " +
                            ("mfma_mac2w_kernel alone (it writes the next dense layer's limb tensor itself)" if p["out_form"] == ca.NTTL else "mfma_mac2w_kernel + the conversion of its slot-major result (3-9 % of the call)"))
         achieved = alg_bytes / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
-        macs_launch = layer_macs(kind, a) * C
+        macs_launch = layer_macs(kind, a) * CL
         # HBM traffic of that launch: rocprofv3 PMC passes (FETCH_SIZE corrected x2 for gfx950, WRITE_SIZE) collected OFFLINE with
         # tools/bench_mac.py and committed under profiles/ -- bench.py cannot run the profiler on itself, so this is not measured in this run
         traffic, traffic_source = None, None
         kname = "mfma_mac2w_kernel" if p.get("w_form") == ca.NTTL else "mfma_conv1_kernel" if p.get("w_form") == ca.NTTL1 else "mac3_kernel"
-        kernel_label = f"{kname} ({name}, {C} images/launch)" if kind in ("conv", "fc") else f"{kind} ({name})"
+        kernel_label = f"{kname} ({name}, {CL} images/launch)" if kind in ("conv", "fc") else f"{kind} ({name})"
         for pf in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", pf))).get(cfg_name)
@@ -614,7 +625,7 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
             "metric": "encrypted images/sec", "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": f"synthetic ({D} distinct MNIST-like encrypted images per GPU tiled to the batch" + ("" if window == B else f", resident as a {window}-image window") + f"; trained weights from {model}.h5)",
-            "config": {"workload": f"{model}.h5 n={cfg['n']} k={cfg['k']} t=2^{cfg['t'].bit_length() - 1} batch={B}/GPU chunk={C} ({cfg_name}, BASELINE configs)",
+            "config": {"workload": f"{model}.h5 n={cfg['n']} k={cfg['k']} t=2^{cfg['t'].bit_length() - 1} batch={B}/GPU chunk={C}" + (f" (dense layers: {C * G})" if G > 1 else "") + f" ({cfg_name}, BASELINE configs)",
                        "mode": args.mode + ("+conv/pool folding" if want_fuse else ""), "parallelism": f"image-sharded x{world}, RCCL weight broadcast"},
             "ms_per_layer": ms_per_layer,
             "mac_kernel_per_layer": {pl[1]: ("mfma_mac2w_kernel (int8 limb GEMM, CRC_NTTL)" if pl[3].get("w_form") == ca.NTTL else

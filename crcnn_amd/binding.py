@@ -111,6 +111,9 @@ def load():
     L.crc_limb_tensor_bytes.restype = SZ; L.crc_limb_tensor_bytes.argtypes = [VP, CI, CI, CI, CI]
     L.crc_limb_weights_bytes.restype = SZ; L.crc_limb_weights_bytes.argtypes = [VP, CI, CI, CI, CI]
     L.crc_limb_pack_weights.argtypes = [VP, VP, CI, CI, CI, CI, VP, VP]
+    L.crc_limb_pack_weights_tile.argtypes = [VP, VP, CI, CI, CI, CI, CI, CI, VP, VP]
+    L.crc_plan_mac.argtypes = [VP] + [CI] * 10 + [ctypes.POINTER(CI)]
+    L.crc_plan_fold_pool.argtypes = [VP] + [CI] * 12 + [ctypes.POINTER(CI)]
     L.crc_limb_pack_tensor.argtypes = [VP, VP, CI, CI, CI, CI, CI, VP, VP]
     L.crc_limb_conv1_supported.argtypes = [VP] + [CI] * 8
     L.crc_limb_conv1_weights_bytes.restype = SZ; L.crc_limb_conv1_weights_bytes.argtypes = [VP]
@@ -401,6 +404,20 @@ class Engine:
 
     def limb_pack_weights(self, d_w_ntt, nf, zd, xf, yf, d_wl):
         _chk(self.L.crc_limb_pack_weights(self.c, self.p(d_w_ntt), nf, zd, xf, yf, self.p(d_wl), self.stream), "crc_limb_pack_weights")
+
+    def plan_mac(self, zd, xd, yd, xs, ys, xf, yf, nf, B, matrix_cores=True):
+        """the weight form (= kernel) of a conv / dense layer launched on B images (B = 0: shape only): crc_plan_mac, the policy shared with the C++ host classes"""
+        wf = CI(0)
+        _chk(self.L.crc_plan_mac(self.c, zd, xd, yd, xs, ys, xf, yf, nf, int(B or 0), 1 if matrix_cores else 0, ctypes.byref(wf)), "crc_plan_mac")
+        return wf.value
+
+    def plan_fold_pool(self, zd, xd, yd, xs, ys, xf, yf, nf, pxs, pys, pxf, pyf):
+        f = CI(0)
+        _chk(self.L.crc_plan_fold_pool(self.c, zd, xd, yd, xs, ys, xf, yf, nf, pxs, pys, pxf, pyf, ctypes.byref(f)), "crc_plan_fold_pool")
+        return bool(f.value)
+
+    def limb_pack_weights_tile(self, d_w_tile, nf, f0, ft, zd, xf, yf, d_wl):
+        _chk(self.L.crc_limb_pack_weights_tile(self.c, self.p(d_w_tile), nf, f0, ft, zd, xf, yf, self.p(d_wl), self.stream), "crc_limb_pack_weights_tile")
 
     def limb_pack_tensor(self, d_x, in_form, B, zd, xd, yd, d_xl):
         _chk(self.L.crc_limb_pack_tensor(self.c, self.p(d_x), in_form, B, zd, xd, yd, self.p(d_xl), self.stream), "crc_limb_pack_tensor")

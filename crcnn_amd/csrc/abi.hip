@@ -105,6 +105,12 @@ extern "C" int crc_limb_pack_weights(crc_ctx *c, const uint64_t *d_w_ntt, int nf
     if (!crc_limb_supported(c, zd, xf, yf)) return CRC_ERR_UNSUPPORTED;
     return k_limb_pack_weights(c, d_w_ntt, (signed char *)d_wl, nf, zd, xf * yf, S(stream));
 }
+extern "C" int crc_limb_pack_weights_tile(crc_ctx *c, const uint64_t *d_w_tile_ntt, int nf, int f0, int ft, int zd, int xf, int yf, void *d_wl, void *stream)
+{
+    CHECK_CTX(c); if (!d_w_tile_ntt || !d_wl || nf < 1 || zd < 1 || xf < 1 || yf < 1 || f0 < 0 || ft < 1 || f0 + ft > nf) return CRC_ERR_INVALID_ARGUMENT;
+    if (!crc_limb_supported(c, zd, xf, yf)) return CRC_ERR_UNSUPPORTED;
+    return k_limb_pack_weights(c, d_w_tile_ntt, (signed char *)d_wl, nf, zd, xf * yf, S(stream), f0, ft);
+}
 extern "C" int crc_limb_pack_tensor(crc_ctx *c, const uint64_t *d_x, int in_form, int B, int zd, int xd, int yd, void *d_xl, void *stream)
 {
     CHECK_CTX(c); if (!d_x || !d_xl || B < 0 || zd < 1 || xd < 1 || yd < 1 || (in_form != CRC_NTT && in_form != CRC_NTTP)) return CRC_ERR_INVALID_ARGUMENT;
@@ -319,6 +325,44 @@ extern "C" int crc_batchnorm(crc_ctx *c, uint64_t *d_x, int B, int zd, int xd, i
     RUN(k_ntt_ct(c, false, d_x, d_x, cnt, 2, false, st, nullptr, 0, 0));
     RUN(k_rowwise(c, d_x, d_invstd, cnt, 2, 2, 1, hw, (size_t)zd, st));
     return k_ntt_ct(c, true, d_x, d_x, cnt, 2, false, st, nullptr, 0, 0);
+}
+
+// ---- kernel selection: ONE statement of the policy for every host (netrun.py, crcnn_amd/host) ------------------------------------------------------
+// which multiply-accumulate kernel a conv / dense layer (dense: xd = yd = xf = yf = xs = ys = 1, zd = in_dim, nf = out_dim) runs on when launched on B images
+extern "C" int crc_plan_mac(const crc_ctx *c, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int B, int matrix_cores, int *w_form)
+{
+    if (!c || !w_form || zd < 1 || nf < 1 || !conv_shape_ok(xd, yd, xs, ys, xf, yf)) return CRC_ERR_INVALID_ARGUMENT;
+    bool packable = true;
+    for (int i = 0; i < c->k; i++) if (c->tabs[i].m.bits > 55) packable = false;
+    *w_form = packable ? CRC_NTTP : CRC_NTT;                      // mac3_kernel / mac2_kernel on 28-bit limb pairs (canonical residues above 55 bits)
+    if (!matrix_cores || !packable) return CRC_OK;
+    // one-channel convolutions (conv1, alone or with its pooling layer folded in) have their own matrix-core kernel
+    if (zd == 1) { if (k_limb_conv1_shape(c, zd, xd, yd, xs, ys, xf, yf, nf)) *w_form = CRC_NTTL1; return CRC_OK; }
+    // the limb GEMM pays from 8 reduction steps of 32 channels on (below that its fixed costs per output tile and the channel padding eat the gain), and only with at
+    // least half a 64-row tile of rows = (image, pixel, poly) per launch: with fewer, most of every MFMA is padding and every slot's weights are streamed for a
+    // handful of rows (PlainModelWoPad at 6 images per launch: fc4 0.23 ms per image on mac3_kernel against 1.59)
+    const int min_steps = c->tune.mfma_min_steps > 0 ? c->tune.mfma_min_steps : 8;
+    const long long P = (long long)((xd - xf) / xs + 1) * ((yd - yf) / ys + 1);
+    if (zd >= 16 && (long long)((zd + 31) / 32) * xf * yf >= min_steps && crc_limb_supported(c, zd, xf, yf) && (B <= 0 || (long long)B * 2 * P >= 32)) *w_form = CRC_NTTL;
+    return CRC_OK;
+}
+// should a (sum / average) pooling layer be folded into the convolution in front of it (crc_conv2d_fold_pool: exact)?  Cost in units of one multiply-accumulate
+// term per output ciphertext: the MAC kernels pay ~24 terms of prologue / epilogue per output and take filters in multiples of 8; a pooling pass moves
+// (window + 1) ciphertexts per output at HBM rate, ~10 term-times each.  Folding wins whenever it removes MACs (decimating pools) and narrowly for CrCNN's stride-1 pools.
+extern "C" int crc_plan_fold_pool(const crc_ctx *c, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int pxs, int pys, int pxf, int pyf, int *fold)
+{
+    if (!c || !fold || zd < 1 || nf < 1 || !conv_shape_ok(xd, yd, xs, ys, xf, yf) || pxs < 1 || pys < 1 || pxf < 1 || pyf < 1) return CRC_ERR_INVALID_ARGUMENT;
+    *fold = 0;
+    const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys + 1;
+    const int xf2 = (pxf - 1) * xs + xf, yf2 = (pyf - 1) * ys + yf, xs2 = xs * pxs, ys2 = ys * pys;
+    if (xf2 > xd || yf2 > yd || pxf > xo || pyf > yo) return CRC_OK;
+    const int xo2 = (xd - xf2) / xs2 + 1, yo2 = (yd - yf2) / ys2 + 1;
+    if (xo2 != (xo - pxf) / pxs + 1 || yo2 != (yo - pyf) / pys + 1) return CRC_OK;           // the folded convolution must produce exactly the pooled tensor
+    const long long fpad = (nf + 7) / 8 * 8, T1 = (long long)zd * xf * yf, T2 = (long long)zd * xf2 * yf2;
+    const long long cost_sep = fpad * xo * yo * (T1 + 24) + (long long)nf * xo2 * yo2 * 10 * (pxf * pyf + 1);
+    const long long cost_fused = fpad * xo2 * yo2 * (T2 + 24);
+    *fold = cost_fused < cost_sep ? 1 : 0;
+    return CRC_OK;
 }
 
 // ---- square + relinearize -----------------------------------------------------------------------------------------

@@ -389,8 +389,9 @@ __global__ void __launch_bounds__(64) limb_pack_tensor_kernel(const u64 *x, i8 *
         }
     }
 }
-// NTT-form weights w [F][zd][taps][k][n] (canonical) -> Wl (pre-zeroed: channel / filter padding).  One thread per (slot, filter, tap, channel block)
-__global__ void __launch_bounds__(64) limb_pack_weights_kernel(const u64 *w, i8 *wl, const ModParams *mods, int n, int k, int F, int Fp, int zd, int zblks, int taps)
+// NTT-form weights w [F][zd][taps][k][n] (canonical) -> Wl (pre-zeroed: channel / filter padding).  One thread per (slot, filter, tap, channel block).
+// w may be a TILE of the layer's filters: filter f of w is filter f0 + f of Wl (whose filter stride Fp belongs to the whole layer)
+__global__ void __launch_bounds__(64) limb_pack_weights_kernel(const u64 *w, i8 *wl, const ModParams *mods, int n, int k, int F, int Fp, int zd, int zblks, int taps, int f0)
 {
     const int sblocks = n / 64;
     const int sb = blockIdx.x % (sblocks * k), i = sb / sblocks, s = (sb % sblocks) * 64 + threadIdx.x;
@@ -413,7 +414,7 @@ __global__ void __launch_bounds__(64) limb_pack_weights_kernel(const u64 *w, i8 
             for (int l = 0; l < NPL; l++) pl[l][z >> 2] |= (u32)(d[l] & 0xff) << (8 * (z & 3));
         }
     }
-    i8 *dst = wl + ((size_t)i * n + s) * ((size_t)((taps * zblks + 1) & ~1) * NPL * Fp * 32) + ((size_t)tap * zblks + zb) * (NPL * Fp * 32) + (size_t)f * 32;
+    i8 *dst = wl + ((size_t)i * n + s) * ((size_t)((taps * zblks + 1) & ~1) * NPL * Fp * 32) + ((size_t)tap * zblks + zb) * (NPL * Fp * 32) + (size_t)(f0 + f) * 32;
 #pragma unroll
     for (int l = 0; l < NPL; l++) {
         uint4 *o = reinterpret_cast<uint4 *>(dst + (size_t)l * Fp * 32);
@@ -499,13 +500,21 @@ int k_limb_pack_tensor(crc_ctx *c, const u64 *x, i8 *xl, int B, int zd, int npos
     HIPCHK(hipGetLastError());
     return CRC_OK;
 }
-int k_limb_pack_weights(crc_ctx *c, const u64 *w, i8 *wl, int nf, int zd, int taps, hipStream_t st)
+// w: filters f0 .. f0 + ft of the layer's nf (ft = nf, f0 = 0: the whole layer); the padding of Wl is zeroed when the first tile (f0 = 0) is packed
+int k_limb_pack_weights(crc_ctx *c, const u64 *w, i8 *wl, int nf, int zd, int taps, hipStream_t st, int f0, int ft)
 {
+    if (ft < 0) ft = nf;
+    if (f0 < 0 || ft < 1 || f0 + ft > nf) return CRC_ERR_INVALID_ARGUMENT;
     const int zblks = round_up(zd, 32) / 32, Fp = round_up(nf, 64);
-    HIPCHK(hipMemsetAsync(wl, 0, k_limb_weights_bytes(c, nf, zd, taps), st));
-    const size_t blocks = (size_t)(c->n / 64) * c->k * nf * taps * zblks;
+    if (f0 == 0) {
+        // zero what no filter / channel / step writes: with whole filter and channel blocks that is only the zero step that evens out an odd number of reduction steps
+        const size_t step = (size_t)NPL * Fp * 32, steps = (size_t)taps * zblks, slot = (size_t)round_up((int)steps, 2) * step;
+        if (nf % 64 == 0 && zd % 32 == 0) { if (steps & 1) HIPCHK(hipMemset2DAsync(wl + steps * step, slot, 0, step, (size_t)c->n * c->k, st)); }
+        else HIPCHK(hipMemsetAsync(wl, 0, k_limb_weights_bytes(c, nf, zd, taps), st));
+    }
+    const size_t blocks = (size_t)(c->n / 64) * c->k * ft * taps * zblks;
     if (blocks > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(limb_pack_weights_kernel, dim3((unsigned)blocks), dim3(64), 0, st, w, wl, c->d_mods, c->n, c->k, nf, Fp, zd, zblks, taps);
+    hipLaunchKernelGGL(limb_pack_weights_kernel, dim3((unsigned)blocks), dim3(64), 0, st, w, wl, c->d_mods, c->n, c->k, ft, Fp, zd, zblks, taps, f0);
     HIPCHK(hipGetLastError());
     return CRC_OK;
 }

@@ -331,13 +331,19 @@ static void forwardStreamed(const ciphertext3D &input, ciphertext3D &out, int zd
     }
 }
 
-// canonical NTT-form weights -> limb form (CRC_NTTL) when the reduction is long enough for the matrix-core kernel to pay (same rule as netrun.py) and the
-// second copy fits beside the first; the canonical copy is dropped
-static bool toLimb(shared_ptr<DeviceBuffer> &d_w, int &w_form, int nf, int zd, int xf, int yf, long rows)
+// the kernel crc_plan_mac picks for a conv / dense layer launched on B images (the one statement of the policy, shared with netrun.py)
+static int plannedForm(int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int B)
+{
+    int wf = CRC_NTT;
+    chk(crc_plan_mac(ctx(), zd, xd, yd, xs, ys, xf, yf, nf, B, 1, &wf), "crc_plan_mac");
+    return wf;
+}
+// canonical NTT-form weights -> limb form (CRC_NTTL) when crc_plan_mac says the limb GEMM pays for this shape and launch size and the second copy fits beside the
+// first; the canonical copy is dropped
+static bool toLimb(shared_ptr<DeviceBuffer> &d_w, int &w_form, int nf, int zd, int xf, int yf, bool planned)
 {
     if (w_form == CRC_NTTL) return true;
-    if (rows < 32) return false;                            // less than half a 64-row tile per launch: mostly padding, the vector-ALU kernel is faster
-    if (zd < 16 || (zd + 31) / 32 * xf * yf < 8 || !crc_limb_supported(ctx(), zd, xf, yf)) return false;
+    if (!planned) return false;
     const size_t nbytes = crc_limb_weights_bytes(ctx(), nf, zd, xf, yf);
     size_t free_b = 0, total_b = 0;
     chk(crc_mem_info(ctx(), &free_b, &total_b), "crc_mem_info");
@@ -390,14 +396,15 @@ bool ConvolutionalLayer::limbWeights(int B)
     if (streamed) return false;
     if (w_form == CRC_NTTL || w_form == CRC_NTTL1) return true;
     if (w_form == CRC_NTTP) packWeights(true);
-    if (crc_limb_conv1_supported(ctx(), zd, xd, yd, xs, ys, xf, yf, nf)) {          // one-channel convolutions have their own matrix-core kernel (kernels_mfma1.hip)
+    const int planned = plannedForm(zd, xd, yd, xs, ys, xf, yf, nf, B);
+    if (planned == CRC_NTTL1) {          // one-channel convolutions have their own matrix-core kernel (kernels_mfma1.hip)
         auto wl = make_shared<DeviceBuffer>(crc_limb_conv1_weights_bytes(ctx()));
         chk(crc_limb_conv1_pack_weights(ctx(), (const uint64_t *)d_w->ptr, nf, xf, yf, wl->ptr, nullptr), "crc_limb_conv1_pack_weights");
         chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
         d_w_canon = d_w; d_w = wl; w_form = CRC_NTTL1;         // (the canonical copy of a one-channel layer is small: kept, so that the weights can go back on the wire)
         return true;
     }
-    return toLimb(d_w, w_form, nf, zd, xf, yf, (long)B * 2 * xo * yo);
+    return toLimb(d_w, w_form, nf, zd, xf, yf, planned == CRC_NTTL);
 }
 void ConvolutionalLayer::packWeights(bool unpack)
 {
@@ -469,7 +476,7 @@ void FullyConnectedLayer::deviceParameters(vector<shared_ptr<DeviceBuffer>> &out
     if (streamed && !d_plain) d_plain = make_shared<DeviceBuffer>((size_t)in_dim * out_dim * N() * 8);
     out.push_back(streamed ? d_plain : d_w); out.push_back(d_b[0]); out.push_back(d_b[1]);
 }
-bool FullyConnectedLayer::limbWeights(int B) { upload(); if (streamed) return false; if (w_form == CRC_NTTL) return true; if (w_form == CRC_NTTP) packWeights(true); return toLimb(d_w, w_form, out_dim, in_dim, 1, 1, (long)B * 2); }
+bool FullyConnectedLayer::limbWeights(int B) { upload(); if (streamed) return false; if (w_form == CRC_NTTL) return true; if (w_form == CRC_NTTP) packWeights(true); return toLimb(d_w, w_form, out_dim, in_dim, 1, 1, plannedForm(in_dim, 1, 1, 1, 1, 1, 1, out_dim, B) == CRC_NTTL); }
 void FullyConnectedLayer::packWeights(bool unpack)
 {
     upload();
@@ -707,12 +714,11 @@ int Network::fuse()
         if (xf2 > conv->xd || yf2 > conv->yd) continue;
         const int xo2 = (conv->xd - xf2) / xs2 + 1, yo2 = (conv->yd - yf2) / ys2 + 1;
         if (xo2 != pool->xo || yo2 != pool->yo) continue;
-        // cost in MAC terms per output ciphertext (the MAC kernel pays ~24 terms of prologue/epilogue per output, filters come in
-        // multiples of 8; a pooling pass moves window+1 ciphertexts per output at HBM rate, ~10 term-times each)
-        const long long fpad = (conv->nf + 7) / 8 * 8, T1 = (long long)conv->zd * conv->xf * conv->yf, T2 = (long long)conv->zd * xf2 * yf2;
-        const long long cost_sep = fpad * conv->xo * conv->yo * (T1 + 24) + (long long)conv->nf * xo2 * yo2 * 10 * (pool->xf * pool->yf + 1);
-        const long long cost_fused = fpad * xo2 * yo2 * (T2 + 24);
-        if (cost_fused >= cost_sep) continue;
+        // the cost model lives behind the C ABI (crc_plan_fold_pool), shared with netrun.py
+        const long long T2 = (long long)conv->zd * xf2 * yf2;
+        int fold = 0;
+        chk(crc_plan_fold_pool(ctx(), conv->zd, conv->xd, conv->yd, conv->xs, conv->ys, conv->xf, conv->yf, conv->nf, pool->xs, pool->ys, pool->xf, pool->yf, &fold), "crc_plan_fold_pool");
+        if (!fold) continue;
         conv->upload();
         vector<Plaintext> nob; plaintext4D nof;
         auto fused = make_shared<ConvolutionalLayer>(conv->name + "+" + pool->name, conv->xd, conv->yd, conv->zd, xs2, ys2, xf2, yf2, conv->nf, conv->th_count, nof, nob);

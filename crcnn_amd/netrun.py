@@ -101,6 +101,16 @@ class Network:
                 if eng.device >= 0 and wv.size * E_k_n_8(eng) > self.stream_share * eng.mem_info()[1]:
                     p["w"] = None; p["streamed"] = True
                     p["plain"] = self._encode_plain(wv, encode_chunk)
+                elif eng.device >= 0 and resident and self.limb_eligible(kind, a) and self._needs_tilewise(kind, a, wv.size):
+                    # the matrix-core form of this layer's weights is built a filter tile at a time straight from the plaintexts (encode -> lift + NTT ->
+                    # batch-norm fold -> limb tile), once the layer folding is known: the canonical NTT-form copy (202 GiB for PlainModelWoPad's fc3 at
+                    # n = 16384, k = 4) never exists beside the limb copy (177 GiB)
+                    nf_, zd_, xf_, yf_ = (a["nf"], a["zd"], a["xf"], a["yf"]) if kind == "conv" else (a["out_dim"], a["in_dim"], 1, 1)
+                    nbytes = eng.limb_weights_bytes(nf_, zd_, xf_, yf_)
+                    p["w"] = self.alloc(nbytes); p["w_form"] = binding.NTTL; p["tilewise"] = dict(wv=np.ascontiguousarray(wv, dtype=np.float32).reshape(nf_, -1), built=False)
+                    self.weight_bytes += nbytes
+                    self.param_bufs.append((p["w"], nbytes))
+                    self._encode_chunk = encode_chunk
                 else:
                     p["w"] = self._encode_ntt(wv, encode_chunk)
                 p["b"] = self._delta(get(name + ".bias"), out_form)
@@ -129,21 +139,91 @@ class Network:
 
     # ---- operand form of the MAC kernels (CRC_NTTP: 28-bit limb pairs): weights are packed once, and a conv / dense layer that feeds
     # another one hands its output over packed, so that no kernel has to split a residue again (+12 % on the conv / dense layers)
+    @staticmethod
+    def _geom(kind, a):
+        """(zd, xd, yd, xs, ys, xf, yf, nf) of a conv / dense layer (a dense layer is the 1 x 1 convolution zd = in_dim, nf = out_dim)"""
+        return (a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"]) if kind == "conv" else (a["in_dim"], 1, 1, 1, 1, 1, 1, a["out_dim"])
+
+    def planned_form(self, kind, a, B=0):
+        """the kernel (weight form) crc_plan_mac picks for the layer launched on B images (0: by shape alone) -- the policy lives behind the C ABI, shared with the C++ host
+        classes: reductions of at least 8 steps of 32 channels with at least 32 rows per launch -> limb GEMM (CRC_NTTL), one-channel convolutions -> their own matrix-core
+        kernel (CRC_NTTL1), everything else -> the vector-ALU kernel"""
+        if kind not in ("conv", "fc"):
+            return NTT
+        wf = self.E.plan_mac(*self._geom(kind, a), B, matrix_cores=self.limb)
+        if wf == binding.NTTL1 and os.environ.get("CRC_MFMA_CONV1", "1") == "0":
+            wf = binding.NTTP
+        return wf
+
     def limb_eligible(self, kind, a):
-        """reductions of at least 8 steps of 32 channels go to the matrix-core kernel (below that its fixed costs per output tile -- ring fill, the reduction of 13
-        diagonals, layout conversions -- and the channel padding eat the gain).  ApproxPlainModel's conv2, 9 steps of 20/32 channels and 50/64 filters, runs 1.6x
-        faster there than on mac3_kernel once conv1 hands it the limb tensor (1.58 vs 2.57 ms per image at n = 8192, k = 3)"""
-        if kind == "conv":
-            zd, xf, yf = a["zd"], a["xf"], a["yf"]
-        elif kind == "fc":
-            zd, xf, yf = a["in_dim"], 1, 1
-        else:
-            return False
-        return self.limb and zd >= 16 and -(-zd // 32) * xf * yf >= int(os.environ.get("CRC_MFMA_MIN_STEPS", "8")) and self.E.limb_supported(zd, xf, yf)
+        return self.planned_form(kind, a, 0) == binding.NTTL
 
     def conv1_eligible(self, kind, a):
-        """one-channel convolutions (conv1, alone or with its pooling layer folded in) have their own matrix-core kernel (kernels_mfma1.hip)"""
-        return self.limb and kind == "conv" and a["zd"] == 1 and self.E.limb_conv1_supported(1, a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"])
+        return self.planned_form(kind, a, 0) == binding.NTTL1
+
+    def _needs_tilewise(self, kind, a, count):
+        """True when the canonical NTT-form weights and their limb copy (7/8 of the bytes, filters padded to 64) do not fit in what HBM has left, but the limb copy does"""
+        E = self.E
+        nf, zd, xf, yf = (a["nf"], a["zd"], a["xf"], a["yf"]) if kind == "conv" else (a["out_dim"], a["in_dim"], 1, 1)
+        canon, limb = count * E_k_n_8(E), E.limb_weights_bytes(nf, zd, xf, yf)
+        free = E.mem_info()[0]
+        return canon + limb + self.limb_reserve > free and limb + self.limb_reserve + (8 << 30) <= free
+
+    def _build_tilewise(self):
+        """fill the limb weights of the tile-wise layers (after fuse(): a batch-norm layer folded into such a layer is applied to every tile before it is packed)"""
+        E = self.E
+        if not self.materialize:
+            return
+        rowb = E.k * E.n * 8
+        for (kind, name, a, p, ishape, oshape) in self.plan:
+            tw = p.get("tilewise")
+            want = "folded" if p.get("bn_fold") else "plain"
+            if not tw or tw["built"] == want:
+                continue
+            # (built "plain" before fuse() -- bench.py's pass over the reference layer structure -- it is built again with the fold; the bias is still the original)
+            assert tw["built"] is False or want == "folded", "a batch-norm fold cannot be taken back"
+            nf, zd, xf, yf = (a["nf"], a["zd"], a["xf"], a["yf"]) if kind == "conv" else (a["out_dim"], a["in_dim"], 1, 1)
+            T = zd * xf * yf
+            wv = tw["wv"]                                    # [nf][T] floats
+            ft = int(max(1, min(nf, (4 << 30) // (T * rowb))))
+            wt = self.alloc(ft * T * rowb)
+            chunk = max(1, min(self._encode_chunk, ft * T))
+            stage = self.alloc(chunk * E.n * 8)
+            bn = p.get("bn_fold")
+            if bn:
+                fake = self.alloc(T * 2 * rowb); outc = self.alloc(ft * 2 * rowb)
+                E.L.crc_memset(E.c, E.p(fake), 0, T * 2 * rowb, E.stream)
+                for z in range(bn["ch"]):
+                    for t in range(bn["per_ch"]):
+                        E.L.crc_memcpy_d2d(E.c, E.p(fake) + (z * bn["per_ch"] + t) * 2 * rowb, E.p(bn["mean"]) + z * rowb, rowb, E.stream)
+                wk = self.alloc(max(E.dense_work_bytes(1, T, ft, NTT), 256))
+                bias = E.download(E.p(p["b"]), (nf, E.k, E.n))
+                qv = np.array(E.q, dtype=np.uint64).reshape(1, E.k, 1)
+            for f0 in range(0, nf, ft):
+                fn = min(ft, nf - f0)
+                vals = np.ascontiguousarray(wv[f0:f0 + fn]).reshape(-1)
+                for o in range(0, vals.size, chunk):
+                    pl, _ = E.encode(vals[o:o + chunk])
+                    E.L.crc_memcpy_h2d(E.c, E.p(stage), pl.ctypes.data, pl.nbytes, E.stream)
+                    E.plain_to_ntt(stage, len(pl), E.p(wt) + o * rowb)
+                    E.sync()
+                if bn:
+                    for f in range(fn):          # w'[f][z][tap] = w (*) s[z]
+                        E.L.crc_multiply_plain_ntt(E.c, E.p(wt) + f * T * rowb, E.p(bn["invstd"]), T, bn["per_ch"], 1, E.stream)
+                    E.dense(fake, wt, None, 1, T, fn, NTT, NTT, outc, wk)        # correction[f] = sum_t w'[f][t] (*) M[z(t)]
+                    E.sync()
+                    corr = E.download(E.p(outc), (fn, 2, E.k, E.n))[:, 0]
+                    bias[f0:f0 + fn] = (bias[f0:f0 + fn] + (qv - corr)) % qv
+                E.limb_pack_weights_tile(wt, nf, f0, fn, zd, xf, yf, p["w"])
+                E.sync()
+            if bn:
+                bias = np.ascontiguousarray(bias)
+                E.L.crc_memcpy_h2d(E.c, E.p(p["b"]), bias.ctypes.data, bias.nbytes, E.stream)
+                E.sync()
+                for b_ in (fake, outc, wk):
+                    self._free(b_)
+            self._free(wt); self._free(stage)
+            tw["built"] = want
 
     def _limb_operands(self, B=None):
         """conv / dense weights of the eligible layers -> limb form (the canonical copy is dropped: call after fuse()); a limb layer that feeds a dense
@@ -152,8 +232,9 @@ class Network:
         if self._limbed or not self.limb:
             return
         assert not self._packed
+        self._build_tilewise()
         for idx, (kind, name, a, p, ishape, oshape) in enumerate(self.plan):
-            if self.conv1_eligible(kind, a) and not p.get("streamed") and os.environ.get("CRC_MFMA_CONV1", "1") != "0":
+            if self.conv1_eligible(kind, a) and not p.get("streamed"):
                 nbytes = E.limb_conv1_weights_bytes()
                 wl = self.alloc(nbytes)
                 E.limb_conv1_pack_weights(p["w"], a["nf"], a["xf"], a["yf"], wl)
@@ -162,12 +243,10 @@ class Network:
                 self._free(p["w"])
                 p["w"], p["w_form"] = wl, binding.NTTL1
                 continue
-            if not self.limb_eligible(kind, a) or p.get("streamed"):
+            if not self.limb_eligible(kind, a) or p.get("streamed") or p.get("tilewise"):
                 continue
-            # a workgroup covers 64 rows = (image, pixel, poly): with fewer than half a tile of rows per launch (dense layers at small chunks) most of every MFMA is
-            # padding and every slot's weights are streamed for a handful of rows -- mac3_kernel is faster there (PlainModelWoPad at chunk 6: fc4 0.23 vs 1.59 ms/image)
-            # (rows = images x 2 polys x output PIXELS: one for a dense layer, whose oshape is (1, out_dim, 1))
-            if B is not None and B * 2 * (1 if kind == "fc" else int(np.prod(oshape[1:]))) < 32:
+            # (crc_plan_mac: with fewer than half a 64-row tile of rows = images x 2 polys x output pixels per launch the vector-ALU kernel is faster)
+            if B is not None and self.planned_form(kind, a, B) != binding.NTTL:
                 p["limb_skipped"] = "fewer than 32 rows per launch"
                 continue
             nf, zd, xf, yf = (a["nf"], a["zd"], a["xf"], a["yf"]) if kind == "conv" else (a["out_dim"], a["in_dim"], 1, 1)
@@ -240,7 +319,7 @@ class Network:
         while i < len(self.plan):
             kind, name, a, p, ishape, oshape = self.plan[i]
             nxt = self.plan[i + 1] if i + 1 < len(self.plan) else None
-            if kind == "conv" and not p.get("streamed") and nxt and nxt[0] in ("pool", "avgpool") and p["out_form"] == NTT and nxt[3]["form"] == NTT:
+            if kind == "conv" and not p.get("streamed") and not p.get("tilewise") and nxt and nxt[0] in ("pool", "avgpool") and p["out_form"] == NTT and nxt[3]["form"] == NTT:
                 pa = nxt[2]
                 xf2, yf2 = (pa["xf"] - 1) * a["xs"] + a["xf"], (pa["yf"] - 1) * a["ys"] + a["yf"]
                 xs2, ys2 = a["xs"] * pa["xs"], a["ys"] * pa["ys"]
@@ -248,14 +327,9 @@ class Network:
                 macs_sep = layer_macs("conv", a)
                 macs_fused = a["nf"] * xo2 * yo2 * a["zd"] * xf2 * yf2
                 same_shape = (a["nf"], xo2, yo2) == tuple(nxt[5])
-                # cost in units of one MAC term per output ciphertext: the MAC kernel pays ~24 terms of prologue/epilogue per output tile
-                #  and filters in multiples of 8; a pooling pass moves (window + 1) ciphertexts per output at HBM rate,
-                # ~10 term-times each.  Folding wins whenever it removes MACs (decimating pools) and narrowly for CrCNN's stride-1 pools.
-                fpad = -(-a["nf"] // 8) * 8
-                cost_sep = fpad * (macs_sep // a["nf"] // (a["zd"] * a["xf"] * a["yf"])) * (a["zd"] * a["xf"] * a["yf"] + 24) \
-                    + a["nf"] * xo2 * yo2 * 10 * (pa["xf"] * pa["yf"] + 1)
-                cost_fused = fpad * xo2 * yo2 * (a["zd"] * xf2 * yf2 + 24)
-                if same_shape and cost_fused < cost_sep:
+                # (crc_plan_fold_pool: the cost model behind the C ABI, shared with the C++ host classes -- folding wins whenever it removes MACs and narrowly for
+                # CrCNN's stride-1 pools)
+                if same_shape and E.plan_fold_pool(a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"], pa["xs"], pa["ys"], pa["xf"], pa["yf"]):
                     cnt = a["nf"] * a["zd"] * xf2 * yf2
                     w2 = self.alloc(cnt * E.k * E.n * 8); b2 = self.alloc(a["nf"] * E.k * E.n * 8)
                     if self.materialize:
@@ -292,7 +366,10 @@ class Network:
                 else:
                     F, per_ch, T = na["out_dim"], ishape[1] * ishape[2], na["in_dim"]
                 assert T == ch * per_ch
-                if self.materialize:
+                if np_.get("tilewise"):
+                    # the fold is applied tile by tile when the limb weights are built (_build_tilewise)
+                    np_["bn_fold"] = dict(mean=p["mean"], invstd=p["invstd"], ch=ch, per_ch=per_ch)
+                elif self.materialize:
                     # w'[f][z][tap] = w (*) s[z]: one multiply_plain_ntt per output row (plaintext index = tap / per_ch)
                     for f in range(F):
                         E.L.crc_multiply_plain_ntt(E.c, E.p(np_["w"]) + f * T * rowb, E.p(p["invstd"]), T, per_ch, 1, E.stream)
@@ -382,10 +459,15 @@ class Network:
         big = sorted(acts, reverse=True)
         need_act = (big[0] + big[1]) * B * self.ct_bytes()
         work = 0
-        for (kind, name, a, p, ishape, oshape) in self.plan:
+        B0 = B
+        for li, (kind, name, a, p, ishape, oshape) in enumerate(self.plan):
+            B = B0 * getattr(self, "G", 1) if li >= getattr(self, "split", len(self.plan)) else B0
             if p.get("streamed"):
-                g = self._stream_geometry(kind, a)
-                work = max(work, E.conv2d_forms_work_bytes(B, g["zd"], g["xd"], g["yd"], g["xs"], g["ys"], g["xf"], g["yf"], g["ft"], p["in_form"], NTT, p["out_form"]))
+                g = self._stream_geometry(kind, a, B)
+                if g["limb"]:
+                    work = max(work, E.conv2d_forms_work_bytes(B, g["zd"], g["xd"], g["yd"], g["xs"], g["ys"], g["xf"], g["yf"], g["ft"], binding.NTTL, binding.NTTL, p["out_form"]))
+                else:
+                    work = max(work, E.conv2d_forms_work_bytes(B, g["zd"], g["xd"], g["yd"], g["xs"], g["ys"], g["xf"], g["yf"], g["ft"], p["in_form"], NTT, p["out_form"]))
                 continue
             if kind == "conv":
                 work = max(work, E.conv2d_forms_work_bytes(B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], a["nf"], p["in_form"], p.get("w_form", NTT), p["out_form"]))
@@ -395,31 +477,46 @@ class Network:
                 work = max(work, E.square_relin_work_bytes(B * int(np.prod(ishape)), self.dbc))
         return need_act, work
 
-    def _stream_geometry(self, kind, a):
+    def _stream_geometry(self, kind, a, B=None):
         """a streamed layer as a convolution + the filter tile: as many filters (a multiple of 8, the MAC kernel's filter granule) as make 2-16 GiB of NTT-form
-        weights, by what HBM has left (a tile of 2 filters runs the MAC kernel at a quarter of its rate and costs 250 launches per chunk)"""
+        weights, by what HBM has left (a tile of 2 filters runs the MAC kernel at a quarter of its rate and costs 250 launches per chunk).
+        On the matrix cores (reductions the limb GEMM takes, at least 32 rows per launch): tiles of 64 filters in limb form, built from canonical sub-tiles of 8 filters
+        (crc_limb_pack_weights_tile), the layer's input converted to limb form once per launch"""
         g = dict(zd=a["zd"], xd=a["xd"], yd=a["yd"], xs=a["xs"], ys=a["ys"], xf=a["xf"], yf=a["yf"], nf=a["nf"]) if kind == "conv" else \
             dict(zd=a["in_dim"], xd=1, yd=1, xs=1, ys=1, xf=1, yf=1, nf=a["out_dim"])
         T = g["zd"] * g["xf"] * g["yf"]
         g["T"] = T
+        g["P"] = ((g["xd"] - g["xf"]) // g["xs"] + 1) * ((g["yd"] - g["yf"]) // g["ys"] + 1)
+        g["limb"] = bool(self.limb and self.limb_eligible(kind, a) and B is not None and B * 2 * g["P"] >= 32)
+        if g["limb"]:
+            g["ft"] = min(64, g["nf"]); g["sub"] = min(8, g["ft"])
+            return g
         if not hasattr(self, "_stream_tile_bytes"):
             self._stream_tile_bytes = max(2 << 30, min(16 << 30, self.E.mem_info()[0] // 8))
         ft = self._stream_tile_bytes // (T * self.E.k * self.E.n * 8)
         g["ft"] = max(1, min(g["nf"], ft // 8 * 8 if ft >= 8 else ft))
-        g["P"] = ((g["xd"] - g["xf"]) // g["xs"] + 1) * ((g["yd"] - g["yf"]) // g["ys"] + 1)
         return g
 
     def _forward_streamed(self, kind, a, p, cur, B, out):
         """lift + NTT a tile of filters, run the layer on the tile, scatter the tile's output channels into the [B][F][P] tensor"""
         E = self.E
-        g = self._stream_geometry(kind, a)
+        g = self._stream_geometry(kind, a, B)
         rowb = E.k * E.n * 8; ctb = self.ct_bytes()
-        coeff_out = p["out_form"] == COEFF
+        if g["limb"]:
+            E.limb_pack_tensor(cur, p["in_form"], B, g["zd"], g["xd"], g["yd"], self.xltile)
         for f0 in range(0, g["nf"], g["ft"]):
             ft = min(g["ft"], g["nf"] - f0)
-            E.plain_to_ntt(E.p(p["plain"]) + f0 * g["T"] * E.n * 8, ft * g["T"], self.wtile)
             bias = E.p(p["b"]) + f0 * rowb
-            E.conv2d(cur, self.wtile, bias, B, g["zd"], g["xd"], g["yd"], g["xs"], g["ys"], g["xf"], g["yf"], ft, p["in_form"], p["out_form"], self.ytile, self.work)
+            if g["limb"]:
+                for s0 in range(0, ft, g["sub"]):
+                    fs = min(g["sub"], ft - s0)
+                    E.plain_to_ntt(E.p(p["plain"]) + (f0 + s0) * g["T"] * E.n * 8, fs * g["T"], self.wtile)
+                    E.limb_pack_weights_tile(self.wtile, ft, s0, fs, g["zd"], g["xf"], g["yf"], self.wltile)
+                E.conv2d(self.xltile, self.wltile, bias, B, g["zd"], g["xd"], g["yd"], g["xs"], g["ys"], g["xf"], g["yf"], ft, binding.NTTL, p["out_form"], self.ytile, self.work,
+                         w_form=binding.NTTL)
+            else:
+                E.plain_to_ntt(E.p(p["plain"]) + f0 * g["T"] * E.n * 8, ft * g["T"], self.wtile)
+                E.conv2d(cur, self.wtile, bias, B, g["zd"], g["xd"], g["yd"], g["xs"], g["ys"], g["xf"], g["yf"], ft, p["in_form"], p["out_form"], self.ytile, self.work)
             for b in range(B):
                 E.L.crc_memcpy_d2d(E.c, E.p(out) + (b * g["nf"] + f0) * g["P"] * ctb, E.p(self.ytile) + b * ft * g["P"] * ctb, ft * g["P"] * ctb, E.stream)
 
@@ -434,18 +531,28 @@ class Network:
                 slots.append(cur)
         return slots
 
-    def prepare(self, B, limb=True):
+    def prepare(self, B, limb=True, tail_group=1):
         """allocate the two ping-pong activation buffers and the work space for chunks of B images; put the MAC operands into their kernel's operand form
         (limb=False keeps every layer on the vector-ALU kernel: needed while fuse() is still to come)"""
         if self.materialize:
+            self._build_tilewise()
             if limb:
-                self._limb_operands(B)
+                self._limb_operands(B * max(1, tail_group))
             self._pack_operands()
         acts = self.activation_cts()
         self.B = B
+        self.G = max(1, int(tail_group))
+        # two-level chunking: the layers in front of the first dense layer run on chunks of B images (their activations bound the chunk), the dense layers on
+        # G chunks at once: a dense layer streams all of its weights per launch (PlainModelWoPad's fc3 at n = 16384: 177 GiB), so its time per image falls with the
+        # number of rows = 2 x images the stream is used for -- and a 64-row matrix-core tile wants 32 images
+        self.split = next((i for i, pl_ in enumerate(self.plan) if pl_[0] == "fc"), len(self.plan)) if self.G > 1 else len(self.plan)
+        if self.split == 0 or self.split == len(self.plan):
+            self.G = 1; self.split = len(self.plan)
         self.slots = self._slots()
         size = [1, 1]
         for i, sl in enumerate(self.slots):
+            if i >= self.split:
+                continue
             size[sl] = max(size[sl], acts[i + 1] * B * self.ct_bytes())
             of = self.plan[i][3].get("out_form")
             if of == binding.NTTLC:          # a limb tensor pads the channels to 32 (7 bytes per residue instead of 8)
@@ -455,26 +562,64 @@ class Network:
                 size[sl] = max(size[sl], self.E.limb_tensor_bytes(B, acts[i + 1], 1, 1))      # ciphertexts themselves below 217 channels)
         self.buf = [self.alloc(size[0]), self.alloc(size[1])]
         self.act_bytes = size[0] + size[1]
+        self.tail_in = self.tail_buf = None
+        if self.G > 1:
+            Bt = B * self.G
+            self.tail_in_img = acts[self.split] * self.ct_bytes()                 # bytes per image of the tensor handed to the first dense layer
+            self.tail_in = self.alloc(Bt * self.tail_in_img)
+            tsize = [1, 1]
+            for i in range(self.split, len(self.plan)):
+                sl = self.slots[i]
+                tsize[sl] = max(tsize[sl], acts[i + 1] * Bt * self.ct_bytes())
+                if self.plan[i][3].get("out_form") == binding.NTTL:
+                    tsize[sl] = max(tsize[sl], self.E.limb_tensor_bytes(Bt, acts[i + 1], 1, 1))
+            self.tail_buf = [self.alloc(tsize[0]), self.alloc(tsize[1])]
+            self.act_bytes += Bt * self.tail_in_img + tsize[0] + tsize[1]
         _, work = self.scratch_bytes(B)
         self.work = self.alloc(max(work, 256))
         self.work_bytes = max(work, 256)
-        self.wtile = self.ytile = None
-        for (kind, name, a, p, ishape, oshape) in self.plan:
+        self.wtile = self.ytile = self.wltile = self.xltile = None
+        for li, (kind, name, a, p, ishape, oshape) in enumerate(self.plan):
             if p.get("streamed"):
-                g = self._stream_geometry(kind, a)
-                wt, yt = g["ft"] * g["T"] * self.E.k * self.E.n * 8, B * g["ft"] * g["P"] * self.ct_bytes()
+                Bl = B * self.G if li >= self.split else B
+                g = self._stream_geometry(kind, a, Bl)
+                wt, yt = (g["sub"] if g["limb"] else g["ft"]) * g["T"] * self.E.k * self.E.n * 8, Bl * g["ft"] * g["P"] * self.ct_bytes()
                 if self.wtile is None or self._wtile_bytes < wt:
                     self.wtile, self._wtile_bytes = self.alloc(wt), wt
                 if self.ytile is None or self._ytile_bytes < yt:
                     self.ytile, self._ytile_bytes = self.alloc(yt), yt
+                if g["limb"]:
+                    self.wltile = self.alloc(self.E.limb_weights_bytes(g["ft"], g["zd"], g["xf"], g["yf"]))
+                    self.xltile = self.alloc(self.E.limb_tensor_bytes(Bl, g["zd"], g["xd"], g["yd"]))
+                p["stream_kernel"] = "mfma_mac2w_kernel on 64-filter limb tiles" if g["limb"] else "mac3_kernel"
 
     # ---- forward over one chunk of B images; d_x: [B][1][28][28] cts in coefficient form.  Returns device ptr of the
     # [B][10] output cts (coefficient form).  `timer(i, name)` (optional) is called around every layer.
     def forward(self, d_x, B, timer=None):
+        assert self.G == 1, "prepared for two-level chunking: use forward_group"
+        return self._run(0, len(self.plan), d_x, B, self.buf, timer)
+
+    def forward_group(self, d_xs, B, timer=None):
+        """two-level chunking (prepare(..., tail_group=G)): d_xs = up to G chunks of B images each; the layers in front of the first dense layer run chunk by chunk,
+        the dense layers once on all of them.  Returns the device pointer of the [len(d_xs) * B][10] output ciphertexts."""
+        E = self.E
+        if self.G == 1:
+            assert len(d_xs) == 1
+            return self._run(0, len(self.plan), d_xs[0], B, self.buf, timer)
+        assert 1 <= len(d_xs) <= self.G
+        for c, d_x in enumerate(d_xs):
+            dst = E.p(self.tail_in) + c * B * self.tail_in_img
+            self._run(0, self.split, d_x, B, self.buf, timer, last_out=dst)
+        return self._run(self.split, len(self.plan), self.tail_in, len(d_xs) * B, self.tail_buf, timer)
+
+    def _run(self, lo, hi, d_x, B, bufs, timer=None, last_out=None):
         E = self.E
         cur = d_x
-        for i, (kind, name, a, p, ishape, oshape) in enumerate(self.plan):
-            out = self.buf[self.slots[i]]
+        for i in range(lo, hi):
+            kind, name, a, p, ishape, oshape = self.plan[i]
+            out = bufs[self.slots[i]]
+            if last_out is not None and i == hi - 1 and kind != "bn":
+                out = last_out                   # the last layer in front of the dense layers writes straight into the group's staging tensor
             if timer:
                 timer(i, name, kind, 0)
             if p.get("streamed"):
@@ -500,4 +645,6 @@ class Network:
                 cur = out
             if timer:
                 timer(i, name, kind, 1)
+        if last_out is not None and E.p(cur) != last_out:        # (an in-place last layer: copy its tensor over)
+            E.L.crc_memcpy_d2d(E.c, last_out, E.p(cur), B * int(np.prod(self.plan[hi - 1][5])) * self.ct_bytes(), E.stream)
         return cur

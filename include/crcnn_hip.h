@@ -198,6 +198,18 @@ int    crc_limb_supported(const crc_ctx *ctx, int zd, int xf, int yf);
 size_t crc_limb_tensor_bytes(const crc_ctx *ctx, int B, int zd, int xd, int yd);
 size_t crc_limb_weights_bytes(const crc_ctx *ctx, int nf, int zd, int xf, int yf);
 int    crc_limb_pack_weights(crc_ctx *ctx, const uint64_t *d_w_ntt, int nf, int zd, int xf, int yf, void *d_wl, void *stream);
+/* the same a filter tile at a time: d_w_tile_ntt holds filters f0 .. f0 + ft of the layer's nf ([ft][zd][xf][yf][k][n]); the tiles must be packed in order from
+ * f0 = 0 (that call zeroes the padding of d_wl).  A layer whose canonical NTT-form weights and limb copy do not fit in HBM together (PlainModelWoPad's fc3 at
+ * n = 16384: 202 + 177 GiB) is built this way straight from its plaintexts: encode -> crc_plain_to_ntt -> (batch-norm fold) -> tile, the canonical tile being scratch */
+int    crc_limb_pack_weights_tile(crc_ctx *ctx, const uint64_t *d_w_tile_ntt, int nf, int f0, int ft, int zd, int xf, int yf, void *d_wl, void *stream);
+/* Kernel selection -- the ONE statement of the policy, asked by every host (crcnn_amd/netrun.py and the C++ classes of crcnn_amd/host):
+ *   crc_plan_mac        the weight form (= kernel) of a conv / dense layer launched on B images (B <= 0: do not apply the rows-per-launch guard):
+ *                       CRC_NTTL1 one-channel convolution on the matrix cores, CRC_NTTL limb GEMM (>= 8 reduction steps of 32 channels and >= 32 rows = images x
+ *                       2 polys x output pixels per launch), CRC_NTTP the vector-ALU kernel on 28-bit limb pairs, CRC_NTT canonical (moduli above 55 bits).
+ *                       A dense layer is the 1 x 1 convolution zd = in_dim, nf = out_dim.  matrix_cores = 0 keeps everything on the vector ALU.
+ *   crc_plan_fold_pool  whether folding a pooling layer into the convolution in front of it (crc_conv2d_fold_pool) pays, by the cost model of DESIGN.md section 4 */
+int    crc_plan_mac(const crc_ctx *ctx, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int B, int matrix_cores, int *w_form);
+int    crc_plan_fold_pool(const crc_ctx *ctx, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int pxs, int pys, int pxf, int pyf, int *fold);
 /* an NTT-form tensor (CRC_NTT canonical or CRC_NTTP) -> limb form; crc_conv2d_forms does this itself for such inputs, the separate entry point lets a
  * caller convert once and reuse (d_xl: crc_limb_tensor_bytes) */
 int    crc_limb_pack_tensor(crc_ctx *ctx, const uint64_t *d_x, int in_form, int B, int zd, int xd, int yd, void *d_xl, void *stream);

@@ -75,6 +75,78 @@ def test_streamed_weights_match_reference(name, monkeypatch):
     assert sha(out[0]) == g["out_sha256"] and sha(out[1]) == g["out_sha256"]
 
 
+@pytest.mark.parametrize("name", ["tiny256", "wopad256"])
+def test_streamed_weights_on_the_matrix_cores(name, monkeypatch):
+    """a streamed dense / conv layer with at least 32 rows per launch builds 64-filter limb tiles from 8-filter canonical sub-tiles (crc_limb_pack_weights_tile) and runs
+    the limb GEMM on them (PlainModelWoPad's fc3 with all eight primes at n = 16384); 16 images here, every one the compiled reference's ciphertexts"""
+    monkeypatch.setenv("CRC_STREAM_SHARE", "1e-9")
+    import crcnn_amd as ca
+    from crcnn_amd.netrun import Network
+    g = load_net_golden(name)
+    O, sk, pk, evk, img, x = make_inputs(g)
+    E = ca.Engine(g["n"], g["q"], g["t"], device=0)
+    net = Network(E, g["model"], h5_path=os.path.join(GOLD, "models", g["model"] + ".h5"), resident=True, d_evk=E.upload(evk))
+    net.prepare(16)
+    kern = {pl[1]: pl[3].get("stream_kernel") for pl in net.plan if pl[3].get("streamed")}
+    assert kern["classifier.fc3"].startswith("mfma_mac2w_kernel") and kern["classifier.fc4"].startswith("mfma_mac2w_kernel"), kern
+    assert kern["pool1_features.conv1"] == "mac3_kernel"           # one channel: not a limb GEMM shape
+    out = E.download(net.forward(E.upload(np.ascontiguousarray(np.repeat(x[None], 16, axis=0))), 16), (16, 1, 10, 1, 2, E.k, E.n))
+    E.close()
+    assert all(sha(out[b]) == g["out_sha256"] for b in range(16))
+
+
+@pytest.mark.parametrize("name", ["wopad256", "approx256"])
+def test_tilewise_limb_weights_and_two_level_chunking(name, monkeypatch):
+    """PlainModelWoPad's fc3 at n = 16384, k = 4 is 202 GiB in canonical NTT form and 177 GiB in limb form: the two cannot sit in HBM together, so the limb weights are
+    built a filter tile at a time straight from the plaintexts, the batch-norm layer in front folded into every tile (netrun._build_tilewise).  And a dense layer
+    streams all of its weights per launch, so the dense layers run once per GROUP of chunks (netrun.prepare(tail_group)).  Both forced here on a small ring: 8 chunks
+    of 2 images, the dense layers once on all 16 -- every image the compiled reference's ciphertexts"""
+    import crcnn_amd as ca
+    from crcnn_amd import netrun
+    monkeypatch.setattr(netrun.Network, "_needs_tilewise", lambda self, kind, a, count: kind == "fc" and a["in_dim"] == 800)
+    g = load_net_golden(name)
+    O, sk, pk, evk, img, x = make_inputs(g)
+    E = ca.Engine(g["n"], g["q"], g["t"], device=0)
+    net = netrun.Network(E, g["model"], h5_path=os.path.join(GOLD, "models", g["model"] + ".h5"), resident=True, d_evk=E.upload(evk))
+    fc3 = [pl for pl in net.plan if pl[1].endswith("classifier.fc3")][0]
+    assert fc3[3]["tilewise"]["built"] is False and fc3[3]["w_form"] == ca.NTTL
+    net.fuse()
+    net.prepare(2, tail_group=8)
+    fc3 = [pl for pl in net.plan if pl[1].endswith("classifier.fc3")][0]
+    assert fc3[1] == "pool2_features.norm2+classifier.fc3" and fc3[3]["tilewise"]["built"] == "folded" and net.G == 8 and net.plan[net.split] is fc3
+    fc4 = net.plan[-1]
+    assert fc4[3]["w_form"] == ca.NTTL and fc3[3]["out_form"] == ca.NTTL              # 16 images x 2 polys = half a tile: fc4 on the matrix cores too, limb hand-over
+    xb = E.upload(np.ascontiguousarray(np.repeat(x[None], 2, axis=0)))
+    out = E.download(net.forward_group([xb] * 8, 2), (16, 1, 10, 1, 2, E.k, E.n))
+    assert all(sha(out[b]) == g["out_sha256"] for b in range(16))
+    # a shorter last group
+    out = E.download(net.forward_group([xb] * 3, 2), (6, 1, 10, 1, 2, E.k, E.n))
+    assert all(sha(out[b]) == g["out_sha256"] for b in range(6))
+    E.close()
+
+
+def test_kernel_choice_follows_the_rows_per_launch():
+    """PlainModelWoPad at a chunk of 6 images: conv2 (6 x 2 x 25 rows) is a limb GEMM, the dense layers (12 rows = a fifth of a 64-row tile: every slot's weights would be
+    streamed for a handful of rows) stay on the vector-ALU kernel -- the guard counts PIXELS per image, one for a dense layer; at 16 images both dense layers move over"""
+    import crcnn_amd as ca
+    from crcnn_amd.netrun import Network
+    g = load_net_golden("wopad256")
+    O, sk, pk, evk, img, x = make_inputs(g)
+    for B, dense_limb in ((6, False), (16, True)):
+        E = ca.Engine(g["n"], g["q"], g["t"], device=0)
+        net = Network(E, g["model"], h5_path=os.path.join(GOLD, "models", g["model"] + ".h5"), resident=True, d_evk=E.upload(evk))
+        net.fuse(); net.prepare(B)
+        forms = {pl[1].split("+")[-1]: pl[3] for pl in net.plan if pl[0] in ("conv", "fc")}
+        assert forms["pool2_features.conv2"].get("w_form") == ca.NTTL
+        for nm in ("classifier.fc3", "classifier.fc4"):
+            assert (forms[nm].get("w_form") == ca.NTTL) == dense_limb, (B, nm, forms[nm].get("w_form"))
+            if not dense_limb:
+                assert forms[nm]["limb_skipped"] == "fewer than 32 rows per launch"
+        out = E.download(net.forward(E.upload(np.ascontiguousarray(np.repeat(x[None], B, axis=0))), B), (B, 1, 10, 1, 2, E.k, E.n))
+        assert all(sha(out[b]) == g["out_sha256"] for b in range(B))
+        E.close()
+
+
 def test_matrix_core_dense_layers_match_reference():
     """with at least half a 64-row tile per launch (16 images x 2 polys) the dense layers run on the matrix-core kernel too, and conv2 hands its tensor to fc3 in limb
     form (CRC_NTTL): every image of the batch must still come out as the compiled reference's ciphertexts"""
