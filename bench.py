@@ -352,6 +352,10 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
     keep = []
 
     def alloc(nbytes):
+        if os.environ.get("CRC_BENCH_ALLOC_LOG") and nbytes > (1 << 30):          # (debugging aid: where the HBM goes)
+            import traceback
+            fr = traceback.extract_stack(limit=3)[0]
+            sys.stderr.write(f"alloc {nbytes / 2**30:8.2f} GiB  {os.path.basename(fr.filename)}:{fr.lineno} {fr.name}   (torch allocated {torch.cuda.memory_allocated(dev) / 2**30:.1f} GiB)\n")
         t = torch.empty((int(nbytes) + 7) // 8, dtype=torch.int64, device=dev); keep.append(t); return t
 
     model = cfg["model"]

@@ -112,6 +112,7 @@ def load():
     L.crc_limb_weights_bytes.restype = SZ; L.crc_limb_weights_bytes.argtypes = [VP, CI, CI, CI, CI]
     L.crc_limb_pack_weights.argtypes = [VP, VP, CI, CI, CI, CI, VP, VP]
     L.crc_limb_pack_weights_tile.argtypes = [VP, VP, CI, CI, CI, CI, CI, CI, VP, VP]
+    L.crc_limb_pack_tensor_at.argtypes = [VP, VP, CI, CI, CI, CI, CI, VP, CI, CI, VP]
     L.crc_plan_mac.argtypes = [VP] + [CI] * 10 + [ctypes.POINTER(CI)]
     L.crc_plan_fold_pool.argtypes = [VP] + [CI] * 12 + [ctypes.POINTER(CI)]
     L.crc_limb_pack_tensor.argtypes = [VP, VP, CI, CI, CI, CI, CI, VP, VP]
@@ -421,6 +422,9 @@ class Engine:
 
     def limb_pack_tensor(self, d_x, in_form, B, zd, xd, yd, d_xl):
         _chk(self.L.crc_limb_pack_tensor(self.c, self.p(d_x), in_form, B, zd, xd, yd, self.p(d_xl), self.stream), "crc_limb_pack_tensor")
+
+    def limb_pack_tensor_at(self, d_x, in_form, B, zd, xd, yd, d_xl, Btot, b0):
+        _chk(self.L.crc_limb_pack_tensor_at(self.c, self.p(d_x), in_form, B, zd, xd, yd, self.p(d_xl), Btot, b0, self.stream), "crc_limb_pack_tensor_at")
 
     # ---- one-channel convolutions on the matrix cores (weight form CRC_NTTL1)
     def limb_conv1_supported(self, zd, xd, yd, xs, ys, xf, yf, nf):

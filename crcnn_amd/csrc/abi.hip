@@ -117,6 +117,12 @@ extern "C" int crc_limb_pack_tensor(crc_ctx *c, const uint64_t *d_x, int in_form
     if (!crc_limb_supported(c, zd, 1, 1)) return CRC_ERR_UNSUPPORTED;
     return k_limb_pack_tensor(c, d_x, (signed char *)d_xl, B, zd, xd * yd, in_form == CRC_NTTP, S(stream));
 }
+extern "C" int crc_limb_pack_tensor_at(crc_ctx *c, const uint64_t *d_x, int in_form, int B, int zd, int xd, int yd, void *d_xl, int Btot, int b0, void *stream)
+{
+    CHECK_CTX(c); if (!d_x || !d_xl || B < 0 || zd < 1 || xd < 1 || yd < 1 || Btot < B || b0 < 0 || b0 + B > Btot || (in_form != CRC_NTT && in_form != CRC_NTTP)) return CRC_ERR_INVALID_ARGUMENT;
+    if (!crc_limb_supported(c, zd, 1, 1)) return CRC_ERR_UNSUPPORTED;
+    return k_limb_pack_tensor(c, d_x, (signed char *)d_xl, B, zd, xd * yd, in_form == CRC_NTTP, S(stream), Btot, b0);
+}
 // one-channel convolutions (CRC_NTTL1, kernels_mfma1.hip)
 extern "C" int crc_limb_conv1_supported(const crc_ctx *c, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf)
 {
@@ -343,7 +349,9 @@ extern "C" int crc_plan_mac(const crc_ctx *c, int zd, int xd, int yd, int xs, in
     // handful of rows (PlainModelWoPad at 6 images per launch: fc4 0.23 ms per image on mac3_kernel against 1.59)
     const int min_steps = c->tune.mfma_min_steps > 0 ? c->tune.mfma_min_steps : 8;
     const long long P = (long long)((xd - xf) / xs + 1) * ((yd - yf) / ys + 1);
-    if (zd >= 16 && (long long)((zd + 31) / 32) * xf * yf >= min_steps && crc_limb_supported(c, zd, xf, yf) && (B <= 0 || (long long)B * 2 * P >= 32)) *w_form = CRC_NTTL;
+    // ... and with at least 24 filters: the limb form pads the filters to 64 (a 10-filter layer -- CrCNN's fc4 -- would spend 6x its canonical bytes and 5/6 of its
+    // MFMAs on zeros: 0.16 against 0.11 ms per image on the vector-ALU kernel for PlainModelWoPad's fc4)
+    if (zd >= 16 && nf >= 24 && (long long)((zd + 31) / 32) * xf * yf >= min_steps && crc_limb_supported(c, zd, xf, yf) && (B <= 0 || (long long)B * 2 * P >= 32)) *w_form = CRC_NTTL;
     return CRC_OK;
 }
 // should a (sum / average) pooling layer be folded into the convolution in front of it (crc_conv2d_fold_pool: exact)?  Cost in units of one multiply-accumulate

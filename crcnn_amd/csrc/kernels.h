@@ -44,7 +44,7 @@ bool   k_limb_supported(const crc_ctx *c, int T);
 size_t k_limb_tensor_bytes(const crc_ctx *c, int B, int zd, int npos);
 size_t k_limb_weights_bytes(const crc_ctx *c, int nf, int zd, int taps);
 size_t k_limb_result_words(const crc_ctx *c, int B, int nf, int P);
-int k_limb_pack_tensor(crc_ctx *c, const u64 *x, signed char *xl, int B, int zd, int npos, bool packed, hipStream_t st);
+int k_limb_pack_tensor(crc_ctx *c, const u64 *x, signed char *xl, int B, int zd, int npos, bool packed, hipStream_t st, int Btot = 0, int b0 = 0);
 int k_limb_pack_weights(crc_ctx *c, const u64 *w, signed char *wl, int nf, int zd, int taps, hipStream_t st, int f0 = 0, int ft = -1);
 int k_limb_result_to_rows(crc_ctx *c, const u64 *ys, u64 *y, size_t rows, bool pack_out, hipStream_t st);
 int k_limb_result_to_limb(crc_ctx *c, const u64 *ys, signed char *xl, int B, int zd, hipStream_t st);

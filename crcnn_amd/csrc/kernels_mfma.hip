@@ -214,6 +214,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int mt = a.mfast ? tile % a.mtiles : tile / ntiles2, nt = a.mfast ? tile / a.mtiles : tile % ntiles2;
     const int i = slot / a.n, s = slot % a.n;
     const int m0 = mt * 64, f0 = nt * 32;
+    if (f0 >= a.F) return;                                        // a 32-filter tile that is all padding (filters are padded to 64): nothing to compute or store
     const ModParams m = a.mods[i];
     const u64 qinv = a.qinv[i];
     const i8 *xs = a.xl + (size_t)slot * a.B * a.img_bytes;
@@ -350,7 +351,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 // position, poly, 32-channel block); lanes run over 64 consecutive slots, so every read is a coalesced 512-B row segment; every lane writes 7 x 32 B into its
 // own slot block (1.4x write amplification at the memory side, profiles/r02_pmc_traffic.json).  Tried and not kept: a variant that transposes through LDS and
 // writes whole 128-B lines per (slot, plane) -- 48.1 vs 46.4 ms for the conv2+pool2 layer call; 4 or 8 adjacent pieces per thread -- 3-7 % slower.
-__global__ void __launch_bounds__(64) limb_pack_tensor_kernel(const u64 *x, i8 *xl, const ModParams *mods, int n, int k, int B, int zd, int zdp, int npos, int packed, int group)
+// (Btot, b0: the B images are images b0 .. b0 + B of a tensor of Btot -- a group of chunks assembling one dense layer's input; Btot = B, b0 = 0 otherwise)
+__global__ void __launch_bounds__(64) limb_pack_tensor_kernel(const u64 *x, i8 *xl, const ModParams *mods, int n, int k, int B, int zd, int zdp, int npos, int packed, int group,
+                                                              int Btot, int b0)
 {
     const int sblocks = n / 64;
     const int sb = blockIdx.x % (sblocks * k), i = sb / sblocks, s = (sb % sblocks) * 64 + threadIdx.x;
@@ -379,9 +382,9 @@ __global__ void __launch_bounds__(64) limb_pack_tensor_kernel(const u64 *x, i8 *
             }
         }
         // one position (a dense layer's input): K-blocked [plane][channel block][row = image * 2 + poly][32]
-        i8 *dst = npos == 1 ? xl + ((size_t)i * n + s) * ((size_t)NPL * 2 * B * zdp) + ((size_t)zb * (2 * B) + b * 2 + c) * 32
-                            : xl + (((size_t)i * n + s) * B + b) * ((size_t)NPL * npos * 2 * zdp) + ((size_t)pos * 2 + c) * zdp + zb * 32;
-        const size_t plane_stride = npos == 1 ? (size_t)zblks * (2 * B) * 32 : (size_t)npos * 2 * zdp;
+        i8 *dst = npos == 1 ? xl + ((size_t)i * n + s) * ((size_t)NPL * 2 * Btot * zdp) + ((size_t)zb * (2 * Btot) + (b0 + b) * 2 + c) * 32
+                            : xl + (((size_t)i * n + s) * Btot + b0 + b) * ((size_t)NPL * npos * 2 * zdp) + ((size_t)pos * 2 + c) * zdp + zb * 32;
+        const size_t plane_stride = npos == 1 ? (size_t)zblks * (2 * Btot) * 32 : (size_t)npos * 2 * zdp;
 #pragma unroll
         for (int l = 0; l < NPL; l++) {
             uint4 *o = reinterpret_cast<uint4 *>(dst + (size_t)l * plane_stride);
@@ -488,15 +491,17 @@ size_t k_limb_tensor_bytes(const crc_ctx *c, int B, int zd, int npos) { return (
 size_t k_limb_weights_bytes(const crc_ctx *c, int nf, int zd, int taps) { return (size_t)c->n * c->k * round_up(taps * (round_up(zd, 32) / 32), 2) * NPL * round_up(nf, 64) * 32; }      // (an odd number of reduction steps gets a zero step)
 size_t k_limb_result_words(const crc_ctx *c, int B, int nf, int P) { return (size_t)c->n * c->k * B * nf * P * 2; }
 
-int k_limb_pack_tensor(crc_ctx *c, const u64 *x, i8 *xl, int B, int zd, int npos, bool packed, hipStream_t st)
+int k_limb_pack_tensor(crc_ctx *c, const u64 *x, i8 *xl, int B, int zd, int npos, bool packed, hipStream_t st, int Btot, int b0)
 {
+    if (Btot <= 0) { Btot = B; b0 = 0; }
+    if (b0 < 0 || b0 + B > Btot) return CRC_ERR_INVALID_ARGUMENT;
     const int zdp = round_up(zd, 32);
     const int group = c->tune.limb_pack_group;     // (4 and 8 adjacent pieces per thread measured 3-7 % slower)
     const size_t items = (size_t)B * npos * 2 * (zdp / 32);
     const size_t blocks = (size_t)(c->n / 64) * c->k * ((items + group - 1) / group);
     if (blocks == 0) return CRC_OK;
     if (blocks > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(limb_pack_tensor_kernel, dim3((unsigned)blocks), dim3(64), 0, st, x, xl, c->d_mods, c->n, c->k, B, zd, zdp, npos, packed ? 1 : 0, group);
+    hipLaunchKernelGGL(limb_pack_tensor_kernel, dim3((unsigned)blocks), dim3(64), 0, st, x, xl, c->d_mods, c->n, c->k, B, zd, zdp, npos, packed ? 1 : 0, group, Btot, b0);
     HIPCHK(hipGetLastError());
     return CRC_OK;
 }

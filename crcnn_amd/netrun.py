@@ -465,7 +465,8 @@ class Network:
             if p.get("streamed"):
                 g = self._stream_geometry(kind, a, B)
                 if g["limb"]:
-                    work = max(work, E.conv2d_forms_work_bytes(B, g["zd"], g["xd"], g["yd"], g["xs"], g["ys"], g["xf"], g["yf"], g["ft"], binding.NTTL, binding.NTTL, p["out_form"]))
+                    fin = binding.NTTL if p["in_form"] in (NTT, binding.NTTP, binding.NTTL) else p["in_form"]
+                    work = max(work, E.conv2d_forms_work_bytes(B, g["zd"], g["xd"], g["yd"], g["xs"], g["ys"], g["xf"], g["yf"], g["ft"], fin, binding.NTTL, p["out_form"]))
                 else:
                     work = max(work, E.conv2d_forms_work_bytes(B, g["zd"], g["xd"], g["yd"], g["xs"], g["ys"], g["xf"], g["yf"], g["ft"], p["in_form"], NTT, p["out_form"]))
                 continue
@@ -502,8 +503,12 @@ class Network:
         E = self.E
         g = self._stream_geometry(kind, a, B)
         rowb = E.k * E.n * 8; ctb = self.ct_bytes()
-        if g["limb"]:
+        # the layer's input goes to limb form once for all filter tiles (a coefficient-form input -- the reference's layer contract -- is left to every tile's call)
+        pre = g["limb"] and p["in_form"] in (NTT, binding.NTTP)
+        if pre:
             E.limb_pack_tensor(cur, p["in_form"], B, g["zd"], g["xd"], g["yd"], self.xltile)
+        elif g["limb"] and p["in_form"] == binding.NTTL:          # (a group's limb tensor assembled by forward_group)
+            pre = True; xl_in = cur
         for f0 in range(0, g["nf"], g["ft"]):
             ft = min(g["ft"], g["nf"] - f0)
             bias = E.p(p["b"]) + f0 * rowb
@@ -512,8 +517,8 @@ class Network:
                     fs = min(g["sub"], ft - s0)
                     E.plain_to_ntt(E.p(p["plain"]) + (f0 + s0) * g["T"] * E.n * 8, fs * g["T"], self.wtile)
                     E.limb_pack_weights_tile(self.wtile, ft, s0, fs, g["zd"], g["xf"], g["yf"], self.wltile)
-                E.conv2d(self.xltile, self.wltile, bias, B, g["zd"], g["xd"], g["yd"], g["xs"], g["ys"], g["xf"], g["yf"], ft, binding.NTTL, p["out_form"], self.ytile, self.work,
-                         w_form=binding.NTTL)
+                E.conv2d((xl_in if p["in_form"] == binding.NTTL else self.xltile) if pre else cur, self.wltile, bias, B, g["zd"], g["xd"], g["yd"], g["xs"], g["ys"], g["xf"], g["yf"], ft, binding.NTTL if pre else p["in_form"],
+                         p["out_form"], self.ytile, self.work, w_form=binding.NTTL)
             else:
                 E.plain_to_ntt(E.p(p["plain"]) + f0 * g["T"] * E.n * 8, ft * g["T"], self.wtile)
                 E.conv2d(cur, self.wtile, bias, B, g["zd"], g["xd"], g["yd"], g["xs"], g["ys"], g["xf"], g["yf"], ft, p["in_form"], p["out_form"], self.ytile, self.work)
@@ -534,6 +539,9 @@ class Network:
     def prepare(self, B, limb=True, tail_group=1):
         """allocate the two ping-pong activation buffers and the work space for chunks of B images; put the MAC operands into their kernel's operand form
         (limb=False keeps every layer on the vector-ALU kernel: needed while fuse() is still to come)"""
+        for pl_ in self.plan:                               # (a previous prepare() with two-level chunking re-typed the first dense layer's input)
+            if "in_form_chunked" in pl_[3]:
+                pl_[3]["in_form"] = pl_[3].pop("in_form_chunked")
         if self.materialize:
             self._build_tilewise()
             if limb:
@@ -563,10 +571,20 @@ class Network:
         self.buf = [self.alloc(size[0]), self.alloc(size[1])]
         self.act_bytes = size[0] + size[1]
         self.tail_in = self.tail_buf = None
+        self.tail_limb = None
         if self.G > 1:
             Bt = B * self.G
             self.tail_in_img = acts[self.split] * self.ct_bytes()                 # bytes per image of the tensor handed to the first dense layer
-            self.tail_in = self.alloc(Bt * self.tail_in_img)
+            tk, _, ta, t0 = self.plan[self.split][:4]
+            on_cores = t0.get("w_form") == binding.NTTL or (t0.get("streamed") and self._stream_geometry(tk, ta, Bt)["limb"])
+            if on_cores and t0["in_form"] in (NTT, binding.NTTP):
+                # the first dense layer runs on the matrix cores: every chunk's tensor goes straight into ITS limb tensor (crc_limb_pack_tensor_at), 7/8 of the
+                # ciphertext bytes and no second conversion buffer inside the layer call (17.6 GiB for PlainModelWoPad's fc3 at 24 images)
+                self.tail_limb = dict(form=t0["in_form"], ch=acts[self.split])
+                t0["in_form_chunked"] = t0["in_form"]; t0["in_form"] = binding.NTTL
+                self.tail_in = self.alloc(self.E.limb_tensor_bytes(Bt, acts[self.split], 1, 1))
+            else:
+                self.tail_in = self.alloc(Bt * self.tail_in_img)
             tsize = [1, 1]
             for i in range(self.split, len(self.plan)):
                 sl = self.slots[i]
@@ -588,9 +606,12 @@ class Network:
                     self.wtile, self._wtile_bytes = self.alloc(wt), wt
                 if self.ytile is None or self._ytile_bytes < yt:
                     self.ytile, self._ytile_bytes = self.alloc(yt), yt
-                if g["limb"]:
-                    self.wltile = self.alloc(self.E.limb_weights_bytes(g["ft"], g["zd"], g["xf"], g["yf"]))
-                    self.xltile = self.alloc(self.E.limb_tensor_bytes(Bl, g["zd"], g["xd"], g["yd"]))
+                if g["limb"]:                 # (one set of tile buffers serves every streamed layer: the largest of each)
+                    wl, xl = self.E.limb_weights_bytes(g["ft"], g["zd"], g["xf"], g["yf"]), self.E.limb_tensor_bytes(Bl, g["zd"], g["xd"], g["yd"])
+                    if self.wltile is None or self._wltile_bytes < wl:
+                        self.wltile, self._wltile_bytes = self.alloc(wl), wl
+                    if self.xltile is None or self._xltile_bytes < xl:
+                        self.xltile, self._xltile_bytes = self.alloc(xl), xl
                 p["stream_kernel"] = "mfma_mac2w_kernel on 64-filter limb tiles" if g["limb"] else "mac3_kernel"
 
     # ---- forward over one chunk of B images; d_x: [B][1][28][28] cts in coefficient form.  Returns device ptr of the
@@ -607,10 +628,14 @@ class Network:
             assert len(d_xs) == 1
             return self._run(0, len(self.plan), d_xs[0], B, self.buf, timer)
         assert 1 <= len(d_xs) <= self.G
+        Bt = len(d_xs) * B
         for c, d_x in enumerate(d_xs):
-            dst = E.p(self.tail_in) + c * B * self.tail_in_img
-            self._run(0, self.split, d_x, B, self.buf, timer, last_out=dst)
-        return self._run(self.split, len(self.plan), self.tail_in, len(d_xs) * B, self.tail_buf, timer)
+            if self.tail_limb:
+                cur = self._run(0, self.split, d_x, B, self.buf, timer)
+                E.limb_pack_tensor_at(cur, self.tail_limb["form"], B, self.tail_limb["ch"], 1, 1, self.tail_in, Bt, c * B)
+            else:
+                self._run(0, self.split, d_x, B, self.buf, timer, last_out=E.p(self.tail_in) + c * B * self.tail_in_img)
+        return self._run(self.split, len(self.plan), self.tail_in, Bt, self.tail_buf, timer)
 
     def _run(self, lo, hi, d_x, B, bufs, timer=None, last_out=None):
         E = self.E

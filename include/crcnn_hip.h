@@ -213,6 +213,9 @@ int    crc_plan_fold_pool(const crc_ctx *ctx, int zd, int xd, int yd, int xs, in
 /* an NTT-form tensor (CRC_NTT canonical or CRC_NTTP) -> limb form; crc_conv2d_forms does this itself for such inputs, the separate entry point lets a
  * caller convert once and reuse (d_xl: crc_limb_tensor_bytes) */
 int    crc_limb_pack_tensor(crc_ctx *ctx, const uint64_t *d_x, int in_form, int B, int zd, int xd, int yd, void *d_xl, void *stream);
+/* the same for images b0 .. b0 + B of a limb tensor of Btot images (d_xl: crc_limb_tensor_bytes(Btot, ...)): several chunks assemble the input of one dense-layer launch
+ * (a dense layer streams all of its weights per launch, so it is run on as many images as fit: netrun's / Network's two-level chunking) */
+int    crc_limb_pack_tensor_at(crc_ctx *ctx, const uint64_t *d_x, int in_form, int B, int zd, int xd, int yd, void *d_xl, int Btot, int b0, void *stream);
 /* one-channel convolutions on the matrix cores (w_form = CRC_NTTL1): eligibility of a shape, size of the weights, conversion from CRC_NTT weights */
 int    crc_limb_conv1_supported(const crc_ctx *ctx, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf);
 size_t crc_limb_conv1_weights_bytes(const crc_ctx *ctx);

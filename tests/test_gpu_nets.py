@@ -88,8 +88,8 @@ def test_streamed_weights_on_the_matrix_cores(name, monkeypatch):
     net = Network(E, g["model"], h5_path=os.path.join(GOLD, "models", g["model"] + ".h5"), resident=True, d_evk=E.upload(evk))
     net.prepare(16)
     kern = {pl[1]: pl[3].get("stream_kernel") for pl in net.plan if pl[3].get("streamed")}
-    assert kern["classifier.fc3"].startswith("mfma_mac2w_kernel") and kern["classifier.fc4"].startswith("mfma_mac2w_kernel"), kern
-    assert kern["pool1_features.conv1"] == "mac3_kernel"           # one channel: not a limb GEMM shape
+    assert kern["classifier.fc3"].startswith("mfma_mac2w_kernel") and kern["pool2_features.conv2"].startswith("mfma_mac2w_kernel"), kern
+    assert kern["pool1_features.conv1"] == "mac3_kernel" and kern["classifier.fc4"] == "mac3_kernel"      # one channel / ten filters: not limb GEMM shapes (crc_plan_mac)
     out = E.download(net.forward(E.upload(np.ascontiguousarray(np.repeat(x[None], 16, axis=0))), 16), (16, 1, 10, 1, 2, E.k, E.n))
     E.close()
     assert all(sha(out[b]) == g["out_sha256"] for b in range(16))
@@ -115,7 +115,7 @@ def test_tilewise_limb_weights_and_two_level_chunking(name, monkeypatch):
     fc3 = [pl for pl in net.plan if pl[1].endswith("classifier.fc3")][0]
     assert fc3[1] == "pool2_features.norm2+classifier.fc3" and fc3[3]["tilewise"]["built"] == "folded" and net.G == 8 and net.plan[net.split] is fc3
     fc4 = net.plan[-1]
-    assert fc4[3]["w_form"] == ca.NTTL and fc3[3]["out_form"] == ca.NTTL              # 16 images x 2 polys = half a tile: fc4 on the matrix cores too, limb hand-over
+    assert fc4[3]["w_form"] == ca.NTTP and fc3[3]["in_form"] == ca.NTTL              # ten filters: fc4 stays on the vector-ALU kernel; fc3's input is the group's limb tensor
     xb = E.upload(np.ascontiguousarray(np.repeat(x[None], 2, axis=0)))
     out = E.download(net.forward_group([xb] * 8, 2), (16, 1, 10, 1, 2, E.k, E.n))
     assert all(sha(out[b]) == g["out_sha256"] for b in range(16))
@@ -126,8 +126,9 @@ def test_tilewise_limb_weights_and_two_level_chunking(name, monkeypatch):
 
 
 def test_kernel_choice_follows_the_rows_per_launch():
-    """PlainModelWoPad at a chunk of 6 images: conv2 (6 x 2 x 25 rows) is a limb GEMM, the dense layers (12 rows = a fifth of a 64-row tile: every slot's weights would be
-    streamed for a handful of rows) stay on the vector-ALU kernel -- the guard counts PIXELS per image, one for a dense layer; at 16 images both dense layers move over"""
+    """PlainModelWoPad at a chunk of 6 images: conv2 (6 x 2 x 25 rows) is a limb GEMM, fc3 (12 rows = a fifth of a 64-row tile: every slot's weights would be
+    streamed for a handful of rows) stays on the vector-ALU kernel -- the guard counts PIXELS per image, one for a dense layer; at 16 images fc3 moves over; fc4's ten
+    filters never do"""
     import crcnn_amd as ca
     from crcnn_amd.netrun import Network
     g = load_net_golden("wopad256")
@@ -138,10 +139,10 @@ def test_kernel_choice_follows_the_rows_per_launch():
         net.fuse(); net.prepare(B)
         forms = {pl[1].split("+")[-1]: pl[3] for pl in net.plan if pl[0] in ("conv", "fc")}
         assert forms["pool2_features.conv2"].get("w_form") == ca.NTTL
-        for nm in ("classifier.fc3", "classifier.fc4"):
-            assert (forms[nm].get("w_form") == ca.NTTL) == dense_limb, (B, nm, forms[nm].get("w_form"))
-            if not dense_limb:
-                assert forms[nm]["limb_skipped"] == "fewer than 32 rows per launch"
+        assert (forms["classifier.fc3"].get("w_form") == ca.NTTL) == dense_limb, (B, forms["classifier.fc3"].get("w_form"))
+        if not dense_limb:
+            assert forms["classifier.fc3"]["limb_skipped"] == "fewer than 32 rows per launch"
+        assert forms["classifier.fc4"].get("w_form") == ca.NTTP and "limb_skipped" not in forms["classifier.fc4"]       # ten filters: never a limb GEMM (crc_plan_mac)
         out = E.download(net.forward(E.upload(np.ascontiguousarray(np.repeat(x[None], B, axis=0))), B), (B, 1, 10, 1, 2, E.k, E.n))
         assert all(sha(out[b]) == g["out_sha256"] for b in range(B))
         E.close()
@@ -158,7 +159,7 @@ def test_matrix_core_dense_layers_match_reference():
     net = Network(E, g["model"], h5_path=os.path.join(GOLD, "models", g["model"] + ".h5"), resident=True)
     net.fuse(); net.prepare(16)
     forms = {pl[1]: pl[3].get("w_form") for pl in net.plan if pl[0] in ("conv", "fc")}
-    assert forms["classifier.fc3"] == ca.NTTL and forms["classifier.fc4"] == ca.NTTL and [pl[3]["in_form"] for pl in net.plan if pl[1] == "classifier.fc3"] == [ca.NTTL]
+    assert forms["classifier.fc3"] == ca.NTTL and forms["classifier.fc4"] == ca.NTTP and [pl[3]["in_form"] for pl in net.plan if pl[1] == "classifier.fc3"] == [ca.NTTL]
     d_x = E.upload(np.ascontiguousarray(np.repeat(x[None], 16, axis=0)))
     out = E.download(net.forward(d_x, 16), (16, 1, 10, 1, 2, E.k, E.n))
     E.close()
