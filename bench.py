@@ -40,7 +40,7 @@ CONFIGS = {
     "approx8192k4": dict(model="ApproxPlainModel", n=8192, k=4, t=1 << 42, batch=1024, chunk=16),
     # every prime of coeff_modulus_128(16384), the coefficient modulus CrCNN's own setParameters(16384, t) picks: 424 GB of NTT-form weights -- fc3 keeps
     # coefficient-form plaintexts in HBM and is lifted + transformed a filter tile at a time inside every forward (netrun: streamed layers)
-    "wopad16384k8": dict(model="PlainModelWoPad", n=16384, k=8, t=1 << 44, batch=96, chunk=8, tail=4),
+    "wopad16384k8": dict(model="PlainModelWoPad", n=16384, k=8, t=1 << 44, batch=96, chunk=4, tail=8),
     # small ring for the tests of this script and single-GPU rehearsals of the multi-rank path (golden: net_tiny1024_eng.json)
     "tiny1024": dict(model="PlainModelTiny", n=1024, k=2, q=[0x7fffffff380001, 0x3fffffff000001], t=1 << 32, batch=48, chunk=24),
 }
@@ -634,7 +634,8 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
             "ms_per_layer": ms_per_layer,
             "mac_kernel_per_layer": {pl[1]: ("mfma_mac2w_kernel (int8 limb GEMM, CRC_NTTL)" if pl[3].get("w_form") == ca.NTTL else
                                              "mfma_conv1_kernel (one-channel convolution on the matrix cores, CRC_NTTL1)" if pl[3].get("w_form") == ca.NTTL1 else
-                                             "mac3_kernel (v_mad_u64_u32, CRC_NTTP)" + (", streamed weights" if pl[3].get("streamed") else "") +
+                                             (pl[3]["stream_kernel"] + ", streamed weights (coefficient-form plaintexts lifted + transformed a filter tile at a time)" if pl[3].get("streamed") else
+                                              "mac3_kernel (v_mad_u64_u32, CRC_NTTP)") +
                                              (f" [{pl[3]['limb_skipped']}]" if pl[3].get("limb_skipped") else "")) for pl in net.plan if pl[0] in ("conv", "fc")},
             "reference_layer_structure": unfused, "roofline": roofline, "cpu_baseline": cpu,
             "check": {"tiled_outputs_identical": bool(ok_tile), "predictions_match_plain_model": f"{preds_ok}/{D}", "max_logit_abs_err": round(max_err, 6),

@@ -374,12 +374,13 @@ extern "C" int crc_plan_fold_pool(const crc_ctx *c, int zd, int xd, int yd, int 
 }
 
 // ---- square + relinearize -----------------------------------------------------------------------------------------
-static const size_t kSquareChunk = 512;           // ciphertexts per internal pass (bounds the scratch footprint)
+// ciphertexts per internal pass (bounds the scratch footprint: ~10 GB at every ring size -- 512 up to n k = 65536, 256 at n = 16384 with all eight primes)
+static size_t square_chunk(const crc_ctx *c) { const size_t nk = (size_t)c->n * c->k; return nk <= 65536 ? 512 : nk <= 131072 ? 256 : 128; }
 
 extern "C" size_t crc_square_relin_work_bytes(const crc_ctx *c, size_t count, int dbc)
 {
     if (!c) return 0;
-    const size_t ch = count < kSquareChunk ? count : kSquareChunk;
+    const size_t kSquareChunk = square_chunk(c); const size_t ch = count < kSquareChunk ? count : kSquareChunk;
     const size_t sq = k_square_work_words(c, ch), rl = k_relin_work_words(c, ch, dbc);
     // [packed keys][size-3 intermediates of one pass][scratch of the square, then of the relinearisation]
     return 8 * (k_relin_keys_words(c, dbc) + (sq > rl ? sq : rl) + ch * crc_ct_words(c, 3)) + 256;
@@ -402,6 +403,7 @@ extern "C" int crc_square(crc_ctx *c, const uint64_t *d_x, size_t count, uint64_
 {
     CHECK_CTX(c); if (!d_x || !d_y3 || !d_work) return CRC_ERR_INVALID_ARGUMENT;
     u64 *w = (u64 *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
+    const size_t kSquareChunk = square_chunk(c);
     for (size_t o = 0; o < count; o += kSquareChunk) {
         const size_t ch = count - o < kSquareChunk ? count - o : kSquareChunk;
         RUN(k_square(c, d_x + o * crc_ct_words(c, 2), ch, d_y3 + o * crc_ct_words(c, 3), w, S(stream)));
@@ -412,6 +414,7 @@ extern "C" int crc_relinearize(crc_ctx *c, const uint64_t *d_x3, size_t count, c
 {
     CHECK_CTX(c); if (!d_x3 || !d_y || !d_evk || !d_work) return CRC_ERR_INVALID_ARGUMENT;
     u64 *w = (u64 *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
+    const size_t kSquareChunk = square_chunk(c);
     for (size_t o = 0; o < count; o += kSquareChunk) {
         const size_t ch = count - o < kSquareChunk ? count - o : kSquareChunk;
         RUN(k_relinearize(c, d_x3 + o * crc_ct_words(c, 3), ch, d_evk, dbc, d_y + o * crc_ct_words(c, 2), w + k_relin_keys_words(c, dbc), w, S(stream), false, false, o != 0));
@@ -423,6 +426,7 @@ extern "C" int crc_square_relin_forms(crc_ctx *c, const uint64_t *d_x, int in_fo
 {
     CHECK_CTX(c); if (!d_x || !d_y || !d_evk || !d_work || !form_ok(in_form) || !form_ok(out_form)) return CRC_ERR_INVALID_ARGUMENT;
     u64 *w = (u64 *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
+    const size_t kSquareChunk = square_chunk(c);
     const size_t ch0 = count < kSquareChunk ? count : kSquareChunk;
     for (size_t o = 0; o < count; o += kSquareChunk) {
         const size_t ch = count - o < kSquareChunk ? count - o : kSquareChunk;

@@ -501,7 +501,8 @@ class Network:
     def _forward_streamed(self, kind, a, p, cur, B, out):
         """lift + NTT a tile of filters, run the layer on the tile, scatter the tile's output channels into the [B][F][P] tensor"""
         E = self.E
-        g = self._stream_geometry(kind, a, B)
+        # (an input that arrives as a group's limb tensor keeps the layer on the matrix cores whatever the size of this particular group)
+        g = self._stream_geometry(kind, a, B if p["in_form"] != binding.NTTL else max(B, 32))
         rowb = E.k * E.n * 8; ctb = self.ct_bytes()
         # the layer's input goes to limb form once for all filter tiles (a coefficient-form input -- the reference's layer contract -- is left to every tile's call)
         pre = g["limb"] and p["in_form"] in (NTT, binding.NTTP)
@@ -607,7 +608,8 @@ class Network:
                 if self.ytile is None or self._ytile_bytes < yt:
                     self.ytile, self._ytile_bytes = self.alloc(yt), yt
                 if g["limb"]:                 # (one set of tile buffers serves every streamed layer: the largest of each)
-                    wl, xl = self.E.limb_weights_bytes(g["ft"], g["zd"], g["xf"], g["yf"]), self.E.limb_tensor_bytes(Bl, g["zd"], g["xd"], g["yd"])
+                    wl = self.E.limb_weights_bytes(g["ft"], g["zd"], g["xf"], g["yf"])
+                    xl = self.E.limb_tensor_bytes(Bl, g["zd"], g["xd"], g["yd"]) if p["in_form"] != binding.NTTL else 8         # (a group's limb tensor needs no copy)
                     if self.wltile is None or self._wltile_bytes < wl:
                         self.wltile, self._wltile_bytes = self.alloc(wl), wl
                     if self.xltile is None or self._xltile_bytes < xl:
