@@ -8,9 +8,12 @@ One "step" = one pass of the hot path (Network::forward: conv/pool/[bn/square]/d
 `--batch` synthetic encrypted MNIST-like images per GPU.  Inputs are encrypted before the timed region and are resident in
 HBM; the encoded (NTT-form) weights are built on rank 0 and broadcast with RCCL; images are sharded across ranks (weak
 scaling, no data-path collective).  Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      achieved HBM GB/s of the dominant kernel (algorithmic bytes / measured duration) vs the 8 TB/s peak
-  cpu_baseline  the CPU oracle executing the reference's own operation order on the host cores, on a bounded sample
-  ms_per_layer  per-image milliseconds per layer (the reference's T_LAYER_i columns, mainparams.cpp:81)
+  roofline      the dominant kernel against the roof that bounds it: int8 matrix-core TOP/s for the limb GEMM (frac = executed, useful_frac = without channel /
+                filter padding; the HBM view of the same launch beside it), HBM GB/s (algorithmic bytes / measured duration vs the 8 TB/s peak) for everything else
+  cpu_baseline  the compiled reference (oracle/_ref/ref_harness; the CPU oracle where that binary is absent) on the host cores, on a bounded sample: conv1 + pool1 of
+                image 0, one batch-norm ciphertext and one Square ciphertext, extrapolated by MAC / ciphertext counts
+  ms_per_layer  per-image milliseconds per (fused) layer; reference_layer_structure.production_kernels.T_LAYER = the reference's own T_LAYER_i columns
+                (mainparams.cpp:81: one per layer of the unfused network) on the same kernels
 """
 import argparse
 import datetime
@@ -157,7 +160,7 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("CRC_CPU_THREADS", "16"))))
 
 
-def cpu_baseline_reference(cfg, q, W, x0, cores):
+def cpu_baseline_reference(cfg, q, W, x0, cores, evk=None):
     """CPU baseline with the REFERENCE ITSELF: oracle/_ref/ref_harness (SEAL 2.3.1 + the CrCNN layer sources compiled in place by
     oracle/Makefile, shipped as a prebuilt binary) runs CrCNN's own ConvolutionalLayer::forward and pooling forward of the first
     two layers on image 0 with th_count = host cores; per-image time extrapolated by MAC count.  Returns None if the binary is absent."""
@@ -182,16 +185,51 @@ def cpu_baseline_reference(cfg, q, W, x0, cores):
             rows = [ln.split() for ln in open(os.path.join(d, "ref_digests.txt")).read().splitlines()]
         except Exception:
             return None
+        # ... and, for the networks that have them, ONE ciphertext through CrCNN's BatchNormLayer and SquareLayer (Evaluator::square + relinearize): the first
+        # ciphertext of the image as a 1 x 1 x 1 tensor
+        t_bn = t_sq = None
+        bn_l = [(n_, a_) for k_, n_, a_ in topo if k_ == "bn"]
+        if bn_l and evk is not None and any(k_ == "square" for k_, _, _ in topo):
+            try:
+                d2 = os.path.join(d, "one"); os.makedirs(d2)
+                np.array([cfg["n"], len(q), cfg["t"]] + list(q), dtype=np.uint64).tofile(os.path.join(d2, "params.u64"))
+                np.array([1, 1, 1], dtype=np.uint64).tofile(os.path.join(d2, "net_in_dims.u64"))
+                np.ascontiguousarray(x0.reshape(-1, 2, len(q), cfg["n"])[:1]).tofile(os.path.join(d2, "net_in.u64"))
+                np.ascontiguousarray(evk).tofile(os.path.join(d2, "evk.u64"))
+                bn_name = bn_l[0][0]
+                W[bn_name + ".running_mean"][:1].astype(np.float64).tofile(os.path.join(d2, bn_name + ".running_mean.f64"))
+                W[bn_name + ".running_var"][:1].astype(np.float64).tofile(os.path.join(d2, bn_name + ".running_var.f64"))
+                with open(os.path.join(d2, "topology.txt"), "w") as f:
+                    f.write(f"bn {bn_name} 1\nsquare act1 1\n")
+                subprocess.run([harness, "net", d2], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+                r2 = [ln.split() for ln in open(os.path.join(d2, "ref_digests.txt")).read().splitlines()]
+                t_bn, t_sq = float(r2[0][4].rstrip("us")) * 1e-6, float(r2[1][4].rstrip("us")) * 1e-6
+            except Exception:
+                t_bn = t_sq = None
     t_conv, t_pool = float(rows[0][4].rstrip("us")) * 1e-6, float(rows[1][4].rstrip("us")) * 1e-6
     macs0 = layer_macs(k0, a0)
     total_macs = sum(layer_macs(k_, a_) for k_, _, a_ in topo)
     pool_cts = sum(a_["zd"] * ((a_["xd"] - a_["xf"]) // a_["xs"] + 1) * ((a_["yd"] - a_["yf"]) // a_["ys"] + 1) for k_, _, a_ in topo if k_ in ("pool", "avgpool"))
     cts1 = a1["zd"] * ((a1["xd"] - a1["xf"]) // a1["xs"] + 1) * ((a1["yd"] - a1["yf"]) // a1["ys"] + 1)
     t_image = total_macs / (macs0 / t_conv) + pool_cts * (t_pool / cts1)
+    extra = "square/bn layers not sampled" if any(k_ in ("square", "bn") for k_, _, _ in topo) else "the network has no square / batch-norm layer"
+    if t_bn is not None:
+        # ciphertexts per image through each batch-norm / square layer (shapes follow the topology)
+        shape, bn_cts, sq_cts = (1, 28, 28), 0, 0
+        from crcnn_amd.netrun import out_shape
+        for k_, _, a_ in topo:
+            if k_ == "bn":
+                bn_cts += int(np.prod(shape))
+            elif k_ == "square":
+                sq_cts += int(np.prod(shape))
+            shape = out_shape(k_, a_, shape)
+        t_image += bn_cts * t_bn + sq_cts * t_sq / cores        # (SquareLayer splits its ciphertexts over th_count threads; BatchNormLayer and the pools are single-threaded)
+        extra = (f"one ciphertext through BatchNormLayer::forward in {t_bn * 1e3:.1f} ms (x {bn_cts} per image, single-threaded in the reference) and through SquareLayer::forward "
+                 f"(Evaluator::square + relinearize, dbc 16) in {t_sq * 1e3:.1f} ms (x {sq_cts} per image / th_count={cores})")
     return dict(value=1.0 / t_image, unit="encrypted images/sec", cores=cores, kind="reference",
                 sample=f"the compiled reference (SEAL 2.3.1 + CrCNN ConvolutionalLayer/{'Avg' if k1 == 'avgpool' else ''}PoolingLayer::forward, oracle/_ref/ref_harness) on image 0: "
                        f"{n0} {macs0} ct*pt MACs in {t_conv:.2f}s with th_count={cores}, {n1} in {t_pool:.2f}s (single-threaded in the reference); "
-                       f"per-image time extrapolated by MAC count ({total_macs} MACs/image) and pooled-ciphertext count; square/bn layers not sampled",
+                       f"per-image time extrapolated by MAC count ({total_macs} MACs/image) and pooled-ciphertext count; {extra}",
                 mac_per_s=macs0 / t_conv)
 
 
@@ -367,7 +405,7 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
     t_setup = time.time()
     sk, pk = E.keygen(KEY_SEED)
     needs_evk = any(k_ == "square" for k_, _, _ in TOPOLOGIES[model])
-    d_evk = None
+    d_evk = evk = None
     if needs_evk:
         evk = E.gen_evk(EVK_SEED, sk)
         d_evk = alloc(evk.nbytes); d_evk.copy_(torch.from_numpy(evk.view(np.int64)))
@@ -437,6 +475,39 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
     unfused = None
     want_fuse = args.mode == "resident" and not args.no_fuse
     tilewise = any(pl[3].get("tilewise") for pl in net.plan)       # (their limb weights would have to be built twice, before and after the folding: skipped)
+    prod_ref = None
+    if want_fuse and full and args.unfused_images > 0 and not tilewise and world == 1:
+        # the reference's OWN layer structure (no folding: every CrCNN layer its own kernel sequence, NTT-resident) on the PRODUCTION kernels (matrix cores): the
+        # reference's T_LAYER_0..N columns (mainparams.cpp:81) for this engine.  A second encoded network (the limb conversion drops the canonical weights that fuse()
+        # needs), freed again before the main pass
+        mark = len(keep)
+        net_r = Network(E, model, weights=W, alloc=alloc, resident=True, d_evk=d_evk, materialize=True, fuse_pool=False)
+        net_r.release = release
+        Cu = min(C, 16)                                # (two encoded networks are resident during this pass: a smaller chunk of unfused activations)
+        nu = min(B, max(Cu, args.unfused_images // Cu * Cu))
+        net_r.prepare(Cu, limb=True)
+        net_r.forward(x_all[0], 1); torch.cuda.synchronize()
+        lev = []
+
+        def timer_r(i, name, kind, phase):
+            e = torch.cuda.Event(enable_timing=True); e.record(); lev.append((i, e))
+        t0 = time.perf_counter()
+        for c0 in range(0, nu, Cu):
+            d_out = net_r.forward(x_all[c0 % window], min(Cu, nu - c0), timer=timer_r)
+            E.L.crc_memcpy_d2d(E.c, out_all[c0].data_ptr(), E.p(d_out), min(Cu, nu - c0) * 10 * ctw * 8, E.stream)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        tl = np.zeros(len(net_r.plan))
+        for j in range(0, len(lev), 2):
+            tl[lev[j][0]] += lev[j][1].elapsed_time(lev[j + 1][1])
+        prod_ref = dict(images=nu, images_per_s=round(nu / dt, 3), ms_per_image=round(dt / nu * 1e3, 3), first_outputs=out_all[:min(D, nu)].clone(),
+                        T_LAYER={f"T_LAYER_{i}": round(float(tl[i] / nu), 4) for i in range(len(net_r.plan))},
+                        layers=[pl[1] for pl in net_r.plan],
+                        mac_kernel_per_layer={pl[1]: {ca.NTTL: "mfma_mac2w_kernel", ca.NTTL1: "mfma_conv1_kernel"}.get(pl[3].get("w_form"), "mac3_kernel") for pl in net_r.plan if pl[0] in ("conv", "fc")},
+                        note="ms per image and layer of the UNFUSED network in the column order of the reference's timing rows (mainparams.cpp:81), matrix-core kernels")
+        del net_r, lev
+        del keep[mark:]
+        torch.cuda.empty_cache()
     if want_fuse and full and args.unfused_images > 0 and not tilewise:
         Cu = min(C, 32)                                # the unfused conv1 output is 18 432 ciphertexts per image (Tiny): a smaller chunk than the main pass
         nu = min(B, max(Cu, args.unfused_images // Cu * Cu))
@@ -449,7 +520,7 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         unfused = dict(images=nu, images_per_s=round(nu / dt, 3), ms_per_image=round(dt / nu * 1e3, 3), first_outputs=out_all[:min(D, nu)].clone(),
-                       layers=[pl[1] for pl in net.plan])
+                       layers=[pl[1] for pl in net.plan], kernels="vector ALU only (mac3_kernel: the canonical weights are still needed by the folding that follows)")
         for t_ in list(net.buf) + [net.work]:          # give the large unfused activation buffers back before the main pass
             keep[:] = [k_ for k_ in keep if k_ is not t_]
         del net.buf, net.work, t_
@@ -513,6 +584,13 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
     if unfused is not None:     # folding pooling into the convolution must not change a single output bit
         fo = unfused.pop("first_outputs")
         ok_fused = unfused["outputs_identical_to_fused"] = bool(torch.equal(fo, out_all[:fo.shape[0]]))
+    if prod_ref is not None:
+        fo = prod_ref.pop("first_outputs")
+        prod_ref["outputs_identical_to_fused"] = bool(torch.equal(fo, out_all[:fo.shape[0]]))
+        ok_fused = ok_fused and prod_ref["outputs_identical_to_fused"]
+        if unfused is None:
+            unfused = {}
+        unfused["production_kernels"] = prod_ref
     outs = out_all[:D].cpu().numpy().view(np.uint64).reshape(D, 10, 2, E.k, E.n)
     import hashlib
     gold_ok, gold_name = golden_check(cfg_name, cfg, q, rank, x0_sha, hashlib.sha256(np.ascontiguousarray(outs[0]).tobytes()).hexdigest())
@@ -591,9 +669,13 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
         traffic, traffic_source = None, None
         kname = "mfma_mac2w_kernel" if p.get("w_form") == ca.NTTL else "mfma_conv1_kernel" if p.get("w_form") == ca.NTTL1 else "mac3_kernel"
         kernel_label = f"{kname} ({name}, {CL} images/launch)" if kind in ("conv", "fc") else f"{kind} ({name})"
-        for pf in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for pf in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", pf))).get(cfg_name)
+                if pm and pm.get("per_ciphertext") and kind == "square":      # the Square + relinearise sequence: PMC bytes per ciphertext x the launch's ciphertexts
+                    traffic = int(pm["traffic_bytes_per_ciphertext"] * CL * in_cts)
+                    traffic_source = f"profiles/{pf} ({pm['kernel']}), offline rocprofv3 --pmc passes of tools/bench_square.py on the same ring (not measured in this run)"
+                    break
                 if pm and pm["kernel"] == kernel_label:
                     traffic = int(pm["traffic_bytes"]); traffic_source = f"profiles/{pf}, offline rocprofv3 --pmc passes of the same launch (not measured in this run)"
                     break
@@ -604,17 +686,25 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
             # the matrix-core kernel is bound by the int8 MFMA rate, not by HBM: 49 limb products (98 int8 operations) per modular multiply-add, against the dense
             # int8 peak (2x the bf16 rate per clock: MI355X_MICROARCH.md, matrix cores).  The HBM view of the same launch stays beside it
             tops = modmul_s * 98 / 1e12
-            roofline = dict(bound="mfma", achieved=round(tops, 1), peak=INT8_PEAK_TOPS, unit="TFLOP/s", frac=round(tops / INT8_PEAK_TOPS, 5), traffic=traffic,
-                            ops="int8 multiply and add, 98 per modular multiply-add (7 x 7 balanced base-256 limb products); algorithmic = the layer's ct x pt multiply-adds x 2 polys x k n",
+            # executed = what the matrix cores really multiply: rows padded to 64-row tiles, channels to 32 per reduction step (an odd number of steps to even),
+            # filters to 32-filter tiles; useful = the layer's own multiply-adds (ApproxPlainModel's conv2: 20 of 32 channels, 50 of 64 filters, 9 of 10 steps)
+            gz = (a["zd"], a["xf"] * a["yf"], a["nf"]) if kind == "conv" else (a["in_dim"], 1, a["out_dim"])
+            rows_l = CL * (out_cts // gz[2]) * 2
+            steps = -(-gz[0] // 32) * gz[1]
+            exec_over_useful = (-(-rows_l // 64) * 64 / rows_l) * ((steps + (steps & 1)) * 32 / (gz[0] * gz[1])) * (-(-gz[2] // 32) * 32 / gz[2])
+            roofline = dict(bound="mfma", achieved=round(tops * exec_over_useful, 1), peak=INT8_PEAK_TOPS, unit="TOP/s (int8)", frac=round(tops * exec_over_useful / INT8_PEAK_TOPS, 5),
+                            useful_achieved=round(tops, 1), useful_frac=round(tops / INT8_PEAK_TOPS, 5), traffic=traffic,
+                            ops="int8 multiply and add, 98 per modular multiply-add (7 x 7 balanced base-256 limb products); useful = the layer's ct x pt multiply-adds x 2 polys x k n, "
+                                "executed = the same with rows / channels / filters padded to the kernel's tiles",
                             hbm_achieved_GBps=round(achieved, 2), hbm_frac=round(achieved / HBM_PEAK_GBS, 5))
         else:
             roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic)
         roofline.update(traffic_source=traffic_source, kernel=kernel_label, kernel_timing=kernel_note, launch_ms=round(float(dur_ms), 3), layer_call_ms=round(float(layer_ms), 3),
                         algorithmic_bytes_per_launch=int(alg_bytes), modmul_per_s=round(modmul_s, 1) if modmul_s else None)
         cpu = None
-        if full and args.cpu_seconds > 0 and world == 1:      # (the CPU leg runs at N = 1 only: at N > 1 the host cores are busy driving N ranks)
+        if args.cpu_seconds > 0 and world == 1:      # (the CPU leg runs at N = 1 only: at N > 1 the host cores are busy driving N ranks)
             x0 = x_all[0].cpu().numpy().view(np.uint64).reshape(1, 28, 28, 2, E.k, E.n)
-            cpu = cpu_baseline_reference(cfg, q, W, x0, host_cores()) or cpu_baseline(cfg, q, W, x0, args.cpu_seconds)
+            cpu = cpu_baseline_reference(cfg, q, W, x0, host_cores(), evk=evk) or cpu_baseline(cfg, q, W, x0, args.cpu_seconds)
             cpu["value"] = round(cpu["value"], 6); cpu["mac_per_s"] = round(cpu["mac_per_s"], 1)
             try:            # configs[0] measured in full in the build container (not extrapolated): oracle/make_c1.py
                 c1f = json.load(open(c1_path))
@@ -661,13 +751,17 @@ def main():
     line, ok = run_config(args, D_, args.config, args.steps, args.warmup, batch=args.batch, chunk=args.chunk, full=True)
     also = args.also
     if also == "auto":
-        also = "approx8192" if args.config == "tiny4096" and args.batch is None else "none"
+        # the default invocation also measures BASELINE configs[2] (ApproxPlainModel, n = 8192, k = 3) and configs[4]'s workload on one GPU (PlainModelWoPad, n = 16384,
+        # k = 4: batch 96 -- 202 GiB of weights leave room for 6-image chunks)
+        also = "approx8192,wopad16384" if args.config == "tiny4096" and args.batch is None else "none"
     if also != "none":
-        second, ok2 = run_config(args, D_, also, args.also_steps, 0, batch=args.also_batch, full=False)
-        ok = ok and ok2
-        if line is not None:
-            line["also"] = [{k_: second[k_] for k_ in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "config", "data", "ms_per_layer", "roofline", "check", "setup_s",
-                                                       "weight_broadcast", "weight_bytes")}]
+        for nm in also.split(","):
+            b2 = args.also_batch or (96 if nm.startswith("wopad") else None)
+            second, ok2 = run_config(args, D_, nm, 1 if nm.startswith("wopad") else args.also_steps, 0, batch=b2, full=False)
+            ok = ok and ok2
+            if line is not None:
+                line.setdefault("also", []).append({k_: second[k_] for k_ in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "config", "data", "ms_per_layer", "mac_kernel_per_layer",
+                                                                              "roofline", "cpu_baseline", "check", "setup_s", "weight_broadcast", "weight_bytes")})
     if line is not None:
         print(json.dumps(line), flush=True)
     if D_.world > 1:
