@@ -690,8 +690,8 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
             # filters to 32-filter tiles; useful = the layer's own multiply-adds (ApproxPlainModel's conv2: 20 of 32 channels, 50 of 64 filters, 9 of 10 steps)
             gz = (a["zd"], a["xf"] * a["yf"], a["nf"]) if kind == "conv" else (a["in_dim"], 1, a["out_dim"])
             rows_l = CL * (out_cts // gz[2]) * 2
-            steps = -(-gz[0] // 32) * gz[1]
-            exec_over_useful = (-(-rows_l // 64) * 64 / rows_l) * ((steps + (steps & 1)) * 32 / (gz[0] * gz[1])) * (-(-gz[2] // 32) * 32 / gz[2])
+            ksteps = -(-gz[0] // 32) * gz[1]
+            exec_over_useful = (-(-rows_l // 64) * 64 / rows_l) * ((ksteps + (ksteps & 1)) * 32 / (gz[0] * gz[1])) * (-(-gz[2] // 32) * 32 / gz[2])
             roofline = dict(bound="mfma", achieved=round(tops * exec_over_useful, 1), peak=INT8_PEAK_TOPS, unit="TOP/s (int8)", frac=round(tops * exec_over_useful / INT8_PEAK_TOPS, 5),
                             useful_achieved=round(tops, 1), useful_frac=round(tops / INT8_PEAK_TOPS, 5), traffic=traffic,
                             ops="int8 multiply and add, 98 per modular multiply-add (7 x 7 balanced base-256 limb products); useful = the layer's ct x pt multiply-adds x 2 polys x k n, "
