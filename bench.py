@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--also", default="auto", help="a second workload measured in the same invocation and reported under \"also\" (auto: approx8192 = BASELINE "
                     "configs[2]/[3] beside the tiny4096 headline; none: skip)")
     ap.add_argument("--also-steps", type=int, default=2)
+    ap.add_argument("--host-cpp", type=int, default=1, help="1: also time the same workload through the C++ host classes (crcnn_amd/lib/bench_host) and check it against the Python twin")
+    ap.add_argument("--host-cpp-steps", type=int, default=3)
     ap.add_argument("--also-batch", type=int, default=None)
     ap.add_argument("--launch-check", action="store_true", help="only start the ranks, rendezvous (gloo, no GPU call) and report: CPU test of the self-launch path")
     return ap.parse_args()
@@ -732,11 +734,57 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
                       "noise_budget_bits": budgets, "ranks_verified": f"{ranks_ok}/{world}", "golden_match": gold_ok, "golden": gold_name, "c1_images_match_reference": c1_ok, "all_ok": bool(all_ok)},
             "setup_s": round(setup_s, 1), "weight_broadcast": bcast, "weight_broadcast_s": bcast["seconds"] if bcast else 0.0, "weight_bytes": int(net.weight_bytes),
         }
+    # the same workload through the C++ host classes (crcnn_amd/host: the drop-in for the reference's Layer / Network / CnnBuilder) is measured by main() once this
+    # engine has given its memory back: the distinct encrypted images go to a scratch file
+    if result is not None and full and world == 1 and args.host_cpp and q == ca.default_coeff_modulus_128(cfg["n"])[:cfg["k"]]:
+        import tempfile
+        hd = tempfile.mkdtemp(prefix="crc_host_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        x_all[:D].cpu().numpy().tofile(os.path.join(hd, "inputs.u64"))
+        result["_host_job"] = dict(dir=hd, model=model, n=cfg["n"], k=cfg["k"], t=cfg["t"], distinct=D, batch=B, chunk=C, golden=GOLDEN_FOR.get(cfg_name),
+                                   golden_input_ok=bool(gold_ok is not None), python_images_per_s=result["value"])
     # give everything back before a second workload
     del net, x_all, out_all, outs, keep[:]
     E.sync(); E.close()
     torch.cuda.empty_cache()
     return result, bool(all_ok)
+
+
+def host_cpp_leg(line, job, args):
+    """north_star's "C++ host code calls hand-written HIP kernels" as a measured path: crcnn_amd/lib/bench_host builds the same network with the C++ CnnBuilder, fuses it,
+    and times Network::forward over the same encrypted images in the same chunks.  The check fails when its 10 output ciphertexts of image 0 are not the golden's
+    (= this run's) or its images/s differ from the Python twin's by more than 3 %"""
+    import hashlib
+    import shutil
+    import subprocess
+    exe = os.path.join(ROOT, "crcnn_amd", "lib", "bench_host")
+    h5 = os.path.join(ROOT, "tests", "golden", "models", job["model"] + ".h5")
+    out0 = os.path.join(job["dir"], "out0.u64")
+    steps = max(1, min(args.steps, args.host_cpp_steps))
+    res = dict(binary="crcnn_amd/lib/bench_host (crcnn_amd/host/bench_host.cpp)")
+    try:
+        if not os.path.exists(exe):
+            raise RuntimeError("crcnn_amd/lib/bench_host has not been built")
+        p = subprocess.run([exe, job["model"], h5, str(job["n"]), str(job["k"]), str(job["t"]), os.path.join(job["dir"], "inputs.u64"), str(job["distinct"]), str(job["batch"]),
+                            str(job["chunk"]), str(steps), out0], capture_output=True, text=True, timeout=900)
+        if p.returncode != 0:
+            raise RuntimeError(f"exit {p.returncode}: {p.stderr[-400:]}")
+        r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        sha = hashlib.sha256(open(out0, "rb").read()).hexdigest()
+        g = json.load(open(os.path.join(ROOT, "tests", "golden", f"net_{job['golden']}.json"))) if job["golden"] and job["golden_input_ok"] else None
+        ratio = r["images_per_s"] / job["python_images_per_s"]
+        res.update(images_per_s=r["images_per_s"], ms_per_image=r["ms_per_image"], steps=steps, chunk=r["chunk"], setup_s=r["setup_s"],
+                   T_LAYER={f"T_LAYER_{i}": v for i, v in enumerate(r["T_LAYER_ms_per_image"])}, layers=r["layers"],
+                   vs_python_twin=round(ratio, 4), within_3_percent=bool(abs(ratio - 1) <= 0.03),
+                   golden_match=(sha == g["out_sha256"]) if g else None, out0_sha256=sha)
+        ok = res["within_3_percent"] and res["golden_match"] is not False
+    except Exception as ex:
+        res["error"] = f"{type(ex).__name__}: {ex}"
+        ok = False
+    shutil.rmtree(job["dir"], ignore_errors=True)
+    line["host_cpp"] = res
+    line["check"]["host_cpp_ok"] = bool(ok)
+    line["check"]["all_ok"] = bool(line["check"]["all_ok"] and ok)
+    return ok
 
 
 def main():
@@ -749,6 +797,8 @@ def main():
         sys.exit(self_launch(args))
     D_ = Dist(args)
     line, ok = run_config(args, D_, args.config, args.steps, args.warmup, batch=args.batch, chunk=args.chunk, full=True)
+    if line is not None and line.get("_host_job"):
+        ok = host_cpp_leg(line, line.pop("_host_job"), args) and ok
     also = args.also
     if also == "auto":
         # the default invocation also measures BASELINE configs[2] (ApproxPlainModel, n = 8192, k = 3) and configs[4]'s workload on one GPU (PlainModelWoPad, n = 16384,

@@ -7,6 +7,8 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <list>
+#include <mutex>
 
 using namespace std;
 
@@ -37,8 +39,51 @@ static int N() { return crc_ctx_n(ctx()); }
 static int K() { return crc_ctx_k(ctx()); }
 static size_t ctBytes() { return crc_ct_words(ctx(), 2) * 8; }
 
-DeviceBuffer::DeviceBuffer(size_t b) : bytes(b) { chk(crc_malloc(ctx(), b ? b : 8, &ptr), "crc_malloc"); }
-DeviceBuffer::~DeviceBuffer() { if (ptr && context) crc_free(context, ptr); }
+// Device allocations are recycled by exact size: the reference passes its tensors by value and so do these classes -- every Layer::forward makes a new output
+// tensor -- but a hipMalloc / hipFree pair per layer and chunk (the free synchronises the device) would cost more than some of the layers.  Freed buffers wait in a
+// pool (bounded: beyond the cap they go back to the driver; an allocation that fails empties the pool and tries again); delParameters() empties it.
+namespace {
+struct BufferPool {
+    std::mutex mu;
+    std::list<std::pair<size_t, void *>> lru;               // oldest first
+    size_t pooled = 0;
+    static constexpr size_t kCap = (size_t)128 << 30;
+    void *take(size_t b)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto it = lru.begin(); it != lru.end(); ++it) if (it->first == b) { void *p = it->second; lru.erase(it); pooled -= b; return p; }
+        return nullptr;
+    }
+    // the newest buffer stays; the least recently returned ones (the one-off scratch of model building, typically) make room for it
+    bool give(size_t b, void *p)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (b > kCap) return false;
+        while (pooled + b > kCap && !lru.empty()) { if (context) crc_free(context, lru.front().second); pooled -= lru.front().first; lru.pop_front(); }
+        lru.emplace_back(b, p); pooled += b;
+        return true;
+    }
+    void flush() { std::lock_guard<std::mutex> g(mu); for (auto &e : lru) if (context) crc_free(context, e.second); lru.clear(); pooled = 0; }
+};
+BufferPool g_pool;
+}
+DeviceBuffer::DeviceBuffer(size_t b) : bytes(b)
+{
+    const size_t want = b ? b : 8;
+    if ((ptr = g_pool.take(want))) return;
+    static const bool trace = getenv("CRC_HOST_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "[host] hipMalloc %.3f GiB (pool miss)\n", want / 1073741824.0);
+    if (crc_malloc(ctx(), want, &ptr) >= 0) return;
+    g_pool.flush();
+    chk(crc_malloc(ctx(), want, &ptr), "crc_malloc");
+}
+DeviceBuffer::~DeviceBuffer()
+{
+    if (!ptr || !context) return;
+    if (g_pool.give(bytes ? bytes : 8, ptr)) return;
+    if (getenv("CRC_HOST_TRACE")) fprintf(stderr, "[host] hipFree %.3f GiB (pool full)\n", bytes / 1073741824.0);
+    crc_free(context, ptr);
+}
 
 // ---- Plaintext ------------------------------------------------------------------------------------------------------
 void Plaintext::dense(uint64_t *out, int n) const
@@ -173,6 +218,7 @@ void setParameters(int poly_modulus, const vector<uint64_t> &coeff_modulus, uint
 void delParameters()
 {
     ev_keys16.reset();
+    g_pool.flush();
     if (context) { crc_ctx_destroy(context); context = nullptr; }
 }
 static void writeFile(const string &path, const vector<uint8_t> &b) { ofstream f(path, ofstream::binary); if (!f) throw runtime_error("cannot write " + path); f.write((const char *)b.data(), (streamsize)b.size()); }

@@ -89,7 +89,7 @@ def test_streamed_weights_on_the_matrix_cores(name, monkeypatch):
     net.prepare(16)
     kern = {pl[1]: pl[3].get("stream_kernel") for pl in net.plan if pl[3].get("streamed")}
     assert kern["classifier.fc3"].startswith("mfma_mac2w_kernel") and kern["pool2_features.conv2"].startswith("mfma_mac2w_kernel"), kern
-    assert kern["pool1_features.conv1"] == "mac3_kernel" and kern["classifier.fc4"] == "mac3_kernel"      # one channel / ten filters: not limb GEMM shapes (crc_plan_mac)
+    assert kern["pool1_features.conv1"] == "mac3_kernel" and kern["classifier.fc4"] == "mac3_kernel"      # one channel; ten filters with only 32 rows (crc_plan_mac)
     out = E.download(net.forward(E.upload(np.ascontiguousarray(np.repeat(x[None], 16, axis=0))), 16), (16, 1, 10, 1, 2, E.k, E.n))
     E.close()
     assert all(sha(out[b]) == g["out_sha256"] for b in range(16))
@@ -115,7 +115,7 @@ def test_tilewise_limb_weights_and_two_level_chunking(name, monkeypatch):
     fc3 = [pl for pl in net.plan if pl[1].endswith("classifier.fc3")][0]
     assert fc3[1] == "pool2_features.norm2+classifier.fc3" and fc3[3]["tilewise"]["built"] == "folded" and net.G == 8 and net.plan[net.split] is fc3
     fc4 = net.plan[-1]
-    assert fc4[3]["w_form"] == ca.NTTP and fc3[3]["in_form"] == ca.NTTL              # ten filters: fc4 stays on the vector-ALU kernel; fc3's input is the group's limb tensor
+    assert fc4[3]["w_form"] == ca.NTTP and fc3[3]["in_form"] == ca.NTTL              # ten filters, 32 rows: fc4 stays on the vector-ALU kernel; fc3's input is the group's limb tensor
     xb = E.upload(np.ascontiguousarray(np.repeat(x[None], 2, axis=0)))
     out = E.download(net.forward_group([xb] * 8, 2), (16, 1, 10, 1, 2, E.k, E.n))
     assert all(sha(out[b]) == g["out_sha256"] for b in range(16))
@@ -142,7 +142,7 @@ def test_kernel_choice_follows_the_rows_per_launch():
         assert (forms["classifier.fc3"].get("w_form") == ca.NTTL) == dense_limb, (B, forms["classifier.fc3"].get("w_form"))
         if not dense_limb:
             assert forms["classifier.fc3"]["limb_skipped"] == "fewer than 32 rows per launch"
-        assert forms["classifier.fc4"].get("w_form") == ca.NTTP and "limb_skipped" not in forms["classifier.fc4"]       # ten filters: never a limb GEMM (crc_plan_mac)
+        assert forms["classifier.fc4"].get("w_form") == ca.NTTP           # ten filters: a limb GEMM only from a full 64-row tile on (crc_plan_mac)
         out = E.download(net.forward(E.upload(np.ascontiguousarray(np.repeat(x[None], B, axis=0))), B), (B, 1, 10, 1, 2, E.k, E.n))
         assert all(sha(out[b]) == g["out_sha256"] for b in range(B))
         E.close()
@@ -162,8 +162,15 @@ def test_matrix_core_dense_layers_match_reference():
     assert forms["classifier.fc3"] == ca.NTTL and forms["classifier.fc4"] == ca.NTTP and [pl[3]["in_form"] for pl in net.plan if pl[1] == "classifier.fc3"] == [ca.NTTL]
     d_x = E.upload(np.ascontiguousarray(np.repeat(x[None], 16, axis=0)))
     out = E.download(net.forward(d_x, 16), (16, 1, 10, 1, 2, E.k, E.n))
-    E.close()
     assert all(sha(out[b]) == g["out_sha256"] for b in range(16))
+    # a full tile of rows (32 images): the ten-filter fc4 moves to the matrix cores as well and fc3 hands its tensor over in limb form
+    net2 = Network(E, g["model"], h5_path=os.path.join(GOLD, "models", g["model"] + ".h5"), resident=True)
+    net2.fuse(); net2.prepare(32)
+    f2 = {pl[1]: pl[3] for pl in net2.plan if pl[0] == "fc"}
+    assert f2["classifier.fc4"]["w_form"] == ca.NTTL and f2["classifier.fc3"]["out_form"] == ca.NTTL
+    out = E.download(net2.forward(E.upload(np.ascontiguousarray(np.repeat(x[None], 32, axis=0))), 32), (32, 1, 10, 1, 2, E.k, E.n))
+    E.close()
+    assert all(sha(out[b]) == g["out_sha256"] for b in range(32))
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, "net_tiny4096_t32.json")), reason="needs the n=4096 golden")

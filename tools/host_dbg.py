@@ -1,0 +1,16 @@
+import os, sys, subprocess, numpy as np
+sys.path.insert(0, os.getcwd())
+import crcnn_amd as ca
+from crcnn_amd.synth import normalize, synth_image
+n, k, t = 4096, 2, 1 << 32
+q = ca.default_coeff_modulus_128(n)[:k]
+E = ca.Engine(n, q, t, device=-1)
+sk, pk = E.keygen(2024)
+xs = []
+for i in range(2):
+    pl, _ = E.encode(normalize(synth_image(i)).reshape(-1))
+    xs.append(E.encrypt(pk, pl, 7000 + 1000 * i))
+np.ascontiguousarray(np.stack(xs)).tofile("/dev/shm/in.u64")
+env = dict(os.environ, CRC_HOST_TRACE="1")
+p = subprocess.run(["crcnn_amd/lib/bench_host", "PlainModelTiny", "tests/golden/models/PlainModelTiny.h5", str(n), str(k), str(t), "/dev/shm/in.u64", "2", "256", "128", "1", "/dev/shm/out0.u64"], capture_output=True, text=True, env=env)
+print(p.stdout[-2000:]); print(p.stderr[-3000:])
