@@ -132,42 +132,58 @@ __global__ void __launch_bounds__(1024) mfma_conv1_kernel(Conv1Args a)
 }
 
 // ---- operand preparation -----------------------------------------------------------------------------------------------------------------
-// NTT-form image x [B][xd*yd cts][2][k][n] (one channel; canonical or 28-bit packed) -> Xr [slot][B][plane][poly][row][32 columns] (yd <= 32, zero padded).  One thread
-// per (slot, image, poly, group of RG rows); lanes run over 64 consecutive slots (coalesced 512-B row segments); a row is 32 contiguous bytes per plane, written as
-// two adjacent 16-byte stores
+// NTT-form image x [B][xd*yd cts][2][k][n] (one channel; canonical or 28-bit packed) -> Xr [slot][B][plane][poly][row][32 columns] (yd <= 32, zero padded).
+// A workgroup = 64 consecutive slots x (image, poly, group of RG rows): thread (slot lane, row q of the group) reads its row's columns -- lanes run over the slots, so
+// every load is a coalesced 512-byte segment of one ciphertext row -- and stages the seven planes' 32 bytes in LDS; then the workgroup writes the staged block out so
+// that the RG * 32 = 128 contiguous bytes a (slot, plane) owns in Xr leave as ONE full line from eight adjacent lanes.  (Round 2's form -- every thread storing its own
+// 16-byte pieces, neighbouring lanes 1.6 MB apart -- moved 26 GB at 1.7 TB/s; a forward transform that writes this layout itself would have to hold 32 columns of a
+// row at once, 32 polynomials per workgroup: the image layout is slot-major because the convolution's workgroup walks one slot's image, the transform's row is
+// slot-minor, and the transpose between them is this pass.)
 #define RG 4
-__global__ void __launch_bounds__(64) limb_pack_rows1_kernel(const u64 *x, i8 *xr, const ModParams *mods, int n, int k, int B, int xd, int yd, int packed,
-                                                             unsigned img_stride, unsigned plane_bytes, unsigned poly_bytes)
+__global__ void __launch_bounds__(64 * RG) limb_pack_rows1_kernel(const u64 *x, i8 *xr, const ModParams *mods, int n, int k, int B, int xd, int yd, int packed,
+                                                                  unsigned img_stride, unsigned plane_bytes, unsigned poly_bytes)
 {
+    __shared__ __attribute__((aligned(16))) i8 st[64 * NPL * RG * 32];           // [slot][plane][row of the group][32 columns]
     const int sblocks = n / 64;
-    const int sb = blockIdx.x % (sblocks * k), i = sb / sblocks, s = (sb % sblocks) * 64 + threadIdx.x;
+    const int sb = blockIdx.x % (sblocks * k), i = sb / sblocks, s0 = (sb % sblocks) * 64;
     const int rgs = (xd + RG - 1) / RG;
     size_t r = blockIdx.x / (sblocks * k);                       // (b*2 + c)*rgs + row group
     const int rg = (int)(r % rgs); r /= rgs; const int c = (int)(r % 2); const int b = (int)(r / 2);
     const u64 q = mods[i].q;
-    i8 *dimg = xr + (((size_t)i * n + s) * B + b) * img_stride + (size_t)c * poly_bytes;
-    for (int row = rg * RG; row < min(xd, rg * RG + RG); row++) {
+    const int lane = threadIdx.x & 63, qrow = threadIdx.x >> 6, row = rg * RG + qrow;
+    {
         u32 pl[NPL][8];
 #pragma unroll
         for (int l = 0; l < NPL; l++)
 #pragma unroll
             for (int wv = 0; wv < 8; wv++) pl[l][wv] = 0;
-        const u64 *src = x + ((((size_t)b * xd * yd + (size_t)row * yd) * 2 + c) * k + i) * (size_t)n + s;
+        if (row < xd) {
+            const u64 *src = x + ((((size_t)b * xd * yd + (size_t)row * yd) * 2 + c) * k + i) * (size_t)n + s0 + lane;
 #pragma unroll
-        for (int colx = 0; colx < 32; colx++)
-            if (colx < yd) {
-                u64 v = src[(size_t)colx * 2 * k * n];
-                if (packed) v = (v & 0xffffffffULL) | ((v >> 32) << 28);
-                const u64 dg = balanced_digit_bytes(v, q);         // the 7 balanced digits, one per byte
+            for (int colx = 0; colx < 32; colx++)
+                if (colx < yd) {
+                    u64 v = src[(size_t)colx * 2 * k * n];
+                    if (packed) v = (v & 0xffffffffULL) | ((v >> 32) << 28);
+                    const u64 dg = balanced_digit_bytes(v, q);         // the 7 balanced digits, one per byte
 #pragma unroll
-                for (int l = 0; l < NPL; l++) pl[l][colx >> 2] |= (u32)((dg >> (8 * l)) & 0xff) << (8 * (colx & 3));
-            }
-        i8 *drow = dimg + (size_t)row * 32;
+                    for (int l = 0; l < NPL; l++) pl[l][colx >> 2] |= (u32)((dg >> (8 * l)) & 0xff) << (8 * (colx & 3));
+                }
+        }
+        i8 *sp = st + (size_t)lane * (NPL * RG * 32) + qrow * 32;
 #pragma unroll
         for (int l = 0; l < NPL; l++) {
-            uint4 *o = reinterpret_cast<uint4 *>(drow + (size_t)l * plane_bytes);
+            uint4 *o = reinterpret_cast<uint4 *>(sp + l * (RG * 32));
             o[0] = make_uint4(pl[l][0], pl[l][1], pl[l][2], pl[l][3]); o[1] = make_uint4(pl[l][4], pl[l][5], pl[l][6], pl[l][7]);
         }
+    }
+    __syncthreads();
+    // 64 slots x 7 planes runs of RG * 32 bytes, 16 bytes per lane: eight adjacent lanes write one run (rows past xd of a ragged last group are not stored)
+    const int pieces_per_run = RG * 2, rows_here = min(RG, xd - rg * RG);
+    for (int o = threadIdx.x; o < 64 * NPL * pieces_per_run; o += 64 * RG) {
+        const int run = o / pieces_per_run, part = o - run * pieces_per_run, sl = run / NPL, l = run - sl * NPL;
+        if ((part >> 1) >= rows_here) continue;
+        i8 *dst = xr + (((size_t)i * n + s0 + sl) * B + b) * img_stride + (size_t)l * plane_bytes + (size_t)c * poly_bytes + (size_t)(rg * RG) * 32 + part * 16;
+        *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(st + (size_t)run * (RG * 32) + part * 16);
     }
 }
 // NTT-form weights w [F][1][xf][yf][k][n] -> Wl1 [slot][7 planes][32 filters][64 taps], tap = kx*8 + ky (pre-zeroed), each weight times 2^64 mod q (the Montgomery factor the
@@ -230,7 +246,7 @@ int k_limb_conv1(crc_ctx *c, const u64 *x, bool packed, i8 *xr, const i8 *wl, u6
     {
         const size_t blocks = (size_t)(c->n / 64) * c->k * B * 2 * ((xd + RG - 1) / RG);
         if (blocks > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
-        hipLaunchKernelGGL(limb_pack_rows1_kernel, dim3((unsigned)blocks), dim3(64), 0, st, x, xr, c->d_mods, c->n, c->k, B, xd, yd, packed ? 1 : 0, a.img_stride, a.plane_bytes,
+        hipLaunchKernelGGL(limb_pack_rows1_kernel, dim3((unsigned)blocks), dim3(64 * RG), 0, st, x, xr, c->d_mods, c->n, c->k, B, xd, yd, packed ? 1 : 0, a.img_stride, a.plane_bytes,
                            a.poly_bytes);
         HIPCHK(hipGetLastError());
     }
