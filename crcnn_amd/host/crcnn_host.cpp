@@ -47,7 +47,7 @@ struct BufferPool {
     std::mutex mu;
     std::list<std::pair<size_t, void *>> lru;               // oldest first
     size_t pooled = 0;
-    static constexpr size_t kCap = (size_t)128 << 30;
+    static constexpr size_t kCap = (size_t)128 << 30, kReserve = (size_t)16 << 30;
     void *take(size_t b)
     {
         std::lock_guard<std::mutex> g(mu);
@@ -60,6 +60,10 @@ struct BufferPool {
         std::lock_guard<std::mutex> g(mu);
         if (b > kCap) return false;
         while (pooled + b > kCap && !lru.empty()) { if (context) crc_free(context, lru.front().second); pooled -= lru.front().first; lru.pop_front(); }
+        // ... and the device keeps kReserve free for allocations that do not come through here (the HIP runtime's scratch for spilling kernels, RCCL)
+        size_t free_b = 0, total_b = 0;
+        while (context && crc_mem_info(context, &free_b, &total_b) >= 0 && free_b < kReserve && !lru.empty()) { crc_free(context, lru.front().second); pooled -= lru.front().first; lru.pop_front(); }
+        if (context && free_b < kReserve) return false;
         lru.emplace_back(b, p); pooled += b;
         return true;
     }

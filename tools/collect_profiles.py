@@ -2,7 +2,7 @@
 """Copy the outputs of tools/measure_round.sh (gpurun_out/final) into profiles/ under this round's names and derive the PMC traffic summary of the
 dominant launch that bench.py cites (roofline.traffic).  usage: collect_profiles.py r02"""
 import collections, csv, json, os, shutil, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 F = os.path.join(ROOT, "gpurun_out", "final"); P = os.path.join(ROOT, "profiles")
 
@@ -12,12 +12,15 @@ def cp(src, dst):
         shutil.copy(os.path.join(F, src), os.path.join(P, f"{R}_{dst}"))
 
 
-for c in ("tiny4096", "approx8192", "approx8192k4_b256", "wopad16384_b96", "wopad16384k8_b32"):
+for c in ("default_invocation", "tiny4096", "approx8192", "approx8192k4_b256", "wopad16384_b96", "wopad16384k8_b96"):
     cp(f"bench_{c}.json", f"bench_{c}.json")
 cp("prof_tiny/tiny_kernel_stats.csv", "bench_tiny4096_b256_kernel_stats.csv")
 cp("prof_approx/approx_kernel_stats.csv", "bench_approx8192_b96_kernel_stats.csv")
-cp("prof_sq/sq_kernel_stats.csv", "square_relin_8192k3_kernel_stats.csv")
 cp("prof_c1/c1_kernel_stats.csv", "conv1_4096k2_b128_kernel_stats.csv")
+for tag in ("8192_3_1250", "16384_4_512", "16384_8_256"):
+    cp(f"prof_square_{tag}.txt", f"square_relin_{tag}_kernels.txt"); cp(f"prof_square_old_{tag}.txt", f"square_relin_{tag}_kernels_round2_path.txt")
+cp("square_paths.txt", "square_relin_paths.txt")
+cp("../prof_sq_8192_3_1250/sq_8192_3_1250_kernel_stats.csv", "square_relin_8192k3_kernel_stats.csv")
 for src, dst in (("ntt_elementwise.txt", "ntt_elementwise_kernels.txt"), ("mac_geometries.txt", "mac_geometries.txt"), ("conv1.txt", "conv1_kernel.txt"), ("mfma_shape.txt", "mfma_shape.txt"),
                  ("square.txt", "square_relin_raw.txt")):
     if os.path.exists(os.path.join(F, src)):
@@ -67,6 +70,19 @@ try:
                                           "note": "wave-parked (s_waitcnt / barrier) = SQ_WAIT_ANY / SQ_WAVE_CYCLES, issue stall (MFMA pipe / dependency) = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES"}
     except Exception as e:
         print("no conv1 / issue-split summary:", e)
+    # Square + relinearise sequence (tools/pmc_square.sh): bytes per ciphertext, keyed by the bench configuration that runs on that ring
+    for tag, cfgs in (("8192_3_1250", ("approx8192",)), ("16384_4_512", ("wopad16384",)), ("16384_8_256", ("wopad16384k8",))):
+        try:
+            sm = json.load(open(os.path.join(F, f"pmc_square_{tag}.json")))
+            for cn in cfgs:
+                out[cn] = dict(kernel=f"Square + relinearise sequence (crc_square_relin_forms, n = {sm['config']['n']}, k = {sm['config']['k']})", per_ciphertext=True,
+                               traffic_bytes_per_ciphertext=sm["total"]["sum"], read_bytes_per_ciphertext=sm["total"]["read"], write_bytes_per_ciphertext=sm["total"]["write"],
+                               algorithmic_bytes_per_ciphertext=sm["total"]["algorithmic"], ratio_to_algorithmic=sm["total"]["ratio"], kernels=sm["kernels"],
+                               read_counter_calibration=sm["read_counter_calibration"],
+                               note="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over tools/bench_square.py (NTT form in and out); the read counter is calibrated on the "
+                                    "plain row inverse transform of the same run, whose bytes are known (8 B per lane reads: MI355X_MICROARCH.md gives the factor 2 for 16 B per lane only)")
+        except Exception as e:
+            print("no square PMC summary for", tag, e)
     json.dump(out, open(os.path.join(P, f"{R}_pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(out["tiny4096"])[:400])
 except Exception as e:

@@ -3,11 +3,12 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/final; mkdir -p $O
 P=${1:-all}
 if [ $P = all ] || [ $P = bench ]; then
-timeout -k 10 500 python bench.py --steps 5 --warmup 1 > $O/bench_tiny4096.json 2> $O/bench_tiny4096.err
+timeout -k 10 900 python bench.py --steps 5 --warmup 1 > $O/bench_default_invocation.json 2> $O/bench_default.err
+timeout -k 10 500 python bench.py --also none --steps 5 --warmup 1 > $O/bench_tiny4096.json 2> $O/bench_tiny4096.err
 timeout -k 10 500 python bench.py --config approx8192 --also none --steps 2 > $O/bench_approx8192.json 2> $O/bench_approx8192.err
 timeout -k 10 500 python bench.py --config approx8192k4 --also none --steps 1 --batch 256 > $O/bench_approx8192k4_b256.json 2> $O/bench_approx8192k4.err
 timeout -k 10 500 python bench.py --config wopad16384 --also none --steps 1 --batch 96 > $O/bench_wopad16384_b96.json 2> $O/bench_wopad.err
-timeout -k 10 500 python bench.py --config wopad16384k8 --also none --steps 1 --batch 32 --cpu-seconds 0 > $O/bench_wopad16384k8_b32.json 2> $O/bench_wopadk8.err
+timeout -k 10 700 python bench.py --config wopad16384k8 --also none --steps 1 --batch 96 --distinct 2 --cpu-seconds 0 --unfused-images 0 > $O/bench_wopad16384k8_b96.json 2> $O/bench_wopadk8.err
 fi
 if [ $P = all ] || [ $P = prof ]; then
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_tiny -o tiny -- python3 bench.py --cpu-seconds 0 --unfused-images 0 --also none --batch 256 > $O/prof_tiny.log 2>&1
@@ -20,6 +21,15 @@ timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
 timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_grbm -o g -- python3 tools/bench_mac.py conv2p 128 1 limbk > $O/pmc_grbm.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 tools/bench_mac.py conv2p 128 1 limbk > $O/pmc_fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 tools/bench_mac.py conv2p 128 1 limbk > $O/pmc_write.log 2>&1
+fi
+if [ $P = all ] || [ $P = square ]; then
+# Square + relinearise: per-kernel stats and PMC traffic at the three rings, and the round-2 key switching (CRC_RELIN_PATH=1) beside it
+for cfg in "8192 3 1250" "16384 4 512" "16384 8 256"; do tag=$(echo $cfg | tr ' ' '_')
+  bash tools/prof_square.sh "$cfg" sq_$tag 0 > $O/prof_square_$tag.txt 2>&1
+  bash tools/prof_square.sh "$cfg" sqold_$tag 1 > $O/prof_square_old_$tag.txt 2>&1
+  bash tools/pmc_square.sh "$cfg" $tag > $O/pmc_square_$tag.json 2> $O/pmc_square_$tag.err
+done
+(for cfg in "8192 3 1250" "8192 4 1250" "16384 4 512" "16384 8 256"; do for p in 1 0; do echo "relin_path=$p"; CRC_RELIN_PATH=$p python tools/bench_square.py $cfg 2>&1 | grep -v amdgpu; done; done) > $O/square_paths.txt
 fi
 if [ $P = all ] || [ $P = micro ]; then
 (python tools/bench_ntt.py 4096 2 8192; python tools/bench_ntt.py 8192 3 4096; python tools/bench_ntt.py 16384 4 1024) > $O/ntt_elementwise.txt 2>&1
