@@ -173,6 +173,8 @@ static void read_tuning(CrcTuning &t)
     t.relin_path = (int)geti("CRC_RELIN_PATH", 0);
     t.f64_radix = (int)geti("CRC_F64_RADIX", 0);
     t.mfma_min_steps = (int)geti("CRC_MFMA_MIN_STEPS", 0);
+    t.relin_mac_ct = (int)geti("CRC_RELIN_MAC_CT", 0);
+    t.ntt_split = (int)geti("CRC_NTT_SPLIT", 1);
 }
 extern "C" int crc_ctx_set_tuning(crc_ctx *c, const char *name, long long value)
 {
@@ -192,6 +194,8 @@ extern "C" int crc_ctx_set_tuning(crc_ctx *c, const char *name, long long value)
     else if (s == "relin_path") t.relin_path = (int)value;
     else if (s == "f64_radix") t.f64_radix = (int)value;
     else if (s == "mfma_min_steps") t.mfma_min_steps = (int)value;
+    else if (s == "relin_mac_ct") t.relin_mac_ct = (int)value;
+    else if (s == "ntt_split") t.ntt_split = (int)value;
     else return CRC_ERR_NOT_FOUND;             // (no_fold is baked into the tables at creation)
     return CRC_OK;
 }

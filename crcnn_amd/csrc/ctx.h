@@ -90,6 +90,8 @@ struct CrcTuning {
     int mac_order = -1;           // CRC_MAC_ORDER=0|1
     int mac_regstage = 0;         // CRC_MAC_REGSTAGE=1: register-staged mac2_kernel instead of the LDS-DMA mac3_kernel
     int mac2_dbg = 0;             // CRC_MAC2_DBG (only in -DCRC_TUNING builds)
+    int ntt_split = 1;            // CRC_NTT_SPLIT=0: rows of n = 16384 as one 128-KiB LDS image (one workgroup per CU) instead of two 64-KiB halves
+    int relin_mac_ct = 0;         // CRC_RELIN_MAC_CT=8: eight ciphertexts per thread in relin_mac_f64_kernel for k >= 4 (default 4)
     int mfma_min_steps = 0;       // CRC_MFMA_MIN_STEPS: reduction steps of 32 channels from which a conv / dense layer goes to the limb GEMM (0: 8)
     int f64_radix = 0;            // CRC_F64_RADIX=3|4|5: butterfly stages per LDS pass of the fp64 transforms (0: default)
     int relin_path = 0;           // CRC_RELIN_PATH=0: by parameters, 1: key switching over the coefficient moduli (round-2 path), 2: over the two fp64 primes

@@ -135,6 +135,138 @@ __device__ __forceinline__ void ntt_rows_body(const NttArgs &a)
 
 template <bool INV, bool LAZY, int PRO>
 __global__ void __launch_bounds__(1024) ntt_rows_kernel(NttArgs a) { ntt_rows_body<INV, LAZY, PRO>(a); }
+
+// n = 16384: a whole row is 128 KiB of LDS = ONE resident workgroup per CU, and nothing overlaps its loads, barriers and stores.  Split form: the row as two halves of
+// n/2 values that go through the SAME 64-KiB image one after the other (two workgroups per CU again).
+//   forward  stage 0 pairs j with j + n/2 (one twiddle, W[1]): it is applied while the half is staged -- half h takes X + W Y (h = 0) or X - W Y (h = 1), both source
+//            values read for each half (the second time from L2) -- and the remaining stages are the transform of n/2 points whose twiddle block index is (2 + h) m
+//            instead of m (global block I = h m' + i' of a stage with 2 m' blocks sits at table index 2 m' + I);
+//   inverse  the stages up to gap n/4 are two independent half transforms (again block index (2 + H) h'); the first half's result is parked in the destination row
+//            (written and re-read by the same threads), the last stage (one twiddle, W[1]) combines it with the second half straight out of the image.
+// Value ranges, prologues and epilogues are those of ntt_rows_body: the same butterflies in the same order, hence the same (canonical) results.
+template <bool INV, bool LAZY, int PRO>
+__device__ __forceinline__ void ntt_rows_split_body(const NttArgs &a)
+{
+    extern __shared__ u64 sm[];
+    const int n = a.n, n2 = n >> 1, logn2 = a.logn - 1, tid = threadIdx.x, nt = blockDim.x;
+    const size_t row = blockIdx.x;
+    const int mloc = (int)(row % a.mod_count);
+    const int mi = a.mod_base + mloc;
+    const ModParams m = a.mods[mi];
+    const u64 q = m.q, q2 = m.two_q, q4 = q2 + q2;
+    const float rq = 1.0f / (float)((u32)(q >> 32) + 1);
+    const ulonglong2 *W = a.w + (size_t)mi * n;
+    u64 *dst = a.dst + row * (size_t)n;
+    // ---- the value the transform reads at index s (the load prologues of ntt_rows_body)
+    const u64 *pa = nullptr, *pb = nullptr, *src = nullptr; int prod = 0, sh = 0;
+    if (INV && PRO == 4) {
+        const size_t ct = row / (3 * (size_t)a.mod_count); prod = (int)((row / a.mod_count) % 3);
+        pa = a.src + ((ct * 2 + (prod == 2 ? 1 : 0)) * a.mod_count + mloc) * (size_t)n;
+        pb = a.src + ((ct * 2 + (prod == 0 ? 0 : 1)) * a.mod_count + mloc) * (size_t)n;
+    } else if (!INV && PRO == 3) {
+        const size_t item = row / a.mod_count, ct = item / a.D; const int g = (int)(item % a.D);
+        src = a.src + ((ct * a.src_size + a.src_poly) * a.mod_count + a.dig_i[g]) * (size_t)n; sh = a.dig_shift[g];
+    } else {
+        const size_t srow = a.dst_ct_rows ? (row / a.dst_ct_rows) * a.src_ct_rows + row % a.dst_ct_rows : (a.src_rows_per_item ? (row / a.mod_count) : row);
+        src = a.src + srow * (size_t)n;
+    }
+    auto load = [&](int s) -> u64 {
+        if (INV && PRO == 4) { u64 v = mulmod(pa[s], pb[s], m); if (prod == 1) v = addmod(v, v, q); return v; }
+        if (!INV && PRO == 3) return (src[s] >> sh) & a.dig_mask;
+        u64 v = src[s];
+        if (a.prologue == 1) v = plain_lift(v, a.pp, mloc, m);
+        else if (a.prologue == 2) {
+            u64 lo, hi; mul64wide(a.pp.delta[mloc], v, lo, hi);
+            if (v >= a.pp.threshold) { u64 l2 = lo + a.pp.uhi[mloc]; hi += (l2 < lo); lo = l2; }
+            v = barrett128(lo, hi, m);
+        }
+        return v;
+    };
+    auto passes = [&](int h) {          // the half transform: n/2 points, twiddle block index (2 + h) m
+        const int full = logn2 / 3, rem = logn2 - 3 * full, tm = 2 + h;
+        if (!INV) {
+            int t = n2 >> 1;
+            for (int p = 0; p < full; p++, t >>= 3) ntt_pass<false, 3, LAZY>(sm, W, n2, t >> 2, tm * (n2 / (2 * t)), q, q2);
+            if (rem == 2) ntt_pass<false, 2, LAZY>(sm, W, n2, t >> 1, tm * (n2 / (2 * t)), q, q2);
+            else if (rem == 1) ntt_pass<false, 1, LAZY>(sm, W, n2, t, tm * (n2 / (2 * t)), q, q2);
+        } else {
+            int t = 1;
+            for (int p = 0; p < full; p++, t <<= 3) ntt_pass<true, 3, LAZY>(sm, W, n2, t, tm * (n2 / (2 * t)), q, q2);
+            if (rem == 2) ntt_pass<true, 2, LAZY>(sm, W, n2, t, tm * (n2 / (2 * t)), q, q2);
+            else if (rem == 1) ntt_pass<true, 1, LAZY>(sm, W, n2, t, tm * (n2 / (2 * t)), q, q2);
+        }
+    };
+    auto canon = [&](u64 v) -> u64 {
+        if (LAZY) return reduce_small(v, q, q2, rq);
+        v = v >= q2 ? v - q2 : v; return v >= q ? v - q : v;
+    };
+    const ulonglong2 tw = W[1];
+    if (!INV) {
+        const u64 *add = a.addend ? a.addend + row * (size_t)n : nullptr;
+        auto stage0 = [&](int h) {
+            for (int s = tid; s < n2; s += nt) {
+                u64 X = load(s); const u64 Y = load(s + n2);
+                u64 v;
+                if (LAZY) { const u64 Q = shoup_lazy4(Y, tw.x, tw.y, q); v = h ? X + (q4 - Q) : X + Q; }
+                else { X = X >= q2 ? X - q2 : X; const u64 Q = mulmod_shoup_lazy(Y, tw.x, tw.y, q); v = h ? X + (q2 - Q) : X + Q; }
+                sm[lpad(s)] = v;
+            }
+            __syncthreads();
+        };
+        // the transform may run in place (src == dst): nothing is stored before the second half has read its inputs -- the first half's result waits in registers
+        constexpr int NPT = 8;                          // n/2 = 8192 values on 1024 threads (the split form serves n = 16384 only)
+        u64 r0[NPT];
+        stage0(0);
+        passes(0);
+#pragma unroll
+        for (int u = 0; u < NPT; u++) { const int s = tid + u * nt; if (s < n2) r0[u] = canon(sm[lpad(s)]); }
+        __syncthreads();
+        stage0(1);
+#pragma unroll
+        for (int u = 0; u < NPT; u++) {
+            const int s = tid + u * nt;
+            if (s < n2) { u64 v = r0[u]; if (add) v = addmod(v, add[s], q); dst[s] = a.pack_out ? split28v(v) : v; }
+        }
+        passes(1);
+        for (int s = tid; s < n2; s += nt) {
+            u64 v = canon(sm[lpad(s)]);
+            if (add) v = addmod(v, add[n2 + s], q);
+            dst[n2 + s] = a.pack_out ? split28v(v) : v;
+        }
+    } else {
+        const u64 *add = nullptr;
+        if (a.addend) {
+            const size_t ct = row / a.rows_per_ct; const int p = (int)((row % a.rows_per_ct) / a.mod_count);
+            if (a.add_mode == 2) add = a.addend + ((ct * a.add_size + p) * a.mod_count + mloc) * (size_t)n;
+            else if (p == 0) { size_t g = ct / a.add_group; if (a.add_mod) g %= a.add_mod; add = a.addend + (g * a.mod_count + mloc) * (size_t)n; }
+        }
+        for (int s = tid; s < n2; s += nt) sm[lpad(s)] = load(s);
+        __syncthreads();
+        passes(0);
+        for (int s = tid; s < n2; s += nt) dst[s] = sm[lpad(s)];        // parked (lazy, below 2^63); read back by this very thread below
+        __syncthreads();
+        for (int s = tid; s < n2; s += nt) sm[lpad(s)] = load(s + n2);
+        __syncthreads();
+        passes(1);
+        const u64 q16 = q2 << 3;
+        for (int s = tid; s < n2; s += nt) {
+            const u64 U = dst[s], V = sm[lpad(s)];
+            u64 lo, hi;
+            if (LAZY) {
+                const u64 T = q16 - V + U, cu = U + V;
+                lo = (cu + ((cu & 1) ? q : 0)) >> 1; hi = shoup_lazy4(T, tw.x, tw.y, q);
+            } else {
+                const u64 T = q2 - V + U; u64 cu = U + V; cu = cu >= q2 ? cu - q2 : cu;
+                lo = (cu + ((cu & 1) ? q : 0)) >> 1; hi = mulmod_shoup_lazy(T, tw.x, tw.y, q);
+            }
+            lo = canon(lo); hi = canon(hi);
+            if (add) { if (a.add_sign > 0) { lo = addmod(lo, add[s], q); hi = addmod(hi, add[s + n2], q); } else { lo = submod(lo, add[s], q); hi = submod(hi, add[s + n2], q); } }
+            dst[s] = lo; dst[s + n2] = hi;
+        }
+    }
+}
+template <bool INV, bool LAZY, int PRO>
+__global__ void __launch_bounds__(1024, 8) ntt_rows_split_kernel(NttArgs a) { ntt_rows_split_body<INV, LAZY, PRO>(a); }
 // the inverse transform over the 61-bit auxiliary base (Harvey form, full 64 x 64 high products) allocates 68 VGPRs on its own: one 1024-thread workgroup
 // per CU at n = 8192.  Held to 64 (8 waves per SIMD = two workgroups per CU) it spills five dwords outside the butterfly loops and runs faster.
 template <int PRO>
@@ -217,6 +349,16 @@ static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t
     bool lazy = true;
     for (int i = a.mod_base; i < a.mod_base + a.mod_count; i++) if (c->tabs[i].m.bits > 57 || c->tabs[i].m.bits < 45) lazy = false;
     const int cus = c->cus;
+    if ((a.prologue == 3 && inv) || (a.prologue == 4 && !inv)) return CRC_ERR_INVALID_ARGUMENT;
+    if (c->n == 16384 && nt == 1024 && c->tune.ntt_split != 0) {                   // n = 16384: the row as two halves through a 64-KiB image -- two workgroups per CU (ntt_rows_split_body)
+        lds /= 2;
+        auto ks = a.prologue == 4 ? (lazy ? ntt_rows_split_kernel<true, true, 4> : ntt_rows_split_kernel<true, false, 4>)
+                : a.prologue == 3 ? (lazy ? ntt_rows_split_kernel<false, true, 3> : ntt_rows_split_kernel<false, false, 3>)
+                : inv ? (lazy ? ntt_rows_split_kernel<true, true, 0> : ntt_rows_split_kernel<true, false, 0>) : (lazy ? ntt_rows_split_kernel<false, true, 0> : ntt_rows_split_kernel<false, false, 0>);
+        hipLaunchKernelGGL(ks, dim3((unsigned)rows), dim3(nt), lds, st, a);
+        HIPCHK(hipGetLastError());
+        return CRC_OK;
+    }
     if (c->n / nt == 16 && rows > (size_t)cus && a.prologue < 3) {     // n = 16384: one resident workgroup per CU, prefetching the next row
         a.rows = rows;
         auto pk = inv ? (lazy ? ntt_rows_prefetch_kernel<true, true> : ntt_rows_prefetch_kernel<true, false>) : (lazy ? ntt_rows_prefetch_kernel<false, true> : ntt_rows_prefetch_kernel<false, false>);

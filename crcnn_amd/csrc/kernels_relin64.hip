@@ -100,19 +100,21 @@ __device__ __forceinline__ void ntt_tail_pass_f64(int rem, double *sm, const d2 
 // 2^52 (lazy sums of up to 48 products); every pass reduces on load.
 // (RB = stages per pass: 2^RB values per thread in registers between two LDS round trips.  The fp64 butterfly is a third of the 64-bit integer one's issue cycles, so
 // the LDS passes, their barriers and the twiddle loads weigh more here than in ntt_device.h: fewer, wider passes)
+// tm: twiddle block multiplier -- 1 for a whole row; 2 + h when the n points are half h of a 2n-point row whose stage 0 (forward) / last stage (inverse) is done by
+// the caller (global block I = h m' + i' of a stage with 2 m' blocks sits at table index 2 m' + I: kernels.hip ntt_rows_split_body)
 template <bool INV, int RB>
-__device__ __forceinline__ void ntt_row_passes_f64(double *sm, const d2 *W, int n, int logn, const F64Mod md)
+__device__ __forceinline__ void ntt_row_passes_f64(double *sm, const d2 *W, int n, int logn, const F64Mod md, int tm = 1)
 {
     const int full = logn / RB, rem = logn - RB * full;
     if (!INV) {
         // gaps n/2, n/4, ...: a pass of R stages starting at gap 2^lt works on groups of stride 2^(lt - R + 1); twiddle block index n / 2^(lt + 1)
         int lt = logn - 1;
-        for (int p = 0; p < full; p++, lt -= RB) ntt_pass_f64<false, RB, RB>(sm, W, n, lt - RB + 1, n >> (lt + 1), md, false);
-        if (rem) ntt_tail_pass_f64<false, RB>(rem, sm, W, n, lt - rem + 1, n >> (lt + 1), md);
+        for (int p = 0; p < full; p++, lt -= RB) ntt_pass_f64<false, RB, RB>(sm, W, n, lt - RB + 1, tm * (n >> (lt + 1)), md, false);
+        if (rem) ntt_tail_pass_f64<false, RB>(rem, sm, W, n, lt - rem + 1, tm * (n >> (lt + 1)), md);
     } else {
         int lt = 0;
-        for (int p = 0; p < full; p++, lt += RB) ntt_pass_f64<true, RB, RB>(sm, W, n, lt, n >> (lt + 1), md, true);
-        if (rem) ntt_tail_pass_f64<true, RB>(rem, sm, W, n, lt, n >> (lt + 1), md);
+        for (int p = 0; p < full; p++, lt += RB) ntt_pass_f64<true, RB, RB>(sm, W, n, lt, tm * (n >> (lt + 1)), md, true);
+        if (rem) ntt_tail_pass_f64<true, RB>(rem, sm, W, n, lt, tm * (n >> (lt + 1)), md);
     }
 }
 
@@ -149,7 +151,8 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024) relin_keys_f64_kernel(co
 
 // ---- K1: digits of c2' under both primes ---------------------------------------------------------------------------------------------------------------------------
 // src: size-`src_size` ciphertexts, poly `src_poly` = c2 (q/q_i)^-1 mod q_i (evaluator.cpp:984-985); E [ct][g][m][n], unreduced (|.| < 14 p)
-template <int RB>
+// SPLIT (n = 16384): the 128-KiB row as two halves through a 64-KiB image, stage 0 applied while a half is staged (two workgroups per CU; kernels.hip ntt_rows_split_body)
+template <int RB, bool SPLIT = false>
 __global__ void __launch_bounds__(RB == 5 ? 512 : 1024) relin_digits_f64_kernel(const u64 *src, int src_size, int src_poly, double *E, const d2 *Wf, F64Params fp, int n, int logn, int k, int D,
                                                                 int dbc, Relin64Tab tab)
 {
@@ -161,10 +164,25 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024) relin_digits_f64_kernel(
     for (int d = 0; d < L; d++) {
         const int sh = d * dbc;
         for (int m = 0; m < CRC_NF64; m++) {
+            double *dst = E + ((ct * D + g0 + d) * CRC_NF64 + m) * (size_t)n;
+            if (SPLIT) {
+                const int n2 = n >> 1;
+                const d2 tw = Wf[(size_t)m * n + 1];
+                for (int h = 0; h < 2; h++) {
+                    for (int s = threadIdx.x; s < n2; s += blockDim.x) {
+                        const double X = (double)(u32)((row[s] >> sh) & mask), T = f64_mulmod_const((double)(u32)((row[s + n2] >> sh) & mask), tw.x, tw.y, fp.m[m].p);
+                        smd[swz<RB>(s)] = h ? X - T : X + T;
+                    }
+                    __syncthreads();
+                    ntt_row_passes_f64<false, RB>(smd, Wf + (size_t)m * n, n2, logn - 1, fp.m[m], 2 + h);
+                    for (int s = threadIdx.x; s < n2; s += blockDim.x) dst[h * n2 + s] = smd[swz<RB>(s)];
+                    __syncthreads();
+                }
+                continue;
+            }
             for (int s = threadIdx.x; s < n; s += blockDim.x) smd[swz<RB>(s)] = (double)(u32)((row[s] >> sh) & mask);
             __syncthreads();
             ntt_row_passes_f64<false, RB>(smd, Wf + (size_t)m * n, n, logn, fp.m[m]);
-            double *dst = E + ((ct * D + g0 + d) * CRC_NF64 + m) * (size_t)n;
             for (int s = threadIdx.x; s < n; s += blockDim.x) dst[s] = smd[swz<RB>(s)];
             __syncthreads();
         }
@@ -215,8 +233,10 @@ __global__ void __launch_bounds__(256) relin_mac_f64_kernel(const double *E, con
 // ---- K3: inverse transforms, CRT lift, mod q_j, + (c0, c1) -------------------------------------------------------------------------------------------------------------
 // A [ct][poly k + j][m][n] (overwritten: the first prime's result is parked in its own row -- L2-hot when it is read back -- while the LDS image serves the second
 // transform); x3: size-`add_size` ciphertexts whose polys 0, 1 are added (coefficient form); y [ct][2][k][n].
-template <int RB, bool OUT_NTT, bool LAZY>
-__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 ? 8 : 4) relin_inv_crt_kernel(double *A, const u64 *x3, int add_size, u64 *y, const ModParams *mods, const d2 *Wi, const ulonglong2 *Wq, F64Params fp,
+// (ONE_PER_CU: the row image takes more than half of the LDS -- n = 16384 -- so one workgroup per CU is all there is and the register cap that buys the second
+// workgroup at n <= 8192 would only spill)
+template <int RB, bool OUT_NTT, bool LAZY, bool ONE_PER_CU = false>
+__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 && !ONE_PER_CU ? 8 : 4) relin_inv_crt_kernel(double *A, const u64 *x3, int add_size, u64 *y, const ModParams *mods, const d2 *Wi, const ulonglong2 *Wq, F64Params fp,
                                                                              int n, int logn, int k)
 {
     extern __shared__ double smd[];
@@ -314,11 +334,11 @@ int k_relin64_prepare_keys(crc_ctx *c, const u64 *evk, int dbc, u64 *kp, u64 *sc
     return CRC_OK;
 }
 
-template <int K>
+template <int K, int BIGCT = 4>
 static int relin64_mac(crc_ctx *c, const double *E, const double *Kf, double *A, int D, size_t cnt, hipStream_t st)
 {
     // accumulators: CT x PJ doubles per thread (32..48)
-    constexpr int PJ = 2 * K <= 8 ? 2 * K : (2 * K) % 8 == 0 ? 8 : (2 * K) % 6 == 0 ? 6 : (2 * K) % 5 == 0 ? 5 : 7, CT = PJ <= 4 ? 8 : PJ <= 6 ? 6 : 4, PJS = 2 * K / PJ;
+    constexpr int PJ = 2 * K <= 8 ? 2 * K : (2 * K) % 8 == 0 ? 8 : (2 * K) % 6 == 0 ? 6 : (2 * K) % 5 == 0 ? 5 : 7, CT = PJ <= 4 ? 8 : PJ <= 6 ? 6 : BIGCT, PJS = 2 * K / PJ;
     static_assert(PJ * PJS == 2 * K, "key columns must split evenly");
     const int threads = c->n < 256 ? c->n : 256, sblocks = c->n / threads;
     const size_t groups = (cnt + CT - 1) / CT;
@@ -333,7 +353,9 @@ static int relin64_tail(crc_ctx *c, double *A, const u64 *x3, int add_size, u64 
     bool lazy = true;
     for (int i = 0; i < c->k; i++) if (c->tabs[i].m.bits > 57 || c->tabs[i].m.bits < 45) lazy = false;
     const size_t lds = (size_t)c->n * 8;
-    auto kern = !out_ntt ? relin_inv_crt_kernel<RB, false, false> : lazy ? relin_inv_crt_kernel<RB, true, true> : relin_inv_crt_kernel<RB, true, false>;
+    const bool one = lds > 80 * 1024;
+    auto kern = one ? (!out_ntt ? relin_inv_crt_kernel<RB, false, false, true> : lazy ? relin_inv_crt_kernel<RB, true, true, true> : relin_inv_crt_kernel<RB, true, false, true>)
+                    : (!out_ntt ? relin_inv_crt_kernel<RB, false, false> : lazy ? relin_inv_crt_kernel<RB, true, true> : relin_inv_crt_kernel<RB, true, false>);
     { const int rc = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (rc) return rc; }
     hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * 2 * c->k)), dim3(f64_threads(c, RB)), lds, st, A, x3, add_size, y, c->d_mods, reinterpret_cast<const d2 *>(c->d_f64_irp),
                        reinterpret_cast<const ulonglong2 *>(c->d_rp), c->f64, c->n, c->logn, c->k);
@@ -358,14 +380,18 @@ int k_relinearize64(crc_ctx *c, const u64 *src, int src_size, int src_poly, cons
     const size_t lds = n * 8;
     const int RB = f64_radix(c);
     {
-        auto kern = RB == 3 ? relin_digits_f64_kernel<3> : RB == 4 ? relin_digits_f64_kernel<4> : relin_digits_f64_kernel<5>;
-        const int r2 = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (r2) return r2;
-        hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * k)), dim3(f64_threads(c, RB)), lds, st, src, src_size, src_poly, E, reinterpret_cast<const d2 *>(c->d_f64_rp), c->f64, c->n, c->logn,
+        // (the split form of the digit transforms -- two 64-KiB halves at n = 16384 -- measured SLOWER than the whole 128-KiB row, 18.4 against 17.7 us per ciphertext
+        // at k = 4: each half converts both source words again and the kernel is bound by instruction issue, not by occupancy; kept behind CRC_NTT_SPLIT=2 for tools/)
+        const bool split = RB == 3 && c->n == 16384 && c->tune.ntt_split == 2;
+        auto kern = split ? relin_digits_f64_kernel<3, true> : RB == 3 ? relin_digits_f64_kernel<3> : RB == 4 ? relin_digits_f64_kernel<4> : relin_digits_f64_kernel<5>;
+        const size_t ldsk = split ? lds / 2 : lds;
+        const int r2 = crc_ctx_ensure_lds(c, (const void *)kern, ldsk); if (r2) return r2;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * k)), dim3(f64_threads(c, RB)), ldsk, st, src, src_size, src_poly, E, reinterpret_cast<const d2 *>(c->d_f64_rp), c->f64, c->n, c->logn,
                            c->k, D, dbc, tab);
         HIPCHK(hipGetLastError());
     }
     switch (c->k) {
-#define MACK(KV) case KV: rc = relin64_mac<KV>(c, E, Kf, A, D, cnt, st); break;
+#define MACK(KV) case KV: rc = c->tune.relin_mac_ct == 8 ? relin64_mac<KV, 8>(c, E, Kf, A, D, cnt, st) : relin64_mac<KV, 4>(c, E, Kf, A, D, cnt, st); break;
     MACK(1) MACK(2) MACK(3) MACK(4) MACK(5) MACK(6) MACK(7) MACK(8)
 #undef MACK
     default: return CRC_ERR_UNSUPPORTED;
