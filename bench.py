@@ -478,7 +478,8 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
     want_fuse = args.mode == "resident" and not args.no_fuse
     tilewise = any(pl[3].get("tilewise") for pl in net.plan)       # (their limb weights would have to be built twice, before and after the folding: skipped)
     prod_ref = None
-    if want_fuse and full and args.unfused_images > 0 and not tilewise and world == 1:
+    est_w_gib = est_weights / 2**30
+    if want_fuse and full and args.unfused_images > 0 and not tilewise and world == 1 and est_w_gib < 60:      # (a SECOND encoded network is resident during this pass)
         # the reference's OWN layer structure (no folding: every CrCNN layer its own kernel sequence, NTT-resident) on the PRODUCTION kernels (matrix cores): the
         # reference's T_LAYER_0..N columns (mainparams.cpp:81) for this engine.  A second encoded network (the limb conversion drops the canonical weights that fuse()
         # needs), freed again before the main pass
@@ -507,9 +508,10 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
                         layers=[pl[1] for pl in net_r.plan],
                         mac_kernel_per_layer={pl[1]: {ca.NTTL: "mfma_mac2w_kernel", ca.NTTL1: "mfma_conv1_kernel"}.get(pl[3].get("w_form"), "mac3_kernel") for pl in net_r.plan if pl[0] in ("conv", "fc")},
                         note="ms per image and layer of the UNFUSED network in the column order of the reference's timing rows (mainparams.cpp:81), matrix-core kernels")
-        del net_r, lev
+        del net_r, lev, d_out
         del keep[mark:]
-        torch.cuda.empty_cache()
+        import gc
+        gc.collect(); torch.cuda.empty_cache()
     if want_fuse and full and args.unfused_images > 0 and not tilewise:
         Cu = min(C, 32)                                # the unfused conv1 output is 18 432 ciphertexts per image (Tiny): a smaller chunk than the main pass
         nu = min(B, max(Cu, args.unfused_images // Cu * Cu))
@@ -736,7 +738,9 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
         }
     # the same workload through the C++ host classes (crcnn_amd/host: the drop-in for the reference's Layer / Network / CnnBuilder) is measured by main() once this
     # engine has given its memory back: the distinct encrypted images go to a scratch file
-    if result is not None and full and world == 1 and args.host_cpp and q == ca.default_coeff_modulus_128(cfg["n"])[:cfg["k"]]:
+    # (the configurations whose encoded weights leave the C++ classes' per-call tensors room in HBM: PlainModelTiny -- the host classes allocate every layer's output
+    # through a recycling pool, and with 200 GiB of weights resident the pool has nothing to recycle from)
+    if result is not None and full and world == 1 and args.host_cpp and est_w_gib < 60 and q == ca.default_coeff_modulus_128(cfg["n"])[:cfg["k"]]:
         import tempfile
         hd = tempfile.mkdtemp(prefix="crc_host_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
         x_all[:D].cpu().numpy().tofile(os.path.join(hd, "inputs.u64"))

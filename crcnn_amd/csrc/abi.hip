@@ -352,8 +352,10 @@ extern "C" int crc_plan_mac(const crc_ctx *c, int zd, int xd, int yd, int xs, in
     // ... a full tile of rows for layers of fewer than 24 filters: the limb form pads the filters to 64, so a 10-filter layer -- CrCNN's fc4 -- spends 6x its canonical
     // bytes and 5/6 of its MFMAs on zeros (PlainModelWoPad's fc4 at 24 images: 14 GiB of weights, 0.16 against 0.11 ms per image on the vector-ALU kernel; with 64 rows
     // and more -- PlainModelTiny at 128 images, ApproxPlainModel at 32 -- it still wins, not least because the layer in front hands its tensor over in limb form)
+    // -- and only on the smaller rings (n k <= 32768), where those 6x are a few GB (28 GiB at n = 16384 with eight primes)
     const long long rows = (long long)B * 2 * P, min_rows = nf >= 24 ? 32 : 64;
-    if (zd >= 16 && (long long)((zd + 31) / 32) * xf * yf >= min_steps && crc_limb_supported(c, zd, xf, yf) && (B <= 0 || rows >= min_rows)) *w_form = CRC_NTTL;
+    const bool few_filters_ok = nf >= 24 || (long long)c->n * c->k <= 32768;
+    if (zd >= 16 && few_filters_ok && (long long)((zd + 31) / 32) * xf * yf >= min_steps && crc_limb_supported(c, zd, xf, yf) && (B <= 0 || rows >= min_rows)) *w_form = CRC_NTTL;
     return CRC_OK;
 }
 // should a (sum / average) pooling layer be folded into the convolution in front of it (crc_conv2d_fold_pool: exact)?  Cost in units of one multiply-accumulate

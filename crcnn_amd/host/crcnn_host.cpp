@@ -151,12 +151,23 @@ static shared_ptr<DeviceBuffer> uploadPlain(const vector<const Plaintext *> &pl,
 }
 
 // ---- tensors ----------------------------------------------------------------------------------------------------------
+// Network::forward's two ping-pong activation slots: the NEXT tensor constructed on this thread takes (and, if it is too small, replaces) the slot the hint points
+// at instead of a buffer of its own -- every layer constructs its output tensor first.  With 200 GiB of weights resident there is no room for a recycling pool, and a
+// hipMalloc / hipFree pair per layer costs more than most layers (PlainModelWoPad at n = 16384: 113 ms instead of 3.8 ms per image for conv1).
+static thread_local shared_ptr<DeviceBuffer> *g_out_hint = nullptr;
+
 ciphertext3D::ciphertext3D(int B, int zd, int xd, int yd, int form) : B(B), zd(zd), xd(xd), yd(yd), form(form)
 {
     size_t bytes = count() * ctBytes();
     if (form == CRC_NTTLC) { const size_t lb = crc_limb_tensor_bytes(ctx(), B, zd, xd, yd); if (lb > bytes) bytes = lb; }      // channels padded to 32
     // a dense consumer's limb tensor: every output a channel of ONE position, rounded up to 32 (7 bytes per residue: larger than the ciphertexts below 217 channels)
     if (form == CRC_NTTL) { const size_t lb = crc_limb_tensor_bytes(ctx(), B, zd * xd * yd, 1, 1); if (lb > bytes) bytes = lb; }
+    if (g_out_hint) {
+        shared_ptr<DeviceBuffer> *slot = g_out_hint; g_out_hint = nullptr;
+        if (!*slot || (*slot)->bytes < bytes) { slot->reset(); *slot = make_shared<DeviceBuffer>(bytes); }
+        buf = *slot;
+        return;
+    }
     buf = make_shared<DeviceBuffer>(bytes);
 }
 ciphertext3D ciphertext3D::fromHost(const uint64_t *h, int B, int zd, int xd, int yd)
@@ -698,7 +709,11 @@ ciphertext3D Network::forward(ciphertext3D input)
             input = stackImages(enc);
         }
         auto t0 = chrono::high_resolution_clock::now();
+        // every layer but the last writes into one of the network's two activation slots (the one its input does not live in); the last layer's output -- ten
+        // ciphertexts per image -- is the caller's own tensor, as in the reference
+        if (i + 1 < L) { const int s_in = input.buf == act_slot[0] ? 0 : input.buf == act_slot[1] ? 1 : -1; g_out_hint = &act_slot[s_in == 0 ? 1 : 0]; }
         input = layers[i]->forward(input);
+        g_out_hint = nullptr;
         chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
         last_layer_ms[i] = chrono::duration<double, milli>(chrono::high_resolution_clock::now() - t0).count();
     }

@@ -233,6 +233,7 @@ public:
     // refreshed and the layer repeated while refreshes are left, then OutOfBudgetException(i - 1) is thrown.  -1: plain forward.
     int max_num_of_reencryptions = -1;
     std::vector<double> last_layer_ms;                      // per-layer wall milliseconds of the last forward (T_LAYER_i, mainparams.cpp:81)
+    std::shared_ptr<DeviceBuffer> act_slot[2];              // the two ping-pong activation buffers forward() keeps across calls (sized by the largest layer output so far)
     Network() {}
     ~Network() {}
     int getNumLayers() { return (int)layers.size(); }
