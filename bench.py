@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--also", default="auto", help="a second workload measured in the same invocation and reported under \"also\" (auto: approx8192 = BASELINE "
                     "configs[2]/[3] beside the tiny4096 headline; none: skip)")
     ap.add_argument("--also-steps", type=int, default=2)
-    ap.add_argument("--host-cpp", type=int, default=1, help="1: also time the same workload through the C++ host classes (crcnn_amd/lib/bench_host) and check it against the Python twin")
+    ap.add_argument("--host-cpp", type=int, default=1, help="1: also time the same workload through the C++ host classes (crcnn_amd/lib/bench_host) and check it against the Python twin (models below 60 GiB of encoded weights; 2: any model)")
     ap.add_argument("--host-cpp-steps", type=int, default=3)
     ap.add_argument("--also-batch", type=int, default=None)
     ap.add_argument("--launch-check", action="store_true", help="only start the ranks, rendezvous (gloo, no GPU call) and report: CPU test of the self-launch path")
@@ -740,11 +740,11 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
     # engine has given its memory back: the distinct encrypted images go to a scratch file
     # (the configurations whose encoded weights leave the C++ classes' per-call tensors room in HBM: PlainModelTiny -- the host classes allocate every layer's output
     # through a recycling pool, and with 200 GiB of weights resident the pool has nothing to recycle from)
-    if result is not None and full and world == 1 and args.host_cpp and est_w_gib < 60 and q == ca.default_coeff_modulus_128(cfg["n"])[:cfg["k"]]:
+    if result is not None and full and world == 1 and args.host_cpp and (est_w_gib < 60 or args.host_cpp == 2) and q == ca.default_coeff_modulus_128(cfg["n"])[:cfg["k"]]:
         import tempfile
         hd = tempfile.mkdtemp(prefix="crc_host_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
         x_all[:D].cpu().numpy().tofile(os.path.join(hd, "inputs.u64"))
-        result["_host_job"] = dict(dir=hd, model=model, n=cfg["n"], k=cfg["k"], t=cfg["t"], distinct=D, batch=B, chunk=C, golden=GOLDEN_FOR.get(cfg_name),
+        result["_host_job"] = dict(dir=hd, model=model, n=cfg["n"], k=cfg["k"], t=cfg["t"], distinct=D, batch=B, chunk=C, group=G, golden=GOLDEN_FOR.get(cfg_name),
                                    golden_input_ok=bool(gold_ok is not None), python_images_per_s=result["value"])
     # give everything back before a second workload
     del net, x_all, out_all, outs, keep[:]
@@ -769,7 +769,7 @@ def host_cpp_leg(line, job, args):
         if not os.path.exists(exe):
             raise RuntimeError("crcnn_amd/lib/bench_host has not been built")
         p = subprocess.run([exe, job["model"], h5, str(job["n"]), str(job["k"]), str(job["t"]), os.path.join(job["dir"], "inputs.u64"), str(job["distinct"]), str(job["batch"]),
-                            str(job["chunk"]), str(steps), out0], capture_output=True, text=True, timeout=900)
+                            str(job["chunk"]), str(steps), out0, str(job["group"])], capture_output=True, text=True, timeout=900)
         if p.returncode != 0:
             raise RuntimeError(f"exit {p.returncode}: {p.stderr[-400:]}")
         r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])

@@ -445,7 +445,16 @@ extern "C" int crc_mem_info(crc_ctx *c, size_t *free_bytes, size_t *total_bytes)
     if (!c || c->device < 0 || !free_bytes || !total_bytes) return CRC_ERR_INVALID_ARGUMENT;
     HIPCHK(hipSetDevice(c->device)); HIPCHK(hipMemGetInfo(free_bytes, total_bytes)); return CRC_OK;
 }
-extern "C" int crc_malloc(crc_ctx *c, size_t bytes, void **p) { HIPCHK(hipSetDevice(c->device)); HIPCHK(hipMalloc(p, bytes)); return CRC_OK; }
+extern "C" int crc_malloc(crc_ctx *c, size_t bytes, void **p)
+{
+    HIPCHK(hipSetDevice(c->device));
+    if (hipMalloc(p, bytes) != hipSuccess) {
+        (void)hipGetLastError();        // a caller may free something and try again: do not leave the failure for the next launch check to find
+        *p = nullptr;
+        return CRC_ERR_HIP;
+    }
+    return CRC_OK;
+}
 extern "C" int crc_free(crc_ctx *c, void *p) { (void)c; HIPCHK(hipFree(p)); return CRC_OK; }
 extern "C" int crc_memcpy_h2d(crc_ctx *c, void *d, const void *h, size_t b, void *s) { (void)c; HIPCHK(hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice, (hipStream_t)s)); return CRC_OK; }
 extern "C" int crc_memcpy_d2h(crc_ctx *c, void *h, const void *d, size_t b, void *s) { (void)c; HIPCHK(hipMemcpyAsync(h, d, b, hipMemcpyDeviceToHost, (hipStream_t)s)); return CRC_OK; }

@@ -170,6 +170,14 @@ ciphertext3D::ciphertext3D(int B, int zd, int xd, int yd, int form) : B(B), zd(z
     }
     buf = make_shared<DeviceBuffer>(bytes);
 }
+ciphertext3D ciphertext3D::images(int b0, int count) const
+{
+    if (!buf || b0 < 0 || count < 1 || b0 + count > B) throw invalid_argument("ciphertext3D::images: range outside the batch");
+    if (form == CRC_NTTL || form == CRC_NTTLC) throw invalid_argument("ciphertext3D::images: a limb tensor is laid out for its whole batch");
+    ciphertext3D v; v.B = count; v.zd = zd; v.xd = xd; v.yd = yd; v.form = form; v.buf = buf;
+    v.offset = offset + (size_t)b0 * zd * xd * yd * ctBytes();
+    return v;
+}
 ciphertext3D ciphertext3D::fromHost(const uint64_t *h, int B, int zd, int xd, int yd)
 {
     ciphertext3D t(B, zd, xd, yd);
@@ -180,7 +188,7 @@ ciphertext3D ciphertext3D::fromHost(const uint64_t *h, int B, int zd, int xd, in
 vector<uint64_t> ciphertext3D::toHost() const
 {
     vector<uint64_t> h(count() * ctBytes() / 8);
-    chk(crc_memcpy_d2h(ctx(), h.data(), buf->ptr, h.size() * 8, nullptr), "crc_memcpy_d2h");
+    chk(crc_memcpy_d2h(ctx(), h.data(), data(), h.size() * 8, nullptr), "crc_memcpy_d2h");
     chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
     return h;
 }
@@ -191,14 +199,14 @@ ciphertext3D stackImages(const vector<ciphertext3D> &images)
     int B = 0; for (auto &im : images) { if (im.zd != f.zd || im.xd != f.xd || im.yd != f.yd || im.form != f.form) throw invalid_argument("image shapes differ"); B += im.B; }
     ciphertext3D t(B, f.zd, f.xd, f.yd, f.form);
     size_t off = 0;
-    for (auto &im : images) { chk(crc_memcpy_d2d(ctx(), (char *)t.buf->ptr + off, im.buf->ptr, im.count() * ctBytes(), nullptr), "crc_memcpy_d2d"); off += im.count() * ctBytes(); }
+    for (auto &im : images) { chk(crc_memcpy_d2d(ctx(), (char *)t.data() + off, im.data(), im.count() * ctBytes(), nullptr), "crc_memcpy_d2d"); off += im.count() * ctBytes(); }
     chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
     return t;
 }
 ciphertext3D deepCopyImage(const ciphertext3D &image)
 {
     ciphertext3D t(image.B, image.zd, image.xd, image.yd, image.form);
-    chk(crc_memcpy_d2d(ctx(), t.buf->ptr, image.buf->ptr, image.count() * ctBytes(), nullptr), "crc_memcpy_d2d");
+    chk(crc_memcpy_d2d(ctx(), t.data(), image.data(), image.count() * ctBytes(), nullptr), "crc_memcpy_d2d");
     return t;
 }
 
@@ -230,9 +238,14 @@ void setParameters(int poly_modulus, const vector<uint64_t> &coeff_modulus, uint
     chk(crc_memcpy_h2d(context, ev_keys16->ptr, ev_keys16_host.data(), ev_keys16_host.size() * 8, nullptr), "crc_memcpy_h2d");
     chk(crc_stream_sync(context, nullptr), "crc_stream_sync");
 }
+// One kernel scratch area for every layer of the process: layers run one after another on one stream, so their scratch never overlaps in
+// time, and the largest request decides the size (a per-layer buffer summed to ~40 GiB at WoPad 16384 beside the 182 GiB limb weights).
+static shared_ptr<DeviceBuffer> g_scratch;
+
 void delParameters()
 {
     ev_keys16.reset();
+    g_scratch.reset();
     g_pool.flush();
     if (context) { crc_ctx_destroy(context); context = nullptr; }
 }
@@ -337,7 +350,7 @@ floatCube decryptImage(const ciphertext3D &t)
 int noiseBudget(const ciphertext3D &t, size_t index)
 {
     vector<uint64_t> h(ctBytes() / 8);
-    chk(crc_memcpy_d2h(ctx(), h.data(), (char *)t.buf->ptr + index * ctBytes(), ctBytes(), nullptr), "crc_memcpy_d2h");
+    chk(crc_memcpy_d2h(ctx(), h.data(), (char *)t.data() + index * ctBytes(), ctBytes(), nullptr), "crc_memcpy_d2h");
     chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
     return crc_noise_budget(ctx(), secret_key.data(), h.data(), 2);
 }
@@ -401,14 +414,17 @@ static int plannedForm(int zd, int xd, int yd, int xs, int ys, int xf, int yf, i
 }
 // canonical NTT-form weights -> limb form (CRC_NTTL) when crc_plan_mac says the limb GEMM pays for this shape and launch size and the second copy fits beside the
 // first; the canonical copy is dropped
+static bool limbFits(int nf, int zd, int xf, int yf)
+{
+    size_t free_b = 0, total_b = 0;
+    chk(crc_mem_info(ctx(), &free_b, &total_b), "crc_mem_info");
+    return free_b >= crc_limb_weights_bytes(ctx(), nf, zd, xf, yf) + ((size_t)24 << 30);
+}
 static bool toLimb(shared_ptr<DeviceBuffer> &d_w, int &w_form, int nf, int zd, int xf, int yf, bool planned)
 {
     if (w_form == CRC_NTTL) return true;
-    if (!planned) return false;
+    if (!planned || !limbFits(nf, zd, xf, yf)) return false;
     const size_t nbytes = crc_limb_weights_bytes(ctx(), nf, zd, xf, yf);
-    size_t free_b = 0, total_b = 0;
-    chk(crc_mem_info(ctx(), &free_b, &total_b), "crc_mem_info");
-    if (free_b < nbytes + ((size_t)24 << 30)) return false;
     auto wl = make_shared<DeviceBuffer>(nbytes);
     chk(crc_limb_pack_weights(ctx(), (const uint64_t *)d_w->ptr, nf, zd, xf, yf, wl->ptr, nullptr), "crc_limb_pack_weights");
     chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
@@ -456,8 +472,11 @@ bool ConvolutionalLayer::limbWeights(int B)
     upload();
     if (streamed) return false;
     if (w_form == CRC_NTTL || w_form == CRC_NTTL1) return true;
-    if (w_form == CRC_NTTP) packWeights(true);
     const int planned = plannedForm(zd, xd, yd, xs, ys, xf, yf, nf, B);
+    // (decided BEFORE the weights are touched: a layer that stays on the vector-ALU kernel keeps its 28-bit packed weights -- unpacking and re-packing them on every
+    // forward() is a read-modify-write of the whole layer)
+    if (planned != CRC_NTTL1 && !(planned == CRC_NTTL && limbFits(nf, zd, xf, yf))) return false;
+    if (w_form == CRC_NTTP) packWeights(true);
     if (planned == CRC_NTTL1) {          // one-channel convolutions have their own matrix-core kernel (kernels_mfma1.hip)
         auto wl = make_shared<DeviceBuffer>(crc_limb_conv1_weights_bytes(ctx()));
         chk(crc_limb_conv1_pack_weights(ctx(), (const uint64_t *)d_w->ptr, nf, xf, yf, wl->ptr, nullptr), "crc_limb_conv1_pack_weights");
@@ -482,12 +501,12 @@ ciphertext3D ConvolutionalLayer::forward(ciphertext3D input)
     checkInput(input, zd, xd, yd, "ConvolutionalLayer");
     upload();
     ciphertext3D out(input.B, zo, xo, yo, out_form);
-    if (streamed) { forwardStreamed(input, out, zd, xd, yd, xs, ys, xf, yf, nf, out_form, d_plain, d_b, d_wtile, d_ytile, d_work); return out; }
+    if (streamed) { forwardStreamed(input, out, zd, xd, yd, xs, ys, xf, yf, nf, out_form, d_plain, d_b, d_wtile, d_ytile, g_scratch); return out; }
     size_t wb = crc_conv2d_forms_work_bytes(ctx(), input.B, zd, xd, yd, xs, ys, xf, yf, nf, input.form, w_form, out_form);
     if (!wb) throw invalid_argument("ConvolutionalLayer: unsupported geometry");
-    ensure(d_work, wb);
+    ensure(g_scratch, wb);
     chk(crc_conv2d_forms(ctx(), input.data(), (const uint64_t *)d_w->ptr, w_form, (const uint64_t *)d_b[out_form != CRC_COEFF]->ptr, input.B, zd, xd, yd, xs, ys, xf, yf, nf,
-                         input.form, out_form, out.data(), d_work->ptr, nullptr), "crc_conv2d_forms");
+                         input.form, out_form, out.data(), g_scratch->ptr, nullptr), "crc_conv2d_forms");
     if (out_form == CRC_NTTLC) out.form = CRC_NTTL;         // what the convolution behind reads as its limb-form input
     return out;
 }
@@ -520,9 +539,68 @@ void FullyConnectedLayer::upload()
     vector<const Plaintext *> w, b;
     for (int i = 0; i < out_dim; i++) { if ((int)weights[i].size() != in_dim) throw invalid_argument("fc: row length mismatch"); for (int j = 0; j < in_dim; j++) w.push_back(&weights[i][j]); b.push_back(&biases[i]); }
     streamed = tooLargeForHbm(w.size());
-    if (streamed) d_plain = uploadPlain(w, 3); else d_w = uploadPlain(w, 0);
+    if (!streamed && plannedForm(in_dim, 1, 1, 1, 1, 1, 1, out_dim, 0) == CRC_NTTL) {
+        // canonical + limb copy beyond what HBM has left, the limb copy alone within it: build the limb weights tile by tile at the first forward (buildTilewise)
+        size_t free_b = 0, total_b = 0;
+        chk(crc_mem_info(ctx(), &free_b, &total_b), "crc_mem_info");
+        const size_t canon = w.size() * (size_t)K() * N() * 8, limb = crc_limb_weights_bytes(ctx(), out_dim, in_dim, 1, 1), reserve = (size_t)24 << 30;
+        tilewise = (canon + limb + reserve > free_b && limb + reserve + ((size_t)8 << 30) <= free_b) || getenv("CRC_FORCE_TILEWISE") != nullptr;      // (the tests force it on small rings)
+    }
+    if (streamed) d_plain = uploadPlain(w, 3); else if (!tilewise) d_w = uploadPlain(w, 0);
     d_b[0] = uploadPlain(b, 1); d_b[1] = uploadPlain(b, 2);
     weights_already_ntt = true;
+}
+void FullyConnectedLayer::buildTilewise()
+{
+    if (tile_built) return;
+    const int n = N(), k = K();
+    const size_t rowb = (size_t)k * n * 8, T = (size_t)in_dim;
+    d_w = make_shared<DeviceBuffer>(crc_limb_weights_bytes(ctx(), out_dim, in_dim, 1, 1));
+    const int ft = (int)max<size_t>(1, min<size_t>((size_t)out_dim, ((size_t)4 << 30) / (T * rowb)));
+    shared_ptr<DeviceBuffer> fake, outc, wk;
+    vector<uint64_t> bias, corr, q(k);
+    int ch = 0, per_ch = 0;
+    if (fold_bn) {
+        ch = fold_bn->num_channels; per_ch = in_dim / ch;
+        fake = make_shared<DeviceBuffer>(T * 2 * rowb); outc = make_shared<DeviceBuffer>((size_t)ft * 2 * rowb);
+        wk = make_shared<DeviceBuffer>(max<size_t>(crc_dense_work_bytes(ctx(), 1, in_dim, ft, CRC_NTT), 256));
+        chk(crc_memset(ctx(), fake->ptr, 0, T * 2 * rowb, nullptr), "crc_memset");
+        for (int z = 0; z < ch; z++) for (int t = 0; t < per_ch; t++)
+            chk(crc_memcpy_d2d(ctx(), (char *)fake->ptr + ((size_t)z * per_ch + t) * 2 * rowb, (char *)fold_bn->d_mean[1]->ptr + (size_t)z * rowb, rowb, nullptr), "crc_memcpy_d2d");
+        bias.resize((size_t)out_dim * k * n); corr.resize((size_t)ft * 2 * k * n);
+        chk(crc_memcpy_d2h(ctx(), bias.data(), d_b[1]->ptr, bias.size() * 8, nullptr), "crc_memcpy_d2h");
+        chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+        chk(crc_ctx_table(ctx(), "q", q.data(), k) < 0 ? CRC_ERR_INVALID_ARGUMENT : CRC_OK, "crc_ctx_table");
+    }
+    for (int f0 = 0; f0 < out_dim; f0 += ft) {
+        const int fn = min(ft, out_dim - f0);
+        vector<const Plaintext *> w;
+        for (int i = f0; i < f0 + fn; i++) for (int j = 0; j < in_dim; j++) w.push_back(&weights[i][j]);
+        shared_ptr<DeviceBuffer> wt = uploadPlain(w, 0);                                   // lift + NTT of the tile's plaintexts (canonical, scratch)
+        if (fold_bn) {
+            for (int f = 0; f < fn; f++)                                                   // w'[f][z][tap] = w (*) s[z]
+                chk(crc_multiply_plain_ntt(ctx(), (uint64_t *)wt->ptr + (size_t)f * T * k * n, (const uint64_t *)fold_bn->d_invstd->ptr, T, per_ch, 1, nullptr), "crc_multiply_plain_ntt");
+            chk(crc_dense(ctx(), (const uint64_t *)fake->ptr, (const uint64_t *)wt->ptr, nullptr, 1, in_dim, fn, CRC_NTT, CRC_NTT, (uint64_t *)outc->ptr, wk->ptr, nullptr), "crc_dense");
+            chk(crc_memcpy_d2h(ctx(), corr.data(), outc->ptr, (size_t)fn * 2 * rowb, nullptr), "crc_memcpy_d2h");
+            chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+            for (int f = 0; f < fn; f++) for (int m = 0; m < k; m++) for (int s2 = 0; s2 < n; s2++) {
+                uint64_t &b = bias[((size_t)(f0 + f) * k + m) * n + s2]; const uint64_t c = corr[(((size_t)f * 2) * k + m) * n + s2];
+                b = b >= c ? b - c : b + q[m] - c;
+            }
+        }
+        chk(crc_limb_pack_weights_tile(ctx(), (const uint64_t *)wt->ptr, out_dim, f0, fn, in_dim, 1, 1, d_w->ptr, nullptr), "crc_limb_pack_weights_tile");
+        chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+    }
+    if (fold_bn) {
+        d_b[1] = make_shared<DeviceBuffer>(bias.size() * 8);
+        chk(crc_memcpy_h2d(ctx(), d_b[1]->ptr, bias.data(), bias.size() * 8, nullptr), "crc_memcpy_h2d");
+        chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+        d_b[0] = make_shared<DeviceBuffer>(bias.size() * 8);
+        chk(crc_memcpy_d2d(ctx(), d_b[0]->ptr, d_b[1]->ptr, bias.size() * 8, nullptr), "crc_memcpy_d2d");
+        chk(crc_ntt_inv(ctx(), (uint64_t *)d_b[0]->ptr, (size_t)out_dim, 1, nullptr), "crc_ntt_inv");
+        chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+    }
+    w_form = CRC_NTTL; tile_built = true;
 }
 void FullyConnectedLayer::deviceParameters(vector<shared_ptr<DeviceBuffer>> &out, bool allocate_only)
 {
@@ -537,11 +615,20 @@ void FullyConnectedLayer::deviceParameters(vector<shared_ptr<DeviceBuffer>> &out
     if (streamed && !d_plain) d_plain = make_shared<DeviceBuffer>((size_t)in_dim * out_dim * N() * 8);
     out.push_back(streamed ? d_plain : d_w); out.push_back(d_b[0]); out.push_back(d_b[1]);
 }
-bool FullyConnectedLayer::limbWeights(int B) { upload(); if (streamed) return false; if (w_form == CRC_NTTL) return true; if (w_form == CRC_NTTP) packWeights(true); return toLimb(d_w, w_form, out_dim, in_dim, 1, 1, plannedForm(in_dim, 1, 1, 1, 1, 1, 1, out_dim, B) == CRC_NTTL); }
+bool FullyConnectedLayer::limbWeights(int B)
+{
+    upload();
+    if (streamed) return false;
+    if (tilewise) { buildTilewise(); return true; }
+    if (w_form == CRC_NTTL) return true;
+    if (plannedForm(in_dim, 1, 1, 1, 1, 1, 1, out_dim, B) != CRC_NTTL || !limbFits(out_dim, in_dim, 1, 1)) return false;      // (before the packed weights are touched)
+    if (w_form == CRC_NTTP) packWeights(true);
+    return toLimb(d_w, w_form, out_dim, in_dim, 1, 1, true);
+}
 void FullyConnectedLayer::packWeights(bool unpack)
 {
     upload();
-    if (streamed) return;
+    if (streamed || (tilewise && !tile_built)) return;
     if (w_form == CRC_NTTL) { if (unpack) throw logic_error("FullyConnectedLayer " + name + ": weights are in limb form (fuse() / broadcastParameters() must precede the first forward())"); return; }
     if ((w_form == CRC_NTTP) == !unpack) return;
     chk(crc_pack28(ctx(), (uint64_t *)d_w->ptr, (size_t)in_dim * out_dim * K(), unpack ? 1 : 0, nullptr), "crc_pack28");
@@ -552,10 +639,10 @@ ciphertext3D FullyConnectedLayer::forward(ciphertext3D input)
     if (!input.buf || input.zd * input.xd * input.yd != in_dim) throw invalid_argument("FullyConnectedLayer: input size does not match in_dim");   // reshapeInput, :38-56
     upload();
     ciphertext3D out(input.B, 1, out_dim, 1, out_form);
-    if (streamed) { forwardStreamed(input, out, in_dim, 1, 1, 1, 1, 1, 1, out_dim, out_form, d_plain, d_b, d_wtile, d_ytile, d_work); return out; }
-    ensure(d_work, crc_conv2d_forms_work_bytes(ctx(), input.B, in_dim, 1, 1, 1, 1, 1, 1, out_dim, input.form, w_form, out_form));
+    if (streamed) { forwardStreamed(input, out, in_dim, 1, 1, 1, 1, 1, 1, out_dim, out_form, d_plain, d_b, d_wtile, d_ytile, g_scratch); return out; }
+    ensure(g_scratch, crc_conv2d_forms_work_bytes(ctx(), input.B, in_dim, 1, 1, 1, 1, 1, 1, out_dim, input.form, w_form, out_form));
     chk(crc_dense_forms(ctx(), input.data(), (const uint64_t *)d_w->ptr, w_form, (const uint64_t *)d_b[out_form != CRC_COEFF]->ptr, input.B, in_dim, out_dim, input.form, out_form,
-                        out.data(), d_work->ptr, nullptr), "crc_dense_forms");
+                        out.data(), g_scratch->ptr, nullptr), "crc_dense_forms");
     return out;
 }
 void FullyConnectedLayer::savePlaintextParameters(ostream *outfile)
@@ -601,8 +688,8 @@ ciphertext3D SquareLayer::forward(ciphertext3D input)
     if (!ev_keys16) throw invalid_argument("not enough evaluation keys");
     // either form in, the requested form out: crc_square_relin_forms keeps an NTT-resident network resident
     ciphertext3D out(input.B, input.zd, input.xd, input.yd, out_form);
-    ensure(d_work, crc_square_relin_work_bytes(ctx(), input.count(), 16));
-    chk(crc_square_relin_forms(ctx(), input.data(), input.form, input.count(), (const uint64_t *)ev_keys16->ptr, 16, out.data(), out_form, d_work->ptr, nullptr),
+    ensure(g_scratch, crc_square_relin_work_bytes(ctx(), input.count(), 16));
+    chk(crc_square_relin_forms(ctx(), input.data(), input.form, input.count(), (const uint64_t *)ev_keys16->ptr, 16, out.data(), out_form, g_scratch->ptr, nullptr),
         "crc_square_relin_forms");
     return out;
 }
@@ -663,16 +750,23 @@ ciphertext3D Network::forward(ciphertext3D input)
     { vector<uint64_t> q(K()); crc_ctx_table(ctx(), "q", q.data(), K()); for (uint64_t v : q) if (v >> 55) packable = false; }
     auto isMac = [&](int i) { return i >= 0 && i < L && (dynamic_pointer_cast<ConvolutionalLayer>(layers[i]) || dynamic_pointer_cast<FullyConnectedLayer>(layers[i])); };
     vector<char> limb(L, 0);
+    // two-level chunking: the layers in front of the first dense layer on sub-batches of head_chunk images, the dense layers on the whole batch
+    int split = L;
+    if (head_chunk > 0 && input.B > head_chunk && ntt_resident && max_num_of_reencryptions < 0 && layer_before_reenc < 0)
+        for (int i = 1; i < L; i++) if (dynamic_pointer_cast<FullyConnectedLayer>(layers[i])) { split = i; break; }
+    const bool chunked = split < L;
     if (packable)
         for (int i = 0; i < L; i++) {
-            if (auto c = dynamic_pointer_cast<ConvolutionalLayer>(layers[i])) { limb[i] = matrix_cores && c->limbWeights(input.B); if (!limb[i]) c->packWeights(false); }
-            else if (auto f = dynamic_pointer_cast<FullyConnectedLayer>(layers[i])) { limb[i] = matrix_cores && f->limbWeights(input.B); if (!limb[i]) f->packWeights(false); }
+            const int Bi = chunked && i < split ? head_chunk : input.B;
+            if (auto c = dynamic_pointer_cast<ConvolutionalLayer>(layers[i])) { limb[i] = matrix_cores && c->limbWeights(Bi); if (!limb[i]) c->packWeights(false); }
+            else if (auto f = dynamic_pointer_cast<FullyConnectedLayer>(layers[i])) { limb[i] = matrix_cores && f->limbWeights(Bi); if (!limb[i]) f->packWeights(false); }
         }
     for (int i = 0; i < L; i++) {
         bool coeff = !ntt_resident || i == L - 1 || i + 1 == layer_before_reenc;
         // a conv / dense layer feeding another one hands its tensor over packed as well
-        // ... and a limb layer feeding a DENSE limb layer hands it over in limb form
-        const bool to_dense_limb = i + 1 < L && limb[i] && limb[i + 1] && dynamic_pointer_cast<FullyConnectedLayer>(layers[i + 1]);
+        // ... and a limb layer feeding a DENSE limb layer hands it over in limb form (not across the chunk boundary: a dense layer's limb tensor is laid out for its
+        // whole batch, the chunks are assembled into it below)
+        const bool to_dense_limb = i + 1 < L && limb[i] && limb[i + 1] && dynamic_pointer_cast<FullyConnectedLayer>(layers[i + 1]) && !(chunked && i + 1 == split);
         // ... and a one-channel convolution writes the limb tensor of a matrix-core CONVOLUTION behind it itself
         auto ci = dynamic_pointer_cast<ConvolutionalLayer>(layers[i]);
         auto cn = i + 1 < L ? dynamic_pointer_cast<ConvolutionalLayer>(layers[i + 1]) : nullptr;
@@ -702,7 +796,37 @@ ciphertext3D Network::forward(ciphertext3D input)
         }
         return input;
     }
-    for (int i = 0; i < L; i++) {
+    int first = 0;
+    if (chunked) {
+        const int B = input.B;
+        ciphertext3D tail_in;
+        for (int b0 = 0; b0 < B; b0 += head_chunk) {
+            const int Bc = min(head_chunk, B - b0);
+            ciphertext3D t = input.images(b0, Bc);
+            for (int i = 0; i < split; i++) {
+                auto t0 = chrono::high_resolution_clock::now();
+                { const int s_in = t.buf == act_slot[0] ? 0 : t.buf == act_slot[1] ? 1 : -1; g_out_hint = &act_slot[s_in == 0 ? 1 : 0]; }
+                t = layers[i]->forward(t);
+                g_out_hint = nullptr;
+                chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+                last_layer_ms[i] += chrono::duration<double, milli>(chrono::high_resolution_clock::now() - t0).count();
+            }
+            const size_t out_cts = (size_t)t.zd * t.xd * t.yd;
+            if (!tail_in.buf) {         // kept across calls like the activation slots: next to 182 GiB of weights the pool has no room to hold it
+                g_out_hint = &tail_slot;
+                tail_in = ciphertext3D(B, t.zd, t.xd, t.yd, limb[split] ? CRC_NTTL : t.form);
+                g_out_hint = nullptr;
+            }
+            if (limb[split])      // every chunk's tensor goes straight into the dense layer's K-blocked limb tensor
+                chk(crc_limb_pack_tensor_at(ctx(), t.data(), t.form, Bc, (int)out_cts, 1, 1, tail_in.data(), B, b0, nullptr), "crc_limb_pack_tensor_at");
+            else
+                chk(crc_memcpy_d2d(ctx(), (char *)tail_in.data() + (size_t)b0 * out_cts * ctBytes(), t.data(), (size_t)Bc * out_cts * ctBytes(), nullptr), "crc_memcpy_d2d");
+        }
+        chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+        input = tail_in;
+        first = split;
+    }
+    for (int i = first; i < L; i++) {
         if (i == layer_before_reenc) {                      // client-side refresh (needs the secret key), network.cpp:30-34
             vector<floatCube> imgs = decryptImages(input);
             vector<ciphertext3D> enc; for (auto &im : imgs) enc.push_back(encryptImage(im));
@@ -810,6 +934,14 @@ int Network::fuse()
         if (conv) { if (conv->zd != ch) continue; F = conv->nf; per_ch = conv->xf * conv->yf; T = conv->zd * per_ch; conv->upload(); if (conv->streamed) continue; }
         else { if (fc->in_dim % ch) continue; F = fc->out_dim; per_ch = fc->in_dim / ch; T = fc->in_dim; fc->upload(); if (fc->streamed) continue; }
         bn->upload();
+        if (fc && fc->tilewise) {                           // no canonical weights to fold into: the fold is applied tile by tile when the limb weights are built
+            if (fc->tile_built) continue;
+            fc->fold_bn = bn;
+            layers[i + 1]->name = bn->name + "+" + layers[i + 1]->name;
+            layers.erase(layers.begin() + i);
+            removed++;
+            continue;
+        }
         shared_ptr<DeviceBuffer> &dw = conv ? conv->d_w : fc->d_w;
         shared_ptr<DeviceBuffer> *db = conv ? conv->d_b : fc->d_b;
         // w'[f][z][tap] = w (*) s[z]

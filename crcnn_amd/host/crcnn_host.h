@@ -42,10 +42,12 @@ class ciphertext3D {          // device tensor of size-2 ciphertexts, [B][zd][xd
 public:
     int B = 0, zd = 0, xd = 0, yd = 0, form = CRC_COEFF;
     std::shared_ptr<DeviceBuffer> buf;
+    size_t offset = 0;        // bytes into buf: images() hands out views of a batch without copying it
     ciphertext3D() {}
     ciphertext3D(int B, int zd, int xd, int yd, int form = CRC_COEFF);
     size_t count() const { return (size_t)B * zd * xd * yd; }
-    uint64_t *data() const { return buf ? (uint64_t *)buf->ptr : nullptr; }
+    uint64_t *data() const { return buf ? (uint64_t *)((char *)buf->ptr + offset) : nullptr; }
+    ciphertext3D images(int b0, int count) const;             // view of images [b0, b0 + count) (ciphertext forms only)
     // CrCNN code indexes input[0].size() etc.; the equivalents:
     int size() const { return zd; }
     static ciphertext3D fromHost(const uint64_t *h, int B, int zd, int xd, int yd);    // h: [B][zd][xd][yd][2][k][n]
@@ -99,6 +101,7 @@ public:
     virtual void deviceParameters(std::vector<std::shared_ptr<DeviceBuffer>> &out, bool allocate_only) { (void)out; (void)allocate_only; }
 };
 
+class BatchNormLayer;
 class ConvolutionalLayer : public Layer {                   // convolutionalLayer.h:33-34
 public:
     friend class Network;
@@ -116,7 +119,7 @@ public:
     void loadPlaintextParameters(std::istream *infile) override;
     void printLayerStructure() override;
 private:
-    std::shared_ptr<DeviceBuffer> d_w, d_b[2], d_work;      // NTT-form weights, bias delta in coefficient / NTT form
+    std::shared_ptr<DeviceBuffer> d_w, d_b[2];              // NTT-form weights, bias delta in coefficient / NTT form
     // weights whose NTT form (k rows each) would take more than 75 % of HBM stay coefficient-form plaintexts (ONE row each) and are lifted + transformed a
     // ~2-GiB filter tile at a time inside every forward (SURVEY section 7's fall-back; PlainModelWoPad's fc3 with all eight primes of n = 16384 is 419 GB)
     bool streamed = false;
@@ -146,10 +149,16 @@ public:
     void loadPlaintextParameters(std::istream *infile) override;
     void printLayerStructure() override;
 private:
-    std::shared_ptr<DeviceBuffer> d_w, d_b[2], d_work;
+    std::shared_ptr<DeviceBuffer> d_w, d_b[2];
     bool streamed = false;                                  // see ConvolutionalLayer
     std::shared_ptr<DeviceBuffer> d_plain, d_wtile, d_ytile;
     int w_form = CRC_NTT;
+    // A layer whose canonical NTT-form weights and their limb copy do not fit in HBM together (PlainModelWoPad's fc3 at n = 16384, k = 4: 202 + 182 GiB) never gets a
+    // canonical copy: its limb weights are built a tile of output rows at a time straight from the plaintexts (lift + NTT -> batch-norm fold of the tile -> pack), a
+    // batch-norm layer that Network::fuse() folds into it being applied to every tile (same ciphertexts; netrun.py does the same)
+    bool tilewise = false, tile_built = false;
+    std::shared_ptr<BatchNormLayer> fold_bn;
+    void buildTilewise();
     void upload();
     void packWeights(bool unpack);
     bool limbWeights(int B);
@@ -185,12 +194,12 @@ public:
     void loadPlaintextParameters(std::istream *) override {}
     void printLayerStructure() override;
 private:
-    std::shared_ptr<DeviceBuffer> d_work;
 };
 
 class BatchNormLayer : public Layer {                       // batchNormLayer.h:18-20
 public:
     friend class Network;
+    friend class FullyConnectedLayer;
     int num_channels;
     std::vector<Plaintext> mean, var;                       // var already holds encode(1/sqrt(var+1e-5)) (cnnBuilder.cpp:100-102)
     BatchNormLayer(std::string name, int num_channels, std::vector<Plaintext> &mean, std::vector<Plaintext> &var);
@@ -233,6 +242,11 @@ public:
     // refreshed and the layer repeated while refreshes are left, then OutOfBudgetException(i - 1) is thrown.  -1: plain forward.
     int max_num_of_reencryptions = -1;
     std::vector<double> last_layer_ms;                      // per-layer wall milliseconds of the last forward (T_LAYER_i, mainparams.cpp:81)
+    // Two-level chunking (> 0): the layers in front of the first dense layer run on sub-batches of `head_chunk` images, the dense layers once on the whole batch -- a
+    // dense layer streams all of its weights per launch, so its time per image falls with the rows it is used for (PlainModelWoPad at n = 16384: 6-image chunks fit
+    // beside 190 GiB of weights, fc3 wants 24+ images).  0: every layer on the whole batch
+    int head_chunk = 0;
+    std::shared_ptr<DeviceBuffer> tail_slot;                // ... and the dense layers' whole-batch input under two-level chunking
     std::shared_ptr<DeviceBuffer> act_slot[2];              // the two ping-pong activation buffers forward() keeps across calls (sized by the largest layer output so far)
     Network() {}
     ~Network() {}

@@ -15,14 +15,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DRIVER = os.path.join(ROOT, "crcnn_amd", "lib", "test_host")
 
 
-def run_driver(name, resident, batch=1, fuse=False):
+def run_driver(name, resident, batch=1, fuse=False, head_chunk=0, env=None):
     g = load_net_golden(name)
     O, sk, pk, evk, img, x = make_inputs(g)
     d = tempfile.mkdtemp()
     np.array([g["n"], len(g["q"]), g["t"]] + g["q"], dtype=np.uint64).tofile(os.path.join(d, "params.u64"))
     evk.tofile(os.path.join(d, "evk.u64")); x.tofile(os.path.join(d, "net_in.u64"))
     h5 = os.path.join(GOLD, "models", g["model"] + ".h5")
-    subprocess.check_call([DRIVER, "net", g["model"], h5, d, "1" if resident else "0", str(batch), "1" if fuse else "0"])
+    subprocess.check_call([DRIVER, "net", g["model"], h5, d, "1" if resident else "0", str(batch), "1" if fuse else "0", str(head_chunk)], env=dict(os.environ, **(env or {})))
     return g, O, d
 
 
@@ -112,6 +112,16 @@ def test_cpp_network_fused_equals_reference(name):
     g, O, d = run_driver(name, resident=True, batch=2, fuse=True)
     out = np.fromfile(os.path.join(d, "out.u64"), dtype=np.uint64).reshape(2, -1)
     assert sha(out[0]) == g["out_sha256"] and sha(out[1]) == g["out_sha256"]
+
+
+@pytest.mark.parametrize("name", ["wopad256", "tiny256"])
+def test_cpp_two_level_chunking_and_tilewise_weights(name):
+    """Network::head_chunk (the layers in front of the first dense layer on sub-batches, the dense layers once on the whole batch, every chunk packed straight into the
+    dense layer's limb tensor) and FullyConnectedLayer's tile-wise limb weights with the batch-norm fold applied per tile (forced on the small ring: at n = 16384 the
+    canonical and the limb copy of PlainModelWoPad's fc3 do not fit in HBM together) -- 16 images in chunks of 3 (a ragged last chunk), each one the reference's ciphertexts"""
+    g, O, d = run_driver(name, resident=True, batch=16, fuse=True, head_chunk=3, env={"CRC_FORCE_TILEWISE": "1"})
+    out = np.fromfile(os.path.join(d, "out.u64"), dtype=np.uint64).reshape(16, -1)
+    assert all(sha(out[b]) == g["out_sha256"] for b in range(16))
 
 
 def test_cpp_example_driver():
