@@ -738,8 +738,8 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
         }
     # the same workload through the C++ host classes (crcnn_amd/host: the drop-in for the reference's Layer / Network / CnnBuilder) is measured by main() once this
     # engine has given its memory back: the distinct encrypted images go to a scratch file
-    # (the configurations whose encoded weights leave the C++ classes' per-call tensors room in HBM: PlainModelTiny -- the host classes allocate every layer's output
-    # through a recycling pool, and with 200 GiB of weights resident the pool has nothing to recycle from)
+    # (by default for the configurations below 60 GiB of encoded weights, where building the network a second time costs seconds; --host-cpp 2 for any: at WoPad 16384 the
+    # C++ classes build their 182 GiB of limb weights tile by tile and chunk on two levels exactly like the Python twin, ~25 s of setup)
     if result is not None and full and world == 1 and args.host_cpp and (est_w_gib < 60 or args.host_cpp == 2) and q == ca.default_coeff_modulus_128(cfg["n"])[:cfg["k"]]:
         import tempfile
         hd = tempfile.mkdtemp(prefix="crc_host_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)

@@ -171,6 +171,7 @@ static void read_tuning(CrcTuning &t)
     t.mac_regstage = (int)geti("CRC_MAC_REGSTAGE", 0);
     t.mac2_dbg = (int)geti("CRC_MAC2_DBG", 0);
     t.relin_path = (int)geti("CRC_RELIN_PATH", 0);
+    t.sq_path = (int)geti("CRC_SQ_PATH", 0);
     t.f64_radix = (int)geti("CRC_F64_RADIX", 0);
     t.mfma_min_steps = (int)geti("CRC_MFMA_MIN_STEPS", 0);
     t.relin_mac_ct = (int)geti("CRC_RELIN_MAC_CT", 0);
@@ -192,6 +193,7 @@ extern "C" int crc_ctx_set_tuning(crc_ctx *c, const char *name, long long value)
     else if (s == "mac_regstage") t.mac_regstage = (int)value;
     else if (s == "ntt_inv61_loose") t.ntt_inv61_loose = value ? 1 : 0;
     else if (s == "relin_path") t.relin_path = (int)value;
+    else if (s == "sq_path") t.sq_path = (int)value;
     else if (s == "f64_radix") t.f64_radix = (int)value;
     else if (s == "mfma_min_steps") t.mfma_min_steps = (int)value;
     else if (s == "relin_mac_ct") t.relin_mac_ct = (int)value;
@@ -318,17 +320,26 @@ extern "C" int crc_ctx_create(int n, const uint64_t *q, int k, uint64_t t, int d
     c->inv_gamma_mod_t = h_invmod(kGamma % t, t);
 
     // fp64 NTT primes: the largest primes below 2^47 that are 1 mod 2^16 (so that every ring degree up to 32768 has its 2n-th roots)
-    std::vector<std::vector<double>> f64rp(CRC_NF64), f64irp(CRC_NF64);
+    std::vector<std::vector<double>> f64rp(CRC_NF64A), f64irp(CRC_NF64A);
     {
         int found = 0;
-        for (u64 cand = ((u64)1 << CRC_F64_PRIME_BITS) - 65536 + 1; found < CRC_NF64; cand -= 65536) if (is_prime(cand)) c->f64_primes[found++] = cand;
+        for (u64 cand = ((u64)1 << CRC_F64_PRIME_BITS) - 65536 + 1; found < CRC_NF64A; cand -= 65536) if (is_prime(cand)) c->f64_primes[found++] = cand;
         F64Params &f = c->f64; memset(&f, 0, sizeof f);
         auto centred = [](u64 v, u64 p) { return v > p / 2 ? (double)((long long)v - (long long)p) : (double)v; };
         auto quot = [](double w, u64 p) { return (double)((long double)w / (long double)p); };
-        for (int m = 0; m < CRC_NF64; m++) {
+        // the square's auxiliary base: the fewest primes with prod p_j >= 2 n t q (ctx.h Sq64Params; every p_j > 2^46.9999); transforms on an LDS image of n doubles
+        Sq64Params &sq = c->sq64; memset(&sq, 0, sizeof sq);
+        if (n <= 16384) {
+            const int need = 1 + c->logn + sigbits(t) + c->total_bits;
+            for (int kf = 3; kf <= CRC_NF64A; kf++) if ((int)(kf * 46.9999) >= need) { sq.kf = kf; break; }
+        }
+        c->nf64 = sq.kf > CRC_NF64 ? sq.kf : CRC_NF64;
+        for (int m = 0; m < c->nf64; m++) {
             const u64 p = c->f64_primes[m];
-            f.m[m].p = (double)p; f.m[m].pinv = 1.0 / (double)p;
-            f.ninv[m] = centred(h_invmod((u64)n, p), p); f.ninv_q[m] = quot(f.ninv[m], p);
+            if (m < CRC_NF64) {
+                f.m[m].p = (double)p; f.m[m].pinv = 1.0 / (double)p;
+                f.ninv[m] = centred(h_invmod((u64)n, p), p); f.ninv_q[m] = quot(f.ninv[m], p);
+            }
             if (device >= 0) {
                 const u64 psi = minimal_primitive_root(2 * (u64)n, p), ipsi = h_invmod(psi, p);
                 if (!psi) { delete c; return CRC_ERR_PARAMETERS; }
@@ -346,6 +357,32 @@ extern "C" int crc_ctx_create(int n, const uint64_t *q, int k, uint64_t t, int d
         f.inv_p0_p1 = centred(h_invmod(c->f64_primes[0] % c->f64_primes[1], c->f64_primes[1]), c->f64_primes[1]);
         f.inv_p0_p1_q = quot(f.inv_p0_p1, c->f64_primes[1]);
         for (int i = 0; i < k; i++) f.p0_mod_q[i] = c->f64_primes[0] % q[i];
+        if (sq.kf) {
+            const int kf = sq.kf, kB = kf - 1;
+            const u64 *P = c->f64_primes, msk = P[kB];
+            auto put = [&](double *dst, u64 v, u64 p) { dst[0] = centred(v, p); dst[1] = quot(dst[0], p); };
+            const u64 two32 = (u64)1 << 32;
+            for (int j = 0; j < kf; j++) {
+                const u64 p = P[j];
+                sq.m[j].p = (double)p; sq.m[j].pinv = 1.0 / (double)p;
+                const u64 q_p = prod_mod(q, k, -1, p), inv_q = h_invmod(q_p, p), inv_mt = h_invmod(kMtilde % p, p);
+                put(sq.lift_r[j], h_mulmod(q_p, inv_mt, p), p);
+                put(sq.floor_x[j], h_mulmod(h_mulmod(t % p, inv_q, p), h_invmod((u64)n, p), p), p);
+                for (int i = 0; i < k; i++) {
+                    const u64 qhat = prod_mod(q, k, i, p);
+                    const u64 lc = h_mulmod(qhat, inv_mt, p), fc = negmod(h_mulmod(qhat, inv_q, p), p);
+                    put(sq.lift_c[j][i], lc, p); put(sq.lift_c[j][i] + 2, h_mulmod(lc, two32 % p, p), p);
+                    put(sq.floor_c[j][i], fc, p); put(sq.floor_c[j][i] + 2, h_mulmod(fc, two32 % p, p), p);
+                }
+                if (j < kB) {
+                    put(sq.inv_mhat[j], h_invmod(prod_mod(P, kB, j, p), p), p);
+                    put(sq.mhat_msk[j], prod_mod(P, kB, j, msk), msk);
+                    for (int i = 0; i < k; i++) sq.mhat_q[i][j] = prod_mod(P, kB, j, q[i]);
+                }
+            }
+            put(sq.inv_B_msk, h_invmod(prod_mod(P, kB, -1, msk), msk), msk);
+            for (int i = 0; i < k; i++) sq.B_q[i] = prod_mod(P, kB, -1, q[i]);
+        }
     }
 
     // upload (device < 0: host-only context for encode / client-side use and CPU-only tests of the tables)
@@ -374,8 +411,9 @@ extern "C" int crc_ctx_create(int n, const uint64_t *q, int k, uint64_t t, int d
             fail(e); crc_ctx_destroy(c); return rc;
         }
         const size_t ftw = (size_t)n * 16;
-        if ((e = hipMalloc(&c->d_f64_rp, ftw * CRC_NF64)) != hipSuccess || (e = hipMalloc(&c->d_f64_irp, ftw * CRC_NF64)) != hipSuccess) { fail(e); crc_ctx_destroy(c); return rc; }
-        for (int m = 0; m < CRC_NF64; m++)
+        if ((e = hipMalloc(&c->d_f64_rp, ftw * c->nf64)) != hipSuccess || (e = hipMalloc(&c->d_f64_irp, ftw * c->nf64)) != hipSuccess ||
+            (e = hipMalloc(&c->d_sq64, sizeof(Sq64Params))) != hipSuccess || (e = hipMemcpy(c->d_sq64, &c->sq64, sizeof(Sq64Params), hipMemcpyHostToDevice)) != hipSuccess) { fail(e); crc_ctx_destroy(c); return rc; }
+        for (int m = 0; m < c->nf64; m++)
             if ((e = hipMemcpy((char *)c->d_f64_rp + m * ftw, f64rp[m].data(), ftw, hipMemcpyHostToDevice)) != hipSuccess ||
                 (e = hipMemcpy((char *)c->d_f64_irp + m * ftw, f64irp[m].data(), ftw, hipMemcpyHostToDevice)) != hipSuccess) { fail(e); crc_ctx_destroy(c); return rc; }
         c->d_scratch = c->d_zero + 512;
@@ -391,7 +429,7 @@ extern "C" void crc_ctx_destroy(crc_ctx *c)
     if (!c) return;
     if (c->device >= 0) {
         (void)hipFree(c->d_mods); (void)hipFree(c->d_rp); (void)hipFree(c->d_irp2); (void)hipFree(c->d_behz); (void)hipFree(c->d_zero);
-        (void)hipFree(c->d_f64_rp); (void)hipFree(c->d_f64_irp);
+        (void)hipFree(c->d_f64_rp); (void)hipFree(c->d_f64_irp); (void)hipFree(c->d_sq64);
     }
     delete c;
 }
@@ -432,6 +470,7 @@ extern "C" int crc_ctx_table(const crc_ctx *c, const char *name, uint64_t *out, 
     else if (s == "bsk") for (int j = 0; j < kb; j++) v.push_back(c->tabs[k + j].m.q);
     else if (s == "bsk_root") for (int j = 0; j < kb; j++) v.push_back(c->tabs[k + j].root);
     else if (s == "f64_primes") for (int m = 0; m < CRC_NF64; m++) v.push_back(c->f64_primes[m]);
+    else if (s == "sq64_primes") for (int m = 0; m < c->sq64.kf; m++) v.push_back(c->f64_primes[m]);
     else if (s.rfind("root_powers:", 0) == 0) { int mi = atoi(name + 12); if (mi < 0 || mi >= k + kb) return CRC_ERR_INVALID_ARGUMENT; v = c->tabs[mi].rp; }
     else if (s.rfind("inv_root_powers_div_two:", 0) == 0) { int mi = atoi(name + 24); if (mi < 0 || mi >= k + kb) return CRC_ERR_INVALID_ARGUMENT; v = c->tabs[mi].irp2; }
     else return CRC_ERR_NOT_FOUND;

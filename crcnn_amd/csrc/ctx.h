@@ -69,6 +69,25 @@ struct F64Params {
     u64 p0_mod_q[CRC_MAXK];                       // p_0 mod q_j
 };
 
+// The auxiliary base of the ciphertext square over the engine's fp64 primes (kernels_square64.hip).  BEHZ's results do not depend on WHICH auxiliary base carries the
+// intermediate integers as long as it is large enough (fastbconv_sk is exact once |floor(t P / q)| / B + #B < m_sk / 2): instead of SEAL's k (+1) 61-bit primes and
+// m_sk the engine takes kf of its own 47-bit primes, p_0 .. p_{kf-2} as B and p_{kf-1} as m_sk, whose transforms and base conversions are fp64 arithmetic.
+// Constants are {centred residue, residue / p} pairs for f64_mulmod_const; a 55..60-bit operand enters as its two 32-bit halves, hence the "x 2^32" twins.
+#define CRC_NF64A 12
+struct Sq64Params {
+    int kf;                                       // primes in use (0: the parameters do not fit 12 primes -- the 61-bit base is used)
+    F64Mod m[CRC_NF64A];
+    double lift_c[CRC_NF64A][CRC_MAXK][4];        // (q/q_i) m~^-1 mod p_j: {w, w/p} and {2^32 w, 2^32 w / p}        (BehzParams.lift_c)
+    double lift_r[CRC_NF64A][2];                  // q m~^-1 mod p_j                                                   (lift_r)
+    double floor_x[CRC_NF64A][2];                 // t q^-1 n^-1 mod p_j: the inverse transforms do not scale           (floor_x)
+    double floor_c[CRC_NF64A][CRC_MAXK][4];       // -(q/q_i) q^-1 mod p_j and its 2^32 twin                            (floor_c)
+    double inv_mhat[CRC_NF64A][2];                // (B/p_j)^-1 mod p_j, j < kf - 1                                     (inv_mhat)
+    double mhat_msk[CRC_NF64A][2];                // (B/p_j) mod m_sk                                                   (mhat_mod_msk)
+    double inv_B_msk[2];                          // B^-1 mod m_sk                                                      (inv_M_mod_msk)
+    u64 mhat_q[CRC_MAXK][CRC_NF64A];              // (B/p_j) mod q_i                                                    (mhat_mod_q)
+    u64 B_q[CRC_MAXK];                            // B mod q_i                                                          (M_mod_q)
+};
+
 struct HostNtt {               // one modulus
     ModParams m;
     u64 root, inv_n;
@@ -94,6 +113,7 @@ struct CrcTuning {
     int relin_mac_ct = 0;         // CRC_RELIN_MAC_CT=8: eight ciphertexts per thread in relin_mac_f64_kernel for k >= 4 (default 4)
     int mfma_min_steps = 0;       // CRC_MFMA_MIN_STEPS: reduction steps of 32 channels from which a conv / dense layer goes to the limb GEMM (0: 8)
     int f64_radix = 0;            // CRC_F64_RADIX=3|4|5: butterfly stages per LDS pass of the fp64 transforms (0: default)
+    int sq_path = 0;              // CRC_SQ_PATH=0: by parameters, 1: the square's auxiliary base is SEAL's 61-bit one (round-2 kernels), 2: the engine's fp64 primes
     int relin_path = 0;           // CRC_RELIN_PATH=0: by parameters, 1: key switching over the coefficient moduli (round-2 path), 2: over the two fp64 primes
 };
 
@@ -114,9 +134,12 @@ struct crc_ctx {
     ModParams *d_mods = nullptr;             // [k+kb]
     u64 *d_rp = nullptr, *d_irp2 = nullptr;   // [(k+kb)][n][2]: {bit-reversed root power, its Shoup companion} (forward / inverse-div-2)
     BehzParams *d_behz = nullptr;
-    u64 f64_primes[CRC_NF64] = {0, 0};
+    u64 f64_primes[CRC_NF64A] = {0};
+    int nf64 = CRC_NF64;                     // fp64 primes with transform tables: max(CRC_NF64, sq64.kf)
     F64Params f64;
-    double *d_f64_rp = nullptr, *d_f64_irp = nullptr;   // [CRC_NF64][n][2]: {bit-reversed power of psi_m (centred), that / p_m} forward; psi_m^-1 powers inverse
+    Sq64Params sq64;
+    Sq64Params *d_sq64 = nullptr;
+    double *d_f64_rp = nullptr, *d_f64_irp = nullptr;   // [nf64][n][2]: {bit-reversed power of psi_m (centred), that / p_m} forward; psi_m^-1 powers inverse
     u64 *d_zero = nullptr;                   // 4 KiB of zeros (source row of reduction terms past T in mac3_kernel) + 4 KiB context scratch
     u64 *d_scratch = nullptr;                // = d_zero + 512 words (crc_checksum64 accumulators)
     int cus = 256;                           // compute units of THIS context's device

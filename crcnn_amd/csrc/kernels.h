@@ -29,6 +29,9 @@ int k_relin64_prepare_keys(crc_ctx *c, const u64 *evk, int dbc, u64 *kp, u64 *sc
 int k_relinearize64(crc_ctx *c, const u64 *src, int src_size, int src_poly, const u64 *x3, int add_size, size_t cnt, int dbc, u64 *y, u64 *work, const u64 *kp,
                     hipStream_t st, bool out_ntt);
 int k_square(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStream_t st, bool in_ntt = false, bool premul_c2 = false);
+// kernels_square64.hip: the square's auxiliary base over the engine's fp64 primes
+bool k_square64_supported(const crc_ctx *c);
+int k_square64(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStream_t st, bool in_ntt, bool premul_c2);
 int k_relinearize(crc_ctx *c, const u64 *x3, size_t cnt, const u64 *evk, int dbc, u64 *y, u64 *work, u64 *kp, hipStream_t st, bool out_ntt = false,
                   bool c2_premul = false, bool keys_ready = false);
 int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, const int *d_toff, int B, int P, int F, int T, int in_cts,

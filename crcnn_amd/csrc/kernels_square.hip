@@ -202,8 +202,8 @@ __global__ void __launch_bounds__(256) relin_premul_kernel(const u64 *x3, u64 *p
 
 size_t k_square_work_words(const crc_ctx *c, size_t cnt)
 {
-    const size_t n = c->n, k = c->k, kb = c->kb;
-    // QN[2k] BS[2kb] DQ[3k] DB[3kb]
+    const size_t n = c->n, k = c->k, kb = k_square64_supported(c) && (size_t)c->sq64.kf > (size_t)c->kb ? c->sq64.kf : c->kb;
+    // QN[2k] BS[2kb] DQ[3k] DB[3kb]   (kb: whichever auxiliary base has more rows -- SEAL's 61-bit one or the engine's fp64 primes, kernels_square64.hip)
     return cnt * n * (2 * k + 2 * kb + 3 * k + 3 * kb);
 }
 size_t k_relin_work_words(const crc_ctx *c, size_t cnt, int dbc)
@@ -219,6 +219,10 @@ size_t k_relin_keys_words(const crc_ctx *c, int dbc) { return k_relin64_keys_wor
 int k_square(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStream_t st, bool in_ntt, bool premul_c2)
 {
     if (cnt == 0) return CRC_OK;
+    // the auxiliary base over the engine's fp64 primes whenever the parameters fit (every set of the reference's does); tune.sq_path = 1 keeps SEAL's 61-bit base
+    // (by default only while the fp64 base needs at most one row more than SEAL's -- k <= 4 with the reference's parameter sets: 5 rows for 4 at (8192, 3), 6 for 5
+    // at (16384, 4); at k = 8 it is 11 for 9 and the cheaper rows no longer pay for the two extra ones: 40.0 against 39.2 us per ciphertext)
+    if (c->tune.sq_path != 1 && k_square64_supported(c) && (c->tune.sq_path == 2 || c->sq64.kf <= c->kb + 1)) return k_square64(c, x, cnt, y3, work, st, in_ntt, premul_c2);
     const size_t n = c->n, k = c->k, kb = c->kb;
     u64 *QN = work, *BS = QN + cnt * 2 * k * n, *DQ = BS + cnt * 2 * kb * n, *DB = DQ + cnt * 3 * k * n;
     const int threads = c->n < 256 ? c->n : 256, sblocks = c->n / threads;

@@ -1,0 +1,222 @@
+// kernels_square64.hip -- the auxiliary-base half of the BFV ciphertext square over the engine's own fp64 primes.
+//
+// Reference: Evaluator::square (evaluator.cpp:702-884) with BaseConverter::fastbconv_mtilde / mont_rq / fast_floor / fastbconv_sk (util/baseconverter.cpp:388-742).
+// BEHZ carries the tensor product in TWO bases: q (the coefficient moduli) and an auxiliary base B U {m_sk} that only has to be large enough to hold the integers
+//     c' = (S + q r) / m~  (|c'| < q (1 + k 2^-32)),   P = c'_a (*) c'_b   (|P| <= 2 n q^2),   R = (t P - fastbconv_q(t P)) / q   (|R| <= 2 n t q + k)
+// exactly: fastbconv_q's sums S are integers that do not depend on where they are reduced, and fastbconv_sk returns R mod q_i exactly as soon as
+// |R| / B + #B + 1 < m_sk / 2.  The reference takes k (+1) 61-bit primes and a 61-bit m_sk; ANY base of that size gives the same R, hence the same residues mod q_i
+// (tests: the oracle's restatement with SEAL's base, and every golden of the reference itself).  The engine takes kf of its own 47-bit fp64 primes (ctx.h Sq64Params:
+// the fewest with prod p_j >= 4 n t q): 5 instead of 4 rows per polynomial at (8192, k = 3), 6 instead of 5 at (16384, 4), 11 instead of 9 at (16384, 8) -- but a row
+// transform in 6-flop fp64 arithmetic costs half of one over a 61-bit modulus, which has no lazy form (profiles/r03_square_relin_*: 0.041 against 0.069-0.088 us per
+// row at n = 8192, 0.090 against 0.16-0.21 at 16384).  The q half (dyadic products and inverse transforms over the coefficient moduli) stays in kernels.hip.
+//   sq64_lift_kernel  : q -> {p_j}: fastbconv_mtilde + mont_rq, residues written as centred doubles                                  LB [ct][2][kf][n]
+//   sq64_fwd_kernel   : forward transform of every LB row in place
+//   sq64_inv_kernel   : a^2, 2ab, b^2 formed while a row is staged, inverse transform (unscaled: n^-1 sits in floor_x)                   DB [ct][3][kf][n]
+//   sq64_floor_kernel : x t, fast_floor, fastbconv_sk back to q (one lazy 128-bit sum + one reduction per q_i), optional (q/q_i)^-1 on c2 for relinearisation
+#include "kernels.h"
+#include "ntt_f64.h"
+
+// every (k, kf) a context can have is not known at compile time (kf depends on t): instances for k = 1..8 with the kf range 3..12 the size rule can produce for 40-60-bit q_i
+#define CRC_FOR_ALL_K_KF(X) \
+    X(1, 3) X(1, 4) X(2, 3) X(2, 4) X(2, 5) X(3, 4) X(3, 5) X(3, 6) X(4, 5) X(4, 6) X(4, 7) X(5, 6) X(5, 7) X(5, 8) X(5, 9) X(6, 7) X(6, 8) X(6, 9) X(6, 10) \
+    X(7, 8) X(7, 9) X(7, 10) X(7, 11) X(8, 9) X(8, 10) X(8, 11) X(8, 12)
+
+namespace {
+struct acc128 { u64 lo, hi; };
+__device__ __forceinline__ void acc_mad(acc128 &a, u64 x, u64 y)
+{
+    u64 pl, ph; mul64wide(x, y, pl, ph);
+    const u64 nl = a.lo + pl; a.hi += ph + (nl < pl); a.lo = nl;
+}
+// (hi 2^32 + lo) w mod p from the constant's two pairs {w, w/p, 2^32 w, 2^32 w / p}: both halves are below 2^32, each product comes back below 0.875 p
+__device__ __forceinline__ double mul_split(double hi, double lo, const double *c, double p)
+{
+    return f64_mulmod_const(lo, c[0], c[1], p) + f64_mulmod_const(hi, c[2], c[3], p);
+}
+}
+
+// x: [count][2][K][n] coefficient form over q  ->  out: [count][2][KF][n] doubles, |.| <= (p_j + 1) / 2
+template <int K, int KF>
+__global__ void __launch_bounds__(256) sq64_lift_kernel(const u64 *x, double *out, const ModParams *mods, const BehzParams *bp, const Sq64Params *sp, int n)
+{
+    const BehzParams &b = *bp; const Sq64Params &f = *sp;
+    const int sblocks = n / blockDim.x;
+    const size_t poly = blockIdx.x / sblocks;                       // ct*2 + p
+    const int s = (blockIdx.x % sblocks) * blockDim.x + threadIdx.x;
+    const u64 *src = x + poly * (size_t)K * n + s;
+    double th[K], tl[K];
+    u32 xm = 0;
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        const u64 tr = mulmod_shoup(src[(size_t)i * n], b.mt_inv_qhat[i], b.mt_inv_qhat_s[i], mods[i].q);      // baseconverter.cpp:686-696
+        xm += (u32)tr * (u32)b.qhat_mod_mt[i];                                                                  // residue mod m~ = 2^32 (:720-741)
+        th[i] = (double)(u32)(tr >> 32); tl[i] = (double)(u32)tr;
+    }
+    const double r = (double)(0u - xm * (u32)b.inv_q_mod_mt);       // r = -(x_m~ q^-1) mod m~ in [0, m~): mont_rq :604-612 (not centred in SEAL 2.3.1)
+    double *dst = out + poly * (size_t)KF * n + s;
+#pragma unroll
+    for (int j = 0; j < KF; j++) {
+        // (sum_i tr_i (q/q_i) + q r) m~^-1 mod p_j (:698-718, 614-619), m~^-1 folded into the constants: 2K + 1 products below 0.875 p each, one reduction
+        const double p = f.m[j].p;
+        double a = f64_mulmod_const(r, f.lift_r[j][0], f.lift_r[j][1], p);
+#pragma unroll
+        for (int i = 0; i < K; i++) a += mul_split(th[i], tl[i], f.lift_c[j][i], p);
+        dst[(size_t)j * n] = f64_reduce(a, f.m[j]);
+    }
+}
+
+// rows: [count * 2 * kf][n] doubles, transformed in place under p_(row % kf); results reduced
+template <int RB>
+__global__ void __launch_bounds__(RB == 5 ? 512 : 1024) sq64_fwd_kernel(double *rows, const d2 *Wf, const Sq64Params *sp, int n, int logn, int kf)
+{
+    extern __shared__ double smd[];
+    const int j = blockIdx.x % kf;
+    const F64Mod md = sp->m[j];
+    double *row = rows + (size_t)blockIdx.x * n;
+    for (int s = threadIdx.x; s < n; s += blockDim.x) smd[swz<RB>(s)] = row[s];
+    __syncthreads();
+    ntt_row_passes_f64<false, RB>(smd, Wf + (size_t)j * n, n, logn, md);
+    for (int s = threadIdx.x; s < n; s += blockDim.x) row[s] = f64_reduce(smd[swz<RB>(s)], md);
+}
+
+// in: [count][2][kf][n] transformed rows (a, b)  ->  out: [count][3][kf][n]: n (a^2, 2ab, b^2) in coefficient form, reduced.  One workgroup per (ciphertext, prime):
+// the three products share the two source rows (read again from L2 rather than held in registers across the transforms)
+template <int RB>
+__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 ? 8 : 4) sq64_inv_kernel(const double *in, double *out, const d2 *Wi, const Sq64Params *sp, int n, int logn, int kf)
+{
+    extern __shared__ double smd[];
+    const size_t ct = blockIdx.x / kf; const int j = blockIdx.x % kf;
+    const F64Mod md = sp->m[j];
+    const double *a = in + ((ct * 2 + 0) * kf + j) * (size_t)n, *b = in + ((ct * 2 + 1) * kf + j) * (size_t)n;
+    for (int o = 0; o < 3; o++) {
+        const double *u = o == 2 ? b : a, *v = o == 0 ? a : b;
+        const double sc = o == 1 ? 2.0 : 1.0;
+        for (int s = threadIdx.x; s < n; s += blockDim.x) smd[swz<RB>(s)] = sc * f64_mulmod(u[s], v[s], md);      // |.| < 1.75 p: the first pass reduces on load
+        __syncthreads();
+        ntt_row_passes_f64<true, RB>(smd, Wi + (size_t)j * n, n, logn, md);
+        double *dst = out + ((ct * 3 + o) * kf + j) * (size_t)n;
+        for (int s = threadIdx.x; s < n; s += blockDim.x) dst[s] = f64_reduce(smd[swz<RB>(s)], md);
+        __syncthreads();
+    }
+}
+
+// dq: [count][3][K][n] u64 (coefficient form over q, scaled), db: [count][3][KF][n] doubles (n times the coefficient, reduced) -> y3: [count][3][K][n]
+template <int K, int KF>
+__global__ void __launch_bounds__(256) sq64_floor_kernel(const u64 *dq, const double *db, u64 *y3, const ModParams *mods, const BehzParams *bp, const Sq64Params *sp, int n, int premul_c2)
+{
+    const BehzParams &b = *bp; const Sq64Params &f = *sp;
+    constexpr int KB = KF - 1;
+    const int sblocks = n / blockDim.x;
+    const size_t poly = blockIdx.x / sblocks;                       // ct*3 + p
+    const int s = (blockIdx.x % sblocks) * blockDim.x + threadIdx.x;
+    const u64 *xq = dq + poly * (size_t)K * n + s;
+    const double *xb = db + poly * (size_t)KF * n + s;
+    double th[K], tl[K];
+    // x t (evaluator.cpp:856-871) and the (q/q_i)^-1 of fastbconv (:413-423) are one constant
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        const u64 tr = mulmod_shoup(xq[(size_t)i * n], b.t_inv_qhat[i], b.t_inv_qhat_s[i], mods[i].q);
+        th[i] = (double)(u32)(tr >> 32); tl[i] = (double)(u32)tr;
+    }
+    // fast_floor (:646-660): (x_p t - fastbconv(x_q t)) q^-1 mod p_j, with q^-1 (and the inverse transform's n^-1) folded into floor_x / floor_c
+    double fl[KF];
+#pragma unroll
+    for (int j = 0; j < KF; j++) {
+        const double p = f.m[j].p;
+        double a = f64_mulmod_const(xb[(size_t)j * n], f.floor_x[j][0], f.floor_x[j][1], p);
+#pragma unroll
+        for (int i = 0; i < K; i++) a += mul_split(th[i], tl[i], f.floor_c[j][i], p);                            // :425-445
+        fl[j] = f64_reduce(a, f.m[j]);
+    }
+    // fastbconv_sk (:448-579): z_j = fl_j (B/p_j)^-1 mod p_j in [0, p_j)
+    const F64Mod msk = f.m[KB];
+    double z[KB], v = 0.0;
+#pragma unroll
+    for (int j = 0; j < KB; j++) {
+        double zz = f64_reduce(f64_mulmod_const(fl[j], f.inv_mhat[j][0], f.inv_mhat[j][1], f.m[j].p), f.m[j]);
+        zz = zz < 0.0 ? zz + f.m[j].p : zz;
+        z[j] = zz;
+        v += f64_mulmod_const(zz, f.mhat_msk[j][0], f.mhat_msk[j][1], msk.p);
+    }
+    // alpha = (sum_j z_j (B/p_j) - R) / B, from its residue mod m_sk: a small integer (|alpha| <= KB + |R| / B, far inside the centred range), exact in the double
+    const double ad = f64_reduce(f64_mulmod_const(f64_reduce(v - fl[KB], msk), f.inv_B_msk[0], f.inv_B_msk[1], msk.p), msk);
+    const long long alpha = (long long)ad;
+    const bool neg = alpha < 0;
+    const u64 am = (u64)(neg ? -alpha : alpha);
+    u64 *dst = y3 + poly * (size_t)K * n + s;
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        const ModParams mi = mods[i];
+        acc128 a{0, 0};
+#pragma unroll
+        for (int j = 0; j < KB; j++) acc_mad(a, (u64)z[j], f.mhat_q[i][j]);          // 47 x <= 60 bits, at most 11 terms: below 2^111
+        acc_mad(a, neg ? f.B_q[i] : mi.q - f.B_q[i], am);                            // - alpha B   (:553-569)
+        u64 r = barrett128(a.lo, a.hi, mi);
+        if (premul_c2 && poly % 3 == 2) r = mulmod_shoup(r, b.inv_qhat[i], b.inv_qhat_s[i], mi.q);
+        dst[(size_t)i * n] = r;
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------------------------------------------------------
+static int sq64_threads(const crc_ctx *c, int RB) { int nt = c->n >> RB; if (nt < 64) nt = 64; if (nt > (RB == 5 ? 512 : 1024)) nt = RB == 5 ? 512 : 1024; return nt; }
+static int sq64_radix(const crc_ctx *c) { const int r = c->tune.f64_radix; return r >= 3 && r <= 5 ? r : 3; }
+
+bool k_square64_supported(const crc_ctx *c)
+{
+    if (c->sq64.kf < 3 || c->n < 64 || c->n > 16384) return false;
+#define HAVE(KV, KFV) if (c->k == KV && c->sq64.kf == KFV) return true;
+    CRC_FOR_ALL_K_KF(HAVE)
+#undef HAVE
+    return false;
+}
+
+// work: QN [2k] | LB [2 kf] | DQ [3k] | DB [3 kf]   (k_square_work_words sizes the rows by max(kb, kf))
+int k_square64(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStream_t st, bool in_ntt, bool premul_c2)
+{
+    if (cnt == 0) return CRC_OK;
+    if (!k_square64_supported(c)) return CRC_ERR_UNSUPPORTED;
+    const size_t n = c->n, k = c->k, kf = c->sq64.kf;
+    u64 *QN = work, *LBw = QN + cnt * 2 * k * n, *DQ = LBw + cnt * 2 * kf * n, *DBw = DQ + cnt * 3 * k * n;
+    double *LB = reinterpret_cast<double *>(LBw), *DB = reinterpret_cast<double *>(DBw);
+    const int threads = c->n < 256 ? c->n : 256, sblocks = c->n / threads;
+    int rc;
+    const u64 *xc = x, *xn = QN;
+    if (in_ntt) { if ((rc = k_ntt_ct(c, true, x, QN, cnt, 2, false, st, nullptr, 0, 0, 0))) return rc; xc = QN; xn = x; }
+    {
+        const dim3 grid((unsigned)(cnt * 2 * sblocks)), blk(threads);
+        bool launched = false;
+#define LIFT(KV, KFV) if (c->k == KV && c->sq64.kf == KFV) { hipLaunchKernelGGL((sq64_lift_kernel<KV, KFV>), grid, blk, 0, st, xc, LB, c->d_mods, c->d_behz, c->d_sq64, c->n); launched = true; }
+        CRC_FOR_ALL_K_KF(LIFT)
+#undef LIFT
+        if (!launched) return CRC_ERR_UNSUPPORTED;
+        HIPCHK(hipGetLastError());
+    }
+    if (!in_ntt && (rc = k_ntt_ct(c, false, x, QN, cnt, 2, false, st, nullptr, 0, 0, 0))) return rc;
+    const size_t lds = n * 8;
+    const int RB = sq64_radix(c), nt = sq64_threads(c, RB);
+    const d2 *Wf = reinterpret_cast<const d2 *>(c->d_f64_rp), *Wi = reinterpret_cast<const d2 *>(c->d_f64_irp);
+    {
+        auto kern = RB == 3 ? sq64_fwd_kernel<3> : RB == 4 ? sq64_fwd_kernel<4> : sq64_fwd_kernel<5>;
+        if ((rc = crc_ctx_ensure_lds(c, (const void *)kern, lds))) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * 2 * kf)), dim3(nt), lds, st, LB, Wf, c->d_sq64, c->n, c->logn, (int)kf);
+        HIPCHK(hipGetLastError());
+    }
+    // a^2, 2ab, b^2 over q are formed while the inverse transforms load their rows (kernels.hip); over the fp64 primes in sq64_inv_kernel
+    if ((rc = k_square_intt(c, xn, DQ, cnt, false, st))) return rc;
+    {
+        auto kern = RB == 3 ? sq64_inv_kernel<3> : RB == 4 ? sq64_inv_kernel<4> : sq64_inv_kernel<5>;
+        if ((rc = crc_ctx_ensure_lds(c, (const void *)kern, lds))) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * kf)), dim3(nt), lds, st, LB, DB, Wi, c->d_sq64, c->n, c->logn, (int)kf);
+        HIPCHK(hipGetLastError());
+    }
+    {
+        const dim3 grid((unsigned)(cnt * 3 * sblocks)), blk(threads);
+        bool launched = false;
+#define FLOOR(KV, KFV) if (c->k == KV && c->sq64.kf == KFV) { hipLaunchKernelGGL((sq64_floor_kernel<KV, KFV>), grid, blk, 0, st, DQ, DB, y3, c->d_mods, c->d_behz, c->d_sq64, c->n, premul_c2 ? 1 : 0); launched = true; }
+        CRC_FOR_ALL_K_KF(FLOOR)
+#undef FLOOR
+        if (!launched) return CRC_ERR_UNSUPPORTED;
+        HIPCHK(hipGetLastError());
+    }
+    return CRC_OK;
+}

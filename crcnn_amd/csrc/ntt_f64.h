@@ -1,0 +1,108 @@
+// ntt_f64.h -- negacyclic row transforms modulo the engine's own fp64 primes (f64mod.h) on an LDS image: the device functions shared by relinearisation's key
+// switching (kernels_relin64.hip) and the auxiliary-base half of the ciphertext square (kernels_square64.hip).
+#pragma once
+#include "kernels.h"
+#include "ntt_device.h"
+
+typedef double2 d2;
+
+// ---- fp64 butterflies (the index arithmetic of ntt_device.h's fwd_stages / inv_stages; arithmetic of f64mod.h) ---------------------------------------------------
+// forward: values grow by at most 0.875 p per stage: 16-bit inputs stay below 14 p < 2^51 through 15 stages -- no reduction anywhere
+// The 2^R - 1 twiddles of a thread's R stages are fetched up front (tw[(1 << st) - 1 + j] = twiddle j of stage st), in front of the LDS reads of the pass: one
+// exposed memory latency per pass instead of one per stage (the compiler keeps loads where they are written and waits right in front of the first use)
+template <int R>
+__device__ __forceinline__ void load_tw_fwd(d2 (&tw)[(1 << R) - 1], const d2 *W, int m, int blk)
+{
+#pragma unroll
+    for (int st = 0; st < R; st++)
+#pragma unroll
+        for (int j = 0; j < (1 << st); j++) tw[(1 << st) - 1 + j] = W[(m << st) + (blk << st) + j];
+}
+template <int R>
+__device__ __forceinline__ void load_tw_inv(d2 (&tw)[(1 << R) - 1], const d2 *W, int h, int blk)
+{
+#pragma unroll
+    for (int st = 0; st < R; st++)
+#pragma unroll
+        for (int j = 0; j < (1 << (R - 1 - st)); j++) tw[(1 << R) - (1 << (R - st)) + j] = W[(h >> st) + (blk << (R - 1 - st)) + j];
+}
+template <int R>
+__device__ __forceinline__ void fwd_stages_f64(double (&v)[1 << R], const d2 (&tw)[(1 << R) - 1], double p)
+{
+#pragma unroll
+    for (int st = 0; st < R; st++) {
+        const int half = 1 << (R - 1 - st);
+#pragma unroll
+        for (int c = 0; c < (1 << R); c++) {
+            if (c & half) continue;
+            const d2 t2 = tw[(1 << st) - 1 + (c >> (R - st))];
+            const double X = v[c], T = f64_mulmod_const(v[c + half], t2.x, t2.y, p);
+            v[c] = X + T; v[c + half] = X - T;
+        }
+    }
+}
+// inverse (Gentleman-Sande, no halving: n^-1 sits in the keys): sums double per stage, so a pass starts from reduced values (|x| <= p/2 -> below 4 p after three stages)
+template <int R>
+__device__ __forceinline__ void inv_stages_f64(double (&v)[1 << R], const d2 (&tw)[(1 << R) - 1], double p)
+{
+#pragma unroll
+    for (int st = 0; st < R; st++) {
+        const int half = 1 << st;
+#pragma unroll
+        for (int c = 0; c < (1 << R); c++) {
+            if (c & half) continue;
+            const d2 t2 = tw[(1 << R) - (1 << (R - st)) + (c >> (st + 1))];
+            const double U = v[c], V = v[c + half];
+            v[c] = U + V; v[c + half] = f64_mulmod_const(U - V, t2.x, t2.y, p);
+        }
+    }
+}
+// s = 2^ls: element stride inside a group.  The swizzles are XORs of shifted index bits, i.e. linear over GF(2), and (c << ls) occupies bits that are zero in
+// `base`: swz(base + c s) = swz(base) ^ swz(c s) -- one vector XOR per element against a wave-uniform constant instead of the whole index arithmetic
+template <bool INV, int R, int RB>
+__device__ __forceinline__ void ntt_pass_f64(double *sm, const d2 *W, int n, int ls, int tabidx, const F64Mod md, bool reduce_in)
+{
+    const unsigned groups = (unsigned)n >> R;
+    for (unsigned g = threadIdx.x; g < groups; g += blockDim.x) {
+        const unsigned blk = g >> ls, l = g & ((1u << ls) - 1);
+        const int a0 = swz<RB>((int)((blk << (ls + R)) + l));
+        d2 tw[(1 << R) - 1];
+        if (INV) load_tw_inv<R>(tw, W, tabidx, (int)blk); else load_tw_fwd<R>(tw, W, tabidx, (int)blk);
+        double v[1 << R];
+#pragma unroll
+        for (int c = 0; c < (1 << R); c++) { v[c] = sm[a0 ^ swz<RB>(c << ls)]; if (INV && reduce_in) v[c] = f64_reduce(v[c], md); }
+        if (INV) inv_stages_f64<R>(v, tw, md.p); else fwd_stages_f64<R>(v, tw, md.p);
+#pragma unroll
+        for (int c = 0; c < (1 << R); c++) sm[a0 ^ swz<RB>(c << ls)] = v[c];
+    }
+    __syncthreads();
+}
+template <bool INV, int RB>
+__device__ __forceinline__ void ntt_tail_pass_f64(int rem, double *sm, const d2 *W, int n, int ls, int tabidx, const F64Mod md)
+{
+    if (rem == 1) ntt_pass_f64<INV, 1, RB>(sm, W, n, ls, tabidx, md, INV);
+    else if (rem == 2) ntt_pass_f64<INV, 2, RB>(sm, W, n, ls, tabidx, md, INV);
+    else if (RB > 3 && rem == 3) ntt_pass_f64<INV, 3, RB>(sm, W, n, ls, tabidx, md, INV);
+    else if (RB > 4 && rem == 4) ntt_pass_f64<INV, 4, RB>(sm, W, n, ls, tabidx, md, INV);
+}
+// all passes of one row on the LDS image (lpad-swizzled); caller has synchronised after filling it, returns synchronised.  Inverse: the image holds values below
+// 2^52 (lazy sums of up to 48 products); every pass reduces on load.
+// (RB = stages per pass: 2^RB values per thread in registers between two LDS round trips.  The fp64 butterfly is a third of the 64-bit integer one's issue cycles, so
+// the LDS passes, their barriers and the twiddle loads weigh more here than in ntt_device.h: fewer, wider passes)
+// tm: twiddle block multiplier -- 1 for a whole row; 2 + h when the n points are half h of a 2n-point row whose stage 0 (forward) / last stage (inverse) is done by
+// the caller (global block I = h m' + i' of a stage with 2 m' blocks sits at table index 2 m' + I: kernels.hip ntt_rows_split_body)
+template <bool INV, int RB>
+__device__ __forceinline__ void ntt_row_passes_f64(double *sm, const d2 *W, int n, int logn, const F64Mod md, int tm = 1)
+{
+    const int full = logn / RB, rem = logn - RB * full;
+    if (!INV) {
+        // gaps n/2, n/4, ...: a pass of R stages starting at gap 2^lt works on groups of stride 2^(lt - R + 1); twiddle block index n / 2^(lt + 1)
+        int lt = logn - 1;
+        for (int p = 0; p < full; p++, lt -= RB) ntt_pass_f64<false, RB, RB>(sm, W, n, lt - RB + 1, tm * (n >> (lt + 1)), md, false);
+        if (rem) ntt_tail_pass_f64<false, RB>(rem, sm, W, n, lt - rem + 1, tm * (n >> (lt + 1)), md);
+    } else {
+        int lt = 0;
+        for (int p = 0; p < full; p++, lt += RB) ntt_pass_f64<true, RB, RB>(sm, W, n, lt, tm * (n >> (lt + 1)), md, true);
+        if (rem) ntt_tail_pass_f64<true, RB>(rem, sm, W, n, lt, tm * (n >> (lt + 1)), md);
+    }
+}

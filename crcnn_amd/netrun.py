@@ -488,7 +488,7 @@ class Network:
         T = g["zd"] * g["xf"] * g["yf"]
         g["T"] = T
         g["P"] = ((g["xd"] - g["xf"]) // g["xs"] + 1) * ((g["yd"] - g["yf"]) // g["ys"] + 1)
-        g["limb"] = bool(self.limb and self.limb_eligible(kind, a) and B is not None and B * 2 * g["P"] >= 32)
+        g["limb"] = bool(self.limb and B is not None and self.planned_form(kind, a, B) == binding.NTTL)        # (crc_plan_mac: row count and filter count rules included)
         if g["limb"]:
             g["ft"] = min(64, g["nf"]); g["sub"] = min(8, g["ft"])
             return g

@@ -226,6 +226,77 @@ def test_relinearise_over_fp64_primes_equals_reference_arithmetic(n, k, cnt):
     E.close()
 
 
+SQ64_SETS = [(256, 1, 1 << 16, 3), (1024, 2, 1 << 30, 3), (4096, 2, 1 << 32, 2), (8192, 3, 1 << 42, 2), (8192, 4, 1 << 42, 2), (16384, 4, 1 << 44, 2), (16384, 8, 1 << 44, 1)]
+
+
+@pytest.mark.parametrize("n,k,t,cnt", SQ64_SETS, ids=[f"n{p[0]}_k{p[1]}" for p in SQ64_SETS])
+def test_square_over_fp64_auxiliary_base_equals_reference_base(n, k, t, cnt):
+    """Evaluator::square (evaluator.cpp:702-884) two ways on the same inputs: with BEHZ's auxiliary base taken from the engine's fp64 primes (kernels_square64.hip, the
+    default) and with SEAL's own 61-bit base (the round-2 kernels, which follow baseconverter.cpp constant by constant), plus the CPU oracle (SEAL's base) at the
+    sizes it finishes in seconds.  The plain moduli are the bench's (2^42 at n = 8192, 2^44 at 16384: the size rule for the number of primes is tight there) and the
+    inputs include the extremes of the integer bound |t P / q| <= 2 n t q: every residue q_i - 1 (largest products), zero, and 1."""
+    import crcnn_amd as ca
+    from oracle import orc
+    q = ca.default_coeff_modulus_128(n)[:k] if n >= 4096 else [0x7fffffff380001, 0x3fffffff000001][:k]
+    E = ca.Engine(n, q, t, device=0)
+    primes = [int(v) for v in E.table("sq64_primes")]
+    assert len(primes) >= 3, "the fp64 auxiliary base is not in use for this parameter set"
+    need = 4 * n * t
+    for v in q:
+        need *= v
+    have = 1
+    for v in primes:
+        have *= v
+    assert have >= need, "prod p_j >= 4 n t q: the base holds |floor(t P / q)| with room for fastbconv_sk's correction"
+    assert len(primes) == 3 or have // primes[-1] < 2 * need, "no more primes than the size rule needs"
+    rng = np.random.default_rng(7 * n + k)
+    qa = np.array(q, dtype=np.uint64)
+    x = np.empty((cnt + 4, 2, k, n), dtype=np.uint64)
+    for i in range(k):
+        x[:, :, i] = rng.integers(0, q[i], size=(cnt + 4, 2, n), dtype=np.uint64)
+    x[cnt] = (qa - np.uint64(1))[None, :, None]
+    x[cnt + 1] = 0
+    x[cnt + 2] = 1
+    x[cnt + 3, 0] = (qa - np.uint64(1))[:, None]; x[cnt + 3, 1] = (qa >> np.uint64(1))[:, None]
+    N = cnt + 4
+    d_x = E.upload(x); d_w = E.alloc(E.square_relin_work_bytes(N))
+    outs = {}
+    for path in (1, 2):
+        E.set_tuning("sq_path", path)
+        d_y3 = E.alloc(N * 3 * k * n * 8)
+        E.square(d_x, N, d_y3, d_w)
+        outs[path] = E.download(d_y3, (N, 3, k, n))
+    assert np.array_equal(outs[2], outs[1]), "the square over the fp64 auxiliary base differs from the one over SEAL's base"
+    if n <= 4096:
+        O = orc.Oracle(n, q, t)
+        for i in range(N):
+            assert np.array_equal(outs[2][i], O.square(x[i])), ("oracle", i)
+    for radix in (4, 5):
+        E.set_tuning("f64_radix", radix)
+        d_y3 = E.alloc(N * 3 * k * n * 8)
+        E.square(d_x, N, d_y3, d_w)
+        assert np.array_equal(E.download(d_y3, (N, 3, k, n)), outs[1]), ("radix", radix)
+    E.set_tuning("f64_radix", 0)
+    # (2 forces the fp64 base; left to itself the engine takes it while it needs at most one row more than SEAL's base)
+    # ... and through the NTT-resident entry point with relinearisation behind it (input inverse-transformed inside, third polynomial handed over premultiplied)
+    evk = np.empty(E.L.crc_evk_words(E.c, 16), dtype=np.uint64)
+    rows = evk.reshape(-1, k, n)
+    for i in range(k):
+        rows[:, i] = rng.integers(0, q[i], size=(rows.shape[0], n), dtype=np.uint64)
+    d_evk = E.upload(evk)
+    res = {}
+    for path in (1, 2):
+        E.set_tuning("sq_path", path)
+        for fin, fout in [(ca.COEFF, ca.COEFF), (ca.NTT, ca.NTT)]:
+            d_y = E.alloc(x.nbytes)
+            E.square_relin(d_x, N, d_evk, d_y, d_w, in_form=fin, out_form=fout)
+            res[(path, fin, fout)] = E.download(d_y, x.shape)
+    for key, v in res.items():
+        if key[0] == 2:
+            assert np.array_equal(v, res[(1,) + key[1:]]), key
+    E.close()
+
+
 @pytest.mark.parametrize("n,k,t", [(4096, 2, 1 << 20), (8192, 3, 1 << 30), (1024, 2, 1 << 16)])
 def test_device_encryptor(n, k, t):
     """SURVEY 8f-2: Encryptor::encrypt on the device.  The reference samples from std::random_device, so the check is semantic, and

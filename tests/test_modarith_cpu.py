@@ -45,3 +45,30 @@ def test_fp64_modular_arithmetic_against_int128():
     assert [int(v) for v in E.table("f64_primes")] == [int(v) for v in out[3:5]]
     for p in E.table("f64_primes"):
         assert int(p) % 65536 == 1 and int(p) < (1 << 47)
+
+
+def test_square_fp64_auxiliary_base_size_rule():
+    """The square's auxiliary base over the engine's fp64 primes (crcnn_amd/csrc/kernels_square64.hip): for every BASELINE parameter set the context takes distinct
+    primes below 2^47 that are 1 mod 2^16, the first two being relinearisation's, and just enough of them for prod p_j >= 4 n t q -- BEHZ's fastbconv_sk
+    (baseconverter.cpp:448-579) is exact once |floor(t P / q)| / B + #B + 1 < m_sk / 2, with |t P / q| <= 2 n t q for SEAL 2.3.1's non-centred mont_rq"""
+    import crcnn_amd as ca
+    sets = [(4096, 2, 1 << 32), (8192, 3, 1 << 42), (8192, 4, 1 << 42), (16384, 4, 1 << 44), (16384, 8, 1 << 44), (4096, 2, 1 << 20), (8192, 3, 1 << 30)]
+    want = {(4096, 2, 1 << 32): 4, (8192, 3, 1 << 42): 5, (8192, 4, 1 << 42): 6, (16384, 4, 1 << 44): 6, (16384, 8, 1 << 44): 11}
+    for n, k, t in sets:
+        q = ca.default_coeff_modulus_128(n)[:k]
+        E = ca.Engine(n, q, t, device=-1)
+        primes = [int(v) for v in E.table("sq64_primes")]
+        assert primes[:2] == [int(v) for v in E.table("f64_primes")]
+        assert len(set(primes)) == len(primes) >= 3
+        need = 4 * n * t
+        for v in q:
+            need *= v
+        have = 1
+        for p in primes:
+            assert p % 65536 == 1 and p < (1 << 47) and pow(2, p - 1, p) == 1
+            have *= p
+        assert have >= need
+        B, msk = have // primes[-1], primes[-1]
+        assert (2 * n * t * (need // (4 * n * t)) + k) // B + len(primes) + 1 < msk // 2
+        if (n, k, t) in want:
+            assert len(primes) == want[(n, k, t)], (n, k, t, len(primes))

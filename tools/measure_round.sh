@@ -7,7 +7,7 @@ timeout -k 10 900 python bench.py --steps 5 --warmup 1 > $O/bench_default_invoca
 timeout -k 10 500 python bench.py --also none --steps 5 --warmup 1 > $O/bench_tiny4096.json 2> $O/bench_tiny4096.err
 timeout -k 10 500 python bench.py --config approx8192 --also none --steps 2 > $O/bench_approx8192.json 2> $O/bench_approx8192.err
 timeout -k 10 500 python bench.py --config approx8192k4 --also none --steps 1 --batch 256 > $O/bench_approx8192k4_b256.json 2> $O/bench_approx8192k4.err
-timeout -k 10 500 python bench.py --config wopad16384 --also none --steps 1 --batch 96 > $O/bench_wopad16384_b96.json 2> $O/bench_wopad.err
+timeout -k 10 500 python bench.py --config wopad16384 --also none --steps 1 --batch 96 --host-cpp 2 > $O/bench_wopad16384_b96.json 2> $O/bench_wopad.err
 timeout -k 10 700 python bench.py --config wopad16384k8 --also none --steps 1 --batch 96 --distinct 2 --cpu-seconds 0 --unfused-images 0 > $O/bench_wopad16384k8_b96.json 2> $O/bench_wopadk8.err
 fi
 if [ $P = all ] || [ $P = prof ]; then
