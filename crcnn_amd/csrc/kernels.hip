@@ -70,29 +70,30 @@ __device__ __forceinline__ void ntt_rows_body(const NttArgs &a)
         const size_t ct = row / (3 * (size_t)a.mod_count); const int p = (int)((row / a.mod_count) % 3);
         const u64 *pa = a.src + ((ct * 2 + (p == 2 ? 1 : 0)) * a.mod_count + mloc) * (size_t)n;
         const u64 *pb = a.src + ((ct * 2 + (p == 0 ? 0 : 1)) * a.mod_count + mloc) * (size_t)n;
-        for (int s = tid; s < n; s += nt) {
-            u64 v = mulmod(pa[s], pb[s], m);
-            if (p == 1) v = addmod(v, v, q);
-            sm[lpad(s)] = v;
+        for (int s = 2 * tid; s < n; s += 2 * nt) {
+            const ulonglong2 av = ld2(pa + s), bv = ld2(pb + s);
+            u64 v0 = mulmod(av.x, bv.x, m), v1 = mulmod(av.y, bv.y, m);
+            if (p == 1) { v0 = addmod(v0, v0, q); v1 = addmod(v1, v1, q); }
+            sm_store_pair64(sm, s, v0, v1);
         }
     } else if (!INV && PRO == 3) {
         const size_t item = row / a.mod_count, ct = item / a.D; const int g = (int)(item % a.D);
         const u64 *src = a.src + ((ct * a.src_size + a.src_poly) * a.mod_count + a.dig_i[g]) * (size_t)n;
         const int sh = a.dig_shift[g];
-        for (int s = tid; s < n; s += nt) sm[lpad(s)] = (src[s] >> sh) & a.dig_mask;
+        for (int s = 2 * tid; s < n; s += 2 * nt) { const ulonglong2 v = ld2(src + s); sm_store_pair64(sm, s, (v.x >> sh) & a.dig_mask, (v.y >> sh) & a.dig_mask); }
     } else {
         const size_t srow = a.dst_ct_rows ? (row / a.dst_ct_rows) * a.src_ct_rows + row % a.dst_ct_rows : (a.src_rows_per_item ? (row / a.mod_count) : row);
         const u64 *src = a.src + srow * (size_t)n;
-        for (int s = tid; s < n; s += nt) {
-            u64 v = src[s];
+        auto pro = [&](u64 v) -> u64 {
             if (a.prologue == 1) v = plain_lift(v, a.pp, mloc, m);
             else if (a.prologue == 2) {
                 u64 lo, hi; mul64wide(a.pp.delta[mloc], v, lo, hi);
                 if (v >= a.pp.threshold) { u64 l2 = lo + a.pp.uhi[mloc]; hi += (l2 < lo); lo = l2; }
                 v = barrett128(lo, hi, m);
             }
-            sm[lpad(s)] = v;
-        }
+            return v;
+        };
+        for (int s = 2 * tid; s < n; s += 2 * nt) { const ulonglong2 v = ld2(src + s); sm_store_pair64(sm, s, pro(v.x), pro(v.y)); }
     }
     __syncthreads();
 
@@ -104,12 +105,15 @@ __device__ __forceinline__ void ntt_rows_body(const NttArgs &a)
         if (rem == 2) ntt_pass<false, 2, LAZY>(sm, W, n, t >> 1, n / (2 * t), q, q2);
         else if (rem == 1) ntt_pass<false, 1, LAZY>(sm, W, n, t, n / (2 * t), q, q2);
         const u64 *add = a.addend ? a.addend + row * (size_t)n : nullptr;      // forward epilogue: + an NTT-form row of the same index
-        for (int s = tid; s < n; s += nt) {
-            u64 v = sm[lpad(s)];
-            if (LAZY) v = reduce_small(v, q, q2, rq);
-            else { v = v >= q2 ? v - q2 : v; v = v >= q ? v - q : v; }
-            if (add) v = addmod(v, add[s], q);
-            dst[s] = a.pack_out ? split28v(v) : v;
+        auto fin = [&](u64 v) -> u64 {
+            if (LAZY) return reduce_small(v, q, q2, rq);
+            v = v >= q2 ? v - q2 : v; return v >= q ? v - q : v;
+        };
+        for (int s = 2 * tid; s < n; s += 2 * nt) {
+            ulonglong2 v = sm_load_pair64(sm, s);
+            v.x = fin(v.x); v.y = fin(v.y);
+            if (add) { const ulonglong2 ad = ld2(add + s); v.x = addmod(v.x, ad.x, q); v.y = addmod(v.y, ad.y, q); }
+            if (a.pack_out) st2(dst + s, split28v(v.x), split28v(v.y)); else st2(dst + s, v.x, v.y);
         }
     } else {
         // gaps 1, 2, 4, ...
@@ -123,12 +127,18 @@ __device__ __forceinline__ void ntt_rows_body(const NttArgs &a)
             if (a.add_mode == 2) add = a.addend + ((ct * a.add_size + p) * a.mod_count + mloc) * (size_t)n;
             else if (p == 0) { size_t g = ct / a.add_group; if (a.add_mod) g %= a.add_mod; add = a.addend + (g * a.mod_count + mloc) * (size_t)n; }
         }
-        for (int s = tid; s < n; s += nt) {
-            u64 v = sm[lpad(s)];
-            if (LAZY) v = reduce_small(v, q, q2, rq);
-            else { v = v >= q2 ? v - q2 : v; v = v >= q ? v - q : v; }
-            if (add) v = a.add_sign > 0 ? addmod(v, add[s], q) : submod(v, add[s], q);
-            dst[s] = v;
+        auto fin = [&](u64 v) -> u64 {
+            if (LAZY) return reduce_small(v, q, q2, rq);
+            v = v >= q2 ? v - q2 : v; return v >= q ? v - q : v;
+        };
+        for (int s = 2 * tid; s < n; s += 2 * nt) {
+            ulonglong2 v = sm_load_pair64(sm, s);
+            v.x = fin(v.x); v.y = fin(v.y);
+            if (add) {
+                const ulonglong2 ad = ld2(add + s);
+                if (a.add_sign > 0) { v.x = addmod(v.x, ad.x, q); v.y = addmod(v.y, ad.y, q); } else { v.x = submod(v.x, ad.x, q); v.y = submod(v.y, ad.y, q); }
+            }
+            st2(dst + s, v.x, v.y);
         }
     }
 }
@@ -170,10 +180,7 @@ __device__ __forceinline__ void ntt_rows_split_body(const NttArgs &a)
         const size_t srow = a.dst_ct_rows ? (row / a.dst_ct_rows) * a.src_ct_rows + row % a.dst_ct_rows : (a.src_rows_per_item ? (row / a.mod_count) : row);
         src = a.src + srow * (size_t)n;
     }
-    auto load = [&](int s) -> u64 {
-        if (INV && PRO == 4) { u64 v = mulmod(pa[s], pb[s], m); if (prod == 1) v = addmod(v, v, q); return v; }
-        if (!INV && PRO == 3) return (src[s] >> sh) & a.dig_mask;
-        u64 v = src[s];
+    auto pro = [&](u64 v) -> u64 {
         if (a.prologue == 1) v = plain_lift(v, a.pp, mloc, m);
         else if (a.prologue == 2) {
             u64 lo, hi; mul64wide(a.pp.delta[mloc], v, lo, hi);
@@ -181,6 +188,17 @@ __device__ __forceinline__ void ntt_rows_split_body(const NttArgs &a)
             v = barrett128(lo, hi, m);
         }
         return v;
+    };
+    auto load2 = [&](int s) -> ulonglong2 {        // points s, s + 1 (s even): 16-byte accesses throughout
+        if (INV && PRO == 4) {
+            const ulonglong2 av = ld2(pa + s), bv = ld2(pb + s);
+            ulonglong2 v{mulmod(av.x, bv.x, m), mulmod(av.y, bv.y, m)};
+            if (prod == 1) { v.x = addmod(v.x, v.x, q); v.y = addmod(v.y, v.y, q); }
+            return v;
+        }
+        const ulonglong2 v = ld2(src + s);
+        if (!INV && PRO == 3) return ulonglong2{(v.x >> sh) & a.dig_mask, (v.y >> sh) & a.dig_mask};
+        return ulonglong2{pro(v.x), pro(v.y)};
     };
     auto passes = [&](int h) {          // the half transform: n/2 points, twiddle block index (2 + h) m
         const int full = logn2 / 3, rem = logn2 - 3 * full, tm = 2 + h;
@@ -203,15 +221,20 @@ __device__ __forceinline__ void ntt_rows_split_body(const NttArgs &a)
     const ulonglong2 tw = W[1];
     if (!INV) {
         const u64 *add = a.addend ? a.addend + row * (size_t)n : nullptr;
+        auto bf = [&](u64 X, u64 Y, int h) -> u64 {
+            if (LAZY) { const u64 Q = shoup_lazy4(Y, tw.x, tw.y, q); return h ? X + (q4 - Q) : X + Q; }
+            X = X >= q2 ? X - q2 : X; const u64 Q = mulmod_shoup_lazy(Y, tw.x, tw.y, q); return h ? X + (q2 - Q) : X + Q;
+        };
         auto stage0 = [&](int h) {
-            for (int s = tid; s < n2; s += nt) {
-                u64 X = load(s); const u64 Y = load(s + n2);
-                u64 v;
-                if (LAZY) { const u64 Q = shoup_lazy4(Y, tw.x, tw.y, q); v = h ? X + (q4 - Q) : X + Q; }
-                else { X = X >= q2 ? X - q2 : X; const u64 Q = mulmod_shoup_lazy(Y, tw.x, tw.y, q); v = h ? X + (q2 - Q) : X + Q; }
-                sm[lpad(s)] = v;
+            for (int s = 2 * tid; s < n2; s += 2 * nt) {
+                const ulonglong2 X = load2(s), Y = load2(s + n2);
+                sm_store_pair64(sm, s, bf(X.x, Y.x, h), bf(X.y, Y.y, h));
             }
             __syncthreads();
+        };
+        auto put = [&](int s, u64 v0, u64 v1) {        // s: index inside the whole row
+            if (add) { const ulonglong2 ad = ld2(add + s); v0 = addmod(v0, ad.x, q); v1 = addmod(v1, ad.y, q); }
+            if (a.pack_out) st2(dst + s, split28v(v0), split28v(v1)); else st2(dst + s, v0, v1);
         };
         // the transform may run in place (src == dst): nothing is stored before the second half has read its inputs -- the first half's result waits in registers
         constexpr int NPT = 8;                          // n/2 = 8192 values on 1024 threads (the split form serves n = 16384 only)
@@ -219,20 +242,13 @@ __device__ __forceinline__ void ntt_rows_split_body(const NttArgs &a)
         stage0(0);
         passes(0);
 #pragma unroll
-        for (int u = 0; u < NPT; u++) { const int s = tid + u * nt; if (s < n2) r0[u] = canon(sm[lpad(s)]); }
+        for (int u = 0; u < NPT / 2; u++) { const int s = 2 * (tid + u * nt); if (s < n2) { const ulonglong2 v = sm_load_pair64(sm, s); r0[2 * u] = canon(v.x); r0[2 * u + 1] = canon(v.y); } }
         __syncthreads();
         stage0(1);
 #pragma unroll
-        for (int u = 0; u < NPT; u++) {
-            const int s = tid + u * nt;
-            if (s < n2) { u64 v = r0[u]; if (add) v = addmod(v, add[s], q); dst[s] = a.pack_out ? split28v(v) : v; }
-        }
+        for (int u = 0; u < NPT / 2; u++) { const int s = 2 * (tid + u * nt); if (s < n2) put(s, r0[2 * u], r0[2 * u + 1]); }
         passes(1);
-        for (int s = tid; s < n2; s += nt) {
-            u64 v = canon(sm[lpad(s)]);
-            if (add) v = addmod(v, add[n2 + s], q);
-            dst[n2 + s] = a.pack_out ? split28v(v) : v;
-        }
+        for (int s = 2 * tid; s < n2; s += 2 * nt) { const ulonglong2 v = sm_load_pair64(sm, s); put(n2 + s, canon(v.x), canon(v.y)); }
     } else {
         const u64 *add = nullptr;
         if (a.addend) {
@@ -240,18 +256,16 @@ __device__ __forceinline__ void ntt_rows_split_body(const NttArgs &a)
             if (a.add_mode == 2) add = a.addend + ((ct * a.add_size + p) * a.mod_count + mloc) * (size_t)n;
             else if (p == 0) { size_t g = ct / a.add_group; if (a.add_mod) g %= a.add_mod; add = a.addend + (g * a.mod_count + mloc) * (size_t)n; }
         }
-        for (int s = tid; s < n2; s += nt) sm[lpad(s)] = load(s);
+        for (int s = 2 * tid; s < n2; s += 2 * nt) { const ulonglong2 v = load2(s); sm_store_pair64(sm, s, v.x, v.y); }
         __syncthreads();
         passes(0);
-        for (int s = tid; s < n2; s += nt) dst[s] = sm[lpad(s)];        // parked (lazy, below 2^63); read back by this very thread below
+        for (int s = 2 * tid; s < n2; s += 2 * nt) { const ulonglong2 v = sm_load_pair64(sm, s); st2(dst + s, v.x, v.y); }        // parked (lazy, below 2^63); read back by this very thread below
         __syncthreads();
-        for (int s = tid; s < n2; s += nt) sm[lpad(s)] = load(s + n2);
+        for (int s = 2 * tid; s < n2; s += 2 * nt) { const ulonglong2 v = load2(s + n2); sm_store_pair64(sm, s, v.x, v.y); }
         __syncthreads();
         passes(1);
         const u64 q16 = q2 << 3;
-        for (int s = tid; s < n2; s += nt) {
-            const u64 U = dst[s], V = sm[lpad(s)];
-            u64 lo, hi;
+        auto last = [&](u64 U, u64 V, u64 &lo, u64 &hi) {
             if (LAZY) {
                 const u64 T = q16 - V + U, cu = U + V;
                 lo = (cu + ((cu & 1) ? q : 0)) >> 1; hi = shoup_lazy4(T, tw.x, tw.y, q);
@@ -260,8 +274,17 @@ __device__ __forceinline__ void ntt_rows_split_body(const NttArgs &a)
                 lo = (cu + ((cu & 1) ? q : 0)) >> 1; hi = mulmod_shoup_lazy(T, tw.x, tw.y, q);
             }
             lo = canon(lo); hi = canon(hi);
-            if (add) { if (a.add_sign > 0) { lo = addmod(lo, add[s], q); hi = addmod(hi, add[s + n2], q); } else { lo = submod(lo, add[s], q); hi = submod(hi, add[s + n2], q); } }
-            dst[s] = lo; dst[s + n2] = hi;
+        };
+        for (int s = 2 * tid; s < n2; s += 2 * nt) {
+            const ulonglong2 U = ld2(dst + s), V = sm_load_pair64(sm, s);
+            u64 lo0, hi0, lo1, hi1;
+            last(U.x, V.x, lo0, hi0); last(U.y, V.y, lo1, hi1);
+            if (add) {
+                const ulonglong2 al = ld2(add + s), ah = ld2(add + s + n2);
+                if (a.add_sign > 0) { lo0 = addmod(lo0, al.x, q); lo1 = addmod(lo1, al.y, q); hi0 = addmod(hi0, ah.x, q); hi1 = addmod(hi1, ah.y, q); }
+                else { lo0 = submod(lo0, al.x, q); lo1 = submod(lo1, al.y, q); hi0 = submod(hi0, ah.x, q); hi1 = submod(hi1, ah.y, q); }
+            }
+            st2(dst + s, lo0, lo1); st2(dst + s + n2, hi0, hi1);
         }
     }
 }

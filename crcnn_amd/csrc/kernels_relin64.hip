@@ -80,10 +80,13 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024) relin_digits_f64_kernel(
                 }
                 continue;
             }
-            for (int s = threadIdx.x; s < n; s += blockDim.x) smd[swz<RB>(s)] = (double)(u32)((row[s] >> sh) & mask);
+            for (int s = 2 * threadIdx.x; s < n; s += 2 * blockDim.x) {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(row + s);
+                sm_store_pair<RB>(smd, s, (double)(u32)((v.x >> sh) & mask), (double)(u32)((v.y >> sh) & mask));
+            }
             __syncthreads();
             ntt_row_passes_f64<false, RB>(smd, Wf + (size_t)m * n, n, logn, fp.m[m]);
-            for (int s = threadIdx.x; s < n; s += blockDim.x) dst[s] = smd[swz<RB>(s)];
+            for (int s = 2 * threadIdx.x; s < n; s += 2 * blockDim.x) *reinterpret_cast<d2 *>(dst + s) = sm_load_pair<RB>(smd, s);
             __syncthreads();
         }
     }
@@ -145,11 +148,14 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 && !ONE_PER_CU ?
     double *a0row = A + ((ct * 2 * k + pj) * CRC_NF64) * (size_t)n;
     for (int m = 0; m < CRC_NF64; m++) {
         const double *src = a0row + (size_t)m * n;
-        for (int s = tid; s < n; s += nt) smd[swz<RB>(s)] = src[s];
+        for (int s = 2 * tid; s < n; s += 2 * nt) { const d2 v = *reinterpret_cast<const d2 *>(src + s); sm_store_pair<RB>(smd, s, v.x, v.y); }
         __syncthreads();
         ntt_row_passes_f64<true, RB>(smd, Wi + (size_t)m * n, n, logn, fp.m[m]);
         if (m == 0) {
-            for (int s = tid; s < n; s += nt) a0row[s] = f64_reduce(smd[swz<RB>(s)], fp.m[0]);
+            for (int s = 2 * tid; s < n; s += 2 * nt) {
+                const d2 v = sm_load_pair<RB>(smd, s);
+                *reinterpret_cast<d2 *>(a0row + s) = d2{f64_reduce(v.x, fp.m[0]), f64_reduce(v.y, fp.m[0])};
+            }
             __syncthreads();
         }
     }
@@ -158,10 +164,9 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 && !ONE_PER_CU ?
     const u64 q = mq.q, p0q = fp.p0_mod_q[j];
     const u64 *add = x3 + ((ct * add_size + poly) * k + j) * (size_t)n;
     u64 *dst = y + ((ct * 2 + poly) * k + j) * (size_t)n;
-    u64 *sm = reinterpret_cast<u64 *>(smd);           // (a thread reads and rewrites only its own positions of the image here: no barrier in between)
-    for (int s = tid; s < n; s += nt) {
-        const double a0 = a0row[s];                   // (written by this very thread above)
-        const double a1 = f64_reduce(smd[swz<RB>(s)], fp.m[1]);
+    u64 *sm = reinterpret_cast<u64 *>(smd);           // (a thread reads and rewrites only its own slot of the image here: no barrier in between)
+    auto lift = [&](double a0, double a1r, u64 addv) {
+        const double a1 = f64_reduce(a1r, fp.m[1]);
         const double t = f64_reduce(f64_mulmod_const(a1 - a0, fp.inv_p0_p1, fp.inv_p0_p1_q, fp.m[1].p), fp.m[1]);
         const long long ti = (long long)t, a0i = (long long)a0;
         u64 lo, hi; mul64wide((u64)(ti < 0 ? -ti : ti), p0q, lo, hi);
@@ -170,19 +175,30 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 && !ONE_PER_CU ?
         u64 a0m = (u64)(a0i < 0 ? -a0i : a0i);                    // |a0| < 2^46: below q for the 54..60-bit coefficient moduli, not for SEAL's 40-bit ones
         if (a0m >= q) a0m = barrett128(a0m, 0, mq);
         r = addmod(r, a0i < 0 ? negmod(a0m, q) : a0m, q);
-        r = addmod(r, add[s], q);
-        if (OUT_NTT) sm[swz<RB>(s)] = r; else dst[s] = r;
+        return addmod(r, addv, q);
+    };
+    for (int s = 2 * tid; s < n; s += 2 * nt) {
+        const d2 a0 = *reinterpret_cast<const d2 *>(a0row + s);              // (written by this very thread above)
+        const d2 a1 = sm_load_pair<RB>(smd, s);
+        const ulonglong2 av = *reinterpret_cast<const ulonglong2 *>(add + s);
+        const u64 r0 = lift(a0.x, a1.x, av.x), r1 = lift(a0.y, a1.y, av.y);
+        if (OUT_NTT) {
+            const int a = swz<RB>(s);
+            *reinterpret_cast<ulonglong2 *>(sm + (a & ~1)) = (a & 1) ? ulonglong2{r1, r0} : ulonglong2{r0, r1};
+        } else *reinterpret_cast<ulonglong2 *>(dst + s) = ulonglong2{r0, r1};
     }
     if (!OUT_NTT) return;
     // NTT-resident result: forward transform over q_j of (c_poly + R) in the same LDS image, same layout (ntt_device.h's radix-8 passes on the fp64 image's swizzle)
     __syncthreads();
     ntt_row_passes<false, LAZY, RB>(sm, Wq + (size_t)j * n, n, logn, q, mq.two_q);
     const float rq = 1.0f / (float)((u32)(q >> 32) + 1);
-    for (int s = tid; s < n; s += nt) {
-        u64 v = sm[swz<RB>(s)];
-        if (LAZY) v = reduce_small(v, q, mq.two_q, rq);
-        else { v = v >= mq.two_q ? v - mq.two_q : v; v = v >= q ? v - q : v; }
-        dst[s] = v;
+    for (int s = 2 * tid; s < n; s += 2 * nt) {
+        const int a = swz<RB>(s);
+        ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(sm + (a & ~1));
+        if (a & 1) { const u64 t = v.x; v.x = v.y; v.y = t; }
+        if (LAZY) { v.x = reduce_small(v.x, q, mq.two_q, rq); v.y = reduce_small(v.y, q, mq.two_q, rq); }
+        else { v.x = v.x >= mq.two_q ? v.x - mq.two_q : v.x; v.x = v.x >= q ? v.x - q : v.x; v.y = v.y >= mq.two_q ? v.y - mq.two_q : v.y; v.y = v.y >= q ? v.y - q : v.y; }
+        *reinterpret_cast<ulonglong2 *>(dst + s) = v;
     }
 }
 

@@ -11,6 +11,21 @@ __device__ __forceinline__ int lpad(int i) { return i ^ ((i >> 3) & 7) ^ (((i >>
 // the same idea for passes of 16 / 32 values per thread (the fp64 transforms of kernels_relin64.hip): XOR of higher index bits into the low four = the sixteen 8-byte
 // slots of a 128-byte LDS row; found by enumerating every pass's access pattern in groups of 16 lanes (forward and inverse, n = 4096 / 8192 / 16384): conflict-free for
 // their own radix, at most 2-way in one pass of the radix-8 transforms below when those run on an image laid out this way
+// (s, s + 1), s even, share one aligned 16-byte slot of the image (the swizzle only XORs higher index bits into bit 0), in either order: rows move between memory and
+// the image two points per lane -- one 16-byte global access and one ds_*_b128
+__device__ __forceinline__ void sm_store_pair64(u64 *sm, int s, u64 x, u64 y)
+{
+    const int a = lpad(s);
+    *reinterpret_cast<ulonglong2 *>(sm + (a & ~1)) = (a & 1) ? ulonglong2{y, x} : ulonglong2{x, y};
+}
+__device__ __forceinline__ ulonglong2 sm_load_pair64(const u64 *sm, int s)
+{
+    const int a = lpad(s);
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(sm + (a & ~1));
+    return (a & 1) ? ulonglong2{v.y, v.x} : v;
+}
+__device__ __forceinline__ ulonglong2 ld2(const u64 *p) { return *reinterpret_cast<const ulonglong2 *>(p); }
+__device__ __forceinline__ void st2(u64 *p, u64 x, u64 y) { *reinterpret_cast<ulonglong2 *>(p) = ulonglong2{x, y}; }
 template <int SW> __device__ __forceinline__ int swz(int i);
 template <> __device__ __forceinline__ int swz<3>(int i) { return lpad(i); }
 template <> __device__ __forceinline__ int swz<4>(int i) { return i ^ ((i >> 2) & 1) ^ ((i >> 4) & 15); }
