@@ -220,9 +220,7 @@ int k_square(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStream
 {
     if (cnt == 0) return CRC_OK;
     // the auxiliary base over the engine's fp64 primes whenever the parameters fit (every set of the reference's does); tune.sq_path = 1 keeps SEAL's 61-bit base
-    // (by default only while the fp64 base needs at most one row more than SEAL's -- k <= 4 with the reference's parameter sets: 5 rows for 4 at (8192, 3), 6 for 5
-    // at (16384, 4); at k = 8 it is 11 for 9 and the cheaper rows no longer pay for the two extra ones: 40.0 against 39.2 us per ciphertext)
-    if (c->tune.sq_path != 1 && k_square64_supported(c) && (c->tune.sq_path == 2 || c->sq64.kf <= c->kb + 1)) return k_square64(c, x, cnt, y3, work, st, in_ntt, premul_c2);
+    if (c->tune.sq_path != 1 && k_square64_supported(c)) return k_square64(c, x, cnt, y3, work, st, in_ntt, premul_c2);
     const size_t n = c->n, k = c->k, kb = c->kb;
     u64 *QN = work, *BS = QN + cnt * 2 * k * n, *DQ = BS + cnt * 2 * kb * n, *DB = DQ + cnt * 3 * k * n;
     const int threads = c->n < 256 ? c->n : 256, sblocks = c->n / threads;

@@ -28,6 +28,29 @@ for src, dst in (("ntt_elementwise.txt", "ntt_elementwise_kernels.txt"), ("mac_g
         open(os.path.join(P, f"{R}_{dst}"), "w").writelines(lines)
 
 
+# per launch shape: the kernel-stats average mixes launches of different layers (and the single-image module-load pass); the dominant launch is one shape
+def by_shape(trace, dst, title):
+    if not os.path.exists(trace):
+        return
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(trace)):
+        name = r["Kernel_Name"].split("(")[0]
+        grid = int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
+        acc[(name, grid, int(r["Workgroup_Size_X"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    rows = sorted(acc.items(), key=lambda kv: -sum(kv[1]))
+    with open(dst, "w") as f:
+        f.write(f"# {title}, by launch shape (under the profiler the clock is a few % lower than in bench runs)\n# kernel | grid (threads) | workgroup | launches | average ms | min | max\n")
+        for (name, grid, wg), v in rows:
+            if sum(v) < 0.05:
+                continue
+            f.write(f"{name[:60]:60s} {grid:>12d} {wg:>5d} {len(v):>5d} {sum(v) / len(v):>10.3f} {min(v):>10.3f} {max(v):>10.3f}\n")
+
+
+by_shape(os.path.join(F, "prof_tiny/tiny_kernel_trace.csv"), os.path.join(P, f"{R}_bench_tiny4096_by_launch_shape.txt"),
+         "rocprofv3 --kernel-trace of `python3 bench.py --cpu-seconds 0 --unfused-images 0 --also none --batch 256` (tiny4096, 128 images per launch)")
+by_shape(os.path.join(F, "prof_approx/approx_kernel_trace.csv"), os.path.join(P, f"{R}_bench_approx8192_by_launch_shape.txt"),
+         "rocprofv3 --kernel-trace of `python3 bench.py --config approx8192 --batch 96 --cpu-seconds 0 --unfused-images 0 --also none` (32 images per launch)")
+
 # PMC: counters are KiB; FETCH_SIZE is doubled on gfx950 for wide coalesced reads (MI355X_MICROARCH.md, HBM section)
 def tot(path, counter, kernel):
     acc = collections.defaultdict(float); t = {}
@@ -80,7 +103,7 @@ try:
                                algorithmic_bytes_per_ciphertext=sm["total"]["algorithmic"], ratio_to_algorithmic=sm["total"]["ratio"], kernels=sm["kernels"],
                                read_counter_calibration=sm["read_counter_calibration"],
                                note="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over tools/bench_square.py (NTT form in and out); the read counter is calibrated on the "
-                                    "plain row inverse transform of the same run, whose bytes are known (8 B per lane reads: MI355X_MICROARCH.md gives the factor 2 for 16 B per lane only)")
+                                    "plain row inverse transform of the same run, whose bytes are known (MI355X_MICROARCH.md gives the factor 2 for 16 B per lane reads; the kernels of the sequence mix widths)")
         except Exception as e:
             print("no square PMC summary for", tag, e)
     json.dump(out, open(os.path.join(P, f"{R}_pmc_traffic.json"), "w"), indent=1)

@@ -26,10 +26,15 @@ if [ $P = all ] || [ $P = square ]; then
 # Square + relinearise: per-kernel stats and PMC traffic at the three rings, and the round-2 key switching (CRC_RELIN_PATH=1) beside it
 for cfg in "8192 3 1250" "16384 4 512" "16384 8 256"; do tag=$(echo $cfg | tr ' ' '_')
   bash tools/prof_square.sh "$cfg" sq_$tag 0 > $O/prof_square_$tag.txt 2>&1
-  bash tools/prof_square.sh "$cfg" sqold_$tag 1 > $O/prof_square_old_$tag.txt 2>&1
+  CRC_SQ_PATH=1 bash tools/prof_square.sh "$cfg" sqold_$tag 1 > $O/prof_square_old_$tag.txt 2>&1
   bash tools/pmc_square.sh "$cfg" $tag > $O/pmc_square_$tag.json 2> $O/pmc_square_$tag.err
 done
-(for cfg in "8192 3 1250" "8192 4 1250" "16384 4 512" "16384 8 256"; do for p in 1 0; do echo "relin_path=$p"; CRC_RELIN_PATH=$p python tools/bench_square.py $cfg 2>&1 | grep -v amdgpu; done; done) > $O/square_paths.txt
+(for cfg in "8192 3 1250" "8192 4 1250" "16384 4 512" "16384 8 256"; do
+   echo "round-2 kernels (CRC_SQ_PATH=1 CRC_RELIN_PATH=1: SEAL's 61-bit auxiliary base, key switching over the coefficient moduli)"; CRC_SQ_PATH=1 CRC_RELIN_PATH=1 python tools/bench_square.py $cfg 2>&1 | grep -v amdgpu
+   echo "key switching over two fp64 primes, SEAL's auxiliary base (CRC_SQ_PATH=1)"; CRC_SQ_PATH=1 python tools/bench_square.py $cfg 2>&1 | grep -v amdgpu
+   echo "key switching and auxiliary base over fp64 primes (CRC_SQ_PATH=2)"; CRC_SQ_PATH=2 python tools/bench_square.py $cfg 2>&1 | grep -v amdgpu
+   echo "default"; python tools/bench_square.py $cfg 2>&1 | grep -v amdgpu
+ done) > $O/square_paths.txt
 fi
 if [ $P = all ] || [ $P = micro ]; then
 (python tools/bench_ntt.py 4096 2 8192; python tools/bench_ntt.py 8192 3 4096; python tools/bench_ntt.py 16384 4 1024) > $O/ntt_elementwise.txt 2>&1

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise the two PMC passes of tools/pmc_square.sh: HBM bytes per ciphertext and kernel of the Square + relinearise sequence.
 Counters are KiB (rocprofv3 derived FETCH_SIZE / WRITE_SIZE).  MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half of the bytes of wide (16 B / lane) coalesced
-reads and other widths are uncalibrated -- these kernels read 8 B per lane, so the read counter is calibrated here on a kernel of the same sequence whose bytes are known
+reads and other widths are uncalibrated -- the kernels of this sequence mix widths, so the read counter is calibrated here on a kernel of the same sequence whose bytes are known
 exactly: the row inverse transform ntt_rows_kernel<true, true, 0> reads each of its rows once (8 n bytes per row)."""
 import collections, csv, glob, json, sys
 O, cfg = sys.argv[1], sys.argv[2]
@@ -33,7 +33,7 @@ if cal_name:
     rows_calls = calls[cal_name]
     cal = known / fetch[cal_name] if fetch[cal_name] else None
 out = dict(config=dict(n=n, k=k, cts=cts), unit="bytes per ciphertext", read_counter_calibration=dict(kernel=cal_name, factor=cal,
-           note="known bytes / FETCH_SIZE of the plain row inverse transform (8 B per lane reads); the guide's factor for 16 B per lane reads is 2"), kernels={})
+           note="known bytes / FETCH_SIZE of the plain row inverse transform (16 B per lane reads since round 3's pair accesses; the guide's factor for such reads is 2, this kernel's known bytes give the factor used here)"), kernels={})
 tot_r = tot_w = 0.0
 for nm in sorted(ours, key=lambda x: -(fetch[x] + write.get(x, 0))):
     r = fetch[nm] * (cal or 2.0) / per; w = write.get(nm, 0.0) / per
