@@ -20,6 +20,20 @@ cp("prof_c1/c1_kernel_stats.csv", "conv1_4096k2_b128_kernel_stats.csv")
 for tag in ("8192_3_1250", "16384_4_512", "16384_8_256"):
     cp(f"prof_square_{tag}.txt", f"square_relin_{tag}_kernels.txt"); cp(f"prof_square_old_{tag}.txt", f"square_relin_{tag}_kernels_round2_path.txt")
 cp("square_paths.txt", "square_relin_paths.txt")
+# one file with the before / after per-kernel numbers and the path-by-path timings (what VERDICT r2 item 1 asks for)
+with open(os.path.join(P, f"{R}_square_relin.txt"), "w") as f:
+    f.write("# Square + relinearise (crc_square_relin_forms, NTT form in and out), us per ciphertext and kernel: rocprofv3 --kernel-trace --stats over tools/bench_square.py\n"
+            "# (tools/prof_square.sh; 4 sequences per run).  'round-2 kernels' = CRC_SQ_PATH=1 CRC_RELIN_PATH=1 on the same box and build: SEAL's 61-bit auxiliary base and key\n"
+            "# switching over the coefficient moduli; 'round 3' = the default (fp64 auxiliary base, key switching over two fp64 primes, 16-byte row accesses).\n")
+    for tag in ("8192_3_1250", "16384_4_512", "16384_8_256"):
+        n_, k_, c_ = tag.split("_")
+        for src, label in ((f"prof_square_old_{tag}.txt", "round-2 kernels"), (f"prof_square_{tag}.txt", "round 3")):
+            if os.path.exists(os.path.join(F, src)):
+                f.write(f"\n== n = {n_}, k = {k_}, {c_} ciphertexts per call: {label}\n")
+                f.writelines(l for l in open(os.path.join(F, src)) if "amdgpu.ids" not in l and not l.startswith("+") and "at::native" not in l and "rocclr" not in l)
+    if os.path.exists(os.path.join(F, "square_paths.txt")):
+        f.write("\n== wall time per call (HIP events, no profiler), path by path\n")
+        f.writelines(open(os.path.join(F, "square_paths.txt")))
 cp("../prof_sq_8192_3_1250/sq_8192_3_1250_kernel_stats.csv", "square_relin_8192k3_kernel_stats.csv")
 for src, dst in (("ntt_elementwise.txt", "ntt_elementwise_kernels.txt"), ("mac_geometries.txt", "mac_geometries.txt"), ("conv1.txt", "conv1_kernel.txt"), ("mfma_shape.txt", "mfma_shape.txt"),
                  ("square.txt", "square_relin_raw.txt")):
