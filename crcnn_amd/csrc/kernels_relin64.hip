@@ -102,11 +102,14 @@ __global__ void __launch_bounds__(256) relin_mac_f64_kernel(const double *E, con
 {
     constexpr int PJS = 2 * K / PJ;
     const int sblocks = n / blockDim.x;
+    // ciphertext group fastest: the workgroups that are resident together work on the SAME key tile (D x PJ values for 256 slots, 0.1-0.5 MiB: one L2 fill per XCD)
+    // and stream only their own digit values -- with the slot block fastest every ciphertext group pulled the whole key set (9-17 MB, more than an L2) again
+    const unsigned groups = (unsigned)((cnt + CT - 1) / CT);
     unsigned b = blockIdx.x;
+    const size_t ct0 = (size_t)(b % groups) * CT; b /= groups;
     const int s = (b % sblocks) * blockDim.x + threadIdx.x; b /= sblocks;
     const int pj0 = (b % PJS) * PJ; b /= PJS;
     const int m = b % CRC_NF64;
-    const size_t ct0 = (size_t)(b / CRC_NF64) * CT;
     const F64Mod md = fp.m[m];
     double acc[CT][PJ];
 #pragma unroll
