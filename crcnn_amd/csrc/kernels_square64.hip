@@ -15,7 +15,6 @@
 //   sq64_floor_kernel : x t, fast_floor, fastbconv_sk back to q (one lazy 128-bit sum + one reduction per q_i), optional (q/q_i)^-1 on c2 for relinearisation
 #include "kernels.h"
 #include "ntt_f64.h"
-#include <type_traits>
 
 // every (k, kf) a context can have is not known at compile time (kf depends on t): instances for k = 1..8 with the kf range 3..12 the size rule can produce for 40-60-bit q_i
 #define CRC_FOR_ALL_K_KF(X) \
@@ -115,85 +114,60 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 ? 8 : 4) sq64_in
 }
 
 // dq: [count][3][K][n] u64 (coefficient form over q, scaled), db: [count][3][KF][n] doubles (n times the coefficient, reduced) -> y3: [count][3][K][n].
-// V neighbouring coefficients per thread (1: see the launch)
-template <int V> struct VecOf;
-template <> struct VecOf<1> { typedef u64 U; typedef double D; };
-template <> struct VecOf<2> { typedef ulonglong2 U; typedef d2 D; };
-template <int V, typename T, typename S> __device__ __forceinline__ void vload(T (&dst)[V], const S *src)
-{
-    if constexpr (V == 1) dst[0] = src[0];
-    else { const auto v = *reinterpret_cast<const typename std::conditional<sizeof(S) == 8 && std::is_same<S, double>::value, d2, ulonglong2>::type *>(src); dst[0] = v.x; dst[1] = v.y; }
-}
-template <int K, int KF, int V>
+// (One coefficient per thread: two, as in the lift kernel, cost more in occupancy than the 16-byte accesses returned -- 0.77 against 0.64 us per ciphertext at (8192, 3))
+template <int K, int KF>
 __global__ void __launch_bounds__(256) sq64_floor_kernel(const u64 *dq, const double *db, u64 *y3, const ModParams *mods, const BehzParams *bp, const Sq64Params *sp, int n, int premul_c2)
 {
     const BehzParams &b = *bp; const Sq64Params &f = *sp;
     constexpr int KB = KF - 1;
-    const int sblocks = n / (V * blockDim.x);
+    const int sblocks = n / blockDim.x;
     const size_t poly = blockIdx.x / sblocks;                       // ct*3 + p
-    const int s = ((blockIdx.x % sblocks) * blockDim.x + threadIdx.x) * V;
+    const int s = (blockIdx.x % sblocks) * blockDim.x + threadIdx.x;
     const u64 *xq = dq + poly * (size_t)K * n + s;
     const double *xb = db + poly * (size_t)KF * n + s;
-    double th[K][V], tl[K][V];
+    double th[K], tl[K];
     // x t (evaluator.cpp:856-871) and the (q/q_i)^-1 of fastbconv (:413-423) are one constant
 #pragma unroll
     for (int i = 0; i < K; i++) {
-        u64 xv[V]; vload<V>(xv, xq + (size_t)i * n);
-#pragma unroll
-        for (int e = 0; e < V; e++) {
-            const u64 tr = mulmod_shoup(xv[e], b.t_inv_qhat[i], b.t_inv_qhat_s[i], mods[i].q);
-            th[i][e] = (double)(u32)(tr >> 32); tl[i][e] = (double)(u32)tr;
-        }
+        const u64 tr = mulmod_shoup(xq[(size_t)i * n], b.t_inv_qhat[i], b.t_inv_qhat_s[i], mods[i].q);
+        th[i] = (double)(u32)(tr >> 32); tl[i] = (double)(u32)tr;
     }
-    // fast_floor (:646-660): (x_p t - fastbconv(x_q t)) q^-1 mod p_j, with q^-1 (and the inverse transform's n^-1) folded into floor_x / floor_c;
-    // fastbconv_sk (:448-579): z_j = fl_j (B/p_j)^-1 mod p_j in [0, p_j)
-    const F64Mod msk = f.m[KB];
-    double z[KB][V], v[V], flsk[V];
-#pragma unroll
-    for (int e = 0; e < V; e++) v[e] = 0.0;
+    // fast_floor (:646-660): (x_p t - fastbconv(x_q t)) q^-1 mod p_j, with q^-1 (and the inverse transform's n^-1) folded into floor_x / floor_c
+    double fl[KF];
 #pragma unroll
     for (int j = 0; j < KF; j++) {
         const double p = f.m[j].p;
-        double x[V]; vload<V>(x, xb + (size_t)j * n);
+        double a = f64_mulmod_const(xb[(size_t)j * n], f.floor_x[j][0], f.floor_x[j][1], p);
 #pragma unroll
-        for (int e = 0; e < V; e++) {
-            double a = f64_mulmod_const(x[e], f.floor_x[j][0], f.floor_x[j][1], p);
-#pragma unroll
-            for (int i = 0; i < K; i++) a += mul_split(th[i][e], tl[i][e], f.floor_c[j][i], p);                  // :425-445
-            const double fl = f64_reduce(a, f.m[j]);
-            if (j < KB) {
-                double zz = f64_reduce(f64_mulmod_const(fl, f.inv_mhat[j][0], f.inv_mhat[j][1], p), f.m[j]);
-                zz = zz < 0.0 ? zz + p : zz;
-                z[j < KB ? j : 0][e] = zz;
-                v[e] += f64_mulmod_const(zz, f.mhat_msk[j][0], f.mhat_msk[j][1], msk.p);
-            } else flsk[e] = fl;
-        }
+        for (int i = 0; i < K; i++) a += mul_split(th[i], tl[i], f.floor_c[j][i], p);                            // :425-445
+        fl[j] = f64_reduce(a, f.m[j]);
     }
+    // fastbconv_sk (:448-579): z_j = fl_j (B/p_j)^-1 mod p_j in [0, p_j)
+    const F64Mod msk = f.m[KB];
+    double z[KB], v = 0.0;
+#pragma unroll
+    for (int j = 0; j < KB; j++) {
+        double zz = f64_reduce(f64_mulmod_const(fl[j], f.inv_mhat[j][0], f.inv_mhat[j][1], f.m[j].p), f.m[j]);
+        zz = zz < 0.0 ? zz + f.m[j].p : zz;
+        z[j] = zz;
+        v += f64_mulmod_const(zz, f.mhat_msk[j][0], f.mhat_msk[j][1], msk.p);
+    }
+    // alpha = (sum_j z_j (B/p_j) - R) / B, from its residue mod m_sk: a small integer (|alpha| <= KB + |R| / B, far inside the centred range), exact in the double
+    const double ad = f64_reduce(f64_mulmod_const(f64_reduce(v - fl[KB], msk), f.inv_B_msk[0], f.inv_B_msk[1], msk.p), msk);
+    const long long alpha = (long long)ad;
+    const bool neg = alpha < 0;
+    const u64 am = (u64)(neg ? -alpha : alpha);
     u64 *dst = y3 + poly * (size_t)K * n + s;
-    u64 out[K][V];
-#pragma unroll
-    for (int e = 0; e < V; e++) {
-        // alpha = (sum_j z_j (B/p_j) - R) / B, from its residue mod m_sk: a small integer (|alpha| <= KB + |R| / B, far inside the centred range), exact in the double
-        const double ad = f64_reduce(f64_mulmod_const(f64_reduce(v[e] - flsk[e], msk), f.inv_B_msk[0], f.inv_B_msk[1], msk.p), msk);
-        const long long alpha = (long long)ad;
-        const bool neg = alpha < 0;
-        const u64 am = (u64)(neg ? -alpha : alpha);
-#pragma unroll
-        for (int i = 0; i < K; i++) {
-            const ModParams mi = mods[i];
-            acc128 a{0, 0};
-#pragma unroll
-            for (int j = 0; j < KB; j++) acc_mad(a, (u64)z[j][e], f.mhat_q[i][j]);       // 47 x <= 60 bits, at most 11 terms: below 2^111
-            acc_mad(a, neg ? f.B_q[i] : mi.q - f.B_q[i], am);                            // - alpha B   (:553-569)
-            u64 r = barrett128(a.lo, a.hi, mi);
-            if (premul_c2 && poly % 3 == 2) r = mulmod_shoup(r, b.inv_qhat[i], b.inv_qhat_s[i], mi.q);
-            out[i][e] = r;
-        }
-    }
 #pragma unroll
     for (int i = 0; i < K; i++) {
-        if constexpr (V == 1) dst[(size_t)i * n] = out[i][0];
-        else *reinterpret_cast<ulonglong2 *>(dst + (size_t)i * n) = ulonglong2{out[i][0], out[i][1]};
+        const ModParams mi = mods[i];
+        acc128 a{0, 0};
+#pragma unroll
+        for (int j = 0; j < KB; j++) acc_mad(a, (u64)z[j], f.mhat_q[i][j]);          // 47 x <= 60 bits, at most 11 terms: below 2^111
+        acc_mad(a, neg ? f.B_q[i] : mi.q - f.B_q[i], am);                            // - alpha B   (:553-569)
+        u64 r = barrett128(a.lo, a.hi, mi);
+        if (premul_c2 && poly % 3 == 2) r = mulmod_shoup(r, b.inv_qhat[i], b.inv_qhat_s[i], mi.q);
+        dst[(size_t)i * n] = r;
     }
 }
 
@@ -250,11 +224,10 @@ int k_square64(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStre
         HIPCHK(hipGetLastError());
     }
     {
-        constexpr int V = 1;      // (two coefficients per thread, as in the lift kernel, cost more in occupancy here than the wider accesses return: 0.77 against 0.64 us at (8192, 3))
-        const int fthreads = c->n < 256 * V ? c->n / V : 256;
-        const dim3 grid((unsigned)(cnt * 3 * (c->n / (V * fthreads)))), blk(fthreads);
+        const int threads = c->n < 256 ? c->n : 256;
+        const dim3 grid((unsigned)(cnt * 3 * (c->n / threads))), blk(threads);
         bool launched = false;
-#define FLOOR(KV, KFV) if (c->k == KV && c->sq64.kf == KFV) { hipLaunchKernelGGL((sq64_floor_kernel<KV, KFV, V>), grid, blk, 0, st, DQ, DB, y3, c->d_mods, c->d_behz, c->d_sq64, c->n, premul_c2 ? 1 : 0); launched = true; }
+#define FLOOR(KV, KFV) if (c->k == KV && c->sq64.kf == KFV) { hipLaunchKernelGGL((sq64_floor_kernel<KV, KFV>), grid, blk, 0, st, DQ, DB, y3, c->d_mods, c->d_behz, c->d_sq64, c->n, premul_c2 ? 1 : 0); launched = true; }
         CRC_FOR_ALL_K_KF(FLOOR)
 #undef FLOOR
         if (!launched) return CRC_ERR_UNSUPPORTED;
