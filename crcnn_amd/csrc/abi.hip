@@ -379,7 +379,7 @@ extern "C" int crc_plan_fold_pool(const crc_ctx *c, int zd, int xd, int yd, int 
 
 // ---- square + relinearize -----------------------------------------------------------------------------------------
 // ciphertexts per internal pass (bounds the scratch footprint: ~10 GB at every ring size -- 512 up to n k = 65536, 256 at n = 16384 with all eight primes)
-static size_t square_chunk(const crc_ctx *c) { const size_t nk = (size_t)c->n * c->k; return nk <= 65536 ? 512 : nk <= 131072 ? 256 : 128; }
+static size_t square_chunk(const crc_ctx *c) { if (c->tune.sq_chunk > 0) return (size_t)c->tune.sq_chunk; const size_t nk = (size_t)c->n * c->k; return nk <= 65536 ? 512 : nk <= 131072 ? 256 : 128; }
 
 extern "C" size_t crc_square_relin_work_bytes(const crc_ctx *c, size_t count, int dbc)
 {

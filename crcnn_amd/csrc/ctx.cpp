@@ -172,6 +172,7 @@ static void read_tuning(CrcTuning &t)
     t.mac2_dbg = (int)geti("CRC_MAC2_DBG", 0);
     t.relin_path = (int)geti("CRC_RELIN_PATH", 0);
     t.sq_path = (int)geti("CRC_SQ_PATH", 0);
+    t.sq_chunk = (int)geti("CRC_SQ_CHUNK", 0);
     t.f64_radix = (int)geti("CRC_F64_RADIX", 0);
     t.mfma_min_steps = (int)geti("CRC_MFMA_MIN_STEPS", 0);
     t.relin_mac_ct = (int)geti("CRC_RELIN_MAC_CT", 0);
@@ -194,6 +195,7 @@ extern "C" int crc_ctx_set_tuning(crc_ctx *c, const char *name, long long value)
     else if (s == "ntt_inv61_loose") t.ntt_inv61_loose = value ? 1 : 0;
     else if (s == "relin_path") t.relin_path = (int)value;
     else if (s == "sq_path") t.sq_path = (int)value;
+    else if (s == "sq_chunk") t.sq_chunk = (int)value;
     else if (s == "f64_radix") t.f64_radix = (int)value;
     else if (s == "mfma_min_steps") t.mfma_min_steps = (int)value;
     else if (s == "relin_mac_ct") t.relin_mac_ct = (int)value;

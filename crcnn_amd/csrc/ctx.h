@@ -113,6 +113,7 @@ struct CrcTuning {
     int relin_mac_ct = 0;         // CRC_RELIN_MAC_CT=8: eight ciphertexts per thread in relin_mac_f64_kernel for k >= 4 (default 4)
     int mfma_min_steps = 0;       // CRC_MFMA_MIN_STEPS: reduction steps of 32 channels from which a conv / dense layer goes to the limb GEMM (0: 8)
     int f64_radix = 0;            // CRC_F64_RADIX=3|4|5: butterfly stages per LDS pass of the fp64 transforms (0: default)
+    int sq_chunk = 0;             // CRC_SQ_CHUNK: ciphertexts per internal pass of square + relinearise (0: by ring size)
     int sq_path = 0;              // CRC_SQ_PATH=0: by parameters, 1: the square's auxiliary base is SEAL's 61-bit one (round-2 kernels), 2: the engine's fp64 primes
     int relin_path = 0;           // CRC_RELIN_PATH=0: by parameters, 1: key switching over the coefficient moduli (round-2 path), 2: over the two fp64 primes
 };

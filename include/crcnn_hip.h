@@ -89,11 +89,15 @@ int  crc_ctx_device(const crc_ctx *ctx);
 size_t crc_ct_words(const crc_ctx *ctx, int size);     /* size*k*n */
 size_t crc_evk_words(const crc_ctx *ctx, int dbc);     /* words of an evaluation-key blob: sum_l 2*L_l*k*n */
 /* named host-side table read-out (tests): "root","const_ratio","delta","upper_half_increment","bsk","bsk_root",
- * "root_powers:<i>","inv_root_powers_div_two:<i>"; returns word count */
+ * "root_powers:<i>","inv_root_powers_div_two:<i>", "f64_primes" (the two fp64 primes of relinearisation's key switching), "sq64_primes" (the fp64 primes that
+ * carry the square's auxiliary base: B' = all but the last, m_sk' = the last; empty when the parameters do not fit twelve of them); returns word count */
 int  crc_ctx_table(const crc_ctx *ctx, const char *name, uint64_t *h_out, int cap);
 /* Tuning switches of tools/ and the tests (none is needed for normal use).  The engine reads its environment (CRC_MFMA_VARIANT, CRC_CONV1_PASS_BYTES, ...) exactly
  * once, inside crc_ctx_create; this call changes one switch of a context nobody is launching on: "mfma_variant", "mfma_order", "mfma_ring", "conv1_waves",
- * "conv1_pass_bytes", "limb_pack_group", "mac2_cfg", "mac_order", "mac_regstage", "ntt_inv61_loose", "relin_path".  CRC_ERR_NOT_FOUND for anything else. */
+ * "conv1_pass_bytes", "limb_pack_group", "mac2_cfg", "mac_order", "mac_regstage", "ntt_inv61_loose", "ntt_split", "mfma_min_steps", "f64_radix", "relin_mac_ct",
+ * "relin_path" (1: key switching over the coefficient moduli, as the reference does it, instead of over two fp64 primes), "sq_path" (1: the square's auxiliary base is SEAL's 61-bit
+ * one instead of the engine's fp64 primes; 2: force the latter), "sq_chunk" (ciphertexts per internal pass of square + relinearise; changes crc_square_relin_work_bytes).
+ * Every path gives the same ciphertexts.  CRC_ERR_NOT_FOUND for anything else. */
 int  crc_ctx_set_tuning(crc_ctx *ctx, const char *name, long long value);
 
 /* thin device-memory helpers so that C / C++ / ctypes callers need not link HIP themselves */
@@ -171,7 +175,10 @@ int crc_multiply_plain(crc_ctx *ctx, uint64_t *d_ct, const uint64_t *d_w_ntt, si
  *   crc_square_relin  SquareLayer::forward (squareLayer.cpp:22-74) = Evaluator::square (evaluator.cpp:702-884) +
  *                relinearize (:886-1069) with decomposition-bit-count `dbc` keys.  Coefficient form in and out.
  *                d_evk: for l<k: [2*L_l][k][n] (= evaluation_keys.data()[0][l], pad words dropped), values may be
- *                SEAL's lazy non-canonical residues.
+ *                SEAL's lazy non-canonical residues.  The result is the reference's ciphertext bit for bit; HOW it is computed differs where
+ *                BFV leaves the evaluator a choice of moduli: BEHZ's auxiliary base (baseconverter.cpp:47-56 takes 61-bit primes) and the key-switching
+ *                inner products (evaluator.cpp:997-1030 transforms every digit under every q_j) run over 47-bit primes of the engine's own in exact fp64
+ *                arithmetic; crc_ctx_set_tuning "sq_path" / "relin_path" = 1 select kernels that follow the reference step by step.
  * ------------------------------------------------------------------------------------------------------------- */
 size_t crc_conv2d_work_bytes(const crc_ctx *ctx, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int in_form);
 int crc_conv2d(crc_ctx *ctx, const uint64_t *d_x, const uint64_t *d_w_ntt, const uint64_t *d_bias_delta,
