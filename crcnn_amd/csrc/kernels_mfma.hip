@@ -364,7 +364,9 @@ __global__ void __launch_bounds__(64) limb_pack_tensor_kernel(const u64 *x, i8 *
     // the L2 can merge them into whole lines before they go to HBM
     for (size_t r0 = (size_t)(blockIdx.x / (sblocks * k)) * group, u = 0; u < (size_t)group && r0 + u < items; u++) {
         size_t r = r0 + u;
-        const int zb = (int)(r % zblks); r /= zblks; const int c = (int)(r % 2); r /= 2; const int pos = (int)(r % npos); const int b = (int)(r / npos);
+        int zb, c, pos, b;
+        if (npos == 1) { const size_t rows = (size_t)B * 2; zb = (int)(r / rows); r %= rows; c = (int)(r & 1); b = (int)(r >> 1); pos = 0; }      // K-blocked: a thread's items are neighbouring rows of one channel block
+        else { zb = (int)(r % zblks); r /= zblks; c = (int)(r % 2); r /= 2; pos = (int)(r % npos); b = (int)(r / npos); }
         u32 pl[NPL][8];
 #pragma unroll
         for (int l = 0; l < NPL; l++)
@@ -496,7 +498,9 @@ int k_limb_pack_tensor(crc_ctx *c, const u64 *x, i8 *xl, int B, int zd, int npos
     if (Btot <= 0) { Btot = B; b0 = 0; }
     if (b0 < 0 || b0 + B > Btot) return CRC_ERR_INVALID_ARGUMENT;
     const int zdp = round_up(zd, 32);
-    const int group = c->tune.limb_pack_group;     // (4 and 8 adjacent pieces per thread measured 3-7 % slower)
+    // pieces per thread: a dense layer's K-blocked tensor (one position) takes 4 neighbouring rows of a channel block -- 4 x 32 B = one whole line per plane, written back to
+    // back; for the convolution layout 4 and 8 adjacent pieces per thread measured 3-7 % slower
+    const int group = c->tune.limb_pack_group > 1 ? c->tune.limb_pack_group : (npos == 1 && (B * 2) % 4 == 0 ? 4 : 1);
     const size_t items = (size_t)B * npos * 2 * (zdp / 32);
     const size_t blocks = (size_t)(c->n / 64) * c->k * ((items + group - 1) / group);
     if (blocks == 0) return CRC_OK;
