@@ -394,36 +394,58 @@ __global__ void __launch_bounds__(64) limb_pack_tensor_kernel(const u64 *x, i8 *
         }
     }
 }
-// NTT-form weights w [F][zd][taps][k][n] (canonical) -> Wl (pre-zeroed: channel / filter padding).  One thread per (slot, filter, tap, channel block).
+// NTT-form weights w [F][zd][taps][k][n] (canonical) -> Wl (pre-zeroed: channel / filter padding).  A transpose: the source rows are slot-minor, Wl is slot-major with
+// the 32-byte piece of a (filter, tap, channel block) as its unit.  A workgroup = 64 consecutive slots x 4 neighbouring filters of one (tap, channel block): thread
+// (slot lane, filter) reads its 32 channel values -- lanes run over the slots, every load a coalesced 512-byte row segment -- and stages the seven planes' 32 bytes in
+// LDS; then the workgroup writes the staged block so that the 4 x 32 = 128 contiguous bytes a (slot, plane) owns leave as ONE whole line from eight adjacent lanes.
+// (Round 2's form -- one thread per piece, every lane storing 32 bytes into its own slot block 3.5 MB from its neighbour's -- ran at 1.0 TB/s; a streamed layer packs
+// its weights inside every forward: PlainModelWoPad's fc3 with all eight primes spent 23 of its 40 ms per image here.)
 // w may be a TILE of the layer's filters: filter f of w is filter f0 + f of Wl (whose filter stride Fp belongs to the whole layer)
-__global__ void __launch_bounds__(64) limb_pack_weights_kernel(const u64 *w, i8 *wl, const ModParams *mods, int n, int k, int F, int Fp, int zd, int zblks, int taps, int f0)
+#define WFG 4
+#define WSL 32
+// (32 slots per workgroup: 28 KiB of staging, five workgroups per CU -- the loads of one overlap the digit arithmetic and the stores of the others; with 64 slots and two
+// workgroups per CU loads, arithmetic and stores ran one after the other: 8 + 8 + 11 ms of a 27-ms call.)  Fz >= F: filters F .. Fz-1 are written as zeros (the filter
+// padding of the layer's last tile), so nothing has to be cleared beforehand
+__global__ void __launch_bounds__(256) limb_pack_weights_kernel(const u64 *w, i8 *wl, const ModParams *mods, int n, int k, int F, int Fz, int Fp, int zd, int zblks, int taps, int f0)
 {
-    const int sblocks = n / 64;
-    const int sb = blockIdx.x % (sblocks * k), i = sb / sblocks, s = (sb % sblocks) * 64 + threadIdx.x;
-    size_t r = blockIdx.x / (sblocks * k);                       // (f*taps + tap)*zblks + zb
-    const int zb = (int)(r % zblks); r /= zblks; const int tap = (int)(r % taps); const int f = (int)(r / taps);
+    __shared__ __attribute__((aligned(16))) i8 st[WSL * NPL * WFG * 32];         // [slot][plane][filter of the group][32 channels]
+    const int sblocks = n / WSL;
+    const int sb = blockIdx.x % (sblocks * k), i = sb / sblocks, s0 = (sb % sblocks) * WSL;
+    size_t r = blockIdx.x / (sblocks * k);                       // (fg*taps + tap)*zblks + zb, fg = group of WFG filters
+    const int zb = (int)(r % zblks); r /= zblks; const int tap = (int)(r % taps); const int fg = (int)(r / taps);
     const ModParams m = mods[i];
     const u64 R = barrett128(0, 1, m);                           // 2^64 mod q: the factor the kernel's Montgomery reduction divides out
-    u32 pl[NPL][8];
+    const int lane = threadIdx.x & (WSL - 1), fq = (threadIdx.x >> 5) & (WFG - 1), h = threadIdx.x >> 7, f = fg * WFG + fq;      // thread = (slot, filter, 16-channel half)
+    {
+        u32 pl[NPL][4];
 #pragma unroll
-    for (int l = 0; l < NPL; l++)
+        for (int l = 0; l < NPL; l++)
 #pragma unroll
-        for (int wv = 0; wv < 8; wv++) pl[l][wv] = 0;
+            for (int wv = 0; wv < 4; wv++) pl[l][wv] = 0;
+        if (f < F) {
+            const u64 *src = w + ((((size_t)f * zd + (size_t)zb * 32 + h * 16) * taps + tap) * k + i) * (size_t)n + s0 + lane;
 #pragma unroll
-    for (int z = 0; z < 32; z++) {
-        const int zz = zb * 32 + z;
-        if (zz < zd) {
-            const u64 v = mulmod(w[((((size_t)f * zd + zz) * taps + tap) * k + i) * (size_t)n + s], R, m);
-            int d[NPL]; limb_digits(v, m.q, d);
+            for (int z = 0; z < 16; z++)
+                if (zb * 32 + h * 16 + z < zd) {
+                    const u64 v = mulmod(src[(size_t)z * taps * k * n], R, m);
+                    int d[NPL]; limb_digits(v, m.q, d);
 #pragma unroll
-            for (int l = 0; l < NPL; l++) pl[l][z >> 2] |= (u32)(d[l] & 0xff) << (8 * (z & 3));
+                    for (int l = 0; l < NPL; l++) pl[l][z >> 2] |= (u32)(d[l] & 0xff) << (8 * (z & 3));
+                }
         }
-    }
-    i8 *dst = wl + ((size_t)i * n + s) * ((size_t)((taps * zblks + 1) & ~1) * NPL * Fp * 32) + ((size_t)tap * zblks + zb) * (NPL * Fp * 32) + (size_t)(f0 + f) * 32;
+        i8 *sp = st + (size_t)lane * (NPL * WFG * 32) + fq * 32 + h * 16;
 #pragma unroll
-    for (int l = 0; l < NPL; l++) {
-        uint4 *o = reinterpret_cast<uint4 *>(dst + (size_t)l * Fp * 32);
-        o[0] = make_uint4(pl[l][0], pl[l][1], pl[l][2], pl[l][3]); o[1] = make_uint4(pl[l][4], pl[l][5], pl[l][6], pl[l][7]);
+        for (int l = 0; l < NPL; l++) *reinterpret_cast<uint4 *>(sp + l * (WFG * 32)) = make_uint4(pl[l][0], pl[l][1], pl[l][2], pl[l][3]);
+    }
+    __syncthreads();
+    // WSL slots x 7 planes runs of WFG * 32 bytes, 16 bytes per lane: eight adjacent lanes write one run (filters past Fz of a ragged last group are not stored)
+    const int pieces_per_run = WFG * 2, filters_here = min(WFG, Fz - fg * WFG);
+    const size_t slot_stride = (size_t)((taps * zblks + 1) & ~1) * NPL * Fp * 32;
+    for (int o = threadIdx.x; o < WSL * NPL * pieces_per_run; o += 256) {
+        const int run = o / pieces_per_run, part = o - run * pieces_per_run, sl = run / NPL, l = run - sl * NPL;
+        if ((part >> 1) >= filters_here) continue;
+        i8 *dst = wl + ((size_t)i * n + s0 + sl) * slot_stride + ((size_t)tap * zblks + zb) * (NPL * Fp * 32) + (size_t)l * Fp * 32 + (size_t)(f0 + fg * WFG) * 32 + part * 16;
+        *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(st + (size_t)run * (WFG * 32) + part * 16);
     }
 }
 // Ys [slot][rows] (rows = B*F*P*2 canonical u64, slot-major) -> y [rows][k][n] (the engine's slot-minor tensor layout): 64 x 64 tile transpose through LDS
@@ -515,15 +537,14 @@ int k_limb_pack_weights(crc_ctx *c, const u64 *w, i8 *wl, int nf, int zd, int ta
     if (ft < 0) ft = nf;
     if (f0 < 0 || ft < 1 || f0 + ft > nf) return CRC_ERR_INVALID_ARGUMENT;
     const int zblks = round_up(zd, 32) / 32, Fp = round_up(nf, 64);
-    if (f0 == 0) {
-        // zero what no filter / channel / step writes: with whole filter and channel blocks that is only the zero step that evens out an odd number of reduction steps
-        const size_t step = (size_t)NPL * Fp * 32, steps = (size_t)taps * zblks, slot = (size_t)round_up((int)steps, 2) * step;
-        if (nf % 64 == 0 && zd % 32 == 0) { if (steps & 1) HIPCHK(hipMemset2DAsync(wl + steps * step, slot, 0, step, (size_t)c->n * c->k, st)); }
-        else HIPCHK(hipMemsetAsync(wl, 0, k_limb_weights_bytes(c, nf, zd, taps), st));
-    }
-    const size_t blocks = (size_t)(c->n / 64) * c->k * ft * taps * zblks;
+    // the kernel writes every channel of every filter it is given, zeros for the channel padding; the call that holds the layer's last filter also writes the filter
+    // padding up to Fp as zeros.  What no call writes is the zero step that evens out an odd number of reduction steps: cleared with the first tile
+    const size_t step = (size_t)NPL * Fp * 32, steps = (size_t)taps * zblks, slot = (size_t)round_up((int)steps, 2) * step;
+    if (f0 == 0 && (steps & 1)) HIPCHK(hipMemset2DAsync(wl + steps * step, slot, 0, step, (size_t)c->n * c->k, st));
+    const int fz = f0 + ft == nf ? Fp - f0 : ft;
+    const size_t blocks = (size_t)(c->n / WSL) * c->k * ((fz + WFG - 1) / WFG) * taps * zblks;
     if (blocks > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(limb_pack_weights_kernel, dim3((unsigned)blocks), dim3(64), 0, st, w, wl, c->d_mods, c->n, c->k, ft, Fp, zd, zblks, taps, f0);
+    hipLaunchKernelGGL(limb_pack_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, wl, c->d_mods, c->n, c->k, ft, fz, Fp, zd, zblks, taps, f0);
     HIPCHK(hipGetLastError());
     return CRC_OK;
 }
