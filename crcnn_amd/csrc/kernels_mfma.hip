@@ -394,6 +394,53 @@ __global__ void __launch_bounds__(64) limb_pack_tensor_kernel(const u64 *x, i8 *
         }
     }
 }
+// The same conversion for ONE position (a dense layer's K-blocked tensor [plane][channel block][row = image * 2 + poly][32]) as an LDS-staged transpose, the structure of
+// limb_pack_weights_kernel below: a workgroup = 32 slots x 4 neighbouring rows of one channel block; thread (slot, row, 16-channel half) reads its channel values (lanes
+// over slots: coalesced row segments), stages the seven planes' bytes, and the workgroup writes every (slot, plane)'s 4 x 32 = 128 contiguous bytes as one line.
+#define TRG 4
+#define TSL 32
+__global__ void __launch_bounds__(256) limb_pack_dense_kernel(const u64 *x, i8 *xl, const ModParams *mods, int n, int k, int B, int zd, int zdp, int packed, int Btot, int b0)
+{
+    __shared__ __attribute__((aligned(16))) i8 st[TSL * NPL * TRG * 32];         // [slot][plane][row of the group][32 channels]
+    const int sblocks = n / TSL, zblks = zdp / 32, rgs = (2 * B + TRG - 1) / TRG;
+    const int sb = blockIdx.x % (sblocks * k), i = sb / sblocks, s0 = (sb % sblocks) * TSL;
+    size_t r = blockIdx.x / (sblocks * k);                       // zb * rgs + row group
+    const int rg = (int)(r % rgs), zb = (int)(r / rgs);
+    const u64 q = mods[i].q;
+    const int lane = threadIdx.x & (TSL - 1), qrow = (threadIdx.x >> 5) & (TRG - 1), h = threadIdx.x >> 7, row = rg * TRG + qrow;      // row = image * 2 + poly inside this call
+    {
+        u32 pl[NPL][4];
+#pragma unroll
+        for (int l = 0; l < NPL; l++)
+#pragma unroll
+            for (int wv = 0; wv < 4; wv++) pl[l][wv] = 0;
+        if (row < 2 * B) {
+            const int b = row >> 1, c = row & 1, z0 = zb * 32 + h * 16;
+            const u64 *src = x + ((((size_t)b * zd + z0) * 2 + c) * k + i) * (size_t)n + s0 + lane;
+#pragma unroll
+            for (int z = 0; z < 16; z++)
+                if (z0 + z < zd) {
+                    u64 v = src[(size_t)z * 2 * k * n];
+                    if (packed) v = (v & 0xffffffffULL) | ((v >> 32) << 28);
+                    int d[NPL]; limb_digits(v, q, d);
+#pragma unroll
+                    for (int l = 0; l < NPL; l++) pl[l][z >> 2] |= (u32)(d[l] & 0xff) << (8 * (z & 3));
+                }
+        }
+        i8 *sp = st + (size_t)lane * (NPL * TRG * 32) + qrow * 32 + h * 16;
+#pragma unroll
+        for (int l = 0; l < NPL; l++) *reinterpret_cast<uint4 *>(sp + l * (TRG * 32)) = make_uint4(pl[l][0], pl[l][1], pl[l][2], pl[l][3]);
+    }
+    __syncthreads();
+    const int pieces_per_run = TRG * 2, rows_here = min(TRG, 2 * B - rg * TRG);
+    const size_t plane_stride = (size_t)zblks * (2 * Btot) * 32, slot_stride = (size_t)NPL * plane_stride;
+    for (int o = threadIdx.x; o < TSL * NPL * pieces_per_run; o += 256) {
+        const int run = o / pieces_per_run, part = o - run * pieces_per_run, sl = run / NPL, l = run - sl * NPL;
+        if ((part >> 1) >= rows_here) continue;
+        i8 *dst = xl + ((size_t)i * n + s0 + sl) * slot_stride + (size_t)l * plane_stride + ((size_t)zb * (2 * Btot) + (size_t)b0 * 2 + rg * TRG) * 32 + part * 16;
+        *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(st + (size_t)run * (TRG * 32) + part * 16);
+    }
+}
 // NTT-form weights w [F][zd][taps][k][n] (canonical) -> Wl (pre-zeroed: channel / filter padding).  A transpose: the source rows are slot-minor, Wl is slot-major with
 // the 32-byte piece of a (filter, tap, channel block) as its unit.  A workgroup = 64 consecutive slots x 4 neighbouring filters of one (tap, channel block): thread
 // (slot lane, filter) reads its 32 channel values -- lanes run over the slots, every load a coalesced 512-byte row segment -- and stages the seven planes' 32 bytes in
@@ -524,6 +571,14 @@ int k_limb_pack_tensor(crc_ctx *c, const u64 *x, i8 *xl, int B, int zd, int npos
     // back; for the convolution layout 4 and 8 adjacent pieces per thread measured 3-7 % slower
     const int group = c->tune.limb_pack_group > 1 ? c->tune.limb_pack_group : (npos == 1 && (B * 2) % 4 == 0 ? 4 : 1);
     const size_t items = (size_t)B * npos * 2 * (zdp / 32);
+    if (npos == 1 && c->tune.limb_pack_group <= 1) {       // a dense layer's tensor: the LDS-staged transpose (whole-line stores)
+        const size_t blocks = (size_t)(c->n / TSL) * c->k * (zdp / 32) * ((2 * (size_t)B + TRG - 1) / TRG);
+        if (blocks == 0) return CRC_OK;
+        if (blocks > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
+        hipLaunchKernelGGL(limb_pack_dense_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, xl, c->d_mods, c->n, c->k, B, zd, zdp, packed ? 1 : 0, Btot, b0);
+        HIPCHK(hipGetLastError());
+        return CRC_OK;
+    }
     const size_t blocks = (size_t)(c->n / 64) * c->k * ((items + group - 1) / group);
     if (blocks == 0) return CRC_OK;
     if (blocks > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;

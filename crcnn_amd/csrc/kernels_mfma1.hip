@@ -140,28 +140,32 @@ __global__ void __launch_bounds__(1024) mfma_conv1_kernel(Conv1Args a)
 // row at once, 32 polynomials per workgroup: the image layout is slot-major because the convolution's workgroup walks one slot's image, the transform's row is
 // slot-minor, and the transpose between them is this pass.)
 #define RG 4
-__global__ void __launch_bounds__(64 * RG) limb_pack_rows1_kernel(const u64 *x, i8 *xr, const ModParams *mods, int n, int k, int B, int xd, int yd, int packed,
-                                                                  unsigned img_stride, unsigned plane_bytes, unsigned poly_bytes)
+#define RSL 32
+// (32 slots per workgroup, thread = (slot, row of the group, 16-column half): 28 KiB of staging and five workgroups per CU, so that the loads of one overlap the digit
+// arithmetic and the stores of the others -- with 64 slots and two workgroups per CU the three ran one after the other: 2.5 TB/s, the same restructuring took the
+// weight pack of kernels_mfma.hip from 1.0 to 3.7 TB/s)
+__global__ void __launch_bounds__(256) limb_pack_rows1_kernel(const u64 *x, i8 *xr, const ModParams *mods, int n, int k, int B, int xd, int yd, int packed,
+                                                              unsigned img_stride, unsigned plane_bytes, unsigned poly_bytes)
 {
-    __shared__ __attribute__((aligned(16))) i8 st[64 * NPL * RG * 32];           // [slot][plane][row of the group][32 columns]
-    const int sblocks = n / 64;
-    const int sb = blockIdx.x % (sblocks * k), i = sb / sblocks, s0 = (sb % sblocks) * 64;
+    __shared__ __attribute__((aligned(16))) i8 st[RSL * NPL * RG * 32];          // [slot][plane][row of the group][32 columns]
+    const int sblocks = n / RSL;
+    const int sb = blockIdx.x % (sblocks * k), i = sb / sblocks, s0 = (sb % sblocks) * RSL;
     const int rgs = (xd + RG - 1) / RG;
     size_t r = blockIdx.x / (sblocks * k);                       // (b*2 + c)*rgs + row group
     const int rg = (int)(r % rgs); r /= rgs; const int c = (int)(r % 2); const int b = (int)(r / 2);
     const u64 q = mods[i].q;
-    const int lane = threadIdx.x & 63, qrow = threadIdx.x >> 6, row = rg * RG + qrow;
+    const int lane = threadIdx.x & (RSL - 1), qrow = (threadIdx.x >> 5) & (RG - 1), h = threadIdx.x >> 7, row = rg * RG + qrow;
     {
-        u32 pl[NPL][8];
+        u32 pl[NPL][4];
 #pragma unroll
         for (int l = 0; l < NPL; l++)
 #pragma unroll
-            for (int wv = 0; wv < 8; wv++) pl[l][wv] = 0;
+            for (int wv = 0; wv < 4; wv++) pl[l][wv] = 0;
         if (row < xd) {
-            const u64 *src = x + ((((size_t)b * xd * yd + (size_t)row * yd) * 2 + c) * k + i) * (size_t)n + s0 + lane;
+            const u64 *src = x + ((((size_t)b * xd * yd + (size_t)row * yd + h * 16) * 2 + c) * k + i) * (size_t)n + s0 + lane;
 #pragma unroll
-            for (int colx = 0; colx < 32; colx++)
-                if (colx < yd) {
+            for (int colx = 0; colx < 16; colx++)
+                if (h * 16 + colx < yd) {
                     u64 v = src[(size_t)colx * 2 * k * n];
                     if (packed) v = (v & 0xffffffffULL) | ((v >> 32) << 28);
                     const u64 dg = balanced_digit_bytes(v, q);         // the 7 balanced digits, one per byte
@@ -169,17 +173,14 @@ __global__ void __launch_bounds__(64 * RG) limb_pack_rows1_kernel(const u64 *x, 
                     for (int l = 0; l < NPL; l++) pl[l][colx >> 2] |= (u32)((dg >> (8 * l)) & 0xff) << (8 * (colx & 3));
                 }
         }
-        i8 *sp = st + (size_t)lane * (NPL * RG * 32) + qrow * 32;
+        i8 *sp = st + (size_t)lane * (NPL * RG * 32) + qrow * 32 + h * 16;
 #pragma unroll
-        for (int l = 0; l < NPL; l++) {
-            uint4 *o = reinterpret_cast<uint4 *>(sp + l * (RG * 32));
-            o[0] = make_uint4(pl[l][0], pl[l][1], pl[l][2], pl[l][3]); o[1] = make_uint4(pl[l][4], pl[l][5], pl[l][6], pl[l][7]);
-        }
+        for (int l = 0; l < NPL; l++) *reinterpret_cast<uint4 *>(sp + l * (RG * 32)) = make_uint4(pl[l][0], pl[l][1], pl[l][2], pl[l][3]);
     }
     __syncthreads();
-    // 64 slots x 7 planes runs of RG * 32 bytes, 16 bytes per lane: eight adjacent lanes write one run (rows past xd of a ragged last group are not stored)
+    // RSL slots x 7 planes runs of RG * 32 bytes, 16 bytes per lane: eight adjacent lanes write one run (rows past xd of a ragged last group are not stored)
     const int pieces_per_run = RG * 2, rows_here = min(RG, xd - rg * RG);
-    for (int o = threadIdx.x; o < 64 * NPL * pieces_per_run; o += 64 * RG) {
+    for (int o = threadIdx.x; o < RSL * NPL * pieces_per_run; o += 256) {
         const int run = o / pieces_per_run, part = o - run * pieces_per_run, sl = run / NPL, l = run - sl * NPL;
         if ((part >> 1) >= rows_here) continue;
         i8 *dst = xr + (((size_t)i * n + s0 + sl) * B + b) * img_stride + (size_t)l * plane_bytes + (size_t)c * poly_bytes + (size_t)(rg * RG) * 32 + part * 16;
@@ -244,9 +245,9 @@ int k_limb_conv1(crc_ctx *c, const u64 *x, bool packed, i8 *xr, const i8 *wl, u6
     a.out_img_bytes = (unsigned)(NPL * a.P * 2 * 32);
     conv1_tables(c, a);
     {
-        const size_t blocks = (size_t)(c->n / 64) * c->k * B * 2 * ((xd + RG - 1) / RG);
+        const size_t blocks = (size_t)(c->n / RSL) * c->k * B * 2 * ((xd + RG - 1) / RG);
         if (blocks > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
-        hipLaunchKernelGGL(limb_pack_rows1_kernel, dim3((unsigned)blocks), dim3(64 * RG), 0, st, x, xr, c->d_mods, c->n, c->k, B, xd, yd, packed ? 1 : 0, a.img_stride, a.plane_bytes,
+        hipLaunchKernelGGL(limb_pack_rows1_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, xr, c->d_mods, c->n, c->k, B, xd, yd, packed ? 1 : 0, a.img_stride, a.plane_bytes,
                            a.poly_bytes);
         HIPCHK(hipGetLastError());
     }
