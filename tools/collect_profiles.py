@@ -36,7 +36,7 @@ with open(os.path.join(P, f"{R}_square_relin.txt"), "w") as f:
         f.writelines(open(os.path.join(F, "square_paths.txt")))
 cp("../prof_sq_8192_3_1250/sq_8192_3_1250_kernel_stats.csv", "square_relin_8192k3_kernel_stats.csv")
 for src, dst in (("ntt_elementwise.txt", "ntt_elementwise_kernels.txt"), ("mac_geometries.txt", "mac_geometries.txt"), ("conv1.txt", "conv1_kernel.txt"), ("mfma_shape.txt", "mfma_shape.txt"),
-                 ("square.txt", "square_relin_raw.txt")):
+                 ("square.txt", "square_relin_raw.txt"), ("pack.txt", "limb_pack_weights.txt")):
     if os.path.exists(os.path.join(F, src)):
         lines = [l for l in open(os.path.join(F, src)) if "amdgpu.ids" not in l and not l.startswith("+")]
         open(os.path.join(P, f"{R}_{dst}"), "w").writelines(lines)

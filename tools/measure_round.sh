@@ -43,6 +43,7 @@ rm -f $O/mac_geometries.txt
 for g in conv1 conv1p conv2 conv2p fc3 aconv1 aconv2 afc3; do python tools/bench_mac.py $g 32 2 packed 2>&1 | grep -v amdgpu >> $O/mac_geometries.txt; done
 (python tools/check_conv1.py 4096 2 32 tiny; python tools/check_conv1.py 8192 3 16 approx) 2>&1 | grep -v "amdgpu\|^[EW]2" > $O/conv1.txt
 (timeout -k 10 120 ./tools/mfma_shape; timeout -k 10 120 ./tools/mfma_shape zeros) > $O/mfma_shape.txt 2>&1
+(python tools/bench_pack.py 8192 3 1250; python tools/bench_pack.py 16384 8 3920) 2>&1 | grep -v amdgpu > $O/pack.txt
 for g in conv2p fc3 aconv2 afc3; do python tools/bench_mac.py $g 32 2 limb 2>&1 | grep -v amdgpu >> $O/mac_geometries.txt; python tools/bench_mac.py $g 32 2 limbk 2>&1 | grep -v amdgpu >> $O/mac_geometries.txt; done
 fi
 ls $O
