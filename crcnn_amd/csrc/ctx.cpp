@@ -1,5 +1,6 @@
 // ctx.cpp -- builds the context tables on the host and uploads them to HBM.
 #include "ctx.h"
+#include <algorithm>
 #include <cstring>
 #include <cstdlib>
 #include <string>
@@ -332,8 +333,22 @@ extern "C" int crc_ctx_create(int n, const uint64_t *q, int k, uint64_t t, int d
         // the square's auxiliary base: the fewest primes with prod p_j >= 2 n t q (ctx.h Sq64Params; every p_j > 2^46.9999); transforms on an LDS image of n doubles
         Sq64Params &sq = c->sq64; memset(&sq, 0, sizeof sq);
         if (n <= 16384) {
-            const int need = 1 + c->logn + sigbits(t) + c->total_bits;
-            for (int kf = 3; kf <= CRC_NF64A; kf++) if ((int)(kf * 46.9999) >= need) { sq.kf = kf; break; }
+            // exact, in multi-limb integers: X = 4 n t q (1 + 2^-27 + 2^-40) -- twice the bound 2 n t q (1 + k 2^-32)^2 + k on |floor(t P / q)| of SEAL 2.3.1's non-centred
+            // mont_rq, plus fastbconv_sk's own 2 B (1 + #B) -- must not exceed prod p_j
+            auto mul = [](std::vector<u64> a, u64 m) { u64 carry = 0; for (auto &l : a) { u128 z = (u128)l * m + carry; l = (u64)z; carry = (u64)(z >> 64); } if (carry) a.push_back(carry); return a; };
+            auto shr = [](const std::vector<u64> &a, int sh) { std::vector<u64> r(a.size(), 0); const int w = sh / 64, b = sh % 64;
+                for (size_t i = w; i < a.size(); i++) { r[i - w] = a[i] >> b; if (b && i + 1 < a.size()) r[i - w] |= a[i + 1] << (64 - b); } return r; };
+            auto add = [](std::vector<u64> a, const std::vector<u64> &b) { a.resize(std::max(a.size(), b.size()) + 1, 0); u64 carry = 0;
+                for (size_t i = 0; i < a.size(); i++) { u128 z = (u128)a[i] + (i < b.size() ? b[i] : 0) + carry; a[i] = (u64)z; carry = (u64)(z >> 64); } return a; };
+            auto geq = [](std::vector<u64> a, std::vector<u64> b) { const size_t m = std::max(a.size(), b.size()); a.resize(m, 0); b.resize(m, 0);
+                for (size_t i = m; i-- > 0;) if (a[i] != b[i]) return a[i] > b[i]; return true; };
+            std::vector<u64> X = mul(mul(mul(c->qbig, t), (u64)n), 4);
+            X = add(add(X, shr(X, 27)), shr(X, 40));
+            std::vector<u64> prod{1};
+            for (int kf = 1; kf <= CRC_NF64A; kf++) {
+                prod = mul(prod, c->f64_primes[kf - 1]);
+                if (kf >= 3 && geq(prod, X)) { sq.kf = kf; break; }
+            }
         }
         c->nf64 = sq.kf > CRC_NF64 ? sq.kf : CRC_NF64;
         for (int m = 0; m < c->nf64; m++) {

@@ -71,7 +71,7 @@ struct F64Params {
 
 // The auxiliary base of the ciphertext square over the engine's fp64 primes (kernels_square64.hip).  BEHZ's results do not depend on WHICH auxiliary base carries the
 // intermediate integers as long as it is large enough (fastbconv_sk is exact once |floor(t P / q)| / B + #B < m_sk / 2): instead of SEAL's k (+1) 61-bit primes and
-// m_sk the engine takes kf of its own 47-bit primes, p_0 .. p_{kf-2} as B and p_{kf-1} as m_sk, whose transforms and base conversions are fp64 arithmetic.
+// m_sk the engine takes kf of its own 47-bit primes -- the fewest with prod p_j >= 4 n t q (1 + 2^-27 + 2^-40), decided in exact integers (ctx.cpp) --, p_0 .. p_{kf-2} as B and p_{kf-1} as m_sk, whose transforms and base conversions are fp64 arithmetic.
 // Constants are {centred residue, residue / p} pairs for f64_mulmod_const; a 55..60-bit operand enters as its two 32-bit halves, hence the "x 2^32" twins.
 #define CRC_NF64A 12
 struct Sq64Params {

@@ -67,8 +67,11 @@ def test_square_fp64_auxiliary_base_size_rule():
         for p in primes:
             assert p % 65536 == 1 and p < (1 << 47) and pow(2, p - 1, p) == 1
             have *= p
-        assert have >= need
+        assert have >= need + (need >> 27) + (need >> 40)            # the context's rule, exact: room for (1 + k 2^-32)^2 and for the Shenoy-Kumaresan correction
+        assert len(primes) == 3 or have // primes[-1] < need + (need >> 27) + (need >> 40), "the fewest primes that satisfy it"
         B, msk = have // primes[-1], primes[-1]
-        assert (2 * n * t * (need // (4 * n * t)) + k) // B + len(primes) + 1 < msk // 2
+        qq = need // (4 * n * t)
+        R_max = (2 * n * t * qq * (2**32 + k) ** 2) // 2**64 + k + 1      # |floor(t P / q)| <= 2 n t q (1 + k 2^-32)^2 + k
+        assert R_max // B + len(primes) + 1 < msk // 2
         if (n, k, t) in want:
             assert len(primes) == want[(n, k, t)], (n, k, t, len(primes))
