@@ -98,3 +98,38 @@ def test_seal_layout_roundtrip():
     assert np.array_equal(back, ct)
     seal[0, 0, 256] = 1
     assert E.L.crc_import_seal(E.c, seal.ctypes.data_as(PU), 2, back.ctypes.data_as(PU)) < 0
+
+
+def test_kernel_selection_policy_of_the_abi():
+    """crc_plan_mac / crc_plan_fold_pool -- the one statement of which multiply-accumulate kernel a conv / dense layer runs on, asked by both hosts (netrun.py, the C++
+    classes) -- on host-only contexts: the layers of the three CrCNN topologies (cnnBuilder.cpp:109-169) at the bench's chunk sizes, and the rules' edges"""
+    T = ca.Engine(4096, ca.default_coeff_modulus_128(4096), 1 << 32, device=-1)
+    A = ca.Engine(8192, ca.default_coeff_modulus_128(8192)[:3], 1 << 42, device=-1)
+    W8 = ca.Engine(16384, ca.default_coeff_modulus_128(16384), 1 << 44, device=-1)
+    NTTL, NTTL1, NTTP = ca.NTTL, ca.NTTL1, ca.NTTP
+    # PlainModelTiny, chunk 128: conv1+pool1 (one channel, 6 x 6 stride 2) on its own matrix-core kernel, conv2+pool2 / fc3 / fc4 on the limb GEMM
+    assert T.plan_mac(1, 28, 28, 2, 2, 6, 6, 32, 128) == NTTL1
+    assert T.plan_mac(32, 12, 12, 2, 2, 6, 6, 64, 128) == NTTL
+    assert T.plan_mac(1024, 1, 1, 1, 1, 1, 1, 512, 128) == NTTL
+    assert T.plan_mac(512, 1, 1, 1, 1, 1, 1, 10, 128) == NTTL
+    # ApproxPlainModel, chunk 32: conv1+pool1 folded = 7 x 7 stride 2 (one channel), conv2 = 3 x 3 on 20 channels (9 steps of one padded channel block), fc3 800 -> 500,
+    # fc4 500 -> 10 with 64 rows on a ring of n k = 24576
+    assert A.plan_mac(1, 28, 28, 2, 2, 7, 7, 20, 32) == NTTL1
+    assert A.plan_mac(20, 11, 11, 2, 2, 3, 3, 50, 32) == NTTL
+    assert A.plan_mac(800, 1, 1, 1, 1, 1, 1, 500, 32) == NTTL
+    assert A.plan_mac(500, 1, 1, 1, 1, 1, 1, 10, 32) == NTTL and A.plan_mac(500, 1, 1, 1, 1, 1, 1, 10, 31) == NTTP
+    # fewer than 8 reduction steps of 32 channels: vector ALU (packed operand form)
+    assert T.plan_mac(32, 12, 12, 2, 2, 2, 2, 64, 128) == NTTP          # 4 taps x 1 channel block
+    assert T.plan_mac(224, 1, 1, 1, 1, 1, 1, 64, 128) == NTTP and T.plan_mac(225, 1, 1, 1, 1, 1, 1, 64, 128) == NTTL
+    # fewer than 32 rows per launch (a dense layer has 2 per image): vector ALU; below 24 filters the 64-filter tile is mostly padding: 64 rows, and small rings only
+    assert T.plan_mac(1024, 1, 1, 1, 1, 1, 1, 512, 15) == NTTP and T.plan_mac(1024, 1, 1, 1, 1, 1, 1, 512, 16) == NTTL
+    assert T.plan_mac(512, 1, 1, 1, 1, 1, 1, 10, 16) == NTTP and T.plan_mac(512, 1, 1, 1, 1, 1, 1, 10, 32) == NTTL
+    assert W8.plan_mac(500, 1, 1, 1, 1, 1, 1, 10, 128) == NTTP and W8.plan_mac(800, 1, 1, 1, 1, 1, 1, 500, 32) == NTTL
+    # one-channel kernel: window <= 8 x 8, <= 32 filters, image width <= 32; otherwise the generic rules
+    assert T.plan_mac(1, 28, 28, 1, 1, 9, 9, 32, 128) != NTTL1 and T.plan_mac(1, 28, 28, 2, 2, 6, 6, 33, 128) != NTTL1 and T.plan_mac(1, 40, 40, 2, 2, 6, 6, 32, 128) != NTTL1
+    # matrix_cores = False keeps everything on the vector ALU
+    assert T.plan_mac(32, 12, 12, 2, 2, 6, 6, 64, 128, matrix_cores=False) == NTTP and T.plan_mac(1, 28, 28, 2, 2, 6, 6, 32, 128, matrix_cores=False) == NTTP
+    # folding a 2 x 2 / 2 average pool into the 5 x 5 convolution in front of it (6 x 6 stride 2: 2.8x fewer multiply-adds) pays
+    assert T.plan_fold_pool(1, 28, 28, 1, 1, 5, 5, 32, 2, 2, 2, 2) is True
+    assert T.plan_fold_pool(32, 12, 12, 1, 1, 5, 5, 64, 2, 2, 2, 2) is True
+    assert A.plan_fold_pool(1, 28, 28, 2, 2, 5, 5, 20, 1, 1, 2, 2) is True       # CrCNN's stride-1 pool behind a one-channel convolution: narrowly
