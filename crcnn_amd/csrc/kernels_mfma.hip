@@ -349,8 +349,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 // ---- layout conversions ------------------------------------------------------------------------------------------------------------------
 // slot-minor NTT-form tensor x [B][zd*npos cts][2][k][n] (canonical residues, or 28-bit limb pairs when `packed`) -> Xl.  One thread per (slot, image,
 // position, poly, 32-channel block); lanes run over 64 consecutive slots, so every read is a coalesced 512-B row segment; every lane writes 7 x 32 B into its
-// own slot block (1.4x write amplification at the memory side, profiles/r02_pmc_traffic.json).  Tried and not kept: a variant that transposes through LDS and
-// writes whole 128-B lines per (slot, plane) -- 48.1 vs 46.4 ms for the conv2+pool2 layer call; 4 or 8 adjacent pieces per thread -- 3-7 % slower.
+// own slot block (1.4x write amplification at the memory side, profiles/r02_pmc_traffic.json).  This form serves the CONVOLUTION layout (several positions) only, which
+// no bench configuration reaches any more (conv1 writes conv2's limb tensor itself); a dense layer's tensor goes through limb_pack_dense_kernel below.  (Round 2 tried an
+// LDS transpose with 64 slots per workgroup here and dropped it -- 48.1 vs 46.4 ms; what it lacked was occupancy, see limb_pack_weights_kernel.)
 // (Btot, b0: the B images are images b0 .. b0 + B of a tensor of Btot -- a group of chunks assembling one dense layer's input; Btot = B, b0 = 0 otherwise)
 __global__ void __launch_bounds__(64) limb_pack_tensor_kernel(const u64 *x, i8 *xl, const ModParams *mods, int n, int k, int B, int zd, int zdp, int npos, int packed, int group,
                                                               int Btot, int b0)
