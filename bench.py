@@ -34,7 +34,7 @@ CONFIGS = {
     # BASELINE.json configs[1]: PlainModelTiny.h5, n=4096, batch=1024 on one MI355X  (q = coeff_modulus_128(4096), t = 2^20)
     "tiny4096": dict(model="PlainModelTiny", n=4096, k=2, t=1 << 32, batch=1024, chunk=128),   # t=2^32: exact logits without the client-side refresh
     # configs[2]: ApproxPlainModel.h5, n=8192, 3 coeff moduli, batch=1024
-    "approx8192": dict(model="ApproxPlainModel", n=8192, k=3, t=1 << 42, batch=1024, chunk=32),   # t=2^42: exact logits, 19 bits of budget left
+    "approx8192": dict(model="ApproxPlainModel", n=8192, k=3, t=1 << 42, batch=1024, chunk=32, tail=2),   # t=2^42: exact logits, 19 bits of budget left; dense layers per 64 images (+1 %)
     # configs[4]: PlainModelWoPad.h5, n=16384, 4 coeff moduli
     # (tail=4: the dense layers run once per 4 chunks = 24 images -- two-level chunking, netrun.prepare: fc3 streams 177 GiB of limb-form weights per launch)
     "wopad16384": dict(model="PlainModelWoPad", n=16384, k=4, t=1 << 44, batch=1024, chunk=6, tail=4),
