@@ -174,6 +174,8 @@ static void read_tuning(CrcTuning &t)
     t.relin_path = (int)geti("CRC_RELIN_PATH", 0);
     t.sq_path = (int)geti("CRC_SQ_PATH", 0);
     t.sq_chunk = (int)geti("CRC_SQ_CHUNK", 0);
+    t.sq_fuse = (int)geti("CRC_SQ_FUSE", 1);
+    t.f64_hold_nt = (int)geti("CRC_F64_HOLD_NT", 0);
     t.f64_radix = (int)geti("CRC_F64_RADIX", 0);
     t.mfma_min_steps = (int)geti("CRC_MFMA_MIN_STEPS", 0);
     t.relin_mac_ct = (int)geti("CRC_RELIN_MAC_CT", 0);
@@ -197,6 +199,8 @@ extern "C" int crc_ctx_set_tuning(crc_ctx *c, const char *name, long long value)
     else if (s == "relin_path") t.relin_path = (int)value;
     else if (s == "sq_path") t.sq_path = (int)value;
     else if (s == "sq_chunk") t.sq_chunk = (int)value;
+    else if (s == "sq_fuse") t.sq_fuse = (int)value;
+    else if (s == "f64_hold_nt") t.f64_hold_nt = (int)value;
     else if (s == "f64_radix") t.f64_radix = (int)value;
     else if (s == "mfma_min_steps") t.mfma_min_steps = (int)value;
     else if (s == "relin_mac_ct") t.relin_mac_ct = (int)value;
@@ -330,7 +334,7 @@ extern "C" int crc_ctx_create(int n, const uint64_t *q, int k, uint64_t t, int d
         F64Params &f = c->f64; memset(&f, 0, sizeof f);
         auto centred = [](u64 v, u64 p) { return v > p / 2 ? (double)((long long)v - (long long)p) : (double)v; };
         auto quot = [](double w, u64 p) { return (double)((long double)w / (long double)p); };
-        // the square's auxiliary base: the fewest primes with prod p_j >= 2 n t q (ctx.h Sq64Params; every p_j > 2^46.9999); transforms on an LDS image of n doubles
+        // the square's auxiliary base: the fewest primes with prod p_j >= 4 n t q (1 + 2^-27 + 2^-40) (ctx.h Sq64Params; every p_j > 2^46.9999); transforms on an LDS image of n doubles
         Sq64Params &sq = c->sq64; memset(&sq, 0, sizeof sq);
         if (n <= 16384) {
             // exact, in multi-limb integers: X = 4 n t q (1 + 2^-27 + 2^-40) -- twice the bound 2 n t q (1 + k 2^-32)^2 + k on |floor(t P / q)| of SEAL 2.3.1's non-centred
@@ -358,15 +362,14 @@ extern "C" int crc_ctx_create(int n, const uint64_t *q, int k, uint64_t t, int d
                 f.ninv[m] = centred(h_invmod((u64)n, p), p); f.ninv_q[m] = quot(f.ninv[m], p);
             }
             if (device >= 0) {
-                const u64 psi = minimal_primitive_root(2 * (u64)n, p), ipsi = h_invmod(psi, p);
+                const u64 psi = minimal_primitive_root(2 * (u64)n, p);
                 if (!psi) { delete c; return CRC_ERR_PARAMETERS; }
-                f64rp[m].assign((size_t)2 * n, 0.0); f64irp[m].assign((size_t)2 * n, 0.0);
+                const u64 ipsi = h_invmod(psi, p);
+                f64rp[m].assign((size_t)n, 0.0); f64irp[m].assign((size_t)n, 0.0);
                 u64 a = 1, b = 1;
                 for (int i = 0; i < n; i++) {
                     const u32 j = bitrev((u32)i, c->logn);
-                    const double wa = centred(a, p), wb = centred(b, p);
-                    f64rp[m][2 * j] = wa; f64rp[m][2 * j + 1] = quot(wa, p);
-                    f64irp[m][2 * j] = wb; f64irp[m][2 * j + 1] = quot(wb, p);
+                    f64rp[m][j] = centred(a, p); f64irp[m][j] = centred(b, p);
                     a = h_mulmod(a, psi, p); b = h_mulmod(b, ipsi, p);
                 }
             }
@@ -427,7 +430,7 @@ extern "C" int crc_ctx_create(int n, const uint64_t *q, int k, uint64_t t, int d
             (e = hipMemcpy(c->d_behz, &c->behz, sizeof(BehzParams), hipMemcpyHostToDevice)) != hipSuccess) {
             fail(e); crc_ctx_destroy(c); return rc;
         }
-        const size_t ftw = (size_t)n * 16;
+        const size_t ftw = (size_t)n * 8;
         if ((e = hipMalloc(&c->d_f64_rp, ftw * c->nf64)) != hipSuccess || (e = hipMalloc(&c->d_f64_irp, ftw * c->nf64)) != hipSuccess ||
             (e = hipMalloc(&c->d_sq64, sizeof(Sq64Params))) != hipSuccess || (e = hipMemcpy(c->d_sq64, &c->sq64, sizeof(Sq64Params), hipMemcpyHostToDevice)) != hipSuccess) { fail(e); crc_ctx_destroy(c); return rc; }
         for (int m = 0; m < c->nf64; m++)

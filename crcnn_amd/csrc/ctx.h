@@ -114,6 +114,8 @@ struct CrcTuning {
     int mfma_min_steps = 0;       // CRC_MFMA_MIN_STEPS: reduction steps of 32 channels from which a conv / dense layer goes to the limb GEMM (0: 8)
     int f64_radix = 0;            // CRC_F64_RADIX=3|4|5: butterfly stages per LDS pass of the fp64 transforms (0: default)
     int sq_chunk = 0;             // CRC_SQ_CHUNK: ciphertexts per internal pass of square + relinearise (0: by ring size)
+    int f64_hold_nt = 0;          // CRC_F64_HOLD_NT=512: threads per workgroup of the fp64 transform kernels that keep a row in registers (0: n / 8, at most 1024)
+    int sq_fuse = 1;              // CRC_SQ_FUSE=0: an NTT-resident square lifts and transforms in separate kernels (round 3) instead of inside the forward transforms
     int sq_path = 0;              // CRC_SQ_PATH=0: by parameters, 1: the square's auxiliary base is SEAL's 61-bit one (round-2 kernels), 2: the engine's fp64 primes
     int relin_path = 0;           // CRC_RELIN_PATH=0: by parameters, 1: key switching over the coefficient moduli (round-2 path), 2: over the two fp64 primes
 };
@@ -140,7 +142,7 @@ struct crc_ctx {
     F64Params f64;
     Sq64Params sq64;
     Sq64Params *d_sq64 = nullptr;
-    double *d_f64_rp = nullptr, *d_f64_irp = nullptr;   // [nf64][n][2]: {bit-reversed power of psi_m (centred), that / p_m} forward; psi_m^-1 powers inverse
+    double *d_f64_rp = nullptr, *d_f64_irp = nullptr;   // [nf64][n]: bit-reversed powers of psi_m (centred residues) forward; of psi_m^-1 inverse
     u64 *d_zero = nullptr;                   // 4 KiB of zeros (source row of reduction terms past T in mac3_kernel) + 4 KiB context scratch
     u64 *d_scratch = nullptr;                // = d_zero + 512 words (crc_checksum64 accumulators)
     int cus = 256;                           // compute units of THIS context's device

@@ -2,6 +2,9 @@
 #pragma once
 #include "ctx.h"
 
+// grid of a launch whose workgroups are mapped by xcd_group (ntt_device.h): `groups` groups of G workgroups, each group on one XCD
+static inline unsigned xcd_grid(size_t groups, unsigned G) { return (unsigned)((groups + 7) / 8 * 8 * G); }
+
 int k_ntt_ct(crc_ctx *c, bool inv, const u64 *src, u64 *dst, size_t count, int size, bool bsk, hipStream_t st,
              const u64 *addend, int add_sign, size_t add_group, int add_mod = 0, int pack_out = 0);
 int k_ntt_ct_addct(crc_ctx *c, const u64 *src, u64 *dst, size_t count, const u64 *addct, int add_size, hipStream_t st);
@@ -10,6 +13,7 @@ int k_spread_ntt(crc_ctx *c, const u64 *src, size_t items, u64 *dst, hipStream_t
 int k_digit_ntt(crc_ctx *c, const u64 *src, int src_size, int src_poly, size_t count, int D, const unsigned char *dig_i, const unsigned char *dig_shift, int dbc,
                 u64 *dst, hipStream_t st, int pack_out = 0);
 int k_square_intt(crc_ctx *c, const u64 *src, u64 *dst, size_t count, bool bsk, hipStream_t st);
+int k_ntt_ct_inv_scaled(crc_ctx *c, const u64 *src, u64 *dst, size_t count, int size, const u64 *mul, const u64 *mul_s, hipStream_t st);
 int k_plain_ntt(crc_ctx *c, const u64 *d_plain, size_t count, int mode, bool do_ntt, u64 *d_out, hipStream_t st);
 int k_rowwise(crc_ctx *c, u64 *acc, const u64 *b, size_t count, int size, int op, int sign, size_t group, size_t gmod, hipStream_t st);
 int k_pool(crc_ctx *c, const u64 *x, u64 *y, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, const u64 *mul, hipStream_t st, int pack_out = 0);

@@ -24,13 +24,18 @@ struct NttArgs {
     size_t rows;                                               // total rows of the launch (prefetch variant)
     int pack_out;                                              // forward only: store the result as 28-bit limb pairs (operand form of the MAC kernels)
     int src_ct_rows, dst_ct_rows;                              // both > 0: dst row r = (ct, j < dst_ct_rows) reads src row ct*src_ct_rows + j (leading polys of wider cts)
-    int prologue;                                              // 0 none, 1 plain lift, 2 delta scale, 3 relinearisation digit, 4 square products
+    int prologue;                                              // 0 none, 1 plain lift, 2 delta scale, 3 relinearisation digit, 4 square products, 5 (inverse) scaled result
     // prologue 3 (forward): row = ((ct*D + g)*k + j); the source row is the premultiplied third polynomial c2 (q/q_i)^-1 mod q_i of ciphertext ct under
     //   modulus i = dig_i[g] (src = size-`src_size` ciphertexts, poly `src_poly`); the value fed to the transform is its digit (v >> dig_shift[g]) & dig_mask
     //   (relinearize_one_step, evaluator.cpp:984-1001) -- the digit polynomials never exist in memory
     // prologue 4 (inverse): row = ((ct*3 + p)*mod_count + j); sources are the NTT-form rows a, b of polys 0 and 1 of ciphertext ct in `src` ([ct][2][mod_count][n]);
     //   the value fed to the transform is a^2, 2ab or b^2 (Evaluator::square's dyadic products, evaluator.cpp:798-852)
+    //   (prologue 4: the three products of one (ciphertext, modulus) pair run on ONE XCD, blockIdx -> row through xcd_group; `pairs` = ciphertexts x mod_count)
+    // prologue 5 (inverse): the result leaves multiplied by the per-modulus constant post_mul (Shoup companion post_mul_s) -- the square's lift wants
+    //   x m~ (q/q_i)^-1 mod q_i (baseconverter.cpp:686-696), and the Shoup multiplication takes the lazy value in place of the final reduction
     int D, src_size, src_poly; unsigned long long dig_mask;
+    size_t pairs;
+    u64 post_mul[CRC_MAXK], post_mul_s[CRC_MAXK];
     unsigned char dig_i[48], dig_shift[48];
     const u64 *addend; int add_sign; int rows_per_ct; long long add_group;   // epilogue (inverse only)
     int add_mod;                                               // plaintext index = (ct / add_group) % add_mod (0: no modulo)
@@ -58,7 +63,12 @@ __device__ __forceinline__ void ntt_rows_body(const NttArgs &a)
 {
     extern __shared__ u64 sm[];
     const int n = a.n, logn = a.logn, tid = threadIdx.x, nt = blockDim.x;
-    const size_t row = blockIdx.x;
+    size_t row = blockIdx.x;
+    if (INV && PRO == 4) {
+        size_t pair; unsigned p;
+        if (!xcd_group(blockIdx.x, 3, a.pairs, pair, p)) return;
+        row = ((pair / a.mod_count) * 3 + p) * a.mod_count + pair % a.mod_count;
+    }
     const int mloc = (int)(row % a.mod_count);
     const int mi = a.mod_base + mloc;
     const ModParams m = a.mods[mi];
@@ -127,7 +137,9 @@ __device__ __forceinline__ void ntt_rows_body(const NttArgs &a)
             if (a.add_mode == 2) add = a.addend + ((ct * a.add_size + p) * a.mod_count + mloc) * (size_t)n;
             else if (p == 0) { size_t g = ct / a.add_group; if (a.add_mod) g %= a.add_mod; add = a.addend + (g * a.mod_count + mloc) * (size_t)n; }
         }
+        const u64 pm = PRO == 5 ? a.post_mul[mloc] : 0, pms = PRO == 5 ? a.post_mul_s[mloc] : 0;
         auto fin = [&](u64 v) -> u64 {
+            if (PRO == 5) return mulmod_shoup(v, pm, pms, q);                 // (any 64-bit value in, canonical out)
             if (LAZY) return reduce_small(v, q, q2, rq);
             v = v >= q2 ? v - q2 : v; return v >= q ? v - q : v;
         };
@@ -159,7 +171,12 @@ __device__ __forceinline__ void ntt_rows_split_body(const NttArgs &a)
 {
     extern __shared__ u64 sm[];
     const int n = a.n, n2 = n >> 1, logn2 = a.logn - 1, tid = threadIdx.x, nt = blockDim.x;
-    const size_t row = blockIdx.x;
+    size_t row = blockIdx.x;
+    if (INV && PRO == 4) {
+        size_t pair; unsigned p;
+        if (!xcd_group(blockIdx.x, 3, a.pairs, pair, p)) return;
+        row = ((pair / a.mod_count) * 3 + p) * a.mod_count + pair % a.mod_count;
+    }
     const int mloc = (int)(row % a.mod_count);
     const int mi = a.mod_base + mloc;
     const ModParams m = a.mods[mi];
@@ -273,7 +290,8 @@ __device__ __forceinline__ void ntt_rows_split_body(const NttArgs &a)
                 const u64 T = q2 - V + U; u64 cu = U + V; cu = cu >= q2 ? cu - q2 : cu;
                 lo = (cu + ((cu & 1) ? q : 0)) >> 1; hi = mulmod_shoup_lazy(T, tw.x, tw.y, q);
             }
-            lo = canon(lo); hi = canon(hi);
+            if (PRO == 5) { lo = mulmod_shoup(lo, a.post_mul[mloc], a.post_mul_s[mloc], q); hi = mulmod_shoup(hi, a.post_mul[mloc], a.post_mul_s[mloc], q); }
+            else { lo = canon(lo); hi = canon(hi); }
         };
         for (int s = 2 * tid; s < n2; s += 2 * nt) {
             const ulonglong2 U = ld2(dst + s), V = sm_load_pair64(sm, s);
@@ -372,10 +390,12 @@ static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t
     bool lazy = true;
     for (int i = a.mod_base; i < a.mod_base + a.mod_count; i++) if (c->tabs[i].m.bits > 57 || c->tabs[i].m.bits < 45) lazy = false;
     const int cus = c->cus;
-    if ((a.prologue == 3 && inv) || (a.prologue == 4 && !inv)) return CRC_ERR_INVALID_ARGUMENT;
+    if ((a.prologue == 3 && inv) || ((a.prologue == 4 || a.prologue == 5) && !inv)) return CRC_ERR_INVALID_ARGUMENT;
+    if (a.prologue == 4) rows = xcd_grid(a.pairs, 3);                  // (the three products of a pair on one XCD: ntt_rows_body)
     if (c->n == 16384 && nt == 1024 && c->tune.ntt_split != 0) {                   // n = 16384: the row as two halves through a 64-KiB image -- two workgroups per CU (ntt_rows_split_body)
         lds /= 2;
         auto ks = a.prologue == 4 ? (lazy ? ntt_rows_split_kernel<true, true, 4> : ntt_rows_split_kernel<true, false, 4>)
+                : a.prologue == 5 ? (lazy ? ntt_rows_split_kernel<true, true, 5> : ntt_rows_split_kernel<true, false, 5>)
                 : a.prologue == 3 ? (lazy ? ntt_rows_split_kernel<false, true, 3> : ntt_rows_split_kernel<false, false, 3>)
                 : inv ? (lazy ? ntt_rows_split_kernel<true, true, 0> : ntt_rows_split_kernel<true, false, 0>) : (lazy ? ntt_rows_split_kernel<false, true, 0> : ntt_rows_split_kernel<false, false, 0>);
         hipLaunchKernelGGL(ks, dim3((unsigned)rows), dim3(nt), lds, st, a);
@@ -393,6 +413,7 @@ static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t
     if ((a.prologue == 3 && inv) || (a.prologue == 4 && !inv)) return CRC_ERR_INVALID_ARGUMENT;
     const bool strict61 = !c->tune.ntt_inv61_loose;
     auto kern = a.prologue == 4 ? (lazy ? ntt_rows_kernel<true, true, 4> : strict61 ? ntt_rows_inv61_kernel<4> : ntt_rows_kernel<true, false, 4>)
+              : a.prologue == 5 ? (lazy ? ntt_rows_kernel<true, true, 5> : ntt_rows_kernel<true, false, 5>)
               : a.prologue == 3 ? (lazy ? ntt_rows_kernel<false, true, 3> : ntt_rows_kernel<false, false, 3>)
               : inv ? (lazy ? ntt_rows_kernel<true, true, 0> : strict61 ? ntt_rows_inv61_kernel<0> : ntt_rows_kernel<true, false, 0>) : (lazy ? ntt_rows_kernel<false, true, 0> : ntt_rows_kernel<false, false, 0>);
     { const int rc = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (rc) return rc; }
@@ -462,8 +483,18 @@ int k_square_intt(crc_ctx *c, const u64 *src, u64 *dst, size_t count, bool bsk, 
 {
     NttArgs a{};
     a.src = src; a.dst = dst; a.mod_base = bsk ? c->k : 0; a.mod_count = bsk ? c->kb : c->k; a.prologue = 4;
-    a.rows_per_ct = 3 * a.mod_count; a.add_group = 1;
+    a.rows_per_ct = 3 * a.mod_count; a.add_group = 1; a.pairs = count * a.mod_count;
     return ntt_launch(c, true, a, count * 3 * a.mod_count, st);
+}
+
+// inverse NTT of size-`size` ciphertexts over q whose result leaves multiplied by mul[i] mod q_i (mul_s: Shoup companions) -- NttArgs prologue 5
+int k_ntt_ct_inv_scaled(crc_ctx *c, const u64 *src, u64 *dst, size_t count, int size, const u64 *mul, const u64 *mul_s, hipStream_t st)
+{
+    NttArgs a{};
+    a.src = src; a.dst = dst; a.mod_base = 0; a.mod_count = c->k; a.prologue = 5;
+    a.rows_per_ct = size * c->k; a.add_group = 1;
+    for (int i = 0; i < c->k; i++) { a.post_mul[i] = mul[i]; a.post_mul_s[i] = mul_s[i]; }
+    return ntt_launch(c, true, a, count * size * c->k, st);
 }
 
 int k_plain_ntt(crc_ctx *c, const u64 *d_plain, size_t count, int mode, bool do_ntt, u64 *d_out, hipStream_t st);

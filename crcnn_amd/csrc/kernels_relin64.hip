@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(256) evk_canon_kernel(const u64 *evk, u64 *out
 }
 // kc: the keys in coefficient form over q_j, rows [2 g + poly][j] (blob order)  ->  Kf [g][poly k + j][m][n]: centred residue mod p_m, forward transform, times n^-1
 template <int RB>
-__global__ void __launch_bounds__(RB == 5 ? 512 : 1024) relin_keys_f64_kernel(const u64 *kc, double *Kf, const ModParams *mods, const d2 *Wf, F64Params fp, int n, int logn, int k)
+__global__ void __launch_bounds__(RB == 5 ? 512 : 1024) relin_keys_f64_kernel(const u64 *kc, double *Kf, const ModParams *mods, const double *Wf, F64Params fp, int n, int logn, int k)
 {
     extern __shared__ double smd[];
     const int m = blockIdx.x % CRC_NF64; const size_t row = blockIdx.x / CRC_NF64;       // row = (2 g + poly) k + j
@@ -51,42 +51,36 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024) relin_keys_f64_kernel(co
 
 // ---- K1: digits of c2' under both primes ---------------------------------------------------------------------------------------------------------------------------
 // src: size-`src_size` ciphertexts, poly `src_poly` = c2 (q/q_i)^-1 mod q_i (evaluator.cpp:984-985); E [ct][g][m][n], unreduced (|.| < 14 p)
-// SPLIT (n = 16384): the 128-KiB row as two halves through a 64-KiB image, stage 0 applied while a half is staged (two workgroups per CU; kernels.hip ntt_rows_split_body)
-template <int RB, bool SPLIT = false>
-__global__ void __launch_bounds__(RB == 5 ? 512 : 1024) relin_digits_f64_kernel(const u64 *src, int src_size, int src_poly, double *E, const d2 *Wf, F64Params fp, int n, int logn, int k, int D,
-                                                                int dbc, Relin64Tab tab)
+// The source row is read ONCE and waits in registers (NPT points per thread) through the 2 L_i transforms cut from it: round 3 read it again in front of every
+// transform, 8 times at 16-bit digits, and the L2 had long been swept by then (20 row reads per ciphertext for 3 rows at (8192, 3))
+template <int RB, int NPT>
+__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 && NPT <= 8 ? 8 : 4) relin_digits_f64_kernel(const u64 *src, int src_size, int src_poly, double *E, const double *Wf, F64Params fp, int n, int logn,
+                                                                                                         int k, int D, int dbc, Relin64Tab tab)
 {
     extern __shared__ double smd[];
     const size_t ct = blockIdx.x / k; const int i = blockIdx.x % k;
+    const int tid = threadIdx.x, nt = blockDim.x;
     const u64 *row = src + ((ct * src_size + src_poly) * k + i) * (size_t)n;
     const u64 mask = (1ULL << dbc) - 1;
     const int L = tab.L[i], g0 = tab.g0[i];
+    u64 r[NPT];
+#pragma unroll
+    for (int u = 0; u < NPT / 2; u++) {
+        const int s = 2 * (tid + u * nt);
+        if (s < n) { const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(row + s); r[2 * u] = v.x; r[2 * u + 1] = v.y; }
+    }
     for (int d = 0; d < L; d++) {
         const int sh = d * dbc;
         for (int m = 0; m < CRC_NF64; m++) {
             double *dst = E + ((ct * D + g0 + d) * CRC_NF64 + m) * (size_t)n;
-            if (SPLIT) {
-                const int n2 = n >> 1;
-                const d2 tw = Wf[(size_t)m * n + 1];
-                for (int h = 0; h < 2; h++) {
-                    for (int s = threadIdx.x; s < n2; s += blockDim.x) {
-                        const double X = (double)(u32)((row[s] >> sh) & mask), T = f64_mulmod_const((double)(u32)((row[s + n2] >> sh) & mask), tw.x, tw.y, fp.m[m].p);
-                        smd[swz<RB>(s)] = h ? X - T : X + T;
-                    }
-                    __syncthreads();
-                    ntt_row_passes_f64<false, RB>(smd, Wf + (size_t)m * n, n2, logn - 1, fp.m[m], 2 + h);
-                    for (int s = threadIdx.x; s < n2; s += blockDim.x) dst[h * n2 + s] = smd[swz<RB>(s)];
-                    __syncthreads();
-                }
-                continue;
-            }
-            for (int s = 2 * threadIdx.x; s < n; s += 2 * blockDim.x) {
-                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(row + s);
-                sm_store_pair<RB>(smd, s, (double)(u32)((v.x >> sh) & mask), (double)(u32)((v.y >> sh) & mask));
+#pragma unroll
+            for (int u = 0; u < NPT / 2; u++) {
+                const int s = 2 * (tid + u * nt);
+                if (s < n) sm_store_pair<RB>(smd, s, (double)(u32)((r[2 * u] >> sh) & mask), (double)(u32)((r[2 * u + 1] >> sh) & mask));
             }
             __syncthreads();
             ntt_row_passes_f64<false, RB>(smd, Wf + (size_t)m * n, n, logn, fp.m[m]);
-            for (int s = 2 * threadIdx.x; s < n; s += 2 * blockDim.x) *reinterpret_cast<d2 *>(dst + s) = sm_load_pair<RB>(smd, s);
+            for (int s = 2 * tid; s < n; s += 2 * nt) *reinterpret_cast<d2 *>(dst + s) = sm_load_pair<RB>(smd, s);
             __syncthreads();
         }
     }
@@ -137,27 +131,30 @@ __global__ void __launch_bounds__(256) relin_mac_f64_kernel(const double *E, con
 }
 
 // ---- K3: inverse transforms, CRT lift, mod q_j, + (c0, c1) -------------------------------------------------------------------------------------------------------------
-// A [ct][poly k + j][m][n] (overwritten: the first prime's result is parked in its own row -- L2-hot when it is read back -- while the LDS image serves the second
-// transform); x3: size-`add_size` ciphertexts whose polys 0, 1 are added (coefficient form); y [ct][2][k][n].
+// A [ct][poly k + j][m][n]; x3: size-`add_size` ciphertexts whose polys 0, 1 are added (coefficient form); y [ct][2][k][n].  The first prime's result waits in
+// registers (NPT points per thread, reduced) while the image serves the second transform -- round 3 parked it in its own row of A (6 rows written and read back per
+// ciphertext at (8192, 3), and 11 spilled registers: the twiddle companions took the room)
 // (ONE_PER_CU: the row image takes more than half of the LDS -- n = 16384 -- so one workgroup per CU is all there is and the register cap that buys the second
 // workgroup at n <= 8192 would only spill)
-template <int RB, bool OUT_NTT, bool LAZY, bool ONE_PER_CU = false>
-__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 && !ONE_PER_CU ? 8 : 4) relin_inv_crt_kernel(double *A, const u64 *x3, int add_size, u64 *y, const ModParams *mods, const d2 *Wi, const ulonglong2 *Wq, F64Params fp,
-                                                                             int n, int logn, int k)
+template <int RB, int NPT, bool OUT_NTT, bool LAZY, bool ONE_PER_CU = false>
+__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 && NPT <= 8 && !ONE_PER_CU ? 8 : 4) relin_inv_crt_kernel(const double *A, const u64 *x3, int add_size, u64 *y, const ModParams *mods, const double *Wi,
+                                                                                                                     const ulonglong2 *Wq, F64Params fp, int n, int logn, int k)
 {
     extern __shared__ double smd[];
     const size_t ct = blockIdx.x / (2 * k); const int pj = blockIdx.x % (2 * k), poly = pj / k, j = pj % k;
     const int tid = threadIdx.x, nt = blockDim.x;
-    double *a0row = A + ((ct * 2 * k + pj) * CRC_NF64) * (size_t)n;
+    const double *a0row = A + ((ct * 2 * k + pj) * CRC_NF64) * (size_t)n;
+    double a0[NPT];
     for (int m = 0; m < CRC_NF64; m++) {
         const double *src = a0row + (size_t)m * n;
         for (int s = 2 * tid; s < n; s += 2 * nt) { const d2 v = *reinterpret_cast<const d2 *>(src + s); sm_store_pair<RB>(smd, s, v.x, v.y); }
         __syncthreads();
         ntt_row_passes_f64<true, RB>(smd, Wi + (size_t)m * n, n, logn, fp.m[m]);
         if (m == 0) {
-            for (int s = 2 * tid; s < n; s += 2 * nt) {
-                const d2 v = sm_load_pair<RB>(smd, s);
-                *reinterpret_cast<d2 *>(a0row + s) = d2{f64_reduce(v.x, fp.m[0]), f64_reduce(v.y, fp.m[0])};
+#pragma unroll
+            for (int u = 0; u < NPT / 2; u++) {
+                const int s = 2 * (tid + u * nt);
+                if (s < n) { const d2 v = sm_load_pair<RB>(smd, s); a0[2 * u] = f64_reduce(v.x, fp.m[0]); a0[2 * u + 1] = f64_reduce(v.y, fp.m[0]); }
             }
             __syncthreads();
         }
@@ -168,10 +165,10 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 && !ONE_PER_CU ?
     const u64 *add = x3 + ((ct * add_size + poly) * k + j) * (size_t)n;
     u64 *dst = y + ((ct * 2 + poly) * k + j) * (size_t)n;
     u64 *sm = reinterpret_cast<u64 *>(smd);           // (a thread reads and rewrites only its own slot of the image here: no barrier in between)
-    auto lift = [&](double a0, double a1r, u64 addv) {
+    auto lift = [&](double a0v, double a1r, u64 addv) {
         const double a1 = f64_reduce(a1r, fp.m[1]);
-        const double t = f64_reduce(f64_mulmod_const(a1 - a0, fp.inv_p0_p1, fp.inv_p0_p1_q, fp.m[1].p), fp.m[1]);
-        const long long ti = (long long)t, a0i = (long long)a0;
+        const double t = f64_reduce(f64_mulmod_const(a1 - a0v, fp.inv_p0_p1, fp.inv_p0_p1_q, fp.m[1].p), fp.m[1]);
+        const long long ti = (long long)t, a0i = (long long)a0v;
         u64 lo, hi; mul64wide((u64)(ti < 0 ? -ti : ti), p0q, lo, hi);
         u64 r = barrett128(lo, hi, mq);
         if (ti < 0) r = negmod(r, q);
@@ -180,15 +177,18 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 && !ONE_PER_CU ?
         r = addmod(r, a0i < 0 ? negmod(a0m, q) : a0m, q);
         return addmod(r, addv, q);
     };
-    for (int s = 2 * tid; s < n; s += 2 * nt) {
-        const d2 a0 = *reinterpret_cast<const d2 *>(a0row + s);              // (written by this very thread above)
-        const d2 a1 = sm_load_pair<RB>(smd, s);
-        const ulonglong2 av = *reinterpret_cast<const ulonglong2 *>(add + s);
-        const u64 r0 = lift(a0.x, a1.x, av.x), r1 = lift(a0.y, a1.y, av.y);
-        if (OUT_NTT) {
-            const int a = swz<RB>(s);
-            *reinterpret_cast<ulonglong2 *>(sm + (a & ~1)) = (a & 1) ? ulonglong2{r1, r0} : ulonglong2{r0, r1};
-        } else *reinterpret_cast<ulonglong2 *>(dst + s) = ulonglong2{r0, r1};
+#pragma unroll
+    for (int u = 0; u < NPT / 2; u++) {
+        const int s = 2 * (tid + u * nt);
+        if (s < n) {
+            const d2 a1 = sm_load_pair<RB>(smd, s);
+            const ulonglong2 av = *reinterpret_cast<const ulonglong2 *>(add + s);
+            const u64 r0 = lift(a0[2 * u], a1.x, av.x), r1 = lift(a0[2 * u + 1], a1.y, av.y);
+            if (OUT_NTT) {
+                const int a = swz<RB>(s);
+                *reinterpret_cast<ulonglong2 *>(sm + (a & ~1)) = (a & 1) ? ulonglong2{r1, r0} : ulonglong2{r0, r1};
+            } else *reinterpret_cast<ulonglong2 *>(dst + s) = ulonglong2{r0, r1};
+        }
     }
     if (!OUT_NTT) return;
     // NTT-resident result: forward transform over q_j of (c_poly + R) in the same LDS image, same layout (ntt_device.h's radix-8 passes on the fp64 image's swizzle)
@@ -233,6 +233,10 @@ static int f64_threads(const crc_ctx *c, int RB) { int nt = c->n >> RB; if (nt <
 // 3 stages (8 values per thread) per LDS pass by default: measured on (8192, 3) the digit kernel runs 0.90 / 1.08 / 1.34 us per ciphertext with 3 / 4 / 5 -- the wider
 // passes save LDS round trips and barriers but cost occupancy (76 / 134 registers), and the kernel is bound by instruction issue, not by LDS (profiles/r03_square_relin.txt)
 static int f64_radix(const crc_ctx *c) { const int r = c->tune.f64_radix; return r >= 3 && r <= 5 ? r : 3; }
+// points per thread of the kernels that keep a row in registers: n / threads, rounded up to the instances that exist (radix 3: 8 | 16, radix 4: 16, radix 5: 32)
+// (tune.f64_hold_nt = 512: those kernels run 512-thread workgroups with 16 points per thread at radix 3 and n <= 8192 -- twice the registers per thread, half the waves)
+static int f64_hold_threads(const crc_ctx *c, int RB) { const int nt = f64_threads(c, RB); return RB == 3 && c->tune.f64_hold_nt == 512 && c->n <= 8192 && nt > 512 ? 512 : nt; }
+static int f64_npt(const crc_ctx *c, int RB) { const int v = c->n / f64_hold_threads(c, RB); return v <= 8 ? 8 : v <= 16 ? 16 : 32; }
 
 // kp: k_relin64_keys_words; scratch: crc_evk_words (k_relin64_work_words covers it)
 int k_relin64_prepare_keys(crc_ctx *c, const u64 *evk, int dbc, u64 *kp, u64 *scratch, hipStream_t st)
@@ -248,7 +252,7 @@ int k_relin64_prepare_keys(crc_ctx *c, const u64 *evk, int dbc, u64 *kp, u64 *sc
     const int RB = f64_radix(c);
     auto kern = RB == 3 ? relin_keys_f64_kernel<3> : RB == 4 ? relin_keys_f64_kernel<4> : relin_keys_f64_kernel<5>;
     { const int r2 = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (r2) return r2; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(rows * CRC_NF64)), dim3(f64_threads(c, RB)), lds, st, scratch, Kf, c->d_mods, reinterpret_cast<const d2 *>(c->d_f64_rp), c->f64, c->n, c->logn, c->k);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(rows * CRC_NF64)), dim3(f64_threads(c, RB)), lds, st, scratch, Kf, c->d_mods, c->d_f64_rp, c->f64, c->n, c->logn, c->k);
     HIPCHK(hipGetLastError());
     return CRC_OK;
 }
@@ -266,17 +270,17 @@ static int relin64_mac(crc_ctx *c, const double *E, const double *Kf, double *A,
     return CRC_OK;
 }
 
-template <int RB>
-static int relin64_tail(crc_ctx *c, double *A, const u64 *x3, int add_size, u64 *y, size_t cnt, bool out_ntt, hipStream_t st)
+template <int RB, int NPT>
+static int relin64_tail(crc_ctx *c, const double *A, const u64 *x3, int add_size, u64 *y, size_t cnt, bool out_ntt, hipStream_t st)
 {
     bool lazy = true;
     for (int i = 0; i < c->k; i++) if (c->tabs[i].m.bits > 57 || c->tabs[i].m.bits < 45) lazy = false;
     const size_t lds = (size_t)c->n * 8;
     const bool one = lds > 80 * 1024;
-    auto kern = one ? (!out_ntt ? relin_inv_crt_kernel<RB, false, false, true> : lazy ? relin_inv_crt_kernel<RB, true, true, true> : relin_inv_crt_kernel<RB, true, false, true>)
-                    : (!out_ntt ? relin_inv_crt_kernel<RB, false, false> : lazy ? relin_inv_crt_kernel<RB, true, true> : relin_inv_crt_kernel<RB, true, false>);
+    auto kern = one ? (!out_ntt ? relin_inv_crt_kernel<RB, NPT, false, false, true> : lazy ? relin_inv_crt_kernel<RB, NPT, true, true, true> : relin_inv_crt_kernel<RB, NPT, true, false, true>)
+                    : (!out_ntt ? relin_inv_crt_kernel<RB, NPT, false, false> : lazy ? relin_inv_crt_kernel<RB, NPT, true, true> : relin_inv_crt_kernel<RB, NPT, true, false>);
     { const int rc = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (rc) return rc; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * 2 * c->k)), dim3(f64_threads(c, RB)), lds, st, A, x3, add_size, y, c->d_mods, reinterpret_cast<const d2 *>(c->d_f64_irp),
+    hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * 2 * c->k)), dim3(f64_hold_threads(c, RB)), lds, st, A, x3, add_size, y, c->d_mods, c->d_f64_irp,
                        reinterpret_cast<const ulonglong2 *>(c->d_rp), c->f64, c->n, c->logn, c->k);
     HIPCHK(hipGetLastError());
     return CRC_OK;
@@ -297,16 +301,12 @@ int k_relinearize64(crc_ctx *c, const u64 *src, int src_size, int src_poly, cons
     int rc;
     double *E = reinterpret_cast<double *>(work), *A = E + cnt * D * CRC_NF64 * n;
     const size_t lds = n * 8;
-    const int RB = f64_radix(c);
+    const int RB = f64_radix(c), npt = f64_npt(c, RB);
+    if (RB == 3 && npt > 16) return CRC_ERR_UNSUPPORTED;
     {
-        // (the split form of the digit transforms -- two 64-KiB halves at n = 16384 -- measured SLOWER than the whole 128-KiB row, 18.4 against 17.7 us per ciphertext
-        // at k = 4: each half converts both source words again and the kernel is bound by instruction issue, not by occupancy; kept behind CRC_NTT_SPLIT=2 for tools/)
-        const bool split = RB == 3 && c->n == 16384 && c->tune.ntt_split == 2;
-        auto kern = split ? relin_digits_f64_kernel<3, true> : RB == 3 ? relin_digits_f64_kernel<3> : RB == 4 ? relin_digits_f64_kernel<4> : relin_digits_f64_kernel<5>;
-        const size_t ldsk = split ? lds / 2 : lds;
-        const int r2 = crc_ctx_ensure_lds(c, (const void *)kern, ldsk); if (r2) return r2;
-        hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * k)), dim3(f64_threads(c, RB)), ldsk, st, src, src_size, src_poly, E, reinterpret_cast<const d2 *>(c->d_f64_rp), c->f64, c->n, c->logn,
-                           c->k, D, dbc, tab);
+        auto kern = RB == 3 ? (npt == 8 ? relin_digits_f64_kernel<3, 8> : relin_digits_f64_kernel<3, 16>) : RB == 4 ? relin_digits_f64_kernel<4, 16> : relin_digits_f64_kernel<5, 32>;
+        const int r2 = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (r2) return r2;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * k)), dim3(f64_hold_threads(c, RB)), lds, st, src, src_size, src_poly, E, c->d_f64_rp, c->f64, c->n, c->logn, c->k, D, dbc, tab);
         HIPCHK(hipGetLastError());
     }
     switch (c->k) {
@@ -316,6 +316,6 @@ int k_relinearize64(crc_ctx *c, const u64 *src, int src_size, int src_poly, cons
     default: return CRC_ERR_UNSUPPORTED;
     }
     if (rc) return rc;
-    return RB == 3 ? relin64_tail<3>(c, A, x3, add_size, y, cnt, out_ntt, st) : RB == 4 ? relin64_tail<4>(c, A, x3, add_size, y, cnt, out_ntt, st)
-                                                                                          : relin64_tail<5>(c, A, x3, add_size, y, cnt, out_ntt, st);
+    return RB == 3 ? (npt == 8 ? relin64_tail<3, 8>(c, A, x3, add_size, y, cnt, out_ntt, st) : relin64_tail<3, 16>(c, A, x3, add_size, y, cnt, out_ntt, st))
+         : RB == 4 ? relin64_tail<4, 16>(c, A, x3, add_size, y, cnt, out_ntt, st) : relin64_tail<5, 32>(c, A, x3, add_size, y, cnt, out_ntt, st);
 }

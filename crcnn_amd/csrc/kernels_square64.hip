@@ -11,6 +11,10 @@
 // row at n = 8192, 0.090 against 0.16-0.21 at 16384).  The q half (dyadic products and inverse transforms over the coefficient moduli) stays in kernels.hip.
 //   sq64_lift_kernel  : q -> {p_j}: fastbconv_mtilde + mont_rq, residues written as centred doubles                                  LB [ct][2][kf][n]
 //   sq64_fwd_kernel   : forward transform of every LB row in place
+//   sq64_liftfwd_kernel (round 4, NTT-resident callers): the two above in one -- the inverse transform that brings x to coefficient form leaves it multiplied by
+//                       m~ (q/q_i)^-1 (NttArgs prologue 5), and the forward transform under p_j lifts its row while it stages it: the kf workgroups of a polynomial
+//                       share their k source rows through one XCD's L2, LB is written once and never read back untransformed (-20 of 260 row transfers per
+//                       ciphertext at (8192, 3), one kernel less)
 //   sq64_inv_kernel   : a^2, 2ab, b^2 formed while a row is staged, inverse transform (unscaled: n^-1 sits in floor_x)                   DB [ct][3][kf][n]
 //   sq64_floor_kernel : x t, fast_floor, fastbconv_sk back to q (one lazy 128-bit sum + one reduction per q_i), optional (q/q_i)^-1 on c2 for relinearisation
 #include "kernels.h"
@@ -71,7 +75,7 @@ __global__ void __launch_bounds__(256) sq64_lift_kernel(const u64 *x, double *ou
 
 // rows: [count * 2 * kf][n] doubles, transformed in place under p_(row % kf); results reduced
 template <int RB>
-__global__ void __launch_bounds__(RB == 5 ? 512 : 1024) sq64_fwd_kernel(double *rows, const d2 *Wf, const Sq64Params *sp, int n, int logn, int kf)
+__global__ void __launch_bounds__(RB == 5 ? 512 : 1024) sq64_fwd_kernel(double *rows, const double *Wf, const Sq64Params *sp, int n, int logn, int kf)
 {
     extern __shared__ double smd[];
     const int j = blockIdx.x % kf;
@@ -86,31 +90,91 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024) sq64_fwd_kernel(double *
     }
 }
 
+// tr: [count][2][K][n] = x m~ (q/q_i)^-1 mod q_i in coefficient form (k_ntt_ct_inv_scaled)  ->  out [count][2][kf][n]: the lifted polynomial under p_j, transformed, reduced.
+// One workgroup per (polynomial, prime); the kf workgroups of a polynomial sit on one XCD (xcd_group) and read the same k rows.  The lift is sq64_lift_kernel's
+// (baseconverter.cpp:663-742, 581-622) for ONE target prime, computed while the row is staged into the image
+template <int K, int RB>
+__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 ? 8 : 4) sq64_liftfwd_kernel(const u64 *tr, double *out, const double *Wf, const BehzParams *bp, const Sq64Params *sp,
+                                                                                           int n, int logn, int kf, size_t polys)
+{
+    extern __shared__ double smd[];
+    size_t poly; unsigned j;
+    if (!xcd_group(blockIdx.x, (unsigned)kf, polys, poly, j)) return;
+    const BehzParams &b = *bp; const Sq64Params &f = *sp;
+    const F64Mod md = f.m[j];
+    const u64 *src = tr + poly * (size_t)K * n;
+    const u32 iq = (u32)b.inv_q_mod_mt;
+    for (int s = 2 * threadIdx.x; s < n; s += 2 * blockDim.x) {
+        u32 xm0 = 0, xm1 = 0;
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + (size_t)i * n + s);
+            xm0 += (u32)v.x * (u32)b.qhat_mod_mt[i]; xm1 += (u32)v.y * (u32)b.qhat_mod_mt[i];                        // residue mod m~ = 2^32 (:720-741)
+            a0 += mul_split((double)(u32)(v.x >> 32), (double)(u32)v.x, f.lift_c[j][i], md.p);
+            a1 += mul_split((double)(u32)(v.y >> 32), (double)(u32)v.y, f.lift_c[j][i], md.p);
+        }
+        // r = -(x_m~ q^-1) mod m~ in [0, m~): mont_rq :604-612 (not centred in SEAL 2.3.1); (sum_i tr_i (q/q_i) + q r) m~^-1 mod p_j: 2K + 1 products below 0.875 p each
+        a0 += f64_mulmod_const((double)(0u - xm0 * iq), f.lift_r[j][0], f.lift_r[j][1], md.p);
+        a1 += f64_mulmod_const((double)(0u - xm1 * iq), f.lift_r[j][0], f.lift_r[j][1], md.p);
+        sm_store_pair<RB>(smd, s, f64_reduce(a0, md), f64_reduce(a1, md));
+    }
+    __syncthreads();
+    ntt_row_passes_f64<false, RB>(smd, Wf + (size_t)j * n, n, logn, md);
+    double *row = out + (poly * kf + j) * (size_t)n;
+    for (int s = 2 * threadIdx.x; s < n; s += 2 * blockDim.x) {
+        const d2 v = sm_load_pair<RB>(smd, s);
+        *reinterpret_cast<d2 *>(row + s) = d2{f64_reduce(v.x, md), f64_reduce(v.y, md)};
+    }
+}
+
 // in: [count][2][kf][n] transformed rows (a, b)  ->  out: [count][3][kf][n]: n (a^2, 2ab, b^2) in coefficient form, reduced.  One workgroup per (ciphertext, prime):
-// the three products share the two source rows (read again from L2 rather than held in registers across the transforms)
-template <int RB>
-__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 ? 8 : 4) sq64_inv_kernel(const double *in, double *out, const d2 *Wi, const Sq64Params *sp, int n, int logn, int kf)
+// the three products share the two source rows, each of which is read ONCE and waits in registers (NPT = points per thread) while the transform in front of its
+// second use runs -- round 3 read them again, and by then the L2 had been swept by the other workgroups' rows (20 row reads per ciphertext for 10 rows at (8192, 3))
+template <int RB, int NPT>
+__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 && NPT <= 8 ? 8 : 4) sq64_inv_kernel(const double *in, double *out, const double *Wi, const Sq64Params *sp, int n, int logn, int kf)
 {
     extern __shared__ double smd[];
     const size_t ct = blockIdx.x / kf; const int j = blockIdx.x % kf;
     const F64Mod md = sp->m[j];
+    const int tid = threadIdx.x, nt = blockDim.x;
     const double *a = in + ((ct * 2 + 0) * kf + j) * (size_t)n, *b = in + ((ct * 2 + 1) * kf + j) * (size_t)n;
-    for (int o = 0; o < 3; o++) {
-        const double *u = o == 2 ? b : a, *v = o == 0 ? a : b;
-        const double sc = o == 1 ? 2.0 : 1.0;
-        for (int s = 2 * threadIdx.x; s < n; s += 2 * blockDim.x) {
-            const d2 uv = *reinterpret_cast<const d2 *>(u + s), vv = *reinterpret_cast<const d2 *>(v + s);
-            sm_store_pair<RB>(smd, s, sc * f64_mulmod(uv.x, vv.x, md), sc * f64_mulmod(uv.y, vv.y, md));            // |.| < 1.75 p: the first pass reduces on load
-        }
+    double r[NPT];
+    auto transform_store = [&](int o) {
         __syncthreads();
         ntt_row_passes_f64<true, RB>(smd, Wi + (size_t)j * n, n, logn, md);
         double *dst = out + ((ct * 3 + o) * kf + j) * (size_t)n;
-        for (int s = 2 * threadIdx.x; s < n; s += 2 * blockDim.x) {
-            const d2 r = sm_load_pair<RB>(smd, s);
-            *reinterpret_cast<d2 *>(dst + s) = d2{f64_reduce(r.x, md), f64_reduce(r.y, md)};
+        for (int s = 2 * tid; s < n; s += 2 * nt) {
+            const d2 v = sm_load_pair<RB>(smd, s);
+            *reinterpret_cast<d2 *>(dst + s) = d2{f64_reduce(v.x, md), f64_reduce(v.y, md)};
         }
         __syncthreads();
+    };
+    // a^2 (|.| < 0.875 p: the first pass reduces on load); a stays in r
+#pragma unroll
+    for (int u = 0; u < NPT / 2; u++) {
+        const int s = 2 * (tid + u * nt);
+        if (s < n) { const d2 v = *reinterpret_cast<const d2 *>(a + s); r[2 * u] = v.x; r[2 * u + 1] = v.y; sm_store_pair<RB>(smd, s, f64_mulmod(v.x, v.x, md), f64_mulmod(v.y, v.y, md)); }
     }
+    transform_store(0);
+    // 2ab; b replaces a in r
+#pragma unroll
+    for (int u = 0; u < NPT / 2; u++) {
+        const int s = 2 * (tid + u * nt);
+        if (s < n) {
+            const d2 v = *reinterpret_cast<const d2 *>(b + s);
+            sm_store_pair<RB>(smd, s, 2.0 * f64_mulmod(r[2 * u], v.x, md), 2.0 * f64_mulmod(r[2 * u + 1], v.y, md));
+            r[2 * u] = v.x; r[2 * u + 1] = v.y;
+        }
+    }
+    transform_store(1);
+    // b^2
+#pragma unroll
+    for (int u = 0; u < NPT / 2; u++) {
+        const int s = 2 * (tid + u * nt);
+        if (s < n) sm_store_pair<RB>(smd, s, f64_mulmod(r[2 * u], r[2 * u], md), f64_mulmod(r[2 * u + 1], r[2 * u + 1], md));
+    }
+    transform_store(2);
 }
 
 // dq: [count][3][K][n] u64 (coefficient form over q, scaled), db: [count][3][KF][n] doubles (n times the coefficient, reduced) -> y3: [count][3][K][n].
@@ -184,6 +248,10 @@ bool k_square64_supported(const crc_ctx *c)
     return false;
 }
 
+// points per thread of a row transform kernel that keeps a row in registers: n / threads, rounded up to the instances that exist (8 | 16 | 32)
+static int sq64_hold_threads(const crc_ctx *c, int RB) { const int nt = sq64_threads(c, RB); return RB == 3 && c->tune.f64_hold_nt == 512 && c->n <= 8192 && nt > 512 ? 512 : nt; }
+static int sq64_npt(const crc_ctx *c, int RB) { const int v = c->n / sq64_hold_threads(c, RB); return v <= 8 ? 8 : v <= 16 ? 16 : 32; }
+
 // work: QN [2k] | LB [2 kf] | DQ [3k] | DB [3 kf]   (k_square_work_words sizes the rows by max(kb, kf))
 int k_square64(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStream_t st, bool in_ntt, bool premul_c2)
 {
@@ -194,22 +262,37 @@ int k_square64(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStre
     double *LB = reinterpret_cast<double *>(LBw), *DB = reinterpret_cast<double *>(DBw);
     const int lthreads = c->n < 512 ? c->n / 2 : 256, lblocks = c->n / (2 * lthreads);         // (the lift kernel: two coefficients per thread)
     int rc;
-    const u64 *xc = x, *xn = QN;
-    if (in_ntt) { if ((rc = k_ntt_ct(c, true, x, QN, cnt, 2, false, st, nullptr, 0, 0, 0))) return rc; xc = QN; xn = x; }
-    {
-        const dim3 grid((unsigned)(cnt * 2 * lblocks)), blk(lthreads);
+    const size_t lds = n * 8;
+    const int RB = sq64_radix(c), nt = sq64_threads(c, RB), npt = sq64_npt(c, RB);
+    const double *Wf = c->d_f64_rp, *Wi = c->d_f64_irp;
+    const u64 *xn = QN;
+    if (in_ntt && c->tune.sq_fuse != 0) {
+        // NTT-resident caller: the coefficient form exists only for the lift, so it is made premultiplied and lifted inside the forward transforms (sq64_liftfwd_kernel)
+        if ((rc = k_ntt_ct_inv_scaled(c, x, QN, cnt, 2, c->behz.mt_inv_qhat, c->behz.mt_inv_qhat_s, st))) return rc;
+        xn = x;
         bool launched = false;
-#define LIFT(KV, KFV) if (c->k == KV && c->sq64.kf == KFV) { hipLaunchKernelGGL((sq64_lift_kernel<KV, KFV>), grid, blk, 0, st, xc, LB, c->d_mods, c->d_behz, c->d_sq64, c->n); launched = true; }
-        CRC_FOR_ALL_K_KF(LIFT)
-#undef LIFT
+        const unsigned grid = xcd_grid(cnt * 2, (unsigned)kf);
+#define LIFTFWD(KV) if (c->k == KV) { \
+            auto kern = RB == 3 ? sq64_liftfwd_kernel<KV, 3> : RB == 4 ? sq64_liftfwd_kernel<KV, 4> : sq64_liftfwd_kernel<KV, 5>; \
+            if ((rc = crc_ctx_ensure_lds(c, (const void *)kern, lds))) return rc; \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), lds, st, QN, LB, Wf, c->d_behz, c->d_sq64, c->n, c->logn, (int)kf, cnt * 2); launched = true; }
+        LIFTFWD(1) LIFTFWD(2) LIFTFWD(3) LIFTFWD(4) LIFTFWD(5) LIFTFWD(6) LIFTFWD(7) LIFTFWD(8)
+#undef LIFTFWD
         if (!launched) return CRC_ERR_UNSUPPORTED;
         HIPCHK(hipGetLastError());
-    }
-    if (!in_ntt && (rc = k_ntt_ct(c, false, x, QN, cnt, 2, false, st, nullptr, 0, 0, 0))) return rc;
-    const size_t lds = n * 8;
-    const int RB = sq64_radix(c), nt = sq64_threads(c, RB);
-    const d2 *Wf = reinterpret_cast<const d2 *>(c->d_f64_rp), *Wi = reinterpret_cast<const d2 *>(c->d_f64_irp);
-    {
+    } else {
+        const u64 *xc = x;
+        if (in_ntt) { if ((rc = k_ntt_ct(c, true, x, QN, cnt, 2, false, st, nullptr, 0, 0, 0))) return rc; xc = QN; xn = x; }
+        {
+            const dim3 grid((unsigned)(cnt * 2 * lblocks)), blk(lthreads);
+            bool launched = false;
+#define LIFT(KV, KFV) if (c->k == KV && c->sq64.kf == KFV) { hipLaunchKernelGGL((sq64_lift_kernel<KV, KFV>), grid, blk, 0, st, xc, LB, c->d_mods, c->d_behz, c->d_sq64, c->n); launched = true; }
+            CRC_FOR_ALL_K_KF(LIFT)
+#undef LIFT
+            if (!launched) return CRC_ERR_UNSUPPORTED;
+            HIPCHK(hipGetLastError());
+        }
+        if (!in_ntt && (rc = k_ntt_ct(c, false, x, QN, cnt, 2, false, st, nullptr, 0, 0, 0))) return rc;
         auto kern = RB == 3 ? sq64_fwd_kernel<3> : RB == 4 ? sq64_fwd_kernel<4> : sq64_fwd_kernel<5>;
         if ((rc = crc_ctx_ensure_lds(c, (const void *)kern, lds))) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * 2 * kf)), dim3(nt), lds, st, LB, Wf, c->d_sq64, c->n, c->logn, (int)kf);
@@ -218,9 +301,10 @@ int k_square64(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStre
     // a^2, 2ab, b^2 over q are formed while the inverse transforms load their rows (kernels.hip); over the fp64 primes in sq64_inv_kernel
     if ((rc = k_square_intt(c, xn, DQ, cnt, false, st))) return rc;
     {
-        auto kern = RB == 3 ? sq64_inv_kernel<3> : RB == 4 ? sq64_inv_kernel<4> : sq64_inv_kernel<5>;
+        auto kern = RB == 3 ? (npt == 8 ? sq64_inv_kernel<3, 8> : sq64_inv_kernel<3, 16>) : RB == 4 ? sq64_inv_kernel<4, 16> : sq64_inv_kernel<5, 32>;
+        if (RB == 3 && npt > 16) return CRC_ERR_UNSUPPORTED;
         if ((rc = crc_ctx_ensure_lds(c, (const void *)kern, lds))) return rc;
-        hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * kf)), dim3(nt), lds, st, LB, DB, Wi, c->d_sq64, c->n, c->logn, (int)kf);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * kf)), dim3(sq64_hold_threads(c, RB)), lds, st, LB, DB, Wi, c->d_sq64, c->n, c->logn, (int)kf);
         HIPCHK(hipGetLastError());
     }
     {

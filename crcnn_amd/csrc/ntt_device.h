@@ -4,6 +4,17 @@
 #include "modarith.h"
 #include <hip/hip_runtime.h>
 
+// Workgroups that read the same rows -- the kf transforms that lift one polynomial, the three products of one (ciphertext, modulus) pair -- should share an L2.
+// Blocks b and b + 8 run on the same XCD (dispatch deals blocks round-robin over the eight XCDs: observed, not promised, and only speed depends on it), so the G
+// members of a group take consecutive slots of ONE XCD: the rows come from memory once and from that XCD's L2 afterwards.  Launch xcd_grid(groups, G) blocks
+// (kernels.h); blocks past the last group return at once.
+__device__ __forceinline__ bool xcd_group(unsigned b, unsigned G, size_t groups, size_t &grp, unsigned &member)
+{
+    const unsigned xcd = b & 7u, slot = b >> 3;
+    member = slot % G; grp = (size_t)(slot / G) * 8 + xcd;
+    return grp < groups;
+}
+
 // LDS index swizzle (XOR, no padding): conflict-free ds_read/write_b64 for the contiguous staging accesses AND for every strided
 // register-tile pattern of the radix-8 passes at n = 4096 (at most 2-way in the short tail pass of n = 8192 / 16384); found by
 // enumerating the access patterns (bank = index mod 32 per 32-lane group)

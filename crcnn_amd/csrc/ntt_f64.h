@@ -25,8 +25,13 @@ template <int SW> __device__ __forceinline__ d2 sm_load_pair(const double *sm, i
 // forward: values grow by at most 0.875 p per stage: 16-bit inputs stay below 14 p < 2^51 through 15 stages -- no reduction anywhere
 // The 2^R - 1 twiddles of a thread's R stages are fetched up front (tw[(1 << st) - 1 + j] = twiddle j of stage st), in front of the LDS reads of the pass: one
 // exposed memory latency per pass instead of one per stage (the compiler keeps loads where they are written and waits right in front of the first use)
+// A twiddle is ONE double (the centred power of psi): the quotient of a butterfly product is estimated from the product itself (f64_mulmod: fl(h / p) instead of
+// y (w / p) -- the same six flops, one more link in the dependency chain), not from a precomputed companion w / p.  Half the table bytes and, what matters more,
+// 7 instead of 14 live twiddle registers per radix-8 pass: every transform kernel sits at the 64-register line of two 1024-thread workgroups per CU, and the registers
+// returned hold a row across its transforms (relinearisation's source row, the square's a / b rows, the first prime's result in front of the CRT step) instead of
+// re-reading it from memory or parking it there (round 3: 17 + 10 + 12 of 260 row transfers per ciphertext at (8192, 3))
 template <int R>
-__device__ __forceinline__ void load_tw_fwd(d2 (&tw)[(1 << R) - 1], const d2 *W, int m, int blk)
+__device__ __forceinline__ void load_tw_fwd(double (&tw)[(1 << R) - 1], const double *W, int m, int blk)
 {
 #pragma unroll
     for (int st = 0; st < R; st++)
@@ -34,7 +39,7 @@ __device__ __forceinline__ void load_tw_fwd(d2 (&tw)[(1 << R) - 1], const d2 *W,
         for (int j = 0; j < (1 << st); j++) tw[(1 << st) - 1 + j] = W[(m << st) + (blk << st) + j];
 }
 template <int R>
-__device__ __forceinline__ void load_tw_inv(d2 (&tw)[(1 << R) - 1], const d2 *W, int h, int blk)
+__device__ __forceinline__ void load_tw_inv(double (&tw)[(1 << R) - 1], const double *W, int h, int blk)
 {
 #pragma unroll
     for (int st = 0; st < R; st++)
@@ -42,7 +47,7 @@ __device__ __forceinline__ void load_tw_inv(d2 (&tw)[(1 << R) - 1], const d2 *W,
         for (int j = 0; j < (1 << (R - 1 - st)); j++) tw[(1 << R) - (1 << (R - st)) + j] = W[(h >> st) + (blk << (R - 1 - st)) + j];
 }
 template <int R>
-__device__ __forceinline__ void fwd_stages_f64(double (&v)[1 << R], const d2 (&tw)[(1 << R) - 1], double p)
+__device__ __forceinline__ void fwd_stages_f64(double (&v)[1 << R], const double (&tw)[(1 << R) - 1], const F64Mod md)
 {
 #pragma unroll
     for (int st = 0; st < R; st++) {
@@ -50,15 +55,14 @@ __device__ __forceinline__ void fwd_stages_f64(double (&v)[1 << R], const d2 (&t
 #pragma unroll
         for (int c = 0; c < (1 << R); c++) {
             if (c & half) continue;
-            const d2 t2 = tw[(1 << st) - 1 + (c >> (R - st))];
-            const double X = v[c], T = f64_mulmod_const(v[c + half], t2.x, t2.y, p);
+            const double X = v[c], T = f64_mulmod(tw[(1 << st) - 1 + (c >> (R - st))], v[c + half], md);
             v[c] = X + T; v[c + half] = X - T;
         }
     }
 }
 // inverse (Gentleman-Sande, no halving: n^-1 sits in the keys): sums double per stage, so a pass starts from reduced values (|x| <= p/2 -> below 4 p after three stages)
 template <int R>
-__device__ __forceinline__ void inv_stages_f64(double (&v)[1 << R], const d2 (&tw)[(1 << R) - 1], double p)
+__device__ __forceinline__ void inv_stages_f64(double (&v)[1 << R], const double (&tw)[(1 << R) - 1], const F64Mod md)
 {
 #pragma unroll
     for (int st = 0; st < R; st++) {
@@ -66,34 +70,33 @@ __device__ __forceinline__ void inv_stages_f64(double (&v)[1 << R], const d2 (&t
 #pragma unroll
         for (int c = 0; c < (1 << R); c++) {
             if (c & half) continue;
-            const d2 t2 = tw[(1 << R) - (1 << (R - st)) + (c >> (st + 1))];
             const double U = v[c], V = v[c + half];
-            v[c] = U + V; v[c + half] = f64_mulmod_const(U - V, t2.x, t2.y, p);
+            v[c] = U + V; v[c + half] = f64_mulmod(tw[(1 << R) - (1 << (R - st)) + (c >> (st + 1))], U - V, md);
         }
     }
 }
 // s = 2^ls: element stride inside a group.  The swizzles are XORs of shifted index bits, i.e. linear over GF(2), and (c << ls) occupies bits that are zero in
 // `base`: swz(base + c s) = swz(base) ^ swz(c s) -- one vector XOR per element against a wave-uniform constant instead of the whole index arithmetic
 template <bool INV, int R, int RB>
-__device__ __forceinline__ void ntt_pass_f64(double *sm, const d2 *W, int n, int ls, int tabidx, const F64Mod md, bool reduce_in)
+__device__ __forceinline__ void ntt_pass_f64(double *sm, const double *W, int n, int ls, int tabidx, const F64Mod md, bool reduce_in)
 {
     const unsigned groups = (unsigned)n >> R;
     for (unsigned g = threadIdx.x; g < groups; g += blockDim.x) {
         const unsigned blk = g >> ls, l = g & ((1u << ls) - 1);
         const int a0 = swz<RB>((int)((blk << (ls + R)) + l));
-        d2 tw[(1 << R) - 1];
+        double tw[(1 << R) - 1];
         if (INV) load_tw_inv<R>(tw, W, tabidx, (int)blk); else load_tw_fwd<R>(tw, W, tabidx, (int)blk);
         double v[1 << R];
 #pragma unroll
         for (int c = 0; c < (1 << R); c++) { v[c] = sm[a0 ^ swz<RB>(c << ls)]; if (INV && reduce_in) v[c] = f64_reduce(v[c], md); }
-        if (INV) inv_stages_f64<R>(v, tw, md.p); else fwd_stages_f64<R>(v, tw, md.p);
+        if (INV) inv_stages_f64<R>(v, tw, md); else fwd_stages_f64<R>(v, tw, md);
 #pragma unroll
         for (int c = 0; c < (1 << R); c++) sm[a0 ^ swz<RB>(c << ls)] = v[c];
     }
     __syncthreads();
 }
 template <bool INV, int RB>
-__device__ __forceinline__ void ntt_tail_pass_f64(int rem, double *sm, const d2 *W, int n, int ls, int tabidx, const F64Mod md)
+__device__ __forceinline__ void ntt_tail_pass_f64(int rem, double *sm, const double *W, int n, int ls, int tabidx, const F64Mod md)
 {
     if (rem == 1) ntt_pass_f64<INV, 1, RB>(sm, W, n, ls, tabidx, md, INV);
     else if (rem == 2) ntt_pass_f64<INV, 2, RB>(sm, W, n, ls, tabidx, md, INV);
@@ -107,7 +110,7 @@ __device__ __forceinline__ void ntt_tail_pass_f64(int rem, double *sm, const d2 
 // tm: twiddle block multiplier -- 1 for a whole row; 2 + h when the n points are half h of a 2n-point row whose stage 0 (forward) / last stage (inverse) is done by
 // the caller (global block I = h m' + i' of a stage with 2 m' blocks sits at table index 2 m' + I: kernels.hip ntt_rows_split_body)
 template <bool INV, int RB>
-__device__ __forceinline__ void ntt_row_passes_f64(double *sm, const d2 *W, int n, int logn, const F64Mod md, int tm = 1)
+__device__ __forceinline__ void ntt_row_passes_f64(double *sm, const double *W, int n, int logn, const F64Mod md, int tm = 1)
 {
     const int full = logn / RB, rem = logn - RB * full;
     if (!INV) {

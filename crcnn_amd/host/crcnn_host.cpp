@@ -155,6 +155,13 @@ static shared_ptr<DeviceBuffer> uploadPlain(const vector<const Plaintext *> &pl,
 // at instead of a buffer of its own -- every layer constructs its output tensor first.  With 200 GiB of weights resident there is no room for a recycling pool, and a
 // hipMalloc / hipFree pair per layer costs more than most layers (PlainModelWoPad at n = 16384: 113 ms instead of 3.8 ms per image for conv1).
 static thread_local shared_ptr<DeviceBuffer> *g_out_hint = nullptr;
+// arms the hint for ONE layer call and disarms it when the scope ends, however it ends: a layer that throws before it has constructed its output must not leave the
+// hint pointing at the network's slot for whatever tensor the caller constructs next (an encryptImage in a retry, or a slot of a Network that no longer exists)
+struct OutHint {
+    explicit OutHint(shared_ptr<DeviceBuffer> *slot) { g_out_hint = slot; }
+    ~OutHint() { g_out_hint = nullptr; }
+    OutHint(const OutHint &) = delete; OutHint &operator=(const OutHint &) = delete;
+};
 
 ciphertext3D::ciphertext3D(int B, int zd, int xd, int yd, int form) : B(B), zd(zd), xd(xd), yd(yd), form(form)
 {
@@ -449,16 +456,17 @@ void ConvolutionalLayer::upload()
         for (int z = 0; z < zd; z++) for (int i = 0; i < xf; i++) for (int j = 0; j < yf; j++) w.push_back(&filters[f][z][i][j]);
         b.push_back(&biases[f]);
     }
-    streamed = tooLargeForHbm(w.size());
+    streamed = forced_placement >= 0 ? forced_placement == 1 : tooLargeForHbm(w.size());
     if (streamed) d_plain = uploadPlain(w, 3); else d_w = uploadPlain(w, 0);
     d_b[0] = uploadPlain(b, 1); d_b[1] = uploadPlain(b, 2);
     filters_already_ntt = true;            // transform_kernel_to_ntt, convolutionalLayer.cpp:151-156 (done once)
 }
+int ConvolutionalLayer::placement() { upload(); return streamed ? 1 : 0; }
 void ConvolutionalLayer::deviceParameters(vector<shared_ptr<DeviceBuffer>> &out, bool allocate_only)
 {
     if (allocate_only && !filters_already_ntt) {
         const size_t rowb = (size_t)K() * N() * 8;
-        streamed = tooLargeForHbm((size_t)nf * zd * xf * yf);
+        streamed = forced_placement >= 0 ? forced_placement == 1 : tooLargeForHbm((size_t)nf * zd * xf * yf);
         if (!streamed) d_w = make_shared<DeviceBuffer>((size_t)nf * zd * xf * yf * rowb);
         d_b[0] = make_shared<DeviceBuffer>(nf * rowb); d_b[1] = make_shared<DeviceBuffer>(nf * rowb);
         filters_already_ntt = true;
@@ -538,8 +546,9 @@ void FullyConnectedLayer::upload()
     if ((int)weights.size() != out_dim || (int)biases.size() != out_dim) throw invalid_argument("fc: weight/bias count mismatch");
     vector<const Plaintext *> w, b;
     for (int i = 0; i < out_dim; i++) { if ((int)weights[i].size() != in_dim) throw invalid_argument("fc: row length mismatch"); for (int j = 0; j < in_dim; j++) w.push_back(&weights[i][j]); b.push_back(&biases[i]); }
-    streamed = tooLargeForHbm(w.size());
-    if (!streamed && plannedForm(in_dim, 1, 1, 1, 1, 1, 1, out_dim, 0) == CRC_NTTL) {
+    streamed = forced_placement >= 0 ? forced_placement == 1 : tooLargeForHbm(w.size());
+    if (forced_placement >= 0) tilewise = forced_placement == 2;
+    else if (!streamed && plannedForm(in_dim, 1, 1, 1, 1, 1, 1, out_dim, 0) == CRC_NTTL) {
         // canonical + limb copy beyond what HBM has left, the limb copy alone within it: build the limb weights tile by tile at the first forward (buildTilewise)
         size_t free_b = 0, total_b = 0;
         chk(crc_mem_info(ctx(), &free_b, &total_b), "crc_mem_info");
@@ -602,15 +611,22 @@ void FullyConnectedLayer::buildTilewise()
     }
     w_form = CRC_NTTL; tile_built = true;
 }
+int FullyConnectedLayer::placement() { upload(); return streamed ? 1 : tilewise ? 2 : 0; }
 void FullyConnectedLayer::deviceParameters(vector<shared_ptr<DeviceBuffer>> &out, bool allocate_only)
 {
-    if (allocate_only && !weights_already_ntt) {
+    if (allocate_only && !weights_already_ntt && forced_placement == 2) {
+        // a tile-wise layer is never on the wire (its only device copy is the limb tensor -- 182 GiB for PlainModelWoPad's fc3 at n = 16384, k = 4 -- which every
+        // rank builds from its own plaintexts, deterministically): a receiving rank needs the model's plaintexts like the root
+        if ((int)weights.size() != out_dim) throw logic_error("FullyConnectedLayer " + name + ": tile-wise weights are built on every rank -- a receiving rank must load the model too");
+    } else if (allocate_only && !weights_already_ntt) {
         const size_t rowb = (size_t)K() * N() * 8;
-        streamed = tooLargeForHbm((size_t)in_dim * out_dim);
+        streamed = forced_placement >= 0 ? forced_placement == 1 : tooLargeForHbm((size_t)in_dim * out_dim);
         if (!streamed) d_w = make_shared<DeviceBuffer>((size_t)in_dim * out_dim * rowb);
         d_b[0] = make_shared<DeviceBuffer>(out_dim * rowb); d_b[1] = make_shared<DeviceBuffer>(out_dim * rowb);
         weights_already_ntt = true;
     }
+    upload();
+    if (tilewise) { buildTilewise(); return; }              // nothing to send or receive (see above)
     packWeights(true);
     if (streamed && !d_plain) d_plain = make_shared<DeviceBuffer>((size_t)in_dim * out_dim * N() * 8);
     out.push_back(streamed ? d_plain : d_w); out.push_back(d_b[0]); out.push_back(d_b[1]);
@@ -638,6 +654,9 @@ ciphertext3D FullyConnectedLayer::forward(ciphertext3D input)
 {
     if (!input.buf || input.zd * input.xd * input.yd != in_dim) throw invalid_argument("FullyConnectedLayer: input size does not match in_dim");   // reshapeInput, :38-56
     upload();
+    // a tile-wise layer has no canonical weights: whoever reaches it first -- Network::forward through limbWeights, a direct call, a network with matrix_cores off --
+    // builds the limb tensor, the only form its weights exist in (the layer then runs on the limb GEMM whatever the plan would have been)
+    if (tilewise && !tile_built) buildTilewise();
     ciphertext3D out(input.B, 1, out_dim, 1, out_form);
     if (streamed) { forwardStreamed(input, out, in_dim, 1, 1, 1, 1, 1, 1, out_dim, out_form, d_plain, d_b, d_wtile, d_ytile, g_scratch); return out; }
     ensure(g_scratch, crc_conv2d_forms_work_bytes(ctx(), input.B, in_dim, 1, 1, 1, 1, 1, 1, out_dim, input.form, w_form, out_form));
@@ -805,17 +824,14 @@ ciphertext3D Network::forward(ciphertext3D input)
             ciphertext3D t = input.images(b0, Bc);
             for (int i = 0; i < split; i++) {
                 auto t0 = chrono::high_resolution_clock::now();
-                { const int s_in = t.buf == act_slot[0] ? 0 : t.buf == act_slot[1] ? 1 : -1; g_out_hint = &act_slot[s_in == 0 ? 1 : 0]; }
-                t = layers[i]->forward(t);
-                g_out_hint = nullptr;
+                { OutHint hint(&act_slot[t.buf == act_slot[0] ? 1 : 0]); t = layers[i]->forward(t); }
                 chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
                 last_layer_ms[i] += chrono::duration<double, milli>(chrono::high_resolution_clock::now() - t0).count();
             }
             const size_t out_cts = (size_t)t.zd * t.xd * t.yd;
             if (!tail_in.buf) {         // kept across calls like the activation slots: next to 182 GiB of weights the pool has no room to hold it
-                g_out_hint = &tail_slot;
+                OutHint hint(&tail_slot);
                 tail_in = ciphertext3D(B, t.zd, t.xd, t.yd, limb[split] ? CRC_NTTL : t.form);
-                g_out_hint = nullptr;
             }
             if (limb[split])      // every chunk's tensor goes straight into the dense layer's K-blocked limb tensor
                 chk(crc_limb_pack_tensor_at(ctx(), t.data(), t.form, Bc, (int)out_cts, 1, 1, tail_in.data(), B, b0, nullptr), "crc_limb_pack_tensor_at");
@@ -835,9 +851,17 @@ ciphertext3D Network::forward(ciphertext3D input)
         auto t0 = chrono::high_resolution_clock::now();
         // every layer but the last writes into one of the network's two activation slots (the one its input does not live in); the last layer's output -- ten
         // ciphertexts per image -- is the caller's own tensor, as in the reference
-        if (i + 1 < L) { const int s_in = input.buf == act_slot[0] ? 0 : input.buf == act_slot[1] ? 1 : -1; g_out_hint = &act_slot[s_in == 0 ? 1 : 0]; }
-        input = layers[i]->forward(input);
-        g_out_hint = nullptr;
+        if (i + 1 < L) { OutHint hint(&act_slot[input.buf == act_slot[0] ? 1 : 0]); input = layers[i]->forward(input); }
+        else {
+            ciphertext3D output = layers[i]->forward(input);
+            // a last layer that hands its input back (none of CrCNN's does) must not give the caller a tensor that lives in an activation slot the next forward overwrites
+            if (output.buf && (output.buf == act_slot[0] || output.buf == act_slot[1] || output.buf == tail_slot)) {
+                ciphertext3D own(output.B, output.zd, output.xd, output.yd, output.form);
+                chk(crc_memcpy_d2d(ctx(), own.data(), output.data(), output.count() * ctBytes(), nullptr), "crc_memcpy_d2d");
+                output = own;
+            }
+            input = output;
+        }
         chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
         last_layer_ms[i] = chrono::duration<double, milli>(chrono::high_resolution_clock::now() - t0).count();
     }
@@ -849,6 +873,15 @@ size_t Network::broadcastParameters(crc_comm *comm, int root)
     if (!comm) throw invalid_argument("broadcastParameters: no communicator");
     const int rank = crc_comm_rank(comm), world = crc_comm_world(comm);
     if (root < 0 || root >= world) throw invalid_argument("broadcastParameters: bad root");
+    // the root's placement of every layer's weights (resident / streamed / tile-wise) sizes the buffers on the wire: every rank adopts it before it allocates
+    {
+        const size_t L = layers.size();
+        vector<uint64_t> mine_pl(L, 0), all_pl(L * (size_t)world, 0);
+        if (rank == root) for (size_t i = 0; i < L; i++) mine_pl[i] = (uint64_t)layers[i]->placement();
+        if (L > 64) throw invalid_argument("broadcastParameters: more than 64 layers");
+        if (L) chk(crc_comm_allgather_u64(comm, mine_pl.data(), L, all_pl.data(), nullptr), "crc_comm_allgather_u64");
+        if (rank != root) for (size_t i = 0; i < L; i++) layers[i]->adoptPlacement((int)all_pl[(size_t)root * L + i]);
+    }
     vector<shared_ptr<DeviceBuffer>> bufs;
     for (auto &l : layers) l->deviceParameters(bufs, rank != root);
     if (!ev_keys16) throw logic_error("setParameters() must be called first");

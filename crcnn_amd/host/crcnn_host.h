@@ -99,6 +99,11 @@ public:
     // device-resident encoded parameters of this layer, in a fixed order (Network::broadcastParameters).  allocate_only: a receiving
     // rank sizes the buffers without encoding anything; otherwise the plaintext parameters are lifted + NTT'd into them first.
     virtual void deviceParameters(std::vector<std::shared_ptr<DeviceBuffer>> &out, bool allocate_only) { (void)out; (void)allocate_only; }
+    // where this layer keeps its weights: 0 resident in NTT form, 1 streamed (coefficient-form plaintexts, transformed tile by tile inside every forward),
+    // 2 tile-wise limb weights (no canonical copy is ever made).  Decided from the memory the rank has; Network::broadcastParameters makes every rank adopt the
+    // root's decision, because the buffers on the wire are sized by it
+    virtual int placement() { return 0; }
+    virtual void adoptPlacement(int p) { (void)p; }
 };
 
 class BatchNormLayer;
@@ -126,11 +131,14 @@ private:
     std::shared_ptr<DeviceBuffer> d_plain, d_wtile, d_ytile;
     int w_form = CRC_NTT;                                   // CRC_NTTP / CRC_NTTL / CRC_NTTL1 once Network::forward has put the weights into their MAC kernel's operand form
     std::shared_ptr<DeviceBuffer> d_w_canon;                // CRC_NTTL1 only: the canonical NTT-form weights
+    int forced_placement = -1;
     void upload();
     void packWeights(bool unpack);
     bool limbWeights(int B);                                // -> CRC_NTTL (matrix-core kernel) when the layer qualifies (for batches of B) and HBM has room for the second copy
 public:
     void deviceParameters(std::vector<std::shared_ptr<DeviceBuffer>> &out, bool allocate_only) override;
+    int placement() override;
+    void adoptPlacement(int p) override { forced_placement = p; }
 };
 
 class FullyConnectedLayer : public Layer {                  // fullyConnectedLayer.h:22-24
@@ -157,6 +165,7 @@ private:
     // canonical copy: its limb weights are built a tile of output rows at a time straight from the plaintexts (lift + NTT -> batch-norm fold of the tile -> pack), a
     // batch-norm layer that Network::fuse() folds into it being applied to every tile (same ciphertexts; netrun.py does the same)
     bool tilewise = false, tile_built = false;
+    int forced_placement = -1;
     std::shared_ptr<BatchNormLayer> fold_bn;
     void buildTilewise();
     void upload();
@@ -164,6 +173,8 @@ private:
     bool limbWeights(int B);
 public:
     void deviceParameters(std::vector<std::shared_ptr<DeviceBuffer>> &out, bool allocate_only) override;
+    int placement() override;
+    void adoptPlacement(int p) override { forced_placement = p; }
 };
 
 class PoolingLayer : public Layer {                         // poolingLayer.h:15
