@@ -114,8 +114,7 @@ struct CrcTuning {
     int mfma_min_steps = 0;       // CRC_MFMA_MIN_STEPS: reduction steps of 32 channels from which a conv / dense layer goes to the limb GEMM (0: 8)
     int f64_radix = 0;            // CRC_F64_RADIX=3|4|5: butterfly stages per LDS pass of the fp64 transforms (0: default)
     int sq_chunk = 0;             // CRC_SQ_CHUNK: ciphertexts per internal pass of square + relinearise (0: by ring size)
-    int f64_hold_nt = 0;          // CRC_F64_HOLD_NT=512: threads per workgroup of the fp64 transform kernels that keep a row in registers (0: n / 8, at most 1024)
-    int sq_fuse = 1;              // CRC_SQ_FUSE=0: an NTT-resident square lifts and transforms in separate kernels (round 3) instead of inside the forward transforms
+    int sq_fuse = -1;             // CRC_SQ_FUSE=1: an NTT-resident square lifts inside its forward fp64 transforms, 0: in a kernel of its own (round 3), -1: by k (fused up to k = 4)
     int sq_path = 0;              // CRC_SQ_PATH=0: by parameters, 1: the square's auxiliary base is SEAL's 61-bit one (round-2 kernels), 2: the engine's fp64 primes
     int relin_path = 0;           // CRC_RELIN_PATH=0: by parameters, 1: key switching over the coefficient moduli (round-2 path), 2: over the two fp64 primes
 };

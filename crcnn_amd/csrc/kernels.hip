@@ -76,6 +76,10 @@ __device__ __forceinline__ void ntt_rows_body(const NttArgs &a)
     const float rq = 1.0f / (float)((u32)(q >> 32) + 1);
     const ulonglong2 *W = a.w + (size_t)mi * n;
     u64 *dst = a.dst + row * (size_t)n;
+    // the gap-1 stage is applied here, in the loops that fill (inverse) / drain (forward) the image, when it would otherwise be a pass of its own (ntt_device.h)
+    const bool fuse1 = ntt_fused_stage(logn);
+    const ulonglong2 *W1 = W + (n >> 1);
+    auto put = [&](int s, u64 v0, u64 v1) { ulonglong2 v{v0, v1}; if (INV && fuse1) inv_pair_stage<LAZY>(v, W1[s >> 1], q, q2); sm_store_pair64(sm, s, v.x, v.y); };
     if (INV && PRO == 4) {
         const size_t ct = row / (3 * (size_t)a.mod_count); const int p = (int)((row / a.mod_count) % 3);
         const u64 *pa = a.src + ((ct * 2 + (p == 2 ? 1 : 0)) * a.mod_count + mloc) * (size_t)n;
@@ -84,7 +88,7 @@ __device__ __forceinline__ void ntt_rows_body(const NttArgs &a)
             const ulonglong2 av = ld2(pa + s), bv = ld2(pb + s);
             u64 v0 = mulmod(av.x, bv.x, m), v1 = mulmod(av.y, bv.y, m);
             if (p == 1) { v0 = addmod(v0, v0, q); v1 = addmod(v1, v1, q); }
-            sm_store_pair64(sm, s, v0, v1);
+            put(s, v0, v1);
         }
     } else if (!INV && PRO == 3) {
         const size_t item = row / a.mod_count, ct = item / a.D; const int g = (int)(item % a.D);
@@ -103,17 +107,13 @@ __device__ __forceinline__ void ntt_rows_body(const NttArgs &a)
             }
             return v;
         };
-        for (int s = 2 * tid; s < n; s += 2 * nt) { const ulonglong2 v = ld2(src + s); sm_store_pair64(sm, s, pro(v.x), pro(v.y)); }
+        for (int s = 2 * tid; s < n; s += 2 * nt) { const ulonglong2 v = ld2(src + s); put(s, pro(v.x), pro(v.y)); }
     }
     __syncthreads();
 
-    const int full = logn / 3, rem = logn - 3 * full;
     if (!INV) {
         // gaps n/2, n/4, ...: radix-8 passes first, a radix-4 / radix-2 pass finishes when log2(n) is not a multiple of 3
-        int t = n >> 1;
-        for (int p = 0; p < full; p++, t >>= 3) ntt_pass<false, 3, LAZY>(sm, W, n, t >> 2, n / (2 * t), q, q2);
-        if (rem == 2) ntt_pass<false, 2, LAZY>(sm, W, n, t >> 1, n / (2 * t), q, q2);
-        else if (rem == 1) ntt_pass<false, 1, LAZY>(sm, W, n, t, n / (2 * t), q, q2);
+        ntt_row_passes<false, LAZY, 3, true>(sm, W, n, logn, q, q2);
         const u64 *add = a.addend ? a.addend + row * (size_t)n : nullptr;      // forward epilogue: + an NTT-form row of the same index
         auto fin = [&](u64 v) -> u64 {
             if (LAZY) return reduce_small(v, q, q2, rq);
@@ -121,16 +121,14 @@ __device__ __forceinline__ void ntt_rows_body(const NttArgs &a)
         };
         for (int s = 2 * tid; s < n; s += 2 * nt) {
             ulonglong2 v = sm_load_pair64(sm, s);
+            if (fuse1) fwd_pair_stage<LAZY>(v, W1[s >> 1], q, q2);
             v.x = fin(v.x); v.y = fin(v.y);
             if (add) { const ulonglong2 ad = ld2(add + s); v.x = addmod(v.x, ad.x, q); v.y = addmod(v.y, ad.y, q); }
             if (a.pack_out) st2(dst + s, split28v(v.x), split28v(v.y)); else st2(dst + s, v.x, v.y);
         }
     } else {
         // gaps 1, 2, 4, ...
-        int t = 1;
-        for (int p = 0; p < full; p++, t <<= 3) ntt_pass<true, 3, LAZY>(sm, W, n, t, n / (2 * t), q, q2);
-        if (rem == 2) ntt_pass<true, 2, LAZY>(sm, W, n, t, n / (2 * t), q, q2);
-        else if (rem == 1) ntt_pass<true, 1, LAZY>(sm, W, n, t, n / (2 * t), q, q2);
+        ntt_row_passes<true, LAZY, 3, true>(sm, W, n, logn, q, q2);
         const u64 *add = nullptr;
         if (a.addend) {
             const size_t ct = row / a.rows_per_ct; const int p = (int)((row % a.rows_per_ct) / a.mod_count);
@@ -217,20 +215,23 @@ __device__ __forceinline__ void ntt_rows_split_body(const NttArgs &a)
         if (!INV && PRO == 3) return ulonglong2{(v.x >> sh) & a.dig_mask, (v.y >> sh) & a.dig_mask};
         return ulonglong2{pro(v.x), pro(v.y)};
     };
+    // (the gap-1 stage of a half transform -- its last stage forward, its first inverse -- is applied by the loops that drain / fill the image: ntt_device.h)
+    const bool fuse1 = ntt_fused_stage(logn2);
     auto passes = [&](int h) {          // the half transform: n/2 points, twiddle block index (2 + h) m
-        const int full = logn2 / 3, rem = logn2 - 3 * full, tm = 2 + h;
+        const int full = logn2 / 3, rem = fuse1 ? 0 : logn2 - 3 * full, tm = 2 + h;
         if (!INV) {
             int t = n2 >> 1;
             for (int p = 0; p < full; p++, t >>= 3) ntt_pass<false, 3, LAZY>(sm, W, n2, t >> 2, tm * (n2 / (2 * t)), q, q2);
             if (rem == 2) ntt_pass<false, 2, LAZY>(sm, W, n2, t >> 1, tm * (n2 / (2 * t)), q, q2);
             else if (rem == 1) ntt_pass<false, 1, LAZY>(sm, W, n2, t, tm * (n2 / (2 * t)), q, q2);
         } else {
-            int t = 1;
+            int t = fuse1 ? 2 : 1;
             for (int p = 0; p < full; p++, t <<= 3) ntt_pass<true, 3, LAZY>(sm, W, n2, t, tm * (n2 / (2 * t)), q, q2);
             if (rem == 2) ntt_pass<true, 2, LAZY>(sm, W, n2, t, tm * (n2 / (2 * t)), q, q2);
             else if (rem == 1) ntt_pass<true, 1, LAZY>(sm, W, n2, t, tm * (n2 / (2 * t)), q, q2);
         }
     };
+    auto pair_tw = [&](int h, int s) { return W[(2 + h) * (n2 >> 1) + (s >> 1)]; };       // twiddle of the pair (s, s + 1) of half h in its gap-1 stage
     auto canon = [&](u64 v) -> u64 {
         if (LAZY) return reduce_small(v, q, q2, rq);
         v = v >= q2 ? v - q2 : v; return v >= q ? v - q : v;
@@ -259,13 +260,16 @@ __device__ __forceinline__ void ntt_rows_split_body(const NttArgs &a)
         stage0(0);
         passes(0);
 #pragma unroll
-        for (int u = 0; u < NPT / 2; u++) { const int s = 2 * (tid + u * nt); if (s < n2) { const ulonglong2 v = sm_load_pair64(sm, s); r0[2 * u] = canon(v.x); r0[2 * u + 1] = canon(v.y); } }
+        for (int u = 0; u < NPT / 2; u++) {
+            const int s = 2 * (tid + u * nt);
+            if (s < n2) { ulonglong2 v = sm_load_pair64(sm, s); if (fuse1) fwd_pair_stage<LAZY>(v, pair_tw(0, s), q, q2); r0[2 * u] = canon(v.x); r0[2 * u + 1] = canon(v.y); }
+        }
         __syncthreads();
         stage0(1);
 #pragma unroll
         for (int u = 0; u < NPT / 2; u++) { const int s = 2 * (tid + u * nt); if (s < n2) put(s, r0[2 * u], r0[2 * u + 1]); }
         passes(1);
-        for (int s = 2 * tid; s < n2; s += 2 * nt) { const ulonglong2 v = sm_load_pair64(sm, s); put(n2 + s, canon(v.x), canon(v.y)); }
+        for (int s = 2 * tid; s < n2; s += 2 * nt) { ulonglong2 v = sm_load_pair64(sm, s); if (fuse1) fwd_pair_stage<LAZY>(v, pair_tw(1, s), q, q2); put(n2 + s, canon(v.x), canon(v.y)); }
     } else {
         const u64 *add = nullptr;
         if (a.addend) {
@@ -273,12 +277,12 @@ __device__ __forceinline__ void ntt_rows_split_body(const NttArgs &a)
             if (a.add_mode == 2) add = a.addend + ((ct * a.add_size + p) * a.mod_count + mloc) * (size_t)n;
             else if (p == 0) { size_t g = ct / a.add_group; if (a.add_mod) g %= a.add_mod; add = a.addend + (g * a.mod_count + mloc) * (size_t)n; }
         }
-        for (int s = 2 * tid; s < n2; s += 2 * nt) { const ulonglong2 v = load2(s); sm_store_pair64(sm, s, v.x, v.y); }
+        for (int s = 2 * tid; s < n2; s += 2 * nt) { ulonglong2 v = load2(s); if (fuse1) inv_pair_stage<LAZY>(v, pair_tw(0, s), q, q2); sm_store_pair64(sm, s, v.x, v.y); }
         __syncthreads();
         passes(0);
         for (int s = 2 * tid; s < n2; s += 2 * nt) { const ulonglong2 v = sm_load_pair64(sm, s); st2(dst + s, v.x, v.y); }        // parked (lazy, below 2^63); read back by this very thread below
         __syncthreads();
-        for (int s = 2 * tid; s < n2; s += 2 * nt) { const ulonglong2 v = load2(s + n2); sm_store_pair64(sm, s, v.x, v.y); }
+        for (int s = 2 * tid; s < n2; s += 2 * nt) { ulonglong2 v = load2(s + n2); if (fuse1) inv_pair_stage<LAZY>(v, pair_tw(1, s), q, q2); sm_store_pair64(sm, s, v.x, v.y); }
         __syncthreads();
         passes(1);
         const u64 q16 = q2 << 3;

@@ -38,15 +38,20 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024) relin_keys_f64_kernel(co
     const int j = (int)(row % k); const size_t gp = row / k; const size_t g = gp >> 1; const int poly = (int)(gp & 1);
     const u64 q = mods[j].q;
     const F64Mod md = fp.m[m];
+    const double *W = Wf + (size_t)m * n;
     const u64 *src = kc + row * (size_t)n;
-    for (int s = threadIdx.x; s < n; s += blockDim.x) {
-        const u64 v = src[s];
-        smd[swz<RB>(s)] = f64_from_i64(v > (q >> 1) ? (long long)v - (long long)q : (long long)v, md);
+    auto cen = [&](u64 v) { return f64_from_i64(v > (q >> 1) ? (long long)v - (long long)q : (long long)v, md); };
+    for (int s = 2 * threadIdx.x; s < n; s += 2 * blockDim.x) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + s);
+        sm_store_pair<RB>(smd, s, cen(v.x), cen(v.y));
     }
     __syncthreads();
-    ntt_row_passes_f64<false, RB>(smd, Wf + (size_t)m * n, n, logn, md);
+    ntt_row_passes_f64<false, RB>(smd, W, n, logn, md);
     double *dst = Kf + (((g * 2 * k + (size_t)poly * k + j) * CRC_NF64) + m) * (size_t)n;
-    for (int s = threadIdx.x; s < n; s += blockDim.x) dst[s] = f64_reduce(f64_mulmod_const(smd[swz<RB>(s)], fp.ninv[m], fp.ninv_q[m], md.p), md);
+    for (int s = 2 * threadIdx.x; s < n; s += 2 * blockDim.x) {
+        const d2 v = f64_stage_out<false, RB>(sm_load_pair<RB>(smd, s), W, n, logn, s, md);
+        *reinterpret_cast<d2 *>(dst + s) = d2{f64_reduce(f64_mulmod_const(v.x, fp.ninv[m], fp.ninv_q[m], md.p), md), f64_reduce(f64_mulmod_const(v.y, fp.ninv[m], fp.ninv_q[m], md.p), md)};
+    }
 }
 
 // ---- K1: digits of c2' under both primes ---------------------------------------------------------------------------------------------------------------------------
@@ -54,7 +59,7 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024) relin_keys_f64_kernel(co
 // The source row is read ONCE and waits in registers (NPT points per thread) through the 2 L_i transforms cut from it: round 3 read it again in front of every
 // transform, 8 times at 16-bit digits, and the L2 had long been swept by then (20 row reads per ciphertext for 3 rows at (8192, 3))
 template <int RB, int NPT>
-__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 && NPT <= 8 ? 8 : 4) relin_digits_f64_kernel(const u64 *src, int src_size, int src_poly, double *E, const double *Wf, F64Params fp, int n, int logn,
+__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_digits_f64_kernel(const u64 *src, int src_size, int src_poly, double *E, const double *Wf, F64Params fp, int n, int logn,
                                                                                                          int k, int D, int dbc, Relin64Tab tab)
 {
     extern __shared__ double smd[];
@@ -80,7 +85,7 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 && NPT <= 8 ? 8 
             }
             __syncthreads();
             ntt_row_passes_f64<false, RB>(smd, Wf + (size_t)m * n, n, logn, fp.m[m]);
-            for (int s = 2 * tid; s < n; s += 2 * nt) *reinterpret_cast<d2 *>(dst + s) = sm_load_pair<RB>(smd, s);
+            for (int s = 2 * tid; s < n; s += 2 * nt) *reinterpret_cast<d2 *>(dst + s) = f64_stage_out<false, RB>(sm_load_pair<RB>(smd, s), Wf + (size_t)m * n, n, logn, s, fp.m[m]);
             __syncthreads();
         }
     }
@@ -134,10 +139,11 @@ __global__ void __launch_bounds__(256) relin_mac_f64_kernel(const double *E, con
 // A [ct][poly k + j][m][n]; x3: size-`add_size` ciphertexts whose polys 0, 1 are added (coefficient form); y [ct][2][k][n].  The first prime's result waits in
 // registers (NPT points per thread, reduced) while the image serves the second transform -- round 3 parked it in its own row of A (6 rows written and read back per
 // ciphertext at (8192, 3), and 11 spilled registers: the twiddle companions took the room)
-// (ONE_PER_CU: the row image takes more than half of the LDS -- n = 16384 -- so one workgroup per CU is all there is and the register cap that buys the second
-// workgroup at n <= 8192 would only spill)
-template <int RB, int NPT, bool OUT_NTT, bool LAZY, bool ONE_PER_CU = false>
-__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 && NPT <= 8 && !ONE_PER_CU ? 8 : 4) relin_inv_crt_kernel(const double *A, const u64 *x3, int add_size, u64 *y, const ModParams *mods, const double *Wi,
+// Workgroups of n / 16 threads, 16 points each: at n = 8192 two 512-thread workgroups per CU, four waves per SIMD and 128 registers -- with 1024 threads and 8 points
+// the 64-register line of the second workgroup left no room for the held row (18 spilled registers, 16.6 instead of 12.2 MB of traffic per ciphertext and 5.55
+// instead of 5.19 us at (8192, 3): profiles/r04_square_relin_ab_step1.txt)
+template <int RB, int NPT, bool OUT_NTT, bool LAZY>
+__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_inv_crt_kernel(const double *A, const u64 *x3, int add_size, u64 *y, const ModParams *mods, const double *Wi,
                                                                                                                      const ulonglong2 *Wq, F64Params fp, int n, int logn, int k)
 {
     extern __shared__ double smd[];
@@ -147,7 +153,10 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 && NPT <= 8 && !
     double a0[NPT];
     for (int m = 0; m < CRC_NF64; m++) {
         const double *src = a0row + (size_t)m * n;
-        for (int s = 2 * tid; s < n; s += 2 * nt) { const d2 v = *reinterpret_cast<const d2 *>(src + s); sm_store_pair<RB>(smd, s, v.x, v.y); }
+        for (int s = 2 * tid; s < n; s += 2 * nt) {
+            const d2 v = f64_stage_in<true, RB>(*reinterpret_cast<const d2 *>(src + s), Wi + (size_t)m * n, n, logn, s, fp.m[m]);
+            sm_store_pair<RB>(smd, s, v.x, v.y);
+        }
         __syncthreads();
         ntt_row_passes_f64<true, RB>(smd, Wi + (size_t)m * n, n, logn, fp.m[m]);
         if (m == 0) {
@@ -193,12 +202,14 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 && NPT <= 8 && !
     if (!OUT_NTT) return;
     // NTT-resident result: forward transform over q_j of (c_poly + R) in the same LDS image, same layout (ntt_device.h's radix-8 passes on the fp64 image's swizzle)
     __syncthreads();
-    ntt_row_passes<false, LAZY, RB>(sm, Wq + (size_t)j * n, n, logn, q, mq.two_q);
+    ntt_row_passes<false, LAZY, RB, true>(sm, Wq + (size_t)j * n, n, logn, q, mq.two_q);
     const float rq = 1.0f / (float)((u32)(q >> 32) + 1);
+    const bool fuse1 = ntt_fused_stage(logn);                  // (the gap-1 stage of the forward transform is applied here, while the image is drained: ntt_device.h)
     for (int s = 2 * tid; s < n; s += 2 * nt) {
         const int a = swz<RB>(s);
         ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(sm + (a & ~1));
         if (a & 1) { const u64 t = v.x; v.x = v.y; v.y = t; }
+        if (fuse1) fwd_pair_stage<LAZY>(v, Wq[(size_t)j * n + (n >> 1) + (s >> 1)], q, mq.two_q);
         if (LAZY) { v.x = reduce_small(v.x, q, mq.two_q, rq); v.y = reduce_small(v.y, q, mq.two_q, rq); }
         else { v.x = v.x >= mq.two_q ? v.x - mq.two_q : v.x; v.x = v.x >= q ? v.x - q : v.x; v.y = v.y >= mq.two_q ? v.y - mq.two_q : v.y; v.y = v.y >= q ? v.y - q : v.y; }
         *reinterpret_cast<ulonglong2 *>(dst + s) = v;
@@ -233,10 +244,9 @@ static int f64_threads(const crc_ctx *c, int RB) { int nt = c->n >> RB; if (nt <
 // 3 stages (8 values per thread) per LDS pass by default: measured on (8192, 3) the digit kernel runs 0.90 / 1.08 / 1.34 us per ciphertext with 3 / 4 / 5 -- the wider
 // passes save LDS round trips and barriers but cost occupancy (76 / 134 registers), and the kernel is bound by instruction issue, not by LDS (profiles/r03_square_relin.txt)
 static int f64_radix(const crc_ctx *c) { const int r = c->tune.f64_radix; return r >= 3 && r <= 5 ? r : 3; }
-// points per thread of the kernels that keep a row in registers: n / threads, rounded up to the instances that exist (radix 3: 8 | 16, radix 4: 16, radix 5: 32)
-// (tune.f64_hold_nt = 512: those kernels run 512-thread workgroups with 16 points per thread at radix 3 and n <= 8192 -- twice the registers per thread, half the waves)
-static int f64_hold_threads(const crc_ctx *c, int RB) { const int nt = f64_threads(c, RB); return RB == 3 && c->tune.f64_hold_nt == 512 && c->n <= 8192 && nt > 512 ? 512 : nt; }
-static int f64_npt(const crc_ctx *c, int RB) { const int v = c->n / f64_hold_threads(c, RB); return v <= 8 ? 8 : v <= 16 ? 16 : 32; }
+// threads of the kernels that keep a row in registers
+// (16 points per thread at radix 8 and 16, 32 at radix 32: n / 16 threads, at least a wave, at most 1024)
+static int f64_hold_threads(const crc_ctx *c, int RB) { int nt = c->n >> (RB == 5 ? 5 : 4); if (nt < 64) nt = 64; if (nt > (RB == 5 ? 512 : 1024)) nt = RB == 5 ? 512 : 1024; return nt; }
 
 // kp: k_relin64_keys_words; scratch: crc_evk_words (k_relin64_work_words covers it)
 int k_relin64_prepare_keys(crc_ctx *c, const u64 *evk, int dbc, u64 *kp, u64 *scratch, hipStream_t st)
@@ -276,9 +286,7 @@ static int relin64_tail(crc_ctx *c, const double *A, const u64 *x3, int add_size
     bool lazy = true;
     for (int i = 0; i < c->k; i++) if (c->tabs[i].m.bits > 57 || c->tabs[i].m.bits < 45) lazy = false;
     const size_t lds = (size_t)c->n * 8;
-    const bool one = lds > 80 * 1024;
-    auto kern = one ? (!out_ntt ? relin_inv_crt_kernel<RB, NPT, false, false, true> : lazy ? relin_inv_crt_kernel<RB, NPT, true, true, true> : relin_inv_crt_kernel<RB, NPT, true, false, true>)
-                    : (!out_ntt ? relin_inv_crt_kernel<RB, NPT, false, false> : lazy ? relin_inv_crt_kernel<RB, NPT, true, true> : relin_inv_crt_kernel<RB, NPT, true, false>);
+    auto kern = !out_ntt ? relin_inv_crt_kernel<RB, NPT, false, false> : lazy ? relin_inv_crt_kernel<RB, NPT, true, true> : relin_inv_crt_kernel<RB, NPT, true, false>;
     { const int rc = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (rc) return rc; }
     hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * 2 * c->k)), dim3(f64_hold_threads(c, RB)), lds, st, A, x3, add_size, y, c->d_mods, c->d_f64_irp,
                        reinterpret_cast<const ulonglong2 *>(c->d_rp), c->f64, c->n, c->logn, c->k);
@@ -301,10 +309,9 @@ int k_relinearize64(crc_ctx *c, const u64 *src, int src_size, int src_poly, cons
     int rc;
     double *E = reinterpret_cast<double *>(work), *A = E + cnt * D * CRC_NF64 * n;
     const size_t lds = n * 8;
-    const int RB = f64_radix(c), npt = f64_npt(c, RB);
-    if (RB == 3 && npt > 16) return CRC_ERR_UNSUPPORTED;
+    const int RB = f64_radix(c);
     {
-        auto kern = RB == 3 ? (npt == 8 ? relin_digits_f64_kernel<3, 8> : relin_digits_f64_kernel<3, 16>) : RB == 4 ? relin_digits_f64_kernel<4, 16> : relin_digits_f64_kernel<5, 32>;
+        auto kern = RB == 3 ? relin_digits_f64_kernel<3, 16> : RB == 4 ? relin_digits_f64_kernel<4, 16> : relin_digits_f64_kernel<5, 32>;
         const int r2 = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (r2) return r2;
         hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * k)), dim3(f64_hold_threads(c, RB)), lds, st, src, src_size, src_poly, E, c->d_f64_rp, c->f64, c->n, c->logn, c->k, D, dbc, tab);
         HIPCHK(hipGetLastError());
@@ -316,6 +323,6 @@ int k_relinearize64(crc_ctx *c, const u64 *src, int src_size, int src_poly, cons
     default: return CRC_ERR_UNSUPPORTED;
     }
     if (rc) return rc;
-    return RB == 3 ? (npt == 8 ? relin64_tail<3, 8>(c, A, x3, add_size, y, cnt, out_ntt, st) : relin64_tail<3, 16>(c, A, x3, add_size, y, cnt, out_ntt, st))
+    return RB == 3 ? relin64_tail<3, 16>(c, A, x3, add_size, y, cnt, out_ntt, st)
          : RB == 4 ? relin64_tail<4, 16>(c, A, x3, add_size, y, cnt, out_ntt, st) : relin64_tail<5, 32>(c, A, x3, add_size, y, cnt, out_ntt, st);
 }

@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024) sq64_fwd_kernel(double *
     __syncthreads();
     ntt_row_passes_f64<false, RB>(smd, Wf + (size_t)j * n, n, logn, md);
     for (int s = 2 * threadIdx.x; s < n; s += 2 * blockDim.x) {
-        const d2 v = sm_load_pair<RB>(smd, s);
+        const d2 v = f64_stage_out<false, RB>(sm_load_pair<RB>(smd, s), Wf + (size_t)j * n, n, logn, s, md);
         *reinterpret_cast<d2 *>(row + s) = d2{f64_reduce(v.x, md), f64_reduce(v.y, md)};
     }
 }
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 ? 8 : 4) sq64_li
     ntt_row_passes_f64<false, RB>(smd, Wf + (size_t)j * n, n, logn, md);
     double *row = out + (poly * kf + j) * (size_t)n;
     for (int s = 2 * threadIdx.x; s < n; s += 2 * blockDim.x) {
-        const d2 v = sm_load_pair<RB>(smd, s);
+        const d2 v = f64_stage_out<false, RB>(sm_load_pair<RB>(smd, s), Wf + (size_t)j * n, n, logn, s, md);
         *reinterpret_cast<d2 *>(row + s) = d2{f64_reduce(v.x, md), f64_reduce(v.y, md)};
     }
 }
@@ -132,17 +132,19 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 ? 8 : 4) sq64_li
 // the three products share the two source rows, each of which is read ONCE and waits in registers (NPT = points per thread) while the transform in front of its
 // second use runs -- round 3 read them again, and by then the L2 had been swept by the other workgroups' rows (20 row reads per ciphertext for 10 rows at (8192, 3))
 template <int RB, int NPT>
-__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 && NPT <= 8 ? 8 : 4) sq64_inv_kernel(const double *in, double *out, const double *Wi, const Sq64Params *sp, int n, int logn, int kf)
+__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) sq64_inv_kernel(const double *in, double *out, const double *Wi, const Sq64Params *sp, int n, int logn, int kf)
 {
     extern __shared__ double smd[];
     const size_t ct = blockIdx.x / kf; const int j = blockIdx.x % kf;
     const F64Mod md = sp->m[j];
     const int tid = threadIdx.x, nt = blockDim.x;
     const double *a = in + ((ct * 2 + 0) * kf + j) * (size_t)n, *b = in + ((ct * 2 + 1) * kf + j) * (size_t)n;
+    const double *W = Wi + (size_t)j * n;
+    auto put = [&](int s, double x, double y) { const d2 v = f64_stage_in<true, RB>(d2{x, y}, W, n, logn, s, md); sm_store_pair<RB>(smd, s, v.x, v.y); };
     double r[NPT];
     auto transform_store = [&](int o) {
         __syncthreads();
-        ntt_row_passes_f64<true, RB>(smd, Wi + (size_t)j * n, n, logn, md);
+        ntt_row_passes_f64<true, RB>(smd, W, n, logn, md);
         double *dst = out + ((ct * 3 + o) * kf + j) * (size_t)n;
         for (int s = 2 * tid; s < n; s += 2 * nt) {
             const d2 v = sm_load_pair<RB>(smd, s);
@@ -154,7 +156,7 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 && NPT <= 8 ? 8 
 #pragma unroll
     for (int u = 0; u < NPT / 2; u++) {
         const int s = 2 * (tid + u * nt);
-        if (s < n) { const d2 v = *reinterpret_cast<const d2 *>(a + s); r[2 * u] = v.x; r[2 * u + 1] = v.y; sm_store_pair<RB>(smd, s, f64_mulmod(v.x, v.x, md), f64_mulmod(v.y, v.y, md)); }
+        if (s < n) { const d2 v = *reinterpret_cast<const d2 *>(a + s); r[2 * u] = v.x; r[2 * u + 1] = v.y; put(s, f64_mulmod(v.x, v.x, md), f64_mulmod(v.y, v.y, md)); }
     }
     transform_store(0);
     // 2ab; b replaces a in r
@@ -163,7 +165,7 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 && NPT <= 8 ? 8 
         const int s = 2 * (tid + u * nt);
         if (s < n) {
             const d2 v = *reinterpret_cast<const d2 *>(b + s);
-            sm_store_pair<RB>(smd, s, 2.0 * f64_mulmod(r[2 * u], v.x, md), 2.0 * f64_mulmod(r[2 * u + 1], v.y, md));
+            put(s, 2.0 * f64_mulmod(r[2 * u], v.x, md), 2.0 * f64_mulmod(r[2 * u + 1], v.y, md));
             r[2 * u] = v.x; r[2 * u + 1] = v.y;
         }
     }
@@ -172,7 +174,7 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 && NPT <= 8 ? 8 
 #pragma unroll
     for (int u = 0; u < NPT / 2; u++) {
         const int s = 2 * (tid + u * nt);
-        if (s < n) sm_store_pair<RB>(smd, s, f64_mulmod(r[2 * u], r[2 * u], md), f64_mulmod(r[2 * u + 1], r[2 * u + 1], md));
+        if (s < n) put(s, f64_mulmod(r[2 * u], r[2 * u], md), f64_mulmod(r[2 * u + 1], r[2 * u + 1], md));
     }
     transform_store(2);
 }
@@ -248,9 +250,8 @@ bool k_square64_supported(const crc_ctx *c)
     return false;
 }
 
-// points per thread of a row transform kernel that keeps a row in registers: n / threads, rounded up to the instances that exist (8 | 16 | 32)
-static int sq64_hold_threads(const crc_ctx *c, int RB) { const int nt = sq64_threads(c, RB); return RB == 3 && c->tune.f64_hold_nt == 512 && c->n <= 8192 && nt > 512 ? 512 : nt; }
-static int sq64_npt(const crc_ctx *c, int RB) { const int v = c->n / sq64_hold_threads(c, RB); return v <= 8 ? 8 : v <= 16 ? 16 : 32; }
+// threads of the kernel that keeps a row in registers: 16 points per thread (32 at radix 32) -- kernels_relin64.hip relin_inv_crt_kernel
+static int sq64_hold_threads(const crc_ctx *c, int RB) { int nt = c->n >> (RB == 5 ? 5 : 4); if (nt < 64) nt = 64; if (nt > (RB == 5 ? 512 : 1024)) nt = RB == 5 ? 512 : 1024; return nt; }
 
 // work: QN [2k] | LB [2 kf] | DQ [3k] | DB [3 kf]   (k_square_work_words sizes the rows by max(kb, kf))
 int k_square64(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStream_t st, bool in_ntt, bool premul_c2)
@@ -263,10 +264,12 @@ int k_square64(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStre
     const int lthreads = c->n < 512 ? c->n / 2 : 256, lblocks = c->n / (2 * lthreads);         // (the lift kernel: two coefficients per thread)
     int rc;
     const size_t lds = n * 8;
-    const int RB = sq64_radix(c), nt = sq64_threads(c, RB), npt = sq64_npt(c, RB);
+    const int RB = sq64_radix(c), nt = sq64_threads(c, RB);
     const double *Wf = c->d_f64_rp, *Wi = c->d_f64_irp;
     const u64 *xn = QN;
-    if (in_ntt && c->tune.sq_fuse != 0) {
+    // (fused up to k = 4: every one of the kf workgroups of a polynomial reads its k source rows, and at k = 8, kf = 11 that costs more than the lift kernel's
+    // round trip -- 35.7 against 34.3 us per ciphertext at (16384, 8), 14.6 against 14.75 at (16384, 4), 5.55 against 5.69 at (8192, 3): profiles/r04_square_relin_ab_step1.txt)
+    if (in_ntt && (c->tune.sq_fuse < 0 ? c->k <= 4 : c->tune.sq_fuse != 0)) {
         // NTT-resident caller: the coefficient form exists only for the lift, so it is made premultiplied and lifted inside the forward transforms (sq64_liftfwd_kernel)
         if ((rc = k_ntt_ct_inv_scaled(c, x, QN, cnt, 2, c->behz.mt_inv_qhat, c->behz.mt_inv_qhat_s, st))) return rc;
         xn = x;
@@ -301,8 +304,7 @@ int k_square64(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStre
     // a^2, 2ab, b^2 over q are formed while the inverse transforms load their rows (kernels.hip); over the fp64 primes in sq64_inv_kernel
     if ((rc = k_square_intt(c, xn, DQ, cnt, false, st))) return rc;
     {
-        auto kern = RB == 3 ? (npt == 8 ? sq64_inv_kernel<3, 8> : sq64_inv_kernel<3, 16>) : RB == 4 ? sq64_inv_kernel<4, 16> : sq64_inv_kernel<5, 32>;
-        if (RB == 3 && npt > 16) return CRC_ERR_UNSUPPORTED;
+        auto kern = RB == 3 ? sq64_inv_kernel<3, 16> : RB == 4 ? sq64_inv_kernel<4, 16> : sq64_inv_kernel<5, 32>;
         if ((rc = crc_ctx_ensure_lds(c, (const void *)kern, lds))) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * kf)), dim3(sq64_hold_threads(c, RB)), lds, st, LB, DB, Wi, c->d_sq64, c->n, c->logn, (int)kf);
         HIPCHK(hipGetLastError());

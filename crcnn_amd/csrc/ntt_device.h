@@ -118,6 +118,26 @@ __device__ __forceinline__ void inv_stages(u64 (&v)[1 << R], const ulonglong2 *W
     }
 }
 
+// The stage with gap 1 -- the last of a forward transform, the first of an inverse one -- pairs the two points (s, s + 1), s even, that share one 16-byte slot of
+// the image, i.e. what one lane moves between memory and the image.  When log2 n = 3 m + 1 (n = 8192, and the halves of n = 16384) that stage would be an LDS pass
+// of its own with one butterfly per thread; instead the loops that fill / drain the image apply it in registers (ntt_fused_stage: four passes and barriers per row
+// instead of five).  Same butterflies in the same order on the same values, hence the same results.  Twiddle of the pair: table index n/2 + s/2 (both directions).
+__device__ __forceinline__ bool ntt_fused_stage(int logn) { return logn > 3 && logn % 3 == 1; }
+template <bool LAZY>
+__device__ __forceinline__ void fwd_pair_stage(ulonglong2 &v, const ulonglong2 tw, u64 q, u64 q2)
+{
+    u64 X = v.x; const u64 Y = v.y;
+    if (LAZY) { const u64 Q = shoup_lazy4(Y, tw.x, tw.y, q); v.x = X + Q; v.y = X + (q2 + q2 - Q); }
+    else { X = X >= q2 ? X - q2 : X; const u64 Q = mulmod_shoup_lazy(Y, tw.x, tw.y, q); v.x = X + Q; v.y = X + (q2 - Q); }
+}
+template <bool LAZY>
+__device__ __forceinline__ void inv_pair_stage(ulonglong2 &v, const ulonglong2 tw, u64 q, u64 q2)
+{
+    const u64 U = v.x, V = v.y;
+    if (LAZY) { const u64 T = (q2 << 3) - V + U, cu = U + V; v.x = (cu + ((cu & 1) ? q : 0)) >> 1; v.y = shoup_lazy4(T, tw.x, tw.y, q); }
+    else { const u64 T = q2 - V + U; u64 cu = U + V; cu = cu >= q2 ? cu - q2 : cu; v.x = (cu + ((cu & 1) ? q : 0)) >> 1; v.y = mulmod_shoup_lazy(T, tw.x, tw.y, q); }
+}
+
 // one pass over the whole row: every thread takes groups of 2^R values that interact in the next R stages
 template <bool INV, int R, bool LAZY, int SW = 3>
 __device__ __forceinline__ void ntt_pass(u64 *sm, const ulonglong2 *W, int n, int s /*element stride inside a group*/, int tabidx, u64 q, u64 q2)
@@ -140,17 +160,19 @@ __device__ __forceinline__ void ntt_pass(u64 *sm, const ulonglong2 *W, int n, in
 // all passes of one row transform on the LDS image `sm` (n values, lpad-swizzled); the caller has synchronised after filling it and
 // the function returns synchronised.  Forward: gaps n/2, n/4, ... (radix-8 passes, then a radix-4 / radix-2 pass when log2 n is not
 // a multiple of 3); inverse: gaps 1, 2, 4, ...
-template <bool INV, bool LAZY, int SW = 3>
+// FUSE1: the caller applies the gap-1 stage itself while it fills (inverse) / drains (forward) the image whenever ntt_fused_stage(logn) says so
+template <bool INV, bool LAZY, int SW = 3, bool FUSE1 = false>
 __device__ __forceinline__ void ntt_row_passes(u64 *sm, const ulonglong2 *W, int n, int logn, u64 q, u64 q2)
 {
-    const int full = logn / 3, rem = logn - 3 * full;
+    const bool fused = FUSE1 && ntt_fused_stage(logn);
+    const int full = logn / 3, rem = fused ? 0 : logn - 3 * full;
     if (!INV) {
         int t = n >> 1;
         for (int p = 0; p < full; p++, t >>= 3) ntt_pass<false, 3, LAZY, SW>(sm, W, n, t >> 2, n / (2 * t), q, q2);
         if (rem == 2) ntt_pass<false, 2, LAZY, SW>(sm, W, n, t >> 1, n / (2 * t), q, q2);
         else if (rem == 1) ntt_pass<false, 1, LAZY, SW>(sm, W, n, t, n / (2 * t), q, q2);
     } else {
-        int t = 1;
+        int t = fused ? 2 : 1;
         for (int p = 0; p < full; p++, t <<= 3) ntt_pass<true, 3, LAZY, SW>(sm, W, n, t, n / (2 * t), q, q2);
         if (rem == 2) ntt_pass<true, 2, LAZY, SW>(sm, W, n, t, n / (2 * t), q, q2);
         else if (rem == 1) ntt_pass<true, 1, LAZY, SW>(sm, W, n, t, n / (2 * t), q, q2);

@@ -103,24 +103,44 @@ __device__ __forceinline__ void ntt_tail_pass_f64(int rem, double *sm, const dou
     else if (RB > 3 && rem == 3) ntt_pass_f64<INV, 3, RB>(sm, W, n, ls, tabidx, md, INV);
     else if (RB > 4 && rem == 4) ntt_pass_f64<INV, 4, RB>(sm, W, n, ls, tabidx, md, INV);
 }
-// all passes of one row on the LDS image (lpad-swizzled); caller has synchronised after filling it, returns synchronised.  Inverse: the image holds values below
-// 2^52 (lazy sums of up to 48 products); every pass reduces on load.
+// The single leftover stage of a transform whose log2 n is not a multiple of RB plus one... is not a pass: when log2 n = RB m + 1 (n = 8192 at radix 8) the
+// leftover stage is the one with gap 1 -- the last of a forward transform, the first of an inverse one -- and its two points are the two halves of ONE 16-byte
+// slot of the image, i.e. exactly what a lane moves between memory and the image.  The loops that fill and drain the image apply it in registers
+// (f64_stage_in / f64_stage_out below): four LDS passes and barriers per row instead of five.  Twiddle of the pair (s, s + 1): table index n/2 + s/2, both ways.
+template <int RB> __device__ __forceinline__ bool f64_fused_stage(int logn) { return logn > RB && logn % RB == 1; }
+// what goes INTO the image for points (s, s + 1) holding v.  Inverse with a fused first stage: inputs may be lazy sums below 2^52 -- reduced first, as a pass does on load
+template <bool INV, int RB>
+__device__ __forceinline__ d2 f64_stage_in(d2 v, const double *W, int n, int logn, int s, const F64Mod md)
+{
+    if (!INV || !f64_fused_stage<RB>(logn)) return v;
+    const double U = f64_reduce(v.x, md), V = f64_reduce(v.y, md);
+    return d2{U + V, f64_mulmod(W[(n >> 1) + (s >> 1)], U - V, md)};
+}
+// what comes OUT of the image for points (s, s + 1) holding v (forward with a fused last stage: values below 13 p in, below 14 p out -- unreduced, like a pass leaves them)
+template <bool INV, int RB>
+__device__ __forceinline__ d2 f64_stage_out(d2 v, const double *W, int n, int logn, int s, const F64Mod md)
+{
+    if (INV || !f64_fused_stage<RB>(logn)) return v;
+    const double T = f64_mulmod(W[(n >> 1) + (s >> 1)], v.y, md);
+    return d2{v.x + T, v.x - T};
+}
+// all LDS passes of one row on the image (swizzled); the caller has filled it through f64_stage_in and synchronised, the function returns synchronised, the caller
+// drains it through f64_stage_out.  Inverse: the image holds values below 2^52 (lazy sums of up to 48 products); every pass reduces on load.
 // (RB = stages per pass: 2^RB values per thread in registers between two LDS round trips.  The fp64 butterfly is a third of the 64-bit integer one's issue cycles, so
 // the LDS passes, their barriers and the twiddle loads weigh more here than in ntt_device.h: fewer, wider passes)
-// tm: twiddle block multiplier -- 1 for a whole row; 2 + h when the n points are half h of a 2n-point row whose stage 0 (forward) / last stage (inverse) is done by
-// the caller (global block I = h m' + i' of a stage with 2 m' blocks sits at table index 2 m' + I: kernels.hip ntt_rows_split_body)
 template <bool INV, int RB>
-__device__ __forceinline__ void ntt_row_passes_f64(double *sm, const double *W, int n, int logn, const F64Mod md, int tm = 1)
+__device__ __forceinline__ void ntt_row_passes_f64(double *sm, const double *W, int n, int logn, const F64Mod md)
 {
-    const int full = logn / RB, rem = logn - RB * full;
+    const bool fused = f64_fused_stage<RB>(logn);
+    const int full = logn / RB, rem = fused ? 0 : logn - RB * full;
     if (!INV) {
         // gaps n/2, n/4, ...: a pass of R stages starting at gap 2^lt works on groups of stride 2^(lt - R + 1); twiddle block index n / 2^(lt + 1)
         int lt = logn - 1;
-        for (int p = 0; p < full; p++, lt -= RB) ntt_pass_f64<false, RB, RB>(sm, W, n, lt - RB + 1, tm * (n >> (lt + 1)), md, false);
-        if (rem) ntt_tail_pass_f64<false, RB>(rem, sm, W, n, lt - rem + 1, tm * (n >> (lt + 1)), md);
+        for (int p = 0; p < full; p++, lt -= RB) ntt_pass_f64<false, RB, RB>(sm, W, n, lt - RB + 1, n >> (lt + 1), md, false);
+        if (rem) ntt_tail_pass_f64<false, RB>(rem, sm, W, n, lt - rem + 1, n >> (lt + 1), md);
     } else {
-        int lt = 0;
-        for (int p = 0; p < full; p++, lt += RB) ntt_pass_f64<true, RB, RB>(sm, W, n, lt, tm * (n >> (lt + 1)), md, true);
-        if (rem) ntt_tail_pass_f64<true, RB>(rem, sm, W, n, lt, tm * (n >> (lt + 1)), md);
+        int lt = fused ? 1 : 0;
+        for (int p = 0; p < full; p++, lt += RB) ntt_pass_f64<true, RB, RB>(sm, W, n, lt, n >> (lt + 1), md, true);
+        if (rem) ntt_tail_pass_f64<true, RB>(rem, sm, W, n, lt, n >> (lt + 1), md);
     }
 }

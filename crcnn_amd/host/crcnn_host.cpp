@@ -794,6 +794,7 @@ ciphertext3D Network::forward(ciphertext3D input)
                             : (packable && max_num_of_reencryptions < 0 && isMac(i) && isMac(i + 1) ? CRC_NTTP : CRC_NTT);
     }
     last_layer_ms.assign(L, 0.0);
+    last_reenc_ms = 0.0;
     if (max_num_of_reencryptions >= 0) {                    // network.cpp:52-96
         int refreshes_left = max_num_of_reencryptions;
         for (int i = 0; i < L; i++) {
@@ -804,9 +805,12 @@ ciphertext3D Network::forward(ciphertext3D input)
             last_layer_ms[i] += chrono::duration<double, milli>(chrono::high_resolution_clock::now() - t0).count();
             if (noiseBudget(output) <= 5) {
                 if (refreshes_left <= 0) throw OutOfBudgetException(i - 1);
+                auto r0 = chrono::high_resolution_clock::now();
                 vector<floatCube> imgs = decryptImages(input);
                 vector<ciphertext3D> enc; for (auto &im : imgs) enc.push_back(encryptImage(im));
                 input = stackImages(enc);
+                chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+                last_reenc_ms += chrono::duration<double, milli>(chrono::high_resolution_clock::now() - r0).count();
                 refreshes_left--;
                 i--;
                 continue;
@@ -843,10 +847,13 @@ ciphertext3D Network::forward(ciphertext3D input)
         first = split;
     }
     for (int i = first; i < L; i++) {
-        if (i == layer_before_reenc) {                      // client-side refresh (needs the secret key), network.cpp:30-34
+        if (i == layer_before_reenc) {                      // client-side refresh (needs the secret key), network.cpp:30-34; timed as T_REENC (:29-37)
+            auto r0 = chrono::high_resolution_clock::now();
             vector<floatCube> imgs = decryptImages(input);
             vector<ciphertext3D> enc; for (auto &im : imgs) enc.push_back(encryptImage(im));
             input = stackImages(enc);
+            chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+            last_reenc_ms += chrono::duration<double, milli>(chrono::high_resolution_clock::now() - r0).count();
         }
         auto t0 = chrono::high_resolution_clock::now();
         // every layer but the last writes into one of the network's two activation slots (the one its input does not live in); the last layer's output -- ten

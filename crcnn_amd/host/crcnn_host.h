@@ -253,6 +253,7 @@ public:
     // refreshed and the layer repeated while refreshes are left, then OutOfBudgetException(i - 1) is thrown.  -1: plain forward.
     int max_num_of_reencryptions = -1;
     std::vector<double> last_layer_ms;                      // per-layer wall milliseconds of the last forward (T_LAYER_i, mainparams.cpp:81)
+    double last_reenc_ms = 0.0;                             // T_REENC of that line: decrypt + re-encrypt in front of layer_before_reenc (network.cpp:30-37), all refreshes of the budget-checking forward (:52-96); 0 when none ran
     // Two-level chunking (> 0): the layers in front of the first dense layer run on sub-batches of `head_chunk` images, the dense layers once on the whole batch -- a
     // dense layer streams all of its weights per launch, so its time per image falls with the rows it is used for (PlainModelWoPad at n = 16384: 6-image chunks fit
     // beside 190 GiB of weights, fc3 wants 24+ images).  0: every layer on the whole batch

@@ -1,8 +1,10 @@
 // example_main.cpp -- a CrCNN-style driver on the MI355X engine: what CrCNN/src/mainparams.cpp:64-116 does (set parameters, build the
 // network from the HDF5 model, then per image: encrypt, Network::forward, decrypt, compare the arg-max with the plaintext model's),
 // written against crcnn_host.h / plain_modulus_search.h only.  It prints the reference's CSV columns (mainparams.cpp:81):
-//   OUTPUT: <index>,<T_LAYER_0 ms>,...,<prediction>,<Success|Mispredicted|Out of Budget>
-// usage: example_main <model name> <model.h5> <images.f32 (N x 784 normalised float32)> <poly_modulus> <plain_modulus> <num images> [fuse 0|1]
+//   OUTPUT: <index>,<T_LAYER_0 ms>,...,<T_REENC ms>,<T_LAYER_r ms>,...,<prediction>,<Success|Mispredicted|Out of Budget>
+// T_REENC (the client-side refresh of network.cpp:29-37) stands where the reference prints it -- in front of the layer it precedes -- when a refresh layer is set;
+// with the budget-checking forward (max re-encryptions) it is the total of the refreshes that ran and stands after the layer columns.
+// usage: example_main <model name> <model.h5> <images.f32 (N x 784 normalised float32)> <poly_modulus> <plain_modulus> <num images> [fuse 0|1] [layer_before_reenc] [max_reencryptions]
 #include "crcnn_host.h"
 #include "plain_modulus_search.h"
 #include <algorithm>
@@ -29,8 +31,12 @@ int main(int argc, char **argv)
         CnnBuilder build(h5);
         Network net = build.buildNetworkByName(model);
         if (fuse) net.fuse();
+        if (argc > 8) net.layer_before_reenc = atoi(argv[8]);
+        if (argc > 9) net.max_num_of_reencryptions = atoi(argv[9]);
+        const int reenc_at = net.max_num_of_reencryptions >= 0 ? net.getNumLayers() : net.layer_before_reenc;      // column position of T_REENC (-1: no refresh, no column)
         cout << "INDEX_IMG";
-        for (int i = 0; i < net.getNumLayers(); i++) cout << ",T_LAYER_" << i;
+        for (int i = 0; i < net.getNumLayers(); i++) { if (i == reenc_at) cout << ",T_REENC"; cout << ",T_LAYER_" << i; }
+        if (reenc_at == net.getNumLayers()) cout << ",T_REENC";
         cout << ",PREDICTION" << endl;
         int ok = 0;
         for (int i = 0; i < num_images_to_test && i < (int)cnt; i++) {
@@ -42,7 +48,8 @@ int main(int argc, char **argv)
             int predicted = -1;
             try {
                 encrypted_image = net.forward(encrypted_image);
-                for (double ms : net.last_layer_ms) cout << ms << ",";
+                for (int l = 0; l < (int)net.last_layer_ms.size(); l++) { if (l == reenc_at) cout << net.last_reenc_ms << ","; cout << net.last_layer_ms[l] << ","; }
+                if (reenc_at == (int)net.last_layer_ms.size()) cout << net.last_reenc_ms << ",";
                 if (noiseBudget(encrypted_image) <= 0) ret_value = OUT_OF_BUDGET;
                 floatCube image = decryptImage(encrypted_image);
                 predicted = 0;

@@ -97,7 +97,7 @@ int  crc_ctx_table(const crc_ctx *ctx, const char *name, uint64_t *h_out, int ca
  * "conv1_pass_bytes", "limb_pack_group", "mac2_cfg", "mac_order", "mac_regstage", "ntt_inv61_loose", "ntt_split", "mfma_min_steps", "f64_radix", "relin_mac_ct",
  * "relin_path" (1: key switching over the coefficient moduli, as the reference does it, instead of over two fp64 primes), "sq_path" (1: the square's auxiliary base is SEAL's 61-bit
  * one instead of the engine's fp64 primes; 2: force the latter), "sq_chunk" (ciphertexts per internal pass of square + relinearise; changes crc_square_relin_work_bytes),
- * "sq_fuse" (0: an NTT-resident square lifts to its auxiliary base in a kernel of its own instead of inside the forward transforms).
+ * "sq_fuse" (1: an NTT-resident square lifts to its auxiliary base inside the forward transforms, 0: in a kernel of its own, -1: by the number of moduli).
  * Every path gives the same ciphertexts.  CRC_ERR_NOT_FOUND for anything else. */
 int  crc_ctx_set_tuning(crc_ctx *ctx, const char *name, long long value);
 

@@ -20,6 +20,19 @@ int main()
                       // Below 52 bits fold_constant must refuse them (three folds no longer reach [0, 2q)) and the generic Barrett path must be exact
                       0xffffe80001ULL, 0xffffc40001ULL, 0x1fffff980001ULL, 0xfffffff00001ULL, 0x3ffffffb80001ULL, 0x3fffffec80001ULL, 0x7ffffff9c0001ULL,
                       0xffffffff00001ULL, 0xfffffffe40001ULL, 0x1fffffffd80001ULL};
+    // known answers the reference's authors wrote down (SEAL 2.3.1 SEALTest/util/uintarithsmallmod.cpp:143-213: BarrettReduce128, MultiplyUIntUIntSmallMod), on
+    // the product's barrett128 / mulmod -- data only; tests/test_seal_known_answers.py replays them on the oracle
+    {
+        const u64 ALL = ~0ULL, M62 = 4611686018427289601ULL;
+        const u64 br[][4] = {{0, 0, 2, 0}, {1, 0, 2, 1}, {ALL, ALL, 2, 1}, {0, 0, 3, 0}, {1, 0, 3, 1}, {123, 456, 3, 0}, {ALL, ALL, 3, 0}, {0, 0, 13131313131313ULL, 0},
+                             {1, 0, 13131313131313ULL, 1}, {123, 456, 13131313131313ULL, 8722750765283ULL}, {24242424242424ULL, 79797979797979ULL, 13131313131313ULL, 1010101010101ULL}};
+        for (auto &v : br) { const ModParams m = make(v[2], true); if (barrett128(v[0], v[1], m) != v[3]) { printf("SEALTest BarrettReduce128 vector failed: mod %llu\n", (unsigned long long)v[2]); return 1; } }
+        const u64 mm[][4] = {{0, 0, 2, 0}, {0, 1, 2, 0}, {1, 0, 2, 0}, {1, 1, 2, 1}, {0, 0, 10, 0}, {0, 1, 10, 0}, {1, 0, 10, 0}, {1, 1, 10, 1}, {7, 7, 10, 9}, {6, 7, 10, 2}, {7, 6, 10, 2},
+                             {0, 0, M62, 0}, {0, 1, M62, 0}, {1, 0, M62, 0}, {1, 1, M62, 1}, {2305843009213644800ULL, 2305843009213644801ULL, M62, 1152921504606822400ULL},
+                             {2305843009213644801ULL, 2305843009213644800ULL, M62, 1152921504606822400ULL}, {2305843009213644801ULL, 2305843009213644801ULL, M62, 3458764513820467201ULL},
+                             {4611686018427289600ULL, 4611686018427289600ULL, M62, 1}};
+        for (auto &v : mm) { const ModParams m = make(v[2], true); if (mulmod(v[0], v[1], m) != v[3]) { printf("SEALTest MultiplyUIntUIntSmallMod vector failed: mod %llu\n", (unsigned long long)v[2]); return 1; } }
+    }
     u64 x = 88172645463325252ULL; auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
     long checked = 0;
     for (u64 q : qs) for (int fold = 0; fold < 2; fold++) {

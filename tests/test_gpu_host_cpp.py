@@ -138,6 +138,13 @@ def test_cpp_example_driver():
         lines = [l for l in out.split("\n") if l.startswith("OUTPUT:")]
         assert len(lines) == 2 and all(l.endswith("Success") for l in lines), out
         assert "SUMMARY: 2 of 2" in out
+    # the reference's T_REENC column (mainparams.cpp:81; the refresh of network.cpp:29-37): in front of the layer it precedes, and a positive time
+    out = subprocess.check_output([exe, "PlainModelTiny", h5, os.path.join(d, "images.f32"), "4096", str(1 << 32), "1", "0", "4"], text=True)
+    head = [l for l in out.split("\n") if l.startswith("INDEX_IMG")][0].split(",")
+    assert head[1:8] == ["T_LAYER_0", "T_LAYER_1", "T_LAYER_2", "T_LAYER_3", "T_REENC", "T_LAYER_4", "T_LAYER_5"], head
+    line = [l for l in out.split("\n") if l.startswith("OUTPUT:")][0]
+    cols = line.split(",")
+    assert line.endswith("Success") and float(cols[5]) > 0.0, line
 
 
 def test_cpp_crcnn_files_interchange_with_the_reference():

@@ -223,12 +223,6 @@ def test_relinearise_over_fp64_primes_equals_reference_arithmetic(n, k, cnt):
         E.square_relin(d_x, cnt + 2, d_evk, d_y, d_w, in_form=ca.NTT, out_form=ca.NTT)
         assert np.array_equal(E.download(d_y, x.shape), res[(1, ca.NTT, ca.NTT)]), ("radix", radix, "forms")
     E.set_tuning("f64_radix", 0)
-    # 512-thread workgroups for the kernels that keep a row in registers (tuning variant)
-    E.set_tuning("f64_hold_nt", 512)
-    d_y = E.alloc((cnt + 2) * 2 * k * n * 8)
-    E.relinearize(d_x3, cnt + 2, d_evk, d_y, d_w)
-    assert np.array_equal(E.download(d_y, (cnt + 2, 2, k, n)), outs[1]), "f64_hold_nt 512"
-    E.set_tuning("f64_hold_nt", 0)
     E.close()
 
 
@@ -300,18 +294,17 @@ def test_square_over_fp64_auxiliary_base_equals_reference_base(n, k, t, cnt):
     for key, v in res.items():
         if key[0] == 2:
             assert np.array_equal(v, res[(1,) + key[1:]]), key
-    # round 4: an NTT-resident square lifts inside its forward transforms (sq_fuse, the default) or in a kernel of its own; the kernels that keep a row in registers
-    # run 1024- or 512-thread workgroups (f64_hold_nt).  Every combination gives the reference base's ciphertexts
+    # round 4: an NTT-resident square lifts inside its forward transforms (sq_fuse 1) or in a kernel of its own (0); left to itself (-1) the engine picks by k.
+    # Every choice gives the reference base's ciphertexts, at every radix of the fp64 transforms
     E.set_tuning("sq_path", 2)
-    for fuse, hold in [(0, 0), (1, 512), (0, 512)]:
-        E.set_tuning("sq_fuse", fuse); E.set_tuning("f64_hold_nt", hold)
-        d_y = E.alloc(x.nbytes)
-        E.square_relin(d_x, N, d_evk, d_y, d_w, in_form=ca.NTT, out_form=ca.NTT)
-        assert np.array_equal(E.download(d_y, x.shape), res[(1, ca.NTT, ca.NTT)]), ("sq_fuse", fuse, "f64_hold_nt", hold)
-        d_y3 = E.alloc(N * 3 * k * n * 8)
-        E.square(d_x, N, d_y3, d_w)
-        assert np.array_equal(E.download(d_y3, (N, 3, k, n)), outs[1]), ("square", "f64_hold_nt", hold)
-    E.set_tuning("sq_fuse", 1); E.set_tuning("f64_hold_nt", 0)
+    for fuse in (0, 1):
+        E.set_tuning("sq_fuse", fuse)
+        for radix in (0, 4):
+            E.set_tuning("f64_radix", radix)
+            d_y = E.alloc(x.nbytes)
+            E.square_relin(d_x, N, d_evk, d_y, d_w, in_form=ca.NTT, out_form=ca.NTT)
+            assert np.array_equal(E.download(d_y, x.shape), res[(1, ca.NTT, ca.NTT)]), ("sq_fuse", fuse, "radix", radix)
+    E.set_tuning("sq_fuse", -1); E.set_tuning("f64_radix", 0)
     E.close()
 
 
