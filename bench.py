@@ -149,6 +149,21 @@ def plain_forward(model, W, img):
     return x.reshape(-1)
 
 
+def limb_exec_over_useful(kind, a, images, out_cts):
+    """executed / useful int8 work of a layer on the limb GEMM (kernels_mfma.hip): rows = (image, pixel, poly) padded to 64-row tiles, the reduction to 32-term steps
+    (an odd number of steps to even) -- per (tap, 32-channel block), or, for layers of fewer than 32 channels (the flat form), per 32-byte piece of a window row's
+    (ky, channel) run with the channels rounded up to 4 -- and the filters to 32-filter tiles.  ApproxPlainModel's conv2 (20 channels, 3 x 3, 50 filters): 6 steps of
+    32 for 180 terms since round 4 (was 10)."""
+    zd, xf, yf, nf = (a["zd"], a["xf"], a["yf"], a["nf"]) if kind == "conv" else (a["in_dim"], 1, 1, a["out_dim"])
+    rows = images * (out_cts // nf) * 2
+    if zd < 32:
+        zdc = -(-zd // 4) * 4
+        ksteps = xf * -(-(yf * zdc) // 32)
+    else:
+        ksteps = -(-zd // 32) * xf * yf
+    return (-(-rows // 64) * 64 / rows) * ((ksteps + (ksteps & 1)) * 32 / (zd * xf * yf)) * (-(-nf // 32) * 32 / nf)
+
+
 def host_cores():
     """CPU cores this process may really use: scheduler affinity capped by the cgroup CPU quota (a GPU box gives one GPU's
     share of the host, not all of its hardware threads)"""
@@ -690,12 +705,8 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
             # the matrix-core kernel is bound by the int8 MFMA rate, not by HBM: 49 limb products (98 int8 operations) per modular multiply-add, against the dense
             # int8 peak (2x the bf16 rate per clock: MI355X_MICROARCH.md, matrix cores).  The HBM view of the same launch stays beside it
             tops = modmul_s * 98 / 1e12
-            # executed = what the matrix cores really multiply: rows padded to 64-row tiles, channels to 32 per reduction step (an odd number of steps to even),
-            # filters to 32-filter tiles; useful = the layer's own multiply-adds (ApproxPlainModel's conv2: 20 of 32 channels, 50 of 64 filters, 9 of 10 steps)
-            gz = (a["zd"], a["xf"] * a["yf"], a["nf"]) if kind == "conv" else (a["in_dim"], 1, a["out_dim"])
-            rows_l = CL * (out_cts // gz[2]) * 2
-            ksteps = -(-gz[0] // 32) * gz[1]
-            exec_over_useful = (-(-rows_l // 64) * 64 / rows_l) * ((ksteps + (ksteps & 1)) * 32 / (gz[0] * gz[1])) * (-(-gz[2] // 32) * 32 / gz[2])
+            # executed = what the matrix cores really multiply (limb_exec_over_useful); useful = the layer's own multiply-adds
+            exec_over_useful = limb_exec_over_useful(kind, a, CL, out_cts)
             roofline = dict(bound="mfma", achieved=round(tops * exec_over_useful, 1), peak=INT8_PEAK_TOPS, unit="TOP/s (int8)", frac=round(tops * exec_over_useful / INT8_PEAK_TOPS, 5),
                             useful_achieved=round(tops, 1), useful_frac=round(tops / INT8_PEAK_TOPS, 5), traffic=traffic,
                             ops="int8 multiply and add, 98 per modular multiply-add (7 x 7 balanced base-256 limb products); useful = the layer's ct x pt multiply-adds x 2 polys x k n, "
@@ -731,6 +742,8 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
                                              (pl[3]["stream_kernel"] + ", streamed weights (coefficient-form plaintexts lifted + transformed a filter tile at a time)" if pl[3].get("streamed") else
                                               "mac3_kernel (v_mad_u64_u32, CRC_NTTP)") +
                                              (f" [{pl[3]['limb_skipped']}]" if pl[3].get("limb_skipped") else "")) for pl in net.plan if pl[0] in ("conv", "fc")},
+            "mfma_useful_frac_per_layer": {pl[1]: round(1.0 / limb_exec_over_useful(pl[0], pl[2], C * G if li >= net.split else C, int(np.prod(pl[5]))), 4)
+                                           for li, pl in enumerate(net.plan) if pl[0] in ("conv", "fc") and pl[3].get("w_form") == ca.NTTL},
             "reference_layer_structure": unfused, "roofline": roofline, "cpu_baseline": cpu,
             "check": {"tiled_outputs_identical": bool(ok_tile), "predictions_match_plain_model": f"{preds_ok}/{D}", "max_logit_abs_err": round(max_err, 6),
                       "noise_budget_bits": budgets, "ranks_verified": f"{ranks_ok}/{world}", "golden_match": gold_ok, "golden": gold_name, "c1_images_match_reference": c1_ok, "all_ok": bool(all_ok)},
@@ -814,7 +827,7 @@ def main():
             second, ok2 = run_config(args, D_, nm, 1 if nm.startswith("wopad") else args.also_steps, 0, batch=b2, full=False)
             ok = ok and ok2
             if line is not None:
-                line.setdefault("also", []).append({k_: second[k_] for k_ in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "config", "data", "ms_per_layer", "mac_kernel_per_layer",
+                line.setdefault("also", []).append({k_: second[k_] for k_ in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "config", "data", "ms_per_layer", "mac_kernel_per_layer", "mfma_useful_frac_per_layer",
                                                                               "roofline", "cpu_baseline", "check", "setup_s", "weight_broadcast", "weight_bytes")})
     if line is not None:
         print(json.dumps(line), flush=True)

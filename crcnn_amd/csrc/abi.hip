@@ -95,21 +95,21 @@ extern "C" size_t crc_conv2d_work_bytes(const crc_ctx *c, int B, int zd, int xd,
 extern "C" int crc_limb_supported(const crc_ctx *c, int zd, int xf, int yf)
 {
     if (!c || zd < 1 || xf < 1 || yf < 1) return 0;
-    return k_limb_supported(c, ((zd + 31) / 32) * 32 * xf * yf) ? 1 : 0;
+    return k_limb_supported(c, k_limb_steps(zd, xf, yf) * 32) ? 1 : 0;
 }
 extern "C" size_t crc_limb_tensor_bytes(const crc_ctx *c, int B, int zd, int xd, int yd) { return c ? k_limb_tensor_bytes(c, B, zd, xd * yd) : 0; }
-extern "C" size_t crc_limb_weights_bytes(const crc_ctx *c, int nf, int zd, int xf, int yf) { return c ? k_limb_weights_bytes(c, nf, zd, xf * yf) : 0; }
+extern "C" size_t crc_limb_weights_bytes(const crc_ctx *c, int nf, int zd, int xf, int yf) { return c ? k_limb_weights_bytes(c, nf, zd, xf, yf) : 0; }
 extern "C" int crc_limb_pack_weights(crc_ctx *c, const uint64_t *d_w_ntt, int nf, int zd, int xf, int yf, void *d_wl, void *stream)
 {
     CHECK_CTX(c); if (!d_w_ntt || !d_wl || nf < 1 || zd < 1 || xf < 1 || yf < 1) return CRC_ERR_INVALID_ARGUMENT;
     if (!crc_limb_supported(c, zd, xf, yf)) return CRC_ERR_UNSUPPORTED;
-    return k_limb_pack_weights(c, d_w_ntt, (signed char *)d_wl, nf, zd, xf * yf, S(stream));
+    return k_limb_pack_weights(c, d_w_ntt, (signed char *)d_wl, nf, zd, xf, yf, S(stream));
 }
 extern "C" int crc_limb_pack_weights_tile(crc_ctx *c, const uint64_t *d_w_tile_ntt, int nf, int f0, int ft, int zd, int xf, int yf, void *d_wl, void *stream)
 {
     CHECK_CTX(c); if (!d_w_tile_ntt || !d_wl || nf < 1 || zd < 1 || xf < 1 || yf < 1 || f0 < 0 || ft < 1 || f0 + ft > nf) return CRC_ERR_INVALID_ARGUMENT;
     if (!crc_limb_supported(c, zd, xf, yf)) return CRC_ERR_UNSUPPORTED;
-    return k_limb_pack_weights(c, d_w_tile_ntt, (signed char *)d_wl, nf, zd, xf * yf, S(stream), f0, ft);
+    return k_limb_pack_weights(c, d_w_tile_ntt, (signed char *)d_wl, nf, zd, xf, yf, S(stream), f0, ft);
 }
 extern "C" int crc_limb_pack_tensor(crc_ctx *c, const uint64_t *d_x, int in_form, int B, int zd, int xd, int yd, void *d_xl, void *stream)
 {

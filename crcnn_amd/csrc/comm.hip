@@ -153,7 +153,10 @@ extern "C" int crc_checksum64(crc_ctx *c, const uint64_t *d_words, size_t words,
     if (!c || c->device < 0 || !h_out || (!d_words && words)) return CRC_ERR_INVALID_ARGUMENT;
     GUARD(c->device);                                    // the kernel and the copies below belong to THIS context's GPU, whatever the thread's current device is
     hipStream_t st = (hipStream_t)stream;
-    u64 *acc = c->d_scratch;                       // context scratch: one checksum at a time per context
+    // the two accumulator words live in the context's scratch: 256 slots handed out round robin, so that checksums issued from several host threads (each on its
+    // own stream) neither share accumulators nor wait for one another; a slot comes round again after 255 other calls, each of which has synchronised its stream
+    const unsigned slot = c->scratch_next.fetch_add(1, std::memory_order_relaxed) & 255u;
+    u64 *acc = c->d_scratch + 2 * slot;
     HIPCHK(hipMemsetAsync(acc, 0, 16, st));
     if (words) {
         size_t blocks = (words + 255) / 256; if (blocks > 4096) blocks = 4096;

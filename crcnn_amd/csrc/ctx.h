@@ -5,6 +5,7 @@
 // MI355X-first: one flat table set in HBM, indexed by "modulus index" mi (0..k-1 = q_i, k..k+kb-1 = Bsk_j).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -143,7 +144,8 @@ struct crc_ctx {
     Sq64Params *d_sq64 = nullptr;
     double *d_f64_rp = nullptr, *d_f64_irp = nullptr;   // [nf64][n]: bit-reversed powers of psi_m (centred residues) forward; of psi_m^-1 inverse
     u64 *d_zero = nullptr;                   // 4 KiB of zeros (source row of reduction terms past T in mac3_kernel) + 4 KiB context scratch
-    u64 *d_scratch = nullptr;                // = d_zero + 512 words (crc_checksum64 accumulators)
+    u64 *d_scratch = nullptr;                // = d_zero + 512 words: 256 two-word accumulator slots of crc_checksum64
+    std::atomic<unsigned> scratch_next{0};
     int cus = 256;                           // compute units of THIS context's device
     // kernels whose dynamic-LDS limit has been raised on this context's device (hipFuncSetAttribute is a driver call: once, not per launch)
     std::mutex attr_mu;

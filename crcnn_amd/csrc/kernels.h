@@ -49,10 +49,12 @@ int k_encrypt(crc_ctx *c, const u64 *pk, const u64 *plain, size_t cnt, const Cha
 // kernels_mfma.hip: conv / dense multiply-accumulate as an int8 limb GEMM on the matrix cores (operand form CRC_NTTL)
 bool   k_limb_supported(const crc_ctx *c, int T);
 size_t k_limb_tensor_bytes(const crc_ctx *c, int B, int zd, int npos);
-size_t k_limb_weights_bytes(const crc_ctx *c, int nf, int zd, int taps);
+size_t k_limb_weights_bytes(const crc_ctx *c, int nf, int zd, int xf, int yf);
+int    k_limb_flat_zdc(int zd);                        // channel bytes per position of the flat form (layers of fewer than 32 channels), 0: blocked form
+int    k_limb_steps(int zd, int xf, int yf);           // 32-term reduction steps of a layer
 size_t k_limb_result_words(const crc_ctx *c, int B, int nf, int P);
 int k_limb_pack_tensor(crc_ctx *c, const u64 *x, signed char *xl, int B, int zd, int npos, bool packed, hipStream_t st, int Btot = 0, int b0 = 0);
-int k_limb_pack_weights(crc_ctx *c, const u64 *w, signed char *wl, int nf, int zd, int taps, hipStream_t st, int f0 = 0, int ft = -1);
+int k_limb_pack_weights(crc_ctx *c, const u64 *w, signed char *wl, int nf, int zd, int xf, int yf, hipStream_t st, int f0 = 0, int ft = -1);
 int k_limb_result_to_rows(crc_ctx *c, const u64 *ys, u64 *y, size_t rows, bool pack_out, hipStream_t st);
 int k_limb_result_to_limb(crc_ctx *c, const u64 *ys, signed char *xl, int B, int zd, hipStream_t st);
 bool k_limb_direct_dense(int P);

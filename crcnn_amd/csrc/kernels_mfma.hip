@@ -18,6 +18,13 @@
 //                 (channel-innermost rows 1 KiB apart filled a quarter of every cache line the LDS-DMA touched: fc3 ran 20 % below the convolution's rate)
 //     weights  Wl [slot][reduction step = (tap, 32-channel block)][7 planes][Fp][32]   int8, Fp = filters rounded up to 64 (zero padded), an odd number of
 //                 steps rounded up to even with a zero step; every weight times 2^64 mod q
+//     FLAT form (round 4; layers of fewer than 32 channels, CrCNN's second convolution has 20): padding every tap's channels to 32 made such a layer's GEMM 20/32
+//                 useful work at best (ApproxPlainModel's conv2: 10 steps for 180 terms, 44 % with the filter padding).  There the tensor is
+//                 Xl [slot][B][7 planes][2 polys][positions][zdc], zdc = channels rounded up to 4: for one window row kx the (ky, channel) terms of an output pixel are
+//                 yf zdc CONTIGUOUS bytes, and the reduction runs over that flattened run in 32-byte steps -- step = (kx, 32-byte piece of the run), S = ceil(yf zdc / 32)
+//                 steps per window row (3 x 20 = 60 bytes: 2 steps per row, 6 instead of 10 for that layer).  The piece that sticks out of the run reads the next
+//                 position's bytes and meets zero weights.  Weights: same container, steps in that order.  The LDS-DMA pieces are then only 4-byte aligned in memory
+//                 (tools/lds_dma_unaligned.hip).  limb_flat() is the one rule every producer and consumer asks.
 //     result   Ys [slot][B][F][P][2] u64 canonical (internal), then transposed to the slot-minor tensor layout or re-limbed for a dense consumer
 // Workgroup = one slot, 64 rows x 64 filters: 4 waves (one per SIMD), a 32 x 32 tile = 2 x 2 sub-tiles x 13 diagonals x 4 int32 accumulators (208 AGPRs) each.
 // Per 32-term reduction step the workgroup stages 64 x 32 B x 7 planes of A -- implicit im2col: each lane's LDS-DMA piece reads its own (pixel + tap) address, no
@@ -39,6 +46,7 @@ struct MfmaArgs {
     i8 *xl_out; int lp2; unsigned zdp_out;             // direct limb result for a dense consumer (2P = 2^lp2 divides 64): [slot][B][7][2][zdp_out], channel = f P + p
     int n, k, B, zdp, npos, yd, xs, ys_, yf, yo, P, F, Fp, zblks, ksteps, M, mtiles, ntiles;      // ksteps: rounded up to even (the weights carry a zero step)
     unsigned img_bytes; unsigned long long wslot_bytes; int ksteps_real;
+    int flat, S, zdc; unsigned fplane;                 // flat form: S steps per window row, zdc channel bytes per position, fplane = 2 npos zdc bytes per plane
     int acc0[8][13];                                   // initial value of the 13 diagonal accumulators, per modulus (limb_tables)
     u64 qinv[8];                                       // q^-1 mod 2^64
 };
@@ -82,7 +90,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             const int b = mm / (2 * a.P), p = (mm >> 1) % a.P, c = mm & 1;
             const int ox = p / a.yo, oy = p % a.yo;
             src_off[j] = a.npos == 1 ? (u32)(plane * a.zblks * (2 * a.B) + mm) * 32 + half * 16        // dense input: K-blocked rows (mm = image * 2 + poly)
-                                     : (u32)b * a.img_bytes + (u32)(plane * (a.npos * 2 * a.zdp) + (((ox * a.xs) * a.yd + oy * a.ys_) * 2 + c) * a.zdp + half * 16);
+                       : a.flat ? (u32)b * a.img_bytes + (u32)(plane * a.fplane + (c * a.npos + (ox * a.xs) * a.yd + oy * a.ys_) * a.zdc + half * 16)
+                                : (u32)b * a.img_bytes + (u32)(plane * (a.npos * 2 * a.zdp) + (((ox * a.xs) * a.yd + oy * a.ys_) * 2 + c) * a.zdp + half * 16);
         } else src_off[j] = (u32)(((pc - 14) >> 1) * (a.Fp * 32) + ((pc - 14) & 1) * 1024 + lane * 16);
     }
     const int kreal = a.ksteps_real;
@@ -90,7 +99,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         const int ka = min(ks, kreal - 1);                        // the padding step multiplies by zero weights: any valid rows will do
         const int tap = ka / a.zblks, zb = ka - tap * a.zblks;
         const int kx = tap / a.yf, ky = tap - kx * a.yf;
-        const u32 delta = a.npos == 1 ? (u32)zb * (2 * a.B) * 32 : (u32)((kx * a.yd + ky) * 2 * a.zdp + zb * 32);
+        const int fkx = ka / a.S;                                    // flat form: window row, piece of its run
+        const u32 delta = a.npos == 1 ? (u32)zb * (2 * a.B) * 32 : a.flat ? (u32)(fkx * a.yd * a.zdc + (ka - fkx * a.S) * 32) : (u32)((kx * a.yd + ky) * 2 * a.zdp + zb * 32);
         i8 *dst = lds + (ks % NST) * (2 * TILE_B);
         const i8 *wt = ws + (size_t)ks * (NPL * a.Fp * 32);
 #pragma unroll
@@ -234,14 +244,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         const int b = mm / (2 * a.P), p = (mm >> 1) % a.P, c = mm & 1;
         const int ox = p / a.yo, oy = p % a.yo;
         src_off[j] = a.npos == 1 ? (u32)(plane * a.zblks * (2 * a.B) + mm) * 32 + half * 16
-                                 : (u32)b * a.img_bytes + (u32)(plane * (a.npos * 2 * a.zdp) + (((ox * a.xs) * a.yd + oy * a.ys_) * 2 + c) * a.zdp + half * 16);
+                   : a.flat ? (u32)b * a.img_bytes + (u32)(plane * a.fplane + (c * a.npos + (ox * a.xs) * a.yd + oy * a.ys_) * a.zdc + half * 16)
+                            : (u32)b * a.img_bytes + (u32)(plane * (a.npos * 2 * a.zdp) + (((ox * a.xs) * a.yd + oy * a.ys_) * 2 + c) * a.zdp + half * 16);
     }
     const int kreal = a.ksteps_real;
     auto issue_a = [&](int ks) {
         const int ka = min(ks, kreal - 1);
         const int tap = ka / a.zblks, zb = ka - tap * a.zblks;
         const int kx = tap / a.yf, ky = tap - kx * a.yf;
-        const u32 delta = a.npos == 1 ? (u32)zb * (2 * a.B) * 32 : (u32)((kx * a.yd + ky) * 2 * a.zdp + zb * 32);
+        const int fkx = ka / a.S;                                    // flat form: window row, piece of its run
+        const u32 delta = a.npos == 1 ? (u32)zb * (2 * a.B) * 32 : a.flat ? (u32)(fkx * a.yd * a.zdc + (ka - fkx * a.S) * 32) : (u32)((kx * a.yd + ky) * 2 * a.zdp + zb * 32);
         i8 *dst = lds + (ks % NST) * TILE_A;
 #pragma unroll
         for (int j = 0; j < 4; j++)
@@ -354,7 +366,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 // LDS transpose with 64 slots per workgroup here and dropped it -- 48.1 vs 46.4 ms; what it lacked was occupancy, see limb_pack_weights_kernel.)
 // (Btot, b0: the B images are images b0 .. b0 + B of a tensor of Btot -- a group of chunks assembling one dense layer's input; Btot = B, b0 = 0 otherwise)
 __global__ void __launch_bounds__(64) limb_pack_tensor_kernel(const u64 *x, i8 *xl, const ModParams *mods, int n, int k, int B, int zd, int zdp, int npos, int packed, int group,
-                                                              int Btot, int b0)
+                                                              int Btot, int b0, int flat_zdc, unsigned flat_img)
 {
     const int sblocks = n / 64;
     const int sb = blockIdx.x % (sblocks * k), i = sb / sblocks, s = (sb % sblocks) * 64 + threadIdx.x;
@@ -383,6 +395,16 @@ __global__ void __launch_bounds__(64) limb_pack_tensor_kernel(const u64 *x, i8 *
 #pragma unroll
                 for (int l = 0; l < NPL; l++) pl[l][z >> 2] |= (u32)(d[l] & 0xff) << (8 * (z & 3));
             }
+        }
+        if (flat_zdc) {                 // flat form (fewer than 32 channels): [plane][poly][position][zdc], zdc bytes per piece, 4-byte aligned
+            i8 *dstf = xl + (((size_t)i * n + s) * Btot + b0 + b) * (size_t)flat_img + ((size_t)c * npos + pos) * flat_zdc;
+#pragma unroll
+            for (int l = 0; l < NPL; l++) {
+                u32 *o = reinterpret_cast<u32 *>(dstf + (size_t)l * 2 * npos * flat_zdc);
+#pragma unroll
+                for (int wv = 0; wv < 8; wv++) if (wv * 4 < flat_zdc) o[wv] = pl[l][wv];
+            }
+            continue;
         }
         // one position (a dense layer's input): K-blocked [plane][channel block][row = image * 2 + poly][32]
         i8 *dst = npos == 1 ? xl + ((size_t)i * n + s) * ((size_t)NPL * 2 * Btot * zdp) + ((size_t)zb * (2 * Btot) + (b0 + b) * 2 + c) * 32
@@ -454,16 +476,17 @@ __global__ void __launch_bounds__(256) limb_pack_dense_kernel(const u64 *x, i8 *
 // (32 slots per workgroup: 28 KiB of staging, five workgroups per CU -- the loads of one overlap the digit arithmetic and the stores of the others; with 64 slots and two
 // workgroups per CU loads, arithmetic and stores ran one after the other: 8 + 8 + 11 ms of a 27-ms call.)  Fz >= F: filters F .. Fz-1 are written as zeros (the filter
 // padding of the layer's last tile), so nothing has to be cleared beforehand
-__global__ void __launch_bounds__(256) limb_pack_weights_kernel(const u64 *w, i8 *wl, const ModParams *mods, int n, int k, int F, int Fz, int Fp, int zd, int zblks, int taps, int f0)
+__global__ void __launch_bounds__(256) limb_pack_weights_kernel(const u64 *w, i8 *wl, const ModParams *mods, int n, int k, int F, int Fz, int Fp, int zd, int zblks, int xf, int yf, int f0,
+                                                                int flat_zdc, int S)
 {
     __shared__ __attribute__((aligned(16))) i8 st[WSL * NPL * WFG * 32];         // [slot][plane][filter of the group][32 channels]
-    const int sblocks = n / WSL;
+    const int sblocks = n / WSL, taps = xf * yf, steps = flat_zdc ? xf * S : taps * zblks;
     const int sb = blockIdx.x % (sblocks * k), i = sb / sblocks, s0 = (sb % sblocks) * WSL;
-    size_t r = blockIdx.x / (sblocks * k);                       // (fg*taps + tap)*zblks + zb, fg = group of WFG filters
-    const int zb = (int)(r % zblks); r /= zblks; const int tap = (int)(r % taps); const int fg = (int)(r / taps);
+    size_t r = blockIdx.x / (sblocks * k);                       // fg * steps + step, fg = group of WFG filters
+    const int step = (int)(r % steps); const int fg = (int)(r / steps);
     const ModParams m = mods[i];
     const u64 R = barrett128(0, 1, m);                           // 2^64 mod q: the factor the kernel's Montgomery reduction divides out
-    const int lane = threadIdx.x & (WSL - 1), fq = (threadIdx.x >> 5) & (WFG - 1), h = threadIdx.x >> 7, f = fg * WFG + fq;      // thread = (slot, filter, 16-channel half)
+    const int lane = threadIdx.x & (WSL - 1), fq = (threadIdx.x >> 5) & (WFG - 1), h = threadIdx.x >> 7, f = fg * WFG + fq;      // thread = (slot, filter, 16-term half of the step)
     {
         u32 pl[NPL][4];
 #pragma unroll
@@ -471,15 +494,22 @@ __global__ void __launch_bounds__(256) limb_pack_weights_kernel(const u64 *w, i8
 #pragma unroll
             for (int wv = 0; wv < 4; wv++) pl[l][wv] = 0;
         if (f < F) {
-            const u64 *src = w + ((((size_t)f * zd + (size_t)zb * 32 + h * 16) * taps + tap) * k + i) * (size_t)n + s0 + lane;
+            // term e = 16 h + z of the step  ->  (tap, channel).  Blocked form: step = (tap, 32-channel block).  Flat form: step = (window row kx, 32-byte piece of the
+            // row's run of (ky, channel) terms, zdc bytes per ky); bytes past yf zdc and the channel padding are zero weights
+            int tap, ch, ky = 0, kx = 0;
+            if (flat_zdc) { kx = step / S; const int j0 = (step - kx * S) * 32 + h * 16; ky = j0 / flat_zdc; ch = j0 - ky * flat_zdc; tap = kx * yf + ky; }
+            else { tap = step / zblks; ch = (step - tap * zblks) * 32 + h * 16; }
 #pragma unroll
-            for (int z = 0; z < 16; z++)
-                if (zb * 32 + h * 16 + z < zd) {
-                    const u64 v = mulmod(src[(size_t)z * taps * k * n], R, m);
+            for (int z = 0; z < 16; z++) {
+                if (ch < zd && (!flat_zdc || ky < yf)) {
+                    const u64 v = mulmod(w[((((size_t)f * zd + ch) * taps + tap) * k + i) * (size_t)n + s0 + lane], R, m);
                     int d[NPL]; limb_digits(v, m.q, d);
 #pragma unroll
                     for (int l = 0; l < NPL; l++) pl[l][z >> 2] |= (u32)(d[l] & 0xff) << (8 * (z & 3));
                 }
+                ch++;
+                if (flat_zdc && ch == flat_zdc) { ch = 0; ky++; tap++; }
+            }
         }
         i8 *sp = st + (size_t)lane * (NPL * WFG * 32) + fq * 32 + h * 16;
 #pragma unroll
@@ -488,11 +518,11 @@ __global__ void __launch_bounds__(256) limb_pack_weights_kernel(const u64 *w, i8
     __syncthreads();
     // WSL slots x 7 planes runs of WFG * 32 bytes, 16 bytes per lane: eight adjacent lanes write one run (filters past Fz of a ragged last group are not stored)
     const int pieces_per_run = WFG * 2, filters_here = min(WFG, Fz - fg * WFG);
-    const size_t slot_stride = (size_t)((taps * zblks + 1) & ~1) * NPL * Fp * 32;
+    const size_t slot_stride = (size_t)((steps + 1) & ~1) * NPL * Fp * 32;
     for (int o = threadIdx.x; o < WSL * NPL * pieces_per_run; o += 256) {
         const int run = o / pieces_per_run, part = o - run * pieces_per_run, sl = run / NPL, l = run - sl * NPL;
         if ((part >> 1) >= filters_here) continue;
-        i8 *dst = wl + ((size_t)i * n + s0 + sl) * slot_stride + ((size_t)tap * zblks + zb) * (NPL * Fp * 32) + (size_t)l * Fp * 32 + (size_t)(f0 + fg * WFG) * 32 + part * 16;
+        i8 *dst = wl + ((size_t)i * n + s0 + sl) * slot_stride + (size_t)step * (NPL * Fp * 32) + (size_t)l * Fp * 32 + (size_t)(f0 + fg * WFG) * 32 + part * 16;
         *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(st + (size_t)run * (WFG * 32) + part * 16);
     }
 }
@@ -546,21 +576,32 @@ __global__ void __launch_bounds__(256) slotmajor_to_limb_kernel(const u64 *ys, i
     for (int l = 0; l < NPL; l++) *reinterpret_cast<uint4 *>(dst + (size_t)l * (zdp / 32) * (2 * B) * 32) = make_uint4(pl[l][0], pl[l][1], pl[l][2], pl[l][3]);
 }
 
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+int k_limb_flat_zdc(int zd);
 static void limb_tables(const crc_ctx *c, int T, int (*acc0)[13], u64 *qinv)      // limbred.h: accumulator biases and q^-1 mod 2^64 per modulus
 {
     for (int i = 0; i < c->k; i++) { limb_bias_table(c->tabs[i].m.q, T, acc0[i]); qinv[i] = inverse_mod_2_64(c->tabs[i].m.q); }
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------------------------------
-static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 bool k_limb_supported(const crc_ctx *c, int T)
 {
     if (c->n < 64 || T > 18000) return false;
     for (int i = 0; i < c->k; i++) if (c->tabs[i].m.bits > 55) return false;          // 7 balanced bytes hold |r'| < 2^54
     return true;
 }
-size_t k_limb_tensor_bytes(const crc_ctx *c, int B, int zd, int npos) { return (size_t)c->n * c->k * B * NPL * npos * 2 * round_up(zd, 32); }
-size_t k_limb_weights_bytes(const crc_ctx *c, int nf, int zd, int taps) { return (size_t)c->n * c->k * round_up(taps * (round_up(zd, 32) / 32), 2) * NPL * round_up(nf, 64) * 32; }      // (an odd number of reduction steps gets a zero step)
+// the flat form (header): layers of fewer than 32 channels.  zdc = channel bytes per position; a dense layer (one position) keeps its K-blocked tensor, its one
+// reduction step is the same bytes either way
+int k_limb_flat_zdc(int zd) { return zd < 32 ? round_up(zd, 4) : 0; }
+int k_limb_steps(int zd, int xf, int yf) { const int zdc = k_limb_flat_zdc(zd); return zdc ? xf * ((yf * zdc + 31) / 32) : xf * yf * (round_up(zd, 32) / 32); }
+// bytes of one image of a convolution's limb tensor (npos > 1)
+static size_t limb_img_bytes(int zd, int npos) { const int zdc = k_limb_flat_zdc(zd); return zdc ? (size_t)round_up(NPL * 2 * npos * zdc, 16) : (size_t)NPL * npos * 2 * round_up(zd, 32); }
+size_t k_limb_tensor_bytes(const crc_ctx *c, int B, int zd, int npos)
+{
+    if (npos == 1) return (size_t)c->n * c->k * B * NPL * 2 * round_up(zd, 32);
+    return (size_t)c->n * c->k * B * limb_img_bytes(zd, npos) + 64;                     // (+ 64: the last 32-byte piece of a flat run may read past the last position)
+}
+size_t k_limb_weights_bytes(const crc_ctx *c, int nf, int zd, int xf, int yf) { return (size_t)c->n * c->k * round_up(k_limb_steps(zd, xf, yf), 2) * NPL * round_up(nf, 64) * 32; }      // (an odd number of reduction steps gets a zero step)
 size_t k_limb_result_words(const crc_ctx *c, int B, int nf, int P) { return (size_t)c->n * c->k * B * nf * P * 2; }
 
 int k_limb_pack_tensor(crc_ctx *c, const u64 *x, i8 *xl, int B, int zd, int npos, bool packed, hipStream_t st, int Btot, int b0)
@@ -583,24 +624,26 @@ int k_limb_pack_tensor(crc_ctx *c, const u64 *x, i8 *xl, int B, int zd, int npos
     const size_t blocks = (size_t)(c->n / 64) * c->k * ((items + group - 1) / group);
     if (blocks == 0) return CRC_OK;
     if (blocks > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(limb_pack_tensor_kernel, dim3((unsigned)blocks), dim3(64), 0, st, x, xl, c->d_mods, c->n, c->k, B, zd, zdp, npos, packed ? 1 : 0, group, Btot, b0);
+    const int fz = npos > 1 ? k_limb_flat_zdc(zd) : 0;
+    hipLaunchKernelGGL(limb_pack_tensor_kernel, dim3((unsigned)blocks), dim3(64), 0, st, x, xl, c->d_mods, c->n, c->k, B, zd, zdp, npos, packed ? 1 : 0, group, Btot, b0, fz,
+                       (unsigned)limb_img_bytes(zd, npos));
     HIPCHK(hipGetLastError());
     return CRC_OK;
 }
 // w: filters f0 .. f0 + ft of the layer's nf (ft = nf, f0 = 0: the whole layer); the padding of Wl is zeroed when the first tile (f0 = 0) is packed
-int k_limb_pack_weights(crc_ctx *c, const u64 *w, i8 *wl, int nf, int zd, int taps, hipStream_t st, int f0, int ft)
+int k_limb_pack_weights(crc_ctx *c, const u64 *w, i8 *wl, int nf, int zd, int xf, int yf, hipStream_t st, int f0, int ft)
 {
     if (ft < 0) ft = nf;
     if (f0 < 0 || ft < 1 || f0 + ft > nf) return CRC_ERR_INVALID_ARGUMENT;
-    const int zblks = round_up(zd, 32) / 32, Fp = round_up(nf, 64);
-    // the kernel writes every channel of every filter it is given, zeros for the channel padding; the call that holds the layer's last filter also writes the filter
+    const int zblks = round_up(zd, 32) / 32, Fp = round_up(nf, 64), zdc = k_limb_flat_zdc(zd), S = zdc ? (yf * zdc + 31) / 32 : 0;
+    // the kernel writes every term of every step of every filter it is given, zeros for the padding; the call that holds the layer's last filter also writes the filter
     // padding up to Fp as zeros.  What no call writes is the zero step that evens out an odd number of reduction steps: cleared with the first tile
-    const size_t step = (size_t)NPL * Fp * 32, steps = (size_t)taps * zblks, slot = (size_t)round_up((int)steps, 2) * step;
+    const size_t step = (size_t)NPL * Fp * 32, steps = (size_t)k_limb_steps(zd, xf, yf), slot = (size_t)round_up((int)steps, 2) * step;
     if (f0 == 0 && (steps & 1)) HIPCHK(hipMemset2DAsync(wl + steps * step, slot, 0, step, (size_t)c->n * c->k, st));
     const int fz = f0 + ft == nf ? Fp - f0 : ft;
-    const size_t blocks = (size_t)(c->n / WSL) * c->k * ((fz + WFG - 1) / WFG) * taps * zblks;
+    const size_t blocks = (size_t)(c->n / WSL) * c->k * ((fz + WFG - 1) / WFG) * steps;
     if (blocks > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(limb_pack_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, wl, c->d_mods, c->n, c->k, ft, fz, Fp, zd, zblks, taps, f0);
+    hipLaunchKernelGGL(limb_pack_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, wl, c->d_mods, c->n, c->k, ft, fz, Fp, zd, zblks, xf, yf, f0, zdc, S);
     HIPCHK(hipGetLastError());
     return CRC_OK;
 }
@@ -633,9 +676,10 @@ int k_limb_mac(crc_ctx *c, const i8 *xl, const i8 *wl, u64 *ys, i8 *xl_out, cons
     a.xl = xl; a.wl = wl; a.ys = ys; a.mods = c->d_mods; a.bias = bias_ntt;
     a.xl_out = nullptr; a.lp2 = -1; a.zdp_out = 0; a.mfast = 0;
     a.n = c->n; a.k = c->k; a.B = B; a.zdp = round_up(zd, 32); a.npos = xd * yd; a.yd = yd; a.xs = xs; a.ys_ = ys_; a.yf = yf; a.yo = yo; a.P = xo * yo;
-    a.F = nf; a.Fp = round_up(nf, 64); a.zblks = a.zdp / 32; a.ksteps_real = xf * yf * a.zblks; a.M = B * a.P * 2;
+    a.F = nf; a.Fp = round_up(nf, 64); a.zblks = a.zdp / 32; a.ksteps_real = k_limb_steps(zd, xf, yf); a.M = B * a.P * 2;
     a.mtiles = (a.M + 63) / 64; a.ntiles = a.Fp / 64;
-    const size_t img = (size_t)NPL * a.npos * 2 * a.zdp;
+    a.zdc = a.npos > 1 ? k_limb_flat_zdc(zd) : 0; a.flat = a.zdc ? 1 : 0; a.S = a.zdc ? (yf * a.zdc + 31) / 32 : 1; a.fplane = (unsigned)(2 * a.npos * a.zdc);
+    const size_t img = a.npos == 1 ? (size_t)NPL * 2 * a.zdp : limb_img_bytes(zd, a.npos);
     if (img * B > 0xffffffffULL || !k_limb_supported(c, a.ksteps_real * 32)) return CRC_ERR_UNSUPPORTED;
     if (xl_out) {
         if (!k_limb_direct_dense(a.P)) return CRC_ERR_INVALID_ARGUMENT;

@@ -29,7 +29,8 @@ struct Conv1Args {
     const i8 *xr; const i8 *wl; u64 *ys; i8 *xl_out; const ModParams *mods; const u64 *bias;
     int n, k, B, Bout, b0, xd, yo, xs, ystr, P, F, mtiles;   // B images in this launch; the limb result is image b0 + b of Bout
     unsigned img_stride, plane_bytes, poly_bytes;      // per (slot, image): 7 planes x 2 polys x xd rows x 32 bytes (+ 8: the last window may read past its row), rounded up to 1 KiB
-    unsigned out_img_bytes;                            // 7 * P * 2 * 32 (limb output)
+    unsigned out_img_bytes;                            // limb output, bytes per image: 7 * P * 2 * 32, or the flat form's 7 * 2 * P * zdc rounded up to 16 (kernels_mfma.hip)
+    int out_zdc;                                       // flat form (fewer than 32 filters = channels of the next convolution): channel bytes per position, else 0
     int acc0[MAXK][13];                                // initial value of the 13 diagonal accumulators, per modulus (conv1_tables)
     u64 qinv[MAXK];                                    // q^-1 mod 2^64
 };
@@ -70,6 +71,8 @@ __global__ void __launch_bounds__(1024) mfma_conv1_kernel(Conv1Args a)
         for (int pc = wave; pc < pieces; pc += nwaves)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + pc * 1024), (__attribute__((address_space(3))) void *)(dst + pc * 1024), 16, 0, 0);
     };
+    // (flat limb result: the bytes between the last position and the image's 16-byte end leave with every image -- zero, like the tensor the pack kernel makes)
+    if (a.xl_out && a.out_zdc && threadIdx.x < 16) { const unsigned e = a.out_img_bytes - 16 + threadIdx.x; if (e >= (unsigned)(NPL * 2 * a.P * a.out_zdc)) stage[e] = 0; }
     issue_img(0);
     for (int b = 0; b < a.B; b++) {
         __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));    // this wave's pieces of image b have landed (and its stores of image b-1's staging copy have left) ...
@@ -109,11 +112,19 @@ __global__ void __launch_bounds__(1024) mfma_conv1_kernel(Conv1Args a)
                 // rows alternate poly 0 / poly 1 (16 | tile base, 4 | lane base): the bias joins poly 0.  One pass from the diagonals to the centred representative
                 const long long cv = (reg & 1) == 0 ? diag_reduce_short_centred<true>(D, q, qinv, bvc) : diag_reduce_short_centred<false>(D, q, qinv, 0);
                 if (mm < 2 * a.P) {
-                    if (a.xl_out) {               // limb tensor of the next convolution: [plane][pixel][poly][32 channels], channels past F stay zero
+                    if (a.xl_out) {               // limb tensor of the next convolution, channels past F stay zero: staged in LDS as the byte image that leaves
                         const u64 dg = col < a.F ? centred_digit_bytes(cv) : 0;     // the seven balanced digits, one per byte
-                        i8 *sp = stage + mm * (NPL * 32) + col;            // staged [row][plane][32 channels]: the seven stores share one address
+                        if (a.out_zdc) {          // flat form [plane][poly][pixel][zdc]
+                            if (col < a.out_zdc) {
+                                i8 *sp = stage + ((mm & 1) * a.P + (mm >> 1)) * a.out_zdc + col;
 #pragma unroll
-                        for (int l = 0; l < NPL; l++) sp[l * 32] = (i8)(dg >> (8 * l));
+                                for (int l = 0; l < NPL; l++) sp[l * (2 * a.P * a.out_zdc)] = (i8)(dg >> (8 * l));
+                            }
+                        } else {
+                            i8 *sp = stage + mm * (NPL * 32) + col;            // staged [row][plane][32 channels]: the seven stores share one address
+#pragma unroll
+                            for (int l = 0; l < NPL; l++) sp[l * 32] = (i8)(dg >> (8 * l));
+                        }
                     } else if (col < a.F)
                         a.ys[(((size_t)slot * a.B + b) * a.F + col) * (2 * a.P) + mm] = (u64)(cv + ((cv >> 63) & (long long)q));       // canonical
                 }
@@ -122,10 +133,15 @@ __global__ void __launch_bounds__(1024) mfma_conv1_kernel(Conv1Args a)
         if (a.xl_out) {
             __syncthreads();
             i8 *dst = a.xl_out + ((size_t)slot * a.Bout + a.b0 + b) * a.out_img_bytes;
-            const unsigned per_plane = a.out_img_bytes / (NPL * 16);      // 16-byte pieces of one plane: (row, half)
-            for (unsigned o = threadIdx.x; o < NPL * per_plane; o += blockDim.x) {
-                const unsigned l = o / per_plane, rem = o - l * per_plane;
-                *reinterpret_cast<uint4 *>(dst + (size_t)o * 16) = *reinterpret_cast<const uint4 *>(stage + (rem >> 1) * (NPL * 32) + l * 32 + (rem & 1) * 16);
+            if (a.out_zdc) {              // the staging area IS the image's byte layout
+                for (unsigned o = threadIdx.x; o < a.out_img_bytes / 16; o += blockDim.x)
+                    *reinterpret_cast<uint4 *>(dst + (size_t)o * 16) = *reinterpret_cast<const uint4 *>(stage + (size_t)o * 16);
+            } else {
+                const unsigned per_plane = a.out_img_bytes / (NPL * 16);      // 16-byte pieces of one plane: (row, half)
+                for (unsigned o = threadIdx.x; o < NPL * per_plane; o += blockDim.x) {
+                    const unsigned l = o / per_plane, rem = o - l * per_plane;
+                    *reinterpret_cast<uint4 *>(dst + (size_t)o * 16) = *reinterpret_cast<const uint4 *>(stage + (rem >> 1) * (NPL * 32) + l * 32 + (rem & 1) * 16);
+                }
             }
         }
     }
@@ -211,7 +227,7 @@ bool k_limb_conv1_shape(const crc_ctx *c, int zd, int xd, int yd, int xs, int ys
     // the epilogue's bounds (conv1_tables): a Montgomery quotient in (-q, 2^51.6] needs q > 2^52; 7 balanced digits with |top digit| <= 64 need q < 2^55
     for (int i = 0; i < c->k; i++) if (c->tabs[i].m.bits > 55 || c->tabs[i].m.bits < 53) return false;
     const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys_ + 1;
-    // two image buffers + the staging area of a limb result must fit the 160 KiB of LDS
+    // two image buffers + the staging area of a limb result (at most 32 channel bytes per position) must fit the 160 KiB of LDS
     return 2 * (size_t)conv1_img_stride(xd) + (size_t)NPL * xo * yo * 2 * 32 <= 160 * 1024;
 }
 size_t k_limb_conv1_weights_bytes(const crc_ctx *c) { return (size_t)c->n * c->k * NPL * 32 * 64; }
@@ -242,7 +258,8 @@ int k_limb_conv1(crc_ctx *c, const u64 *x, bool packed, i8 *xr, const i8 *wl, u6
     a.xr = xr; a.wl = wl; a.ys = ys; a.xl_out = xl_out; a.mods = c->d_mods; a.bias = bias_ntt;
     a.n = c->n; a.k = c->k; a.B = B; a.Bout = Bout; a.b0 = b0; a.xd = xd; a.yo = yo; a.xs = xs; a.ystr = ys_; a.P = xo * yo; a.F = nf; a.mtiles = (2 * a.P + 15) / 16;
     a.poly_bytes = (unsigned)xd * 32; a.plane_bytes = 2 * a.poly_bytes; a.img_stride = conv1_img_stride(xd);
-    a.out_img_bytes = (unsigned)(NPL * a.P * 2 * 32);
+    a.out_zdc = a.P > 1 ? k_limb_flat_zdc(nf) : 0;            // (the limb tensor of the convolution behind: its layout follows ITS channel count = this layer's filters)
+    a.out_img_bytes = a.out_zdc ? (unsigned)((NPL * 2 * a.P * a.out_zdc + 15) / 16 * 16) : (unsigned)(NPL * a.P * 2 * 32);
     conv1_tables(c, a);
     {
         const size_t blocks = (size_t)(c->n / RSL) * c->k * B * 2 * ((xd + RG - 1) / RG);

@@ -462,6 +462,15 @@ void ConvolutionalLayer::upload()
     filters_already_ntt = true;            // transform_kernel_to_ntt, convolutionalLayer.cpp:151-156 (done once)
 }
 int ConvolutionalLayer::placement() { upload(); return streamed ? 1 : 0; }
+void ConvolutionalLayer::restoreCanonical()
+{
+    if (w_form == CRC_NTTP) { packWeights(true); return; }
+    if (w_form == CRC_NTTL1 && d_w_canon) { d_w = d_w_canon; d_w_canon.reset(); w_form = CRC_NTT; return; }
+    if (w_form != CRC_NTTL && w_form != CRC_NTTL1) return;
+    if ((int)filters.size() != nf) throw logic_error("ConvolutionalLayer " + name + ": a folded layer's weights are in limb form and it has no plaintexts to rebuild them from");
+    d_w.reset(); w_form = CRC_NTT; filters_already_ntt = false;
+    upload();
+}
 void ConvolutionalLayer::deviceParameters(vector<shared_ptr<DeviceBuffer>> &out, bool allocate_only)
 {
     if (allocate_only && !filters_already_ntt) {
@@ -612,6 +621,15 @@ void FullyConnectedLayer::buildTilewise()
     w_form = CRC_NTTL; tile_built = true;
 }
 int FullyConnectedLayer::placement() { upload(); return streamed ? 1 : tilewise ? 2 : 0; }
+void FullyConnectedLayer::restoreCanonical()
+{
+    if (w_form == CRC_NTTP) { packWeights(true); return; }
+    if (w_form != CRC_NTTL) return;
+    if ((int)weights.size() != out_dim) throw logic_error("FullyConnectedLayer " + name + ": weights are in limb form and there are no plaintexts to rebuild them from");
+    // (a tile-wise layer goes back to "not built": the next forward builds its limb tensor again, with whatever batch-norm layer fuse() folds into it)
+    d_w.reset(); w_form = CRC_NTT; weights_already_ntt = false; tile_built = false;
+    upload();
+}
 void FullyConnectedLayer::deviceParameters(vector<shared_ptr<DeviceBuffer>> &out, bool allocate_only)
 {
     if (allocate_only && !weights_already_ntt && forced_placement == 2) {
@@ -921,8 +939,10 @@ int Network::fuse()
     const size_t rowb = (size_t)k * n * 8;
     int removed = 0;
     for (auto &l : layers) {                                // the folding kernels work on canonical residues
-        if (auto c = dynamic_pointer_cast<ConvolutionalLayer>(l)) { if (c->w_form == CRC_NTTP) c->packWeights(true); }
-        else if (auto f = dynamic_pointer_cast<FullyConnectedLayer>(l)) { if (f->w_form == CRC_NTTP) f->packWeights(true); }
+        // (a network that has already run holds its weights in the MAC kernels' operand forms: packed residues are unpacked, matrix-core forms -- which drop the
+        // canonical copy -- are rebuilt from the layer's plaintexts, so fuse() may follow a forward())
+        if (auto c = dynamic_pointer_cast<ConvolutionalLayer>(l)) c->restoreCanonical();
+        else if (auto f = dynamic_pointer_cast<FullyConnectedLayer>(l)) f->restoreCanonical();
     }
     auto inttCopy = [&](const shared_ptr<DeviceBuffer> &ntt_rows, size_t rows) {       // coefficient-form twin of NTT-form delta rows
         auto out = make_shared<DeviceBuffer>(rows * rowb);

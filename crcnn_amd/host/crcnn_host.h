@@ -139,6 +139,7 @@ public:
     void deviceParameters(std::vector<std::shared_ptr<DeviceBuffer>> &out, bool allocate_only) override;
     int placement() override;
     void adoptPlacement(int p) override { forced_placement = p; }
+    void restoreCanonical();                                // weights back to canonical NTT form (unpacked; rebuilt from the plaintexts when the matrix-core form replaced them)
 };
 
 class FullyConnectedLayer : public Layer {                  // fullyConnectedLayer.h:22-24
@@ -175,6 +176,7 @@ public:
     void deviceParameters(std::vector<std::shared_ptr<DeviceBuffer>> &out, bool allocate_only) override;
     int placement() override;
     void adoptPlacement(int p) override { forced_placement = p; }
+    void restoreCanonical();
 };
 
 class PoolingLayer : public Layer {                         // poolingLayer.h:15

@@ -73,6 +73,36 @@ static int do_net(int argc, char **argv)
     return 0;
 }
 
+// net3 <model> <h5> <dir> <batch>: the three NTT-resident runs of tests/test_gpu_host_cpp.py's full-size cases from ONE built network (the encode + lift + NTT of
+// 10^5 .. 10^6 plaintexts is most of a case's time): Network::forward as built (one image), after Network::fuse() (one image), and fused on `batch` images.
+// Writes out_unfused.u64, out_fused.u64, out_fused_batch.u64
+static int do_net3(int argc, char **argv)
+{
+    if (argc < 6) return 1;
+    string model = argv[2], h5 = argv[3], dir = argv[4]; const int batch = atoi(argv[5]);
+    setup(dir);
+    ifstream evf(dir + "/evk.u64", ios::binary);
+    if (evf) {
+        auto evk = rd(dir + "/evk.u64");
+        ev_keys16 = make_shared<DeviceBuffer>(evk.size() * 8);
+        crc_memcpy_h2d(context, ev_keys16->ptr, evk.data(), evk.size() * 8, nullptr); crc_stream_sync(context, nullptr);
+    }
+    CnnBuilder builder(h5);
+    Network net = builder.buildNetworkByName(model);
+    net.ntt_resident = true;
+    auto x = rd(dir + "/net_in.u64");
+    const ciphertext3D one = ciphertext3D::fromHost(x.data(), 1, 1, 28, 28);
+    // (the unfused run leaves the weights in the matrix-core forms; Network::fuse() rebuilds the canonical ones from the plaintexts before it folds)
+    { ciphertext3D out = net.forward(one); wr(dir + "/out_unfused.u64", out.toHost()); }
+    const int removed = net.fuse();
+    fprintf(stderr, "fused: %d layers removed, %d left\n", removed, net.getNumLayers());
+    { ciphertext3D out = net.forward(one); wr(dir + "/out_fused.u64", out.toHost()); }
+    vector<ciphertext3D> imgs(batch, one);
+    { ciphertext3D out = net.forward(stackImages(imgs)); wr(dir + "/out_fused_batch.u64", out.toHost()); }
+    delParameters();
+    return 0;
+}
+
 static vector<double> rdf(const string &p)
 {
     ifstream f(p, ios::binary); if (!f) { fprintf(stderr, "missing %s\n", p.c_str()); exit(2); }
@@ -256,6 +286,7 @@ int main(int argc, char **argv)
     if (argc < 2) return 1;
     try {
         if (!strcmp(argv[1], "net")) return do_net(argc, argv);
+        if (!strcmp(argv[1], "net3")) return do_net3(argc, argv);
         if (!strcmp(argv[1], "api")) return do_api(argc, argv);
         if (!strcmp(argv[1], "files")) return do_files(argc, argv);
         if (!strcmp(argv[1], "searchlogic")) return do_searchlogic(argc, argv);

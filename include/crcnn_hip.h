@@ -19,9 +19,14 @@
  *   - all functions return 0 on success or a negative crc_status; nothing throws across the ABI.  The reference
  *     signals errors by C++ exceptions (std::invalid_argument, evaluator.cpp:1549-1556) -- the C++ host classes turn a
  *     non-zero status back into std::invalid_argument / std::runtime_error.
- *   - a context is immutable after creation and may be used from several host threads; every launch goes to the HIP
- *     stream passed in (`stream` is a hipStream_t cast to void*, NULL = default stream).  No entry point allocates,
- *     frees or synchronises unless its name says so; scratch memory is passed in (`d_work`, sized by *_work_bytes).
+ *   - a context is immutable after creation (crc_ctx_set_tuning excepted: tools and tests only, on a context nobody is launching on) and may be used
+ *     from several host threads at once, provided every concurrent call has its own stream and its own `d_work`: every launch goes to the HIP
+ *     stream passed in (`stream` is a hipStream_t cast to void*, NULL = default stream), no entry point keeps state between calls, and the one
+ *     piece of context scratch (crc_checksum64's accumulators) is handed out per call (tests/test_gpu_threads.py: two host threads, two streams,
+ *     a convolution on one and square + relinearise on the other, both against the reference's goldens).  No entry point allocates, frees or
+ *     synchronises unless its name says so; scratch memory is passed in (`d_work`, sized by *_work_bytes).  The C++ host classes
+ *     (crcnn_amd/host/crcnn_host.h) are NOT thread-safe: like the reference they keep the context, the keys and a work buffer in globals
+ *     (CrCNN/src/globals.h:18-26) and launch on the default stream.
  */
 #ifndef CRCNN_HIP_H
 #define CRCNN_HIP_H

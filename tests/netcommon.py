@@ -18,8 +18,21 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+_INPUTS = {}
+
+
 def make_inputs(g):
-    """regenerate keys + the encrypted synthetic image exactly as oracle/make_golden_nets.py did"""
+    """regenerate keys + the encrypted synthetic image exactly as oracle/make_golden_nets.py did (cached per golden input: the CPU-side key generation and the 784
+    encryptions take seconds at n = 16384, and every test of a parameter set -- layer-wise, NTT-resident, the C++ classes -- starts from the same input)"""
+    key = (g["n"], tuple(g["q"]), g["t"], g["input_sha256"])
+    if key not in _INPUTS:
+        if len(_INPUTS) >= 6:
+            _INPUTS.pop(next(iter(_INPUTS)))
+        _INPUTS[key] = _make_inputs(g)
+    return _INPUTS[key]
+
+
+def _make_inputs(g):
     O = orc.Oracle(g["n"], g["q"], g["t"])
     img = orc.normalize(orc.synth_image(g["image_index"]))
     if g.get("input_gen") == "engine":

@@ -88,21 +88,41 @@ def test_cpp_plain_modulus_search():
 FULL = [n for n in ["tiny4096_t32", "approx8192_t42", "wopad16384_t44"] if os.path.exists(os.path.join(GOLD, f"net_{n}.json"))]
 
 
+_FULL_RUNS = {}
+
+
+def full_size_outputs(name):
+    """the three NTT-resident runs of one full-size model from ONE built network (test_host net3): building it -- 10^5..10^6 plaintexts encoded on the CPU, lifted and
+    transformed -- is most of a case's time, so the cases of a model share the driver process (round 3 built the network once per case: 130 s of the GPU suite)"""
+    if name not in _FULL_RUNS:
+        g = load_net_golden(name)
+        O, sk, pk, evk, img, x = make_inputs(g)
+        d = tempfile.mkdtemp()
+        np.array([g["n"], len(g["q"]), g["t"]] + g["q"], dtype=np.uint64).tofile(os.path.join(d, "params.u64"))
+        evk.tofile(os.path.join(d, "evk.u64")); x.tofile(os.path.join(d, "net_in.u64"))
+        h5 = os.path.join(GOLD, "models", g["model"] + ".h5")
+        batch = 6 if name.startswith("wopad16384") else 16      # 202 GiB of weights leave room for six images' activations (bench.py's chunk for this configuration)
+        subprocess.check_call([DRIVER, "net3", g["model"], h5, d, str(batch)])
+        outs = {}
+        for key, fn, b in [("unfused", "out_unfused.u64", 1), ("fused", "out_fused.u64", 1), ("fused-batch16", "out_fused_batch.u64", batch)]:
+            outs[key] = np.fromfile(os.path.join(d, fn), dtype=np.uint64).reshape(b, -1)
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+        _FULL_RUNS[name] = (g, outs)
+    return _FULL_RUNS[name]
+
+
 @pytest.mark.parametrize("name", FULL)
-@pytest.mark.parametrize("fuse,batch", [(False, 1), (True, 1), (True, 16)], ids=["unfused", "fused", "fused-batch16"])
-def test_cpp_network_full_size_equals_reference(name, fuse, batch):
+@pytest.mark.parametrize("case", ["unfused", "fused", "fused-batch16"])
+def test_cpp_network_full_size_equals_reference(name, case):
     """the drop-in itself (C++ Layer / Network / CnnBuilder) at the BASELINE ring sizes and the plain moduli bench.py runs at:
-    CnnBuilder reads the real model, Network::forward (NTT-resident, with and without Network::fuse) must produce the compiled
-    reference's output ciphertexts bit for bit.  Batch 16 gives a dense layer 32 rows = (image, poly): the C++ classes' dense limb path (a batch-1 dense layer
-    stays on the vector-ALU kernel) and the limb hand-overs conv -> dense, dense -> dense are golden-checked at BASELINE sizes too"""
-    if batch > 1 and name.startswith("wopad16384"):
-        batch = 6                   # 202 GiB of weights leave room for six images' activations (bench.py's chunk for this configuration)
-    g, O, d = run_driver(name, resident=True, batch=batch, fuse=fuse)
-    out = np.fromfile(os.path.join(d, "out.u64"), dtype=np.uint64).reshape(batch, -1)
-    for b in range(batch):
-        assert sha(out[b]) == g["out_sha256"], (name, b)
-    import shutil
-    shutil.rmtree(d, ignore_errors=True)
+    CnnBuilder reads the real model, Network::forward (NTT-resident, before and after Network::fuse -- which here follows a forward, so it rebuilds the canonical weights
+    from the plaintexts) must produce the compiled reference's output ciphertexts bit for bit.  Batch 16 gives a dense layer 32 rows = (image, poly): the C++ classes'
+    dense limb path (a batch-1 dense layer stays on the vector-ALU kernel) and the limb hand-overs conv -> dense, dense -> dense are golden-checked at BASELINE sizes too"""
+    g, outs = full_size_outputs(name)
+    out = outs[case]
+    for b in range(out.shape[0]):
+        assert sha(out[b]) == g["out_sha256"], (name, case, b)
 
 
 @pytest.mark.parametrize("name", ["tiny256", "approx256", "wopad256"])
