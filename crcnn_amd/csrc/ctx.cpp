@@ -518,6 +518,18 @@ extern "C" int crc_memcpy_d2h(crc_ctx *c, void *h, const void *d, size_t b, void
 extern "C" int crc_memcpy_d2d(crc_ctx *c, void *d, const void *s0, size_t b, void *s) { (void)c; HIPCHK(hipMemcpyAsync(d, s0, b, hipMemcpyDeviceToDevice, (hipStream_t)s)); return CRC_OK; }
 extern "C" int crc_memset(crc_ctx *c, void *d, int v, size_t b, void *s) { (void)c; HIPCHK(hipMemsetAsync(d, v, b, (hipStream_t)s)); return CRC_OK; }
 extern "C" int crc_stream_sync(crc_ctx *c, void *s) { (void)c; HIPCHK(hipStreamSynchronize((hipStream_t)s)); return CRC_OK; }
+// HIP events for hosts that do not link HIP themselves (the C++ host classes time their layers with them: on the stream the kernels are launched on, no
+// synchronisation between layers)
+extern "C" int crc_event_create(crc_ctx *c, void **ev) { if (!c || !ev || c->device < 0) return CRC_ERR_INVALID_ARGUMENT; hipEvent_t e; HIPCHK(hipEventCreate(&e)); *ev = (void *)e; return CRC_OK; }
+extern "C" int crc_event_destroy(crc_ctx *c, void *ev) { (void)c; if (!ev) return CRC_OK; HIPCHK(hipEventDestroy((hipEvent_t)ev)); return CRC_OK; }
+extern "C" int crc_event_record(crc_ctx *c, void *ev, void *s) { (void)c; if (!ev) return CRC_ERR_INVALID_ARGUMENT; HIPCHK(hipEventRecord((hipEvent_t)ev, (hipStream_t)s)); return CRC_OK; }
+extern "C" int crc_event_elapsed_ms(crc_ctx *c, void *ev0, void *ev1, float *ms)
+{
+    (void)c; if (!ev0 || !ev1 || !ms) return CRC_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipEventSynchronize((hipEvent_t)ev1));
+    HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)ev0, (hipEvent_t)ev1));
+    return CRC_OK;
+}
 
 extern "C" int crc_import_seal(const crc_ctx *c, const uint64_t *seal, int size, uint64_t *out)
 {

@@ -461,6 +461,15 @@ void ConvolutionalLayer::upload()
     d_b[0] = uploadPlain(b, 1); d_b[1] = uploadPlain(b, 2);
     filters_already_ntt = true;            // transform_kernel_to_ntt, convolutionalLayer.cpp:151-156 (done once)
 }
+static size_t bytesOf(const shared_ptr<DeviceBuffer> &b) { return b ? b->bytes : 0; }
+static string macKernelName(int w_form, bool streamed)
+{
+    const string k = w_form == CRC_NTTL ? "mfma_mac2w_kernel (int8 limb GEMM, CRC_NTTL)" : w_form == CRC_NTTL1 ? "mfma_conv1_kernel (one-channel convolution on the matrix cores, CRC_NTTL1)"
+                   : w_form == CRC_NTTP ? "mac3_kernel (v_mad_u64_u32, CRC_NTTP)" : "mac3_kernel (v_mad_u64_u32, canonical residues)";
+    return streamed ? k + ", streamed weights" : k;
+}
+size_t ConvolutionalLayer::deviceBytes() const { return bytesOf(d_w) + bytesOf(d_b[0]) + bytesOf(d_b[1]) + bytesOf(d_plain) + bytesOf(d_wtile) + bytesOf(d_ytile) + bytesOf(d_w_canon); }
+string ConvolutionalLayer::kernelName() const { return macKernelName(w_form, streamed); }
 int ConvolutionalLayer::placement() { upload(); return streamed ? 1 : 0; }
 void ConvolutionalLayer::restoreCanonical()
 {
@@ -620,6 +629,8 @@ void FullyConnectedLayer::buildTilewise()
     }
     w_form = CRC_NTTL; tile_built = true;
 }
+size_t FullyConnectedLayer::deviceBytes() const { return bytesOf(d_w) + bytesOf(d_b[0]) + bytesOf(d_b[1]) + bytesOf(d_plain) + bytesOf(d_wtile) + bytesOf(d_ytile); }
+string FullyConnectedLayer::kernelName() const { return macKernelName(w_form, streamed) + (tilewise ? ", limb weights built tile by tile" : ""); }
 int FullyConnectedLayer::placement() { upload(); return streamed ? 1 : tilewise ? 2 : 0; }
 void FullyConnectedLayer::restoreCanonical()
 {
@@ -812,15 +823,38 @@ ciphertext3D Network::forward(ciphertext3D input)
                             : (packable && max_num_of_reencryptions < 0 && isMac(i) && isMac(i + 1) ? CRC_NTTP : CRC_NTT);
     }
     last_layer_ms.assign(L, 0.0);
+    last_layer_launches.assign(L, 0);
     last_reenc_ms = 0.0;
+    // one timed Layer::forward call: events on the launch stream (read after the last layer), or wall clock + stream synchronisation
+    vector<pair<int, pair<void *, void *>>> timed;
+    size_t ev_used = 0;
+    if (time_with_events && !event_pool) event_pool = make_shared<EventPool>();
+    auto next_event = [&]() { auto &ev = event_pool->ev; if (ev_used == ev.size()) { void *e = nullptr; chk(crc_event_create(ctx(), &e), "crc_event_create"); ev.push_back(e); } return ev[ev_used++]; };
+    auto run_layer = [&](int i, const ciphertext3D &in) {
+        last_layer_launches[i]++;
+        if (time_with_events) {
+            void *e0 = next_event(), *e1 = next_event();
+            chk(crc_event_record(ctx(), e0, nullptr), "crc_event_record");
+            ciphertext3D out = layers[i]->forward(in);
+            chk(crc_event_record(ctx(), e1, nullptr), "crc_event_record");
+            timed.push_back({i, {e0, e1}});
+            return out;
+        }
+        auto t0 = chrono::high_resolution_clock::now();
+        ciphertext3D out = layers[i]->forward(in);
+        chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+        last_layer_ms[i] += chrono::duration<double, milli>(chrono::high_resolution_clock::now() - t0).count();
+        return out;
+    };
+    auto read_events = [&]() {
+        for (auto &t : timed) { float ms = 0; chk(crc_event_elapsed_ms(ctx(), t.second.first, t.second.second, &ms), "crc_event_elapsed_ms"); last_layer_ms[t.first] += ms; }
+        timed.clear();
+    };
     if (max_num_of_reencryptions >= 0) {                    // network.cpp:52-96
         int refreshes_left = max_num_of_reencryptions;
         for (int i = 0; i < L; i++) {
             layers[i]->out_form = CRC_COEFF;
-            auto t0 = chrono::high_resolution_clock::now();
-            ciphertext3D output = layers[i]->forward(input);
-            chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
-            last_layer_ms[i] += chrono::duration<double, milli>(chrono::high_resolution_clock::now() - t0).count();
+            ciphertext3D output = run_layer(i, input);
             if (noiseBudget(output) <= 5) {
                 if (refreshes_left <= 0) throw OutOfBudgetException(i - 1);
                 auto r0 = chrono::high_resolution_clock::now();
@@ -835,6 +869,7 @@ ciphertext3D Network::forward(ciphertext3D input)
             }
             input = output;
         }
+        read_events();
         return input;
     }
     int first = 0;
@@ -844,12 +879,7 @@ ciphertext3D Network::forward(ciphertext3D input)
         for (int b0 = 0; b0 < B; b0 += head_chunk) {
             const int Bc = min(head_chunk, B - b0);
             ciphertext3D t = input.images(b0, Bc);
-            for (int i = 0; i < split; i++) {
-                auto t0 = chrono::high_resolution_clock::now();
-                { OutHint hint(&act_slot[t.buf == act_slot[0] ? 1 : 0]); t = layers[i]->forward(t); }
-                chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
-                last_layer_ms[i] += chrono::duration<double, milli>(chrono::high_resolution_clock::now() - t0).count();
-            }
+            for (int i = 0; i < split; i++) { OutHint hint(&act_slot[t.buf == act_slot[0] ? 1 : 0]); t = run_layer(i, t); }
             const size_t out_cts = (size_t)t.zd * t.xd * t.yd;
             if (!tail_in.buf) {         // kept across calls like the activation slots: next to 182 GiB of weights the pool has no room to hold it
                 OutHint hint(&tail_slot);
@@ -873,12 +903,11 @@ ciphertext3D Network::forward(ciphertext3D input)
             chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
             last_reenc_ms += chrono::duration<double, milli>(chrono::high_resolution_clock::now() - r0).count();
         }
-        auto t0 = chrono::high_resolution_clock::now();
         // every layer but the last writes into one of the network's two activation slots (the one its input does not live in); the last layer's output -- ten
         // ciphertexts per image -- is the caller's own tensor, as in the reference
-        if (i + 1 < L) { OutHint hint(&act_slot[input.buf == act_slot[0] ? 1 : 0]); input = layers[i]->forward(input); }
+        if (i + 1 < L) { OutHint hint(&act_slot[input.buf == act_slot[0] ? 1 : 0]); input = run_layer(i, input); }
         else {
-            ciphertext3D output = layers[i]->forward(input);
+            ciphertext3D output = run_layer(i, input);
             // a last layer that hands its input back (none of CrCNN's does) must not give the caller a tensor that lives in an activation slot the next forward overwrites
             if (output.buf && (output.buf == act_slot[0] || output.buf == act_slot[1] || output.buf == tail_slot)) {
                 ciphertext3D own(output.B, output.zd, output.xd, output.yd, output.form);
@@ -887,11 +916,20 @@ ciphertext3D Network::forward(ciphertext3D input)
             }
             input = output;
         }
-        chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
-        last_layer_ms[i] = chrono::duration<double, milli>(chrono::high_resolution_clock::now() - t0).count();
     }
+    if (time_with_events) { chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync"); read_events(); }
     return input;
 }
+Network::HbmPlan Network::hbmPlan() const
+{
+    HbmPlan p;
+    for (auto &l : layers) p.parameters += l->deviceBytes();
+    p.activations = bytesOf(act_slot[0]) + bytesOf(act_slot[1]) + bytesOf(tail_slot);
+    p.work = bytesOf(g_scratch);
+    p.keys = bytesOf(ev_keys16);
+    return p;
+}
+Network::EventPool::~EventPool() { if (context) for (void *e : ev) crc_event_destroy(context, e); }
 
 size_t Network::broadcastParameters(crc_comm *comm, int root)
 {

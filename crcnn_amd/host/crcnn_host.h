@@ -104,6 +104,10 @@ public:
     // root's decision, because the buffers on the wire are sized by it
     virtual int placement() { return 0; }
     virtual void adoptPlacement(int p) { (void)p; }
+    // reporting (bench_host): bytes this layer holds in HBM right now (parameters in whatever operand form they are in, streaming tiles), and the multiply-accumulate
+    // kernel a conv / dense layer runs on ("" for the others)
+    virtual size_t deviceBytes() const { return 0; }
+    virtual std::string kernelName() const { return ""; }
 };
 
 class BatchNormLayer;
@@ -140,6 +144,8 @@ public:
     int placement() override;
     void adoptPlacement(int p) override { forced_placement = p; }
     void restoreCanonical();                                // weights back to canonical NTT form (unpacked; rebuilt from the plaintexts when the matrix-core form replaced them)
+    size_t deviceBytes() const override;
+    std::string kernelName() const override;
 };
 
 class FullyConnectedLayer : public Layer {                  // fullyConnectedLayer.h:22-24
@@ -177,6 +183,8 @@ public:
     int placement() override;
     void adoptPlacement(int p) override { forced_placement = p; }
     void restoreCanonical();
+    size_t deviceBytes() const override;
+    std::string kernelName() const override;
 };
 
 class PoolingLayer : public Layer {                         // poolingLayer.h:15
@@ -190,6 +198,8 @@ public:
     void printLayerStructure() override;
 protected:
     std::shared_ptr<DeviceBuffer> d_div;                    // NTT-form divisor (AvgPoolingLayer only)
+public:
+    size_t deviceBytes() const override { return d_div ? d_div->bytes : 0; }
 };
 
 class AvgPoolingLayer : public PoolingLayer {               // avgPoolingLayer.h:11
@@ -225,6 +235,9 @@ public:
     void printLayerStructure() override;
 private:
     std::shared_ptr<DeviceBuffer> d_mean[2], d_invstd;
+public:
+    size_t deviceBytes() const override { return (d_mean[0] ? d_mean[0]->bytes : 0) + (d_mean[1] ? d_mean[1]->bytes : 0) + (d_invstd ? d_invstd->bytes : 0); }
+private:
     void upload();
 public:
     void deviceParameters(std::vector<std::shared_ptr<DeviceBuffer>> &out, bool allocate_only) override;
@@ -247,19 +260,31 @@ public:
     int layer_before_reenc = -1;
     bool ntt_resident = true;                               // keep tensors in NTT form between linear layers (bit-identical)
     // conv / dense layers with long reductions (>= 8 steps of 32 channels) run as an int8 limb GEMM on the matrix cores (CRC_NTTL, kernels_mfma.hip):
-    // exact integer arithmetic, identical ciphertexts, about 4x the vector-ALU kernel.  The conversion of a layer's weights drops their canonical copy,
-    // so fuse() and broadcastParameters() must come before the first forward().
+    // exact integer arithmetic, identical ciphertexts, about 4x the vector-ALU kernel.  The conversion of a layer's weights drops their canonical copy:
+    // broadcastParameters() must come before the first forward(); fuse() may follow one (it rebuilds the canonical weights from the plaintexts).
     bool matrix_cores = true;
     // >= 0 selects the budget-checking forward the reference keeps for its parameter search (network.cpp:52-96): after every layer the
     // noise budget of output[0][0][0] is measured (secret key, coefficient form at every boundary); at <= 5 bits the layer's input is
     // refreshed and the layer repeated while refreshes are left, then OutOfBudgetException(i - 1) is thrown.  -1: plain forward.
     int max_num_of_reencryptions = -1;
     std::vector<double> last_layer_ms;                      // per-layer wall milliseconds of the last forward (T_LAYER_i, mainparams.cpp:81)
+    // true: last_layer_ms comes from HIP events recorded on the launch stream around every layer call -- no synchronisation between the layers, what a throughput
+    // measurement wants (crcnn_amd/host/bench_host.cpp); false: wall clock around Layer::forward + a stream synchronisation, as the reference's driver measures
+    bool time_with_events = false;
+    std::vector<int> last_layer_launches;                   // Layer::forward calls per layer in the last forward (two-level chunking: a head layer runs once per chunk)
     double last_reenc_ms = 0.0;                             // T_REENC of that line: decrypt + re-encrypt in front of layer_before_reenc (network.cpp:30-37), all refreshes of the budget-checking forward (:52-96); 0 when none ran
     // Two-level chunking (> 0): the layers in front of the first dense layer run on sub-batches of `head_chunk` images, the dense layers once on the whole batch -- a
     // dense layer streams all of its weights per launch, so its time per image falls with the rows it is used for (PlainModelWoPad at n = 16384: 6-image chunks fit
     // beside 190 GiB of weights, fc3 wants 24+ images).  0: every layer on the whole batch
     int head_chunk = 0;
+    // where this rank's HBM goes (bytes): the layers' parameters in their current operand forms, the activation slots forward() keeps, the shared work buffer, the
+    // evaluation keys
+    struct HbmPlan { size_t parameters = 0, activations = 0, work = 0, keys = 0; };
+    HbmPlan hbmPlan() const;
+private:
+    struct EventPool { std::vector<void *> ev; ~EventPool(); };
+    std::shared_ptr<EventPool> event_pool;                  // HIP events of time_with_events, reused from forward to forward (copies of a Network share them)
+public:
     std::shared_ptr<DeviceBuffer> tail_slot;                // ... and the dense layers' whole-batch input under two-level chunking
     std::shared_ptr<DeviceBuffer> act_slot[2];              // the two ping-pong activation buffers forward() keeps across calls (sized by the largest layer output so far)
     Network() {}

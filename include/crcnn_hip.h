@@ -115,6 +115,11 @@ int crc_memcpy_d2h(crc_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, v
 int crc_memcpy_d2d(crc_ctx *ctx, void *d_dst, const void *d_src, size_t bytes, void *stream);
 int crc_memset(crc_ctx *ctx, void *d_dst, int value, size_t bytes, void *stream);
 int crc_stream_sync(crc_ctx *ctx, void *stream);
+/* HIP events (hipEvent_t behind void*): record on the stream the kernels go to, read the time between two of them (waits for the second) */
+int crc_event_create(crc_ctx *ctx, void **event);
+int crc_event_destroy(crc_ctx *ctx, void *event);
+int crc_event_record(crc_ctx *ctx, void *event, void *stream);
+int crc_event_elapsed_ms(crc_ctx *ctx, void *event_start, void *event_end, float *ms);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * encoding (host)   replaces: FractionalEncoder(t, x^n+1, 64, 32, 3)::encode/decode (encoder.cpp:1013-1076,

@@ -87,14 +87,20 @@ def _run_bench(extra, env_extra=None):
 
 
 def test_bench_small_workload_matches_reference_golden():
-    """bench.py's own output ciphertexts for image 0 are, bit for bit, what the compiled reference computed from the same encrypted
-    input (tests/golden/net_tiny1024_eng.json), with and without the layer folding"""
-    line = _run_bench(["--gpus", "1", "--unfused-images", "24"])
+    """bench.py's measured path (N = 1: crcnn_amd/lib/bench_host, the C++ host classes) on the small workload: the output ciphertexts of image 0 are, bit for bit, what the
+    compiled reference computed from the same encrypted input (tests/golden/net_tiny1024_eng.json); the line carries the contract fields, the per-layer times from HIP
+    events, a roofline entry and the rank's HBM plan.  With --python-twin the same workload through netrun.py, with the reference's layer structure run unfused as well"""
+    line = _run_bench(["--gpus", "1", "--python-twin", "--unfused-images", "24"])
     c = line["check"]
     assert line["n_gpus"] == 1 and c["golden_match"] is True and c["golden"] == "net_tiny1024_eng.json" and c["all_ok"] is True
-    assert c["tiled_outputs_identical"] and c["predictions_match_plain_model"] == "4/4"
-    assert line["reference_layer_structure"]["outputs_identical_to_fused"] is True
-    assert line["roofline"]["frac"] > 0 and line["roofline"]["traffic_source"] is None
+    assert c["predictions_match_plain_model"] == "4/4"
+    assert line["config"]["host"].startswith("C++ host classes") and line["value"] > 0 and line["dtype"] == "u64" and line["vs_baseline"] is None
+    assert set(line["ms_per_layer"]) == {"pool1_features.conv1+pool1", "pool2_features.conv2+pool2", "classifier.fc3", "classifier.fc4"}
+    assert line["roofline"]["frac"] > 0 and line["roofline"]["launch_ms"] > 0 and line["roofline"]["traffic_source"] is None
+    assert line["hbm_plan"]["parameters"] > 0 and line["hbm_plan"]["total_bytes"] > line["hbm_plan"]["parameters"]
+    tw = line["python_twin"]
+    assert tw["check"]["golden_match"] is True and tw["check"]["tiled_outputs_identical"] and tw["reference_layer_structure"]["outputs_identical_to_fused"] is True
+    assert 0.5 < tw["vs_host"] < 2.0
 
 
 def test_bench_two_ranks_end_to_end_on_one_device():
@@ -105,3 +111,20 @@ def test_bench_two_ranks_end_to_end_on_one_device():
     assert c["ranks_verified"] == "2/2" and c["golden_match"] is True and c["all_ok"] is True
     b = line["weight_broadcast"]
     assert b["checksums_match"] == "2/2" and b["bytes"] > 0 and b["seconds"] > 0 and b["via"].startswith("torch.distributed (gloo)")
+
+
+def test_bench_two_ranks_over_rccl():
+    """the multi-GPU path as the driver launches it, on real RCCL: two ranks on two GPUs (`python bench.py --gpus 2`, self-launch), the encoded weights built on rank 0
+    only and broadcast by crc_broadcast_weights (ncclBroadcast through the engine's C ABI), every rank's device checksum equal to the root's, every rank's output
+    ciphertexts verified against the reference golden.  Needs two visible GPUs: skipped on the one-GPU boxes this repository is developed on (the path is rehearsed there
+    over gloo, test_bench_two_ranks_end_to_end_on_one_device)"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs at least two GPUs")
+    line = _run_bench(["--gpus", "2"], {"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    c = line["check"]
+    assert c["ranks_verified"] == "2/2" and c["golden_match"] is True and c["all_ok"] is True
+    b = line["weight_broadcast"]
+    assert b["via"].startswith("crc_broadcast_weights") and b["checksums_match"] == "2/2" and b["bytes"] > 0 and b["seconds"] > 0
+    assert line["hbm_plan"]["parameters"] > 0

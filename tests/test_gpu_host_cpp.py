@@ -57,7 +57,7 @@ def test_cpp_plain_modulus_search():
     found must have succeeded, and the plaintext labels must be those of the float model."""
     from crcnn_amd import synth
     from oracle import search_ref as ref
-    import bench
+    from benchkit.plain import plain_forward
     d = tempfile.mkdtemp()
     n, q = 4096, [0x7fffffff380001, 0x3fffffff000001]        # coeff_modulus_128(4096); the encoder needs this much room for a 6-layer net
     imgs = np.stack([synth.normalize(synth.synth_image(i)).reshape(-1) for i in range(4)]).astype(np.float32)
@@ -71,7 +71,7 @@ def test_cpp_plain_modulus_search():
     # plaintext labels = argmax of the float forward
     from crcnn_amd import binding
     W = {nm: binding.h5_read(h5, nm) for nm in binding.h5_list(h5)}
-    assert labels == [int(np.argmax(bench.plain_forward("PlainModelTiny", W, im.reshape(28, 28)))) for im in imgs]
+    assert labels == [int(np.argmax(plain_forward("PlainModelTiny", W, im.reshape(28, 28)))) for im in imgs]
     # replay the reference's control flow over the observed verdicts: same sequence of candidates, same result
     table = dict(tried)
     seen = []

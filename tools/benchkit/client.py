@@ -1,0 +1,79 @@
+"""bench.py's client side (untimed): keys, the encrypted synthetic images, and the verification of what came back -- the reference's goldens, BASELINE configs[0]'s
+32 images, decrypted logits against the plaintext model.  Everything is seeded (deterministic, NOT secure) on purpose: image 0 of rank 0 is the input of the
+reference-made golden of the configuration (configs.GOLDEN_FOR)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+
+from .configs import ENC_SEED, EVK_SEED, KEY_SEED, ROOT, golden_check
+from .plain import plain_forward
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+class Client:
+    """host-side (CPU) client of one configuration: crc_keygen / crc_gen_evk / crc_encrypt / crc_decrypt through a host-only engine context"""
+
+    def __init__(self, cfg, q, rank=0):
+        import crcnn_amd as ca
+        self.cfg, self.q, self.rank = cfg, q, rank
+        self.E = ca.Engine(cfg["n"], q, cfg["t"], device=-1)
+        self.sk, self.pk = self.E.keygen(KEY_SEED)
+        self.evk = None
+        h5 = os.path.join(ROOT, "tests", "golden", "models", cfg["model"] + ".h5")
+        self.W = {nm: ca.h5_read(h5, nm) for nm in ca.h5_list(h5) if not nm.endswith("num_batches_tracked")}
+
+    def evaluation_keys(self):
+        if self.evk is None:
+            self.evk = self.E.gen_evk(EVK_SEED, self.sk)
+        return self.evk
+
+    def images(self, D):
+        from crcnn_amd.synth import normalize, synth_image
+        return [normalize(synth_image(self.rank * 100003 + i)) for i in range(D)]
+
+    def encrypt_images(self, imgs, path, threads=1):
+        """the images' 784 ciphertexts each, written to `path` ([D][784][2][k][n] u64); returns SHA-256 of image 0's ciphertexts.  One image per host thread (the
+        calls are independent and ctypes releases the GIL: 2.7 s per image at n = 4096 on one core of the build container, 15 s at n = 16384)"""
+        from concurrent.futures import ThreadPoolExecutor
+
+        def one(i):
+            pl, _ = self.E.encode(imgs[i].reshape(-1))
+            return np.ascontiguousarray(self.E.encrypt(self.pk, pl, ENC_SEED + 1000 * i))
+        x0_sha = None
+        with open(path, "wb") as f, ThreadPoolExecutor(max_workers=max(1, min(threads, len(imgs)))) as pool:
+            for i, ct in enumerate(pool.map(one, range(len(imgs)))):
+                if i == 0:
+                    x0_sha = sha(ct)
+                f.write(ct.tobytes())
+        return x0_sha
+
+    def verify(self, cfg_name, imgs, outs, x0_sha):
+        """outs: [D][10][2][k][n] output ciphertexts of the D distinct images.  Returns the "check" dictionary of the bench line and whether everything held."""
+        E, cfg = self.E, self.cfg
+        D = len(imgs)
+        gold_ok, gold_name = golden_check(cfg_name, cfg, self.q, self.rank, x0_sha, sha(outs[0]))
+        # BASELINE configs[0] in full (tests/golden/c1_tiny4096_t32.json: 32 images through the compiled reference): this run's distinct images ARE its first images
+        c1_ok = None
+        c1_path = os.path.join(ROOT, "tests", "golden", "c1_tiny4096_t32.json")
+        if self.rank == 0 and cfg_name == "tiny4096" and os.path.exists(c1_path):
+            c1 = json.load(open(c1_path))
+            if (c1["t"], [int(v) for v in c1["q"]], c1["key_seed"], c1["enc_seed_base"], c1["enc_seed_stride"]) == (cfg["t"], [int(v) for v in self.q], KEY_SEED, ENC_SEED, 1000):
+                have = [i for i in range(D) if str(i) in c1["images"]]
+                hits = sum(1 for i in have if c1["images"][str(i)]["out_sha256"] == sha(outs[i]))
+                c1_ok = f"{hits}/{len(have)}"
+        preds_ok, budgets, max_err = 0, [], 0.0
+        for i in range(D):
+            dec = E.decrypt(self.sk, outs[i])
+            logits = np.array([E.decode(dec[j]) for j in range(10)])
+            want = plain_forward(cfg["model"], self.W, imgs[i])
+            budgets.append(E.noise_budget(self.sk, outs[i][0]))
+            max_err = max(max_err, float(np.abs(logits - want).max()))
+            preds_ok += int(np.argmax(logits) == np.argmax(want))
+        ok = bool(preds_ok == D and gold_ok is not False and (c1_ok is None or c1_ok.split("/")[0] == c1_ok.split("/")[1]))
+        return {"predictions_match_plain_model": f"{preds_ok}/{D}", "max_logit_abs_err": round(max_err, 6), "noise_budget_bits": budgets, "golden_match": gold_ok, "golden": gold_name,
+                "c1_images_match_reference": c1_ok}, ok
