@@ -289,8 +289,12 @@ int crc_seal_sk_load(const crc_ctx *ctx, const void *buf, size_t bytes, uint64_t
  * model loader (host)   replaces LoadH5::getDataVfloat (CrCNN/src/H5Easy.cpp:584-644) as used by
  *           CnnBuilder::getPretrained (cnnBuilder.cpp:20-23): flat float32 read of dataset `name` (e.g.
  *           "pool1_features.conv1.weight") from an HDF5 file written by PlainModel/ToH5.py.
- *           Built-in reader (superblock v0, contiguous little-endian float32 datasets); no libhdf5 needed.
+ *           Two readers behind these entry points: a built-in one for the files the reference ships (superblock v0, contiguous little-endian
+ *           float32 datasets; no dependency), and -- for every other layout: newer superblocks, chunked / compressed datasets, other float
+ *           types -- libhdf5 itself, the library the reference links, loaded with dlopen when the machine has it (CRC_LIBHDF5 names one;
+ *           CRC_H5_BACKEND=lite|hdf5 forces a reader).  A file neither can read gives CRC_ERR_IO.
  * ------------------------------------------------------------------------------------------------------------- */
+int crc_h5_backend_available(void);                               /* 1 when libhdf5 (>= 1.10) could be loaded */
 int crc_h5_dataset_count(const char *path, const char *name, size_t *count);
 int crc_h5_read_f32(const char *path, const char *name, float *h_out, size_t cap, size_t *count);
 int crc_h5_list(const char *path, char *h_names, size_t cap);   /* newline-separated dataset names */
