@@ -103,7 +103,7 @@ struct CrcTuning {
     int mfma_order = -1;          // CRC_MFMA_ORDER=0|1: force the tile walk order of the limb GEMM (-1: by shape)
     int mfma_variant = 2;         // CRC_MFMA_VARIANT=2: two workgroups per CU (mfma_mac2w_kernel), 1: mfma_mac_kernel
     int mfma_ring = 0;            // CRC_MFMA_RING=4|5: LDS ring slots of mfma_mac_kernel
-    int conv1_waves = 0;          // CRC_CONV1_WAVES=8|12|16
+    int conv1_waves = 0;          // CRC_CONV1_WAVES=8|12
     long long conv1_pass_bytes = 0;   // CRC_CONV1_PASS_BYTES: work-space cap per internal pass of a one-channel convolution (0: 16 GiB)
     int limb_pack_group = 1;      // CRC_LIMB_PACK_GROUP
     int mac2_cfg = 0;             // CRC_MAC2_CFG=16|8: force a tile shape (mac2_kernel)

@@ -8,10 +8,14 @@
 //             whole reduction.  The 7 weight fragments of a wave's 16 filters live in registers for the whole workgroup, and a workgroup walks ALL images of
 //             the chunk for its slot (image b+1 arrives by LDS-DMA while image b is multiplied);
 //   a cheap   the accumulators start at per-diagonal biases B_d (so every diagonal stays in [0, 2^24) and their sum is a multiple of q: no signs, no
-//   epilogue  correction term), pairs of diagonals pack into 32-bit words without carries, the 128-bit value is two word vectors added once, and a Montgomery
-//             step (weights carry the factor 2^64) replaces the 128-bit Barrett / folding reduction: ~90 VALU operations per output instead of ~340.
+//   epilogue  correction term), pairs of diagonals pack into 32-bit words without carries, the 128-bit value is two word vectors added once.  Round 4: the value is
+//             reduced by FOLDING (q = 2^b - f: three folds, 3 + 1 multiplies: limbred.h diag_fold_short_centred) instead of a Montgomery step (7 quarter-rate
+//             multiplies: 112 of ~370 issue cycles per output), and the MFMA operands are swapped -- weights as the A operand, image windows as B -- so that a lane's four
+//             accumulator registers are FOUR CONSECUTIVE FILTERS of one output row: their digit bytes transpose in registers (v_perm_b32) into one dword per limb plane,
+//             stored with 7 ds_write_b32 per four outputs instead of 28 byte stores (the byte-wise staging was most of the 23 % of CU cycles lost to LDS bank
+//             conflicts, profiles/r03_pmc_conv1_issue.json; the two polys' image blocks now sit 8 banks apart for the window reads).
 // 8 or 12 waves per workgroup (2-3 per SIMD: one wave's epilogue overlaps another's MFMAs); a wave owns 16 filters and every (waves/2)-th 16-row tile.
-//   per image   the limb image [plane][poly][row][32 columns] (12.5 KiB for 28 x 28) in LDS, double-buffered; a lane's A fragment is two 8-byte LDS reads per
+//   per image   the limb image [plane][poly][row + 1 pad][32 columns] (13 KiB for 28 x 28) in LDS, double-buffered; a lane's A fragment is two 8-byte LDS reads per
 //               plane (window rows kx, kx+1): the three words around byte offset oy * stride, byte-aligned in registers;
 //   output      either the limb tensor of a following convolution, staged in LDS and written out as one contiguous [plane][pixel][poly][32 channels] block
 //               (no limb_pack_tensor pass in front of conv2), or slot-major u64 for the generic conversions.
@@ -32,7 +36,7 @@ struct Conv1Args {
     unsigned out_img_bytes;                            // limb output, bytes per image: 7 * P * 2 * 32, or the flat form's 7 * 2 * P * zdc rounded up to 16 (kernels_mfma.hip)
     int out_zdc;                                       // flat form (fewer than 32 filters = channels of the next convolution): channel bytes per position, else 0
     int acc0[MAXK][13];                                // initial value of the 13 diagonal accumulators, per modulus (conv1_tables)
-    u64 qinv[MAXK];                                    // q^-1 mod 2^64
+    u32 qbits[MAXK], qfold[MAXK];                      // q = 2^qbits - qfold (limbred.h conv1_fold_ok)
 };
 
 // canonical residue -> 7 balanced base-256 digits of its centred representative
@@ -43,25 +47,39 @@ __device__ __forceinline__ void limb_digits1(u64 r, u64 q, int (&d)[NPL])
     for (int l = 0; l < NPL; l++) { d[l] = (int)(signed char)(v & 0xff); v = (v - d[l]) >> 8; }
 }
 
-__global__ void __launch_bounds__(1024) mfma_conv1_kernel(Conv1Args a)
+__global__ void __launch_bounds__(768) mfma_conv1_kernel(Conv1Args a)
 {
     extern __shared__ __attribute__((aligned(16))) i8 lds[];                  // [2 image buffers][output staging]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
     const int slot = blockIdx.x, i = slot / a.n, s = slot % a.n;
-    const u64 q = a.mods[i].q, qinv = a.qinv[i];
-    const int nt = wave & 1, col = nt * 16 + (lane & 15), g = lane >> 4;      // this wave's 16 filters; this lane's filter and K group (window rows 2g, 2g+1)
-    // the weight fragments of this lane's filter, resident for the whole workgroup
+    const u64 q = a.mods[i].q;
+    const u32 qbits = a.qbits[i], qfold = a.qfold[i];
+    const int nt = wave & 1, g = lane >> 4, r16 = lane & 15;
+    // operand A of the MFMA = the weights: this lane's filter nt * 16 + r16, K group g (window rows 2g, 2g+1): resident for the whole workgroup
     v4i wv[NPL];
     {
-        const i8 *ws = a.wl + (size_t)slot * (NPL * 32 * 64) + col * 64 + g * 16;
+        const i8 *ws = a.wl + (size_t)slot * (NPL * 32 * 64) + (nt * 16 + r16) * 64 + g * 16;
 #pragma unroll
         for (int l = 0; l < NPL; l++) wv[l] = *reinterpret_cast<const v4i *>(ws + l * (32 * 64));
     }
-    int acc0[13];
+    // the accumulators start at zero (an inline constant of the MFMAs); the per-diagonal biases join pair by pair in the reduction (limbred.h)
+    u32 PB[7];
 #pragma unroll
-    for (int d = 0; d < 13; d++) acc0[d] = a.acc0[i][d];
-    const u64 bv = (a.bias && col < a.F) ? a.bias[((size_t)col * a.k + i) * a.n + s] : 0;
-    const long long bvc = bv > (q >> 1) ? (long long)(bv - q) : (long long)bv;        // the bias, centred
+    for (int j = 0; j < 6; j++) PB[j] = (u32)a.acc0[i][2 * j] + ((u32)a.acc0[i][2 * j + 1] << 8);
+    PB[6] = (u32)a.acc0[i][12];
+    // output pixel -> (row, column) of the output map with one multiply: p < 1024, yo <= 32, so (p rcp) >> 16 is exact
+    const u32 rcp_yo = (65536u + (u32)a.yo - 1) / (u32)a.yo;
+    // C/D layout of a 16 x 16 tile: col = lane & 15, row = 4 (lane >> 4) + reg.  With the weights as A the ROW is the filter and the COLUMN the output row: this lane
+    // owns output row (pixel, poly) r16 of every tile and filters f0 .. f0 + 3, four consecutive channels of the next layer.  Rows alternate poly 0 / poly 1 and
+    // tiles start at multiples of 16, so a lane's poly is lane & 1 for good: the bias (poly 0 only), centred, is a per-lane constant
+    const int f0 = nt * 16 + 4 * g;
+    long long bvc[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        const int f = f0 + reg;
+        const u64 bv = (a.bias && f < a.F && !(lane & 1)) ? a.bias[((size_t)f * a.k + i) * a.n + s] : 0;
+        bvc[reg] = bv > (q >> 1) ? (long long)(bv - q) : (long long)bv;
+    }
     i8 *stage = lds + 2 * (size_t)a.img_stride;
     const i8 *ximg = a.xr + (size_t)slot * a.B * a.img_stride;
     const int pieces = a.img_stride / 1024;
@@ -74,6 +92,7 @@ __global__ void __launch_bounds__(1024) mfma_conv1_kernel(Conv1Args a)
     // (flat limb result: the bytes between the last position and the image's 16-byte end leave with every image -- zero, like the tensor the pack kernel makes)
     if (a.xl_out && a.out_zdc && threadIdx.x < 16) { const unsigned e = a.out_img_bytes - 16 + threadIdx.x; if (e >= (unsigned)(NPL * 2 * a.P * a.out_zdc)) stage[e] = 0; }
     issue_img(0);
+    const int chan_bytes = a.out_zdc ? a.out_zdc : 32;          // channel bytes per (pixel, poly) position of a limb result
     for (int b = 0; b < a.B; b++) {
         __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));    // this wave's pieces of image b have landed (and its stores of image b-1's staging copy have left) ...
         __syncthreads();                                          // ... everybody's; the other image buffer and the staging area are free
@@ -82,9 +101,9 @@ __global__ void __launch_bounds__(1024) mfma_conv1_kernel(Conv1Args a)
         for (int mt = wave >> 1; mt < a.mtiles; mt += nwaves >> 1) {
             v4i acc[13];
 #pragma unroll
-            for (int d = 0; d < 13; d++) acc[d] = v4i{acc0[d], acc0[d], acc0[d], acc0[d]};
-            // this lane's A row: output pixel p, poly c (rows past 2P re-read the last one and are never stored)
-            const int mrow = min(mt * 16 + (lane & 15), 2 * a.P - 1), p = mrow >> 1, c = mrow & 1, ox = p / a.yo, oy = p - ox * a.yo;
+            for (int d = 0; d < 13; d++) acc[d] = v4i{0, 0, 0, 0};
+            // operand B = this lane's output row: pixel p, poly c (rows past 2P re-read the last one and are never stored)
+            const int mm = mt * 16 + r16, mrow = min(mm, 2 * a.P - 1), p = mrow >> 1, c = mrow & 1, ox = (int)(((u32)p * rcp_yo) >> 16), oy = p - ox * a.yo;
             // k = 16 g + j  <->  window row kx = 2 g + (j >> 3), window column ky = j & 7: per row the three words around the window's first column, cut to its
             // 8 bytes with a byte alignment (rows clamped, and columns past the window may belong to the next row: their weights are zero)
             const int r0 = min(ox * a.xs + 2 * g, a.xd - 1), r1 = min(ox * a.xs + 2 * g + 1, a.xd - 1);
@@ -99,35 +118,43 @@ __global__ void __launch_bounds__(1024) mfma_conv1_kernel(Conv1Args a)
                 hi.x = (int)__builtin_amdgcn_alignbyte(b1, b0, sh); hi.y = (int)__builtin_amdgcn_alignbyte(b2, b1, sh);
                 const v4i av = {lo.x, lo.y, hi.x, hi.y};
 #pragma unroll
-                for (int mm = 0; mm < NPL; mm++)
-                    acc[l + mm] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, wv[mm], acc[l + mm], 0, 0, 0);
+                for (int m2 = 0; m2 < NPL; m2++)
+                    acc[l + m2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv[m2], av, acc[l + m2], 0, 0, 0);
             }
-            // epilogue: C/D layout of a 16 x 16 tile: col = lane & 15, row = 4 (lane >> 4) + reg
+            // epilogue: four consecutive filters of output row mm
+            long long cv[4];
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
-                const int mm = mt * 16 + 4 * g + reg;
                 int D[13];
 #pragma unroll
                 for (int d = 0; d < 13; d++) D[d] = acc[d][reg];
-                // rows alternate poly 0 / poly 1 (16 | tile base, 4 | lane base): the bias joins poly 0.  One pass from the diagonals to the centred representative
-                const long long cv = (reg & 1) == 0 ? diag_reduce_short_centred<true>(D, q, qinv, bvc) : diag_reduce_short_centred<false>(D, q, qinv, 0);
-                if (mm < 2 * a.P) {
-                    if (a.xl_out) {               // limb tensor of the next convolution, channels past F stay zero: staged in LDS as the byte image that leaves
-                        const u64 dg = col < a.F ? centred_digit_bytes(cv) : 0;     // the seven balanced digits, one per byte
-                        if (a.out_zdc) {          // flat form [plane][poly][pixel][zdc]
-                            if (col < a.out_zdc) {
-                                i8 *sp = stage + ((mm & 1) * a.P + (mm >> 1)) * a.out_zdc + col;
+                cv[reg] = diag_fold_short_centred(D, q, qbits, qfold, bvc[reg], PB);   // one pass from the diagonals to the centred representative, bias included
+            }
+            if (mm >= 2 * a.P) continue;
+            if (a.xl_out) {               // limb tensor of the next convolution, staged in LDS as it leaves: [row][plane][32 channels], or the flat form [plane][poly][pixel][zdc]
+                if (f0 >= chan_bytes) continue;                                      // (flat form: channel padding is a multiple of 4, this group is past it)
+                u32 lo[4], hi[4];
 #pragma unroll
-                                for (int l = 0; l < NPL; l++) sp[l * (2 * a.P * a.out_zdc)] = (i8)(dg >> (8 * l));
-                            }
-                        } else {
-                            i8 *sp = stage + mm * (NPL * 32) + col;            // staged [row][plane][32 channels]: the seven stores share one address
+                for (int reg = 0; reg < 4; reg++) { const u64 dg = f0 + reg < a.F ? centred_digit_bytes(cv[reg]) : 0; lo[reg] = (u32)dg; hi[reg] = (u32)(dg >> 32); }
+                // 4 x 7 byte transpose: dword l = digit l of the four filters (v_perm_b32: result byte = selector byte picks from {second operand: 0-3, first: 4-7})
+                const u32 t0 = __builtin_amdgcn_perm(lo[1], lo[0], 0x05010400u), t1 = __builtin_amdgcn_perm(lo[1], lo[0], 0x07030602u);
+                const u32 u0 = __builtin_amdgcn_perm(lo[3], lo[2], 0x05010400u), u1 = __builtin_amdgcn_perm(lo[3], lo[2], 0x07030602u);
+                const u32 t2 = __builtin_amdgcn_perm(hi[1], hi[0], 0x05010400u), t3 = __builtin_amdgcn_perm(hi[1], hi[0], 0x07030602u);
+                const u32 u2 = __builtin_amdgcn_perm(hi[3], hi[2], 0x05010400u), u3 = __builtin_amdgcn_perm(hi[3], hi[2], 0x07030602u);
+                u32 pl[NPL];
+                pl[0] = __builtin_amdgcn_perm(u0, t0, 0x05040100u); pl[1] = __builtin_amdgcn_perm(u0, t0, 0x07060302u);
+                pl[2] = __builtin_amdgcn_perm(u1, t1, 0x05040100u); pl[3] = __builtin_amdgcn_perm(u1, t1, 0x07060302u);
+                pl[4] = __builtin_amdgcn_perm(u2, t2, 0x05040100u); pl[5] = __builtin_amdgcn_perm(u2, t2, 0x07060302u);
+                pl[6] = __builtin_amdgcn_perm(u3, t3, 0x05040100u);
+                i8 *sp; unsigned pstride;
+                if (a.out_zdc) { sp = stage + ((mm & 1) * a.P + (mm >> 1)) * a.out_zdc + f0; pstride = 2 * a.P * a.out_zdc; }
+                else { sp = stage + mm * (NPL * 32) + f0; pstride = 32; }
 #pragma unroll
-                            for (int l = 0; l < NPL; l++) sp[l * 32] = (i8)(dg >> (8 * l));
-                        }
-                    } else if (col < a.F)
-                        a.ys[(((size_t)slot * a.B + b) * a.F + col) * (2 * a.P) + mm] = (u64)(cv + ((cv >> 63) & (long long)q));       // canonical
-                }
+                for (int l = 0; l < NPL; l++) *reinterpret_cast<u32 *>(sp + l * pstride) = pl[l];
+            } else {
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++)
+                    if (f0 + reg < a.F) a.ys[(((size_t)slot * a.B + b) * a.F + f0 + reg) * (2 * a.P) + mm] = (u64)(cv[reg] + ((cv[reg] >> 63) & (long long)q));       // canonical
             }
         }
         if (a.xl_out) {
@@ -203,8 +230,8 @@ __global__ void __launch_bounds__(256) limb_pack_rows1_kernel(const u64 *x, i8 *
         *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(st + (size_t)run * (RG * 32) + part * 16);
     }
 }
-// NTT-form weights w [F][1][xf][yf][k][n] -> Wl1 [slot][7 planes][32 filters][64 taps], tap = kx*8 + ky (pre-zeroed), each weight times 2^64 mod q (the Montgomery factor the
-// kernel's reduction divides out)
+// NTT-form weights w [F][1][xf][yf][k][n] -> Wl1 [slot][7 planes][32 filters][64 taps], tap = kx*8 + ky (pre-zeroed).  (No 2^64 factor since round 4: the kernel's reduction
+// folds, it no longer divides by 2^64.)
 __global__ void __launch_bounds__(64) limb_pack_w1_kernel(const u64 *w, i8 *wl, const ModParams *mods, int n, int k, int F, int xf, int yf)
 {
     const int sblocks = n / 64;
@@ -212,21 +239,24 @@ __global__ void __launch_bounds__(64) limb_pack_w1_kernel(const u64 *w, i8 *wl, 
     size_t r = blockIdx.x / (sblocks * k);                       // (f*xf + kx)*yf + ky
     const int ky = (int)(r % yf); r /= yf; const int kx = (int)(r % xf); const int f = (int)(r / xf);
     const ModParams m = mods[i];
-    const u64 R = barrett128(0, 1, m);                           // 2^64 mod q
-    int d[NPL]; limb_digits1(mulmod(w[((((size_t)f * xf + kx) * yf + ky) * k + i) * (size_t)n + s], R, m), m.q, d);
+    int d[NPL]; limb_digits1(w[((((size_t)f * xf + kx) * yf + ky) * k + i) * (size_t)n + s], m.q, d);
     i8 *dst = wl + ((size_t)i * n + s) * (NPL * 32 * 64) + f * 64 + kx * 8 + ky;
 #pragma unroll
     for (int l = 0; l < NPL; l++) dst[(size_t)l * (32 * 64)] = (i8)d[l];
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------------------------------
-static inline unsigned conv1_img_stride(int xd) { const unsigned b = NPL * 2 * (unsigned)xd * 32 + 8; return (b + 1023) / 1024 * 1024; }
+// per (slot, image): 7 planes x 2 polys x (xd rows + 1) x 32 bytes: the extra row puts the two polys' blocks 8 LDS banks apart (xd = 28: 896-byte blocks would be
+// 224 dwords = 0 banks apart, and the window reads of a pixel's two polys -- neighbouring lanes -- a two-way conflict each); it also takes the last window's read-ahead
+static inline unsigned conv1_poly_bytes(int xd) { return ((unsigned)xd + 1) * 32; }
+static inline unsigned conv1_img_stride(int xd) { const unsigned b = NPL * 2 * conv1_poly_bytes(xd); return (b + 1023) / 1024 * 1024; }
 bool k_limb_conv1_shape(const crc_ctx *c, int zd, int xd, int yd, int xs, int ys_, int xf, int yf, int nf)
 {
     if (zd != 1 || xf > 8 || yf > 8 || nf > 32 || yd > 32 || c->n < 64 || c->k > MAXK) return false;
-    // the epilogue's bounds (conv1_tables): a Montgomery quotient in (-q, 2^51.6] needs q > 2^52; 7 balanced digits with |top digit| <= 64 need q < 2^55
-    for (int i = 0; i < c->k; i++) if (c->tabs[i].m.bits > 55 || c->tabs[i].m.bits < 53) return false;
+    // the epilogue's bounds: the folding reduction wants q = 2^b - f with 53 <= b <= 55 and a small f (limbred.h conv1_fold_ok); 7 balanced digits with |top digit| <= 64 need q < 2^55
+    for (int i = 0; i < c->k; i++) if (!conv1_fold_ok(c->tabs[i].m.q, c->tabs[i].m.bits, fold_constant(c->tabs[i].m.q, c->tabs[i].m.bits))) return false;
     const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys_ + 1;
+    if (xo * yo > 1024) return false;                          // (the kernel's reciprocal division of a pixel index by yo <= 32 is exact below 2048)
     // two image buffers + the staging area of a limb result (at most 32 channel bytes per position) must fit the 160 KiB of LDS
     return 2 * (size_t)conv1_img_stride(xd) + (size_t)NPL * xo * yo * 2 * 32 <= 160 * 1024;
 }
@@ -235,7 +265,7 @@ size_t k_limb_conv1_image_bytes(const crc_ctx *c, int B, int xd) { return (size_
 
 static void conv1_tables(const crc_ctx *c, Conv1Args &a)      // limbred.h: accumulator biases and q^-1 mod 2^64 per modulus
 {
-    for (int i = 0; i < c->k; i++) { conv1_bias_table(c->tabs[i].m.q, a.acc0[i]); a.qinv[i] = inverse_mod_2_64(c->tabs[i].m.q); }
+    for (int i = 0; i < c->k; i++) { conv1_bias_table(c->tabs[i].m.q, a.acc0[i]); a.qbits[i] = c->tabs[i].m.bits; a.qfold[i] = fold_constant(c->tabs[i].m.q, c->tabs[i].m.bits); }
 }
 
 int k_limb_conv1_pack_weights(crc_ctx *c, const u64 *w, i8 *wl, int nf, int xf, int yf, hipStream_t st)
@@ -257,7 +287,7 @@ int k_limb_conv1(crc_ctx *c, const u64 *x, bool packed, i8 *xr, const i8 *wl, u6
     Conv1Args a{};
     a.xr = xr; a.wl = wl; a.ys = ys; a.xl_out = xl_out; a.mods = c->d_mods; a.bias = bias_ntt;
     a.n = c->n; a.k = c->k; a.B = B; a.Bout = Bout; a.b0 = b0; a.xd = xd; a.yo = yo; a.xs = xs; a.ystr = ys_; a.P = xo * yo; a.F = nf; a.mtiles = (2 * a.P + 15) / 16;
-    a.poly_bytes = (unsigned)xd * 32; a.plane_bytes = 2 * a.poly_bytes; a.img_stride = conv1_img_stride(xd);
+    a.poly_bytes = conv1_poly_bytes(xd); a.plane_bytes = 2 * a.poly_bytes; a.img_stride = conv1_img_stride(xd);
     a.out_zdc = a.P > 1 ? k_limb_flat_zdc(nf) : 0;            // (the limb tensor of the convolution behind: its layout follows ITS channel count = this layer's filters)
     a.out_img_bytes = a.out_zdc ? (unsigned)((NPL * 2 * a.P * a.out_zdc + 15) / 16 * 16) : (unsigned)(NPL * a.P * 2 * 32);
     conv1_tables(c, a);

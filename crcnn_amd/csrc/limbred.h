@@ -68,6 +68,61 @@ CRC_HD long long diag_reduce_short_centred(const int (&D)[13], u64 q, u64 qinv, 
     if (HAS_BIAS) t -= t > h ? (long long)q : 0;
     return t;
 }
+// Round 4: the same value WITHOUT the Montgomery step.  For q = 2^b - f (every modulus the one-channel kernel accepts: 53 <= b <= 55, f < 2^26) the 116-bit U folds
+// down as  U = Uh 2^b + Ul  ==  Ul + Uh f:  three folds (Uh < 2^63, then < 2^32, then < 32) leave a value below 2^b + 2^31 < 2q.  Multiplies: two 32 x 32 -> 64 and
+// one more for the second fold, one 32-bit low product for the third -- against seven 32 x 32 products of m = U_lo q^-1 and hi64(m q); v_mad_u64_u32 / v_mul_lo_u32 are
+// quarter rate, so they were 112 of the ~370 issue cycles of an output.  The weights then carry NO 2^64 factor (limb_pack_w1_kernel).  Returns the centred
+// representative of (U + bias) mod q, bias centred: in [-(q-1)/2, (q-1)/2].  conv1_fold_ok() is the precondition (checked on the host).
+CRC_HD bool conv1_fold_ok(u64 q, u32 bits, u32 fold)
+{
+    typedef unsigned __int128 u128;
+    // U < 2^115.6 < 0xC3 2^108 (conv1_bias_table); the second fold wants (Ul + (U >> b) f) >> b below 2^32; the third multiplies a value below 2^5 by f < 2^26
+    if (bits < 53 || bits > 55 || fold == 0 || fold >= (1u << 26) || (((u64)1 << bits) - fold) != q) return false;
+    const u128 uh_max = (((u128)0xC3) << 108) >> bits;
+    return uh_max * fold + ((u128)1 << bits) < ((u128)1 << (bits + 32));
+}
+// (written in 32-bit words: b >= 53 puts every shift by b inside the upper words -- v_alignbit_b32 -- and every multiply-add is one v_mad_u64_u32 with its 64-bit addend;
+// the compiler's own lowering of the same arithmetic on 64-bit values spent 22 64-bit shifts and 9 64-bit adds per output)
+CRC_HD u32 crc_alignbit(u32 hi, u32 lo, u32 sh)      // low word of (hi:lo) >> sh, 0 <= sh < 32
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+    return (u32)((((u64)hi << 32) | lo) >> sh);
+#endif
+}
+// PB: the accumulator biases of conv1_bias_table pair by pair, PB_j = B_2j + B_2j+1 2^8 (j < 6), PB_6 = B_12 -- null when the diagonals arrive biased already.  (The
+// kernel starts its accumulators at ZERO -- an inline constant of the first MFMA that touches a diagonal, instead of 13 x 4 register moves per tile -- and adds the biases
+// here, one word add per pair: D + B is the same word either way.)
+CRC_HD long long diag_fold_short_centred(const int (&D)[13], u64 q, u32 bits, u32 fold, long long bias_centred, const u32 *PB = nullptr)
+{
+    u32 P[7];
+    for (int j = 0; j < 6; j++) P[j] = (u32)D[2 * j] + ((u32)D[2 * j + 1] << 8);
+    P[6] = (u32)D[12];
+    if (PB) for (int j = 0; j < 7; j++) P[j] += PB[j];
+    // U = E + (O << 16), E = words (P0, P2, P4, P6), O = words (P1, P3, P5): four words u0..u3 (u3 < 2^20)
+    const u32 o0 = P[1] << 16, o1 = crc_alignbit(P[3], P[1], 16), o2 = crc_alignbit(P[5], P[3], 16), o3 = P[5] >> 16;
+    const u64 lo64 = (((u64)P[2] << 32) | P[0]) + (((u64)o1 << 32) | o0);
+    const u64 hi64 = (((u64)P[6] << 32) | P[4]) + (((u64)o3 << 32) | o2) + (lo64 < (((u64)P[2] << 32) | P[0]));
+    const u32 u0 = (u32)lo64, u1 = (u32)(lo64 >> 32), u2 = (u32)hi64, u3 = (u32)(hi64 >> 32);
+    const u32 sb = bits - 32, m1 = (1u << sb) - 1;
+    // fold 1: Uh = U >> b = (h1:h0) < 2^63;  x1 = Ul + h0 f + (h1 f << 32)  as words (A.lo, B.lo, B.hi)
+    const u32 h0 = crc_alignbit(u2, u1, sb), h1 = crc_alignbit(u3, u2, sb);
+    const u64 A = (u64)h0 * fold + (((u64)(u1 & m1) << 32) | u0);      // < 2^58 + 2^55
+    const u64 B = (u64)h1 * fold + (A >> 32);                           // < 2^57
+    // fold 2: Uh1 = x1 >> b < 2^32
+    const u32 uh1 = crc_alignbit((u32)(B >> 32), (u32)B, sb);
+    const u64 x2 = (u64)uh1 * fold + (((u64)((u32)B & m1) << 32) | (u32)A);      // < 2^b + 2^58
+    // fold 3: x2 >> b < 2^5
+    u64 r = (u64)((u32)(x2 >> 32) >> sb) * fold + (((u64)((u32)(x2 >> 32) & m1) << 32) | (u32)x2);      // < 2^b + 2^31 < 2 q
+    // centred representative of r + bias: r - q + bias lies in (-1.5 q, q/2 + 2^31): one conditional + q, then (the bias may have pushed it past q/2) one conditional - q
+    // (callers that have the choice pass bias_centred - q precomputed ... the compiler folds the constant subtraction when q and the bias are loop invariants)
+    long long t = (long long)(r - q) + bias_centred;
+    const long long h = (long long)(q >> 1);
+    t += t < -h ? (long long)q : 0;
+    t -= t > h ? (long long)q : 0;
+    return t;
+}
 CRC_HD u64 centred_digit_bytes(long long cv) { return ((u64)cv + 0x0080808080808080ULL) ^ 0x0080808080808080ULL; }
 
 // the 7 balanced base-256 digits of a canonical residue's centred representative, one per byte: the bytes of (centred value + 0x80...80) with their top bits flipped

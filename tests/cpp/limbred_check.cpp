@@ -27,7 +27,7 @@ int main()
                       0x7ffffffe4c0001ULL, 0x1fffffffd80001ULL /* 53 bits */, 0xffffffff00001ULL /* 52 */, 0x3ffffffb80001ULL /* 50 */, 0xffffe80001ULL /* 40 */,
                       18014398509481951ULL /* 2^54 - 33: not of the SEAL shape; odd */};
     u64 x = 88172645463325252ULL; auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
-    long checked = 0;
+    long checked = 0, folded_checked = 0;
     for (u64 q : qs) for (int fold = 0; fold < 2; fold++) {
         const ModParams m = make(q, fold);
         if (fold && !m.fold) continue;
@@ -75,6 +75,22 @@ int main()
                     const long long got = diag_reduce_short_centred<true>(Ds, q, qinv, centre(bias));
                     if (got != centre((u64)(((u128)expect + bias) % q)) || got < -hq || got > hq) { printf("diag_reduce_short_centred (bias) mismatch q=%llx mode=%d\n", (unsigned long long)q, mode); return 1; }
                     if (centred_digit_bytes(got) != balanced_digit_bytes((u64)(((u128)expect + bias) % q), q)) { printf("centred_digit_bytes mismatch\n"); return 1; }
+                    // round 4's form: the folding reduction of the same diagonals gives sum x sv mod q itself (no 2^64 factor to divide out), centred, bias included
+                    if (conv1_fold_ok(q, m.bits, fold_constant(q, m.bits))) {
+                        const u32 f = fold_constant(q, m.bits);
+                        const u64 plain = (u64)want;
+                        if (diag_fold_short_centred(Ds, q, m.bits, f, 0) != centre(plain)) { printf("diag_fold_short_centred mismatch q=%llx mode=%d\n", (unsigned long long)q, mode); return 1; }
+                        {   // the kernel's form: accumulators started at zero, the biases added pair by pair inside the reduction
+                            int Dz[13]; u32 PB[7];
+                            for (int d = 0; d < 13; d++) Dz[d] = (int)(D[d] - (u32)B[d]);
+                            for (int j = 0; j < 6; j++) PB[j] = (u32)B[2 * j] + ((u32)B[2 * j + 1] << 8);
+                            PB[6] = (u32)B[12];
+                            if (diag_fold_short_centred(Dz, q, m.bits, f, 0, PB) != centre(plain)) { printf("diag_fold_short_centred (zero start) mismatch q=%llx mode=%d\n", (unsigned long long)q, mode); return 1; }
+                        }
+                        const long long g2 = diag_fold_short_centred(Ds, q, m.bits, f, centre(bias));
+                        if (g2 != centre((u64)(((u128)plain + bias) % q)) || g2 < -hq || g2 > hq) { printf("diag_fold_short_centred (bias) mismatch q=%llx mode=%d\n", (unsigned long long)q, mode); return 1; }
+                        folded_checked++;
+                    }
                 }
                 {
                     if (shortform) { int Bg[13]; limb_bias_table(q, T, Bg); for (int d = 0; d < 13; d++) Ds[d] = (int)(D[d] - (u32)B[d] + (u32)Bg[d]); }
@@ -84,6 +100,7 @@ int main()
             }
         }
     }
+    if (folded_checked < 1000) { printf("the folding short form was not exercised (%ld)\n", folded_checked); return 1; }
     printf("ok %ld\n", checked);
     return 0;
 }
