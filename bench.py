@@ -87,7 +87,12 @@ def run_host(args, cfg_name, steps, warmup, batch=None, device=0):
     t_client = time.time()
     client = Client(cfg, q)
     imgs = client.images(D)
-    work = tempfile.mkdtemp(prefix="crc_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    # (CRC_BENCH_KEEP=<dir>: the encrypted inputs and the bench_host command line stay there afterwards -- tools/measure_round.sh profiles that command with rocprofv3)
+    keep_dir = os.environ.get("CRC_BENCH_KEEP")
+    if keep_dir:
+        work = os.path.join(keep_dir, cfg_name); os.makedirs(work, exist_ok=True)
+    else:
+        work = tempfile.mkdtemp(prefix="crc_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
         x0_sha = client.encrypt_images(imgs, os.path.join(work, "inputs.u64"), threads=cores)
         ctw = 2 * cfg["k"] * cfg["n"]
@@ -99,13 +104,16 @@ def run_host(args, cfg_name, steps, warmup, batch=None, device=0):
         cmd = [exe, f"model={cfg['model']}", "h5=" + os.path.join(ROOT, "tests", "golden", "models", cfg["model"] + ".h5"), f"n={cfg['n']}", f"k={cfg['k']}", f"t={cfg['t']}",
                "q=" + ",".join(str(int(v)) for v in q), "inputs=" + os.path.join(work, "inputs.u64"), f"distinct={D}", f"batch={B}", f"chunk={C}", f"group={G}", f"steps={steps}",
                f"warmup={warmup}", "outputs=" + os.path.join(work, "outputs.u64"), f"fuse={0 if args.no_fuse else 1}", f"key_seed={KEY_SEED}", f"device={device}"]
+        if keep_dir:
+            open(os.path.join(work, "cmd.txt"), "w").write(" ".join(cmd) + "\n")
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=3000)
         if p.returncode != 0:
             raise SystemExit(f"bench.py: bench_host failed (exit {p.returncode}): {p.stderr[-600:]}")
         r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
         outs = np.fromfile(os.path.join(work, "outputs.u64"), dtype=np.uint64).reshape(D, 10, 2, cfg["k"], cfg["n"])
     finally:
-        shutil.rmtree(work, ignore_errors=True)
+        if not keep_dir:
+            shutil.rmtree(work, ignore_errors=True)
     check, ok = client.verify(cfg_name, imgs, outs, x0_sha)
     check["ranks_verified"] = "1/1" if ok else "0/1"
 

@@ -25,7 +25,7 @@ CRC_HD double f64_mulmod_const(double y, double w, double wq, double p)
     const double c = __builtin_rint(y * wq);
     return __builtin_fma(-c, p, h) + l;
 }
-// a b mod p for |a| <= p/2, |b| < 2^51 (no precomputed quotient: fl(h pinv) carries three roundings of a value below 2^50, so c = rint(.) differs from a b / p by
+// a b mod p for |a| <= (p + 1)/2 (a twiddle or a residue as f64_reduce leaves it), |b| < 2^51 (no precomputed quotient: fl(h pinv) carries three roundings of a value below 2^50, so c = rint(.) differs from a b / p by
 // at most 0.5 + 3 2^-3): |result| < 0.875 p
 CRC_HD double f64_mulmod(double a, double b, const F64Mod &m)
 {
@@ -34,7 +34,7 @@ CRC_HD double f64_mulmod(double a, double b, const F64Mod &m)
     const double c = __builtin_rint(h * m.pinv);
     return __builtin_fma(-c, m.p, h) + l;
 }
-// |x| < 2^52  ->  a residue with |result| <= (p + 1) / 2; for |x| <= 8 p it is exactly the centred one (x / p is at least 1/(2p) = 2^-48 away from a half-integer and
+// |x| < 2^53 (every such integer is exact in a double: relinearisation's lazy sums of 48 products reach 42 p = 2^52.4)  ->  a residue with |result| <= (p + 1) / 2; for |x| <= 8 p it is exactly the centred one (x / p is at least 1/(2p) = 2^-48 away from a half-integer and
 // fl(x pinv) is off by at most |x / p| 2^-52).  Further out a value within 2^-48 |x / p| of a half-integer may land on the other side: (p + 1)/2 instead of
 // -(p - 1)/2 -- still the right class, one past the centred range, which is all the transforms and the CRT step need (their true values are nowhere near p/2).
 CRC_HD double f64_reduce(double x, const F64Mod &m)

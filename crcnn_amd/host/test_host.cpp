@@ -51,6 +51,7 @@ static int do_net(int argc, char **argv)
     net.ntt_resident = resident;
     if (argc > 7 && atoi(argv[7])) { const int removed = net.fuse(); fprintf(stderr, "fused: %d layers removed, %d left\n", removed, net.getNumLayers()); }
     if (argc > 8) net.head_chunk = atoi(argv[8]);             // two-level chunking: the layers in front of the first dense layer on sub-batches of this many images
+    if (argc > 9) net.matrix_cores = atoi(argv[9]) != 0;
     auto x = rd(dir + "/net_in.u64");
     vector<ciphertext3D> imgs;
     for (int b = 0; b < batch; b++) imgs.push_back(ciphertext3D::fromHost(x.data(), 1, 1, 28, 28));

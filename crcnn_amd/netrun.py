@@ -225,7 +225,7 @@ class Network:
             self._free(wt); self._free(stage)
             tw["built"] = want
 
-    def _limb_operands(self, B=None):
+    def _limb_operands(self, B=None, B_tail=None, split=None):
         """conv / dense weights of the eligible layers -> limb form (the canonical copy is dropped: call after fuse()); a limb layer that feeds a dense
         limb layer hands its tensor over in limb form"""
         E = self.E
@@ -246,7 +246,8 @@ class Network:
             if not self.limb_eligible(kind, a) or p.get("streamed") or p.get("tilewise"):
                 continue
             # (crc_plan_mac: with fewer than half a 64-row tile of rows = images x 2 polys x output pixels per launch the vector-ALU kernel is faster)
-            if B is not None and self.planned_form(kind, a, B) != binding.NTTL:
+            Bl = B if (B_tail is None or split is None or idx < split) else B_tail          # images this layer is launched on
+            if Bl is not None and self.planned_form(kind, a, Bl) != binding.NTTL:
                 p["limb_skipped"] = "fewer than 32 rows per launch"
                 continue
             nf, zd, xf, yf = (a["nf"], a["zd"], a["xf"], a["yf"]) if kind == "conv" else (a["out_dim"], a["in_dim"], 1, 1)
@@ -543,12 +544,6 @@ class Network:
         for pl_ in self.plan:                               # (a previous prepare() with two-level chunking re-typed the first dense layer's input)
             if "in_form_chunked" in pl_[3]:
                 pl_[3]["in_form"] = pl_[3].pop("in_form_chunked")
-        if self.materialize:
-            self._build_tilewise()
-            if limb:
-                self._limb_operands(B * max(1, tail_group))
-            self._pack_operands()
-        acts = self.activation_cts()
         self.B = B
         self.G = max(1, int(tail_group))
         # two-level chunking: the layers in front of the first dense layer run on chunks of B images (their activations bound the chunk), the dense layers on
@@ -557,6 +552,14 @@ class Network:
         self.split = next((i for i, pl_ in enumerate(self.plan) if pl_[0] == "fc"), len(self.plan)) if self.G > 1 else len(self.plan)
         if self.split == 0 or self.split == len(self.plan):
             self.G = 1; self.split = len(self.plan)
+        if self.materialize:
+            self._build_tilewise()
+            if limb:
+                # (the split is known first: every layer is planned -- crc_plan_mac's rows-per-launch rule -- for the images IT will be launched on: B in front of the
+                # split, B G behind it; a degenerate split runs everything on B)
+                self._limb_operands(B, B * self.G, self.split)
+            self._pack_operands()
+        acts = self.activation_cts()
         self.slots = self._slots()
         size = [1, 1]
         for i, sl in enumerate(self.slots):
@@ -593,7 +596,7 @@ class Network:
                 if self.plan[i][3].get("out_form") == binding.NTTL:
                     tsize[sl] = max(tsize[sl], self.E.limb_tensor_bytes(Bt, acts[i + 1], 1, 1))
             self.tail_buf = [self.alloc(tsize[0]), self.alloc(tsize[1])]
-            self.act_bytes += Bt * self.tail_in_img + tsize[0] + tsize[1]
+            self.act_bytes += (self.E.limb_tensor_bytes(Bt, acts[self.split], 1, 1) if self.tail_limb else Bt * self.tail_in_img) + tsize[0] + tsize[1]
         _, work = self.scratch_bytes(B)
         self.work = self.alloc(max(work, 256))
         self.work_bytes = max(work, 256)

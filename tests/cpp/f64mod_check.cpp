@@ -52,6 +52,18 @@ int main()
             }
             const double r = f64_reduce((double)y, m);
             if (std::fabs(r) > (double)(half + 1) || centre((long long)r, p) != centre(y, p) || (std::llabs(y) <= 8 * p && (long long)r != centre(y, p))) { printf("f64_reduce wrong: %lld -> %.1f (want %lld)\n", y, r, centre(y, p)); return 1; }
+            {   // the widened contracts: f64_reduce up to 2^53 -- relinearisation's lazy sums of 48 products reach 42 p = 2^52.4 -- and f64_mulmod with |a| = (p + 1) / 2,
+                // what f64_reduce may leave one past the centred range
+                const long long y2 = it % 3 == 0 ? 42 * p - (long long)(rnd() % 1000) : it % 3 == 1 ? -(((long long)1 << 53) - 1 - (long long)(rnd() % 1000)) : (long long)(rnd() >> 12) + ((long long)1 << 52) - 1;
+                const double r2 = f64_reduce((double)y2, m);
+                if (r2 != std::floor(r2) || std::fabs(r2) > (double)(half + 1) || centre((long long)r2, p) != centre(y2, p)) { printf("f64_reduce (wide) wrong: %lld -> %.1f\n", y2, r2); return 1; }
+                const long long a2 = (it & 1) ? half + 1 : -(half + 1);
+                if (std::llabs(y) < ((long long)1 << 51)) {
+                    const double U2 = f64_mulmod((double)a2, (double)y, m);
+                    if (U2 != std::floor(U2) || std::fabs(U2) >= 0.875 * m.p || (long long)(((i128)a2 * y - (i128)(long long)U2) % p) != 0) { printf("f64_mulmod (|a| = (p+1)/2) wrong: %lld %lld -> %.1f\n", a2, y, U2); return 1; }
+                }
+                checked += 2;
+            }
             const long long v = (long long)(rnd() >> 2) - ((long long)1 << 61);
             const double fv = f64_from_i64(v, m);
             if ((long long)fv != centre(v, p)) { printf("f64_from_i64 wrong: %lld -> %.1f\n", v, fv); return 1; }

@@ -15,14 +15,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DRIVER = os.path.join(ROOT, "crcnn_amd", "lib", "test_host")
 
 
-def run_driver(name, resident, batch=1, fuse=False, head_chunk=0, env=None):
+def run_driver(name, resident, batch=1, fuse=False, head_chunk=0, env=None, matrix_cores=True):
     g = load_net_golden(name)
     O, sk, pk, evk, img, x = make_inputs(g)
     d = tempfile.mkdtemp()
     np.array([g["n"], len(g["q"]), g["t"]] + g["q"], dtype=np.uint64).tofile(os.path.join(d, "params.u64"))
     evk.tofile(os.path.join(d, "evk.u64")); x.tofile(os.path.join(d, "net_in.u64"))
     h5 = os.path.join(GOLD, "models", g["model"] + ".h5")
-    subprocess.check_call([DRIVER, "net", g["model"], h5, d, "1" if resident else "0", str(batch), "1" if fuse else "0", str(head_chunk)], env=dict(os.environ, **(env or {})))
+    subprocess.check_call([DRIVER, "net", g["model"], h5, d, "1" if resident else "0", str(batch), "1" if fuse else "0", str(head_chunk), "1" if matrix_cores else "0"], env=dict(os.environ, **(env or {})))
     return g, O, d
 
 
@@ -142,6 +142,20 @@ def test_cpp_two_level_chunking_and_tilewise_weights(name):
     g, O, d = run_driver(name, resident=True, batch=16, fuse=True, head_chunk=3, env={"CRC_FORCE_TILEWISE": "1"})
     out = np.fromfile(os.path.join(d, "out.u64"), dtype=np.uint64).reshape(16, -1)
     assert all(sha(out[b]) == g["out_sha256"] for b in range(16))
+
+
+@pytest.mark.parametrize("name", ["wopad256", "tiny256"])
+def test_cpp_tilewise_layer_outside_the_matrix_core_plan(name):
+    """a tile-wise dense layer has no canonical weights, so whoever reaches it first must build its limb tensor -- also a direct
+    Layer::forward (the driver's layer-by-layer mode calls every layer itself, coefficient form at every boundary: the reference's own digests must come out) and a
+    Network with matrix_cores = false (the plan would keep the layer off the limb GEMM; it runs there all the same, the only form its weights exist in)"""
+    g, O, d = run_driver(name, resident=False, env={"CRC_FORCE_TILEWISE": "1"})
+    for i, L in enumerate(g["layers"]):
+        t = np.fromfile(os.path.join(d, f"layer_{i}.u64"), dtype=np.uint64)
+        assert sha(t) == L["sha256"], (name, i, L["name"])
+    g, O, d = run_driver(name, resident=True, batch=3, env={"CRC_FORCE_TILEWISE": "1"}, matrix_cores=False)
+    out = np.fromfile(os.path.join(d, "out.u64"), dtype=np.uint64).reshape(3, -1)
+    assert all(sha(out[b]) == g["out_sha256"] for b in range(3))
 
 
 def test_cpp_example_driver():

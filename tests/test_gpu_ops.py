@@ -277,7 +277,7 @@ def test_square_over_fp64_auxiliary_base_equals_reference_base(n, k, t, cnt):
         E.square(d_x, N, d_y3, d_w)
         assert np.array_equal(E.download(d_y3, (N, 3, k, n)), outs[1]), ("radix", radix)
     E.set_tuning("f64_radix", 0)
-    # (2 forces the fp64 base; left to itself the engine takes it while it needs at most one row more than SEAL's base)
+    # (sq_path 2 and the default 0 both take the fp64 base whenever the parameters fit twelve of the engine's primes; 1 keeps SEAL's 61-bit base)
     # ... and through the NTT-resident entry point with relinearisation behind it (input inverse-transformed inside, third polynomial handed over premultiplied)
     evk = np.empty(E.L.crc_evk_words(E.c, 16), dtype=np.uint64)
     rows = evk.reshape(-1, k, n)

@@ -2,7 +2,7 @@
 """Copy the outputs of tools/measure_round.sh (gpurun_out/final) into profiles/ under this round's names and derive the PMC traffic summary of the
 dominant launch that bench.py cites (roofline.traffic).  usage: collect_profiles.py r02"""
 import collections, csv, json, os, shutil, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 F = os.path.join(ROOT, "gpurun_out", "final"); P = os.path.join(ROOT, "profiles")
 
@@ -12,10 +12,10 @@ def cp(src, dst):
         shutil.copy(os.path.join(F, src), os.path.join(P, f"{R}_{dst}"))
 
 
-for c in ("default_invocation", "tiny4096", "approx8192", "approx8192k4_b256", "wopad16384_b96", "wopad16384k8_b96"):
+for c in ("default_invocation", "approx8192k4_b256", "wopad16384k8_b96", "tiny4096_with_python_twin"):
     cp(f"bench_{c}.json", f"bench_{c}.json")
-cp("prof_tiny/tiny_kernel_stats.csv", "bench_tiny4096_b256_kernel_stats.csv")
-cp("prof_approx/approx_kernel_stats.csv", "bench_approx8192_b96_kernel_stats.csv")
+cp("prof_tiny4096/tiny4096_kernel_stats.csv", "bench_tiny4096_b256_kernel_stats.csv")
+cp("prof_approx8192/approx8192_kernel_stats.csv", "bench_approx8192_b96_kernel_stats.csv")
 cp("prof_c1/c1_kernel_stats.csv", "conv1_4096k2_b128_kernel_stats.csv")
 for tag in ("8192_3_1250", "16384_4_512", "16384_8_256"):
     cp(f"prof_square_{tag}.txt", f"square_relin_{tag}_kernels.txt"); cp(f"prof_square_old_{tag}.txt", f"square_relin_{tag}_kernels_round2_path.txt")
@@ -24,10 +24,11 @@ cp("square_paths.txt", "square_relin_paths.txt")
 with open(os.path.join(P, f"{R}_square_relin.txt"), "w") as f:
     f.write("# Square + relinearise (crc_square_relin_forms, NTT form in and out), us per ciphertext and kernel: rocprofv3 --kernel-trace --stats over tools/bench_square.py\n"
             "# (tools/prof_square.sh; 4 sequences per run).  'round-2 kernels' = CRC_SQ_PATH=1 CRC_RELIN_PATH=1 on the same box and build: SEAL's 61-bit auxiliary base and key\n"
-            "# switching over the coefficient moduli; 'round 3' = the default (fp64 auxiliary base, key switching over two fp64 primes, 16-byte row accesses).\n")
+            "# switching over the coefficient moduli; 'this round' = the default (fp64 auxiliary base, key switching over two fp64 primes; round 4: lift fused into the forward\n"
+            "# transforms, rows held in registers, gap-1 stage in the fill / drain loops).\n")
     for tag in ("8192_3_1250", "16384_4_512", "16384_8_256"):
         n_, k_, c_ = tag.split("_")
-        for src, label in ((f"prof_square_old_{tag}.txt", "round-2 kernels"), (f"prof_square_{tag}.txt", "round 3")):
+        for src, label in ((f"prof_square_old_{tag}.txt", "round-2 kernels"), (f"prof_square_{tag}.txt", "this round")):
             if os.path.exists(os.path.join(F, src)):
                 f.write(f"\n== n = {n_}, k = {k_}, {c_} ciphertexts per call: {label}\n")
                 f.writelines(l for l in open(os.path.join(F, src)) if "amdgpu.ids" not in l and not l.startswith("+") and "at::native" not in l and "rocclr" not in l)
@@ -60,10 +61,10 @@ def by_shape(trace, dst, title):
             f.write(f"{name[:60]:60s} {grid:>12d} {wg:>5d} {len(v):>5d} {sum(v) / len(v):>10.3f} {min(v):>10.3f} {max(v):>10.3f}\n")
 
 
-by_shape(os.path.join(F, "prof_tiny/tiny_kernel_trace.csv"), os.path.join(P, f"{R}_bench_tiny4096_by_launch_shape.txt"),
-         "rocprofv3 --kernel-trace of `python3 bench.py --cpu-seconds 0 --unfused-images 0 --also none --batch 256` (tiny4096, 128 images per launch)")
-by_shape(os.path.join(F, "prof_approx/approx_kernel_trace.csv"), os.path.join(P, f"{R}_bench_approx8192_by_launch_shape.txt"),
-         "rocprofv3 --kernel-trace of `python3 bench.py --config approx8192 --batch 96 --cpu-seconds 0 --unfused-images 0 --also none` (32 images per launch)")
+by_shape(os.path.join(F, "prof_tiny4096/tiny4096_kernel_trace.csv"), os.path.join(P, f"{R}_bench_tiny4096_by_launch_shape.txt"),
+         "rocprofv3 --kernel-trace of bench.py's measured path (crcnn_amd/lib/bench_host, tiny4096, batch 256, 128 images per launch)")
+by_shape(os.path.join(F, "prof_approx8192/approx8192_kernel_trace.csv"), os.path.join(P, f"{R}_bench_approx8192_by_launch_shape.txt"),
+         "rocprofv3 --kernel-trace of bench.py's measured path (crcnn_amd/lib/bench_host, approx8192, batch 96, 32 images per launch, dense layers per 64)")
 
 # PMC: counters are KiB; FETCH_SIZE is doubled on gfx950 for wide coalesced reads (MI355X_MICROARCH.md, HBM section)
 def tot(path, counter, kernel):

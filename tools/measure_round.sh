@@ -4,15 +4,18 @@ O=gpurun_out/final; mkdir -p $O
 P=${1:-all}
 if [ $P = all ] || [ $P = bench ]; then
 timeout -k 10 900 python bench.py --steps 5 --warmup 1 > $O/bench_default_invocation.json 2> $O/bench_default.err
-timeout -k 10 500 python bench.py --also none --steps 5 --warmup 1 > $O/bench_tiny4096.json 2> $O/bench_tiny4096.err
-timeout -k 10 500 python bench.py --config approx8192 --also none --steps 2 > $O/bench_approx8192.json 2> $O/bench_approx8192.err
 timeout -k 10 500 python bench.py --config approx8192k4 --also none --steps 1 --batch 256 > $O/bench_approx8192k4_b256.json 2> $O/bench_approx8192k4.err
-timeout -k 10 500 python bench.py --config wopad16384 --also none --steps 1 --batch 96 --host-cpp 2 > $O/bench_wopad16384_b96.json 2> $O/bench_wopad.err
-timeout -k 10 700 python bench.py --config wopad16384k8 --also none --steps 1 --batch 96 --distinct 2 --cpu-seconds 0 --unfused-images 0 > $O/bench_wopad16384k8_b96.json 2> $O/bench_wopadk8.err
+timeout -k 10 700 python bench.py --config wopad16384k8 --also none --steps 1 --batch 96 --cpu-seconds 0 > $O/bench_wopad16384k8_b96.json 2> $O/bench_wopadk8.err
+timeout -k 10 500 python bench.py --also none --steps 3 --python-twin --unfused-images 128 > $O/bench_tiny4096_with_python_twin.json 2> $O/bench_tiny4096_twin.err
 fi
 if [ $P = all ] || [ $P = prof ]; then
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_tiny -o tiny -- python3 bench.py --cpu-seconds 0 --unfused-images 0 --also none --batch 256 > $O/prof_tiny.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_approx -o approx -- python3 bench.py --config approx8192 --batch 96 --cpu-seconds 0 --unfused-images 0 --also none > $O/prof_approx.log 2>&1
+# per-kernel traces of the measured path itself: bench.py leaves the encrypted inputs and the bench_host command line behind (CRC_BENCH_KEEP), rocprofv3 runs that command
+K=/tmp/crc_keep; rm -rf $K; mkdir -p $K
+CRC_BENCH_KEEP=$K timeout -k 10 400 python bench.py --also approx8192 --cpu-seconds 0 --batch 256 --also-batch 96 --also-steps 1 > $O/prof_prepare.json 2> $O/prof_prepare.err
+for cfg in tiny4096 approx8192; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$cfg -o $cfg -- $(cat $K/$cfg/cmd.txt) > $O/prof_$cfg.log 2>&1
+done
+rm -rf $K
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_sq -o sq -- python3 tools/bench_square.py 8192 3 1250 > $O/prof_sq.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c1 -o c1 -- python3 tools/check_conv1.py 4096 2 128 tiny > $O/prof_c1.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_c1_fetch -o f -- python3 tools/check_conv1.py 4096 2 128 tiny > $O/pmc_c1_fetch.log 2>&1
