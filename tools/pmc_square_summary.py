@@ -26,7 +26,7 @@ fetch, calls = load("fetch", "FETCH_SIZE")
 write, _ = load("write", "WRITE_SIZE")
 ours = [nm for nm in fetch if not nm.startswith(("void at::", "at::", "__amd"))]
 per = cts * runs
-cal_name = next((nm for nm in ours if "ntt_rows_kernel<true, true, 0>" in nm or "ntt_rows_kernel<true, true, 5>" in nm), None)      # (round 4: prologue 5 = the same transform with a scaled result)
+cal_name = next((nm for nm in ours if any(t in nm for t in ("ntt_rows_kernel<true, true, 0>", "ntt_rows_kernel<true, true, 5>", "ntt_rows_split_kernel<true, true, 5>"))), None)      # (round 4: prologue 5 = the same transform with a scaled result)
 cal = None
 if cal_name:
     known = 2 * k * 8 * n * per          # the first inverse transform of the NTT-resident input: 2k rows per ciphertext, each read once
