@@ -248,11 +248,13 @@ void setParameters(int poly_modulus, const vector<uint64_t> &coeff_modulus, uint
 // One kernel scratch area for every layer of the process: layers run one after another on one stream, so their scratch never overlaps in
 // time, and the largest request decides the size (a per-layer buffer summed to ~40 GiB at WoPad 16384 beside the 182 GiB limb weights).
 static shared_ptr<DeviceBuffer> g_scratch;
+// limb-form tile buffers of the streamed layers (one set serves every streamed layer: they run one after the other)
+static shared_ptr<DeviceBuffer> g_wltile, g_xltile;
 
 void delParameters()
 {
     ev_keys16.reset();
-    g_scratch.reset();
+    g_scratch.reset(); g_wltile.reset(); g_xltile.reset();
     g_pool.flush();
     if (context) { crc_ctx_destroy(context); context = nullptr; }
 }
@@ -387,15 +389,52 @@ static bool tooLargeForHbm(size_t weights)
     return (double)weights * K() * N() * 8 > share * (double)total_b;
 }
 // a streamed layer: lift + NTT a tile of filters, run the layer on the tile, scatter the tile's output channels into the [B][F][P] tensor
+static int plannedForm(int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int B);
 static void forwardStreamed(const ciphertext3D &input, ciphertext3D &out, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int out_form,
                             shared_ptr<DeviceBuffer> &d_plain, shared_ptr<DeviceBuffer> *d_b, shared_ptr<DeviceBuffer> &d_wtile, shared_ptr<DeviceBuffer> &d_ytile, shared_ptr<DeviceBuffer> &d_work)
 {
     const size_t n = N(), k = K(), rowb = k * n * 8, ctb = ctBytes();
     const size_t T = (size_t)zd * xf * yf, P = (size_t)((xd - xf) / xs + 1) * ((yd - yf) / ys + 1);
+    auto scatter = [&](int f0, int ft) {
+        for (int b = 0; b < input.B; b++)
+            chk(crc_memcpy_d2d(ctx(), (char *)out.buf->ptr + ((size_t)b * nf + f0) * P * ctb, (const char *)d_ytile->ptr + (size_t)b * ft * P * ctb, (size_t)ft * P * ctb, nullptr), "crc_memcpy_d2d");
+    };
+    // On the matrix cores (a reduction the limb GEMM takes, at least 32 rows in this launch: crc_plan_mac): tiles of 64 filters in limb form, built from canonical sub-tiles
+    // of 8 filters (crc_limb_pack_weights_tile), the layer's input converted to limb form once per launch -- PlainModelWoPad's fc3 with all eight primes of n = 16384
+    // (netrun.py does the same: 25 against 58 ms per image on the vector-ALU tiles)
+    const bool ntt_in = input.form == CRC_NTT || input.form == CRC_NTTP || input.form == CRC_NTTL;
+    if (ntt_in && plannedForm(zd, xd, yd, xs, ys, xf, yf, nf, input.B) == CRC_NTTL) {
+        const int ft_max = min(64, nf), sub = min(8, ft_max);
+        const size_t wt = (size_t)sub * T * rowb, wl = crc_limb_weights_bytes(ctx(), ft_max, zd, xf, yf), yt = (size_t)input.B * ft_max * P * ctb;
+        if (!d_wtile || d_wtile->bytes < wt) d_wtile = make_shared<DeviceBuffer>(wt);
+        if (!d_ytile || d_ytile->bytes < yt) d_ytile = make_shared<DeviceBuffer>(yt);
+        if (!g_wltile || g_wltile->bytes < wl) g_wltile = make_shared<DeviceBuffer>(wl);
+        const void *xl = input.data();
+        if (input.form != CRC_NTTL) {
+            const size_t xb = crc_limb_tensor_bytes(ctx(), input.B, zd, xd, yd);
+            if (!g_xltile || g_xltile->bytes < xb) g_xltile = make_shared<DeviceBuffer>(xb);
+            chk(crc_limb_pack_tensor(ctx(), input.data(), input.form, input.B, zd, xd, yd, g_xltile->ptr, nullptr), "crc_limb_pack_tensor");
+            xl = g_xltile->ptr;
+        }
+        const size_t wb = crc_conv2d_forms_work_bytes(ctx(), input.B, zd, xd, yd, xs, ys, xf, yf, ft_max, CRC_NTTL, CRC_NTTL, out_form);
+        if (!d_work || d_work->bytes < wb) d_work = make_shared<DeviceBuffer>(wb);
+        for (int f0 = 0; f0 < nf; f0 += ft_max) {
+            const int ft = min(ft_max, nf - f0);
+            for (int s0 = 0; s0 < ft; s0 += sub) {
+                const int fs = min(sub, ft - s0);
+                chk(crc_plain_to_ntt(ctx(), (const uint64_t *)d_plain->ptr + (size_t)(f0 + s0) * T * n, (size_t)fs * T, (uint64_t *)d_wtile->ptr, nullptr), "crc_plain_to_ntt");
+                chk(crc_limb_pack_weights_tile(ctx(), (const uint64_t *)d_wtile->ptr, ft, s0, fs, zd, xf, yf, g_wltile->ptr, nullptr), "crc_limb_pack_weights_tile");
+            }
+            chk(crc_conv2d_forms(ctx(), (const uint64_t *)xl, (const uint64_t *)g_wltile->ptr, CRC_NTTL, (const uint64_t *)((const char *)d_b[out_form != CRC_COEFF]->ptr + (size_t)f0 * rowb),
+                                 input.B, zd, xd, yd, xs, ys, xf, yf, ft, CRC_NTTL, out_form, (uint64_t *)d_ytile->ptr, d_work->ptr, nullptr), "crc_conv2d_forms");
+            scatter(f0, ft);
+        }
+        return;
+    }
     // tile: as many filters (a multiple of 8, the MAC kernel's filter granule) as make 2-16 GiB of NTT-form weights, by what HBM has left
     size_t free_b = 0, total_b = 0;
     chk(crc_mem_info(ctx(), &free_b, &total_b), "crc_mem_info");
-    const size_t tile_bytes = d_wtile ? d_wtile->bytes : max<size_t>((size_t)2 << 30, min<size_t>((size_t)16 << 30, free_b / 8));
+    const size_t tile_bytes = d_wtile && d_wtile->bytes >= ((size_t)1 << 30) ? d_wtile->bytes : max<size_t>((size_t)2 << 30, min<size_t>((size_t)16 << 30, free_b / 8));
     size_t ftv = tile_bytes / (T * rowb); if (ftv >= 8) ftv = ftv / 8 * 8;
     const int ft_max = (int)max<size_t>(1, min<size_t>(nf, ftv));
     if (!d_wtile || d_wtile->bytes < ft_max * T * rowb) d_wtile = make_shared<DeviceBuffer>(ft_max * T * rowb);
@@ -407,16 +446,16 @@ static void forwardStreamed(const ciphertext3D &input, ciphertext3D &out, int zd
         chk(crc_plain_to_ntt(ctx(), (const uint64_t *)d_plain->ptr + (size_t)f0 * T * n, (size_t)ft * T, (uint64_t *)d_wtile->ptr, nullptr), "crc_plain_to_ntt");
         chk(crc_conv2d_forms(ctx(), input.data(), (const uint64_t *)d_wtile->ptr, CRC_NTT, (const uint64_t *)((const char *)d_b[out_form != CRC_COEFF]->ptr + (size_t)f0 * rowb), input.B,
                              zd, xd, yd, xs, ys, xf, yf, ft, input.form, out_form, (uint64_t *)d_ytile->ptr, d_work->ptr, nullptr), "crc_conv2d_forms");
-        for (int b = 0; b < input.B; b++)
-            chk(crc_memcpy_d2d(ctx(), (char *)out.buf->ptr + ((size_t)b * nf + f0) * P * ctb, (const char *)d_ytile->ptr + (size_t)b * ft * P * ctb, (size_t)ft * P * ctb, nullptr), "crc_memcpy_d2d");
+        scatter(f0, ft);
     }
 }
 
 // the kernel crc_plan_mac picks for a conv / dense layer launched on B images (the one statement of the policy, shared with netrun.py)
+static bool g_matrix_cores = true;                  // Network::matrix_cores of the forward in progress (layers called directly plan with the default)
 static int plannedForm(int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int B)
 {
     int wf = CRC_NTT;
-    chk(crc_plan_mac(ctx(), zd, xd, yd, xs, ys, xf, yf, nf, B, 1, &wf), "crc_plan_mac");
+    chk(crc_plan_mac(ctx(), zd, xd, yd, xs, ys, xf, yf, nf, B, g_matrix_cores ? 1 : 0, &wf), "crc_plan_mac");
     return wf;
 }
 // canonical NTT-form weights -> limb form (CRC_NTTL) when crc_plan_mac says the limb GEMM pays for this shape and launch size and the second copy fits beside the
@@ -792,6 +831,7 @@ void Network::printNetworkStructure()
 ciphertext3D Network::forward(ciphertext3D input)
 {   // network.cpp:22-47
     const int L = (int)layers.size();
+    g_matrix_cores = matrix_cores;
     // choose the form of every boundary: NTT between linear layers when resident, coefficient form into Square and out of the net
     // conv / dense weights go into the MAC kernels' operand form (28-bit limb pairs) once; moduli above 55 bits cannot be packed
     bool packable = true;

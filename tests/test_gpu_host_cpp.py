@@ -217,5 +217,10 @@ def test_cpp_network_streamed_weights_equal_reference(name):
             g, O, d = run_driver(name, resident=True, batch=2, fuse=fuse)
             out = np.fromfile(os.path.join(d, "out.u64"), dtype=np.uint64).reshape(2, -1)
             assert sha(out[0]) == g["out_sha256"] and sha(out[1]) == g["out_sha256"]
+        # ... and with 16 images = 32 rows per launch the streamed dense / multi-channel conv layers take the matrix-core route: 64-filter limb tiles built from
+        # 8-filter canonical sub-tiles inside the forward (round 4; netrun.py's twin: tests/test_gpu_nets.py::test_streamed_weights_on_the_matrix_cores)
+        g, O, d = run_driver(name, resident=True, batch=16, fuse=True)
+        out = np.fromfile(os.path.join(d, "out.u64"), dtype=np.uint64).reshape(16, -1)
+        assert all(sha(out[b]) == g["out_sha256"] for b in range(16))
     finally:
         del os.environ["CRC_STREAM_SHARE"]
