@@ -121,7 +121,7 @@ def run_host(args, cfg_name, steps, warmup, batch=None, device=0):
     L = r["layers"]
     ms_per_layer = {nm: ms for nm, ms in zip(L, r["T_LAYER_ms_per_image"])}
     kernels = {nm: kn for nm, kn in zip(L, r["kernel_per_layer"]) if kn}
-    plan = None if args.no_fuse else geometry.fused_plan(client.E, cfg["model"])
+    plan = None if args.no_fuse else geometry.fused_plan(client.E, cfg["model"], names=L)
     roofline, useful = None, {}
     if plan is not None and [pl[1] for pl in plan] == L:
         split = next((i for i, pl in enumerate(plan) if pl[0] == "fc" and i > 0), len(plan)) if G > 1 else len(plan)

@@ -21,6 +21,7 @@
 #include <fstream>
 #include <iostream>
 #include <map>
+#include <unistd.h>
 using namespace std;
 
 static string jstr(const string &s) { string o = "\""; for (char c : s) { if (c == '"' || c == '\\') o += '\\'; o += c; } return o + "\""; }
@@ -113,6 +114,7 @@ int main(int argc, char **argv)
         return 0;
     } catch (const exception &e) {
         fprintf(stderr, "bench_host: %s\n", e.what());
-        return 2;
+        fflush(stderr);
+        _exit(2);                                               // (no unwinding of device state after a failed launch or allocation: the message above is the report)
     }
 }

@@ -390,7 +390,7 @@ static bool tooLargeForHbm(size_t weights)
 }
 // a streamed layer: lift + NTT a tile of filters, run the layer on the tile, scatter the tile's output channels into the [B][F][P] tensor
 static int plannedForm(int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int B);
-static void forwardStreamed(const ciphertext3D &input, ciphertext3D &out, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int out_form,
+static int forwardStreamed(const ciphertext3D &input, ciphertext3D &out, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int out_form,
                             shared_ptr<DeviceBuffer> &d_plain, shared_ptr<DeviceBuffer> *d_b, shared_ptr<DeviceBuffer> &d_wtile, shared_ptr<DeviceBuffer> &d_ytile, shared_ptr<DeviceBuffer> &d_work)
 {
     const size_t n = N(), k = K(), rowb = k * n * 8, ctb = ctBytes();
@@ -429,7 +429,7 @@ static void forwardStreamed(const ciphertext3D &input, ciphertext3D &out, int zd
                                  input.B, zd, xd, yd, xs, ys, xf, yf, ft, CRC_NTTL, out_form, (uint64_t *)d_ytile->ptr, d_work->ptr, nullptr), "crc_conv2d_forms");
             scatter(f0, ft);
         }
-        return;
+        return CRC_NTTL;
     }
     // tile: as many filters (a multiple of 8, the MAC kernel's filter granule) as make 2-16 GiB of NTT-form weights, by what HBM has left
     size_t free_b = 0, total_b = 0;
@@ -448,6 +448,7 @@ static void forwardStreamed(const ciphertext3D &input, ciphertext3D &out, int zd
                              zd, xd, yd, xs, ys, xf, yf, ft, input.form, out_form, (uint64_t *)d_ytile->ptr, d_work->ptr, nullptr), "crc_conv2d_forms");
         scatter(f0, ft);
     }
+    return CRC_NTT;
 }
 
 // the kernel crc_plan_mac picks for a conv / dense layer launched on B images (the one statement of the policy, shared with netrun.py)
@@ -505,10 +506,10 @@ static string macKernelName(int w_form, bool streamed)
 {
     const string k = w_form == CRC_NTTL ? "mfma_mac2w_kernel (int8 limb GEMM, CRC_NTTL)" : w_form == CRC_NTTL1 ? "mfma_conv1_kernel (one-channel convolution on the matrix cores, CRC_NTTL1)"
                    : w_form == CRC_NTTP ? "mac3_kernel (v_mad_u64_u32, CRC_NTTP)" : "mac3_kernel (v_mad_u64_u32, canonical residues)";
-    return streamed ? k + ", streamed weights" : k;
+    return streamed ? k + (w_form == CRC_NTTL ? ", streamed weights (64-filter limb tiles built inside the forward)" : ", streamed weights") : k;
 }
 size_t ConvolutionalLayer::deviceBytes() const { return bytesOf(d_w) + bytesOf(d_b[0]) + bytesOf(d_b[1]) + bytesOf(d_plain) + bytesOf(d_wtile) + bytesOf(d_ytile) + bytesOf(d_w_canon); }
-string ConvolutionalLayer::kernelName() const { return macKernelName(w_form, streamed); }
+string ConvolutionalLayer::kernelName() const { return macKernelName(streamed ? stream_form : w_form, streamed); }
 int ConvolutionalLayer::placement() { upload(); return streamed ? 1 : 0; }
 void ConvolutionalLayer::restoreCanonical()
 {
@@ -566,7 +567,7 @@ ciphertext3D ConvolutionalLayer::forward(ciphertext3D input)
     checkInput(input, zd, xd, yd, "ConvolutionalLayer");
     upload();
     ciphertext3D out(input.B, zo, xo, yo, out_form);
-    if (streamed) { forwardStreamed(input, out, zd, xd, yd, xs, ys, xf, yf, nf, out_form, d_plain, d_b, d_wtile, d_ytile, g_scratch); return out; }
+    if (streamed) { stream_form = forwardStreamed(input, out, zd, xd, yd, xs, ys, xf, yf, nf, out_form, d_plain, d_b, d_wtile, d_ytile, g_scratch); return out; }
     size_t wb = crc_conv2d_forms_work_bytes(ctx(), input.B, zd, xd, yd, xs, ys, xf, yf, nf, input.form, w_form, out_form);
     if (!wb) throw invalid_argument("ConvolutionalLayer: unsupported geometry");
     ensure(g_scratch, wb);
@@ -669,8 +670,9 @@ void FullyConnectedLayer::buildTilewise()
     w_form = CRC_NTTL; tile_built = true;
 }
 size_t FullyConnectedLayer::deviceBytes() const { return bytesOf(d_w) + bytesOf(d_b[0]) + bytesOf(d_b[1]) + bytesOf(d_plain) + bytesOf(d_wtile) + bytesOf(d_ytile); }
-string FullyConnectedLayer::kernelName() const { return macKernelName(w_form, streamed) + (tilewise ? ", limb weights built tile by tile" : ""); }
+string FullyConnectedLayer::kernelName() const { return macKernelName(streamed ? stream_form : w_form, streamed) + (tilewise ? ", limb weights built tile by tile" : ""); }
 int FullyConnectedLayer::placement() { upload(); return streamed ? 1 : tilewise ? 2 : 0; }
+bool FullyConnectedLayer::streamsOnMatrixCores(int B) { upload(); return streamed && plannedForm(in_dim, 1, 1, 1, 1, 1, 1, out_dim, B) == CRC_NTTL; }
 void FullyConnectedLayer::restoreCanonical()
 {
     if (w_form == CRC_NTTP) { packWeights(true); return; }
@@ -726,7 +728,7 @@ ciphertext3D FullyConnectedLayer::forward(ciphertext3D input)
     // builds the limb tensor, the only form its weights exist in (the layer then runs on the limb GEMM whatever the plan would have been)
     if (tilewise && !tile_built) buildTilewise();
     ciphertext3D out(input.B, 1, out_dim, 1, out_form);
-    if (streamed) { forwardStreamed(input, out, in_dim, 1, 1, 1, 1, 1, 1, out_dim, out_form, d_plain, d_b, d_wtile, d_ytile, g_scratch); return out; }
+    if (streamed) { stream_form = forwardStreamed(input, out, in_dim, 1, 1, 1, 1, 1, 1, out_dim, out_form, d_plain, d_b, d_wtile, d_ytile, g_scratch); return out; }
     ensure(g_scratch, crc_conv2d_forms_work_bytes(ctx(), input.B, in_dim, 1, 1, 1, 1, 1, 1, out_dim, input.form, w_form, out_form));
     chk(crc_dense_forms(ctx(), input.data(), (const uint64_t *)d_w->ptr, w_form, (const uint64_t *)d_b[out_form != CRC_COEFF]->ptr, input.B, in_dim, out_dim, input.form, out_form,
                         out.data(), g_scratch->ptr, nullptr), "crc_dense_forms");
@@ -837,7 +839,7 @@ ciphertext3D Network::forward(ciphertext3D input)
     bool packable = true;
     { vector<uint64_t> q(K()); crc_ctx_table(ctx(), "q", q.data(), K()); for (uint64_t v : q) if (v >> 55) packable = false; }
     auto isMac = [&](int i) { return i >= 0 && i < L && (dynamic_pointer_cast<ConvolutionalLayer>(layers[i]) || dynamic_pointer_cast<FullyConnectedLayer>(layers[i])); };
-    vector<char> limb(L, 0);
+    vector<char> limb(L, 0), streams(L, 0);
     // two-level chunking: the layers in front of the first dense layer on sub-batches of head_chunk images, the dense layers on the whole batch
     int split = L;
     if (head_chunk > 0 && input.B > head_chunk && ntt_resident && max_num_of_reencryptions < 0 && layer_before_reenc < 0)
@@ -847,14 +849,20 @@ ciphertext3D Network::forward(ciphertext3D input)
         for (int i = 0; i < L; i++) {
             const int Bi = chunked && i < split ? head_chunk : input.B;
             if (auto c = dynamic_pointer_cast<ConvolutionalLayer>(layers[i])) { limb[i] = matrix_cores && c->limbWeights(Bi); if (!limb[i]) c->packWeights(false); }
-            else if (auto f = dynamic_pointer_cast<FullyConnectedLayer>(layers[i])) { limb[i] = matrix_cores && f->limbWeights(Bi); if (!limb[i]) f->packWeights(false); }
+            else if (auto f = dynamic_pointer_cast<FullyConnectedLayer>(layers[i])) {
+                limb[i] = matrix_cores && f->limbWeights(Bi);
+                if (!limb[i]) f->packWeights(false);
+                // a STREAMED dense layer that will run on the matrix cores (64-filter limb tiles built inside the forward) reads a limb tensor like a resident one:
+                // the chunks of a group are packed straight into it, and no second copy of the group's input is made inside the layer
+                if (matrix_cores && f->streamsOnMatrixCores(Bi)) { limb[i] = 1; streams[i] = 1; }
+            }
         }
     for (int i = 0; i < L; i++) {
         bool coeff = !ntt_resident || i == L - 1 || i + 1 == layer_before_reenc;
         // a conv / dense layer feeding another one hands its tensor over packed as well
         // ... and a limb layer feeding a DENSE limb layer hands it over in limb form (not across the chunk boundary: a dense layer's limb tensor is laid out for its
         // whole batch, the chunks are assembled into it below)
-        const bool to_dense_limb = i + 1 < L && limb[i] && limb[i + 1] && dynamic_pointer_cast<FullyConnectedLayer>(layers[i + 1]) && !(chunked && i + 1 == split);
+        const bool to_dense_limb = i + 1 < L && limb[i] && !streams[i] && limb[i + 1] && dynamic_pointer_cast<FullyConnectedLayer>(layers[i + 1]) && !(chunked && i + 1 == split);
         // ... and a one-channel convolution writes the limb tensor of a matrix-core CONVOLUTION behind it itself
         auto ci = dynamic_pointer_cast<ConvolutionalLayer>(layers[i]);
         auto cn = i + 1 < L ? dynamic_pointer_cast<ConvolutionalLayer>(layers[i + 1]) : nullptr;

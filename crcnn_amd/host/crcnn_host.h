@@ -132,6 +132,7 @@ private:
     // weights whose NTT form (k rows each) would take more than 75 % of HBM stay coefficient-form plaintexts (ONE row each) and are lifted + transformed a
     // ~2-GiB filter tile at a time inside every forward (SURVEY section 7's fall-back; PlainModelWoPad's fc3 with all eight primes of n = 16384 is 419 GB)
     bool streamed = false;
+    int stream_form = CRC_NTT;                              // operand form of the last streamed forward (CRC_NTTL: 64-filter limb tiles on the matrix cores)
     std::shared_ptr<DeviceBuffer> d_plain, d_wtile, d_ytile;
     int w_form = CRC_NTT;                                   // CRC_NTTP / CRC_NTTL / CRC_NTTL1 once Network::forward has put the weights into their MAC kernel's operand form
     std::shared_ptr<DeviceBuffer> d_w_canon;                // CRC_NTTL1 only: the canonical NTT-form weights
@@ -166,6 +167,7 @@ public:
 private:
     std::shared_ptr<DeviceBuffer> d_w, d_b[2];
     bool streamed = false;                                  // see ConvolutionalLayer
+    int stream_form = CRC_NTT;
     std::shared_ptr<DeviceBuffer> d_plain, d_wtile, d_ytile;
     int w_form = CRC_NTT;
     // A layer whose canonical NTT-form weights and their limb copy do not fit in HBM together (PlainModelWoPad's fc3 at n = 16384, k = 4: 202 + 182 GiB) never gets a
@@ -178,6 +180,7 @@ private:
     void upload();
     void packWeights(bool unpack);
     bool limbWeights(int B);
+    bool streamsOnMatrixCores(int B);                      // streamed, and a launch on B images takes the limb GEMM (forwardStreamed's 64-filter limb tiles)
 public:
     void deviceParameters(std::vector<std::shared_ptr<DeviceBuffer>> &out, bool allocate_only) override;
     int placement() override;

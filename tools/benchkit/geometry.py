@@ -24,10 +24,11 @@ def limb_exec_over_useful(kind, a, images, out_cts):
     return (-(-rows // 64) * 64 / rows) * ((ksteps + (ksteps & 1)) * 32 / (zd * xf * yf)) * (-(-nf // 32) * 32 / nf)
 
 
-def fused_plan(E, model):
+def fused_plan(E, model, names=None):
     """the layer sequence Network::fuse() (crcnn_amd/host) leaves, with its geometry: [kind, name, geometry, input shape, output shape] per layer.  Pooling layers fold
     into the convolution in front of them where crc_plan_fold_pool says so (the cost model behind the C ABI), batch-norm layers into the conv / dense layer behind
-    them.  Names are built the way the C++ classes build them, so bench.py can match bench_host's layer list against this plan."""
+    them.  Names are built the way the C++ classes build them, so bench.py can match bench_host's layer list against this plan.  `names` (bench_host's own list) settles
+    the one choice the host makes from the HBM it finds: a batch norm is not folded into a layer whose weights are streamed (the fold is applied to NTT-form weights)."""
     from crcnn_amd.netrun import TOPOLOGIES, out_shape
     shape, plan = (1, 28, 28), []
     for kind, name, a in TOPOLOGIES[model]:
@@ -47,7 +48,7 @@ def fused_plan(E, model):
     out, i = [], 0
     while i < len(folded):
         nxt = folded[i + 1] if i + 1 < len(folded) else None
-        if folded[i][0] == "bn" and nxt and nxt[0] in ("conv", "fc"):
+        if folded[i][0] == "bn" and nxt and nxt[0] in ("conv", "fc") and (names is None or folded[i][1] + "+" + nxt[1] in names):
             out.append([nxt[0], folded[i][1] + "+" + nxt[1], nxt[2], folded[i][3], nxt[4]]); i += 2
             continue
         out.append(folded[i]); i += 1
