@@ -87,6 +87,8 @@ def load():
     L.crc_decode.restype = ctypes.c_double; L.crc_decode.argtypes = [VP, PU]
     L.crc_bn_invstd_f32.argtypes = [ctypes.POINTER(ctypes.c_float), SZ, ctypes.POINTER(ctypes.c_float)]
     L.crc_plain_to_ntt.argtypes = [VP, VP, SZ, VP, VP]
+    L.crc_encode_f32_compact.argtypes = [VP, ctypes.POINTER(ctypes.c_float), SZ, PU, ctypes.POINTER(ctypes.c_int32)]
+    L.crc_plain_expand.argtypes = [VP, VP, SZ, VP, VP]
     L.crc_plain_to_delta.argtypes = [VP, VP, SZ, CI, VP, VP]
     L.crc_ntt_fwd.argtypes = [VP, VP, SZ, CI, VP]
     L.crc_ntt_inv.argtypes = [VP, VP, SZ, CI, VP]
@@ -293,6 +295,19 @@ class Engine:
         else:
             _chk(self.L.crc_encode_f64(self.c, values.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), values.size, _pu(out), cc.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))), "crc_encode_f64")
         return out, cc
+
+    COMPACT_WORDS = 96        # CRC_PLAIN_COMPACT_WORDS
+
+    def encode_to_device(self, values, d_plain, d_compact):
+        """float32 weights -> dense coefficient-form plaintexts [count][n] at d_plain: encoded in compact form on the host threads (96 words per weight, the only
+        coefficients the encoder sets), copied down as they are and zero-extended on the device.  d_compact: count * 96 * 8 bytes of device staging"""
+        values = np.ascontiguousarray(np.asarray(values, dtype=np.float32).reshape(-1))
+        cp = np.empty((values.size, self.COMPACT_WORDS), dtype=np.uint64)
+        _chk(self.L.crc_encode_f32_compact(self.c, values.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), values.size, _pu(cp), None), "crc_encode_f32_compact")
+        _chk(self.L.crc_memcpy_h2d(self.c, self.p(d_compact), cp.ctypes.data, cp.nbytes, self.stream), "crc_memcpy_h2d")
+        _chk(self.L.crc_plain_expand(self.c, self.p(d_compact), values.size, self.p(d_plain), self.stream), "crc_plain_expand")
+        self.sync()             # cp is the source of an asynchronous copy until here
+        return values.size
 
     def decode(self, plain):
         return self.L.crc_decode(self.c, _pu(np.ascontiguousarray(plain)))

@@ -18,6 +18,11 @@ extern "C" int crc_plain_to_ntt(crc_ctx *c, const uint64_t *d_plain, size_t coun
     CHECK_CTX(c); if (!d_plain || !d_out) return CRC_ERR_INVALID_ARGUMENT;
     return k_plain_ntt(c, d_plain, count, 1, true, d_out, S(stream));
 }
+extern "C" int crc_plain_expand(crc_ctx *c, const uint64_t *d_compact, size_t count, uint64_t *d_plain, void *stream)
+{
+    CHECK_CTX(c); if (!d_compact || !d_plain) return CRC_ERR_INVALID_ARGUMENT;
+    return k_plain_expand(c, d_compact, count, d_plain, S(stream));
+}
 extern "C" int crc_plain_to_delta(crc_ctx *c, const uint64_t *d_plain, size_t count, int form, uint64_t *d_out, void *stream)
 {
     CHECK_CTX(c); if (!d_plain || !d_out || !form_ok(form)) return CRC_ERR_INVALID_ARGUMENT;

@@ -7,6 +7,7 @@
 // uint64 "seed" entry points expand a public seed and exist for tests / bench / goldens only.  SEAL draws from std::random_device,
 // so the reference defines sampling laws, not bits.
 #include "ctx.h"
+#include "host_parallel.h"
 #include "chacha.h"
 #include <cmath>
 #include <cstring>
@@ -163,9 +164,11 @@ extern "C" int crc_gen_evk(const crc_ctx *c, uint64_t seed, const uint64_t *sk, 
 static int encrypt_impl(const crc_ctx *c, const uint64_t *pk, const uint64_t *plain, size_t count, const ChaChaKey &key, uint64_t stream_base, uint64_t *ct)
 {
     const int n = c->n, k = c->k;
+    // one keystream per ciphertext: ranges of ciphertexts on the host threads, the same bits however they are split
+    crc_host::parallel_for(count, 8, [&](size_t m0, size_t m1) {
     std::vector<u64> u((size_t)k * n), e((size_t)k * n);
-    for (size_t m = 0; m < count; m++) {
-        const u64 sid = stream_base + m;                  // one keystream per ciphertext
+    for (size_t m = m0; m < m1; m++) {
+        const u64 sid = stream_base + m;
         Rng r(key, (u32)sid, (u32)(sid >> 32), (u32)CHACHA_DOM_ENC_HOST << 24);
         u64 *o = ct + m * 2 * (size_t)k * n; const u64 *pl = plain + m * (size_t)n;
         ternary(c, r, u.data());
@@ -184,6 +187,7 @@ static int encrypt_impl(const crc_ctx *c, const uint64_t *pk, const uint64_t *pl
             }
         }
     }
+    });
     return CRC_OK;
 }
 extern "C" int crc_encrypt_key(const crc_ctx *c, const uint64_t *pk, const uint64_t *plain, size_t count, const uint8_t *key, uint64_t stream_base, uint64_t *ct)

@@ -7,6 +7,7 @@
 //   f expanded to 32 balanced ternary digits d_1..d_32 (weights 3^-m, ties toward zero), digit d_m stored on
 //   coefficient n-m with the opposite sign (x^n = -1 turns x^(n-m) into -x^-m).
 #include "ctx.h"
+#include "host_parallel.h"
 #include <cmath>
 #include <cstring>
 
@@ -51,6 +52,27 @@ int encode_one(const crc_ctx *c, double value, u64 *co)
     return n + 1;
 }
 
+// the same plaintext as encode_one in compact form: words 0..63 = coefficients 0..63, words 64..95 = coefficients n-32..n-1 (every other coefficient is zero)
+int encode_one_compact(const crc_ctx *c, double value, u64 *cp)
+{
+    const u64 t = c->t;
+    std::memset(cp, 0, sizeof(u64) * CRC_PLAIN_COMPACT_WORDS);
+    u64 ip[80];
+    const int64_t whole = (int64_t)std::round(value);
+    const int icc = encode_integer(t, whole, ip, 80);
+    double f = value - (double)whole;
+    for (int i = 0; i < icc && i < CRC_PLAIN_COMPACT_LOW; i++) cp[i] = ip[i];
+    if (f == 0) return icc;
+    for (int m = 1; m <= kFrac; m++) {
+        f *= 3;
+        const double mag = std::ceil(std::fabs(f) - 0.5);
+        const int64_t d = f >= 0 ? (int64_t)mag : -(int64_t)mag;
+        f -= (double)d;
+        cp[CRC_PLAIN_COMPACT_LOW + kFrac - m] = d == 0 ? 0 : (d > 0 ? t - (u64)d : (u64)(-d));
+    }
+    return c->n + 1;
+}
+
 int64_t balanced_value(u64 t, const u64 *cf, int cnt)
 {
     const u64 thr = (t + 1) >> 1;
@@ -65,14 +87,22 @@ extern "C" int crc_encode_f64(const crc_ctx *c, const double *v, size_t count, u
 {
     if (!c || !v || !plain) return CRC_ERR_INVALID_ARGUMENT;
     if (kInt + kFrac >= c->n + 1) return CRC_ERR_INVALID_ARGUMENT;            // encoder.cpp:993-996
-    for (size_t i = 0; i < count; i++) { int r = encode_one(c, v[i], plain + i * (size_t)c->n); if (cc) cc[i] = r; }
+    crc_host::parallel_for(count, 256, [&](size_t b, size_t e) { for (size_t i = b; i < e; i++) { int r = encode_one(c, v[i], plain + i * (size_t)c->n); if (cc) cc[i] = r; } });
     return CRC_OK;
 }
 extern "C" int crc_encode_f32(const crc_ctx *c, const float *v, size_t count, uint64_t *plain, int32_t *cc)
 {
     if (!c || !v || !plain) return CRC_ERR_INVALID_ARGUMENT;
     if (kInt + kFrac >= c->n + 1) return CRC_ERR_INVALID_ARGUMENT;
-    for (size_t i = 0; i < count; i++) { int r = encode_one(c, (double)v[i], plain + i * (size_t)c->n); if (cc) cc[i] = r; }
+    crc_host::parallel_for(count, 256, [&](size_t b, size_t e) { for (size_t i = b; i < e; i++) { int r = encode_one(c, (double)v[i], plain + i * (size_t)c->n); if (cc) cc[i] = r; } });
+    return CRC_OK;
+}
+extern "C" int crc_encode_f32_compact(const crc_ctx *c, const float *v, size_t count, uint64_t *compact, int32_t *cc)
+{
+    static_assert(CRC_PLAIN_COMPACT_LOW == kInt && CRC_PLAIN_COMPACT_HIGH == kFrac && CRC_PLAIN_COMPACT_WORDS == kInt + kFrac, "compact plaintext layout");
+    if (!c || !v || !compact) return CRC_ERR_INVALID_ARGUMENT;
+    if (kInt + kFrac >= c->n + 1) return CRC_ERR_INVALID_ARGUMENT;
+    crc_host::parallel_for(count, 1024, [&](size_t b, size_t e) { for (size_t i = b; i < e; i++) { int r = encode_one_compact(c, (double)v[i], compact + i * (size_t)CRC_PLAIN_COMPACT_WORDS); if (cc) cc[i] = r; } });
     return CRC_OK;
 }
 extern "C" double crc_decode(const crc_ctx *c, const uint64_t *plain)

@@ -1,0 +1,52 @@
+// host_parallel.h -- the host side's one threading primitive: contiguous ranges of an index space on a few std::threads.
+//
+// The client-side work (fractional encoding of 10^5..10^6 weights, one ChaCha20 keystream + three transforms per encrypted pixel) is independent per item and
+// bit-identical however it is split, so it runs on up to CRC_HOST_THREADS threads (default: the hardware's, at most 16 -- a GPU box's CPU share).  Threads come from
+// ONE budget per library: a caller that is itself one of many threads (benchkit's client encrypts images on a pool) finds the budget spent and runs its range
+// inline, so nested parallelism never multiplies thread counts.
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+
+namespace crc_host {
+inline int thread_limit()
+{
+    static const int lim = [] {
+        int v = 0;
+        if (const char *e = std::getenv("CRC_HOST_THREADS")) v = std::atoi(e);
+        if (v <= 0) v = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        return std::min(v, 64);
+    }();
+    return lim;
+}
+inline std::atomic<int> &budget() { static std::atomic<int> b{thread_limit() - 1}; return b; }    // threads beside the caller's own
+
+// fn(begin, end) over [0, count) in contiguous ranges of at least `grain` items; returns when all ranges are done.  fn must not throw.
+template <class F> void parallel_for(size_t count, size_t grain, F &&fn)
+{
+    if (count == 0) return;
+    size_t want = std::min<size_t>((count + grain - 1) / std::max<size_t>(1, grain), (size_t)thread_limit());
+    int extra = 0;
+    if (want > 1) {
+        int have = budget().load(std::memory_order_relaxed);
+        while (have > 0) {
+            const int take = std::min<int>(have, (int)want - 1);
+            if (budget().compare_exchange_weak(have, have - take, std::memory_order_acq_rel)) { extra = take; break; }
+        }
+    }
+    if (extra == 0) { fn((size_t)0, count); return; }
+    const size_t parts = (size_t)extra + 1, per = (count + parts - 1) / parts;
+    std::vector<std::thread> th;
+    th.reserve(extra);
+    for (size_t p = 1; p < parts; p++) {
+        const size_t b = std::min(count, p * per), e = std::min(count, b + per);
+        if (b < e) th.emplace_back([&fn, b, e] { fn(b, e); });
+    }
+    fn((size_t)0, std::min(count, per));
+    for (auto &t : th) t.join();
+    budget().fetch_add(extra, std::memory_order_acq_rel);
+}
+}  // namespace crc_host

@@ -535,6 +535,28 @@ int k_plain_ntt(crc_ctx *c, const u64 *d_plain, size_t count, int mode, bool do_
     return CRC_OK;
 }
 
+// compact plaintexts [count][CRC_PLAIN_COMPACT_WORDS] -> dense [count][n]: the fractional encoder only ever sets coefficients 0..63 (integer part) and n-32..n-1
+// (fraction), so the host ships 96 words per weight instead of n (PlainModelWoPad's fc3 at n = 16384: 0.3 GB over PCIe instead of 52 GB)
+__global__ void __launch_bounds__(256) plain_expand_kernel(const u64 *compact, u64 *out, int n)
+{
+    const size_t row = blockIdx.x;
+    const u64 *src = compact + row * (size_t)CRC_PLAIN_COMPACT_WORDS; u64 *dst = out + row * (size_t)n;
+    for (int s = threadIdx.x * 2; s < n; s += blockDim.x * 2) {
+        ulonglong2 v = make_ulonglong2(0, 0);
+        if (s < CRC_PLAIN_COMPACT_LOW) { v.x = src[s]; v.y = src[s + 1]; }
+        else if (s >= n - CRC_PLAIN_COMPACT_HIGH) { v.x = src[CRC_PLAIN_COMPACT_LOW + s - (n - CRC_PLAIN_COMPACT_HIGH)]; v.y = src[CRC_PLAIN_COMPACT_LOW + s + 1 - (n - CRC_PLAIN_COMPACT_HIGH)]; }
+        *reinterpret_cast<ulonglong2 *>(dst + s) = v;
+    }
+}
+int k_plain_expand(crc_ctx *c, const u64 *d_compact, size_t count, u64 *d_plain, hipStream_t st)
+{
+    if (count == 0) return CRC_OK;
+    if (count > 0x7fffffffu) return CRC_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(plain_expand_kernel, dim3((unsigned)count), dim3(256), 0, st, d_compact, d_plain, c->n);
+    HIPCHK(hipGetLastError());
+    return CRC_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // element-wise row kernels (HBM-bound): 16 B per lane
 // ---------------------------------------------------------------------------------------------------------------

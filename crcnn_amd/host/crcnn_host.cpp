@@ -1,6 +1,8 @@
 // crcnn_host.cpp -- implementation of the CrCNN-compatible C++ host classes on top of the C ABI (include/crcnn_hip.h).
 #include "crcnn_host.h"
+#include "../csrc/host_parallel.h"          // std::thread ranges (header only; no other csrc internals are used here: the engine is reached through the C ABI)
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -135,12 +137,32 @@ static shared_ptr<DeviceBuffer> uploadPlain(const vector<const Plaintext *> &pl,
     const int n = N(), k = mode == 3 ? 1 : K();
     auto out = make_shared<DeviceBuffer>(pl.size() * (size_t)k * n * 8);
     const size_t chunk = max<size_t>(1, min<size_t>(pl.size(), (64u << 20) / ((size_t)n * 8)));
-    DeviceBuffer stage(chunk * (size_t)n * 8);
-    vector<uint64_t> host(chunk * (size_t)n);
+    DeviceBuffer stage(chunk * (size_t)n * 8), cstage(chunk * (size_t)CRC_PLAIN_COMPACT_WORDS * 8);
+    vector<uint64_t> host, chost(chunk * (size_t)CRC_PLAIN_COMPACT_WORDS);
     for (size_t o = 0; o < pl.size(); o += chunk) {
         const size_t c = min(chunk, pl.size() - o);
-        for (size_t i = 0; i < c; i++) pl[o + i]->dense(host.data() + i * n, n);
-        chk(crc_memcpy_h2d(ctx(), stage.ptr, host.data(), c * (size_t)n * 8, nullptr), "crc_memcpy_h2d");
+        // what the fractional encoder produces has non-zero coefficients only at 0..63 and n-32..n-1: such plaintexts travel in compact form (96 words each,
+        // crc_plain_expand zero-extends them on the device); anything else -- a plaintext loaded from a file may be arbitrary -- goes down dense
+        atomic<bool> compact{true};
+        crc_host::parallel_for(c, 64, [&](size_t b, size_t e) {
+            for (size_t i = b; i < e; i++) {
+                uint64_t *row = chost.data() + i * CRC_PLAIN_COMPACT_WORDS;
+                memset(row, 0, sizeof(uint64_t) * CRC_PLAIN_COMPACT_WORDS);
+                for (auto &z : pl[o + i]->nz) {
+                    if (z.first < CRC_PLAIN_COMPACT_LOW) row[z.first] = z.second;
+                    else if (z.first >= n - CRC_PLAIN_COMPACT_HIGH && z.first < n) row[CRC_PLAIN_COMPACT_LOW + z.first - (n - CRC_PLAIN_COMPACT_HIGH)] = z.second;
+                    else { compact = false; return; }
+                }
+            }
+        });
+        if (compact) {
+            chk(crc_memcpy_h2d(ctx(), cstage.ptr, chost.data(), c * (size_t)CRC_PLAIN_COMPACT_WORDS * 8, nullptr), "crc_memcpy_h2d");
+            chk(crc_plain_expand(ctx(), (const uint64_t *)cstage.ptr, c, (uint64_t *)stage.ptr, nullptr), "crc_plain_expand");
+        } else {
+            host.resize(chunk * (size_t)n);
+            crc_host::parallel_for(c, 64, [&](size_t b, size_t e) { for (size_t i = b; i < e; i++) pl[o + i]->dense(host.data() + i * n, n); });
+            chk(crc_memcpy_h2d(ctx(), stage.ptr, host.data(), c * (size_t)n * 8, nullptr), "crc_memcpy_h2d");
+        }
         uint64_t *dst = (uint64_t *)out->ptr + o * (size_t)k * n;
         if (mode == 3) chk(crc_memcpy_d2d(ctx(), dst, stage.ptr, c * (size_t)n * 8, nullptr), "crc_memcpy_d2d");
         else if (mode == 0) chk(crc_plain_to_ntt(ctx(), (const uint64_t *)stage.ptr, c, dst, nullptr), "crc_plain_to_ntt");
@@ -1132,11 +1154,19 @@ vector<float> CnnBuilder::getPretrained(string var_name)
 }
 static vector<Plaintext> encodeAll(const vector<float> &v)
 {
+    // compact form (crc_encode_f32_compact: the 96 coefficients the encoder can set), encoded and turned into Plaintexts on the host threads (csrc/host_parallel.h)
     const int n = N();
-    vector<uint64_t> co(v.size() * (size_t)n); vector<int32_t> cc(v.size());
-    chk(crc_encode_f32(ctx(), v.data(), v.size(), co.data(), cc.data()), "crc_encode_f32");
+    vector<uint64_t> cp(v.size() * (size_t)CRC_PLAIN_COMPACT_WORDS); vector<int32_t> cc(v.size());
+    chk(crc_encode_f32_compact(ctx(), v.data(), v.size(), cp.data(), cc.data()), "crc_encode_f32_compact");
     vector<Plaintext> out(v.size());
-    for (size_t i = 0; i < v.size(); i++) out[i] = fromDense(co.data() + i * n, n, cc[i]);
+    crc_host::parallel_for(v.size(), 256, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; i++) {
+            const uint64_t *row = cp.data() + i * CRC_PLAIN_COMPACT_WORDS;
+            Plaintext &p = out[i]; p.coeff_count_ = cc[i];
+            for (int j = 0; j < CRC_PLAIN_COMPACT_LOW; j++) if (row[j]) p.nz.emplace_back(j, row[j]);
+            for (int j = 0; j < CRC_PLAIN_COMPACT_HIGH; j++) if (row[CRC_PLAIN_COMPACT_LOW + j]) p.nz.emplace_back(n - CRC_PLAIN_COMPACT_HIGH + j, row[CRC_PLAIN_COMPACT_LOW + j]);
+        }
+    });
     return out;
 }
 ConvolutionalLayer *CnnBuilder::buildConvolutionalLayer(string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf, int nf, int th_count, istream *infile)

@@ -188,7 +188,7 @@ class Network:
             ft = int(max(1, min(nf, (4 << 30) // (T * rowb))))
             wt = self.alloc(ft * T * rowb)
             chunk = max(1, min(self._encode_chunk, ft * T))
-            stage = self.alloc(chunk * E.n * 8)
+            stage = self.alloc(chunk * E.n * 8); cstage = self.alloc(chunk * E.COMPACT_WORDS * 8)
             bn = p.get("bn_fold")
             if bn:
                 fake = self.alloc(T * 2 * rowb); outc = self.alloc(ft * 2 * rowb)
@@ -203,9 +203,8 @@ class Network:
                 fn = min(ft, nf - f0)
                 vals = np.ascontiguousarray(wv[f0:f0 + fn]).reshape(-1)
                 for o in range(0, vals.size, chunk):
-                    pl, _ = E.encode(vals[o:o + chunk])
-                    E.L.crc_memcpy_h2d(E.c, E.p(stage), pl.ctypes.data, pl.nbytes, E.stream)
-                    E.plain_to_ntt(stage, len(pl), E.p(wt) + o * rowb)
+                    cnt = E.encode_to_device(vals[o:o + chunk], stage, cstage)
+                    E.plain_to_ntt(stage, cnt, E.p(wt) + o * rowb)
                     E.sync()
                 if bn:
                     for f in range(fn):          # w'[f][z][tap] = w (*) s[z]
@@ -222,7 +221,7 @@ class Network:
                 E.sync()
                 for b_ in (fake, outc, wk):
                     self._free(b_)
-            self._free(wt); self._free(stage)
+            self._free(wt); self._free(stage); self._free(cstage)
             tw["built"] = want
 
     def _limb_operands(self, B=None, B_tail=None, split=None):
@@ -409,11 +408,18 @@ class Network:
         if not self.materialize:
             return out
         stage = self.alloc(min(chunk, vals.size) * E.n * 8)
+        cstage = self.alloc(min(chunk, vals.size) * E.COMPACT_WORDS * 8) if dtype == np.float32 else None
         for o in range(0, vals.size, chunk):
-            pl, _ = E.encode(vals[o:o + chunk], dtype=dtype)
-            E.L.crc_memcpy_h2d(E.c, E.p(stage), pl.ctypes.data, pl.nbytes, E.stream)
-            E.plain_to_ntt(stage, len(pl), E.p(out) + o * E.k * E.n * 8)
+            if cstage is not None:          # 96 words per weight over PCIe, zero-extended on the device
+                cnt = E.encode_to_device(vals[o:o + chunk], stage, cstage)
+            else:
+                pl, _ = E.encode(vals[o:o + chunk], dtype=dtype); cnt = len(pl)
+                E.L.crc_memcpy_h2d(E.c, E.p(stage), pl.ctypes.data, pl.nbytes, E.stream)
+            E.plain_to_ntt(stage, cnt, E.p(out) + o * E.k * E.n * 8)
             E.sync()
+        self._free(stage)
+        if cstage is not None:
+            self._free(cstage)
         return out
 
     def _encode_plain(self, vals, chunk, dtype=np.float32):
@@ -425,10 +431,16 @@ class Network:
         self.param_bufs.append((out, vals.size * E.n * 8))
         if not self.materialize:
             return out
+        cstage = self.alloc(min(chunk, vals.size) * E.COMPACT_WORDS * 8) if dtype == np.float32 else None
         for o in range(0, vals.size, chunk):
-            pl, _ = E.encode(vals[o:o + chunk], dtype=dtype)
-            E.L.crc_memcpy_h2d(E.c, E.p(out) + o * E.n * 8, pl.ctypes.data, pl.nbytes, E.stream)
-            E.sync()
+            if cstage is not None:
+                E.encode_to_device(vals[o:o + chunk], E.p(out) + o * E.n * 8, cstage)
+            else:
+                pl, _ = E.encode(vals[o:o + chunk], dtype=dtype)
+                E.L.crc_memcpy_h2d(E.c, E.p(out) + o * E.n * 8, pl.ctypes.data, pl.nbytes, E.stream)
+                E.sync()
+        if cstage is not None:
+            self._free(cstage)
         return out
 
     def _delta(self, vals, form):

@@ -130,6 +130,13 @@ int crc_event_elapsed_ms(crc_ctx *ctx, void *event_start, void *event_end, float
 int    crc_encode_f32(const crc_ctx *ctx, const float *h_values, size_t count, uint64_t *h_plain /*[count][n]*/, int32_t *h_coeff_count);
 int    crc_encode_f64(const crc_ctx *ctx, const double *h_values, size_t count, uint64_t *h_plain, int32_t *h_coeff_count);
 double crc_decode(const crc_ctx *ctx, const uint64_t *h_plain /*[n]*/);
+/* the same plaintexts in COMPACT form: the encoder only ever sets coefficients 0..63 (integer part: at most ceil(64 / log2 3) + 1 = 42 digits) and n-32..n-1
+ * (fraction), so a weight travels as CRC_PLAIN_COMPACT_WORDS words -- words 0..63 = coefficients 0..63, words 64..95 = coefficients n-32..n-1 -- and
+ * crc_plain_expand (below) zero-extends it on the device.  PlainModelWoPad's fc3 at n = 16384: 0.3 GB over PCIe instead of 52 GB. */
+#define CRC_PLAIN_COMPACT_LOW   64
+#define CRC_PLAIN_COMPACT_HIGH  32
+#define CRC_PLAIN_COMPACT_WORDS 96
+int    crc_encode_f32_compact(const crc_ctx *ctx, const float *h_values, size_t count, uint64_t *h_compact /*[count][96]*/, int32_t *h_coeff_count);
 /* batch-norm parameters: invstd = float(1/sqrt(double(var)+0.00001))  (cnnBuilder.cpp:100-102) */
 int    crc_bn_invstd_f32(const float *h_var, size_t count, float *h_invstd);
 
@@ -141,6 +148,8 @@ int    crc_bn_invstd_f32(const float *h_var, size_t count, float *h_invstd);
  *                        "negative" c) mod q_i.  form=CRC_NTT additionally NTTs it (for NTT-resident tensors).
  * ------------------------------------------------------------------------------------------------------------- */
 int crc_plain_to_ntt(crc_ctx *ctx, const uint64_t *d_plain, size_t count, uint64_t *d_out, void *stream);
+/* compact plaintexts on the device (crc_encode_f32_compact, copied down as they are) -> dense [count][n] for the two calls around this one */
+int crc_plain_expand(crc_ctx *ctx, const uint64_t *d_compact /*[count][96]*/, size_t count, uint64_t *d_plain /*[count][n]*/, void *stream);
 int crc_plain_to_delta(crc_ctx *ctx, const uint64_t *d_plain, size_t count, int form, uint64_t *d_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------------

@@ -15,7 +15,36 @@ def load_net_golden(name):
 
 
 def sha(a):
-    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    return hashlib.sha256(np.ascontiguousarray(a)).hexdigest()          # (the array's own buffer: no second copy of a multi-GB tensor)
+
+
+_PIECES = []
+
+
+def sha_device(E, buf, nbytes, offset=0, piece=64 << 20):
+    """SHA-256 of nbytes of a device buffer, streamed through two reused 64-MiB host pieces: the next piece is copied down while the previous one is hashed
+    (hashlib releases the GIL), and no multi-GB host tensor is allocated and page-faulted just to be hashed once (PlainModelWoPad's conv1 output at n = 16384
+    is 11.5 GB: the layer-wise parity tests spent a third of their time there)"""
+    from concurrent.futures import ThreadPoolExecutor
+    if not _PIECES:
+        _PIECES.extend(np.empty(piece, dtype=np.uint8) for _ in range(2))
+    h = hashlib.sha256()
+    base = E.p(buf) + offset
+    E.sync()
+    with ThreadPoolExecutor(1) as pool:
+        pending = None
+        for j, o in enumerate(range(0, nbytes, piece)):
+            m = min(piece, nbytes - o)
+            dst = _PIECES[j & 1]
+            from crcnn_amd.binding import _chk
+            _chk(E.L.crc_memcpy_d2h(E.c, dst.ctypes.data, base + o, m, E.stream), "crc_memcpy_d2h")
+            E.sync()
+            if pending is not None:
+                pending.result()
+            pending = pool.submit(h.update, dst[:m])
+        if pending is not None:
+            pending.result()
+    return h.hexdigest()
 
 
 _INPUTS = {}

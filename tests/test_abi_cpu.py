@@ -62,6 +62,26 @@ def test_host_tables_and_encoder_match_reference(path):
 
 
 @pytest.mark.parametrize("path", SETS, ids=[os.path.basename(s)[:-4] for s in SETS])
+def test_compact_plaintexts_are_the_dense_ones(path):
+    """crc_encode_f32_compact (96 words per weight: coefficients 0..63 and n-32..n-1, what the host ships to the device) against crc_encode_f32, itself pinned
+    to the reference's fraencoder above: the golden's floats, integers of both signs up to 2^62, tiny fractions, and random weights"""
+    import ctypes
+    g = dict(np.load(path))
+    E = ca.Engine(int(g["n"]), [int(x) for x in g["q"]], int(g["t"]), device=-1)
+    rng = np.random.default_rng(7)
+    vals = np.concatenate([np.asarray(g["floats"], dtype=np.float32), np.array([0, 1, -1, 2.5, -2.5, 3 ** 20, -(3.0 ** 20), 2.0 ** 62, -(2.0 ** 62), 1e-9, -1e-9, 1 / 3, -1 / 3], dtype=np.float32),
+                           rng.standard_normal(3000).astype(np.float32), (rng.standard_normal(200) * 1e6).astype(np.float32)])
+    dense, cc = E.encode(vals)
+    cp = np.zeros((vals.size, E.COMPACT_WORDS), dtype=np.uint64); cc2 = np.zeros(vals.size, dtype=np.int32)
+    assert E.L.crc_encode_f32_compact(E.c, vals.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), vals.size, cp.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+                                      cc2.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))) == 0
+    assert np.array_equal(cc, cc2)
+    assert np.array_equal(dense[:, :64], cp[:, :64]) and np.array_equal(dense[:, E.n - 32:], cp[:, 64:])
+    assert not dense[:, 64:E.n - 32].any()
+    E.close()
+
+
+@pytest.mark.parametrize("path", SETS, ids=[os.path.basename(s)[:-4] for s in SETS])
 def test_client_side_interoperates_with_reference(path):
     """engine decrypts the reference's (SEAL-made) ciphertexts; oracle (pinned to SEAL) decrypts the engine's"""
     g = dict(np.load(path))

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from netcommon import GOLD, load_net_golden, make_inputs, sha
+from netcommon import GOLD, load_net_golden, make_inputs, sha, sha_device
 
 pytestmark = pytest.mark.gpu
 
@@ -33,9 +33,8 @@ def run_net(name, resident, batch=1):
 
     def timer(i, lname, kind, phase):
         if phase == 1 and not resident:      # coefficient form between layers: the reference's own layer boundary
-            oshape = net.plan[i][5]
-            t = E.download(net.buf[net.slots[i]], (batch,) + tuple(oshape) + (2, E.k, E.n))
-            digests[i] = [sha(t[b]) for b in range(batch)]
+            per_image = int(np.prod(net.plan[i][5])) * 2 * E.k * E.n * 8
+            digests[i] = [sha_device(E, net.buf[net.slots[i]], per_image, b * per_image) for b in range(batch)]
 
     d_out = net.forward(d_x, batch, timer=timer)
     out = E.download(d_out, (batch, 1, 10, 1, 2, E.k, E.n))
@@ -208,15 +207,15 @@ def test_baseline_configs0_in_full():
     E = ca.Engine(c1["n"], c1["q"], c1["t"], device=0)
     sk, pk = E.keygen(c1["key_seed"])
     xs = []
-    for i in range(32):
+    for i in range(32):         # (crc_encrypt spreads an image's 784 ciphertexts over the host threads: one keystream per ciphertext)
         pl, _ = E.encode(synth.normalize(synth.synth_image(i)).reshape(-1))
         x = E.encrypt(pk, pl, c1["enc_seed_base"] + c1["enc_seed_stride"] * i)
-        assert hashlib.sha256(np.ascontiguousarray(x).tobytes()).hexdigest() == c1["images"][str(i)]["input_sha256"], i
+        assert sha(x) == c1["images"][str(i)]["input_sha256"], i
         xs.append(x.reshape(28 * 28, 2, E.k, E.n))
     net = Network(E, "PlainModelTiny", h5_path=os.path.join(GOLD, "models", "PlainModelTiny.h5"), resident=True)
     net.prepare(32)
     out = E.download(net.forward(E.upload(np.ascontiguousarray(np.stack(xs))), 32), (32, 10, 2, E.k, E.n))
-    bad = [i for i in range(32) if hashlib.sha256(np.ascontiguousarray(out[i]).tobytes()).hexdigest() != c1["images"][str(i)]["out_sha256"]]
+    bad = [i for i in range(32) if sha(out[i]) != c1["images"][str(i)]["out_sha256"]]
     assert not bad, bad
     from oracle import orc
     O = orc.Oracle(c1["n"], c1["q"], c1["t"])

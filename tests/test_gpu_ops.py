@@ -40,6 +40,17 @@ def test_plain_to_ntt(gs):
     assert np.array_equal(E.download(d_o, (len(pl), E.k, E.n)), g["ref_plain_ntt"])
 
 
+def test_compact_plaintexts_expand_on_the_device(gs):
+    """crc_plain_expand: the 96-word compact plaintexts the host ships (crc_encode_f32_compact) zero-extended to [count][n] on the device == the dense encoding"""
+    g, E = gs
+    vals = np.concatenate([np.asarray(g["floats"], dtype=np.float32), np.random.default_rng(3).standard_normal(777).astype(np.float32)])
+    dense, _ = E.encode(vals)
+    d_p = E.alloc(vals.size * E.n * 8); d_c = E.alloc(vals.size * E.COMPACT_WORDS * 8)
+    E.L.crc_memset(E.c, E.p(d_p), 0xff, vals.size * E.n * 8, E.stream)
+    assert E.encode_to_device(vals, d_p, d_c) == vals.size
+    assert np.array_equal(E.download(d_p, dense.shape), dense)
+
+
 def test_add(gs):
     g, E = gs
     cts = g["ct_in"]; nct = len(cts)
