@@ -1,0 +1,5 @@
+set -x
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r4o; mkdir -p $O
+( time timeout -k 10 900 python -m pytest tests -x -q -m gpu --durations=40 ) > $O/tests.log 2>&1; echo "pytest exit $?" >> $O/tests.log
+tail -8 $O/tests.log
