@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 int D[13];
 #pragma unroll
                 for (int d = 0; d < 13; d++) D[d] = acc[rs][cs][d][reg];
-                u64 v = diag_reduce(D, m, qinv);
+                u64 v = diag_reduce_w(D, m, qinv);
                 if ((reg & 1) == 0) v = addmod(v, bv, m.q);
                 if (a.xl_out) {
                     const u32 rt = wm * 32 + rs * 16 + 4 * kg + reg, bl = rt >> a.lp2, qq = rt & (P2 - 1);        // row in the tile -> image in the tile, (pixel, poly)
@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     if ((slots & 7) == 0) { const int xcd = g & 7, r = g >> 3; slot = xcd * (slots >> 3) + r / per; tile = r % per; }
     else { slot = g / per; tile = g % per; }
     const int mt = a.mfast ? tile % a.mtiles : tile / ntiles2, nt = a.mfast ? tile / a.mtiles : tile % ntiles2;
-    const int i = slot / a.n, s = slot % a.n;
+    const int lgn = __builtin_ctz(a.n), i = slot >> lgn, s = slot & (a.n - 1);          // (n is a power of two)
     const int m0 = mt * 64, f0 = nt * 32;
     if (f0 >= a.F) return;                                        // a 32-filter tile that is all padding (filters are padded to 64): nothing to compute or store
     const ModParams m = a.mods[i];
@@ -234,30 +234,41 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int wplane = a.Fp * 32, wstep = NPL * a.Fp * 32;
     // A staging: 14 LDS-DMA pieces of 1 KiB per 32-term step, pieces wave, wave + 4, ...; waves 2 and 3 load pieces 10 / 11 twice so that every wave issues four
     // loads per step (uniform counts: the waits below are immediates)
+    // (round 4: a thread's four pieces are the same tile row -- piece parity = wave parity -- in four planes, so the row's image / pixel / window origin is divided
+    // out ONCE, not per piece: the start-up of a tile was 690 vector + 900 scalar instructions, most of them these divisions and the ones of the step addresses below)
     u32 src_off[4]; int pcs[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int pc = wave + 4 * j < 14 ? wave + 4 * j : wave + 8, c16 = pc * 64 + lane;
-        pcs[j] = pc;
-        const int plane = c16 >> 7, row = (c16 >> 1) & 63, half = c16 & 1;
+    {
+        const int row = ((wave & 1) << 5) + (lane >> 1), half = lane & 1;
         const int mm = min(m0 + row, a.M - 1);
-        const int b = mm / (2 * a.P), p = (mm >> 1) % a.P, c = mm & 1;
-        const int ox = p / a.yo, oy = p % a.yo;
-        src_off[j] = a.npos == 1 ? (u32)(plane * a.zblks * (2 * a.B) + mm) * 32 + half * 16
-                   : a.flat ? (u32)b * a.img_bytes + (u32)(plane * a.fplane + (c * a.npos + (ox * a.xs) * a.yd + oy * a.ys_) * a.zdc + half * 16)
-                            : (u32)b * a.img_bytes + (u32)(plane * (a.npos * 2 * a.zdp) + (((ox * a.xs) * a.yd + oy * a.ys_) * 2 + c) * a.zdp + half * 16);
+        const int b = mm / (2 * a.P), rem = mm - b * (2 * a.P), p = rem >> 1, c = rem & 1;
+        const int ox = p / a.yo, oy = p - ox * a.yo;
+        const u32 rowpart = a.npos == 1 ? (u32)mm * 32 + half * 16
+                          : a.flat ? (u32)b * a.img_bytes + (u32)((c * a.npos + (ox * a.xs) * a.yd + oy * a.ys_) * a.zdc + half * 16)
+                                   : (u32)b * a.img_bytes + (u32)((((ox * a.xs) * a.yd + oy * a.ys_) * 2 + c) * a.zdp + half * 16);
+        const u32 pstride = a.npos == 1 ? (u32)(a.zblks * (2 * a.B)) * 32 : a.flat ? a.fplane : (u32)(a.npos * 2 * a.zdp);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            pcs[j] = wave + 4 * j < 14 ? wave + 4 * j : wave + 8;
+            src_off[j] = rowpart + (u32)(pcs[j] >> 1) * pstride;          // plane = piece / 2
+        }
     }
     const int kreal = a.ksteps_real;
+    // A(ks) is issued for ks = 0, 1, 2, ... in order (the first loads, then two per double step), so the step's address offset and ring buffer are running counters
+    // instead of three divisions per step; the padding step of an odd reduction re-reads the last real one (its weights are zero)
+    int iss = 0, ibuf = 0, zb = 0, ky = 0, kx = 0;
+    u32 delta = 0;
     auto issue_a = [&](int ks) {
-        const int ka = min(ks, kreal - 1);
-        const int tap = ka / a.zblks, zb = ka - tap * a.zblks;
-        const int kx = tap / a.yf, ky = tap - kx * a.yf;
-        const int fkx = ka / a.S;                                    // flat form: window row, piece of its run
-        const u32 delta = a.npos == 1 ? (u32)zb * (2 * a.B) * 32 : a.flat ? (u32)(fkx * a.yd * a.zdc + (ka - fkx * a.S) * 32) : (u32)((kx * a.yd + ky) * 2 * a.zdp + zb * 32);
-        i8 *dst = lds + (ks % NST) * TILE_A;
+        (void)ks;                                                     // == iss
+        i8 *dst = lds + ibuf * TILE_A;
 #pragma unroll
         for (int j = 0; j < 4; j++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xs + src_off[j] + delta), (__attribute__((address_space(3))) void *)(dst + pcs[j] * 1024), 16, 0, 0);
+        iss++; ibuf = ibuf + 1 == NST ? 0 : ibuf + 1;
+        if (iss < kreal) {
+            if (a.npos == 1) delta += (u32)(2 * a.B) * 32;                                                           // next 32-channel block
+            else if (a.flat) { if (++zb == a.S) { zb = 0; kx++; } delta = (u32)(kx * a.yd * a.zdc + zb * 32); }    // next piece of the window row's run, or next window row
+            else { if (++zb == a.zblks) { zb = 0; if (++ky == a.yf) { ky = 0; kx++; } } delta = (u32)((kx * a.yd + ky) * 2 * a.zdp + zb * 32); }
+        }
     };
     auto load_w = [&](int ks, v4i (&w)[NPL]) {
         const i8 *pw = wlane + (size_t)ks * wstep;
@@ -313,22 +324,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         if (ks + 2 < K) dstep(ks + 2, w1, w0);
         if (ks + 4 < K) dstep(ks + 4, w2, w1);
     }
-    // epilogue as in mfma_mac_kernel: 8 outputs per lane
+    // epilogue: 8 outputs per lane (diag_reduce_w: the reduction in 32-bit words)
     u64 *yslot = a.ys + (size_t)slot * a.B * a.F * (2 * a.P);
     const u32 P2 = 2 * a.P;
     const u32 RL = 32 * a.P;                                      // bytes of one run of a direct limb result (this tile's 32 filters)
     if (a.xl_out) __syncthreads();
     const int fl = wn * 16 + r16, f = f0 + fl;
     const u64 bv = (a.bias && f < a.F) ? a.bias[((size_t)f * a.k + i) * a.n + s] : 0;
+    const u32 img_jump = (u32)(a.F - 1) * P2;                     // Ys [image][filter][2P]: rows run on inside an image's filter block, the next image's is F - 1 blocks further
 #pragma unroll
     for (int rs = 0; rs < 2; rs++) {
         const u32 mbase = m0 + wm * 32 + rs * 16 + 4 * kg, bb = mbase / P2, rem = mbase - bb * P2;
+        const u32 idx0 = bb * img_jump + (u32)f * P2 + mbase;
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
             int D[13];
 #pragma unroll
             for (int d = 0; d < 13; d++) D[d] = acc[rs][d][reg];
-            u64 v = diag_reduce(D, m, qinv);
+            u64 v = diag_reduce_w(D, m, qinv);
             if ((reg & 1) == 0) v = addmod(v, bv, m.q);
             if (a.xl_out) {
                 const u32 rt = wm * 32 + rs * 16 + 4 * kg + reg, bl = rt >> a.lp2, qq = rt & (P2 - 1);
@@ -337,8 +350,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                 for (int l = 0; l < NPL; l++) sp[(size_t)l * (2 * RL)] = (i8)(dg >> (8 * l));
             } else {
-                const u32 r = rem + reg, b = bb + (r >= P2) + (r >= 2 * P2);
-                if (mbase + reg < (u32)a.M && f < a.F) yslot[b * (u32)(a.F - 1) * P2 + (u32)f * P2 + mbase + reg] = v;
+                const u32 r = rem + reg, over = (u32)(r >= P2) + (u32)(r >= 2 * P2);
+                if (mbase + reg < (u32)a.M && f < a.F) yslot[idx0 + reg + over * img_jump] = v;
             }
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -11,6 +11,15 @@
 #pragma once
 #include "modarith.h"
 
+CRC_HD u32 crc_alignbit(u32 hi, u32 lo, u32 sh)      // low word of (hi:lo) >> sh, 0 <= sh < 32
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+    return (u32)((((u64)hi << 32) | lo) >> sh);
+#endif
+}
+
 // generic form: any 32-bit D'_d (reductions of up to 18 000 terms), 0 < U < 2^127.  The diagonals d = r (mod 4) are the words of one number each (no overlap); U is
 // their sum at byte offsets 0..3.  After the Montgomery step t + q is in (0, 2^63 + q): folded (q = 2^b - f) or Barrett-reduced to the canonical residue.
 CRC_HD u64 diag_reduce(const int (&D)[13], const ModParams &m, u64 qinv)
@@ -26,6 +35,28 @@ CRC_HD u64 diag_reduce(const int (&D)[13], const ModParams &m, u64 qinv)
     const u64 t = uhi - mulhi64(mq, m.q) + m.q;                  // in (0, 2^63 + q)
     if (m.fold) {                                                 // 2^b = f (mod q): (t >> b) < 2^12, f < 2^26
         const u64 r = (t & (((u64)1 << m.bits) - 1)) + (u64)(u32)(t >> m.bits) * (u32)m.fold;        // one 32 x 32 multiply
+        return r >= m.q ? r - m.q : r;
+    }
+    return barrett128(t, 0, m);
+}
+
+// The same value from pre-shifted 32-bit words (round 4).  The compiler lowers the 128-bit shifts of s1 << 8, s2 << 16, s3 << 24 above to chains of 64-bit shifts and
+// ors (a quarter of the epilogue's instructions); here every shifted word is one v_alignbit_b32, the four numbers add as two carry chains, and the fold after the
+// Montgomery step works on the upper word (bits >= 32 for every modulus with a fold constant).  Same contract, same result as diag_reduce.
+CRC_HD u64 diag_reduce_w(const int (&D)[13], const ModParams &m, u64 qinv)
+{
+    typedef unsigned __int128 u128;
+    const u32 a0 = (u32)D[1] << 8,  a1 = crc_alignbit((u32)D[5], (u32)D[1], 24), a2 = crc_alignbit((u32)D[9], (u32)D[5], 24),  a3 = (u32)D[9] >> 24;
+    const u32 b0 = (u32)D[2] << 16, b1 = crc_alignbit((u32)D[6], (u32)D[2], 16), b2 = crc_alignbit((u32)D[10], (u32)D[6], 16), b3 = (u32)D[10] >> 16;
+    const u32 c0 = (u32)D[3] << 24, c1 = crc_alignbit((u32)D[7], (u32)D[3], 8),  c2 = crc_alignbit((u32)D[11], (u32)D[7], 8),  c3 = (u32)D[11] >> 8;
+    auto w128 = [](u32 w3, u32 w2, u32 w1, u32 w0) { return ((u128)(((u64)w3 << 32) | w2) << 64) | (((u64)w1 << 32) | w0); };
+    const u128 U = w128((u32)D[12], (u32)D[8], (u32)D[4], (u32)D[0]) + w128(a3, a2, a1, a0) + w128(b3, b2, b1, b0) + w128(c3, c2, c1, c0);
+    const u64 ulo = (u64)U, uhi = (u64)(U >> 64);
+    const u64 mq = ulo * qinv;
+    const u64 t = uhi - mulhi64(mq, m.q) + m.q;                  // in (0, 2^63 + q)
+    if (m.fold) {                                                 // 2^b = f (mod q), b >= 52: (t >> b) < 2^12 lives in the upper word
+        const u32 th = (u32)(t >> 32), sb = m.bits - 32;
+        const u64 r = (((u64)(th & ((1u << sb) - 1)) << 32) | (u32)t) + (u64)(th >> sb) * (u32)m.fold;
         return r >= m.q ? r - m.q : r;
     }
     return barrett128(t, 0, m);
@@ -83,14 +114,6 @@ CRC_HD bool conv1_fold_ok(u64 q, u32 bits, u32 fold)
 }
 // (written in 32-bit words: b >= 53 puts every shift by b inside the upper words -- v_alignbit_b32 -- and every multiply-add is one v_mad_u64_u32 with its 64-bit addend;
 // the compiler's own lowering of the same arithmetic on 64-bit values spent 22 64-bit shifts and 9 64-bit adds per output)
-CRC_HD u32 crc_alignbit(u32 hi, u32 lo, u32 sh)      // low word of (hi:lo) >> sh, 0 <= sh < 32
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_alignbit(hi, lo, sh);
-#else
-    return (u32)((((u64)hi << 32) | lo) >> sh);
-#endif
-}
 // PB: the accumulator biases of conv1_bias_table pair by pair, PB_j = B_2j + B_2j+1 2^8 (j < 6), PB_6 = B_12 -- null when the diagonals arrive biased already.  (The
 // kernel starts its accumulators at ZERO -- an inline constant of the first MFMA that touches a diagonal, instead of 13 x 4 register moves per tile -- and adds the biases
 // here, one word add per pair: D + B is the same word either way.)

@@ -94,6 +94,7 @@ int main()
                 }
                 {
                     if (shortform) { int Bg[13]; limb_bias_table(q, T, Bg); for (int d = 0; d < 13; d++) Ds[d] = (int)(D[d] - (u32)B[d] + (u32)Bg[d]); }
+                    if (diag_reduce_w(Ds, m, qinv) != expect) { printf("diag_reduce_w mismatch q=%llx T=%d mode=%d fold=%d\n", (unsigned long long)q, T, mode, fold); return 1; }
                     if (diag_reduce(Ds, m, qinv) != expect) { printf("diag_reduce mismatch q=%llx T=%d mode=%d fold=%d\n", (unsigned long long)q, T, mode, fold); return 1; }
                 }
                 checked++;
