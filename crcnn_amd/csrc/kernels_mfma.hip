@@ -42,6 +42,7 @@ typedef signed char i8;
 
 struct MfmaArgs {
     const i8 *xl; const i8 *wl; u64 *ys; const ModParams *mods; const u64 *bias;     // bias: NTT-form delta rows [F][k][n] added to poly 0, or null
+    int xcdmap;                                        // grid x carries the XCD in its low three bits (the slot count is a multiple of 8)
     int mfast;                                         // tile order inside a slot: row tiles fastest (neighbouring workgroups share the weight tile) instead of filter tiles fastest
     i8 *xl_out; int lp2; unsigned zdp_out;             // direct limb result for a dense consumer (2P = 2^lp2 divides 64): [slot][B][7][2][zdp_out], channel = f P + p
     int n, k, B, zdp, npos, yd, xs, ys_, yf, yo, P, F, Fp, zblks, ksteps, M, mtiles, ntiles;      // ksteps: rounded up to even (the weights carry a zero step)
@@ -212,16 +213,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 // straight from L2 into registers (a lane's fragment is 16 contiguous bytes of Wl; they are prefetched one double step ahead) and only A goes through LDS: 5 x 14 KiB per
 // workgroup, <= 256 registers per wave, so TWO workgroups share a CU and one's stalls are the other's issue slots.
 #define TILE_A (NPL * 64 * 32)
-template <int NST>
+// MODE: the tensor's addressing -- 0 a dense layer's K-blocked tensor (one position), 1 the flat form of a convolution with fewer than 32 channels, 2 32-channel blocks
+template <int NST, int MODE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) mfma_mac2w_kernel(MfmaArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) i8 lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 1, wn = wave & 1;
-    const int ntiles2 = a.Fp / 32, slots = a.n * a.k, per = a.mtiles * ntiles2;
-    int g = blockIdx.x, slot, tile;
-    if ((slots & 7) == 0) { const int xcd = g & 7, r = g >> 3; slot = xcd * (slots >> 3) + r / per; tile = r % per; }
-    else { slot = g / per; tile = g % per; }
-    const int mt = a.mfast ? tile % a.mtiles : tile / ntiles2, nt = a.mfast ? tile / a.mtiles : tile % ntiles2;
+    // 3-D grid (round 4: no divisions on the way to the tile): x = 8 * (fast tile index) + XCD -- the dispatcher deals consecutive workgroups to the eight XCDs in
+    // turn and gridDim.x is a multiple of 8 -- y = the slow tile index, z = the slot within the XCD's share.  The workgroups of an XCD walk the tiles of one slot, then
+    // of the next: its L2 holds that slot's operands meanwhile.  (Rings whose slot count is not a multiple of 8 -- none of CrCNN's -- put the slot in z as it is.)
+    const int slots = a.n * a.k;
+    const int fast = a.xcdmap ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, slow = (int)blockIdx.y;
+    const int slot = a.xcdmap ? (int)(blockIdx.x & 7) * (slots >> 3) + (int)blockIdx.z : (int)blockIdx.z;
+    const int mt = a.mfast ? fast : slow, nt = a.mfast ? slow : fast;
     const int lgn = __builtin_ctz(a.n), i = slot >> lgn, s = slot & (a.n - 1);          // (n is a power of two)
     const int m0 = mt * 64, f0 = nt * 32;
     if (f0 >= a.F) return;                                        // a 32-filter tile that is all padding (filters are padded to 64): nothing to compute or store
@@ -242,10 +246,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         const int mm = min(m0 + row, a.M - 1);
         const int b = mm / (2 * a.P), rem = mm - b * (2 * a.P), p = rem >> 1, c = rem & 1;
         const int ox = p / a.yo, oy = p - ox * a.yo;
-        const u32 rowpart = a.npos == 1 ? (u32)mm * 32 + half * 16
-                          : a.flat ? (u32)b * a.img_bytes + (u32)((c * a.npos + (ox * a.xs) * a.yd + oy * a.ys_) * a.zdc + half * 16)
+        const u32 rowpart = MODE == 0 ? (u32)mm * 32 + half * 16
+                          : MODE == 1 ? (u32)b * a.img_bytes + (u32)((c * a.npos + (ox * a.xs) * a.yd + oy * a.ys_) * a.zdc + half * 16)
                                    : (u32)b * a.img_bytes + (u32)((((ox * a.xs) * a.yd + oy * a.ys_) * 2 + c) * a.zdp + half * 16);
-        const u32 pstride = a.npos == 1 ? (u32)(a.zblks * (2 * a.B)) * 32 : a.flat ? a.fplane : (u32)(a.npos * 2 * a.zdp);
+        const u32 pstride = MODE == 0 ? (u32)(a.zblks * (2 * a.B)) * 32 : MODE == 1 ? a.fplane : (u32)(a.npos * 2 * a.zdp);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             pcs[j] = wave + 4 * j < 14 ? wave + 4 * j : wave + 8;
@@ -265,8 +269,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xs + src_off[j] + delta), (__attribute__((address_space(3))) void *)(dst + pcs[j] * 1024), 16, 0, 0);
         iss++; ibuf = ibuf + 1 == NST ? 0 : ibuf + 1;
         if (iss < kreal) {
-            if (a.npos == 1) delta += (u32)(2 * a.B) * 32;                                                           // next 32-channel block
-            else if (a.flat) { if (++zb == a.S) { zb = 0; kx++; } delta = (u32)(kx * a.yd * a.zdc + zb * 32); }    // next piece of the window row's run, or next window row
+            if (MODE == 0) delta += (u32)(2 * a.B) * 32;                                                           // next 32-channel block
+            else if (MODE == 1) { if (++zb == a.S) { zb = 0; kx++; } delta = (u32)(kx * a.yd * a.zdc + zb * 32); }    // next piece of the window row's run, or next window row
             else { if (++zb == a.zblks) { zb = 0; if (++ky == a.yf) { ky = 0; kx++; } } delta = (u32)((kx * a.yd + ky) * 2 * a.zdp + zb * 32); }
         }
     };
@@ -350,8 +354,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                 for (int l = 0; l < NPL; l++) sp[(size_t)l * (2 * RL)] = (i8)(dg >> (8 * l));
             } else {
-                const u32 r = rem + reg, over = (u32)(r >= P2) + (u32)(r >= 2 * P2);
-                if (mbase + reg < (u32)a.M && f < a.F) yslot[idx0 + reg + over * img_jump] = v;
+                const u32 r = rem + reg, jump = (r >= P2 ? img_jump : 0u) + (r >= 2 * P2 ? img_jump : 0u);
+                if (mbase + reg < (u32)a.M && f < a.F) yslot[idx0 + reg + jump] = v;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -711,11 +715,14 @@ int k_limb_mac(crc_ctx *c, const i8 *xl, const i8 *wl, u64 *ys, i8 *xl_out, cons
     a.mfast = c->tune.mfma_order >= 0 ? c->tune.mfma_order : (a.mtiles < a.Fp / 32 ? 1 : 0);
     const int variant = c->tune.mfma_variant;                    // 2 (default): two workgroups per CU (mfma_mac2w_kernel); 1: mfma_mac_kernel (the tests run both: crc_ctx_set_tuning)
     if (variant == 2) {
-        const size_t grid2 = (size_t)c->n * c->k * a.mtiles * (a.Fp / 32);
-        if (grid2 > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
+        const int slots = c->n * c->k, ntiles2 = a.Fp / 32;
+        a.xcdmap = (slots & 7) == 0 ? 1 : 0;
+        const unsigned gfast = (unsigned)(a.mfast ? a.mtiles : ntiles2) * (a.xcdmap ? 8u : 1u), gslow = (unsigned)(a.mfast ? ntiles2 : a.mtiles), gz = (unsigned)(a.xcdmap ? slots >> 3 : slots);
+        if (gslow > 65535u || gz > 65535u) return CRC_ERR_INVALID_ARGUMENT;
         const size_t lds = (size_t)5 * TILE_A;
-        { const int rc = crc_ctx_ensure_lds(c, (const void *)mfma_mac2w_kernel<5>, lds); if (rc) return rc; }
-        hipLaunchKernelGGL(mfma_mac2w_kernel<5>, dim3((unsigned)grid2), dim3(256), lds, st, a);
+        auto kern2 = a.npos == 1 ? mfma_mac2w_kernel<5, 0> : a.flat ? mfma_mac2w_kernel<5, 1> : mfma_mac2w_kernel<5, 2>;
+        { const int rc = crc_ctx_ensure_lds(c, (const void *)kern2, lds); if (rc) return rc; }
+        hipLaunchKernelGGL(kern2, dim3(gfast, gslow, gz), dim3(256), lds, st, a);
         HIPCHK(hipGetLastError());
         return CRC_OK;
     }
