@@ -27,6 +27,9 @@
  *     synchronises unless its name says so; scratch memory is passed in (`d_work`, sized by *_work_bytes).  The C++ host classes
  *     (crcnn_amd/host/crcnn_host.h) are NOT thread-safe: like the reference they keep the context, the keys and a work buffer in globals
  *     (CrCNN/src/globals.h:18-26) and launch on the default stream.
+ *   - host-side calls that work item by item (crc_encode_f32 / _f64 / _compact, crc_encrypt / crc_encrypt_key) spread their items over up to CRC_HOST_THREADS
+ *     std::threads (default: the hardware's, at most 16) drawn from one budget per process, so callers that are themselves pool threads do not multiply
+ *     thread counts; results do not depend on the split (one keystream per ciphertext, one weight per plaintext)
  */
 #ifndef CRCNN_HIP_H
 #define CRCNN_HIP_H
