@@ -3,6 +3,7 @@ CPU only: the ChaCha20 block function against RFC 8439's known answer and an ind
 laws (uniform ternary, clipped normal sigma 3.19 cut at 6 sigma -- SEAL util/globals.cpp:13-15) observed through public
 structure; key-based entry points are key- and stream-separated."""
 import ctypes
+import os
 import struct
 
 import numpy as np
@@ -85,3 +86,22 @@ def test_sampling_laws():
     b = [E.noise_budget(sk_ntt, cts[i]) for i in range(16)]
     assert max(b) - min(b) <= 2 and 76 <= min(b) <= 80, b
     assert not np.any(E.decrypt(sk_ntt, cts))
+
+
+def test_host_threads_do_not_change_the_bits():
+    """csrc/host_parallel.h: encoding and encryption run item ranges on CRC_HOST_THREADS threads (one keystream per ciphertext, one weight per plaintext):
+    1 thread and 7 threads give the same plaintexts and ciphertexts"""
+    import hashlib
+    import subprocess
+    import sys
+    prog = ("import numpy as np, hashlib, crcnn_amd as ca\n"
+            "n = 1024; q = ca.default_coeff_modulus_128(n)[:1]\n"
+            "E = ca.Engine(n, q, 1 << 20, device=-1)\n"
+            "sk, pk = E.keygen(11)\n"
+            "vals = np.random.default_rng(5).standard_normal(300).astype(np.float32)\n"
+            "pl, cc = E.encode(vals)\n"
+            "ct = E.encrypt(pk, pl, 99)\n"
+            "print(hashlib.sha256(pl).hexdigest(), hashlib.sha256(cc).hexdigest(), hashlib.sha256(ct).hexdigest())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = [subprocess.check_output([sys.executable, "-c", prog], cwd=root, env=dict(os.environ, CRC_HOST_THREADS=str(t), PYTHONPATH=root), text=True).strip() for t in (1, 7)]
+    assert outs[0] == outs[1] and len(outs[0].split()) == 3
