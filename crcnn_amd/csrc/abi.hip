@@ -446,6 +446,42 @@ extern "C" int crc_square_relin_forms(crc_ctx *c, const uint64_t *d_x, int in_fo
     }
     return CRC_OK;
 }
+// Square + relinearise + sum pooling as ONE key switch per pooled ciphertext (kernels_relin64.hip: relin_digits_pool_f64_kernel).  Internal passes take whole
+// channel planes (a window never leaves its plane): [packed keys][size-3 squares of a pass][pooled (c0, c1) of the pass][scratch]
+static size_t sqpool_planes(const crc_ctx *c, int xd, int yd) { const size_t per = (size_t)xd * yd, ch = square_chunk(c); return ch / per ? ch / per : 1; }
+extern "C" int crc_square_pool_relin_supported(const crc_ctx *c, int dbc, int xf, int yf)
+{
+    return c && c->tune.sq_path != 1 && c->tune.relin_path != 1 && k_relin64_pool_supported(c, dbc, xf * yf) ? 1 : 0;
+}
+extern "C" size_t crc_square_pool_relin_work_bytes(const crc_ctx *c, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int dbc)
+{
+    if (!c || xd < xf || yd < yf || xs < 1 || ys < 1) return 0;
+    const size_t planes = (size_t)B * zd, pp = planes < sqpool_planes(c, xd, yd) ? planes : sqpool_planes(c, xd, yd);
+    const size_t xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys + 1, cin = pp * xd * yd, cout = pp * xo * yo;
+    const size_t sq = k_square_work_words(c, cin), rl = k_relin_work_words(c, cout, dbc);
+    return 8 * (k_relin_keys_words(c, dbc) + cin * crc_ct_words(c, 3) + cout * crc_ct_words(c, 2) + (sq > rl ? sq : rl)) + 256;
+}
+extern "C" int crc_square_pool_relin_forms(crc_ctx *c, const uint64_t *d_x, int in_form, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf,
+                                           const uint64_t *d_evk, int dbc, uint64_t *d_y, int out_form, void *d_work, void *stream)
+{
+    CHECK_CTX(c); if (!d_x || !d_y || !d_evk || !d_work || !form_ok(in_form) || !form_ok(out_form)) return CRC_ERR_INVALID_ARGUMENT;
+    if (B < 0 || zd < 1 || xd < xf || yd < yf || xs < 1 || ys < 1 || xf < 1 || yf < 1) return CRC_ERR_INVALID_ARGUMENT;
+    if (!crc_square_pool_relin_supported(c, dbc, xf, yf)) return CRC_ERR_UNSUPPORTED;
+    u64 *w = (u64 *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
+    const PoolGeom pg{xd, yd, xs, ys, xf, yf, (xd - xf) / xs + 1, (yd - yf) / ys + 1};
+    const size_t planes = (size_t)B * zd, step = sqpool_planes(c, xd, yd), pp0 = planes < step ? planes : step;
+    const size_t pin = (size_t)xd * yd, pout = (size_t)pg.xo * pg.yo;
+    u64 *kp = w, *y3 = kp + k_relin_keys_words(c, dbc), *pc = y3 + pp0 * pin * crc_ct_words(c, 3), *rest = pc + pp0 * pout * crc_ct_words(c, 2);
+    for (size_t o = 0; o < planes; o += step) {
+        const size_t pp = planes - o < step ? planes - o : step, cin = pp * pin, cout = pp * pout;
+        RUN(k_square(c, d_x + o * pin * crc_ct_words(c, 2), cin, y3, rest, S(stream), in_form == CRC_NTT, true));
+        // (c0, c1) of the window, coefficient form: what the key switch's result is added to
+        RUN(k_pool(c, y3, pc, (int)pp, 1, xd, yd, xs, ys, xf, yf, nullptr, S(stream), 0, 3));
+        if (o == 0) RUN(k_relin64_prepare_keys(c, d_evk, dbc, kp, rest, S(stream)));
+        RUN(k_relinearize64(c, y3, 3, 2, pc, 2, cout, dbc, d_y + o * pout * crc_ct_words(c, 2), rest, kp, S(stream), out_form == CRC_NTT, &pg));
+    }
+    return CRC_OK;
+}
 extern "C" int crc_square_relin(crc_ctx *c, const uint64_t *d_x, size_t count, const uint64_t *d_evk, int dbc, uint64_t *d_y, void *d_work, void *stream)
 {
     return crc_square_relin_forms(c, d_x, CRC_COEFF, count, d_evk, dbc, d_y, CRC_COEFF, d_work, stream);

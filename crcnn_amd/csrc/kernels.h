@@ -17,7 +17,7 @@ int k_ntt_ct_inv_scaled(crc_ctx *c, const u64 *src, u64 *dst, size_t count, int 
 int k_plain_ntt(crc_ctx *c, const u64 *d_plain, size_t count, int mode, bool do_ntt, u64 *d_out, hipStream_t st);
 int k_plain_expand(crc_ctx *c, const u64 *d_compact, size_t count, u64 *d_plain, hipStream_t st);
 int k_rowwise(crc_ctx *c, u64 *acc, const u64 *b, size_t count, int size, int op, int sign, size_t group, size_t gmod, hipStream_t st);
-int k_pool(crc_ctx *c, const u64 *x, u64 *y, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, const u64 *mul, hipStream_t st, int pack_out = 0);
+int k_pool(crc_ctx *c, const u64 *x, u64 *y, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, const u64 *mul, hipStream_t st, int pack_out = 0, int in_size = 2);
 int k_bn_ntt(crc_ctx *c, u64 *x, int B, int zd, int hw, const u64 *mean, const u64 *invstd, hipStream_t st);
 int k_mac(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, const int *d_toff, int B, int P, int F, int T, int in_cts,
           const u64 *bias_ntt, hipStream_t st, int xp = 0, int wp = 0, int yp = 0);
@@ -31,8 +31,12 @@ bool   k_relin64_supported(const crc_ctx *c, int dbc);
 size_t k_relin64_keys_words(const crc_ctx *c, int dbc);
 size_t k_relin64_work_words(const crc_ctx *c, size_t cnt, int dbc);
 int k_relin64_prepare_keys(crc_ctx *c, const u64 *evk, int dbc, u64 *kp, u64 *scratch, hipStream_t st);
+// a window of the sum pooling that follows a Square layer: the key switch is linear in the digit polynomials, so the digits of a window's c2's are summed before
+// they are transformed and ONE key switch serves the pooled ciphertext (kernels_relin64.hip)
+struct PoolGeom { int xd, yd, xs, ys, xf, yf, xo, yo; };
+bool k_relin64_pool_supported(const crc_ctx *c, int dbc, int window);
 int k_relinearize64(crc_ctx *c, const u64 *src, int src_size, int src_poly, const u64 *x3, int add_size, size_t cnt, int dbc, u64 *y, u64 *work, const u64 *kp,
-                    hipStream_t st, bool out_ntt);
+                    hipStream_t st, bool out_ntt, const PoolGeom *pool = nullptr);
 int k_square(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStream_t st, bool in_ntt = false, bool premul_c2 = false);
 // kernels_square64.hip: the square's auxiliary base over the engine's fp64 primes
 bool k_square64_supported(const crc_ctx *c);

@@ -91,6 +91,55 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_digits_f64_kern
     }
 }
 
+// K1 for a Square layer with a sum pooling behind it: one workgroup per (POOLED ciphertext, i).  Sum_w relin(ct_w) = Sum_w c0_w + Sum_g (Sum_w digit_g(c2'_w)) (*) key_g:
+// the digit polynomials of the window's ciphertexts are added (integers below W 2^dbc) and transformed once -- the same element of Z_q as relinearising every
+// ciphertext and adding the results (evaluator.cpp:934-1069 + poolingLayer.cpp:22-44), hence the same bits, with xo yo / (xd yd) of the transforms, inner products
+// and inverse transforms.  Up to four digits per residue (16-bit digits of a 55..64-bit modulus), two 32-bit fields per register word.
+template <int RB, int NPT>
+__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_digits_pool_f64_kernel(const u64 *src, int src_size, int src_poly, double *E, const double *Wf, F64Params fp, int n, int logn,
+                                                                                                              int k, int D, int dbc, Relin64Tab tab, PoolGeom pg)
+{
+    extern __shared__ double smd[];
+    const size_t o = blockIdx.x / k; const int i = blockIdx.x % k;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const size_t per = (size_t)pg.xo * pg.yo, plane = o / per; const int rem = (int)(o % per), ox = rem / pg.yo, oy = rem % pg.yo;
+    const size_t ct0 = (plane * pg.xd + (size_t)ox * pg.xs) * pg.yd + (size_t)oy * pg.ys;
+    const u64 mask = (1ULL << dbc) - 1;
+    const int L = tab.L[i], g0 = tab.g0[i];
+    u64 lo[NPT], hi[NPT];
+#pragma unroll
+    for (int u = 0; u < NPT; u++) { lo[u] = 0; hi[u] = 0; }
+    for (int kx = 0; kx < pg.xf; kx++) for (int ky = 0; ky < pg.yf; ky++) {
+        const u64 *row = src + (((ct0 + (size_t)kx * pg.yd + ky) * src_size + src_poly) * k + i) * (size_t)n;
+#pragma unroll
+        for (int u = 0; u < NPT / 2; u++) {
+            const int s = 2 * (tid + u * nt);
+            if (s < n) {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(row + s);
+                lo[2 * u] += (v.x & mask) | (((v.x >> dbc) & mask) << 32);          hi[2 * u] += ((v.x >> (2 * dbc)) & mask) | (((v.x >> (3 * dbc)) & mask) << 32);
+                lo[2 * u + 1] += (v.y & mask) | (((v.y >> dbc) & mask) << 32);      hi[2 * u + 1] += ((v.y >> (2 * dbc)) & mask) | (((v.y >> (3 * dbc)) & mask) << 32);
+            }
+        }
+    }
+    for (int d = 0; d < L; d++) {
+        for (int m = 0; m < CRC_NF64; m++) {
+            double *dst = E + ((o * D + g0 + d) * CRC_NF64 + m) * (size_t)n;
+#pragma unroll
+            for (int u = 0; u < NPT / 2; u++) {
+                const int s = 2 * (tid + u * nt);
+                if (s < n) {
+                    const u64 f0 = d < 2 ? lo[2 * u] : hi[2 * u], f1 = d < 2 ? lo[2 * u + 1] : hi[2 * u + 1];
+                    sm_store_pair<RB>(smd, s, (double)(u32)(d & 1 ? f0 >> 32 : f0), (double)(u32)(d & 1 ? f1 >> 32 : f1));
+                }
+            }
+            __syncthreads();
+            ntt_row_passes_f64<false, RB>(smd, Wf + (size_t)m * n, n, logn, fp.m[m]);
+            for (int s = 2 * tid; s < n; s += 2 * nt) *reinterpret_cast<d2 *>(dst + s) = f64_stage_out<false, RB>(sm_load_pair<RB>(smd, s), Wf + (size_t)m * n, n, logn, s, fp.m[m]);
+            __syncthreads();
+        }
+    }
+}
+
 // ---- K2: slot-wise inner products ------------------------------------------------------------------------------------------------------------------------------------
 // A[ct][pj][m][s] = sum_g Kf[g][pj][m][s] E[ct][g][m][s]: every product reduced below 0.875 p, the sum of D <= 48 of them stays below 2^53 (exact); CT ciphertexts share
 // every key value a thread loads
@@ -229,6 +278,16 @@ bool k_relin64_supported(const crc_ctx *c, int dbc)
     // log2(n D 2^dbc q_max) <= logn + dbits + dbc + qbits  must be <= 2 * 47 - 2 (p_m > 2^46.99)
     return c->logn + dbits + dbc + qbits <= 2 * CRC_F64_PRIME_BITS - 3;
 }
+// the pooled form: the integer inner products are `window` times larger, a residue has at most four digits (two 32-bit fields per word hold their sums)
+bool k_relin64_pool_supported(const crc_ctx *c, int dbc, int window)
+{
+    if (!k_relin64_supported(c, dbc) || window < 1 || window > 64 || dbc > 20) return false;
+    int D = 0, qbits = 0;
+    for (int i = 0; i < c->k; i++) { const int L = evk_digits(c->q[i], dbc); if (L > 4) return false; D += L; if ((int)c->tabs[i].m.bits > qbits) qbits = c->tabs[i].m.bits; }
+    int dbits = 0; while ((1 << dbits) < D) dbits++;
+    int wbits = 0; while ((1 << wbits) < window) wbits++;
+    return c->logn + dbits + wbits + dbc + qbits <= 2 * CRC_F64_PRIME_BITS - 3;
+}
 size_t k_relin64_keys_words(const crc_ctx *c, int dbc) { return (size_t)CRC_NF64 * crc_evk_words(c, dbc); }
 // scratch words: E [cnt][D][2][n] + A [cnt][2k][2][n] (+ PM [cnt][k][n] when the caller's c2 is not premultiplied); the key preparation borrows the same space
 size_t k_relin64_work_words(const crc_ctx *c, size_t cnt, int dbc)
@@ -297,10 +356,11 @@ static int relin64_tail(crc_ctx *c, const double *A, const u64 *x3, int add_size
 // src / src_size / src_poly: where c2 (q/q_i)^-1 lives; x3 / add_size: the ciphertexts whose (c0, c1) are added; kp: the keys as k_relin64_prepare_keys left them;
 // work: cnt n (2 D + 4 k) words
 int k_relinearize64(crc_ctx *c, const u64 *src, int src_size, int src_poly, const u64 *x3, int add_size, size_t cnt, int dbc, u64 *y, u64 *work, const u64 *kp,
-                    hipStream_t st, bool out_ntt)
+                    hipStream_t st, bool out_ntt, const PoolGeom *pool)
 {
     if (cnt == 0) return CRC_OK;
     if (!k_relin64_supported(c, dbc)) return CRC_ERR_UNSUPPORTED;
+    if (pool && !k_relin64_pool_supported(c, dbc, pool->xf * pool->yf)) return CRC_ERR_UNSUPPORTED;      // (cnt counts POOLED ciphertexts then; src holds the unpooled ones)
     const size_t n = c->n, k = c->k;
     Relin64Tab tab{};
     int D = 0;
@@ -310,7 +370,12 @@ int k_relinearize64(crc_ctx *c, const u64 *src, int src_size, int src_poly, cons
     double *E = reinterpret_cast<double *>(work), *A = E + cnt * D * CRC_NF64 * n;
     const size_t lds = n * 8;
     const int RB = f64_radix(c);
-    {
+    if (pool) {
+        auto kern = RB == 3 ? relin_digits_pool_f64_kernel<3, 16> : RB == 4 ? relin_digits_pool_f64_kernel<4, 16> : relin_digits_pool_f64_kernel<5, 32>;
+        const int r2 = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (r2) return r2;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * k)), dim3(f64_hold_threads(c, RB)), lds, st, src, src_size, src_poly, E, c->d_f64_rp, c->f64, c->n, c->logn, c->k, D, dbc, tab, *pool);
+        HIPCHK(hipGetLastError());
+    } else {
         auto kern = RB == 3 ? relin_digits_f64_kernel<3, 16> : RB == 4 ? relin_digits_f64_kernel<4, 16> : relin_digits_f64_kernel<5, 32>;
         const int r2 = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (r2) return r2;
         hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * k)), dim3(f64_hold_threads(c, RB)), lds, st, src, src_size, src_poly, E, c->d_f64_rp, c->f64, c->n, c->logn, c->k, D, dbc, tab);

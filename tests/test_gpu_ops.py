@@ -107,6 +107,42 @@ def test_square_and_relinearize(gs):
     assert np.array_equal(E.download(d_xn, cts.shape), xn)
 
 
+def test_square_pool_with_one_key_switch_per_window(gs):
+    """crc_square_pool_relin_forms: Square + relinearise + sum pooling with the digit polynomials of a window added BEFORE the key switch (one key switch per pooled
+    ciphertext).  Must be the ciphertexts of crc_square_relin_forms followed by crc_pool -- themselves pinned to the reference's relinearize / pooling goldens above and
+    in test_gpu_layers.py -- bit for bit, in every combination of forms, for CrCNN's overlapping 2 x 2 / 1 window and a decimating 2 x 2 / 2 one"""
+    import crcnn_amd as ca
+    g, E = gs
+    base = g["ct_in"]
+    if not E.square_pool_relin_supported(2, 2):
+        pytest.skip("the pooled key switch does not hold this ring's integers")
+    rng = np.random.default_rng(11)
+    qv = np.array(E.q, dtype=np.uint64).reshape(1, 1, E.k, 1)
+    for (B, zd, xd, yd, xs, ys, xf, yf) in [(2, 3, 5, 5, 1, 1, 2, 2), (1, 2, 4, 6, 2, 2, 2, 2), (1, 1, 3, 3, 1, 1, 3, 3)]:
+        if not E.square_pool_relin_supported(xf, yf):
+            continue
+        cnt = B * zd * xd * yd
+        # distinct ciphertexts: the golden's encryptions, each plus a different encryption of the set (sums of valid ciphertexts are valid ciphertexts)
+        idx = rng.integers(0, len(base), size=(cnt, 2))
+        cts = np.ascontiguousarray((base[idx[:, 0]] + base[idx[:, 1]]) % qv)
+        xo, yo = (xd - xf) // xs + 1, (yd - yf) // ys + 1
+        out_cnt = B * zd * xo * yo
+        d_evk = E.upload(g["evk"])
+        d_x = E.upload(cts); d_xn = E.upload(cts); E.ntt_fwd(d_xn, cnt)
+        d_w = E.alloc(max(E.square_relin_work_bytes(cnt), E.square_pool_relin_work_bytes(B, zd, xd, yd, xs, ys, xf, yf)))
+        d_r = E.alloc(cts.nbytes); d_p = E.alloc(out_cnt * 2 * E.k * E.n * 8); d_f = E.alloc(out_cnt * 2 * E.k * E.n * 8)
+        E.square_relin(d_x, cnt, d_evk, d_r, d_w)
+        E.pool(d_r, B, zd, xd, yd, xs, ys, xf, yf, None, ca.COEFF, d_p)
+        want = E.download(d_p, (out_cnt, 2, E.k, E.n))
+        for fin, fout in [(ca.COEFF, ca.COEFF), (ca.NTT, ca.NTT), (ca.NTT, ca.COEFF), (ca.COEFF, ca.NTT)]:
+            E.L.crc_memset(E.c, E.p(d_f), 0xff, out_cnt * 2 * E.k * E.n * 8, E.stream)
+            E.square_pool_relin(d_xn if fin == ca.NTT else d_x, B, zd, xd, yd, xs, ys, xf, yf, d_evk, d_f, d_w, in_form=fin, out_form=fout)
+            if fout == ca.NTT:
+                E.ntt_inv(d_f, out_cnt)
+            assert np.array_equal(E.download(d_f, want.shape), want), (B, zd, xd, yd, xs, ys, xf, yf, fin, fout)
+        assert np.array_equal(E.download(d_x, cts.shape), cts)
+
+
 def test_square_with_seal_made_keys(gs):
     """SEAL's evaluation keys hold lazy (non-canonical) residues: same bits required"""
     g, E = gs
