@@ -135,7 +135,7 @@ def run_host(args, cfg_name, steps, warmup, batch=None, device=0):
         alg_bytes, macs = geometry.layer_bytes_and_macs(client.E, kind, a, ish, osh, CL)
         achieved = alg_bytes / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
         kname = kernels.get(name, "").split(" ")[0] or kind
-        label = f"{kname} ({name}, {CL} images/launch)" if kind in ("conv", "fc") else "Square + relinearise sequence (crc_square_relin_forms)" if kind == "square" else f"{kind} ({name})"
+        label = f"{kname} ({name}, {CL} images/launch)" if kind in ("conv", "fc") else "Square + relinearise sequence (crc_square_relin_forms)" if kind == "square" else "Square + pooled key switch sequence (crc_square_pool_relin_forms)" if kind == "squarepool" else f"{kind} ({name})"
         traffic, traffic_source = geometry.offline_traffic(cfg_name, kind, label, CL * int(np.prod(ish)))
         modmul_s = macs * 2 * cfg["k"] * cfg["n"] / (dur_ms * 1e-3) if dur_ms > 0 and macs else None
         if kname == "mfma_mac2w_kernel" and modmul_s:
@@ -156,7 +156,7 @@ def run_host(args, cfg_name, steps, warmup, batch=None, device=0):
                         algorithmic_bytes_per_launch=int(alg_bytes), modmul_per_s=round(modmul_s, 1) if modmul_s else None)
     cpu_line = None
     if args.cpu_seconds > 0:
-        evk = client.evaluation_keys() if any(pl[0] == "square" for pl in (plan or [])) else None
+        evk = client.evaluation_keys() if any(pl[0] in ("square", "squarepool") for pl in (plan or [])) else None
         cpu_line = cpu.cpu_baseline_reference(cfg, q, client.W, x0, cores, evk=evk) or cpu.cpu_baseline(cfg, q, client.W, x0, args.cpu_seconds)
         cpu_line["value"] = round(cpu_line["value"], 6); cpu_line["mac_per_s"] = round(cpu_line["mac_per_s"], 1)
         c1_path = os.path.join(ROOT, "tests", "golden", "c1_tiny4096_t32.json")

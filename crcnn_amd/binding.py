@@ -110,7 +110,7 @@ def load():
     L.crc_square_relin_forms.argtypes = [VP, VP, CI, SZ, VP, CI, VP, CI, VP, VP]
     L.crc_square_pool_relin_supported.argtypes = [VP, CI, CI, CI]
     L.crc_square_pool_relin_work_bytes.restype = SZ; L.crc_square_pool_relin_work_bytes.argtypes = [VP] + [CI] * 9
-    L.crc_square_pool_relin_forms.argtypes = [VP, VP, CI] + [CI] * 8 + [VP, CI, VP, CI, VP, VP]
+    L.crc_square_pool_relin_forms.argtypes = [VP, VP, CI] + [CI] * 8 + [VP, CI, VP, VP, CI, VP, VP]
     L.crc_conv2d_forms.argtypes = [VP, VP, VP, CI, VP] + [CI] * 9 + [CI, CI, VP, VP, VP]
     L.crc_dense_forms.argtypes = [VP, VP, VP, CI, VP, CI, CI, CI, CI, CI, VP, VP, VP]
     L.crc_pack28.argtypes = [VP, VP, SZ, CI, VP]
@@ -495,9 +495,10 @@ class Engine:
     def square_pool_relin_work_bytes(self, B, zd, xd, yd, xs, ys, xf, yf, dbc=16):
         return self.L.crc_square_pool_relin_work_bytes(self.c, B, zd, xd, yd, xs, ys, xf, yf, dbc)
 
-    def square_pool_relin(self, d_x, B, zd, xd, yd, xs, ys, xf, yf, d_evk, d_y, d_work, dbc=16, in_form=COEFF, out_form=COEFF):
-        """Square + relinearise + sum pooling with one key switch per pooled ciphertext (crc_square_pool_relin_forms)"""
-        _chk(self.L.crc_square_pool_relin_forms(self.c, self.p(d_x), in_form, B, zd, xd, yd, xs, ys, xf, yf, self.p(d_evk), dbc, self.p(d_y), out_form, self.p(d_work), self.stream),
+    def square_pool_relin(self, d_x, B, zd, xd, yd, xs, ys, xf, yf, d_evk, d_y, d_work, dbc=16, in_form=COEFF, out_form=COEFF, d_div=None):
+        """Square + relinearise + sum / average pooling with one key switch per pooled ciphertext (crc_square_pool_relin_forms)"""
+        _chk(self.L.crc_square_pool_relin_forms(self.c, self.p(d_x), in_form, B, zd, xd, yd, xs, ys, xf, yf, self.p(d_evk), dbc, self.p(d_div), self.p(d_y), out_form, self.p(d_work),
+                                                self.stream),
              "crc_square_pool_relin_forms")
 
     def encrypt_dev_work_bytes(self, count):

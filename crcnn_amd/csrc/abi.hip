@@ -462,9 +462,10 @@ extern "C" size_t crc_square_pool_relin_work_bytes(const crc_ctx *c, int B, int 
     return 8 * (k_relin_keys_words(c, dbc) + cin * crc_ct_words(c, 3) + cout * crc_ct_words(c, 2) + (sq > rl ? sq : rl)) + 256;
 }
 extern "C" int crc_square_pool_relin_forms(crc_ctx *c, const uint64_t *d_x, int in_form, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf,
-                                           const uint64_t *d_evk, int dbc, uint64_t *d_y, int out_form, void *d_work, void *stream)
+                                           const uint64_t *d_evk, int dbc, const uint64_t *d_div_ntt, uint64_t *d_y, int out_form, void *d_work, void *stream)
 {
     CHECK_CTX(c); if (!d_x || !d_y || !d_evk || !d_work || !form_ok(in_form) || !form_ok(out_form)) return CRC_ERR_INVALID_ARGUMENT;
+    if (d_div_ntt && out_form != CRC_NTT) return CRC_ERR_INVALID_ARGUMENT;           // the divisor multiplies slot-wise
     if (B < 0 || zd < 1 || xd < xf || yd < yf || xs < 1 || ys < 1 || xf < 1 || yf < 1) return CRC_ERR_INVALID_ARGUMENT;
     if (!crc_square_pool_relin_supported(c, dbc, xf, yf)) return CRC_ERR_UNSUPPORTED;
     u64 *w = (u64 *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
@@ -478,7 +479,7 @@ extern "C" int crc_square_pool_relin_forms(crc_ctx *c, const uint64_t *d_x, int 
         // (c0, c1) of the window, coefficient form: what the key switch's result is added to
         RUN(k_pool(c, y3, pc, (int)pp, 1, xd, yd, xs, ys, xf, yf, nullptr, S(stream), 0, 3));
         if (o == 0) RUN(k_relin64_prepare_keys(c, d_evk, dbc, kp, rest, S(stream)));
-        RUN(k_relinearize64(c, y3, 3, 2, pc, 2, cout, dbc, d_y + o * pout * crc_ct_words(c, 2), rest, kp, S(stream), out_form == CRC_NTT, &pg));
+        RUN(k_relinearize64(c, y3, 3, 2, pc, 2, cout, dbc, d_y + o * pout * crc_ct_words(c, 2), rest, kp, S(stream), out_form == CRC_NTT, &pg, d_div_ntt));
     }
     return CRC_OK;
 }

@@ -36,7 +36,7 @@ int k_relin64_prepare_keys(crc_ctx *c, const u64 *evk, int dbc, u64 *kp, u64 *sc
 struct PoolGeom { int xd, yd, xs, ys, xf, yf, xo, yo; };
 bool k_relin64_pool_supported(const crc_ctx *c, int dbc, int window);
 int k_relinearize64(crc_ctx *c, const u64 *src, int src_size, int src_poly, const u64 *x3, int add_size, size_t cnt, int dbc, u64 *y, u64 *work, const u64 *kp,
-                    hipStream_t st, bool out_ntt, const PoolGeom *pool = nullptr);
+                    hipStream_t st, bool out_ntt, const PoolGeom *pool = nullptr, const u64 *mul = nullptr);
 int k_square(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStream_t st, bool in_ntt = false, bool premul_c2 = false);
 // kernels_square64.hip: the square's auxiliary base over the engine's fp64 primes
 bool k_square64_supported(const crc_ctx *c);

@@ -95,9 +95,11 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_digits_f64_kern
 // the digit polynomials of the window's ciphertexts are added (integers below W 2^dbc) and transformed once -- the same element of Z_q as relinearising every
 // ciphertext and adding the results (evaluator.cpp:934-1069 + poolingLayer.cpp:22-44), hence the same bits, with xo yo / (xd yd) of the transforms, inner products
 // and inverse transforms.  Up to four digits per residue (16-bit digits of a 55..64-bit modulus), two 32-bit fields per register word.
-template <int RB, int NPT>
+// ONE: all digit sums of a value in one word -- fields of F = dbc + log2 W bits (the top digit of a 55-bit residue has 7 bits: 3 x 18 + 9 = 63 bits for a 2 x 2 window) --
+// so the window's sums take the registers the unpooled kernel spends on its one source row; otherwise two words of two 32-bit fields each
+template <int RB, int NPT, bool ONE>
 __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_digits_pool_f64_kernel(const u64 *src, int src_size, int src_poly, double *E, const double *Wf, F64Params fp, int n, int logn,
-                                                                                                              int k, int D, int dbc, Relin64Tab tab, PoolGeom pg)
+                                                                                                              int k, int D, int dbc, Relin64Tab tab, PoolGeom pg, int F)
 {
     extern __shared__ double smd[];
     const size_t o = blockIdx.x / k; const int i = blockIdx.x % k;
@@ -106,9 +108,10 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_digits_pool_f64
     const size_t ct0 = (plane * pg.xd + (size_t)ox * pg.xs) * pg.yd + (size_t)oy * pg.ys;
     const u64 mask = (1ULL << dbc) - 1;
     const int L = tab.L[i], g0 = tab.g0[i];
-    u64 lo[NPT], hi[NPT];
+    u64 lo[NPT], hi[ONE ? 2 : NPT];
 #pragma unroll
-    for (int u = 0; u < NPT; u++) { lo[u] = 0; hi[u] = 0; }
+    for (int u = 0; u < NPT; u++) { lo[u] = 0; if (!ONE) hi[u] = 0; }
+    auto spread = [&](u64 v) { return (v & mask) | (((v >> dbc) & mask) << F) | (((v >> (2 * dbc)) & mask) << (2 * F)) | ((v >> (3 * dbc)) << (3 * F)); };
     for (int kx = 0; kx < pg.xf; kx++) for (int ky = 0; ky < pg.yf; ky++) {
         const u64 *row = src + (((ct0 + (size_t)kx * pg.yd + ky) * src_size + src_poly) * k + i) * (size_t)n;
 #pragma unroll
@@ -116,11 +119,15 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_digits_pool_f64
             const int s = 2 * (tid + u * nt);
             if (s < n) {
                 const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(row + s);
-                lo[2 * u] += (v.x & mask) | (((v.x >> dbc) & mask) << 32);          hi[2 * u] += ((v.x >> (2 * dbc)) & mask) | (((v.x >> (3 * dbc)) & mask) << 32);
-                lo[2 * u + 1] += (v.y & mask) | (((v.y >> dbc) & mask) << 32);      hi[2 * u + 1] += ((v.y >> (2 * dbc)) & mask) | (((v.y >> (3 * dbc)) & mask) << 32);
+                if (ONE) { lo[2 * u] += spread(v.x); lo[2 * u + 1] += spread(v.y); }
+                else {
+                    lo[2 * u] += (v.x & mask) | (((v.x >> dbc) & mask) << 32);          hi[(2 * u) % (ONE ? 2 : NPT)] += ((v.x >> (2 * dbc)) & mask) | (((v.x >> (3 * dbc)) & mask) << 32);
+                    lo[2 * u + 1] += (v.y & mask) | (((v.y >> dbc) & mask) << 32);      hi[(2 * u + 1) % (ONE ? 2 : NPT)] += ((v.y >> (2 * dbc)) & mask) | (((v.y >> (3 * dbc)) & mask) << 32);
+                }
             }
         }
     }
+    const u64 fmask = (1ULL << F) - 1;
     for (int d = 0; d < L; d++) {
         for (int m = 0; m < CRC_NF64; m++) {
             double *dst = E + ((o * D + g0 + d) * CRC_NF64 + m) * (size_t)n;
@@ -128,8 +135,11 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_digits_pool_f64
             for (int u = 0; u < NPT / 2; u++) {
                 const int s = 2 * (tid + u * nt);
                 if (s < n) {
-                    const u64 f0 = d < 2 ? lo[2 * u] : hi[2 * u], f1 = d < 2 ? lo[2 * u + 1] : hi[2 * u + 1];
-                    sm_store_pair<RB>(smd, s, (double)(u32)(d & 1 ? f0 >> 32 : f0), (double)(u32)(d & 1 ? f1 >> 32 : f1));
+                    if (ONE) sm_store_pair<RB>(smd, s, (double)(u32)((lo[2 * u] >> (d * F)) & fmask), (double)(u32)((lo[2 * u + 1] >> (d * F)) & fmask));
+                    else {
+                        const u64 f0 = d < 2 ? lo[2 * u] : hi[(2 * u) % (ONE ? 2 : NPT)], f1 = d < 2 ? lo[2 * u + 1] : hi[(2 * u + 1) % (ONE ? 2 : NPT)];
+                        sm_store_pair<RB>(smd, s, (double)(u32)(d & 1 ? f0 >> 32 : f0), (double)(u32)(d & 1 ? f1 >> 32 : f1));
+                    }
                 }
             }
             __syncthreads();
@@ -193,7 +203,7 @@ __global__ void __launch_bounds__(256) relin_mac_f64_kernel(const double *E, con
 // instead of 5.19 us at (8192, 3): profiles/r04_square_relin_ab_step1.txt)
 template <int RB, int NPT, bool OUT_NTT, bool LAZY>
 __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_inv_crt_kernel(const double *A, const u64 *x3, int add_size, u64 *y, const ModParams *mods, const double *Wi,
-                                                                                                                     const ulonglong2 *Wq, F64Params fp, int n, int logn, int k)
+                                                                                                                     const ulonglong2 *Wq, F64Params fp, int n, int logn, int k, const u64 *mul)
 {
     extern __shared__ double smd[];
     const size_t ct = blockIdx.x / (2 * k); const int pj = blockIdx.x % (2 * k), poly = pj / k, j = pj % k;
@@ -261,6 +271,10 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_inv_crt_kernel(
         if (fuse1) fwd_pair_stage<LAZY>(v, Wq[(size_t)j * n + (n >> 1) + (s >> 1)], q, mq.two_q);
         if (LAZY) { v.x = reduce_small(v.x, q, mq.two_q, rq); v.y = reduce_small(v.y, q, mq.two_q, rq); }
         else { v.x = v.x >= mq.two_q ? v.x - mq.two_q : v.x; v.x = v.x >= q ? v.x - q : v.x; v.y = v.y >= mq.two_q ? v.y - mq.two_q : v.y; v.y = v.y >= q ? v.y - q : v.y; }
+        if (mul) {          // the divisor of an average pooling behind the Square layer (an NTT-form plaintext [k][n]): slot-wise, while the result leaves
+            const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(mul + (size_t)j * n + s);
+            v.x = mulmod(v.x, w.x, mq); v.y = mulmod(v.y, w.y, mq);
+        }
         *reinterpret_cast<ulonglong2 *>(dst + s) = v;
     }
 }
@@ -340,7 +354,7 @@ static int relin64_mac(crc_ctx *c, const double *E, const double *Kf, double *A,
 }
 
 template <int RB, int NPT>
-static int relin64_tail(crc_ctx *c, const double *A, const u64 *x3, int add_size, u64 *y, size_t cnt, bool out_ntt, hipStream_t st)
+static int relin64_tail(crc_ctx *c, const double *A, const u64 *x3, int add_size, u64 *y, size_t cnt, bool out_ntt, hipStream_t st, const u64 *mul)
 {
     bool lazy = true;
     for (int i = 0; i < c->k; i++) if (c->tabs[i].m.bits > 57 || c->tabs[i].m.bits < 45) lazy = false;
@@ -348,7 +362,7 @@ static int relin64_tail(crc_ctx *c, const double *A, const u64 *x3, int add_size
     auto kern = !out_ntt ? relin_inv_crt_kernel<RB, NPT, false, false> : lazy ? relin_inv_crt_kernel<RB, NPT, true, true> : relin_inv_crt_kernel<RB, NPT, true, false>;
     { const int rc = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (rc) return rc; }
     hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * 2 * c->k)), dim3(f64_hold_threads(c, RB)), lds, st, A, x3, add_size, y, c->d_mods, c->d_f64_irp,
-                       reinterpret_cast<const ulonglong2 *>(c->d_rp), c->f64, c->n, c->logn, c->k);
+                       reinterpret_cast<const ulonglong2 *>(c->d_rp), c->f64, c->n, c->logn, c->k, mul);
     HIPCHK(hipGetLastError());
     return CRC_OK;
 }
@@ -356,7 +370,7 @@ static int relin64_tail(crc_ctx *c, const double *A, const u64 *x3, int add_size
 // src / src_size / src_poly: where c2 (q/q_i)^-1 lives; x3 / add_size: the ciphertexts whose (c0, c1) are added; kp: the keys as k_relin64_prepare_keys left them;
 // work: cnt n (2 D + 4 k) words
 int k_relinearize64(crc_ctx *c, const u64 *src, int src_size, int src_poly, const u64 *x3, int add_size, size_t cnt, int dbc, u64 *y, u64 *work, const u64 *kp,
-                    hipStream_t st, bool out_ntt, const PoolGeom *pool)
+                    hipStream_t st, bool out_ntt, const PoolGeom *pool, const u64 *mul)
 {
     if (cnt == 0) return CRC_OK;
     if (!k_relin64_supported(c, dbc)) return CRC_ERR_UNSUPPORTED;
@@ -371,9 +385,16 @@ int k_relinearize64(crc_ctx *c, const u64 *src, int src_size, int src_poly, cons
     const size_t lds = n * 8;
     const int RB = f64_radix(c);
     if (pool) {
-        auto kern = RB == 3 ? relin_digits_pool_f64_kernel<3, 16> : RB == 4 ? relin_digits_pool_f64_kernel<4, 16> : relin_digits_pool_f64_kernel<5, 32>;
+        // all digit sums of a value in one word when they fit: fields of F = dbc + log2 W bits, the top digit of residue i has bits_i - (L_i - 1) dbc (+ log2 W) bits
+        int wbits = 0; while ((1 << wbits) < pool->xf * pool->yf) wbits++;
+        const int F = dbc + wbits;
+        bool one = true;
+        for (int i = 0; i < c->k; i++) { const int L = tab.L[i]; if ((L - 1) * F + ((int)c->tabs[i].m.bits - (L - 1) * dbc + wbits) > 64 || F > 32) one = false; }
+        auto kern = RB == 3 ? (one ? relin_digits_pool_f64_kernel<3, 16, true> : relin_digits_pool_f64_kernel<3, 16, false>)
+                  : RB == 4 ? (one ? relin_digits_pool_f64_kernel<4, 16, true> : relin_digits_pool_f64_kernel<4, 16, false>)
+                            : (one ? relin_digits_pool_f64_kernel<5, 32, true> : relin_digits_pool_f64_kernel<5, 32, false>);
         const int r2 = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (r2) return r2;
-        hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * k)), dim3(f64_hold_threads(c, RB)), lds, st, src, src_size, src_poly, E, c->d_f64_rp, c->f64, c->n, c->logn, c->k, D, dbc, tab, *pool);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * k)), dim3(f64_hold_threads(c, RB)), lds, st, src, src_size, src_poly, E, c->d_f64_rp, c->f64, c->n, c->logn, c->k, D, dbc, tab, *pool, F);
         HIPCHK(hipGetLastError());
     } else {
         auto kern = RB == 3 ? relin_digits_f64_kernel<3, 16> : RB == 4 ? relin_digits_f64_kernel<4, 16> : relin_digits_f64_kernel<5, 32>;
@@ -388,6 +409,7 @@ int k_relinearize64(crc_ctx *c, const u64 *src, int src_size, int src_poly, cons
     default: return CRC_ERR_UNSUPPORTED;
     }
     if (rc) return rc;
-    return RB == 3 ? relin64_tail<3, 16>(c, A, x3, add_size, y, cnt, out_ntt, st)
-         : RB == 4 ? relin64_tail<4, 16>(c, A, x3, add_size, y, cnt, out_ntt, st) : relin64_tail<5, 32>(c, A, x3, add_size, y, cnt, out_ntt, st);
+    if (mul && !out_ntt) return CRC_ERR_INVALID_ARGUMENT;
+    return RB == 3 ? relin64_tail<3, 16>(c, A, x3, add_size, y, cnt, out_ntt, st, mul)
+         : RB == 4 ? relin64_tail<4, 16>(c, A, x3, add_size, y, cnt, out_ntt, st, mul) : relin64_tail<5, 32>(c, A, x3, add_size, y, cnt, out_ntt, st, mul);
 }

@@ -806,6 +806,28 @@ ciphertext3D SquareLayer::forward(ciphertext3D input)
 }
 void SquareLayer::printLayerStructure() { cerr << "Square run with " << th_count << " threads" << endl; }
 
+// ---- Square + pooling (Network::fuse) ---------------------------------------------------------------------------------
+SquarePoolLayer::SquarePoolLayer(string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf, int th_count, shared_ptr<DeviceBuffer> d_div)
+    : Layer(name), xd(xd), yd(yd), zd(zd), xs(xs), ys(ys), xf(xf), yf(yf), xo((xd - xf) / xs + 1), yo((yd - yf) / ys + 1), zo(zd), th_count(th_count), d_div(d_div) {}
+ciphertext3D SquarePoolLayer::forward(ciphertext3D input)
+{
+    checkInput(input, zd, xd, yd, "SquarePoolLayer");
+    if (!ev_keys16) throw invalid_argument("not enough evaluation keys");
+    // an average pooling's divisor multiplies slot-wise: the pooled tensor is made NTT-resident for it whatever form the network asked for
+    const int of = d_div ? CRC_NTT : out_form;
+    ciphertext3D out(input.B, zo, xo, yo, of);
+    ensure(g_scratch, crc_square_pool_relin_work_bytes(ctx(), input.B, zd, xd, yd, xs, ys, xf, yf, 16));
+    chk(crc_square_pool_relin_forms(ctx(), input.data(), input.form, input.B, zd, xd, yd, xs, ys, xf, yf, (const uint64_t *)ev_keys16->ptr, 16,
+                                    d_div ? (const uint64_t *)d_div->ptr : nullptr, out.data(), of, g_scratch->ptr, nullptr), "crc_square_pool_relin_forms");
+    if (of != out_form) { chk(crc_ntt_inv(ctx(), out.data(), out.count(), 2, nullptr), "crc_ntt_inv"); out.form = out_form; }
+    return out;
+}
+void SquarePoolLayer::printLayerStructure()
+{
+    cerr << "Square + Pooling " << name << " : input (" << zd << "," << xd << "," << yd << "); kernel(" << xf << "," << yf << "); stride(" << xs << "," << ys << "); output(" << zo << "," << xo << ","
+         << yo << "); one key switch per pooled ciphertext" << endl;
+}
+
 // ---- BatchNorm --------------------------------------------------------------------------------------------------------
 BatchNormLayer::BatchNormLayer(string name, int num_channels, vector<Plaintext> &mean, vector<Plaintext> &var) : Layer(name), num_channels(num_channels), mean(mean), var(var) {}
 BatchNormLayer::BatchNormLayer(string name, int num_channels, istream *infile) : Layer(name), num_channels(num_channels) { loadPlaintextParameters(infile); }
@@ -1087,6 +1109,16 @@ int Network::fuse()
         fused->d_b[0] = inttCopy(fused->d_b[1], conv->nf);
         fused->filters_already_ntt = true;
         layers[i] = fused;
+        layers.erase(layers.begin() + i + 1);
+        removed++;
+    }
+    // 1b. Square + pooling: one key switch per pooled ciphertext (SquarePoolLayer)
+    for (size_t i = 0; i + 1 < layers.size(); i++) {
+        auto sq = dynamic_pointer_cast<SquareLayer>(layers[i]);
+        auto pool = dynamic_pointer_cast<PoolingLayer>(layers[i + 1]);
+        if (!sq || !pool || (int)i + 1 == layer_before_reenc) continue;
+        if (!crc_square_pool_relin_supported(ctx(), 16, pool->xf, pool->yf)) continue;
+        layers[i] = make_shared<SquarePoolLayer>(sq->name + "+" + pool->name, pool->xd, pool->yd, pool->zd, pool->xs, pool->ys, pool->xf, pool->yf, sq->th_count, pool->d_div);
         layers.erase(layers.begin() + i + 1);
         removed++;
     }

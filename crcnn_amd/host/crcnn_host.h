@@ -222,6 +222,22 @@ public:
 private:
 };
 
+// Network::fuse(): a SquareLayer with a (sum or average) PoolingLayer behind it.  Relinearisation is linear in the digit polynomials of c2, so the digits of a
+// pooling window are added and ONE key switch serves the pooled ciphertext (crc_square_pool_relin_forms): the ciphertexts squareLayer.cpp:21-39 followed by
+// poolingLayer.cpp:22-44 produce, bit for bit, with xo yo / (xd yd) of the key-switching work
+class SquarePoolLayer : public Layer {
+public:
+    int xd, yd, zd, xs, ys, xf, yf, xo, yo, zo, th_count;
+    SquarePoolLayer(std::string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf, int th_count, std::shared_ptr<DeviceBuffer> d_div);
+    ciphertext3D forward(ciphertext3D input) override;
+    void savePlaintextParameters(std::ostream *) override {}
+    void loadPlaintextParameters(std::istream *) override {}
+    void printLayerStructure() override;
+    size_t deviceBytes() const override { return d_div ? d_div->bytes : 0; }
+private:
+    std::shared_ptr<DeviceBuffer> d_div;                    // NTT-form divisor of an average pooling (applied to the pooled ciphertexts)
+};
+
 class BatchNormLayer : public Layer {                       // batchNormLayer.h:18-20
 public:
     friend class Network;

@@ -347,7 +347,24 @@ class Network:
                     continue
             plan.append(self.plan[i]); i += 1
         self.plan = plan
+        self._pair_square_pool()
         self._fold_batchnorm()
+
+    def _pair_square_pool(self):
+        """a Square layer with a (sum or average) pooling behind it: relinearisation is linear in the digit polynomials of c2, so the digits of a pooling window are
+        added and ONE key switch serves the pooled ciphertext (crc_square_pool_relin_forms) -- the same ciphertexts, xo yo / (xd yd) of the key-switching work"""
+        E = self.E
+        plan, i = [], 0
+        while i < len(self.plan):
+            kind, name, a, p, ishape, oshape = self.plan[i]
+            nxt = self.plan[i + 1] if i + 1 < len(self.plan) else None
+            if (kind == "square" and nxt and nxt[0] in ("pool", "avgpool") and p["out_form"] == NTT and nxt[3]["form"] == NTT
+                    and E.square_pool_relin_supported(nxt[2]["xf"], nxt[2]["yf"], self.dbc)):
+                plan.append(("squarepool", name + "+" + nxt[1], dict(nxt[2]), dict(in_form=p["in_form"], out_form=NTT, div=nxt[3]["div"]), ishape, nxt[5]))
+                i += 2
+                continue
+            plan.append(self.plan[i]); i += 1
+        self.plan = plan
 
     # ---- batch-norm folding: bn (per-channel  s (*) (x - M), M on poly 0 only) followed by a conv / dense layer is that layer with
     # weights w (*) s[channel] and bias  B - sum_taps w (*) s (*) M  -- ring-linear over Z_q, so the ciphertexts are identical
@@ -489,6 +506,8 @@ class Network:
                 work = max(work, E.conv2d_forms_work_bytes(B, a["in_dim"], 1, 1, 1, 1, 1, 1, a["out_dim"], p["in_form"], p.get("w_form", NTT), p["out_form"]))
             elif kind == "square":
                 work = max(work, E.square_relin_work_bytes(B * int(np.prod(ishape)), self.dbc))
+            elif kind == "squarepool":
+                work = max(work, E.square_pool_relin_work_bytes(B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], self.dbc))
         return need_act, work
 
     def _stream_geometry(self, kind, a, B=None):
@@ -684,6 +703,10 @@ class Network:
                 E.batchnorm(cur, B, ishape[0], ishape[1], ishape[2], p["mean"], p["invstd"], p["form"])
             elif kind == "square":
                 E.square_relin(cur, B * int(np.prod(ishape)), self.d_evk, out, self.work, self.dbc, p["in_form"], p["out_form"])
+                cur = out
+            elif kind == "squarepool":
+                E.square_pool_relin(cur, B, a["zd"], a["xd"], a["yd"], a["xs"], a["ys"], a["xf"], a["yf"], self.d_evk, out, self.work, self.dbc, p["in_form"], p["out_form"],
+                                    d_div=p["div"])          # (an average pooling's divisor multiplies the pooled tensor as it leaves the key switch)
                 cur = out
             if timer:
                 timer(i, name, kind, 1)

@@ -274,12 +274,13 @@ int crc_square_relin_forms(crc_ctx *ctx, const uint64_t *d_x, int in_form, size_
  *     Sum_w relin(ct_w) = Sum_w (c0, c1)_w + Sum_g (Sum_w digit_g(c2'_w)) (*) key_g
  * -- the same element of Z_q as squaring, relinearising and pooling one after the other (evaluator.cpp:934-1069, poolingLayer.cpp:22-44), hence the same bits,
  * with xo yo / (xd yd) of the key switch's transforms and inner products (16 / 25 for CrCNN's 5 x 5 -> 4 x 4 pool2).  d_x: [B][zd][xd][yd] ciphertexts, d_y:
- * [B][zd][xo][yo].  An average pooling's divisor is applied by the caller afterwards (crc_multiply_plain_ntt).  crc_square_pool_relin_supported: the key switch over
+ * [B][zd][xo][yo].  d_div_ntt: an average pooling's divisor (NTT-form plaintext [k][n], as crc_pool takes it), multiplied in while an NTT-form result leaves the
+ * last kernel (out_form must be CRC_NTT then).  crc_square_pool_relin_supported: the key switch over
  * the fp64 primes must hold the window's larger integers (n D W 2^dbc q below p_0 p_1 / 4) and a residue at most four digits. */
 int    crc_square_pool_relin_supported(const crc_ctx *ctx, int dbc, int xf, int yf);
 size_t crc_square_pool_relin_work_bytes(const crc_ctx *ctx, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int dbc);
 int    crc_square_pool_relin_forms(crc_ctx *ctx, const uint64_t *d_x, int in_form, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf,
-                                   const uint64_t *d_evk, int dbc, uint64_t *d_y, int out_form, void *d_work, void *stream);
+                                   const uint64_t *d_evk, int dbc, const uint64_t *d_div_ntt /* NULL = sum pool */, uint64_t *d_y, int out_form, void *d_work, void *stream);
 /* the two halves separately (unit tests): square -> size-3 ciphertexts; relinearize -> size 2 */
 int crc_square(crc_ctx *ctx, const uint64_t *d_x, size_t count, uint64_t *d_y3, void *d_work, void *stream);
 int crc_relinearize(crc_ctx *ctx, const uint64_t *d_x3, size_t count, const uint64_t *d_evk, int dbc, uint64_t *d_y,

@@ -10,8 +10,8 @@ from benchkit.configs import CONFIGS
 def test_fused_plan_names_and_shapes():
     want = {
         "tiny4096": ["pool1_features.conv1+pool1", "pool2_features.conv2+pool2", "classifier.fc3", "classifier.fc4"],
-        "approx8192": ["pool1_features.conv1+pool1", "pool1_features.norm1+pool2_features.conv2", "act1", "pool2", "pool2_features.norm2+classifier.fc3", "classifier.fc4"],
-        "wopad16384": ["pool1_features.conv1+pool1", "pool1_features.norm1+pool2_features.conv2", "act1", "pool2", "pool2_features.norm2+classifier.fc3", "classifier.fc4"],
+        "approx8192": ["pool1_features.conv1+pool1", "pool1_features.norm1+pool2_features.conv2", "act1+pool2", "pool2_features.norm2+classifier.fc3", "classifier.fc4"],
+        "wopad16384": ["pool1_features.conv1+pool1", "pool1_features.norm1+pool2_features.conv2", "act1+pool2", "pool2_features.norm2+classifier.fc3", "classifier.fc4"],
     }
     for name, layers in want.items():
         cfg = CONFIGS[name]
@@ -22,6 +22,12 @@ def test_fused_plan_names_and_shapes():
         for a, b in zip(plan, plan[1:]):
             assert int(np.prod(a[4])) == int(np.prod(b[3])), (name, a[1], b[1])         # every layer reads what the one in front wrote
         E.close()
+    # the host decides from the HBM it finds and from what the key switch holds: a layer list without the Square + pooling pair is followed as it is
+    cfg = CONFIGS["approx8192"]
+    E = ca.Engine(cfg["n"], ca.default_coeff_modulus_128(cfg["n"])[:cfg["k"]], cfg["t"], device=-1)
+    unpaired = ["pool1_features.conv1+pool1", "pool1_features.norm1+pool2_features.conv2", "act1", "pool2", "pool2_features.norm2+classifier.fc3", "classifier.fc4"]
+    assert [pl[1] for pl in geometry.fused_plan(E, cfg["model"], names=unpaired)] == unpaired
+    E.close()
 
 
 def test_limb_exec_over_useful_follows_the_tiling():

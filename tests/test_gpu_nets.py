@@ -124,6 +124,27 @@ def test_tilewise_limb_weights_and_two_level_chunking(name, monkeypatch):
     E.close()
 
 
+@pytest.mark.parametrize("name", [n for n in ["approx256", "wopad256", "approx8192_t42", "wopad16384_t44"] if n in NAMES])
+def test_square_and_pooling_share_one_key_switch(name):
+    """Network.fuse() pairs the Square layer with the pooling behind it (crc_square_pool_relin_forms: the digits of a window's c2's are summed before ONE key switch):
+    ApproxPlainModel's average pooling (the divisor multiplies the pooled ciphertexts) and PlainModelWoPad's sum pooling, three images -- the compiled reference's output
+    ciphertexts, logits and noise budget"""
+    import crcnn_amd as ca
+    from crcnn_amd.netrun import Network
+    g = load_net_golden(name)
+    O, sk, pk, evk, img, x = make_inputs(g)
+    E = ca.Engine(g["n"], g["q"], g["t"], device=0)
+    net = Network(E, g["model"], h5_path=os.path.join(GOLD, "models", g["model"] + ".h5"), resident=True, d_evk=E.upload(evk))
+    net.fuse(); net.prepare(3)
+    kinds = [pl[0] for pl in net.plan]
+    assert "squarepool" in kinds and "square" not in kinds and [pl[1] for pl in net.plan if pl[0] == "squarepool"] == ["act1+pool2"], [pl[1] for pl in net.plan]
+    out = E.download(net.forward(E.upload(np.ascontiguousarray(np.repeat(x[None], 3, axis=0))), 3), (3, 1, 10, 1, 2, E.k, E.n))
+    E.close()
+    assert all(sha(out[b]) == g["out_sha256"] for b in range(3))
+    if g["n"] >= 1024:
+        assert [O.decrypt_value(sk, out[2, 0, j, 0]) for j in range(10)] == g["logits"]
+
+
 def test_kernel_choice_follows_the_rows_per_launch():
     """PlainModelWoPad at a chunk of 6 images: conv2 (6 x 2 x 25 rows) is a limb GEMM, fc3 (12 rows = a fifth of a 64-row tile: every slot's weights would be
     streamed for a handful of rows) stays on the vector-ALU kernel -- the guard counts PIXELS per image, one for a dense layer; at 16 images fc3 moves over; fc4's ten

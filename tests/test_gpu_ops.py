@@ -140,6 +140,13 @@ def test_square_pool_with_one_key_switch_per_window(gs):
             if fout == ca.NTT:
                 E.ntt_inv(d_f, out_cnt)
             assert np.array_equal(E.download(d_f, want.shape), want), (B, zd, xd, yd, xs, ys, xf, yf, fin, fout)
+        # an average pooling: the divisor (an NTT-form plaintext) multiplies the pooled tensor inside the last kernel; crc_pool's own product is the reference
+        pl, _ = E.encode(np.array([1.0 / (xf * yf)], dtype=np.float32))
+        d_pl = E.upload(pl); d_div = E.alloc(E.k * E.n * 8); E.plain_to_ntt(d_pl, 1, d_div)
+        E.ntt_fwd(d_r, cnt)
+        E.pool(d_r, B, zd, xd, yd, xs, ys, xf, yf, d_div, ca.NTT, d_p)
+        E.square_pool_relin(d_xn, B, zd, xd, yd, xs, ys, xf, yf, d_evk, d_f, d_w, in_form=ca.NTT, out_form=ca.NTT, d_div=d_div)
+        assert np.array_equal(E.download(d_f, want.shape), E.download(d_p, want.shape)), ("average", xf, yf)
         assert np.array_equal(E.download(d_x, cts.shape), cts)
 
 

@@ -45,6 +45,14 @@ def fused_plan(E, model, names=None):
                 folded.append(["conv", name + "+" + nxt[1], a2, ish, nxt[4]]); i += 2
                 continue
         folded.append(plan[i]); i += 1
+    paired, i = [], 0
+    while i < len(folded):        # Square + pooling -> one key switch per pooled ciphertext (SquarePoolLayer) where the engine's fp64 key switch holds the window's integers
+        nxt = folded[i + 1] if i + 1 < len(folded) else None
+        if folded[i][0] == "square" and nxt and nxt[0] in ("pool", "avgpool") and (E.square_pool_relin_supported(nxt[2]["xf"], nxt[2]["yf"]) if names is None else folded[i][1] + "+" + nxt[1] in names):
+            paired.append(["squarepool", folded[i][1] + "+" + nxt[1], dict(nxt[2]), folded[i][3], nxt[4]]); i += 2
+            continue
+        paired.append(folded[i]); i += 1
+    folded = paired
     out, i = [], 0
     while i < len(folded):
         nxt = folded[i + 1] if i + 1 < len(folded) else None
@@ -76,6 +84,8 @@ def offline_traffic(cfg_name, kind, kernel_label, cts_per_launch):
             pm = json.load(open(os.path.join(ROOT, "profiles", pf))).get(cfg_name)
             if pm and pm.get("per_ciphertext") and kind == "square":      # the Square + relinearise sequence: PMC bytes per ciphertext x the launch's ciphertexts
                 return int(pm["traffic_bytes_per_ciphertext"] * cts_per_launch), f"profiles/{pf} ({pm['kernel']}), offline rocprofv3 --pmc passes of tools/bench_square.py on the same ring (not measured in this run)"
+            if pm and pm.get("pooled") and kind == "squarepool":          # the same with one key switch per pooled ciphertext: bytes per SQUARED ciphertext
+                return int(pm["pooled"]["traffic_bytes_per_ciphertext"] * cts_per_launch), f"profiles/{pf} ({pm['pooled']['kernel']}), offline rocprofv3 --pmc passes of tools/bench_square_pool.py on the same ring (not measured in this run)"
             if pm and pm.get("kernel") == kernel_label:
                 return int(pm["traffic_bytes"]), f"profiles/{pf}, offline rocprofv3 --pmc passes of the same launch (not measured in this run)"
         except Exception:

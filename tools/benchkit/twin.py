@@ -316,12 +316,16 @@ def run_config(args, D_, cfg_name, steps, warmup, batch=None, chunk=None, full=T
         traffic, traffic_source = None, None
         kname = "mfma_mac2w_kernel" if p.get("w_form") == ca.NTTL else "mfma_conv1_kernel" if p.get("w_form") == ca.NTTL1 else "mac3_kernel"
         kernel_label = f"{kname} ({name}, {CL} images/launch)" if kind in ("conv", "fc") else f"{kind} ({name})"
-        for pf in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for pf in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", pf))).get(cfg_name)
                 if pm and pm.get("per_ciphertext") and kind == "square":      # the Square + relinearise sequence: PMC bytes per ciphertext x the launch's ciphertexts
                     traffic = int(pm["traffic_bytes_per_ciphertext"] * CL * in_cts)
                     traffic_source = f"profiles/{pf} ({pm['kernel']}), offline rocprofv3 --pmc passes of tools/bench_square.py on the same ring (not measured in this run)"
+                    break
+                if pm and pm.get("pooled") and kind == "squarepool":          # one key switch per pooled ciphertext: PMC bytes per SQUARED ciphertext
+                    traffic = int(pm["pooled"]["traffic_bytes_per_ciphertext"] * CL * in_cts)
+                    traffic_source = f"profiles/{pf} ({pm['pooled']['kernel']}), offline rocprofv3 --pmc passes of tools/bench_square_pool.py on the same ring (not measured in this run)"
                     break
                 if pm and pm["kernel"] == kernel_label:
                     traffic = int(pm["traffic_bytes"]); traffic_source = f"profiles/{pf}, offline rocprofv3 --pmc passes of the same launch (not measured in this run)"
