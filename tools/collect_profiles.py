@@ -20,6 +20,9 @@ cp("prof_c1/c1_kernel_stats.csv", "conv1_4096k2_b128_kernel_stats.csv")
 for tag in ("8192_3_1250", "16384_4_512", "16384_8_256"):
     cp(f"prof_square_{tag}.txt", f"square_relin_{tag}_kernels.txt"); cp(f"prof_square_old_{tag}.txt", f"square_relin_{tag}_kernels_round2_path.txt")
 cp("square_paths.txt", "square_relin_paths.txt")
+for tag in ("8192_3_1250", "16384_4_1250"):           # the Square + pooling pair with one key switch per pooled ciphertext (per squared ciphertext)
+    cp(f"prof_square_pool_{tag}.txt", f"square_pool_{tag}_kernels.txt")
+cp("square_pool.txt", "square_pool_one_key_switch.txt")
 # one file with the before / after per-kernel numbers and the path-by-path timings (what VERDICT r2 item 1 asks for)
 with open(os.path.join(P, f"{R}_square_relin.txt"), "w") as f:
     f.write("# Square + relinearise (crc_square_relin_forms, NTT form in and out), us per ciphertext and kernel: rocprofv3 --kernel-trace --stats over tools/bench_square.py\n"
@@ -121,6 +124,18 @@ try:
                                     "plain row inverse transform of the same run, whose bytes are known (MI355X_MICROARCH.md gives the factor 2 for 16 B per lane reads; the kernels of the sequence mix widths)")
         except Exception as e:
             print("no square PMC summary for", tag, e)
+    # the layer pair Square + pooling with one key switch per pooled ciphertext (CRC_BENCH_SQ_POOL=1): what the fused networks run; bytes per SQUARED ciphertext
+    for tag, cfgs in (("8192_3_1250", ("approx8192",)), ("16384_4_1250", ("wopad16384",))):
+        try:
+            sm = json.load(open(os.path.join(F, f"pmc_square_pool_{tag}.json")))
+            for cn in cfgs:
+                out.setdefault(cn, {})["pooled"] = dict(
+                    kernel=f"Square + pooled key switch sequence (crc_square_pool_relin_forms, n = {sm['config']['n']}, k = {sm['config']['k']}, 5 x 5 -> 4 x 4)",
+                    traffic_bytes_per_ciphertext=sm["total"]["sum"], read_bytes_per_ciphertext=sm["total"]["read"], write_bytes_per_ciphertext=sm["total"]["write"],
+                    algorithmic_bytes_per_ciphertext=sm["total"]["algorithmic"], ratio_to_algorithmic=sm["total"]["ratio"], kernels=sm["kernels"],
+                    note="per SQUARED ciphertext (1250 per image in, 800 out); same passes and calibration as the unpooled sequence")
+        except Exception as e:
+            print("no pooled square PMC summary for", tag, e)
     json.dump(out, open(os.path.join(P, f"{R}_pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(out["tiny4096"])[:400])
 except Exception as e:

@@ -32,6 +32,12 @@ for cfg in "8192 3 1250" "16384 4 512" "16384 8 256"; do tag=$(echo $cfg | tr ' 
   CRC_SQ_PATH=1 bash tools/prof_square.sh "$cfg" sqold_$tag 1 > $O/prof_square_old_$tag.txt 2>&1
   bash tools/pmc_square.sh "$cfg" $tag > $O/pmc_square_$tag.json 2> $O/pmc_square_$tag.err
 done
+# the layer pair the fused networks run: Square + pooling with one key switch per pooled ciphertext (per squared ciphertext, whole images of 1250)
+for cfg in "8192 3 1250" "16384 4 1250"; do tag=$(echo $cfg | tr ' ' '_')
+  CRC_BENCH_SQ_POOL=1 bash tools/prof_square.sh "$cfg" sqpool_$tag 0 > $O/prof_square_pool_$tag.txt 2>&1
+  CRC_BENCH_SQ_POOL=1 bash tools/pmc_square.sh "$cfg" pool_$tag > $O/pmc_square_pool_$tag.json 2> $O/pmc_square_pool_$tag.err
+done
+(timeout -k 10 200 python tools/bench_square_pool.py 8192 3 32; timeout -k 10 200 python tools/bench_square_pool.py 16384 4 6) 2>&1 | grep -v amdgpu > $O/square_pool.txt
 (for cfg in "8192 3 1250" "8192 4 1250" "16384 4 512" "16384 8 256"; do
    echo "round-2 kernels (CRC_SQ_PATH=1 CRC_RELIN_PATH=1: SEAL's 61-bit auxiliary base, key switching over the coefficient moduli)"; CRC_SQ_PATH=1 CRC_RELIN_PATH=1 python tools/bench_square.py $cfg 2>&1 | grep -v amdgpu
    echo "key switching over two fp64 primes, SEAL's auxiliary base (CRC_SQ_PATH=1)"; CRC_SQ_PATH=1 python tools/bench_square.py $cfg 2>&1 | grep -v amdgpu

@@ -40,5 +40,9 @@ for nm in sorted(ours, key=lambda x: -(fetch[x] + write.get(x, 0))):
     tot_r += r; tot_w += w
     out["kernels"][nm[:80]] = dict(read=round(r), write=round(w), launches=calls[nm])
 alg = 8 * n * (2 * 2 * k + 2 * 2 * k) // 2      # every distinct operand moved once = 2k rows in + 2k rows out
+import os
+if os.environ.get("CRC_BENCH_SQ_POOL") == "1":   # Square + pooling pair: 2k rows in per squared ciphertext, 2k rows out per POOLED one (16 of 25)
+    alg = 8 * n * 2 * k + 8 * n * 2 * k * 16 // 25
+    out["sequence"] = "crc_square_pool_relin_forms: Square + pooling with one key switch per pooled ciphertext; figures are per SQUARED ciphertext"
 out["total"] = dict(read=round(tot_r), write=round(tot_w), sum=round(tot_r + tot_w), algorithmic=alg, ratio=round((tot_r + tot_w) / alg, 2))
 print(json.dumps(out, indent=1))
