@@ -447,7 +447,7 @@ extern "C" int crc_square_relin_forms(crc_ctx *c, const uint64_t *d_x, int in_fo
     return CRC_OK;
 }
 // Square + relinearise + sum pooling as ONE key switch per pooled ciphertext (kernels_relin64.hip: relin_digits_pool_f64_kernel).  Internal passes take whole
-// channel planes (a window never leaves its plane): [packed keys][size-3 squares of a pass][pooled (c0, c1) of the pass][scratch]
+// channel planes (a window never leaves its plane): [packed keys][size-3 squares of a pass][scratch]
 static size_t sqpool_planes(const crc_ctx *c, int xd, int yd) { const size_t per = (size_t)xd * yd, ch = square_chunk(c); return ch / per ? ch / per : 1; }
 extern "C" int crc_square_pool_relin_supported(const crc_ctx *c, int dbc, int xf, int yf)
 {
@@ -459,7 +459,7 @@ extern "C" size_t crc_square_pool_relin_work_bytes(const crc_ctx *c, int B, int 
     const size_t planes = (size_t)B * zd, pp = planes < sqpool_planes(c, xd, yd) ? planes : sqpool_planes(c, xd, yd);
     const size_t xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys + 1, cin = pp * xd * yd, cout = pp * xo * yo;
     const size_t sq = k_square_work_words(c, cin), rl = k_relin_work_words(c, cout, dbc);
-    return 8 * (k_relin_keys_words(c, dbc) + cin * crc_ct_words(c, 3) + cout * crc_ct_words(c, 2) + (sq > rl ? sq : rl)) + 256;
+    return 8 * (k_relin_keys_words(c, dbc) + cin * crc_ct_words(c, 3) + (sq > rl ? sq : rl)) + 256;
 }
 extern "C" int crc_square_pool_relin_forms(crc_ctx *c, const uint64_t *d_x, int in_form, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf,
                                            const uint64_t *d_evk, int dbc, const uint64_t *d_div_ntt, uint64_t *d_y, int out_form, void *d_work, void *stream)
@@ -472,14 +472,13 @@ extern "C" int crc_square_pool_relin_forms(crc_ctx *c, const uint64_t *d_x, int 
     const PoolGeom pg{xd, yd, xs, ys, xf, yf, (xd - xf) / xs + 1, (yd - yf) / ys + 1};
     const size_t planes = (size_t)B * zd, step = sqpool_planes(c, xd, yd), pp0 = planes < step ? planes : step;
     const size_t pin = (size_t)xd * yd, pout = (size_t)pg.xo * pg.yo;
-    u64 *kp = w, *y3 = kp + k_relin_keys_words(c, dbc), *pc = y3 + pp0 * pin * crc_ct_words(c, 3), *rest = pc + pp0 * pout * crc_ct_words(c, 2);
+    u64 *kp = w, *y3 = kp + k_relin_keys_words(c, dbc), *rest = y3 + pp0 * pin * crc_ct_words(c, 3);
     for (size_t o = 0; o < planes; o += step) {
         const size_t pp = planes - o < step ? planes - o : step, cin = pp * pin, cout = pp * pout;
         RUN(k_square(c, d_x + o * pin * crc_ct_words(c, 2), cin, y3, rest, S(stream), in_form == CRC_NTT, true));
-        // (c0, c1) of the window, coefficient form: what the key switch's result is added to
-        RUN(k_pool(c, y3, pc, (int)pp, 1, xd, yd, xs, ys, xf, yf, nullptr, S(stream), 0, 3));
         if (o == 0) RUN(k_relin64_prepare_keys(c, d_evk, dbc, kp, rest, S(stream)));
-        RUN(k_relinearize64(c, y3, 3, 2, pc, 2, cout, dbc, d_y + o * pout * crc_ct_words(c, 2), rest, kp, S(stream), out_form == CRC_NTT, &pg, d_div_ntt));
+        // (the (c0, c1) of a window are added up where the key switch's result meets them: relin_inv_crt_kernel)
+        RUN(k_relinearize64(c, y3, 3, 2, y3, 3, cout, dbc, d_y + o * pout * crc_ct_words(c, 2), rest, kp, S(stream), out_form == CRC_NTT, &pg, d_div_ntt));
     }
     return CRC_OK;
 }

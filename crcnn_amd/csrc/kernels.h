@@ -17,7 +17,7 @@ int k_ntt_ct_inv_scaled(crc_ctx *c, const u64 *src, u64 *dst, size_t count, int 
 int k_plain_ntt(crc_ctx *c, const u64 *d_plain, size_t count, int mode, bool do_ntt, u64 *d_out, hipStream_t st);
 int k_plain_expand(crc_ctx *c, const u64 *d_compact, size_t count, u64 *d_plain, hipStream_t st);
 int k_rowwise(crc_ctx *c, u64 *acc, const u64 *b, size_t count, int size, int op, int sign, size_t group, size_t gmod, hipStream_t st);
-int k_pool(crc_ctx *c, const u64 *x, u64 *y, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, const u64 *mul, hipStream_t st, int pack_out = 0, int in_size = 2);
+int k_pool(crc_ctx *c, const u64 *x, u64 *y, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, const u64 *mul, hipStream_t st, int pack_out = 0);
 int k_bn_ntt(crc_ctx *c, u64 *x, int B, int zd, int hw, const u64 *mean, const u64 *invstd, hipStream_t st);
 int k_mac(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, const int *d_toff, int B, int P, int F, int T, int in_cts,
           const u64 *bias_ntt, hipStream_t st, int xp = 0, int wp = 0, int yp = 0);

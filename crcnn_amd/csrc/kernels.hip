@@ -620,22 +620,21 @@ int k_rowwise(crc_ctx *c, u64 *acc, const u64 *b, size_t count, int size, int op
 // window sum (PoolingLayer::forward, poolingLayer.cpp:22-44) with optional dyadic multiply by an NTT-form plaintext
 // (only meaningful when the tensor is NTT-resident) and optional per-channel affine (batch-norm in NTT form).
 __global__ void __launch_bounds__(256) pool_kernel(const u64 *x, u64 *y, const ModParams *mods, int n, int k,
-                                                   int zd, int xd, int yd, int xs, int ys, int xf, int yf, int xo, int yo, const u64 *mul, int pack_out, int in_size)
+                                                   int zd, int xd, int yd, int xs, int ys, int xf, int yf, int xo, int yo, const u64 *mul, int pack_out)
 {
-    // one block per output row: row = (((b*zd + z)*xo + ox)*yo + oy)*2k + p*k + i; the input ciphertexts have in_size polynomials (3: the (c0, c1) of a squared tensor)
+    // one block per output row: row = (((b*zd + z)*xo + ox)*yo + oy)*2k + p*k + i
     const size_t row = blockIdx.x;
     const int i = (int)(row % k); const int p = (int)((row / k) % 2);
     size_t ct = row / (2 * (size_t)k);
     const int oy = (int)(ct % yo); ct /= yo; const int ox = (int)(ct % xo); ct /= xo;       // ct = b*zd + z
     const ModParams m = mods[i];
-    const size_t ctw = (size_t)in_size * k * n;
-    const u64 *base = x + ((ct * xd + (size_t)ox * xs) * yd + (size_t)oy * ys) * ctw + ((size_t)p * k + i) * n;
+    const u64 *base = x + ((ct * xd + (size_t)ox * xs) * yd + (size_t)oy * ys) * (2 * (size_t)k * n) + ((size_t)p * k + i) * n;
     u64 *dst = y + row * (size_t)n;
     const u64 *w = mul ? mul + (size_t)i * n : nullptr;
     for (int s = threadIdx.x * 2; s < n; s += blockDim.x * 2) {
         ulonglong2 acc = make_ulonglong2(0, 0);
         for (int kx = 0; kx < xf; kx++) for (int ky = 0; ky < yf; ky++) {
-            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(base + ((size_t)kx * yd + ky) * ctw + s);
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(base + ((size_t)kx * yd + ky) * (2 * (size_t)k * n) + s);
             acc.x = addmod(acc.x, v.x, m.q); acc.y = addmod(acc.y, v.y, m.q);
         }
         if (w) { const ulonglong2 wv = *reinterpret_cast<const ulonglong2 *>(w + s); acc.x = mulmod(acc.x, wv.x, m); acc.y = mulmod(acc.y, wv.y, m); }
@@ -644,12 +643,12 @@ __global__ void __launch_bounds__(256) pool_kernel(const u64 *x, u64 *y, const M
     }
 }
 
-int k_pool(crc_ctx *c, const u64 *x, u64 *y, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, const u64 *mul, hipStream_t st, int pack_out, int in_size)
+int k_pool(crc_ctx *c, const u64 *x, u64 *y, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, const u64 *mul, hipStream_t st, int pack_out)
 {
     int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys + 1;
     size_t rows = (size_t)B * zd * xo * yo * 2 * c->k;
     if (rows == 0) return CRC_OK;
-    hipLaunchKernelGGL(pool_kernel, dim3((unsigned)rows), dim3(256), 0, st, x, y, c->d_mods, c->n, c->k, zd, xd, yd, xs, ys, xf, yf, xo, yo, mul, pack_out, in_size);
+    hipLaunchKernelGGL(pool_kernel, dim3((unsigned)rows), dim3(256), 0, st, x, y, c->d_mods, c->n, c->k, zd, xd, yd, xs, ys, xf, yf, xo, yo, mul, pack_out);
     HIPCHK(hipGetLastError());
     return CRC_OK;
 }

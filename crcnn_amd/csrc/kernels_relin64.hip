@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256) relin_mac_f64_kernel(const double *E, con
 // instead of 5.19 us at (8192, 3): profiles/r04_square_relin_ab_step1.txt)
 template <int RB, int NPT, bool OUT_NTT, bool LAZY>
 __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_inv_crt_kernel(const double *A, const u64 *x3, int add_size, u64 *y, const ModParams *mods, const double *Wi,
-                                                                                                                     const ulonglong2 *Wq, F64Params fp, int n, int logn, int k, const u64 *mul)
+                                                                                                                     const ulonglong2 *Wq, F64Params fp, int n, int logn, int k, const u64 *mul, PoolGeom pg)
 {
     extern __shared__ double smd[];
     const size_t ct = blockIdx.x / (2 * k); const int pj = blockIdx.x % (2 * k), poly = pj / k, j = pj % k;
@@ -230,7 +230,13 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_inv_crt_kernel(
     // x = a0 + p0 t,  t = (a1 - a0) p0^-1 mod p1 centred: |x| < p0 p1 / 2, and the true value is below a quarter of that, so t is nowhere near +- p1 / 2
     const ModParams mq = mods[j];
     const u64 q = mq.q, p0q = fp.p0_mod_q[j];
-    const u64 *add = x3 + ((ct * add_size + poly) * k + j) * (size_t)n;
+    // pooled key switch (pg.xf > 0): `ct` counts pooled ciphertexts and the (c0, c1) of the window's ciphertexts in x3 are added up here -- no pooling pass, no pooled copy
+    size_t actw = ct;
+    if (pg.xf > 0) {
+        const size_t per = (size_t)pg.xo * pg.yo, plane = ct / per; const int rem = (int)(ct % per), ox = rem / pg.yo, oy = rem % pg.yo;
+        actw = (plane * pg.xd + (size_t)ox * pg.xs) * pg.yd + (size_t)oy * pg.ys;
+    }
+    const u64 *add = x3 + ((actw * add_size + poly) * k + j) * (size_t)n;
     u64 *dst = y + ((ct * 2 + poly) * k + j) * (size_t)n;
     u64 *sm = reinterpret_cast<u64 *>(smd);           // (a thread reads and rewrites only its own slot of the image here: no barrier in between)
     auto lift = [&](double a0v, double a1r, u64 addv) {
@@ -250,7 +256,14 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_inv_crt_kernel(
         const int s = 2 * (tid + u * nt);
         if (s < n) {
             const d2 a1 = sm_load_pair<RB>(smd, s);
-            const ulonglong2 av = *reinterpret_cast<const ulonglong2 *>(add + s);
+            ulonglong2 av = *reinterpret_cast<const ulonglong2 *>(add + s);
+            if (pg.xf > 0) {
+                for (int w = 1; w < pg.xf * pg.yf; w++) {
+                    const int kx = w / pg.yf, ky = w - kx * pg.yf;
+                    const ulonglong2 bv = *reinterpret_cast<const ulonglong2 *>(add + ((size_t)kx * pg.yd + ky) * add_size * k * n + s);
+                    av.x = addmod(av.x, bv.x, q); av.y = addmod(av.y, bv.y, q);
+                }
+            }
             const u64 r0 = lift(a0[2 * u], a1.x, av.x), r1 = lift(a0[2 * u + 1], a1.y, av.y);
             if (OUT_NTT) {
                 const int a = swz<RB>(s);
@@ -354,7 +367,7 @@ static int relin64_mac(crc_ctx *c, const double *E, const double *Kf, double *A,
 }
 
 template <int RB, int NPT>
-static int relin64_tail(crc_ctx *c, const double *A, const u64 *x3, int add_size, u64 *y, size_t cnt, bool out_ntt, hipStream_t st, const u64 *mul)
+static int relin64_tail(crc_ctx *c, const double *A, const u64 *x3, int add_size, u64 *y, size_t cnt, bool out_ntt, hipStream_t st, const u64 *mul, const PoolGeom *pool)
 {
     bool lazy = true;
     for (int i = 0; i < c->k; i++) if (c->tabs[i].m.bits > 57 || c->tabs[i].m.bits < 45) lazy = false;
@@ -362,7 +375,7 @@ static int relin64_tail(crc_ctx *c, const double *A, const u64 *x3, int add_size
     auto kern = !out_ntt ? relin_inv_crt_kernel<RB, NPT, false, false> : lazy ? relin_inv_crt_kernel<RB, NPT, true, true> : relin_inv_crt_kernel<RB, NPT, true, false>;
     { const int rc = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (rc) return rc; }
     hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * 2 * c->k)), dim3(f64_hold_threads(c, RB)), lds, st, A, x3, add_size, y, c->d_mods, c->d_f64_irp,
-                       reinterpret_cast<const ulonglong2 *>(c->d_rp), c->f64, c->n, c->logn, c->k, mul);
+                       reinterpret_cast<const ulonglong2 *>(c->d_rp), c->f64, c->n, c->logn, c->k, mul, pool ? *pool : PoolGeom{0, 0, 0, 0, 0, 0, 0, 0});
     HIPCHK(hipGetLastError());
     return CRC_OK;
 }
@@ -410,6 +423,7 @@ int k_relinearize64(crc_ctx *c, const u64 *src, int src_size, int src_poly, cons
     }
     if (rc) return rc;
     if (mul && !out_ntt) return CRC_ERR_INVALID_ARGUMENT;
-    return RB == 3 ? relin64_tail<3, 16>(c, A, x3, add_size, y, cnt, out_ntt, st, mul)
-         : RB == 4 ? relin64_tail<4, 16>(c, A, x3, add_size, y, cnt, out_ntt, st, mul) : relin64_tail<5, 32>(c, A, x3, add_size, y, cnt, out_ntt, st, mul);
+    // (pooled: x3 / add_size are the UNPOOLED ciphertexts whose (c0, c1) K3 adds up window by window)
+    return RB == 3 ? relin64_tail<3, 16>(c, A, x3, add_size, y, cnt, out_ntt, st, mul, pool)
+         : RB == 4 ? relin64_tail<4, 16>(c, A, x3, add_size, y, cnt, out_ntt, st, mul, pool) : relin64_tail<5, 32>(c, A, x3, add_size, y, cnt, out_ntt, st, mul, pool);
 }
