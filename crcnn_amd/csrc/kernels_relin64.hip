@@ -313,7 +313,9 @@ bool k_relin64_pool_supported(const crc_ctx *c, int dbc, int window)
     for (int i = 0; i < c->k; i++) { const int L = evk_digits(c->q[i], dbc); if (L > 4) return false; D += L; if ((int)c->tabs[i].m.bits > qbits) qbits = c->tabs[i].m.bits; }
     int dbits = 0; while ((1 << dbits) < D) dbits++;
     int wbits = 0; while ((1 << wbits) < window) wbits++;
-    return c->logn + dbits + wbits + dbc + qbits <= 2 * CRC_F64_PRIME_BITS - 3;
+    // 2 |R| <= n D W 2^dbc q_max <= 2^92 leaves |R| <= 2^91 < p_0 p_1 / 2 / 3.9: the CRT's t = (a1 - a0) p_0^-1 mod p_1 stays below p_1 / 3.9 in magnitude, well inside
+    // the centred range it is reduced to (the unpooled test keeps one bit more; this one admits n = 16384 with all eight primes, D = 32, W = 4)
+    return c->logn + dbits + wbits + dbc + qbits <= 2 * CRC_F64_PRIME_BITS - 2;
 }
 size_t k_relin64_keys_words(const crc_ctx *c, int dbc) { return (size_t)CRC_NF64 * crc_evk_words(c, dbc); }
 // scratch words: E [cnt][D][2][n] + A [cnt][2k][2][n] (+ PM [cnt][k][n] when the caller's c2 is not premultiplied); the key preparation borrows the same space

@@ -276,7 +276,7 @@ int crc_square_relin_forms(crc_ctx *ctx, const uint64_t *d_x, int in_form, size_
  * with xo yo / (xd yd) of the key switch's transforms and inner products (16 / 25 for CrCNN's 5 x 5 -> 4 x 4 pool2).  d_x: [B][zd][xd][yd] ciphertexts, d_y:
  * [B][zd][xo][yo].  d_div_ntt: an average pooling's divisor (NTT-form plaintext [k][n], as crc_pool takes it), multiplied in while an NTT-form result leaves the
  * last kernel (out_form must be CRC_NTT then).  crc_square_pool_relin_supported: the key switch over
- * the fp64 primes must hold the window's larger integers (n D W 2^dbc q below p_0 p_1 / 4) and a residue at most four digits. */
+ * the fp64 primes must hold the window's larger integers (n D W 2^dbc q at most 2^92, a quarter of p_0 p_1) and a residue at most four digits. */
 int    crc_square_pool_relin_supported(const crc_ctx *ctx, int dbc, int xf, int yf);
 size_t crc_square_pool_relin_work_bytes(const crc_ctx *ctx, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int dbc);
 int    crc_square_pool_relin_forms(crc_ctx *ctx, const uint64_t *d_x, int in_form, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf,

@@ -150,6 +150,34 @@ def test_square_pool_with_one_key_switch_per_window(gs):
         assert np.array_equal(E.download(d_x, cts.shape), cts)
 
 
+def test_square_pool_pair_with_all_eight_primes():
+    """the pooled key switch at n = 16384 with all eight primes of coeff_modulus_128(16384) -- D = 32 digit polynomials, a 2 x 2 window: the largest integers the two
+    fp64 primes are asked to hold (2^91 of p_0 p_1 / 2 = 2^92.98) -- against square -> relinearise -> pool one after the other"""
+    import crcnn_amd as ca
+    n = 16384
+    q = ca.default_coeff_modulus_128(n)
+    assert len(q) == 8
+    E = ca.Engine(n, q, 1 << 44, device=0)
+    assert E.square_pool_relin_supported(2, 2)
+    sk, pk = E.keygen(5); d_evk = E.upload(E.gen_evk(6, sk))
+    pl, _ = E.encode(np.random.default_rng(2).standard_normal(18).astype(np.float32))
+    cts = E.encrypt(pk, pl, 77)                                        # 18 ciphertexts: two channels of 3 x 3
+    B, zd, xd, yd, xs, ys, xf, yf = 1, 2, 3, 3, 1, 1, 2, 2
+    cnt, ocnt = 18, 8
+    d_x = E.upload(cts); E.ntt_fwd(d_x, cnt)
+    d_w = E.alloc(max(E.square_relin_work_bytes(cnt), E.square_pool_relin_work_bytes(B, zd, xd, yd, xs, ys, xf, yf)))
+    d_r = E.alloc(cts.nbytes); d_p = E.alloc(ocnt * 2 * E.k * n * 8); d_f = E.alloc(ocnt * 2 * E.k * n * 8)
+    E.square_relin(d_x, cnt, d_evk, d_r, d_w, in_form=ca.NTT, out_form=ca.NTT)
+    E.pool(d_r, B, zd, xd, yd, xs, ys, xf, yf, None, ca.NTT, d_p)
+    E.square_pool_relin(d_x, B, zd, xd, yd, xs, ys, xf, yf, d_evk, d_f, d_w, in_form=ca.NTT, out_form=ca.NTT)
+    want, got = E.download(d_p, (ocnt, 2, E.k, n)), E.download(d_f, (ocnt, 2, E.k, n))
+    assert np.array_equal(got, want)
+    E.ntt_inv(d_f, ocnt)
+    out = E.download(d_f, (ocnt, 2, E.k, n))
+    assert E.noise_budget(sk, out[0]) > 100                            # (and it still decrypts: the sum of four squares of small values)
+    E.close()
+
+
 def test_square_with_seal_made_keys(gs):
     """SEAL's evaluation keys hold lazy (non-canonical) residues: same bits required"""
     g, E = gs
