@@ -117,7 +117,9 @@ CRC_HD bool conv1_fold_ok(u64 q, u32 bits, u32 fold)
 // PB: the accumulator biases of conv1_bias_table pair by pair, PB_j = B_2j + B_2j+1 2^8 (j < 6), PB_6 = B_12 -- null when the diagonals arrive biased already.  (The
 // kernel starts its accumulators at ZERO -- an inline constant of the first MFMA that touches a diagonal, instead of 13 x 4 register moves per tile -- and adds the biases
 // here, one word add per pair: D + B is the same word either way.)
-CRC_HD long long diag_fold_short_centred(const int (&D)[13], u64 q, u32 bits, u32 fold, long long bias_centred, const u32 *PB = nullptr)
+// the two halves of the reduction, so that a kernel can move the four words of U between lanes before it folds them (kernels_mfma1.hip: the 4 leftover filters of a
+// 20-filter layer sit in a quarter of a wave's lanes; the words of four tiles are gathered into one full wave before the expensive half runs)
+CRC_HD void diag_pack_words(const int (&D)[13], const u32 *PB, u32 (&u)[4])
 {
     u32 P[7];
     for (int j = 0; j < 6; j++) P[j] = (u32)D[2 * j] + ((u32)D[2 * j + 1] << 8);
@@ -127,7 +129,10 @@ CRC_HD long long diag_fold_short_centred(const int (&D)[13], u64 q, u32 bits, u3
     const u32 o0 = P[1] << 16, o1 = crc_alignbit(P[3], P[1], 16), o2 = crc_alignbit(P[5], P[3], 16), o3 = P[5] >> 16;
     const u64 lo64 = (((u64)P[2] << 32) | P[0]) + (((u64)o1 << 32) | o0);
     const u64 hi64 = (((u64)P[6] << 32) | P[4]) + (((u64)o3 << 32) | o2) + (lo64 < (((u64)P[2] << 32) | P[0]));
-    const u32 u0 = (u32)lo64, u1 = (u32)(lo64 >> 32), u2 = (u32)hi64, u3 = (u32)(hi64 >> 32);
+    u[0] = (u32)lo64; u[1] = (u32)(lo64 >> 32); u[2] = (u32)hi64; u[3] = (u32)(hi64 >> 32);
+}
+CRC_HD long long fold_words_centred(u32 u0, u32 u1, u32 u2, u32 u3, u64 q, u32 bits, u32 fold, long long bias_centred)
+{
     const u32 sb = bits - 32, m1 = (1u << sb) - 1;
     // fold 1: Uh = U >> b = (h1:h0) < 2^63;  x1 = Ul + h0 f + (h1 f << 32)  as words (A.lo, B.lo, B.hi)
     const u32 h0 = crc_alignbit(u2, u1, sb), h1 = crc_alignbit(u3, u2, sb);
@@ -139,12 +144,17 @@ CRC_HD long long diag_fold_short_centred(const int (&D)[13], u64 q, u32 bits, u3
     // fold 3: x2 >> b < 2^5
     u64 r = (u64)((u32)(x2 >> 32) >> sb) * fold + (((u64)((u32)(x2 >> 32) & m1) << 32) | (u32)x2);      // < 2^b + 2^31 < 2 q
     // centred representative of r + bias: r - q + bias lies in (-1.5 q, q/2 + 2^31): one conditional + q, then (the bias may have pushed it past q/2) one conditional - q
-    // (callers that have the choice pass bias_centred - q precomputed ... the compiler folds the constant subtraction when q and the bias are loop invariants)
     long long t = (long long)(r - q) + bias_centred;
     const long long h = (long long)(q >> 1);
     t += t < -h ? (long long)q : 0;
     t -= t > h ? (long long)q : 0;
     return t;
+}
+CRC_HD long long diag_fold_short_centred(const int (&D)[13], u64 q, u32 bits, u32 fold, long long bias_centred, const u32 *PB = nullptr)
+{
+    u32 u[4];
+    diag_pack_words(D, PB, u);
+    return fold_words_centred(u[0], u[1], u[2], u[3], q, bits, fold, bias_centred);
 }
 CRC_HD u64 centred_digit_bytes(long long cv) { return ((u64)cv + 0x0080808080808080ULL) ^ 0x0080808080808080ULL; }
 

@@ -280,6 +280,9 @@ CONV1_SHAPES = [
     (9, 11, 1, 2, 3, 4, 5, 1),             # ragged: 7 x 4 outputs (one partial row tile), window shorter than 8 both ways
     (12, 10, 3, 1, 8, 8, 32, 2),           # full 8 x 8 window
     (8, 8, 1, 1, 8, 8, 1, 5),              # a single output pixel and filter
+    (10, 9, 1, 1, 3, 3, 17, 2),            # 17 filters (one leftover), 8 x 7 outputs = 7 row tiles: the leftover waves' last group of four is ragged
+    (13, 13, 1, 1, 3, 3, 19, 1),           # 19 filters, 11 x 11 outputs = 16 row tiles (four full groups); one image
+    (7, 6, 1, 1, 4, 4, 20, 3),             # 20 filters, 4 x 3 outputs = 2 row tiles: fewer tiles than one group
 ]
 
 
