@@ -38,15 +38,20 @@ template <class F> void parallel_for(size_t count, size_t grain, F &&fn)
         }
     }
     if (extra == 0) { fn((size_t)0, count); return; }
+    // the threads taken go back to the budget however this scope is left
+    struct Return { int n; ~Return() { budget().fetch_add(n, std::memory_order_acq_rel); } } give_back{extra};
     const size_t parts = (size_t)extra + 1, per = (count + parts - 1) / parts;
     std::vector<std::thread> th;
     th.reserve(extra);
-    for (size_t p = 1; p < parts; p++) {
+    size_t inline_from = count;                 // ranges from here on run on the caller's thread: a thread that could not be started (EAGAIN under a process or
+    for (size_t p = 1; p < parts; p++) {        // thread limit) must not unwind through the joinable ones -- nothing throws across the C ABI above this
         const size_t b = std::min(count, p * per), e = std::min(count, b + per);
-        if (b < e) th.emplace_back([&fn, b, e] { fn(b, e); });
+        if (b >= e) continue;
+        try { th.emplace_back([&fn, b, e] { fn(b, e); }); }
+        catch (...) { inline_from = b; break; }
     }
     fn((size_t)0, std::min(count, per));
+    if (inline_from < count) fn(inline_from, count);
     for (auto &t : th) t.join();
-    budget().fetch_add(extra, std::memory_order_acq_rel);
 }
 }  // namespace crc_host

@@ -111,7 +111,13 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_digits_pool_f64
     u64 lo[NPT], hi[ONE ? 2 : NPT];
 #pragma unroll
     for (int u = 0; u < NPT; u++) { lo[u] = 0; if (!ONE) hi[u] = 0; }
-    auto spread = [&](u64 v) { return (v & mask) | (((v >> dbc) & mask) << F) | (((v >> (2 * dbc)) & mask) << (2 * F)) | ((v >> (3 * dbc)) << (3 * F)); };
+    // (a fourth field exists only where 3 F < 64: with three digits per residue the host's test bounds (L - 1) F alone, and a shift by 64 or more is undefined)
+    const bool four = 3 * F < 64;
+    auto spread = [&](u64 v) {
+        u64 w = (v & mask) | (((v >> dbc) & mask) << F) | (((v >> (2 * dbc)) & mask) << (2 * F));
+        if (four) w |= (v >> (3 * dbc)) << (3 * F);
+        return w;
+    };
     for (int kx = 0; kx < pg.xf; kx++) for (int ky = 0; ky < pg.yf; ky++) {
         const u64 *row = src + (((ct0 + (size_t)kx * pg.yd + ky) * src_size + src_poly) * k + i) * (size_t)n;
 #pragma unroll

@@ -813,7 +813,9 @@ ciphertext3D SquarePoolLayer::forward(ciphertext3D input)
 {
     checkInput(input, zd, xd, yd, "SquarePoolLayer");
     if (!ev_keys16) throw invalid_argument("not enough evaluation keys");
-    // an average pooling's divisor multiplies slot-wise: the pooled tensor is made NTT-resident for it whatever form the network asked for
+    // an average pooling's divisor multiplies slot-wise: the pooled tensor is made NTT-resident for it, and brought back to coefficients when the network asked for
+    // those.  The packed / limb operand forms are not produced here (Network::forward never asks this layer for them)
+    if (out_form != CRC_NTT && out_form != CRC_COEFF) throw invalid_argument("SquarePoolLayer: out_form must be CRC_NTT or CRC_COEFF");
     const int of = d_div ? CRC_NTT : out_form;
     ciphertext3D out(input.B, zo, xo, yo, of);
     ensure(g_scratch, crc_square_pool_relin_work_bytes(ctx(), input.B, zd, xd, yd, xs, ys, xf, yf, 16));
@@ -877,6 +879,8 @@ void Network::printNetworkStructure()
 ciphertext3D Network::forward(ciphertext3D input)
 {   // network.cpp:22-47
     const int L = (int)layers.size();
+    // the planning flag is this forward's only: layers called directly afterwards plan with the default again
+    struct Restore { bool &ref; bool old; ~Restore() { ref = old; } } restore_matrix_cores{g_matrix_cores, g_matrix_cores};
     g_matrix_cores = matrix_cores;
     // choose the form of every boundary: NTT between linear layers when resident, coefficient form into Square and out of the net
     // conv / dense weights go into the MAC kernels' operand form (28-bit limb pairs) once; moduli above 55 bits cannot be packed
@@ -1068,6 +1072,14 @@ int Network::fuse()
     const int n = N(), k = K();
     const size_t rowb = (size_t)k * n * 8;
     int removed = 0;
+    // The client-side refresh sits in front of layers[layer_before_reenc] (network.cpp:30-34).  No fold may span it, and the index follows the layers it
+    // counts: erasing a layer below it moves the refresh point down with the layers behind it, so the refresh still runs in front of the same layer.
+    auto refreshBetween = [&](size_t i) { return layer_before_reenc >= 0 && (int)i + 1 == layer_before_reenc; };
+    auto eraseLayer = [&](size_t idx) {
+        layers.erase(layers.begin() + idx);
+        if (layer_before_reenc >= 0 && (int)idx < layer_before_reenc) layer_before_reenc--;
+        removed++;
+    };
     for (auto &l : layers) {                                // the folding kernels work on canonical residues
         // (a network that has already run holds its weights in the MAC kernels' operand forms: packed residues are unpacked, matrix-core forms -- which drop the
         // canonical copy -- are rebuilt from the layer's plaintexts, so fuse() may follow a forward())
@@ -1084,7 +1096,7 @@ int Network::fuse()
     for (size_t i = 0; i + 1 < layers.size(); i++) {
         auto conv = dynamic_pointer_cast<ConvolutionalLayer>(layers[i]);
         auto pool = dynamic_pointer_cast<PoolingLayer>(layers[i + 1]);
-        if (!conv || !pool || (int)i + 1 == layer_before_reenc) continue;
+        if (!conv || !pool || refreshBetween(i)) continue;
         conv->upload();
         if (conv->streamed) continue;
         if (pool->zd != conv->nf || pool->xd != conv->xo || pool->yd != conv->yo) continue;
@@ -1109,23 +1121,22 @@ int Network::fuse()
         fused->d_b[0] = inttCopy(fused->d_b[1], conv->nf);
         fused->filters_already_ntt = true;
         layers[i] = fused;
-        layers.erase(layers.begin() + i + 1);
-        removed++;
+        eraseLayer(i + 1);
     }
     // 1b. Square + pooling: one key switch per pooled ciphertext (SquarePoolLayer)
     for (size_t i = 0; i + 1 < layers.size(); i++) {
         auto sq = dynamic_pointer_cast<SquareLayer>(layers[i]);
         auto pool = dynamic_pointer_cast<PoolingLayer>(layers[i + 1]);
-        if (!sq || !pool || (int)i + 1 == layer_before_reenc) continue;
+        if (!sq || !pool || refreshBetween(i)) continue;
         if (!crc_square_pool_relin_supported(ctx(), 16, pool->xf, pool->yf)) continue;
-        layers[i] = make_shared<SquarePoolLayer>(sq->name + "+" + pool->name, pool->xd, pool->yd, pool->zd, pool->xs, pool->ys, pool->xf, pool->yf, sq->th_count, pool->d_div);
-        layers.erase(layers.begin() + i + 1);
-        removed++;
+        layers[i] = make_shared<SquarePoolLayer>(sq->name + "+" + pool->name, pool->xd, pool->yd, pool->zd, pool->xs, pool->ys, pool->xf, pool->yf, sq->th_count,
+                                                 pool->d_div);
+        eraseLayer(i + 1);
     }
     // 2. batch-norm + conv / dense
     for (size_t i = 0; i + 1 < layers.size(); i++) {
         auto bn = dynamic_pointer_cast<BatchNormLayer>(layers[i]);
-        if (!bn || (int)i + 1 == layer_before_reenc) continue;
+        if (!bn || refreshBetween(i)) continue;
         auto conv = dynamic_pointer_cast<ConvolutionalLayer>(layers[i + 1]);
         auto fc = dynamic_pointer_cast<FullyConnectedLayer>(layers[i + 1]);
         if (!conv && !fc) continue;
@@ -1138,8 +1149,7 @@ int Network::fuse()
             if (fc->tile_built) continue;
             fc->fold_bn = bn;
             layers[i + 1]->name = bn->name + "+" + layers[i + 1]->name;
-            layers.erase(layers.begin() + i);
-            removed++;
+            eraseLayer(i);
             continue;
         }
         shared_ptr<DeviceBuffer> &dw = conv ? conv->d_w : fc->d_w;
@@ -1167,8 +1177,7 @@ int Network::fuse()
         chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
         db[0] = inttCopy(db[1], F);
         layers[i + 1]->name = bn->name + "+" + layers[i + 1]->name;
-        layers.erase(layers.begin() + i);
-        removed++;
+        eraseLayer(i);
     }
     chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
     return removed;

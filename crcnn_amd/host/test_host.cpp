@@ -233,6 +233,40 @@ static int do_api(int argc, char **argv)
     // refresh path (network.cpp:30-34) keeps the result
     net.layer_before_reenc = 3; floatCube dec2 = decryptImage(net.forward(x)); net.layer_before_reenc = -1;
     for (int o = 0; o < 3; o++) if (fabs(dec2[0][o][0] - dec[0][o][0]) > 1e-4) { fprintf(stderr, "refresh changed the result\n"); return 7; }
+    // fuse() and the refresh point: the refresh stays in front of the SAME layer when folds below it shift the indices, and no fold spans it.
+    // [conv, avgpool, square, pool2, fc] with the refresh in front of pool2 (index 3): conv + avgpool fold (index 3 -> 2), square + pool2 must not pair up.
+    {
+        plaintext2D gw(3, vector<Plaintext>(50)); vector<Plaintext> gb(3);
+        for (int i = 0; i < 3; i++) { for (int j = 0; j < 50; j++) gw[i][j] = enc(fw[(i * 50 + j) % 216]); gb[i] = enc(fb[i]); }
+        auto build = [&]() {
+            Network nn;
+            nn.getLayers().push_back(shared_ptr<Layer>(new ConvolutionalLayer("c", 14, 14, 1, 1, 1, 3, 3, 2, 4, ew, eb)));
+            nn.getLayers().push_back(shared_ptr<Layer>(new AvgPoolingLayer("p", 12, 12, 2, 2, 2, 2, 2)));
+            nn.getLayers().push_back(shared_ptr<Layer>(new SquareLayer("s", 2)));
+            nn.getLayers().push_back(shared_ptr<Layer>(new PoolingLayer("p2", 6, 6, 2, 1, 1, 2, 2)));
+            nn.getLayers().push_back(shared_ptr<Layer>(new FullyConnectedLayer("g", 50, 3, 2, gw, gb)));
+            return nn;
+        };
+        Network plain = build(); plain.layer_before_reenc = 3;
+        floatCube want = decryptImage(plain.forward(x));
+        Network fusedn = build(); fusedn.layer_before_reenc = 3;
+        const int removed = fusedn.fuse();
+        const int at = fusedn.layer_before_reenc;
+        if (at < 0 || at >= fusedn.getNumLayers() || fusedn.getLayer(at)->getName() != "p2") {
+            fprintf(stderr, "fuse() moved the refresh point: %d layers removed, refresh now in front of index %d (%s)\n", removed, at,
+                    at >= 0 && at < fusedn.getNumLayers() ? fusedn.getLayer(at)->getName().c_str() : "?");
+            return 14;
+        }
+        if (at != 3 - removed) { fprintf(stderr, "refresh index %d after %d folds below it\n", at, removed); return 14; }
+        floatCube got = decryptImage(fusedn.forward(x));
+        for (int o = 0; o < 3; o++)
+            if (fabs(got[0][o][0] - want[0][o][0]) > 1e-4) { fprintf(stderr, "fused network with a refresh differs: %f vs %f\n", got[0][o][0], want[0][o][0]); return 14; }
+        // without a refresh the same network does pair square + pool2, bit-identically
+        Network a = build(), b2 = build();
+        const int removed2 = b2.fuse();
+        if (removed2 <= removed) { fprintf(stderr, "square + pooling did not pair up without a refresh (%d vs %d)\n", removed2, removed); return 14; }
+        if (a.forward(x).toHost() != b2.forward(x).toHost()) { fprintf(stderr, "fused network differs from the unfused one\n"); return 14; }
+    }
     // save / load of the encoded parameters in SEAL's Plaintext wire format (savePlaintextParameters / istream ctor)
     { ofstream f(dir + "/enc_model.bin", ios::binary); for (int i = 0; i < net.getNumLayers(); i++) net.getLayer(i)->savePlaintextParameters(&f); }
     { ifstream f(dir + "/enc_model.bin", ios::binary);

@@ -18,7 +18,7 @@ NAMES = [n for n in ["tiny256", "approx256", "wopad256", "tiny1024_eng", "tiny40
          if os.path.exists(os.path.join(GOLD, f"net_{n}.json"))]
 
 
-def run_net(name, resident, batch=1):
+def run_net(name, resident, batch=1, fuse=False):
     import crcnn_amd as ca
     from crcnn_amd.netrun import Network
     g = load_net_golden(name)
@@ -26,6 +26,8 @@ def run_net(name, resident, batch=1):
     E = ca.Engine(g["n"], g["q"], g["t"], device=0)
     d_evk = E.upload(evk)
     net = Network(E, g["model"], h5_path=os.path.join(GOLD, "models", g["model"] + ".h5"), resident=resident, d_evk=d_evk)
+    if fuse:
+        net.fuse()
     net.prepare(batch)
     xb = np.ascontiguousarray(np.repeat(x[None], batch, axis=0))
     d_x = E.upload(xb)
@@ -38,6 +40,7 @@ def run_net(name, resident, batch=1):
 
     d_out = net.forward(d_x, batch, timer=timer)
     out = E.download(d_out, (batch, 1, 10, 1, 2, E.k, E.n))
+    run_net.last_plan = [(pl[0], pl[1]) for pl in net.plan]
     E.close()
     return g, O, sk, out, digests
 
@@ -124,7 +127,7 @@ def test_tilewise_limb_weights_and_two_level_chunking(name, monkeypatch):
     E.close()
 
 
-@pytest.mark.parametrize("name", [n for n in ["approx256", "wopad256", "approx8192_t42", "wopad16384_t44"] if n in NAMES])
+@pytest.mark.parametrize("name", [n for n in ["approx256", "wopad256", "approx8192_t42", "approx8192k4_t42", "wopad16384_t44"] if n in NAMES])
 def test_square_and_pooling_share_one_key_switch(name):
     """Network.fuse() pairs the Square layer with the pooling behind it (crc_square_pool_relin_forms: the digits of a window's c2's are summed before ONE key switch):
     ApproxPlainModel's average pooling (the divisor multiplies the pooled ciphertexts) and PlainModelWoPad's sum pooling, three images -- the compiled reference's output
@@ -208,8 +211,13 @@ def test_bench_chunk_matches_reference():
 def test_all_eight_primes_match_reference():
     """PlainModelWoPad at n = 16384 with all EIGHT primes of coeff_modulus_128(16384) -- the coefficient modulus CrCNN's own setParameters picks (globals.cpp) -- and
     t = 2^44 >= q_i / 2^11 (the slow plain lift).  fc3's NTT-form weights (419 GB) do not fit: the layer streams coefficient-form plaintexts (netrun stream_share).
-    One image, NTT-resident: the compiled reference's ciphertext (an hour of CPU time in oracle/make_golden_nets.py)"""
+    One image, NTT-resident: the compiled reference's ciphertext (an hour of CPU time in oracle/make_golden_nets.py).
+    Then the same after Network.fuse(): Square + pooling with ONE key switch per pooled ciphertext (crc_square_pool_relin_forms) where its integers are largest --
+    D = 32 digit polynomials, a 2 x 2 window: up to 2^91 of the 2^92.98 the two fp64 primes hold -- against the same reference ciphertext"""
     g, O, sk, out, _ = run_net("wopad16384k8_t44", resident=True, batch=1)
+    assert sha(out[0]) == g["out_sha256"]
+    g, O, sk, out, _ = run_net("wopad16384k8_t44", resident=True, batch=1, fuse=True)
+    assert ("squarepool", "act1+pool2") in run_net.last_plan, run_net.last_plan
     assert sha(out[0]) == g["out_sha256"]
 
 

@@ -110,7 +110,8 @@ def test_square_and_relinearize(gs):
 def test_square_pool_with_one_key_switch_per_window(gs):
     """crc_square_pool_relin_forms: Square + relinearise + sum pooling with the digit polynomials of a window added BEFORE the key switch (one key switch per pooled
     ciphertext).  Must be the ciphertexts of crc_square_relin_forms followed by crc_pool -- themselves pinned to the reference's relinearize / pooling goldens above and
-    in test_gpu_layers.py -- bit for bit, in every combination of forms, for CrCNN's overlapping 2 x 2 / 1 window and a decimating 2 x 2 / 2 one"""
+    in test_gpu_layers.py -- AND those of the CPU oracle's square -> relinearise -> pool, bit for bit, in every combination of forms, for CrCNN's overlapping
+    2 x 2 / 1 window and a decimating 2 x 2 / 2 one"""
     import crcnn_amd as ca
     g, E = gs
     base = g["ct_in"]
@@ -134,6 +135,14 @@ def test_square_pool_with_one_key_switch_per_window(gs):
         E.square_relin(d_x, cnt, d_evk, d_r, d_w)
         E.pool(d_r, B, zd, xd, yd, xs, ys, xf, yf, None, ca.COEFF, d_p)
         want = E.download(d_p, (out_cnt, 2, E.k, E.n))
+        if E.n <= 4096:
+            # ... and of the CPU oracle's Evaluator::square + relinearize followed by PoolingLayer::forward (evaluator.cpp:702-884, 934-1069; poolingLayer.cpp:22-44),
+            # image by image: the pooled path is checked against the restatement of the reference, not only against the engine's own unpooled sequence
+            from oracle import orc
+            O = orc.Oracle(E.n, [int(v) for v in E.q], E.t)
+            per = cts.reshape(B, zd, xd, yd, 2, E.k, E.n)
+            ow = np.stack([np.asarray(O.pool(O.square_layer(per[b], g["evk"]), xs, ys, xf, yf)) for b in range(B)])
+            assert np.array_equal(want, ow.reshape(want.shape)), ("oracle", B, zd, xd, yd, xs, ys, xf, yf)
         for fin, fout in [(ca.COEFF, ca.COEFF), (ca.NTT, ca.NTT), (ca.NTT, ca.COEFF), (ca.COEFF, ca.NTT)]:
             E.L.crc_memset(E.c, E.p(d_f), 0xff, out_cnt * 2 * E.k * E.n * 8, E.stream)
             E.square_pool_relin(d_xn if fin == ca.NTT else d_x, B, zd, xd, yd, xs, ys, xf, yf, d_evk, d_f, d_w, in_form=fin, out_form=fout)
