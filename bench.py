@@ -12,9 +12,14 @@ the C++ host classes (crcnn_amd/host: CnnBuilder builds the network from the HDF
 and signatures) over include/crcnn_hip.h.  This script is the harness around it: the client side (keys, encrypted inputs: tools/benchkit/client.py), the child process,
 the verification of the ciphertexts that come back (the compiled reference's goldens, decrypted logits), the roofline arithmetic and the CPU baseline.
   --python-twin  additionally times the same workload through the Python twin (crcnn_amd/netrun.py, ctypes over the same C ABI) as a cross-check
-N > 1: one rank per GPU under torch.distributed; every rank runs the Python twin (tools/benchkit/twin.py: image-sharded, the encoded weights broadcast once with RCCL
-through the engine's C ABI, barrier + synchronise on both sides of the timed steps, max over ranks).  The C++ classes have the same broadcast
-(Network::broadcastParameters) but no launcher of their own.
+N > 1: the SAME measured path, one bench_host process per GPU.  Every rank of this script (started by torch.distributed.run, or by the script itself when it is
+given --gpus N without a launcher) prepares its own encrypted images on the host cores and starts its bench_host child -- the Python ranks never touch a GPU.  Rank 0's
+child makes the RCCL rendezvous id (crc_comm_unique_id) and leaves it in a file, every child joins (crc_comm_create), the encoded model goes out once with
+Network::broadcastParameters, and the children bracket their timed steps with an all-gather + stream synchronisation and gather the elapsed times: `value` = all ranks'
+images / the slowest rank's time.  The Python ranks only rendezvous over gloo (CPU) to agree on the file name and to count the ranks whose outputs verified.
+  --python-twin at N > 1: the round-4 path (every rank runs netrun.py under torch.distributed) instead
+  --stream-inputs ciphertext|plaintext|both: besides the resident measurement, passes in which every launch's images are uploaded over PCIe while the previous
+                launch is evaluated (two device buffers, a copy stream beside the compute stream); reported under "streamed"
 
 Besides the contract fields the line carries
   roofline      the dominant kernel against the roof that bounds it: int8 matrix-core TOP/s for the limb GEMM (frac = executed, useful_frac = without padding; the HBM view
@@ -50,8 +55,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="encrypted images per GPU per step (default: the config's)")
     ap.add_argument("--chunk", type=int, default=None, help="images processed per layer launch")
     ap.add_argument("--tail", type=int, default=None, help="chunks per launch of the dense layers (two-level chunking; default: the config's)")
-    ap.add_argument("--distinct", type=int, default=None, help="distinct encrypted images, tiled to the batch (default: 32 for tiny4096 -- BASELINE configs[0]'s images, every "
-                    "one checked against the compiled reference -- 4 otherwise)")
+    ap.add_argument("--distinct", type=int, default=None, help="distinct encrypted images, tiled to the batch (default: the config's -- 32 for tiny4096 = BASELINE configs[0]'s "
+                    "images, every one checked against the compiled reference; 32 for approx8192; 12 for wopad16384, whose images are 784 MiB each)")
     ap.add_argument("--no-fuse", action="store_true", help="do not fold pooling / batch-norm layers (Network::fuse)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--also", default="auto", help="further workloads measured in the same invocation and reported under \"also\" (auto: approx8192 = BASELINE configs[2]/[3] and "
@@ -64,6 +69,12 @@ def parse():
     ap.add_argument("--unfused-images", type=int, default=0, help="twin only: images of an extra pass with every reference layer run separately (the reference's T_LAYER columns)")
     ap.add_argument("--t-bits", type=int, default=None, help="twin only: override the plain modulus t = 2^bits")
     ap.add_argument("--launch-check", action="store_true", help="only start the ranks, rendezvous (gloo, no GPU call) and report: CPU test of the self-launch path")
+    ap.add_argument("--stream-inputs", default="none", choices=["none", "ciphertext", "plaintext", "both"],
+                    help="also measure with the input launches streamed over PCIe (double-buffered upload beside the kernels): 784 ciphertexts per image, or the 784 pixel "
+                         "plaintexts per image + encryption on the device")
+    ap.add_argument("--stream-steps", type=int, default=2, help="passes over the batch of the streamed measurement")
+    ap.add_argument("--mnist-dir", default=os.environ.get("CRC_MNIST_DIR", ""), help="directory with t10k-images-idx3-ubyte (and t10k-labels-idx1-ubyte): when present the "
+                    "distinct images are real MNIST test images and the line reports agreement with the float model's predictions (utils.cpp:20-53)")
     return ap.parse_args()
 
 
@@ -74,19 +85,21 @@ def sizes(args, cfg, batch=None):
     return B, C, G
 
 
-def run_host(args, cfg_name, steps, warmup, batch=None, device=0):
-    """one workload through crcnn_amd/lib/bench_host.  Returns (bench line dict, all checks ok)."""
+def run_host(args, cfg_name, steps, warmup, batch=None, device=0, ranks=None, stream="none"):
+    """one workload through crcnn_amd/lib/bench_host.  Returns (bench line dict, all checks ok).  ranks: benchkit.dist.HostRanks when this process is one of several
+    (one bench_host per GPU); only rank 0 gets a line back."""
     import crcnn_amd as ca
     from benchkit import cpu, geometry
     from benchkit.client import Client
     cfg = dict(CONFIGS[cfg_name])
     B, C, G = sizes(args, cfg, batch)
     q = cfg.get("q") or ca.default_coeff_modulus_128(cfg["n"])[:cfg["k"]]
-    D = max(1, min(args.distinct or (32 if cfg_name == "tiny4096" else 4), C * G, B))
-    cores = cpu.host_cores()
+    D = max(1, min(args.distinct or cfg.get("distinct", 4), C * G, B))
+    rank, world = (ranks.rank, ranks.world) if ranks else (0, 1)
+    cores = max(1, cpu.host_cores() // (ranks.local_world if ranks else 1))
     t_client = time.time()
-    client = Client(cfg, q)
-    imgs = client.images(D)
+    client = Client(cfg, q, rank=rank)
+    imgs, mnist = client.images_or_mnist(D, args.mnist_dir)
     # (CRC_BENCH_KEEP=<dir>: the encrypted inputs and the bench_host command line stay there afterwards -- tools/measure_round.sh profiles that command with rocprofv3)
     keep_dir = os.environ.get("CRC_BENCH_KEEP")
     if keep_dir:
@@ -104,18 +117,59 @@ def run_host(args, cfg_name, steps, warmup, batch=None, device=0):
         cmd = [exe, f"model={cfg['model']}", "h5=" + os.path.join(ROOT, "tests", "golden", "models", cfg["model"] + ".h5"), f"n={cfg['n']}", f"k={cfg['k']}", f"t={cfg['t']}",
                "q=" + ",".join(str(int(v)) for v in q), "inputs=" + os.path.join(work, "inputs.u64"), f"distinct={D}", f"batch={B}", f"chunk={C}", f"group={G}", f"steps={steps}",
                f"warmup={warmup}", "outputs=" + os.path.join(work, "outputs.u64"), f"fuse={0 if args.no_fuse else 1}", f"key_seed={KEY_SEED}", f"device={device}"]
+        if ranks:
+            cmd += [f"rank={rank}", f"world={world}", f"local_world={ranks.local_world}", "rendezvous=" + ranks.rendezvous_path(cfg_name)]
+        modes = {"none": [], "both": ["ciphertext", "plaintext"]}.get(stream, [stream])
+        if modes:
+            if "plaintext" in modes:
+                client.write_plain_images(imgs, os.path.join(work, "plain_inputs.u64"))
+                cmd.append("plain_inputs=" + os.path.join(work, "plain_inputs.u64"))
+            cmd += ["stream_inputs=" + ",".join(modes), f"stream_steps={max(1, args.stream_steps)}"]
         if keep_dir:
             open(os.path.join(work, "cmd.txt"), "w").write(" ".join(cmd) + "\n")
-        p = subprocess.run(cmd, capture_output=True, text=True, timeout=3000)
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC (RCCL across processes)
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=3000, env=env)
+        failed = None
         if p.returncode != 0:
-            raise SystemExit(f"bench.py: bench_host failed (exit {p.returncode}): {p.stderr[-600:]}")
+            failed = f"bench.py: bench_host failed on rank {rank} (exit {p.returncode}): {p.stderr[-600:]}"
+        if ranks and ranks.any(failed is not None):                # every rank learns of a failure anywhere: nobody waits for a line that will not come
+            raise SystemExit(failed or f"bench.py: bench_host failed on another rank (this is rank {rank})")
+        if failed:
+            raise SystemExit(failed)
         r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
         outs = np.fromfile(os.path.join(work, "outputs.u64"), dtype=np.uint64).reshape(D, 10, 2, cfg["k"], cfg["n"])
+        outs_pt = None
+        if "plaintext" in modes:
+            outs_pt = np.fromfile(os.path.join(work, "outputs.u64.streamed"), dtype=np.uint64).reshape(D, 10, 2, cfg["k"], cfg["n"])
     finally:
         if not keep_dir:
             shutil.rmtree(work, ignore_errors=True)
-    check, ok = client.verify(cfg_name, imgs, outs, x0_sha)
-    check["ranks_verified"] = "1/1" if ok else "0/1"
+    check, ok = client.verify(cfg_name, imgs, outs, x0_sha, golden=mnist is None)
+    if mnist is not None:               # real test images: agreement of the decrypted predictions with the labels and with the float model's predictions the reference ships
+        preds = client.last_predictions
+        mnist = dict(mnist, encrypted_predictions=preds)
+        if "labels" in mnist:
+            mnist["agree_with_labels"] = f"{sum(int(a == b) for a, b in zip(preds, mnist['labels']))}/{len(preds)}"
+        if "reference_predictions" in mnist:
+            mnist["agree_with_reference_plain_model"] = f"{sum(int(a == b) for a, b in zip(preds, mnist['reference_predictions']))}/{len(preds)}"
+        check["mnist"] = mnist
+    streamed = None
+    if modes:
+        streamed = r.get("streamed")
+        for sm in streamed or []:
+            sm["vs_resident"] = round(sm["images_per_s"] / r["images_per_s"], 4)
+            if sm["mode"] == "plaintext":                            # fresh device-side encryptions of the same images: checked by decrypting what came back
+                chk_pt, ok_pt = client.verify(cfg_name, imgs, outs_pt, None, golden=False)
+                sm["check"] = {k_: chk_pt[k_] for k_ in ("predictions_match_plain_model", "max_logit_abs_err", "noise_budget_bits")}
+                ok = ok and ok_pt
+            else:
+                ok = ok and bool(sm["outputs_identical_to_resident"])
+    verified = ranks.count(ok) if ranks else int(ok)
+    check["ranks_verified"] = f"{verified}/{world}"
+    ok = verified == world
+    if ranks and rank != 0:
+        return None, ok
 
     # ---- per-layer figures and the roofline of the dominant kernel: algorithmic bytes per launch / measured launch duration
     L = r["layers"]
@@ -155,7 +209,7 @@ def run_host(args, cfg_name, steps, warmup, batch=None, device=0):
                                       "the kernel named plus, where the neighbouring layer wants another operand form, one conversion kernel",
                         algorithmic_bytes_per_launch=int(alg_bytes), modmul_per_s=round(modmul_s, 1) if modmul_s else None)
     cpu_line = None
-    if args.cpu_seconds > 0:
+    if args.cpu_seconds > 0 and world == 1:                        # (the CPU baseline is timed on rank 0 at N = 1 only)
         evk = client.evaluation_keys() if any(pl[0] in ("square", "squarepool") for pl in (plan or [])) else None
         cpu_line = cpu.cpu_baseline_reference(cfg, q, client.W, x0, cores, evk=evk) or cpu.cpu_baseline(cfg, q, client.W, x0, args.cpu_seconds)
         cpu_line["value"] = round(cpu_line["value"], 6); cpu_line["mac_per_s"] = round(cpu_line["mac_per_s"], 1)
@@ -166,14 +220,15 @@ def run_host(args, cfg_name, steps, warmup, batch=None, device=0):
                                           threads=c1f["ref_threads"], where="build container (8 cores), the compiled reference on 32 images: tests/golden/c1_tiny4096_t32.json")
     hbm = r["hbm"]
     line = {
-        "metric": "encrypted images/sec", "value": round(r["images_per_s"], 4), "unit": "images/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": r["ms_per_step"],
+        "metric": "encrypted images/sec", "value": round(r["images_per_s"], 4), "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": r["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
         "data": f"synthetic ({D} distinct MNIST-like encrypted images tiled to the batch: one launch of {C * G} images resident in HBM, re-read by every launch of the step; "
                 f"trained weights from {cfg['model']}.h5)",
         "config": {"workload": f"{cfg['model']}.h5 n={cfg['n']} k={cfg['k']} t=2^{cfg['t'].bit_length() - 1} batch={B}/GPU chunk={C}" + (f" (dense layers: {C * G})" if G > 1 else "") + f" ({cfg_name}, BASELINE configs)",
-                   "host": r["host"], "mode": "NTT-resident" + ("" if args.no_fuse else " + Network::fuse (conv/pool and batch-norm folding)"), "parallelism": "image-sharded x1"},
+                   "host": r["host"], "mode": "NTT-resident" + ("" if args.no_fuse else " + Network::fuse (conv/pool and batch-norm folding)"), "parallelism": f"image-sharded x{world}"},
         "ms_per_layer": ms_per_layer, "mac_kernel_per_layer": kernels, "mfma_useful_frac_per_layer": useful, "roofline": roofline, "cpu_baseline": cpu_line, "check": dict(check, all_ok=bool(ok)),
-        "setup_s": r["setup_s"], "client_setup_s": round(client_s, 1), "weight_broadcast": None,
+        "setup_s": r["setup_s"], "client_setup_s": round(client_s, 1), "weight_broadcast": r.get("weight_broadcast"), "timing": r.get("timing"), "per_rank": r.get("per_rank"),
+        "streamed": streamed,
         "hbm_plan": dict(hbm, note="bytes on this rank: parameters = the layers' encoded weights in their kernels' operand forms (limb copies replace the canonical ones), activation_slots = "
                                    "the two ping-pong tensors Network::forward keeps + the dense layers' group input, work_buffer = the shared scratch of the layer calls, input_launch = the "
                                    "encrypted images of one launch"),
@@ -187,7 +242,7 @@ def twin_line(args, D_, cfg_name, steps, warmup, batch, full):
 
 
 ALSO_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "config", "data", "ms_per_layer", "mac_kernel_per_layer", "mfma_useful_frac_per_layer", "roofline",
-             "cpu_baseline", "check", "setup_s", "weight_broadcast", "hbm_plan", "python_twin")
+             "cpu_baseline", "check", "setup_s", "weight_broadcast", "per_rank", "streamed", "hbm_plan", "python_twin")
 
 
 def main():
@@ -207,19 +262,27 @@ def main():
         also = "approx8192,wopad16384" if args.config == "tiny4096" and args.batch is None else "none"
     names = [] if also == "none" else also.split(",")
     line, ok = None, True
-    if world == 1:
-        line, ok = run_host(args, args.config, args.steps, args.warmup, batch=args.batch)
-        D_ = None
-        if args.python_twin:
+    if world == 1 or not args.python_twin:
+        ranks = bdist.HostRanks(args) if world > 1 else None
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if ranks:                                                   # (counting devices does not initialise the GPU; a rehearsal with more ranks than GPUs shares devices)
+            import torch
+            local %= max(1, torch.cuda.device_count())
+        line, ok = run_host(args, args.config, args.steps, args.warmup, batch=args.batch, device=local, ranks=ranks, stream=args.stream_inputs)
+        if args.python_twin and world == 1:
             D_ = bdist.Dist(args)
             tw, ok2 = twin_line(args, D_, args.config, args.steps, args.warmup, args.batch, True)
             line["python_twin"] = dict(value=tw["value"], ms_per_layer=tw["ms_per_layer"], check=tw["check"], vs_host=round(tw["value"] / line["value"], 4),
                                        reference_layer_structure=tw.get("reference_layer_structure"))
             ok = ok and ok2
         for nm in names:
-            second, ok2 = run_host(args, nm, args.also_steps, 0, batch=args.also_batch)
+            second, ok2 = run_host(args, nm, args.also_steps, 0, batch=args.also_batch, device=local, ranks=ranks,
+                                   stream="ciphertext" if args.stream_inputs != "none" and nm == "approx8192" else "none")
             ok = ok and ok2
-            line.setdefault("also", []).append({k_: second[k_] for k_ in ALSO_KEYS if k_ in second})
+            if line is not None:
+                line.setdefault("also", []).append({k_: second[k_] for k_ in ALSO_KEYS if k_ in second})
+        if ranks:
+            ranks.close()
     else:
         D_ = bdist.Dist(args)
         line, ok = twin_line(args, D_, args.config, args.steps, args.warmup, args.batch, True)

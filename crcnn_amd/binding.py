@@ -82,6 +82,9 @@ def load():
     L.crc_stream_sync.argtypes = [VP, VP]
     L.crc_event_create.argtypes = [VP, ctypes.POINTER(VP)]; L.crc_event_destroy.argtypes = [VP, VP]; L.crc_event_record.argtypes = [VP, VP, VP]
     L.crc_event_elapsed_ms.argtypes = [VP, VP, VP, ctypes.POINTER(ctypes.c_float)]
+    L.crc_stream_create.argtypes = [VP, ctypes.POINTER(VP)]; L.crc_stream_destroy.argtypes = [VP, VP]; L.crc_stream_wait_event.argtypes = [VP, VP, VP]
+    L.crc_host_alloc.argtypes = [VP, SZ, ctypes.POINTER(VP)]; L.crc_host_free.argtypes = [VP, VP]
+    L.crc_host_thread_limit.argtypes = []
     L.crc_encode_f32.argtypes = [VP, ctypes.POINTER(ctypes.c_float), SZ, PU, ctypes.POINTER(ctypes.c_int32)]
     L.crc_encode_f64.argtypes = [VP, ctypes.POINTER(ctypes.c_double), SZ, PU, ctypes.POINTER(ctypes.c_int32)]
     L.crc_decode.restype = ctypes.c_double; L.crc_decode.argtypes = [VP, PU]

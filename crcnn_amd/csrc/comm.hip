@@ -8,13 +8,36 @@
 // analogue (its only parallelism is the std::thread fan-out of convolutionalLayer.cpp:177-191).
 #include "kernels.h"
 #include <rccl/rccl.h>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
 #include <vector>
+
+// Rehearsal transport (CRC_COMM_TRANSPORT=shm).  RCCL refuses two ranks on one GPU, and the boxes this engine is developed on have one: with this switch the
+// SAME entry points (crc_comm_unique_id / crc_comm_create / crc_broadcast_weights / crc_comm_allgather_u64) move their bytes through a POSIX shared-memory segment
+// staged by hipMemcpy, so the multi-rank host code above them -- Network::broadcastParameters, bench_host's rendezvous, barrier and max-over-ranks timing -- runs
+// end to end with two processes on one device (tests/test_gpu_comm.py).  It is a transport for tests, never chosen by default and never faster than RCCL.
+struct ShmSeg {
+    std::atomic<uint64_t> arrived, generation;    // sense-reversing barrier of `world` processes
+    uint64_t gather[64 * 64];                      // all-gather slots: [rank][kScratchWords]
+    unsigned char stage[1];                        // broadcast staging (kShmStage bytes)
+};
+static const size_t kShmStage = (size_t)64 << 20;
+static const char kShmMagic[8] = {'C', 'R', 'C', 'S', 'H', 'M', ':', 0};
 
 struct crc_comm {
     ncclComm_t comm = nullptr;
     int world = 1, rank = 0, device = 0;
     u64 *d_scratch = nullptr;                     // [kScratchWords * (world + 1)]: all-gather send + receive staging
+    ShmSeg *shm = nullptr;                        // rehearsal transport (see above): the mapped segment, else null
+    char shm_name[64] = {0};
 };
 
 static const size_t kPieceWords = (size_t)1 << 27;     // 1 GiB
@@ -35,9 +58,34 @@ struct DeviceGuard {
 };
 #define GUARD(dev) DeviceGuard guard_(dev); if (!guard_.ok) return crc_set_hip_error(hipErrorInvalidDevice)
 
+static bool shm_wanted() { const char *e = std::getenv("CRC_COMM_TRANSPORT"); return e && !std::strcmp(e, "shm"); }
+// all `world` processes arrive, the last one opens the next generation; bounded: a rank that never arrives is an error after 10 minutes, not a hang
+static int shm_barrier(crc_comm *cm)
+{
+    ShmSeg *s = cm->shm;
+    const uint64_t gen = s->generation.load(std::memory_order_acquire);
+    if (s->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint64_t)cm->world) {
+        s->arrived.store(0, std::memory_order_relaxed);
+        s->generation.store(gen + 1, std::memory_order_release);
+        return CRC_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    while (s->generation.load(std::memory_order_acquire) == gen) {
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::minutes(10)) return CRC_ERR_COMM;
+    }
+    return CRC_OK;
+}
+
 extern "C" int crc_comm_unique_id(uint8_t *h_id)
 {
     if (!h_id) return CRC_ERR_INVALID_ARGUMENT;
+    if (shm_wanted()) {                           // the "id" names a fresh shared-memory segment
+        std::memset(h_id, 0, CRC_COMM_ID_BYTES);
+        std::memcpy(h_id, kShmMagic, sizeof kShmMagic);
+        std::snprintf((char *)h_id + 8, 48, "/crc_comm_%ld_%llx", (long)getpid(), (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count());
+        return CRC_OK;
+    }
     ncclUniqueId id;
     NCCLCHK(ncclGetUniqueId(&id));
     std::memcpy(h_id, &id, sizeof id);
@@ -55,6 +103,22 @@ extern "C" int crc_comm_create(crc_ctx *c, int world, int rank, const uint8_t *h
 {
     if (!c || c->device < 0 || !h_id || !out || world < 1 || rank < 0 || rank >= world) return CRC_ERR_INVALID_ARGUMENT;
     GUARD(c->device);
+    if (!std::memcmp(h_id, kShmMagic, sizeof kShmMagic)) {
+        if (world > 64) return CRC_ERR_INVALID_ARGUMENT;
+        crc_comm *cm = new crc_comm(); cm->world = world; cm->rank = rank; cm->device = c->device;
+        std::snprintf(cm->shm_name, sizeof cm->shm_name, "%s", (const char *)h_id + 8);
+        const size_t bytes = sizeof(ShmSeg) + kShmStage;
+        // every rank opens (creating if it is first) and sizes the segment: a fresh one reads as zeros, which is the barrier's initial state
+        const int fd = shm_open(cm->shm_name, O_CREAT | O_RDWR, 0600);
+        void *p = fd >= 0 && ftruncate(fd, (off_t)bytes) == 0 ? mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
+        if (fd >= 0) close(fd);
+        if (p == MAP_FAILED) { delete cm; return CRC_ERR_COMM; }
+        cm->shm = (ShmSeg *)p;
+        const int rc = comm_finish(cm);
+        if (rc || (rc == 0 && shm_barrier(cm))) { crc_comm_destroy(cm); return rc ? rc : CRC_ERR_COMM; }
+        *out = cm;
+        return CRC_OK;
+    }
     ncclUniqueId id; std::memcpy(&id, h_id, sizeof id);
     crc_comm *cm = new crc_comm(); cm->world = world; cm->rank = rank; cm->device = c->device;
     ncclResult_t r = ncclCommInitRank(&cm->comm, world, id, rank);
@@ -91,6 +155,7 @@ extern "C" void crc_comm_destroy(crc_comm *cm)
     if (!cm) return;
     DeviceGuard guard_(cm->device);
     if (cm->d_scratch) (void)hipFree(cm->d_scratch);
+    if (cm->shm) { munmap(cm->shm, sizeof(ShmSeg) + kShmStage); if (cm->rank == 0) shm_unlink(cm->shm_name); }
     if (cm->comm) ncclCommDestroy(cm->comm);
     delete cm;
 }
@@ -101,6 +166,17 @@ extern "C" int crc_broadcast_weights(crc_comm *cm, uint64_t *d_w, size_t words, 
 {
     if (!cm || (!d_w && words) || root < 0 || root >= cm->world) return CRC_ERR_INVALID_ARGUMENT;
     GUARD(cm->device);
+    if (cm->shm) {                                       // rehearsal transport: root -> staging -> everybody else, a staging buffer at a time
+        hipStream_t st = (hipStream_t)stream;
+        for (size_t o = 0; o < words; o += kShmStage / 8) {
+            const size_t cnt = words - o < kShmStage / 8 ? words - o : kShmStage / 8;
+            if (cm->rank == root) { HIPCHK(hipMemcpyAsync(cm->shm->stage, d_w + o, cnt * 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); }
+            if (shm_barrier(cm)) return CRC_ERR_COMM;
+            if (cm->rank != root) { HIPCHK(hipMemcpyAsync(d_w + o, cm->shm->stage, cnt * 8, hipMemcpyHostToDevice, st)); HIPCHK(hipStreamSynchronize(st)); }
+            if (shm_barrier(cm)) return CRC_ERR_COMM;
+        }
+        return CRC_OK;
+    }
     for (size_t o = 0; o < words; o += kPieceWords) {
         const size_t cnt = words - o < kPieceWords ? words - o : kPieceWords;
         NCCLCHK(ncclBroadcast(d_w + o, d_w + o, cnt, ncclUint64, root, cm->comm, (hipStream_t)stream));
@@ -130,6 +206,13 @@ extern "C" int crc_comm_allgather_u64(crc_comm *cm, const uint64_t *h_in, size_t
     if (!cm || !h_in || !h_out || words == 0 || words > kScratchWords) return CRC_ERR_INVALID_ARGUMENT;
     GUARD(cm->device);
     hipStream_t st = (hipStream_t)stream;
+    if (cm->shm) {
+        HIPCHK(hipStreamSynchronize(st));                // (the RCCL form synchronises the stream too: callers use this as their barrier)
+        std::memcpy(cm->shm->gather + (size_t)cm->rank * kScratchWords, h_in, words * 8);
+        if (shm_barrier(cm)) return CRC_ERR_COMM;
+        for (int r = 0; r < cm->world; r++) std::memcpy(h_out + (size_t)r * words, cm->shm->gather + (size_t)r * kScratchWords, words * 8);
+        return shm_barrier(cm) ? CRC_ERR_COMM : CRC_OK;
+    }
     u64 *send = cm->d_scratch, *recv = cm->d_scratch + kScratchWords;
     HIPCHK(hipMemcpyAsync(send, h_in, words * 8, hipMemcpyHostToDevice, st));
     NCCLCHK(ncclAllGather(send, recv, words, ncclUint64, cm->comm, st));

@@ -1,5 +1,6 @@
 // ctx.cpp -- builds the context tables on the host and uploads them to HBM.
 #include "ctx.h"
+#include "host_parallel.h"
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
@@ -518,6 +519,31 @@ extern "C" int crc_memcpy_d2h(crc_ctx *c, void *h, const void *d, size_t b, void
 extern "C" int crc_memcpy_d2d(crc_ctx *c, void *d, const void *s0, size_t b, void *s) { (void)c; HIPCHK(hipMemcpyAsync(d, s0, b, hipMemcpyDeviceToDevice, (hipStream_t)s)); return CRC_OK; }
 extern "C" int crc_memset(crc_ctx *c, void *d, int v, size_t b, void *s) { (void)c; HIPCHK(hipMemsetAsync(d, v, b, (hipStream_t)s)); return CRC_OK; }
 extern "C" int crc_stream_sync(crc_ctx *c, void *s) { (void)c; HIPCHK(hipStreamSynchronize((hipStream_t)s)); return CRC_OK; }
+// Streams of the caller's own: non-blocking ones (no implicit ordering against the default stream), so that a host can put the next chunk's upload beside the
+// current chunk's kernels; ordered with events (crc_event_record on one, crc_stream_wait_event on the other)
+extern "C" int crc_stream_create(crc_ctx *c, void **stream)
+{
+    if (!c || !stream || c->device < 0) return CRC_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s; HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); *stream = (void *)s; return CRC_OK;
+}
+extern "C" int crc_stream_destroy(crc_ctx *c, void *stream) { (void)c; if (!stream) return CRC_OK; HIPCHK(hipStreamDestroy((hipStream_t)stream)); return CRC_OK; }
+extern "C" int crc_stream_wait_event(crc_ctx *c, void *stream, void *ev)
+{
+    (void)c; if (!ev) return CRC_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0)); return CRC_OK;
+}
+// page-locked host memory: what an asynchronous upload needs to run beside kernels at the link's rate
+extern "C" int crc_host_alloc(crc_ctx *c, size_t bytes, void **h_ptr)
+{
+    if (!c || !h_ptr || c->device < 0) return CRC_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(c->device));
+    if (hipHostMalloc(h_ptr, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *h_ptr = nullptr; return CRC_ERR_HIP; }
+    return CRC_OK;
+}
+extern "C" int crc_host_free(crc_ctx *c, void *h_ptr) { (void)c; if (!h_ptr) return CRC_OK; HIPCHK(hipHostFree(h_ptr)); return CRC_OK; }
+// threads the host-side item loops of this process use (csrc/host_parallel.h: CRC_HOST_THREADS, else the hardware's, at most 16, divided by the ranks of the node)
+extern "C" int crc_host_thread_limit(void) { return crc_host::thread_limit(); }
 // HIP events for hosts that do not link HIP themselves (the C++ host classes time their layers with them: on the stream the kernels are launched on, no
 // synchronisation between layers)
 extern "C" int crc_event_create(crc_ctx *c, void **ev) { if (!c || !ev || c->device < 0) return CRC_ERR_INVALID_ARGUMENT; hipEvent_t e; HIPCHK(hipEventCreate(&e)); *ev = (void *)e; return CRC_OK; }

@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_digits_f64_kern
             }
             __syncthreads();
             ntt_row_passes_f64<false, RB>(smd, Wf + (size_t)m * n, n, logn, fp.m[m]);
-            for (int s = 2 * tid; s < n; s += 2 * nt) *reinterpret_cast<d2 *>(dst + s) = f64_stage_out<false, RB>(sm_load_pair<RB>(smd, s), Wf + (size_t)m * n, n, logn, s, fp.m[m]);
+            f64_drain<false, RB, NPT / 4>(smd, Wf + (size_t)m * n, n, logn, fp.m[m], [&](int s, d2 v) { *reinterpret_cast<d2 *>(dst + s) = v; });
             __syncthreads();
         }
     }
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_digits_pool_f64
             }
             __syncthreads();
             ntt_row_passes_f64<false, RB>(smd, Wf + (size_t)m * n, n, logn, fp.m[m]);
-            for (int s = 2 * tid; s < n; s += 2 * nt) *reinterpret_cast<d2 *>(dst + s) = f64_stage_out<false, RB>(sm_load_pair<RB>(smd, s), Wf + (size_t)m * n, n, logn, s, fp.m[m]);
+            f64_drain<false, RB, NPT / 4>(smd, Wf + (size_t)m * n, n, logn, fp.m[m], [&](int s, d2 v) { *reinterpret_cast<d2 *>(dst + s) = v; });
             __syncthreads();
         }
     }
@@ -218,12 +218,10 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_inv_crt_kernel(
     double a0[NPT];
     for (int m = 0; m < CRC_NF64; m++) {
         const double *src = a0row + (size_t)m * n;
-        for (int s = 2 * tid; s < n; s += 2 * nt) {
-            const d2 v = f64_stage_in<true, RB>(*reinterpret_cast<const d2 *>(src + s), Wi + (size_t)m * n, n, logn, s, fp.m[m]);
-            sm_store_pair<RB>(smd, s, v.x, v.y);
-        }
+        f64_fill_inv<RB, NPT / 2>(smd, Wi + (size_t)m * n, n, logn, fp.m[m], [&](int s) { return *reinterpret_cast<const d2 *>(src + s); });
         __syncthreads();
-        ntt_row_passes_f64<true, RB>(smd, Wi + (size_t)m * n, n, logn, fp.m[m]);
+        // (A holds lazy sums below 2^52.4: the fused first stage reduces them while it fills the image, otherwise the first pass does)
+        ntt_row_passes_f64<true, RB>(smd, Wi + (size_t)m * n, n, logn, fp.m[m], !f64_fused_stage<RB>(logn));
         if (m == 0) {
 #pragma unroll
             for (int u = 0; u < NPT / 2; u++) {

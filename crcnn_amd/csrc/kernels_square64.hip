@@ -84,10 +84,7 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024) sq64_fwd_kernel(double *
     for (int s = 2 * threadIdx.x; s < n; s += 2 * blockDim.x) { const d2 v = *reinterpret_cast<const d2 *>(row + s); sm_store_pair<RB>(smd, s, v.x, v.y); }
     __syncthreads();
     ntt_row_passes_f64<false, RB>(smd, Wf + (size_t)j * n, n, logn, md);
-    for (int s = 2 * threadIdx.x; s < n; s += 2 * blockDim.x) {
-        const d2 v = f64_stage_out<false, RB>(sm_load_pair<RB>(smd, s), Wf + (size_t)j * n, n, logn, s, md);
-        *reinterpret_cast<d2 *>(row + s) = d2{f64_reduce(v.x, md), f64_reduce(v.y, md)};
-    }
+    f64_drain<false, RB, 4>(smd, Wf + (size_t)j * n, n, logn, md, [&](int s, d2 v) { *reinterpret_cast<d2 *>(row + s) = d2{f64_reduce(v.x, md), f64_reduce(v.y, md)}; });
 }
 
 // tr: [count][2][K][n] = x m~ (q/q_i)^-1 mod q_i in coefficient form (k_ntt_ct_inv_scaled)  ->  out [count][2][kf][n]: the lifted polynomial under p_j, transformed, reduced.
@@ -122,10 +119,7 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 ? 8 : 4) sq64_li
     __syncthreads();
     ntt_row_passes_f64<false, RB>(smd, Wf + (size_t)j * n, n, logn, md);
     double *row = out + (poly * kf + j) * (size_t)n;
-    for (int s = 2 * threadIdx.x; s < n; s += 2 * blockDim.x) {
-        const d2 v = f64_stage_out<false, RB>(sm_load_pair<RB>(smd, s), Wf + (size_t)j * n, n, logn, s, md);
-        *reinterpret_cast<d2 *>(row + s) = d2{f64_reduce(v.x, md), f64_reduce(v.y, md)};
-    }
+    f64_drain<false, RB, 4>(smd, Wf + (size_t)j * n, n, logn, md, [&](int s, d2 v) { *reinterpret_cast<d2 *>(row + s) = d2{f64_reduce(v.x, md), f64_reduce(v.y, md)}; });
 }
 
 // in: [count][2][kf][n] transformed rows (a, b)  ->  out: [count][3][kf][n]: n (a^2, 2ab, b^2) in coefficient form, reduced.  One workgroup per (ciphertext, prime):
@@ -144,12 +138,9 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) sq64_inv_kernel(const
     double r[NPT];
     auto transform_store = [&](int o) {
         __syncthreads();
-        ntt_row_passes_f64<true, RB>(smd, W, n, logn, md);
+        ntt_row_passes_f64<true, RB>(smd, W, n, logn, md, false);           // (the image holds reduced products / one fused stage of them: below 1.75 p)
         double *dst = out + ((ct * 3 + o) * kf + j) * (size_t)n;
-        for (int s = 2 * tid; s < n; s += 2 * nt) {
-            const d2 v = sm_load_pair<RB>(smd, s);
-            *reinterpret_cast<d2 *>(dst + s) = d2{f64_reduce(v.x, md), f64_reduce(v.y, md)};
-        }
+        f64_drain<true, RB, NPT / 2>(smd, W, n, logn, md, [&](int s, d2 v) { *reinterpret_cast<d2 *>(dst + s) = d2{f64_reduce(v.x, md), f64_reduce(v.y, md)}; });
         __syncthreads();
     };
     // a^2 (|.| < 0.875 p: the first pass reduces on load); a stays in r

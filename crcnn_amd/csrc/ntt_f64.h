@@ -77,6 +77,13 @@ __device__ __forceinline__ void inv_stages_f64(double (&v)[1 << R], const double
 }
 // s = 2^ls: element stride inside a group.  The swizzles are XORs of shifted index bits, i.e. linear over GF(2), and (c << ls) occupies bits that are zero in
 // `base`: swz(base + c s) = swz(base) ^ swz(c s) -- one vector XOR per element against a wave-uniform constant instead of the whole index arithmetic
+//
+// Inverse passes and their reductions (round 5).  A Gentleman-Sande stage leaves a sum (magnitudes add) and a product (back below m = 0.875 p), so after the three
+// stages of a radix-8 group whose inputs are bounded by B the outputs are bounded by [8 B, 4 m, 2 m, 2 m, m, m, m, m]: only TWO of the eight values grow.  With
+// B = 1.75 p the largest difference a stage multiplies is 8 B = 14 p < 2^51 (f64_mulmod's operand range) and the largest sum 14 p < 2^53 (exact), and reducing
+// just v[0] and v[1] on the way out restores the bound for the next pass: 6 instead of 24 reduction flops per group (120 -> 102 flops, -14 % measured on the
+// whole transform: tools/f64_row_timeline.hip, profiles/r05_f64_row_timeline.txt).  reduce_in = true keeps the old form (every input reduced on load) for a first
+// pass whose inputs may be lazy sums up to 2^52.4 and for the tail passes.
 template <bool INV, int R, int RB>
 __device__ __forceinline__ void ntt_pass_f64(double *sm, const double *W, int n, int ls, int tabidx, const F64Mod md, bool reduce_in)
 {
@@ -90,6 +97,7 @@ __device__ __forceinline__ void ntt_pass_f64(double *sm, const double *W, int n,
 #pragma unroll
         for (int c = 0; c < (1 << R); c++) { v[c] = sm[a0 ^ swz<RB>(c << ls)]; if (INV && reduce_in) v[c] = f64_reduce(v[c], md); }
         if (INV) inv_stages_f64<R>(v, tw, md); else fwd_stages_f64<R>(v, tw, md);
+        if (INV && !reduce_in) { v[0] = f64_reduce(v[0], md); if (R >= 2) v[1] = f64_reduce(v[1], md); }
 #pragma unroll
         for (int c = 0; c < (1 << R); c++) sm[a0 ^ swz<RB>(c << ls)] = v[c];
     }
@@ -124,12 +132,62 @@ __device__ __forceinline__ d2 f64_stage_out(d2 v, const double *W, int n, int lo
     const double T = f64_mulmod(W[(n >> 1) + (s >> 1)], v.y, md);
     return d2{v.x + T, v.x - T};
 }
+// Draining the image (round 5).  A loop that reads a pair from the image, fetches the fused stage's twiddle, multiplies and stores runs one memory latency per
+// iteration -- a quarter of a whole forward transform in the kernels that keep 16 points per thread (tools/f64_row_timeline.hip: 5200 of 20 400 cycles).  Here
+// the LDS reads and twiddle loads of CH pairs are issued together before the first of them is used.  store(s, v) gets the pair (s, s + 1) after the fused stage.
+template <bool INV, int RB, int CH, class F>
+__device__ __forceinline__ void f64_drain(const double *sm, const double *W, int n, int logn, const F64Mod md, F &&store)
+{
+    const bool fused = !INV && f64_fused_stage<RB>(logn);
+    const int step = 2 * (int)blockDim.x;
+    for (int s0 = 2 * (int)threadIdx.x; s0 < n; s0 += step * CH) {
+        d2 v[CH]; double tw[CH];
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const int s = s0 + c * step;
+            if (s < n) { v[c] = sm_load_pair<RB>(sm, s); if (fused) tw[c] = W[(n >> 1) + (s >> 1)]; }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const int s = s0 + c * step;
+            if (s < n) {
+                if (fused) { const double T = f64_mulmod(tw[c], v[c].y, md); v[c] = d2{v[c].x + T, v[c].x - T}; }
+                store(s, v[c]);
+            }
+        }
+    }
+}
+// ... and filling it for an inverse transform from pairs the caller provides: load(s) returns the pair (s, s + 1) (a global load, a product of held values);
+// the fused first stage's twiddles are fetched beside the caller's loads
+template <int RB, int CH, class F>
+__device__ __forceinline__ void f64_fill_inv(double *sm, const double *W, int n, int logn, const F64Mod md, F &&load)
+{
+    const bool fused = f64_fused_stage<RB>(logn);
+    const int step = 2 * (int)blockDim.x;
+    for (int s0 = 2 * (int)threadIdx.x; s0 < n; s0 += step * CH) {
+        d2 v[CH]; double tw[CH];
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const int s = s0 + c * step;
+            if (s < n) { v[c] = load(s); if (fused) tw[c] = W[(n >> 1) + (s >> 1)]; }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const int s = s0 + c * step;
+            if (s < n) {
+                if (fused) { const double U = f64_reduce(v[c].x, md), V = f64_reduce(v[c].y, md); v[c] = d2{U + V, f64_mulmod(tw[c], U - V, md)}; }
+                sm_store_pair<RB>(sm, s, v[c].x, v[c].y);
+            }
+        }
+    }
+}
 // all LDS passes of one row on the image (swizzled); the caller has filled it through f64_stage_in and synchronised, the function returns synchronised, the caller
-// drains it through f64_stage_out.  Inverse: the image holds values below 2^52 (lazy sums of up to 48 products); every pass reduces on load.
+// drains it through f64_stage_out.  Inverse: the image holds values below 2^52 (lazy sums of up to 48 products) when first_reduce is set, below 1.75 p otherwise;
+// what comes out is below 14 p (the caller reduces while it drains).
 // (RB = stages per pass: 2^RB values per thread in registers between two LDS round trips.  The fp64 butterfly is a third of the 64-bit integer one's issue cycles, so
 // the LDS passes, their barriers and the twiddle loads weigh more here than in ntt_device.h: fewer, wider passes)
 template <bool INV, int RB>
-__device__ __forceinline__ void ntt_row_passes_f64(double *sm, const double *W, int n, int logn, const F64Mod md)
+__device__ __forceinline__ void ntt_row_passes_f64(double *sm, const double *W, int n, int logn, const F64Mod md, bool first_reduce = true)
 {
     const bool fused = f64_fused_stage<RB>(logn);
     const int full = logn / RB, rem = fused ? 0 : logn - RB * full;
@@ -139,8 +197,11 @@ __device__ __forceinline__ void ntt_row_passes_f64(double *sm, const double *W, 
         for (int p = 0; p < full; p++, lt -= RB) ntt_pass_f64<false, RB, RB>(sm, W, n, lt - RB + 1, n >> (lt + 1), md, false);
         if (rem) ntt_tail_pass_f64<false, RB>(rem, sm, W, n, lt - rem + 1, n >> (lt + 1), md);
     } else {
+        // radix-8 passes reduce lazily (two outputs per group, see ntt_pass_f64): the image must hold values below 1.75 p when the first pass starts -- callers whose
+        // image holds lazy sums (relin_inv_crt_kernel without a fused first stage) ask for first_reduce, which reduces every input of the first pass instead.  The
+        // wider passes keep the reduction on load: their sums grow past the multiplier's operand range within a pass.
         int lt = fused ? 1 : 0;
-        for (int p = 0; p < full; p++, lt += RB) ntt_pass_f64<true, RB, RB>(sm, W, n, lt, n >> (lt + 1), md, true);
+        for (int p = 0; p < full; p++, lt += RB) ntt_pass_f64<true, RB, RB>(sm, W, n, lt, n >> (lt + 1), md, RB != 3 || (p == 0 && first_reduce));
         if (rem) ntt_tail_pass_f64<true, RB>(rem, sm, W, n, lt, n >> (lt + 1), md);
     }
 }

@@ -15,6 +15,13 @@
 using namespace std;
 
 crc_ctx *context = nullptr;
+// The stream every ABI call of these classes is launched on.  NULL (the default stream) unless the caller installs its own (setStream): a driver that uploads the
+// next chunk of encrypted images on a second stream while this one computes (bench_host's streamed inputs) needs a non-blocking one here -- the default stream
+// would order itself against every other blocking stream of the process.  A global like the context, the keys and the work buffer (CrCNN/src/globals.h:18-26).
+static void *g_stream = nullptr;
+void setStream(void *s) { g_stream = s; }
+void *getStream() { return g_stream; }
+static inline void *stream() { return g_stream; }
 vector<uint64_t> secret_key, public_key, ev_keys16_host;
 shared_ptr<DeviceBuffer> ev_keys16;
 static bool g_det = false;                                  // setDeterministicSeed(): tests / bench only
@@ -156,18 +163,18 @@ static shared_ptr<DeviceBuffer> uploadPlain(const vector<const Plaintext *> &pl,
             }
         });
         if (compact) {
-            chk(crc_memcpy_h2d(ctx(), cstage.ptr, chost.data(), c * (size_t)CRC_PLAIN_COMPACT_WORDS * 8, nullptr), "crc_memcpy_h2d");
-            chk(crc_plain_expand(ctx(), (const uint64_t *)cstage.ptr, c, (uint64_t *)stage.ptr, nullptr), "crc_plain_expand");
+            chk(crc_memcpy_h2d(ctx(), cstage.ptr, chost.data(), c * (size_t)CRC_PLAIN_COMPACT_WORDS * 8, stream()), "crc_memcpy_h2d");
+            chk(crc_plain_expand(ctx(), (const uint64_t *)cstage.ptr, c, (uint64_t *)stage.ptr, stream()), "crc_plain_expand");
         } else {
             host.resize(chunk * (size_t)n);
             crc_host::parallel_for(c, 64, [&](size_t b, size_t e) { for (size_t i = b; i < e; i++) pl[o + i]->dense(host.data() + i * n, n); });
-            chk(crc_memcpy_h2d(ctx(), stage.ptr, host.data(), c * (size_t)n * 8, nullptr), "crc_memcpy_h2d");
+            chk(crc_memcpy_h2d(ctx(), stage.ptr, host.data(), c * (size_t)n * 8, stream()), "crc_memcpy_h2d");
         }
         uint64_t *dst = (uint64_t *)out->ptr + o * (size_t)k * n;
-        if (mode == 3) chk(crc_memcpy_d2d(ctx(), dst, stage.ptr, c * (size_t)n * 8, nullptr), "crc_memcpy_d2d");
-        else if (mode == 0) chk(crc_plain_to_ntt(ctx(), (const uint64_t *)stage.ptr, c, dst, nullptr), "crc_plain_to_ntt");
-        else chk(crc_plain_to_delta(ctx(), (const uint64_t *)stage.ptr, c, mode == 2 ? CRC_NTT : CRC_COEFF, dst, nullptr), "crc_plain_to_delta");
-        chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+        if (mode == 3) chk(crc_memcpy_d2d(ctx(), dst, stage.ptr, c * (size_t)n * 8, stream()), "crc_memcpy_d2d");
+        else if (mode == 0) chk(crc_plain_to_ntt(ctx(), (const uint64_t *)stage.ptr, c, dst, stream()), "crc_plain_to_ntt");
+        else chk(crc_plain_to_delta(ctx(), (const uint64_t *)stage.ptr, c, mode == 2 ? CRC_NTT : CRC_COEFF, dst, stream()), "crc_plain_to_delta");
+        chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
     }
     return out;
 }
@@ -210,15 +217,15 @@ ciphertext3D ciphertext3D::images(int b0, int count) const
 ciphertext3D ciphertext3D::fromHost(const uint64_t *h, int B, int zd, int xd, int yd)
 {
     ciphertext3D t(B, zd, xd, yd);
-    chk(crc_memcpy_h2d(ctx(), t.buf->ptr, h, t.count() * ctBytes(), nullptr), "crc_memcpy_h2d");
-    chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+    chk(crc_memcpy_h2d(ctx(), t.buf->ptr, h, t.count() * ctBytes(), stream()), "crc_memcpy_h2d");
+    chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
     return t;
 }
 vector<uint64_t> ciphertext3D::toHost() const
 {
     vector<uint64_t> h(count() * ctBytes() / 8);
-    chk(crc_memcpy_d2h(ctx(), h.data(), data(), h.size() * 8, nullptr), "crc_memcpy_d2h");
-    chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+    chk(crc_memcpy_d2h(ctx(), h.data(), data(), h.size() * 8, stream()), "crc_memcpy_d2h");
+    chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
     return h;
 }
 ciphertext3D stackImages(const vector<ciphertext3D> &images)
@@ -228,14 +235,14 @@ ciphertext3D stackImages(const vector<ciphertext3D> &images)
     int B = 0; for (auto &im : images) { if (im.zd != f.zd || im.xd != f.xd || im.yd != f.yd || im.form != f.form) throw invalid_argument("image shapes differ"); B += im.B; }
     ciphertext3D t(B, f.zd, f.xd, f.yd, f.form);
     size_t off = 0;
-    for (auto &im : images) { chk(crc_memcpy_d2d(ctx(), (char *)t.data() + off, im.data(), im.count() * ctBytes(), nullptr), "crc_memcpy_d2d"); off += im.count() * ctBytes(); }
-    chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+    for (auto &im : images) { chk(crc_memcpy_d2d(ctx(), (char *)t.data() + off, im.data(), im.count() * ctBytes(), stream()), "crc_memcpy_d2d"); off += im.count() * ctBytes(); }
+    chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
     return t;
 }
 ciphertext3D deepCopyImage(const ciphertext3D &image)
 {
     ciphertext3D t(image.B, image.zd, image.xd, image.yd, image.form);
-    chk(crc_memcpy_d2d(ctx(), t.data(), image.data(), image.count() * ctBytes(), nullptr), "crc_memcpy_d2d");
+    chk(crc_memcpy_d2d(ctx(), t.data(), image.data(), image.count() * ctBytes(), stream()), "crc_memcpy_d2d");
     return t;
 }
 
@@ -264,8 +271,8 @@ void setParameters(int poly_modulus, const vector<uint64_t> &coeff_modulus, uint
         chk(crc_gen_evk_key(context, g_master_key, secret_key.data(), 16, ev_keys16_host.data()), "crc_gen_evk_key");
     }
     ev_keys16 = make_shared<DeviceBuffer>(ev_keys16_host.size() * 8);
-    chk(crc_memcpy_h2d(context, ev_keys16->ptr, ev_keys16_host.data(), ev_keys16_host.size() * 8, nullptr), "crc_memcpy_h2d");
-    chk(crc_stream_sync(context, nullptr), "crc_stream_sync");
+    chk(crc_memcpy_h2d(context, ev_keys16->ptr, ev_keys16_host.data(), ev_keys16_host.size() * 8, stream()), "crc_memcpy_h2d");
+    chk(crc_stream_sync(context, stream()), "crc_stream_sync");
 }
 // One kernel scratch area for every layer of the process: layers run one after another on one stream, so their scratch never overlaps in
 // time, and the largest request decides the size (a per-layer buffer summed to ~40 GiB at WoPad 16384 beside the 182 GiB limb weights).
@@ -302,8 +309,8 @@ void initFromKeys(string public_key_path, string secret_key_path, string evaluat
     b = readFile(evaluation_key_path); int dbc = 0;
     chk(crc_seal_evk_load(context, b.data(), b.size(), ev_keys16_host.data(), &dbc), "evaluation_keys is not valid for encryption parameters");
     if (dbc != 16) throw invalid_argument("evaluation keys must have decomposition_bit_count 16");
-    chk(crc_memcpy_h2d(context, ev_keys16->ptr, ev_keys16_host.data(), ev_keys16_host.size() * 8, nullptr), "crc_memcpy_h2d");
-    chk(crc_stream_sync(context, nullptr), "crc_stream_sync");
+    chk(crc_memcpy_h2d(context, ev_keys16->ptr, ev_keys16_host.data(), ev_keys16_host.size() * 8, stream()), "crc_memcpy_h2d");
+    chk(crc_stream_sync(context, stream()), "crc_stream_sync");
 }
 ciphertext3D encryptAndSaveImage(vector<float> image, int zd, int xd, int yd, string file_name)
 {   // globals.cpp:174-190: the ciphertexts back to back in Ciphertext::save format
@@ -333,17 +340,17 @@ static ciphertext3D encryptPixels(const vector<float> &px, int zd, int xd, int y
     vector<uint64_t> pl(px.size() * n);
     chk(crc_encode_f32(ctx(), px.data(), px.size(), pl.data(), nullptr), "crc_encode_f32");
     DeviceBuffer d_pl(pl.size() * 8), d_pk(public_key.size() * 8), d_work(crc_encrypt_dev_work_bytes(ctx(), px.size()));
-    chk(crc_memcpy_h2d(ctx(), d_pl.ptr, pl.data(), pl.size() * 8, nullptr), "crc_memcpy_h2d");
-    chk(crc_memcpy_h2d(ctx(), d_pk.ptr, public_key.data(), public_key.size() * 8, nullptr), "crc_memcpy_h2d");
+    chk(crc_memcpy_h2d(ctx(), d_pl.ptr, pl.data(), pl.size() * 8, stream()), "crc_memcpy_h2d");
+    chk(crc_memcpy_h2d(ctx(), d_pk.ptr, public_key.data(), public_key.size() * 8, stream()), "crc_memcpy_h2d");
     ciphertext3D out(1, zd, xd, yd, CRC_COEFF);
     if (g_det)
         chk(crc_encrypt_dev(ctx(), (const uint64_t *)d_pk.ptr, (const uint64_t *)d_pl.ptr, px.size(), g_det_seed + 1000003 * (g_enc_counter + 1),
-                            (uint64_t *)out.buf->ptr, d_work.ptr, nullptr), "crc_encrypt_dev");
+                            (uint64_t *)out.buf->ptr, d_work.ptr, stream()), "crc_encrypt_dev");
     else                                                    // one keystream per ciphertext, never reused under this key
         chk(crc_encrypt_dev_key(ctx(), (const uint64_t *)d_pk.ptr, (const uint64_t *)d_pl.ptr, px.size(), g_master_key, g_enc_counter,
-                                (uint64_t *)out.buf->ptr, d_work.ptr, nullptr), "crc_encrypt_dev_key");
+                                (uint64_t *)out.buf->ptr, d_work.ptr, stream()), "crc_encrypt_dev_key");
     g_enc_counter += px.size();
-    chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+    chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
     return out;
 }
 ciphertext3D encryptImage(vector<float> image, int zd, int xd, int yd)
@@ -381,8 +388,8 @@ floatCube decryptImage(const ciphertext3D &t)
 int noiseBudget(const ciphertext3D &t, size_t index)
 {
     vector<uint64_t> h(ctBytes() / 8);
-    chk(crc_memcpy_d2h(ctx(), h.data(), (char *)t.data() + index * ctBytes(), ctBytes(), nullptr), "crc_memcpy_d2h");
-    chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+    chk(crc_memcpy_d2h(ctx(), h.data(), (char *)t.data() + index * ctBytes(), ctBytes(), stream()), "crc_memcpy_d2h");
+    chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
     return crc_noise_budget(ctx(), secret_key.data(), h.data(), 2);
 }
 
@@ -419,7 +426,7 @@ static int forwardStreamed(const ciphertext3D &input, ciphertext3D &out, int zd,
     const size_t T = (size_t)zd * xf * yf, P = (size_t)((xd - xf) / xs + 1) * ((yd - yf) / ys + 1);
     auto scatter = [&](int f0, int ft) {
         for (int b = 0; b < input.B; b++)
-            chk(crc_memcpy_d2d(ctx(), (char *)out.buf->ptr + ((size_t)b * nf + f0) * P * ctb, (const char *)d_ytile->ptr + (size_t)b * ft * P * ctb, (size_t)ft * P * ctb, nullptr), "crc_memcpy_d2d");
+            chk(crc_memcpy_d2d(ctx(), (char *)out.buf->ptr + ((size_t)b * nf + f0) * P * ctb, (const char *)d_ytile->ptr + (size_t)b * ft * P * ctb, (size_t)ft * P * ctb, stream()), "crc_memcpy_d2d");
     };
     // On the matrix cores (a reduction the limb GEMM takes, at least 32 rows in this launch: crc_plan_mac): tiles of 64 filters in limb form, built from canonical sub-tiles
     // of 8 filters (crc_limb_pack_weights_tile), the layer's input converted to limb form once per launch -- PlainModelWoPad's fc3 with all eight primes of n = 16384
@@ -435,7 +442,7 @@ static int forwardStreamed(const ciphertext3D &input, ciphertext3D &out, int zd,
         if (input.form != CRC_NTTL) {
             const size_t xb = crc_limb_tensor_bytes(ctx(), input.B, zd, xd, yd);
             if (!g_xltile || g_xltile->bytes < xb) g_xltile = make_shared<DeviceBuffer>(xb);
-            chk(crc_limb_pack_tensor(ctx(), input.data(), input.form, input.B, zd, xd, yd, g_xltile->ptr, nullptr), "crc_limb_pack_tensor");
+            chk(crc_limb_pack_tensor(ctx(), input.data(), input.form, input.B, zd, xd, yd, g_xltile->ptr, stream()), "crc_limb_pack_tensor");
             xl = g_xltile->ptr;
         }
         const size_t wb = crc_conv2d_forms_work_bytes(ctx(), input.B, zd, xd, yd, xs, ys, xf, yf, ft_max, CRC_NTTL, CRC_NTTL, out_form);
@@ -444,11 +451,11 @@ static int forwardStreamed(const ciphertext3D &input, ciphertext3D &out, int zd,
             const int ft = min(ft_max, nf - f0);
             for (int s0 = 0; s0 < ft; s0 += sub) {
                 const int fs = min(sub, ft - s0);
-                chk(crc_plain_to_ntt(ctx(), (const uint64_t *)d_plain->ptr + (size_t)(f0 + s0) * T * n, (size_t)fs * T, (uint64_t *)d_wtile->ptr, nullptr), "crc_plain_to_ntt");
-                chk(crc_limb_pack_weights_tile(ctx(), (const uint64_t *)d_wtile->ptr, ft, s0, fs, zd, xf, yf, g_wltile->ptr, nullptr), "crc_limb_pack_weights_tile");
+                chk(crc_plain_to_ntt(ctx(), (const uint64_t *)d_plain->ptr + (size_t)(f0 + s0) * T * n, (size_t)fs * T, (uint64_t *)d_wtile->ptr, stream()), "crc_plain_to_ntt");
+                chk(crc_limb_pack_weights_tile(ctx(), (const uint64_t *)d_wtile->ptr, ft, s0, fs, zd, xf, yf, g_wltile->ptr, stream()), "crc_limb_pack_weights_tile");
             }
             chk(crc_conv2d_forms(ctx(), (const uint64_t *)xl, (const uint64_t *)g_wltile->ptr, CRC_NTTL, (const uint64_t *)((const char *)d_b[out_form != CRC_COEFF]->ptr + (size_t)f0 * rowb),
-                                 input.B, zd, xd, yd, xs, ys, xf, yf, ft, CRC_NTTL, out_form, (uint64_t *)d_ytile->ptr, d_work->ptr, nullptr), "crc_conv2d_forms");
+                                 input.B, zd, xd, yd, xs, ys, xf, yf, ft, CRC_NTTL, out_form, (uint64_t *)d_ytile->ptr, d_work->ptr, stream()), "crc_conv2d_forms");
             scatter(f0, ft);
         }
         return CRC_NTTL;
@@ -465,9 +472,9 @@ static int forwardStreamed(const ciphertext3D &input, ciphertext3D &out, int zd,
     if (!d_work || d_work->bytes < wb) d_work = make_shared<DeviceBuffer>(wb);
     for (int f0 = 0; f0 < nf; f0 += ft_max) {
         const int ft = min(ft_max, nf - f0);
-        chk(crc_plain_to_ntt(ctx(), (const uint64_t *)d_plain->ptr + (size_t)f0 * T * n, (size_t)ft * T, (uint64_t *)d_wtile->ptr, nullptr), "crc_plain_to_ntt");
+        chk(crc_plain_to_ntt(ctx(), (const uint64_t *)d_plain->ptr + (size_t)f0 * T * n, (size_t)ft * T, (uint64_t *)d_wtile->ptr, stream()), "crc_plain_to_ntt");
         chk(crc_conv2d_forms(ctx(), input.data(), (const uint64_t *)d_wtile->ptr, CRC_NTT, (const uint64_t *)((const char *)d_b[out_form != CRC_COEFF]->ptr + (size_t)f0 * rowb), input.B,
-                             zd, xd, yd, xs, ys, xf, yf, ft, input.form, out_form, (uint64_t *)d_ytile->ptr, d_work->ptr, nullptr), "crc_conv2d_forms");
+                             zd, xd, yd, xs, ys, xf, yf, ft, input.form, out_form, (uint64_t *)d_ytile->ptr, d_work->ptr, stream()), "crc_conv2d_forms");
         scatter(f0, ft);
     }
     return CRC_NTT;
@@ -495,8 +502,8 @@ static bool toLimb(shared_ptr<DeviceBuffer> &d_w, int &w_form, int nf, int zd, i
     if (!planned || !limbFits(nf, zd, xf, yf)) return false;
     const size_t nbytes = crc_limb_weights_bytes(ctx(), nf, zd, xf, yf);
     auto wl = make_shared<DeviceBuffer>(nbytes);
-    chk(crc_limb_pack_weights(ctx(), (const uint64_t *)d_w->ptr, nf, zd, xf, yf, wl->ptr, nullptr), "crc_limb_pack_weights");
-    chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+    chk(crc_limb_pack_weights(ctx(), (const uint64_t *)d_w->ptr, nf, zd, xf, yf, wl->ptr, stream()), "crc_limb_pack_weights");
+    chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
     d_w = wl; w_form = CRC_NTTL;
     return true;
 }
@@ -567,8 +574,8 @@ bool ConvolutionalLayer::limbWeights(int B)
     if (w_form == CRC_NTTP) packWeights(true);
     if (planned == CRC_NTTL1) {          // one-channel convolutions have their own matrix-core kernel (kernels_mfma1.hip)
         auto wl = make_shared<DeviceBuffer>(crc_limb_conv1_weights_bytes(ctx()));
-        chk(crc_limb_conv1_pack_weights(ctx(), (const uint64_t *)d_w->ptr, nf, xf, yf, wl->ptr, nullptr), "crc_limb_conv1_pack_weights");
-        chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+        chk(crc_limb_conv1_pack_weights(ctx(), (const uint64_t *)d_w->ptr, nf, xf, yf, wl->ptr, stream()), "crc_limb_conv1_pack_weights");
+        chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
         d_w_canon = d_w; d_w = wl; w_form = CRC_NTTL1;         // (the canonical copy of a one-channel layer is small: kept, so that the weights can go back on the wire)
         return true;
     }
@@ -581,7 +588,7 @@ void ConvolutionalLayer::packWeights(bool unpack)
     if (w_form == CRC_NTTL1 && unpack) { d_w = d_w_canon; d_w_canon.reset(); w_form = CRC_NTT; return; }
     if (w_form == CRC_NTTL || w_form == CRC_NTTL1) { if (unpack) throw logic_error("ConvolutionalLayer " + name + ": weights are in limb form (fuse() / broadcastParameters() must precede the first forward())"); return; }
     if ((w_form == CRC_NTTP) == !unpack) return;
-    chk(crc_pack28(ctx(), (uint64_t *)d_w->ptr, (size_t)nf * zd * xf * yf * K(), unpack ? 1 : 0, nullptr), "crc_pack28");
+    chk(crc_pack28(ctx(), (uint64_t *)d_w->ptr, (size_t)nf * zd * xf * yf * K(), unpack ? 1 : 0, stream()), "crc_pack28");
     w_form = unpack ? CRC_NTT : CRC_NTTP;
 }
 ciphertext3D ConvolutionalLayer::forward(ciphertext3D input)
@@ -594,7 +601,7 @@ ciphertext3D ConvolutionalLayer::forward(ciphertext3D input)
     if (!wb) throw invalid_argument("ConvolutionalLayer: unsupported geometry");
     ensure(g_scratch, wb);
     chk(crc_conv2d_forms(ctx(), input.data(), (const uint64_t *)d_w->ptr, w_form, (const uint64_t *)d_b[out_form != CRC_COEFF]->ptr, input.B, zd, xd, yd, xs, ys, xf, yf, nf,
-                         input.form, out_form, out.data(), g_scratch->ptr, nullptr), "crc_conv2d_forms");
+                         input.form, out_form, out.data(), g_scratch->ptr, stream()), "crc_conv2d_forms");
     if (out_form == CRC_NTTLC) out.form = CRC_NTTL;         // what the convolution behind reads as its limb-form input
     return out;
 }
@@ -653,12 +660,12 @@ void FullyConnectedLayer::buildTilewise()
         ch = fold_bn->num_channels; per_ch = in_dim / ch;
         fake = make_shared<DeviceBuffer>(T * 2 * rowb); outc = make_shared<DeviceBuffer>((size_t)ft * 2 * rowb);
         wk = make_shared<DeviceBuffer>(max<size_t>(crc_dense_work_bytes(ctx(), 1, in_dim, ft, CRC_NTT), 256));
-        chk(crc_memset(ctx(), fake->ptr, 0, T * 2 * rowb, nullptr), "crc_memset");
+        chk(crc_memset(ctx(), fake->ptr, 0, T * 2 * rowb, stream()), "crc_memset");
         for (int z = 0; z < ch; z++) for (int t = 0; t < per_ch; t++)
-            chk(crc_memcpy_d2d(ctx(), (char *)fake->ptr + ((size_t)z * per_ch + t) * 2 * rowb, (char *)fold_bn->d_mean[1]->ptr + (size_t)z * rowb, rowb, nullptr), "crc_memcpy_d2d");
+            chk(crc_memcpy_d2d(ctx(), (char *)fake->ptr + ((size_t)z * per_ch + t) * 2 * rowb, (char *)fold_bn->d_mean[1]->ptr + (size_t)z * rowb, rowb, stream()), "crc_memcpy_d2d");
         bias.resize((size_t)out_dim * k * n); corr.resize((size_t)ft * 2 * k * n);
-        chk(crc_memcpy_d2h(ctx(), bias.data(), d_b[1]->ptr, bias.size() * 8, nullptr), "crc_memcpy_d2h");
-        chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+        chk(crc_memcpy_d2h(ctx(), bias.data(), d_b[1]->ptr, bias.size() * 8, stream()), "crc_memcpy_d2h");
+        chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
         chk(crc_ctx_table(ctx(), "q", q.data(), k) < 0 ? CRC_ERR_INVALID_ARGUMENT : CRC_OK, "crc_ctx_table");
     }
     for (int f0 = 0; f0 < out_dim; f0 += ft) {
@@ -668,26 +675,26 @@ void FullyConnectedLayer::buildTilewise()
         shared_ptr<DeviceBuffer> wt = uploadPlain(w, 0);                                   // lift + NTT of the tile's plaintexts (canonical, scratch)
         if (fold_bn) {
             for (int f = 0; f < fn; f++)                                                   // w'[f][z][tap] = w (*) s[z]
-                chk(crc_multiply_plain_ntt(ctx(), (uint64_t *)wt->ptr + (size_t)f * T * k * n, (const uint64_t *)fold_bn->d_invstd->ptr, T, per_ch, 1, nullptr), "crc_multiply_plain_ntt");
-            chk(crc_dense(ctx(), (const uint64_t *)fake->ptr, (const uint64_t *)wt->ptr, nullptr, 1, in_dim, fn, CRC_NTT, CRC_NTT, (uint64_t *)outc->ptr, wk->ptr, nullptr), "crc_dense");
-            chk(crc_memcpy_d2h(ctx(), corr.data(), outc->ptr, (size_t)fn * 2 * rowb, nullptr), "crc_memcpy_d2h");
-            chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+                chk(crc_multiply_plain_ntt(ctx(), (uint64_t *)wt->ptr + (size_t)f * T * k * n, (const uint64_t *)fold_bn->d_invstd->ptr, T, per_ch, 1, stream()), "crc_multiply_plain_ntt");
+            chk(crc_dense(ctx(), (const uint64_t *)fake->ptr, (const uint64_t *)wt->ptr, nullptr, 1, in_dim, fn, CRC_NTT, CRC_NTT, (uint64_t *)outc->ptr, wk->ptr, stream()), "crc_dense");
+            chk(crc_memcpy_d2h(ctx(), corr.data(), outc->ptr, (size_t)fn * 2 * rowb, stream()), "crc_memcpy_d2h");
+            chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
             for (int f = 0; f < fn; f++) for (int m = 0; m < k; m++) for (int s2 = 0; s2 < n; s2++) {
                 uint64_t &b = bias[((size_t)(f0 + f) * k + m) * n + s2]; const uint64_t c = corr[(((size_t)f * 2) * k + m) * n + s2];
                 b = b >= c ? b - c : b + q[m] - c;
             }
         }
-        chk(crc_limb_pack_weights_tile(ctx(), (const uint64_t *)wt->ptr, out_dim, f0, fn, in_dim, 1, 1, d_w->ptr, nullptr), "crc_limb_pack_weights_tile");
-        chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+        chk(crc_limb_pack_weights_tile(ctx(), (const uint64_t *)wt->ptr, out_dim, f0, fn, in_dim, 1, 1, d_w->ptr, stream()), "crc_limb_pack_weights_tile");
+        chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
     }
     if (fold_bn) {
         d_b[1] = make_shared<DeviceBuffer>(bias.size() * 8);
-        chk(crc_memcpy_h2d(ctx(), d_b[1]->ptr, bias.data(), bias.size() * 8, nullptr), "crc_memcpy_h2d");
-        chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+        chk(crc_memcpy_h2d(ctx(), d_b[1]->ptr, bias.data(), bias.size() * 8, stream()), "crc_memcpy_h2d");
+        chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
         d_b[0] = make_shared<DeviceBuffer>(bias.size() * 8);
-        chk(crc_memcpy_d2d(ctx(), d_b[0]->ptr, d_b[1]->ptr, bias.size() * 8, nullptr), "crc_memcpy_d2d");
-        chk(crc_ntt_inv(ctx(), (uint64_t *)d_b[0]->ptr, (size_t)out_dim, 1, nullptr), "crc_ntt_inv");
-        chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+        chk(crc_memcpy_d2d(ctx(), d_b[0]->ptr, d_b[1]->ptr, bias.size() * 8, stream()), "crc_memcpy_d2d");
+        chk(crc_ntt_inv(ctx(), (uint64_t *)d_b[0]->ptr, (size_t)out_dim, 1, stream()), "crc_ntt_inv");
+        chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
     }
     w_form = CRC_NTTL; tile_built = true;
 }
@@ -739,7 +746,7 @@ void FullyConnectedLayer::packWeights(bool unpack)
     if (streamed || (tilewise && !tile_built)) return;
     if (w_form == CRC_NTTL) { if (unpack) throw logic_error("FullyConnectedLayer " + name + ": weights are in limb form (fuse() / broadcastParameters() must precede the first forward())"); return; }
     if ((w_form == CRC_NTTP) == !unpack) return;
-    chk(crc_pack28(ctx(), (uint64_t *)d_w->ptr, (size_t)in_dim * out_dim * K(), unpack ? 1 : 0, nullptr), "crc_pack28");
+    chk(crc_pack28(ctx(), (uint64_t *)d_w->ptr, (size_t)in_dim * out_dim * K(), unpack ? 1 : 0, stream()), "crc_pack28");
     w_form = unpack ? CRC_NTT : CRC_NTTP;
 }
 ciphertext3D FullyConnectedLayer::forward(ciphertext3D input)
@@ -753,7 +760,7 @@ ciphertext3D FullyConnectedLayer::forward(ciphertext3D input)
     if (streamed) { stream_form = forwardStreamed(input, out, in_dim, 1, 1, 1, 1, 1, 1, out_dim, out_form, d_plain, d_b, d_wtile, d_ytile, g_scratch); return out; }
     ensure(g_scratch, crc_conv2d_forms_work_bytes(ctx(), input.B, in_dim, 1, 1, 1, 1, 1, 1, out_dim, input.form, w_form, out_form));
     chk(crc_dense_forms(ctx(), input.data(), (const uint64_t *)d_w->ptr, w_form, (const uint64_t *)d_b[out_form != CRC_COEFF]->ptr, input.B, in_dim, out_dim, input.form, out_form,
-                        out.data(), g_scratch->ptr, nullptr), "crc_dense_forms");
+                        out.data(), g_scratch->ptr, stream()), "crc_dense_forms");
     return out;
 }
 void FullyConnectedLayer::savePlaintextParameters(ostream *outfile)
@@ -775,9 +782,9 @@ ciphertext3D PoolingLayer::forward(ciphertext3D input)
 {
     checkInput(input, zd, xd, yd, "PoolingLayer");
     ciphertext3D out(input.B, zo, xo, yo, input.form);
-    chk(crc_pool(ctx(), input.data(), input.B, zd, xd, yd, xs, ys, xf, yf, d_div ? (const uint64_t *)d_div->ptr : nullptr, input.form, out.data(), nullptr), "crc_pool");
+    chk(crc_pool(ctx(), input.data(), input.B, zd, xd, yd, xs, ys, xf, yf, d_div ? (const uint64_t *)d_div->ptr : nullptr, input.form, out.data(), stream()), "crc_pool");
     if (out_form != out.form) {      // pooling is form-preserving; convert only if the network asked for the other form
-        if (out_form == CRC_NTT) chk(crc_ntt_fwd(ctx(), out.data(), out.count(), 2, nullptr), "crc_ntt_fwd"); else chk(crc_ntt_inv(ctx(), out.data(), out.count(), 2, nullptr), "crc_ntt_inv");
+        if (out_form == CRC_NTT) chk(crc_ntt_fwd(ctx(), out.data(), out.count(), 2, stream()), "crc_ntt_fwd"); else chk(crc_ntt_inv(ctx(), out.data(), out.count(), 2, stream()), "crc_ntt_inv");
         out.form = out_form;
     }
     return out;
@@ -800,7 +807,7 @@ ciphertext3D SquareLayer::forward(ciphertext3D input)
     // either form in, the requested form out: crc_square_relin_forms keeps an NTT-resident network resident
     ciphertext3D out(input.B, input.zd, input.xd, input.yd, out_form);
     ensure(g_scratch, crc_square_relin_work_bytes(ctx(), input.count(), 16));
-    chk(crc_square_relin_forms(ctx(), input.data(), input.form, input.count(), (const uint64_t *)ev_keys16->ptr, 16, out.data(), out_form, g_scratch->ptr, nullptr),
+    chk(crc_square_relin_forms(ctx(), input.data(), input.form, input.count(), (const uint64_t *)ev_keys16->ptr, 16, out.data(), out_form, g_scratch->ptr, stream()),
         "crc_square_relin_forms");
     return out;
 }
@@ -820,8 +827,8 @@ ciphertext3D SquarePoolLayer::forward(ciphertext3D input)
     ciphertext3D out(input.B, zo, xo, yo, of);
     ensure(g_scratch, crc_square_pool_relin_work_bytes(ctx(), input.B, zd, xd, yd, xs, ys, xf, yf, 16));
     chk(crc_square_pool_relin_forms(ctx(), input.data(), input.form, input.B, zd, xd, yd, xs, ys, xf, yf, (const uint64_t *)ev_keys16->ptr, 16,
-                                    d_div ? (const uint64_t *)d_div->ptr : nullptr, out.data(), of, g_scratch->ptr, nullptr), "crc_square_pool_relin_forms");
-    if (of != out_form) { chk(crc_ntt_inv(ctx(), out.data(), out.count(), 2, nullptr), "crc_ntt_inv"); out.form = out_form; }
+                                    d_div ? (const uint64_t *)d_div->ptr : nullptr, out.data(), of, g_scratch->ptr, stream()), "crc_square_pool_relin_forms");
+    if (of != out_form) { chk(crc_ntt_inv(ctx(), out.data(), out.count(), 2, stream()), "crc_ntt_inv"); out.form = out_form; }
     return out;
 }
 void SquarePoolLayer::printLayerStructure()
@@ -855,9 +862,9 @@ ciphertext3D BatchNormLayer::forward(ciphertext3D input)
     if (!input.buf || input.zd != num_channels) throw invalid_argument("BatchNormLayer: channel count mismatch");
     upload();
     ciphertext3D out = deepCopyImage(input);                // the reference works on its by-value copy (batchNormLayer.cpp:29)
-    chk(crc_batchnorm(ctx(), out.data(), out.B, out.zd, out.xd, out.yd, (const uint64_t *)d_mean[out.form == CRC_NTT]->ptr, (const uint64_t *)d_invstd->ptr, out.form, nullptr), "crc_batchnorm");
+    chk(crc_batchnorm(ctx(), out.data(), out.B, out.zd, out.xd, out.yd, (const uint64_t *)d_mean[out.form == CRC_NTT]->ptr, (const uint64_t *)d_invstd->ptr, out.form, stream()), "crc_batchnorm");
     if (out_form != out.form) {
-        if (out_form == CRC_NTT) chk(crc_ntt_fwd(ctx(), out.data(), out.count(), 2, nullptr), "crc_ntt_fwd"); else chk(crc_ntt_inv(ctx(), out.data(), out.count(), 2, nullptr), "crc_ntt_inv");
+        if (out_form == CRC_NTT) chk(crc_ntt_fwd(ctx(), out.data(), out.count(), 2, stream()), "crc_ntt_fwd"); else chk(crc_ntt_inv(ctx(), out.data(), out.count(), 2, stream()), "crc_ntt_inv");
         out.form = out_form;
     }
     return out;
@@ -930,15 +937,15 @@ ciphertext3D Network::forward(ciphertext3D input)
         last_layer_launches[i]++;
         if (time_with_events) {
             void *e0 = next_event(), *e1 = next_event();
-            chk(crc_event_record(ctx(), e0, nullptr), "crc_event_record");
+            chk(crc_event_record(ctx(), e0, stream()), "crc_event_record");
             ciphertext3D out = layers[i]->forward(in);
-            chk(crc_event_record(ctx(), e1, nullptr), "crc_event_record");
+            chk(crc_event_record(ctx(), e1, stream()), "crc_event_record");
             timed.push_back({i, {e0, e1}});
             return out;
         }
         auto t0 = chrono::high_resolution_clock::now();
         ciphertext3D out = layers[i]->forward(in);
-        chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+        chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
         last_layer_ms[i] += chrono::duration<double, milli>(chrono::high_resolution_clock::now() - t0).count();
         return out;
     };
@@ -957,7 +964,7 @@ ciphertext3D Network::forward(ciphertext3D input)
                 vector<floatCube> imgs = decryptImages(input);
                 vector<ciphertext3D> enc; for (auto &im : imgs) enc.push_back(encryptImage(im));
                 input = stackImages(enc);
-                chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+                chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
                 last_reenc_ms += chrono::duration<double, milli>(chrono::high_resolution_clock::now() - r0).count();
                 refreshes_left--;
                 i--;
@@ -982,11 +989,11 @@ ciphertext3D Network::forward(ciphertext3D input)
                 tail_in = ciphertext3D(B, t.zd, t.xd, t.yd, limb[split] ? CRC_NTTL : t.form);
             }
             if (limb[split])      // every chunk's tensor goes straight into the dense layer's K-blocked limb tensor
-                chk(crc_limb_pack_tensor_at(ctx(), t.data(), t.form, Bc, (int)out_cts, 1, 1, tail_in.data(), B, b0, nullptr), "crc_limb_pack_tensor_at");
+                chk(crc_limb_pack_tensor_at(ctx(), t.data(), t.form, Bc, (int)out_cts, 1, 1, tail_in.data(), B, b0, stream()), "crc_limb_pack_tensor_at");
             else
-                chk(crc_memcpy_d2d(ctx(), (char *)tail_in.data() + (size_t)b0 * out_cts * ctBytes(), t.data(), (size_t)Bc * out_cts * ctBytes(), nullptr), "crc_memcpy_d2d");
+                chk(crc_memcpy_d2d(ctx(), (char *)tail_in.data() + (size_t)b0 * out_cts * ctBytes(), t.data(), (size_t)Bc * out_cts * ctBytes(), stream()), "crc_memcpy_d2d");
         }
-        chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+        chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
         input = tail_in;
         first = split;
     }
@@ -996,7 +1003,7 @@ ciphertext3D Network::forward(ciphertext3D input)
             vector<floatCube> imgs = decryptImages(input);
             vector<ciphertext3D> enc; for (auto &im : imgs) enc.push_back(encryptImage(im));
             input = stackImages(enc);
-            chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+            chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
             last_reenc_ms += chrono::duration<double, milli>(chrono::high_resolution_clock::now() - r0).count();
         }
         // every layer but the last writes into one of the network's two activation slots (the one its input does not live in); the last layer's output -- ten
@@ -1007,13 +1014,13 @@ ciphertext3D Network::forward(ciphertext3D input)
             // a last layer that hands its input back (none of CrCNN's does) must not give the caller a tensor that lives in an activation slot the next forward overwrites
             if (output.buf && (output.buf == act_slot[0] || output.buf == act_slot[1] || output.buf == tail_slot)) {
                 ciphertext3D own(output.B, output.zd, output.xd, output.yd, output.form);
-                chk(crc_memcpy_d2d(ctx(), own.data(), output.data(), output.count() * ctBytes(), nullptr), "crc_memcpy_d2d");
+                chk(crc_memcpy_d2d(ctx(), own.data(), output.data(), output.count() * ctBytes(), stream()), "crc_memcpy_d2d");
                 output = own;
             }
             input = output;
         }
     }
-    if (time_with_events) { chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync"); read_events(); }
+    if (time_with_events) { chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync"); read_events(); }
     return input;
 }
 Network::HbmPlan Network::hbmPlan() const
@@ -1038,7 +1045,7 @@ size_t Network::broadcastParameters(crc_comm *comm, int root)
         vector<uint64_t> mine_pl(L, 0), all_pl(L * (size_t)world, 0);
         if (rank == root) for (size_t i = 0; i < L; i++) mine_pl[i] = (uint64_t)layers[i]->placement();
         if (L > 64) throw invalid_argument("broadcastParameters: more than 64 layers");
-        if (L) chk(crc_comm_allgather_u64(comm, mine_pl.data(), L, all_pl.data(), nullptr), "crc_comm_allgather_u64");
+        if (L) chk(crc_comm_allgather_u64(comm, mine_pl.data(), L, all_pl.data(), stream()), "crc_comm_allgather_u64");
         if (rank != root) for (size_t i = 0; i < L; i++) layers[i]->adoptPlacement((int)all_pl[(size_t)root * L + i]);
     }
     vector<shared_ptr<DeviceBuffer>> bufs;
@@ -1049,20 +1056,20 @@ size_t Network::broadcastParameters(crc_comm *comm, int root)
     uint64_t mine[2] = {0, 0};
     for (auto &b : bufs) {
         const size_t words = b->bytes / 8;
-        chk(crc_broadcast_weights(comm, (uint64_t *)b->ptr, words, root, nullptr), "crc_broadcast_weights");
+        chk(crc_broadcast_weights(comm, (uint64_t *)b->ptr, words, root, stream()), "crc_broadcast_weights");
         uint64_t cs[2];
-        chk(crc_checksum64(ctx(), (const uint64_t *)b->ptr, words, cs, nullptr), "crc_checksum64");
+        chk(crc_checksum64(ctx(), (const uint64_t *)b->ptr, words, cs, stream()), "crc_checksum64");
         mine[0] ^= cs[0]; mine[1] = mine[1] * 0x9E3779B97F4A7C15ULL + cs[1];
         bytes += b->bytes;
     }
     vector<uint64_t> all((size_t)2 * world);
-    chk(crc_comm_allgather_u64(comm, mine, 2, all.data(), nullptr), "crc_comm_allgather_u64");
+    chk(crc_comm_allgather_u64(comm, mine, 2, all.data(), stream()), "crc_comm_allgather_u64");
     for (int r = 0; r < world; r++)
         if (all[2 * r] != all[2 * root] || all[2 * r + 1] != all[2 * root + 1])
             throw runtime_error("broadcastParameters: rank " + to_string(r) + " holds different parameter bytes than the root");
     if (rank != root) {                                     // host copy of the keys follows the device copy
-        chk(crc_memcpy_d2h(ctx(), ev_keys16_host.data(), ev_keys16->ptr, ev_keys16_host.size() * 8, nullptr), "crc_memcpy_d2h");
-        chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+        chk(crc_memcpy_d2h(ctx(), ev_keys16_host.data(), ev_keys16->ptr, ev_keys16_host.size() * 8, stream()), "crc_memcpy_d2h");
+        chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
     }
     return bytes;
 }
@@ -1088,8 +1095,8 @@ int Network::fuse()
     }
     auto inttCopy = [&](const shared_ptr<DeviceBuffer> &ntt_rows, size_t rows) {       // coefficient-form twin of NTT-form delta rows
         auto out = make_shared<DeviceBuffer>(rows * rowb);
-        chk(crc_memcpy_d2d(ctx(), out->ptr, ntt_rows->ptr, rows * rowb, nullptr), "crc_memcpy_d2d");
-        chk(crc_ntt_inv(ctx(), (uint64_t *)out->ptr, rows, 1, nullptr), "crc_ntt_inv");
+        chk(crc_memcpy_d2d(ctx(), out->ptr, ntt_rows->ptr, rows * rowb, stream()), "crc_memcpy_d2d");
+        chk(crc_ntt_inv(ctx(), (uint64_t *)out->ptr, rows, 1, stream()), "crc_ntt_inv");
         return out;
     };
     // 1. conv + pool
@@ -1116,7 +1123,7 @@ int Network::fuse()
         fused->d_w = make_shared<DeviceBuffer>((size_t)conv->nf * T2 * rowb);
         fused->d_b[1] = make_shared<DeviceBuffer>((size_t)conv->nf * rowb);
         chk(crc_conv2d_fold_pool(ctx(), (const uint64_t *)conv->d_w->ptr, (const uint64_t *)conv->d_b[1]->ptr, pool->d_div ? (const uint64_t *)pool->d_div->ptr : nullptr,
-                                 conv->nf, conv->zd, conv->xf, conv->yf, conv->xs, conv->ys, pool->xf, pool->yf, (uint64_t *)fused->d_w->ptr, (uint64_t *)fused->d_b[1]->ptr, nullptr),
+                                 conv->nf, conv->zd, conv->xf, conv->yf, conv->xs, conv->ys, pool->xf, pool->yf, (uint64_t *)fused->d_w->ptr, (uint64_t *)fused->d_b[1]->ptr, stream()),
             "crc_conv2d_fold_pool");
         fused->d_b[0] = inttCopy(fused->d_b[1], conv->nf);
         fused->filters_already_ntt = true;
@@ -1156,30 +1163,30 @@ int Network::fuse()
         shared_ptr<DeviceBuffer> *db = conv ? conv->d_b : fc->d_b;
         // w'[f][z][tap] = w (*) s[z]
         for (int f = 0; f < F; f++)
-            chk(crc_multiply_plain_ntt(ctx(), (uint64_t *)dw->ptr + (size_t)f * T * k * n, (const uint64_t *)bn->d_invstd->ptr, T, per_ch, 1, nullptr), "crc_multiply_plain_ntt");
+            chk(crc_multiply_plain_ntt(ctx(), (uint64_t *)dw->ptr + (size_t)f * T * k * n, (const uint64_t *)bn->d_invstd->ptr, T, per_ch, 1, stream()), "crc_multiply_plain_ntt");
         // correction[f] = sum_t w'[f][t] (*) M[z(t)]: the dense kernel on one pseudo-image whose ciphertexts are (M[z(t)], 0)
         DeviceBuffer fake((size_t)T * 2 * rowb), outc((size_t)F * 2 * rowb), wk(max<size_t>(crc_dense_work_bytes(ctx(), 1, T, F, CRC_NTT), 256));
-        chk(crc_memset(ctx(), fake.ptr, 0, (size_t)T * 2 * rowb, nullptr), "crc_memset");
+        chk(crc_memset(ctx(), fake.ptr, 0, (size_t)T * 2 * rowb, stream()), "crc_memset");
         for (int z = 0; z < ch; z++) for (int t = 0; t < per_ch; t++)
-            chk(crc_memcpy_d2d(ctx(), (char *)fake.ptr + ((size_t)z * per_ch + t) * 2 * rowb, (char *)bn->d_mean[1]->ptr + (size_t)z * rowb, rowb, nullptr), "crc_memcpy_d2d");
-        chk(crc_dense(ctx(), (const uint64_t *)fake.ptr, (const uint64_t *)dw->ptr, nullptr, 1, T, F, CRC_NTT, CRC_NTT, (uint64_t *)outc.ptr, wk.ptr, nullptr), "crc_dense");
+            chk(crc_memcpy_d2d(ctx(), (char *)fake.ptr + ((size_t)z * per_ch + t) * 2 * rowb, (char *)bn->d_mean[1]->ptr + (size_t)z * rowb, rowb, stream()), "crc_memcpy_d2d");
+        chk(crc_dense(ctx(), (const uint64_t *)fake.ptr, (const uint64_t *)dw->ptr, nullptr, 1, T, F, CRC_NTT, CRC_NTT, (uint64_t *)outc.ptr, wk.ptr, stream()), "crc_dense");
         vector<uint64_t> corr((size_t)F * 2 * k * n), bias((size_t)F * k * n), q(k);
-        chk(crc_memcpy_d2h(ctx(), corr.data(), outc.ptr, corr.size() * 8, nullptr), "crc_memcpy_d2h");
-        chk(crc_memcpy_d2h(ctx(), bias.data(), db[1]->ptr, bias.size() * 8, nullptr), "crc_memcpy_d2h");
-        chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+        chk(crc_memcpy_d2h(ctx(), corr.data(), outc.ptr, corr.size() * 8, stream()), "crc_memcpy_d2h");
+        chk(crc_memcpy_d2h(ctx(), bias.data(), db[1]->ptr, bias.size() * 8, stream()), "crc_memcpy_d2h");
+        chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
         chk(crc_ctx_table(ctx(), "q", q.data(), k) < 0 ? CRC_ERR_INVALID_ARGUMENT : CRC_OK, "crc_ctx_table");
         for (int f = 0; f < F; f++) for (int m = 0; m < k; m++) for (int s2 = 0; s2 < n; s2++) {
             uint64_t &b = bias[((size_t)f * k + m) * n + s2]; const uint64_t c = corr[(((size_t)f * 2) * k + m) * n + s2];
             b = b >= c ? b - c : b + q[m] - c;
         }
         db[1] = make_shared<DeviceBuffer>(bias.size() * 8);
-        chk(crc_memcpy_h2d(ctx(), db[1]->ptr, bias.data(), bias.size() * 8, nullptr), "crc_memcpy_h2d");
-        chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+        chk(crc_memcpy_h2d(ctx(), db[1]->ptr, bias.data(), bias.size() * 8, stream()), "crc_memcpy_h2d");
+        chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
         db[0] = inttCopy(db[1], F);
         layers[i + 1]->name = bn->name + "+" + layers[i + 1]->name;
         eraseLayer(i);
     }
-    chk(crc_stream_sync(ctx(), nullptr), "crc_stream_sync");
+    chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
     return removed;
 }
 

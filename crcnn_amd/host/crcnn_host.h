@@ -58,6 +58,10 @@ ciphertext3D deepCopyImage(const ciphertext3D &image);                  // globa
 
 // ---- process-global crypto context (CrCNN/src/globals.h:18-48) --------------------------------------------------------
 extern crc_ctx *context;                                    // the engine context (SEALContext + Evaluator tables)
+// the HIP stream (hipStream_t behind void*; crc_stream_create makes one) all layer calls, copies and synchronisations of these classes go to; NULL = the
+// default stream.  Install it before the first forward(); the caller keeps ownership and orders its own streams against it with events
+void setStream(void *stream);
+void *getStream();
 extern std::vector<uint64_t> secret_key, public_key, ev_keys16_host;
 extern std::shared_ptr<DeviceBuffer> ev_keys16;             // evaluation keys, dbc = 16, resident in HBM
 // Client-side randomness (secret key, evaluation keys, every encryption).  The reference draws from std::random_device (SEAL 2.3.1

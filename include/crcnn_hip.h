@@ -118,6 +118,17 @@ int crc_memcpy_d2h(crc_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, v
 int crc_memcpy_d2d(crc_ctx *ctx, void *d_dst, const void *d_src, size_t bytes, void *stream);
 int crc_memset(crc_ctx *ctx, void *d_dst, int value, size_t bytes, void *stream);
 int crc_stream_sync(crc_ctx *ctx, void *stream);
+/* Streams of the caller's own (hipStream_t behind void*, created non-blocking: no implicit ordering against the default stream) and page-locked host memory:
+ * what a host needs to upload the next chunk of encrypted images while the current one is evaluated -- the reference's driver encrypts, evaluates and decrypts
+ * one image after the other (CrCNN/src/mainparams.cpp:85-112).  crc_stream_wait_event makes `stream` wait for an event recorded on another one. */
+int crc_stream_create(crc_ctx *ctx, void **stream);
+int crc_stream_destroy(crc_ctx *ctx, void *stream);
+int crc_stream_wait_event(crc_ctx *ctx, void *stream, void *event);
+int crc_host_alloc(crc_ctx *ctx, size_t bytes, void **h_ptr);
+int crc_host_free(crc_ctx *ctx, void *h_ptr);
+/* threads the host-side item loops of this process use (the reference's th_count fan-out, convolutionalLayer.cpp:177-191, has no process-wide cap): CRC_HOST_THREADS,
+ * else the hardware's, at most 16, divided by the ranks that share the node (LOCAL_WORLD_SIZE / CRC_LOCAL_WORLD) */
+int crc_host_thread_limit(void);
 /* HIP events (hipEvent_t behind void*): record on the stream the kernels go to, read the time between two of them (waits for the second) */
 int crc_event_create(crc_ctx *ctx, void **event);
 int crc_event_destroy(crc_ctx *ctx, void *event);
@@ -378,6 +389,9 @@ int crc_encrypt_dev(crc_ctx *ctx, const uint64_t *d_pk, const uint64_t *d_plain,
  *   crc_checksum64        position-sensitive checksum of a device buffer: h_out[0] = xor of all words, h_out[1] =
  *                         sum_i w_i * (2i+1) mod 2^64; synchronises `stream`.  Every rank checks what it received against the
  *                         root's pair.
+ * Rehearsal on one GPU: RCCL refuses two ranks on the same device.  With CRC_COMM_TRANSPORT=shm in the environment crc_comm_unique_id names a POSIX shared-memory
+ * segment instead of an RCCL rendezvous and the same calls stage their bytes through it (hipMemcpy, a process-shared barrier): the multi-rank HOST code above this
+ * header runs unchanged with several processes on one device.  A transport for tests only; never the default.
  * ------------------------------------------------------------------------------------------------------------- */
 typedef struct crc_comm crc_comm;
 #define CRC_COMM_ID_BYTES 128

@@ -93,7 +93,7 @@ def test_bench_small_workload_matches_reference_golden():
     line = _run_bench(["--gpus", "1", "--python-twin", "--unfused-images", "24"])
     c = line["check"]
     assert line["n_gpus"] == 1 and c["golden_match"] is True and c["golden"] == "net_tiny1024_eng.json" and c["all_ok"] is True
-    assert c["predictions_match_plain_model"] == "4/4"
+    assert c["predictions_match_plain_model"] in ("4/4", "24/24")
     assert line["config"]["host"].startswith("C++ host classes") and line["value"] > 0 and line["dtype"] == "u64" and line["vs_baseline"] is None
     assert set(line["ms_per_layer"]) == {"pool1_features.conv1+pool1", "pool2_features.conv2+pool2", "classifier.fc3", "classifier.fc4"}
     assert line["roofline"]["frac"] > 0 and line["roofline"]["launch_ms"] > 0 and line["roofline"]["traffic_source"] is None
@@ -104,8 +104,8 @@ def test_bench_small_workload_matches_reference_golden():
 
 
 def test_bench_two_ranks_end_to_end_on_one_device():
-    """plain `python bench.py --gpus 2` (self-launch), weights built on rank 0 only, broadcast, per-rank checksums, every rank verified"""
-    line = _run_bench(["--gpus", "2", "--unfused-images", "0"], {"CRC_DIST_BACKEND": "gloo"})
+    """the Python twin (--python-twin) at N = 2, self-launched: weights built on rank 0 only, broadcast, per-rank checksums, every rank verified"""
+    line = _run_bench(["--gpus", "2", "--python-twin", "--unfused-images", "0"], {"CRC_DIST_BACKEND": "gloo"})
     assert line["n_gpus"] == 2 and line["scaling"] == "weak"
     c = line["check"]
     assert c["ranks_verified"] == "2/2" and c["golden_match"] is True and c["all_ok"] is True
@@ -113,18 +113,50 @@ def test_bench_two_ranks_end_to_end_on_one_device():
     assert b["checksums_match"] == "2/2" and b["bytes"] > 0 and b["seconds"] > 0 and b["via"].startswith("torch.distributed (gloo)")
 
 
+def _assert_cpp_ranks(line, world):
+    assert line["n_gpus"] == world and line["scaling"] == "weak"
+    assert line["config"]["host"].startswith("C++ host classes") and line["config"]["parallelism"] == f"image-sharded x{world}"
+    c = line["check"]
+    assert c["ranks_verified"] == f"{world}/{world}" and c["golden_match"] is True and c["all_ok"] is True
+    b = line["weight_broadcast"]
+    assert b["via"].startswith("Network::broadcastParameters") and b["bytes"] > 0 and b["seconds"] > 0
+    pr = line["per_rank"]
+    assert [r["rank"] for r in pr] == list(range(world)) and all(r["images"] > 0 and r["elapsed_s"] > 0 and r["parameters"] > 0 for r in pr)
+    # whole-job rate = all ranks' images / the slowest rank's time
+    assert abs(line["value"] - sum(r["images"] for r in pr) / max(r["elapsed_s"] for r in pr)) < 1e-3 * line["value"]
+
+
+def test_bench_two_cpp_ranks_rehearsed_on_one_device():
+    """`python bench.py --gpus 2` as the driver launches it, with the C++ host as the measured path on EVERY rank: two bench_host children (started by two Python ranks
+    that never touch the GPU), rank 0's rendezvous id through the file, crc_comm_create, Network::broadcastParameters, all-gather barriers around the timed steps, the
+    elapsed times gathered.  On this one-GPU box the communicator's bytes travel through the shared-memory rehearsal transport (CRC_COMM_TRANSPORT=shm: RCCL refuses two
+    ranks on one device); everything above crc_comm_* is the code that runs on eight GPUs"""
+    line = _run_bench(["--gpus", "2"], {"CRC_COMM_TRANSPORT": "shm"})
+    _assert_cpp_ranks(line, 2)
+    assert "shared-memory rehearsal transport" in line["weight_broadcast"]["via"]
+
+
+def test_bench_streamed_inputs_beside_the_resident_line():
+    """--stream-inputs both: after the resident measurement the same network is fed launch by launch over PCIe -- ciphertexts from page-locked memory (same bits out as the
+    resident launch), or pixel plaintexts that are encrypted on the device in front of the first layer (fresh ciphertexts: checked by decrypting the logits)"""
+    line = _run_bench(["--gpus", "1", "--stream-inputs", "both", "--stream-steps", "2"])
+    assert line["check"]["all_ok"] is True
+    st = {m["mode"]: m for m in line["streamed"]}
+    assert set(st) == {"ciphertext", "plaintext"}
+    assert st["ciphertext"]["outputs_identical_to_resident"] is True and st["ciphertext"]["h2d_GBps"] > 0 and st["ciphertext"]["images_per_s"] > 0
+    assert st["plaintext"]["check"]["predictions_match_plain_model"].split("/")[0] == st["plaintext"]["check"]["predictions_match_plain_model"].split("/")[1]
+    assert st["plaintext"]["bytes_per_image"] * 2 * 2 == st["ciphertext"]["bytes_per_image"]          # a ciphertext is 2 polys x k = 2 residues of its plaintext's size
+
+
 def test_bench_two_ranks_over_rccl():
-    """the multi-GPU path as the driver launches it, on real RCCL: two ranks on two GPUs (`python bench.py --gpus 2`, self-launch), the encoded weights built on rank 0
-    only and broadcast by crc_broadcast_weights (ncclBroadcast through the engine's C ABI), every rank's device checksum equal to the root's, every rank's output
-    ciphertexts verified against the reference golden.  Needs two visible GPUs: skipped on the one-GPU boxes this repository is developed on (the path is rehearsed there
+    """the multi-GPU path as the driver launches it, on real RCCL: two C++ bench_host ranks on two GPUs (`python bench.py --gpus 2`, self-launch), the encoded weights
+    built on rank 0 only and sent by Network::broadcastParameters (crc_broadcast_weights: ncclBroadcast), every rank's device checksum equal to the root's, every rank's
+    output ciphertexts verified against the reference golden.  Needs two visible GPUs: skipped on the one-GPU boxes this repository is developed on (the path is rehearsed there
     over gloo, test_bench_two_ranks_end_to_end_on_one_device)"""
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs at least two GPUs")
     line = _run_bench(["--gpus", "2"], {"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
-    c = line["check"]
-    assert c["ranks_verified"] == "2/2" and c["golden_match"] is True and c["all_ok"] is True
-    b = line["weight_broadcast"]
-    assert b["via"].startswith("crc_broadcast_weights") and b["checksums_match"] == "2/2" and b["bytes"] > 0 and b["seconds"] > 0
+    _assert_cpp_ranks(line, 2)
+    assert "ncclBroadcast" in line["weight_broadcast"]["via"]
     assert line["hbm_plan"]["parameters"] > 0

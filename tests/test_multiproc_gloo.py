@@ -78,7 +78,10 @@ def test_bench_self_launches_its_ranks():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert line == {"launch_check": True, "n_gpus": 2, "ranks_seen": 2, "self_launched": True}
+    assert (line["launch_check"], line["n_gpus"], line["ranks_seen"], line["self_launched"]) == (True, 2, 2, True)
+    # the launcher of the measured path: one C++ bench_host child per rank, rank 0's rendezvous id reached the other through the file, and the ranks split the host cores
+    assert line["host"].startswith("C++ bench_host") and line["same_rendezvous_id_on_every_rank"] is True
+    assert line["host_threads_per_rank"] == [max(1, min(16, (os.cpu_count() or 1) // 2))]
     # a rank that fails makes the parent fail: --gpus 3 announced, but the check insists on what the flag says
     bad = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                           os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launch-check"], capture_output=True, text=True, env=env, timeout=300)

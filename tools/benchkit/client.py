@@ -36,6 +36,43 @@ class Client:
         from crcnn_amd.synth import normalize, synth_image
         return [normalize(synth_image(self.rank * 100003 + i)) for i in range(D)]
 
+    def images_or_mnist(self, D, mnist_dir):
+        """the D distinct images of this rank: synthetic MNIST-like ones, or -- when `mnist_dir` holds t10k-images-idx3-ubyte (the reference reads it through
+        mnist_reader, utils.cpp:20-53; the file is not part of either repository) -- the first D real test images behind this rank's offset, normalised as utils.cpp:13
+        does.  Returns (images, None) or (images, {..., "labels": [...]}); with real images the reference-made goldens do not apply (their inputs are the synthetic ones)"""
+        path = os.path.join(mnist_dir, "t10k-images-idx3-ubyte") if mnist_dir else ""
+        if not path or not os.path.exists(path):
+            return self.images(D), None
+        from crcnn_amd.synth import normalize
+        raw = np.fromfile(path, dtype=np.uint8)
+        magic, count, rows, cols = (int.from_bytes(raw[4 * i:4 * i + 4].tobytes(), "big") for i in range(4))
+        if magic != 2051 or rows != 28 or cols != 28 or raw.size < 16 + count * 784:
+            raise SystemExit(f"bench.py: {path} is not an idx3 file of 28 x 28 images")
+        first = (self.rank * D) % max(1, count - D + 1)
+        px = raw[16 + first * 784:16 + (first + D) * 784].reshape(D, 28, 28)
+        info = {"file": path, "first_index": first, "images": D}
+        lab = os.path.join(mnist_dir, "t10k-labels-idx1-ubyte")
+        if os.path.exists(lab):
+            lraw = np.fromfile(lab, dtype=np.uint8)
+            info["labels"] = [int(v) for v in lraw[8 + first:8 + first + D]]
+        # the float model's predictions the reference ships (PlainModel/predictions<Model>.csv, read by loadMNISTPlainModelPredictions, utils.cpp:41-53): one label per
+        # test image; copies of the three data files sit under tests/golden/predictions/
+        for d in (mnist_dir, os.path.join(ROOT, "tests", "golden", "predictions")):
+            csv = os.path.join(d, f"predictions{self.cfg['model']}.csv")
+            if os.path.exists(csv):
+                vals = [int(v) for v in open(csv).read().replace(",", " ").split()]
+                if len(vals) >= first + D:
+                    info["reference_predictions"] = vals[first:first + D]; info["reference_predictions_file"] = csv
+                break
+        return [normalize(p) for p in px], info
+
+    def write_plain_images(self, imgs, path):
+        """the images' 784 pixel plaintexts each ([D][784][n] u64, coefficients below t): what a client that encrypts on the device uploads"""
+        with open(path, "wb") as f:
+            for im in imgs:
+                pl, _ = self.E.encode(im.reshape(-1))
+                f.write(np.ascontiguousarray(pl).tobytes())
+
     def encrypt_images(self, imgs, path, threads=1):
         """the images' 784 ciphertexts each, written to `path` ([D][784][2][k][n] u64); returns SHA-256 of image 0's ciphertexts.  One image per host thread (the
         calls are independent and ctypes releases the GIL: 2.7 s per image at n = 4096 on one core of the build container, 15 s at n = 16384)"""
@@ -52,21 +89,21 @@ class Client:
                 f.write(ct.tobytes())
         return x0_sha
 
-    def verify(self, cfg_name, imgs, outs, x0_sha):
+    def verify(self, cfg_name, imgs, outs, x0_sha, golden=True):
         """outs: [D][10][2][k][n] output ciphertexts of the D distinct images.  Returns the "check" dictionary of the bench line and whether everything held."""
         E, cfg = self.E, self.cfg
         D = len(imgs)
-        gold_ok, gold_name = golden_check(cfg_name, cfg, self.q, self.rank, x0_sha, sha(outs[0]))
+        gold_ok, gold_name = golden_check(cfg_name, cfg, self.q, self.rank, x0_sha, sha(outs[0])) if golden else (None, None)
         # BASELINE configs[0] in full (tests/golden/c1_tiny4096_t32.json: 32 images through the compiled reference): this run's distinct images ARE its first images
         c1_ok = None
         c1_path = os.path.join(ROOT, "tests", "golden", "c1_tiny4096_t32.json")
-        if self.rank == 0 and cfg_name == "tiny4096" and os.path.exists(c1_path):
+        if golden and self.rank == 0 and cfg_name == "tiny4096" and os.path.exists(c1_path):
             c1 = json.load(open(c1_path))
             if (c1["t"], [int(v) for v in c1["q"]], c1["key_seed"], c1["enc_seed_base"], c1["enc_seed_stride"]) == (cfg["t"], [int(v) for v in self.q], KEY_SEED, ENC_SEED, 1000):
                 have = [i for i in range(D) if str(i) in c1["images"]]
                 hits = sum(1 for i in have if c1["images"][str(i)]["out_sha256"] == sha(outs[i]))
                 c1_ok = f"{hits}/{len(have)}"
-        preds_ok, budgets, max_err = 0, [], 0.0
+        preds_ok, budgets, max_err, preds = 0, [], 0.0, []
         for i in range(D):
             dec = E.decrypt(self.sk, outs[i])
             logits = np.array([E.decode(dec[j]) for j in range(10)])
@@ -74,6 +111,8 @@ class Client:
             budgets.append(E.noise_budget(self.sk, outs[i][0]))
             max_err = max(max_err, float(np.abs(logits - want).max()))
             preds_ok += int(np.argmax(logits) == np.argmax(want))
+            preds.append(int(np.argmax(logits)))
+        self.last_predictions = preds
         ok = bool(preds_ok == D and gold_ok is not False and (c1_ok is None or c1_ok.split("/")[0] == c1_ok.split("/")[1]))
         return {"predictions_match_plain_model": f"{preds_ok}/{D}", "max_logit_abs_err": round(max_err, 6), "noise_budget_bits": budgets, "golden_match": gold_ok, "golden": gold_name,
                 "c1_images_match_reference": c1_ok}, ok

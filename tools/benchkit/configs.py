@@ -13,13 +13,13 @@ INT8_PEAK_TOPS = 5000.0        # dense int8 MFMA peak: 2x the ~2.5 PF bf16 rate 
 
 CONFIGS = {
     # BASELINE.json configs[1]: PlainModelTiny.h5, n=4096, batch=1024 on one MI355X  (q = coeff_modulus_128(4096), t = 2^20)
-    "tiny4096": dict(model="PlainModelTiny", n=4096, k=2, t=1 << 32, batch=1024, chunk=128),   # t=2^32: exact logits without the client-side refresh
+    "tiny4096": dict(model="PlainModelTiny", n=4096, k=2, t=1 << 32, batch=1024, chunk=128, distinct=32),   # t=2^32: exact logits without the client-side refresh
     # configs[2]: ApproxPlainModel.h5, n=8192, 3 coeff moduli, batch=1024
-    "approx8192": dict(model="ApproxPlainModel", n=8192, k=3, t=1 << 42, batch=1024, chunk=32, tail=2),   # t=2^42: exact logits, 19 bits of budget left; dense layers per 64 images (+1 %)
+    "approx8192": dict(model="ApproxPlainModel", n=8192, k=3, t=1 << 42, batch=1024, chunk=32, tail=2, distinct=32),   # t=2^42: exact logits, 19 bits of budget left; dense layers per 64 images (+1 %)
     # configs[4]: PlainModelWoPad.h5, n=16384, 4 coeff moduli
     # (tail=5: the dense layers run once per 5 chunks = 30 images -- two-level chunking, netrun.prepare: fc3 streams 177 GiB of limb-form weights per launch and is
     # bound by its MFMAs, which a 64-row tile costs whether 48 (24 images, round 3) or 60 of its rows are real)
-    "wopad16384": dict(model="PlainModelWoPad", n=16384, k=4, t=1 << 44, batch=1024, chunk=6, tail=5),
+    "wopad16384": dict(model="PlainModelWoPad", n=16384, k=4, t=1 << 44, batch=1024, chunk=6, tail=5, distinct=12),
     # the coefficient modulus CrCNN itself would run at n=8192 (all four primes of coeff_modulus_128(8192)); at n=16384 the
     # eight default primes would need 424 GB for PlainModelWoPad's encoded weights alone (> HBM), so that one stays at k=4
     "approx8192k4": dict(model="ApproxPlainModel", n=8192, k=4, t=1 << 42, batch=1024, chunk=16, tail=2),      # (dense layers per 32 images: a full 64-row tile, +7 %)

@@ -38,19 +38,79 @@ def self_launch(args):
 
 
 def launch_check(args):
-    """ranks rendezvous over gloo and count themselves; nothing touches a GPU (tests/test_multiproc_gloo.py)"""
-    import torch
-    import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    seen = world
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")
-        t = torch.tensor([1], dtype=torch.int64); dist.all_reduce(t); seen = int(t.item())
-        dist.barrier(); dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": seen, "self_launched": bool(os.environ.get("CRC_SELF_LAUNCHED"))}), flush=True)
-    return 0 if seen == args.gpus else 1
+    """CPU test of the launcher (tests/test_multiproc_gloo.py): the Python ranks rendezvous over gloo, every rank starts its bench_host child with launch_check=1 -- the
+    file rendezvous of the real run with a random id in place of RCCL's, and the per-rank share of the host threads -- and the ranks compare what the children saw.
+    Nothing touches a GPU."""
+    import subprocess
+    ranks = HostRanks(args)
+    exe = os.path.join(ROOT, "crcnn_amd", "lib", "bench_host")
+    ok, seen, rec = True, ranks.world, None
+    if not os.path.exists(exe):
+        ok = False
+    else:
+        p = subprocess.run([exe, "launch_check=1", f"rank={ranks.rank}", f"world={ranks.world}", f"local_world={ranks.local_world}", "rendezvous=" + ranks.rendezvous_path("check")],
+                           capture_output=True, text=True, timeout=900)
+        if p.returncode == 0:
+            rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+        else:
+            sys.stderr.write(p.stderr[-400:]); ok = False
+    recs = ranks.gather(rec)
+    ids = {r["id_fnv1a"] for r in recs if r}
+    ok = ok and all(recs) and len(ids) == 1 and sorted(r["rank"] for r in recs) == list(range(ranks.world))
+    seen = sum(1 for r in recs if r)
+    if ranks.rank == 0:
+        try:
+            os.remove(ranks.rendezvous_path("check"))
+        except OSError:
+            pass
+        print(json.dumps({"launch_check": True, "n_gpus": ranks.world, "ranks_seen": seen, "self_launched": bool(os.environ.get("CRC_SELF_LAUNCHED")),
+                          "host": "C++ bench_host (one child per rank, file rendezvous)", "same_rendezvous_id_on_every_rank": len(ids) == 1,
+                          "host_threads_per_rank": sorted({r["host_threads"] for r in recs if r})}), flush=True)
+    ranks.close()
+    return 0 if ok and seen == args.gpus else 1
+
+
+class HostRanks:
+    """the Python side of a multi-rank C++ run: this process is ONE rank's harness (torch.distributed.run set RANK / WORLD_SIZE / LOCAL_RANK) and never touches a GPU.
+    gloo (CPU) carries three tiny things: a fresh token for the rendezvous file name, "did any child fail", and the count of ranks whose outputs verified."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0")); self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(self.world)))
+        if self.world != args.gpus and self.world > 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        self.token = "solo"
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=30))
+            obj = [f"{os.getpid()}_{int(time.time() * 1e3)}" if self.rank == 0 else None]
+            dist.broadcast_object_list(obj, src=0)
+            self.token = obj[0]
+
+    def rendezvous_path(self, tag):
+        d = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+        return os.path.join(d, f"crc_rendezvous_{self.token}_{tag}")
+
+    def gather(self, obj):
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def any(self, flag):
+        return any(self.gather(bool(flag)))
+
+    def count(self, flag):
+        return sum(int(bool(f)) for f in self.gather(bool(flag)))
+
+    def close(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
 
 
 class Dist:
