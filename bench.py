@@ -69,9 +69,10 @@ def parse():
     ap.add_argument("--unfused-images", type=int, default=0, help="twin only: images of an extra pass with every reference layer run separately (the reference's T_LAYER columns)")
     ap.add_argument("--t-bits", type=int, default=None, help="twin only: override the plain modulus t = 2^bits")
     ap.add_argument("--launch-check", action="store_true", help="only start the ranks, rendezvous (gloo, no GPU call) and report: CPU test of the self-launch path")
-    ap.add_argument("--stream-inputs", default="none", choices=["none", "ciphertext", "plaintext", "both"],
+    ap.add_argument("--stream-inputs", default="auto", choices=["auto", "none", "ciphertext", "plaintext", "both"],
                     help="also measure with the input launches streamed over PCIe (double-buffered upload beside the kernels): 784 ciphertexts per image, or the 784 pixel "
-                         "plaintexts per image + encryption on the device")
+                         "plaintexts per image + encryption on the device (auto: both for the tiny4096 headline and ciphertext for approx8192 of the default invocation, "
+                         "none otherwise)")
     ap.add_argument("--stream-steps", type=int, default=2, help="passes over the batch of the streamed measurement")
     ap.add_argument("--mnist-dir", default=os.environ.get("CRC_MNIST_DIR", ""), help="directory with t10k-images-idx3-ubyte (and t10k-labels-idx1-ubyte): when present the "
                     "distinct images are real MNIST test images and the line reports agreement with the float model's predictions (utils.cpp:20-53)")
@@ -261,6 +262,8 @@ def main():
         # 1024 images) in the same process
         also = "approx8192,wopad16384" if args.config == "tiny4096" and args.batch is None else "none"
     names = [] if also == "none" else also.split(",")
+    if args.stream_inputs == "auto":
+        args.stream_inputs = "both" if args.config == "tiny4096" and args.batch is None else "none"
     line, ok = None, True
     if world == 1 or not args.python_twin:
         ranks = bdist.HostRanks(args) if world > 1 else None

@@ -124,7 +124,8 @@ extern "C" int crc_limb_pack_tensor(crc_ctx *c, const uint64_t *d_x, int in_form
 }
 extern "C" int crc_limb_pack_tensor_at(crc_ctx *c, const uint64_t *d_x, int in_form, int B, int zd, int xd, int yd, void *d_xl, int Btot, int b0, void *stream)
 {
-    CHECK_CTX(c); if (!d_x || !d_xl || B < 0 || zd < 1 || xd < 1 || yd < 1 || Btot < B || b0 < 0 || b0 + B > Btot || (in_form != CRC_NTT && in_form != CRC_NTTP)) return CRC_ERR_INVALID_ARGUMENT;
+    CHECK_CTX(c); if (!d_x || !d_xl || B < 0 || zd < 1 || xd < 1 || yd < 1 || Btot < B || b0 < 0 || b0 + B > Btot || (in_form != CRC_NTT &&
+        in_form != CRC_NTTP)) return CRC_ERR_INVALID_ARGUMENT;
     if (!crc_limb_supported(c, zd, 1, 1)) return CRC_ERR_UNSUPPORTED;
     return k_limb_pack_tensor(c, d_x, (signed char *)d_xl, B, zd, xd * yd, in_form == CRC_NTTP, S(stream), Btot, b0);
 }
@@ -152,11 +153,13 @@ static int conv1_sub_batch(const crc_ctx *c, int B, int xd, int yo, int nf, int 
     const size_t fit = cap / (per ? per : 1);
     return (int)(fit < 1 ? 1 : fit > (size_t)B ? (size_t)B : fit);
 }
-static int conv2d_limb1(crc_ctx *c, const uint64_t *d_x, const void *d_wl, const uint64_t *d_bias, int B, int xd, int yd, int xs, int ys, int xf, int yf, int nf,
+static int conv2d_limb1(crc_ctx *c, const uint64_t *d_x, const void *d_wl, const uint64_t *d_bias, int B, int xd, int yd, int xs, int ys, int xf, int yf,
+    int nf,
                         int in_form, int out_form, uint64_t *d_y, void *d_work, hipStream_t st)
 {
     const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys + 1, P = xo * yo, in_cts = xd * yd;
-    if (out_form == CRC_NTTLC && P == 1) out_form = CRC_NTTL;   // a 1 x 1 result is a dense layer's input: the K-blocked form (kernels_mfma.hip), made from the slot-major result
+    // a 1 x 1 result is a dense layer's input: the K-blocked form (kernels_mfma.hip), made from the slot-major result
+    if (out_form == CRC_NTTLC && P == 1) out_form = CRC_NTTL;
     const int Bs = conv1_sub_batch(c, B, xd, yo, nf, P, out_form);
     const size_t ctw = crc_ct_words(c, 2);
     char *w = (char *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
@@ -168,7 +171,8 @@ static int conv2d_limb1(crc_ctx *c, const uint64_t *d_x, const void *d_wl, const
         const int Bn = B - b0 < Bs ? B - b0 : Bs;
         const u64 *xn = d_x + (size_t)b0 * in_cts * ctw; bool packed = in_form == CRC_NTTP;
         if (in_form == CRC_COEFF) { RUN(k_ntt_ct(c, false, xn, buf, (size_t)Bn * in_cts, 2, false, st, nullptr, 0, 0, 0, 0)); xn = buf; packed = false; }
-        RUN(k_limb_conv1(c, xn, packed, Xr, (const signed char *)d_wl, Ys, out_form == CRC_NTTLC ? (signed char *)d_y : nullptr, B, b0, out_form != CRC_COEFF ? d_bias : nullptr,
+        RUN(k_limb_conv1(c, xn, packed, Xr, (const signed char *)d_wl, Ys, out_form == CRC_NTTLC ? (signed char *)d_y : nullptr, B, b0,
+            out_form != CRC_COEFF ? d_bias : nullptr,
                          Bn, xd, yd, xs, ys, xf, yf, nf, st));
         if (out_form == CRC_NTTLC) continue;
         if (out_form == CRC_NTTL) return k_limb_result_to_limb(c, Ys, (signed char *)d_y, B, nf * P, st);     // (Bs == B)
@@ -177,7 +181,8 @@ static int conv2d_limb1(crc_ctx *c, const uint64_t *d_x, const void *d_wl, const
     if (out_form == CRC_COEFF) RUN(k_ntt_ct(c, true, d_y, d_y, (size_t)B * nf * P, 2, false, st, d_bias, 1, (size_t)P, nf));
     return CRC_OK;
 }
-extern "C" size_t crc_conv2d_forms_work_bytes(const crc_ctx *c, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int in_form, int w_form, int out_form)
+extern "C" size_t crc_conv2d_forms_work_bytes(const crc_ctx *c, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int in_form,
+    int w_form, int out_form)
 {
     if (w_form == CRC_NTTL1) {
         if (!c || !conv_shape_ok(xd, yd, xs, ys, xf, yf)) return 0;
@@ -198,7 +203,8 @@ extern "C" size_t crc_conv2d_forms_work_bytes(const crc_ctx *c, int B, int zd, i
     if (in_form == CRC_COEFF) b += align256((size_t)B * zd * xd * yd * crc_ct_words(c, 2) * 8);          // NTT copy of the input
     return b + 256;
 }
-static int conv2d_limb(crc_ctx *c, const uint64_t *d_x, const void *d_wl, const uint64_t *d_bias, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf,
+static int conv2d_limb(crc_ctx *c, const uint64_t *d_x, const void *d_wl, const uint64_t *d_bias, int B, int zd, int xd, int yd, int xs, int ys, int xf,
+    int yf, int nf,
                        int in_form, int out_form, uint64_t *d_y, void *d_work, hipStream_t st)
 {
     if (!crc_limb_supported(c, zd, xf, yf)) return CRC_ERR_UNSUPPORTED;
@@ -209,7 +215,8 @@ static int conv2d_limb(crc_ctx *c, const uint64_t *d_x, const void *d_wl, const 
     if (in_form != CRC_NTTL) {
         signed char *Xl = (signed char *)w; w += align256(k_limb_tensor_bytes(c, B, zd, xd * yd));
         const u64 *xn = d_x; bool packed = in_form == CRC_NTTP;
-        if (in_form == CRC_COEFF) { u64 *buf = (u64 *)w; RUN(k_ntt_ct(c, false, d_x, buf, (size_t)B * in_cts, 2, false, st, nullptr, 0, 0, 0, 0)); xn = buf; packed = false; }
+        if (in_form == CRC_COEFF) { u64 *buf = (u64 *)w; RUN(k_ntt_ct(c, false, d_x, buf, (size_t)B * in_cts, 2, false, st, nullptr, 0, 0, 0, 0)); xn = buf;
+            packed = false; }
         RUN(k_limb_pack_tensor(c, xn, Xl, B, zd, xd * yd, packed, st));
         xl = Xl;
     }
@@ -228,14 +235,16 @@ extern "C" int crc_conv2d_forms(crc_ctx *c, const uint64_t *d_x, const uint64_t 
 {
     CHECK_CTX(c);
     if (w_form == CRC_NTTL1) {
-        if (!d_x || !d_w || !d_y || !d_work || B < 0 || nf < 1 || !nform_ok(in_form) || !(lform_ok(out_form) || out_form == CRC_NTTLC) || !conv_shape_ok(xd, yd, xs, ys, xf, yf))
+        if (!d_x || !d_w || !d_y || !d_work || B < 0 || nf < 1 || !nform_ok(in_form) || !(lform_ok(out_form) || out_form == CRC_NTTLC) || !conv_shape_ok(xd,
+            yd, xs, ys, xf, yf))
             return CRC_ERR_INVALID_ARGUMENT;
         if (!k_limb_conv1_shape(c, zd, xd, yd, xs, ys, xf, yf, nf)) return CRC_ERR_UNSUPPORTED;
         if (B == 0) return CRC_OK;
         return conv2d_limb1(c, d_x, d_w, d_bias, B, xd, yd, xs, ys, xf, yf, nf, in_form, out_form, d_y, d_work, S(stream));
     }
     if (w_form == CRC_NTTL) {
-        if (!d_x || !d_w || !d_y || !d_work || B < 0 || zd < 1 || nf < 1 || !lform_ok(in_form) || !lform_ok(out_form) || !conv_shape_ok(xd, yd, xs, ys, xf, yf)) return CRC_ERR_INVALID_ARGUMENT;
+        if (!d_x || !d_w || !d_y || !d_work || B < 0 || zd < 1 || nf < 1 || !lform_ok(in_form) || !lform_ok(out_form) || !conv_shape_ok(xd, yd, xs, ys, xf,
+            yf)) return CRC_ERR_INVALID_ARGUMENT;
         if (B == 0) return CRC_OK;
         return conv2d_limb(c, d_x, d_w, d_bias, B, zd, xd, yd, xs, ys, xf, yf, nf, in_form, out_form, d_y, d_work, S(stream));
     }
@@ -260,7 +269,8 @@ extern "C" int crc_conv2d_forms(crc_ctx *c, const uint64_t *d_x, const uint64_t 
         xn = buf;
     }
     // sum of products in the NTT domain; bias joins here when the output stays NTT-resident
-    RUN(k_mac2(c, xn, d_w, d_y, xoff, toff, B, P, nf, T, in_cts, out_form != CRC_COEFF ? d_bias : nullptr, xd, yd, xf, yf, toffw, st, xp, w_form == CRC_NTTP, out_form == CRC_NTTP));
+    RUN(k_mac2(c, xn, d_w, d_y, xoff, toff, B, P, nf, T, in_cts, out_form != CRC_COEFF ? d_bias : nullptr, xd, yd, xf, yf, toffw, st, xp, w_form == CRC_NTTP,
+        out_form == CRC_NTTP));
     if (out_form == CRC_COEFF)                    // one inverse NTT per output ciphertext, add_plain(bias) fused into its store
         RUN(k_ntt_ct(c, true, d_y, d_y, (size_t)B * nf * P, 2, false, st, d_bias, 1, (size_t)P, nf));
     return CRC_OK;
@@ -298,7 +308,8 @@ extern "C" int crc_conv2d_fold_pool(crc_ctx *c, const uint64_t *d_w, const uint6
                                     int cxs, int cys, int pxf, int pyf, uint64_t *d_w_out, uint64_t *d_bias_out, void *stream)
 {
     CHECK_CTX(c);
-    if (!d_w || !d_bias_ntt || !d_w_out || !d_bias_out || nf < 1 || zd < 1 || xf < 1 || yf < 1 || cxs < 1 || cys < 1 || pxf < 1 || pyf < 1) return CRC_ERR_INVALID_ARGUMENT;
+    if (!d_w || !d_bias_ntt || !d_w_out || !d_bias_out || nf < 1 || zd < 1 || xf < 1 || yf < 1 || cxs < 1 || cys < 1 || pxf < 1 ||
+        pyf < 1) return CRC_ERR_INVALID_ARGUMENT;
     return k_fold_pool(c, d_w, d_bias_ntt, d_div_ntt, d_w_out, d_bias_out, nf, zd, xf, yf, cxs, cys, pxf, pyf, S(stream));
 }
 
@@ -349,24 +360,28 @@ extern "C" int crc_plan_mac(const crc_ctx *c, int zd, int xd, int yd, int xs, in
     if (!matrix_cores || !packable) return CRC_OK;
     // one-channel convolutions (conv1, alone or with its pooling layer folded in) have their own matrix-core kernel
     if (zd == 1) { if (k_limb_conv1_shape(c, zd, xd, yd, xs, ys, xf, yf, nf)) *w_form = CRC_NTTL1; return CRC_OK; }
-    // the limb GEMM pays from 8 reduction steps of 32 channels on (below that its fixed costs per output tile and the channel padding eat the gain), and only with at
-    // least half a 64-row tile of rows = (image, pixel, poly) per launch: with fewer, most of every MFMA is padding and every slot's weights are streamed for a
-    // handful of rows (PlainModelWoPad at 6 images per launch: fc4 0.23 ms per image on mac3_kernel against 1.59)
+    // the limb GEMM pays from 8 reduction steps of 32 channels on (below that its fixed costs per output tile and the channel padding eat the gain), and only
+    // with at least half a 64-row tile of rows = (image, pixel, poly) per launch: with fewer, most of every MFMA is padding and every slot's weights are
+    // streamed for a handful of rows (PlainModelWoPad at 6 images per launch: fc4 0.23 ms per image on mac3_kernel against 1.59)
     const int min_steps = c->tune.mfma_min_steps > 0 ? c->tune.mfma_min_steps : 8;
     const long long P = (long long)((xd - xf) / xs + 1) * ((yd - yf) / ys + 1);
-    // ... a full tile of rows for layers of fewer than 24 filters: the limb form pads the filters to 64, so a 10-filter layer -- CrCNN's fc4 -- spends 6x its canonical
-    // bytes and 5/6 of its MFMAs on zeros (PlainModelWoPad's fc4 at 24 images: 14 GiB of weights, 0.16 against 0.11 ms per image on the vector-ALU kernel; with 64 rows
-    // and more -- PlainModelTiny at 128 images, ApproxPlainModel at 32 -- it still wins, not least because the layer in front hands its tensor over in limb form)
+    // ... a full tile of rows for layers of fewer than 24 filters: the limb form pads the filters to 64, so a 10-filter layer -- CrCNN's fc4 -- spends 6x its
+    // canonical bytes and 5/6 of its MFMAs on zeros (PlainModelWoPad's fc4 at 24 images: 14 GiB of weights, 0.16 against 0.11 ms per image on the vector-ALU
+    // kernel; with 64 rows and more -- PlainModelTiny at 128 images, ApproxPlainModel at 32 -- it still wins, not least because the layer in front hands its
+    // tensor over in limb form)
     // -- and only on the smaller rings (n k <= 32768), where those 6x are a few GB (28 GiB at n = 16384 with eight primes)
     const long long rows = (long long)B * 2 * P, min_rows = nf >= 24 ? 32 : 64;
     const bool few_filters_ok = nf >= 24 || (long long)c->n * c->k <= 32768;
-    if (zd >= 16 && few_filters_ok && (long long)((zd + 31) / 32) * xf * yf >= min_steps && crc_limb_supported(c, zd, xf, yf) && (B <= 0 || rows >= min_rows)) *w_form = CRC_NTTL;
+    if (zd >= 16 && few_filters_ok && (long long)((zd + 31) / 32) * xf * yf >= min_steps && crc_limb_supported(c, zd, xf, yf) && (B <= 0 ||
+        rows >= min_rows)) *w_form = CRC_NTTL;
     return CRC_OK;
 }
 // should a (sum / average) pooling layer be folded into the convolution in front of it (crc_conv2d_fold_pool: exact)?  Cost in units of one multiply-accumulate
-// term per output ciphertext: the MAC kernels pay ~24 terms of prologue / epilogue per output and take filters in multiples of 8; a pooling pass moves
-// (window + 1) ciphertexts per output at HBM rate, ~10 term-times each.  Folding wins whenever it removes MACs (decimating pools) and narrowly for CrCNN's stride-1 pools.
-extern "C" int crc_plan_fold_pool(const crc_ctx *c, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int pxs, int pys, int pxf, int pyf, int *fold)
+// term per output ciphertext: the MAC kernels pay ~24 terms of prologue / epilogue per output and take filters in multiples of 8; a pooling pass moves (window
+// + 1) ciphertexts per output at HBM rate, ~10 term-times each.  Folding wins whenever it removes MACs (decimating pools) and narrowly for CrCNN's stride-1
+// pools.
+extern "C" int crc_plan_fold_pool(const crc_ctx *c, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int pxs, int pys, int pxf, int pyf,
+    int *fold)
 {
     if (!c || !fold || zd < 1 || nf < 1 || !conv_shape_ok(xd, yd, xs, ys, xf, yf) || pxs < 1 || pys < 1 || pxf < 1 || pyf < 1) return CRC_ERR_INVALID_ARGUMENT;
     *fold = 0;
@@ -382,9 +397,16 @@ extern "C" int crc_plan_fold_pool(const crc_ctx *c, int zd, int xd, int yd, int 
     return CRC_OK;
 }
 
-// ---- square + relinearize -----------------------------------------------------------------------------------------
-// ciphertexts per internal pass (bounds the scratch footprint: ~10 GB at every ring size -- 512 up to n k = 65536, 256 at n = 16384 with all eight primes)
-static size_t square_chunk(const crc_ctx *c) { if (c->tune.sq_chunk > 0) return (size_t)c->tune.sq_chunk; const size_t nk = (size_t)c->n * c->k; return nk <= 65536 ? 512 : nk <= 131072 ? 256 : 128; }
+// ---- square + relinearize ----------------------------------------------------------------------------------------- ciphertexts per internal pass (bounds the
+// scratch footprint: ~10 GB at every ring size -- 512 up to n k = 65536, 256 at n = 16384 with all eight primes) ciphertexts per internal pass of square +
+// relinearise.  (Round 5: 1024 up to n k = 32768 -- the eight kernels of a pass each end in a partly filled last wave of workgroups; at (8192, 3) twice the
+// pass is 2 % faster, at (16384, 4) it changes nothing: profiles/r05_square_chunk_sweep.txt)
+static size_t square_chunk(const crc_ctx *c)
+{
+    if (c->tune.sq_chunk > 0) return (size_t)c->tune.sq_chunk;
+    const size_t nk = (size_t)c->n * c->k;
+    return nk <= 32768 ? 1024 : nk <= 65536 ? 512 : nk <= 131072 ? 256 : 128;
+}
 
 extern "C" size_t crc_square_relin_work_bytes(const crc_ctx *c, size_t count, int dbc)
 {
@@ -402,7 +424,8 @@ extern "C" int crc_encrypt_dev_key(crc_ctx *c, const uint64_t *d_pk, const uint6
     u64 *w = (u64 *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
     return k_encrypt(c, d_pk, d_plain, count, chacha_load_key(key), stream_base, d_ct, w, S(stream));
 }
-extern "C" int crc_encrypt_dev(crc_ctx *c, const uint64_t *d_pk, const uint64_t *d_plain, size_t count, uint64_t seed, uint64_t *d_ct, void *d_work, void *stream)
+extern "C" int crc_encrypt_dev(crc_ctx *c, const uint64_t *d_pk, const uint64_t *d_plain, size_t count, uint64_t seed, uint64_t *d_ct, void *d_work,
+    void *stream)
 {
     CHECK_CTX(c); if (!d_pk || !d_plain || !d_ct || !d_work) return CRC_ERR_INVALID_ARGUMENT;
     u64 *w = (u64 *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
@@ -426,7 +449,8 @@ extern "C" int crc_relinearize(crc_ctx *c, const uint64_t *d_x3, size_t count, c
     const size_t kSquareChunk = square_chunk(c);
     for (size_t o = 0; o < count; o += kSquareChunk) {
         const size_t ch = count - o < kSquareChunk ? count - o : kSquareChunk;
-        RUN(k_relinearize(c, d_x3 + o * crc_ct_words(c, 3), ch, d_evk, dbc, d_y + o * crc_ct_words(c, 2), w + k_relin_keys_words(c, dbc), w, S(stream), false, false, o != 0));
+        RUN(k_relinearize(c, d_x3 + o * crc_ct_words(c, 3), ch, d_evk, dbc, d_y + o * crc_ct_words(c, 2), w + k_relin_keys_words(c, dbc), w, S(stream), false,
+            false, o != 0));
     }
     return CRC_OK;
 }

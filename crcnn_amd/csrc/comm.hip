@@ -21,9 +21,10 @@
 #include <vector>
 
 // Rehearsal transport (CRC_COMM_TRANSPORT=shm).  RCCL refuses two ranks on one GPU, and the boxes this engine is developed on have one: with this switch the
-// SAME entry points (crc_comm_unique_id / crc_comm_create / crc_broadcast_weights / crc_comm_allgather_u64) move their bytes through a POSIX shared-memory segment
-// staged by hipMemcpy, so the multi-rank host code above them -- Network::broadcastParameters, bench_host's rendezvous, barrier and max-over-ranks timing -- runs
-// end to end with two processes on one device (tests/test_gpu_comm.py).  It is a transport for tests, never chosen by default and never faster than RCCL.
+// SAME entry points (crc_comm_unique_id / crc_comm_create / crc_broadcast_weights / crc_comm_allgather_u64) move their bytes through a POSIX shared-memory
+// segment staged by hipMemcpy, so the multi-rank host code above them -- Network::broadcastParameters, bench_host's rendezvous, barrier and max-over-ranks
+// timing -- runs end to end with two processes on one device (tests/test_gpu_comm.py).  It is a transport for tests, never chosen by default and never faster
+// than RCCL.
 struct ShmSeg {
     std::atomic<uint64_t> arrived, generation;    // sense-reversing barrier of `world` processes
     uint64_t gather[64 * 64];                      // all-gather slots: [rank][kScratchWords]
@@ -83,7 +84,8 @@ extern "C" int crc_comm_unique_id(uint8_t *h_id)
     if (shm_wanted()) {                           // the "id" names a fresh shared-memory segment
         std::memset(h_id, 0, CRC_COMM_ID_BYTES);
         std::memcpy(h_id, kShmMagic, sizeof kShmMagic);
-        std::snprintf((char *)h_id + 8, 48, "/crc_comm_%ld_%llx", (long)getpid(), (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count());
+        std::snprintf((char *)h_id + 8, 48, "/crc_comm_%ld_%llx", (long)getpid(),
+            (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count());
         return CRC_OK;
     }
     ncclUniqueId id;
@@ -145,7 +147,8 @@ extern "C" int crc_comm_create_all(crc_ctx *const *ctxs, int ndev, crc_comm **ou
         crc_comm *cm = new crc_comm(); cm->comm = comms[i]; cm->world = ndev; cm->rank = i; cm->device = devs[i];
         out[i] = cm;
         const int rc = comm_finish(cm);
-        if (rc) { for (int j = 0; j <= i; j++) { crc_comm_destroy(out[j]); out[j] = nullptr; } for (int j = i + 1; j < ndev; j++) ncclCommDestroy(comms[j]); return rc; }
+        if (rc) { for (int j = 0; j <= i; j++) { crc_comm_destroy(out[j]); out[j] = nullptr; } for (int j = i + 1; j < ndev; j++) ncclCommDestroy(comms[j]);
+            return rc; }
     }
     return CRC_OK;
 }
@@ -228,16 +231,19 @@ __global__ void __launch_bounds__(256) checksum_kernel(const u64 *w, size_t word
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += stride) { const u64 v = w[i]; x ^= v; s += v * (2 * (u64)i + 1); }
     for (int off = 32; off > 0; off >>= 1) { x ^= __shfl_down(x, off, 64); s += __shfl_down(s, off, 64); }
-    if ((threadIdx.x & 63) == 0) { atomicXor((unsigned long long *)&out[0], (unsigned long long)x); atomicAdd((unsigned long long *)&out[1], (unsigned long long)s); }
+    if ((threadIdx.x & 63) == 0) { atomicXor((unsigned long long *)&out[0], (unsigned long long)x);
+        atomicAdd((unsigned long long *)&out[1], (unsigned long long)s); }
 }
 
 extern "C" int crc_checksum64(crc_ctx *c, const uint64_t *d_words, size_t words, uint64_t *h_out, void *stream)
 {
     if (!c || c->device < 0 || !h_out || (!d_words && words)) return CRC_ERR_INVALID_ARGUMENT;
-    GUARD(c->device);                                    // the kernel and the copies below belong to THIS context's GPU, whatever the thread's current device is
+    // the kernel and the copies below belong to THIS context's GPU, whatever the thread's current device is
+    GUARD(c->device);
     hipStream_t st = (hipStream_t)stream;
-    // the two accumulator words live in the context's scratch: 256 slots handed out round robin, so that checksums issued from several host threads (each on its
-    // own stream) neither share accumulators nor wait for one another; a slot comes round again after 255 other calls, each of which has synchronised its stream
+    // the two accumulator words live in the context's scratch: 256 slots handed out round robin, so that checksums issued from several host threads (each on
+    // its own stream) neither share accumulators nor wait for one another; a slot comes round again after 255 other calls, each of which has synchronised its
+    // stream
     const unsigned slot = c->scratch_next.fetch_add(1, std::memory_order_relaxed) & 255u;
     u64 *acc = c->d_scratch + 2 * slot;
     HIPCHK(hipMemsetAsync(acc, 0, 16, st));

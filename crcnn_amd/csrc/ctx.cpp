@@ -212,7 +212,8 @@ extern "C" int crc_default_coeff_modulus_128(int n, uint64_t *q, int cap)
 {
     static const u64 m1024[] = {0x7e00001}, m2048[] = {0x3fffffff000001}, m4096[] = {0x7fffffff380001, 0x3fffffff000001},
         m8192[] = {0x7fffffff380001, 0x7ffffffef00001, 0x3fffffff000001, 0x3ffffffef40001},
-        m16384[] = {0x7fffffff380001, 0x7ffffffef00001, 0x7ffffffeac0001, 0x7ffffffe700001, 0x7ffffffe600001, 0x7ffffffe4c0001, 0x3fffffff000001, 0x3ffffffef40001};
+        m16384[] = {0x7fffffff380001, 0x7ffffffef00001, 0x7ffffffeac0001, 0x7ffffffe700001, 0x7ffffffe600001, 0x7ffffffe4c0001, 0x3fffffff000001,
+            0x3ffffffef40001};
     const u64 *src; int cnt;
     switch (n) {
     case 1024: src = m1024; cnt = 1; break;
@@ -261,7 +262,8 @@ extern "C" int crc_ctx_create(int n, const uint64_t *q, int k, uint64_t t, int d
     // floor(q/t) mod q_i and (q mod t) mod q_i, evaluator.cpp:66-105 -- long division of the multi-limb q by t
     {
         std::vector<u64> big(k, 0); big[0] = 1;
-        for (int i = 0; i < k; i++) { u64 carry = 0; for (int l = 0; l < k; l++) { u128 z = (u128)big[l] * q[i] + carry; big[l] = (u64)z; carry = (u64)(z >> 64); } }
+        for (int i = 0; i < k; i++) { u64 carry = 0; for (int l = 0; l < k; l++) { u128 z = (u128)big[l] * q[i] + carry; big[l] = (u64)z;
+            carry = (u64)(z >> 64); } }
         c->qbig = big;
         c->total_bits = 0; for (int l = k - 1; l >= 0; l--) if (big[l]) { c->total_bits = 64 * l + sigbits(big[l]); break; }
         std::vector<u64> quo(big); u64 rem = 0;
@@ -333,16 +335,19 @@ extern "C" int crc_ctx_create(int n, const uint64_t *q, int k, uint64_t t, int d
         F64Params &f = c->f64; memset(&f, 0, sizeof f);
         auto centred = [](u64 v, u64 p) { return v > p / 2 ? (double)((long long)v - (long long)p) : (double)v; };
         auto quot = [](double w, u64 p) { return (double)((long double)w / (long double)p); };
-        // the square's auxiliary base: the fewest primes with prod p_j >= 4 n t q (1 + 2^-27 + 2^-40) (ctx.h Sq64Params; every p_j > 2^46.9999); transforms on an LDS image of n doubles
+        // the square's auxiliary base: the fewest primes with prod p_j >= 4 n t q (1 + 2^-27 + 2^-40) (ctx.h Sq64Params; every p_j > 2^46.9999); transforms on
+        // an LDS image of n doubles
         Sq64Params &sq = c->sq64; memset(&sq, 0, sizeof sq);
         if (n <= 16384) {
-            // exact, in multi-limb integers: X = 4 n t q (1 + 2^-27 + 2^-40) -- twice the bound 2 n t q (1 + k 2^-32)^2 + k on |floor(t P / q)| of SEAL 2.3.1's non-centred
-            // mont_rq, plus fastbconv_sk's own 2 B (1 + #B) -- must not exceed prod p_j
-            auto mul = [](std::vector<u64> a, u64 m) { u64 carry = 0; for (auto &l : a) { u128 z = (u128)l * m + carry; l = (u64)z; carry = (u64)(z >> 64); } if (carry) a.push_back(carry); return a; };
+            // exact, in multi-limb integers: X = 4 n t q (1 + 2^-27 + 2^-40) -- twice the bound 2 n t q (1 + k 2^-32)^2 + k on |floor(t P / q)| of SEAL 2.3.1's
+            // non-centred mont_rq, plus fastbconv_sk's own 2 B (1 + #B) -- must not exceed prod p_j
+            auto mul = [](std::vector<u64> a, u64 m) { u64 carry = 0; for (auto &l : a) { u128 z = (u128)l * m + carry; l = (u64)z; carry = (u64)(z >> 64);
+                } if (carry) a.push_back(carry); return a; };
             auto shr = [](const std::vector<u64> &a, int sh) { std::vector<u64> r(a.size(), 0); const int w = sh / 64, b = sh % 64;
                 for (size_t i = w; i < a.size(); i++) { r[i - w] = a[i] >> b; if (b && i + 1 < a.size()) r[i - w] |= a[i + 1] << (64 - b); } return r; };
             auto add = [](std::vector<u64> a, const std::vector<u64> &b) { a.resize(std::max(a.size(), b.size()) + 1, 0); u64 carry = 0;
-                for (size_t i = 0; i < a.size(); i++) { u128 z = (u128)a[i] + (i < b.size() ? b[i] : 0) + carry; a[i] = (u64)z; carry = (u64)(z >> 64); } return a; };
+                for (size_t i = 0; i < a.size(); i++) { u128 z = (u128)a[i] + (i < b.size() ? b[i] : 0) + carry; a[i] = (u64)z; carry = (u64)(z >> 64);
+                    } return a; };
             auto geq = [](std::vector<u64> a, std::vector<u64> b) { const size_t m = std::max(a.size(), b.size()); a.resize(m, 0); b.resize(m, 0);
                 for (size_t i = m; i-- > 0;) if (a[i] != b[i]) return a[i] > b[i]; return true; };
             std::vector<u64> X = mul(mul(mul(c->qbig, t), (u64)n), 4);
@@ -431,10 +436,12 @@ extern "C" int crc_ctx_create(int n, const uint64_t *q, int k, uint64_t t, int d
         }
         const size_t ftw = (size_t)n * 8;
         if ((e = hipMalloc(&c->d_f64_rp, ftw * c->nf64)) != hipSuccess || (e = hipMalloc(&c->d_f64_irp, ftw * c->nf64)) != hipSuccess ||
-            (e = hipMalloc(&c->d_sq64, sizeof(Sq64Params))) != hipSuccess || (e = hipMemcpy(c->d_sq64, &c->sq64, sizeof(Sq64Params), hipMemcpyHostToDevice)) != hipSuccess) { fail(e); crc_ctx_destroy(c); return rc; }
+            (e = hipMalloc(&c->d_sq64, sizeof(Sq64Params))) != hipSuccess || (e = hipMemcpy(c->d_sq64, &c->sq64, sizeof(Sq64Params),
+                hipMemcpyHostToDevice)) != hipSuccess) { fail(e); crc_ctx_destroy(c); return rc; }
         for (int m = 0; m < c->nf64; m++)
             if ((e = hipMemcpy((char *)c->d_f64_rp + m * ftw, f64rp[m].data(), ftw, hipMemcpyHostToDevice)) != hipSuccess ||
-                (e = hipMemcpy((char *)c->d_f64_irp + m * ftw, f64irp[m].data(), ftw, hipMemcpyHostToDevice)) != hipSuccess) { fail(e); crc_ctx_destroy(c); return rc; }
+                (e = hipMemcpy((char *)c->d_f64_irp + m * ftw, f64irp[m].data(), ftw, hipMemcpyHostToDevice)) != hipSuccess) { fail(e); crc_ctx_destroy(c);
+                    return rc; }
         c->d_scratch = c->d_zero + 512;
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->cus = cus;
@@ -491,7 +498,8 @@ extern "C" int crc_ctx_table(const crc_ctx *c, const char *name, uint64_t *out, 
     else if (s == "f64_primes") for (int m = 0; m < CRC_NF64; m++) v.push_back(c->f64_primes[m]);
     else if (s == "sq64_primes") for (int m = 0; m < c->sq64.kf; m++) v.push_back(c->f64_primes[m]);
     else if (s.rfind("root_powers:", 0) == 0) { int mi = atoi(name + 12); if (mi < 0 || mi >= k + kb) return CRC_ERR_INVALID_ARGUMENT; v = c->tabs[mi].rp; }
-    else if (s.rfind("inv_root_powers_div_two:", 0) == 0) { int mi = atoi(name + 24); if (mi < 0 || mi >= k + kb) return CRC_ERR_INVALID_ARGUMENT; v = c->tabs[mi].irp2; }
+    else if (s.rfind("inv_root_powers_div_two:", 0) == 0) { int mi = atoi(name + 24); if (mi < 0 || mi >= k + kb) return CRC_ERR_INVALID_ARGUMENT;
+        v = c->tabs[mi].irp2; }
     else return CRC_ERR_NOT_FOUND;
     for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = v[i];
     return (int)v.size();
@@ -514,9 +522,12 @@ extern "C" int crc_malloc(crc_ctx *c, size_t bytes, void **p)
     return CRC_OK;
 }
 extern "C" int crc_free(crc_ctx *c, void *p) { (void)c; HIPCHK(hipFree(p)); return CRC_OK; }
-extern "C" int crc_memcpy_h2d(crc_ctx *c, void *d, const void *h, size_t b, void *s) { (void)c; HIPCHK(hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice, (hipStream_t)s)); return CRC_OK; }
-extern "C" int crc_memcpy_d2h(crc_ctx *c, void *h, const void *d, size_t b, void *s) { (void)c; HIPCHK(hipMemcpyAsync(h, d, b, hipMemcpyDeviceToHost, (hipStream_t)s)); return CRC_OK; }
-extern "C" int crc_memcpy_d2d(crc_ctx *c, void *d, const void *s0, size_t b, void *s) { (void)c; HIPCHK(hipMemcpyAsync(d, s0, b, hipMemcpyDeviceToDevice, (hipStream_t)s)); return CRC_OK; }
+extern "C" int crc_memcpy_h2d(crc_ctx *c, void *d, const void *h, size_t b, void *s) { (void)c; HIPCHK(hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice,
+    (hipStream_t)s)); return CRC_OK; }
+extern "C" int crc_memcpy_d2h(crc_ctx *c, void *h, const void *d, size_t b, void *s) { (void)c; HIPCHK(hipMemcpyAsync(h, d, b, hipMemcpyDeviceToHost,
+    (hipStream_t)s)); return CRC_OK; }
+extern "C" int crc_memcpy_d2d(crc_ctx *c, void *d, const void *s0, size_t b, void *s) { (void)c; HIPCHK(hipMemcpyAsync(d, s0, b, hipMemcpyDeviceToDevice,
+    (hipStream_t)s)); return CRC_OK; }
 extern "C" int crc_memset(crc_ctx *c, void *d, int v, size_t b, void *s) { (void)c; HIPCHK(hipMemsetAsync(d, v, b, (hipStream_t)s)); return CRC_OK; }
 extern "C" int crc_stream_sync(crc_ctx *c, void *s) { (void)c; HIPCHK(hipStreamSynchronize((hipStream_t)s)); return CRC_OK; }
 // Streams of the caller's own: non-blocking ones (no implicit ordering against the default stream), so that a host can put the next chunk's upload beside the
@@ -527,7 +538,8 @@ extern "C" int crc_stream_create(crc_ctx *c, void **stream)
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s; HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); *stream = (void *)s; return CRC_OK;
 }
-extern "C" int crc_stream_destroy(crc_ctx *c, void *stream) { (void)c; if (!stream) return CRC_OK; HIPCHK(hipStreamDestroy((hipStream_t)stream)); return CRC_OK; }
+extern "C" int crc_stream_destroy(crc_ctx *c, void *stream) { (void)c; if (!stream) return CRC_OK; HIPCHK(hipStreamDestroy((hipStream_t)stream));
+    return CRC_OK; }
 extern "C" int crc_stream_wait_event(crc_ctx *c, void *stream, void *ev)
 {
     (void)c; if (!ev) return CRC_ERR_INVALID_ARGUMENT;
@@ -542,13 +554,16 @@ extern "C" int crc_host_alloc(crc_ctx *c, size_t bytes, void **h_ptr)
     return CRC_OK;
 }
 extern "C" int crc_host_free(crc_ctx *c, void *h_ptr) { (void)c; if (!h_ptr) return CRC_OK; HIPCHK(hipHostFree(h_ptr)); return CRC_OK; }
-// threads the host-side item loops of this process use (csrc/host_parallel.h: CRC_HOST_THREADS, else the hardware's, at most 16, divided by the ranks of the node)
+// threads the host-side item loops of this process use (csrc/host_parallel.h: CRC_HOST_THREADS, else the hardware's, at most 16, divided by the ranks of the
+// node)
 extern "C" int crc_host_thread_limit(void) { return crc_host::thread_limit(); }
 // HIP events for hosts that do not link HIP themselves (the C++ host classes time their layers with them: on the stream the kernels are launched on, no
 // synchronisation between layers)
-extern "C" int crc_event_create(crc_ctx *c, void **ev) { if (!c || !ev || c->device < 0) return CRC_ERR_INVALID_ARGUMENT; hipEvent_t e; HIPCHK(hipEventCreate(&e)); *ev = (void *)e; return CRC_OK; }
+extern "C" int crc_event_create(crc_ctx *c, void **ev) { if (!c || !ev || c->device < 0) return CRC_ERR_INVALID_ARGUMENT; hipEvent_t e;
+    HIPCHK(hipEventCreate(&e)); *ev = (void *)e; return CRC_OK; }
 extern "C" int crc_event_destroy(crc_ctx *c, void *ev) { (void)c; if (!ev) return CRC_OK; HIPCHK(hipEventDestroy((hipEvent_t)ev)); return CRC_OK; }
-extern "C" int crc_event_record(crc_ctx *c, void *ev, void *s) { (void)c; if (!ev) return CRC_ERR_INVALID_ARGUMENT; HIPCHK(hipEventRecord((hipEvent_t)ev, (hipStream_t)s)); return CRC_OK; }
+extern "C" int crc_event_record(crc_ctx *c, void *ev, void *s) { (void)c; if (!ev) return CRC_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipEventRecord((hipEvent_t)ev, (hipStream_t)s)); return CRC_OK; }
 extern "C" int crc_event_elapsed_ms(crc_ctx *c, void *ev0, void *ev1, float *ms)
 {
     (void)c; if (!ev0 || !ev1 || !ms) return CRC_ERR_INVALID_ARGUMENT;

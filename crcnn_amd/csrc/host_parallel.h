@@ -1,7 +1,8 @@
 // host_parallel.h -- the host side's one threading primitive: contiguous ranges of an index space on a few std::threads.
 //
 // The client-side work (fractional encoding of 10^5..10^6 weights, one ChaCha20 keystream + three transforms per encrypted pixel) is independent per item and
-// bit-identical however it is split, so it runs on up to CRC_HOST_THREADS threads (default: the hardware's, at most 16 -- a GPU box's CPU share -- divided by the
+// bit-identical however it is split, so it runs on up to CRC_HOST_THREADS threads (default: the hardware's, at most 16 -- a GPU box's CPU share -- divided by
+// the
 // ranks of the node when there are several: LOCAL_WORLD_SIZE).  Threads come from
 // ONE budget per library: a caller that is itself one of many threads (benchkit's client encrypts images on a pool) finds the budget spent and runs its range
 // inline, so nested parallelism never multiplies thread counts.
@@ -21,8 +22,8 @@ inline int thread_limit()
         if (v <= 0) {
             const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
             v = std::min(16, hw);
-            // one process per GPU: the ranks of a node share its cores (LOCAL_WORLD_SIZE is torch.distributed.run's, CRC_LOCAL_WORLD bench_host's own) -- eight ranks
-            // encoding weights at once must not start 8 x 16 threads
+            // one process per GPU: the ranks of a node share its cores (LOCAL_WORLD_SIZE is torch.distributed.run's, CRC_LOCAL_WORLD bench_host's own) -- eight
+            // ranks encoding weights at once must not start 8 x 16 threads
             int ranks = 1;
             for (const char *name : {"CRC_LOCAL_WORLD", "LOCAL_WORLD_SIZE"})
                 if (const char *e = std::getenv(name)) { const int r = std::atoi(e); if (r > 1) { ranks = r; break; } }

@@ -1,15 +1,15 @@
 // kernels_relin64.hip -- relinearisation's key switching over TWO fp64 NTT primes instead of the k coefficient moduli.
 //
 // Reference: Evaluator::relinearize_one_step (evaluator.cpp:934-1069).  For every target modulus q_j and output polynomial the reference forms
-//     R_j = sum_{i < k} sum_{d < L_i}  e_{i,d} (*) key_{i,d}[j]      mod q_j         ((*) = negacyclic product, e_{i,d} = digit d of c2 (q/q_i)^-1 mod q_i)
-// with 4 k^2 forward transforms over the 55-bit primes (every digit polynomial under every q_j), 2 k inverse ones, and adds c0, c1.  The digits are below 2^dbc (16
-// bits) and the key residues below q_j, so over the INTEGERS |R_j| <= n D 2^dbc q_j / 2 (keys taken as centred residues) < 2^90: R_j is a fixed integer polynomial,
-// and its residue mod q_j -- all the reference needs -- can be had from its residues modulo ANY primes whose product exceeds 2 |R_j|.  We take the two fp64 primes of
-// the context (p_0 p_1 ~ 2^94, f64mod.h): 2 D forward transforms of 16-bit polynomials and 2 * 2k inverse ones per ciphertext in 6-flop fp64 arithmetic, the keys
-// re-expressed once per call (inverse transform mod q_j, centre, reduce mod p_m, forward transform mod p_m, times n^-1), a CRT lift per coefficient.  Same element of
-// Z_q, hence the same bits (goldens: tests/golden/ops_*.npz ref_relin*, layers / nets).
-//   K1 relin_digits_f64_kernel : one workgroup per (ciphertext, i): the L_i digits of row c2'_i, each transformed under p_0 and p_1 in LDS     -> E  [ct][g][m][n]
-//   K2 relin_mac_f64_kernel    : per slot: A[ct][poly][j][m] = sum_g E[ct][g][m] Kf[g][poly][j][m]  (lazy sum of reduced products, < 42 p)         -> A  [ct][2k][m][n]
+//     R_j = sum_{i < k} sum_{d < L_i}  e_{i,d} (*) key_{i,d}[j]  mod q_j  ((*) = negacyclic product, e_{i,d} = digit d of c2 (q/q_i)^-1 mod q_i) with 4 k^2
+//     forward transforms over the 55-bit primes (every digit polynomial under every q_j), 2 k inverse ones, and adds c0, c1.  The digits are below 2^dbc (16
+//     bits) and the key residues below q_j, so over the INTEGERS |R_j| <= n D 2^dbc q_j / 2 (keys taken as centred residues) < 2^90: R_j is a fixed integer
+//     polynomial, and its residue mod q_j -- all the reference needs -- can be had from its residues modulo ANY primes whose product exceeds 2 |R_j|.  We take
+//     the two fp64 primes of the context (p_0 p_1 ~ 2^94, f64mod.h): 2 D forward transforms of 16-bit polynomials and 2 * 2k inverse ones per ciphertext in
+//     6-flop fp64 arithmetic, the keys re-expressed once per call (inverse transform mod q_j, centre, reduce mod p_m, forward transform mod p_m, times n^-1), a
+//     CRT lift per coefficient.  Same element of Z_q, hence the same bits (goldens: tests/golden/ops_*.npz ref_relin*, layers / nets).
+//   K1 relin_digits_f64_kernel : one workgroup per (ciphertext, i): the L_i digits of row c2'_i, each transformed under p_0 and p_1 in LDS  -> E  [ct][g][m][n]
+//   K2 relin_mac_f64_kernel  : per slot: A[ct][poly][j][m] = sum_g E[ct][g][m] Kf[g][poly][j][m]  (lazy sum of reduced products, < 42 p)  -> A  [ct][2k][m][n]
 //   K3 relin_inv_crt_kernel    : one workgroup per (ciphertext, poly, j): both inverse transforms, CRT lift, mod q_j, + c_poly; coefficient form out, or the
 //                                forward transform over q_j in the same LDS image for an NTT-resident result
 #include "kernels.h"
@@ -20,8 +20,9 @@
 
 struct Relin64Tab { unsigned char L[CRC_MAXK], g0[CRC_MAXK]; };
 
-// ---- key preparation (once per call) ------------------------------------------------------------------------------------------------------------------------------
-// evaluation keys as SEAL hands them over (NTT form over q_j, residues possibly lazy / non-canonical) -> canonical
+// ---- key preparation (once per call)
+// ------------------------------------------------------------------------------------------------------------------------------ evaluation keys as SEAL hands
+// them over (NTT form over q_j, residues possibly lazy / non-canonical) -> canonical
 __global__ void __launch_bounds__(256) evk_canon_kernel(const u64 *evk, u64 *out, const ModParams *mods, int n, int k)
 {
     const size_t row = blockIdx.x;
@@ -29,9 +30,11 @@ __global__ void __launch_bounds__(256) evk_canon_kernel(const u64 *evk, u64 *out
     const u64 *src = evk + row * (size_t)n; u64 *dst = out + row * (size_t)n;
     for (int s = threadIdx.x; s < n; s += blockDim.x) dst[s] = barrett128(src[s], 0, m);
 }
-// kc: the keys in coefficient form over q_j, rows [2 g + poly][j] (blob order)  ->  Kf [g][poly k + j][m][n]: centred residue mod p_m, forward transform, times n^-1
+// kc: the keys in coefficient form over q_j, rows [2 g + poly][j] (blob order)  ->  Kf [g][poly k + j][m][n]: centred residue mod p_m, forward transform, times
+// n^-1
 template <int RB>
-__global__ void __launch_bounds__(RB == 5 ? 512 : 1024) relin_keys_f64_kernel(const u64 *kc, double *Kf, const ModParams *mods, const double *Wf, F64Params fp, int n, int logn, int k)
+__global__ void __launch_bounds__(RB == 5 ? 512 : 1024) relin_keys_f64_kernel(const u64 *kc, double *Kf, const ModParams *mods, const double *Wf,
+    F64Params fp, int n, int logn, int k)
 {
     extern __shared__ double smd[];
     const int m = blockIdx.x % CRC_NF64; const size_t row = blockIdx.x / CRC_NF64;       // row = (2 g + poly) k + j
@@ -50,16 +53,19 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024) relin_keys_f64_kernel(co
     double *dst = Kf + (((g * 2 * k + (size_t)poly * k + j) * CRC_NF64) + m) * (size_t)n;
     for (int s = 2 * threadIdx.x; s < n; s += 2 * blockDim.x) {
         const d2 v = f64_stage_out<false, RB>(sm_load_pair<RB>(smd, s), W, n, logn, s, md);
-        *reinterpret_cast<d2 *>(dst + s) = d2{f64_reduce(f64_mulmod_const(v.x, fp.ninv[m], fp.ninv_q[m], md.p), md), f64_reduce(f64_mulmod_const(v.y, fp.ninv[m], fp.ninv_q[m], md.p), md)};
+        *reinterpret_cast<d2 *>(dst + s) = d2{f64_reduce(f64_mulmod_const(v.x, fp.ninv[m], fp.ninv_q[m], md.p), md), f64_reduce(f64_mulmod_const(v.y,
+            fp.ninv[m], fp.ninv_q[m], md.p), md)};
     }
 }
 
-// ---- K1: digits of c2' under both primes ---------------------------------------------------------------------------------------------------------------------------
-// src: size-`src_size` ciphertexts, poly `src_poly` = c2 (q/q_i)^-1 mod q_i (evaluator.cpp:984-985); E [ct][g][m][n], unreduced (|.| < 14 p)
-// The source row is read ONCE and waits in registers (NPT points per thread) through the 2 L_i transforms cut from it: round 3 read it again in front of every
-// transform, 8 times at 16-bit digits, and the L2 had long been swept by then (20 row reads per ciphertext for 3 rows at (8192, 3))
+// ---- K1: digits of c2' under both primes
+// --------------------------------------------------------------------------------------------------------------------------- src: size-`src_size` ciphertexts,
+// poly `src_poly` = c2 (q/q_i)^-1 mod q_i (evaluator.cpp:984-985); E [ct][g][m][n], unreduced (|.| < 14 p) The source row is read ONCE and waits in registers
+// (NPT points per thread) through the 2 L_i transforms cut from it: round 3 read it again in front of every transform, 8 times at 16-bit digits, and the L2 had
+// long been swept by then (20 row reads per ciphertext for 3 rows at (8192, 3))
 template <int RB, int NPT>
-__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_digits_f64_kernel(const u64 *src, int src_size, int src_poly, double *E, const double *Wf, F64Params fp, int n, int logn,
+__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_digits_f64_kernel(const u64 *src, int src_size, int src_poly, double *E, const double *Wf,
+    F64Params fp, int n, int logn,
                                                                                                          int k, int D, int dbc, Relin64Tab tab)
 {
     extern __shared__ double smd[];
@@ -91,15 +97,17 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_digits_f64_kern
     }
 }
 
-// K1 for a Square layer with a sum pooling behind it: one workgroup per (POOLED ciphertext, i).  Sum_w relin(ct_w) = Sum_w c0_w + Sum_g (Sum_w digit_g(c2'_w)) (*) key_g:
-// the digit polynomials of the window's ciphertexts are added (integers below W 2^dbc) and transformed once -- the same element of Z_q as relinearising every
-// ciphertext and adding the results (evaluator.cpp:934-1069 + poolingLayer.cpp:22-44), hence the same bits, with xo yo / (xd yd) of the transforms, inner products
-// and inverse transforms.  Up to four digits per residue (16-bit digits of a 55..64-bit modulus), two 32-bit fields per register word.
-// ONE: all digit sums of a value in one word -- fields of F = dbc + log2 W bits (the top digit of a 55-bit residue has 7 bits: 3 x 18 + 9 = 63 bits for a 2 x 2 window) --
-// so the window's sums take the registers the unpooled kernel spends on its one source row; otherwise two words of two 32-bit fields each
+// K1 for a Square layer with a sum pooling behind it: one workgroup per (POOLED ciphertext, i).  Sum_w relin(ct_w) = Sum_w c0_w + Sum_g (Sum_w digit_g(c2'_w))
+// (*) key_g: the digit polynomials of the window's ciphertexts are added (integers below W 2^dbc) and transformed once -- the same element of Z_q as
+// relinearising every ciphertext and adding the results (evaluator.cpp:934-1069 + poolingLayer.cpp:22-44), hence the same bits, with xo yo / (xd yd) of the
+// transforms, inner products and inverse transforms.  Up to four digits per residue (16-bit digits of a 55..64-bit modulus), two 32-bit fields per register
+// word. ONE: all digit sums of a value in one word -- fields of F = dbc + log2 W bits (the top digit of a 55-bit residue has 7 bits: 3 x 18 + 9 = 63 bits for a
+// 2 x 2 window) -- so the window's sums take the registers the unpooled kernel spends on its one source row; otherwise two words of two 32-bit fields each
 template <int RB, int NPT, bool ONE>
-__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_digits_pool_f64_kernel(const u64 *src, int src_size, int src_poly, double *E, const double *Wf, F64Params fp, int n, int logn,
-                                                                                                              int k, int D, int dbc, Relin64Tab tab, PoolGeom pg, int F)
+__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_digits_pool_f64_kernel(const u64 *src, int src_size, int src_poly, double *E,
+    const double *Wf, F64Params fp, int n, int logn,
+                                                                                                              int k, int D, int dbc, Relin64Tab tab,
+                                                                                                                  PoolGeom pg, int F)
 {
     extern __shared__ double smd[];
     const size_t o = blockIdx.x / k; const int i = blockIdx.x % k;
@@ -127,8 +135,10 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_digits_pool_f64
                 const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(row + s);
                 if (ONE) { lo[2 * u] += spread(v.x); lo[2 * u + 1] += spread(v.y); }
                 else {
-                    lo[2 * u] += (v.x & mask) | (((v.x >> dbc) & mask) << 32);          hi[(2 * u) % (ONE ? 2 : NPT)] += ((v.x >> (2 * dbc)) & mask) | (((v.x >> (3 * dbc)) & mask) << 32);
-                    lo[2 * u + 1] += (v.y & mask) | (((v.y >> dbc) & mask) << 32);      hi[(2 * u + 1) % (ONE ? 2 : NPT)] += ((v.y >> (2 * dbc)) & mask) | (((v.y >> (3 * dbc)) & mask) << 32);
+                    lo[2 * u] += (v.x & mask) | (((v.x >> dbc) & mask) << 32);          hi[(2 * u) % (ONE ? 2 :
+                        NPT)] += ((v.x >> (2 * dbc)) & mask) | (((v.x >> (3 * dbc)) & mask) << 32);
+                    lo[2 * u + 1] += (v.y & mask) | (((v.y >> dbc) & mask) << 32);      hi[(2 * u + 1) % (ONE ? 2 :
+                        NPT)] += ((v.y >> (2 * dbc)) & mask) | (((v.y >> (3 * dbc)) & mask) << 32);
                 }
             }
         }
@@ -156,18 +166,20 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_digits_pool_f64
     }
 }
 
-// ---- K2: slot-wise inner products ------------------------------------------------------------------------------------------------------------------------------------
-// A[ct][pj][m][s] = sum_g Kf[g][pj][m][s] E[ct][g][m][s]: every product reduced below 0.875 p, the sum of D <= 48 of them stays below 2^53 (exact); CT ciphertexts share
-// every key value a thread loads
-// A thread owns one slot of one prime for CT ciphertexts x PJ of the 2k key columns (PJS = 2k / PJ thread groups share the E values through L2): per digit CT + PJ
-// loads feed CT PJ products -- the kernel is bound by L2 bandwidth on the key and digit values, not by the 7 flops per product
+// ---- K2: slot-wise inner products
+// ------------------------------------------------------------------------------------------------------------------------------------ A[ct][pj][m][s] = sum_g
+// Kf[g][pj][m][s] E[ct][g][m][s]: every product reduced below 0.875 p, the sum of D <= 48 of them stays below 2^53 (exact); CT ciphertexts share every key
+// value a thread loads A thread owns one slot of one prime for CT ciphertexts x PJ of the 2k key columns (PJS = 2k / PJ thread groups share the E values
+// through L2): per digit CT + PJ loads feed CT PJ products -- the kernel is bound by L2 bandwidth on the key and digit values, not by the 7 flops per product
 template <int K, int CT, int PJ>
-__global__ void __launch_bounds__(256) relin_mac_f64_kernel(const double *E, const double *Kf, double *A, F64Params fp, int n, int D, size_t cnt)
+__global__ void __launch_bounds__(256, CT * PJ <= 36 ? 4 : 1) relin_mac_f64_kernel(const double *E, const double *Kf, double *A, F64Params fp, int n, int D,
+    size_t cnt)
 {
     constexpr int PJS = 2 * K / PJ;
     const int sblocks = n / blockDim.x;
-    // ciphertext group fastest: the workgroups that are resident together work on the SAME key tile (D x PJ values for 256 slots, 0.1-0.5 MiB: one L2 fill per XCD)
-    // and stream only their own digit values -- with the slot block fastest every ciphertext group pulled the whole key set (9-17 MB, more than an L2) again
+    // ciphertext group fastest: the workgroups that are resident together work on the SAME key tile (D x PJ values for 256 slots, 0.1-0.5 MiB: one L2 fill per
+    // XCD) and stream only their own digit values -- with the slot block fastest every ciphertext group pulled the whole key set (9-17 MB, more than an L2)
+    // again
     const unsigned groups = (unsigned)((cnt + CT - 1) / CT);
     unsigned b = blockIdx.x;
     const size_t ct0 = (size_t)(b % groups) * CT; b /= groups;
@@ -181,16 +193,30 @@ __global__ void __launch_bounds__(256) relin_mac_f64_kernel(const double *E, con
 #pragma unroll
         for (int pj = 0; pj < PJ; pj++) acc[c][pj] = 0.0;
     const size_t nn = (size_t)n;
-    for (int g = 0; g < D; g++) {
-        double e[CT];
+    // (round 5) the digit values of g + 1 -- the operand that comes from HBM; the key tile is L2-resident -- are requested before the CT x PJ products of digit
+    // g are formed: the kernel waits on memory half of its time (profiles/r05_pmc_square_pool_8192_issue.json) and every iteration started with an exposed
+    // round trip
+    constexpr bool AHEAD = CT * PJ <= 36;                 // (the wider tiles have no registers to spare)
+    double e[CT];
+    auto fetch = [&](int g, double (&ev)[CT]) {
 #pragma unroll
-        for (int c = 0; c < CT; c++) e[c] = ct0 + c < cnt ? E[(((ct0 + c) * D + g) * CRC_NF64 + m) * nn + s] : 0.0;
+        for (int c = 0; c < CT; c++) ev[c] = ct0 + c < cnt ? E[(((ct0 + c) * D + g) * CRC_NF64 + m) * nn + s] : 0.0;
+    };
+    fetch(0, e);
+    for (int g = 0; g < D; g++) {
+        double en[CT];
+        if (AHEAD && g + 1 < D) fetch(g + 1, en);
         const double *kr = Kf + (((size_t)g * 2 * K + pj0) * CRC_NF64 + m) * nn + s;
 #pragma unroll
         for (int pj = 0; pj < PJ; pj++) {
             const double kv = kr[(size_t)pj * CRC_NF64 * nn];
 #pragma unroll
             for (int c = 0; c < CT; c++) acc[c][pj] += f64_mulmod(kv, e[c], md);
+        }
+        if (g + 1 < D) {
+            if (!AHEAD) fetch(g + 1, en);
+#pragma unroll
+            for (int c = 0; c < CT; c++) e[c] = en[c];
         }
     }
 #pragma unroll
@@ -200,16 +226,19 @@ __global__ void __launch_bounds__(256) relin_mac_f64_kernel(const double *E, con
             for (int pj = 0; pj < PJ; pj++) A[(((ct0 + c) * 2 * K + pj0 + pj) * CRC_NF64 + m) * nn + s] = acc[c][pj];
 }
 
-// ---- K3: inverse transforms, CRT lift, mod q_j, + (c0, c1) -------------------------------------------------------------------------------------------------------------
-// A [ct][poly k + j][m][n]; x3: size-`add_size` ciphertexts whose polys 0, 1 are added (coefficient form); y [ct][2][k][n].  The first prime's result waits in
-// registers (NPT points per thread, reduced) while the image serves the second transform -- round 3 parked it in its own row of A (6 rows written and read back per
-// ciphertext at (8192, 3), and 11 spilled registers: the twiddle companions took the room)
-// Workgroups of n / 16 threads, 16 points each: at n = 8192 two 512-thread workgroups per CU, four waves per SIMD and 128 registers -- with 1024 threads and 8 points
-// the 64-register line of the second workgroup left no room for the held row (18 spilled registers, 16.6 instead of 12.2 MB of traffic per ciphertext and 5.55
-// instead of 5.19 us at (8192, 3): profiles/r04_square_relin_ab_step1.txt)
+// ---- K3: inverse transforms, CRT lift, mod q_j, + (c0, c1)
+// ------------------------------------------------------------------------------------------------------------- A [ct][poly k + j][m][n]; x3: size-`add_size`
+// ciphertexts whose polys 0, 1 are added (coefficient form); y [ct][2][k][n].  The first prime's result waits in registers (NPT points per thread, reduced)
+// while the image serves the second transform -- round 3 parked it in its own row of A (6 rows written and read back per ciphertext at (8192, 3), and 11
+// spilled registers: the twiddle companions took the room) Workgroups of n / 16 threads, 16 points each: at n = 8192 two 512-thread workgroups per CU, four
+// waves per SIMD and 128 registers -- with 1024 threads and 8 points the 64-register line of the second workgroup left no room for the held row (18 spilled
+// registers, 16.6 instead of 12.2 MB of traffic per ciphertext and 5.55 instead of 5.19 us at (8192, 3): profiles/r04_square_relin_ab_step1.txt)
 template <int RB, int NPT, bool OUT_NTT, bool LAZY>
-__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_inv_crt_kernel(const double *A, const u64 *x3, int add_size, u64 *y, const ModParams *mods, const double *Wi,
-                                                                                                                     const ulonglong2 *Wq, F64Params fp, int n, int logn, int k, const u64 *mul, PoolGeom pg)
+__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_inv_crt_kernel(const double *A, const u64 *x3, int add_size, u64 *y, const ModParams *mods,
+    const double *Wi,
+                                                                                                                     const ulonglong2 *Wq, F64Params fp,
+                                                                                                                         int n, int logn, int k,
+                                                                                                                         const u64 *mul, PoolGeom pg)
 {
     extern __shared__ double smd[];
     const size_t ct = blockIdx.x / (2 * k); const int pj = blockIdx.x % (2 * k), poly = pj / k, j = pj % k;
@@ -234,7 +263,8 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_inv_crt_kernel(
     // x = a0 + p0 t,  t = (a1 - a0) p0^-1 mod p1 centred: |x| < p0 p1 / 2, and the true value is below a quarter of that, so t is nowhere near +- p1 / 2
     const ModParams mq = mods[j];
     const u64 q = mq.q, p0q = fp.p0_mod_q[j];
-    // pooled key switch (pg.xf > 0): `ct` counts pooled ciphertexts and the (c0, c1) of the window's ciphertexts in x3 are added up here -- no pooling pass, no pooled copy
+    // pooled key switch (pg.xf > 0): `ct` counts pooled ciphertexts and the (c0, c1) of the window's ciphertexts in x3 are added up here -- no pooling pass, no
+    // pooled copy
     size_t actw = ct;
     if (pg.xf > 0) {
         const size_t per = (size_t)pg.xo * pg.yo, plane = ct / per; const int rem = (int)(ct % per), ox = rem / pg.yo, oy = rem % pg.yo;
@@ -276,18 +306,21 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_inv_crt_kernel(
         }
     }
     if (!OUT_NTT) return;
-    // NTT-resident result: forward transform over q_j of (c_poly + R) in the same LDS image, same layout (ntt_device.h's radix-8 passes on the fp64 image's swizzle)
+    // NTT-resident result: forward transform over q_j of (c_poly + R) in the same LDS image, same layout (ntt_device.h's radix-8 passes on the fp64 image's
+    // swizzle)
     __syncthreads();
     ntt_row_passes<false, LAZY, RB, true>(sm, Wq + (size_t)j * n, n, logn, q, mq.two_q);
     const float rq = 1.0f / (float)((u32)(q >> 32) + 1);
-    const bool fuse1 = ntt_fused_stage(logn);                  // (the gap-1 stage of the forward transform is applied here, while the image is drained: ntt_device.h)
+    // (the gap-1 stage of the forward transform is applied here, while the image is drained: ntt_device.h)
+    const bool fuse1 = ntt_fused_stage(logn);
     for (int s = 2 * tid; s < n; s += 2 * nt) {
         const int a = swz<RB>(s);
         ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(sm + (a & ~1));
         if (a & 1) { const u64 t = v.x; v.x = v.y; v.y = t; }
         if (fuse1) fwd_pair_stage<LAZY>(v, Wq[(size_t)j * n + (n >> 1) + (s >> 1)], q, mq.two_q);
         if (LAZY) { v.x = reduce_small(v.x, q, mq.two_q, rq); v.y = reduce_small(v.y, q, mq.two_q, rq); }
-        else { v.x = v.x >= mq.two_q ? v.x - mq.two_q : v.x; v.x = v.x >= q ? v.x - q : v.x; v.y = v.y >= mq.two_q ? v.y - mq.two_q : v.y; v.y = v.y >= q ? v.y - q : v.y; }
+        else { v.x = v.x >= mq.two_q ? v.x - mq.two_q : v.x; v.x = v.x >= q ? v.x - q : v.x; v.y = v.y >= mq.two_q ? v.y - mq.two_q : v.y;
+            v.y = v.y >= q ? v.y - q : v.y; }
         if (mul) {          // the divisor of an average pooling behind the Square layer (an NTT-form plaintext [k][n]): slot-wise, while the result leaves
             const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(mul + (size_t)j * n + s);
             v.x = mulmod(v.x, w.x, mq); v.y = mulmod(v.y, w.y, mq);
@@ -296,9 +329,10 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_inv_crt_kernel(
     }
 }
 
-// ---- host side ------------------------------------------------------------------------------------------------------------------------------------------------------------
-// can this context / key set take the fp64 path?  2 |R_j| <= n D 2^dbc q_max must stay below p_0 p_1 / 2 (a factor 2 of slack for the floating CRT), the row must fit
-// the LDS image the transforms work on, and at most 48 products may be summed lazily
+// ---- host side
+// ------------------------------------------------------------------------------------------------------------------------------------------------------------
+// can this context / key set take the fp64 path?  2 |R_j| <= n D 2^dbc q_max must stay below p_0 p_1 / 2 (a factor 2 of slack for the floating CRT), the row
+// must fit the LDS image the transforms work on, and at most 48 products may be summed lazily
 bool k_relin64_supported(const crc_ctx *c, int dbc)
 {
     if (c->n < 64 || c->n > 16384 || dbc < 1 || dbc > 32) return false;
@@ -314,11 +348,12 @@ bool k_relin64_pool_supported(const crc_ctx *c, int dbc, int window)
 {
     if (!k_relin64_supported(c, dbc) || window < 1 || window > 64 || dbc > 20) return false;
     int D = 0, qbits = 0;
-    for (int i = 0; i < c->k; i++) { const int L = evk_digits(c->q[i], dbc); if (L > 4) return false; D += L; if ((int)c->tabs[i].m.bits > qbits) qbits = c->tabs[i].m.bits; }
+    for (int i = 0; i < c->k; i++) { const int L = evk_digits(c->q[i], dbc); if (L > 4) return false; D += L;
+        if ((int)c->tabs[i].m.bits > qbits) qbits = c->tabs[i].m.bits; }
     int dbits = 0; while ((1 << dbits) < D) dbits++;
     int wbits = 0; while ((1 << wbits) < window) wbits++;
-    // 2 |R| <= n D W 2^dbc q_max <= 2^92 leaves |R| <= 2^91 < p_0 p_1 / 2 / 3.9: the CRT's t = (a1 - a0) p_0^-1 mod p_1 stays below p_1 / 3.9 in magnitude, well inside
-    // the centred range it is reduced to (the unpooled test keeps one bit more; this one admits n = 16384 with all eight primes, D = 32, W = 4)
+    // 2 |R| <= n D W 2^dbc q_max <= 2^92 leaves |R| <= 2^91 < p_0 p_1 / 2 / 3.9: the CRT's t = (a1 - a0) p_0^-1 mod p_1 stays below p_1 / 3.9 in magnitude,
+    // well inside the centred range it is reduced to (the unpooled test keeps one bit more; this one admits n = 16384 with all eight primes, D = 32, W = 4)
     return c->logn + dbits + wbits + dbc + qbits <= 2 * CRC_F64_PRIME_BITS - 2;
 }
 size_t k_relin64_keys_words(const crc_ctx *c, int dbc) { return (size_t)CRC_NF64 * crc_evk_words(c, dbc); }
@@ -332,13 +367,16 @@ size_t k_relin64_work_words(const crc_ctx *c, size_t cnt, int dbc)
 }
 
 // threads per workgroup for passes of 2^RB values per thread
-static int f64_threads(const crc_ctx *c, int RB) { int nt = c->n >> RB; if (nt < 64) nt = 64; if (nt > (RB == 5 ? 512 : 1024)) nt = RB == 5 ? 512 : 1024; return nt; }
-// 3 stages (8 values per thread) per LDS pass by default: measured on (8192, 3) the digit kernel runs 0.90 / 1.08 / 1.34 us per ciphertext with 3 / 4 / 5 -- the wider
-// passes save LDS round trips and barriers but cost occupancy (76 / 134 registers), and the kernel is bound by instruction issue, not by LDS (profiles/r03_square_relin.txt)
+static int f64_threads(const crc_ctx *c, int RB) { int nt = c->n >> RB; if (nt < 64) nt = 64; if (nt > (RB == 5 ? 512 : 1024)) nt = RB == 5 ? 512 : 1024;
+    return nt; }
+// 3 stages (8 values per thread) per LDS pass by default: measured on (8192, 3) the digit kernel runs 0.90 / 1.08 / 1.34 us per ciphertext with 3 / 4 / 5 --
+// the wider passes save LDS round trips and barriers but cost occupancy (76 / 134 registers), and the kernel is bound by instruction issue, not by LDS
+// (profiles/r03_square_relin.txt)
 static int f64_radix(const crc_ctx *c) { const int r = c->tune.f64_radix; return r >= 3 && r <= 5 ? r : 3; }
 // threads of the kernels that keep a row in registers
 // (16 points per thread at radix 8 and 16, 32 at radix 32: n / 16 threads, at least a wave, at most 1024)
-static int f64_hold_threads(const crc_ctx *c, int RB) { int nt = c->n >> (RB == 5 ? 5 : 4); if (nt < 64) nt = 64; if (nt > (RB == 5 ? 512 : 1024)) nt = RB == 5 ? 512 : 1024; return nt; }
+static int f64_hold_threads(const crc_ctx *c, int RB) { int nt = c->n >> (RB == 5 ? 5 : 4); if (nt < 64) nt = 64;
+    if (nt > (RB == 5 ? 512 : 1024)) nt = RB == 5 ? 512 : 1024; return nt; }
 
 // kp: k_relin64_keys_words; scratch: crc_evk_words (k_relin64_work_words covers it)
 int k_relin64_prepare_keys(crc_ctx *c, const u64 *evk, int dbc, u64 *kp, u64 *scratch, hipStream_t st)
@@ -354,7 +392,8 @@ int k_relin64_prepare_keys(crc_ctx *c, const u64 *evk, int dbc, u64 *kp, u64 *sc
     const int RB = f64_radix(c);
     auto kern = RB == 3 ? relin_keys_f64_kernel<3> : RB == 4 ? relin_keys_f64_kernel<4> : relin_keys_f64_kernel<5>;
     { const int r2 = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (r2) return r2; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(rows * CRC_NF64)), dim3(f64_threads(c, RB)), lds, st, scratch, Kf, c->d_mods, c->d_f64_rp, c->f64, c->n, c->logn, c->k);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(rows * CRC_NF64)), dim3(f64_threads(c, RB)), lds, st, scratch, Kf, c->d_mods, c->d_f64_rp, c->f64, c->n, c->logn,
+        c->k);
     HIPCHK(hipGetLastError());
     return CRC_OK;
 }
@@ -363,22 +402,26 @@ template <int K, int BIGCT = 4>
 static int relin64_mac(crc_ctx *c, const double *E, const double *Kf, double *A, int D, size_t cnt, hipStream_t st)
 {
     // accumulators: CT x PJ doubles per thread (32..48)
-    constexpr int PJ = 2 * K <= 8 ? 2 * K : (2 * K) % 8 == 0 ? 8 : (2 * K) % 6 == 0 ? 6 : (2 * K) % 5 == 0 ? 5 : 7, CT = PJ <= 4 ? 8 : PJ <= 6 ? 6 : BIGCT, PJS = 2 * K / PJ;
+    constexpr int PJ = 2 * K <= 8 ? 2 * K : (2 * K) % 8 == 0 ? 8 : (2 * K) % 6 == 0 ? 6 : (2 * K) % 5 == 0 ? 5 : 7, CT = PJ <= 4 ? 8 : PJ <= 6 ? 6 : BIGCT,
+        PJS = 2 * K / PJ;
     static_assert(PJ * PJS == 2 * K, "key columns must split evenly");
     const int threads = c->n < 256 ? c->n : 256, sblocks = c->n / threads;
     const size_t groups = (cnt + CT - 1) / CT;
-    hipLaunchKernelGGL((relin_mac_f64_kernel<K, CT, PJ>), dim3((unsigned)(groups * CRC_NF64 * PJS * sblocks)), dim3(threads), 0, st, E, Kf, A, c->f64, c->n, D, cnt);
+    hipLaunchKernelGGL((relin_mac_f64_kernel<K, CT, PJ>), dim3((unsigned)(groups * CRC_NF64 * PJS * sblocks)), dim3(threads), 0, st, E, Kf, A, c->f64, c->n,
+        D, cnt);
     HIPCHK(hipGetLastError());
     return CRC_OK;
 }
 
 template <int RB, int NPT>
-static int relin64_tail(crc_ctx *c, const double *A, const u64 *x3, int add_size, u64 *y, size_t cnt, bool out_ntt, hipStream_t st, const u64 *mul, const PoolGeom *pool)
+static int relin64_tail(crc_ctx *c, const double *A, const u64 *x3, int add_size, u64 *y, size_t cnt, bool out_ntt, hipStream_t st, const u64 *mul,
+    const PoolGeom *pool)
 {
     bool lazy = true;
     for (int i = 0; i < c->k; i++) if (c->tabs[i].m.bits > 57 || c->tabs[i].m.bits < 45) lazy = false;
     const size_t lds = (size_t)c->n * 8;
-    auto kern = !out_ntt ? relin_inv_crt_kernel<RB, NPT, false, false> : lazy ? relin_inv_crt_kernel<RB, NPT, true, true> : relin_inv_crt_kernel<RB, NPT, true, false>;
+    auto kern = !out_ntt ? relin_inv_crt_kernel<RB, NPT, false, false> : lazy ? relin_inv_crt_kernel<RB, NPT, true, true> : relin_inv_crt_kernel<RB, NPT,
+        true, false>;
     { const int rc = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (rc) return rc; }
     hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * 2 * c->k)), dim3(f64_hold_threads(c, RB)), lds, st, A, x3, add_size, y, c->d_mods, c->d_f64_irp,
                        reinterpret_cast<const ulonglong2 *>(c->d_rp), c->f64, c->n, c->logn, c->k, mul, pool ? *pool : PoolGeom{0, 0, 0, 0, 0, 0, 0, 0});
@@ -386,14 +429,15 @@ static int relin64_tail(crc_ctx *c, const double *A, const u64 *x3, int add_size
     return CRC_OK;
 }
 
-// src / src_size / src_poly: where c2 (q/q_i)^-1 lives; x3 / add_size: the ciphertexts whose (c0, c1) are added; kp: the keys as k_relin64_prepare_keys left them;
-// work: cnt n (2 D + 4 k) words
+// src / src_size / src_poly: where c2 (q/q_i)^-1 lives; x3 / add_size: the ciphertexts whose (c0, c1) are added; kp: the keys as k_relin64_prepare_keys left
+// them; work: cnt n (2 D + 4 k) words
 int k_relinearize64(crc_ctx *c, const u64 *src, int src_size, int src_poly, const u64 *x3, int add_size, size_t cnt, int dbc, u64 *y, u64 *work, const u64 *kp,
                     hipStream_t st, bool out_ntt, const PoolGeom *pool, const u64 *mul)
 {
     if (cnt == 0) return CRC_OK;
     if (!k_relin64_supported(c, dbc)) return CRC_ERR_UNSUPPORTED;
-    if (pool && !k_relin64_pool_supported(c, dbc, pool->xf * pool->yf)) return CRC_ERR_UNSUPPORTED;      // (cnt counts POOLED ciphertexts then; src holds the unpooled ones)
+    // (cnt counts POOLED ciphertexts then; src holds the unpooled ones)
+    if (pool && !k_relin64_pool_supported(c, dbc, pool->xf * pool->yf)) return CRC_ERR_UNSUPPORTED;
     const size_t n = c->n, k = c->k;
     Relin64Tab tab{};
     int D = 0;
@@ -404,21 +448,25 @@ int k_relinearize64(crc_ctx *c, const u64 *src, int src_size, int src_poly, cons
     const size_t lds = n * 8;
     const int RB = f64_radix(c);
     if (pool) {
-        // all digit sums of a value in one word when they fit: fields of F = dbc + log2 W bits, the top digit of residue i has bits_i - (L_i - 1) dbc (+ log2 W) bits
+        // all digit sums of a value in one word when they fit: fields of F = dbc + log2 W bits, the top digit of residue i has bits_i - (L_i - 1) dbc (+ log2
+        // W) bits
         int wbits = 0; while ((1 << wbits) < pool->xf * pool->yf) wbits++;
         const int F = dbc + wbits;
         bool one = true;
-        for (int i = 0; i < c->k; i++) { const int L = tab.L[i]; if ((L - 1) * F + ((int)c->tabs[i].m.bits - (L - 1) * dbc + wbits) > 64 || F > 32) one = false; }
+        for (int i = 0; i < c->k; i++) { const int L = tab.L[i]; if ((L - 1) * F + ((int)c->tabs[i].m.bits - (L - 1) * dbc + wbits) > 64 || F > 32) one =
+            false; }
         auto kern = RB == 3 ? (one ? relin_digits_pool_f64_kernel<3, 16, true> : relin_digits_pool_f64_kernel<3, 16, false>)
                   : RB == 4 ? (one ? relin_digits_pool_f64_kernel<4, 16, true> : relin_digits_pool_f64_kernel<4, 16, false>)
                             : (one ? relin_digits_pool_f64_kernel<5, 32, true> : relin_digits_pool_f64_kernel<5, 32, false>);
         const int r2 = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (r2) return r2;
-        hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * k)), dim3(f64_hold_threads(c, RB)), lds, st, src, src_size, src_poly, E, c->d_f64_rp, c->f64, c->n, c->logn, c->k, D, dbc, tab, *pool, F);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * k)), dim3(f64_hold_threads(c, RB)), lds, st, src, src_size, src_poly, E, c->d_f64_rp, c->f64, c->n,
+            c->logn, c->k, D, dbc, tab, *pool, F);
         HIPCHK(hipGetLastError());
     } else {
         auto kern = RB == 3 ? relin_digits_f64_kernel<3, 16> : RB == 4 ? relin_digits_f64_kernel<4, 16> : relin_digits_f64_kernel<5, 32>;
         const int r2 = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (r2) return r2;
-        hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * k)), dim3(f64_hold_threads(c, RB)), lds, st, src, src_size, src_poly, E, c->d_f64_rp, c->f64, c->n, c->logn, c->k, D, dbc, tab);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * k)), dim3(f64_hold_threads(c, RB)), lds, st, src, src_size, src_poly, E, c->d_f64_rp, c->f64, c->n,
+            c->logn, c->k, D, dbc, tab);
         HIPCHK(hipGetLastError());
     }
     switch (c->k) {
@@ -431,5 +479,6 @@ int k_relinearize64(crc_ctx *c, const u64 *src, int src_size, int src_poly, cons
     if (mul && !out_ntt) return CRC_ERR_INVALID_ARGUMENT;
     // (pooled: x3 / add_size are the UNPOOLED ciphertexts whose (c0, c1) K3 adds up window by window)
     return RB == 3 ? relin64_tail<3, 16>(c, A, x3, add_size, y, cnt, out_ntt, st, mul, pool)
-         : RB == 4 ? relin64_tail<4, 16>(c, A, x3, add_size, y, cnt, out_ntt, st, mul, pool) : relin64_tail<5, 32>(c, A, x3, add_size, y, cnt, out_ntt, st, mul, pool);
+         : RB == 4 ? relin64_tail<4, 16>(c, A, x3, add_size, y, cnt, out_ntt, st, mul, pool) : relin64_tail<5, 32>(c, A, x3, add_size, y, cnt, out_ntt, st,
+             mul, pool);
 }

@@ -4,15 +4,18 @@
 // BEHZ carries the tensor product in TWO bases: q (the coefficient moduli) and an auxiliary base B U {m_sk} that only has to be large enough to hold the integers
 //     c' = (S + q r) / m~  (|c'| < q (1 + k 2^-32)),   P = c'_a (*) c'_b   (|P| <= 2 n q^2),   R = (t P - fastbconv_q(t P)) / q   (|R| <= 2 n t q + k)
 // exactly: fastbconv_q's sums S are integers that do not depend on where they are reduced, and fastbconv_sk returns R mod q_i exactly as soon as
-// |R| / B + #B + 1 < m_sk / 2.  The reference takes k (+1) 61-bit primes and a 61-bit m_sk; ANY base of that size gives the same R, hence the same residues mod q_i
-// (tests: the oracle's restatement with SEAL's base, and every golden of the reference itself).  The engine takes kf of its own 47-bit fp64 primes (ctx.h Sq64Params:
-// the fewest with prod p_j >= 4 n t q): 5 instead of 4 rows per polynomial at (8192, k = 3), 6 instead of 5 at (16384, 4), 11 instead of 9 at (16384, 8) -- but a row
-// transform in 6-flop fp64 arithmetic costs half of one over a 61-bit modulus, which has no lazy form (profiles/r03_square_relin_*: 0.041 against 0.069-0.088 us per
-// row at n = 8192, 0.090 against 0.16-0.21 at 16384).  The q half (dyadic products and inverse transforms over the coefficient moduli) stays in kernels.hip.
+// |R| / B + #B + 1 < m_sk / 2.  The reference takes k (+1) 61-bit primes and a 61-bit m_sk; ANY base of that size gives the same R, hence the same residues mod
+// q_i (tests: the oracle's restatement with SEAL's base, and every golden of the reference itself).  The engine takes kf of its own 47-bit fp64 primes (ctx.h
+// Sq64Params: the fewest with prod p_j >= 4 n t q): 5 instead of 4 rows per polynomial at (8192, k = 3), 6 instead of 5 at (16384, 4), 11 instead of 9 at
+// (16384, 8) -- but a row transform in 6-flop fp64 arithmetic costs half of one over a 61-bit modulus, which has no lazy form (profiles/r03_square_relin_*:
+// 0.041 against 0.069-0.088 us per row at n = 8192, 0.090 against 0.16-0.21 at 16384).  The q half (dyadic products and inverse transforms over the coefficient
+// moduli) stays in kernels.hip.
 //   sq64_lift_kernel  : q -> {p_j}: fastbconv_mtilde + mont_rq, residues written as centred doubles                                  LB [ct][2][kf][n]
 //   sq64_fwd_kernel   : forward transform of every LB row in place
-//   sq64_liftfwd_kernel (round 4, NTT-resident callers): the two above in one -- the inverse transform that brings x to coefficient form leaves it multiplied by
-//                       m~ (q/q_i)^-1 (NttArgs prologue 5), and the forward transform under p_j lifts its row while it stages it: the kf workgroups of a polynomial
+//   sq64_liftfwd_kernel (round 4, NTT-resident callers): the two above in one -- the inverse transform that brings x to coefficient form leaves it multiplied
+//   by
+//                       m~ (q/q_i)^-1 (NttArgs prologue 5), and the forward transform under p_j lifts its row while it stages it: the kf workgroups of a
+//                       polynomial
 //                       share their k source rows through one XCD's L2, LB is written once and never read back untransformed (-20 of 260 row transfers per
 //                       ciphertext at (8192, 3), one kernel less)
 //   sq64_inv_kernel   : a^2, 2ab, b^2 formed while a row is staged, inverse transform (unscaled: n^-1 sits in floor_x)                   DB [ct][3][kf][n]
@@ -20,7 +23,8 @@
 #include "kernels.h"
 #include "ntt_f64.h"
 
-// every (k, kf) a context can have is not known at compile time (kf depends on t): instances for k = 1..8 with the kf range 3..12 the size rule can produce for 40-60-bit q_i
+// every (k, kf) a context can have is not known at compile time (kf depends on t): instances for k = 1..8 with the kf range 3..12 the size rule can produce for
+// 40-60-bit q_i
 #define CRC_FOR_ALL_K_KF(X) \
     X(1, 3) X(1, 4) X(2, 3) X(2, 4) X(2, 5) X(3, 4) X(3, 5) X(3, 6) X(4, 5) X(4, 6) X(4, 7) X(5, 6) X(5, 7) X(5, 8) X(5, 9) X(6, 7) X(6, 8) X(6, 9) X(6, 10) \
     X(7, 8) X(7, 9) X(7, 10) X(7, 11) X(8, 9) X(8, 10) X(8, 11) X(8, 12)
@@ -39,7 +43,8 @@ __device__ __forceinline__ double mul_split(double hi, double lo, const double *
 }
 }
 
-// x: [count][2][K][n] coefficient form over q  ->  out: [count][2][KF][n] doubles, |.| <= (p_j + 1) / 2.  Two neighbouring coefficients per thread: 16-byte loads and stores
+// x: [count][2][K][n] coefficient form over q  ->  out: [count][2][KF][n] doubles, |.| <= (p_j + 1) / 2.  Two neighbouring coefficients per thread: 16-byte
+// loads and stores
 template <int K, int KF>
 __global__ void __launch_bounds__(256) sq64_lift_kernel(const u64 *x, double *out, const ModParams *mods, const BehzParams *bp, const Sq64Params *sp, int n)
 {
@@ -84,14 +89,16 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024) sq64_fwd_kernel(double *
     for (int s = 2 * threadIdx.x; s < n; s += 2 * blockDim.x) { const d2 v = *reinterpret_cast<const d2 *>(row + s); sm_store_pair<RB>(smd, s, v.x, v.y); }
     __syncthreads();
     ntt_row_passes_f64<false, RB>(smd, Wf + (size_t)j * n, n, logn, md);
-    f64_drain<false, RB, 4>(smd, Wf + (size_t)j * n, n, logn, md, [&](int s, d2 v) { *reinterpret_cast<d2 *>(row + s) = d2{f64_reduce(v.x, md), f64_reduce(v.y, md)}; });
+    f64_drain<false, RB, 4>(smd, Wf + (size_t)j * n, n, logn, md, [&](int s, d2 v) { *reinterpret_cast<d2 *>(row + s) = d2{f64_reduce(v.x, md),
+        f64_reduce(v.y, md)}; });
 }
 
-// tr: [count][2][K][n] = x m~ (q/q_i)^-1 mod q_i in coefficient form (k_ntt_ct_inv_scaled)  ->  out [count][2][kf][n]: the lifted polynomial under p_j, transformed, reduced.
-// One workgroup per (polynomial, prime); the kf workgroups of a polynomial sit on one XCD (xcd_group) and read the same k rows.  The lift is sq64_lift_kernel's
-// (baseconverter.cpp:663-742, 581-622) for ONE target prime, computed while the row is staged into the image
+// tr: [count][2][K][n] = x m~ (q/q_i)^-1 mod q_i in coefficient form (k_ntt_ct_inv_scaled)  ->  out [count][2][kf][n]: the lifted polynomial under p_j,
+// transformed, reduced. One workgroup per (polynomial, prime); the kf workgroups of a polynomial sit on one XCD (xcd_group) and read the same k rows.  The lift
+// is sq64_lift_kernel's (baseconverter.cpp:663-742, 581-622) for ONE target prime, computed while the row is staged into the image
 template <int K, int RB>
-__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 ? 8 : 4) sq64_liftfwd_kernel(const u64 *tr, double *out, const double *Wf, const BehzParams *bp, const Sq64Params *sp,
+__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 ? 8 : 4) sq64_liftfwd_kernel(const u64 *tr, double *out, const double *Wf,
+    const BehzParams *bp, const Sq64Params *sp,
                                                                                            int n, int logn, int kf, size_t polys)
 {
     extern __shared__ double smd[];
@@ -111,7 +118,8 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 ? 8 : 4) sq64_li
             a0 += mul_split((double)(u32)(v.x >> 32), (double)(u32)v.x, f.lift_c[j][i], md.p);
             a1 += mul_split((double)(u32)(v.y >> 32), (double)(u32)v.y, f.lift_c[j][i], md.p);
         }
-        // r = -(x_m~ q^-1) mod m~ in [0, m~): mont_rq :604-612 (not centred in SEAL 2.3.1); (sum_i tr_i (q/q_i) + q r) m~^-1 mod p_j: 2K + 1 products below 0.875 p each
+        // r = -(x_m~ q^-1) mod m~ in [0, m~): mont_rq :604-612 (not centred in SEAL 2.3.1); (sum_i tr_i (q/q_i) + q r) m~^-1 mod p_j: 2K + 1 products below
+        // 0.875 p each
         a0 += f64_mulmod_const((double)(0u - xm0 * iq), f.lift_r[j][0], f.lift_r[j][1], md.p);
         a1 += f64_mulmod_const((double)(0u - xm1 * iq), f.lift_r[j][0], f.lift_r[j][1], md.p);
         sm_store_pair<RB>(smd, s, f64_reduce(a0, md), f64_reduce(a1, md));
@@ -119,14 +127,17 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, RB == 3 ? 8 : 4) sq64_li
     __syncthreads();
     ntt_row_passes_f64<false, RB>(smd, Wf + (size_t)j * n, n, logn, md);
     double *row = out + (poly * kf + j) * (size_t)n;
-    f64_drain<false, RB, 4>(smd, Wf + (size_t)j * n, n, logn, md, [&](int s, d2 v) { *reinterpret_cast<d2 *>(row + s) = d2{f64_reduce(v.x, md), f64_reduce(v.y, md)}; });
+    f64_drain<false, RB, 4>(smd, Wf + (size_t)j * n, n, logn, md, [&](int s, d2 v) { *reinterpret_cast<d2 *>(row + s) = d2{f64_reduce(v.x, md),
+        f64_reduce(v.y, md)}; });
 }
 
-// in: [count][2][kf][n] transformed rows (a, b)  ->  out: [count][3][kf][n]: n (a^2, 2ab, b^2) in coefficient form, reduced.  One workgroup per (ciphertext, prime):
-// the three products share the two source rows, each of which is read ONCE and waits in registers (NPT = points per thread) while the transform in front of its
-// second use runs -- round 3 read them again, and by then the L2 had been swept by the other workgroups' rows (20 row reads per ciphertext for 10 rows at (8192, 3))
+// in: [count][2][kf][n] transformed rows (a, b)  ->  out: [count][3][kf][n]: n (a^2, 2ab, b^2) in coefficient form, reduced.  One workgroup per (ciphertext,
+// prime): the three products share the two source rows, each of which is read ONCE and waits in registers (NPT = points per thread) while the transform in
+// front of its second use runs -- round 3 read them again, and by then the L2 had been swept by the other workgroups' rows (20 row reads per ciphertext for 10
+// rows at (8192, 3))
 template <int RB, int NPT>
-__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) sq64_inv_kernel(const double *in, double *out, const double *Wi, const Sq64Params *sp, int n, int logn, int kf)
+__global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) sq64_inv_kernel(const double *in, double *out, const double *Wi, const Sq64Params *sp, int n,
+    int logn, int kf)
 {
     extern __shared__ double smd[];
     const size_t ct = blockIdx.x / kf; const int j = blockIdx.x % kf;
@@ -140,14 +151,16 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) sq64_inv_kernel(const
         __syncthreads();
         ntt_row_passes_f64<true, RB>(smd, W, n, logn, md, false);           // (the image holds reduced products / one fused stage of them: below 1.75 p)
         double *dst = out + ((ct * 3 + o) * kf + j) * (size_t)n;
-        f64_drain<true, RB, NPT / 2>(smd, W, n, logn, md, [&](int s, d2 v) { *reinterpret_cast<d2 *>(dst + s) = d2{f64_reduce(v.x, md), f64_reduce(v.y, md)}; });
+        f64_drain<true, RB, NPT / 2>(smd, W, n, logn, md, [&](int s, d2 v) { *reinterpret_cast<d2 *>(dst + s) = d2{f64_reduce(v.x, md), f64_reduce(v.y,
+            md)}; });
         __syncthreads();
     };
     // a^2 (|.| < 0.875 p: the first pass reduces on load); a stays in r
 #pragma unroll
     for (int u = 0; u < NPT / 2; u++) {
         const int s = 2 * (tid + u * nt);
-        if (s < n) { const d2 v = *reinterpret_cast<const d2 *>(a + s); r[2 * u] = v.x; r[2 * u + 1] = v.y; put(s, f64_mulmod(v.x, v.x, md), f64_mulmod(v.y, v.y, md)); }
+        if (s < n) { const d2 v = *reinterpret_cast<const d2 *>(a + s); r[2 * u] = v.x; r[2 * u + 1] = v.y;
+            put(s, f64_mulmod(v.x, v.x, md), f64_mulmod(v.y, v.y, md)); }
     }
     transform_store(0);
     // 2ab; b replaces a in r
@@ -170,10 +183,12 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) sq64_inv_kernel(const
     transform_store(2);
 }
 
-// dq: [count][3][K][n] u64 (coefficient form over q, scaled), db: [count][3][KF][n] doubles (n times the coefficient, reduced) -> y3: [count][3][K][n].
-// (One coefficient per thread: two, as in the lift kernel, cost more in occupancy than the 16-byte accesses returned -- 0.77 against 0.64 us per ciphertext at (8192, 3))
+// dq: [count][3][K][n] u64 (coefficient form over q, scaled), db: [count][3][KF][n] doubles (n times the coefficient, reduced) -> y3: [count][3][K][n]. (One
+// coefficient per thread: two, as in the lift kernel, cost more in occupancy than the 16-byte accesses returned -- 0.77 against 0.64 us per ciphertext at
+// (8192, 3))
 template <int K, int KF>
-__global__ void __launch_bounds__(256) sq64_floor_kernel(const u64 *dq, const double *db, u64 *y3, const ModParams *mods, const BehzParams *bp, const Sq64Params *sp, int n, int premul_c2)
+__global__ void __launch_bounds__(256) sq64_floor_kernel(const u64 *dq, const double *db, u64 *y3, const ModParams *mods, const BehzParams *bp,
+    const Sq64Params *sp, int n, int premul_c2)
 {
     const BehzParams &b = *bp; const Sq64Params &f = *sp;
     constexpr int KB = KF - 1;
@@ -209,7 +224,8 @@ __global__ void __launch_bounds__(256) sq64_floor_kernel(const u64 *dq, const do
         z[j] = zz;
         v += f64_mulmod_const(zz, f.mhat_msk[j][0], f.mhat_msk[j][1], msk.p);
     }
-    // alpha = (sum_j z_j (B/p_j) - R) / B, from its residue mod m_sk: a small integer (|alpha| <= KB + |R| / B, far inside the centred range), exact in the double
+    // alpha = (sum_j z_j (B/p_j) - R) / B, from its residue mod m_sk: a small integer (|alpha| <= KB + |R| / B, far inside the centred range), exact in the
+    // double
     const double ad = f64_reduce(f64_mulmod_const(f64_reduce(v - fl[KB], msk), f.inv_B_msk[0], f.inv_B_msk[1], msk.p), msk);
     const long long alpha = (long long)ad;
     const bool neg = alpha < 0;
@@ -228,8 +244,10 @@ __global__ void __launch_bounds__(256) sq64_floor_kernel(const u64 *dq, const do
     }
 }
 
-// ---- host side ------------------------------------------------------------------------------------------------------------------------------------------------------------
-static int sq64_threads(const crc_ctx *c, int RB) { int nt = c->n >> RB; if (nt < 64) nt = 64; if (nt > (RB == 5 ? 512 : 1024)) nt = RB == 5 ? 512 : 1024; return nt; }
+// ---- host side
+// ------------------------------------------------------------------------------------------------------------------------------------------------------------
+static int sq64_threads(const crc_ctx *c, int RB) { int nt = c->n >> RB; if (nt < 64) nt = 64; if (nt > (RB == 5 ? 512 : 1024)) nt = RB == 5 ? 512 : 1024;
+    return nt; }
 static int sq64_radix(const crc_ctx *c) { const int r = c->tune.f64_radix; return r >= 3 && r <= 5 ? r : 3; }
 
 bool k_square64_supported(const crc_ctx *c)
@@ -242,7 +260,8 @@ bool k_square64_supported(const crc_ctx *c)
 }
 
 // threads of the kernel that keeps a row in registers: 16 points per thread (32 at radix 32) -- kernels_relin64.hip relin_inv_crt_kernel
-static int sq64_hold_threads(const crc_ctx *c, int RB) { int nt = c->n >> (RB == 5 ? 5 : 4); if (nt < 64) nt = 64; if (nt > (RB == 5 ? 512 : 1024)) nt = RB == 5 ? 512 : 1024; return nt; }
+static int sq64_hold_threads(const crc_ctx *c, int RB) { int nt = c->n >> (RB == 5 ? 5 : 4); if (nt < 64) nt = 64;
+    if (nt > (RB == 5 ? 512 : 1024)) nt = RB == 5 ? 512 : 1024; return nt; }
 
 // work: QN [2k] | LB [2 kf] | DQ [3k] | DB [3 kf]   (k_square_work_words sizes the rows by max(kb, kf))
 int k_square64(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStream_t st, bool in_ntt, bool premul_c2)
@@ -259,9 +278,11 @@ int k_square64(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStre
     const double *Wf = c->d_f64_rp, *Wi = c->d_f64_irp;
     const u64 *xn = QN;
     // (fused up to k = 4: every one of the kf workgroups of a polynomial reads its k source rows, and at k = 8, kf = 11 that costs more than the lift kernel's
-    // round trip -- 35.7 against 34.3 us per ciphertext at (16384, 8), 14.6 against 14.75 at (16384, 4), 5.55 against 5.69 at (8192, 3): profiles/r04_square_relin_ab_step1.txt)
+    // round trip -- 35.7 against 34.3 us per ciphertext at (16384, 8), 14.6 against 14.75 at (16384, 4), 5.55 against 5.69 at (8192, 3):
+    // profiles/r04_square_relin_ab_step1.txt)
     if (in_ntt && (c->tune.sq_fuse < 0 ? c->k <= 4 : c->tune.sq_fuse != 0)) {
-        // NTT-resident caller: the coefficient form exists only for the lift, so it is made premultiplied and lifted inside the forward transforms (sq64_liftfwd_kernel)
+        // NTT-resident caller: the coefficient form exists only for the lift, so it is made premultiplied and lifted inside the forward transforms
+        // (sq64_liftfwd_kernel)
         if ((rc = k_ntt_ct_inv_scaled(c, x, QN, cnt, 2, c->behz.mt_inv_qhat, c->behz.mt_inv_qhat_s, st))) return rc;
         xn = x;
         bool launched = false;

@@ -6,9 +6,9 @@
 
 typedef double2 d2;
 
-// Two neighbouring points of a row (even s, s + 1) sit in ONE aligned 16-byte slot of the swizzled image -- every swizzle only XORs higher index bits into bit 0 -- in
-// either order: rows move between memory and the image in 16-byte pieces per lane (one global access and one ds_*_b128 for two points; 8-byte accesses ran the base
-// conversion kernels at 2.6 TB/s against 4.1 with 16-byte ones, profiles/r03_square_relin_*)
+// Two neighbouring points of a row (even s, s + 1) sit in ONE aligned 16-byte slot of the swizzled image -- every swizzle only XORs higher index bits into bit
+// 0 -- in either order: rows move between memory and the image in 16-byte pieces per lane (one global access and one ds_*_b128 for two points; 8-byte accesses
+// ran the base conversion kernels at 2.6 TB/s against 4.1 with 16-byte ones, profiles/r03_square_relin_*)
 template <int SW> __device__ __forceinline__ void sm_store_pair(double *sm, int s, double x, double y)
 {
     const int a = swz<SW>(s);
@@ -21,15 +21,16 @@ template <int SW> __device__ __forceinline__ d2 sm_load_pair(const double *sm, i
     return (a & 1) ? d2{v.y, v.x} : v;
 }
 
-// ---- fp64 butterflies (the index arithmetic of ntt_device.h's fwd_stages / inv_stages; arithmetic of f64mod.h) ---------------------------------------------------
-// forward: values grow by at most 0.875 p per stage: 16-bit inputs stay below 14 p < 2^51 through 15 stages -- no reduction anywhere
-// The 2^R - 1 twiddles of a thread's R stages are fetched up front (tw[(1 << st) - 1 + j] = twiddle j of stage st), in front of the LDS reads of the pass: one
-// exposed memory latency per pass instead of one per stage (the compiler keeps loads where they are written and waits right in front of the first use)
-// A twiddle is ONE double (the centred power of psi): the quotient of a butterfly product is estimated from the product itself (f64_mulmod: fl(h / p) instead of
-// y (w / p) -- the same six flops, one more link in the dependency chain), not from a precomputed companion w / p.  Half the table bytes and, what matters more,
-// 7 instead of 14 live twiddle registers per radix-8 pass: every transform kernel sits at the 64-register line of two 1024-thread workgroups per CU, and the registers
-// returned hold a row across its transforms (relinearisation's source row, the square's a / b rows, the first prime's result in front of the CRT step) instead of
-// re-reading it from memory or parking it there (round 3: 17 + 10 + 12 of 260 row transfers per ciphertext at (8192, 3))
+// ---- fp64 butterflies (the index arithmetic of ntt_device.h's fwd_stages / inv_stages; arithmetic of f64mod.h)
+// --------------------------------------------------- forward: values grow by at most 0.875 p per stage: 16-bit inputs stay below 14 p < 2^51 through 15 stages
+// -- no reduction anywhere The 2^R - 1 twiddles of a thread's R stages are fetched up front (tw[(1 << st) - 1 + j] = twiddle j of stage st), in front of the
+// LDS reads of the pass: one exposed memory latency per pass instead of one per stage (the compiler keeps loads where they are written and waits right in front
+// of the first use) A twiddle is ONE double (the centred power of psi): the quotient of a butterfly product is estimated from the product itself (f64_mulmod:
+// fl(h / p) instead of y (w / p) -- the same six flops, one more link in the dependency chain), not from a precomputed companion w / p.  Half the table bytes
+// and, what matters more, 7 instead of 14 live twiddle registers per radix-8 pass: every transform kernel sits at the 64-register line of two 1024-thread
+// workgroups per CU, and the registers returned hold a row across its transforms (relinearisation's source row, the square's a / b rows, the first prime's
+// result in front of the CRT step) instead of re-reading it from memory or parking it there (round 3: 17 + 10 + 12 of 260 row transfers per ciphertext at
+// (8192, 3))
 template <int R>
 __device__ __forceinline__ void load_tw_fwd(double (&tw)[(1 << R) - 1], const double *W, int m, int blk)
 {
@@ -60,7 +61,8 @@ __device__ __forceinline__ void fwd_stages_f64(double (&v)[1 << R], const double
         }
     }
 }
-// inverse (Gentleman-Sande, no halving: n^-1 sits in the keys): sums double per stage, so a pass starts from reduced values (|x| <= p/2 -> below 4 p after three stages)
+// inverse (Gentleman-Sande, no halving: n^-1 sits in the keys): sums double per stage, so a pass starts from reduced values (|x| <= p/2 -> below 4 p after
+// three stages)
 template <int R>
 __device__ __forceinline__ void inv_stages_f64(double (&v)[1 << R], const double (&tw)[(1 << R) - 1], const F64Mod md)
 {
@@ -78,11 +80,13 @@ __device__ __forceinline__ void inv_stages_f64(double (&v)[1 << R], const double
 // s = 2^ls: element stride inside a group.  The swizzles are XORs of shifted index bits, i.e. linear over GF(2), and (c << ls) occupies bits that are zero in
 // `base`: swz(base + c s) = swz(base) ^ swz(c s) -- one vector XOR per element against a wave-uniform constant instead of the whole index arithmetic
 //
-// Inverse passes and their reductions (round 5).  A Gentleman-Sande stage leaves a sum (magnitudes add) and a product (back below m = 0.875 p), so after the three
+// Inverse passes and their reductions (round 5).  A Gentleman-Sande stage leaves a sum (magnitudes add) and a product (back below m = 0.875 p), so after the
+// three
 // stages of a radix-8 group whose inputs are bounded by B the outputs are bounded by [8 B, 4 m, 2 m, 2 m, m, m, m, m]: only TWO of the eight values grow.  With
 // B = 1.75 p the largest difference a stage multiplies is 8 B = 14 p < 2^51 (f64_mulmod's operand range) and the largest sum 14 p < 2^53 (exact), and reducing
 // just v[0] and v[1] on the way out restores the bound for the next pass: 6 instead of 24 reduction flops per group (120 -> 102 flops, -14 % measured on the
-// whole transform: tools/f64_row_timeline.hip, profiles/r05_f64_row_timeline.txt).  reduce_in = true keeps the old form (every input reduced on load) for a first
+// whole transform: tools/f64_row_timeline.hip, profiles/r05_f64_row_timeline.txt).  reduce_in = true keeps the old form (every input reduced on load) for a
+// first
 // pass whose inputs may be lazy sums up to 2^52.4 and for the tail passes.
 template <bool INV, int R, int RB>
 __device__ __forceinline__ void ntt_pass_f64(double *sm, const double *W, int n, int ls, int tabidx, const F64Mod md, bool reduce_in)
@@ -113,10 +117,11 @@ __device__ __forceinline__ void ntt_tail_pass_f64(int rem, double *sm, const dou
 }
 // The single leftover stage of a transform whose log2 n is not a multiple of RB plus one... is not a pass: when log2 n = RB m + 1 (n = 8192 at radix 8) the
 // leftover stage is the one with gap 1 -- the last of a forward transform, the first of an inverse one -- and its two points are the two halves of ONE 16-byte
-// slot of the image, i.e. exactly what a lane moves between memory and the image.  The loops that fill and drain the image apply it in registers
-// (f64_stage_in / f64_stage_out below): four LDS passes and barriers per row instead of five.  Twiddle of the pair (s, s + 1): table index n/2 + s/2, both ways.
+// slot of the image, i.e. exactly what a lane moves between memory and the image.  The loops that fill and drain the image apply it in registers (f64_stage_in
+// / f64_stage_out below): four LDS passes and barriers per row instead of five.  Twiddle of the pair (s, s + 1): table index n/2 + s/2, both ways.
 template <int RB> __device__ __forceinline__ bool f64_fused_stage(int logn) { return logn > RB && logn % RB == 1; }
-// what goes INTO the image for points (s, s + 1) holding v.  Inverse with a fused first stage: inputs may be lazy sums below 2^52 -- reduced first, as a pass does on load
+// what goes INTO the image for points (s, s + 1) holding v.  Inverse with a fused first stage: inputs may be lazy sums below 2^52 -- reduced first, as a pass
+// does on load
 template <bool INV, int RB>
 __device__ __forceinline__ d2 f64_stage_in(d2 v, const double *W, int n, int logn, int s, const F64Mod md)
 {
@@ -124,7 +129,8 @@ __device__ __forceinline__ d2 f64_stage_in(d2 v, const double *W, int n, int log
     const double U = f64_reduce(v.x, md), V = f64_reduce(v.y, md);
     return d2{U + V, f64_mulmod(W[(n >> 1) + (s >> 1)], U - V, md)};
 }
-// what comes OUT of the image for points (s, s + 1) holding v (forward with a fused last stage: values below 13 p in, below 14 p out -- unreduced, like a pass leaves them)
+// what comes OUT of the image for points (s, s + 1) holding v (forward with a fused last stage: values below 13 p in, below 14 p out -- unreduced, like a pass
+// leaves them)
 template <bool INV, int RB>
 __device__ __forceinline__ d2 f64_stage_out(d2 v, const double *W, int n, int logn, int s, const F64Mod md)
 {
@@ -134,7 +140,8 @@ __device__ __forceinline__ d2 f64_stage_out(d2 v, const double *W, int n, int lo
 }
 // Draining the image (round 5).  A loop that reads a pair from the image, fetches the fused stage's twiddle, multiplies and stores runs one memory latency per
 // iteration -- a quarter of a whole forward transform in the kernels that keep 16 points per thread (tools/f64_row_timeline.hip: 5200 of 20 400 cycles).  Here
-// the LDS reads and twiddle loads of CH pairs are issued together before the first of them is used.  store(s, v) gets the pair (s, s + 1) after the fused stage.
+// the LDS reads and twiddle loads of CH pairs are issued together before the first of them is used.  store(s, v) gets the pair (s, s + 1) after the fused
+// stage.
 template <bool INV, int RB, int CH, class F>
 __device__ __forceinline__ void f64_drain(const double *sm, const double *W, int n, int logn, const F64Mod md, F &&store)
 {
@@ -181,11 +188,11 @@ __device__ __forceinline__ void f64_fill_inv(double *sm, const double *W, int n,
         }
     }
 }
-// all LDS passes of one row on the image (swizzled); the caller has filled it through f64_stage_in and synchronised, the function returns synchronised, the caller
-// drains it through f64_stage_out.  Inverse: the image holds values below 2^52 (lazy sums of up to 48 products) when first_reduce is set, below 1.75 p otherwise;
-// what comes out is below 14 p (the caller reduces while it drains).
-// (RB = stages per pass: 2^RB values per thread in registers between two LDS round trips.  The fp64 butterfly is a third of the 64-bit integer one's issue cycles, so
-// the LDS passes, their barriers and the twiddle loads weigh more here than in ntt_device.h: fewer, wider passes)
+// all LDS passes of one row on the image (swizzled); the caller has filled it through f64_stage_in and synchronised, the function returns synchronised, the
+// caller drains it through f64_stage_out.  Inverse: the image holds values below 2^52 (lazy sums of up to 48 products) when first_reduce is set, below 1.75 p
+// otherwise; what comes out is below 14 p (the caller reduces while it drains). (RB = stages per pass: 2^RB values per thread in registers between two LDS
+// round trips.  The fp64 butterfly is a third of the 64-bit integer one's issue cycles, so the LDS passes, their barriers and the twiddle loads weigh more here
+// than in ntt_device.h: fewer, wider passes)
 template <bool INV, int RB>
 __device__ __forceinline__ void ntt_row_passes_f64(double *sm, const double *W, int n, int logn, const F64Mod md, bool first_reduce = true)
 {
@@ -197,9 +204,9 @@ __device__ __forceinline__ void ntt_row_passes_f64(double *sm, const double *W, 
         for (int p = 0; p < full; p++, lt -= RB) ntt_pass_f64<false, RB, RB>(sm, W, n, lt - RB + 1, n >> (lt + 1), md, false);
         if (rem) ntt_tail_pass_f64<false, RB>(rem, sm, W, n, lt - rem + 1, n >> (lt + 1), md);
     } else {
-        // radix-8 passes reduce lazily (two outputs per group, see ntt_pass_f64): the image must hold values below 1.75 p when the first pass starts -- callers whose
-        // image holds lazy sums (relin_inv_crt_kernel without a fused first stage) ask for first_reduce, which reduces every input of the first pass instead.  The
-        // wider passes keep the reduction on load: their sums grow past the multiplier's operand range within a pass.
+        // radix-8 passes reduce lazily (two outputs per group, see ntt_pass_f64): the image must hold values below 1.75 p when the first pass starts -- callers
+        // whose image holds lazy sums (relin_inv_crt_kernel without a fused first stage) ask for first_reduce, which reduces every input of the first pass
+        // instead. The wider passes keep the reduction on load: their sums grow past the multiplier's operand range within a pass.
         int lt = fused ? 1 : 0;
         for (int p = 0; p < full; p++, lt += RB) ntt_pass_f64<true, RB, RB>(sm, W, n, lt, n >> (lt + 1), md, RB != 3 || (p == 0 && first_reduce));
         if (rem) ntt_tail_pass_f64<true, RB>(rem, sm, W, n, lt, n >> (lt + 1), md);

@@ -1,24 +1,27 @@
-// bench_host.cpp -- the MEASURED path of bench.py: the C++ host classes (crcnn_host.h: the drop-in for the reference's Layer / Network / CnnBuilder) over the C ABI.
-// The reference's timed driver is CrCNN/src/mainparams.cpp:64-116 (one image at a time, chrono around every layer -> the T_LAYER_i columns, mainparams.cpp:81);
-// this is the same loop over chunks of encrypted images: CnnBuilder builds the network from the HDF5 model, Network::fuse() folds it, Network::forward runs it.
+// bench_host.cpp -- the MEASURED path of bench.py: the C++ host classes (crcnn_host.h: the drop-in for the reference's Layer / Network / CnnBuilder) over the C
+// ABI. The reference's timed driver is CrCNN/src/mainparams.cpp:64-116 (one image at a time, chrono around every layer -> the T_LAYER_i columns,
+// mainparams.cpp:81); this is the same loop over chunks of encrypted images: CnnBuilder builds the network from the HDF5 model, Network::fuse() folds it,
+// Network::forward runs it.
 //
-//   bench_host model=<name> h5=<model.h5> n=<n> k=<k> t=<t> [q=<p0>,<p1>,..] inputs=<file> distinct=<D> batch=<B> chunk=<C> group=<G> steps=<K> warmup=<W> outputs=<file> [fuse=1]
+//   bench_host model=<name> h5=<model.h5> n=<n> k=<k> t=<t> [q=<p0>,<p1>,..] inputs=<file> distinct=<D> batch=<B> chunk=<C> group=<G> steps=<K> warmup=<W>
+//   outputs=<file> [fuse=1]
 //
-// inputs   D encrypted images ([D][784][2][k][n] u64, coefficient form: bench.py's client side writes them), tiled to one launch of C * G images that every chunk
+// inputs  D encrypted images ([D][784][2][k][n] u64, coefficient form: bench.py's client side writes them), tiled to one launch of C * G images that every
+// chunk
 //          of the batch re-reads (the same bytes per image as a resident batch; bench.py states it under "data")
 // group    > 1: two-level chunking -- Network::forward gets C * G images with head_chunk = C: the layers in front of the first dense layer per chunk, the dense
 //          layers once per group
 // timing   W untimed passes over the batch, then K timed ones bracketed by stream synchronisations; per-layer times from HIP events on the launch stream
 //          (Network::time_with_events: no synchronisation between layers)
-// outputs  the 10 output ciphertexts of the first D images of an untimed launch ([D][10][2][k][n] u64): bench.py hashes them against the reference's goldens and
-//          decrypts them
-// Several ranks (world=<N> rank=<r> rendezvous=<file>; one process per GPU, started by bench.py -- the reference's driver has no counterpart: mainparams.cpp:64-116
-// runs one process): rank 0 makes the RCCL rendezvous id (crc_comm_unique_id) and writes it to <file>, every rank joins (crc_comm_create), the encoded model goes
-// out once with Network::broadcastParameters (the ONE collective of the path), then every rank evaluates its own batch: no data-path collective.  The timed region
-// is bracketed on every rank by an all-gather (the barrier) + stream synchronisation, the elapsed times are gathered and the line carries the MAX over ranks and
-// the whole-job rate (all ranks' images / that time).  launch_check=1: rendezvous through the file only (no GPU, no RCCL): the CPU-side test of the launcher.
-// stream_inputs=ciphertext|plaintext: the input launch is not resident -- see stream_inputs below.
-// Prints ONE JSON line on stdout.
+// outputs  the 10 output ciphertexts of the first D images of an untimed launch ([D][10][2][k][n] u64): bench.py hashes them against the reference's goldens
+// and
+//          decrypts them Several ranks (world=<N> rank=<r> rendezvous=<file>; one process per GPU, started by bench.py -- the reference's driver has no
+//          counterpart: mainparams.cpp:64-116 runs one process): rank 0 makes the RCCL rendezvous id (crc_comm_unique_id) and writes it to <file>, every rank
+//          joins (crc_comm_create), the encoded model goes out once with Network::broadcastParameters (the ONE collective of the path), then every rank
+//          evaluates its own batch: no data-path collective.  The timed region is bracketed on every rank by an all-gather (the barrier) + stream
+//          synchronisation, the elapsed times are gathered and the line carries the MAX over ranks and the whole-job rate (all ranks' images / that time).
+//          launch_check=1: rendezvous through the file only (no GPU, no RCCL): the CPU-side test of the launcher. stream_inputs=ciphertext|plaintext: the input
+//          launch is not resident -- see stream_inputs below. Prints ONE JSON line on stdout.
 #include "crcnn_host.h"
 #include <chrono>
 #include <cstdio>
@@ -35,7 +38,8 @@ using namespace std;
 static void rendezvous_id(const string &path, int rank, uint8_t *id, bool make_nccl_id)
 {
     if (rank == 0) {
-        if (make_nccl_id) { if (crc_comm_unique_id(id)) throw runtime_error("crc_comm_unique_id failed (rccl error " + to_string(crc_last_comm_error()) + ")"); }
+        if (make_nccl_id) { if (crc_comm_unique_id(id)) throw runtime_error("crc_comm_unique_id failed (rccl error " + to_string(crc_last_comm_error()) +
+            ")"); }
         else { ifstream r("/dev/urandom", ios::binary); r.read((char *)id, CRC_COMM_ID_BYTES); }
         const string tmp = path + ".tmp";
         { ofstream o(tmp, ios::binary); o.write((const char *)id, CRC_COMM_ID_BYTES); if (!o) throw runtime_error("cannot write " + tmp); }
@@ -70,7 +74,8 @@ int main(int argc, char **argv)
             uint8_t id[CRC_COMM_ID_BYTES];
             rendezvous_id(need("rendezvous"), rank, id, false);
             uint64_t h = 1469598103934665603ULL; for (uint8_t b : id) h = (h ^ b) * 1099511628211ULL;
-            printf("{\"launch_check\": true, \"host\": \"C++ bench_host\", \"rank\": %d, \"world\": %d, \"id_fnv1a\": \"%016llx\", \"host_threads\": %d}\n", rank, world,
+            printf("{\"launch_check\": true, \"host\": \"C++ bench_host\", \"rank\": %d, \"world\": %d, \"id_fnv1a\": \"%016llx\", \"host_threads\": %d}\n",
+                rank, world,
                    (unsigned long long)h, crc_host_thread_limit());
             return 0;
         } catch (const exception &e) { fprintf(stderr, "bench_host: %s\n", e.what()); return 2; }
@@ -80,9 +85,9 @@ int main(int argc, char **argv)
     const int distinct = (int)geti("distinct", 1), batch = (int)geti("batch", 1), head = (int)geti("chunk", 1), group = max(1, (int)geti("group", 1));
     const int steps = (int)geti("steps", 1), warmup = (int)geti("warmup", 0), fuse = (int)geti("fuse", 1);
     const int launch = head * group;                          // images per Network::forward
-    // stream_inputs: after the resident measurement, `stream_steps` more passes in which every launch's images come over PCIe while the previous launch is evaluated
-    // (mainparams.cpp:85-112 encrypts, evaluates and decrypts image after image).  ciphertext: 784 ciphertexts per image from page-locked host memory;
-    // plaintext: the 784 pixel plaintexts per image (n words each) and Encryptor::encrypt on the device (crc_encrypt_dev) inside the pipeline
+    // stream_inputs: after the resident measurement, `stream_steps` more passes in which every launch's images come over PCIe while the previous launch is
+    // evaluated (mainparams.cpp:85-112 encrypts, evaluates and decrypts image after image).  ciphertext: 784 ciphertexts per image from page-locked host
+    // memory; plaintext: the 784 pixel plaintexts per image (n words each) and Encryptor::encrypt on the device (crc_encrypt_dev) inside the pipeline
     const string stream_mode = a.count("stream_inputs") ? a["stream_inputs"] : "none";
     const int stream_steps = (int)geti("stream_steps", 1);
     try {
@@ -94,7 +99,8 @@ int main(int argc, char **argv)
             if (!known) throw invalid_argument("stream_inputs= none | ciphertext | plaintext | ciphertext,plaintext");
         }
         uint64_t q[16];
-        if (a.count("q")) {                                      // explicit coefficient modulus (q=<prime>,<prime>,...); default: the first k primes of coeff_modulus_128(n)
+        // explicit coefficient modulus (q=<prime>,<prime>,...); default: the first k primes of coeff_modulus_128(n)
+        if (a.count("q")) {
             int cnt = 0; const char *p = a["q"].c_str();
             while (*p && cnt < 16) { char *e; q[cnt++] = strtoull(p, &e, 0); p = *e == ',' ? e + 1 : e; if (e == p && *e) break; }
             if (cnt != k) throw invalid_argument("q= must list k primes");
@@ -103,7 +109,8 @@ int main(int argc, char **argv)
             if (kd < k) throw invalid_argument("coeff_modulus_128(n) has fewer primes than asked for");
         }
         const auto t_setup = chrono::high_resolution_clock::now();
-        setDeterministicSeed((uint64_t)geti("key_seed", 2024));   // the seeded client side of bench.py: the same evaluation keys, hence the same ciphertexts behind Square
+        // the seeded client side of bench.py: the same evaluation keys, hence the same ciphertexts behind Square
+        setDeterministicSeed((uint64_t)geti("key_seed", 2024));
         setParameters(n, vector<uint64_t>(q, q + k), t, (int)geti("device", 0));
         // every call of the host classes goes to ONE non-blocking stream of this process (no implicit ordering against the copy stream of the streamed mode)
         void *compute = nullptr, *copy = nullptr;
@@ -114,15 +121,18 @@ int main(int argc, char **argv)
         // ---- several ranks: communicator, then the one collective of the path
         crc_comm *comm = nullptr;
         vector<uint64_t> gathered((size_t)world * 4);
-        auto allgather = [&](uint64_t v0, uint64_t v1, uint64_t v2, uint64_t v3) {        // (also the barrier: it synchronises the stream and waits for every rank)
+        // (also the barrier: it synchronises the stream and waits for every rank)
+        auto allgather = [&](uint64_t v0, uint64_t v1, uint64_t v2, uint64_t v3) {
             uint64_t mine[4] = {v0, v1, v2, v3};
             if (!comm) { memcpy(gathered.data(), mine, sizeof mine); return; }
-            if (crc_comm_allgather_u64(comm, mine, 4, gathered.data(), compute)) throw runtime_error("crc_comm_allgather_u64 failed (rccl error " + to_string(crc_last_comm_error()) + ")");
+            if (crc_comm_allgather_u64(comm, mine, 4, gathered.data(), compute)) throw runtime_error("crc_comm_allgather_u64 failed (rccl error " +
+                to_string(crc_last_comm_error()) + ")");
         };
         if (world > 1) {
             uint8_t id[CRC_COMM_ID_BYTES];
             rendezvous_id(need("rendezvous"), rank, id, true);
-            if (crc_comm_create(context, world, rank, id, &comm)) throw runtime_error("crc_comm_create failed (rccl error " + to_string(crc_last_comm_error()) + ")");
+            if (crc_comm_create(context, world, rank, id, &comm)) throw runtime_error("crc_comm_create failed (rccl error " +
+                to_string(crc_last_comm_error()) + ")");
         }
         CnnBuilder build(h5);
         Network net = build.buildNetworkByName(model);
@@ -130,7 +140,8 @@ int main(int argc, char **argv)
         if (comm) {
             allgather(0, 0, 0, 0);
             const auto tb = chrono::high_resolution_clock::now();
-            bcast_bytes = net.broadcastParameters(comm, 0);       // rank 0 lifts + transforms the weights, everybody else receives them (checksums compared inside)
+            // rank 0 lifts + transforms the weights, everybody else receives them (checksums compared inside)
+            bcast_bytes = net.broadcastParameters(comm, 0);
             allgather(0, 0, 0, 0);
             bcast_s = chrono::duration<double>(chrono::high_resolution_clock::now() - tb).count();
         }
@@ -159,10 +170,12 @@ int main(int argc, char **argv)
         }
         const double setup_s = chrono::duration<double>(chrono::high_resolution_clock::now() - t_setup).count();
         size_t free1 = 0; crc_mem_info(context, &free1, &total);
-        // a rank that starts its timed region with a few GB left dies in the first allocation that grows (an activation slot, the work buffer): say so now, readably
+        // a rank that starts its timed region with a few GB left dies in the first allocation that grows (an activation slot, the work buffer): say so now,
+        // readably
         const double min_free_gib = a.count("min_free_gib") ? atof(a["min_free_gib"].c_str()) : (world > 1 ? 8.0 : 0.0);
         if ((double)free1 < min_free_gib * (double)((size_t)1 << 30))
-            throw runtime_error("rank " + to_string(rank) + ": only " + to_string(free1 >> 20) + " MiB of HBM free after the first launch (min_free_gib=" + to_string(min_free_gib) +
+            throw runtime_error("rank " + to_string(rank) + ": only " + to_string(free1 >> 20) + " MiB of HBM free after the first launch (min_free_gib=" +
+                to_string(min_free_gib) +
                                 "): lower chunk= / group= or the batch per GPU");
         const Network::HbmPlan plan = net.hbmPlan();
         const int L = net.getNumLayers();
@@ -188,7 +201,8 @@ int main(int argc, char **argv)
         bool st_same = true;
         string streamed_json;
         vector<string> modes;
-        if (stream_mode != "none") { size_t p0 = 0; while (p0 <= stream_mode.size()) { const size_t c = stream_mode.find(',', p0); modes.push_back(stream_mode.substr(p0, c == string::npos ? c : c - p0)); if (c == string::npos) break; p0 = c + 1; } }
+        if (stream_mode != "none") { size_t p0 = 0; while (p0 <= stream_mode.size()) { const size_t c = stream_mode.find(',', p0);
+            modes.push_back(stream_mode.substr(p0, c == string::npos ? c : c - p0)); if (c == string::npos) break; p0 = c + 1; } }
         for (const string &mode : modes) {
             double st_dt = 0.0, st_images = 0.0, st_bytes = 0.0; bool same = true;
             const bool pt = mode == "plaintext";
@@ -205,21 +219,25 @@ int main(int argc, char **argv)
                 for (auto &u : up) u = make_shared<DeviceBuffer>((size_t)launch * unit * 8);
                 d_pk = make_shared<DeviceBuffer>(public_key.size() * 8);
                 d_encwork = make_shared<DeviceBuffer>(crc_encrypt_dev_work_bytes(context, (size_t)launch * 784));
-                if (crc_memcpy_h2d(context, d_pk->ptr, public_key.data(), public_key.size() * 8, compute) || crc_stream_sync(context, compute)) throw runtime_error("public key upload");
+                if (crc_memcpy_h2d(context, d_pk->ptr, public_key.data(), public_key.size() * 8, compute) || crc_stream_sync(context,
+                    compute)) throw runtime_error("public key upload");
             }
             void *copied[2], *consumed[2];
-            for (int i = 0; i < 2; i++) if (crc_event_create(context, &copied[i]) || crc_event_create(context, &consumed[i])) throw runtime_error("crc_event_create");
+            for (int i = 0; i < 2; i++) if (crc_event_create(context, &copied[i]) || crc_event_create(context,
+                &consumed[i])) throw runtime_error("crc_event_create");
             uint64_t enc_seed = 0x5eed0000;
             auto upload = [&](int slot, bool wait_consumed) {
                 if (wait_consumed && crc_stream_wait_event(context, copy, consumed[slot])) throw runtime_error("crc_stream_wait_event");
                 char *dst = pt ? (char *)up[slot]->ptr : (char *)xin[slot].data();
                 for (int b = 0; b < launch; b++)
-                    if (crc_memcpy_h2d(context, dst + (size_t)b * unit * 8, pinned + (size_t)(b % distinct) * unit, unit * 8, copy)) throw runtime_error("crc_memcpy_h2d");
+                    if (crc_memcpy_h2d(context, dst + (size_t)b * unit * 8, pinned + (size_t)(b % distinct) * unit, unit * 8,
+                        copy)) throw runtime_error("crc_memcpy_h2d");
                 if (crc_event_record(context, copied[slot], copy)) throw runtime_error("crc_event_record");
             };
             auto run = [&](int slot) {
                 if (crc_stream_wait_event(context, compute, copied[slot])) throw runtime_error("crc_stream_wait_event");
-                if (pt && crc_encrypt_dev(context, (const uint64_t *)d_pk->ptr, (const uint64_t *)up[slot]->ptr, (size_t)launch * 784, enc_seed++, xin[slot].data(),
+                if (pt && crc_encrypt_dev(context, (const uint64_t *)d_pk->ptr, (const uint64_t *)up[slot]->ptr, (size_t)launch * 784, enc_seed++,
+                    xin[slot].data(),
                                           d_encwork->ptr, compute)) throw runtime_error("crc_encrypt_dev");
                 ciphertext3D y = net.forward(xin[slot]);
                 if (crc_event_record(context, consumed[slot], compute)) throw runtime_error("crc_event_record");
@@ -256,26 +274,38 @@ int main(int argc, char **argv)
             for (int i = 0; i < 2; i++) { crc_event_destroy(context, copied[i]); crc_event_destroy(context, consumed[i]); }
             crc_host_free(context, pinned);
             char buf[1400];
-            snprintf(buf, sizeof buf, "%s{\"mode\": %s, \"images_per_s\": %.4f, \"elapsed_s\": %.6f, \"steps\": %d, \"h2d_GBps\": %.2f, \"bytes_per_image\": %zu, "
-                     "\"outputs_identical_to_resident\": %s, \"how\": \"two device input buffers; the next launch's images are copied from page-locked host memory on a copy stream "
-                     "while the compute stream evaluates the current one (events order the two)%s\"}", streamed_json.empty() ? "" : ", ", jstr(mode).c_str(), st_images / st_dt, st_dt,
+            snprintf(buf, sizeof buf,
+                "%s{\"mode\": %s, \"images_per_s\": %.4f, \"elapsed_s\": %.6f, \"steps\": %d, \"h2d_GBps\": %.2f, \"bytes_per_image\": %zu, "
+                     "\"outputs_identical_to_resident\": %s, \"how\": \"two device input buffers; the next launch's images are copied from page-locked host "
+                         "memory on a copy stream "
+                     "while the compute stream evaluates the current one (events order the two)%s\"}", streamed_json.empty() ? "" : ", ", jstr(mode).c_str(),
+                         st_images / st_dt, st_dt,
                      stream_steps, st_bytes / st_dt / 1e9, (size_t)(unit * 8), pt ? "null" : same ? "true" : "false",
                      pt ? "; the 784 pixel plaintexts per image are encrypted on the device (crc_encrypt_dev) in front of the first layer" : "");
             streamed_json += buf;
         }
 
-        printf("{\"host\": \"C++ host classes (crcnn_amd/host: CnnBuilder / Network::fuse / Network::forward) over the C ABI\", \"model\": %s, \"n\": %d, \"k\": %d, \"batch\": %d, \"chunk\": %d, "
-               "\"group\": %d, \"steps\": %d, \"warmup\": %d, \"rank\": %d, \"world\": %d, \"images_per_s\": %.4f, \"elapsed_s\": %.6f, \"ms_per_step\": %.3f, \"ms_per_image\": %.4f, \"setup_s\": %.1f, ",
-               jstr(model).c_str(), n, k, launches * launch, head, group, steps, warmup, rank, world, images_all / dt_max, dt_max, dt_max / steps * 1e3, dt / images * 1e3, setup_s);
-        printf("\"timing\": \"all-gather (barrier) + stream synchronisation on both sides of the timed steps on every rank; elapsed_s = max over ranks, images_per_s = all ranks' images / that\", "
+        printf("{\"host\": \"C++ host classes (crcnn_amd/host: CnnBuilder / Network::fuse / Network::forward) over the C ABI\", \"model\": %s, \"n\": %d, "
+            "\"k\": %d, \"batch\": %d, \"chunk\": %d, "
+               "\"group\": %d, \"steps\": %d, \"warmup\": %d, \"rank\": %d, \"world\": %d, \"images_per_s\": %.4f, \"elapsed_s\": %.6f, \"ms_per_step\": "
+                   "%.3f, \"ms_per_image\": %.4f, \"setup_s\": %.1f, ",
+               jstr(model).c_str(), n, k, launches * launch, head, group, steps, warmup, rank, world, images_all / dt_max, dt_max, dt_max / steps * 1e3,
+                   dt / images * 1e3, setup_s);
+        printf("\"timing\": \"all-gather (barrier) + stream synchronisation on both sides of the timed steps on every rank; elapsed_s = max over ranks, "
+            "images_per_s = all ranks' images / that\", "
                "\"per_rank\": [");
         for (int r = 0; r < world; r++)
-            printf("%s{\"rank\": %d, \"elapsed_s\": %.6f, \"images\": %llu, \"free_after_first_launch\": %llu, \"parameters\": %llu}", r ? ", " : "", r, (double)per_rank[(size_t)r * 4] * 1e-9,
-                   (unsigned long long)per_rank[(size_t)r * 4 + 1], (unsigned long long)per_rank[(size_t)r * 4 + 2], (unsigned long long)per_rank[(size_t)r * 4 + 3]);
+            printf("%s{\"rank\": %d, \"elapsed_s\": %.6f, \"images\": %llu, \"free_after_first_launch\": %llu, \"parameters\": %llu}", r ? ", " : "", r,
+                (double)per_rank[(size_t)r * 4] * 1e-9,
+                   (unsigned long long)per_rank[(size_t)r * 4 + 1], (unsigned long long)per_rank[(size_t)r * 4 + 2],
+                       (unsigned long long)per_rank[(size_t)r * 4 + 3]);
         printf("], ");
-        if (comm) printf("\"weight_broadcast\": {\"via\": \"Network::broadcastParameters (crc_broadcast_weights: %s; per-rank checksums compared with the root's)\", \"bytes\": %zu, "
-                         "\"seconds\": %.3f, \"GBps\": %.2f, \"host_threads_per_rank\": %d}, ", getenv("CRC_COMM_TRANSPORT") && !strcmp(getenv("CRC_COMM_TRANSPORT"), "shm") ?
-                         "shared-memory rehearsal transport" : "ncclBroadcast over RCCL in <= 1 GiB pieces", bcast_bytes, bcast_s, bcast_s > 0 ? bcast_bytes / bcast_s / 1e9 : 0.0, crc_host_thread_limit());
+        if (comm) printf("\"weight_broadcast\": {\"via\": \"Network::broadcastParameters (crc_broadcast_weights: %s; per-rank checksums compared with the "
+            "root's)\", \"bytes\": %zu, "
+                         "\"seconds\": %.3f, \"GBps\": %.2f, \"host_threads_per_rank\": %d}, ", getenv("CRC_COMM_TRANSPORT") &&
+                             !strcmp(getenv("CRC_COMM_TRANSPORT"), "shm") ?
+                         "shared-memory rehearsal transport" : "ncclBroadcast over RCCL in <= 1 GiB pieces", bcast_bytes, bcast_s, bcast_s > 0 ?
+                             bcast_bytes / bcast_s / 1e9 : 0.0, crc_host_thread_limit());
         else printf("\"weight_broadcast\": null, ");
         if (!streamed_json.empty()) printf("\"streamed\": [%s], ", streamed_json.c_str());
         printf("\"layers\": [");
@@ -289,8 +319,10 @@ int main(int argc, char **argv)
         printf("], \"layer_launches\": [");
         for (int i = 0; i < L; i++) printf("%s%lld", i ? ", " : "", calls[i]);
         printf("], \"layer_timing\": \"HIP events on the launch stream around every Layer::forward inside the timed region\", ");
-        printf("\"hbm\": {\"total_bytes\": %zu, \"free_before_build\": %zu, \"free_after_first_launch\": %zu, \"parameters\": %zu, \"activation_slots\": %zu, \"work_buffer\": %zu, "
-               "\"evaluation_keys\": %zu, \"input_launch\": %zu}}\n", total, free0, free1, plan.parameters, plan.activations, plan.work, plan.keys, (size_t)launch * imgw * 8);
+        printf("\"hbm\": {\"total_bytes\": %zu, \"free_before_build\": %zu, \"free_after_first_launch\": %zu, \"parameters\": %zu, \"activation_slots\": %zu, "
+            "\"work_buffer\": %zu, "
+               "\"evaluation_keys\": %zu, \"input_launch\": %zu}}\n", total, free0, free1, plan.parameters, plan.activations, plan.work, plan.keys,
+                   (size_t)launch * imgw * 8);
         fflush(stdout);
         if (comm) crc_comm_destroy(comm);
         setStream(nullptr);
@@ -299,6 +331,7 @@ int main(int argc, char **argv)
     } catch (const exception &e) {
         fprintf(stderr, "bench_host: %s\n", e.what());
         fflush(stderr);
-        _exit(2);                                               // (no unwinding of device state after a failed launch or allocation: the message above is the report)
+        // (no unwinding of device state after a failed launch or allocation: the message above is the report)
+        _exit(2);
     }
 }

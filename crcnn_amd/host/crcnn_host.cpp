@@ -15,9 +15,10 @@
 using namespace std;
 
 crc_ctx *context = nullptr;
-// The stream every ABI call of these classes is launched on.  NULL (the default stream) unless the caller installs its own (setStream): a driver that uploads the
-// next chunk of encrypted images on a second stream while this one computes (bench_host's streamed inputs) needs a non-blocking one here -- the default stream
-// would order itself against every other blocking stream of the process.  A global like the context, the keys and the work buffer (CrCNN/src/globals.h:18-26).
+// The stream every ABI call of these classes is launched on.  NULL (the default stream) unless the caller installs its own (setStream): a driver that uploads
+// the next chunk of encrypted images on a second stream while this one computes (bench_host's streamed inputs) needs a non-blocking one here -- the default
+// stream would order itself against every other blocking stream of the process.  A global like the context, the keys and the work buffer
+// (CrCNN/src/globals.h:18-26).
 static void *g_stream = nullptr;
 void setStream(void *s) { g_stream = s; }
 void *getStream() { return g_stream; }
@@ -49,8 +50,8 @@ static int K() { return crc_ctx_k(ctx()); }
 static size_t ctBytes() { return crc_ct_words(ctx(), 2) * 8; }
 
 // Device allocations are recycled by exact size: the reference passes its tensors by value and so do these classes -- every Layer::forward makes a new output
-// tensor -- but a hipMalloc / hipFree pair per layer and chunk (the free synchronises the device) would cost more than some of the layers.  Freed buffers wait in a
-// pool (bounded: beyond the cap they go back to the driver; an allocation that fails empties the pool and tries again); delParameters() empties it.
+// tensor -- but a hipMalloc / hipFree pair per layer and chunk (the free synchronises the device) would cost more than some of the layers.  Freed buffers wait
+// in a pool (bounded: beyond the cap they go back to the driver; an allocation that fails empties the pool and tries again); delParameters() empties it.
 namespace {
 struct BufferPool {
     std::mutex mu;
@@ -71,7 +72,8 @@ struct BufferPool {
         while (pooled + b > kCap && !lru.empty()) { if (context) crc_free(context, lru.front().second); pooled -= lru.front().first; lru.pop_front(); }
         // ... and the device keeps kReserve free for allocations that do not come through here (the HIP runtime's scratch for spilling kernels, RCCL)
         size_t free_b = 0, total_b = 0;
-        while (context && crc_mem_info(context, &free_b, &total_b) >= 0 && free_b < kReserve && !lru.empty()) { crc_free(context, lru.front().second); pooled -= lru.front().first; lru.pop_front(); }
+        while (context && crc_mem_info(context, &free_b, &total_b) >= 0 && free_b < kReserve && !lru.empty()) { crc_free(context, lru.front().second);
+            pooled -= lru.front().first; lru.pop_front(); }
         if (context && free_b < kReserve) return false;
         lru.emplace_back(b, p); pooled += b;
         return true;
@@ -137,8 +139,8 @@ Plaintext fraencode(double value)
 }
 double fradecode(const vector<uint64_t> &plain) { return crc_decode(ctx(), plain.data()); }
 
-// plaintext list -> device buffer of [count][k][n]: mode 0 = NTT-form weights, 1 = delta coefficient form, 2 = delta NTT form; mode 3 = the plaintext coefficients
-// themselves, [count][n] (streamed layers)
+// plaintext list -> device buffer of [count][k][n]: mode 0 = NTT-form weights, 1 = delta coefficient form, 2 = delta NTT form; mode 3 = the plaintext
+// coefficients themselves, [count][n] (streamed layers)
 static shared_ptr<DeviceBuffer> uploadPlain(const vector<const Plaintext *> &pl, int mode)
 {
     const int n = N(), k = mode == 3 ? 1 : K();
@@ -157,7 +159,8 @@ static shared_ptr<DeviceBuffer> uploadPlain(const vector<const Plaintext *> &pl,
                 memset(row, 0, sizeof(uint64_t) * CRC_PLAIN_COMPACT_WORDS);
                 for (auto &z : pl[o + i]->nz) {
                     if (z.first < CRC_PLAIN_COMPACT_LOW) row[z.first] = z.second;
-                    else if (z.first >= n - CRC_PLAIN_COMPACT_HIGH && z.first < n) row[CRC_PLAIN_COMPACT_LOW + z.first - (n - CRC_PLAIN_COMPACT_HIGH)] = z.second;
+                    else if (z.first >= n - CRC_PLAIN_COMPACT_HIGH && z.first < n) row[CRC_PLAIN_COMPACT_LOW + z.first - (n - CRC_PLAIN_COMPACT_HIGH)] =
+                        z.second;
                     else { compact = false; return; }
                 }
             }
@@ -179,13 +182,14 @@ static shared_ptr<DeviceBuffer> uploadPlain(const vector<const Plaintext *> &pl,
     return out;
 }
 
-// ---- tensors ----------------------------------------------------------------------------------------------------------
-// Network::forward's two ping-pong activation slots: the NEXT tensor constructed on this thread takes (and, if it is too small, replaces) the slot the hint points
-// at instead of a buffer of its own -- every layer constructs its output tensor first.  With 200 GiB of weights resident there is no room for a recycling pool, and a
-// hipMalloc / hipFree pair per layer costs more than most layers (PlainModelWoPad at n = 16384: 113 ms instead of 3.8 ms per image for conv1).
+// ---- tensors ---------------------------------------------------------------------------------------------------------- Network::forward's two ping-pong
+// activation slots: the NEXT tensor constructed on this thread takes (and, if it is too small, replaces) the slot the hint points at instead of a buffer of its
+// own -- every layer constructs its output tensor first.  With 200 GiB of weights resident there is no room for a recycling pool, and a hipMalloc / hipFree
+// pair per layer costs more than most layers (PlainModelWoPad at n = 16384: 113 ms instead of 3.8 ms per image for conv1).
 static thread_local shared_ptr<DeviceBuffer> *g_out_hint = nullptr;
-// arms the hint for ONE layer call and disarms it when the scope ends, however it ends: a layer that throws before it has constructed its output must not leave the
-// hint pointing at the network's slot for whatever tensor the caller constructs next (an encryptImage in a retry, or a slot of a Network that no longer exists)
+// arms the hint for ONE layer call and disarms it when the scope ends, however it ends: a layer that throws before it has constructed its output must not leave
+// the hint pointing at the network's slot for whatever tensor the caller constructs next (an encryptImage in a retry, or a slot of a Network that no longer
+// exists)
 struct OutHint {
     explicit OutHint(shared_ptr<DeviceBuffer> *slot) { g_out_hint = slot; }
     ~OutHint() { g_out_hint = nullptr; }
@@ -196,7 +200,8 @@ ciphertext3D::ciphertext3D(int B, int zd, int xd, int yd, int form) : B(B), zd(z
 {
     size_t bytes = count() * ctBytes();
     if (form == CRC_NTTLC) { const size_t lb = crc_limb_tensor_bytes(ctx(), B, zd, xd, yd); if (lb > bytes) bytes = lb; }      // channels padded to 32
-    // a dense consumer's limb tensor: every output a channel of ONE position, rounded up to 32 (7 bytes per residue: larger than the ciphertexts below 217 channels)
+    // a dense consumer's limb tensor: every output a channel of ONE position, rounded up to 32 (7 bytes per residue: larger than the ciphertexts below 217
+    // channels)
     if (form == CRC_NTTL) { const size_t lb = crc_limb_tensor_bytes(ctx(), B, zd * xd * yd, 1, 1); if (lb > bytes) bytes = lb; }
     if (g_out_hint) {
         shared_ptr<DeviceBuffer> *slot = g_out_hint; g_out_hint = nullptr;
@@ -232,10 +237,15 @@ ciphertext3D stackImages(const vector<ciphertext3D> &images)
 {
     if (images.empty()) throw invalid_argument("no images");
     const ciphertext3D &f = images[0];
-    int B = 0; for (auto &im : images) { if (im.zd != f.zd || im.xd != f.xd || im.yd != f.yd || im.form != f.form) throw invalid_argument("image shapes differ"); B += im.B; }
+    int B = 0;
+    for (auto &im : images) {
+        if (im.zd != f.zd || im.xd != f.xd || im.yd != f.yd || im.form != f.form) throw invalid_argument("image shapes differ");
+        B += im.B;
+    }
     ciphertext3D t(B, f.zd, f.xd, f.yd, f.form);
     size_t off = 0;
-    for (auto &im : images) { chk(crc_memcpy_d2d(ctx(), (char *)t.data() + off, im.data(), im.count() * ctBytes(), stream()), "crc_memcpy_d2d"); off += im.count() * ctBytes(); }
+    for (auto &im : images) { chk(crc_memcpy_d2d(ctx(), (char *)t.data() + off, im.data(), im.count() * ctBytes(), stream()), "crc_memcpy_d2d");
+        off += im.count() * ctBytes(); }
     chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
     return t;
 }
@@ -257,7 +267,8 @@ void setParameters(int poly_modulus, uint64_t plain_modulus)
 void setParameters(int poly_modulus, const vector<uint64_t> &coeff_modulus, uint64_t plain_modulus, int device)
 {
     delParameters();
-    chk(crc_ctx_create(poly_modulus, coeff_modulus.data(), (int)coeff_modulus.size(), plain_modulus, device, &context), "encryption parameters are not set correctly");
+    chk(crc_ctx_create(poly_modulus, coeff_modulus.data(), (int)coeff_modulus.size(), plain_modulus, device, &context),
+        "encryption parameters are not set correctly");
     const int n = N(), k = K();
     secret_key.assign((size_t)k * n, 0); public_key.assign((size_t)2 * k * n, 0);
     ev_keys16_host.assign(crc_evk_words(context, 16), 0);                  // keygen->generate_evaluation_keys(16, *ev_keys16), globals.cpp:54
@@ -287,7 +298,8 @@ void delParameters()
     g_pool.flush();
     if (context) { crc_ctx_destroy(context); context = nullptr; }
 }
-static void writeFile(const string &path, const vector<uint8_t> &b) { ofstream f(path, ofstream::binary); if (!f) throw runtime_error("cannot write " + path); f.write((const char *)b.data(), (streamsize)b.size()); }
+static void writeFile(const string &path, const vector<uint8_t> &b) { ofstream f(path, ofstream::binary); if (!f) throw runtime_error("cannot write " + path);
+    f.write((const char *)b.data(), (streamsize)b.size()); }
 static vector<uint8_t> readFile(const string &path)
 {
     ifstream f(path, ifstream::binary); if (!f) throw runtime_error("cannot open " + path);
@@ -297,14 +309,18 @@ void setAndSaveParameters(string public_key_path, string secret_key_path, string
 {   // globals.cpp:58-74
     setParameters(poly_modulus, plain_modulus);
     size_t w = 0;
-    vector<uint8_t> b(crc_seal_pk_bytes(context)); chk(crc_seal_pk_save(context, public_key.data(), b.data(), b.size(), &w), "crc_seal_pk_save"); writeFile(public_key_path, b);
-    b.assign(crc_seal_sk_bytes(context), 0); chk(crc_seal_sk_save(context, secret_key.data(), b.data(), b.size(), &w), "crc_seal_sk_save"); writeFile(secret_key_path, b);
-    b.assign(crc_seal_evk_bytes(context, 16), 0); chk(crc_seal_evk_save(context, ev_keys16_host.data(), 16, b.data(), b.size(), &w), "crc_seal_evk_save"); writeFile(evaluation_key_path, b);
+    vector<uint8_t> b(crc_seal_pk_bytes(context)); chk(crc_seal_pk_save(context, public_key.data(), b.data(), b.size(), &w), "crc_seal_pk_save");
+        writeFile(public_key_path, b);
+    b.assign(crc_seal_sk_bytes(context), 0); chk(crc_seal_sk_save(context, secret_key.data(), b.data(), b.size(), &w), "crc_seal_sk_save");
+        writeFile(secret_key_path, b);
+    b.assign(crc_seal_evk_bytes(context, 16), 0); chk(crc_seal_evk_save(context, ev_keys16_host.data(), 16, b.data(), b.size(), &w), "crc_seal_evk_save");
+        writeFile(evaluation_key_path, b);
 }
 void initFromKeys(string public_key_path, string secret_key_path, string evaluation_key_path, int poly_modulus, uint64_t plain_modulus)
 {   // globals.cpp:77-111
     setParameters(poly_modulus, plain_modulus);
-    vector<uint8_t> b = readFile(public_key_path); chk(crc_seal_pk_load(context, b.data(), b.size(), public_key.data()), "public_key is not valid for encryption parameters");
+    vector<uint8_t> b = readFile(public_key_path); chk(crc_seal_pk_load(context, b.data(), b.size(), public_key.data()),
+        "public_key is not valid for encryption parameters");
     b = readFile(secret_key_path); chk(crc_seal_sk_load(context, b.data(), b.size(), secret_key.data()), "secret_key is not valid for encryption parameters");
     b = readFile(evaluation_key_path); int dbc = 0;
     chk(crc_seal_evk_load(context, b.data(), b.size(), ev_keys16_host.data(), &dbc), "evaluation_keys is not valid for encryption parameters");
@@ -420,17 +436,19 @@ static bool tooLargeForHbm(size_t weights)
 // a streamed layer: lift + NTT a tile of filters, run the layer on the tile, scatter the tile's output channels into the [B][F][P] tensor
 static int plannedForm(int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int B);
 static int forwardStreamed(const ciphertext3D &input, ciphertext3D &out, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int out_form,
-                            shared_ptr<DeviceBuffer> &d_plain, shared_ptr<DeviceBuffer> *d_b, shared_ptr<DeviceBuffer> &d_wtile, shared_ptr<DeviceBuffer> &d_ytile, shared_ptr<DeviceBuffer> &d_work)
+                            shared_ptr<DeviceBuffer> &d_plain, shared_ptr<DeviceBuffer> *d_b, shared_ptr<DeviceBuffer> &d_wtile,
+                                shared_ptr<DeviceBuffer> &d_ytile, shared_ptr<DeviceBuffer> &d_work)
 {
     const size_t n = N(), k = K(), rowb = k * n * 8, ctb = ctBytes();
     const size_t T = (size_t)zd * xf * yf, P = (size_t)((xd - xf) / xs + 1) * ((yd - yf) / ys + 1);
     auto scatter = [&](int f0, int ft) {
         for (int b = 0; b < input.B; b++)
-            chk(crc_memcpy_d2d(ctx(), (char *)out.buf->ptr + ((size_t)b * nf + f0) * P * ctb, (const char *)d_ytile->ptr + (size_t)b * ft * P * ctb, (size_t)ft * P * ctb, stream()), "crc_memcpy_d2d");
+            chk(crc_memcpy_d2d(ctx(), (char *)out.buf->ptr + ((size_t)b * nf + f0) * P * ctb, (const char *)d_ytile->ptr + (size_t)b * ft * P * ctb,
+                (size_t)ft * P * ctb, stream()), "crc_memcpy_d2d");
     };
-    // On the matrix cores (a reduction the limb GEMM takes, at least 32 rows in this launch: crc_plan_mac): tiles of 64 filters in limb form, built from canonical sub-tiles
-    // of 8 filters (crc_limb_pack_weights_tile), the layer's input converted to limb form once per launch -- PlainModelWoPad's fc3 with all eight primes of n = 16384
-    // (netrun.py does the same: 25 against 58 ms per image on the vector-ALU tiles)
+    // On the matrix cores (a reduction the limb GEMM takes, at least 32 rows in this launch: crc_plan_mac): tiles of 64 filters in limb form, built from
+    // canonical sub-tiles of 8 filters (crc_limb_pack_weights_tile), the layer's input converted to limb form once per launch -- PlainModelWoPad's fc3 with all
+    // eight primes of n = 16384 (netrun.py does the same: 25 against 58 ms per image on the vector-ALU tiles)
     const bool ntt_in = input.form == CRC_NTT || input.form == CRC_NTTP || input.form == CRC_NTTL;
     if (ntt_in && plannedForm(zd, xd, yd, xs, ys, xf, yf, nf, input.B) == CRC_NTTL) {
         const int ft_max = min(64, nf), sub = min(8, ft_max);
@@ -451,11 +469,15 @@ static int forwardStreamed(const ciphertext3D &input, ciphertext3D &out, int zd,
             const int ft = min(ft_max, nf - f0);
             for (int s0 = 0; s0 < ft; s0 += sub) {
                 const int fs = min(sub, ft - s0);
-                chk(crc_plain_to_ntt(ctx(), (const uint64_t *)d_plain->ptr + (size_t)(f0 + s0) * T * n, (size_t)fs * T, (uint64_t *)d_wtile->ptr, stream()), "crc_plain_to_ntt");
-                chk(crc_limb_pack_weights_tile(ctx(), (const uint64_t *)d_wtile->ptr, ft, s0, fs, zd, xf, yf, g_wltile->ptr, stream()), "crc_limb_pack_weights_tile");
+                chk(crc_plain_to_ntt(ctx(), (const uint64_t *)d_plain->ptr + (size_t)(f0 + s0) * T * n, (size_t)fs * T, (uint64_t *)d_wtile->ptr, stream()),
+                    "crc_plain_to_ntt");
+                chk(crc_limb_pack_weights_tile(ctx(), (const uint64_t *)d_wtile->ptr, ft, s0, fs, zd, xf, yf, g_wltile->ptr, stream()),
+                    "crc_limb_pack_weights_tile");
             }
-            chk(crc_conv2d_forms(ctx(), (const uint64_t *)xl, (const uint64_t *)g_wltile->ptr, CRC_NTTL, (const uint64_t *)((const char *)d_b[out_form != CRC_COEFF]->ptr + (size_t)f0 * rowb),
-                                 input.B, zd, xd, yd, xs, ys, xf, yf, ft, CRC_NTTL, out_form, (uint64_t *)d_ytile->ptr, d_work->ptr, stream()), "crc_conv2d_forms");
+            chk(crc_conv2d_forms(ctx(), (const uint64_t *)xl, (const uint64_t *)g_wltile->ptr, CRC_NTTL,
+                (const uint64_t *)((const char *)d_b[out_form != CRC_COEFF]->ptr + (size_t)f0 * rowb),
+                                 input.B, zd, xd, yd, xs, ys, xf, yf, ft, CRC_NTTL, out_form, (uint64_t *)d_ytile->ptr, d_work->ptr, stream()),
+                                     "crc_conv2d_forms");
             scatter(f0, ft);
         }
         return CRC_NTTL;
@@ -463,7 +485,8 @@ static int forwardStreamed(const ciphertext3D &input, ciphertext3D &out, int zd,
     // tile: as many filters (a multiple of 8, the MAC kernel's filter granule) as make 2-16 GiB of NTT-form weights, by what HBM has left
     size_t free_b = 0, total_b = 0;
     chk(crc_mem_info(ctx(), &free_b, &total_b), "crc_mem_info");
-    const size_t tile_bytes = d_wtile && d_wtile->bytes >= ((size_t)1 << 30) ? d_wtile->bytes : max<size_t>((size_t)2 << 30, min<size_t>((size_t)16 << 30, free_b / 8));
+    const size_t tile_bytes = d_wtile && d_wtile->bytes >= ((size_t)1 << 30) ? d_wtile->bytes : max<size_t>((size_t)2 << 30, min<size_t>((size_t)16 << 30,
+        free_b / 8));
     size_t ftv = tile_bytes / (T * rowb); if (ftv >= 8) ftv = ftv / 8 * 8;
     const int ft_max = (int)max<size_t>(1, min<size_t>(nf, ftv));
     if (!d_wtile || d_wtile->bytes < ft_max * T * rowb) d_wtile = make_shared<DeviceBuffer>(ft_max * T * rowb);
@@ -472,8 +495,10 @@ static int forwardStreamed(const ciphertext3D &input, ciphertext3D &out, int zd,
     if (!d_work || d_work->bytes < wb) d_work = make_shared<DeviceBuffer>(wb);
     for (int f0 = 0; f0 < nf; f0 += ft_max) {
         const int ft = min(ft_max, nf - f0);
-        chk(crc_plain_to_ntt(ctx(), (const uint64_t *)d_plain->ptr + (size_t)f0 * T * n, (size_t)ft * T, (uint64_t *)d_wtile->ptr, stream()), "crc_plain_to_ntt");
-        chk(crc_conv2d_forms(ctx(), input.data(), (const uint64_t *)d_wtile->ptr, CRC_NTT, (const uint64_t *)((const char *)d_b[out_form != CRC_COEFF]->ptr + (size_t)f0 * rowb), input.B,
+        chk(crc_plain_to_ntt(ctx(), (const uint64_t *)d_plain->ptr + (size_t)f0 * T * n, (size_t)ft * T, (uint64_t *)d_wtile->ptr, stream()),
+            "crc_plain_to_ntt");
+        chk(crc_conv2d_forms(ctx(), input.data(), (const uint64_t *)d_wtile->ptr, CRC_NTT, (const uint64_t *)((const char *)d_b[out_form != CRC_COEFF]->ptr +
+            (size_t)f0 * rowb), input.B,
                              zd, xd, yd, xs, ys, xf, yf, ft, input.form, out_form, (uint64_t *)d_ytile->ptr, d_work->ptr, stream()), "crc_conv2d_forms");
         scatter(f0, ft);
     }
@@ -488,8 +513,8 @@ static int plannedForm(int zd, int xd, int yd, int xs, int ys, int xf, int yf, i
     chk(crc_plan_mac(ctx(), zd, xd, yd, xs, ys, xf, yf, nf, B, g_matrix_cores ? 1 : 0, &wf), "crc_plan_mac");
     return wf;
 }
-// canonical NTT-form weights -> limb form (CRC_NTTL) when crc_plan_mac says the limb GEMM pays for this shape and launch size and the second copy fits beside the
-// first; the canonical copy is dropped
+// canonical NTT-form weights -> limb form (CRC_NTTL) when crc_plan_mac says the limb GEMM pays for this shape and launch size and the second copy fits beside
+// the first; the canonical copy is dropped
 static bool limbFits(int nf, int zd, int xf, int yf)
 {
     size_t free_b = 0, total_b = 0;
@@ -509,7 +534,8 @@ static bool toLimb(shared_ptr<DeviceBuffer> &d_w, int &w_form, int nf, int zd, i
 }
 
 // ---- ConvolutionalLayer -----------------------------------------------------------------------------------------------
-ConvolutionalLayer::ConvolutionalLayer(string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf, int nf, int th_count, plaintext4D &filters, vector<Plaintext> &biases)
+ConvolutionalLayer::ConvolutionalLayer(string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf, int nf, int th_count, plaintext4D &filters,
+    vector<Plaintext> &biases)
     : Layer(name), xd(xd), yd(yd), zd(zd), xs(xs), ys(ys), xf(xf), yf(yf), nf(nf), th_count(th_count),
       xo((xd - xf) / xs + 1), yo((yd - yf) / ys + 1), zo(nf), filters(filters), biases(biases) {}
 ConvolutionalLayer::ConvolutionalLayer(string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf, int nf, int th_count, istream *infile)
@@ -521,7 +547,8 @@ void ConvolutionalLayer::upload()
     if ((int)filters.size() != nf || (int)biases.size() != nf) throw invalid_argument("conv: filter/bias count mismatch");
     vector<const Plaintext *> w, b;
     for (int f = 0; f < nf; f++) {
-        if ((int)filters[f].size() != zd || (int)filters[f][0].size() != xf || (int)filters[f][0][0].size() != yf) throw invalid_argument("conv: kernel shape mismatch");
+        if ((int)filters[f].size() != zd || (int)filters[f][0].size() != xf ||
+            (int)filters[f][0][0].size() != yf) throw invalid_argument("conv: kernel shape mismatch");
         for (int z = 0; z < zd; z++) for (int i = 0; i < xf; i++) for (int j = 0; j < yf; j++) w.push_back(&filters[f][z][i][j]);
         b.push_back(&biases[f]);
     }
@@ -533,11 +560,13 @@ void ConvolutionalLayer::upload()
 static size_t bytesOf(const shared_ptr<DeviceBuffer> &b) { return b ? b->bytes : 0; }
 static string macKernelName(int w_form, bool streamed)
 {
-    const string k = w_form == CRC_NTTL ? "mfma_mac2w_kernel (int8 limb GEMM, CRC_NTTL)" : w_form == CRC_NTTL1 ? "mfma_conv1_kernel (one-channel convolution on the matrix cores, CRC_NTTL1)"
+    const string k = w_form == CRC_NTTL ? "mfma_mac2w_kernel (int8 limb GEMM, CRC_NTTL)" : w_form == CRC_NTTL1 ?
+        "mfma_conv1_kernel (one-channel convolution on the matrix cores, CRC_NTTL1)"
                    : w_form == CRC_NTTP ? "mac3_kernel (v_mad_u64_u32, CRC_NTTP)" : "mac3_kernel (v_mad_u64_u32, canonical residues)";
     return streamed ? k + (w_form == CRC_NTTL ? ", streamed weights (64-filter limb tiles built inside the forward)" : ", streamed weights") : k;
 }
-size_t ConvolutionalLayer::deviceBytes() const { return bytesOf(d_w) + bytesOf(d_b[0]) + bytesOf(d_b[1]) + bytesOf(d_plain) + bytesOf(d_wtile) + bytesOf(d_ytile) + bytesOf(d_w_canon); }
+size_t ConvolutionalLayer::deviceBytes() const { return bytesOf(d_w) + bytesOf(d_b[0]) + bytesOf(d_b[1]) + bytesOf(d_plain) + bytesOf(d_wtile) +
+    bytesOf(d_ytile) + bytesOf(d_w_canon); }
 string ConvolutionalLayer::kernelName() const { return macKernelName(streamed ? stream_form : w_form, streamed); }
 int ConvolutionalLayer::placement() { upload(); return streamed ? 1 : 0; }
 void ConvolutionalLayer::restoreCanonical()
@@ -545,7 +574,8 @@ void ConvolutionalLayer::restoreCanonical()
     if (w_form == CRC_NTTP) { packWeights(true); return; }
     if (w_form == CRC_NTTL1 && d_w_canon) { d_w = d_w_canon; d_w_canon.reset(); w_form = CRC_NTT; return; }
     if (w_form != CRC_NTTL && w_form != CRC_NTTL1) return;
-    if ((int)filters.size() != nf) throw logic_error("ConvolutionalLayer " + name + ": a folded layer's weights are in limb form and it has no plaintexts to rebuild them from");
+    if ((int)filters.size() != nf) throw logic_error("ConvolutionalLayer " + name +
+        ": a folded layer's weights are in limb form and it has no plaintexts to rebuild them from");
     d_w.reset(); w_form = CRC_NTT; filters_already_ntt = false;
     upload();
 }
@@ -568,15 +598,16 @@ bool ConvolutionalLayer::limbWeights(int B)
     if (streamed) return false;
     if (w_form == CRC_NTTL || w_form == CRC_NTTL1) return true;
     const int planned = plannedForm(zd, xd, yd, xs, ys, xf, yf, nf, B);
-    // (decided BEFORE the weights are touched: a layer that stays on the vector-ALU kernel keeps its 28-bit packed weights -- unpacking and re-packing them on every
-    // forward() is a read-modify-write of the whole layer)
+    // (decided BEFORE the weights are touched: a layer that stays on the vector-ALU kernel keeps its 28-bit packed weights -- unpacking and re-packing them on
+    // every forward() is a read-modify-write of the whole layer)
     if (planned != CRC_NTTL1 && !(planned == CRC_NTTL && limbFits(nf, zd, xf, yf))) return false;
     if (w_form == CRC_NTTP) packWeights(true);
     if (planned == CRC_NTTL1) {          // one-channel convolutions have their own matrix-core kernel (kernels_mfma1.hip)
         auto wl = make_shared<DeviceBuffer>(crc_limb_conv1_weights_bytes(ctx()));
         chk(crc_limb_conv1_pack_weights(ctx(), (const uint64_t *)d_w->ptr, nf, xf, yf, wl->ptr, stream()), "crc_limb_conv1_pack_weights");
         chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
-        d_w_canon = d_w; d_w = wl; w_form = CRC_NTTL1;         // (the canonical copy of a one-channel layer is small: kept, so that the weights can go back on the wire)
+        // (the canonical copy of a one-channel layer is small: kept, so that the weights can go back on the wire)
+        d_w_canon = d_w; d_w = wl; w_form = CRC_NTTL1;
         return true;
     }
     return toLimb(d_w, w_form, nf, zd, xf, yf, planned == CRC_NTTL);
@@ -586,7 +617,8 @@ void ConvolutionalLayer::packWeights(bool unpack)
     upload();
     if (streamed) return;
     if (w_form == CRC_NTTL1 && unpack) { d_w = d_w_canon; d_w_canon.reset(); w_form = CRC_NTT; return; }
-    if (w_form == CRC_NTTL || w_form == CRC_NTTL1) { if (unpack) throw logic_error("ConvolutionalLayer " + name + ": weights are in limb form (fuse() / broadcastParameters() must precede the first forward())"); return; }
+    if (w_form == CRC_NTTL || w_form == CRC_NTTL1) { if (unpack) throw logic_error("ConvolutionalLayer " + name +
+        ": weights are in limb form (fuse() / broadcastParameters() must precede the first forward())"); return; }
     if ((w_form == CRC_NTTP) == !unpack) return;
     chk(crc_pack28(ctx(), (uint64_t *)d_w->ptr, (size_t)nf * zd * xf * yf * K(), unpack ? 1 : 0, stream()), "crc_pack28");
     w_form = unpack ? CRC_NTT : CRC_NTTP;
@@ -596,29 +628,35 @@ ciphertext3D ConvolutionalLayer::forward(ciphertext3D input)
     checkInput(input, zd, xd, yd, "ConvolutionalLayer");
     upload();
     ciphertext3D out(input.B, zo, xo, yo, out_form);
-    if (streamed) { stream_form = forwardStreamed(input, out, zd, xd, yd, xs, ys, xf, yf, nf, out_form, d_plain, d_b, d_wtile, d_ytile, g_scratch); return out; }
+    if (streamed) { stream_form = forwardStreamed(input, out, zd, xd, yd, xs, ys, xf, yf, nf, out_form, d_plain, d_b, d_wtile, d_ytile, g_scratch);
+        return out; }
     size_t wb = crc_conv2d_forms_work_bytes(ctx(), input.B, zd, xd, yd, xs, ys, xf, yf, nf, input.form, w_form, out_form);
     if (!wb) throw invalid_argument("ConvolutionalLayer: unsupported geometry");
     ensure(g_scratch, wb);
-    chk(crc_conv2d_forms(ctx(), input.data(), (const uint64_t *)d_w->ptr, w_form, (const uint64_t *)d_b[out_form != CRC_COEFF]->ptr, input.B, zd, xd, yd, xs, ys, xf, yf, nf,
+    chk(crc_conv2d_forms(ctx(), input.data(), (const uint64_t *)d_w->ptr, w_form, (const uint64_t *)d_b[out_form != CRC_COEFF]->ptr, input.B, zd, xd, yd, xs,
+        ys, xf, yf, nf,
                          input.form, out_form, out.data(), g_scratch->ptr, stream()), "crc_conv2d_forms");
     if (out_form == CRC_NTTLC) out.form = CRC_NTTL;         // what the convolution behind reads as its limb-form input
     return out;
 }
 void ConvolutionalLayer::savePlaintextParameters(ostream *outfile)
 {   // order of convolutionalLayer.cpp:213-229
-    if ((int)filters.size() != nf) throw logic_error("ConvolutionalLayer " + name + ": a folded layer has no plaintext parameters to save (save before Network::fuse())");
-    for (int n = 0; n < nf; n++) { for (int z = 0; z < zd; z++) for (int i = 0; i < xf; i++) for (int j = 0; j < yf; j++) filters[n][z][i][j].save(*outfile); biases[n].save(*outfile); outfile->flush(); }
+    if ((int)filters.size() != nf) throw logic_error("ConvolutionalLayer " + name +
+        ": a folded layer has no plaintext parameters to save (save before Network::fuse())");
+    for (int n = 0; n < nf; n++) { for (int z = 0; z < zd; z++) for (int i = 0; i < xf; i++) for (int j = 0; j < yf; j++) filters[n][z][i][j].save(*outfile);
+        biases[n].save(*outfile); outfile->flush(); }
 }
 void ConvolutionalLayer::loadPlaintextParameters(istream *infile)
 {
     filters.assign(nf, plaintext3D(zd, plaintext2D(xf, vector<Plaintext>(yf)))); biases.assign(nf, Plaintext());
-    for (int n = 0; n < nf; n++) { for (int z = 0; z < zd; z++) for (int i = 0; i < xf; i++) for (int j = 0; j < yf; j++) filters[n][z][i][j].load(*infile); biases[n].load(*infile); }
+    for (int n = 0; n < nf; n++) { for (int z = 0; z < zd; z++) for (int i = 0; i < xf; i++) for (int j = 0; j < yf; j++) filters[n][z][i][j].load(*infile);
+        biases[n].load(*infile); }
     filters_already_ntt = false;
 }
 void ConvolutionalLayer::printLayerStructure()
 {
-    cerr << "Convolutional " << name << " : input (" << zd << "," << xd << "," << yd << "); kernel(" << nf << "," << xf << "," << yf << "); stride(" << xs << "," << ys << "); output("
+    cerr << "Convolutional " << name << " : input (" << zd << "," << xd << "," << yd << "); kernel(" << nf << "," << xf << "," << yf << "); stride(" << xs <<
+        "," << ys << "); output("
          << zo << "," << xo << "," << yo << ") " << "run with " << th_count << " threads" << endl;
 }
 
@@ -632,15 +670,21 @@ void FullyConnectedLayer::upload()
     if (weights_already_ntt) return;
     if ((int)weights.size() != out_dim || (int)biases.size() != out_dim) throw invalid_argument("fc: weight/bias count mismatch");
     vector<const Plaintext *> w, b;
-    for (int i = 0; i < out_dim; i++) { if ((int)weights[i].size() != in_dim) throw invalid_argument("fc: row length mismatch"); for (int j = 0; j < in_dim; j++) w.push_back(&weights[i][j]); b.push_back(&biases[i]); }
+    for (int i = 0; i < out_dim; i++) {
+        if ((int)weights[i].size() != in_dim) throw invalid_argument("fc: row length mismatch");
+        for (int j = 0; j < in_dim; j++) w.push_back(&weights[i][j]);
+        b.push_back(&biases[i]);
+    }
     streamed = forced_placement >= 0 ? forced_placement == 1 : tooLargeForHbm(w.size());
     if (forced_placement >= 0) tilewise = forced_placement == 2;
     else if (!streamed && plannedForm(in_dim, 1, 1, 1, 1, 1, 1, out_dim, 0) == CRC_NTTL) {
-        // canonical + limb copy beyond what HBM has left, the limb copy alone within it: build the limb weights tile by tile at the first forward (buildTilewise)
+        // canonical + limb copy beyond what HBM has left, the limb copy alone within it: build the limb weights tile by tile at the first forward
+        // (buildTilewise)
         size_t free_b = 0, total_b = 0;
         chk(crc_mem_info(ctx(), &free_b, &total_b), "crc_mem_info");
         const size_t canon = w.size() * (size_t)K() * N() * 8, limb = crc_limb_weights_bytes(ctx(), out_dim, in_dim, 1, 1), reserve = (size_t)24 << 30;
-        tilewise = (canon + limb + reserve > free_b && limb + reserve + ((size_t)8 << 30) <= free_b) || getenv("CRC_FORCE_TILEWISE") != nullptr;      // (the tests force it on small rings)
+        // (the tests force it on small rings)
+        tilewise = (canon + limb + reserve > free_b && limb + reserve + ((size_t)8 << 30) <= free_b) || getenv("CRC_FORCE_TILEWISE") != nullptr;
     }
     if (streamed) d_plain = uploadPlain(w, 3); else if (!tilewise) d_w = uploadPlain(w, 0);
     d_b[0] = uploadPlain(b, 1); d_b[1] = uploadPlain(b, 2);
@@ -662,7 +706,8 @@ void FullyConnectedLayer::buildTilewise()
         wk = make_shared<DeviceBuffer>(max<size_t>(crc_dense_work_bytes(ctx(), 1, in_dim, ft, CRC_NTT), 256));
         chk(crc_memset(ctx(), fake->ptr, 0, T * 2 * rowb, stream()), "crc_memset");
         for (int z = 0; z < ch; z++) for (int t = 0; t < per_ch; t++)
-            chk(crc_memcpy_d2d(ctx(), (char *)fake->ptr + ((size_t)z * per_ch + t) * 2 * rowb, (char *)fold_bn->d_mean[1]->ptr + (size_t)z * rowb, rowb, stream()), "crc_memcpy_d2d");
+            chk(crc_memcpy_d2d(ctx(), (char *)fake->ptr + ((size_t)z * per_ch + t) * 2 * rowb, (char *)fold_bn->d_mean[1]->ptr + (size_t)z * rowb, rowb,
+                stream()), "crc_memcpy_d2d");
         bias.resize((size_t)out_dim * k * n); corr.resize((size_t)ft * 2 * k * n);
         chk(crc_memcpy_d2h(ctx(), bias.data(), d_b[1]->ptr, bias.size() * 8, stream()), "crc_memcpy_d2h");
         chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
@@ -675,8 +720,10 @@ void FullyConnectedLayer::buildTilewise()
         shared_ptr<DeviceBuffer> wt = uploadPlain(w, 0);                                   // lift + NTT of the tile's plaintexts (canonical, scratch)
         if (fold_bn) {
             for (int f = 0; f < fn; f++)                                                   // w'[f][z][tap] = w (*) s[z]
-                chk(crc_multiply_plain_ntt(ctx(), (uint64_t *)wt->ptr + (size_t)f * T * k * n, (const uint64_t *)fold_bn->d_invstd->ptr, T, per_ch, 1, stream()), "crc_multiply_plain_ntt");
-            chk(crc_dense(ctx(), (const uint64_t *)fake->ptr, (const uint64_t *)wt->ptr, nullptr, 1, in_dim, fn, CRC_NTT, CRC_NTT, (uint64_t *)outc->ptr, wk->ptr, stream()), "crc_dense");
+                chk(crc_multiply_plain_ntt(ctx(), (uint64_t *)wt->ptr + (size_t)f * T * k * n, (const uint64_t *)fold_bn->d_invstd->ptr, T, per_ch, 1,
+                    stream()), "crc_multiply_plain_ntt");
+            chk(crc_dense(ctx(), (const uint64_t *)fake->ptr, (const uint64_t *)wt->ptr, nullptr, 1, in_dim, fn, CRC_NTT, CRC_NTT, (uint64_t *)outc->ptr,
+                wk->ptr, stream()), "crc_dense");
             chk(crc_memcpy_d2h(ctx(), corr.data(), outc->ptr, (size_t)fn * 2 * rowb, stream()), "crc_memcpy_d2h");
             chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
             for (int f = 0; f < fn; f++) for (int m = 0; m < k; m++) for (int s2 = 0; s2 < n; s2++) {
@@ -698,15 +745,18 @@ void FullyConnectedLayer::buildTilewise()
     }
     w_form = CRC_NTTL; tile_built = true;
 }
-size_t FullyConnectedLayer::deviceBytes() const { return bytesOf(d_w) + bytesOf(d_b[0]) + bytesOf(d_b[1]) + bytesOf(d_plain) + bytesOf(d_wtile) + bytesOf(d_ytile); }
-string FullyConnectedLayer::kernelName() const { return macKernelName(streamed ? stream_form : w_form, streamed) + (tilewise ? ", limb weights built tile by tile" : ""); }
+size_t FullyConnectedLayer::deviceBytes() const { return bytesOf(d_w) + bytesOf(d_b[0]) + bytesOf(d_b[1]) + bytesOf(d_plain) + bytesOf(d_wtile) +
+    bytesOf(d_ytile); }
+string FullyConnectedLayer::kernelName() const { return macKernelName(streamed ? stream_form : w_form, streamed) + (tilewise ?
+    ", limb weights built tile by tile" : ""); }
 int FullyConnectedLayer::placement() { upload(); return streamed ? 1 : tilewise ? 2 : 0; }
 bool FullyConnectedLayer::streamsOnMatrixCores(int B) { upload(); return streamed && plannedForm(in_dim, 1, 1, 1, 1, 1, 1, out_dim, B) == CRC_NTTL; }
 void FullyConnectedLayer::restoreCanonical()
 {
     if (w_form == CRC_NTTP) { packWeights(true); return; }
     if (w_form != CRC_NTTL) return;
-    if ((int)weights.size() != out_dim) throw logic_error("FullyConnectedLayer " + name + ": weights are in limb form and there are no plaintexts to rebuild them from");
+    if ((int)weights.size() != out_dim) throw logic_error("FullyConnectedLayer " + name +
+        ": weights are in limb form and there are no plaintexts to rebuild them from");
     // (a tile-wise layer goes back to "not built": the next forward builds its limb tensor again, with whatever batch-norm layer fuse() folds into it)
     d_w.reset(); w_form = CRC_NTT; weights_already_ntt = false; tile_built = false;
     upload();
@@ -714,9 +764,10 @@ void FullyConnectedLayer::restoreCanonical()
 void FullyConnectedLayer::deviceParameters(vector<shared_ptr<DeviceBuffer>> &out, bool allocate_only)
 {
     if (allocate_only && !weights_already_ntt && forced_placement == 2) {
-        // a tile-wise layer is never on the wire (its only device copy is the limb tensor -- 182 GiB for PlainModelWoPad's fc3 at n = 16384, k = 4 -- which every
-        // rank builds from its own plaintexts, deterministically): a receiving rank needs the model's plaintexts like the root
-        if ((int)weights.size() != out_dim) throw logic_error("FullyConnectedLayer " + name + ": tile-wise weights are built on every rank -- a receiving rank must load the model too");
+        // a tile-wise layer is never on the wire (its only device copy is the limb tensor -- 182 GiB for PlainModelWoPad's fc3 at n = 16384, k = 4 -- which
+        // every rank builds from its own plaintexts, deterministically): a receiving rank needs the model's plaintexts like the root
+        if ((int)weights.size() != out_dim) throw logic_error("FullyConnectedLayer " + name +
+            ": tile-wise weights are built on every rank -- a receiving rank must load the model too");
     } else if (allocate_only && !weights_already_ntt) {
         const size_t rowb = (size_t)K() * N() * 8;
         streamed = forced_placement >= 0 ? forced_placement == 1 : tooLargeForHbm((size_t)in_dim * out_dim);
@@ -736,7 +787,8 @@ bool FullyConnectedLayer::limbWeights(int B)
     if (streamed) return false;
     if (tilewise) { buildTilewise(); return true; }
     if (w_form == CRC_NTTL) return true;
-    if (plannedForm(in_dim, 1, 1, 1, 1, 1, 1, out_dim, B) != CRC_NTTL || !limbFits(out_dim, in_dim, 1, 1)) return false;      // (before the packed weights are touched)
+    // (before the packed weights are touched)
+    if (plannedForm(in_dim, 1, 1, 1, 1, 1, 1, out_dim, B) != CRC_NTTL || !limbFits(out_dim, in_dim, 1, 1)) return false;
     if (w_form == CRC_NTTP) packWeights(true);
     return toLimb(d_w, w_form, out_dim, in_dim, 1, 1, true);
 }
@@ -744,22 +796,26 @@ void FullyConnectedLayer::packWeights(bool unpack)
 {
     upload();
     if (streamed || (tilewise && !tile_built)) return;
-    if (w_form == CRC_NTTL) { if (unpack) throw logic_error("FullyConnectedLayer " + name + ": weights are in limb form (fuse() / broadcastParameters() must precede the first forward())"); return; }
+    if (w_form == CRC_NTTL) { if (unpack) throw logic_error("FullyConnectedLayer " + name +
+        ": weights are in limb form (fuse() / broadcastParameters() must precede the first forward())"); return; }
     if ((w_form == CRC_NTTP) == !unpack) return;
     chk(crc_pack28(ctx(), (uint64_t *)d_w->ptr, (size_t)in_dim * out_dim * K(), unpack ? 1 : 0, stream()), "crc_pack28");
     w_form = unpack ? CRC_NTT : CRC_NTTP;
 }
 ciphertext3D FullyConnectedLayer::forward(ciphertext3D input)
 {
-    if (!input.buf || input.zd * input.xd * input.yd != in_dim) throw invalid_argument("FullyConnectedLayer: input size does not match in_dim");   // reshapeInput, :38-56
+    // reshapeInput, :38-56
+    if (!input.buf || input.zd * input.xd * input.yd != in_dim) throw invalid_argument("FullyConnectedLayer: input size does not match in_dim");
     upload();
-    // a tile-wise layer has no canonical weights: whoever reaches it first -- Network::forward through limbWeights, a direct call, a network with matrix_cores off --
-    // builds the limb tensor, the only form its weights exist in (the layer then runs on the limb GEMM whatever the plan would have been)
+    // a tile-wise layer has no canonical weights: whoever reaches it first -- Network::forward through limbWeights, a direct call, a network with matrix_cores
+    // off -- builds the limb tensor, the only form its weights exist in (the layer then runs on the limb GEMM whatever the plan would have been)
     if (tilewise && !tile_built) buildTilewise();
     ciphertext3D out(input.B, 1, out_dim, 1, out_form);
-    if (streamed) { stream_form = forwardStreamed(input, out, in_dim, 1, 1, 1, 1, 1, 1, out_dim, out_form, d_plain, d_b, d_wtile, d_ytile, g_scratch); return out; }
+    if (streamed) { stream_form = forwardStreamed(input, out, in_dim, 1, 1, 1, 1, 1, 1, out_dim, out_form, d_plain, d_b, d_wtile, d_ytile, g_scratch);
+        return out; }
     ensure(g_scratch, crc_conv2d_forms_work_bytes(ctx(), input.B, in_dim, 1, 1, 1, 1, 1, 1, out_dim, input.form, w_form, out_form));
-    chk(crc_dense_forms(ctx(), input.data(), (const uint64_t *)d_w->ptr, w_form, (const uint64_t *)d_b[out_form != CRC_COEFF]->ptr, input.B, in_dim, out_dim, input.form, out_form,
+    chk(crc_dense_forms(ctx(), input.data(), (const uint64_t *)d_w->ptr, w_form, (const uint64_t *)d_b[out_form != CRC_COEFF]->ptr, input.B, in_dim, out_dim,
+        input.form, out_form,
                         out.data(), g_scratch->ptr, stream()), "crc_dense_forms");
     return out;
 }
@@ -773,7 +829,8 @@ void FullyConnectedLayer::loadPlaintextParameters(istream *infile)
     for (int i = 0; i < out_dim; i++) { for (int j = 0; j < in_dim; j++) weights[i][j].load(*infile); biases[i].load(*infile); }
     weights_already_ntt = false;
 }
-void FullyConnectedLayer::printLayerStructure() { cerr << "Fully connected " << name << " : (" << in_dim << " -> " << out_dim << ")" << "run with " << th_count << " threads" << endl; }
+void FullyConnectedLayer::printLayerStructure() { cerr << "Fully connected " << name << " : (" << in_dim << " -> " << out_dim << ")" << "run with " <<
+    th_count << " threads" << endl; }
 
 // ---- Pooling ----------------------------------------------------------------------------------------------------------
 PoolingLayer::PoolingLayer(string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf)
@@ -782,16 +839,19 @@ ciphertext3D PoolingLayer::forward(ciphertext3D input)
 {
     checkInput(input, zd, xd, yd, "PoolingLayer");
     ciphertext3D out(input.B, zo, xo, yo, input.form);
-    chk(crc_pool(ctx(), input.data(), input.B, zd, xd, yd, xs, ys, xf, yf, d_div ? (const uint64_t *)d_div->ptr : nullptr, input.form, out.data(), stream()), "crc_pool");
+    chk(crc_pool(ctx(), input.data(), input.B, zd, xd, yd, xs, ys, xf, yf, d_div ? (const uint64_t *)d_div->ptr : nullptr, input.form, out.data(), stream()),
+        "crc_pool");
     if (out_form != out.form) {      // pooling is form-preserving; convert only if the network asked for the other form
-        if (out_form == CRC_NTT) chk(crc_ntt_fwd(ctx(), out.data(), out.count(), 2, stream()), "crc_ntt_fwd"); else chk(crc_ntt_inv(ctx(), out.data(), out.count(), 2, stream()), "crc_ntt_inv");
+        if (out_form == CRC_NTT) chk(crc_ntt_fwd(ctx(), out.data(), out.count(), 2, stream()), "crc_ntt_fwd");
+            else chk(crc_ntt_inv(ctx(), out.data(), out.count(), 2, stream()), "crc_ntt_inv");
         out.form = out_form;
     }
     return out;
 }
 void PoolingLayer::printLayerStructure()
 {
-    cerr << "Pooling " << name << " : input (" << zo << "," << xd << "," << yd << "); kernel(" << xf << "," << yf << "); stride(" << xs << "," << ys << "); output(" << zo << "," << xo << "," << yo << ")" << endl;
+    cerr << "Pooling " << name << " : input (" << zo << "," << xd << "," << yd << "); kernel(" << xf << "," << yf << "); stride(" << xs << "," << ys <<
+        "); output(" << zo << "," << xo << "," << yo << ")" << endl;
 }
 AvgPoolingLayer::AvgPoolingLayer(string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf) : PoolingLayer(name, xd, yd, zd, xs, ys, xf, yf)
 {
@@ -807,7 +867,8 @@ ciphertext3D SquareLayer::forward(ciphertext3D input)
     // either form in, the requested form out: crc_square_relin_forms keeps an NTT-resident network resident
     ciphertext3D out(input.B, input.zd, input.xd, input.yd, out_form);
     ensure(g_scratch, crc_square_relin_work_bytes(ctx(), input.count(), 16));
-    chk(crc_square_relin_forms(ctx(), input.data(), input.form, input.count(), (const uint64_t *)ev_keys16->ptr, 16, out.data(), out_form, g_scratch->ptr, stream()),
+    chk(crc_square_relin_forms(ctx(), input.data(), input.form, input.count(), (const uint64_t *)ev_keys16->ptr, 16, out.data(), out_form, g_scratch->ptr,
+        stream()),
         "crc_square_relin_forms");
     return out;
 }
@@ -815,13 +876,14 @@ void SquareLayer::printLayerStructure() { cerr << "Square run with " << th_count
 
 // ---- Square + pooling (Network::fuse) ---------------------------------------------------------------------------------
 SquarePoolLayer::SquarePoolLayer(string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf, int th_count, shared_ptr<DeviceBuffer> d_div)
-    : Layer(name), xd(xd), yd(yd), zd(zd), xs(xs), ys(ys), xf(xf), yf(yf), xo((xd - xf) / xs + 1), yo((yd - yf) / ys + 1), zo(zd), th_count(th_count), d_div(d_div) {}
+    : Layer(name), xd(xd), yd(yd), zd(zd), xs(xs), ys(ys), xf(xf), yf(yf), xo((xd - xf) / xs + 1), yo((yd - yf) / ys + 1), zo(zd), th_count(th_count),
+        d_div(d_div) {}
 ciphertext3D SquarePoolLayer::forward(ciphertext3D input)
 {
     checkInput(input, zd, xd, yd, "SquarePoolLayer");
     if (!ev_keys16) throw invalid_argument("not enough evaluation keys");
-    // an average pooling's divisor multiplies slot-wise: the pooled tensor is made NTT-resident for it, and brought back to coefficients when the network asked for
-    // those.  The packed / limb operand forms are not produced here (Network::forward never asks this layer for them)
+    // an average pooling's divisor multiplies slot-wise: the pooled tensor is made NTT-resident for it, and brought back to coefficients when the network asked
+    // for those.  The packed / limb operand forms are not produced here (Network::forward never asks this layer for them)
     if (out_form != CRC_NTT && out_form != CRC_COEFF) throw invalid_argument("SquarePoolLayer: out_form must be CRC_NTT or CRC_COEFF");
     const int of = d_div ? CRC_NTT : out_form;
     ciphertext3D out(input.B, zo, xo, yo, of);
@@ -833,12 +895,14 @@ ciphertext3D SquarePoolLayer::forward(ciphertext3D input)
 }
 void SquarePoolLayer::printLayerStructure()
 {
-    cerr << "Square + Pooling " << name << " : input (" << zd << "," << xd << "," << yd << "); kernel(" << xf << "," << yf << "); stride(" << xs << "," << ys << "); output(" << zo << "," << xo << ","
+    cerr << "Square + Pooling " << name << " : input (" << zd << "," << xd << "," << yd << "); kernel(" << xf << "," << yf << "); stride(" << xs << "," <<
+        ys << "); output(" << zo << "," << xo << ","
          << yo << "); one key switch per pooled ciphertext" << endl;
 }
 
 // ---- BatchNorm --------------------------------------------------------------------------------------------------------
-BatchNormLayer::BatchNormLayer(string name, int num_channels, vector<Plaintext> &mean, vector<Plaintext> &var) : Layer(name), num_channels(num_channels), mean(mean), var(var) {}
+BatchNormLayer::BatchNormLayer(string name, int num_channels, vector<Plaintext> &mean, vector<Plaintext> &var) : Layer(name), num_channels(num_channels),
+    mean(mean), var(var) {}
 BatchNormLayer::BatchNormLayer(string name, int num_channels, istream *infile) : Layer(name), num_channels(num_channels) { loadPlaintextParameters(infile); }
 void BatchNormLayer::upload()
 {
@@ -852,7 +916,8 @@ void BatchNormLayer::deviceParameters(vector<shared_ptr<DeviceBuffer>> &out, boo
 {
     if (allocate_only && !d_invstd) {
         const size_t rowb = (size_t)K() * N() * 8;
-        d_mean[0] = make_shared<DeviceBuffer>(num_channels * rowb); d_mean[1] = make_shared<DeviceBuffer>(num_channels * rowb); d_invstd = make_shared<DeviceBuffer>(num_channels * rowb);
+        d_mean[0] = make_shared<DeviceBuffer>(num_channels * rowb); d_mean[1] = make_shared<DeviceBuffer>(num_channels * rowb);
+            d_invstd = make_shared<DeviceBuffer>(num_channels * rowb);
     }
     upload();
     out.push_back(d_mean[0]); out.push_back(d_mean[1]); out.push_back(d_invstd);
@@ -862,14 +927,17 @@ ciphertext3D BatchNormLayer::forward(ciphertext3D input)
     if (!input.buf || input.zd != num_channels) throw invalid_argument("BatchNormLayer: channel count mismatch");
     upload();
     ciphertext3D out = deepCopyImage(input);                // the reference works on its by-value copy (batchNormLayer.cpp:29)
-    chk(crc_batchnorm(ctx(), out.data(), out.B, out.zd, out.xd, out.yd, (const uint64_t *)d_mean[out.form == CRC_NTT]->ptr, (const uint64_t *)d_invstd->ptr, out.form, stream()), "crc_batchnorm");
+    chk(crc_batchnorm(ctx(), out.data(), out.B, out.zd, out.xd, out.yd, (const uint64_t *)d_mean[out.form == CRC_NTT]->ptr, (const uint64_t *)d_invstd->ptr,
+        out.form, stream()), "crc_batchnorm");
     if (out_form != out.form) {
-        if (out_form == CRC_NTT) chk(crc_ntt_fwd(ctx(), out.data(), out.count(), 2, stream()), "crc_ntt_fwd"); else chk(crc_ntt_inv(ctx(), out.data(), out.count(), 2, stream()), "crc_ntt_inv");
+        if (out_form == CRC_NTT) chk(crc_ntt_fwd(ctx(), out.data(), out.count(), 2, stream()), "crc_ntt_fwd");
+            else chk(crc_ntt_inv(ctx(), out.data(), out.count(), 2, stream()), "crc_ntt_inv");
         out.form = out_form;
     }
     return out;
 }
-void BatchNormLayer::savePlaintextParameters(ostream *outfile) { for (int i = 0; i < num_channels; i++) { mean[i].save(*outfile); var[i].save(*outfile); outfile->flush(); } }
+void BatchNormLayer::savePlaintextParameters(ostream *outfile) { for (int i = 0; i < num_channels; i++) { mean[i].save(*outfile); var[i].save(*outfile);
+    outfile->flush(); } }
 void BatchNormLayer::loadPlaintextParameters(istream *infile)
 {
     mean.assign(num_channels, Plaintext()); var.assign(num_channels, Plaintext());
@@ -893,7 +961,8 @@ ciphertext3D Network::forward(ciphertext3D input)
     // conv / dense weights go into the MAC kernels' operand form (28-bit limb pairs) once; moduli above 55 bits cannot be packed
     bool packable = true;
     { vector<uint64_t> q(K()); crc_ctx_table(ctx(), "q", q.data(), K()); for (uint64_t v : q) if (v >> 55) packable = false; }
-    auto isMac = [&](int i) { return i >= 0 && i < L && (dynamic_pointer_cast<ConvolutionalLayer>(layers[i]) || dynamic_pointer_cast<FullyConnectedLayer>(layers[i])); };
+    auto isMac = [&](int i) { return i >= 0 && i < L && (dynamic_pointer_cast<ConvolutionalLayer>(layers[i]) ||
+        dynamic_pointer_cast<FullyConnectedLayer>(layers[i])); };
     vector<char> limb(L, 0), streams(L, 0);
     // two-level chunking: the layers in front of the first dense layer on sub-batches of head_chunk images, the dense layers on the whole batch
     int split = L;
@@ -903,26 +972,28 @@ ciphertext3D Network::forward(ciphertext3D input)
     if (packable)
         for (int i = 0; i < L; i++) {
             const int Bi = chunked && i < split ? head_chunk : input.B;
-            if (auto c = dynamic_pointer_cast<ConvolutionalLayer>(layers[i])) { limb[i] = matrix_cores && c->limbWeights(Bi); if (!limb[i]) c->packWeights(false); }
+            if (auto c = dynamic_pointer_cast<ConvolutionalLayer>(layers[i])) { limb[i] = matrix_cores && c->limbWeights(Bi);
+                if (!limb[i]) c->packWeights(false); }
             else if (auto f = dynamic_pointer_cast<FullyConnectedLayer>(layers[i])) {
                 limb[i] = matrix_cores && f->limbWeights(Bi);
                 if (!limb[i]) f->packWeights(false);
-                // a STREAMED dense layer that will run on the matrix cores (64-filter limb tiles built inside the forward) reads a limb tensor like a resident one:
-                // the chunks of a group are packed straight into it, and no second copy of the group's input is made inside the layer
+                // a STREAMED dense layer that will run on the matrix cores (64-filter limb tiles built inside the forward) reads a limb tensor like a resident
+                // one: the chunks of a group are packed straight into it, and no second copy of the group's input is made inside the layer
                 if (matrix_cores && f->streamsOnMatrixCores(Bi)) { limb[i] = 1; streams[i] = 1; }
             }
         }
     for (int i = 0; i < L; i++) {
         bool coeff = !ntt_resident || i == L - 1 || i + 1 == layer_before_reenc;
-        // a conv / dense layer feeding another one hands its tensor over packed as well
-        // ... and a limb layer feeding a DENSE limb layer hands it over in limb form (not across the chunk boundary: a dense layer's limb tensor is laid out for its
-        // whole batch, the chunks are assembled into it below)
-        const bool to_dense_limb = i + 1 < L && limb[i] && !streams[i] && limb[i + 1] && dynamic_pointer_cast<FullyConnectedLayer>(layers[i + 1]) && !(chunked && i + 1 == split);
+        // a conv / dense layer feeding another one hands its tensor over packed as well ... and a limb layer feeding a DENSE limb layer hands it over in limb
+        // form (not across the chunk boundary: a dense layer's limb tensor is laid out for its whole batch, the chunks are assembled into it below)
+        const bool to_dense_limb = i + 1 < L && limb[i] && !streams[i] && limb[i + 1] && dynamic_pointer_cast<FullyConnectedLayer>(layers[i + 1]) &&
+            !(chunked && i + 1 == split);
         // ... and a one-channel convolution writes the limb tensor of a matrix-core CONVOLUTION behind it itself
         auto ci = dynamic_pointer_cast<ConvolutionalLayer>(layers[i]);
         auto cn = i + 1 < L ? dynamic_pointer_cast<ConvolutionalLayer>(layers[i + 1]) : nullptr;
         const bool to_conv_limb = ci && cn && ci->w_form == CRC_NTTL1 && cn->w_form == CRC_NTTL;
-        layers[i]->out_form = coeff ? CRC_COEFF : to_dense_limb && max_num_of_reencryptions < 0 ? CRC_NTTL : to_conv_limb && max_num_of_reencryptions < 0 ? CRC_NTTLC
+        layers[i]->out_form = coeff ? CRC_COEFF : to_dense_limb && max_num_of_reencryptions < 0 ? CRC_NTTL : to_conv_limb && max_num_of_reencryptions < 0 ?
+            CRC_NTTLC
                             : (packable && max_num_of_reencryptions < 0 && isMac(i) && isMac(i + 1) ? CRC_NTTP : CRC_NTT);
     }
     last_layer_ms.assign(L, 0.0);
@@ -932,7 +1003,8 @@ ciphertext3D Network::forward(ciphertext3D input)
     vector<pair<int, pair<void *, void *>>> timed;
     size_t ev_used = 0;
     if (time_with_events && !event_pool) event_pool = make_shared<EventPool>();
-    auto next_event = [&]() { auto &ev = event_pool->ev; if (ev_used == ev.size()) { void *e = nullptr; chk(crc_event_create(ctx(), &e), "crc_event_create"); ev.push_back(e); } return ev[ev_used++]; };
+    auto next_event = [&]() { auto &ev = event_pool->ev; if (ev_used == ev.size()) { void *e = nullptr; chk(crc_event_create(ctx(), &e), "crc_event_create");
+        ev.push_back(e); } return ev[ev_used++]; };
     auto run_layer = [&](int i, const ciphertext3D &in) {
         last_layer_launches[i]++;
         if (time_with_events) {
@@ -950,7 +1022,8 @@ ciphertext3D Network::forward(ciphertext3D input)
         return out;
     };
     auto read_events = [&]() {
-        for (auto &t : timed) { float ms = 0; chk(crc_event_elapsed_ms(ctx(), t.second.first, t.second.second, &ms), "crc_event_elapsed_ms"); last_layer_ms[t.first] += ms; }
+        for (auto &t : timed) { float ms = 0; chk(crc_event_elapsed_ms(ctx(), t.second.first, t.second.second, &ms), "crc_event_elapsed_ms");
+            last_layer_ms[t.first] += ms; }
         timed.clear();
     };
     if (max_num_of_reencryptions >= 0) {                    // network.cpp:52-96
@@ -991,7 +1064,8 @@ ciphertext3D Network::forward(ciphertext3D input)
             if (limb[split])      // every chunk's tensor goes straight into the dense layer's K-blocked limb tensor
                 chk(crc_limb_pack_tensor_at(ctx(), t.data(), t.form, Bc, (int)out_cts, 1, 1, tail_in.data(), B, b0, stream()), "crc_limb_pack_tensor_at");
             else
-                chk(crc_memcpy_d2d(ctx(), (char *)tail_in.data() + (size_t)b0 * out_cts * ctBytes(), t.data(), (size_t)Bc * out_cts * ctBytes(), stream()), "crc_memcpy_d2d");
+                chk(crc_memcpy_d2d(ctx(), (char *)tail_in.data() + (size_t)b0 * out_cts * ctBytes(), t.data(), (size_t)Bc * out_cts * ctBytes(), stream()),
+                    "crc_memcpy_d2d");
         }
         chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
         input = tail_in;
@@ -1011,7 +1085,8 @@ ciphertext3D Network::forward(ciphertext3D input)
         if (i + 1 < L) { OutHint hint(&act_slot[input.buf == act_slot[0] ? 1 : 0]); input = run_layer(i, input); }
         else {
             ciphertext3D output = run_layer(i, input);
-            // a last layer that hands its input back (none of CrCNN's does) must not give the caller a tensor that lives in an activation slot the next forward overwrites
+            // a last layer that hands its input back (none of CrCNN's does) must not give the caller a tensor that lives in an activation slot the next forward
+            // overwrites
             if (output.buf && (output.buf == act_slot[0] || output.buf == act_slot[1] || output.buf == tail_slot)) {
                 ciphertext3D own(output.B, output.zd, output.xd, output.yd, output.form);
                 chk(crc_memcpy_d2d(ctx(), own.data(), output.data(), output.count() * ctBytes(), stream()), "crc_memcpy_d2d");
@@ -1088,8 +1163,8 @@ int Network::fuse()
         removed++;
     };
     for (auto &l : layers) {                                // the folding kernels work on canonical residues
-        // (a network that has already run holds its weights in the MAC kernels' operand forms: packed residues are unpacked, matrix-core forms -- which drop the
-        // canonical copy -- are rebuilt from the layer's plaintexts, so fuse() may follow a forward())
+        // (a network that has already run holds its weights in the MAC kernels' operand forms: packed residues are unpacked, matrix-core forms -- which drop
+        // the canonical copy -- are rebuilt from the layer's plaintexts, so fuse() may follow a forward())
         if (auto c = dynamic_pointer_cast<ConvolutionalLayer>(l)) c->restoreCanonical();
         else if (auto f = dynamic_pointer_cast<FullyConnectedLayer>(l)) f->restoreCanonical();
     }
@@ -1115,15 +1190,19 @@ int Network::fuse()
         // the cost model lives behind the C ABI (crc_plan_fold_pool), shared with netrun.py
         const long long T2 = (long long)conv->zd * xf2 * yf2;
         int fold = 0;
-        chk(crc_plan_fold_pool(ctx(), conv->zd, conv->xd, conv->yd, conv->xs, conv->ys, conv->xf, conv->yf, conv->nf, pool->xs, pool->ys, pool->xf, pool->yf, &fold), "crc_plan_fold_pool");
+        chk(crc_plan_fold_pool(ctx(), conv->zd, conv->xd, conv->yd, conv->xs, conv->ys, conv->xf, conv->yf, conv->nf, pool->xs, pool->ys, pool->xf, pool->yf,
+            &fold), "crc_plan_fold_pool");
         if (!fold) continue;
         conv->upload();
         vector<Plaintext> nob; plaintext4D nof;
-        auto fused = make_shared<ConvolutionalLayer>(conv->name + "+" + pool->name, conv->xd, conv->yd, conv->zd, xs2, ys2, xf2, yf2, conv->nf, conv->th_count, nof, nob);
+        auto fused = make_shared<ConvolutionalLayer>(conv->name + "+" + pool->name, conv->xd, conv->yd, conv->zd, xs2, ys2, xf2, yf2, conv->nf,
+            conv->th_count, nof, nob);
         fused->d_w = make_shared<DeviceBuffer>((size_t)conv->nf * T2 * rowb);
         fused->d_b[1] = make_shared<DeviceBuffer>((size_t)conv->nf * rowb);
-        chk(crc_conv2d_fold_pool(ctx(), (const uint64_t *)conv->d_w->ptr, (const uint64_t *)conv->d_b[1]->ptr, pool->d_div ? (const uint64_t *)pool->d_div->ptr : nullptr,
-                                 conv->nf, conv->zd, conv->xf, conv->yf, conv->xs, conv->ys, pool->xf, pool->yf, (uint64_t *)fused->d_w->ptr, (uint64_t *)fused->d_b[1]->ptr, stream()),
+        chk(crc_conv2d_fold_pool(ctx(), (const uint64_t *)conv->d_w->ptr, (const uint64_t *)conv->d_b[1]->ptr, pool->d_div ?
+            (const uint64_t *)pool->d_div->ptr : nullptr,
+                                 conv->nf, conv->zd, conv->xf, conv->yf, conv->xs, conv->ys, pool->xf, pool->yf, (uint64_t *)fused->d_w->ptr,
+                                     (uint64_t *)fused->d_b[1]->ptr, stream()),
             "crc_conv2d_fold_pool");
         fused->d_b[0] = inttCopy(fused->d_b[1], conv->nf);
         fused->filters_already_ntt = true;
@@ -1136,7 +1215,8 @@ int Network::fuse()
         auto pool = dynamic_pointer_cast<PoolingLayer>(layers[i + 1]);
         if (!sq || !pool || refreshBetween(i)) continue;
         if (!crc_square_pool_relin_supported(ctx(), 16, pool->xf, pool->yf)) continue;
-        layers[i] = make_shared<SquarePoolLayer>(sq->name + "+" + pool->name, pool->xd, pool->yd, pool->zd, pool->xs, pool->ys, pool->xf, pool->yf, sq->th_count,
+        layers[i] = make_shared<SquarePoolLayer>(sq->name + "+" + pool->name, pool->xd, pool->yd, pool->zd, pool->xs, pool->ys, pool->xf, pool->yf,
+            sq->th_count,
                                                  pool->d_div);
         eraseLayer(i + 1);
     }
@@ -1149,10 +1229,12 @@ int Network::fuse()
         if (!conv && !fc) continue;
         const int ch = bn->num_channels;
         int F, per_ch, T;
-        if (conv) { if (conv->zd != ch) continue; F = conv->nf; per_ch = conv->xf * conv->yf; T = conv->zd * per_ch; conv->upload(); if (conv->streamed) continue; }
+        if (conv) { if (conv->zd != ch) continue; F = conv->nf; per_ch = conv->xf * conv->yf; T = conv->zd * per_ch; conv->upload();
+            if (conv->streamed) continue; }
         else { if (fc->in_dim % ch) continue; F = fc->out_dim; per_ch = fc->in_dim / ch; T = fc->in_dim; fc->upload(); if (fc->streamed) continue; }
         bn->upload();
-        if (fc && fc->tilewise) {                           // no canonical weights to fold into: the fold is applied tile by tile when the limb weights are built
+        // no canonical weights to fold into: the fold is applied tile by tile when the limb weights are built
+        if (fc && fc->tilewise) {
             if (fc->tile_built) continue;
             fc->fold_bn = bn;
             layers[i + 1]->name = bn->name + "+" + layers[i + 1]->name;
@@ -1163,13 +1245,16 @@ int Network::fuse()
         shared_ptr<DeviceBuffer> *db = conv ? conv->d_b : fc->d_b;
         // w'[f][z][tap] = w (*) s[z]
         for (int f = 0; f < F; f++)
-            chk(crc_multiply_plain_ntt(ctx(), (uint64_t *)dw->ptr + (size_t)f * T * k * n, (const uint64_t *)bn->d_invstd->ptr, T, per_ch, 1, stream()), "crc_multiply_plain_ntt");
+            chk(crc_multiply_plain_ntt(ctx(), (uint64_t *)dw->ptr + (size_t)f * T * k * n, (const uint64_t *)bn->d_invstd->ptr, T, per_ch, 1, stream()),
+                "crc_multiply_plain_ntt");
         // correction[f] = sum_t w'[f][t] (*) M[z(t)]: the dense kernel on one pseudo-image whose ciphertexts are (M[z(t)], 0)
         DeviceBuffer fake((size_t)T * 2 * rowb), outc((size_t)F * 2 * rowb), wk(max<size_t>(crc_dense_work_bytes(ctx(), 1, T, F, CRC_NTT), 256));
         chk(crc_memset(ctx(), fake.ptr, 0, (size_t)T * 2 * rowb, stream()), "crc_memset");
         for (int z = 0; z < ch; z++) for (int t = 0; t < per_ch; t++)
-            chk(crc_memcpy_d2d(ctx(), (char *)fake.ptr + ((size_t)z * per_ch + t) * 2 * rowb, (char *)bn->d_mean[1]->ptr + (size_t)z * rowb, rowb, stream()), "crc_memcpy_d2d");
-        chk(crc_dense(ctx(), (const uint64_t *)fake.ptr, (const uint64_t *)dw->ptr, nullptr, 1, T, F, CRC_NTT, CRC_NTT, (uint64_t *)outc.ptr, wk.ptr, stream()), "crc_dense");
+            chk(crc_memcpy_d2d(ctx(), (char *)fake.ptr + ((size_t)z * per_ch + t) * 2 * rowb, (char *)bn->d_mean[1]->ptr + (size_t)z * rowb, rowb, stream()),
+                "crc_memcpy_d2d");
+        chk(crc_dense(ctx(), (const uint64_t *)fake.ptr, (const uint64_t *)dw->ptr, nullptr, 1, T, F, CRC_NTT, CRC_NTT, (uint64_t *)outc.ptr, wk.ptr,
+            stream()), "crc_dense");
         vector<uint64_t> corr((size_t)F * 2 * k * n), bias((size_t)F * k * n), q(k);
         chk(crc_memcpy_d2h(ctx(), corr.data(), outc.ptr, corr.size() * 8, stream()), "crc_memcpy_d2h");
         chk(crc_memcpy_d2h(ctx(), bias.data(), db[1]->ptr, bias.size() * 8, stream()), "crc_memcpy_d2h");
@@ -1202,7 +1287,8 @@ vector<float> CnnBuilder::getPretrained(string var_name)
 }
 static vector<Plaintext> encodeAll(const vector<float> &v)
 {
-    // compact form (crc_encode_f32_compact: the 96 coefficients the encoder can set), encoded and turned into Plaintexts on the host threads (csrc/host_parallel.h)
+    // compact form (crc_encode_f32_compact: the 96 coefficients the encoder can set), encoded and turned into Plaintexts on the host threads
+    // (csrc/host_parallel.h)
     const int n = N();
     vector<uint64_t> cp(v.size() * (size_t)CRC_PLAIN_COMPACT_WORDS); vector<int32_t> cc(v.size());
     chk(crc_encode_f32_compact(ctx(), v.data(), v.size(), cp.data(), cc.data()), "crc_encode_f32_compact");
@@ -1212,12 +1298,14 @@ static vector<Plaintext> encodeAll(const vector<float> &v)
             const uint64_t *row = cp.data() + i * CRC_PLAIN_COMPACT_WORDS;
             Plaintext &p = out[i]; p.coeff_count_ = cc[i];
             for (int j = 0; j < CRC_PLAIN_COMPACT_LOW; j++) if (row[j]) p.nz.emplace_back(j, row[j]);
-            for (int j = 0; j < CRC_PLAIN_COMPACT_HIGH; j++) if (row[CRC_PLAIN_COMPACT_LOW + j]) p.nz.emplace_back(n - CRC_PLAIN_COMPACT_HIGH + j, row[CRC_PLAIN_COMPACT_LOW + j]);
+            for (int j = 0; j < CRC_PLAIN_COMPACT_HIGH; j++) if (row[CRC_PLAIN_COMPACT_LOW + j]) p.nz.emplace_back(n - CRC_PLAIN_COMPACT_HIGH + j,
+                row[CRC_PLAIN_COMPACT_LOW + j]);
         }
     });
     return out;
 }
-ConvolutionalLayer *CnnBuilder::buildConvolutionalLayer(string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf, int nf, int th_count, istream *infile)
+ConvolutionalLayer *CnnBuilder::buildConvolutionalLayer(string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf, int nf, int th_count,
+    istream *infile)
 {   // cnnBuilder.cpp:25-50
     if (infile != NULL) return new ConvolutionalLayer(name, xd, yd, zd, xs, ys, xf, yf, nf, th_count, infile);
     vector<float> weights = getPretrained(name + ".weight"), biases = getPretrained(name + ".bias");
@@ -1239,8 +1327,10 @@ FullyConnectedLayer *CnnBuilder::buildFullyConnectedLayer(string name, int in_di
     for (int i = 0; i < out_dim; i++) for (int j = 0; j < in_dim; j++) encoded_weights[i][j] = ew[w++];
     return new FullyConnectedLayer(name, in_dim, out_dim, th_count, encoded_weights, eb);
 }
-PoolingLayer *CnnBuilder::buildPoolingLayer(string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf) { return new PoolingLayer(name, xd, yd, zd, xs, ys, xf, yf); }
-AvgPoolingLayer *CnnBuilder::buildAvgPoolingLayer(string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf) { return new AvgPoolingLayer(name, xd, yd, zd, xs, ys, xf, yf); }
+PoolingLayer *CnnBuilder::buildPoolingLayer(string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf) { return new PoolingLayer(name, xd, yd, zd,
+    xs, ys, xf, yf); }
+AvgPoolingLayer *CnnBuilder::buildAvgPoolingLayer(string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf) { return new AvgPoolingLayer(name, xd,
+    yd, zd, xs, ys, xf, yf); }
 SquareLayer *CnnBuilder::buildSquareLayer(string name, int th_count) { return new SquareLayer(name, th_count); }
 BatchNormLayer *CnnBuilder::buildBatchNormLayer(string name, int num_channels, istream *infile)
 {   // cnnBuilder.cpp:89-105

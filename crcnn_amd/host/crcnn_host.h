@@ -36,7 +36,8 @@ typedef std::vector<std::vector<std::vector<std::vector<Plaintext>>>> plaintext4
 typedef std::vector<std::vector<std::vector<std::vector<float>>>> floatHypercube;
 typedef std::vector<std::vector<std::vector<float>>> floatCube;
 
-struct DeviceBuffer { void *ptr = nullptr; size_t bytes = 0; DeviceBuffer(size_t b); ~DeviceBuffer(); DeviceBuffer(const DeviceBuffer &) = delete; DeviceBuffer &operator=(const DeviceBuffer &) = delete; };
+struct DeviceBuffer { void *ptr = nullptr; size_t bytes = 0; DeviceBuffer(size_t b); ~DeviceBuffer(); DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete; };
 
 class ciphertext3D {          // device tensor of size-2 ciphertexts, [B][zd][xd][yd]
 public:
@@ -108,8 +109,8 @@ public:
     // root's decision, because the buffers on the wire are sized by it
     virtual int placement() { return 0; }
     virtual void adoptPlacement(int p) { (void)p; }
-    // reporting (bench_host): bytes this layer holds in HBM right now (parameters in whatever operand form they are in, streaming tiles), and the multiply-accumulate
-    // kernel a conv / dense layer runs on ("" for the others)
+    // reporting (bench_host): bytes this layer holds in HBM right now (parameters in whatever operand form they are in, streaming tiles), and the
+    // multiply-accumulate kernel a conv / dense layer runs on ("" for the others)
     virtual size_t deviceBytes() const { return 0; }
     virtual std::string kernelName() const { return ""; }
 };
@@ -123,7 +124,8 @@ public:
     plaintext4D filters;                                    // nf,zd,xf,yf
     std::vector<Plaintext> biases;
     bool filters_already_ntt = false;
-    ConvolutionalLayer(std::string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf, int nf, int th_count, plaintext4D &filters, std::vector<Plaintext> &biases);
+    ConvolutionalLayer(std::string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf, int nf, int th_count, plaintext4D &filters,
+        std::vector<Plaintext> &biases);
     ConvolutionalLayer(std::string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf, int nf, int th_count, std::istream *infile);
     ciphertext3D forward(ciphertext3D input) override;
     plaintext3D getKernel(int kernel_index) { return filters[kernel_index]; }
@@ -138,17 +140,20 @@ private:
     bool streamed = false;
     int stream_form = CRC_NTT;                              // operand form of the last streamed forward (CRC_NTTL: 64-filter limb tiles on the matrix cores)
     std::shared_ptr<DeviceBuffer> d_plain, d_wtile, d_ytile;
-    int w_form = CRC_NTT;                                   // CRC_NTTP / CRC_NTTL / CRC_NTTL1 once Network::forward has put the weights into their MAC kernel's operand form
+    // CRC_NTTP / CRC_NTTL / CRC_NTTL1 once Network::forward has put the weights into their MAC kernel's operand form
+    int w_form = CRC_NTT;
     std::shared_ptr<DeviceBuffer> d_w_canon;                // CRC_NTTL1 only: the canonical NTT-form weights
     int forced_placement = -1;
     void upload();
     void packWeights(bool unpack);
-    bool limbWeights(int B);                                // -> CRC_NTTL (matrix-core kernel) when the layer qualifies (for batches of B) and HBM has room for the second copy
+    // -> CRC_NTTL (matrix-core kernel) when the layer qualifies (for batches of B) and HBM has room for the second copy
+    bool limbWeights(int B);
 public:
     void deviceParameters(std::vector<std::shared_ptr<DeviceBuffer>> &out, bool allocate_only) override;
     int placement() override;
     void adoptPlacement(int p) override { forced_placement = p; }
-    void restoreCanonical();                                // weights back to canonical NTT form (unpacked; rebuilt from the plaintexts when the matrix-core form replaced them)
+    // weights back to canonical NTT form (unpacked; rebuilt from the plaintexts when the matrix-core form replaced them)
+    void restoreCanonical();
     size_t deviceBytes() const override;
     std::string kernelName() const override;
 };
@@ -174,9 +179,9 @@ private:
     int stream_form = CRC_NTT;
     std::shared_ptr<DeviceBuffer> d_plain, d_wtile, d_ytile;
     int w_form = CRC_NTT;
-    // A layer whose canonical NTT-form weights and their limb copy do not fit in HBM together (PlainModelWoPad's fc3 at n = 16384, k = 4: 202 + 182 GiB) never gets a
-    // canonical copy: its limb weights are built a tile of output rows at a time straight from the plaintexts (lift + NTT -> batch-norm fold of the tile -> pack), a
-    // batch-norm layer that Network::fuse() folds into it being applied to every tile (same ciphertexts; netrun.py does the same)
+    // A layer whose canonical NTT-form weights and their limb copy do not fit in HBM together (PlainModelWoPad's fc3 at n = 16384, k = 4: 202 + 182 GiB) never
+    // gets a canonical copy: its limb weights are built a tile of output rows at a time straight from the plaintexts (lift + NTT -> batch-norm fold of the tile
+    // -> pack), a batch-norm layer that Network::fuse() folds into it being applied to every tile (same ciphertexts; netrun.py does the same)
     bool tilewise = false, tile_built = false;
     int forced_placement = -1;
     std::shared_ptr<BatchNormLayer> fold_bn;
@@ -271,7 +276,8 @@ class OutOfBudgetException : public std::exception {
 public:
     const int last_layer_computed;
     std::string msg;
-    OutOfBudgetException(int last_layer_computed) : last_layer_computed(last_layer_computed), msg("OutOfBudgetException at layer " + std::to_string(last_layer_computed)) {}
+    OutOfBudgetException(int last_layer_computed) : last_layer_computed(last_layer_computed), msg("OutOfBudgetException at layer " +
+        std::to_string(last_layer_computed)) {}
     const char *what() const throw() override { return msg.c_str(); }
 };
 
@@ -291,17 +297,19 @@ public:
     // refreshed and the layer repeated while refreshes are left, then OutOfBudgetException(i - 1) is thrown.  -1: plain forward.
     int max_num_of_reencryptions = -1;
     std::vector<double> last_layer_ms;                      // per-layer wall milliseconds of the last forward (T_LAYER_i, mainparams.cpp:81)
-    // true: last_layer_ms comes from HIP events recorded on the launch stream around every layer call -- no synchronisation between the layers, what a throughput
-    // measurement wants (crcnn_amd/host/bench_host.cpp); false: wall clock around Layer::forward + a stream synchronisation, as the reference's driver measures
+    // true: last_layer_ms comes from HIP events recorded on the launch stream around every layer call -- no synchronisation between the layers, what a
+    // throughput measurement wants (crcnn_amd/host/bench_host.cpp); false: wall clock around Layer::forward + a stream synchronisation, as the reference's
+    // driver measures
     bool time_with_events = false;
-    std::vector<int> last_layer_launches;                   // Layer::forward calls per layer in the last forward (two-level chunking: a head layer runs once per chunk)
-    double last_reenc_ms = 0.0;                             // T_REENC of that line: decrypt + re-encrypt in front of layer_before_reenc (network.cpp:30-37), all refreshes of the budget-checking forward (:52-96); 0 when none ran
-    // Two-level chunking (> 0): the layers in front of the first dense layer run on sub-batches of `head_chunk` images, the dense layers once on the whole batch -- a
-    // dense layer streams all of its weights per launch, so its time per image falls with the rows it is used for (PlainModelWoPad at n = 16384: 6-image chunks fit
-    // beside 190 GiB of weights, fc3 wants 24+ images).  0: every layer on the whole batch
+    // Layer::forward calls per layer in the last forward (two-level chunking: a head layer runs once per chunk)
+    std::vector<int> last_layer_launches;
+    double last_reenc_ms = 0.0;
+    // Two-level chunking (> 0): the layers in front of the first dense layer run on sub-batches of `head_chunk` images, the dense layers once on the whole
+    // batch -- a dense layer streams all of its weights per launch, so its time per image falls with the rows it is used for (PlainModelWoPad at n = 16384:
+    // 6-image chunks fit beside 190 GiB of weights, fc3 wants 24+ images).  0: every layer on the whole batch
     int head_chunk = 0;
-    // where this rank's HBM goes (bytes): the layers' parameters in their current operand forms, the activation slots forward() keeps, the shared work buffer, the
-    // evaluation keys
+    // where this rank's HBM goes (bytes): the layers' parameters in their current operand forms, the activation slots forward() keeps, the shared work buffer,
+    // the evaluation keys
     struct HbmPlan { size_t parameters = 0, activations = 0, work = 0, keys = 0; };
     HbmPlan hbmPlan() const;
 private:
@@ -309,7 +317,8 @@ private:
     std::shared_ptr<EventPool> event_pool;                  // HIP events of time_with_events, reused from forward to forward (copies of a Network share them)
 public:
     std::shared_ptr<DeviceBuffer> tail_slot;                // ... and the dense layers' whole-batch input under two-level chunking
-    std::shared_ptr<DeviceBuffer> act_slot[2];              // the two ping-pong activation buffers forward() keeps across calls (sized by the largest layer output so far)
+    // the two ping-pong activation buffers forward() keeps across calls (sized by the largest layer output so far)
+    std::shared_ptr<DeviceBuffer> act_slot[2];
     Network() {}
     ~Network() {}
     int getNumLayers() { return (int)layers.size(); }
@@ -339,7 +348,8 @@ public:
     CnnBuilder(std::string plain_model_path) : plain_model_path(plain_model_path) {}
     ~CnnBuilder() {}
     std::vector<float> getPretrained(std::string var_name);
-    ConvolutionalLayer *buildConvolutionalLayer(std::string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf, int nf, int th_count, std::istream *infile);
+    ConvolutionalLayer *buildConvolutionalLayer(std::string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf, int nf, int th_count,
+        std::istream *infile);
     FullyConnectedLayer *buildFullyConnectedLayer(std::string name, int in_dim, int out_dim, int th_count, std::istream *infile);
     PoolingLayer *buildPoolingLayer(std::string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf);
     AvgPoolingLayer *buildAvgPoolingLayer(std::string name, int xd, int yd, int zd, int xs, int ys, int xf, int yf);

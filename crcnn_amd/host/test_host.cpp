@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdio>
 #include <sstream>
+#include <unistd.h>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -50,7 +51,8 @@ static int do_net(int argc, char **argv)
     Network net = builder.buildNetworkByName(model);
     net.ntt_resident = resident;
     if (argc > 7 && atoi(argv[7])) { const int removed = net.fuse(); fprintf(stderr, "fused: %d layers removed, %d left\n", removed, net.getNumLayers()); }
-    if (argc > 8) net.head_chunk = atoi(argv[8]);             // two-level chunking: the layers in front of the first dense layer on sub-batches of this many images
+    // two-level chunking: the layers in front of the first dense layer on sub-batches of this many images
+    if (argc > 8) net.head_chunk = atoi(argv[8]);
     if (argc > 9) net.matrix_cores = atoi(argv[9]) != 0;
     auto x = rd(dir + "/net_in.u64");
     vector<ciphertext3D> imgs;
@@ -74,8 +76,8 @@ static int do_net(int argc, char **argv)
     return 0;
 }
 
-// net3 <model> <h5> <dir> <batch>: the three NTT-resident runs of tests/test_gpu_host_cpp.py's full-size cases from ONE built network (the encode + lift + NTT of
-// 10^5 .. 10^6 plaintexts is most of a case's time): Network::forward as built (one image), after Network::fuse() (one image), and fused on `batch` images.
+// net3 <model> <h5> <dir> <batch>: the three NTT-resident runs of tests/test_gpu_host_cpp.py's full-size cases from ONE built network (the encode + lift + NTT
+// of 10^5 .. 10^6 plaintexts is most of a case's time): Network::forward as built (one image), after Network::fuse() (one image), and fused on `batch` images.
 // Writes out_unfused.u64, out_fused.u64, out_fused_batch.u64
 static int do_net3(int argc, char **argv)
 {
@@ -116,7 +118,8 @@ static int do_files(int argc, char **argv)
     setup(dir);
     secret_key = rd(dir + "/sk.u64"); public_key = rd(dir + "/pk.u64");            // the fixture's key pair (globals are public, as in the reference)
     auto dims = rd(dir + "/layer_dims.u64");
-    const int zd = (int)dims[0], xd = (int)dims[1], yd = (int)dims[2], xs = (int)dims[3], ys = (int)dims[4], xf = (int)dims[5], yf = (int)dims[6], nf = (int)dims[7], od = (int)dims[8];
+    const int zd = (int)dims[0], xd = (int)dims[1], yd = (int)dims[2], xs = (int)dims[3], ys = (int)dims[4], xf = (int)dims[5], yf = (int)dims[6], nf =
+        (int)dims[7], od = (int)dims[8];
     const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys + 1;
     auto run = [&](Layer &c, Layer &b, Layer &f, const ciphertext3D &x, const string &out) {
         c.out_form = b.out_form = f.out_form = CRC_COEFF;
@@ -132,8 +135,10 @@ static int do_files(int argc, char **argv)
     }
     {   // the same files written by the host classes (encoding as CnnBuilder::build*Layer: float32 widened to double)
         auto enc = [&](const vector<double> &v) { vector<Plaintext> o; for (double d : v) o.push_back(fraencode((double)(float)d)); return o; };
-        auto fw = enc(rdf(dir + "/conv_w.f64")), fb = enc(rdf(dir + "/conv_b.f64")), bm = enc(rdf(dir + "/bn_mean.f64")), dw = enc(rdf(dir + "/fc_w.f64")), db = enc(rdf(dir + "/fc_b.f64"));
-        vector<Plaintext> bv; for (double d : rdf(dir + "/bn_var.f64")) { float v = (float)d; v = 1 / sqrt(v + 0.00001); bv.push_back(fraencode((double)v)); }   // cnnBuilder.cpp:100-102
+        auto fw = enc(rdf(dir + "/conv_w.f64")), fb = enc(rdf(dir + "/conv_b.f64")), bm = enc(rdf(dir + "/bn_mean.f64")), dw = enc(rdf(dir + "/fc_w.f64")),
+            db = enc(rdf(dir + "/fc_b.f64"));
+        // cnnBuilder.cpp:100-102
+        vector<Plaintext> bv; for (double d : rdf(dir + "/bn_var.f64")) { float v = (float)d; v = 1 / sqrt(v + 0.00001); bv.push_back(fraencode((double)v)); }
         plaintext4D ew(nf, plaintext3D(zd, plaintext2D(xf, vector<Plaintext>(yf)))); size_t w = 0;
         for (int n = 0; n < nf; n++) for (int z = 0; z < zd; z++) for (int i = 0; i < xf; i++) for (int j = 0; j < yf; j++) ew[n][z][i][j] = fw[w++];
         plaintext2D ed(od, vector<Plaintext>(nf * xo * yo)); w = 0;
@@ -141,7 +146,8 @@ static int do_files(int argc, char **argv)
         ConvolutionalLayer c("conv", xd, yd, zd, xs, ys, xf, yf, nf, 2, ew, fb);
         BatchNormLayer b("bn", nf, bm, bv);
         FullyConnectedLayer f("fc", nf * xo * yo, od, 2, ed, db);
-        { ofstream o(dir + "/our_encoded_layers.bin", ios::binary); c.savePlaintextParameters(&o); b.savePlaintextParameters(&o); f.savePlaintextParameters(&o); }
+        { ofstream o(dir + "/our_encoded_layers.bin", ios::binary); c.savePlaintextParameters(&o); b.savePlaintextParameters(&o);
+            f.savePlaintextParameters(&o); }
         vector<float> image; for (double d : rdf(dir + "/image.f64")) image.push_back((float)d);
         ciphertext3D x = encryptAndSaveImage(image, zd, xd, yd, dir + "/our_cipher_image.bin");
         run(c, b, f, x, "out_from_our_files.u64");
@@ -156,9 +162,11 @@ static const char *status_name(exit_status_forward s) { return s == SUCCESS ? "S
 static int do_searchlogic(int argc, char **argv)
 {
     if (argc < 7) return 1;
-    const u64 lo = strtoull(argv[2], 0, 0), hi = strtoull(argv[3], 0, 0), first_good = strtoull(argv[4], 0, 0), last_good = strtoull(argv[5], 0, 0), min_q = strtoull(argv[6], 0, 0);
+    const u64 lo = strtoull(argv[2], 0, 0), hi = strtoull(argv[3], 0, 0), first_good = strtoull(argv[4], 0, 0), last_good = strtoull(argv[5], 0, 0), min_q =
+        strtoull(argv[6], 0, 0);
     vector<pair<u64, exit_status_forward>> tried;
-    auto pred = [&](u64 t) { exit_status_forward s = t < first_good ? MISPREDICTED : t > last_good ? OUT_OF_BUDGET : SUCCESS; tried.emplace_back(t, s); return s; };
+    auto pred = [&](u64 t) { exit_status_forward s = t < first_good ? MISPREDICTED : t > last_good ? OUT_OF_BUDGET : SUCCESS; tried.emplace_back(t, s);
+        return s; };
     const u64 found = plainModulusBinarySearch(pred, lo, hi, min_q);
     printf("found %llu\n", (unsigned long long)found);
     for (auto &p : tried) printf("tried %llu %s\n", (unsigned long long)p.first, status_name(p.second));
@@ -183,7 +191,8 @@ static int do_search(int argc, char **argv)
     for (size_t i = 0; i < cnt; i++) printf("label %zu %d\n", i, (int)s.predicted_labels[i]);
     const u64 found = s.run(num_images, lo, hi, h5);
     printf("found %llu\n", (unsigned long long)found);
-    for (size_t i = 0; i < s.tried.size(); i++) printf("tried %llu %s %.2f\n", (unsigned long long)s.tried[i].first, status_name(s.tried[i].second), s.test_seconds[i]);
+    for (size_t i = 0; i < s.tried.size(); i++) printf("tried %llu %s %.2f\n", (unsigned long long)s.tried[i].first, status_name(s.tried[i].second),
+        s.test_seconds[i]);
     return 0;
 }
 
@@ -200,7 +209,8 @@ static int do_api(int argc, char **argv)
     vector<float> img(28 * 28); for (int i = 0; i < 784; i++) img[i] = (float)((i % 17) - 8) / 4.0f;
     ciphertext3D ct = encryptImage(img, 1, 28, 28);
     floatCube back = decryptImage(ct);
-    for (int i = 0; i < 28; i++) for (int j = 0; j < 28; j++) if (fabs(back[0][i][j] - img[i * 28 + j]) > 1e-6) { fprintf(stderr, "decrypt mismatch\n"); return 4; }
+    for (int i = 0; i < 28; i++) for (int j = 0; j < 28; j++) if (fabs(back[0][i][j] - img[i * 28 + j]) > 1e-6) { fprintf(stderr, "decrypt mismatch\n");
+        return 4; }
     if (noiseBudget(ct) < 20) { fprintf(stderr, "budget too small\n"); return 4; }
     // a tiny layer stack: conv -> avgpool -> square -> fc, resident vs layerwise must give identical ciphertexts
     vector<float> w(2 * 1 * 3 * 3), b(2), fw(3 * 2 * 6 * 6), fb(3);
@@ -226,9 +236,15 @@ static int do_api(int argc, char **argv)
     // semantic check against float arithmetic
     floatCube dec = decryptImage(o2);
     double conv[2][12][12], pool[2][6][6];
-    for (int f = 0; f < 2; f++) for (int i = 0; i < 12; i++) for (int j = 0; j < 12; j++) { double s = b[f]; for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) s += (double)w[(f * 3 + a) * 3 + c] * small[(i + a) * 14 + j + c]; conv[f][i][j] = s; }
-    for (int f = 0; f < 2; f++) for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { double s = (conv[f][2*i][2*j] + conv[f][2*i][2*j+1] + conv[f][2*i+1][2*j] + conv[f][2*i+1][2*j+1]) / 4; pool[f][i][j] = s * s; }
-    for (int o = 0; o < 3; o++) { double s = fb[o]; for (int f = 0; f < 2; f++) for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) s += (double)fw[o * 72 + (f * 6 + i) * 6 + j] * pool[f][i][j];
+    for (int f = 0; f < 2; f++) for (int i = 0; i < 12; i++) for (int j = 0; j < 12; j++) {
+        double s = b[f];
+        for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) s += (double)w[(f * 3 + a) * 3 + c] * small[(i + a) * 14 + j + c];
+        conv[f][i][j] = s;
+    }
+    for (int f = 0; f < 2; f++) for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { double s = (conv[f][2*i][2*j] + conv[f][2*i][2*j+1] +
+        conv[f][2*i+1][2*j] + conv[f][2*i+1][2*j+1]) / 4; pool[f][i][j] = s * s; }
+    for (int o = 0; o < 3; o++) { double s = fb[o];
+        for (int f = 0; f < 2; f++) for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) s += (double)fw[o * 72 + (f * 6 + i) * 6 + j] * pool[f][i][j];
         if (fabs(s - dec[0][o][0]) > 1e-4) { fprintf(stderr, "semantic mismatch %d: %f vs %f\n", o, s, dec[0][o][0]); return 6; } }
     // refresh path (network.cpp:30-34) keeps the result
     net.layer_before_reenc = 3; floatCube dec2 = decryptImage(net.forward(x)); net.layer_before_reenc = -1;
@@ -260,7 +276,8 @@ static int do_api(int argc, char **argv)
         if (at != 3 - removed) { fprintf(stderr, "refresh index %d after %d folds below it\n", at, removed); return 14; }
         floatCube got = decryptImage(fusedn.forward(x));
         for (int o = 0; o < 3; o++)
-            if (fabs(got[0][o][0] - want[0][o][0]) > 1e-4) { fprintf(stderr, "fused network with a refresh differs: %f vs %f\n", got[0][o][0], want[0][o][0]); return 14; }
+            if (fabs(got[0][o][0] - want[0][o][0]) > 1e-4) { fprintf(stderr, "fused network with a refresh differs: %f vs %f\n", got[0][o][0], want[0][o][0]);
+                return 14; }
         // without a refresh the same network does pair square + pool2, bit-identically
         Network a = build(), b2 = build();
         const int removed2 = b2.fuse();
@@ -280,7 +297,8 @@ static int do_api(int argc, char **argv)
     // "broadcast", checksummed and compared, and the network must still produce the same ciphertexts
     {
         uint8_t id[CRC_COMM_ID_BYTES]; crc_comm *comm = nullptr;
-        if (crc_comm_unique_id(id) || crc_comm_create(context, 1, 0, id, &comm)) { fprintf(stderr, "crc_comm_create failed (rccl error %d)\n", crc_last_comm_error()); return 13; }
+        if (crc_comm_unique_id(id) || crc_comm_create(context, 1, 0, id, &comm)) { fprintf(stderr, "crc_comm_create failed (rccl error %d)\n",
+            crc_last_comm_error()); return 13; }
         const size_t bytes = net.broadcastParameters(comm, 0);
         fprintf(stderr, "broadcastParameters: %zu bytes on %d rank(s)\n", bytes, crc_comm_world(comm));
         net.ntt_resident = true;
@@ -316,10 +334,59 @@ static int do_api(int argc, char **argv)
     return 0;
 }
 
+// test_host bcast <rank> <world> <rendezvous file> <out dir> [device]
+//   Network::broadcastParameters across PROCESSES (one per rank; RCCL when every rank has its own GPU, the shared-memory rehearsal transport --
+//   CRC_COMM_TRANSPORT=shm --
+//   when they share one): rank 0 holds the real weights, every other rank builds the same topology from DIFFERENT weights, joins through the id rank 0 left in
+//   the
+//   file, receives -- and must then produce rank 0's output ciphertexts bit for bit (<out dir>/bcast_out_<rank>.u64)
+static int do_bcast(int argc, char **argv)
+{
+    if (argc < 6) return 1;
+    const int rank = atoi(argv[2]), world = atoi(argv[3]); const string rdv = argv[4], dir = argv[5]; const int device = argc > 6 ? atoi(argv[6]) : 0;
+    setDeterministicSeed(4242);
+    setParameters(1024, {0x7fffffff380001ULL, 0x3fffffff000001ULL}, 1ULL << 20, device);
+    // the non-root ranks start from other weights: only the broadcast can make the outputs agree
+    const float scale = rank == 0 ? 1.0f : -0.5f;
+    auto enc = [&](float v) { return fraencode((double)(v * scale)); };
+    plaintext4D ew(2, plaintext3D(1, plaintext2D(3, vector<Plaintext>(3)))); vector<Plaintext> eb(2);
+    for (int f = 0; f < 2; f++) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) ew[f][0][i][j] = enc(0.05f * (float)(((f * 3 + i) * 3 + j) % 7 -
+        3)); eb[f] = enc(f ? -0.2f : 0.1f); }
+    plaintext2D efw(3, vector<Plaintext>(72)); vector<Plaintext> efb(3);
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 72; j++) efw[i][j] = enc(0.01f * (float)((i * 72 + j) % 11 - 5)); efb[i] = enc(0.125f * (float)(i + 1)); }
+    vector<float> small(14 * 14); for (int i = 0; i < 196; i++) small[i] = (float)((i * 7) % 13 - 6) / 8.0f;
+    ciphertext3D x = encryptImage(small, 1, 14, 14);
+    Network net;
+    net.getLayers().push_back(shared_ptr<Layer>(new ConvolutionalLayer("c", 14, 14, 1, 1, 1, 3, 3, 2, 4, ew, eb)));
+    net.getLayers().push_back(shared_ptr<Layer>(new AvgPoolingLayer("p", 12, 12, 2, 2, 2, 2, 2)));
+    net.getLayers().push_back(shared_ptr<Layer>(new SquareLayer("s", 2)));
+    net.getLayers().push_back(shared_ptr<Layer>(new FullyConnectedLayer("f", 72, 3, 2, efw, efb)));
+    uint8_t id[CRC_COMM_ID_BYTES];
+    if (rank == 0) {
+        if (crc_comm_unique_id(id)) { fprintf(stderr, "crc_comm_unique_id failed (rccl error %d)\n", crc_last_comm_error()); return 13; }
+        { ofstream o(rdv + ".tmp", ios::binary); o.write((const char *)id, sizeof id); }
+        if (rename((rdv + ".tmp").c_str(), rdv.c_str())) return 13;
+    } else {
+        bool got = false;
+        for (int tries = 0; tries < 1200 && !got; tries++) { ifstream f(rdv, ios::binary); got = f && f.read((char *)id, sizeof id); if (!got) usleep(100000); }
+        if (!got) { fprintf(stderr, "no rendezvous id\n"); return 13; }
+    }
+    crc_comm *comm = nullptr;
+    if (crc_comm_create(context, world, rank, id, &comm)) { fprintf(stderr, "crc_comm_create failed (rccl error %d)\n", crc_last_comm_error()); return 13; }
+    const size_t bytes = net.broadcastParameters(comm, 0);
+    net.ntt_resident = true;
+    wr(dir + "/bcast_out_" + to_string(rank) + ".u64", net.forward(x).toHost());
+    printf("bcast ok: rank %d of %d, %zu bytes\n", rank, crc_comm_world(comm), bytes);
+    crc_comm_destroy(comm);
+    delParameters();
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) return 1;
     try {
+        if (!strcmp(argv[1], "bcast")) return do_bcast(argc, argv);
         if (!strcmp(argv[1], "net")) return do_net(argc, argv);
         if (!strcmp(argv[1], "net3")) return do_net3(argc, argv);
         if (!strcmp(argv[1], "api")) return do_api(argc, argv);

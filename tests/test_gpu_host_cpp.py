@@ -50,6 +50,30 @@ def test_cpp_api_behaviour():
     assert "api ok" in out.stdout
 
 
+def _broadcast_across_processes(world, env, devices):
+    d = tempfile.mkdtemp()
+    rdv = os.path.join(d, "rendezvous.id")
+    procs = [subprocess.Popen([DRIVER, "bcast", str(r), str(world), rdv, d, str(devices[r])], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(os.environ, **env)) for r in range(world)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, (r, outs[r][1][-1500:])
+        assert f"bcast ok: rank {r} of {world}" in outs[r][0]
+    res = [np.fromfile(os.path.join(d, f"bcast_out_{r}.u64"), dtype=np.uint64) for r in range(world)]
+    assert res[0].size > 0 and all(np.array_equal(res[0], x) for x in res[1:])
+
+
+def test_cpp_broadcast_parameters_across_processes():
+    """Network::broadcastParameters on a TWO-rank communicator, one process per rank: rank 1 builds the network from different weights, joins through the id rank 0
+    left in a file, receives the encoded parameters and evaluation keys -- and then produces rank 0's output ciphertexts bit for bit.  On a one-GPU box the
+    communicator's bytes go through the shared-memory rehearsal transport (RCCL refuses two ranks on one device); with two GPUs visible the same two processes
+    also run over RCCL (ncclBroadcast)"""
+    import torch
+    _broadcast_across_processes(2, {"CRC_COMM_TRANSPORT": "shm"}, [0, 0])
+    if torch.cuda.device_count() >= 2:
+        _broadcast_across_processes(2, {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}, [0, 1])
+
+
 def test_cpp_plain_modulus_search():
     """the reference's plain-modulus binary search (optimalParametersChooser.cpp) driven by the GPU engine through
     the C++ host classes: setParameters / buildNetwork / encryptImage / Network::forward with budget check / decryptImage per

@@ -55,8 +55,8 @@ class Client:
         if os.path.exists(lab):
             lraw = np.fromfile(lab, dtype=np.uint8)
             info["labels"] = [int(v) for v in lraw[8 + first:8 + first + D]]
-        # the float model's predictions the reference ships (PlainModel/predictions<Model>.csv, read by loadMNISTPlainModelPredictions, utils.cpp:41-53): one label per
-        # test image; copies of the three data files sit under tests/golden/predictions/
+        # the float model's predictions the reference ships (PlainModel/predictions<Model>.csv, read by loadMNISTPlainModelPredictions, utils.cpp:41-53): one
+        # label per test image; copies of the three data files sit under tests/golden/predictions/
         for d in (mnist_dir, os.path.join(ROOT, "tests", "golden", "predictions")):
             csv = os.path.join(d, f"predictions{self.cfg['model']}.csv")
             if os.path.exists(csv):
@@ -94,7 +94,8 @@ class Client:
         E, cfg = self.E, self.cfg
         D = len(imgs)
         gold_ok, gold_name = golden_check(cfg_name, cfg, self.q, self.rank, x0_sha, sha(outs[0])) if golden else (None, None)
-        # BASELINE configs[0] in full (tests/golden/c1_tiny4096_t32.json: 32 images through the compiled reference): this run's distinct images ARE its first images
+        # BASELINE configs[0] in full (tests/golden/c1_tiny4096_t32.json: 32 images through the compiled reference): this run's distinct images ARE its first
+        # images
         c1_ok = None
         c1_path = os.path.join(ROOT, "tests", "golden", "c1_tiny4096_t32.json")
         if golden and self.rank == 0 and cfg_name == "tiny4096" and os.path.exists(c1_path):

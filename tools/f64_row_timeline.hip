@@ -3,15 +3,17 @@
 //
 //   f64_row_timeline [n] [rows] [reps]
 //
-// One workgroup per source row: `reps` transforms of that row (as the digit kernel cuts 8 transforms from one row), each = fill the LDS image, the radix-8 passes,
+// One workgroup per source row: `reps` transforms of that row (as the digit kernel cuts 8 transforms from one row), each = fill the LDS image, the radix-8
+// passes,
 // drain + 16-byte stores.  Variants of the pass (same arithmetic, same results -- the tool checks every variant against variant 0 bit for bit):
 //   0  the product's pass (ntt_pass_f64): per group twiddle loads, LDS reads, butterflies, LDS writes; groups one after the other
 //   1  both groups of a thread loaded before the first is computed (software pipelining across the groups of a pass)
 //   2  variant 1 + twiddles through the scalar cache in the passes whose twiddle block index is wave-uniform (stride 2^ls >= 64 groups)
 //   3  (inverse only) variant 2 + lazy reduction: a pass reduces the two outputs that grew (8 B and 3.5 p) instead of all eight inputs
 //   4 / 5 / 6  the product's pass with scalar twiddles / scalar twiddles + lazy reduction / lazy reduction only (no second group in flight: fewer registers)
-// Throughput: ns per row transform over `rows` rows (HIP events).  Timeline: s_memtime stamps of wave 0 of every workgroup around the phases of the LAST rep,
-// median over workgroups, in shader cycles (a diagnostic build of the same code: the stamps cost a few percent, the throughput numbers come from the build without).
+//   Throughput: ns per row transform over `rows` rows (HIP events).  Timeline: s_memtime stamps of wave 0 of every workgroup around the phases of the LAST rep,
+//   median over workgroups, in shader cycles (a diagnostic build of the same code: the stamps cost a few percent, the throughput numbers come from the build
+//   without).
 #include "../crcnn_amd/csrc/ntt_f64.h"
 #include <algorithm>
 #include <cstdio>
@@ -40,7 +42,8 @@ __device__ __forceinline__ void inv_stages_lazy(double (&v)[8], const double (&t
 }
 
 template <bool INV, int VAR, bool STAMP>
-__device__ __forceinline__ void pass(double *sm, const double *W, int n, int ls, int tabidx, const F64Mod md, bool reduce_in, unsigned long long *st, int &si)   // st: this workgroup's stamp slots in global memory
+// st: this workgroup's stamp slots in global memory
+__device__ __forceinline__ void pass(double *sm, const double *W, int n, int ls, int tabidx, const F64Mod md, bool reduce_in, unsigned long long *st, int &si)
 {
     const unsigned groups = (unsigned)n >> RB;
     const bool uniform = (VAR == 2 || VAR == 3) && ls >= 6;
@@ -92,7 +95,8 @@ __device__ __forceinline__ void pass(double *sm, const double *W, int n, int ls,
 }
 
 template <bool INV, int VAR, bool STAMP>
-__global__ void __launch_bounds__(512, 4) rows_kernel(const double *src, double *dst, const double *Wt, F64Mod md, int n, int logn, int reps, unsigned long long *stamps)
+__global__ void __launch_bounds__(512, 4) rows_kernel(const double *src, double *dst, const double *Wt, F64Mod md, int n, int logn, int reps,
+    unsigned long long *stamps)
 {
     extern __shared__ double smd[];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -100,7 +104,8 @@ __global__ void __launch_bounds__(512, 4) rows_kernel(const double *src, double 
     unsigned long long *st = stamps + (size_t)blockIdx.x * NSTAMP; int si = 0;
     double r[NPT];
 #pragma unroll
-    for (int u = 0; u < NPT / 2; u++) { const int s = 2 * (tid + u * nt); const d2 v = *reinterpret_cast<const d2 *>(row + s); r[2 * u] = v.x; r[2 * u + 1] = v.y; }
+    for (int u = 0; u < NPT / 2; u++) { const int s = 2 * (tid + u * nt); const d2 v = *reinterpret_cast<const d2 *>(row + s); r[2 * u] = v.x;
+        r[2 * u + 1] = v.y; }
     for (int rep = 0; rep < reps; rep++) {
         const bool last = STAMP && rep == reps - 1;
         si = 0;
@@ -116,8 +121,10 @@ __global__ void __launch_bounds__(512, 4) rows_kernel(const double *src, double 
         __syncthreads();
         if (last && tid == 0) st[si++] = now();
         const int full = logn / RB;                                  // (n = 8192: 13 = 4 x 3 + the fused gap-1 stage)
-        if (!INV) { int lt = logn - 1; for (int p = 0; p < full; p++, lt -= RB) { if (last) pass<false, VAR, true>(smd, Wt, n, lt - RB + 1, n >> (lt + 1), md, false, st, si); else pass<false, VAR, false>(smd, Wt, n, lt - RB + 1, n >> (lt + 1), md, false, st, si); } }
-        else { int lt = 1; for (int p = 0; p < full; p++, lt += RB) { if (last) pass<true, VAR, true>(smd, Wt, n, lt, n >> (lt + 1), md, false, st, si); else pass<true, VAR, false>(smd, Wt, n, lt, n >> (lt + 1), md, false, st, si); } }
+        if (!INV) { int lt = logn - 1; for (int p = 0; p < full; p++, lt -= RB) { if (last) pass<false, VAR, true>(smd, Wt, n, lt - RB + 1, n >> (lt + 1), md,
+            false, st, si); else pass<false, VAR, false>(smd, Wt, n, lt - RB + 1, n >> (lt + 1), md, false, st, si); } }
+        else { int lt = 1; for (int p = 0; p < full; p++, lt += RB) { if (last) pass<true, VAR, true>(smd, Wt, n, lt, n >> (lt + 1), md, false, st, si);
+            else pass<true, VAR, false>(smd, Wt, n, lt, n >> (lt + 1), md, false, st, si); } }
         double *out = dst + ((size_t)blockIdx.x * reps + rep) * n;
         for (int s = 2 * tid; s < n; s += 2 * nt) {
             const d2 v = f64_stage_out<INV, RB>(sm_load_pair<RB>(smd, s), Wt, n, logn, s, md);
@@ -131,7 +138,8 @@ __global__ void __launch_bounds__(512, 4) rows_kernel(const double *src, double 
 }
 
 template <bool INV, int VAR>
-static void run(const char *name, const double *src, double *dst, const double *W, F64Mod md, int n, int logn, int rows, int reps, unsigned long long *d_st, std::vector<double> *ref)
+static void run(const char *name, const double *src, double *dst, const double *W, F64Mod md, int n, int logn, int rows, int reps, unsigned long long *d_st,
+    std::vector<double> *ref)
 {
     const size_t lds = (size_t)n * 8;
     auto k0 = rows_kernel<INV, VAR, false>; auto k1 = rows_kernel<INV, VAR, true>;
@@ -162,7 +170,8 @@ static void run(const char *name, const double *src, double *dst, const double *
         std::nth_element(d.begin(), d.begin() + rows / 2, d.end());
         printf(" %lld", d[rows / 2]);
     }
-    { std::vector<long long> d(rows); for (int b = 0; b < rows; b++) d[b] = (long long)(st[(size_t)b * NSTAMP + ns - 1] - st[(size_t)b * NSTAMP]); std::nth_element(d.begin(), d.begin() + rows / 2, d.end()); printf("   | whole %lld\n", d[rows / 2]); }
+    { std::vector<long long> d(rows); for (int b = 0; b < rows; b++) d[b] = (long long)(st[(size_t)b * NSTAMP + ns - 1] - st[(size_t)b * NSTAMP]);
+        std::nth_element(d.begin(), d.begin() + rows / 2, d.end()); printf("   | whole %lld\n", d[rows / 2]); }
 }
 
 int main(int argc, char **argv)
@@ -178,9 +187,11 @@ int main(int argc, char **argv)
     for (auto &v : hs) v = (double)(long long)(rnd() % 65536);
     for (auto &v : hw) v = (double)((long long)(rnd() % (unsigned long long)p) - (long long)(p / 2));
     double *src, *dst, *W; unsigned long long *d_st;
-    CK(hipMalloc(&src, hs.size() * 8)); CK(hipMalloc(&dst, hs.size() * 8 * reps)); CK(hipMalloc(&W, hw.size() * 8)); CK(hipMalloc(&d_st, (size_t)rows * NSTAMP * 8));
+    CK(hipMalloc(&src, hs.size() * 8)); CK(hipMalloc(&dst, hs.size() * 8 * reps)); CK(hipMalloc(&W, hw.size() * 8));
+        CK(hipMalloc(&d_st, (size_t)rows * NSTAMP * 8));
     CK(hipMemcpy(src, hs.data(), hs.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(W, hw.data(), hw.size() * 8, hipMemcpyHostToDevice));
-    printf("n = %d, %d workgroups (one source row each), %d transforms per workgroup, 512 threads x 16 points, 64 KiB LDS image (two workgroups per CU)\n", n, rows, reps);
+    printf("n = %d, %d workgroups (one source row each), %d transforms per workgroup, 512 threads x 16 points, 64 KiB LDS image (two workgroups per CU)\n", n,
+        rows, reps);
     printf("stamp order: fill+barrier | per pass: [loads issued ->] butterflies+stores -> barrier | drain+stores issued | barrier\n");
     std::vector<double> ref;
     run<false, 0>("forward, product pass", src, dst, W, md, n, logn, rows, reps, d_st, &ref);

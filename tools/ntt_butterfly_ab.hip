@@ -33,7 +33,8 @@ __global__ void __launch_bounds__(1024) bf_kernel(u64 *out, const u64 *in, const
 {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     u64 X[8], Y[8], w[8], wp[8];
-    for (int i = 0; i < 8; i++) { X[i] = in[(tid * 8 + i) % 4096] % q; Y[i] = in[(tid * 8 + i + 1) % 4096] % q; w[i] = W[(tid + 17 * i) % 4096]; wp[i] = WP[(tid + 17 * i) % 4096]; }
+    for (int i = 0; i < 8; i++) { X[i] = in[(tid * 8 + i) % 4096] % q; Y[i] = in[(tid * 8 + i + 1) % 4096] % q; w[i] = W[(tid + 17 * i) % 4096];
+        wp[i] = WP[(tid + 17 * i) % 4096]; }
     const u64 q4 = 4 * q;
     for (int it = 0; it < iters; it++) {
 #pragma unroll
@@ -64,8 +65,10 @@ int main()
     std::vector<u64> hw(4096), hwp(4096);
     for (int i = 0; i < 4096; i++) { hw[i] = h[(i * 7 + 3) % 4096] % q; hwp[i] = (u64)(((unsigned __int128)hw[i] << 64) / q); }
     u64 *in, *out, *W, *WP, *res;
-    CK(hipMalloc(&in, 4096 * 8)); CK(hipMalloc(&W, 4096 * 8)); CK(hipMalloc(&WP, 4096 * 8)); CK(hipMalloc(&res, 8192 * 8)); CK(hipMalloc(&out, (size_t)256 * 4 * 1024 * 8));
-    CK(hipMemcpy(in, h.data(), 4096 * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(W, hw.data(), 4096 * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(WP, hwp.data(), 4096 * 8, hipMemcpyHostToDevice));
+    CK(hipMalloc(&in, 4096 * 8)); CK(hipMalloc(&W, 4096 * 8)); CK(hipMalloc(&WP, 4096 * 8)); CK(hipMalloc(&res, 8192 * 8));
+        CK(hipMalloc(&out, (size_t)256 * 4 * 1024 * 8));
+    CK(hipMemcpy(in, h.data(), 4096 * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(W, hw.data(), 4096 * 8, hipMemcpyHostToDevice));
+        CK(hipMemcpy(WP, hwp.data(), 4096 * 8, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(check_kernel, dim3(16), dim3(256), 0, 0, in, W, WP, res, q, b, f);
     std::vector<u64> hr(8192); CK(hipMemcpy(hr.data(), res, 8192 * 8, hipMemcpyDeviceToHost));
     int nbad = 0;
@@ -78,11 +81,13 @@ int main()
     for (int threads = 256; threads <= 512; threads *= 2) {            // x 4 workgroups per CU below = 4 / 8 waves per SIMD
         for (int form = 0; form < 2; form++) {
             hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-            auto launch = [&](int n) { if (form == 0) hipLaunchKernelGGL(bf_kernel<0>, dim3(256 * 4), dim3(threads), 0, 0, out, in, W, WP, n, q, b, f); else hipLaunchKernelGGL(bf_kernel<1>, dim3(256 * 4), dim3(threads), 0, 0, out, in, W, WP, n, q, b, f); };
+            auto launch = [&](int n) { if (form == 0) hipLaunchKernelGGL(bf_kernel<0>, dim3(256 * 4), dim3(threads), 0, 0, out, in, W, WP, n, q, b, f);
+                else hipLaunchKernelGGL(bf_kernel<1>, dim3(256 * 4), dim3(threads), 0, 0, out, in, W, WP, n, q, b, f); };
             launch(10); CK(hipEventRecord(e0)); launch(iters); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             const double per_simd = 8.0 * iters * (threads * 4 / 256);      // butterflies per SIMD lane-group: waves per SIMD x 8 x iters
-            printf("%d waves per SIMD  %-28s %8.3f ms  %6.2f ns per butterfly (wave) and SIMD\n", threads * 4 / 256, form == 0 ? "A Shoup (9 multiplies)" : "B fold (8 multiplies)", ms, ms * 1e6 / per_simd);
+            printf("%d waves per SIMD  %-28s %8.3f ms  %6.2f ns per butterfly (wave) and SIMD\n", threads * 4 / 256, form == 0 ? "A Shoup (9 multiplies)" :
+                "B fold (8 multiplies)", ms, ms * 1e6 / per_simd);
         }
     }
     return 0;
