@@ -130,10 +130,28 @@ def run_host(args, cfg_name, steps, warmup, batch=None, device=0, ranks=None, st
             open(os.path.join(work, "cmd.txt"), "w").write(" ".join(cmd) + "\n")
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC (RCCL across processes)
-        p = subprocess.run(cmd, capture_output=True, text=True, timeout=3000, env=env)
+        # A child that dies leaves the others inside a collective nobody will complete (ncclCommInitRank, the broadcast): the rank whose child failed drops a marker
+        # beside the rendezvous file, every harness polls for it while its own child runs and ends that child -- the job stops in seconds, not at a timeout.
+        marker = ranks.rendezvous_path(cfg_name) + ".failed" if ranks else None
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+        t_end, killed = time.time() + 3000, False
+        while True:
+            try:
+                out_s, err_s = proc.communicate(timeout=2.0)
+                break
+            except subprocess.TimeoutExpired:
+                if (marker and os.path.exists(marker)) or time.time() > t_end:
+                    proc.kill(); killed = True
         failed = None
-        if p.returncode != 0:
-            failed = f"bench.py: bench_host failed on rank {rank} (exit {p.returncode}): {p.stderr[-600:]}"
+        if proc.returncode != 0:
+            failed = (f"bench.py: bench_host on rank {rank} was stopped because another rank's failed" if killed and marker and os.path.exists(marker) else
+                      f"bench.py: bench_host failed on rank {rank} (exit {proc.returncode}): {err_s[-600:]}")
+            if marker and not killed:
+                open(marker, "w").write(str(rank))
+
+        class _P:                                                   # (what the code below reads of a finished child)
+            returncode, stdout, stderr = proc.returncode, out_s, err_s
+        p = _P
         if ranks and ranks.any(failed is not None):                # every rank learns of a failure anywhere: nobody waits for a line that will not come
             raise SystemExit(failed or f"bench.py: bench_host failed on another rank (this is rank {rank})")
         if failed:
