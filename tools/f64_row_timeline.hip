@@ -11,6 +11,9 @@
 //   2  variant 1 + twiddles through the scalar cache in the passes whose twiddle block index is wave-uniform (stride 2^ls >= 64 groups)
 //   3  (inverse only) variant 2 + lazy reduction: a pass reduces the two outputs that grew (8 B and 3.5 p) instead of all eight inputs
 //   4 / 5 / 6  the product's pass with scalar twiddles / scalar twiddles + lazy reduction / lazy reduction only (no second group in flight: fewer registers)
+//   7  the product's pass (lazy reduction when inverse) with the 7 twiddles of a (pass, block) stored as 8 consecutive doubles: one address and four 16-byte loads
+//      instead of seven addresses and seven 8-byte loads; scalar-cache loads where the block index is wave-uniform
+// (all variants drain the image with the product's batched f64_drain since round 5's second half)
 //   Throughput: ns per row transform over `rows` rows (HIP events).  Timeline: s_memtime stamps of wave 0 of every workgroup around the phases of the LAST rep,
 //   median over workgroups, in shader cycles (a diagnostic build of the same code: the stamps cost a few percent, the throughput numbers come from the build
 //   without).
@@ -23,6 +26,7 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 static constexpr int RB = 3, NPT = 16, NSTAMP = 16;
+struct Grouped { const double *g[4]; };           // variant 7: the 7 twiddles of a (pass, block) as 8 consecutive doubles
 
 __device__ __forceinline__ unsigned long long now() { return __builtin_amdgcn_s_memtime(); }
 
@@ -43,17 +47,23 @@ __device__ __forceinline__ void inv_stages_lazy(double (&v)[8], const double (&t
 
 template <bool INV, int VAR, bool STAMP>
 // st: this workgroup's stamp slots in global memory
-__device__ __forceinline__ void pass(double *sm, const double *W, int n, int ls, int tabidx, const F64Mod md, bool reduce_in, unsigned long long *st, int &si)
+__device__ __forceinline__ void pass(double *sm, const double *W, int n, int ls, int tabidx, const F64Mod md, bool reduce_in, unsigned long long *st, int &si,
+                                     const double *G)
 {
     const unsigned groups = (unsigned)n >> RB;
     const bool uniform = (VAR == 2 || VAR == 3) && ls >= 6;
     if (VAR == 0 || VAR >= 4) {
-        const bool scal = (VAR == 4 || VAR == 5) && ls >= 6, lazy = INV && (VAR == 5 || VAR == 6) && !reduce_in;
+        const bool scal = (VAR == 4 || VAR == 5) && ls >= 6, lazy = INV && (VAR == 5 || VAR == 6 || VAR == 7) && !reduce_in;
         for (unsigned g = threadIdx.x; g < groups; g += blockDim.x) {
             const unsigned blk = g >> ls, l = g & ((1u << ls) - 1);
             const int a0 = swz<RB>((int)((blk << (ls + RB)) + l));
             double tw[7], v[8];
-            if (scal) fetch_tw<INV, true>(tw, W, tabidx, blk); else fetch_tw<INV, false>(tw, W, tabidx, blk);
+            if (VAR == 7) {            // one address, four 16-byte loads (scalar-cache loads where the block index is wave-uniform)
+                const unsigned bb = ls >= 6 ? (unsigned)__builtin_amdgcn_readfirstlane((int)blk) : blk;
+                const d2 *gp = reinterpret_cast<const d2 *>(G + (size_t)bb * 8);
+                const d2 t0 = gp[0], t1 = gp[1], t2 = gp[2], t3 = gp[3];
+                tw[0] = t0.x; tw[1] = t0.y; tw[2] = t1.x; tw[3] = t1.y; tw[4] = t2.x; tw[5] = t2.y; tw[6] = t3.x;
+            } else if (scal) fetch_tw<INV, true>(tw, W, tabidx, blk); else fetch_tw<INV, false>(tw, W, tabidx, blk);
 #pragma unroll
             for (int c = 0; c < 8; c++) { v[c] = sm[a0 ^ swz<RB>(c << ls)]; if (INV && !lazy) v[c] = f64_reduce(v[c], md); }
             if (INV) { if (lazy) inv_stages_lazy(v, tw, md); else inv_stages_f64<RB>(v, tw, md); } else fwd_stages_f64<RB>(v, tw, md);
@@ -96,7 +106,7 @@ __device__ __forceinline__ void pass(double *sm, const double *W, int n, int ls,
 
 template <bool INV, int VAR, bool STAMP>
 __global__ void __launch_bounds__(512, 4) rows_kernel(const double *src, double *dst, const double *Wt, F64Mod md, int n, int logn, int reps,
-    unsigned long long *stamps)
+                                                      unsigned long long *stamps, Grouped gr)
 {
     extern __shared__ double smd[];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -121,15 +131,21 @@ __global__ void __launch_bounds__(512, 4) rows_kernel(const double *src, double 
         __syncthreads();
         if (last && tid == 0) st[si++] = now();
         const int full = logn / RB;                                  // (n = 8192: 13 = 4 x 3 + the fused gap-1 stage)
-        if (!INV) { int lt = logn - 1; for (int p = 0; p < full; p++, lt -= RB) { if (last) pass<false, VAR, true>(smd, Wt, n, lt - RB + 1, n >> (lt + 1), md,
-            false, st, si); else pass<false, VAR, false>(smd, Wt, n, lt - RB + 1, n >> (lt + 1), md, false, st, si); } }
-        else { int lt = 1; for (int p = 0; p < full; p++, lt += RB) { if (last) pass<true, VAR, true>(smd, Wt, n, lt, n >> (lt + 1), md, false, st, si);
-            else pass<true, VAR, false>(smd, Wt, n, lt, n >> (lt + 1), md, false, st, si); } }
-        double *out = dst + ((size_t)blockIdx.x * reps + rep) * n;
-        for (int s = 2 * tid; s < n; s += 2 * nt) {
-            const d2 v = f64_stage_out<INV, RB>(sm_load_pair<RB>(smd, s), Wt, n, logn, s, md);
-            *reinterpret_cast<d2 *>(out + s) = d2{f64_reduce(v.x, md), f64_reduce(v.y, md)};
+        if (!INV) {
+            int lt = logn - 1;
+            for (int p = 0; p < full; p++, lt -= RB) {
+                if (last) pass<false, VAR, true>(smd, Wt, n, lt - RB + 1, n >> (lt + 1), md, false, st, si, gr.g[p]);
+                else pass<false, VAR, false>(smd, Wt, n, lt - RB + 1, n >> (lt + 1), md, false, st, si, gr.g[p]);
+            }
+        } else {
+            int lt = 1;
+            for (int p = 0; p < full; p++, lt += RB) {
+                if (last) pass<true, VAR, true>(smd, Wt, n, lt, n >> (lt + 1), md, false, st, si, gr.g[p]);
+                else pass<true, VAR, false>(smd, Wt, n, lt, n >> (lt + 1), md, false, st, si, gr.g[p]);
+            }
         }
+        double *out = dst + ((size_t)blockIdx.x * reps + rep) * n;
+        f64_drain<INV, RB, NPT / 4>(smd, Wt, n, logn, md, [&](int s, d2 v) { *reinterpret_cast<d2 *>(out + s) = d2{f64_reduce(v.x, md), f64_reduce(v.y, md)}; });
         if (last && tid == 0) st[si++] = now();
         __syncthreads();
         if (last && tid == 0) st[si++] = now();
@@ -139,16 +155,16 @@ __global__ void __launch_bounds__(512, 4) rows_kernel(const double *src, double 
 
 template <bool INV, int VAR>
 static void run(const char *name, const double *src, double *dst, const double *W, F64Mod md, int n, int logn, int rows, int reps, unsigned long long *d_st,
-    std::vector<double> *ref)
+                std::vector<double> *ref, Grouped gr = Grouped{})
 {
     const size_t lds = (size_t)n * 8;
     auto k0 = rows_kernel<INV, VAR, false>; auto k1 = rows_kernel<INV, VAR, true>;
     CK(hipFuncSetAttribute((const void *)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CK(hipFuncSetAttribute((const void *)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(k0, dim3(rows), dim3(n / NPT), lds, 0, src, dst, W, md, n, logn, reps, d_st);
+    hipLaunchKernelGGL(k0, dim3(rows), dim3(n / NPT), lds, 0, src, dst, W, md, n, logn, reps, d_st, gr);
     CK(hipEventRecord(e0));
-    for (int it = 0; it < 3; it++) hipLaunchKernelGGL(k0, dim3(rows), dim3(n / NPT), lds, 0, src, dst, W, md, n, logn, reps, d_st);
+    for (int it = 0; it < 3; it++) hipLaunchKernelGGL(k0, dim3(rows), dim3(n / NPT), lds, 0, src, dst, W, md, n, logn, reps, d_st, gr);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     // results of the first 4 rows against variant 0
@@ -156,7 +172,7 @@ static void run(const char *name, const double *src, double *dst, const double *
     CK(hipMemcpy(h.data(), dst, h.size() * 8, hipMemcpyDeviceToHost));
     bool same = true;
     if (ref->empty()) *ref = h; else same = h == *ref;
-    hipLaunchKernelGGL(k1, dim3(rows), dim3(n / NPT), lds, 0, src, dst, W, md, n, logn, reps, d_st);
+    hipLaunchKernelGGL(k1, dim3(rows), dim3(n / NPT), lds, 0, src, dst, W, md, n, logn, reps, d_st, gr);
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> st((size_t)rows * NSTAMP);
     CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
@@ -193,11 +209,30 @@ int main(int argc, char **argv)
     printf("n = %d, %d workgroups (one source row each), %d transforms per workgroup, 512 threads x 16 points, 64 KiB LDS image (two workgroups per CU)\n", n,
         rows, reps);
     printf("stamp order: fill+barrier | per pass: [loads issued ->] butterflies+stores -> barrier | drain+stores issued | barrier\n");
+    // variant 7: per pass and block the 7 twiddles of a radix-8 group as 8 consecutive doubles (the same values the product's table gives, regrouped)
+    auto grouped = [&](bool inv) {
+        Grouped gr{};
+        const int full = logn / RB;
+        int lt = inv ? 1 : logn - 1;
+        for (int p = 0; p < full; p++, lt += inv ? RB : -RB) {
+            const int tab = n >> (lt + 1), blocks = inv ? n >> (lt + RB) : tab;
+            std::vector<double> g((size_t)blocks * 8, 0.0);
+            for (int blk = 0; blk < blocks; blk++)
+                for (int st = 0; st < RB; st++) {
+                    if (!inv) for (int j = 0; j < (1 << st); j++) g[(size_t)blk * 8 + (1 << st) - 1 + j] = hw[(tab << st) + (blk << st) + j];
+                    else for (int j = 0; j < (1 << (RB - 1 - st)); j++) g[(size_t)blk * 8 + (1 << RB) - (1 << (RB - st)) + j] = hw[(tab >> st) + (blk << (RB - 1 - st)) + j];
+                }
+            double *d; CK(hipMalloc(&d, g.size() * 8)); CK(hipMemcpy(d, g.data(), g.size() * 8, hipMemcpyHostToDevice));
+            gr.g[p] = d;
+        }
+        return gr;
+    };
     std::vector<double> ref;
     run<false, 0>("forward, product pass", src, dst, W, md, n, logn, rows, reps, d_st, &ref);
     run<false, 1>("forward, both groups loaded first", src, dst, W, md, n, logn, rows, reps, d_st, &ref);
     run<false, 2>("forward, + scalar twiddles in wave-uniform passes", src, dst, W, md, n, logn, rows, reps, d_st, &ref);
     run<false, 4>("forward, product pass + scalar twiddles", src, dst, W, md, n, logn, rows, reps, d_st, &ref);
+    run<false, 7>("forward, grouped twiddle table (4 x 16-byte loads)", src, dst, W, md, n, logn, rows, reps, d_st, &ref, grouped(false));
     ref.clear();
     run<true, 0>("inverse, product pass", src, dst, W, md, n, logn, rows, reps, d_st, &ref);
     run<true, 1>("inverse, both groups loaded first", src, dst, W, md, n, logn, rows, reps, d_st, &ref);
@@ -206,5 +241,6 @@ int main(int argc, char **argv)
     run<true, 4>("inverse, product pass + scalar twiddles", src, dst, W, md, n, logn, rows, reps, d_st, &ref);
     run<true, 5>("inverse, product pass + scalar twiddles + lazy reduction", src, dst, W, md, n, logn, rows, reps, d_st, &ref);
     run<true, 6>("inverse, product pass + lazy reduction", src, dst, W, md, n, logn, rows, reps, d_st, &ref);
+    run<true, 7>("inverse, lazy reduction + grouped twiddle table", src, dst, W, md, n, logn, rows, reps, d_st, &ref, grouped(true));
     return 0;
 }
