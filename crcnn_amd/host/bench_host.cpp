@@ -302,7 +302,9 @@ int main(int argc, char **argv)
         printf("], ");
         if (comm) printf("\"weight_broadcast\": {\"via\": \"Network::broadcastParameters (crc_broadcast_weights: %s; per-rank checksums compared with the "
             "root's)\", \"bytes\": %zu, "
-                         "\"seconds\": %.3f, \"GBps\": %.2f, \"host_threads_per_rank\": %d}, ", getenv("CRC_COMM_TRANSPORT") &&
+                         "\"seconds\": %.3f, \"GBps\": %.2f, \"seconds_include\": \"the root's lift + NTT of its plaintext weights, the per-rank checksums "
+                             "and their all-gather\", "
+                         "\"host_threads_per_rank\": %d}, ", getenv("CRC_COMM_TRANSPORT") &&
                              !strcmp(getenv("CRC_COMM_TRANSPORT"), "shm") ?
                          "shared-memory rehearsal transport" : "ncclBroadcast over RCCL in <= 1 GiB pieces", bcast_bytes, bcast_s, bcast_s > 0 ?
                              bcast_bytes / bcast_s / 1e9 : 0.0, crc_host_thread_limit());

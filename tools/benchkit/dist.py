@@ -111,6 +111,13 @@ class HostRanks:
         if self.world > 1:
             self.dist.barrier()
             self.dist.destroy_process_group()
+        if self.rank == 0:                                           # the rendezvous ids (and failure markers) of this job
+            import glob
+            for f in glob.glob(self.rendezvous_path("*")):
+                try:
+                    os.remove(f)
+                except OSError:
+                    pass
 
 
 class Dist:
