@@ -70,10 +70,11 @@ struct F64Params {
     u64 p0_mod_q[CRC_MAXK];                       // p_0 mod q_j
 };
 
-// The auxiliary base of the ciphertext square over the engine's fp64 primes (kernels_square64.hip).  BEHZ's results do not depend on WHICH auxiliary base carries the
-// intermediate integers as long as it is large enough (fastbconv_sk is exact once |floor(t P / q)| / B + #B < m_sk / 2): instead of SEAL's k (+1) 61-bit primes and
-// m_sk the engine takes kf of its own 47-bit primes -- the fewest with prod p_j >= 4 n t q (1 + 2^-27 + 2^-40), decided in exact integers (ctx.cpp) --, p_0 .. p_{kf-2} as B and p_{kf-1} as m_sk, whose transforms and base conversions are fp64 arithmetic.
-// Constants are {centred residue, residue / p} pairs for f64_mulmod_const; a 55..60-bit operand enters as its two 32-bit halves, hence the "x 2^32" twins.
+// The auxiliary base of the ciphertext square over the engine's fp64 primes (kernels_square64.hip).  BEHZ's results do not depend on WHICH auxiliary base
+// carries the intermediate integers as long as it is large enough (fastbconv_sk is exact once |floor(t P / q)| / B + #B < m_sk / 2): instead of SEAL's k (+1)
+// 61-bit primes and m_sk the engine takes kf of its own 47-bit primes -- the fewest with prod p_j >= 4 n t q (1 + 2^-27 + 2^-40), decided in exact integers
+// (ctx.cpp) --, p_0 .. p_{kf-2} as B and p_{kf-1} as m_sk, whose transforms and base conversions are fp64 arithmetic. Constants are {centred residue, residue /
+// p} pairs for f64_mulmod_const; a 55..60-bit operand enters as its two 32-bit halves, hence the "x 2^32" twins.
 #define CRC_NF64A 12
 struct Sq64Params {
     int kf;                                       // primes in use (0: the parameters do not fit 12 primes -- the 61-bit base is used)
@@ -115,8 +116,13 @@ struct CrcTuning {
     int mfma_min_steps = 0;       // CRC_MFMA_MIN_STEPS: reduction steps of 32 channels from which a conv / dense layer goes to the limb GEMM (0: 8)
     int f64_radix = 0;            // CRC_F64_RADIX=3|4|5: butterfly stages per LDS pass of the fp64 transforms (0: default)
     int sq_chunk = 0;             // CRC_SQ_CHUNK: ciphertexts per internal pass of square + relinearise (0: by ring size)
-    int sq_fuse = -1;             // CRC_SQ_FUSE=1: an NTT-resident square lifts inside its forward fp64 transforms, 0: in a kernel of its own (round 3), -1: by k (fused up to k = 4)
-    int sq_path = 0;              // CRC_SQ_PATH=0: by parameters, 1: the square's auxiliary base is SEAL's 61-bit one (round-2 kernels), 2: the engine's fp64 primes
+    // CRC_SQ_FUSE=1: an NTT-resident square lifts inside its forward fp64 transforms, 0: in a kernel of its own (round 3), -1: by k (fused up to k = 4)
+    int sq_fuse = -1;
+    int f64_wave = -1;
+                                  // 2 K3, 3 the lifting forward kernel; -1: what measured faster (profiles/r05_square_pool_wave_local_*.txt): 7; 0: round-4
+                                  // kernels
+    // CRC_SQ_PATH=0: by parameters, 1: the square's auxiliary base is SEAL's 61-bit one (round-2 kernels), 2: the engine's fp64 primes
+    int sq_path = 0;
     int relin_path = 0;           // CRC_RELIN_PATH=0: by parameters, 1: key switching over the coefficient moduli (round-2 path), 2: over the two fp64 primes
 };
 

@@ -166,6 +166,66 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_digits_pool_f64
     }
 }
 
+// K1 with ONE workgroup barrier per transform (round 5; ntt_f64.h, wave-local passes): n = 8192 (CS = 3) or 16384 (CS = 4), n / 16 threads.  The source row --
+// or the digit sums of a pooling window, all four of a value in one word (relin_digits_pool_f64_kernel<.., ONE>) -- is held in the cross layout, every digit is
+// cut straight into the registers the cross pass works on (no fill), and the transformed block leaves through the wave's own drain.  POOL: one workgroup per
+// (pooled ciphertext, i); otherwise per (ciphertext, i).
+template <int CS, bool POOL>
+__global__ void __launch_bounds__(CS == 3 ? 512 : 1024, 4) relin_digits_wave_kernel(const u64 *src, int src_size, int src_poly, double *E, const double *Wf,
+    F64Params fp, int n,
+                                                                                int k, int D, int dbc, Relin64Tab tab, PoolGeom pg, int F)
+{
+    extern __shared__ double smd[];
+    const size_t o = blockIdx.x / k; const int i = blockIdx.x % k;
+    const u64 mask = (1ULL << dbc) - 1;
+    const int L = tab.L[i], g0 = tab.g0[i];
+    u64 r[16];
+    auto load_row = [&](const u64 *row, bool first) {
+        if (CS == 3) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(row + f64_cross_point<3>(2 * c));
+                if (!POOL) { r[2 * c] = v.x; r[2 * c + 1] = v.y; continue; }
+                const bool four = 3 * F < 64;
+                auto spread = [&](u64 x) {
+                    u64 w = (x & mask) | (((x >> dbc) & mask) << F) | (((x >> (2 * dbc)) & mask) << (2 * F));
+                    if (four) w |= (x >> (3 * dbc)) << (3 * F);
+                    return w;
+                };
+                r[2 * c] = (first ? 0 : r[2 * c]) + spread(v.x); r[2 * c + 1] = (first ? 0 : r[2 * c + 1]) + spread(v.y);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                const u64 x = row[f64_cross_point<4>(c)];
+                if (!POOL) { r[c] = x; continue; }
+                const bool four = 3 * F < 64;
+                u64 w = (x & mask) | (((x >> dbc) & mask) << F) | (((x >> (2 * dbc)) & mask) << (2 * F));
+                if (four) w |= (x >> (3 * dbc)) << (3 * F);
+                r[c] = (first ? 0 : r[c]) + w;
+                if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (four loads in flight, not sixteen: the sums already take 32 registers)
+            }
+        }
+    };
+    if (POOL) {
+        const size_t per = (size_t)pg.xo * pg.yo, plane = o / per; const int rem = (int)(o % per), ox = rem / pg.yo, oy = rem % pg.yo;
+        const size_t ct0 = (plane * pg.xd + (size_t)ox * pg.xs) * pg.yd + (size_t)oy * pg.ys;
+        for (int kx = 0; kx < pg.xf; kx++) for (int ky = 0; ky < pg.yf; ky++)
+            load_row(src + (((ct0 + (size_t)kx * pg.yd + ky) * src_size + src_poly) * k + i) * (size_t)n, kx == 0 && ky == 0);
+    } else load_row(src + ((o * src_size + src_poly) * k + i) * (size_t)n, true);
+    const int fw = POOL ? F : dbc;                           // width of a digit field in the held words
+    const u64 fmask = (1ULL << fw) - 1;
+    for (int d = 0; d < L; d++) {
+        for (int m = 0; m < CRC_NF64; m++) {
+            double *dst = E + ((o * D + g0 + d) * CRC_NF64 + m) * (size_t)n;
+            const double *W = Wf + (size_t)m * n;
+            f64_wave_forward<CS, 3>(smd, W, n, fp.m[m], [&](int q) { return (double)(u32)((r[q] >> (d * fw)) & fmask); });
+            f64_local_drain<3>(smd, W, n, fp.m[m], [&](int s, d2 pr) { *reinterpret_cast<d2 *>(dst + s) = pr; });
+            __syncthreads();
+        }
+    }
+}
+
 // ---- K2: slot-wise inner products
 // ------------------------------------------------------------------------------------------------------------------------------------ A[ct][pj][m][s] = sum_g
 // Kf[g][pj][m][s] E[ct][g][m][s]: every product reduced below 0.875 p, the sum of D <= 48 of them stays below 2^53 (exact); CT ciphertexts share every key
@@ -329,6 +389,110 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_inv_crt_kernel(
     }
 }
 
+// K3 with ONE workgroup barrier per transform (round 5; ntt_f64.h, wave-local passes): n = 8192 (CS = 3) or 16384 (CS = 4), n / 16 threads.  Both inverse
+// transforms end in the cross pass, i.e. in registers: the first prime's result simply stays there (no LDS read, no parking), the second meets it for the CRT
+// lift, the (c0, c1) rows are read in the same cross layout, and the canonical sums go into the image for the forward transform over q_j (or straight to
+// memory).
+template <int CS, bool OUT_NTT, bool LAZY>
+__global__ void __launch_bounds__(CS == 3 ? 512 : 1024, 4) relin_inv_crt_wave_kernel(const double *A, const u64 *x3, int add_size, u64 *y,
+    const ModParams *mods, const double *Wi,
+                                                                                 const ulonglong2 *Wq, F64Params fp, int n, int logn, int k, const u64 *mul,
+                                                                                     PoolGeom pg)
+{
+    extern __shared__ double smd[];
+    const size_t ct = blockIdx.x / (2 * k); const int pj = blockIdx.x % (2 * k), poly = pj / k, j = pj % k;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const double *a0row = A + ((ct * 2 * k + pj) * CRC_NF64) * (size_t)n;
+    // (two explicit blocks, not a loop over the primes: a loop keeps BOTH result arrays alive through both transforms)
+    double a0[16];
+    {
+        // (A holds lazy sums below 2^52.4: the fill reduces them)
+        f64_local_fill<3>(smd, Wi, n, fp.m[0], [&](int, int s) { return *reinterpret_cast<const d2 *>(a0row + s); });
+        f64_wave_inverse<CS, 3>(smd, Wi, n, fp.m[0], [&](int q, double x) { a0[q] = f64_reduce(x, fp.m[0]); });
+        __syncthreads();                                      // the image is filled again
+    }
+    double a1[16];
+    {
+        const double *src = a0row + n, *W = Wi + n;
+        f64_local_fill<3>(smd, W, n, fp.m[1], [&](int, int s) { return *reinterpret_cast<const d2 *>(src + s); });
+        f64_wave_inverse<CS, 3>(smd, W, n, fp.m[1], [&](int q, double x) { a1[q] = x; });
+    }
+    const ModParams mq = mods[j];
+    const u64 q = mq.q, p0q = fp.p0_mod_q[j];
+    size_t actw = ct;
+    if (pg.xf > 0) {
+        const size_t per = (size_t)pg.xo * pg.yo, plane = ct / per; const int rem = (int)(ct % per), ox = rem / pg.yo, oy = rem % pg.yo;
+        actw = (plane * pg.xd + (size_t)ox * pg.xs) * pg.yd + (size_t)oy * pg.ys;
+    }
+    const u64 *add = x3 + ((actw * add_size + poly) * k + j) * (size_t)n;
+    u64 *dst = y + ((ct * 2 + poly) * k + j) * (size_t)n;
+    // x = a0 + p0 t,  t = (a1 - a0) p0^-1 mod p1 centred (relin_inv_crt_kernel)
+    auto lift = [&](double a0v, double a1r, u64 addv) {
+        const double a1v = f64_reduce(a1r, fp.m[1]);
+        const double t = f64_reduce(f64_mulmod_const(a1v - a0v, fp.inv_p0_p1, fp.inv_p0_p1_q, fp.m[1].p), fp.m[1]);
+        const long long ti = (long long)t, a0i = (long long)a0v;
+        u64 lo, hi; mul64wide((u64)(ti < 0 ? -ti : ti), p0q, lo, hi);
+        u64 r = barrett128(lo, hi, mq);
+        if (ti < 0) r = negmod(r, q);
+        u64 a0m = (u64)(a0i < 0 ? -a0i : a0i);
+        if (a0m >= q) a0m = barrett128(a0m, 0, mq);
+        r = addmod(r, a0i < 0 ? negmod(a0m, q) : a0m, q);
+        return addmod(r, addv, q);
+    };
+    const int nw = pg.xf > 0 ? pg.xf * pg.yf : 1;
+    u64 *sm = reinterpret_cast<u64 *>(smd);
+    if (OUT_NTT) __syncthreads();                             // every wave has read its part of the image in the cross pass: the canonical sums go into it now
+    if constexpr (CS == 3) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int s = f64_cross_point<3>(2 * c);
+            ulonglong2 av = *reinterpret_cast<const ulonglong2 *>(add + s);
+            for (int w = 1; w < nw; w++) {
+                const int kx = w / pg.yf, ky = w - kx * pg.yf;
+                const ulonglong2 bv = *reinterpret_cast<const ulonglong2 *>(add + ((size_t)kx * pg.yd + ky) * add_size * k * n + s);
+                av.x = addmod(av.x, bv.x, q); av.y = addmod(av.y, bv.y, q);
+            }
+            const u64 r0 = lift(a0[2 * c], a1[2 * c], av.x), r1 = lift(a0[2 * c + 1], a1[2 * c + 1], av.y);
+            if (OUT_NTT) {
+                const int a = swz<3>(s);
+                *reinterpret_cast<ulonglong2 *>(sm + (a & ~1)) = (a & 1) ? ulonglong2{r1, r0} : ulonglong2{r0, r1};
+            } else *reinterpret_cast<ulonglong2 *>(dst + s) = ulonglong2{r0, r1};
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            const int s = f64_cross_point<4>(c);
+            u64 av = add[s];
+            for (int w = 1; w < nw; w++) { const int kx = w / pg.yf, ky = w - kx * pg.yf; av = addmod(av, add[((size_t)kx * pg.yd + ky) * add_size * k * n +
+                s], q); }
+            const u64 r0 = lift(a0[c], a1[c], av);
+            if (OUT_NTT) sm[swz<3>(s)] = r0; else dst[s] = r0;
+        }
+    }
+    if (!OUT_NTT) return;
+    // NTT-resident result: forward transform over q_j of (c_poly + R) in the same LDS image (as relin_inv_crt_kernel)
+    __syncthreads();
+    ntt_row_passes<false, LAZY, 3, true>(sm, Wq + (size_t)j * n, n, logn, q, mq.two_q);
+    const float rq = 1.0f / (float)((u32)(q >> 32) + 1);
+    const bool fuse1 = ntt_fused_stage(logn);
+    for (int s = 2 * tid; s < n; s += 2 * nt) {
+        const int a = swz<3>(s);
+        ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(sm + (a & ~1));
+        if (a & 1) { const u64 t = v.x; v.x = v.y; v.y = t; }
+        if (fuse1) fwd_pair_stage<LAZY>(v, Wq[(size_t)j * n + (n >> 1) + (s >> 1)], q, mq.two_q);
+        if (LAZY) { v.x = reduce_small(v.x, q, mq.two_q, rq); v.y = reduce_small(v.y, q, mq.two_q, rq); }
+        else {
+            v.x = v.x >= mq.two_q ? v.x - mq.two_q : v.x; v.x = v.x >= q ? v.x - q : v.x;
+            v.y = v.y >= mq.two_q ? v.y - mq.two_q : v.y; v.y = v.y >= q ? v.y - q : v.y;
+        }
+        if (mul) {
+            const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(mul + (size_t)j * n + s);
+            v.x = mulmod(v.x, w.x, mq); v.y = mulmod(v.y, w.y, mq);
+        }
+        *reinterpret_cast<ulonglong2 *>(dst + s) = v;
+    }
+}
+
 // ---- host side
 // ------------------------------------------------------------------------------------------------------------------------------------------------------------
 // can this context / key set take the fp64 path?  2 |R_j| <= n D 2^dbc q_max must stay below p_0 p_1 / 2 (a factor 2 of slack for the floating CRT), the row
@@ -413,6 +577,16 @@ static int relin64_mac(crc_ctx *c, const double *E, const double *Kf, double *A,
     return CRC_OK;
 }
 
+// the wave-local transforms (one workgroup barrier per transform) serve the two rings the bench configurations use; CRC_F64_WAVE=0 keeps the round-4 kernels
+// (bit 1: the digit kernel, bit 2: K3.  Measured, same box: K1 -17 % at n = 8192, -16 % at 16384; K3 +3 % / +14 % in its first form, which parked the first
+// prime's result in scratch, -0.3 % / -1.5 % of the whole sequence now -- its 64-bit forward transform is untouched: profiles/r05_square_pool_wave_local_*.txt)
+static bool f64_wave_path(const crc_ctx *c, int RB, int bit)
+{
+    if (RB != 3 || (c->logn != 13 && c->logn != 14)) return false;
+    const int sel = c->tune.f64_wave < 0 ? 7 : c->tune.f64_wave;
+    return (sel >> bit) & 1;
+}
+
 template <int RB, int NPT>
 static int relin64_tail(crc_ctx *c, const double *A, const u64 *x3, int add_size, u64 *y, size_t cnt, bool out_ntt, hipStream_t st, const u64 *mul,
     const PoolGeom *pool)
@@ -420,6 +594,17 @@ static int relin64_tail(crc_ctx *c, const double *A, const u64 *x3, int add_size
     bool lazy = true;
     for (int i = 0; i < c->k; i++) if (c->tabs[i].m.bits > 57 || c->tabs[i].m.bits < 45) lazy = false;
     const size_t lds = (size_t)c->n * 8;
+    if (f64_wave_path(c, RB, 2)) {
+        const bool cs3 = c->logn == 13;
+        auto kern = !out_ntt ? (cs3 ? relin_inv_crt_wave_kernel<3, false, false> : relin_inv_crt_wave_kernel<4, false, false>)
+                  : lazy ? (cs3 ? relin_inv_crt_wave_kernel<3, true, true> : relin_inv_crt_wave_kernel<4, true, true>)
+                         : (cs3 ? relin_inv_crt_wave_kernel<3, true, false> : relin_inv_crt_wave_kernel<4, true, false>);
+        { const int rc = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (rc) return rc; }
+        hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * 2 * c->k)), dim3(c->n / 16), lds, st, A, x3, add_size, y, c->d_mods, c->d_f64_irp,
+                           reinterpret_cast<const ulonglong2 *>(c->d_rp), c->f64, c->n, c->logn, c->k, mul, pool ? *pool : PoolGeom{0, 0, 0, 0, 0, 0, 0, 0});
+        HIPCHK(hipGetLastError());
+        return CRC_OK;
+    }
     auto kern = !out_ntt ? relin_inv_crt_kernel<RB, NPT, false, false> : lazy ? relin_inv_crt_kernel<RB, NPT, true, true> : relin_inv_crt_kernel<RB, NPT,
         true, false>;
     { const int rc = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (rc) return rc; }
@@ -455,12 +640,26 @@ int k_relinearize64(crc_ctx *c, const u64 *src, int src_size, int src_poly, cons
         bool one = true;
         for (int i = 0; i < c->k; i++) { const int L = tab.L[i]; if ((L - 1) * F + ((int)c->tabs[i].m.bits - (L - 1) * dbc + wbits) > 64 || F > 32) one =
             false; }
+        if (one && f64_wave_path(c, RB, 1)) {
+            auto kw = c->logn == 13 ? relin_digits_wave_kernel<3, true> : relin_digits_wave_kernel<4, true>;
+            const int r3 = crc_ctx_ensure_lds(c, (const void *)kw, lds); if (r3) return r3;
+            hipLaunchKernelGGL(kw, dim3((unsigned)(cnt * k)), dim3(c->n / 16), lds, st, src, src_size, src_poly, E, c->d_f64_rp, c->f64, c->n, c->k, D, dbc,
+                tab, *pool, F);
+            HIPCHK(hipGetLastError());
+        } else {
         auto kern = RB == 3 ? (one ? relin_digits_pool_f64_kernel<3, 16, true> : relin_digits_pool_f64_kernel<3, 16, false>)
                   : RB == 4 ? (one ? relin_digits_pool_f64_kernel<4, 16, true> : relin_digits_pool_f64_kernel<4, 16, false>)
                             : (one ? relin_digits_pool_f64_kernel<5, 32, true> : relin_digits_pool_f64_kernel<5, 32, false>);
         const int r2 = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (r2) return r2;
         hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * k)), dim3(f64_hold_threads(c, RB)), lds, st, src, src_size, src_poly, E, c->d_f64_rp, c->f64, c->n,
             c->logn, c->k, D, dbc, tab, *pool, F);
+        HIPCHK(hipGetLastError());
+        }
+    } else if (f64_wave_path(c, RB, 1)) {
+        auto kw = c->logn == 13 ? relin_digits_wave_kernel<3, false> : relin_digits_wave_kernel<4, false>;
+        const int r3 = crc_ctx_ensure_lds(c, (const void *)kw, lds); if (r3) return r3;
+        hipLaunchKernelGGL(kw, dim3((unsigned)(cnt * k)), dim3(c->n / 16), lds, st, src, src_size, src_poly, E, c->d_f64_rp, c->f64, c->n, c->k, D, dbc, tab,
+                           PoolGeom{0, 0, 0, 0, 0, 0, 0, 0}, dbc);
         HIPCHK(hipGetLastError());
     } else {
         auto kern = RB == 3 ? relin_digits_f64_kernel<3, 16> : RB == 4 ? relin_digits_f64_kernel<4, 16> : relin_digits_f64_kernel<5, 32>;

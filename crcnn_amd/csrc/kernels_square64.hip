@@ -183,6 +183,94 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) sq64_inv_kernel(const
     transform_store(2);
 }
 
+// ---- the two row kernels with ONE workgroup barrier per transform (round 5; ntt_f64.h, wave-local passes): n = 8192 (CS = 3) or 16384 (CS = 4), n / 16
+// threads ---- sq64_liftfwd_kernel: the lifted values are computed straight into the cross layout (the k source rows are read in it: 16-byte pairs for CS = 3),
+// the cross pass runs on them in registers, the wave drains its own block.
+template <int K, int CS>
+__global__ void __launch_bounds__(CS == 3 ? 512 : 1024, 4) sq64_liftfwd_wave_kernel(const u64 *tr, double *out, const double *Wf, const BehzParams *bp,
+    const Sq64Params *sp,
+                                                                                int n, int kf, size_t polys)
+{
+    extern __shared__ double smd[];
+    size_t poly; unsigned j;
+    if (!xcd_group(blockIdx.x, (unsigned)kf, polys, poly, j)) return;
+    const BehzParams &b = *bp; const Sq64Params &f = *sp;
+    const F64Mod md = f.m[j];
+    const u64 *src = tr + poly * (size_t)K * n;
+    const u32 iq = (u32)b.inv_q_mod_mt;
+    // (sum_i tr_i (q/q_i) + q r) m~^-1 mod p_j of one point from its K residues (sq64_liftfwd_kernel; baseconverter.cpp:663-742, 581-622)
+    double v[16];
+    if constexpr (CS == 3) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int s = f64_cross_point<3>(2 * c);
+            u32 xm0 = 0, xm1 = 0; double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+                const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(src + (size_t)i * n + s);
+                xm0 += (u32)x.x * (u32)b.qhat_mod_mt[i]; xm1 += (u32)x.y * (u32)b.qhat_mod_mt[i];
+                a0 += mul_split((double)(u32)(x.x >> 32), (double)(u32)x.x, f.lift_c[j][i], md.p);
+                a1 += mul_split((double)(u32)(x.y >> 32), (double)(u32)x.y, f.lift_c[j][i], md.p);
+            }
+            a0 += f64_mulmod_const((double)(0u - xm0 * iq), f.lift_r[j][0], f.lift_r[j][1], md.p);
+            a1 += f64_mulmod_const((double)(0u - xm1 * iq), f.lift_r[j][0], f.lift_r[j][1], md.p);
+            v[2 * c] = f64_reduce(a0, md); v[2 * c + 1] = f64_reduce(a1, md);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            const int s = f64_cross_point<4>(c);
+            u32 xm0 = 0; double a0 = 0.0;
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+                const u64 x = src[(size_t)i * n + s];
+                xm0 += (u32)x * (u32)b.qhat_mod_mt[i];
+                a0 += mul_split((double)(u32)(x >> 32), (double)(u32)x, f.lift_c[j][i], md.p);
+            }
+            a0 += f64_mulmod_const((double)(0u - xm0 * iq), f.lift_r[j][0], f.lift_r[j][1], md.p);
+            v[c] = f64_reduce(a0, md);
+        }
+    }
+    const double *W = Wf + (size_t)j * n;
+    f64_wave_forward<CS, 3>(smd, W, n, md, [&](int q) { return v[q]; });
+    double *row = out + (poly * kf + j) * (size_t)n;
+    f64_local_drain<3>(smd, W, n, md, [&](int s, d2 pr) { *reinterpret_cast<d2 *>(row + s) = d2{f64_reduce(pr.x, md), f64_reduce(pr.y, md)}; });
+}
+// sq64_inv_kernel: a / b are held in the block-local layout the fills read them in; every product's transform ends in the cross pass and leaves from registers.
+template <int CS>
+__global__ void __launch_bounds__(CS == 3 ? 512 : 1024, 4) sq64_inv_wave_kernel(const double *in, double *out, const double *Wi, const Sq64Params *sp, int n,
+    int kf)
+{
+    extern __shared__ double smd[];
+    const size_t ct = blockIdx.x / kf; const int j = blockIdx.x % kf;
+    const F64Mod md = sp->m[j];
+    const double *a = in + ((ct * 2 + 0) * kf + j) * (size_t)n, *b = in + ((ct * 2 + 1) * kf + j) * (size_t)n;
+    const double *W = Wi + (size_t)j * n;
+    double r[16], res[16];
+    auto finish = [&](int o) {
+        f64_wave_inverse<CS, 3>(smd, W, n, md, [&](int q, double x) { res[q] = f64_reduce(x, md); });
+        f64_cross_store<CS>(out + ((ct * 3 + o) * kf + j) * (size_t)n, res);
+        __syncthreads();                                      // the image is filled again
+    };
+    // a^2; a stays in r
+    f64_local_fill<3>(smd, W, n, md, [&](int u, int s) {
+        const d2 v = *reinterpret_cast<const d2 *>(a + s); r[2 * u] = v.x; r[2 * u + 1] = v.y;
+        return d2{f64_mulmod(v.x, v.x, md), f64_mulmod(v.y, v.y, md)};
+    });
+    finish(0);
+    // 2ab; b replaces a in r
+    f64_local_fill<3>(smd, W, n, md, [&](int u, int s) {
+        const d2 v = *reinterpret_cast<const d2 *>(b + s);
+        const d2 pr{2.0 * f64_mulmod(r[2 * u], v.x, md), 2.0 * f64_mulmod(r[2 * u + 1], v.y, md)};
+        r[2 * u] = v.x; r[2 * u + 1] = v.y;
+        return pr;
+    });
+    finish(1);
+    // b^2
+    f64_local_fill<3>(smd, W, n, md, [&](int u, int) { return d2{f64_mulmod(r[2 * u], r[2 * u], md), f64_mulmod(r[2 * u + 1], r[2 * u + 1], md)}; });
+    finish(2);
+}
+
 // dq: [count][3][K][n] u64 (coefficient form over q, scaled), db: [count][3][KF][n] doubles (n times the coefficient, reduced) -> y3: [count][3][K][n]. (One
 // coefficient per thread: two, as in the lift kernel, cost more in occupancy than the 16-byte accesses returned -- 0.77 against 0.64 us per ciphertext at
 // (8192, 3))
@@ -248,6 +336,15 @@ __global__ void __launch_bounds__(256) sq64_floor_kernel(const u64 *dq, const do
 // ------------------------------------------------------------------------------------------------------------------------------------------------------------
 static int sq64_threads(const crc_ctx *c, int RB) { int nt = c->n >> RB; if (nt < 64) nt = 64; if (nt > (RB == 5 ? 512 : 1024)) nt = RB == 5 ? 512 : 1024;
     return nt; }
+// the wave-local transforms (one workgroup barrier per transform) serve the two rings the bench configurations use; CRC_F64_WAVE=0 keeps the round-4 kernels
+// (bit 0: sq64_inv_kernel -- -25 % at both rings --, bit 3: the lifting forward kernel -- +2 % / +31 %: it has no row to hold and the round-4 form runs it at
+// eight waves per SIMD; off by default)
+static bool sq64_wave_path(const crc_ctx *c, int RB, int bit)
+{
+    if (RB != 3 || (c->logn != 13 && c->logn != 14)) return false;
+    const int sel = c->tune.f64_wave < 0 ? 7 : c->tune.f64_wave;
+    return (sel >> bit) & 1;
+}
 static int sq64_radix(const crc_ctx *c) { const int r = c->tune.f64_radix; return r >= 3 && r <= 5 ? r : 3; }
 
 bool k_square64_supported(const crc_ctx *c)
@@ -287,7 +384,15 @@ int k_square64(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStre
         xn = x;
         bool launched = false;
         const unsigned grid = xcd_grid(cnt * 2, (unsigned)kf);
-#define LIFTFWD(KV) if (c->k == KV) { \
+        if (sq64_wave_path(c, RB, 3)) {
+#define LIFTW(KV) if (c->k == KV) { \
+            auto kern = c->logn == 13 ? sq64_liftfwd_wave_kernel<KV, 3> : sq64_liftfwd_wave_kernel<KV, 4>; \
+            if ((rc = crc_ctx_ensure_lds(c, (const void *)kern, lds))) return rc; \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(c->n / 16), lds, st, QN, LB, Wf, c->d_behz, c->d_sq64, c->n, (int)kf, cnt * 2); launched = true; }
+            LIFTW(1) LIFTW(2) LIFTW(3) LIFTW(4)
+#undef LIFTW
+        }
+#define LIFTFWD(KV) if (!launched && c->k == KV) { \
             auto kern = RB == 3 ? sq64_liftfwd_kernel<KV, 3> : RB == 4 ? sq64_liftfwd_kernel<KV, 4> : sq64_liftfwd_kernel<KV, 5>; \
             if ((rc = crc_ctx_ensure_lds(c, (const void *)kern, lds))) return rc; \
             hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), lds, st, QN, LB, Wf, c->d_behz, c->d_sq64, c->n, c->logn, (int)kf, cnt * 2); launched = true; }
@@ -315,7 +420,12 @@ int k_square64(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStre
     }
     // a^2, 2ab, b^2 over q are formed while the inverse transforms load their rows (kernels.hip); over the fp64 primes in sq64_inv_kernel
     if ((rc = k_square_intt(c, xn, DQ, cnt, false, st))) return rc;
-    {
+    if (sq64_wave_path(c, RB, 0)) {
+        auto kern = c->logn == 13 ? sq64_inv_wave_kernel<3> : sq64_inv_wave_kernel<4>;
+        if ((rc = crc_ctx_ensure_lds(c, (const void *)kern, lds))) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * kf)), dim3(c->n / 16), lds, st, LB, DB, Wi, c->d_sq64, c->n, (int)kf);
+        HIPCHK(hipGetLastError());
+    } else {
         auto kern = RB == 3 ? sq64_inv_kernel<3, 16> : RB == 4 ? sq64_inv_kernel<4, 16> : sq64_inv_kernel<5, 32>;
         if ((rc = crc_ctx_ensure_lds(c, (const void *)kern, lds))) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * kf)), dim3(sq64_hold_threads(c, RB)), lds, st, LB, DB, Wi, c->d_sq64, c->n, c->logn, (int)kf);

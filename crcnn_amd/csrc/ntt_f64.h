@@ -21,16 +21,14 @@ template <int SW> __device__ __forceinline__ d2 sm_load_pair(const double *sm, i
     return (a & 1) ? d2{v.y, v.x} : v;
 }
 
-// ---- fp64 butterflies (the index arithmetic of ntt_device.h's fwd_stages / inv_stages; arithmetic of f64mod.h)
-// --------------------------------------------------- forward: values grow by at most 0.875 p per stage: 16-bit inputs stay below 14 p < 2^51 through 15 stages
-// -- no reduction anywhere The 2^R - 1 twiddles of a thread's R stages are fetched up front (tw[(1 << st) - 1 + j] = twiddle j of stage st), in front of the
-// LDS reads of the pass: one exposed memory latency per pass instead of one per stage (the compiler keeps loads where they are written and waits right in front
-// of the first use) A twiddle is ONE double (the centred power of psi): the quotient of a butterfly product is estimated from the product itself (f64_mulmod:
-// fl(h / p) instead of y (w / p) -- the same six flops, one more link in the dependency chain), not from a precomputed companion w / p.  Half the table bytes
-// and, what matters more, 7 instead of 14 live twiddle registers per radix-8 pass: every transform kernel sits at the 64-register line of two 1024-thread
-// workgroups per CU, and the registers returned hold a row across its transforms (relinearisation's source row, the square's a / b rows, the first prime's
-// result in front of the CRT step) instead of re-reading it from memory or parking it there (round 3: 17 + 10 + 12 of 260 row transfers per ciphertext at
-// (8192, 3))
+// ---- fp64 butterflies (the index arithmetic of ntt_device.h's fwd_stages / inv_stages; arithmetic of f64mod.h) ----------------------------------------------
+// forward: values grow by at most 0.875 p per stage: 16-bit inputs stay below 14 p < 2^51 through 15 stages -- no reduction anywhere.
+// The 2^R - 1 twiddles of a thread's R stages are fetched up front (tw[(1 << st) - 1 + j] = twiddle j of stage st), in front of the LDS reads of the pass: one
+// exposed memory latency per pass instead of one per stage (the compiler keeps loads where they are written and waits right in front of the first use).
+// A twiddle is ONE double (the centred power of psi): the quotient of a butterfly product is estimated from the product itself (f64_mulmod: fl(h / p) instead
+// of y (w / p) -- the same six flops, one more link in the dependency chain), not from a precomputed companion w / p.  Half the table bytes and, what matters
+// more, 7 instead of 14 live twiddle registers per radix-8 pass: the registers returned hold a row across its transforms (relinearisation's source row, the
+// square's a / b rows, the first prime's result in front of the CRT step) instead of re-reading it from memory or parking it there.
 template <int R>
 __device__ __forceinline__ void load_tw_fwd(double (&tw)[(1 << R) - 1], const double *W, int m, int blk)
 {
@@ -211,4 +209,188 @@ __device__ __forceinline__ void ntt_row_passes_f64(double *sm, const double *W, 
         for (int p = 0; p < full; p++, lt += RB) ntt_pass_f64<true, RB, RB>(sm, W, n, lt, n >> (lt + 1), md, RB != 3 || (p == 0 && first_reduce));
         if (rem) ntt_tail_pass_f64<true, RB>(rem, sm, W, n, lt, n >> (lt + 1), md);
     }
+}
+
+// ---- ONE workgroup barrier per transform: wave-local passes (round 5)
+// ------------------------------------------------------------------------------------------ A workgroup of n / 16 threads has n / 1024 waves; give wave w the
+// 1024-point block [1024 w, 1024 w + 1024).  Only the CS = log2 n - 10 stages with gaps of 1024 and more cross the blocks.  A thread that owns, at every block
+// offset c 1024, the same position(s) inside the block -- the PAIR (2 t, 2 t + 1) for n = 8192 (CS = 3: 8 offsets x 2 points), the single point t for n = 16384
+// (CS = 4: 16 offsets) -- runs those stages in registers, straight from (forward) or to (inverse) memory: the fill and the first pass, or the last pass and the
+// drain, are one step without an LDS round trip.  The other ten stages never leave a block: three radix-8 passes in which wave w works on the 128 groups of ITS
+// block (in every pass with a gap below 1024 the block of group g is g >> 7) and the gap-1 stage, applied while the block is filled (inverse) or drained
+// (forward).  A wave's LDS operations execute in order, so these passes need no workgroup barrier: the image is synchronised ONCE per transform (between the
+// cross pass and the local ones) and once more before it is reused, instead of five to six times -- the waves of a workgroup stop waiting for the slowest of
+// them after every pass (a quarter of a transform's cycles: tools/f64_row_timeline.hip, profiles/r05_f64_row_timeline_one_barrier.txt: 29.5 -> 26.4 ns forward,
+// 30.4 -> 25.1 ns inverse, same results bit for bit). Register layout of a thread's 16 points ("cross layout"): CS = 3: v[2 c + e] = point 2 t + e + 1024 c; CS
+// = 4: v[c] = point t + 1024 c. Block-local layout (fill / drain): pair u of a thread = points 1024 w + 2 lane + 128 u and the next one, u < 8.
+#define CRC_F64_BLOCK 1024
+__device__ __forceinline__ bool f64_wave_geometry(int n, int logn) { return (logn == 13 || logn == 14) && (int)blockDim.x * 16 == n; }
+__device__ __forceinline__ void f64_wave_sync()
+{
+    // the compiler must not move this wave's LDS reads above its own earlier LDS writes (the hardware never does)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int CS> __device__ __forceinline__ int f64_cross_point(int i)
+{
+    return CS == 3 ? 2 * (int)threadIdx.x + (i & 1) + CRC_F64_BLOCK * (i >> 1) : (int)threadIdx.x + CRC_F64_BLOCK * i;
+}
+__device__ __forceinline__ int f64_local_pair(int u) { return CRC_F64_BLOCK * (int)(threadIdx.x >> 6) + 2 * (int)(threadIdx.x & 63) + 128 * u; }
+// a row of doubles in memory <-> the cross layout (16-byte accesses for CS = 3, 8-byte ones -- 512 contiguous bytes per wave instruction -- for CS = 4)
+template <int CS> __device__ __forceinline__ void f64_cross_load(const double *row, double (&v)[16])
+{
+    if (CS == 3) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) { const d2 x = *reinterpret_cast<const d2 *>(row + f64_cross_point<3>(2 * c)); v[2 * c] = x.x; v[2 * c + 1] = x.y; }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 16; c++) v[c] = row[f64_cross_point<4>(c)];
+    }
+}
+template <int CS> __device__ __forceinline__ void f64_cross_store(double *row, const double (&v)[16])
+{
+    if (CS == 3) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) *reinterpret_cast<d2 *>(row + f64_cross_point<3>(2 * c)) = d2{v[2 * c], v[2 * c + 1]};
+    } else {
+#pragma unroll
+        for (int c = 0; c < 16; c++) row[f64_cross_point<4>(c)] = v[c];
+    }
+}
+// the CS stages that cross the blocks, in registers, between a generator / consumer of the cross layout's registers and the image (8-byte LDS accesses: a
+// pair's two points belong to different radix-8 groups here, and keeping both groups alive for a 16-byte access costs 16 registers the row-holding kernels do
+// not have). Every group has block index 0 in these stages: the 2^CS - 1 twiddles are the same for the whole grid. Forward (the first stages of the transform,
+// gaps n/2 ... 1024): get(i) -> register i of the cross layout; results go to the image. Inverse (its last ones): inputs from the image, below 1.75 p (the lazy
+// local passes leave that) -- the radix-16 form reduces them first: four stages of sums would carry a 28 p difference into a multiplier that takes 16 p --;
+// put(i, value) receives register i, unreduced, below 14 p. (a value every lane holds alike, moved to scalar registers: the cross passes' twiddles are the same
+// for the whole grid, and 14 / 30 vector registers of them are what the row-holding kernels spill)
+__device__ __forceinline__ double f64_uniform(double x)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+template <int CS, int RB, class G>
+__device__ __forceinline__ void f64_cross_fwd_to_image(double *sm, const double *W, const F64Mod md, G &&get)
+{
+    double tw[(1 << CS) - 1];
+    load_tw_fwd<CS>(tw, W, 1, 0);
+#pragma unroll
+    for (int i = 0; i < (1 << CS) - 1; i++) tw[i] = f64_uniform(tw[i]);
+    if constexpr (CS == 3) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            double x[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) x[c] = get(2 * c + e);
+            fwd_stages_f64<3>(x, tw, md);
+#pragma unroll
+            for (int c = 0; c < 8; c++) sm[swz<RB>(f64_cross_point<3>(2 * c + e))] = x[c];
+        }
+    } else {
+        double x[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) x[c] = get(c);
+        fwd_stages_f64<4>(x, tw, md);
+#pragma unroll
+        for (int c = 0; c < 16; c++) sm[swz<RB>(f64_cross_point<4>(c))] = x[c];
+    }
+}
+template <int CS, int RB, class P>
+__device__ __forceinline__ void f64_cross_inv_from_image(const double *sm, const double *W, int n, const F64Mod md, P &&put)
+{
+    double tw[(1 << CS) - 1];
+    load_tw_inv<CS>(tw, W, n >> 11, 0);                        // the first of these stages has gap 1024: table index n / 2048
+#pragma unroll
+    for (int i = 0; i < (1 << CS) - 1; i++) tw[i] = f64_uniform(tw[i]);
+    if constexpr (CS == 3) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            double x[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) x[c] = sm[swz<RB>(f64_cross_point<3>(2 * c + e))];
+            inv_stages_f64<3>(x, tw, md);
+#pragma unroll
+            for (int c = 0; c < 8; c++) put(2 * c + e, x[c]);
+        }
+    } else {
+        double x[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) x[c] = f64_reduce(sm[swz<RB>(f64_cross_point<4>(c))], md);
+        inv_stages_f64<4>(x, tw, md);
+#pragma unroll
+        for (int c = 0; c < 16; c++) put(c, x[c]);
+    }
+}
+// the three wave-local radix-8 passes (nine stages: gaps 512 ... 2 forward, 2 ... 512 inverse) on this wave's block of the image
+template <bool INV, int RB>
+__device__ __forceinline__ void f64_local_passes(double *sm, const double *W, int n, const F64Mod md)
+{
+    const unsigned w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int p = 0; p < 3; p++) {
+        const int lt = INV ? 1 + 3 * p : 9 - 3 * p, ls = INV ? lt : lt - 2, tabidx = n >> (lt + 1);
+#pragma unroll 1
+        for (unsigned u = 0; u < 2; u++) {
+            const unsigned g = (w << 7) + lane + 64 * u;
+            const unsigned blk = g >> ls, l = g & ((1u << ls) - 1);
+            const int a0 = swz<RB>((int)((blk << (ls + 3)) + l));
+            double tw[7], v[8];
+            if (INV) load_tw_inv<3>(tw, W, tabidx, (int)blk); else load_tw_fwd<3>(tw, W, tabidx, (int)blk);
+#pragma unroll
+            for (int c = 0; c < 8; c++) v[c] = sm[a0 ^ swz<RB>(c << ls)];
+            if (INV) { inv_stages_f64<3>(v, tw, md); v[0] = f64_reduce(v[0], md); v[1] = f64_reduce(v[1], md); }      // lazy reduction (ntt_pass_f64)
+            else fwd_stages_f64<3>(v, tw, md);
+#pragma unroll
+            for (int c = 0; c < 8; c++) sm[a0 ^ swz<RB>(c << ls)] = v[c];
+        }
+        f64_wave_sync();
+    }
+}
+// forward: drain this wave's block through the gap-1 stage; store(s, pair) gets the unreduced pair (below 14 p).  No barrier in front: the block is the wave's
+// own
+template <int RB, class F>
+__device__ __forceinline__ void f64_local_drain(const double *sm, const double *W, int n, const F64Mod md, F &&store)
+{
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {                             // two batches of four pairs: eight at once cost the row-holding kernels their registers
+        d2 v[4]; double tw[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int s = f64_local_pair(4 * h + u); v[u] = sm_load_pair<RB>(sm, s); tw[u] = W[(n >> 1) + (s >> 1)]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const double T = f64_mulmod(tw[u], v[u].y, md); store(f64_local_pair(4 * h + u), d2{v[u].x + T, v[u].x - T}); }
+    }
+}
+// inverse: fill this wave's block through the gap-1 stage; load(u, s) returns the pair (s, s + 1) = pair u of the thread, any values below 2^52 (reduced here).
+// Ends with the wave-level fence the local passes need, no barrier
+template <int RB, class F>
+__device__ __forceinline__ void f64_local_fill(double *sm, const double *W, int n, const F64Mod md, F &&load)
+{
+#pragma unroll
+    for (int h = 0; h < 2; h++) {                             // (unrolled: load(u, .) indexes the caller's registers)
+        d2 v[4]; double tw[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int s = f64_local_pair(4 * h + u); v[u] = load(4 * h + u, s); tw[u] = W[(n >> 1) + (s >> 1)]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const double U = f64_reduce(v[u].x, md), V = f64_reduce(v[u].y, md);
+            sm_store_pair<RB>(sm, f64_local_pair(4 * h + u), U + V, f64_mulmod(tw[u], U - V, md));
+        }
+    }
+    f64_wave_sync();
+}
+// whole transforms on top of these.  FORWARD: get(i) (register i of the cross layout; any values below 2^35 or so, e.g. digits) -> the image, transformed; the
+// caller drains with f64_local_drain and must __syncthreads() before the image is written again.
+template <int CS, int RB, class G>
+__device__ __forceinline__ void f64_wave_forward(double *sm, const double *W, int n, const F64Mod md, G &&get)
+{
+    f64_cross_fwd_to_image<CS, RB>(sm, W, md, get);
+    __syncthreads();
+    f64_local_passes<false, RB>(sm, W, n, md);
+}
+// INVERSE after f64_local_fill: local passes, the barrier, the cross pass -> put(i, value) for the 16 registers of the cross layout, unreduced (below 14 p).
+// The caller must __syncthreads() before the image is written again.
+template <int CS, int RB, class P>
+__device__ __forceinline__ void f64_wave_inverse(double *sm, const double *W, int n, const F64Mod md, P &&put)
+{
+    f64_local_passes<true, RB>(sm, W, n, md);
+    __syncthreads();
+    f64_cross_inv_from_image<CS, RB>(sm, W, n, md, put);
 }

@@ -105,7 +105,9 @@ int  crc_ctx_table(const crc_ctx *ctx, const char *name, uint64_t *h_out, int ca
  * "conv1_pass_bytes", "limb_pack_group", "mac2_cfg", "mac_order", "mac_regstage", "ntt_inv61_loose", "ntt_split", "mfma_min_steps", "f64_radix", "relin_mac_ct",
  * "relin_path" (1: key switching over the coefficient moduli, as the reference does it, instead of over two fp64 primes), "sq_path" (1: the square's auxiliary base is SEAL's 61-bit
  * one instead of the engine's fp64 primes; 2: force the latter), "sq_chunk" (ciphertexts per internal pass of square + relinearise; changes crc_square_relin_work_bytes),
- * "sq_fuse" (1: an NTT-resident square lifts to its auxiliary base inside the forward transforms, 0: in a kernel of its own, -1: by the number of moduli).
+ * "sq_fuse" (1: an NTT-resident square lifts to its auxiliary base inside the forward transforms, 0: in a kernel of its own, -1: by the number of moduli),
+ * "f64_wave" (bit mask of the fp64 row kernels that run with one workgroup barrier per transform at n = 8192 / 16384: 1 sq64_inv, 2 the digit kernel, 4 K3, 8 the lifting
+ * forward kernel; -1: the measured choice, 0: the round-4 kernels).
  * Every path gives the same ciphertexts.  CRC_ERR_NOT_FOUND for anything else. */
 int  crc_ctx_set_tuning(crc_ctx *ctx, const char *name, long long value);
 

@@ -11,7 +11,8 @@
 //   2  variant 1 + twiddles through the scalar cache in the passes whose twiddle block index is wave-uniform (stride 2^ls >= 64 groups)
 //   3  (inverse only) variant 2 + lazy reduction: a pass reduces the two outputs that grew (8 B and 3.5 p) instead of all eight inputs
 //   4 / 5 / 6  the product's pass with scalar twiddles / scalar twiddles + lazy reduction / lazy reduction only (no second group in flight: fewer registers)
-//   7  the product's pass (lazy reduction when inverse) with the 7 twiddles of a (pass, block) stored as 8 consecutive doubles: one address and four 16-byte loads
+//   7  the product's pass (lazy reduction when inverse) with the 7 twiddles of a (pass, block) stored as 8 consecutive doubles: one address and four 16-byte "
+    "loads
 //      instead of seven addresses and seven 8-byte loads; scalar-cache loads where the block index is wave-uniform
 // (all variants drain the image with the product's batched f64_drain since round 5's second half)
 //   Throughput: ns per row transform over `rows` rows (HIP events).  Timeline: s_memtime stamps of wave 0 of every workgroup around the phases of the LAST rep,
@@ -145,12 +146,131 @@ __global__ void __launch_bounds__(512, 4) rows_kernel(const double *src, double 
             }
         }
         double *out = dst + ((size_t)blockIdx.x * reps + rep) * n;
-        f64_drain<INV, RB, NPT / 4>(smd, Wt, n, logn, md, [&](int s, d2 v) { *reinterpret_cast<d2 *>(out + s) = d2{f64_reduce(v.x, md), f64_reduce(v.y, md)}; });
+        f64_drain<INV, RB, NPT / 4>(smd, Wt, n, logn, md, [&](int s, d2 v) { *reinterpret_cast<d2 *>(out + s) = d2{f64_reduce(v.x, md), f64_reduce(v.y,
+            md)}; });
         if (last && tid == 0) st[si++] = now();
         __syncthreads();
         if (last && tid == 0) st[si++] = now();
     }
     if (STAMP && tid == 0) for (int i = si; i < NSTAMP; i++) st[i] = 0;
+}
+
+// ---- variant 8: ONE workgroup barrier per transform -------------------------------------------------------------------------------------------------------
+// n = 8192 on 512 threads = 8 waves x 1024 points.  The three stages with gaps 1024 / 2048 / 4096 are the only ones that cross the 1024-point blocks;
+    a thread that
+// owns the PAIR (l, l +
+    1) at the eight block offsets c 1024 can run them in registers straight from (forward) / to (inverse) the 16-byte memory accesses -- the fill
+// and the first pass, or the last pass and the drain,
+    become one step without an LDS round trip -- and the other ten stages stay inside a block.  Give block w to wave w
+// and those passes need no workgroup barrier at all: a wave's LDS operations execute in order, so its own writes are visible to its later reads.
+// Forward: registers -> cross pass -> image | BARRIER | three wave-local passes -> block-local drain (fused last stage) -> memory | BARRIER (the image is reused).
+// Inverse: block-local fill (fused first stage) -> three wave-local passes | BARRIER | cross pass from the image -> registers -> memory | BARRIER.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <bool INV>
+__device__ __forceinline__ void local_pass(double *sm, const double *W, int ls, int tabidx, const F64Mod md, bool lazy)
+{
+    const unsigned w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (unsigned u = 0; u < 2; u++) {
+        const unsigned g = (w << 7) + lane + 64 * u;                 // the 128 groups of block w (in every pass with a gap below 1024: block = g >> 7)
+        const unsigned blk = g >> ls, l = g & ((1u << ls) - 1);
+        const int a0 = swz<RB>((int)((blk << (ls + RB)) + l));
+        double tw[7], v[8];
+        if (INV) load_tw_inv<RB>(tw, W, tabidx, (int)blk); else load_tw_fwd<RB>(tw, W, tabidx, (int)blk);
+#pragma unroll
+        for (int c = 0; c < 8; c++) v[c] = sm[a0 ^ swz<RB>(c << ls)];
+        if (INV) { inv_stages_f64<RB>(v, tw, md); if (lazy) { v[0] = f64_reduce(v[0], md); v[1] = f64_reduce(v[1], md); } } else fwd_stages_f64<RB>(v, tw, md);
+#pragma unroll
+        for (int c = 0; c < 8; c++) sm[a0 ^ swz<RB>(c << ls)] = v[c];
+    }
+    wave_sync();
+}
+template <bool INV>
+__global__ void __launch_bounds__(512, 4) rows_kernel_wave(const double *src, double *dst, const double *Wt, F64Mod md, int n, int logn, int reps)
+{
+    extern __shared__ double smd[];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const double *row = src + (size_t)blockIdx.x * n;
+    // the held row: forward in the cross pass's layout (pairs 2 tid + 1024 c), inverse block-local (pairs 1024 w + 2 lane + 128 u)
+    double r[NPT];
+#pragma unroll
+    for (int u = 0; u < NPT / 2; u++) {
+        const int s = INV ? 1024 * w + 2 * lane + 128 * u : 2 * tid + 1024 * u;
+        const d2 v = *reinterpret_cast<const d2 *>(row + s); r[2 * u] = v.x; r[2 * u + 1] = v.y;
+    }
+    for (int rep = 0; rep < reps; rep++) {
+        const double sc = (double)(rep + 1);
+        double *out = dst + ((size_t)blockIdx.x * reps + rep) * n;
+        if (!INV) {
+            double tw[7];
+            load_tw_fwd<RB>(tw, Wt, 1, 0);                            // gaps 4096, 2048, 1024: block index 0 for every group -- seven wave-uniform twiddles
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                double v[8];
+#pragma unroll
+                for (int c = 0; c < 8; c++) v[c] = r[2 * c + e] * sc;
+                fwd_stages_f64<RB>(v, tw, md);
+#pragma unroll
+                // (back into the pair slots: stored as pairs below; r is re-made from the source next rep)
+                for (int c = 0; c < 8; c++) r[2 * c + e] = v[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 8; c++) sm_store_pair<RB>(smd, 2 * tid + 1024 * c, r[2 * c], r[2 * c + 1]);
+            __syncthreads();
+            int lt = logn - 1 - RB;
+            for (int p = 1; p < logn / RB; p++, lt -= RB) local_pass<false>(smd, Wt, lt - RB + 1, n >> (lt + 1), md, false);
+            // block-local drain with the fused gap-1 stage: wave w owns points [1024 w, 1024 w + 1024)
+            d2 v[8]; double t1[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int s = 1024 * w + 2 * lane + 128 * u; v[u] = sm_load_pair<RB>(smd, s); t1[u] = Wt[(n >> 1) + (s >> 1)]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int s = 1024 * w + 2 * lane + 128 * u;
+                const double T = f64_mulmod(t1[u], v[u].y, md);
+                *reinterpret_cast<d2 *>(out + s) = d2{f64_reduce(v[u].x + T, md), f64_reduce(v[u].x - T, md)};
+            }
+            __syncthreads();
+            // (the sandbox re-reads its source row; the digit kernel re-cuts its held words)
+#pragma unroll
+            for (int u = 0; u < NPT / 2; u++) { const d2 x = *reinterpret_cast<const d2 *>(row + 2 * tid + 1024 * u); r[2 * u] = x.x; r[2 * u + 1] = x.y; }
+        } else {
+            // block-local fill with the fused gap-1 stage
+            double t1[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) t1[u] = Wt[(n >> 1) + ((1024 * w + 2 * lane + 128 * u) >> 1)];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int s = 1024 * w + 2 * lane + 128 * u;
+                const double U = f64_reduce(r[2 * u] * sc, md), V = f64_reduce(r[2 * u + 1] * sc, md);
+                sm_store_pair<RB>(smd, s, U + V, f64_mulmod(t1[u], U - V, md));
+            }
+            wave_sync();
+            int lt = 1;
+            for (int p = 0; p + 1 < logn / RB; p++, lt += RB) local_pass<true>(smd, Wt, lt, n >> (lt + 1), md, true);
+            __syncthreads();
+            // cross pass (gaps 1024, 2048, 4096) from the image to registers to memory
+            double tw[7];
+            load_tw_inv<RB>(tw, Wt, n >> (lt + 1), 0);
+            d2 x[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) x[c] = sm_load_pair<RB>(smd, 2 * tid + 1024 * c);
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                double v[8];
+#pragma unroll
+                for (int c = 0; c < 8; c++) v[c] = e ? x[c].y : x[c].x;
+                inv_stages_f64<RB>(v, tw, md);
+#pragma unroll
+                for (int c = 0; c < 8; c++) { if (e) x[c].y = f64_reduce(v[c], md); else x[c].x = f64_reduce(v[c], md); }
+            }
+#pragma unroll
+            for (int c = 0; c < 8; c++) *reinterpret_cast<d2 *>(out + 2 * tid + 1024 * c) = x[c];
+            __syncthreads();
+        }
+    }
 }
 
 template <bool INV, int VAR>
@@ -190,6 +310,24 @@ static void run(const char *name, const double *src, double *dst, const double *
         std::nth_element(d.begin(), d.begin() + rows / 2, d.end()); printf("   | whole %lld\n", d[rows / 2]); }
 }
 
+template <bool INV>
+static void run_wave(const char *name, const double *src, double *dst, const double *W, F64Mod md, int n, int logn, int rows, int reps,
+    const std::vector<double> &ref)
+{
+    const size_t lds = (size_t)n * 8;
+    auto k0 = rows_kernel_wave<INV>;
+    CK(hipFuncSetAttribute((const void *)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k0, dim3(rows), dim3(n / NPT), lds, 0, src, dst, W, md, n, logn, reps);
+    CK(hipEventRecord(e0));
+    for (int it = 0; it < 3; it++) hipLaunchKernelGGL(k0, dim3(rows), dim3(n / NPT), lds, 0, src, dst, W, md, n, logn, reps);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<double> h((size_t)4 * reps * n);
+    CK(hipMemcpy(h.data(), dst, h.size() * 8, hipMemcpyDeviceToHost));
+    printf("%-58s %7.2f ns per row transform   %s\n", name, ms / 3 * 1e6 / ((double)rows * reps), h == ref ? "results = variant 0" : "RESULTS DIFFER");
+}
+
 int main(int argc, char **argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 8192, rows = argc > 2 ? atoi(argv[2]) : 4096, reps = argc > 3 ? atoi(argv[3]) : 4;
@@ -220,7 +358,8 @@ int main(int argc, char **argv)
             for (int blk = 0; blk < blocks; blk++)
                 for (int st = 0; st < RB; st++) {
                     if (!inv) for (int j = 0; j < (1 << st); j++) g[(size_t)blk * 8 + (1 << st) - 1 + j] = hw[(tab << st) + (blk << st) + j];
-                    else for (int j = 0; j < (1 << (RB - 1 - st)); j++) g[(size_t)blk * 8 + (1 << RB) - (1 << (RB - st)) + j] = hw[(tab >> st) + (blk << (RB - 1 - st)) + j];
+                    else for (int j = 0; j < (1 << (RB - 1 - st)); j++) g[(size_t)blk * 8 + (1 << RB) - (1 << (RB - st)) + j] = hw[(tab >> st) + (blk << (RB -
+                        1 - st)) + j];
                 }
             double *d; CK(hipMalloc(&d, g.size() * 8)); CK(hipMemcpy(d, g.data(), g.size() * 8, hipMemcpyHostToDevice));
             gr.g[p] = d;
@@ -233,6 +372,7 @@ int main(int argc, char **argv)
     run<false, 2>("forward, + scalar twiddles in wave-uniform passes", src, dst, W, md, n, logn, rows, reps, d_st, &ref);
     run<false, 4>("forward, product pass + scalar twiddles", src, dst, W, md, n, logn, rows, reps, d_st, &ref);
     run<false, 7>("forward, grouped twiddle table (4 x 16-byte loads)", src, dst, W, md, n, logn, rows, reps, d_st, &ref, grouped(false));
+    run_wave<false>("forward, ONE workgroup barrier (wave-local passes)", src, dst, W, md, n, logn, rows, reps, ref);
     ref.clear();
     run<true, 0>("inverse, product pass", src, dst, W, md, n, logn, rows, reps, d_st, &ref);
     run<true, 1>("inverse, both groups loaded first", src, dst, W, md, n, logn, rows, reps, d_st, &ref);
@@ -242,5 +382,6 @@ int main(int argc, char **argv)
     run<true, 5>("inverse, product pass + scalar twiddles + lazy reduction", src, dst, W, md, n, logn, rows, reps, d_st, &ref);
     run<true, 6>("inverse, product pass + lazy reduction", src, dst, W, md, n, logn, rows, reps, d_st, &ref);
     run<true, 7>("inverse, lazy reduction + grouped twiddle table", src, dst, W, md, n, logn, rows, reps, d_st, &ref, grouped(true));
+    run_wave<true>("inverse, ONE workgroup barrier (wave-local passes, lazy)", src, dst, W, md, n, logn, rows, reps, ref);
     return 0;
 }
