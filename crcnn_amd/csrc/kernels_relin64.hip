@@ -20,8 +20,8 @@
 
 struct Relin64Tab { unsigned char L[CRC_MAXK], g0[CRC_MAXK]; };
 
-// ---- key preparation (once per call)
-// ------------------------------------------------------------------------------------------------------------------------------ evaluation keys as SEAL hands
+// ---- key preparation (once per call) ------------------------------------------------------------------------------------------------------------------------
+// evaluation keys as SEAL hands
 // them over (NTT form over q_j, residues possibly lazy / non-canonical) -> canonical
 __global__ void __launch_bounds__(256) evk_canon_kernel(const u64 *evk, u64 *out, const ModParams *mods, int n, int k)
 {
@@ -58,11 +58,10 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024) relin_keys_f64_kernel(co
     }
 }
 
-// ---- K1: digits of c2' under both primes
-// --------------------------------------------------------------------------------------------------------------------------- src: size-`src_size` ciphertexts,
-// poly `src_poly` = c2 (q/q_i)^-1 mod q_i (evaluator.cpp:984-985); E [ct][g][m][n], unreduced (|.| < 14 p) The source row is read ONCE and waits in registers
-// (NPT points per thread) through the 2 L_i transforms cut from it: round 3 read it again in front of every transform, 8 times at 16-bit digits, and the L2 had
-// long been swept by then (20 row reads per ciphertext for 3 rows at (8192, 3))
+// ---- K1: digits of c2' under both primes --------------------------------------------------------------------------------------------------------------------
+// src: size-`src_size` ciphertexts, poly `src_poly` = c2 (q/q_i)^-1 mod q_i (evaluator.cpp:984-985); E [ct][g][m][n], unreduced (|.| < 14 p) The source row is
+// read ONCE and waits in registers (NPT points per thread) through the 2 L_i transforms cut from it: round 3 read it again in front of every transform, 8 times
+// at 16-bit digits, and the L2 had long been swept by then (20 row reads per ciphertext for 3 rows at (8192, 3))
 template <int RB, int NPT>
 __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_digits_f64_kernel(const u64 *src, int src_size, int src_poly, double *E, const double *Wf,
     F64Params fp, int n, int logn,
@@ -226,11 +225,11 @@ __global__ void __launch_bounds__(CS == 3 ? 512 : 1024, 4) relin_digits_wave_ker
     }
 }
 
-// ---- K2: slot-wise inner products
-// ------------------------------------------------------------------------------------------------------------------------------------ A[ct][pj][m][s] = sum_g
-// Kf[g][pj][m][s] E[ct][g][m][s]: every product reduced below 0.875 p, the sum of D <= 48 of them stays below 2^53 (exact); CT ciphertexts share every key
-// value a thread loads A thread owns one slot of one prime for CT ciphertexts x PJ of the 2k key columns (PJS = 2k / PJ thread groups share the E values
-// through L2): per digit CT + PJ loads feed CT PJ products -- the kernel is bound by L2 bandwidth on the key and digit values, not by the 7 flops per product
+// ---- K2: slot-wise inner products ---------------------------------------------------------------------------------------------------------------------------
+// A[ct][pj][m][s] = sum_g Kf[g][pj][m][s] E[ct][g][m][s]: every product reduced below 0.875 p, the sum of D <= 48 of them stays below 2^53 (exact); CT
+// ciphertexts share every key value a thread loads A thread owns one slot of one prime for CT ciphertexts x PJ of the 2k key columns (PJS = 2k / PJ thread
+// groups share the E values through L2): per digit CT + PJ loads feed CT PJ products -- the kernel is bound by L2 bandwidth on the key and digit values, not by
+// the 7 flops per product
 template <int K, int CT, int PJ>
 __global__ void __launch_bounds__(256, CT * PJ <= 36 ? 4 : 1) relin_mac_f64_kernel(const double *E, const double *Kf, double *A, F64Params fp, int n, int D,
     size_t cnt)
@@ -286,13 +285,13 @@ __global__ void __launch_bounds__(256, CT * PJ <= 36 ? 4 : 1) relin_mac_f64_kern
             for (int pj = 0; pj < PJ; pj++) A[(((ct0 + c) * 2 * K + pj0 + pj) * CRC_NF64 + m) * nn + s] = acc[c][pj];
 }
 
-// ---- K3: inverse transforms, CRT lift, mod q_j, + (c0, c1)
-// ------------------------------------------------------------------------------------------------------------- A [ct][poly k + j][m][n]; x3: size-`add_size`
-// ciphertexts whose polys 0, 1 are added (coefficient form); y [ct][2][k][n].  The first prime's result waits in registers (NPT points per thread, reduced)
-// while the image serves the second transform -- round 3 parked it in its own row of A (6 rows written and read back per ciphertext at (8192, 3), and 11
-// spilled registers: the twiddle companions took the room) Workgroups of n / 16 threads, 16 points each: at n = 8192 two 512-thread workgroups per CU, four
-// waves per SIMD and 128 registers -- with 1024 threads and 8 points the 64-register line of the second workgroup left no room for the held row (18 spilled
-// registers, 16.6 instead of 12.2 MB of traffic per ciphertext and 5.55 instead of 5.19 us at (8192, 3): profiles/r04_square_relin_ab_step1.txt)
+// ---- K3: inverse transforms, CRT lift, mod q_j, + (c0, c1) --------------------------------------------------------------------------------------------------
+// A [ct][poly k + j][m][n]; x3: size-`add_size` ciphertexts whose polys 0, 1 are added (coefficient form); y [ct][2][k][n].  The first prime's result waits in
+// registers (NPT points per thread, reduced) while the image serves the second transform -- round 3 parked it in its own row of A (6 rows written and read back
+// per ciphertext at (8192, 3), and 11 spilled registers: the twiddle companions took the room) Workgroups of n / 16 threads, 16 points each: at n = 8192 two
+// 512-thread workgroups per CU, four waves per SIMD and 128 registers -- with 1024 threads and 8 points the 64-register line of the second workgroup left no
+// room for the held row (18 spilled registers, 16.6 instead of 12.2 MB of traffic per ciphertext and 5.55 instead of 5.19 us at (8192, 3):
+// profiles/r04_square_relin_ab_step1.txt)
 template <int RB, int NPT, bool OUT_NTT, bool LAZY>
 __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_inv_crt_kernel(const double *A, const u64 *x3, int add_size, u64 *y, const ModParams *mods,
     const double *Wi,
@@ -493,8 +492,7 @@ __global__ void __launch_bounds__(CS == 3 ? 512 : 1024, 4) relin_inv_crt_wave_ke
     }
 }
 
-// ---- host side
-// ------------------------------------------------------------------------------------------------------------------------------------------------------------
+// ---- host side ----------------------------------------------------------------------------------------------------------------------------------------------
 // can this context / key set take the fp64 path?  2 |R_j| <= n D 2^dbc q_max must stay below p_0 p_1 / 2 (a factor 2 of slack for the floating CRT), the row
 // must fit the LDS image the transforms work on, and at most 48 products may be summed lazily
 bool k_relin64_supported(const crc_ctx *c, int dbc)

@@ -332,8 +332,7 @@ __global__ void __launch_bounds__(256) sq64_floor_kernel(const u64 *dq, const do
     }
 }
 
-// ---- host side
-// ------------------------------------------------------------------------------------------------------------------------------------------------------------
+// ---- host side ----------------------------------------------------------------------------------------------------------------------------------------------
 static int sq64_threads(const crc_ctx *c, int RB) { int nt = c->n >> RB; if (nt < 64) nt = 64; if (nt > (RB == 5 ? 512 : 1024)) nt = RB == 5 ? 512 : 1024;
     return nt; }
 // the wave-local transforms (one workgroup barrier per transform) serve the two rings the bench configurations use; CRC_F64_WAVE=0 keeps the round-4 kernels

@@ -211,18 +211,18 @@ __device__ __forceinline__ void ntt_row_passes_f64(double *sm, const double *W, 
     }
 }
 
-// ---- ONE workgroup barrier per transform: wave-local passes (round 5)
-// ------------------------------------------------------------------------------------------ A workgroup of n / 16 threads has n / 1024 waves; give wave w the
-// 1024-point block [1024 w, 1024 w + 1024).  Only the CS = log2 n - 10 stages with gaps of 1024 and more cross the blocks.  A thread that owns, at every block
-// offset c 1024, the same position(s) inside the block -- the PAIR (2 t, 2 t + 1) for n = 8192 (CS = 3: 8 offsets x 2 points), the single point t for n = 16384
-// (CS = 4: 16 offsets) -- runs those stages in registers, straight from (forward) or to (inverse) memory: the fill and the first pass, or the last pass and the
-// drain, are one step without an LDS round trip.  The other ten stages never leave a block: three radix-8 passes in which wave w works on the 128 groups of ITS
-// block (in every pass with a gap below 1024 the block of group g is g >> 7) and the gap-1 stage, applied while the block is filled (inverse) or drained
-// (forward).  A wave's LDS operations execute in order, so these passes need no workgroup barrier: the image is synchronised ONCE per transform (between the
-// cross pass and the local ones) and once more before it is reused, instead of five to six times -- the waves of a workgroup stop waiting for the slowest of
-// them after every pass (a quarter of a transform's cycles: tools/f64_row_timeline.hip, profiles/r05_f64_row_timeline_one_barrier.txt: 29.5 -> 26.4 ns forward,
-// 30.4 -> 25.1 ns inverse, same results bit for bit). Register layout of a thread's 16 points ("cross layout"): CS = 3: v[2 c + e] = point 2 t + e + 1024 c; CS
-// = 4: v[c] = point t + 1024 c. Block-local layout (fill / drain): pair u of a thread = points 1024 w + 2 lane + 128 u and the next one, u < 8.
+// ---- ONE workgroup barrier per transform: wave-local passes (round 5) ---------------------------------------------------------------------------------------
+// A workgroup of n / 16 threads has n / 1024 waves; give wave w the 1024-point block [1024 w, 1024 w + 1024).  Only the CS = log2 n - 10 stages with gaps of
+// 1024 and more cross the blocks.  A thread that owns, at every block offset c 1024, the same position(s) inside the block -- the PAIR (2 t, 2 t + 1) for n =
+// 8192 (CS = 3: 8 offsets x 2 points), the single point t for n = 16384 (CS = 4: 16 offsets) -- runs those stages in registers, straight from (forward) or to
+// (inverse) memory: the fill and the first pass, or the last pass and the drain, are one step without an LDS round trip.  The other ten stages never leave a
+// block: three radix-8 passes in which wave w works on the 128 groups of ITS block (in every pass with a gap below 1024 the block of group g is g >> 7) and the
+// gap-1 stage, applied while the block is filled (inverse) or drained (forward).  A wave's LDS operations execute in order, so these passes need no workgroup
+// barrier: the image is synchronised ONCE per transform (between the cross pass and the local ones) and once more before it is reused, instead of five to six
+// times -- the waves of a workgroup stop waiting for the slowest of them after every pass (a quarter of a transform's cycles: tools/f64_row_timeline.hip,
+// profiles/r05_f64_row_timeline_one_barrier.txt: 29.5 -> 26.4 ns forward, 30.4 -> 25.1 ns inverse, same results bit for bit).
+//   cross layout of a thread's 16 points:  CS = 3: v[2 c + e] = point 2 t + e + 1024 c;  CS = 4: v[c] = point t + 1024 c
+//   block-local layout (fill / drain):     pair u of a thread = points 1024 w + 2 lane + 128 u and the next one, u < 8
 #define CRC_F64_BLOCK 1024
 __device__ __forceinline__ bool f64_wave_geometry(int n, int logn) { return (logn == 13 || logn == 14) && (int)blockDim.x * 16 == n; }
 __device__ __forceinline__ void f64_wave_sync()

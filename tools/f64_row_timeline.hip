@@ -162,8 +162,8 @@ __global__ void __launch_bounds__(512, 4) rows_kernel(const double *src, double 
     1) at the eight block offsets c 1024 can run them in registers straight from (forward) / to (inverse) the 16-byte memory accesses -- the fill
 // and the first pass, or the last pass and the drain,
     become one step without an LDS round trip -- and the other ten stages stay inside a block.  Give block w to wave w
-// and those passes need no workgroup barrier at all: a wave's LDS operations execute in order, so its own writes are visible to its later reads.
-// Forward: registers -> cross pass -> image | BARRIER | three wave-local passes -> block-local drain (fused last stage) -> memory | BARRIER (the image is reused).
+// and those passes need no workgroup barrier at all: a wave's LDS operations execute in order, so its own writes are visible to its later reads. Forward:
+// registers -> cross pass -> image | BARRIER | three wave-local passes -> block-local drain (fused last stage) -> memory | BARRIER (the image is reused).
 // Inverse: block-local fill (fused first stage) -> three wave-local passes | BARRIER | cross pass from the image -> registers -> memory | BARRIER.
 __device__ __forceinline__ void wave_sync()
 {

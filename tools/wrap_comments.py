@@ -28,6 +28,11 @@ for path in sys.argv[1:]:
         if sp is None:
             out.append(lines[i]); i += 1; continue
         indent, mark, text = sp
+        if re.search(r"[-=]{8,}", text):                       # a section rule ("// ---- title ------"): never part of a paragraph; trimmed to the limit if too long
+            l = lines[i]
+            if len(l) > LIMIT:
+                l = re.sub(r"([-=]{8,})\s*$", lambda m: m.group(1)[:max(8, len(m.group(1)) - (len(l) - LIMIT))], l.rstrip())
+            out.append(l); i += 1; continue
         # a paragraph: this line + following comment-only lines of the same indent whose text starts with exactly one space and no list / table marker
         para = [text]; j = i + 1
         while j < len(lines):
@@ -35,12 +40,14 @@ for path in sys.argv[1:]:
             if s2 is None or s2[0] != indent or s2[1] != mark:
                 break
             t2 = s2[2]
-            if not t2.startswith(" ") or t2.startswith("  ") or re.match(r" (\*|-|\d+[.)]|\||[A-Za-z0-9_]+ {2,})", t2) or not t2.strip():
+            if not t2.startswith(" ") or t2.startswith("  ") or re.match(r" (\*|-|\d+[.)]|\||[A-Za-z0-9_]+ {2,})", t2) or not t2.strip() or re.search(r"[-=]{8,}", t2):
                 break
             para.append(t2); j += 1
         block = lines[i:j]
         too_long = any(len(l) > LIMIT for l in block)
         orphan = any(len(block[k].split()) <= 3 and len(block[k - 1]) >= LIMIT - 25 for k in range(1, len(block)))
+        # ... or a short line in the middle of flowing text (what a repaired section rule leaves behind)
+        orphan = orphan or any(len(block[k]) < LIMIT - 50 and len(block[k + 1]) >= LIMIT - 15 for k in range(len(block) - 1))
         if not (too_long or orphan) or not text.strip():
             out.extend(block); i = j; continue
         lead = text[:len(text) - len(text.lstrip())] or " "
