@@ -119,8 +119,8 @@ struct CrcTuning {
     // CRC_SQ_FUSE=1: an NTT-resident square lifts inside its forward fp64 transforms, 0: in a kernel of its own (round 3), -1: by k (fused up to k = 4)
     int sq_fuse = -1;
     int f64_wave = -1;
-                                  // 2 K3, 3 the lifting forward kernel; -1: what measured faster (profiles/r05_square_pool_wave_local_*.txt): 7; 0: round-4
-                                  // kernels
+                                  // 2 K3, 3 the lifting forward kernel, 4 K3's 64-bit forward transform (with bit 2); -1: what measured faster
+                                  // (profiles/r05_square_pool_wave_local_*.txt): 7; 0: round-4 kernels
     // CRC_SQ_PATH=0: by parameters, 1: the square's auxiliary base is SEAL's 61-bit one (round-2 kernels), 2: the engine's fp64 primes
     int sq_path = 0;
     int relin_path = 0;           // CRC_RELIN_PATH=0: by parameters, 1: key switching over the coefficient moduli (round-2 path), 2: over the two fp64 primes

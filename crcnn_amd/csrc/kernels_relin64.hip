@@ -391,8 +391,33 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_inv_crt_kernel(
 // K3 with ONE workgroup barrier per transform (round 5; ntt_f64.h, wave-local passes): n = 8192 (CS = 3) or 16384 (CS = 4), n / 16 threads.  Both inverse
 // transforms end in the cross pass, i.e. in registers: the first prime's result simply stays there (no LDS read, no parking), the second meets it for the CRT
 // lift, the (c0, c1) rows are read in the same cross layout, and the canonical sums go into the image for the forward transform over q_j (or straight to
-// memory).
-template <int CS, bool OUT_NTT, bool LAZY>
+// memory). the three wave-local radix-8 passes of a FORWARD transform over a coefficient modulus on this wave's 1024-point block of the image (the 64-bit twin
+// of f64_local_passes: ntt_device.h's butterflies, ntt_f64.h's block ownership)
+template <bool LAZY>
+__device__ __forceinline__ void u64_local_passes_fwd(u64 *sm, const ulonglong2 *W, int n, u64 q, u64 q2)
+{
+    const unsigned w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int p = 0; p < 3; p++) {
+        const int lt = 9 - 3 * p, ls = lt - 2, tabidx = n >> (lt + 1);
+#pragma unroll 1
+        for (unsigned u = 0; u < 2; u++) {
+            const unsigned g = (w << 7) + lane + 64 * u;
+            const unsigned blk = g >> ls, l = g & ((1u << ls) - 1);
+            const int a0 = swz<3>((int)((blk << (ls + 3)) + l));
+            u64 v[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) v[c] = sm[a0 ^ swz<3>(c << ls)];
+            fwd_stages<3, LAZY>(v, W, tabidx, (int)blk, q, q2);
+#pragma unroll
+            for (int c = 0; c < 8; c++) sm[a0 ^ swz<3>(c << ls)] = v[c];
+        }
+        f64_wave_sync();
+    }
+}
+// U64W: the forward transform over q_j that follows the CRT runs wave-locally too -- its cross pass works on the CRT's results where they are made, in
+// registers
+template <int CS, bool OUT_NTT, bool LAZY, bool U64W>
 __global__ void __launch_bounds__(CS == 3 ? 512 : 1024, 4) relin_inv_crt_wave_kernel(const double *A, const u64 *x3, int add_size, u64 *y,
     const ModParams *mods, const double *Wi,
                                                                                  const ulonglong2 *Wq, F64Params fp, int n, int logn, int k, const u64 *mul,
@@ -441,6 +466,54 @@ __global__ void __launch_bounds__(CS == 3 ? 512 : 1024, 4) relin_inv_crt_wave_ke
     const int nw = pg.xf > 0 ? pg.xf * pg.yf : 1;
     u64 *sm = reinterpret_cast<u64 *>(smd);
     if (OUT_NTT) __syncthreads();                             // every wave has read its part of the image in the cross pass: the canonical sums go into it now
+    if constexpr (OUT_NTT && U64W) {
+        const ulonglong2 *W = Wq + (size_t)j * n;
+        auto point_sum = [&](int s) {                         // (c0 | c1)(s) summed over the pooling window
+            u64 av = add[s];
+            for (int w = 1; w < nw; w++) { const int kx = w / pg.yf, ky = w - kx * pg.yf; av = addmod(av, add[((size_t)kx * pg.yd + ky) * add_size * k * n +
+                s], q); }
+            return av;
+        };
+        if constexpr (CS == 3) {
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                u64 x[8];
+#pragma unroll
+                for (int c = 0; c < 8; c++) x[c] = lift(a0[2 * c + e], a1[2 * c + e], point_sum(f64_cross_point<3>(2 * c + e)));
+                fwd_stages<3, LAZY>(x, W, 1, 0, q, mq.two_q);
+#pragma unroll
+                for (int c = 0; c < 8; c++) sm[swz<3>(f64_cross_point<3>(2 * c + e))] = x[c];
+            }
+        } else {
+            u64 x[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) x[c] = lift(a0[c], a1[c], point_sum(f64_cross_point<4>(c)));
+            fwd_stages<4, LAZY>(x, W, 1, 0, q, mq.two_q);
+#pragma unroll
+            for (int c = 0; c < 16; c++) sm[swz<3>(f64_cross_point<4>(c))] = x[c];
+        }
+        __syncthreads();
+        u64_local_passes_fwd<LAZY>(sm, W, n, q, mq.two_q);
+        const float rq = 1.0f / (float)((u32)(q >> 32) + 1);
+#pragma unroll 2
+        for (int u = 0; u < 8; u++) {                         // block-local drain through the gap-1 stage
+            const int s = f64_local_pair(u), a = swz<3>(s);
+            ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(sm + (a & ~1));
+            if (a & 1) { const u64 t = v.x; v.x = v.y; v.y = t; }
+            fwd_pair_stage<LAZY>(v, W[(n >> 1) + (s >> 1)], q, mq.two_q);
+            if (LAZY) { v.x = reduce_small(v.x, q, mq.two_q, rq); v.y = reduce_small(v.y, q, mq.two_q, rq); }
+            else {
+                v.x = v.x >= mq.two_q ? v.x - mq.two_q : v.x; v.x = v.x >= q ? v.x - q : v.x;
+                v.y = v.y >= mq.two_q ? v.y - mq.two_q : v.y; v.y = v.y >= q ? v.y - q : v.y;
+            }
+            if (mul) {
+                const ulonglong2 wv = *reinterpret_cast<const ulonglong2 *>(mul + (size_t)j * n + s);
+                v.x = mulmod(v.x, wv.x, mq); v.y = mulmod(v.y, wv.y, mq);
+            }
+            *reinterpret_cast<ulonglong2 *>(dst + s) = v;
+        }
+        return;
+    }
     if constexpr (CS == 3) {
 #pragma unroll
         for (int c = 0; c < 8; c++) {
@@ -594,9 +667,11 @@ static int relin64_tail(crc_ctx *c, const double *A, const u64 *x3, int add_size
     const size_t lds = (size_t)c->n * 8;
     if (f64_wave_path(c, RB, 2)) {
         const bool cs3 = c->logn == 13;
-        auto kern = !out_ntt ? (cs3 ? relin_inv_crt_wave_kernel<3, false, false> : relin_inv_crt_wave_kernel<4, false, false>)
-                  : lazy ? (cs3 ? relin_inv_crt_wave_kernel<3, true, true> : relin_inv_crt_wave_kernel<4, true, true>)
-                         : (cs3 ? relin_inv_crt_wave_kernel<3, true, false> : relin_inv_crt_wave_kernel<4, true, false>);
+        const bool u64w = f64_wave_path(c, RB, 4);           // (bit 4: the 64-bit forward transform behind the CRT wave-local as well)
+        auto kern = !out_ntt ? (cs3 ? relin_inv_crt_wave_kernel<3, false, false, false> : relin_inv_crt_wave_kernel<4, false, false, false>)
+                  : lazy ? (u64w ? (cs3 ? relin_inv_crt_wave_kernel<3, true, true, true> : relin_inv_crt_wave_kernel<4, true, true, true>)
+                                 : (cs3 ? relin_inv_crt_wave_kernel<3, true, true, false> : relin_inv_crt_wave_kernel<4, true, true, false>))
+                         : (cs3 ? relin_inv_crt_wave_kernel<3, true, false, false> : relin_inv_crt_wave_kernel<4, true, false, false>);
         { const int rc = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (rc) return rc; }
         hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * 2 * c->k)), dim3(c->n / 16), lds, st, A, x3, add_size, y, c->d_mods, c->d_f64_irp,
                            reinterpret_cast<const ulonglong2 *>(c->d_rp), c->f64, c->n, c->logn, c->k, mul, pool ? *pool : PoolGeom{0, 0, 0, 0, 0, 0, 0, 0});

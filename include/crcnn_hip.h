@@ -107,7 +107,7 @@ int  crc_ctx_table(const crc_ctx *ctx, const char *name, uint64_t *h_out, int ca
  * one instead of the engine's fp64 primes; 2: force the latter), "sq_chunk" (ciphertexts per internal pass of square + relinearise; changes crc_square_relin_work_bytes),
  * "sq_fuse" (1: an NTT-resident square lifts to its auxiliary base inside the forward transforms, 0: in a kernel of its own, -1: by the number of moduli),
  * "f64_wave" (bit mask of the fp64 row kernels that run with one workgroup barrier per transform at n = 8192 / 16384: 1 sq64_inv, 2 the digit kernel, 4 K3, 8 the lifting
- * forward kernel; -1: the measured choice, 0: the round-4 kernels).
+ * forward kernel, 16 K3's 64-bit forward transform; -1: the measured choice, 0: the round-4 kernels).
  * Every path gives the same ciphertexts.  CRC_ERR_NOT_FOUND for anything else. */
 int  crc_ctx_set_tuning(crc_ctx *ctx, const char *name, long long value);
 
