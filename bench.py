@@ -184,6 +184,8 @@ def run_host(args, cfg_name, steps, warmup, batch=None, device=0, ranks=None, st
                 ok = ok and ok_pt
             else:
                 ok = ok and bool(sm["outputs_identical_to_resident"])
+    check["last_timed_launch_identical_to_first"] = r.get("last_timed_launch_identical_to_first")
+    ok = ok and bool(r.get("last_timed_launch_identical_to_first"))
     verified = ranks.count(ok) if ranks else int(ok)
     check["ranks_verified"] = f"{verified}/{world}"
     ok = verified == world

@@ -93,7 +93,7 @@ def test_bench_small_workload_matches_reference_golden():
     line = _run_bench(["--gpus", "1", "--python-twin", "--unfused-images", "24"])
     c = line["check"]
     assert line["n_gpus"] == 1 and c["golden_match"] is True and c["golden"] == "net_tiny1024_eng.json" and c["all_ok"] is True
-    assert c["predictions_match_plain_model"] in ("4/4", "24/24")
+    assert c["predictions_match_plain_model"] in ("4/4", "24/24") and c["last_timed_launch_identical_to_first"] is True
     assert line["config"]["host"].startswith("C++ host classes") and line["value"] > 0 and line["dtype"] == "u64" and line["vs_baseline"] is None
     assert set(line["ms_per_layer"]) == {"pool1_features.conv1+pool1", "pool2_features.conv2+pool2", "classifier.fc3", "classifier.fc4"}
     assert line["roofline"]["frac"] > 0 and line["roofline"]["launch_ms"] > 0 and line["roofline"]["traffic_source"] is None
