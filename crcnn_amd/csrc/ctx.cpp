@@ -178,6 +178,7 @@ static void read_tuning(CrcTuning &t)
     t.sq_fuse = (int)geti("CRC_SQ_FUSE", -1);
     t.f64_radix = (int)geti("CRC_F64_RADIX", 0);
     t.f64_wave = (int)geti("CRC_F64_WAVE", -1);
+    t.ntt_wave = (int)geti("CRC_NTT_WAVE", -1);
     t.mfma_min_steps = (int)geti("CRC_MFMA_MIN_STEPS", 0);
     t.relin_mac_ct = (int)geti("CRC_RELIN_MAC_CT", 0);
     t.ntt_split = (int)geti("CRC_NTT_SPLIT", 1);
@@ -203,6 +204,7 @@ extern "C" int crc_ctx_set_tuning(crc_ctx *c, const char *name, long long value)
     else if (s == "sq_fuse") t.sq_fuse = (int)value;
     else if (s == "f64_radix") t.f64_radix = (int)value;
     else if (s == "f64_wave") t.f64_wave = (int)value;
+    else if (s == "ntt_wave") t.ntt_wave = (int)value;
     else if (s == "mfma_min_steps") t.mfma_min_steps = (int)value;
     else if (s == "relin_mac_ct") t.relin_mac_ct = (int)value;
     else if (s == "ntt_split") t.ntt_split = (int)value;

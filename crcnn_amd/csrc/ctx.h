@@ -118,6 +118,9 @@ struct CrcTuning {
     int sq_chunk = 0;             // CRC_SQ_CHUNK: ciphertexts per internal pass of square + relinearise (0: by ring size)
     // CRC_SQ_FUSE=1: an NTT-resident square lifts inside its forward fp64 transforms, 0: in a kernel of its own (round 3), -1: by k (fused up to k = 4)
     int sq_fuse = -1;
+    // CRC_NTT_WAVE: the lazy 64-bit row transforms with one workgroup barrier per transform (ntt_rows_wave_kernel): bit 0 n = 8192, 1 n = 4096,
+    // 2 n = 16384, 3 n = 16384 with the Square prologues; -1: the measured choice (7)
+    int ntt_wave = -1;
     int f64_wave = -1;
                                   // 2 K3, 3 the lifting forward kernel, 4 K3's 64-bit forward transform (with bit 2); -1: what measured faster
                                   // (profiles/r05_square_pool_wave_local_*.txt): 7; 0: round-4 kernels

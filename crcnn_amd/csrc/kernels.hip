@@ -23,12 +23,14 @@ struct NttArgs {
     int src_rows_per_item;                                     // 0: src row = dst row;  >0: plain prologue, src row = r / mod_count
     size_t rows;                                               // total rows of the launch (prefetch variant)
     int pack_out;                                              // forward only: store the result as 28-bit limb pairs (operand form of the MAC kernels)
-    int src_ct_rows, dst_ct_rows;                              // both > 0: dst row r = (ct, j < dst_ct_rows) reads src row ct*src_ct_rows + j (leading polys of wider cts)
-    int prologue;                                              // 0 none, 1 plain lift, 2 delta scale, 3 relinearisation digit, 4 square products, 5 (inverse) scaled result
+    // both > 0: dst row r = (ct, j < dst_ct_rows) reads src row ct*src_ct_rows + j (leading polys of wider cts)
+    int src_ct_rows, dst_ct_rows;
+    // 0 none, 1 plain lift, 2 delta scale, 3 relinearisation digit, 4 square products, 5 (inverse) scaled result
+    int prologue;
     // prologue 3 (forward): row = ((ct*D + g)*k + j); the source row is the premultiplied third polynomial c2 (q/q_i)^-1 mod q_i of ciphertext ct under
     //   modulus i = dig_i[g] (src = size-`src_size` ciphertexts, poly `src_poly`); the value fed to the transform is its digit (v >> dig_shift[g]) & dig_mask
-    //   (relinearize_one_step, evaluator.cpp:984-1001) -- the digit polynomials never exist in memory
-    // prologue 4 (inverse): row = ((ct*3 + p)*mod_count + j); sources are the NTT-form rows a, b of polys 0 and 1 of ciphertext ct in `src` ([ct][2][mod_count][n]);
+    //   (relinearize_one_step, evaluator.cpp:984-1001) -- the digit polynomials never exist in memory prologue 4 (inverse): row = ((ct*3 + p)*mod_count + j);
+    //   sources are the NTT-form rows a, b of polys 0 and 1 of ciphertext ct in `src` ([ct][2][mod_count][n]);
     //   the value fed to the transform is a^2, 2ab or b^2 (Evaluator::square's dyadic products, evaluator.cpp:798-852)
     //   (prologue 4: the three products of one (ciphertext, modulus) pair run on ONE XCD, blockIdx -> row through xcd_group; `pairs` = ciphertexts x mod_count)
     // prologue 5 (inverse): the result leaves multiplied by the per-modulus constant post_mul (Shoup companion post_mul_s) -- the square's lift wants
@@ -54,6 +56,7 @@ __device__ __forceinline__ u64 plain_lift(u64 c, const PlainParams &pp, int i, c
 }
 
 #include "ntt_device.h"  // lpad, shoup_lazy4, reduce_small, fwd_stages / inv_stages, ntt_pass
+#include "ntt_f64.h"     // the wave-local scheme: block ownership, cross layout, u64_local_passes_*
 __device__ __forceinline__ u64 split28v(u64 v) { return (v & 0x0fffffffULL) | ((v >> 28) << 32); }      // = split28 further down
 
 // PRO: load prologue compiled into this instance -- 0: a.prologue in {0 none, 1 plain lift, 2 delta scale}; 3: relinearisation digit; 4: square products
@@ -76,10 +79,12 @@ __device__ __forceinline__ void ntt_rows_body(const NttArgs &a)
     const float rq = 1.0f / (float)((u32)(q >> 32) + 1);
     const ulonglong2 *W = a.w + (size_t)mi * n;
     u64 *dst = a.dst + row * (size_t)n;
-    // the gap-1 stage is applied here, in the loops that fill (inverse) / drain (forward) the image, when it would otherwise be a pass of its own (ntt_device.h)
+    // the gap-1 stage is applied here, in the loops that fill (inverse) / drain (forward) the image, when it would otherwise be a pass of its own
+    // (ntt_device.h)
     const bool fuse1 = ntt_fused_stage(logn);
     const ulonglong2 *W1 = W + (n >> 1);
-    auto put = [&](int s, u64 v0, u64 v1) { ulonglong2 v{v0, v1}; if (INV && fuse1) inv_pair_stage<LAZY>(v, W1[s >> 1], q, q2); sm_store_pair64(sm, s, v.x, v.y); };
+    auto put = [&](int s, u64 v0, u64 v1) { ulonglong2 v{v0, v1}; if (INV && fuse1) inv_pair_stage<LAZY>(v, W1[s >> 1], q, q2);
+        sm_store_pair64(sm, s, v.x, v.y); };
     if (INV && PRO == 4) {
         const size_t ct = row / (3 * (size_t)a.mod_count); const int p = (int)((row / a.mod_count) % 3);
         const u64 *pa = a.src + ((ct * 2 + (p == 2 ? 1 : 0)) * a.mod_count + mloc) * (size_t)n;
@@ -94,7 +99,8 @@ __device__ __forceinline__ void ntt_rows_body(const NttArgs &a)
         const size_t item = row / a.mod_count, ct = item / a.D; const int g = (int)(item % a.D);
         const u64 *src = a.src + ((ct * a.src_size + a.src_poly) * a.mod_count + a.dig_i[g]) * (size_t)n;
         const int sh = a.dig_shift[g];
-        for (int s = 2 * tid; s < n; s += 2 * nt) { const ulonglong2 v = ld2(src + s); sm_store_pair64(sm, s, (v.x >> sh) & a.dig_mask, (v.y >> sh) & a.dig_mask); }
+        for (int s = 2 * tid; s < n; s += 2 * nt) { const ulonglong2 v = ld2(src + s); sm_store_pair64(sm, s, (v.x >> sh) & a.dig_mask,
+            (v.y >> sh) & a.dig_mask); }
     } else {
         const size_t srow = a.dst_ct_rows ? (row / a.dst_ct_rows) * a.src_ct_rows + row % a.dst_ct_rows : (a.src_rows_per_item ? (row / a.mod_count) : row);
         const u64 *src = a.src + srow * (size_t)n;
@@ -156,12 +162,121 @@ __device__ __forceinline__ void ntt_rows_body(const NttArgs &a)
 template <bool INV, bool LAZY, int PRO>
 __global__ void __launch_bounds__(1024) ntt_rows_kernel(NttArgs a) { ntt_rows_body<INV, LAZY, PRO>(a); }
 
-// n = 16384: a whole row is 128 KiB of LDS = ONE resident workgroup per CU, and nothing overlaps its loads, barriers and stores.  Split form: the row as two halves of
-// n/2 values that go through the SAME 64-KiB image one after the other (two workgroups per CU again).
-//   forward  stage 0 pairs j with j + n/2 (one twiddle, W[1]): it is applied while the half is staged -- half h takes X + W Y (h = 0) or X - W Y (h = 1), both source
-//            values read for each half (the second time from L2) -- and the remaining stages are the transform of n/2 points whose twiddle block index is (2 + h) m
+// ONE workgroup barrier per transform (round 5; ntt_f64.h: wave-local passes) for the lazy 64-bit transforms at n = 4096 / 8192 / 16384: n / 16 threads, wave w
+// owns the 1024-point block w.  Forward: 16-byte loads in the cross layout -> the three cross stages in registers -> image | barrier | three wave-local passes
+// -> block-local drain through the gap-1 stage.  Inverse: block-local fill through the gap-1 stage (PRO 4: the square's products formed on the way) -> three
+// wave-local passes | barrier | the cross stages from the image to registers -> final reduction (PRO 5: the scaled result) -> 16-byte stores.  Same butterflies
+// on the same values as ntt_rows_body, hence the same results.  Prologues 0 / 4 / 5 without an addend; everything else stays with ntt_rows_kernel.
+template <bool INV, int PRO, int CS>
+__global__ void __launch_bounds__(CS == 2 ? 256 : CS == 3 ? 512 : 1024, 4) ntt_rows_wave_kernel(NttArgs a)
+{
+    // CS = log2 n - 10 stages cross the 1024-point blocks (n = 4096 / 8192 / 16384: 2 / 3 / 4); a thread owns E = 16 >> CS neighbouring points of every block
+    constexpr int E = 16 >> CS, C = 1 << CS;
+    extern __shared__ u64 sm[];
+    const int n = a.n, tid = threadIdx.x;
+    size_t row = blockIdx.x;
+    if (INV && PRO == 4) {
+        size_t pair; unsigned p;
+        if (!xcd_group(blockIdx.x, 3, a.pairs, pair, p)) return;
+        row = ((pair / a.mod_count) * 3 + p) * a.mod_count + pair % a.mod_count;
+    }
+    const int mloc = (int)(row % a.mod_count), mi = a.mod_base + mloc;
+    const ModParams m = a.mods[mi];
+    const u64 q = m.q, q2 = m.two_q;
+    const float rq = 1.0f / (float)((u32)(q >> 32) + 1);
+    const ulonglong2 *W = a.w + (size_t)mi * n, *W1 = W + (n >> 1);
+    u64 *dst = a.dst + row * (size_t)n;
+    auto pt = [&](int c, int e) { return E * tid + e + 1024 * c; };          // point e of this thread in block c
+    if (!INV) {
+        const size_t srow = a.dst_ct_rows ? (row / a.dst_ct_rows) * a.src_ct_rows + row % a.dst_ct_rows : (a.src_rows_per_item ? (row / a.mod_count) : row);
+        const u64 *src = a.src + srow * (size_t)n;
+        u64 x[16];
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            if constexpr (E == 1) x[c] = src[pt(c, 0)];
+            else {
+#pragma unroll
+                for (int e = 0; e < E; e += 2) { const ulonglong2 v = ld2(src + pt(c, e)); x[c * E + e] = v.x; x[c * E + e + 1] = v.y; }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            u64 y[C];
+#pragma unroll
+            for (int c = 0; c < C; c++) y[c] = x[c * E + e];
+            fwd_stages<CS, true>(y, W, 1, 0, q, q2);
+#pragma unroll
+            for (int c = 0; c < C; c++) sm[swz<3>(pt(c, e))] = y[c];
+        }
+        __syncthreads();
+        u64_local_passes_fwd<true>(sm, W, n, q, q2);
+#pragma unroll 2
+        for (int u = 0; u < 8; u++) {
+            const int s = f64_local_pair(u);
+            ulonglong2 v = sm_load_pair64(sm, s);
+            fwd_pair_stage<true>(v, W1[s >> 1], q, q2);
+            v.x = reduce_small(v.x, q, q2, rq); v.y = reduce_small(v.y, q, q2, rq);
+            if (a.pack_out) st2(dst + s, split28v(v.x), split28v(v.y)); else st2(dst + s, v.x, v.y);
+        }
+    } else {
+        if (PRO == 4) {
+            const size_t ct = row / (3 * (size_t)a.mod_count); const int p = (int)((row / a.mod_count) % 3);
+            const u64 *pa = a.src + ((ct * 2 + (p == 2 ? 1 : 0)) * a.mod_count + mloc) * (size_t)n;
+            const u64 *pb = a.src + ((ct * 2 + (p == 0 ? 0 : 1)) * a.mod_count + mloc) * (size_t)n;
+#pragma unroll 4
+            for (int u = 0; u < 8; u++) {
+                const int s = f64_local_pair(u);
+                const ulonglong2 av = ld2(pa + s), bv = ld2(pb + s);
+                ulonglong2 v{mulmod(av.x, bv.x, m), mulmod(av.y, bv.y, m)};
+                if (p == 1) { v.x = addmod(v.x, v.x, q); v.y = addmod(v.y, v.y, q); }
+                inv_pair_stage<true>(v, W1[s >> 1], q, q2);
+                sm_store_pair64(sm, s, v.x, v.y);
+            }
+        } else {
+            const size_t srow = a.dst_ct_rows ? (row / a.dst_ct_rows) * a.src_ct_rows + row % a.dst_ct_rows : (a.src_rows_per_item ? (row / a.mod_count) : row);
+            const u64 *src = a.src + srow * (size_t)n;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int s = f64_local_pair(u);
+                ulonglong2 v = ld2(src + s);
+                inv_pair_stage<true>(v, W1[s >> 1], q, q2);
+                sm_store_pair64(sm, s, v.x, v.y);
+            }
+        }
+        f64_wave_sync();
+        u64_local_passes_inv<true>(sm, W, n, q, q2);
+        __syncthreads();
+        const u64 pm = PRO == 5 ? a.post_mul[mloc] : 0, pms = PRO == 5 ? a.post_mul_s[mloc] : 0;
+        u64 x[16];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            u64 y[C];
+#pragma unroll
+            for (int c = 0; c < C; c++) y[c] = sm[swz<3>(pt(c, e))];
+            inv_stages<CS, true>(y, W, n >> 11, 0, q, q2);
+#pragma unroll
+            for (int c = 0; c < C; c++) x[c * E + e] = PRO == 5 ? mulmod_shoup(y[c], pm, pms, q) : reduce_small(y[c], q, q2, rq);
+        }
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            if constexpr (E == 1) dst[pt(c, 0)] = x[c];
+            else {
+#pragma unroll
+                for (int e = 0; e < E; e += 2) st2(dst + pt(c, e), x[c * E + e], x[c * E + e + 1]);
+            }
+        }
+    }
+}
+
+// n = 16384: a whole row is 128 KiB of LDS = ONE resident workgroup per CU, and nothing overlaps its loads, barriers and stores.  Split form: the row as two
+// halves of n/2 values that go through the SAME 64-KiB image one after the other (two workgroups per CU again).
+//   forward  stage 0 pairs j with j + n/2 (one twiddle, W[1]): it is applied while the half is staged -- half h takes X + W Y (h = 0) or X - W Y (h = 1), both
+//   source
+//            values read for each half (the second time from L2) -- and the remaining stages are the transform of n/2 points whose twiddle block index is (2 +
+//            h) m
 //            instead of m (global block I = h m' + i' of a stage with 2 m' blocks sits at table index 2 m' + I);
-//   inverse  the stages up to gap n/4 are two independent half transforms (again block index (2 + H) h'); the first half's result is parked in the destination row
+//   inverse  the stages up to gap n/4 are two independent half transforms (again block index (2 + H) h'); the first half's result is parked in the destination
+//   row
 //            (written and re-read by the same threads), the last stage (one twiddle, W[1]) combines it with the second half straight out of the image.
 // Value ranges, prologues and epilogues are those of ntt_rows_body: the same butterflies in the same order, hence the same (canonical) results.
 template <bool INV, bool LAZY, int PRO>
@@ -254,7 +369,8 @@ __device__ __forceinline__ void ntt_rows_split_body(const NttArgs &a)
             if (add) { const ulonglong2 ad = ld2(add + s); v0 = addmod(v0, ad.x, q); v1 = addmod(v1, ad.y, q); }
             if (a.pack_out) st2(dst + s, split28v(v0), split28v(v1)); else st2(dst + s, v0, v1);
         };
-        // the transform may run in place (src == dst): nothing is stored before the second half has read its inputs -- the first half's result waits in registers
+        // the transform may run in place (src == dst): nothing is stored before the second half has read its inputs -- the first half's result waits in
+        // registers
         constexpr int NPT = 8;                          // n/2 = 8192 values on 1024 threads (the split form serves n = 16384 only)
         u64 r0[NPT];
         stage0(0);
@@ -262,14 +378,16 @@ __device__ __forceinline__ void ntt_rows_split_body(const NttArgs &a)
 #pragma unroll
         for (int u = 0; u < NPT / 2; u++) {
             const int s = 2 * (tid + u * nt);
-            if (s < n2) { ulonglong2 v = sm_load_pair64(sm, s); if (fuse1) fwd_pair_stage<LAZY>(v, pair_tw(0, s), q, q2); r0[2 * u] = canon(v.x); r0[2 * u + 1] = canon(v.y); }
+            if (s < n2) { ulonglong2 v = sm_load_pair64(sm, s); if (fuse1) fwd_pair_stage<LAZY>(v, pair_tw(0, s), q, q2); r0[2 * u] = canon(v.x);
+                r0[2 * u + 1] = canon(v.y); }
         }
         __syncthreads();
         stage0(1);
 #pragma unroll
         for (int u = 0; u < NPT / 2; u++) { const int s = 2 * (tid + u * nt); if (s < n2) put(s, r0[2 * u], r0[2 * u + 1]); }
         passes(1);
-        for (int s = 2 * tid; s < n2; s += 2 * nt) { ulonglong2 v = sm_load_pair64(sm, s); if (fuse1) fwd_pair_stage<LAZY>(v, pair_tw(1, s), q, q2); put(n2 + s, canon(v.x), canon(v.y)); }
+        for (int s = 2 * tid; s < n2; s += 2 * nt) { ulonglong2 v = sm_load_pair64(sm, s); if (fuse1) fwd_pair_stage<LAZY>(v, pair_tw(1, s), q, q2);
+            put(n2 + s, canon(v.x), canon(v.y)); }
     } else {
         const u64 *add = nullptr;
         if (a.addend) {
@@ -277,12 +395,15 @@ __device__ __forceinline__ void ntt_rows_split_body(const NttArgs &a)
             if (a.add_mode == 2) add = a.addend + ((ct * a.add_size + p) * a.mod_count + mloc) * (size_t)n;
             else if (p == 0) { size_t g = ct / a.add_group; if (a.add_mod) g %= a.add_mod; add = a.addend + (g * a.mod_count + mloc) * (size_t)n; }
         }
-        for (int s = 2 * tid; s < n2; s += 2 * nt) { ulonglong2 v = load2(s); if (fuse1) inv_pair_stage<LAZY>(v, pair_tw(0, s), q, q2); sm_store_pair64(sm, s, v.x, v.y); }
+        for (int s = 2 * tid; s < n2; s += 2 * nt) { ulonglong2 v = load2(s); if (fuse1) inv_pair_stage<LAZY>(v, pair_tw(0, s), q, q2);
+            sm_store_pair64(sm, s, v.x, v.y); }
         __syncthreads();
         passes(0);
-        for (int s = 2 * tid; s < n2; s += 2 * nt) { const ulonglong2 v = sm_load_pair64(sm, s); st2(dst + s, v.x, v.y); }        // parked (lazy, below 2^63); read back by this very thread below
+        // parked (lazy, below 2^63); read back by this very thread below
+        for (int s = 2 * tid; s < n2; s += 2 * nt) { const ulonglong2 v = sm_load_pair64(sm, s); st2(dst + s, v.x, v.y); }
         __syncthreads();
-        for (int s = 2 * tid; s < n2; s += 2 * nt) { ulonglong2 v = load2(s + n2); if (fuse1) inv_pair_stage<LAZY>(v, pair_tw(1, s), q, q2); sm_store_pair64(sm, s, v.x, v.y); }
+        for (int s = 2 * tid; s < n2; s += 2 * nt) { ulonglong2 v = load2(s + n2); if (fuse1) inv_pair_stage<LAZY>(v, pair_tw(1, s), q, q2);
+            sm_store_pair64(sm, s, v.x, v.y); }
         __syncthreads();
         passes(1);
         const u64 q16 = q2 << 3;
@@ -396,19 +517,40 @@ static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t
     const int cus = c->cus;
     if ((a.prologue == 3 && inv) || ((a.prologue == 4 || a.prologue == 5) && !inv)) return CRC_ERR_INVALID_ARGUMENT;
     if (a.prologue == 4) rows = xcd_grid(a.pairs, 3);                  // (the three products of a pair on one XCD: ntt_rows_body)
-    if (c->n == 16384 && nt == 1024 && c->tune.ntt_split != 0) {                   // n = 16384: the row as two halves through a 64-KiB image -- two workgroups per CU (ntt_rows_split_body)
+    // wave-local passes (ntt_rows_wave_kernel): CRC_NTT_WAVE bit 0 n = 8192, bit 1 n = 4096, bit 2 n = 16384 (plain transforms), bit 3 n = 16384 with the
+    // Square prologues (measured slower than the split kernel there: 11.9 vs 11.7 us per squared ciphertext, profiles/r05_ntt_u64_wave_local_ab.txt); -1: bits
+    // 0 to 2
+    {
+        const int sel = c->tune.ntt_wave < 0 ? 7 : c->tune.ntt_wave;
+        const int bit = c->n == 8192 ? 0 : c->n == 4096 ? 1 : c->n == 16384 ? (a.prologue ? 3 : 2) : -1;
+        if (bit >= 0 && ((sel >> bit) & 1) && lazy && !a.addend && (a.prologue == 0 || a.prologue == 4 || a.prologue == 5)) {
+            lds = (size_t)c->n * 8;
+#define WAVEK(CSV) (a.prologue == 4 ? ntt_rows_wave_kernel<true, 4, CSV> : a.prologue == 5 ? ntt_rows_wave_kernel<true, 5, CSV> \
+                    : inv ? ntt_rows_wave_kernel<true, 0, CSV> : ntt_rows_wave_kernel<false, 0, CSV>)
+            auto kw = bit == 0 ? WAVEK(3) : bit == 1 ? WAVEK(2) : WAVEK(4);
+#undef WAVEK
+            { const int rc = crc_ctx_ensure_lds(c, (const void *)kw, lds); if (rc) return rc; }
+            hipLaunchKernelGGL(kw, dim3((unsigned)rows), dim3(c->n / 16), lds, st, a);
+            HIPCHK(hipGetLastError());
+            return CRC_OK;
+        }
+    }
+    // n = 16384: the row as two halves through a 64-KiB image -- two workgroups per CU (ntt_rows_split_body)
+    if (c->n == 16384 && nt == 1024 && c->tune.ntt_split != 0) {
         lds /= 2;
         auto ks = a.prologue == 4 ? (lazy ? ntt_rows_split_kernel<true, true, 4> : ntt_rows_split_kernel<true, false, 4>)
                 : a.prologue == 5 ? (lazy ? ntt_rows_split_kernel<true, true, 5> : ntt_rows_split_kernel<true, false, 5>)
                 : a.prologue == 3 ? (lazy ? ntt_rows_split_kernel<false, true, 3> : ntt_rows_split_kernel<false, false, 3>)
-                : inv ? (lazy ? ntt_rows_split_kernel<true, true, 0> : ntt_rows_split_kernel<true, false, 0>) : (lazy ? ntt_rows_split_kernel<false, true, 0> : ntt_rows_split_kernel<false, false, 0>);
+                : inv ? (lazy ? ntt_rows_split_kernel<true, true, 0> : ntt_rows_split_kernel<true, false, 0>) : (lazy ? ntt_rows_split_kernel<false, true,
+                    0> : ntt_rows_split_kernel<false, false, 0>);
         hipLaunchKernelGGL(ks, dim3((unsigned)rows), dim3(nt), lds, st, a);
         HIPCHK(hipGetLastError());
         return CRC_OK;
     }
     if (c->n / nt == 16 && rows > (size_t)cus && a.prologue < 3) {     // n = 16384: one resident workgroup per CU, prefetching the next row
         a.rows = rows;
-        auto pk = inv ? (lazy ? ntt_rows_prefetch_kernel<true, true> : ntt_rows_prefetch_kernel<true, false>) : (lazy ? ntt_rows_prefetch_kernel<false, true> : ntt_rows_prefetch_kernel<false, false>);
+        auto pk = inv ? (lazy ? ntt_rows_prefetch_kernel<true, true> : ntt_rows_prefetch_kernel<true, false>) : (lazy ? ntt_rows_prefetch_kernel<false,
+            true> : ntt_rows_prefetch_kernel<false, false>);
         { const int rc = crc_ctx_ensure_lds(c, (const void *)pk, lds); if (rc) return rc; }
         hipLaunchKernelGGL(pk, dim3((unsigned)cus), dim3(nt), lds, st, a);
         HIPCHK(hipGetLastError());
@@ -419,7 +561,8 @@ static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t
     auto kern = a.prologue == 4 ? (lazy ? ntt_rows_kernel<true, true, 4> : strict61 ? ntt_rows_inv61_kernel<4> : ntt_rows_kernel<true, false, 4>)
               : a.prologue == 5 ? (lazy ? ntt_rows_kernel<true, true, 5> : ntt_rows_kernel<true, false, 5>)
               : a.prologue == 3 ? (lazy ? ntt_rows_kernel<false, true, 3> : ntt_rows_kernel<false, false, 3>)
-              : inv ? (lazy ? ntt_rows_kernel<true, true, 0> : strict61 ? ntt_rows_inv61_kernel<0> : ntt_rows_kernel<true, false, 0>) : (lazy ? ntt_rows_kernel<false, true, 0> : ntt_rows_kernel<false, false, 0>);
+              : inv ? (lazy ? ntt_rows_kernel<true, true, 0> : strict61 ? ntt_rows_inv61_kernel<0> : ntt_rows_kernel<true, false, 0>) : (lazy ?
+                  ntt_rows_kernel<false, true, 0> : ntt_rows_kernel<false, false, 0>);
     { const int rc = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (rc) return rc; }
     hipLaunchKernelGGL(kern, dim3((unsigned)rows), dim3(nt), lds, st, a);
     HIPCHK(hipGetLastError());
@@ -469,7 +612,8 @@ int k_spread_ntt(crc_ctx *c, const u64 *src, size_t items, u64 *dst, hipStream_t
 
 // relinearisation digits: forward NTT of digit g of c2 (premultiplied by (q/q_i)^-1, poly `src_poly` of the size-`src_size` ciphertexts `src`) under every q_j:
 // dst [count][D][k][n]; the digit is cut out of the source word while the row is loaded (NttArgs prologue 3)
-int k_digit_ntt(crc_ctx *c, const u64 *src, int src_size, int src_poly, size_t count, int D, const unsigned char *dig_i, const unsigned char *dig_shift, int dbc,
+int k_digit_ntt(crc_ctx *c, const u64 *src, int src_size, int src_poly, size_t count, int D, const unsigned char *dig_i, const unsigned char *dig_shift,
+    int dbc,
                 u64 *dst, hipStream_t st, int pack_out)
 {
     if (D > 48) return CRC_ERR_UNSUPPORTED;
@@ -535,8 +679,8 @@ int k_plain_ntt(crc_ctx *c, const u64 *d_plain, size_t count, int mode, bool do_
     return CRC_OK;
 }
 
-// compact plaintexts [count][CRC_PLAIN_COMPACT_WORDS] -> dense [count][n]: the fractional encoder only ever sets coefficients 0..63 (integer part) and n-32..n-1
-// (fraction), so the host ships 96 words per weight instead of n (PlainModelWoPad's fc3 at n = 16384: 0.3 GB over PCIe instead of 52 GB)
+// compact plaintexts [count][CRC_PLAIN_COMPACT_WORDS] -> dense [count][n]: the fractional encoder only ever sets coefficients 0..63 (integer part) and
+// n-32..n-1 (fraction), so the host ships 96 words per weight instead of n (PlainModelWoPad's fc3 at n = 16384: 0.3 GB over PCIe instead of 52 GB)
 __global__ void __launch_bounds__(256) plain_expand_kernel(const u64 *compact, u64 *out, int n)
 {
     const size_t row = blockIdx.x;
@@ -544,7 +688,8 @@ __global__ void __launch_bounds__(256) plain_expand_kernel(const u64 *compact, u
     for (int s = threadIdx.x * 2; s < n; s += blockDim.x * 2) {
         ulonglong2 v = make_ulonglong2(0, 0);
         if (s < CRC_PLAIN_COMPACT_LOW) { v.x = src[s]; v.y = src[s + 1]; }
-        else if (s >= n - CRC_PLAIN_COMPACT_HIGH) { v.x = src[CRC_PLAIN_COMPACT_LOW + s - (n - CRC_PLAIN_COMPACT_HIGH)]; v.y = src[CRC_PLAIN_COMPACT_LOW + s + 1 - (n - CRC_PLAIN_COMPACT_HIGH)]; }
+        else if (s >= n - CRC_PLAIN_COMPACT_HIGH) { v.x = src[CRC_PLAIN_COMPACT_LOW + s - (n - CRC_PLAIN_COMPACT_HIGH)];
+            v.y = src[CRC_PLAIN_COMPACT_LOW + s + 1 - (n - CRC_PLAIN_COMPACT_HIGH)]; }
         *reinterpret_cast<ulonglong2 *>(dst + s) = v;
     }
 }
@@ -701,7 +846,8 @@ __global__ void conv_offsets_kernel(int *xoff, int *toff, unsigned *toffw, unsig
         toff[idx] = o; toffw[idx] = (unsigned)o * ctw;
     }
 }
-int k_conv_offsets(crc_ctx *c, int *xoff, int *toff, unsigned *toffw, int P, int T, int in_cts, int xd, int yd, int xs, int ys, int xf, int yf, int yo, hipStream_t st)
+int k_conv_offsets(crc_ctx *c, int *xoff, int *toff, unsigned *toffw, int P, int T, int in_cts, int xd, int yd, int xs, int ys, int xf, int yf, int yo,
+    hipStream_t st)
 {
     const int m = P > T + 8 ? P : T + 8;
     const size_t ctw = 2 * (size_t)c->k * c->n;
@@ -780,7 +926,8 @@ __global__ void __launch_bounds__(256) mac_kernel(MacArgs a)
         const size_t to = (size_t)a.toff[t] * ctw;
         u64 xv[PT][2], wv[FT];
 #pragma unroll
-        for (int pp = 0; pp < PT; pp++) { xv[pp][0] = xb[pp][to]; xv[pp][1] = xb[pp][to + (size_t)k * n]; if (a.xp) { xv[pp][0] = unsplit28(xv[pp][0]); xv[pp][1] = unsplit28(xv[pp][1]); } }
+        for (int pp = 0; pp < PT; pp++) { xv[pp][0] = xb[pp][to]; xv[pp][1] = xb[pp][to + (size_t)k * n]; if (a.xp) { xv[pp][0] = unsplit28(xv[pp][0]);
+            xv[pp][1] = unsplit28(xv[pp][1]); } }
 #pragma unroll
         for (int ff = 0; ff < FT; ff++) { wv[ff] = (f0 + ff < a.F) ? wb[ff * wstride_f + t * wstride_t] : 0; if (a.wp) wv[ff] = unsplit28(wv[ff]); }
 #pragma unroll
@@ -920,7 +1067,8 @@ __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_
     auto load_one = [&](int st, int jj, ulonglong2 (&reg)[RLOAD / 2]) {
         const int t = min(st * S + vstep[2 * jj], a.T - 1);
         const u32 off = visx[2 * jj] ? tw[t] : (u32)t * kn32;
-        reg[jj] = *reinterpret_cast<const ulonglong2 *>(reinterpret_cast<const char *>(vbase[2 * jj]) + ((size_t)(off + rown2 + (hmask & vdelta[jj])) << 3));   // consumed only by store_pair
+        // consumed only by store_pair
+        reg[jj] = *reinterpret_cast<const ulonglong2 *>(reinterpret_cast<const char *>(vbase[2 * jj]) + ((size_t)(off + rown2 + (hmask & vdelta[jj])) << 3));
     };
     auto store_pair = [&](int st, int jj, ulonglong2 (&reg)[RLOAD / 2]) {
         u64 *dst = smem + (size_t)(st & 1) * VEC * 64;
@@ -1133,7 +1281,8 @@ __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_
             const u64 *sv = buf + step * (ROWS + FW) * 64 + lane;
             u32 w0[FT], w1[FT], ws[FT];
 #pragma unroll
-            for (int f = 0; f < FT; f++) { const u64 wr = sv[(ROWS + wn * FT + f) * 64]; const u64 wv = WP ? wr : split28(wr); w0[f] = (u32)wv; w1[f] = (u32)(wv >> 32); ws[f] = w0[f] + w1[f]; }
+            for (int f = 0; f < FT; f++) { const u64 wr = sv[(ROWS + wn * FT + f) * 64]; const u64 wv = WP ? wr : split28(wr); w0[f] = (u32)wv;
+                w1[f] = (u32)(wv >> 32); ws[f] = w0[f] + w1[f]; }
 #pragma unroll
             for (int r = 0; r < PX * 2; r++) {
                 const u64 xr = sv[(wm * PX * 2 + r) * 64]; const u64 xv = XP ? xr : split28(xr);
@@ -1257,7 +1406,8 @@ int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, co
     if (!regstage && !cfg && foldable) {
         int rc;
 #define MAC3_GO(XPV, WPV) (pick == 8 ? mac3_launch<3, 4, 4, 2, 4, XPV, WPV>(c, a, st) : mac3_launch<3, 4, 2, 4, 4, XPV, WPV>(c, a, st))
-        if (a.xp && a.wp) rc = MAC3_GO(true, true); else if (a.xp) rc = MAC3_GO(true, false); else if (a.wp) rc = MAC3_GO(false, true); else rc = MAC3_GO(false, false);
+        if (a.xp && a.wp) rc = MAC3_GO(true, true); else if (a.xp) rc = MAC3_GO(true, false); else if (a.wp) rc = MAC3_GO(false, true);
+            else rc = MAC3_GO(false, false);
 #undef MAC3_GO
         if (rc != CRC_ERR_UNSUPPORTED) return rc;
     }
@@ -1274,7 +1424,8 @@ int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, co
 // fused layer has (xf'*yf')/(xf*yf) more terms but pxs*pys fewer outputs: 2.8x fewer MACs for CrCNN's 5x5 conv + 2x2/2 pool.
 // All inputs/outputs in NTT form.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) fold_pool_kernel(const u64 *w, const u64 *bias, const u64 *div, u64 *wout, u64 *bout, const ModParams *mods, int n, int k,
+__global__ void __launch_bounds__(256) fold_pool_kernel(const u64 *w, const u64 *bias, const u64 *div, u64 *wout, u64 *bout, const ModParams *mods, int n,
+    int k,
                                                         int nf, int zd, int xf, int yf, int cxs, int cys, int pxf, int pyf, int xf2, int yf2)
 {
     // rows: first nf*zd*xf2*yf2*k weight rows, then nf*k bias rows
@@ -1310,7 +1461,8 @@ int k_fold_pool(crc_ctx *c, const u64 *w, const u64 *bias, const u64 *div, u64 *
 {
     const int xf2 = (pxf - 1) * cxs + xf, yf2 = (pyf - 1) * cys + yf;
     const size_t rows = ((size_t)nf * zd * xf2 * yf2 + nf) * c->k;
-    hipLaunchKernelGGL(fold_pool_kernel, dim3((unsigned)rows), dim3(256), 0, st, w, bias, div, wout, bout, c->d_mods, c->n, c->k, nf, zd, xf, yf, cxs, cys, pxf, pyf, xf2, yf2);
+    hipLaunchKernelGGL(fold_pool_kernel, dim3((unsigned)rows), dim3(256), 0, st, w, bias, div, wout, bout, c->d_mods, c->n, c->k, nf, zd, xf, yf, cxs, cys,
+        pxf, pyf, xf2, yf2);
     HIPCHK(hipGetLastError());
     return CRC_OK;
 }

@@ -391,30 +391,7 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_inv_crt_kernel(
 // K3 with ONE workgroup barrier per transform (round 5; ntt_f64.h, wave-local passes): n = 8192 (CS = 3) or 16384 (CS = 4), n / 16 threads.  Both inverse
 // transforms end in the cross pass, i.e. in registers: the first prime's result simply stays there (no LDS read, no parking), the second meets it for the CRT
 // lift, the (c0, c1) rows are read in the same cross layout, and the canonical sums go into the image for the forward transform over q_j (or straight to
-// memory). the three wave-local radix-8 passes of a FORWARD transform over a coefficient modulus on this wave's 1024-point block of the image (the 64-bit twin
-// of f64_local_passes: ntt_device.h's butterflies, ntt_f64.h's block ownership)
-template <bool LAZY>
-__device__ __forceinline__ void u64_local_passes_fwd(u64 *sm, const ulonglong2 *W, int n, u64 q, u64 q2)
-{
-    const unsigned w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll 1
-    for (int p = 0; p < 3; p++) {
-        const int lt = 9 - 3 * p, ls = lt - 2, tabidx = n >> (lt + 1);
-#pragma unroll 1
-        for (unsigned u = 0; u < 2; u++) {
-            const unsigned g = (w << 7) + lane + 64 * u;
-            const unsigned blk = g >> ls, l = g & ((1u << ls) - 1);
-            const int a0 = swz<3>((int)((blk << (ls + 3)) + l));
-            u64 v[8];
-#pragma unroll
-            for (int c = 0; c < 8; c++) v[c] = sm[a0 ^ swz<3>(c << ls)];
-            fwd_stages<3, LAZY>(v, W, tabidx, (int)blk, q, q2);
-#pragma unroll
-            for (int c = 0; c < 8; c++) sm[a0 ^ swz<3>(c << ls)] = v[c];
-        }
-        f64_wave_sync();
-    }
-}
+// memory).
 // U64W: the forward transform over q_j that follows the CRT runs wave-locally too -- its cross pass works on the CRT's results where they are made, in
 // registers
 template <int CS, bool OUT_NTT, bool LAZY, bool U64W>

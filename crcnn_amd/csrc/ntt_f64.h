@@ -394,3 +394,51 @@ __device__ __forceinline__ void f64_wave_inverse(double *sm, const double *W, in
     __syncthreads();
     f64_cross_inv_from_image<CS, RB>(sm, W, n, md, put);
 }
+
+// ---- the same scheme for the 64-bit transforms over a coefficient modulus (ntt_device.h's lazy butterflies, the block ownership above) ---------------------
+// the three wave-local radix-8 passes of a FORWARD transform (gaps 512 ... 2) on this wave's 1024-point block of the image
+template <bool LAZY>
+__device__ __forceinline__ void u64_local_passes_fwd(u64 *sm, const ulonglong2 *W, int n, u64 q, u64 q2)
+{
+    const unsigned w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int p = 0; p < 3; p++) {
+        const int lt = 9 - 3 * p, ls = lt - 2, tabidx = n >> (lt + 1);
+#pragma unroll 1
+        for (unsigned u = 0; u < 2; u++) {
+            const unsigned g = (w << 7) + lane + 64 * u;
+            const unsigned blk = g >> ls, l = g & ((1u << ls) - 1);
+            const int a0 = swz<3>((int)((blk << (ls + 3)) + l));
+            u64 v[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) v[c] = sm[a0 ^ swz<3>(c << ls)];
+            fwd_stages<3, LAZY>(v, W, tabidx, (int)blk, q, q2);
+#pragma unroll
+            for (int c = 0; c < 8; c++) sm[a0 ^ swz<3>(c << ls)] = v[c];
+        }
+        f64_wave_sync();
+    }
+}
+// ... and of an INVERSE one (gaps 2 ... 512; the gap-1 stage is applied while the block is filled)
+template <bool LAZY>
+__device__ __forceinline__ void u64_local_passes_inv(u64 *sm, const ulonglong2 *W, int n, u64 q, u64 q2)
+{
+    const unsigned w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int p = 0; p < 3; p++) {
+        const int ls = 1 + 3 * p, tabidx = n >> (ls + 1);
+#pragma unroll 1
+        for (unsigned u = 0; u < 2; u++) {
+            const unsigned g = (w << 7) + lane + 64 * u;
+            const unsigned blk = g >> ls, l = g & ((1u << ls) - 1);
+            const int a0 = swz<3>((int)((blk << (ls + 3)) + l));
+            u64 v[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) v[c] = sm[a0 ^ swz<3>(c << ls)];
+            inv_stages<3, LAZY>(v, W, tabidx, (int)blk, q, q2);
+#pragma unroll
+            for (int c = 0; c < 8; c++) sm[a0 ^ swz<3>(c << ls)] = v[c];
+        }
+        f64_wave_sync();
+    }
+}

@@ -60,13 +60,16 @@ enum { CRC_COEFF = 0, CRC_NTT = 1,
         * Needs coefficient moduli below 2^56. */
        CRC_NTTP = 2,
        /* "limb form": the operand form of the matrix-core multiply-accumulate (kernels_mfma.hip).  Every residue as the seven balanced base-256 digits of
-        * its centred representative (int8), SLOT-MAJOR: tensors [k][n][B][7][positions][2 polys][channels rounded up to 32] (a dense layer's input, one position, is
+        * its centred representative (int8), SLOT-MAJOR: tensors [k][n][B][7][positions][2 polys][channels rounded up to 32] (a dense layer's input, one
+        * position, is
         * K-blocked instead: [k][n][7][channels / 32][B * 2 rows = (image, poly)][32]), weights
-        * [k][n][tap][channel block][7][filters rounded up to 64][32] (times 2^64 mod q: the kernel's Montgomery reduction divides it out).  Exact integer arithmetic on v_mfma_i32_16x16x64_i8 (49 limb products per modular
+        * [k][n][tap][channel block][7][filters rounded up to 64][32] (times 2^64 mod q: the kernel's Montgomery reduction divides it out).  Exact integer
+        * arithmetic on v_mfma_i32_16x16x64_i8 (49 limb products per modular
         * multiply, int32 accumulators, one reduction per output): the same ciphertexts as every other form, about 4x the throughput of the vector-ALU
         * kernel on long reductions.  crc_limb_pack_weights makes the weights; crc_conv2d_forms / crc_dense_forms take w_form = CRC_NTTL, convert a
         * CRC_COEFF / CRC_NTT / CRC_NTTP input themselves and produce any form (out_form = CRC_NTTL hands the tensor to a DENSE layer: channels =
-        * (filter, x, y) flattened, 1 x 1 positions).  Needs coefficient moduli below 2^55 (at most 55 significant bits: |centred residue| < 2^54 fits seven balanced
+        * (filter, x, y) flattened, 1 x 1 positions).  Needs coefficient moduli below 2^55 (at most 55 significant bits: |centred residue| < 2^54 fits seven
+        * balanced
         * bytes) and reductions of at most 18 000 terms; crc_limb_supported answers for a context and shape. */
        CRC_NTTL = 3,
        /* weights of a ONE-CHANNEL convolution (CrCNN's conv1, alone or fused with its pooling layer: window <= 8 x 8, <= 32 filters) for the matrix-core
@@ -100,14 +103,21 @@ size_t crc_evk_words(const crc_ctx *ctx, int dbc);     /* words of an evaluation
  * "root_powers:<i>","inv_root_powers_div_two:<i>", "f64_primes" (the two fp64 primes of relinearisation's key switching), "sq64_primes" (the fp64 primes that
  * carry the square's auxiliary base: B' = all but the last, m_sk' = the last; empty when the parameters do not fit twelve of them); returns word count */
 int  crc_ctx_table(const crc_ctx *ctx, const char *name, uint64_t *h_out, int cap);
-/* Tuning switches of tools/ and the tests (none is needed for normal use).  The engine reads its environment (CRC_MFMA_VARIANT, CRC_CONV1_PASS_BYTES, ...) exactly
+/* Tuning switches of tools/ and the tests (none is needed for normal use).  The engine reads its environment (CRC_MFMA_VARIANT, CRC_CONV1_PASS_BYTES, ...)
+ * exactly
  * once, inside crc_ctx_create; this call changes one switch of a context nobody is launching on: "mfma_variant", "mfma_order", "mfma_ring", "conv1_waves",
- * "conv1_pass_bytes", "limb_pack_group", "mac2_cfg", "mac_order", "mac_regstage", "ntt_inv61_loose", "ntt_split", "mfma_min_steps", "f64_radix", "relin_mac_ct",
- * "relin_path" (1: key switching over the coefficient moduli, as the reference does it, instead of over two fp64 primes), "sq_path" (1: the square's auxiliary base is SEAL's 61-bit
- * one instead of the engine's fp64 primes; 2: force the latter), "sq_chunk" (ciphertexts per internal pass of square + relinearise; changes crc_square_relin_work_bytes),
+ * "conv1_pass_bytes", "limb_pack_group", "mac2_cfg", "mac_order", "mac_regstage", "ntt_inv61_loose", "ntt_split", "mfma_min_steps", "f64_radix",
+ * "relin_mac_ct",
+ * "relin_path" (1: key switching over the coefficient moduli, as the reference does it, instead of over two fp64 primes), "sq_path" (1: the square's auxiliary
+ * base is SEAL's 61-bit
+ * one instead of the engine's fp64 primes; 2: force the latter), "sq_chunk" (ciphertexts per internal pass of square + relinearise; changes
+ * crc_square_relin_work_bytes),
  * "sq_fuse" (1: an NTT-resident square lifts to its auxiliary base inside the forward transforms, 0: in a kernel of its own, -1: by the number of moduli),
- * "f64_wave" (bit mask of the fp64 row kernels that run with one workgroup barrier per transform at n = 8192 / 16384: 1 sq64_inv, 2 the digit kernel, 4 K3, 8 the lifting
- * forward kernel, 16 K3's 64-bit forward transform; -1: the measured choice, 0: the round-4 kernels).
+ * "f64_wave" (bit mask of the fp64 row kernels that run with one workgroup barrier per transform at n = 8192 / 16384: 1 sq64_inv, 2 the digit kernel, 4 K3, 8
+ * the lifting
+ * forward kernel, 16 K3's 64-bit forward transform; -1: the measured choice, 0: the round-4 kernels), "ntt_wave" (the same for the 64-bit row transforms: 1 n =
+ * 8192,
+ * 2 n = 4096, 4 n = 16384, 8 n = 16384 with the square's prologues; -1: the measured choice = 7).
  * Every path gives the same ciphertexts.  CRC_ERR_NOT_FOUND for anything else. */
 int  crc_ctx_set_tuning(crc_ctx *ctx, const char *name, long long value);
 
@@ -128,7 +138,8 @@ int crc_stream_destroy(crc_ctx *ctx, void *stream);
 int crc_stream_wait_event(crc_ctx *ctx, void *stream, void *event);
 int crc_host_alloc(crc_ctx *ctx, size_t bytes, void **h_ptr);
 int crc_host_free(crc_ctx *ctx, void *h_ptr);
-/* threads the host-side item loops of this process use (the reference's th_count fan-out, convolutionalLayer.cpp:177-191, has no process-wide cap): CRC_HOST_THREADS,
+/* threads the host-side item loops of this process use (the reference's th_count fan-out, convolutionalLayer.cpp:177-191, has no process-wide cap):
+ * CRC_HOST_THREADS,
  * else the hardware's, at most 16, divided by the ranks that share the node (LOCAL_WORLD_SIZE / CRC_LOCAL_WORLD) */
 int crc_host_thread_limit(void);
 /* HIP events (hipEvent_t behind void*): record on the stream the kernels go to, read the time between two of them (waits for the second) */
@@ -243,27 +254,32 @@ size_t crc_limb_weights_bytes(const crc_ctx *ctx, int nf, int zd, int xf, int yf
 int    crc_limb_pack_weights(crc_ctx *ctx, const uint64_t *d_w_ntt, int nf, int zd, int xf, int yf, void *d_wl, void *stream);
 /* the same a filter tile at a time: d_w_tile_ntt holds filters f0 .. f0 + ft of the layer's nf ([ft][zd][xf][yf][k][n]); the tiles must be packed in order from
  * f0 = 0 (that call zeroes the padding of d_wl).  A layer whose canonical NTT-form weights and limb copy do not fit in HBM together (PlainModelWoPad's fc3 at
- * n = 16384: 202 + 177 GiB) is built this way straight from its plaintexts: encode -> crc_plain_to_ntt -> (batch-norm fold) -> tile, the canonical tile being scratch */
+ * n = 16384: 202 + 177 GiB) is built this way straight from its plaintexts: encode -> crc_plain_to_ntt -> (batch-norm fold) -> tile, the canonical tile being
+ * scratch */
 int    crc_limb_pack_weights_tile(crc_ctx *ctx, const uint64_t *d_w_tile_ntt, int nf, int f0, int ft, int zd, int xf, int yf, void *d_wl, void *stream);
 /* Kernel selection -- the ONE statement of the policy, asked by every host (crcnn_amd/netrun.py and the C++ classes of crcnn_amd/host):
  *   crc_plan_mac        the weight form (= kernel) of a conv / dense layer launched on B images (B <= 0: do not apply the rows-per-launch guard):
- *                       CRC_NTTL1 one-channel convolution on the matrix cores, CRC_NTTL limb GEMM (>= 8 reduction steps of 32 channels and >= 32 rows = images x
+ *                       CRC_NTTL1 one-channel convolution on the matrix cores, CRC_NTTL limb GEMM (>= 8 reduction steps of 32 channels and >= 32 rows = images
+ *                       x
  *                       2 polys x output pixels per launch), CRC_NTTP the vector-ALU kernel on 28-bit limb pairs, CRC_NTT canonical (moduli above 55 bits).
  *                       A dense layer is the 1 x 1 convolution zd = in_dim, nf = out_dim.  matrix_cores = 0 keeps everything on the vector ALU.
- *   crc_plan_fold_pool  whether folding a pooling layer into the convolution in front of it (crc_conv2d_fold_pool) pays, by the cost model of DESIGN.md section 4 */
+ *   crc_plan_fold_pool  whether folding a pooling layer into the convolution in front of it (crc_conv2d_fold_pool) pays, by the cost model of DESIGN.md section
+ *   4 */
 int    crc_plan_mac(const crc_ctx *ctx, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int B, int matrix_cores, int *w_form);
 int    crc_plan_fold_pool(const crc_ctx *ctx, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int pxs, int pys, int pxf, int pyf, int *fold);
 /* an NTT-form tensor (CRC_NTT canonical or CRC_NTTP) -> limb form; crc_conv2d_forms does this itself for such inputs, the separate entry point lets a
  * caller convert once and reuse (d_xl: crc_limb_tensor_bytes) */
 int    crc_limb_pack_tensor(crc_ctx *ctx, const uint64_t *d_x, int in_form, int B, int zd, int xd, int yd, void *d_xl, void *stream);
-/* the same for images b0 .. b0 + B of a limb tensor of Btot images (d_xl: crc_limb_tensor_bytes(Btot, ...)): several chunks assemble the input of one dense-layer launch
+/* the same for images b0 .. b0 + B of a limb tensor of Btot images (d_xl: crc_limb_tensor_bytes(Btot, ...)): several chunks assemble the input of one
+ * dense-layer launch
  * (a dense layer streams all of its weights per launch, so it is run on as many images as fit: netrun's / Network's two-level chunking) */
 int    crc_limb_pack_tensor_at(crc_ctx *ctx, const uint64_t *d_x, int in_form, int B, int zd, int xd, int yd, void *d_xl, int Btot, int b0, void *stream);
 /* one-channel convolutions on the matrix cores (w_form = CRC_NTTL1): eligibility of a shape, size of the weights, conversion from CRC_NTT weights */
 int    crc_limb_conv1_supported(const crc_ctx *ctx, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf);
 size_t crc_limb_conv1_weights_bytes(const crc_ctx *ctx);
 int    crc_limb_conv1_pack_weights(crc_ctx *ctx, const uint64_t *d_w_ntt, int nf, int xf, int yf, void *d_wl, void *stream);
-size_t crc_conv2d_forms_work_bytes(const crc_ctx *ctx, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int in_form, int w_form, int out_form);
+size_t crc_conv2d_forms_work_bytes(const crc_ctx *ctx, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int nf, int in_form, int w_form,
+int out_form);
 /* in-place CRC_NTT <-> CRC_NTTP conversion of `rows` residue rows (unpack = 0: pack, 1: unpack) */
 int crc_pack28(crc_ctx *ctx, uint64_t *d_rows, size_t rows, int unpack, void *stream);
 size_t crc_dense_work_bytes(const crc_ctx *ctx, int B, int in_dim, int out_dim, int in_form);
@@ -282,18 +298,21 @@ int crc_square_relin(crc_ctx *ctx, const uint64_t *d_x, size_t count, const uint
  * transforms fewer per ciphertext than converting outside. */
 int crc_square_relin_forms(crc_ctx *ctx, const uint64_t *d_x, int in_form, size_t count, const uint64_t *d_evk, int dbc,
                            uint64_t *d_y, int out_form, void *d_work, void *stream);
-/* Square followed by a SUM pooling (CrCNN's act1 -> pool2; Network::fuse pairs them): relinearisation is linear in the digit polynomials of c2, so the digits of
+/* Square followed by a SUM pooling (CrCNN's act1 -> pool2; Network::fuse pairs them): relinearisation is linear in the digit polynomials of c2, so the digits
+ * of
  * a window's ciphertexts are added and ONE key switch serves the pooled ciphertext --
  *     Sum_w relin(ct_w) = Sum_w (c0, c1)_w + Sum_g (Sum_w digit_g(c2'_w)) (*) key_g
  * -- the same element of Z_q as squaring, relinearising and pooling one after the other (evaluator.cpp:934-1069, poolingLayer.cpp:22-44), hence the same bits,
  * with xo yo / (xd yd) of the key switch's transforms and inner products (16 / 25 for CrCNN's 5 x 5 -> 4 x 4 pool2).  d_x: [B][zd][xd][yd] ciphertexts, d_y:
- * [B][zd][xo][yo].  d_div_ntt: an average pooling's divisor (NTT-form plaintext [k][n], as crc_pool takes it), multiplied in while an NTT-form result leaves the
+ * [B][zd][xo][yo].  d_div_ntt: an average pooling's divisor (NTT-form plaintext [k][n], as crc_pool takes it), multiplied in while an NTT-form result leaves
+ * the
  * last kernel (out_form must be CRC_NTT then).  crc_square_pool_relin_supported: the key switch over
  * the fp64 primes must hold the window's larger integers (n D W 2^dbc q at most 2^92, a quarter of p_0 p_1) and a residue at most four digits. */
 int    crc_square_pool_relin_supported(const crc_ctx *ctx, int dbc, int xf, int yf);
 size_t crc_square_pool_relin_work_bytes(const crc_ctx *ctx, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf, int dbc);
 int    crc_square_pool_relin_forms(crc_ctx *ctx, const uint64_t *d_x, int in_form, int B, int zd, int xd, int yd, int xs, int ys, int xf, int yf,
-                                   const uint64_t *d_evk, int dbc, const uint64_t *d_div_ntt /* NULL = sum pool */, uint64_t *d_y, int out_form, void *d_work, void *stream);
+                                   const uint64_t *d_evk, int dbc, const uint64_t *d_div_ntt /* NULL = sum pool */, uint64_t *d_y, int out_form, void *d_work,
+                                   void *stream);
 /* the two halves separately (unit tests): square -> size-3 ciphertexts; relinearize -> size 2 */
 int crc_square(crc_ctx *ctx, const uint64_t *d_x, size_t count, uint64_t *d_y3, void *d_work, void *stream);
 int crc_relinearize(crc_ctx *ctx, const uint64_t *d_x3, size_t count, const uint64_t *d_evk, int dbc, uint64_t *d_y,
@@ -391,8 +410,10 @@ int crc_encrypt_dev(crc_ctx *ctx, const uint64_t *d_pk, const uint64_t *d_plain,
  *   crc_checksum64        position-sensitive checksum of a device buffer: h_out[0] = xor of all words, h_out[1] =
  *                         sum_i w_i * (2i+1) mod 2^64; synchronises `stream`.  Every rank checks what it received against the
  *                         root's pair.
- * Rehearsal on one GPU: RCCL refuses two ranks on the same device.  With CRC_COMM_TRANSPORT=shm in the environment crc_comm_unique_id names a POSIX shared-memory
- * segment instead of an RCCL rendezvous and the same calls stage their bytes through it (hipMemcpy, a process-shared barrier): the multi-rank HOST code above this
+ * Rehearsal on one GPU: RCCL refuses two ranks on the same device.  With CRC_COMM_TRANSPORT=shm in the environment crc_comm_unique_id names a POSIX
+ * shared-memory
+ * segment instead of an RCCL rendezvous and the same calls stage their bytes through it (hipMemcpy, a process-shared barrier): the multi-rank HOST code above
+ * this
  * header runs unchanged with several processes on one device.  A transport for tests only; never the default.
  * ------------------------------------------------------------------------------------------------------------- */
 typedef struct crc_comm crc_comm;

@@ -41,7 +41,8 @@ def test_plain_to_ntt(gs):
 
 
 def test_compact_plaintexts_expand_on_the_device(gs):
-    """crc_plain_expand: the 96-word compact plaintexts the host ships (crc_encode_f32_compact) zero-extended to [count][n] on the device == the dense encoding"""
+    """crc_plain_expand: the 96-word compact plaintexts the host ships (crc_encode_f32_compact) zero-extended to [count][n] on the device == the dense
+    encoding"""
     g, E = gs
     vals = np.concatenate([np.asarray(g["floats"], dtype=np.float32), np.random.default_rng(3).standard_normal(777).astype(np.float32)])
     dense, _ = E.encode(vals)
@@ -108,8 +109,10 @@ def test_square_and_relinearize(gs):
 
 
 def test_square_pool_with_one_key_switch_per_window(gs):
-    """crc_square_pool_relin_forms: Square + relinearise + sum pooling with the digit polynomials of a window added BEFORE the key switch (one key switch per pooled
-    ciphertext).  Must be the ciphertexts of crc_square_relin_forms followed by crc_pool -- themselves pinned to the reference's relinearize / pooling goldens above and
+    """crc_square_pool_relin_forms: Square + relinearise + sum pooling with the digit polynomials of a window added BEFORE the key switch (one key switch per
+    pooled
+    ciphertext).  Must be the ciphertexts of crc_square_relin_forms followed by crc_pool -- themselves pinned to the reference's relinearize / pooling
+    goldens above and
     in test_gpu_layers.py -- AND those of the CPU oracle's square -> relinearise -> pool, bit for bit, in every combination of forms, for CrCNN's overlapping
     2 x 2 / 1 window and a decimating 2 x 2 / 2 one"""
     import crcnn_amd as ca
@@ -136,8 +139,9 @@ def test_square_pool_with_one_key_switch_per_window(gs):
         E.pool(d_r, B, zd, xd, yd, xs, ys, xf, yf, None, ca.COEFF, d_p)
         want = E.download(d_p, (out_cnt, 2, E.k, E.n))
         if E.n <= 4096:
-            # ... and of the CPU oracle's Evaluator::square + relinearize followed by PoolingLayer::forward (evaluator.cpp:702-884, 934-1069; poolingLayer.cpp:22-44),
-            # image by image: the pooled path is checked against the restatement of the reference, not only against the engine's own unpooled sequence
+            # ... and of the CPU oracle's Evaluator::square + relinearize followed by PoolingLayer::forward (evaluator.cpp:702-884, 934-1069;
+            # poolingLayer.cpp:22-44), image by image: the pooled path is checked against the restatement of the reference, not only against the engine's own
+            # unpooled sequence
             from oracle import orc
             O = orc.Oracle(E.n, [int(v) for v in E.q], E.t)
             per = cts.reshape(B, zd, xd, yd, 2, E.k, E.n)
@@ -160,7 +164,8 @@ def test_square_pool_with_one_key_switch_per_window(gs):
 
 
 def test_square_pool_pair_with_all_eight_primes():
-    """the pooled key switch at n = 16384 with all eight primes of coeff_modulus_128(16384) -- D = 32 digit polynomials, a 2 x 2 window: the largest integers the two
+    """the pooled key switch at n = 16384 with all eight primes of coeff_modulus_128(16384) -- D = 32 digit polynomials, a 2 x 2 window: the largest integers
+    the two
     fp64 primes are asked to hold (2^91 of p_0 p_1 / 2 = 2^92.98) -- against square -> relinearise -> pool one after the other"""
     import crcnn_amd as ca
     n = 16384
@@ -211,19 +216,24 @@ def test_baseline_ring_sizes_vs_oracle(n, q, t):
     sk, pk = O.keygen(5); evk = O.gen_evk(6, sk)
     vals = np.array([0.5, -1.25, 2.75], dtype=np.float32)
     cts = O.encrypt_many(pk, O.encode_many(vals), 50)
-    d = E.upload(cts)
-    E.ntt_fwd(d, 3)
     want_ntt = np.stack([O.ct_to_ntt(c) for c in cts])
-    assert np.array_equal(E.download(d, cts.shape), want_ntt)
-    E.ntt_inv(d, 3)
-    assert np.array_equal(E.download(d, cts.shape), cts)
-    # edge values: all-zero and all-(q-1) polynomials survive the lazy butterflies
     edge = np.zeros((2, 2, len(q), n), dtype=np.uint64)
     edge[1] = (np.array(q, dtype=np.uint64) - np.uint64(1))[None, :, None]
-    de = E.upload(edge); E.ntt_fwd(de, 2)
-    assert np.array_equal(E.download(de, edge.shape), np.stack([O.ct_to_ntt(c) for c in edge]))
-    E.ntt_inv(de, 2)
-    assert np.array_equal(E.download(de, edge.shape), edge)
+    want_edge = np.stack([O.ct_to_ntt(c) for c in edge])
+    # the row transforms both ways round: the round-4 kernels (ntt_wave 0), the ones with one workgroup barrier per transform (15: every ring size
+    # that has them, round 5) and the engine's own choice (-1)
+    for wave in (0, 15, -1):
+        E.set_tuning("ntt_wave", wave)
+        d = E.upload(cts)
+        E.ntt_fwd(d, 3)
+        assert np.array_equal(E.download(d, cts.shape), want_ntt), ("ntt_wave", wave)
+        E.ntt_inv(d, 3)
+        assert np.array_equal(E.download(d, cts.shape), cts), ("ntt_wave", wave)
+        # edge values: all-zero and all-(q-1) polynomials survive the lazy butterflies
+        de = E.upload(edge); E.ntt_fwd(de, 2)
+        assert np.array_equal(E.download(de, edge.shape), want_edge), ("ntt_wave", wave)
+        E.ntt_inv(de, 2)
+        assert np.array_equal(E.download(de, edge.shape), edge), ("ntt_wave", wave)
     pl, _ = E.encode(np.array([0.3333, -7.0], dtype=np.float32))
     assert np.array_equal(pl, O.encode_many(np.array([0.3333, -7.0], dtype=np.float32)))
     d_p = E.upload(pl); d_w = E.alloc(2 * len(q) * n * 8); d_dl = E.alloc(2 * len(q) * n * 8)
@@ -247,9 +257,12 @@ RELIN_SETS = [(256, 1, 1), (1024, 2, 3), (4096, 2, 3), (8192, 4, 2), (16384, 8, 
 
 @pytest.mark.parametrize("n,k,cnt", RELIN_SETS, ids=[f"n{p[0]}_k{p[1]}" for p in RELIN_SETS])
 def test_relinearise_over_fp64_primes_equals_reference_arithmetic(n, k, cnt):
-    """Evaluator::relinearize (evaluator.cpp:934-1069) two ways on the same size-3 inputs: key switching over the two fp64 primes + CRT (kernels_relin64.hip, the
-    default) and over the coefficient moduli (the round-2 kernels, which follow the reference transform by transform), plus the CPU oracle.  Inputs are the worst
-    cases for the integer bound of the fp64 path: random full-range residues and c2 polynomials whose every digit is 0xffff / whose residues are all q - 1, under
+    """Evaluator::relinearize (evaluator.cpp:934-1069) two ways on the same size-3 inputs: key switching over the two fp64 primes + CRT (kernels_relin64.hip,
+    the
+    default) and over the coefficient moduli (the round-2 kernels, which follow the reference transform by transform), plus the CPU oracle.  Inputs are the
+    worst
+    cases for the integer bound of the fp64 path: random full-range residues and c2 polynomials whose every digit is 0xffff / whose residues are all q - 1,
+    under
     random full-range key material (a key is any element of R_q as far as the arithmetic is concerned).  Every form of crc_square_relin_forms as well."""
     import crcnn_amd as ca
     from oracle import orc
@@ -262,7 +275,8 @@ def test_relinearise_over_fp64_primes_equals_reference_arithmetic(n, k, cnt):
     for i in range(k):
         x3[:, :, i] = rng.integers(0, q[i], size=(cnt + 2, 3, n), dtype=np.uint64)
     x3[cnt, 2] = (qa - np.uint64(1))[:, None]                        # c2 = q - 1 everywhere
-    # ... and the c2 whose premultiplied form c2 (q/q_i)^-1 mod q_i -- what the digits are cut from -- has its three low 16-bit digits at 0xffff in every coefficient
+    # ... and the c2 whose premultiplied form c2 (q/q_i)^-1 mod q_i -- what the digits are cut from -- has its three low 16-bit digits at 0xffff in every
+    # coefficient
     for i in range(k):
         v = (q[i] - 1) | 0xffffffffffff
         if v >= q[i]:
@@ -317,14 +331,18 @@ def test_relinearise_over_fp64_primes_equals_reference_arithmetic(n, k, cnt):
     E.close()
 
 
-SQ64_SETS = [(256, 1, 1 << 16, 3), (1024, 2, 1 << 30, 3), (4096, 2, 1 << 32, 2), (4096, 2, (1 << 41) - 21, 2), (8192, 3, 1 << 42, 2), (8192, 4, 1 << 42, 2), (16384, 4, 1 << 44, 2), (16384, 8, 1 << 44, 1)]
+SQ64_SETS = [(256, 1, 1 << 16, 3), (1024, 2, 1 << 30, 3), (4096, 2, 1 << 32, 2), (4096, 2, (1 << 41) - 21, 2), (8192, 3, 1 << 42,
+             2), (8192, 4, 1 << 42, 2), (16384, 4, 1 << 44, 2), (16384, 8, 1 << 44, 1)]
 
 
 @pytest.mark.parametrize("n,k,t,cnt", SQ64_SETS, ids=[f"n{p[0]}_k{p[1]}_t{p[2].bit_length()}" for p in SQ64_SETS])
 def test_square_over_fp64_auxiliary_base_equals_reference_base(n, k, t, cnt):
-    """Evaluator::square (evaluator.cpp:702-884) two ways on the same inputs: with BEHZ's auxiliary base taken from the engine's fp64 primes (kernels_square64.hip, the
-    default) and with SEAL's own 61-bit base (the round-2 kernels, which follow baseconverter.cpp constant by constant), plus the CPU oracle (SEAL's base) at the
-    sizes it finishes in seconds.  The plain moduli are the bench's (2^42 at n = 8192, 2^44 at 16384: the size rule for the number of primes is tight there) and the
+    """Evaluator::square (evaluator.cpp:702-884) two ways on the same inputs: with BEHZ's auxiliary base taken from the engine's fp64 primes
+    (kernels_square64.hip, the
+    default) and with SEAL's own 61-bit base (the round-2 kernels, which follow baseconverter.cpp constant by constant), plus the CPU oracle (SEAL's base) at
+    the
+    sizes it finishes in seconds.  The plain moduli are the bench's (2^42 at n = 8192, 2^44 at 16384: the size rule for the number of primes is tight there)
+    and the
     inputs include the extremes of the integer bound |t P / q| <= 2 n t q: every residue q_i - 1 (largest products), zero, and 1."""
     import crcnn_amd as ca
     from oracle import orc
@@ -396,8 +414,8 @@ def test_square_over_fp64_auxiliary_base_equals_reference_base(n, k, t, cnt):
             E.square_relin(d_x, N, d_evk, d_y, d_w, in_form=ca.NTT, out_form=ca.NTT)
             assert np.array_equal(E.download(d_y, x.shape), res[(1, ca.NTT, ca.NTT)]), ("sq_fuse", fuse, "radix", radix)
     E.set_tuning("sq_fuse", -1); E.set_tuning("f64_radix", 0)
-    # round 5: the fp64 row kernels with one workgroup barrier per transform (wave-local passes; n = 8192 / 16384) -- every kernel of the family switched off (0:
-    # the round-4 kernels) and on (15: including the lifting forward kernel the default leaves alone): the reference base's ciphertexts both ways
+    # round 5: the fp64 row kernels with one workgroup barrier per transform (wave-local passes; n = 8192 / 16384) -- every kernel of the family switched off
+    # (0: the round-4 kernels) and on (15: including the lifting forward kernel the default leaves alone): the reference base's ciphertexts both ways
     if n in (8192, 16384):
         for wave in (0, 15):
             E.set_tuning("f64_wave", wave)
@@ -406,6 +424,13 @@ def test_square_over_fp64_auxiliary_base_equals_reference_base(n, k, t, cnt):
                 E.square_relin(d_x, N, d_evk, d_y, d_w, in_form=fin, out_form=fout)
                 assert np.array_equal(E.download(d_y, x.shape), res[(1, fin, fout)]), ("f64_wave", wave, fin, fout)
         E.set_tuning("f64_wave", -1)
+        # ... and the 64-bit row transforms of the chain (the two inverse transforms with the product / the exact scaling fused in) likewise
+        for wave in (0, 15):
+            E.set_tuning("ntt_wave", wave)
+            d_y = E.alloc(x.nbytes)
+            E.square_relin(d_x, N, d_evk, d_y, d_w, in_form=ca.NTT, out_form=ca.NTT)
+            assert np.array_equal(E.download(d_y, x.shape), res[(1, ca.NTT, ca.NTT)]), ("ntt_wave", wave)
+        E.set_tuning("ntt_wave", -1)
     E.close()
 
 

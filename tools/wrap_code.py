@@ -36,7 +36,7 @@ def comment_start(line, st):
 
 
 def wrap(line):
-    if len(line) <= LIMIT or line.lstrip().startswith("#") or line.rstrip().endswith("\\"):
+    if len(line) <= LIMIT or line.lstrip().startswith(("#", "//", "/*", "* ")) or line.rstrip().endswith("\\"):      # (comment lines: tools/wrap_comments.py)
         return [line]
     indent = line[:len(line) - len(line.lstrip())]
     st = scan(line)
