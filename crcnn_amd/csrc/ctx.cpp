@@ -98,17 +98,19 @@ static bool build_ntt(HostNtt &T, int logn, u64 q, bool no_fold)
     if (!T.root) return false;
     u64 iroot = h_invmod(T.root, q);
     T.inv_n = h_invmod((u64)n, q);
-    T.rp.assign(n, 0); T.srp.assign(n, 0); T.irp2.assign(n, 0); T.sirp2.assign(n, 0);
+    T.rp.assign(n, 0); T.srp.assign(n, 0); T.irp2.assign(n, 0); T.sirp2.assign(n, 0); T.irp.assign(n, 0); T.sirp.assign(n, 0);
     u64 p = 1, ip = 1;
     for (int i = 0; i < n; i++) {
         u32 j = bitrev((u32)i, logn);
         T.rp[j] = p;
         T.irp2[j] = (ip & 1) ? (u64)(((u128)ip + q) >> 1) : ip >> 1;       // psi^-i / 2 mod q
+        T.irp[j] = ip;
         p = h_mulmod(p, T.root, q); ip = h_mulmod(ip, iroot, q);
     }
     for (int i = 0; i < n; i++) {
         T.srp[i] = (u64)(((u128)T.rp[i] << 64) / q);
         T.sirp2[i] = (u64)(((u128)T.irp2[i] << 64) / q);
+        T.sirp[i] = (u64)(((u128)T.irp[i] << 64) / q);
     }
     return true;
 }
@@ -421,20 +423,22 @@ extern "C" int crc_ctx_create(int n, const uint64_t *q, int k, uint64_t t, int d
         if (e != hipSuccess) { fail(e); delete c; return rc; }
         int nm = k + c->kb; size_t tw = (size_t)nm * n * 16;      // {twiddle, Shoup companion} interleaved: one 16-byte load per butterfly
         std::vector<ModParams> mods(nm);
-        std::vector<u64> rp((size_t)nm * n * 2), irp2(rp.size());
+        std::vector<u64> rp((size_t)nm * n * 2), irp2(rp.size()), irp(rp.size());
         for (int m = 0; m < nm; m++) {
             mods[m] = c->tabs[m].m;
             for (int i = 0; i < n; i++) {
                 rp[((size_t)m * n + i) * 2] = c->tabs[m].rp[i]; rp[((size_t)m * n + i) * 2 + 1] = c->tabs[m].srp[i];
                 irp2[((size_t)m * n + i) * 2] = c->tabs[m].irp2[i]; irp2[((size_t)m * n + i) * 2 + 1] = c->tabs[m].sirp2[i];
+                irp[((size_t)m * n + i) * 2] = c->tabs[m].irp[i]; irp[((size_t)m * n + i) * 2 + 1] = c->tabs[m].sirp[i];
             }
         }
         if ((e = hipMalloc(&c->d_mods, sizeof(ModParams) * nm)) != hipSuccess || (e = hipMalloc(&c->d_rp, tw)) != hipSuccess ||
-            (e = hipMalloc(&c->d_irp2, tw)) != hipSuccess || (e = hipMalloc(&c->d_behz, sizeof(BehzParams))) != hipSuccess ||
+            (e = hipMalloc(&c->d_irp2, tw)) != hipSuccess || (e = hipMalloc(&c->d_irp, tw)) != hipSuccess || (e = hipMalloc(&c->d_behz, sizeof(BehzParams))) != hipSuccess ||
             (e = hipMalloc(&c->d_zero, 8192)) != hipSuccess || (e = hipMemset(c->d_zero, 0, 8192)) != hipSuccess ||
             (e = hipMemcpy(c->d_mods, mods.data(), sizeof(ModParams) * nm, hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(c->d_rp, rp.data(), tw, hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(c->d_irp2, irp2.data(), tw, hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemcpy(c->d_irp, irp.data(), tw, hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(c->d_behz, &c->behz, sizeof(BehzParams), hipMemcpyHostToDevice)) != hipSuccess) {
             fail(e); crc_ctx_destroy(c); return rc;
         }
@@ -458,7 +462,7 @@ extern "C" void crc_ctx_destroy(crc_ctx *c)
 {
     if (!c) return;
     if (c->device >= 0) {
-        (void)hipFree(c->d_mods); (void)hipFree(c->d_rp); (void)hipFree(c->d_irp2); (void)hipFree(c->d_behz); (void)hipFree(c->d_zero);
+        (void)hipFree(c->d_mods); (void)hipFree(c->d_rp); (void)hipFree(c->d_irp2); (void)hipFree(c->d_irp); (void)hipFree(c->d_behz); (void)hipFree(c->d_zero);
         (void)hipFree(c->d_f64_rp); (void)hipFree(c->d_f64_irp); (void)hipFree(c->d_sq64);
     }
     delete c;

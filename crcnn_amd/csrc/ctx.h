@@ -94,6 +94,7 @@ struct HostNtt {               // one modulus
     ModParams m;
     u64 root, inv_n;
     std::vector<u64> rp, srp, irp2, sirp2;   // bit-reversed powers + Shoup companions (layout as SEAL's tables)
+    std::vector<u64> irp, sirp;              // the inverse powers NOT halved (round 5: the inverse transforms that scale once, at the end)
 };
 
 // Tuning switches of tools/ and the tests.  The environment is read ONCE, inside crc_ctx_create (a host application that calls setenv from another thread
@@ -119,7 +120,7 @@ struct CrcTuning {
     // CRC_SQ_FUSE=1: an NTT-resident square lifts inside its forward fp64 transforms, 0: in a kernel of its own (round 3), -1: by k (fused up to k = 4)
     int sq_fuse = -1;
     // CRC_NTT_WAVE: the lazy 64-bit row transforms with one workgroup barrier per transform (ntt_rows_wave_kernel): bit 0 n = 8192, 1 n = 4096,
-    // 2 n = 16384, 3 n = 16384 with the Square prologues; -1: the measured choice (7)
+    // 2 n = 16384, 3 n = 16384 with the Square prologues, 4 inverse butterflies that halve per stage (round 4) instead of scaling once; -1: measured (15)
     int ntt_wave = -1;
     int f64_wave = -1;
                                   // 2 K3, 3 the lifting forward kernel, 4 K3's 64-bit forward transform (with bit 2); -1: what measured faster
@@ -145,6 +146,7 @@ struct crc_ctx {
     // device copies
     ModParams *d_mods = nullptr;             // [k+kb]
     u64 *d_rp = nullptr, *d_irp2 = nullptr;   // [(k+kb)][n][2]: {bit-reversed root power, its Shoup companion} (forward / inverse-div-2)
+    u64 *d_irp = nullptr;                     // the same layout, inverse powers not halved (ntt_rows_wave_kernel's unscaled inverse butterflies)
     BehzParams *d_behz = nullptr;
     u64 f64_primes[CRC_NF64A] = {0};
     int nf64 = CRC_NF64;                     // fp64 primes with transform tables: max(CRC_NF64, sq64.kf)

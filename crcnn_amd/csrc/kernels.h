@@ -12,7 +12,7 @@ int k_ntt_ct_head_add(crc_ctx *c, const u64 *src, int src_size, u64 *dst, size_t
 int k_spread_ntt(crc_ctx *c, const u64 *src, size_t items, u64 *dst, hipStream_t st);
 int k_digit_ntt(crc_ctx *c, const u64 *src, int src_size, int src_poly, size_t count, int D, const unsigned char *dig_i, const unsigned char *dig_shift, int dbc,
                 u64 *dst, hipStream_t st, int pack_out = 0);
-int k_square_intt(crc_ctx *c, const u64 *src, u64 *dst, size_t count, bool bsk, hipStream_t st);
+int k_square_intt(crc_ctx *c, const u64 *src, u64 *dst, size_t count, bool bsk, hipStream_t st, const u64 *opt_mul = nullptr, bool *applied = nullptr);
 int k_ntt_ct_inv_scaled(crc_ctx *c, const u64 *src, u64 *dst, size_t count, int size, const u64 *mul, const u64 *mul_s, hipStream_t st);
 int k_plain_ntt(crc_ctx *c, const u64 *d_plain, size_t count, int mode, bool do_ntt, u64 *d_out, hipStream_t st);
 int k_plain_expand(crc_ctx *c, const u64 *d_compact, size_t count, u64 *d_plain, hipStream_t st);

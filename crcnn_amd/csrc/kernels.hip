@@ -38,6 +38,8 @@ struct NttArgs {
     int D, src_size, src_poly; unsigned long long dig_mask;
     size_t pairs;
     u64 post_mul[CRC_MAXK], post_mul_s[CRC_MAXK];
+    // host side only, prologue 4: 1 = post_mul is OFFERED -- a kernel that closes with a multiplication anyway takes it in (and says so: 2), the others ignore it
+    int opt_mul;
     unsigned char dig_i[48], dig_shift[48];
     const u64 *addend; int add_sign; int rows_per_ct; long long add_group;   // epilogue (inverse only)
     int add_mod;                                               // plaintext index = (ct / add_group) % add_mod (0: no modulo)
@@ -167,7 +169,7 @@ __global__ void __launch_bounds__(1024) ntt_rows_kernel(NttArgs a) { ntt_rows_bo
 // -> block-local drain through the gap-1 stage.  Inverse: block-local fill through the gap-1 stage (PRO 4: the square's products formed on the way) -> three
 // wave-local passes | barrier | the cross stages from the image to registers -> final reduction (PRO 5: the scaled result) -> 16-byte stores.  Same butterflies
 // on the same values as ntt_rows_body, hence the same results.  Prologues 0 / 4 / 5 without an addend; everything else stays with ntt_rows_kernel.
-template <bool INV, int PRO, int CS>
+template <bool INV, int PRO, int CS, bool UNS>
 __global__ void __launch_bounds__(CS == 2 ? 256 : CS == 3 ? 512 : 1024, 4) ntt_rows_wave_kernel(NttArgs a)
 {
     // CS = log2 n - 10 stages cross the 1024-point blocks (n = 4096 / 8192 / 16384: 2 / 3 / 4); a thread owns E = 16 >> CS neighbouring points of every block
@@ -229,7 +231,7 @@ __global__ void __launch_bounds__(CS == 2 ? 256 : CS == 3 ? 512 : 1024, 4) ntt_r
                 const ulonglong2 av = ld2(pa + s), bv = ld2(pb + s);
                 ulonglong2 v{mulmod(av.x, bv.x, m), mulmod(av.y, bv.y, m)};
                 if (p == 1) { v.x = addmod(v.x, v.x, q); v.y = addmod(v.y, v.y, q); }
-                inv_pair_stage<true>(v, W1[s >> 1], q, q2);
+                if (UNS) inv_pair_stage_unscaled(v, W1[s >> 1], q, q2 + q2); else inv_pair_stage<true>(v, W1[s >> 1], q, q2);
                 sm_store_pair64(sm, s, v.x, v.y);
             }
         } else {
@@ -239,23 +241,24 @@ __global__ void __launch_bounds__(CS == 2 ? 256 : CS == 3 ? 512 : 1024, 4) ntt_r
             for (int u = 0; u < 8; u++) {
                 const int s = f64_local_pair(u);
                 ulonglong2 v = ld2(src + s);
-                inv_pair_stage<true>(v, W1[s >> 1], q, q2);
+                if (UNS) inv_pair_stage_unscaled(v, W1[s >> 1], q, q2 + q2); else inv_pair_stage<true>(v, W1[s >> 1], q, q2);
                 sm_store_pair64(sm, s, v.x, v.y);
             }
         }
         f64_wave_sync();
-        u64_local_passes_inv<true>(sm, W, n, q, q2);
+        if (UNS) u64_local_passes_inv_unscaled(sm, W, n, q, q2, rq); else u64_local_passes_inv<true>(sm, W, n, q, q2);
         __syncthreads();
-        const u64 pm = PRO == 5 ? a.post_mul[mloc] : 0, pms = PRO == 5 ? a.post_mul_s[mloc] : 0;
+        // (UNS: every prologue ends in the multiplication -- by n^-1, times the caller's constant at prologue 5; the host put the product into post_mul)
+        const u64 pm = PRO == 5 || UNS ? a.post_mul[mloc] : 0, pms = PRO == 5 || UNS ? a.post_mul_s[mloc] : 0;
         u64 x[16];
 #pragma unroll
         for (int e = 0; e < E; e++) {
             u64 y[C];
 #pragma unroll
             for (int c = 0; c < C; c++) y[c] = sm[swz<3>(pt(c, e))];
-            inv_stages<CS, true>(y, W, n >> 11, 0, q, q2);
+            if (UNS) inv_stages_unscaled<CS>(y, W, n >> 11, 0, q, q << (CS + 3)); else inv_stages<CS, true>(y, W, n >> 11, 0, q, q2);
 #pragma unroll
-            for (int c = 0; c < C; c++) x[c * E + e] = PRO == 5 ? mulmod_shoup(y[c], pm, pms, q) : reduce_small(y[c], q, q2, rq);
+            for (int c = 0; c < C; c++) x[c * E + e] = PRO == 5 || UNS ? mulmod_shoup(y[c], pm, pms, q) : reduce_small(y[c], q, q2, rq);
         }
 #pragma unroll
         for (int c = 0; c < C; c++) {
@@ -518,16 +521,29 @@ static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t
     if ((a.prologue == 3 && inv) || ((a.prologue == 4 || a.prologue == 5) && !inv)) return CRC_ERR_INVALID_ARGUMENT;
     if (a.prologue == 4) rows = xcd_grid(a.pairs, 3);                  // (the three products of a pair on one XCD: ntt_rows_body)
     // wave-local passes (ntt_rows_wave_kernel): CRC_NTT_WAVE bit 0 n = 8192, bit 1 n = 4096, bit 2 n = 16384 (plain transforms), bit 3 n = 16384 with the
-    // Square prologues (measured slower than the split kernel there: 11.9 vs 11.7 us per squared ciphertext, profiles/r05_ntt_u64_wave_local_ab.txt); -1: bits
-    // 0 to 2
+    // Square prologues (slower than the split kernel with the halving butterflies, 11.9 against 11.7 us per squared ciphertext, faster with the ones that do not
+    // halve: 11.27 against 11.6 -- profiles/r05_ntt_u64_wave_local_ab.txt, r05_ntt_inverse_unscaled_ab.txt), bit 4: keep the halving butterflies; -1: bits 0 to 3
     {
-        const int sel = c->tune.ntt_wave < 0 ? 7 : c->tune.ntt_wave;
+        const int sel = c->tune.ntt_wave < 0 ? 15 : c->tune.ntt_wave;
         const int bit = c->n == 8192 ? 0 : c->n == 4096 ? 1 : c->n == 16384 ? (a.prologue ? 3 : 2) : -1;
         if (bit >= 0 && ((sel >> bit) & 1) && lazy && !a.addend && (a.prologue == 0 || a.prologue == 4 || a.prologue == 5)) {
             lds = (size_t)c->n * 8;
-#define WAVEK(CSV) (a.prologue == 4 ? ntt_rows_wave_kernel<true, 4, CSV> : a.prologue == 5 ? ntt_rows_wave_kernel<true, 5, CSV> \
-                    : inv ? ntt_rows_wave_kernel<true, 0, CSV> : ntt_rows_wave_kernel<false, 0, CSV>)
-            auto kw = bit == 0 ? WAVEK(3) : bit == 1 ? WAVEK(2) : WAVEK(4);
+            // inverse transforms over moduli below 2^55 take the butterflies that do not halve (inv_stages_unscaled; CRC_NTT_WAVE bit 4 switches them off): the
+            // table of plain inverse powers, and n^-1 in the constant of the closing multiplication
+            bool uns = inv && !(sel & 16);
+            for (int i = 0; i < a.mod_count; i++) uns = uns && c->tabs[a.mod_base + i].m.q < (1ull << 55);
+            if (uns) {
+                a.w = reinterpret_cast<const ulonglong2 *>(c->d_irp);
+                for (int i = 0; i < a.mod_count; i++) {
+                    const HostNtt &T = c->tabs[a.mod_base + i]; const u64 q = T.m.q;
+                    const u64 pm = a.prologue == 5 || a.opt_mul ? (u64)(((unsigned __int128)a.post_mul[i] * T.inv_n) % q) : T.inv_n;
+                    a.post_mul[i] = pm; a.post_mul_s[i] = (u64)(((unsigned __int128)pm << 64) / q);
+                }
+                if (a.opt_mul) a.opt_mul = 2;
+            }
+#define WAVEK(CSV, U) (a.prologue == 4 ? ntt_rows_wave_kernel<true, 4, CSV, U> : a.prologue == 5 ? ntt_rows_wave_kernel<true, 5, CSV, U> \
+                       : inv ? ntt_rows_wave_kernel<true, 0, CSV, U> : ntt_rows_wave_kernel<false, 0, CSV, false>)
+            auto kw = uns ? (bit == 0 ? WAVEK(3, true) : bit == 1 ? WAVEK(2, true) : WAVEK(4, true)) : (bit == 0 ? WAVEK(3, false) : bit == 1 ? WAVEK(2, false) : WAVEK(4, false));
 #undef WAVEK
             { const int rc = crc_ctx_ensure_lds(c, (const void *)kw, lds); if (rc) return rc; }
             hipLaunchKernelGGL(kw, dim3((unsigned)rows), dim3(c->n / 16), lds, st, a);
@@ -627,12 +643,17 @@ int k_digit_ntt(crc_ctx *c, const u64 *src, int src_size, int src_poly, size_t c
 
 // inverse NTT of the three dyadic products (a^2, 2ab, b^2) of size-2 NTT-form ciphertexts src [count][2][K][n] -> dst [count][3][K][n] (coefficient form),
 // K = k moduli of q or kb moduli of Bsk; the products are formed while the row is loaded (NttArgs prologue 4)
-int k_square_intt(crc_ctx *c, const u64 *src, u64 *dst, size_t count, bool bsk, hipStream_t st)
+// opt_mul (per modulus, may be null): constants the consumer of dst would multiply the rows by first thing; *applied says whether the transform took them into
+// its closing multiplication (the kernels that end in one: ntt_rows_wave_kernel's unscaled inverse) or left the rows as they are
+int k_square_intt(crc_ctx *c, const u64 *src, u64 *dst, size_t count, bool bsk, hipStream_t st, const u64 *opt_mul, bool *applied)
 {
     NttArgs a{};
     a.src = src; a.dst = dst; a.mod_base = bsk ? c->k : 0; a.mod_count = bsk ? c->kb : c->k; a.prologue = 4;
     a.rows_per_ct = 3 * a.mod_count; a.add_group = 1; a.pairs = count * a.mod_count;
-    return ntt_launch(c, true, a, count * 3 * a.mod_count, st);
+    if (opt_mul) { a.opt_mul = 1; for (int i = 0; i < a.mod_count; i++) a.post_mul[i] = opt_mul[i]; }
+    const int rc = ntt_launch(c, true, a, count * 3 * a.mod_count, st);
+    if (applied) *applied = a.opt_mul == 2;
+    return rc;
 }
 
 // inverse NTT of size-`size` ciphertexts over q whose result leaves multiplied by mul[i] mod q_i (mul_s: Shoup companions) -- NttArgs prologue 5

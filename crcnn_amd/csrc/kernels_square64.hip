@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(CS == 3 ? 512 : 1024, 4) sq64_inv_wave_kernel(
 // (8192, 3))
 template <int K, int KF>
 __global__ void __launch_bounds__(256) sq64_floor_kernel(const u64 *dq, const double *db, u64 *y3, const ModParams *mods, const BehzParams *bp,
-    const Sq64Params *sp, int n, int premul_c2)
+    const Sq64Params *sp, int n, int premul_c2, int dq_scaled)
 {
     const BehzParams &b = *bp; const Sq64Params &f = *sp;
     constexpr int KB = KF - 1;
@@ -289,7 +289,8 @@ __global__ void __launch_bounds__(256) sq64_floor_kernel(const u64 *dq, const do
     // x t (evaluator.cpp:856-871) and the (q/q_i)^-1 of fastbconv (:413-423) are one constant
 #pragma unroll
     for (int i = 0; i < K; i++) {
-        const u64 tr = mulmod_shoup(xq[(size_t)i * n], b.t_inv_qhat[i], b.t_inv_qhat_s[i], mods[i].q);
+        // (dq_scaled: the inverse transform that made the row closed with this very multiplication -- k_square_intt, round 5)
+        const u64 xv = xq[(size_t)i * n], tr = dq_scaled ? xv : mulmod_shoup(xv, b.t_inv_qhat[i], b.t_inv_qhat_s[i], mods[i].q);
         th[i] = (double)(u32)(tr >> 32); tl[i] = (double)(u32)tr;
     }
     // fast_floor (:646-660): (x_p t - fastbconv(x_q t)) q^-1 mod p_j, with q^-1 (and the inverse transform's n^-1) folded into floor_x / floor_c
@@ -317,16 +318,31 @@ __global__ void __launch_bounds__(256) sq64_floor_kernel(const u64 *dq, const do
     const double ad = f64_reduce(f64_mulmod_const(f64_reduce(v - fl[KB], msk), f.inv_B_msk[0], f.inv_B_msk[1], msk.p), msk);
     const long long alpha = (long long)ad;
     const bool neg = alpha < 0;
-    const u64 am = (u64)(neg ? -alpha : alpha);
+    const u64 am = (u64)(neg ? -alpha : alpha);                      // (up to |R| / B + KB: 37 bits at n = 256, t = 2^41 with two 40-bit moduli)
+    const u32 am0 = (u32)am & 0xfffffffu, am1 = (u32)(am >> 28);
+    // sum_j z_j (B/p_j) - alpha B mod q_i (:553-569), lazily: z_j (47 bits) and the constants (up to 60) in 28-bit pieces, so that every partial product is ONE
+    // v_mad_u64_u32 into one of three 64-bit sums that cannot overflow (z0 y0 < 2^56, z0 y1 + z1 y0 < 2^60 + 2^47, z1 y1 < 2^51; at most 12 terms, |alpha| among them) -- 4
+    // instructions per term instead of the 14 of a 64 x 64 -> 128 product and its carry chain; the sums meet in 128 bits once, before the one reduction
+    u32 z0[KB], z1[KB];
+#pragma unroll
+    for (int j = 0; j < KB; j++) { z1[j] = (u32)(z[j] * 0x1p-28); z0[j] = (u32)(z[j] - (double)z1[j] * 0x1p28); }
     u64 *dst = y3 + poly * (size_t)K * n + s;
 #pragma unroll
     for (int i = 0; i < K; i++) {
         const ModParams mi = mods[i];
-        acc128 a{0, 0};
+        u64 P0 = 0, P1 = 0, P2 = 0;
 #pragma unroll
-        for (int j = 0; j < KB; j++) acc_mad(a, (u64)z[j], f.mhat_q[i][j]);          // 47 x <= 60 bits, at most 11 terms: below 2^111
-        acc_mad(a, neg ? f.B_q[i] : mi.q - f.B_q[i], am);                            // - alpha B   (:553-569)
-        u64 r = barrett128(a.lo, a.hi, mi);
+        for (int j = 0; j < KB; j++) {
+            const u64 y = f.mhat_q[i][j]; const u32 y0 = (u32)y & 0xfffffffu, y1 = (u32)(y >> 28);
+            P0 += (u64)z0[j] * y0; P1 += (u64)z0[j] * y1; P1 += (u64)z1[j] * y0; P2 += (u64)z1[j] * y1;
+        }
+        {                                                                                                                             // - alpha B
+            const u64 y = neg ? f.B_q[i] : mi.q - f.B_q[i]; const u32 y0 = (u32)y & 0xfffffffu, y1 = (u32)(y >> 28);
+            P0 += (u64)am0 * y0; P1 += (u64)am0 * y1; P1 += (u64)am1 * y0; P2 += (u64)am1 * y1;
+        }
+        const u64 l1 = P0 + (P1 << 28), t2 = P2 << 56, lo = l1 + t2;
+        const u64 hi = (P1 >> 36) + (l1 < P0) + (P2 >> 8) + (lo < t2);
+        u64 r = barrett128(lo, hi, mi);
         if (premul_c2 && poly % 3 == 2) r = mulmod_shoup(r, b.inv_qhat[i], b.inv_qhat_s[i], mi.q);
         dst[(size_t)i * n] = r;
     }
@@ -418,7 +434,9 @@ int k_square64(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStre
         HIPCHK(hipGetLastError());
     }
     // a^2, 2ab, b^2 over q are formed while the inverse transforms load their rows (kernels.hip); over the fp64 primes in sq64_inv_kernel
-    if ((rc = k_square_intt(c, xn, DQ, cnt, false, st))) return rc;
+    // (x t (q/q_i)^-1, the first thing the floor kernel does to these rows, goes into the transform's closing multiplication where it has one)
+    bool dq_scaled = false;
+    if ((rc = k_square_intt(c, xn, DQ, cnt, false, st, c->behz.t_inv_qhat, &dq_scaled))) return rc;
     if (sq64_wave_path(c, RB, 0)) {
         auto kern = c->logn == 13 ? sq64_inv_wave_kernel<3> : sq64_inv_wave_kernel<4>;
         if ((rc = crc_ctx_ensure_lds(c, (const void *)kern, lds))) return rc;
@@ -434,7 +452,7 @@ int k_square64(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStre
         const int threads = c->n < 256 ? c->n : 256;
         const dim3 grid((unsigned)(cnt * 3 * (c->n / threads))), blk(threads);
         bool launched = false;
-#define FLOOR(KV, KFV) if (c->k == KV && c->sq64.kf == KFV) { hipLaunchKernelGGL((sq64_floor_kernel<KV, KFV>), grid, blk, 0, st, DQ, DB, y3, c->d_mods, c->d_behz, c->d_sq64, c->n, premul_c2 ? 1 : 0); launched = true; }
+#define FLOOR(KV, KFV) if (c->k == KV && c->sq64.kf == KFV) { hipLaunchKernelGGL((sq64_floor_kernel<KV, KFV>), grid, blk, 0, st, DQ, DB, y3, c->d_mods, c->d_behz, c->d_sq64, c->n, premul_c2 ? 1 : 0, dq_scaled ? 1 : 0); launched = true; }
         CRC_FOR_ALL_K_KF(FLOOR)
 #undef FLOOR
         if (!launched) return CRC_ERR_UNSUPPORTED;

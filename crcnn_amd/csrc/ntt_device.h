@@ -118,6 +118,33 @@ __device__ __forceinline__ void inv_stages(u64 (&v)[1 << R], const ulonglong2 *W
     }
 }
 
+// Inverse stages that do NOT halve (round 5; moduli below 2^55, tables of the plain inverse powers): the sum side of a Gentleman-Sande butterfly is U + V and
+// nothing else, the factor n^-1 is one constant in the multiplication every result ends in anyway.  The sums double per stage instead: with inputs below B q a
+// group of 2^R values leaves one value (index 0, the sum of all) below 2^R B q, R more below 2^(R-1) ... 16 q, the rest below 4 q; the caller reduces index 0 when
+// another pass follows.  kq >= the bound of any difference operand V (2^(R-1) B q); everything stays below 2^9 q < 2^64.  Six instructions fewer per butterfly.
+template <int R>
+__device__ __forceinline__ void inv_stages_unscaled(u64 (&v)[1 << R], const ulonglong2 *W, int h, int blk, u64 q, u64 kq)
+{
+#pragma unroll
+    for (int st = 0; st < R; st++) {
+        const int half = 1 << st;
+#pragma unroll
+        for (int c = 0; c < (1 << R); c++) {
+            if (c & half) continue;
+            const int wi = (h >> st) + (blk << (R - 1 - st)) + (c >> (st + 1));
+            const ulonglong2 tw = W[wi];
+            const u64 U = v[c], V = v[c + half];
+            v[c] = U + V;
+            v[c + half] = shoup_lazy4(kq - V + U, tw.x, tw.y, q);
+        }
+    }
+}
+__device__ __forceinline__ void inv_pair_stage_unscaled(ulonglong2 &v, const ulonglong2 tw, u64 q, u64 kq)
+{
+    const u64 U = v.x, V = v.y;
+    v.x = U + V; v.y = shoup_lazy4(kq - V + U, tw.x, tw.y, q);
+}
+
 // The stage with gap 1 -- the last of a forward transform, the first of an inverse one -- pairs the two points (s, s + 1), s even, that share one 16-byte slot of
 // the image, i.e. what one lane moves between memory and the image.  When log2 n = 3 m + 1 (n = 8192, and the halves of n = 16384) that stage would be an LDS pass
 // of its own with one butterfly per thread; instead the loops that fill / drain the image apply it in registers (ntt_fused_stage: four passes and barriers per row

@@ -442,3 +442,27 @@ __device__ __forceinline__ void u64_local_passes_inv(u64 *sm, const ulonglong2 *
         f64_wave_sync();
     }
 }
+// ... the same with the butterflies that do not halve (ntt_device.h inv_stages_unscaled): pass inputs below 16 q, the one sum-of-all value of every group of
+// eight (below 128 q) reduced on the way out
+__device__ __forceinline__ void u64_local_passes_inv_unscaled(u64 *sm, const ulonglong2 *W, int n, u64 q, u64 q2, float rq)
+{
+    const unsigned w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int p = 0; p < 3; p++) {
+        const int ls = 1 + 3 * p, tabidx = n >> (ls + 1);
+#pragma unroll 1
+        for (unsigned u = 0; u < 2; u++) {
+            const unsigned g = (w << 7) + lane + 64 * u;
+            const unsigned blk = g >> ls, l = g & ((1u << ls) - 1);
+            const int a0 = swz<3>((int)((blk << (ls + 3)) + l));
+            u64 v[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) v[c] = sm[a0 ^ swz<3>(c << ls)];
+            inv_stages_unscaled<3>(v, W, tabidx, (int)blk, q, q << 6);
+            v[0] = reduce_small(v[0], q, q2, rq);
+#pragma unroll
+            for (int c = 0; c < 8; c++) sm[a0 ^ swz<3>(c << ls)] = v[c];
+        }
+        f64_wave_sync();
+    }
+}

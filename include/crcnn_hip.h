@@ -116,8 +116,8 @@ int  crc_ctx_table(const crc_ctx *ctx, const char *name, uint64_t *h_out, int ca
  * "f64_wave" (bit mask of the fp64 row kernels that run with one workgroup barrier per transform at n = 8192 / 16384: 1 sq64_inv, 2 the digit kernel, 4 K3, 8
  * the lifting
  * forward kernel, 16 K3's 64-bit forward transform; -1: the measured choice, 0: the round-4 kernels), "ntt_wave" (the same for the 64-bit row transforms: 1 n =
- * 8192,
- * 2 n = 4096, 4 n = 16384, 8 n = 16384 with the square's prologues; -1: the measured choice = 7).
+ * 8192, 2 n = 4096, 4 n = 16384, 8 n = 16384 with the square's prologues, 16 inverse butterflies that halve at every stage as in round 4 instead of scaling once
+ * at the end; -1: the measured choice = 15).
  * Every path gives the same ciphertexts.  CRC_ERR_NOT_FOUND for anything else. */
 int  crc_ctx_set_tuning(crc_ctx *ctx, const char *name, long long value);
 

@@ -221,8 +221,8 @@ def test_baseline_ring_sizes_vs_oracle(n, q, t):
     edge[1] = (np.array(q, dtype=np.uint64) - np.uint64(1))[None, :, None]
     want_edge = np.stack([O.ct_to_ntt(c) for c in edge])
     # the row transforms both ways round: the round-4 kernels (ntt_wave 0), the ones with one workgroup barrier per transform (15: every ring size
-    # that has them, round 5) and the engine's own choice (-1)
-    for wave in (0, 15, -1):
+    # that has them, round 5; 31: with inverse butterflies that halve at every stage instead of scaling once) and the engine's own choice (-1)
+    for wave in (0, 15, 31, -1):
         E.set_tuning("ntt_wave", wave)
         d = E.upload(cts)
         E.ntt_fwd(d, 3)
@@ -425,7 +425,7 @@ def test_square_over_fp64_auxiliary_base_equals_reference_base(n, k, t, cnt):
                 assert np.array_equal(E.download(d_y, x.shape), res[(1, fin, fout)]), ("f64_wave", wave, fin, fout)
         E.set_tuning("f64_wave", -1)
         # ... and the 64-bit row transforms of the chain (the two inverse transforms with the product / the exact scaling fused in) likewise
-        for wave in (0, 15):
+        for wave in (0, 15, 31):
             E.set_tuning("ntt_wave", wave)
             d_y = E.alloc(x.nbytes)
             E.square_relin(d_x, N, d_evk, d_y, d_w, in_form=ca.NTT, out_form=ca.NTT)
