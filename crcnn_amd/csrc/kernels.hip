@@ -225,12 +225,19 @@ __global__ void __launch_bounds__(CS == 2 ? 256 : CS == 3 ? 512 : 1024, 4) ntt_r
             const size_t ct = row / (3 * (size_t)a.mod_count); const int p = (int)((row / a.mod_count) % 3);
             const u64 *pa = a.src + ((ct * 2 + (p == 2 ? 1 : 0)) * a.mod_count + mloc) * (size_t)n;
             const u64 *pb = a.src + ((ct * 2 + (p == 0 ? 0 : 1)) * a.mod_count + mloc) * (size_t)n;
+            const bool lazy_prod = m.fold != 0 && m.bits >= 53;
 #pragma unroll 4
             for (int u = 0; u < 8; u++) {
                 const int s = f64_local_pair(u);
                 const ulonglong2 av = ld2(pa + s), bv = ld2(pb + s);
-                ulonglong2 v{mulmod(av.x, bv.x, m), mulmod(av.y, bv.y, m)};
-                if (p == 1) { v.x = addmod(v.x, v.x, q); v.y = addmod(v.y, v.y, q); }
+                ulonglong2 v;
+                if (UNS && lazy_prod) {          // below 2q each, 4q doubled: the unscaled butterflies take that (inv_stages_unscaled: sums below 8q, v0 of pass 1 below 64q)
+                    v = ulonglong2{mulmod_fold2_lazy(av.x, bv.x, m), mulmod_fold2_lazy(av.y, bv.y, m)};
+                    if (p == 1) { v.x += v.x; v.y += v.y; }
+                } else {
+                    v = ulonglong2{mulmod(av.x, bv.x, m), mulmod(av.y, bv.y, m)};
+                    if (p == 1) { v.x = addmod(v.x, v.x, q); v.y = addmod(v.y, v.y, q); }
+                }
                 if (UNS) inv_pair_stage_unscaled(v, W1[s >> 1], q, q2 + q2); else inv_pair_stage<true>(v, W1[s >> 1], q, q2);
                 sm_store_pair64(sm, s, v.x, v.y);
             }

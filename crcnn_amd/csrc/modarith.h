@@ -90,6 +90,20 @@ CRC_HD u64 fold128(u64 lo, u64 hi, const ModParams &m)
     return r >= m.q ? r - m.q : r;
 }
 
+// a b mod q for CANONICAL a, b and q = 2^b - d with b >= 53 (m.fold != 0, m.bits >= 53), lazily: two folds leave a value below 2^b + 2^52 < 2q -- the third
+// fold and the conditional subtraction of fold128 serve inputs this product cannot have.  (x < 2^2b: h1 = x >> b < 2^b, x1 = h1 d + (x mod 2^b) < 2^(b+26);
+// h2 = x1 >> b < 2^27, x2 = h2 d + (x1 mod 2^b) < 2^53 + 2^b.)  For the transforms whose first butterfly takes lazy operands (ntt_rows_wave_kernel, prologue 4).
+CRC_HD u64 mulmod_fold2_lazy(u64 a, u64 b, const ModParams &m)
+{
+    u64 lo, hi; mul64wide(a, b, lo, hi);
+    const u32 bt = m.bits; const u64 d = m.fold, mask = ((u64)1 << bt) - 1;
+    const u64 h1 = (lo >> bt) | (hi << (64 - bt));
+    u64 pl, ph; mul64wide(h1, d, pl, ph);
+    const u64 x1l = pl + (lo & mask), x1h = ph + (x1l < pl);
+    const u32 h2 = (u32)((x1l >> bt) | (x1h << (64 - bt)));
+    return (u64)h2 * m.fold + (x1l & mask);
+}
+
 // The MAC kernels' epilogue for q = 2^b - d (m.fold, 50 <= b <= 55):  a0 + (a1 - a0 - a2) 2^28 + a2 2^56  mod q  from the three lazy limb
 // accumulators a_j = A_j + o_j 2^63 (o_j < 1024 packed in ov as 3 x 10 bits), canonical.  Every accumulator is folded below 2^b + 2^50
 // first (one word multiply each), so the 2^28 / 2^56 weights never need 128-bit arithmetic: 9 word multiplies in all, about a third of
