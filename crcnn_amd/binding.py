@@ -161,6 +161,9 @@ def load():
     L.crc_gen_evk_key.argtypes = [VP, PB, PU, CI, PU]
     L.crc_encrypt_key.argtypes = [VP, PU, PU, SZ, PB, u64, PU]
     L.crc_encrypt_dev_key.argtypes = [VP, VP, VP, SZ, PB, u64, VP, VP, VP]
+    L.crc_encrypt_dev_forms.argtypes = [VP, VP, VP, SZ, u64, ctypes.c_int, VP, VP, VP]
+    L.crc_encrypt_dev_key_forms.argtypes = [VP, VP, VP, SZ, PB, u64, ctypes.c_int, VP, VP, VP]
+    L.crc_encrypt_dev_noise_thresholds.restype = None; L.crc_encrypt_dev_noise_thresholds.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     L.crc_comm_unique_id.argtypes = [PB]
     L.crc_comm_create.argtypes = [VP, CI, CI, PB, ctypes.POINTER(VP)]
     L.crc_comm_create_all.argtypes = [ctypes.POINTER(VP), CI, ctypes.POINTER(VP)]
@@ -509,6 +512,19 @@ class Engine:
 
     def encrypt_dev(self, d_pk, d_plain, count, seed, d_ct, d_work):
         _chk(self.L.crc_encrypt_dev(self.c, self.p(d_pk), self.p(d_plain), count, seed, self.p(d_ct), self.p(d_work), self.stream), "crc_encrypt_dev")
+
+    def encrypt_dev_forms(self, d_pk, d_plain, count, seed, out_form, d_ct, d_work):
+        _chk(self.L.crc_encrypt_dev_forms(self.c, self.p(d_pk), self.p(d_plain), count, seed, out_form, self.p(d_ct), self.p(d_work), self.stream),
+             "crc_encrypt_dev_forms")
+
+    def encrypt_dev_key_forms(self, d_pk, d_plain, count, key, stream_base, out_form, d_ct, d_work):
+        _chk(self.L.crc_encrypt_dev_key_forms(self.c, self.p(d_pk), self.p(d_plain), count, self._key(key), stream_base, out_form, self.p(d_ct),
+                                              self.p(d_work), self.stream), "crc_encrypt_dev_key_forms")
+
+    def encrypt_dev_noise_thresholds(self):
+        out = (ctypes.c_uint64 * 19)()
+        self.L.crc_encrypt_dev_noise_thresholds(out)
+        return [int(v) for v in out]
 
     def encrypt_dev_key(self, d_pk, d_plain, count, key, stream_base, d_ct, d_work):
         _chk(self.L.crc_encrypt_dev_key(self.c, self.p(d_pk), self.p(d_plain), count, self._key(key), stream_base, self.p(d_ct), self.p(d_work), self.stream), "crc_encrypt_dev_key")

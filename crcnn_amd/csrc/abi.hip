@@ -431,6 +431,21 @@ extern "C" int crc_encrypt_dev(crc_ctx *c, const uint64_t *d_pk, const uint64_t 
     u64 *w = (u64 *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
     return k_encrypt(c, d_pk, d_plain, count, chacha_seed_key(seed), 0, d_ct, w, S(stream));
 }
+extern "C" int crc_encrypt_dev_key_forms(crc_ctx *c, const uint64_t *d_pk, const uint64_t *d_plain, size_t count, const uint8_t *key, uint64_t stream_base,
+                                         int out_form, uint64_t *d_ct, void *d_work, void *stream)
+{
+    CHECK_CTX(c); if (!d_pk || !d_plain || !d_ct || !d_work || !key || (out_form != CRC_COEFF && out_form != CRC_NTT)) return CRC_ERR_INVALID_ARGUMENT;
+    u64 *w = (u64 *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
+    return k_encrypt(c, d_pk, d_plain, count, chacha_load_key(key), stream_base, d_ct, w, S(stream), out_form == CRC_NTT);
+}
+extern "C" int crc_encrypt_dev_forms(crc_ctx *c, const uint64_t *d_pk, const uint64_t *d_plain, size_t count, uint64_t seed, int out_form, uint64_t *d_ct,
+                                     void *d_work, void *stream)
+{
+    CHECK_CTX(c); if (!d_pk || !d_plain || !d_ct || !d_work || (out_form != CRC_COEFF && out_form != CRC_NTT)) return CRC_ERR_INVALID_ARGUMENT;
+    u64 *w = (u64 *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
+    return k_encrypt(c, d_pk, d_plain, count, chacha_seed_key(seed), 0, d_ct, w, S(stream), out_form == CRC_NTT);
+}
+extern "C" void crc_encrypt_dev_noise_thresholds(uint64_t *h_out19) { if (h_out19) k_encrypt_cdt(h_out19); }
 extern "C" int crc_square(crc_ctx *c, const uint64_t *d_x, size_t count, uint64_t *d_y3, void *d_work, void *stream)
 {
     CHECK_CTX(c); if (!d_x || !d_y3 || !d_work) return CRC_ERR_INVALID_ARGUMENT;

@@ -7,6 +7,7 @@ static inline unsigned xcd_grid(size_t groups, unsigned G) { return (unsigned)((
 
 int k_ntt_ct(crc_ctx *c, bool inv, const u64 *src, u64 *dst, size_t count, int size, bool bsk, hipStream_t st,
              const u64 *addend, int add_sign, size_t add_group, int add_mod = 0, int pack_out = 0);
+int k_ntt_ct_fwd_fma(crc_ctx *c, u64 *ct, size_t count, const u64 *u, const u64 *key, hipStream_t st);
 int k_ntt_ct_addct(crc_ctx *c, const u64 *src, u64 *dst, size_t count, const u64 *addct, int add_size, hipStream_t st);
 int k_ntt_ct_head_add(crc_ctx *c, const u64 *src, int src_size, u64 *dst, size_t count, const u64 *addrows, hipStream_t st);
 int k_spread_ntt(crc_ctx *c, const u64 *src, size_t items, u64 *dst, hipStream_t st);
@@ -49,7 +50,8 @@ int k_fold_pool(crc_ctx *c, const u64 *w, const u64 *bias, const u64 *div, u64 *
                 int pxf, int pyf, hipStream_t st);
 size_t k_encrypt_work_words(const crc_ctx *c, size_t cnt);
 struct ChaChaKey;
-int k_encrypt(crc_ctx *c, const u64 *pk, const u64 *plain, size_t cnt, const ChaChaKey &key, u64 stream_base, u64 *ct, u64 *work, hipStream_t st);
+int k_encrypt(crc_ctx *c, const u64 *pk, const u64 *plain, size_t cnt, const ChaChaKey &key, u64 stream_base, u64 *ct, u64 *work, hipStream_t st, bool out_ntt = false);
+void k_encrypt_cdt(u64 *out19);                 // the 19 thresholds of the device encryptor's noise magnitudes (tests)
 
 // kernels_mfma.hip: conv / dense multiply-accumulate as an int8 limb GEMM on the matrix cores (operand form CRC_NTTL)
 bool   k_limb_supported(const crc_ctx *c, int T);

@@ -38,6 +38,8 @@ struct NttArgs {
     int D, src_size, src_poly; unsigned long long dig_mask;
     size_t pairs;
     u64 post_mul[CRC_MAXK], post_mul_s[CRC_MAXK];
+    // forward transforms of size-2 ciphertexts that leave as  NTT(row) + fma_u[ct][i] . fma_k[p][i]  (the device encryptor: noise rows + pk . NTT(u)); null: off
+    const u64 *fma_u, *fma_k;
     // host side only, prologue 4: 1 = post_mul is OFFERED -- a kernel that closes with a multiplication anyway takes it in (and says so: 2), the others ignore it
     int opt_mul;
     unsigned char dig_i[48], dig_shift[48];
@@ -169,7 +171,7 @@ __global__ void __launch_bounds__(1024) ntt_rows_kernel(NttArgs a) { ntt_rows_bo
 // -> block-local drain through the gap-1 stage.  Inverse: block-local fill through the gap-1 stage (PRO 4: the square's products formed on the way) -> three
 // wave-local passes | barrier | the cross stages from the image to registers -> final reduction (PRO 5: the scaled result) -> 16-byte stores.  Same butterflies
 // on the same values as ntt_rows_body, hence the same results.  Prologues 0 / 4 / 5 without an addend; everything else stays with ntt_rows_kernel.
-template <bool INV, int PRO, int CS, bool UNS>
+template <bool INV, int PRO, int CS, bool UNS, bool FMA = false>
 __global__ void __launch_bounds__(CS == 2 ? 256 : CS == 3 ? 512 : 1024, 4) ntt_rows_wave_kernel(NttArgs a)
 {
     // CS = log2 n - 10 stages cross the 1024-point blocks (n = 4096 / 8192 / 16384: 2 / 3 / 4); a thread owns E = 16 >> CS neighbouring points of every block
@@ -211,12 +213,18 @@ __global__ void __launch_bounds__(CS == 2 ? 256 : CS == 3 ? 512 : 1024, 4) ntt_r
             for (int c = 0; c < C; c++) sm[swz<3>(pt(c, e))] = y[c];
         }
         __syncthreads();
+        const bool fma_lazy = m.fold != 0 && m.bits >= 53;
         u64_local_passes_fwd<true>(sm, W, n, q, q2);
 #pragma unroll 2
         for (int u = 0; u < 8; u++) {
             const int s = f64_local_pair(u);
             ulonglong2 v = sm_load_pair64(sm, s);
             fwd_pair_stage<true>(v, W1[s >> 1], q, q2);
+            if (FMA) {          // + u . key, the product lazily (two folds: below 2q) into the value the one reduction takes anyway (below 60 q + 2 q < 128 q)
+                const size_t ctm = row / (2 * (size_t)a.mod_count); const int pp = (int)((row / a.mod_count) & 1);
+                const ulonglong2 uv = ld2(a.fma_u + (ctm * a.mod_count + mloc) * (size_t)n + s), kv = ld2(a.fma_k + ((size_t)pp * a.mod_count + mloc) * n + s);
+                v.x += fma_lazy ? mulmod_fold2_lazy(uv.x, kv.x, m) : mulmod(uv.x, kv.x, m); v.y += fma_lazy ? mulmod_fold2_lazy(uv.y, kv.y, m) : mulmod(uv.y, kv.y, m);
+            }
             v.x = reduce_small(v.x, q, q2, rq); v.y = reduce_small(v.y, q, q2, rq);
             if (a.pack_out) st2(dst + s, split28v(v.x), split28v(v.y)); else st2(dst + s, v.x, v.y);
         }
@@ -551,6 +559,11 @@ static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t
 #define WAVEK(CSV, U) (a.prologue == 4 ? ntt_rows_wave_kernel<true, 4, CSV, U> : a.prologue == 5 ? ntt_rows_wave_kernel<true, 5, CSV, U> \
                        : inv ? ntt_rows_wave_kernel<true, 0, CSV, U> : ntt_rows_wave_kernel<false, 0, CSV, false>)
             auto kw = uns ? (bit == 0 ? WAVEK(3, true) : bit == 1 ? WAVEK(2, true) : WAVEK(4, true)) : (bit == 0 ? WAVEK(3, false) : bit == 1 ? WAVEK(2, false) : WAVEK(4, false));
+            if (a.fma_u) {
+                if (inv || a.prologue || a.pack_out) return CRC_ERR_INVALID_ARGUMENT;
+                kw = bit == 0 ? ntt_rows_wave_kernel<false, 0, 3, false, true> : bit == 1 ? ntt_rows_wave_kernel<false, 0, 2, false, true>
+                                                                                         : ntt_rows_wave_kernel<false, 0, 4, false, true>;
+            }
 #undef WAVEK
             { const int rc = crc_ctx_ensure_lds(c, (const void *)kw, lds); if (rc) return rc; }
             hipLaunchKernelGGL(kw, dim3((unsigned)rows), dim3(c->n / 16), lds, st, a);
@@ -559,6 +572,7 @@ static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t
         }
     }
     // n = 16384: the row as two halves through a 64-KiB image -- two workgroups per CU (ntt_rows_split_body)
+    if (a.fma_u) return CRC_ERR_UNSUPPORTED;          // (only the wave-local kernel above has that epilogue; the caller runs the product as a pass of its own)
     if (c->n == 16384 && nt == 1024 && c->tune.ntt_split != 0) {
         lds /= 2;
         auto ks = a.prologue == 4 ? (lazy ? ntt_rows_split_kernel<true, true, 4> : ntt_rows_split_kernel<true, false, 4>)
@@ -602,6 +616,16 @@ int k_ntt_ct(crc_ctx *c, bool inv, const u64 *src, u64 *dst, size_t count, int s
     a.addend = addend; a.add_sign = add_sign; a.rows_per_ct = size * a.mod_count; a.add_group = (long long)(add_group ? add_group : 1);
     a.add_mode = 1; a.add_mod = add_mod;
     return ntt_launch(c, inv, a, count * size * a.mod_count, st);
+}
+
+// forward NTT in place of size-2 ciphertexts that leave as NTT(row) + u[ct][i] . key[p][i] (u: [count][k][n], key: [2][k][n], both NTT form) -- the device
+// encryptor's last step.  CRC_ERR_UNSUPPORTED where the ring has no wave-local kernel: the caller then transforms and multiplies in two passes
+int k_ntt_ct_fwd_fma(crc_ctx *c, u64 *ct, size_t count, const u64 *u, const u64 *key, hipStream_t st)
+{
+    NttArgs a{};
+    a.src = ct; a.dst = ct; a.mod_base = 0; a.mod_count = c->k; a.rows_per_ct = 2 * c->k; a.add_group = 1; a.add_mode = 1;
+    a.fma_u = u; a.fma_k = key;
+    return ntt_launch(c, false, a, count * 2 * c->k, st);
 }
 
 // inverse NTT of size-2 ciphertexts src -> dst, adding polys 0,1 of a size-`add_size` ciphertext array (relinearize tail)

@@ -87,7 +87,7 @@ int main(int argc, char **argv)
     const int launch = head * group;                          // images per Network::forward
     // stream_inputs: after the resident measurement, `stream_steps` more passes in which every launch's images come over PCIe while the previous launch is
     // evaluated (mainparams.cpp:85-112 encrypts, evaluates and decrypts image after image).  ciphertext: 784 ciphertexts per image from page-locked host
-    // memory; plaintext: the 784 pixel plaintexts per image (n words each) and Encryptor::encrypt on the device (crc_encrypt_dev) inside the pipeline
+    // memory; plaintext: the 784 pixel plaintexts per image (n words each) and Encryptor::encrypt on the device (crc_encrypt_dev_forms) inside the pipeline
     const string stream_mode = a.count("stream_inputs") ? a["stream_inputs"] : "none";
     const int stream_steps = (int)geti("stream_steps", 1);
     try {
@@ -223,7 +223,10 @@ int main(int argc, char **argv)
                 ifstream f(need("plain_inputs"), ios::binary); if (!f) throw runtime_error("cannot open plain_inputs");
                 f.read((char *)pinned, (streamsize)((size_t)distinct * unit * 8)); if (!f) throw runtime_error("short read: plain_inputs");
             } else memcpy(pinned, h.data(), (size_t)distinct * unit * 8);
-            ciphertext3D xin[2] = {ciphertext3D(launch, 1, 28, 28), ciphertext3D(launch, 1, 28, 28)};
+            // (plaintext mode: the device encryptor leaves NTT-form ciphertexts -- crc_encrypt_dev_forms: three forward transforms per modulus, none back --
+            // and the first layer skips the transform it runs on a coefficient-form image)
+            const int xform = pt ? CRC_NTT : CRC_COEFF;
+            ciphertext3D xin[2] = {ciphertext3D(launch, 1, 28, 28, xform), ciphertext3D(launch, 1, 28, 28, xform)};
             shared_ptr<DeviceBuffer> up[2], d_pk, d_encwork;
             if (pt) {
                 for (auto &u : up) u = make_shared<DeviceBuffer>((size_t)launch * unit * 8);
@@ -246,9 +249,8 @@ int main(int argc, char **argv)
             };
             auto run = [&](int slot) {
                 if (crc_stream_wait_event(context, compute, copied[slot])) throw runtime_error("crc_stream_wait_event");
-                if (pt && crc_encrypt_dev(context, (const uint64_t *)d_pk->ptr, (const uint64_t *)up[slot]->ptr, (size_t)launch * 784, enc_seed++,
-                    xin[slot].data(),
-                                          d_encwork->ptr, compute)) throw runtime_error("crc_encrypt_dev");
+                if (pt && crc_encrypt_dev_forms(context, (const uint64_t *)d_pk->ptr, (const uint64_t *)up[slot]->ptr, (size_t)launch * 784, enc_seed++, CRC_NTT,
+                                                xin[slot].data(), d_encwork->ptr, compute)) throw runtime_error("crc_encrypt_dev_forms");
                 ciphertext3D y = net.forward(xin[slot]);
                 if (crc_event_record(context, consumed[slot], compute)) throw runtime_error("crc_event_record");
                 return y;
@@ -291,7 +293,7 @@ int main(int argc, char **argv)
                      "while the compute stream evaluates the current one (events order the two)%s\"}", streamed_json.empty() ? "" : ", ", jstr(mode).c_str(),
                          st_images / st_dt, st_dt,
                      stream_steps, st_bytes / st_dt / 1e9, (size_t)(unit * 8), pt ? "null" : same ? "true" : "false",
-                     pt ? "; the 784 pixel plaintexts per image are encrypted on the device (crc_encrypt_dev) in front of the first layer" : "");
+                     pt ? "; the 784 pixel plaintexts per image are encrypted on the device (crc_encrypt_dev_forms, NTT-form result) in front of the first layer" : "");
             streamed_json += buf;
         }
 

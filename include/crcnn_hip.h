@@ -386,12 +386,22 @@ int crc_noise_budget(const crc_ctx *ctx, const uint64_t *h_sk_ntt, const uint64_
 /* Encryptor::encrypt (encryptor.cpp:71-134) on the device, for the 784 encryptions per image that dominate the client's
  * latency in the reference: d_pk = the public key of crc_keygen copied to the device ([2][k][n], NTT form), d_plain =
  * [count][n] plaintext coefficients (< t), d_ct = [count][2][k][n] coefficient form.  Sampling (ternary u, clipped-normal
- * e1/e2) is ChaCha20 in counter mode, one stream per (ciphertext, coefficient): same laws as crc_encrypt, different bits.
+ * e1/e2) is ChaCha20 in counter mode, one stream (one block) per (ciphertext, coefficient pair): same laws as crc_encrypt, different bits.
  * d_work: crc_encrypt_dev_work_bytes(count). */
 size_t crc_encrypt_dev_work_bytes(const crc_ctx *ctx, size_t count);
 int crc_encrypt_dev_key(crc_ctx *ctx, const uint64_t *d_pk, const uint64_t *d_plain, size_t count, const uint8_t *h_key, uint64_t stream_base,
                         uint64_t *d_ct, void *d_work, void *stream);
 int crc_encrypt_dev(crc_ctx *ctx, const uint64_t *d_pk, const uint64_t *d_plain, size_t count, uint64_t seed, uint64_t *d_ct, void *d_work, void *stream);
+/* The same with the form of the result chosen: CRC_COEFF (as above) or CRC_NTT -- c_p = NTT(e_p (+ Delta m)) + pk_p . NTT(u), three forward transforms per
+ * modulus and no inverse one; the residues are those of crc_ntt_fwd applied to the coefficient-form result of the same (seed / key, stream) -- for a network
+ * whose first layer takes NTT-form inputs (every convolution here does: the transform it would run on a coefficient-form image is skipped). */
+int crc_encrypt_dev_key_forms(crc_ctx *ctx, const uint64_t *d_pk, const uint64_t *d_plain, size_t count, const uint8_t *h_key, uint64_t stream_base, int out_form,
+                              uint64_t *d_ct, void *d_work, void *stream);
+int crc_encrypt_dev_forms(crc_ctx *ctx, const uint64_t *d_pk, const uint64_t *d_plain, size_t count, uint64_t seed, int out_form, uint64_t *d_ct, void *d_work,
+                          void *stream);
+/* The device encryptor samples its noise integers e in [-19, 19] directly from their law (the reference's N(0, 3.19^2) clipped at 6 sigma and truncated,
+ * encryptor.cpp:237-240): |e| = the number of these 19 thresholds T_a = floor(2^64 P(|e| <= a)) that a uniform 64-bit word reaches.  For tests. */
+void crc_encrypt_dev_noise_thresholds(uint64_t *h_out19);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * multi-GPU (SURVEY 8e / 8b `crc_broadcast_weights`).  The reference has no analogue: its only parallelism is the

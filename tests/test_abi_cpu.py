@@ -153,3 +153,38 @@ def test_kernel_selection_policy_of_the_abi():
     assert T.plan_fold_pool(1, 28, 28, 1, 1, 5, 5, 32, 2, 2, 2, 2) is True
     assert T.plan_fold_pool(32, 12, 12, 1, 1, 5, 5, 64, 2, 2, 2, 2) is True
     assert A.plan_fold_pool(1, 28, 28, 2, 2, 5, 5, 20, 1, 1, 2, 2) is True       # CrCNN's stride-1 pool behind a one-channel convolution: narrowly
+
+
+def test_device_encryptor_noise_thresholds_are_the_reference_law():
+    """kernels_client.hip samples the encryption noise as |e| = #{a : x >= T_a} on a uniform 64-bit x.  T_a / 2^64 must be P(|e| <= a) of the reference's sampler
+    (N(0, 3.19^2), redrawn beyond 6 sigma, static_cast<int64_t>: encryptor.cpp:237-240, util/clipnormal.h) -- checked against the closed form in double
+    precision and against that algorithm run literally (numpy) on two million draws."""
+    import ctypes
+    import math
+    L = binding.load()
+    out = (ctypes.c_uint64 * 19)()
+    L.crc_encrypt_dev_noise_thresholds(out)
+    T = [int(v) for v in out]
+    assert T == sorted(T) and T[0] > 0 and T[-1] < 2 ** 64
+    sigma, lim = 3.19, 6 * 3.19
+    Phi = lambda x: 0.5 * math.erfc(-x / (sigma * math.sqrt(2)))
+    Z = Phi(lim) - Phi(-lim)
+    cum = []
+    c = 0.0
+    for a in range(19):
+        c += (Phi(1) - Phi(-1)) / Z if a == 0 else 2 * (Phi(min(a + 1, lim)) - Phi(a)) / Z
+        cum.append(c)
+        assert abs(T[a] / 2.0 ** 64 - c) < 1e-13, a
+    rng = np.random.default_rng(20260505)
+    g = rng.normal(0.0, sigma, size=2_200_000)
+    g = g[np.abs(g) <= lim][:2_000_000]                 # redrawing = conditioning
+    e = np.abs(np.trunc(g).astype(np.int64))
+    N = e.size
+    probs = [cum[0]] + [cum[a] - cum[a - 1] for a in range(1, 19)] + [1.0 - cum[18]]
+    chi, po, pe = 0.0, 0, 0.0
+    for a in range(20):
+        ex, ob = probs[a] * N, int((e == a).sum())
+        if ex >= 20: chi += (ob - ex) ** 2 / ex
+        else: po += ob; pe += ex
+    if pe > 0: chi += (po - pe) ** 2 / pe
+    assert chi < 60, chi                                 # 99.99 % quantile of chi-square with <= 19 degrees of freedom: 51

@@ -476,4 +476,62 @@ def test_device_encryptor(n, k, t):
     E.encrypt_dev(d_pk, d_pl, cnt, 78, d_ct, d_w)
     assert not np.array_equal(E.download(d_ct, (cnt, 2, k, n))[:, 1], ct[:, 1])
     assert not np.array_equal(ct[2, 1], ct[3, 1])
+    # round 5: NTT-form result (three forward transforms per modulus, no inverse one) == crc_ntt_fwd of the coefficient-form result of the same streams
+    d_cn = E.alloc(cnt * 2 * k * n * 8)
+    E.encrypt_dev_forms(d_pk, d_pl, cnt, 77, ca.NTT, d_cn, d_w)
+    d_cc = E.upload(ct); E.ntt_fwd(d_cc, cnt)
+    assert np.array_equal(E.download(d_cn, (cnt, 2, k, n)), E.download(d_cc, (cnt, 2, k, n)))
+    E.encrypt_dev_key_forms(d_pk, d_pl, cnt, key, 1000, ca.NTT, d_cn, d_w)
+    d_cc = E.upload(ck); E.ntt_fwd(d_cc, cnt)
+    assert np.array_equal(E.download(d_cn, (cnt, 2, k, n)), E.download(d_cc, (cnt, 2, k, n)))
+    E.encrypt_dev_forms(d_pk, d_pl, cnt, 77, ca.COEFF, d_cn, d_w)
+    assert np.array_equal(E.download(d_cn, (cnt, 2, k, n)), ct)
+    E.close()
+
+
+def test_device_encryptor_noise_law():
+    """The device encryptor draws its noise integers directly from their law (kernels_client.hip: thresholds on a uniform 64-bit word).  Under an all-zero public
+    key c0 = e1 + Delta m and c1 = e2 are the noise polynomials themselves: their histogram over 2 x 64 x 4096 draws against the law of the reference's
+    sampler -- N(0, 3.19^2), redrawn beyond 6 sigma, truncated toward zero (encryptor.cpp:237-240, util/clipnormal.h) -- computed here independently."""
+    import math
+    import crcnn_amd as ca
+    n, k, t = 4096, 2, 1 << 20
+    q = ca.default_coeff_modulus_128(4096)
+    E = ca.Engine(n, q, t, device=0)
+    cnt = 64
+    d_pk = E.upload(np.zeros((2, k, n), dtype=np.uint64)); d_pl = E.upload(np.zeros((cnt, n), dtype=np.uint64))
+    d_ct = E.alloc(cnt * 2 * k * n * 8); d_w = E.alloc(E.encrypt_dev_work_bytes(cnt))
+    E.encrypt_dev(d_pk, d_pl, cnt, 4242, d_ct, d_w)
+    ct = E.download(d_ct, (cnt, 2, k, n))
+    q0 = int(q[0])
+    e = ct[:, :, 0, :].astype(np.int64); e = np.where(e > q0 // 2, e - q0, e)
+    # the same integers under every modulus
+    e1 = ct[:, :, 1, :].astype(np.int64); e1 = np.where(e1 > int(q[1]) // 2, e1 - int(q[1]), e1)
+    assert np.array_equal(e, e1)
+    assert e.min() >= -19 and e.max() <= 19
+    sigma, lim = 3.19, 6 * 3.19
+    Phi = lambda x: 0.5 * math.erfc(-x / (sigma * math.sqrt(2)))
+    Z = Phi(lim) - Phi(-lim)
+    law = {}
+    for a in range(-19, 20):
+        lo, hi = (-1.0, 1.0) if a == 0 else ((a, min(a + 1, lim)) if a > 0 else (max(a - 1, -lim), a))
+        law[a] = (Phi(hi) - Phi(lo)) / Z
+    assert abs(sum(law.values()) - 1.0) < 1e-12
+    N = e.size
+    counts = {a: int((e == a).sum()) for a in range(-19, 20)}
+    # chi-square over the cells that expect at least 20 draws (the tail beyond is pooled): 99.99 % quantile of chi2 with <= 38 degrees of freedom is below 80
+    chi, pooled_obs, pooled_exp, cells = 0.0, 0, 0.0, 0
+    for a in range(-19, 20):
+        ex = law[a] * N
+        if ex >= 20: chi += (counts[a] - ex) ** 2 / ex; cells += 1
+        else: pooled_obs += counts[a]; pooled_exp += ex
+    if pooled_exp > 0: chi += (pooled_obs - pooled_exp) ** 2 / pooled_exp
+    assert chi < 80, (chi, cells, counts)
+    assert abs(float(e.mean())) < 5 * sigma / math.sqrt(N) and abs(float(e.std()) - math.sqrt(sum(a * a * p for a, p in law.items()))) < 0.02
+    # the thresholds the kernel uses are this law's cumulative probabilities
+    T = E.encrypt_dev_noise_thresholds()
+    cum = 0.0
+    for a in range(19):
+        cum += law[a] if a == 0 else 2 * law[a]
+        assert abs(T[a] / 2.0 ** 64 - cum) < 1e-13, (a, T[a] / 2.0 ** 64, cum)
     E.close()
