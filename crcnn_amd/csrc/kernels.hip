@@ -38,9 +38,11 @@ struct NttArgs {
     int D, src_size, src_poly; unsigned long long dig_mask;
     size_t pairs;
     u64 post_mul[CRC_MAXK], post_mul_s[CRC_MAXK];
-    // forward transforms of size-2 ciphertexts that leave as  NTT(row) + fma_u[ct][i] . fma_k[p][i]  (the device encryptor: noise rows + pk . NTT(u)); null: off
+    // forward transforms of size-2 ciphertexts that leave as  NTT(row) + fma_u[ct][i] . fma_k[p][i]  (the device encryptor: noise rows + pk . NTT(u)); null:
+    // off
     const u64 *fma_u, *fma_k;
-    // host side only, prologue 4: 1 = post_mul is OFFERED -- a kernel that closes with a multiplication anyway takes it in (and says so: 2), the others ignore it
+    // host side only, prologue 4: 1 = post_mul is OFFERED -- a kernel that closes with a multiplication anyway takes it in (and says so: 2), the others ignore
+    // it
     int opt_mul;
     unsigned char dig_i[48], dig_shift[48];
     const u64 *addend; int add_sign; int rows_per_ct; long long add_group;   // epilogue (inverse only)
@@ -223,7 +225,8 @@ __global__ void __launch_bounds__(CS == 2 ? 256 : CS == 3 ? 512 : 1024, 4) ntt_r
             if (FMA) {          // + u . key, the product lazily (two folds: below 2q) into the value the one reduction takes anyway (below 60 q + 2 q < 128 q)
                 const size_t ctm = row / (2 * (size_t)a.mod_count); const int pp = (int)((row / a.mod_count) & 1);
                 const ulonglong2 uv = ld2(a.fma_u + (ctm * a.mod_count + mloc) * (size_t)n + s), kv = ld2(a.fma_k + ((size_t)pp * a.mod_count + mloc) * n + s);
-                v.x += fma_lazy ? mulmod_fold2_lazy(uv.x, kv.x, m) : mulmod(uv.x, kv.x, m); v.y += fma_lazy ? mulmod_fold2_lazy(uv.y, kv.y, m) : mulmod(uv.y, kv.y, m);
+                v.x += fma_lazy ? mulmod_fold2_lazy(uv.x, kv.x, m) : mulmod(uv.x, kv.x, m); v.y += fma_lazy ? mulmod_fold2_lazy(uv.y, kv.y, m) : mulmod(uv.y,
+                    kv.y, m);
             }
             v.x = reduce_small(v.x, q, q2, rq); v.y = reduce_small(v.y, q, q2, rq);
             if (a.pack_out) st2(dst + s, split28v(v.x), split28v(v.y)); else st2(dst + s, v.x, v.y);
@@ -239,7 +242,8 @@ __global__ void __launch_bounds__(CS == 2 ? 256 : CS == 3 ? 512 : 1024, 4) ntt_r
                 const int s = f64_local_pair(u);
                 const ulonglong2 av = ld2(pa + s), bv = ld2(pb + s);
                 ulonglong2 v;
-                if (UNS && lazy_prod) {          // below 2q each, 4q doubled: the unscaled butterflies take that (inv_stages_unscaled: sums below 8q, v0 of pass 1 below 64q)
+                // below 2q each, 4q doubled: the unscaled butterflies take that (inv_stages_unscaled: sums below 8q, v0 of pass 1 below 64q)
+                if (UNS && lazy_prod) {
                     v = ulonglong2{mulmod_fold2_lazy(av.x, bv.x, m), mulmod_fold2_lazy(av.y, bv.y, m)};
                     if (p == 1) { v.x += v.x; v.y += v.y; }
                 } else {
@@ -536,8 +540,9 @@ static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t
     if ((a.prologue == 3 && inv) || ((a.prologue == 4 || a.prologue == 5) && !inv)) return CRC_ERR_INVALID_ARGUMENT;
     if (a.prologue == 4) rows = xcd_grid(a.pairs, 3);                  // (the three products of a pair on one XCD: ntt_rows_body)
     // wave-local passes (ntt_rows_wave_kernel): CRC_NTT_WAVE bit 0 n = 8192, bit 1 n = 4096, bit 2 n = 16384 (plain transforms), bit 3 n = 16384 with the
-    // Square prologues (slower than the split kernel with the halving butterflies, 11.9 against 11.7 us per squared ciphertext, faster with the ones that do not
-    // halve: 11.27 against 11.6 -- profiles/r05_ntt_u64_wave_local_ab.txt, r05_ntt_inverse_unscaled_ab.txt), bit 4: keep the halving butterflies; -1: bits 0 to 3
+    // Square prologues (slower than the split kernel with the halving butterflies, 11.9 against 11.7 us per squared ciphertext, faster with the ones that do
+    // not halve: 11.27 against 11.6 -- profiles/r05_ntt_u64_wave_local_ab.txt, r05_ntt_inverse_unscaled_ab.txt), bit 4: keep the halving butterflies; -1: bits
+    // 0 to 3
     {
         const int sel = c->tune.ntt_wave < 0 ? 15 : c->tune.ntt_wave;
         const int bit = c->n == 8192 ? 0 : c->n == 4096 ? 1 : c->n == 16384 ? (a.prologue ? 3 : 2) : -1;
@@ -558,7 +563,8 @@ static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t
             }
 #define WAVEK(CSV, U) (a.prologue == 4 ? ntt_rows_wave_kernel<true, 4, CSV, U> : a.prologue == 5 ? ntt_rows_wave_kernel<true, 5, CSV, U> \
                        : inv ? ntt_rows_wave_kernel<true, 0, CSV, U> : ntt_rows_wave_kernel<false, 0, CSV, false>)
-            auto kw = uns ? (bit == 0 ? WAVEK(3, true) : bit == 1 ? WAVEK(2, true) : WAVEK(4, true)) : (bit == 0 ? WAVEK(3, false) : bit == 1 ? WAVEK(2, false) : WAVEK(4, false));
+            auto kw = uns ? (bit == 0 ? WAVEK(3, true) : bit == 1 ? WAVEK(2, true) : WAVEK(4, true)) : (bit == 0 ? WAVEK(3, false) : bit == 1 ? WAVEK(2,
+                false) : WAVEK(4, false));
             if (a.fma_u) {
                 if (inv || a.prologue || a.pack_out) return CRC_ERR_INVALID_ARGUMENT;
                 kw = bit == 0 ? ntt_rows_wave_kernel<false, 0, 3, false, true> : bit == 1 ? ntt_rows_wave_kernel<false, 0, 2, false, true>

@@ -37,9 +37,9 @@ __device__ __forceinline__ u32 ternary_field(u32 lo, u32 hi)
     return v;
 }
 
-// U: [count][k][n] ternary polynomial in RNS form (coefficient domain).  ROWS = false: E [count][2][n] signed noise bytes (the coefficient-form pipeline adds them
-// after its inverse transforms); ROWS = true: the rows e1 + Delta m (+ q mod t on the upper half, evaluator.cpp:1168-1191) and e2 of every ciphertext, as residues
-// in ct [count][2][k][n] -- what the NTT-form pipeline transforms next
+// U: [count][k][n] ternary polynomial in RNS form (coefficient domain).  ROWS = false: E [count][2][n] signed noise bytes (the coefficient-form pipeline adds
+// them after its inverse transforms); ROWS = true: the rows e1 + Delta m (+ q mod t on the upper half, evaluator.cpp:1168-1191) and e2 of every ciphertext, as
+// residues in ct [count][2][k][n] -- what the NTT-form pipeline transforms next
 template <bool ROWS>
 __global__ void __launch_bounds__(256) enc_sample_kernel(u64 *U, signed char *E, u64 *ct, const u64 *plain, const ModParams *mods, int n, int k, ChaChaKey key,
                                                          u64 stream_base, EncCdt cdt, PlainParams pp)
@@ -62,7 +62,8 @@ __global__ void __launch_bounds__(256) enc_sample_kernel(u64 *U, signed char *E,
     }
     for (int i = 0; i < k; i++) {
         const u64 qm1 = mods[i].q - 1;
-        *reinterpret_cast<ulonglong2 *>(U + (m * k + i) * (size_t)n + s) = ulonglong2{tv[0] == 0 ? 0 : (tv[0] == 1 ? 1 : qm1), tv[1] == 0 ? 0 : (tv[1] == 1 ? 1 : qm1)};
+        *reinterpret_cast<ulonglong2 *>(U + (m * k + i) * (size_t)n + s) = ulonglong2{tv[0] == 0 ? 0 : (tv[0] == 1 ? 1 : qm1), tv[1] == 0 ? 0 : (tv[1] == 1 ?
+            1 : qm1)};
     }
     if (!ROWS) {
 #pragma unroll
@@ -174,8 +175,10 @@ int k_encrypt(crc_ctx *c, const u64 *pk, const u64 *plain, size_t cnt, const Cha
     if (cnt * (size_t)pblocks > 0x7fffffffULL || cnt * 2 * (size_t)k > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
     int rc;
     if (out_ntt) {
-        // c_p = NTT(e_p (+ Delta m)) + pk_p . NTT(u): three forward transforms per modulus and no inverse one -- the same residues as transforming the coefficient form
-        hipLaunchKernelGGL(enc_sample_kernel<true>, dim3((unsigned)(cnt * pblocks)), dim3(threads), 0, st, U, E, ct, plain, c->d_mods, n, k, key, stream_base, enc_cdt(),
+        // c_p = NTT(e_p (+ Delta m)) + pk_p . NTT(u): three forward transforms per modulus and no inverse one -- the same residues as transforming the
+        // coefficient form
+        hipLaunchKernelGGL(enc_sample_kernel<true>, dim3((unsigned)(cnt * pblocks)), dim3(threads), 0, st, U, E, ct, plain, c->d_mods, n, k, key, stream_base,
+            enc_cdt(),
                            c->plain);
         HIPCHK(hipGetLastError());
         if ((rc = k_ntt_ct(c, false, U, U, cnt, 1, false, st, nullptr, 0, 0, 0))) return rc;
@@ -187,7 +190,8 @@ int k_encrypt(crc_ctx *c, const u64 *pk, const u64 *plain, size_t cnt, const Cha
         HIPCHK(hipGetLastError());
         return CRC_OK;
     }
-    hipLaunchKernelGGL(enc_sample_kernel<false>, dim3((unsigned)(cnt * pblocks)), dim3(threads), 0, st, U, E, ct, plain, c->d_mods, n, k, key, stream_base, enc_cdt(),
+    hipLaunchKernelGGL(enc_sample_kernel<false>, dim3((unsigned)(cnt * pblocks)), dim3(threads), 0, st, U, E, ct, plain, c->d_mods, n, k, key, stream_base,
+        enc_cdt(),
                        c->plain);
     HIPCHK(hipGetLastError());
     if ((rc = k_ntt_ct(c, false, U, U, cnt, 1, false, st, nullptr, 0, 0, 0))) return rc;

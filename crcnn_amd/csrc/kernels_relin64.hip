@@ -391,8 +391,7 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_inv_crt_kernel(
 // K3 with ONE workgroup barrier per transform (round 5; ntt_f64.h, wave-local passes): n = 8192 (CS = 3) or 16384 (CS = 4), n / 16 threads.  Both inverse
 // transforms end in the cross pass, i.e. in registers: the first prime's result simply stays there (no LDS read, no parking), the second meets it for the CRT
 // lift, the (c0, c1) rows are read in the same cross layout, and the canonical sums go into the image for the forward transform over q_j (or straight to
-// memory).
-// U64W: the forward transform over q_j that follows the CRT runs wave-locally too -- its cross pass works on the CRT's results where they are made, in
+// memory). U64W: the forward transform over q_j that follows the CRT runs wave-locally too -- its cross pass works on the CRT's results where they are made, in
 // registers
 template <int CS, bool OUT_NTT, bool LAZY, bool U64W>
 __global__ void __launch_bounds__(CS == 3 ? 512 : 1024, 4) relin_inv_crt_wave_kernel(const double *A, const u64 *x3, int add_size, u64 *y,
@@ -443,54 +442,6 @@ __global__ void __launch_bounds__(CS == 3 ? 512 : 1024, 4) relin_inv_crt_wave_ke
     const int nw = pg.xf > 0 ? pg.xf * pg.yf : 1;
     u64 *sm = reinterpret_cast<u64 *>(smd);
     if (OUT_NTT) __syncthreads();                             // every wave has read its part of the image in the cross pass: the canonical sums go into it now
-    if constexpr (OUT_NTT && U64W) {
-        const ulonglong2 *W = Wq + (size_t)j * n;
-        auto point_sum = [&](int s) {                         // (c0 | c1)(s) summed over the pooling window
-            u64 av = add[s];
-            for (int w = 1; w < nw; w++) { const int kx = w / pg.yf, ky = w - kx * pg.yf; av = addmod(av, add[((size_t)kx * pg.yd + ky) * add_size * k * n +
-                s], q); }
-            return av;
-        };
-        if constexpr (CS == 3) {
-#pragma unroll
-            for (int e = 0; e < 2; e++) {
-                u64 x[8];
-#pragma unroll
-                for (int c = 0; c < 8; c++) x[c] = lift(a0[2 * c + e], a1[2 * c + e], point_sum(f64_cross_point<3>(2 * c + e)));
-                fwd_stages<3, LAZY>(x, W, 1, 0, q, mq.two_q);
-#pragma unroll
-                for (int c = 0; c < 8; c++) sm[swz<3>(f64_cross_point<3>(2 * c + e))] = x[c];
-            }
-        } else {
-            u64 x[16];
-#pragma unroll
-            for (int c = 0; c < 16; c++) x[c] = lift(a0[c], a1[c], point_sum(f64_cross_point<4>(c)));
-            fwd_stages<4, LAZY>(x, W, 1, 0, q, mq.two_q);
-#pragma unroll
-            for (int c = 0; c < 16; c++) sm[swz<3>(f64_cross_point<4>(c))] = x[c];
-        }
-        __syncthreads();
-        u64_local_passes_fwd<LAZY>(sm, W, n, q, mq.two_q);
-        const float rq = 1.0f / (float)((u32)(q >> 32) + 1);
-#pragma unroll 2
-        for (int u = 0; u < 8; u++) {                         // block-local drain through the gap-1 stage
-            const int s = f64_local_pair(u), a = swz<3>(s);
-            ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(sm + (a & ~1));
-            if (a & 1) { const u64 t = v.x; v.x = v.y; v.y = t; }
-            fwd_pair_stage<LAZY>(v, W[(n >> 1) + (s >> 1)], q, mq.two_q);
-            if (LAZY) { v.x = reduce_small(v.x, q, mq.two_q, rq); v.y = reduce_small(v.y, q, mq.two_q, rq); }
-            else {
-                v.x = v.x >= mq.two_q ? v.x - mq.two_q : v.x; v.x = v.x >= q ? v.x - q : v.x;
-                v.y = v.y >= mq.two_q ? v.y - mq.two_q : v.y; v.y = v.y >= q ? v.y - q : v.y;
-            }
-            if (mul) {
-                const ulonglong2 wv = *reinterpret_cast<const ulonglong2 *>(mul + (size_t)j * n + s);
-                v.x = mulmod(v.x, wv.x, mq); v.y = mulmod(v.y, wv.y, mq);
-            }
-            *reinterpret_cast<ulonglong2 *>(dst + s) = v;
-        }
-        return;
-    }
     if constexpr (CS == 3) {
 #pragma unroll
         for (int c = 0; c < 8; c++) {
@@ -519,10 +470,52 @@ __global__ void __launch_bounds__(CS == 3 ? 512 : 1024, 4) relin_inv_crt_wave_ke
         }
     }
     if (!OUT_NTT) return;
+    const float rq = 1.0f / (float)((u32)(q >> 32) + 1);
+    if constexpr (U64W) {
+        // the forward transform wave-locally too.  The points a thread has just written are the cross groups it owns (two of eight at n = 8192, one of sixteen
+        // at 16384): the cross stages read them back in program order -- no barrier --, one barrier later every wave finishes its own block.  (Round 5, first
+        // form: the cross stages on the lifts' results in registers -- with both held transforms still alive that spilled 190-400 bytes per lane and lost 4 %.)
+        const ulonglong2 *W = Wq + (size_t)j * n;
+        constexpr int E = 16 >> CS, C = 1 << CS;
+        // (nothing of the transform is scheduled into the lifts above: they fill the register file as it is)
+        __builtin_amdgcn_sched_barrier(0);
+        int t2 = tid;
+        // (... nor are the sixteen image addresses of the lifts kept alive for it: they are computed again)
+        asm volatile("" : "+v"(t2));
+        auto own = [&](int c, int e) { return swz<3>(CS == 3 ? 2 * t2 + e + CRC_F64_BLOCK * c : t2 + CRC_F64_BLOCK * c); };
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            u64 x[C];
+#pragma unroll
+            for (int c = 0; c < C; c++) x[c] = sm[own(c, e)];
+            fwd_stages<CS, LAZY>(x, W, 1, 0, q, mq.two_q);
+#pragma unroll
+            for (int c = 0; c < C; c++) sm[own(c, e)] = x[c];
+        }
+        __syncthreads();
+        u64_local_passes_fwd<LAZY>(sm, W, n, q, mq.two_q);
+#pragma unroll 2
+        for (int u = 0; u < 8; u++) {                         // block-local drain through the gap-1 stage
+            const int s = f64_local_pair(u), a = swz<3>(s);
+            ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(sm + (a & ~1));
+            if (a & 1) { const u64 t = v.x; v.x = v.y; v.y = t; }
+            fwd_pair_stage<LAZY>(v, W[(n >> 1) + (s >> 1)], q, mq.two_q);
+            if (LAZY) { v.x = reduce_small(v.x, q, mq.two_q, rq); v.y = reduce_small(v.y, q, mq.two_q, rq); }
+            else {
+                v.x = v.x >= mq.two_q ? v.x - mq.two_q : v.x; v.x = v.x >= q ? v.x - q : v.x;
+                v.y = v.y >= mq.two_q ? v.y - mq.two_q : v.y; v.y = v.y >= q ? v.y - q : v.y;
+            }
+            if (mul) {
+                const ulonglong2 wv = *reinterpret_cast<const ulonglong2 *>(mul + (size_t)j * n + s);
+                v.x = mulmod(v.x, wv.x, mq); v.y = mulmod(v.y, wv.y, mq);
+            }
+            *reinterpret_cast<ulonglong2 *>(dst + s) = v;
+        }
+        return;
+    }
     // NTT-resident result: forward transform over q_j of (c_poly + R) in the same LDS image (as relin_inv_crt_kernel)
     __syncthreads();
     ntt_row_passes<false, LAZY, 3, true>(sm, Wq + (size_t)j * n, n, logn, q, mq.two_q);
-    const float rq = 1.0f / (float)((u32)(q >> 32) + 1);
     const bool fuse1 = ntt_fused_stage(logn);
     for (int s = 2 * tid; s < n; s += 2 * nt) {
         const int a = swz<3>(s);

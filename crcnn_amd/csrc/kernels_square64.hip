@@ -321,8 +321,9 @@ __global__ void __launch_bounds__(256) sq64_floor_kernel(const u64 *dq, const do
     const u64 am = (u64)(neg ? -alpha : alpha);                      // (up to |R| / B + KB: 37 bits at n = 256, t = 2^41 with two 40-bit moduli)
     const u32 am0 = (u32)am & 0xfffffffu, am1 = (u32)(am >> 28);
     // sum_j z_j (B/p_j) - alpha B mod q_i (:553-569), lazily: z_j (47 bits) and the constants (up to 60) in 28-bit pieces, so that every partial product is ONE
-    // v_mad_u64_u32 into one of three 64-bit sums that cannot overflow (z0 y0 < 2^56, z0 y1 + z1 y0 < 2^60 + 2^47, z1 y1 < 2^51; at most 12 terms, |alpha| among them) -- 4
-    // instructions per term instead of the 14 of a 64 x 64 -> 128 product and its carry chain; the sums meet in 128 bits once, before the one reduction
+    // v_mad_u64_u32 into one of three 64-bit sums that cannot overflow (z0 y0 < 2^56, z0 y1 + z1 y0 < 2^60 + 2^47, z1 y1 < 2^51; at most 12 terms, |alpha|
+    // among them) -- 4 instructions per term instead of the 14 of a 64 x 64 -> 128 product and its carry chain; the sums meet in 128 bits once, before the one
+    // reduction
     u32 z0[KB], z1[KB];
 #pragma unroll
     for (int j = 0; j < KB; j++) { z1[j] = (u32)(z[j] * 0x1p-28); z0[j] = (u32)(z[j] - (double)z1[j] * 0x1p28); }

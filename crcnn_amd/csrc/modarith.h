@@ -91,8 +91,8 @@ CRC_HD u64 fold128(u64 lo, u64 hi, const ModParams &m)
 }
 
 // a b mod q for CANONICAL a, b and q = 2^b - d with b >= 53 (m.fold != 0, m.bits >= 53), lazily: two folds leave a value below 2^b + 2^52 < 2q -- the third
-// fold and the conditional subtraction of fold128 serve inputs this product cannot have.  (x < 2^2b: h1 = x >> b < 2^b, x1 = h1 d + (x mod 2^b) < 2^(b+26);
-// h2 = x1 >> b < 2^27, x2 = h2 d + (x1 mod 2^b) < 2^53 + 2^b.)  For the transforms whose first butterfly takes lazy operands (ntt_rows_wave_kernel, prologue 4).
+// fold and the conditional subtraction of fold128 serve inputs this product cannot have.  (x < 2^2b: h1 = x >> b < 2^b, x1 = h1 d + (x mod 2^b) < 2^(b+26); h2
+// = x1 >> b < 2^27, x2 = h2 d + (x1 mod 2^b) < 2^53 + 2^b.)  For the transforms whose first butterfly takes lazy operands (ntt_rows_wave_kernel, prologue 4).
 CRC_HD u64 mulmod_fold2_lazy(u64 a, u64 b, const ModParams &m)
 {
     u64 lo, hi; mul64wide(a, b, lo, hi);

@@ -5,8 +5,8 @@
 #include <hip/hip_runtime.h>
 
 // Workgroups that read the same rows -- the kf transforms that lift one polynomial, the three products of one (ciphertext, modulus) pair -- should share an L2.
-// Blocks b and b + 8 run on the same XCD (dispatch deals blocks round-robin over the eight XCDs: observed, not promised, and only speed depends on it), so the G
-// members of a group take consecutive slots of ONE XCD: the rows come from memory once and from that XCD's L2 afterwards.  Launch xcd_grid(groups, G) blocks
+// Blocks b and b + 8 run on the same XCD (dispatch deals blocks round-robin over the eight XCDs: observed, not promised, and only speed depends on it), so the
+// G members of a group take consecutive slots of ONE XCD: the rows come from memory once and from that XCD's L2 afterwards.  Launch xcd_grid(groups, G) blocks
 // (kernels.h); blocks past the last group return at once.
 __device__ __forceinline__ bool xcd_group(unsigned b, unsigned G, size_t groups, size_t &grp, unsigned &member)
 {
@@ -19,11 +19,11 @@ __device__ __forceinline__ bool xcd_group(unsigned b, unsigned G, size_t groups,
 // register-tile pattern of the radix-8 passes at n = 4096 (at most 2-way in the short tail pass of n = 8192 / 16384); found by
 // enumerating the access patterns (bank = index mod 32 per 32-lane group)
 __device__ __forceinline__ int lpad(int i) { return i ^ ((i >> 3) & 7) ^ (((i >> 6) & 3) << 3); }
-// the same idea for passes of 16 / 32 values per thread (the fp64 transforms of kernels_relin64.hip): XOR of higher index bits into the low four = the sixteen 8-byte
-// slots of a 128-byte LDS row; found by enumerating every pass's access pattern in groups of 16 lanes (forward and inverse, n = 4096 / 8192 / 16384): conflict-free for
-// their own radix, at most 2-way in one pass of the radix-8 transforms below when those run on an image laid out this way
-// (s, s + 1), s even, share one aligned 16-byte slot of the image (the swizzle only XORs higher index bits into bit 0), in either order: rows move between memory and
-// the image two points per lane -- one 16-byte global access and one ds_*_b128
+// the same idea for passes of 16 / 32 values per thread (the fp64 transforms of kernels_relin64.hip): XOR of higher index bits into the low four = the sixteen
+// 8-byte slots of a 128-byte LDS row; found by enumerating every pass's access pattern in groups of 16 lanes (forward and inverse, n = 4096 / 8192 / 16384):
+// conflict-free for their own radix, at most 2-way in one pass of the radix-8 transforms below when those run on an image laid out this way (s, s + 1), s even,
+// share one aligned 16-byte slot of the image (the swizzle only XORs higher index bits into bit 0), in either order: rows move between memory and the image two
+// points per lane -- one 16-byte global access and one ds_*_b128
 __device__ __forceinline__ void sm_store_pair64(u64 *sm, int s, u64 x, u64 y)
 {
     const int a = lpad(s);
@@ -120,8 +120,9 @@ __device__ __forceinline__ void inv_stages(u64 (&v)[1 << R], const ulonglong2 *W
 
 // Inverse stages that do NOT halve (round 5; moduli below 2^55, tables of the plain inverse powers): the sum side of a Gentleman-Sande butterfly is U + V and
 // nothing else, the factor n^-1 is one constant in the multiplication every result ends in anyway.  The sums double per stage instead: with inputs below B q a
-// group of 2^R values leaves one value (index 0, the sum of all) below 2^R B q, R more below 2^(R-1) ... 16 q, the rest below 4 q; the caller reduces index 0 when
-// another pass follows.  kq >= the bound of any difference operand V (2^(R-1) B q); everything stays below 2^9 q < 2^64.  Six instructions fewer per butterfly.
+// group of 2^R values leaves one value (index 0, the sum of all) below 2^R B q, R more below 2^(R-1) ... 16 q, the rest below 4 q; the caller reduces index 0
+// when another pass follows.  kq >= the bound of any difference operand V (2^(R-1) B q); everything stays below 2^9 q < 2^64.  Six instructions fewer per
+// butterfly.
 template <int R>
 __device__ __forceinline__ void inv_stages_unscaled(u64 (&v)[1 << R], const ulonglong2 *W, int h, int blk, u64 q, u64 kq)
 {
@@ -145,10 +146,11 @@ __device__ __forceinline__ void inv_pair_stage_unscaled(ulonglong2 &v, const ulo
     v.x = U + V; v.y = shoup_lazy4(kq - V + U, tw.x, tw.y, q);
 }
 
-// The stage with gap 1 -- the last of a forward transform, the first of an inverse one -- pairs the two points (s, s + 1), s even, that share one 16-byte slot of
-// the image, i.e. what one lane moves between memory and the image.  When log2 n = 3 m + 1 (n = 8192, and the halves of n = 16384) that stage would be an LDS pass
-// of its own with one butterfly per thread; instead the loops that fill / drain the image apply it in registers (ntt_fused_stage: four passes and barriers per row
-// instead of five).  Same butterflies in the same order on the same values, hence the same results.  Twiddle of the pair: table index n/2 + s/2 (both directions).
+// The stage with gap 1 -- the last of a forward transform, the first of an inverse one -- pairs the two points (s, s + 1), s even, that share one 16-byte slot
+// of the image, i.e. what one lane moves between memory and the image.  When log2 n = 3 m + 1 (n = 8192, and the halves of n = 16384) that stage would be an
+// LDS pass of its own with one butterfly per thread; instead the loops that fill / drain the image apply it in registers (ntt_fused_stage: four passes and
+// barriers per row instead of five).  Same butterflies in the same order on the same values, hence the same results.  Twiddle of the pair: table index n/2 +
+// s/2 (both directions).
 __device__ __forceinline__ bool ntt_fused_stage(int logn) { return logn > 3 && logn % 3 == 1; }
 template <bool LAZY>
 __device__ __forceinline__ void fwd_pair_stage(ulonglong2 &v, const ulonglong2 tw, u64 q, u64 q2)

@@ -249,7 +249,8 @@ int main(int argc, char **argv)
             };
             auto run = [&](int slot) {
                 if (crc_stream_wait_event(context, compute, copied[slot])) throw runtime_error("crc_stream_wait_event");
-                if (pt && crc_encrypt_dev_forms(context, (const uint64_t *)d_pk->ptr, (const uint64_t *)up[slot]->ptr, (size_t)launch * 784, enc_seed++, CRC_NTT,
+                if (pt && crc_encrypt_dev_forms(context, (const uint64_t *)d_pk->ptr, (const uint64_t *)up[slot]->ptr, (size_t)launch * 784, enc_seed++,
+                    CRC_NTT,
                                                 xin[slot].data(), d_encwork->ptr, compute)) throw runtime_error("crc_encrypt_dev_forms");
                 ciphertext3D y = net.forward(xin[slot]);
                 if (crc_event_record(context, consumed[slot], compute)) throw runtime_error("crc_event_record");
@@ -293,7 +294,8 @@ int main(int argc, char **argv)
                      "while the compute stream evaluates the current one (events order the two)%s\"}", streamed_json.empty() ? "" : ", ", jstr(mode).c_str(),
                          st_images / st_dt, st_dt,
                      stream_steps, st_bytes / st_dt / 1e9, (size_t)(unit * 8), pt ? "null" : same ? "true" : "false",
-                     pt ? "; the 784 pixel plaintexts per image are encrypted on the device (crc_encrypt_dev_forms, NTT-form result) in front of the first layer" : "");
+                     pt ? "; the 784 pixel plaintexts per image are encrypted on the device (crc_encrypt_dev_forms, NTT-form result) in front of the first "
+                         "layer" : "");
             streamed_json += buf;
         }
 
