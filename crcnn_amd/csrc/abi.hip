@@ -68,8 +68,12 @@ extern "C" int crc_multiply_plain_ntt(crc_ctx *c, uint64_t *d_ct, const uint64_t
 extern "C" int crc_multiply_plain(crc_ctx *c, uint64_t *d_ct, const uint64_t *d_w, size_t count, size_t group, void *stream)
 {
     CHECK_CTX(c); if (!d_ct || !d_w) return CRC_ERR_INVALID_ARGUMENT;
-    RUN(k_ntt_ct(c, false, d_ct, d_ct, count, 2, false, S(stream), nullptr, 0, 0));
-    RUN(k_rowwise(c, d_ct, d_w, count, 2, 2, 1, group, 0, S(stream)));
+    // (the dyadic product in the last loop of the forward transform where the ring has the wave-local kernel, else as a pass of its own)
+    const int rc = k_ntt_ct_fwd_mul(c, d_ct, count, d_w, group, S(stream));
+    if (rc == CRC_ERR_UNSUPPORTED) {
+        RUN(k_ntt_ct(c, false, d_ct, d_ct, count, 2, false, S(stream), nullptr, 0, 0));
+        RUN(k_rowwise(c, d_ct, d_w, count, 2, 2, 1, group, 0, S(stream)));
+    } else if (rc) return rc;
     return k_ntt_ct(c, true, d_ct, d_ct, count, 2, false, S(stream), nullptr, 0, 0);
 }
 

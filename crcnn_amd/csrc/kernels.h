@@ -7,6 +7,7 @@ static inline unsigned xcd_grid(size_t groups, unsigned G) { return (unsigned)((
 
 int k_ntt_ct(crc_ctx *c, bool inv, const u64 *src, u64 *dst, size_t count, int size, bool bsk, hipStream_t st,
              const u64 *addend, int add_sign, size_t add_group, int add_mod = 0, int pack_out = 0);
+int k_ntt_ct_fwd_mul(crc_ctx *c, u64 *ct, size_t count, const u64 *w, size_t group, hipStream_t st);
 int k_ntt_ct_fwd_fma(crc_ctx *c, u64 *ct, size_t count, const u64 *u, const u64 *key, hipStream_t st);
 int k_ntt_ct_addct(crc_ctx *c, const u64 *src, u64 *dst, size_t count, const u64 *addct, int add_size, hipStream_t st);
 int k_ntt_ct_head_add(crc_ctx *c, const u64 *src, int src_size, u64 *dst, size_t count, const u64 *addrows, hipStream_t st);

@@ -41,6 +41,7 @@ struct NttArgs {
     // forward transforms of size-2 ciphertexts that leave as  NTT(row) + fma_u[ct][i] . fma_k[p][i]  (the device encryptor: noise rows + pk . NTT(u)); null:
     // off
     const u64 *fma_u, *fma_k;
+    unsigned long long fma_group;                              // fma_u null, fma_k set: the rows leave multiplied by the plaintext row fma_k[ct / fma_group][i]
     // host side only, prologue 4: 1 = post_mul is OFFERED -- a kernel that closes with a multiplication anyway takes it in (and says so: 2), the others ignore
     // it
     int opt_mul;
@@ -173,7 +174,7 @@ __global__ void __launch_bounds__(1024) ntt_rows_kernel(NttArgs a) { ntt_rows_bo
 // -> block-local drain through the gap-1 stage.  Inverse: block-local fill through the gap-1 stage (PRO 4: the square's products formed on the way) -> three
 // wave-local passes | barrier | the cross stages from the image to registers -> final reduction (PRO 5: the scaled result) -> 16-byte stores.  Same butterflies
 // on the same values as ntt_rows_body, hence the same results.  Prologues 0 / 4 / 5 without an addend; everything else stays with ntt_rows_kernel.
-template <bool INV, int PRO, int CS, bool UNS, bool FMA = false>
+template <bool INV, int PRO, int CS, bool UNS, int FMA = 0>
 __global__ void __launch_bounds__(CS == 2 ? 256 : CS == 3 ? 512 : 1024, 4) ntt_rows_wave_kernel(NttArgs a)
 {
     // CS = log2 n - 10 stages cross the 1024-point blocks (n = 4096 / 8192 / 16384: 2 / 3 / 4); a thread owns E = 16 >> CS neighbouring points of every block
@@ -222,7 +223,14 @@ __global__ void __launch_bounds__(CS == 2 ? 256 : CS == 3 ? 512 : 1024, 4) ntt_r
             const int s = f64_local_pair(u);
             ulonglong2 v = sm_load_pair64(sm, s);
             fwd_pair_stage<true>(v, W1[s >> 1], q, q2);
-            if (FMA) {          // + u . key, the product lazily (two folds: below 2q) into the value the one reduction takes anyway (below 60 q + 2 q < 128 q)
+            if (FMA == 2) {     // . plaintext row (crc_multiply_plain: the dyadic product in the transform's last loop instead of a pass of its own)
+                const size_t ctm = row / (2 * (size_t)a.mod_count);
+                const ulonglong2 kv = ld2(a.fma_k + ((ctm / a.fma_group) * a.mod_count + mloc) * (size_t)n + s);
+                v.x = mulmod(reduce_small(v.x, q, q2, rq), kv.x, m); v.y = mulmod(reduce_small(v.y, q, q2, rq), kv.y, m);
+                st2(dst + s, v.x, v.y);
+                continue;
+            }
+            if (FMA == 1) {     // + u . key, the product lazily (two folds: below 2q) into the value the one reduction takes anyway (below 60 q + 2 q < 128 q)
                 const size_t ctm = row / (2 * (size_t)a.mod_count); const int pp = (int)((row / a.mod_count) & 1);
                 const ulonglong2 uv = ld2(a.fma_u + (ctm * a.mod_count + mloc) * (size_t)n + s), kv = ld2(a.fma_k + ((size_t)pp * a.mod_count + mloc) * n + s);
                 v.x += fma_lazy ? mulmod_fold2_lazy(uv.x, kv.x, m) : mulmod(uv.x, kv.x, m); v.y += fma_lazy ? mulmod_fold2_lazy(uv.y, kv.y, m) : mulmod(uv.y,
@@ -565,10 +573,12 @@ static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t
                        : inv ? ntt_rows_wave_kernel<true, 0, CSV, U> : ntt_rows_wave_kernel<false, 0, CSV, false>)
             auto kw = uns ? (bit == 0 ? WAVEK(3, true) : bit == 1 ? WAVEK(2, true) : WAVEK(4, true)) : (bit == 0 ? WAVEK(3, false) : bit == 1 ? WAVEK(2,
                 false) : WAVEK(4, false));
-            if (a.fma_u) {
+            if (a.fma_u || a.fma_k) {
                 if (inv || a.prologue || a.pack_out) return CRC_ERR_INVALID_ARGUMENT;
-                kw = bit == 0 ? ntt_rows_wave_kernel<false, 0, 3, false, true> : bit == 1 ? ntt_rows_wave_kernel<false, 0, 2, false, true>
-                                                                                         : ntt_rows_wave_kernel<false, 0, 4, false, true>;
+                if (a.fma_u) kw = bit == 0 ? ntt_rows_wave_kernel<false, 0, 3, false, 1> : bit == 1 ? ntt_rows_wave_kernel<false, 0, 2, false, 1>
+                                                                                                    : ntt_rows_wave_kernel<false, 0, 4, false, 1>;
+                else kw = bit == 0 ? ntt_rows_wave_kernel<false, 0, 3, false, 2> : bit == 1 ? ntt_rows_wave_kernel<false, 0, 2, false, 2>
+                                                                                            : ntt_rows_wave_kernel<false, 0, 4, false, 2>;
             }
 #undef WAVEK
             { const int rc = crc_ctx_ensure_lds(c, (const void *)kw, lds); if (rc) return rc; }
@@ -578,7 +588,7 @@ static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t
         }
     }
     // n = 16384: the row as two halves through a 64-KiB image -- two workgroups per CU (ntt_rows_split_body)
-    if (a.fma_u) return CRC_ERR_UNSUPPORTED;          // (only the wave-local kernel above has that epilogue; the caller runs the product as a pass of its own)
+    if (a.fma_u || a.fma_k) return CRC_ERR_UNSUPPORTED;   // (only the wave-local kernel above has those epilogues; the caller runs the product as a pass of its own)
     if (c->n == 16384 && nt == 1024 && c->tune.ntt_split != 0) {
         lds /= 2;
         auto ks = a.prologue == 4 ? (lazy ? ntt_rows_split_kernel<true, true, 4> : ntt_rows_split_kernel<true, false, 4>)
@@ -631,6 +641,16 @@ int k_ntt_ct_fwd_fma(crc_ctx *c, u64 *ct, size_t count, const u64 *u, const u64 
     NttArgs a{};
     a.src = ct; a.dst = ct; a.mod_base = 0; a.mod_count = c->k; a.rows_per_ct = 2 * c->k; a.add_group = 1; a.add_mode = 1;
     a.fma_u = u; a.fma_k = key;
+    return ntt_launch(c, false, a, count * 2 * c->k, st);
+}
+
+// forward NTT in place of size-2 ciphertexts, both polys leaving multiplied by the NTT-form plaintext row w[ct / group] ([.][k][n]) -- the first two of
+// multiply_plain's three steps (evaluator.cpp:1193-1323) in one kernel.  CRC_ERR_UNSUPPORTED where the ring has no wave-local kernel
+int k_ntt_ct_fwd_mul(crc_ctx *c, u64 *ct, size_t count, const u64 *w, size_t group, hipStream_t st)
+{
+    NttArgs a{};
+    a.src = ct; a.dst = ct; a.mod_base = 0; a.mod_count = c->k; a.rows_per_ct = 2 * c->k; a.add_group = 1; a.add_mode = 1;
+    a.fma_k = w; a.fma_group = group ? group : 1;
     return ntt_launch(c, false, a, count * 2 * c->k, st);
 }
 
