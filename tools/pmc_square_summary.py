@@ -2,7 +2,7 @@
 """Summarise the two PMC passes of tools/pmc_square.sh: HBM bytes per ciphertext and kernel of the Square + relinearise sequence.
 Counters are KiB (rocprofv3 derived FETCH_SIZE / WRITE_SIZE).  MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half of the bytes of wide (16 B / lane) coalesced
 reads and other widths are uncalibrated -- the kernels of this sequence mix widths, so the read counter is calibrated here on a kernel of the same sequence whose bytes are known
-exactly: the row inverse transform ntt_rows_kernel<true, true, 0> reads each of its rows once (8 n bytes per row)."""
+exactly: the row inverse transform (ntt_rows_kernel<true, true, 0 / 5>, since round 5 ntt_rows_wave_kernel<true, 5, ..>) reads each of its rows once (8 n bytes per row)."""
 import collections, csv, glob, json, sys
 O, cfg = sys.argv[1], sys.argv[2]
 n, k, cts = [int(v) for v in cfg.split()]
@@ -26,7 +26,8 @@ fetch, calls = load("fetch", "FETCH_SIZE")
 write, _ = load("write", "WRITE_SIZE")
 ours = [nm for nm in fetch if not nm.startswith(("void at::", "at::", "__amd"))]
 per = cts * runs
-cal_name = next((nm for nm in ours if any(t in nm for t in ("ntt_rows_kernel<true, true, 0>", "ntt_rows_kernel<true, true, 5>", "ntt_rows_split_kernel<true, true, 5>"))), None)      # (round 4: prologue 5 = the same transform with a scaled result)
+cal_name = next((nm for nm in ours if any(t in nm for t in ("ntt_rows_kernel<true, true, 0>", "ntt_rows_kernel<true, true, 5>", "ntt_rows_split_kernel<true, true, 5>",
+                                                            "ntt_rows_wave_kernel<true, 5,"))), None)      # (round 4: prologue 5 = the same transform with a scaled result)
 cal = None
 if cal_name:
     known = 2 * k * 8 * n * per          # the first inverse transform of the NTT-resident input: 2k rows per ciphertext, each read once
