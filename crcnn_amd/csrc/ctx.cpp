@@ -168,6 +168,7 @@ static void read_tuning(CrcTuning &t)
     t.mfma_variant = (int)geti("CRC_MFMA_VARIANT", 2);
     { const int v = (int)geti("CRC_MFMA_RING", 0); t.mfma_ring = v >= 3 && v <= 5 ? v : 0; }
     { const int v = (int)geti("CRC_CONV1_WAVES", 0); t.conv1_waves = v == 8 || v == 12 ? v : 0; }
+    t.conv1_narrow = (int)geti("CRC_CONV1_NARROW", 1);
     { const long long v = geti("CRC_CONV1_PASS_BYTES", 0); t.conv1_pass_bytes = v > 0 ? v : 0; }
     { const int v = (int)geti("CRC_LIMB_PACK_GROUP", 1); t.limb_pack_group = v > 0 ? v : 1; }
     t.mac2_cfg = (int)geti("CRC_MAC2_CFG", 0);
@@ -194,6 +195,7 @@ extern "C" int crc_ctx_set_tuning(crc_ctx *c, const char *name, long long value)
     else if (s == "mfma_variant") t.mfma_variant = (int)value;
     else if (s == "mfma_ring") t.mfma_ring = value >= 3 && value <= 5 ? (int)value : 0;
     else if (s == "conv1_waves") t.conv1_waves = value == 8 || value == 12 ? (int)value : 0;
+    else if (s == "conv1_narrow") t.conv1_narrow = (int)value;
     else if (s == "conv1_pass_bytes") t.conv1_pass_bytes = value > 0 ? value : 0;
     else if (s == "limb_pack_group") t.limb_pack_group = value > 0 ? (int)value : 1;
     else if (s == "mac2_cfg") t.mac2_cfg = (int)value;

@@ -106,6 +106,7 @@ struct CrcTuning {
     int mfma_variant = 2;         // CRC_MFMA_VARIANT=2: two workgroups per CU (mfma_mac2w_kernel), 1: mfma_mac_kernel
     int mfma_ring = 0;            // CRC_MFMA_RING=4|5: LDS ring slots of mfma_mac_kernel
     int conv1_waves = 0;          // CRC_CONV1_WAVES=8|12
+    int conv1_narrow = 1;         // CRC_CONV1_NARROW=0: 17-20 filters run the second filter group like a full one (round 4) instead of the packed form
     long long conv1_pass_bytes = 0;   // CRC_CONV1_PASS_BYTES: work-space cap per internal pass of a one-channel convolution (0: 16 GiB)
     int limb_pack_group = 1;      // CRC_LIMB_PACK_GROUP
     int mac2_cfg = 0;             // CRC_MAC2_CFG=16|8: force a tile shape (mac2_kernel)

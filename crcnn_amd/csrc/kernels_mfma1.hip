@@ -35,6 +35,8 @@ struct Conv1Args {
     unsigned img_stride, plane_bytes, poly_bytes;      // per (slot, image): 7 planes x 2 polys x xd rows x 32 bytes (+ 8: the last window may read past its row), rounded up to 1 KiB
     unsigned out_img_bytes;                            // limb output, bytes per image: 7 * P * 2 * 32, or the flat form's 7 * 2 * P * zdc rounded up to 16 (kernels_mfma.hip)
     int out_zdc;                                       // flat form (fewer than 32 filters = channels of the next convolution): channel bytes per position, else 0
+    int narrow;                                        // 16 < F <= 20: the second filter group has at most four filters -- its waves pack (filter, weight limb) into the 16 rows of
+                                                       // the MFMA's A operand: 14 MFMAs and ONE output per lane and tile instead of 49 and four (mfma_conv1_kernel)
     int acc0[MAXK][13];                                // initial value of the 13 diagonal accumulators, per modulus (conv1_tables)
     u32 qbits[MAXK], qfold[MAXK];                      // q = 2^qbits - qfold (limbred.h conv1_fold_ok)
 };
@@ -54,13 +56,31 @@ __global__ void __launch_bounds__(768) mfma_conv1_kernel(Conv1Args a)
     const int slot = blockIdx.x, i = slot / a.n, s = slot % a.n;
     const u64 q = a.mods[i].q;
     const u32 qbits = a.qbits[i], qfold = a.qfold[i];
-    const int nt = wave & 1, g = lane >> 4, r16 = lane & 15;
+    // wave roles.  Usually wave w takes filter group w & 1 and row tiles w >> 1, w >> 1 + waves / 2, ...  With a NARROW second group (a.narrow) its waves cost
+    // less than half of the others', and waves w, w + 4, w + 8 share a SIMD: groups alternate in blocks of four waves so that every SIMD hosts both kinds
+    const int g = lane >> 4, r16 = lane & 15;
+    const bool narrow = a.narrow != 0;
+    const int nt = narrow ? (wave >> 2) & 1 : wave & 1;
+    const int tile0 = !narrow ? wave >> 1 : nt ? wave - 4 : (wave < 4 ? wave : wave - 4), tile_step = !narrow ? nwaves >> 1 : nt ? 4 : nwaves - 4;
+    const bool nar = narrow && nt;                          // this wave runs the packed form
     // operand A of the MFMA = the weights: this lane's filter nt * 16 + r16, K group g (window rows 2g, 2g+1): resident for the whole workgroup
     v4i wv[NPL];
     {
         const i8 *ws = a.wl + (size_t)slot * (NPL * 32 * 64) + (nt * 16 + r16) * 64 + g * 16;
+        if (!nar) {
 #pragma unroll
-        for (int l = 0; l < NPL; l++) wv[l] = *reinterpret_cast<const v4i *>(ws + l * (32 * 64));
+            for (int l = 0; l < NPL; l++) wv[l] = *reinterpret_cast<const v4i *>(ws + l * (32 * 64));
+        } else {
+            // packed A operand: row r16 = 4 f + m <-> filter 16 + f, weight limb 4 grp + m (grp = 0, 1: wv[0], wv[1]; limb 7 does not exist: zero rows)
+            const i8 *wp = a.wl + (size_t)slot * (NPL * 32 * 64) + (16 + (r16 >> 2)) * 64 + g * 16;
+#pragma unroll
+            for (int grp = 0; grp < 2; grp++) {
+                const int pl = 4 * grp + (r16 & 3);
+                wv[grp] = pl < NPL ? *reinterpret_cast<const v4i *>(wp + pl * (32 * 64)) : v4i{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int l = 2; l < NPL; l++) wv[l] = v4i{0, 0, 0, 0};
+        }
     }
     // the accumulators start at zero (an inline constant of the MFMAs); the per-diagonal biases join pair by pair in the reduction (limbred.h)
     u32 PB[7];
@@ -80,6 +100,13 @@ __global__ void __launch_bounds__(768) mfma_conv1_kernel(Conv1Args a)
         const u64 bv = (a.bias && f < a.F && !(lane & 1)) ? a.bias[((size_t)f * a.k + i) * a.n + s] : 0;
         bvc[reg] = bv > (q >> 1) ? (long long)(bv - q) : (long long)bv;
     }
+    // (packed form: the lane's ONE filter is 16 + g)
+    long long bvn = 0;
+    if (nar) {
+        const int f = 16 + g;
+        const u64 bv = (a.bias && f < a.F && !(lane & 1)) ? a.bias[((size_t)f * a.k + i) * a.n + s] : 0;
+        bvn = bv > (q >> 1) ? (long long)(bv - q) : (long long)bv;
+    }
     i8 *stage = lds + 2 * (size_t)a.img_stride;
     const i8 *ximg = a.xr + (size_t)slot * a.B * a.img_stride;
     const int pieces = a.img_stride / 1024;
@@ -98,7 +125,7 @@ __global__ void __launch_bounds__(768) mfma_conv1_kernel(Conv1Args a)
         __syncthreads();                                          // ... everybody's; the other image buffer and the staging area are free
         if (b + 1 < a.B) issue_img(b + 1);
         const i8 *img = lds + (b & 1) * (size_t)a.img_stride;
-        for (int mt = wave >> 1; mt < a.mtiles; mt += nwaves >> 1) {
+        for (int mt = tile0; mt < a.mtiles; mt += tile_step) {
             v4i acc[13];
 #pragma unroll
             for (int d = 0; d < 13; d++) acc[d] = v4i{0, 0, 0, 0};
@@ -109,14 +136,53 @@ __global__ void __launch_bounds__(768) mfma_conv1_kernel(Conv1Args a)
             const int r0 = min(ox * a.xs + 2 * g, a.xd - 1), r1 = min(ox * a.xs + 2 * g + 1, a.xd - 1);
             const int off = oy * a.ystr, sh = off & 3;
             const i8 *p0 = img + c * a.poly_bytes + (off & ~3) + r0 * 32, *p1 = img + c * a.poly_bytes + (off & ~3) + r1 * 32;
-#pragma unroll
-            for (int l = 0; l < NPL; l++) {
+            // image limb plane l of this lane's window rows, cut to the window's 8 bytes
+            auto window = [&](int l) {
                 const u32 *q0 = reinterpret_cast<const u32 *>(p0 + l * a.plane_bytes), *q1 = reinterpret_cast<const u32 *>(p1 + l * a.plane_bytes);
                 const u32 a0 = q0[0], a1 = q0[1], a2 = q0[2], b0 = q1[0], b1 = q1[1], b2 = q1[2];
-                int2 lo, hi;
-                lo.x = (int)__builtin_amdgcn_alignbyte(a1, a0, sh); lo.y = (int)__builtin_amdgcn_alignbyte(a2, a1, sh);
-                hi.x = (int)__builtin_amdgcn_alignbyte(b1, b0, sh); hi.y = (int)__builtin_amdgcn_alignbyte(b2, b1, sh);
-                const v4i av = {lo.x, lo.y, hi.x, hi.y};
+                return v4i{(int)__builtin_amdgcn_alignbyte(a1, a0, sh), (int)__builtin_amdgcn_alignbyte(a2, a1, sh), (int)__builtin_amdgcn_alignbyte(b1, b0, sh),
+                           (int)__builtin_amdgcn_alignbyte(b2, b1, sh)};
+            };
+            if (nar) {
+                // packed second filter group: acc[l] = image limb l x weight limbs 0-3, acc[7 + l] (hi6 for l = 6) x limbs 4-6, of filter 16 + g; register m = limb
+                v4i hi6;
+#pragma unroll
+                for (int l = 0; l < NPL; l++) {
+                    const v4i av = window(l);
+                    acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv[0], av, v4i{0, 0, 0, 0}, 0, 0, 0);
+                    if (l < 6) acc[7 + l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv[1], av, v4i{0, 0, 0, 0}, 0, 0, 0);
+                    else hi6 = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv[1], av, v4i{0, 0, 0, 0}, 0, 0, 0);
+                }
+                // the 13 diagonals of this lane's one output: D_d = sum over l + m = d of (image limb l) x (weight limb m); then the same reduction as below
+                int D[13];
+#pragma unroll
+                for (int d = 0; d < 13; d++) {
+                    int sum = 0;
+#pragma unroll
+                    for (int l = 0; l < NPL; l++) {
+                        const int m = d - l;
+                        if (m < 0 || m >= NPL) continue;
+                        sum += m < 4 ? acc[l][m] : (l < 6 ? acc[7 + l][m - 4] : hi6[m - 4]);
+                    }
+                    D[d] = sum;
+                }
+                const long long cvn = diag_fold_short_centred(D, q, qbits, qfold, bvn, PB);
+                const int f = 16 + g;
+                if (mm >= 2 * a.P) continue;
+                if (a.xl_out) {
+                    if (f >= chan_bytes) continue;
+                    const u64 dg = f < a.F ? centred_digit_bytes(cvn) : 0;
+                    i8 *sp; unsigned pstride;
+                    if (a.out_zdc) { sp = stage + ((mm & 1) * a.P + (mm >> 1)) * a.out_zdc + f; pstride = 2 * a.P * a.out_zdc; }
+                    else { sp = stage + mm * (NPL * 32) + f; pstride = 32; }
+#pragma unroll
+                    for (int l = 0; l < NPL; l++) sp[l * pstride] = (i8)(dg >> (8 * l));
+                } else if (f < a.F) a.ys[(((size_t)slot * a.B + b) * a.F + f) * (2 * a.P) + mm] = (u64)(cvn + ((cvn >> 63) & (long long)q));
+                continue;
+            }
+#pragma unroll
+            for (int l = 0; l < NPL; l++) {
+                const v4i av = window(l);
 #pragma unroll
                 for (int m2 = 0; m2 < NPL; m2++)
                     acc[l + m2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv[m2], av, acc[l + m2], 0, 0, 0);
@@ -290,6 +356,7 @@ int k_limb_conv1(crc_ctx *c, const u64 *x, bool packed, i8 *xr, const i8 *wl, u6
     a.poly_bytes = conv1_poly_bytes(xd); a.plane_bytes = 2 * a.poly_bytes; a.img_stride = conv1_img_stride(xd);
     a.out_zdc = a.P > 1 ? k_limb_flat_zdc(nf) : 0;            // (the limb tensor of the convolution behind: its layout follows ITS channel count = this layer's filters)
     a.out_img_bytes = a.out_zdc ? (unsigned)((NPL * 2 * a.P * a.out_zdc + 15) / 16 * 16) : (unsigned)(NPL * a.P * 2 * 32);
+    a.narrow = c->tune.conv1_narrow != 0 && nf > 16 && nf <= 20 ? 1 : 0;
     conv1_tables(c, a);
     {
         const size_t blocks = (size_t)(c->n / RSL) * c->k * B * 2 * ((xd + RG - 1) / RG);
@@ -307,7 +374,8 @@ int k_limb_conv1(crc_ctx *c, const u64 *x, bool packed, i8 *xr, const i8 *wl, u6
         return worst;
     };
     const int forced = c->tune.conv1_waves;     // tuning (tools/)
-    const int nwaves = forced ? forced : busiest(12) <= busiest(8) ? 12 : 8;
+    // (narrow second group: four of its waves + four or eight of the others, one or two heavy waves and one light wave per SIMD either way: 12, for the overlap)
+    const int nwaves = forced ? forced : a.narrow ? 12 : busiest(12) <= busiest(8) ? 12 : 8;
     const size_t lds = 2 * (size_t)a.img_stride + (xl_out ? a.out_img_bytes : 0);
     { const int rc = crc_ctx_ensure_lds(c, (const void *)mfma_conv1_kernel, lds); if (rc) return rc; }
     hipLaunchKernelGGL(mfma_conv1_kernel, dim3((unsigned)(c->n * c->k)), dim3(64 * nwaves), lds, st, a);

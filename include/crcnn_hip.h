@@ -106,7 +106,7 @@ int  crc_ctx_table(const crc_ctx *ctx, const char *name, uint64_t *h_out, int ca
 /* Tuning switches of tools/ and the tests (none is needed for normal use).  The engine reads its environment (CRC_MFMA_VARIANT, CRC_CONV1_PASS_BYTES, ...)
  * exactly
  * once, inside crc_ctx_create; this call changes one switch of a context nobody is launching on: "mfma_variant", "mfma_order", "mfma_ring", "conv1_waves",
- * "conv1_pass_bytes", "limb_pack_group", "mac2_cfg", "mac_order", "mac_regstage", "ntt_inv61_loose", "ntt_split", "mfma_min_steps", "f64_radix",
+ * "conv1_narrow" (0: a one-channel convolution with 17-20 filters runs its second filter group like a full one), "conv1_pass_bytes", "limb_pack_group", "mac2_cfg", "mac_order", "mac_regstage", "ntt_inv61_loose", "ntt_split", "mfma_min_steps", "f64_radix",
  * "relin_mac_ct",
  * "relin_path" (1: key switching over the coefficient moduli, as the reference does it, instead of over two fp64 primes), "sq_path" (1: the square's auxiliary
  * base is SEAL's 61-bit

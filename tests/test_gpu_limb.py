@@ -301,7 +301,11 @@ def test_conv1_matrix_core_kernel(eng, shape, edge):
     rows_y = B * nf * xo * yo * 2 * E.k
     d_y = E.alloc(max(rows_y * E.n * 8, E.limb_tensor_bytes(B, nf, xo, yo)))
     d_xp = E.upload(x); E.pack28(d_xp, B * xd * yd * 2 * E.k)
-    for fin, fout in [(ca.NTT, ca.NTT), (ca.NTTP, ca.NTTP), (ca.NTT, ca.NTTLC)]:
+    # 17-20 filters: the second filter group runs packed (round 5: (filter, weight limb) in the rows of the MFMA's A operand, CRC_CONV1_NARROW) or like a full
+    # one (0: the round-4 form) -- the same results either way
+    forms = [(ca.NTT, ca.NTT, 1), (ca.NTTP, ca.NTTP, 1), (ca.NTT, ca.NTTLC, 1)] + ([(ca.NTT, ca.NTT, 0), (ca.NTT, ca.NTTLC, 0)] if 16 < nf <= 20 else [])
+    for fin, fout, nar in forms:
+        E.set_tuning("conv1_narrow", nar)
         d_work = E.alloc(E.conv2d_forms_work_bytes(B, 1, xd, yd, xs, ys, xf, yf, nf, fin, ca.NTTL1, fout))
         if fout == ca.NTTLC:
             E.L.crc_memset(E.c, E.p(d_y), 0, E.limb_tensor_bytes(B, nf, xo, yo), E.stream)       # (the tensor's tail -- read-ahead room of the flat form -- is nobody's to write)
@@ -317,7 +321,8 @@ def test_conv1_matrix_core_kernel(eng, shape, edge):
             assert np.array_equal(E.download(d_y, (nb // 8,)), E.download(d_ref, (nb // 8,))), (shape, "limb tensor")
         else:
             E.sync()
-            assert np.array_equal(E.download(d_y, (rows_y, E.n)), want), (shape, fin, fout)
+            assert np.array_equal(E.download(d_y, (rows_y, E.n)), want), (shape, fin, fout, nar)
+    E.set_tuning("conv1_narrow", 1)
     # coefficient-form input and output (the layer as the reference calls it): INTT of the NTT-form result
     d_xc = E.upload(x); E.ntt_inv(d_xc, B * xd * yd)
     d_work = E.alloc(E.conv2d_forms_work_bytes(B, 1, xd, yd, xs, ys, xf, yf, nf, ca.COEFF, ca.NTTL1, ca.NTT))
