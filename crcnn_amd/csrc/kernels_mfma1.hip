@@ -8,18 +8,22 @@
 //             whole reduction.  The 7 weight fragments of a wave's 16 filters live in registers for the whole workgroup, and a workgroup walks ALL images of
 //             the chunk for its slot (image b+1 arrives by LDS-DMA while image b is multiplied);
 //   a cheap   the accumulators start at per-diagonal biases B_d (so every diagonal stays in [0, 2^24) and their sum is a multiple of q: no signs, no
-//   epilogue  correction term), pairs of diagonals pack into 32-bit words without carries, the 128-bit value is two word vectors added once.  Round 4: the value is
+//   epilogue  correction term), pairs of diagonals pack into 32-bit words without carries, the 128-bit value is two word vectors added once.  Round 4: the
+//   value is
 //             reduced by FOLDING (q = 2^b - f: three folds, 3 + 1 multiplies: limbred.h diag_fold_short_centred) instead of a Montgomery step (7 quarter-rate
-//             multiplies: 112 of ~370 issue cycles per output), and the MFMA operands are swapped -- weights as the A operand, image windows as B -- so that a lane's four
-//             accumulator registers are FOUR CONSECUTIVE FILTERS of one output row: their digit bytes transpose in registers (v_perm_b32) into one dword per limb plane,
+//             multiplies: 112 of ~370 issue cycles per output), and the MFMA operands are swapped -- weights as the A operand, image windows as B -- so that a
+//             lane's four
+//             accumulator registers are FOUR CONSECUTIVE FILTERS of one output row: their digit bytes transpose in registers (v_perm_b32) into one dword per
+//             limb plane,
 //             stored with 7 ds_write_b32 per four outputs instead of 28 byte stores (the byte-wise staging was most of the 23 % of CU cycles lost to LDS bank
 //             conflicts, profiles/r03_pmc_conv1_issue.json; the two polys' image blocks now sit 8 banks apart for the window reads).
 // 8 or 12 waves per workgroup (2-3 per SIMD: one wave's epilogue overlaps another's MFMAs); a wave owns 16 filters and every (waves/2)-th 16-row tile.
-//   per image   the limb image [plane][poly][row + 1 pad][32 columns] (13 KiB for 28 x 28) in LDS, double-buffered; a lane's A fragment is two 8-byte LDS reads per
+//   per image  the limb image [plane][poly][row + 1 pad][32 columns] (13 KiB for 28 x 28) in LDS, double-buffered; a lane's A fragment is two 8-byte LDS reads
+//   per
 //               plane (window rows kx, kx+1): the three words around byte offset oy * stride, byte-aligned in registers;
 //   output      either the limb tensor of a following convolution, staged in LDS and written out as one contiguous [plane][pixel][poly][32 channels] block
-//               (no limb_pack_tensor pass in front of conv2), or slot-major u64 for the generic conversions.
-// Exact integer arithmetic throughout: the same element of Z_q, hence the same bits, as mac3_kernel and the reference (convolutionalLayer.cpp:56-93).
+//               (no limb_pack_tensor pass in front of conv2), or slot-major u64 for the generic conversions. Exact integer arithmetic throughout: the same
+//               element of Z_q, hence the same bits, as mac3_kernel and the reference (convolutionalLayer.cpp:56-93).
 #include "kernels.h"
 #include "limbred.h"
 #include <cstdlib>
@@ -32,11 +36,16 @@ typedef signed char i8;
 struct Conv1Args {
     const i8 *xr; const i8 *wl; u64 *ys; i8 *xl_out; const ModParams *mods; const u64 *bias;
     int n, k, B, Bout, b0, xd, yo, xs, ystr, P, F, mtiles;   // B images in this launch; the limb result is image b0 + b of Bout
-    unsigned img_stride, plane_bytes, poly_bytes;      // per (slot, image): 7 planes x 2 polys x xd rows x 32 bytes (+ 8: the last window may read past its row), rounded up to 1 KiB
-    unsigned out_img_bytes;                            // limb output, bytes per image: 7 * P * 2 * 32, or the flat form's 7 * 2 * P * zdc rounded up to 16 (kernels_mfma.hip)
-    int out_zdc;                                       // flat form (fewer than 32 filters = channels of the next convolution): channel bytes per position, else 0
-    int narrow;                                        // 16 < F <= 20: the second filter group has at most four filters -- its waves pack (filter, weight limb) into the 16 rows of
-                                                       // the MFMA's A operand: 14 MFMAs and ONE output per lane and tile instead of 49 and four (mfma_conv1_kernel)
+    // per (slot, image): 7 planes x 2 polys x xd rows x 32 bytes (+ 8: the last window may read past its row), rounded up to 1 KiB
+    unsigned img_stride, plane_bytes, poly_bytes;
+    // limb output, bytes per image: 7 * P * 2 * 32, or the flat form's 7 * 2 * P * zdc rounded up to 16 (kernels_mfma.hip)
+    unsigned out_img_bytes;
+    // flat form (fewer than 32 filters = channels of the next convolution): channel bytes per position, else 0
+    int out_zdc;
+    // 16 < F <= 20: the second filter group has at most four filters -- its waves pack (filter, weight limb) into the 16 rows of
+    int narrow;
+                                                       // the MFMA's A operand: 14 MFMAs and ONE output per lane and tile instead of 49 and four
+                                                       // (mfma_conv1_kernel)
     int acc0[MAXK][13];                                // initial value of the 13 diagonal accumulators, per modulus (conv1_tables)
     u32 qbits[MAXK], qfold[MAXK];                      // q = 2^qbits - qfold (limbred.h conv1_fold_ok)
 };
@@ -89,9 +98,9 @@ __global__ void __launch_bounds__(768) mfma_conv1_kernel(Conv1Args a)
     PB[6] = (u32)a.acc0[i][12];
     // output pixel -> (row, column) of the output map with one multiply: p < 1024, yo <= 32, so (p rcp) >> 16 is exact
     const u32 rcp_yo = (65536u + (u32)a.yo - 1) / (u32)a.yo;
-    // C/D layout of a 16 x 16 tile: col = lane & 15, row = 4 (lane >> 4) + reg.  With the weights as A the ROW is the filter and the COLUMN the output row: this lane
-    // owns output row (pixel, poly) r16 of every tile and filters f0 .. f0 + 3, four consecutive channels of the next layer.  Rows alternate poly 0 / poly 1 and
-    // tiles start at multiples of 16, so a lane's poly is lane & 1 for good: the bias (poly 0 only), centred, is a per-lane constant
+    // C/D layout of a 16 x 16 tile: col = lane & 15, row = 4 (lane >> 4) + reg.  With the weights as A the ROW is the filter and the COLUMN the output row:
+    // this lane owns output row (pixel, poly) r16 of every tile and filters f0 .. f0 + 3, four consecutive channels of the next layer.  Rows alternate poly 0 /
+    // poly 1 and tiles start at multiples of 16, so a lane's poly is lane & 1 for good: the bias (poly 0 only), centred, is a per-lane constant
     const int f0 = nt * 16 + 4 * g;
     long long bvc[4];
 #pragma unroll
@@ -114,14 +123,17 @@ __global__ void __launch_bounds__(768) mfma_conv1_kernel(Conv1Args a)
         i8 *dst = lds + (b & 1) * (size_t)a.img_stride;
         const i8 *src = ximg + (size_t)b * a.img_stride + lane * 16;
         for (int pc = wave; pc < pieces; pc += nwaves)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + pc * 1024), (__attribute__((address_space(3))) void *)(dst + pc * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + pc * 1024),
+                (__attribute__((address_space(3))) void *)(dst + pc * 1024), 16, 0, 0);
     };
     // (flat limb result: the bytes between the last position and the image's 16-byte end leave with every image -- zero, like the tensor the pack kernel makes)
-    if (a.xl_out && a.out_zdc && threadIdx.x < 16) { const unsigned e = a.out_img_bytes - 16 + threadIdx.x; if (e >= (unsigned)(NPL * 2 * a.P * a.out_zdc)) stage[e] = 0; }
+    if (a.xl_out && a.out_zdc && threadIdx.x < 16) { const unsigned e = a.out_img_bytes - 16 + threadIdx.x;
+        if (e >= (unsigned)(NPL * 2 * a.P * a.out_zdc)) stage[e] = 0; }
     issue_img(0);
     const int chan_bytes = a.out_zdc ? a.out_zdc : 32;          // channel bytes per (pixel, poly) position of a limb result
     for (int b = 0; b < a.B; b++) {
-        __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));    // this wave's pieces of image b have landed (and its stores of image b-1's staging copy have left) ...
+        // this wave's pieces of image b have landed (and its stores of image b-1's staging copy have left) ...
+        __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
         __syncthreads();                                          // ... everybody's; the other image buffer and the staging area are free
         if (b + 1 < a.B) issue_img(b + 1);
         const i8 *img = lds + (b & 1) * (size_t)a.img_stride;
@@ -140,11 +152,13 @@ __global__ void __launch_bounds__(768) mfma_conv1_kernel(Conv1Args a)
             auto window = [&](int l) {
                 const u32 *q0 = reinterpret_cast<const u32 *>(p0 + l * a.plane_bytes), *q1 = reinterpret_cast<const u32 *>(p1 + l * a.plane_bytes);
                 const u32 a0 = q0[0], a1 = q0[1], a2 = q0[2], b0 = q1[0], b1 = q1[1], b2 = q1[2];
-                return v4i{(int)__builtin_amdgcn_alignbyte(a1, a0, sh), (int)__builtin_amdgcn_alignbyte(a2, a1, sh), (int)__builtin_amdgcn_alignbyte(b1, b0, sh),
+                return v4i{(int)__builtin_amdgcn_alignbyte(a1, a0, sh), (int)__builtin_amdgcn_alignbyte(a2, a1, sh), (int)__builtin_amdgcn_alignbyte(b1, b0,
+                    sh),
                            (int)__builtin_amdgcn_alignbyte(b2, b1, sh)};
             };
             if (nar) {
-                // packed second filter group: acc[l] = image limb l x weight limbs 0-3, acc[7 + l] (hi6 for l = 6) x limbs 4-6, of filter 16 + g; register m = limb
+                // packed second filter group: acc[l] = image limb l x weight limbs 0-3, acc[7 + l] (hi6 for l = 6) x limbs 4-6, of filter 16 + g; register m =
+                // limb
                 v4i hi6;
 #pragma unroll
                 for (int l = 0; l < NPL; l++) {
@@ -194,15 +208,19 @@ __global__ void __launch_bounds__(768) mfma_conv1_kernel(Conv1Args a)
                 int D[13];
 #pragma unroll
                 for (int d = 0; d < 13; d++) D[d] = acc[d][reg];
-                cv[reg] = diag_fold_short_centred(D, q, qbits, qfold, bvc[reg], PB);   // one pass from the diagonals to the centred representative, bias included
+                // one pass from the diagonals to the centred representative, bias included
+                cv[reg] = diag_fold_short_centred(D, q, qbits, qfold, bvc[reg], PB);
             }
             if (mm >= 2 * a.P) continue;
-            if (a.xl_out) {               // limb tensor of the next convolution, staged in LDS as it leaves: [row][plane][32 channels], or the flat form [plane][poly][pixel][zdc]
+            // limb tensor of the next convolution, staged in LDS as it leaves: [row][plane][32 channels], or the flat form [plane][poly][pixel][zdc]
+            if (a.xl_out) {
                 if (f0 >= chan_bytes) continue;                                      // (flat form: channel padding is a multiple of 4, this group is past it)
                 u32 lo[4], hi[4];
 #pragma unroll
-                for (int reg = 0; reg < 4; reg++) { const u64 dg = f0 + reg < a.F ? centred_digit_bytes(cv[reg]) : 0; lo[reg] = (u32)dg; hi[reg] = (u32)(dg >> 32); }
-                // 4 x 7 byte transpose: dword l = digit l of the four filters (v_perm_b32: result byte = selector byte picks from {second operand: 0-3, first: 4-7})
+                for (int reg = 0; reg < 4; reg++) { const u64 dg = f0 + reg < a.F ? centred_digit_bytes(cv[reg]) : 0; lo[reg] = (u32)dg;
+                    hi[reg] = (u32)(dg >> 32); }
+                // 4 x 7 byte transpose: dword l = digit l of the four filters (v_perm_b32: result byte = selector byte picks from {second operand: 0-3, first:
+                // 4-7})
                 const u32 t0 = __builtin_amdgcn_perm(lo[1], lo[0], 0x05010400u), t1 = __builtin_amdgcn_perm(lo[1], lo[0], 0x07030602u);
                 const u32 u0 = __builtin_amdgcn_perm(lo[3], lo[2], 0x05010400u), u1 = __builtin_amdgcn_perm(lo[3], lo[2], 0x07030602u);
                 const u32 t2 = __builtin_amdgcn_perm(hi[1], hi[0], 0x05010400u), t3 = __builtin_amdgcn_perm(hi[1], hi[0], 0x07030602u);
@@ -220,7 +238,8 @@ __global__ void __launch_bounds__(768) mfma_conv1_kernel(Conv1Args a)
             } else {
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++)
-                    if (f0 + reg < a.F) a.ys[(((size_t)slot * a.B + b) * a.F + f0 + reg) * (2 * a.P) + mm] = (u64)(cv[reg] + ((cv[reg] >> 63) & (long long)q));       // canonical
+                    // canonical
+                    if (f0 + reg < a.F) a.ys[(((size_t)slot * a.B + b) * a.F + f0 + reg) * (2 * a.P) + mm] = (u64)(cv[reg] + ((cv[reg] >> 63) & (long long)q));
             }
         }
         if (a.xl_out) {
@@ -233,7 +252,8 @@ __global__ void __launch_bounds__(768) mfma_conv1_kernel(Conv1Args a)
                 const unsigned per_plane = a.out_img_bytes / (NPL * 16);      // 16-byte pieces of one plane: (row, half)
                 for (unsigned o = threadIdx.x; o < NPL * per_plane; o += blockDim.x) {
                     const unsigned l = o / per_plane, rem = o - l * per_plane;
-                    *reinterpret_cast<uint4 *>(dst + (size_t)o * 16) = *reinterpret_cast<const uint4 *>(stage + (rem >> 1) * (NPL * 32) + l * 32 + (rem & 1) * 16);
+                    *reinterpret_cast<uint4 *>(dst + (size_t)o * 16) = *reinterpret_cast<const uint4 *>(stage + (rem >> 1) * (NPL * 32) + l * 32 +
+                        (rem & 1) * 16);
                 }
             }
         }
@@ -241,18 +261,18 @@ __global__ void __launch_bounds__(768) mfma_conv1_kernel(Conv1Args a)
 }
 
 // ---- operand preparation -----------------------------------------------------------------------------------------------------------------
-// NTT-form image x [B][xd*yd cts][2][k][n] (one channel; canonical or 28-bit packed) -> Xr [slot][B][plane][poly][row][32 columns] (yd <= 32, zero padded).
-// A workgroup = 64 consecutive slots x (image, poly, group of RG rows): thread (slot lane, row q of the group) reads its row's columns -- lanes run over the slots, so
-// every load is a coalesced 512-byte segment of one ciphertext row -- and stages the seven planes' 32 bytes in LDS; then the workgroup writes the staged block out so
-// that the RG * 32 = 128 contiguous bytes a (slot, plane) owns in Xr leave as ONE full line from eight adjacent lanes.  (Round 2's form -- every thread storing its own
-// 16-byte pieces, neighbouring lanes 1.6 MB apart -- moved 26 GB at 1.7 TB/s; a forward transform that writes this layout itself would have to hold 32 columns of a
-// row at once, 32 polynomials per workgroup: the image layout is slot-major because the convolution's workgroup walks one slot's image, the transform's row is
-// slot-minor, and the transpose between them is this pass.)
+// NTT-form image x [B][xd*yd cts][2][k][n] (one channel; canonical or 28-bit packed) -> Xr [slot][B][plane][poly][row][32 columns] (yd <= 32, zero padded). A
+// workgroup = 64 consecutive slots x (image, poly, group of RG rows): thread (slot lane, row q of the group) reads its row's columns -- lanes run over the
+// slots, so every load is a coalesced 512-byte segment of one ciphertext row -- and stages the seven planes' 32 bytes in LDS; then the workgroup writes the
+// staged block out so that the RG * 32 = 128 contiguous bytes a (slot, plane) owns in Xr leave as ONE full line from eight adjacent lanes.  (Round 2's form --
+// every thread storing its own 16-byte pieces, neighbouring lanes 1.6 MB apart -- moved 26 GB at 1.7 TB/s; a forward transform that writes this layout itself
+// would have to hold 32 columns of a row at once, 32 polynomials per workgroup: the image layout is slot-major because the convolution's workgroup walks one
+// slot's image, the transform's row is slot-minor, and the transpose between them is this pass.)
 #define RG 4
 #define RSL 32
-// (32 slots per workgroup, thread = (slot, row of the group, 16-column half): 28 KiB of staging and five workgroups per CU, so that the loads of one overlap the digit
-// arithmetic and the stores of the others -- with 64 slots and two workgroups per CU the three ran one after the other: 2.5 TB/s, the same restructuring took the
-// weight pack of kernels_mfma.hip from 1.0 to 3.7 TB/s)
+// (32 slots per workgroup, thread = (slot, row of the group, 16-column half): 28 KiB of staging and five workgroups per CU, so that the loads of one overlap
+// the digit arithmetic and the stores of the others -- with 64 slots and two workgroups per CU the three ran one after the other: 2.5 TB/s, the same
+// restructuring took the weight pack of kernels_mfma.hip from 1.0 to 3.7 TB/s)
 __global__ void __launch_bounds__(256) limb_pack_rows1_kernel(const u64 *x, i8 *xr, const ModParams *mods, int n, int k, int B, int xd, int yd, int packed,
                                                               unsigned img_stride, unsigned plane_bytes, unsigned poly_bytes)
 {
@@ -296,8 +316,8 @@ __global__ void __launch_bounds__(256) limb_pack_rows1_kernel(const u64 *x, i8 *
         *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(st + (size_t)run * (RG * 32) + part * 16);
     }
 }
-// NTT-form weights w [F][1][xf][yf][k][n] -> Wl1 [slot][7 planes][32 filters][64 taps], tap = kx*8 + ky (pre-zeroed).  (No 2^64 factor since round 4: the kernel's reduction
-// folds, it no longer divides by 2^64.)
+// NTT-form weights w [F][1][xf][yf][k][n] -> Wl1 [slot][7 planes][32 filters][64 taps], tap = kx*8 + ky (pre-zeroed).  (No 2^64 factor since round 4: the
+// kernel's reduction folds, it no longer divides by 2^64.)
 __global__ void __launch_bounds__(64) limb_pack_w1_kernel(const u64 *w, i8 *wl, const ModParams *mods, int n, int k, int F, int xf, int yf)
 {
     const int sblocks = n / 64;
@@ -312,14 +332,16 @@ __global__ void __launch_bounds__(64) limb_pack_w1_kernel(const u64 *w, i8 *wl, 
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------------------------------
-// per (slot, image): 7 planes x 2 polys x (xd rows + 1) x 32 bytes: the extra row puts the two polys' blocks 8 LDS banks apart (xd = 28: 896-byte blocks would be
-// 224 dwords = 0 banks apart, and the window reads of a pixel's two polys -- neighbouring lanes -- a two-way conflict each); it also takes the last window's read-ahead
+// per (slot, image): 7 planes x 2 polys x (xd rows + 1) x 32 bytes: the extra row puts the two polys' blocks 8 LDS banks apart (xd = 28: 896-byte blocks would
+// be 224 dwords = 0 banks apart, and the window reads of a pixel's two polys -- neighbouring lanes -- a two-way conflict each); it also takes the last window's
+// read-ahead
 static inline unsigned conv1_poly_bytes(int xd) { return ((unsigned)xd + 1) * 32; }
 static inline unsigned conv1_img_stride(int xd) { const unsigned b = NPL * 2 * conv1_poly_bytes(xd); return (b + 1023) / 1024 * 1024; }
 bool k_limb_conv1_shape(const crc_ctx *c, int zd, int xd, int yd, int xs, int ys_, int xf, int yf, int nf)
 {
     if (zd != 1 || xf > 8 || yf > 8 || nf > 32 || yd > 32 || c->n < 64 || c->k > MAXK) return false;
-    // the epilogue's bounds: the folding reduction wants q = 2^b - f with 53 <= b <= 55 and a small f (limbred.h conv1_fold_ok); 7 balanced digits with |top digit| <= 64 need q < 2^55
+    // the epilogue's bounds: the folding reduction wants q = 2^b - f with 53 <= b <= 55 and a small f (limbred.h conv1_fold_ok); 7 balanced digits with |top
+    // digit| <= 64 need q < 2^55
     for (int i = 0; i < c->k; i++) if (!conv1_fold_ok(c->tabs[i].m.q, c->tabs[i].m.bits, fold_constant(c->tabs[i].m.q, c->tabs[i].m.bits))) return false;
     const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys_ + 1;
     if (xo * yo > 1024) return false;                          // (the kernel's reciprocal division of a pixel index by yo <= 32 is exact below 2048)
@@ -331,7 +353,8 @@ size_t k_limb_conv1_image_bytes(const crc_ctx *c, int B, int xd) { return (size_
 
 static void conv1_tables(const crc_ctx *c, Conv1Args &a)      // limbred.h: accumulator biases and q^-1 mod 2^64 per modulus
 {
-    for (int i = 0; i < c->k; i++) { conv1_bias_table(c->tabs[i].m.q, a.acc0[i]); a.qbits[i] = c->tabs[i].m.bits; a.qfold[i] = fold_constant(c->tabs[i].m.q, c->tabs[i].m.bits); }
+    for (int i = 0; i < c->k; i++) { conv1_bias_table(c->tabs[i].m.q, a.acc0[i]); a.qbits[i] = c->tabs[i].m.bits;
+        a.qfold[i] = fold_constant(c->tabs[i].m.q, c->tabs[i].m.bits); }
 }
 
 int k_limb_conv1_pack_weights(crc_ctx *c, const u64 *w, i8 *wl, int nf, int xf, int yf, hipStream_t st)
@@ -344,7 +367,8 @@ int k_limb_conv1_pack_weights(crc_ctx *c, const u64 *w, i8 *wl, int nf, int xf, 
 }
 // x: B NTT-form one-channel images; xr: k_limb_conv1_image_bytes of scratch; result either images b0 .. b0 + B of a limb tensor of Bout images (xl_out,
 // [slot][Bout][7][P][2][32]) or slot-major u64 (ys, [slot][B][F][P][2])
-int k_limb_conv1(crc_ctx *c, const u64 *x, bool packed, i8 *xr, const i8 *wl, u64 *ys, i8 *xl_out, int Bout, int b0, const u64 *bias_ntt, int B, int xd, int yd, int xs, int ys_,
+int k_limb_conv1(crc_ctx *c, const u64 *x, bool packed, i8 *xr, const i8 *wl, u64 *ys, i8 *xl_out, int Bout, int b0, const u64 *bias_ntt, int B, int xd,
+    int yd, int xs, int ys_,
                  int xf, int yf, int nf, hipStream_t st)
 {
     if (B == 0) return CRC_OK;
@@ -352,21 +376,24 @@ int k_limb_conv1(crc_ctx *c, const u64 *x, bool packed, i8 *xr, const i8 *wl, u6
     const int xo = (xd - xf) / xs + 1, yo = (yd - yf) / ys_ + 1;
     Conv1Args a{};
     a.xr = xr; a.wl = wl; a.ys = ys; a.xl_out = xl_out; a.mods = c->d_mods; a.bias = bias_ntt;
-    a.n = c->n; a.k = c->k; a.B = B; a.Bout = Bout; a.b0 = b0; a.xd = xd; a.yo = yo; a.xs = xs; a.ystr = ys_; a.P = xo * yo; a.F = nf; a.mtiles = (2 * a.P + 15) / 16;
+    a.n = c->n; a.k = c->k; a.B = B; a.Bout = Bout; a.b0 = b0; a.xd = xd; a.yo = yo; a.xs = xs; a.ystr = ys_; a.P = xo * yo; a.F = nf;
+        a.mtiles = (2 * a.P + 15) / 16;
     a.poly_bytes = conv1_poly_bytes(xd); a.plane_bytes = 2 * a.poly_bytes; a.img_stride = conv1_img_stride(xd);
-    a.out_zdc = a.P > 1 ? k_limb_flat_zdc(nf) : 0;            // (the limb tensor of the convolution behind: its layout follows ITS channel count = this layer's filters)
+    // (the limb tensor of the convolution behind: its layout follows ITS channel count = this layer's filters)
+    a.out_zdc = a.P > 1 ? k_limb_flat_zdc(nf) : 0;
     a.out_img_bytes = a.out_zdc ? (unsigned)((NPL * 2 * a.P * a.out_zdc + 15) / 16 * 16) : (unsigned)(NPL * a.P * 2 * 32);
     a.narrow = c->tune.conv1_narrow != 0 && nf > 16 && nf <= 20 ? 1 : 0;
     conv1_tables(c, a);
     {
         const size_t blocks = (size_t)(c->n / RSL) * c->k * B * 2 * ((xd + RG - 1) / RG);
         if (blocks > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
-        hipLaunchKernelGGL(limb_pack_rows1_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, xr, c->d_mods, c->n, c->k, B, xd, yd, packed ? 1 : 0, a.img_stride, a.plane_bytes,
+        hipLaunchKernelGGL(limb_pack_rows1_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, xr, c->d_mods, c->n, c->k, B, xd, yd, packed ? 1 : 0,
+            a.img_stride, a.plane_bytes,
                            a.poly_bytes);
         HIPCHK(hipGetLastError());
     }
-    // waves per workgroup (8 or 12; wave w runs on SIMD w % 4 and takes row tiles w/2, w/2 + waves/2, ...): the count that loads the busiest SIMD least, 12 on a tie
-    // (a third wave per SIMD hides more of the epilogue behind the other waves' MFMAs)
+    // waves per workgroup (8 or 12; wave w runs on SIMD w % 4 and takes row tiles w/2, w/2 + waves/2, ...): the count that loads the busiest SIMD least, 12 on
+    // a tie (a third wave per SIMD hides more of the epilogue behind the other waves' MFMAs)
     auto busiest = [&](int nw) {
         int load[4] = {0, 0, 0, 0}, worst = 0;
         for (int w = 0; w < nw; w++) load[w & 3] += (a.mtiles - (w >> 1) + nw / 2 - 1) / (nw / 2);
@@ -374,7 +401,8 @@ int k_limb_conv1(crc_ctx *c, const u64 *x, bool packed, i8 *xr, const i8 *wl, u6
         return worst;
     };
     const int forced = c->tune.conv1_waves;     // tuning (tools/)
-    // (narrow second group: four of its waves + four or eight of the others, one or two heavy waves and one light wave per SIMD either way: 12, for the overlap)
+    // (narrow second group: four of its waves + four or eight of the others, one or two heavy waves and one light wave per SIMD either way: 12, for the
+    // overlap)
     const int nwaves = forced ? forced : a.narrow ? 12 : busiest(12) <= busiest(8) ? 12 : 8;
     const size_t lds = 2 * (size_t)a.img_stride + (xl_out ? a.out_img_bytes : 0);
     { const int rc = crc_ctx_ensure_lds(c, (const void *)mfma_conv1_kernel, lds); if (rc) return rc; }
