@@ -242,6 +242,14 @@ def test_baseline_ring_sizes_vs_oracle(n, q, t):
     d2 = E.upload(cts[:2]); E.add_plain(d2, d_dl, 2, 1, -1); E.multiply_plain(d2, d_w, 2, 1)
     want = np.stack([O.multiply_plain(O.sub_plain(cts[i], pl[i]), pl[i]) for i in range(2)])
     assert np.array_equal(E.download(d2, want.shape), want)
+    # one plaintext per GROUP of ciphertexts (group 2: ciphertexts 0, 1 take plaintext 0, ciphertext 2 plaintext 1), with the dyadic product inside the forward
+    # transform's last loop (round 5, the rings that have the wave-local kernel) and as a pass of its own (ntt_wave 0): the oracle's products both ways
+    want3 = np.stack([O.multiply_plain(cts[i], pl[i // 2]) for i in range(3)])
+    for wave in (0, -1):
+        E.set_tuning("ntt_wave", wave)
+        d3 = E.upload(cts); E.multiply_plain(d3, d_w, 3, 2)
+        assert np.array_equal(E.download(d3, want3.shape), want3), ("multiply_plain", wave)
+    E.set_tuning("ntt_wave", -1)
     d_evk = E.upload(evk); d_work = E.alloc(E.square_relin_work_bytes(3)); d_y = E.alloc(cts.nbytes)
     E.square_relin(d, 3, d_evk, d_y, d_work)
     got = E.download(d_y, cts.shape)
