@@ -164,6 +164,14 @@ def load():
     L.crc_encrypt_dev_forms.argtypes = [VP, VP, VP, SZ, u64, ctypes.c_int, VP, VP, VP]
     L.crc_encrypt_dev_key_forms.argtypes = [VP, VP, VP, SZ, PB, u64, ctypes.c_int, VP, VP, VP]
     L.crc_encrypt_dev_noise_thresholds.restype = None; L.crc_encrypt_dev_noise_thresholds.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+    L.crc_decrypt_dev_work_bytes.restype = SZ; L.crc_decrypt_dev_work_bytes.argtypes = [VP, SZ, CI, CI]
+    L.crc_decrypt_dev.argtypes = [VP, VP, VP, SZ, CI, CI, VP, VP, VP]
+    L.crc_decode_dev.argtypes = [VP, VP, SZ, VP, VP]
+    L.crc_encode_dev_f32.argtypes = [VP, VP, SZ, VP, VP]
+    L.crc_encode_dev_f64.argtypes = [VP, VP, SZ, VP, VP]
+    L.crc_refresh_dev_work_bytes.restype = SZ; L.crc_refresh_dev_work_bytes.argtypes = [VP, SZ, CI]
+    L.crc_refresh_dev.argtypes = [VP, VP, VP, VP, SZ, CI, u64, CI, VP, VP, VP, VP]
+    L.crc_refresh_dev_key.argtypes = [VP, VP, VP, VP, SZ, CI, PB, u64, CI, VP, VP, VP, VP]
     L.crc_comm_unique_id.argtypes = [PB]
     L.crc_comm_create.argtypes = [VP, CI, CI, PB, ctypes.POINTER(VP)]
     L.crc_comm_create_all.argtypes = [ctypes.POINTER(VP), CI, ctypes.POINTER(VP)]
@@ -520,6 +528,31 @@ class Engine:
     def encrypt_dev_key_forms(self, d_pk, d_plain, count, key, stream_base, out_form, d_ct, d_work):
         _chk(self.L.crc_encrypt_dev_key_forms(self.c, self.p(d_pk), self.p(d_plain), count, self._key(key), stream_base, out_form, self.p(d_ct),
                                               self.p(d_work), self.stream), "crc_encrypt_dev_key_forms")
+
+    # ---- Decryptor::decrypt / FractionalEncoder / the refresh of Network::forward on the device (kernels_decrypt.hip)
+    def decrypt_dev_work_bytes(self, count, size=2, in_form=COEFF):
+        return self.L.crc_decrypt_dev_work_bytes(self.c, count, size, in_form)
+
+    def decrypt_dev(self, d_sk, d_ct, count, d_plain, d_work, size=2, in_form=COEFF):
+        _chk(self.L.crc_decrypt_dev(self.c, self.p(d_sk), self.p(d_ct), count, size, in_form, self.p(d_plain), self.p(d_work), self.stream), "crc_decrypt_dev")
+
+    def decode_dev(self, d_plain, count, d_out):
+        _chk(self.L.crc_decode_dev(self.c, self.p(d_plain), count, self.p(d_out), self.stream), "crc_decode_dev")
+
+    def encode_dev(self, d_values, count, d_plain, f64=False):
+        f = self.L.crc_encode_dev_f64 if f64 else self.L.crc_encode_dev_f32
+        _chk(f(self.c, self.p(d_values), count, self.p(d_plain), self.stream), "crc_encode_dev")
+
+    def refresh_dev_work_bytes(self, count, in_form=COEFF):
+        return self.L.crc_refresh_dev_work_bytes(self.c, count, in_form)
+
+    def refresh_dev(self, d_sk, d_pk, d_ct_in, count, seed, d_ct_out, d_work, in_form=COEFF, out_form=COEFF, d_values=None, key=None, stream_base=0):
+        if key is None:
+            _chk(self.L.crc_refresh_dev(self.c, self.p(d_sk), self.p(d_pk), self.p(d_ct_in), count, in_form, seed, out_form, self.p(d_ct_out), self.p(d_values),
+                                        self.p(d_work), self.stream), "crc_refresh_dev")
+        else:
+            _chk(self.L.crc_refresh_dev_key(self.c, self.p(d_sk), self.p(d_pk), self.p(d_ct_in), count, in_form, self._key(key), stream_base, out_form,
+                                            self.p(d_ct_out), self.p(d_values), self.p(d_work), self.stream), "crc_refresh_dev_key")
 
     def encrypt_dev_noise_thresholds(self):
         out = (ctypes.c_uint64 * 19)()

@@ -450,6 +450,63 @@ extern "C" int crc_encrypt_dev_forms(crc_ctx *c, const uint64_t *d_pk, const uin
     return k_encrypt(c, d_pk, d_plain, count, chacha_seed_key(seed), 0, d_ct, w, S(stream), out_form == CRC_NTT);
 }
 extern "C" void crc_encrypt_dev_noise_thresholds(uint64_t *h_out19) { if (h_out19) k_encrypt_cdt(h_out19); }
+
+// ---- Decryptor::decrypt, FractionalEncoder and the refresh of Network::forward on the device (kernels_decrypt.hip) ----
+static bool ct_form_ok(int f) { return f == CRC_COEFF || f == CRC_NTT; }
+extern "C" size_t crc_decrypt_dev_work_bytes(const crc_ctx *c, size_t count, int size, int in_form)
+{
+    return c && ct_form_ok(in_form) ? 8 * k_decrypt_work_words(c, count, size, in_form == CRC_NTT) + 256 : 0;
+}
+extern "C" int crc_decrypt_dev(crc_ctx *c, const uint64_t *d_sk, const uint64_t *d_ct, size_t count, int size, int in_form, uint64_t *d_plain, void *d_work,
+                               void *stream)
+{
+    CHECK_CTX(c); if (!d_sk || !d_ct || !d_plain || !d_work || !ct_form_ok(in_form)) return CRC_ERR_INVALID_ARGUMENT;
+    u64 *w = (u64 *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
+    return k_decrypt(c, d_sk, d_ct, count, size, in_form == CRC_NTT, d_plain, w, S(stream));
+}
+extern "C" int crc_decode_dev(crc_ctx *c, const uint64_t *d_plain, size_t count, double *d_out, void *stream)
+{
+    CHECK_CTX(c); if (!d_plain || !d_out) return CRC_ERR_INVALID_ARGUMENT;
+    return k_fra_decode(c, d_plain, count, d_out, S(stream));
+}
+extern "C" int crc_encode_dev_f32(crc_ctx *c, const float *d_values, size_t count, uint64_t *d_plain, void *stream)
+{
+    CHECK_CTX(c); if (!d_values || !d_plain) return CRC_ERR_INVALID_ARGUMENT;
+    return k_fra_encode(c, d_values, 0, count, d_plain, nullptr, S(stream));
+}
+extern "C" int crc_encode_dev_f64(crc_ctx *c, const double *d_values, size_t count, uint64_t *d_plain, void *stream)
+{
+    CHECK_CTX(c); if (!d_values || !d_plain) return CRC_ERR_INVALID_ARGUMENT;
+    return k_fra_encode(c, d_values, 1, count, d_plain, nullptr, S(stream));
+}
+// work of a refresh: [plaintexts [count][n]: decrypted, then re-encoded in place][the decryptor's rows, then the encryptor's samples]
+extern "C" size_t crc_refresh_dev_work_bytes(const crc_ctx *c, size_t count, int in_form)
+{
+    if (!c || !ct_form_ok(in_form)) return 0;
+    const size_t dec = k_decrypt_work_words(c, count, 2, in_form == CRC_NTT), enc = k_encrypt_work_words(c, count);
+    return 8 * (count * (size_t)c->n + (dec > enc ? dec : enc)) + 256;
+}
+static int refresh_impl(crc_ctx *c, const u64 *d_sk, const u64 *d_pk, const u64 *d_in, size_t count, int in_form, const ChaChaKey &key, u64 stream_base,
+                        int out_form, u64 *d_out, float *d_vals, void *d_work, hipStream_t st)
+{
+    u64 *plain = (u64 *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255), *w = plain + count * (size_t)c->n;
+    RUN(k_decrypt(c, d_sk, d_in, count, 2, in_form == CRC_NTT, plain, w, st));
+    RUN(k_fra_encode(c, plain, 2, count, plain, d_vals, st));            // decode -> float -> encode, row by row in place
+    return k_encrypt(c, d_pk, plain, count, key, stream_base, d_out, w, st, out_form == CRC_NTT);
+}
+extern "C" int crc_refresh_dev(crc_ctx *c, const uint64_t *d_sk, const uint64_t *d_pk, const uint64_t *d_ct_in, size_t count, int in_form, uint64_t seed,
+                               int out_form, uint64_t *d_ct_out, float *d_values_out, void *d_work, void *stream)
+{
+    CHECK_CTX(c); if (!d_sk || !d_pk || !d_ct_in || !d_ct_out || !d_work || !ct_form_ok(in_form) || !ct_form_ok(out_form)) return CRC_ERR_INVALID_ARGUMENT;
+    return refresh_impl(c, d_sk, d_pk, d_ct_in, count, in_form, chacha_seed_key(seed), 0, out_form, d_ct_out, d_values_out, d_work, S(stream));
+}
+extern "C" int crc_refresh_dev_key(crc_ctx *c, const uint64_t *d_sk, const uint64_t *d_pk, const uint64_t *d_ct_in, size_t count, int in_form,
+                                   const uint8_t *key, uint64_t stream_base, int out_form, uint64_t *d_ct_out, float *d_values_out, void *d_work, void *stream)
+{
+    CHECK_CTX(c); if (!d_sk || !d_pk || !d_ct_in || !d_ct_out || !d_work || !key || !ct_form_ok(in_form) || !ct_form_ok(out_form))
+        return CRC_ERR_INVALID_ARGUMENT;
+    return refresh_impl(c, d_sk, d_pk, d_ct_in, count, in_form, chacha_load_key(key), stream_base, out_form, d_ct_out, d_values_out, d_work, S(stream));
+}
 extern "C" int crc_square(crc_ctx *c, const uint64_t *d_x, size_t count, uint64_t *d_y3, void *d_work, void *stream)
 {
     CHECK_CTX(c); if (!d_x || !d_y3 || !d_work) return CRC_ERR_INVALID_ARGUMENT;

@@ -53,6 +53,11 @@ size_t k_encrypt_work_words(const crc_ctx *c, size_t cnt);
 struct ChaChaKey;
 int k_encrypt(crc_ctx *c, const u64 *pk, const u64 *plain, size_t cnt, const ChaChaKey &key, u64 stream_base, u64 *ct, u64 *work, hipStream_t st, bool out_ntt = false);
 void k_encrypt_cdt(u64 *out19);                 // the 19 thresholds of the device encryptor's noise magnitudes (tests)
+// kernels_decrypt.hip: Decryptor::decrypt and the fractional encoder on the device (the refresh of Network::forward)
+size_t k_decrypt_work_words(const crc_ctx *c, size_t cnt, int size, bool in_ntt);
+int k_decrypt(crc_ctx *c, const u64 *sk, const u64 *ct, size_t cnt, int size, bool in_ntt, u64 *plain, u64 *work, hipStream_t st);
+int k_fra_decode(crc_ctx *c, const u64 *plain, size_t cnt, double *out, hipStream_t st);
+int k_fra_encode(crc_ctx *c, const void *src, int mode, size_t cnt, u64 *plain, float *vals_out, hipStream_t st);
 
 // kernels_mfma.hip: conv / dense multiply-accumulate as an int8 limb GEMM on the matrix cores (operand form CRC_NTTL)
 bool   k_limb_supported(const crc_ctx *c, int T);

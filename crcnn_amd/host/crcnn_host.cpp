@@ -290,10 +290,28 @@ void setParameters(int poly_modulus, const vector<uint64_t> &coeff_modulus, uint
 static shared_ptr<DeviceBuffer> g_scratch;
 // limb-form tile buffers of the streamed layers (one set serves every streamed layer: they run one after the other)
 static shared_ptr<DeviceBuffer> g_wltile, g_xltile;
+// device copies of the client's keys (secret key for the refresh, public key for every encryption); uploaded on first use, dropped with the parameters
+// (the host vectors are public globals, as in the reference: a caller may assign them -- a fingerprint of the words decides whether the copy is current)
+static shared_ptr<DeviceBuffer> g_d_sk, g_d_pk;
+static uint64_t g_d_sk_fp = 0, g_d_pk_fp = 0;
+static const uint64_t *deviceKey(shared_ptr<DeviceBuffer> &d, uint64_t &fp, const vector<uint64_t> &h, const char *what)
+{
+    if (h.empty()) throw logic_error(string("setParameters() or initFromKeys() must be called first (") + what + ")");
+    uint64_t f = 0x9e3779b97f4a7c15ULL ^ h.size();
+    for (uint64_t w : h) f = (f ^ w) * 0xff51afd7ed558ccdULL + (f >> 29);
+    if (!d || d->bytes != h.size() * 8 || f != fp) {
+        fp = f;
+        d = make_shared<DeviceBuffer>(h.size() * 8);
+        chk(crc_memcpy_h2d(ctx(), d->ptr, h.data(), h.size() * 8, stream()), "crc_memcpy_h2d");
+        chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");           // the host vector may change after this call returns
+    }
+    return (const uint64_t *)d->ptr;
+}
 
 void delParameters()
 {
     ev_keys16.reset();
+    g_d_sk.reset(); g_d_pk.reset();
     g_scratch.reset(); g_wltile.reset(); g_xltile.reset();
     g_pool.flush();
     if (context) { crc_ctx_destroy(context); context = nullptr; }
@@ -327,6 +345,7 @@ void initFromKeys(string public_key_path, string secret_key_path, string evaluat
     if (dbc != 16) throw invalid_argument("evaluation keys must have decomposition_bit_count 16");
     chk(crc_memcpy_h2d(context, ev_keys16->ptr, ev_keys16_host.data(), ev_keys16_host.size() * 8, stream()), "crc_memcpy_h2d");
     chk(crc_stream_sync(context, stream()), "crc_stream_sync");
+    g_d_sk.reset(); g_d_pk.reset();
 }
 ciphertext3D encryptAndSaveImage(vector<float> image, int zd, int xd, int yd, string file_name)
 {   // globals.cpp:174-190: the ciphertexts back to back in Ciphertext::save format
@@ -355,15 +374,15 @@ static ciphertext3D encryptPixels(const vector<float> &px, int zd, int xd, int y
     const int n = N();
     vector<uint64_t> pl(px.size() * n);
     chk(crc_encode_f32(ctx(), px.data(), px.size(), pl.data(), nullptr), "crc_encode_f32");
-    DeviceBuffer d_pl(pl.size() * 8), d_pk(public_key.size() * 8), d_work(crc_encrypt_dev_work_bytes(ctx(), px.size()));
+    DeviceBuffer d_pl(pl.size() * 8), d_work(crc_encrypt_dev_work_bytes(ctx(), px.size()));
+    const uint64_t *d_pk = deviceKey(g_d_pk, g_d_pk_fp, public_key, "public key");
     chk(crc_memcpy_h2d(ctx(), d_pl.ptr, pl.data(), pl.size() * 8, stream()), "crc_memcpy_h2d");
-    chk(crc_memcpy_h2d(ctx(), d_pk.ptr, public_key.data(), public_key.size() * 8, stream()), "crc_memcpy_h2d");
     ciphertext3D out(1, zd, xd, yd, CRC_COEFF);
     if (g_det)
-        chk(crc_encrypt_dev(ctx(), (const uint64_t *)d_pk.ptr, (const uint64_t *)d_pl.ptr, px.size(), g_det_seed + 1000003 * (g_enc_counter + 1),
+        chk(crc_encrypt_dev(ctx(), d_pk, (const uint64_t *)d_pl.ptr, px.size(), g_det_seed + 1000003 * (g_enc_counter + 1),
                             (uint64_t *)out.buf->ptr, d_work.ptr, stream()), "crc_encrypt_dev");
     else                                                    // one keystream per ciphertext, never reused under this key
-        chk(crc_encrypt_dev_key(ctx(), (const uint64_t *)d_pk.ptr, (const uint64_t *)d_pl.ptr, px.size(), g_master_key, g_enc_counter,
+        chk(crc_encrypt_dev_key(ctx(), d_pk, (const uint64_t *)d_pl.ptr, px.size(), g_master_key, g_enc_counter,
                                 (uint64_t *)out.buf->ptr, d_work.ptr, stream()), "crc_encrypt_dev_key");
     g_enc_counter += px.size();
     chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
@@ -423,6 +442,44 @@ static shared_ptr<DeviceBuffer> &ensure(shared_ptr<DeviceBuffer> &b, size_t byte
 {
     if (!b || b->bytes < bytes) b = make_shared<DeviceBuffer>(bytes);
     return b;
+}
+
+// The client-side refresh of network.cpp:30-34 -- `floatCube image = decryptImage(input); input = encryptImage(image);` -- for a whole batch on the launch
+// stream (crc_refresh_dev: decrypt, decode, round to float, encode, encrypt; nothing crosses PCIe and the host does not wait).  Passes of bounded size share the
+// layers' scratch area.  Fresh randomness per ciphertext exactly as encryptImage draws it (deterministic only under setDeterministicSeed)
+ciphertext3D refreshImages(const ciphertext3D &t, int out_form, vector<float> *values)
+{
+    if (!t.buf) throw invalid_argument("refreshImages: empty tensor");
+    if ((t.form != CRC_COEFF && t.form != CRC_NTT) || (out_form != CRC_COEFF && out_form != CRC_NTT))
+        throw invalid_argument("refreshImages: ciphertext forms only (CRC_COEFF / CRC_NTT)");
+    const uint64_t *d_sk = deviceKey(g_d_sk, g_d_sk_fp, secret_key, "secret key"), *d_pk = deviceKey(g_d_pk, g_d_pk_fp, public_key, "public key");
+    ciphertext3D out(t.B, t.zd, t.xd, t.yd, out_form);
+    const size_t cnt = t.count(), one = crc_refresh_dev_work_bytes(ctx(), 1, t.form);
+    size_t pass = ((size_t)4 << 30) / (one ? one : 1);
+    if (pass < 1024) pass = 1024;
+    if (pass > cnt) pass = cnt;
+    ensure(g_scratch, crc_refresh_dev_work_bytes(ctx(), pass, t.form));
+    shared_ptr<DeviceBuffer> d_vals;
+    if (values) d_vals = make_shared<DeviceBuffer>(cnt * sizeof(float));
+    for (size_t o = 0; o < cnt; o += pass) {
+        const size_t c = min(pass, cnt - o);
+        const uint64_t *in = (const uint64_t *)((const char *)t.data() + o * ctBytes());
+        uint64_t *dst = (uint64_t *)((char *)out.data() + o * ctBytes());
+        float *dv = d_vals ? (float *)d_vals->ptr + o : nullptr;
+        if (g_det)
+            chk(crc_refresh_dev(ctx(), d_sk, d_pk, in, c, t.form, g_det_seed + 1000003 * (g_enc_counter + 1), out_form, dst, dv, g_scratch->ptr, stream()),
+                "crc_refresh_dev");
+        else
+            chk(crc_refresh_dev_key(ctx(), d_sk, d_pk, in, c, t.form, g_master_key, g_enc_counter, out_form, dst, dv, g_scratch->ptr, stream()),
+                "crc_refresh_dev_key");
+        g_enc_counter += c;
+    }
+    if (values) {
+        values->assign(cnt, 0.f);
+        chk(crc_memcpy_d2h(ctx(), values->data(), d_vals->ptr, cnt * sizeof(float), stream()), "crc_memcpy_d2h");
+        chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
+    }
+    return out;
 }
 
 static bool tooLargeForHbm(size_t weights)
@@ -966,7 +1023,7 @@ ciphertext3D Network::forward(ciphertext3D input)
     vector<char> limb(L, 0), streams(L, 0);
     // two-level chunking: the layers in front of the first dense layer on sub-batches of head_chunk images, the dense layers on the whole batch
     int split = L;
-    if (head_chunk > 0 && input.B > head_chunk && ntt_resident && max_num_of_reencryptions < 0 && layer_before_reenc < 0)
+    if (head_chunk > 0 && input.B > head_chunk && ntt_resident && max_num_of_reencryptions < 0)
         for (int i = 1; i < L; i++) if (dynamic_pointer_cast<FullyConnectedLayer>(layers[i])) { split = i; break; }
     const bool chunked = split < L;
     if (packable)
@@ -983,7 +1040,10 @@ ciphertext3D Network::forward(ciphertext3D input)
             }
         }
     for (int i = 0; i < L; i++) {
-        bool coeff = !ntt_resident || i == L - 1 || i + 1 == layer_before_reenc;
+        // the tensor in front of the refresh is decrypted as it stands (crc_refresh_dev takes either ciphertext form): an NTT-resident network stays resident
+        // across it, but no packed / limb hand-over spans it
+        const bool before_refresh = i + 1 == layer_before_reenc;
+        bool coeff = !ntt_resident || i == L - 1;
         // a conv / dense layer feeding another one hands its tensor over packed as well ... and a limb layer feeding a DENSE limb layer hands it over in limb
         // form (not across the chunk boundary: a dense layer's limb tensor is laid out for its whole batch, the chunks are assembled into it below)
         const bool to_dense_limb = i + 1 < L && limb[i] && !streams[i] && limb[i + 1] && dynamic_pointer_cast<FullyConnectedLayer>(layers[i + 1]) &&
@@ -992,9 +1052,8 @@ ciphertext3D Network::forward(ciphertext3D input)
         auto ci = dynamic_pointer_cast<ConvolutionalLayer>(layers[i]);
         auto cn = i + 1 < L ? dynamic_pointer_cast<ConvolutionalLayer>(layers[i + 1]) : nullptr;
         const bool to_conv_limb = ci && cn && ci->w_form == CRC_NTTL1 && cn->w_form == CRC_NTTL;
-        layers[i]->out_form = coeff ? CRC_COEFF : to_dense_limb && max_num_of_reencryptions < 0 ? CRC_NTTL : to_conv_limb && max_num_of_reencryptions < 0 ?
-            CRC_NTTLC
-                            : (packable && max_num_of_reencryptions < 0 && isMac(i) && isMac(i + 1) ? CRC_NTTP : CRC_NTT);
+        layers[i]->out_form = coeff ? CRC_COEFF : before_refresh ? CRC_NTT : to_dense_limb && max_num_of_reencryptions < 0 ? CRC_NTTL : to_conv_limb &&
+            max_num_of_reencryptions < 0 ? CRC_NTTLC : (packable && max_num_of_reencryptions < 0 && isMac(i) && isMac(i + 1) ? CRC_NTTP : CRC_NTT);
     }
     last_layer_ms.assign(L, 0.0);
     last_layer_launches.assign(L, 0);
@@ -1023,8 +1082,33 @@ ciphertext3D Network::forward(ciphertext3D input)
     };
     auto read_events = [&]() {
         for (auto &t : timed) { float ms = 0; chk(crc_event_elapsed_ms(ctx(), t.second.first, t.second.second, &ms), "crc_event_elapsed_ms");
-            last_layer_ms[t.first] += ms; }
+            (t.first < 0 ? last_reenc_ms : last_layer_ms[t.first]) += ms; }
         timed.clear();
+    };
+    // the refresh (network.cpp:30-34), timed like a layer: T_REENC of mainparams.cpp:81
+    last_reenc_values.clear();
+    auto refresh_into = [&](const ciphertext3D &in, int of) {
+        if (!keep_reenc_values) return refreshImages(in, of);
+        vector<float> v; ciphertext3D out = refreshImages(in, of, &v);
+        last_reenc_values.insert(last_reenc_values.end(), v.begin(), v.end());
+        return out;
+    };
+    auto run_refresh = [&](const ciphertext3D &in) {
+        const int of = ntt_resident && max_num_of_reencryptions < 0 ? CRC_NTT : CRC_COEFF;
+        OutHint hint(&act_slot[in.buf == act_slot[0] ? 1 : 0]);
+        if (time_with_events) {
+            void *e0 = next_event(), *e1 = next_event();
+            chk(crc_event_record(ctx(), e0, stream()), "crc_event_record");
+            ciphertext3D out = refresh_into(in, of);
+            chk(crc_event_record(ctx(), e1, stream()), "crc_event_record");
+            timed.push_back({-1, {e0, e1}});
+            return out;
+        }
+        auto r0 = chrono::high_resolution_clock::now();
+        ciphertext3D out = refresh_into(in, of);
+        chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
+        last_reenc_ms += chrono::duration<double, milli>(chrono::high_resolution_clock::now() - r0).count();
+        return out;
     };
     if (max_num_of_reencryptions >= 0) {                    // network.cpp:52-96
         int refreshes_left = max_num_of_reencryptions;
@@ -1033,12 +1117,7 @@ ciphertext3D Network::forward(ciphertext3D input)
             ciphertext3D output = run_layer(i, input);
             if (noiseBudget(output) <= 5) {
                 if (refreshes_left <= 0) throw OutOfBudgetException(i - 1);
-                auto r0 = chrono::high_resolution_clock::now();
-                vector<floatCube> imgs = decryptImages(input);
-                vector<ciphertext3D> enc; for (auto &im : imgs) enc.push_back(encryptImage(im));
-                input = stackImages(enc);
-                chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
-                last_reenc_ms += chrono::duration<double, milli>(chrono::high_resolution_clock::now() - r0).count();
+                input = run_refresh(input);
                 refreshes_left--;
                 i--;
                 continue;
@@ -1055,7 +1134,11 @@ ciphertext3D Network::forward(ciphertext3D input)
         for (int b0 = 0; b0 < B; b0 += head_chunk) {
             const int Bc = min(head_chunk, B - b0);
             ciphertext3D t = input.images(b0, Bc);
-            for (int i = 0; i < split; i++) { OutHint hint(&act_slot[t.buf == act_slot[0] ? 1 : 0]); t = run_layer(i, t); }
+            for (int i = 0; i < split; i++) {
+                if (i == layer_before_reenc) t = run_refresh(t);
+                OutHint hint(&act_slot[t.buf == act_slot[0] ? 1 : 0]); t = run_layer(i, t);
+            }
+            if (split == layer_before_reenc) t = run_refresh(t);        // in front of the first dense layer: chunk by chunk, before the chunks are assembled
             const size_t out_cts = (size_t)t.zd * t.xd * t.yd;
             if (!tail_in.buf) {         // kept across calls like the activation slots: next to 182 GiB of weights the pool has no room to hold it
                 OutHint hint(&tail_slot);
@@ -1072,14 +1155,9 @@ ciphertext3D Network::forward(ciphertext3D input)
         first = split;
     }
     for (int i = first; i < L; i++) {
-        if (i == layer_before_reenc) {                      // client-side refresh (needs the secret key), network.cpp:30-34; timed as T_REENC (:29-37)
-            auto r0 = chrono::high_resolution_clock::now();
-            vector<floatCube> imgs = decryptImages(input);
-            vector<ciphertext3D> enc; for (auto &im : imgs) enc.push_back(encryptImage(im));
-            input = stackImages(enc);
-            chk(crc_stream_sync(ctx(), stream()), "crc_stream_sync");
-            last_reenc_ms += chrono::duration<double, milli>(chrono::high_resolution_clock::now() - r0).count();
-        }
+        // client-side refresh (needs the secret key), network.cpp:30-34; timed as T_REENC (:29-37).  Under two-level chunking a refresh at or in front of the
+        // first dense layer has already run, chunk by chunk
+        if (i == layer_before_reenc && !(chunked && layer_before_reenc <= split)) input = run_refresh(input);
         // every layer but the last writes into one of the network's two activation slots (the one its input does not live in); the last layer's output -- ten
         // ciphertexts per image -- is the caller's own tensor, as in the reference
         if (i + 1 < L) { OutHint hint(&act_slot[input.buf == act_slot[0] ? 1 : 0]); input = run_layer(i, input); }

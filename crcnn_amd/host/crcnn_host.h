@@ -86,6 +86,10 @@ ciphertext3D encryptImage(floatCube image);                                     
 std::vector<floatCube> decryptImages(const ciphertext3D &encrypted);                     // one floatCube per image of the batch
 floatCube decryptImage(const ciphertext3D &encrypted_image);                             // globals.cpp:207-230 (B must be 1)
 int noiseBudget(const ciphertext3D &t, size_t index = 0);
+// decryptImage -> encryptImage for every image of a batch (the refresh Network::forward runs in front of layer_before_reenc, network.cpp:30-34), on the
+// device and on the launch stream: the tensor may be in coefficient or NTT form, comes back in `out_form` (CRC_COEFF / CRC_NTT) under fresh randomness, and
+// `values` (optional) receives the floats the client saw, [B][zd][xd][yd] -- asking for them makes the call wait for the stream
+ciphertext3D refreshImages(const ciphertext3D &encrypted, int out_form = CRC_COEFF, std::vector<float> *values = nullptr);
 
 // ---- layers (CrCNN/src/layer.h:10-31) ------------------------------------------------------------------------------
 class Layer {
@@ -304,6 +308,10 @@ public:
     // Layer::forward calls per layer in the last forward (two-level chunking: a head layer runs once per chunk)
     std::vector<int> last_layer_launches;
     double last_reenc_ms = 0.0;
+    // true: the floats the client saw at the refresh(es) of the last forward are kept (in the order the refreshes ran: chunk by chunk under two-level
+    // chunking); costs a stream synchronisation per refresh
+    bool keep_reenc_values = false;
+    std::vector<float> last_reenc_values;
     // Two-level chunking (> 0): the layers in front of the first dense layer run on sub-batches of `head_chunk` images, the dense layers once on the whole
     // batch -- a dense layer streams all of its weights per launch, so its time per image falls with the rows it is used for (PlainModelWoPad at n = 16384:
     // 6-image chunks fit beside 190 GiB of weights, fc3 wants 24+ images).  0: every layer on the whole batch

@@ -106,6 +106,52 @@ static int do_net3(int argc, char **argv)
     return 0;
 }
 
+// netr <model> <h5> <dir> <batch> <layer_before_reenc> <fuse 0|1> <head_chunk>: the reference's published configurations -- Network::forward WITH the client-side
+// refresh (network.cpp:30-34), now on the device (refreshImages).  <dir> holds params / evk / net_in as for `net` plus sk.u64 and pk.u64 (the client's keys).
+// Writes pre_<i>.u64 for the layers in front of the refresh (layer by layer, coefficient form: the reference's digests; unfused runs only), reenc_floats.f32
+// (the floats the client saw, per image), dec.u64 ([batch][10][n] decrypted output plaintexts), budget.u64, and prints the per-layer times with T_REENC
+static int do_netr(int argc, char **argv)
+{
+    if (argc < 9) return 1;
+    string model = argv[2], h5 = argv[3], dir = argv[4]; const int batch = atoi(argv[5]), reenc = atoi(argv[6]); const bool fuse = atoi(argv[7]) != 0;
+    const int head_chunk = atoi(argv[8]);
+    setDeterministicSeed(4242);
+    setup(dir);
+    secret_key = rd(dir + "/sk.u64"); public_key = rd(dir + "/pk.u64");
+    { auto evk = rd(dir + "/evk.u64");
+      ev_keys16 = make_shared<DeviceBuffer>(evk.size() * 8);
+      crc_memcpy_h2d(context, ev_keys16->ptr, evk.data(), evk.size() * 8, nullptr); crc_stream_sync(context, nullptr); }
+    CnnBuilder builder(h5);
+    Network net = builder.buildNetworkByName(model);
+    auto x = rd(dir + "/net_in.u64");
+    const ciphertext3D one = ciphertext3D::fromHost(x.data(), 1, 1, 28, 28);
+    if (!fuse) {
+        ciphertext3D t = one;
+        for (int i = 0; i < reenc; i++) { net.getLayer(i)->out_form = CRC_COEFF; t = net.getLayer(i)->forward(t); wr(dir + "/pre_" + to_string(i) + ".u64", t.toHost()); }
+    }
+    net.ntt_resident = true; net.layer_before_reenc = reenc; net.keep_reenc_values = true; net.head_chunk = head_chunk;
+    if (fuse) { const int removed = net.fuse(); fprintf(stderr, "fused: %d layers removed, %d left, refresh in front of layer %d\n", removed, net.getNumLayers(),
+        net.layer_before_reenc); }
+    vector<ciphertext3D> imgs(batch, one);
+    ciphertext3D out = net.forward(stackImages(imgs));
+    { ofstream f(dir + "/reenc_floats.f32", ios::binary); f.write((const char *)net.last_reenc_values.data(), net.last_reenc_values.size() * 4); }
+    vector<u64> h = out.toHost(), pl(out.count() * (size_t)crc_ctx_n(context)), bud;
+    if (crc_decrypt(context, secret_key.data(), h.data(), out.count(), 2, pl.data())) return 3;
+    for (size_t i = 0; i < out.count(); i++) bud.push_back((u64)noiseBudget(out, i));
+    wr(dir + "/dec.u64", pl); wr(dir + "/budget.u64", bud);
+    for (double ms : net.last_layer_ms) fprintf(stderr, "%.3f,", ms);
+    fprintf(stderr, " T_REENC %.3f\n", net.last_reenc_ms);
+    // a second forward draws fresh randomness: other ciphertexts, the same plaintexts
+    ciphertext3D out2 = net.forward(stackImages(imgs));
+    vector<u64> h2 = out2.toHost(), pl2(pl.size());
+    if (crc_decrypt(context, secret_key.data(), h2.data(), out2.count(), 2, pl2.data())) return 3;
+    if (h2 == h) { fprintf(stderr, "the refresh reused its randomness\n"); return 4; }
+    if (pl2 != pl) { fprintf(stderr, "second forward decrypts differently\n"); return 5; }
+    delParameters();
+    printf("netr ok\n");
+    return 0;
+}
+
 static vector<double> rdf(const string &p)
 {
     ifstream f(p, ios::binary); if (!f) { fprintf(stderr, "missing %s\n", p.c_str()); exit(2); }
@@ -389,6 +435,7 @@ int main(int argc, char **argv)
         if (!strcmp(argv[1], "bcast")) return do_bcast(argc, argv);
         if (!strcmp(argv[1], "net")) return do_net(argc, argv);
         if (!strcmp(argv[1], "net3")) return do_net3(argc, argv);
+        if (!strcmp(argv[1], "netr")) return do_netr(argc, argv);
         if (!strcmp(argv[1], "api")) return do_api(argc, argv);
         if (!strcmp(argv[1], "files")) return do_files(argc, argv);
         if (!strcmp(argv[1], "searchlogic")) return do_searchlogic(argc, argv);

@@ -403,6 +403,30 @@ int crc_encrypt_dev_forms(crc_ctx *ctx, const uint64_t *d_pk, const uint64_t *d_
  * encryptor.cpp:237-240): |e| = the number of these 19 thresholds T_a = floor(2^64 P(|e| <= a)) that a uniform 64-bit word reaches.  For tests. */
 void crc_encrypt_dev_noise_thresholds(uint64_t *h_out19);
 
+/* Decryptor::decrypt (SEAL decryptor.cpp:107-236) on the device: d_sk_ntt = the secret key of crc_keygen copied to the device ([k][n], NTT form), d_ct =
+ * [count][size][k][n] ciphertexts of `size` 2 or 3 in `in_form` CRC_COEFF or CRC_NTT (an NTT-resident tensor is decrypted as it stands: c0 + c1 s is formed in
+ * the NTT domain and ONE inverse transform per residue follows), d_plain = [count][n] plaintext coefficients below t -- the polynomial crc_decrypt and the
+ * reference produce, bit for bit (dot product with the secret key, inverse transform, BEHZ correction with the auxiliary prime gamma:
+ * util/baseconverter.cpp:744-797).  d_work: crc_decrypt_dev_work_bytes(count, size, in_form).  Asynchronous on `stream`. */
+size_t crc_decrypt_dev_work_bytes(const crc_ctx *ctx, size_t count, int size, int in_form);
+int crc_decrypt_dev(crc_ctx *ctx, const uint64_t *d_sk_ntt, const uint64_t *d_ct, size_t count, int size, int in_form, uint64_t *d_plain, void *d_work,
+                    void *stream);
+/* FractionalEncoder::decode / encode (encoder.cpp:1226-1270, 1013-1076; 64 integer + 32 fractional coefficients, base 3: CrCNN/src/globals.cpp:52) on the
+ * device: the doubles crc_decode returns for d_plain [count][n], and the dense plaintexts [count][n] crc_encode_f32 / _f64 make of the values -- the same IEEE
+ * operations in the same order as the host encoder, contraction off. */
+int crc_decode_dev(crc_ctx *ctx, const uint64_t *d_plain, size_t count, double *d_out, void *stream);
+int crc_encode_dev_f32(crc_ctx *ctx, const float *d_values, size_t count, uint64_t *d_plain, void *stream);
+int crc_encode_dev_f64(crc_ctx *ctx, const double *d_values, size_t count, uint64_t *d_plain, void *stream);
+/* The client-side refresh of Network::forward (CrCNN/src/network.cpp:30-34: `floatCube image = decryptImage(input); input = encryptImage(image)`,
+ * globals.cpp:207-230 and 144-157) for `count` ciphertexts at once, entirely on `stream`: decrypt -> decode -> float (globals.cpp:221 keeps floats) ->
+ * encode -> Encryptor::encrypt with fresh randomness (seed / key + stream_base as crc_encrypt_dev[_key]_forms).  in_form / out_form: CRC_COEFF or CRC_NTT.
+ * d_values_out (may be NULL): the `count` floats the client saw.  d_ct_out may be d_ct_in.  d_work: crc_refresh_dev_work_bytes(count, in_form). */
+size_t crc_refresh_dev_work_bytes(const crc_ctx *ctx, size_t count, int in_form);
+int crc_refresh_dev(crc_ctx *ctx, const uint64_t *d_sk_ntt, const uint64_t *d_pk, const uint64_t *d_ct_in, size_t count, int in_form, uint64_t seed,
+                    int out_form, uint64_t *d_ct_out, float *d_values_out, void *d_work, void *stream);
+int crc_refresh_dev_key(crc_ctx *ctx, const uint64_t *d_sk_ntt, const uint64_t *d_pk, const uint64_t *d_ct_in, size_t count, int in_form,
+                        const uint8_t *h_key, uint64_t stream_base, int out_form, uint64_t *d_ct_out, float *d_values_out, void *d_work, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * multi-GPU (SURVEY 8e / 8b `crc_broadcast_weights`).  The reference has no analogue: its only parallelism is the
  * std::thread fan-out inside a layer (convolutionalLayer.cpp:177-191).  Here a batch of encrypted images shards over the

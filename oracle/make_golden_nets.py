@@ -40,11 +40,18 @@ NETS = {
     # all eight primes of coeff_modulus_128(16384): what CrCNN's own setParameters(16384, t) picks.  424 GB of NTT-form weights: the engine streams them
     "wopad16384k8_t44": ("PlainModelWoPad", 16384, Q16384[:8], 1 << 44, 50),
 }
+# The reference's PUBLISHED configurations (Doc/Tesi.lyx:12404,12492 and :14701,15468), client-side refresh included: the committed
+# Network::forward refreshes in front of layer 6 (network.cpp:23) = bn2 of ApproxPlainModel; the thesis' PlainModelTiny run refreshes in front of fc3 (layer 4).
+# Digests of the layers in front of the refresh are bits; behind it the re-encryption is randomised, so the goldens hold the floats the client saw at the refresh
+# and the DECRYPTED outputs (plaintext polynomials + logits), which do not depend on the fresh noise.
+NETS["tiny2048r"] = ("PlainModelTiny", 2048, orc.COEFF_MODULUS_128[2048], 1 << 18, 1)
+NETS["approx4096r"] = ("ApproxPlainModel", 4096, orc.COEFF_MODULUS_128[4096], 1 << 29, 4)
+REENC = {"tiny2048r": 4, "approx4096r": 6}
 KEY_SEED, EVK_SEED, ENC_SEED, IMAGE_INDEX = 9000, 9001, 100000, 0
 # The bench-parameter sets take their keys and encrypted input image from the ENGINE's seeded client side (crc_keygen / crc_gen_evk /
 # crc_encrypt on the host, no GPU) with exactly the seeds bench.py uses for image 0 of rank 0: the product can then reproduce the golden
 # input without touching anything under oracle/, and bench.py compares its output digest with the reference's (`golden_match`).
-ENGINE_INPUTS = {"tiny4096_t32", "approx8192_t42", "approx8192k4_t42", "wopad16384_t44", "wopad16384k8_t44", "tiny1024_eng"}
+ENGINE_INPUTS = {"tiny4096_t32", "approx8192_t42", "approx8192k4_t42", "wopad16384_t44", "wopad16384k8_t44", "tiny1024_eng", "tiny2048r", "approx4096r"}
 ENG_KEY_SEED, ENG_EVK_SEED, ENG_ENC_SEED = 2024, 2025, 7000
 NETS["tiny1024_eng"] = ("PlainModelTiny", 1024, [0x7fffffff380001, 0x3fffffff000001], 1 << 32, 1)     # n = 1024: smallest ring in which the fractional encoding survives the four multiplicative levels
 
@@ -97,6 +104,8 @@ def make(name):
     with tempfile.TemporaryDirectory(dir="/tmp") as d:
         put(d, "params.u64", [n, O.k, t] + list(q)); put(d, "evk.u64", evk); put(d, "sk.u64", sk)
         put(d, "net_in_dims.u64", [1, 28, 28]); put(d, "net_in.u64", x)
+        if name in REENC:
+            put(d, "reenc.u64", [REENC[name]]); put(d, "pk.u64", pk)
         open(os.path.join(d, "topology.txt"), "w").write(topology(model, slices))
         for kind, lname, a in TOPOLOGIES[model]:
             for suffix in {"conv": ["weight", "bias"], "fc": ["weight", "bias"], "bn": ["running_mean", "running_var"]}.get(kind, []):
@@ -110,6 +119,14 @@ def make(name):
                  logits=[float(v) for v in get(d, "ref_net_logits.u64").view(np.float64)],
                  budget=[int(v) for v in get(d, "ref_net_budget.u64")],
                  out_sha256=hashlib.sha256(out.tobytes()).hexdigest(), ref_wall_s=round(time.time() - t0, 1), ref_threads=8)
+        if name in REENC:
+            fl = get(d, "ref_reenc_floats.u64").astype(np.uint32).view(np.float32)
+            dec = get(d, "ref_net_dec.u64", (10, n))
+            g.update(layer_before_reenc=REENC[name], reenc_floats_bits=[int(v) for v in fl.view(np.uint32)],
+                     reenc_floats_sha256=hashlib.sha256(fl.tobytes()).hexdigest(), ref_reenc_s=float(get(d, "ref_reenc_us.u64")[0]) / 1e6,
+                     dec_sha256=hashlib.sha256(dec.tobytes()).hexdigest())
+            del g["out_sha256"]                    # depends on the reference's own re-encryption randomness
+            np.savez_compressed(os.path.join(GOLD, f"net_{name}_dec.npz"), dec=dec)
     json.dump(g, open(os.path.join(GOLD, f"net_{name}.json"), "w"), indent=1)
     if n <= 256:
         np.savez_compressed(os.path.join(GOLD, f"net_{name}_out.npz"), out=out)

@@ -443,8 +443,28 @@ static int do_net()
     auto dims = rd("net_in_dims.u64");
     ciphertext3D t = to_tensor(rd("net_in.u64"), dims[0], dims[1], dims[2]);
     ofstream dg(DIR + "/ref_digests.txt");
-    // Network::forward (network.cpp:22-47) without the client-side refresh (needs the secret key)
+    // Network::forward (network.cpp:22-47).  The committed reference refreshes in front of layer 6 (network.cpp:23); here the layer comes from reenc.u64 (absent:
+    // no refresh) and the refresh is the reference's OWN decryptImage / encryptImage (globals.cpp:207-230, 144-157) under the keys of sk.u64 / pk.u64.  The floats
+    // the client sees go to ref_reenc_floats.u64 (one float's bits per word) and the time to ref_reenc_us.u64; digests after the refresh depend on the
+    // re-encryption's randomness, the decrypted outputs do not
+    auto reenc = rd("reenc.u64", false);
+    const int layer_before_reenc = reenc.empty() ? -1 : (int)reenc[0];
+    if (layer_before_reenc >= 0) {
+        PublicKey pk = load_pk(rd("pk.u64")); SecretKey sk2 = load_sk(rd("sk.u64"));
+        encryptor = new Encryptor(*context, pk); decryptor = new Decryptor(*context, sk2);
+    }
     for (int i = 0; i < net.getNumLayers(); i++) {
+        if (i == layer_before_reenc) {
+            auto r0 = chrono::high_resolution_clock::now();
+            floatCube image = decryptImage(t);
+            t = encryptImage(image);
+            auto r1 = chrono::high_resolution_clock::now();
+            vector<u64> fl;
+            for (auto &a : image) for (auto &b : a) for (float v : b) { uint32_t bits; memcpy(&bits, &v, 4); fl.push_back(bits); }
+            wr("ref_reenc_floats.u64", fl);
+            wr("ref_reenc_us.u64", vector<u64>{(u64)chrono::duration_cast<chrono::microseconds>(r1 - r0).count()});
+            fprintf(stderr, "refresh in front of layer %d done\n", i);
+        }
         auto t0 = chrono::high_resolution_clock::now();
         string lname;
         if (sliced.count(i)) {

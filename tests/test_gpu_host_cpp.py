@@ -248,3 +248,48 @@ def test_cpp_network_streamed_weights_equal_reference(name):
         assert all(sha(out[b]) == g["out_sha256"] for b in range(16))
     finally:
         del os.environ["CRC_STREAM_SHARE"]
+
+
+PUBLISHED = [n for n in ["tiny2048r", "approx4096r"] if os.path.exists(os.path.join(GOLD, f"net_{n}.json"))]
+
+
+def _run_refresh_config(name, batch, fuse, head_chunk):
+    g = load_net_golden(name)
+    O, sk, pk, evk, img, x = make_inputs(g)
+    d = tempfile.mkdtemp()
+    np.array([g["n"], len(g["q"]), g["t"]] + g["q"], dtype=np.uint64).tofile(os.path.join(d, "params.u64"))
+    evk.tofile(os.path.join(d, "evk.u64")); x.tofile(os.path.join(d, "net_in.u64")); sk.tofile(os.path.join(d, "sk.u64")); pk.tofile(os.path.join(d, "pk.u64"))
+    h5 = os.path.join(GOLD, "models", g["model"] + ".h5")
+    out = subprocess.run([DRIVER, "netr", g["model"], h5, d, str(batch), str(g["layer_before_reenc"]), "1" if fuse else "0", str(head_chunk)], capture_output=True,
+                         text=True)
+    assert out.returncode == 0 and "netr ok" in out.stdout, out.stderr[-2000:]
+    return g, d
+
+
+@pytest.mark.parametrize("name", PUBLISHED)
+@pytest.mark.parametrize("case", ["unfused", "fused-batch", "fused-chunked"])
+def test_cpp_published_configurations_with_refresh(name, case):
+    """The configurations the reference PUBLISHES (Doc/Tesi.lyx:12404 ApproxPlainModel n = 4096, k = 2, t = 2^29, refresh in front of bn2 -- the committed
+    network.cpp:23; :14701 PlainModelTiny n = 2048, k = 1, t = 2^18, refresh in front of fc3), Network::forward with the refresh on the device
+    (crc_refresh_dev).  Against the compiled reference running its OWN decryptImage / encryptImage at the same layer (oracle/make_golden_nets.py):
+    bits in front of the refresh (per-layer digests), the floats the client sees at the refresh (bit patterns), and -- the re-encryption being randomised --
+    the DECRYPTED output plaintexts behind it, polynomial for polynomial, with the reference's remaining noise budget.  Fused, in a batch, and with the head
+    layers chunked (the refresh then runs chunk by chunk in front of the first dense layer)."""
+    g = load_net_golden(name)
+    batch, fuse, chunk = {"unfused": (1, False, 0), "fused-batch": (5, True, 0), "fused-chunked": (5, True, 2)}[case]
+    g, d = _run_refresh_config(name, batch, fuse, chunk)
+    n = g["n"]
+    if not fuse:
+        for i in range(g["layer_before_reenc"]):
+            assert sha(np.fromfile(os.path.join(d, f"pre_{i}.u64"), dtype=np.uint64)) == g["layers"][i]["sha256"], (name, i)
+    want_fl = np.array(g["reenc_floats_bits"], dtype=np.uint32)
+    fl = np.fromfile(os.path.join(d, "reenc_floats.f32"), dtype=np.uint32).reshape(batch, -1)
+    assert all(np.array_equal(fl[b], want_fl) for b in range(batch))
+    want_dec = np.load(os.path.join(GOLD, f"net_{name}_dec.npz"))["dec"]
+    dec = np.fromfile(os.path.join(d, "dec.u64"), dtype=np.uint64).reshape(batch, 10, n)
+    assert sha(want_dec) == g["dec_sha256"]
+    assert all(np.array_equal(dec[b], want_dec) for b in range(batch))
+    bud = np.fromfile(os.path.join(d, "budget.u64"), dtype=np.uint64).reshape(batch, 10)
+    assert int(bud.min()) >= min(g["budget"]) - 2 and int(bud.max()) <= max(g["budget"]) + 2, (bud, g["budget"])
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)

@@ -543,3 +543,125 @@ def test_device_encryptor_noise_law():
         cum += law[a] if a == 0 else 2 * law[a]
         assert abs(T[a] / 2.0 ** 64 - cum) < 1e-13, (a, T[a] / 2.0 ** 64, cum)
     E.close()
+
+
+def test_device_decryptor_matches_seal(gs):
+    """crc_decrypt_dev against SEAL's own Decryptor::decrypt outputs (ref_dec_in of the input ciphertexts, ref_dec_relin of SEAL's relinearised squares), from
+    coefficient form and from NTT form, and for SEAL's size-3 squares against the host decryptor (itself pinned by tests/test_abi_cpu.py and the oracle)."""
+    import crcnn_amd as ca
+    g, E = gs
+    n, k = E.n, E.k
+    # (ref_relin2: squares SEAL encrypted, squared and relinearised under keys its OWN KeyGenerator made -- ref_sk)
+    for cts, want, key in ((g["ct_in"], g["ref_dec_in"], "sk"), (g["ref_relin"], g.get("ref_dec_relin"), "sk"), (g["ref_relin2"], g["ref_dec_relin2"], "ref_sk"),
+                           (g["ref_sq"], None, "sk"), (g["ref_sq2"], None, "ref_sk")):
+        cnt, size = cts.shape[0], cts.shape[1]
+        d_sk = E.upload(g[key])
+        if want is None:
+            want = E.decrypt(g[key], cts, size=size)
+        d_pl = E.alloc(cnt * n * 8)
+        d_ct = E.upload(cts)
+        d_w = E.alloc(E.decrypt_dev_work_bytes(cnt, size, ca.COEFF))
+        E.decrypt_dev(d_sk, d_ct, cnt, d_pl, d_w, size=size, in_form=ca.COEFF)
+        assert np.array_equal(E.download(d_pl, (cnt, n)), want)
+        assert np.array_equal(E.download(d_ct, cts.shape), cts)            # the input is not modified
+        E.ntt_fwd(d_ct, cnt, size=size)
+        E.L.crc_memset(E.c, E.p(d_pl), 0xff, cnt * n * 8, E.stream)
+        d_w2 = E.alloc(E.decrypt_dev_work_bytes(cnt, size, ca.NTT))
+        E.decrypt_dev(d_sk, d_ct, cnt, d_pl, d_w2, size=size, in_form=ca.NTT)
+        assert np.array_equal(E.download(d_pl, (cnt, n)), want)
+
+
+def test_device_fractional_codec(gs):
+    """crc_decode_dev / crc_encode_dev_f32 / _f64 == the host encoder (pinned to SEAL's FractionalEncoder by ref_enc_floats / ref_decode in
+    tests/test_oracle_golden.py and tests/test_abi_cpu.py), bit for bit, on the golden floats, edge values and 20 000 random ones; and on SEAL's own vectors
+    where the golden set carries them."""
+    g, E = gs
+    n = E.n
+    if n <= 96:
+        pytest.skip("the fractional encoder needs n > 96")
+    rng = np.random.default_rng(17)
+    edge = np.array([0.0, -0.0, 0.5, -0.5, 1.5, -1.5, 2.5, 1 / 3, -1 / 3, 1e-9, -1e-9, 12345.678, -98765.4321, 3.0 ** -32, 0.49999997, 1e6 + 0.5, -1e6 - 0.25],
+                    dtype=np.float64)
+    vals64 = np.concatenate([np.asarray(g["floats"], dtype=np.float64), edge, rng.standard_normal(20000) * 10.0 ** rng.integers(-6, 5, 20000)])
+    vals32 = vals64.astype(np.float32)
+    for vals, f64 in ((vals32, False), (vals64, True)):
+        want, _ = E.encode(vals, dtype=np.float64 if f64 else np.float32)
+        d_v = E.upload(vals); d_p = E.alloc(vals.size * n * 8)
+        E.L.crc_memset(E.c, E.p(d_p), 0xff, vals.size * n * 8, E.stream)
+        E.encode_dev(d_v, vals.size, d_p, f64=f64)
+        got = E.download(d_p, (vals.size, n))
+        assert np.array_equal(got, want)
+        d_o = E.alloc(vals.size * 8)
+        E.decode_dev(d_p, vals.size, d_o)
+        dec = E.download(d_o, (vals.size,), dtype=np.float64)
+        host = np.array([E.decode(want[i]) for i in range(0, vals.size, 97)])
+        assert np.array_equal(dec[::97].view(np.uint64), host.view(np.uint64))
+    # arbitrary plaintexts (what a decryption at an exhausted budget hands the decoder): the same doubles as the host loop
+    junk = rng.integers(0, int(g["t"]), size=(64, n), dtype=np.uint64)
+    d_j = E.upload(junk); d_o = E.alloc(64 * 8)
+    E.decode_dev(d_j, 64, d_o)
+    assert np.array_equal(E.download(d_o, (64,), dtype=np.float64).view(np.uint64), np.array([E.decode(junk[i]) for i in range(64)]).view(np.uint64))
+    if "ref_enc_floats" in g:
+        fl = np.asarray(g["floats"], dtype=np.float64)
+        d_v = E.upload(fl); d_p = E.alloc(fl.size * n * 8)
+        E.encode_dev(d_v, fl.size, d_p, f64=True)
+        assert np.array_equal(E.download(d_p, (fl.size, n)), g["ref_enc_floats"])
+        d_o = E.alloc(fl.size * 8)
+        E.decode_dev(d_p, fl.size, d_o)
+        assert np.array_equal(E.download(d_o, (fl.size,), dtype=np.float64).view(np.uint64), np.asarray(g["ref_decode"], dtype=np.float64).view(np.uint64))
+
+
+@pytest.mark.parametrize("n,k,t", [(4096, 2, 1 << 29), (2048, 1, 1 << 18), (8192, 3, 1 << 42)])
+def test_device_refresh(n, k, t):
+    """crc_refresh_dev == the client-side refresh of Network::forward (network.cpp:30-34): the floats it reports are float(decode(decrypt(ct))) of the host
+    client, and every refreshed ciphertext decrypts -- under the ORACLE -- to encode(that float) with a fresh ciphertext's noise budget; all four combinations
+    of forms; in place; deterministic per seed and different across seeds."""
+    import crcnn_amd as ca
+    from oracle import orc
+    q = {2048: ca.default_coeff_modulus_128(2048), 4096: ca.default_coeff_modulus_128(4096), 8192: ca.default_coeff_modulus_128(8192)[:3]}[n]
+    E = ca.Engine(n, q, t, device=0)
+    O = orc.Oracle(n, q, t)
+    sk, pk = E.keygen(31)
+    rng = np.random.default_rng(9)
+    cnt = 40
+    vals = (rng.standard_normal(cnt) * 3).astype(np.float32)
+    pl, _ = E.encode(vals)
+    ct = E.encrypt(pk, pl, 5)
+    # give the inputs the shape of mid-network ciphertexts: products of two encodings (fraction digits spread over both ends of the polynomial)
+    w, _ = E.encode(np.float32([0.37]))
+    d_ct = E.upload(ct); d_w = E.alloc(E.k * n * 8); E.plain_to_ntt(E.upload(w), 1, d_w)
+    E.ntt_fwd(d_ct, cnt); E.multiply_plain_ntt(d_ct, d_w, cnt, cnt)
+    E.ntt_inv(d_ct, cnt)
+    ct = E.download(d_ct, (cnt, 2, k, n))
+    dec = E.decrypt(sk, ct)
+    want_vals = np.array([np.float32(E.decode(dec[i])) for i in range(cnt)], dtype=np.float32)
+    want_plain, _ = E.encode(want_vals)
+    d_sk, d_pk = E.upload(sk), E.upload(pk)
+    fresh_budget = O.noise_budget(sk, O.encrypt_many(pk, want_plain[:1], 3)[0])
+    outs = {}
+    for in_form in (ca.COEFF, ca.NTT):
+        d_in = E.upload(ct)
+        if in_form == ca.NTT: E.ntt_fwd(d_in, cnt)
+        for out_form in (ca.COEFF, ca.NTT):
+            d_out = E.alloc(cnt * 2 * k * n * 8); d_v = E.alloc(cnt * 4)
+            d_work = E.alloc(E.refresh_dev_work_bytes(cnt, in_form))
+            E.refresh_dev(d_sk, d_pk, d_in, cnt, 123, d_out, d_work, in_form=in_form, out_form=out_form, d_values=d_v)
+            got_vals = E.download(d_v, (cnt,), dtype=np.float32)
+            assert np.array_equal(got_vals.view(np.uint32), want_vals.view(np.uint32))
+            if out_form == ca.NTT: E.ntt_inv(d_out, cnt)
+            r = E.download(d_out, (cnt, 2, k, n))
+            assert np.array_equal(np.stack([O.decrypt(sk, r[i]) for i in range(cnt)]), want_plain)
+            assert min(O.noise_budget(sk, r[i]) for i in range(0, cnt, 7)) >= fresh_budget - 2
+            outs[(in_form, out_form)] = r
+    # the re-encryption's randomness is a function of the seed alone: same ciphertexts whatever the forms
+    assert all(np.array_equal(v, outs[(ca.COEFF, ca.COEFF)]) for v in outs.values())
+    d_in = E.upload(ct); d_work = E.alloc(E.refresh_dev_work_bytes(cnt, ca.COEFF))
+    E.refresh_dev(d_sk, d_pk, d_in, cnt, 124, d_in, d_work)                 # in place, another seed, no values wanted
+    r2 = E.download(d_in, (cnt, 2, k, n))
+    assert not np.array_equal(r2[:, 1], outs[(ca.COEFF, ca.COEFF)][:, 1])
+    assert np.array_equal(np.stack([O.decrypt(sk, r2[i]) for i in range(cnt)]), want_plain)
+    key = E.random_key()
+    E.refresh_dev(d_sk, d_pk, E.upload(ct), cnt, 0, d_in, d_work, key=key, stream_base=77)
+    r3 = E.download(d_in, (cnt, 2, k, n))
+    assert np.array_equal(np.stack([O.decrypt(sk, r3[i]) for i in range(cnt)]), want_plain)
+    E.close()
