@@ -59,8 +59,8 @@ def parse():
                     "images, every one checked against the compiled reference; 32 for approx8192; 12 for wopad16384, whose images are 784 MiB each)")
     ap.add_argument("--no-fuse", action="store_true", help="do not fold pooling / batch-norm layers (Network::fuse)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target size of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--also", default="auto", help="further workloads measured in the same invocation and reported under \"also\" (auto: approx8192 = BASELINE configs[2]/[3] and "
-                    "wopad16384 = configs[4]'s per-GPU share beside the tiny4096 headline; none: skip)")
+    ap.add_argument("--also", default="auto", help="further workloads measured in the same invocation and reported under \"also\" (auto: AUTO_ALSO below beside the tiny4096 "
+                    "headline -- BASELINE configs[2] and configs[4]'s per-GPU share, k = 4 at n = 8192, the no-MFMA pass, the reference's two published configurations; none: skip)")
     ap.add_argument("--also-steps", type=int, default=2)
     ap.add_argument("--also-batch", type=int, default=None)
     ap.add_argument("--python-twin", action="store_true", help="N = 1: also time the workload through the Python twin (netrun.py) and report it beside the C++ figure")
@@ -74,6 +74,11 @@ def parse():
                          "plaintexts per image + encryption on the device (auto: both for the tiny4096 headline and ciphertext for approx8192 of the default invocation, "
                          "none otherwise)")
     ap.add_argument("--stream-steps", type=int, default=2, help="passes over the batch of the streamed measurement")
+    ap.add_argument("--latency", default="auto", choices=["auto", "on", "off"], help="single-image latency lines (batch 1, a synchronisation per image) for the headline and the "
+                    "BASELINE configurations of the default invocation (auto: with the default invocation at N = 1)")
+    ap.add_argument("--weights-via", default="broadcast", choices=["broadcast", "floats"], help="N > 1: how every rank gets the encoded model -- broadcast: rank 0 encodes + "
+                    "transforms, Network::broadcastParameters sends the residues over RCCL; floats: every rank encodes + transforms from the model file itself (SURVEY 8e's "
+                    "alternative), only the evaluation keys and the checksums travel")
     ap.add_argument("--mnist-dir", default=os.environ.get("CRC_MNIST_DIR", ""), help="directory with t10k-images-idx3-ubyte (and t10k-labels-idx1-ubyte): when present the "
                     "distinct images are real MNIST test images and the line reports agreement with the float model's predictions (utils.cpp:20-53)")
     return ap.parse_args()
@@ -86,18 +91,26 @@ def sizes(args, cfg, batch=None):
     return B, C, G
 
 
-def run_host(args, cfg_name, steps, warmup, batch=None, device=0, ranks=None, stream="none"):
-    """one workload through crcnn_amd/lib/bench_host.  Returns (bench line dict, all checks ok).  ranks: benchkit.dist.HostRanks when this process is one of several
-    (one bench_host per GPU); only rank 0 gets a line back."""
-    import crcnn_amd as ca
-    from benchkit import cpu, geometry
+_INPUTS = {}        # the client side of the configuration measured last: keys, images, the encrypted inputs file (one configuration's inputs in /dev/shm at a time)
+
+
+def drop_inputs():
+    keep_dir = os.environ.get("CRC_BENCH_KEEP")
+    for c in _INPUTS.values():
+        if not keep_dir:
+            shutil.rmtree(c["work"], ignore_errors=True)
+    _INPUTS.clear()
+
+
+def client_inputs(args, cfg_name, cfg, q, D, rank, cores):
+    """keys + the D distinct encrypted images of (model, parameters, rank): made once and shared by the measurements of that parameter set that follow each other
+    (throughput, single-image latency, the no-matrix-core pass) -- the inputs are the same ciphertexts, and encrypting them is the longest untimed step"""
     from benchkit.client import Client
-    cfg = dict(CONFIGS[cfg_name])
-    B, C, G = sizes(args, cfg, batch)
-    q = cfg.get("q") or ca.default_coeff_modulus_128(cfg["n"])[:cfg["k"]]
-    D = max(1, min(args.distinct or cfg.get("distinct", 4), C * G, B))
-    rank, world = (ranks.rank, ranks.world) if ranks else (0, 1)
-    cores = max(1, cpu.host_cores() // (ranks.local_world if ranks else 1))
+    key = (cfg["model"], cfg["n"], tuple(int(v) for v in q), cfg["t"], rank)
+    c = _INPUTS.get(key)
+    if c and c["D"] >= D and c["mnist_dir"] == args.mnist_dir:
+        return c, True
+    drop_inputs()
     t_client = time.time()
     client = Client(cfg, q, rank=rank)
     imgs, mnist = client.images_or_mnist(D, args.mnist_dir)
@@ -107,17 +120,50 @@ def run_host(args, cfg_name, steps, warmup, batch=None, device=0, ranks=None, st
         work = os.path.join(keep_dir, cfg_name); os.makedirs(work, exist_ok=True)
     else:
         work = tempfile.mkdtemp(prefix="crc_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    x0_sha = client.encrypt_images(imgs, os.path.join(work, "inputs.u64"), threads=cores)
+    c = dict(client=client, imgs=imgs, mnist=mnist, work=work, x0_sha=x0_sha, D=D, mnist_dir=args.mnist_dir, client_s=time.time() - t_client)
+    _INPUTS[key] = c
+    return c, False
+
+
+def run_host(args, cfg_name, steps, warmup, batch=None, device=0, ranks=None, stream="none", over=None, extra=None, with_cpu=True):
+    """one workload through crcnn_amd/lib/bench_host.  Returns (bench line dict, all checks ok).  ranks: benchkit.dist.HostRanks when this process is one of several
+    (one bench_host per GPU); only rank 0 gets a line back.  over: chunk / tail / distinct of this run (default: the command line's, then the configuration's);
+    extra: further bench_host arguments (sync_each=1 ...)"""
+    import crcnn_amd as ca
+    from benchkit import cpu, geometry
+    cfg = dict(CONFIGS[cfg_name])
+    over = over or {}
+    B = batch or cfg["batch"]
+    C = min(over.get("chunk") or args.chunk or cfg["chunk"], B)
+    G = max(1, min(int(over.get("tail") or args.tail or cfg.get("tail", 1)), B // C))
+    q = cfg.get("q") or ca.default_coeff_modulus_128(cfg["n"])[:cfg["k"]]
+    D = max(1, min(over.get("distinct") or args.distinct or cfg.get("distinct", 4), C * G, B))
+    rank, world = (ranks.rank, ranks.world) if ranks else (0, 1)
+    cores = max(1, cpu.host_cores() // (ranks.local_world if ranks else 1))
+    keep_dir = os.environ.get("CRC_BENCH_KEEP")
+    ci, reused = client_inputs(args, cfg_name, cfg, q, D, rank, cores)
+    client, imgs, mnist, work, x0_sha = ci["client"], ci["imgs"][:D], ci["mnist"], ci["work"], ci["x0_sha"]
+    client.cfg = cfg                                                    # (shared inputs: this run's configuration decides what verify() requires)
+    if mnist is not None:
+        mnist = {k_: (v[:D] if isinstance(v, list) else v) for k_, v in mnist.items()}
+    client_s = 0.0 if reused else ci["client_s"]
     try:
-        x0_sha = client.encrypt_images(imgs, os.path.join(work, "inputs.u64"), threads=cores)
         ctw = 2 * cfg["k"] * cfg["n"]
         x0 = np.fromfile(os.path.join(work, "inputs.u64"), dtype=np.uint64, count=784 * ctw).reshape(1, 28, 28, 2, cfg["k"], cfg["n"])
-        client_s = time.time() - t_client
         exe = os.path.join(ROOT, "crcnn_amd", "lib", "bench_host")
         if not os.path.exists(exe):
             raise SystemExit("bench.py: crcnn_amd/lib/bench_host has not been built (python -c 'import __graft_entry__ as g; g.build()'); there is no fallback path")
         cmd = [exe, f"model={cfg['model']}", "h5=" + os.path.join(ROOT, "tests", "golden", "models", cfg["model"] + ".h5"), f"n={cfg['n']}", f"k={cfg['k']}", f"t={cfg['t']}",
                "q=" + ",".join(str(int(v)) for v in q), "inputs=" + os.path.join(work, "inputs.u64"), f"distinct={D}", f"batch={B}", f"chunk={C}", f"group={G}", f"steps={steps}",
                f"warmup={warmup}", "outputs=" + os.path.join(work, "outputs.u64"), f"fuse={0 if args.no_fuse else 1}", f"key_seed={KEY_SEED}", f"device={device}"]
+        if "reenc" in cfg:
+            cmd.append(f"reenc={cfg['reenc']}")
+        if "matrix_cores" in cfg:
+            cmd.append(f"matrix_cores={cfg['matrix_cores']}")
+        if ranks and args.weights_via != "broadcast":
+            cmd.append(f"weights_via={args.weights_via}")
+        cmd += [f"{k_}={v}" for k_, v in (extra or {}).items()]
         if ranks:
             cmd += [f"rank={rank}", f"world={world}", f"local_world={ranks.local_world}", "rendezvous=" + ranks.rendezvous_path(cfg_name)]
         modes = {"none": [], "both": ["ciphertext", "plaintext"]}.get(stream, [stream])
@@ -127,7 +173,7 @@ def run_host(args, cfg_name, steps, warmup, batch=None, device=0, ranks=None, st
                 cmd.append("plain_inputs=" + os.path.join(work, "plain_inputs.u64"))
             cmd += ["stream_inputs=" + ",".join(modes), f"stream_steps={max(1, args.stream_steps)}"]
         if keep_dir:
-            open(os.path.join(work, "cmd.txt"), "w").write(" ".join(cmd) + "\n")
+            open(os.path.join(work, f"cmd_{cfg_name}{'_b1' if B == 1 else ''}.txt"), "w").write(" ".join(cmd) + "\n")
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC (RCCL across processes)
         # A child that dies leaves the others inside a collective nobody will complete (ncclCommInitRank, the broadcast): the rank whose child failed drops a marker
@@ -143,27 +189,29 @@ def run_host(args, cfg_name, steps, warmup, batch=None, device=0, ranks=None, st
                 if (marker and os.path.exists(marker)) or time.time() > t_end:
                     proc.kill(); killed = True
         failed = None
-        if proc.returncode != 0:
+        # exit code 4 = the run completed but one of bench_host's own comparisons failed (a streamed or the last timed launch differs from the first): its JSON line is
+        # there and names the check -- that is a failed self-check of this rank (reported under "check", exit code 3 of this script), not a crash that stops the job
+        if proc.returncode not in (0, 4):
             failed = (f"bench.py: bench_host on rank {rank} was stopped because another rank's failed" if killed and marker and os.path.exists(marker) else
                       f"bench.py: bench_host failed on rank {rank} (exit {proc.returncode}): {err_s[-600:]}")
             if marker and not killed:
                 open(marker, "w").write(str(rank))
-
-        class _P:                                                   # (what the code below reads of a finished child)
-            returncode, stdout, stderr = proc.returncode, out_s, err_s
-        p = _P
+        r = outs = outs_pt = None
+        if failed is None:
+            try:                                                    # (a short outputs file or a broken line must not leave the other ranks waiting in ranks.any)
+                r = json.loads([ln for ln in out_s.splitlines() if ln.startswith("{")][-1])
+                outs = np.fromfile(os.path.join(work, "outputs.u64"), dtype=np.uint64).reshape(D, 10, 2, cfg["k"], cfg["n"])
+                if "plaintext" in modes:
+                    outs_pt = np.fromfile(os.path.join(work, "outputs.u64.streamed"), dtype=np.uint64).reshape(D, 10, 2, cfg["k"], cfg["n"])
+            except Exception as e:
+                failed = f"bench.py: rank {rank}: cannot read bench_host's results ({type(e).__name__}: {e}); stderr: {err_s[-400:]}"
         if ranks and ranks.any(failed is not None):                # every rank learns of a failure anywhere: nobody waits for a line that will not come
             raise SystemExit(failed or f"bench.py: bench_host failed on another rank (this is rank {rank})")
         if failed:
             raise SystemExit(failed)
-        r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
-        outs = np.fromfile(os.path.join(work, "outputs.u64"), dtype=np.uint64).reshape(D, 10, 2, cfg["k"], cfg["n"])
-        outs_pt = None
-        if "plaintext" in modes:
-            outs_pt = np.fromfile(os.path.join(work, "outputs.u64.streamed"), dtype=np.uint64).reshape(D, 10, 2, cfg["k"], cfg["n"])
-    finally:
-        if not keep_dir:
-            shutil.rmtree(work, ignore_errors=True)
+    except BaseException:
+        drop_inputs()
+        raise
     check, ok = client.verify(cfg_name, imgs, outs, x0_sha, golden=mnist is None)
     if mnist is not None:               # real test images: agreement of the decrypted predictions with the labels and with the float model's predictions the reference ships
         preds = client.last_predictions
@@ -194,16 +242,24 @@ def run_host(args, cfg_name, steps, warmup, batch=None, device=0, ranks=None, st
 
     # ---- per-layer figures and the roofline of the dominant kernel: algorithmic bytes per launch / measured launch duration
     L = r["layers"]
-    ms_per_layer = {nm: ms for nm, ms in zip(L, r["T_LAYER_ms_per_image"])}
+    reenc_at = r.get("layer_before_reenc", -1)                  # (index into the FUSED network's layers; -1: no refresh)
+    ms_per_layer = {}
+    for i, (nm, ms) in enumerate(zip(L, r["T_LAYER_ms_per_image"])):
+        if i == reenc_at:
+            ms_per_layer["T_REENC"] = r["T_REENC_ms_per_image"]     # the client-side refresh, where mainparams.cpp:81 puts its column
+        ms_per_layer[nm] = ms
     kernels = {nm: kn for nm, kn in zip(L, r["kernel_per_layer"]) if kn}
     plan = None if args.no_fuse else geometry.fused_plan(client.E, cfg["model"], names=L)
-    roofline, useful = None, {}
+    roofline, useful, layer_gbps = None, {}, {}
     if plan is not None and [pl[1] for pl in plan] == L:
         split = next((i for i, pl in enumerate(plan) if pl[0] == "fc" and i > 0), len(plan)) if G > 1 else len(plan)
         per_launch = lambda i: C * G if i >= split else C          # images per Layer::forward call (two-level chunking: the dense layers once per group)
         for i, (kind, name, a, ish, osh) in enumerate(plan):
             if kind in ("conv", "fc") and kernels.get(name, "").startswith("mfma_mac2w_kernel"):
                 useful[name] = round(1.0 / geometry.limb_exec_over_useful(kind, a, per_launch(i), int(np.prod(osh))), 4)
+        for i, (kind, name, a, ish, osh) in enumerate(plan):        # every layer call against HBM: algorithmic bytes / its measured duration
+            if r["layer_launch_ms"][i] > 0:
+                layer_gbps[name] = round(geometry.layer_bytes_and_macs(client.E, kind, a, ish, osh, per_launch(i))[0] / (r["layer_launch_ms"][i] * 1e-3) / 1e9, 1)
         dom = int(np.argmax(r["T_LAYER_ms_per_image"]))
         kind, name, a, ish, osh = plan[dom]
         CL, dur_ms = per_launch(dom), r["layer_launch_ms"][dom]
@@ -229,16 +285,43 @@ def run_host(args, cfg_name, steps, warmup, batch=None, device=0, ranks=None, st
                         kernel_timing="HIP events on the launch stream around the layer call, inside the timed region, averaged over its launches (Network::time_with_events); the call is "
                                       "the kernel named plus, where the neighbouring layer wants another operand form, one conversion kernel",
                         algorithmic_bytes_per_launch=int(alg_bytes), modmul_per_s=round(modmul_s, 1) if modmul_s else None)
+    # ---- the reference's published run of this configuration (thesis: one image on a 40-core Xeon), column by column; fused layers take the sum of their columns
+    published = None
+    if cfg.get("published") and not args.no_fuse:
+        from crcnn_amd.netrun import TOPOLOGIES
+        pub = cfg["published"]
+        cols = [c_ for c_ in pub["columns"] if c_ != "T_REENC"]
+        col_of = {nm: (cols[i], pub["seconds"][pub["columns"].index(cols[i])]) for i, (_, nm, _) in enumerate(TOPOLOGIES[cfg["model"]])}
+        rows_ = []
+        for nm, ms in ms_per_layer.items():
+            if nm == "T_REENC":
+                rows_.append(dict(columns="T_REENC", layer="refresh (decrypt + re-encrypt, network.cpp:30-34)", published_s=pub["seconds"][pub["columns"].index("T_REENC")], ours_ms=ms))
+            else:
+                parts = [col_of[p_] for p_ in nm.split("+")]
+                rows_.append(dict(columns="+".join(c_ for c_, _ in parts), layer=nm, published_s=round(sum(s_ for _, s_ in parts), 2), ours_ms=ms))
+        for rw in rows_:
+            rw["ratio"] = round(rw["published_s"] * 1e3 / rw["ours_ms"], 1) if rw["ours_ms"] > 0 else None
+        ours_s = 1.0 / r["images_per_s"]
+        published = dict(source=pub["source"], published_s_per_image=pub["total_s"], ours_s_per_image=round(ours_s, 6), vs_published=round(pub["total_s"] / ours_s, 1),
+                         refresh_share_of_image=round(r["T_REENC_ms_per_image"] / (ours_s * 1e3), 4), per_column=rows_,
+                         note="published: single-image latency on the thesis' CPU; ours: per-image time inside a batch on one MI355X (throughput), same parameters, same refresh point, "
+                              "decrypted outputs equal to the compiled reference's (check.golden_match)")
     cpu_line = None
-    if args.cpu_seconds > 0 and world == 1:                        # (the CPU baseline is timed on rank 0 at N = 1 only)
+    if with_cpu and args.cpu_seconds > 0 and world == 1:           # (the CPU baseline is timed on rank 0 at N = 1 only)
         evk = client.evaluation_keys() if any(pl[0] in ("square", "squarepool") for pl in (plan or [])) else None
-        cpu_line = cpu.cpu_baseline_reference(cfg, q, client.W, x0, cores, evk=evk) or cpu.cpu_baseline(cfg, q, client.W, x0, args.cpu_seconds)
+        # (--cpu-seconds >= 600 buys ONE WHOLE image through the compiled reference instead of the sampled pieces: minutes for PlainModelTiny at n = 4096 on 16 cores)
+        cpu_line = (cpu.cpu_baseline_reference(cfg, q, client.W, x0, cores, evk=evk, full_image=args.cpu_seconds >= 600) or
+                    cpu.cpu_baseline(cfg, q, client.W, x0, args.cpu_seconds))
         cpu_line["value"] = round(cpu_line["value"], 6); cpu_line["mac_per_s"] = round(cpu_line["mac_per_s"], 1)
         c1_path = os.path.join(ROOT, "tests", "golden", "c1_tiny4096_t32.json")
         if cfg_name == "tiny4096" and os.path.exists(c1_path):      # configs[0] measured in full in the build container (not extrapolated): oracle/make_c1.py
             c1f = json.load(open(c1_path))
-            cpu_line["c1_in_full"] = dict(images=len(c1f["images"]), images_per_s=c1f.get("images_per_s_adjusted", c1f["images_per_s"]), total_wall_s=c1f.get("total_wall_s_adjusted", c1f["total_wall_s"]),
+            full_ips = c1f.get("images_per_s_adjusted", c1f["images_per_s"])
+            cpu_line["c1_in_full"] = dict(images=len(c1f["images"]), images_per_s=full_ips, total_wall_s=c1f.get("total_wall_s_adjusted", c1f["total_wall_s"]),
                                           threads=c1f["ref_threads"], where="build container (8 cores), the compiled reference on 32 images: tests/golden/c1_tiny4096_t32.json")
+            # both figures side by side: the one measured in full (other machine, 8 cores) and this run's sample scaled to the same core count
+            cpu_line["value_measured_in_full_elsewhere"] = dict(images_per_s=full_ips, cores=c1f["ref_threads"], per_core=round(full_ips / c1f["ref_threads"], 7))
+            cpu_line["value_per_core"] = round(cpu_line["value"] / max(1, cpu_line["cores"]), 7)
     hbm = r["hbm"]
     line = {
         "metric": "encrypted images/sec", "value": round(r["images_per_s"], 4), "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": r["ms_per_step"],
@@ -246,10 +329,13 @@ def run_host(args, cfg_name, steps, warmup, batch=None, device=0, ranks=None, st
         "data": f"synthetic ({D} distinct MNIST-like encrypted images tiled to the batch: one launch of {C * G} images resident in HBM, re-read by every launch of the step; "
                 f"trained weights from {cfg['model']}.h5)",
         "config": {"workload": f"{cfg['model']}.h5 n={cfg['n']} k={cfg['k']} t=2^{cfg['t'].bit_length() - 1} batch={B}/GPU chunk={C}" + (f" (dense layers: {C * G})" if G > 1 else "") + f" ({cfg_name}, BASELINE configs)",
-                   "host": r["host"], "mode": "NTT-resident" + ("" if args.no_fuse else " + Network::fuse (conv/pool and batch-norm folding)"), "parallelism": f"image-sharded x{world}"},
-        "ms_per_layer": ms_per_layer, "mac_kernel_per_layer": kernels, "mfma_useful_frac_per_layer": useful, "roofline": roofline, "cpu_baseline": cpu_line, "check": dict(check, all_ok=bool(ok)),
+                   "host": r["host"], "mode": "NTT-resident" + ("" if args.no_fuse else " + Network::fuse (conv/pool and batch-norm folding)") +
+                   ("" if r.get("matrix_cores", True) else "; matrix_cores = false: every conv / dense layer on the vector-ALU kernel (north_star's no-MFMA path)") +
+                   (f"; client-side refresh in front of layer {cfg['reenc']} on the device (crc_refresh_dev)" if "reenc" in cfg else ""), "parallelism": f"image-sharded x{world}"},
+        "ms_per_layer": ms_per_layer, "mac_kernel_per_layer": kernels, "mfma_useful_frac_per_layer": useful, "layer_hbm_GBps": layer_gbps, "roofline": roofline, "cpu_baseline": cpu_line,
+        "check": dict(check, all_ok=bool(ok)), "vs_published": published,
         "setup_s": r["setup_s"], "client_setup_s": round(client_s, 1), "weight_broadcast": r.get("weight_broadcast"), "timing": r.get("timing"), "per_rank": r.get("per_rank"),
-        "streamed": streamed,
+        "streamed": streamed, "ms_per_image_sync_each": r.get("ms_per_image_sync_each"),
         "hbm_plan": dict(hbm, note="bytes on this rank: parameters = the layers' encoded weights in their kernels' operand forms (limb copies replace the canonical ones), activation_slots = "
                                    "the two ping-pong tensors Network::forward keeps + the dense layers' group input, work_buffer = the shared scratch of the layer calls, input_launch = the "
                                    "encrypted images of one launch"),
@@ -262,8 +348,28 @@ def twin_line(args, D_, cfg_name, steps, warmup, batch, full):
     return twin.run_config(args, D_, cfg_name, steps, warmup, batch=batch, chunk=args.chunk, full=full)
 
 
-ALSO_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "config", "data", "ms_per_layer", "mac_kernel_per_layer", "mfma_useful_frac_per_layer", "roofline",
-             "cpu_baseline", "check", "setup_s", "weight_broadcast", "per_rank", "streamed", "hbm_plan", "python_twin")
+ALSO_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "config", "data", "ms_per_layer", "mac_kernel_per_layer", "mfma_useful_frac_per_layer", "layer_hbm_GBps",
+             "roofline", "cpu_baseline", "check", "vs_published", "setup_s", "weight_broadcast", "per_rank", "streamed", "hbm_plan", "python_twin")
+
+# what the default invocation measures beside the tiny4096 headline, in this order (configurations that share a parameter set follow each other: they share the
+# encrypted inputs), with the steps / batch of each: the BASELINE configs ([2], [4]'s per-GPU share), CrCNN's own coefficient modulus at n = 8192 (k = 4), north_star's
+# no-MFMA path, and the reference's two PUBLISHED configurations with their client-side refresh
+AUTO_ALSO = [("tiny4096_valu", dict(steps=2)), ("approx8192", dict()), ("wopad16384", dict()), ("approx8192k4", dict(steps=1, batch=512, distinct=8, cpu=False)),
+             ("tiny2048r", dict(steps=2, cpu=False)), ("approx4096r", dict(steps=2, cpu=False))]
+# single-image latency (mainparams.cpp:85-112: the reference's whole usage model is one image at a time): bench_host batch=1 chunk=1, a synchronisation per image
+LATENCY_STEPS = {"tiny4096": 20, "approx8192": 20, "wopad16384": 5}
+
+
+def latency_line(args, cfg_name, device):
+    """one encrypted image at a time through the same network: Network::forward on a batch of ONE, the stream synchronised after every image.  Reports the latency,
+    the per-layer times, the multiply-accumulate kernel crc_plan_mac picks per layer at two rows per launch, and every layer call against the HBM roofline -- at one
+    image a dense layer is a pure weight stream (PlainModelTiny's fc3: 34 GB of NTT-form weights for 2 x 512 outputs)"""
+    ln, ok = run_host(args, cfg_name, LATENCY_STEPS.get(cfg_name, 10), 2, batch=1, device=device, over=dict(chunk=1, tail=1, distinct=1), extra=dict(sync_each=1), with_cpu=False)
+    lat = dict(workload=ln["config"]["workload"], latency_ms=ln["ms_per_image_sync_each"], images_timed=ln["steps"], ms_per_layer=ln["ms_per_layer"],
+               kernel_per_layer=ln["mac_kernel_per_layer"], layer_hbm_GBps=ln["layer_hbm_GBps"],
+               layer_hbm_frac={k_: round(v / HBM_PEAK_GBS, 4) for k_, v in ln["layer_hbm_GBps"].items()}, check=ln["check"], setup_s=ln["setup_s"],
+               how="bench_host batch=1 chunk=1 sync_each=1: wall clock around Network::forward + stream synchronisation per image, inputs resident; per-layer times from HIP events")
+    return lat, ok
 
 
 def main():
@@ -280,17 +386,18 @@ def main():
     if also == "auto":
         # the default invocation also measures BASELINE configs[2] (ApproxPlainModel, n = 8192, k = 3) and configs[4]'s per-GPU share (PlainModelWoPad, n = 16384, k = 4,
         # 1024 images) in the same process
-        also = "approx8192,wopad16384" if args.config == "tiny4096" and args.batch is None else "none"
+        also = ",".join(nm for nm, _ in AUTO_ALSO) if args.config == "tiny4096" and args.batch is None else "none"
     names = [] if also == "none" else also.split(",")
+    auto = dict(AUTO_ALSO) if args.also == "auto" else {}
+    latency_on = args.latency == "on" or (args.latency == "auto" and args.also == "auto" and args.config == "tiny4096" and args.batch is None and world == 1)
     if args.stream_inputs == "auto":
         args.stream_inputs = "both" if args.config == "tiny4096" and args.batch is None else "none"
     line, ok = None, True
     if world == 1 or not args.python_twin:
         ranks = bdist.HostRanks(args) if world > 1 else None
         local = int(os.environ.get("LOCAL_RANK", "0"))
-        if ranks:                                                   # (counting devices does not initialise the GPU; a rehearsal with more ranks than GPUs shares devices)
-            import torch
-            local %= max(1, torch.cuda.device_count())
+        if ranks and os.environ.get("CRC_COMM_TRANSPORT") == "shm":  # a rehearsal with more ranks than GPUs shares devices; the KFD topology is read, no HIP call is made
+            local %= max(1, bdist.gpu_count_without_hip())
         line, ok = run_host(args, args.config, args.steps, args.warmup, batch=args.batch, device=local, ranks=ranks, stream=args.stream_inputs)
         if args.python_twin and world == 1:
             D_ = bdist.Dist(args)
@@ -298,12 +405,35 @@ def main():
             line["python_twin"] = dict(value=tw["value"], ms_per_layer=tw["ms_per_layer"], check=tw["check"], vs_host=round(tw["value"] / line["value"], 4),
                                        reference_layer_structure=tw.get("reference_layer_structure"))
             ok = ok and ok2
+        latency = []
+        if latency_on and (args.config in LATENCY_STEPS or args.latency == "on"):
+            lat, ok2 = latency_line(args, args.config, local); latency.append(lat); ok = ok and ok2
         for nm in names:
-            second, ok2 = run_host(args, nm, args.also_steps, 0, batch=args.also_batch, device=local, ranks=ranks,
-                                   stream="ciphertext" if args.stream_inputs != "none" and nm == "approx8192" else "none")
+            o = auto.get(nm, {})
+            second, ok2 = run_host(args, nm, o.get("steps", args.also_steps), 0, batch=args.also_batch or o.get("batch"), device=local, ranks=ranks,
+                                   stream="ciphertext" if args.stream_inputs != "none" and nm == "approx8192" else "none",
+                                   over=dict(distinct=o.get("distinct")), with_cpu=o.get("cpu", True))
             ok = ok and ok2
             if line is not None:
                 line.setdefault("also", []).append({k_: second[k_] for k_ in ALSO_KEYS if k_ in second})
+            if latency_on and nm in LATENCY_STEPS:
+                lat, ok2 = latency_line(args, nm, local); latency.append(lat); ok = ok and ok2
+        drop_inputs()
+        if line is not None:
+            if latency:
+                line["latency"] = latency
+            # the driver's record keeps the contract keys, `config`, `roofline` and `cpu_baseline` whole: the figures a reader should not have to dig out of "also" /
+            # "streamed" / "latency" are summarised inside `config`
+            cfgd = line["config"]
+            if line.get("streamed"):
+                cfgd["streamed_images_per_s"] = {sm["mode"]: dict(images_per_s=round(sm["images_per_s"], 2), vs_resident=sm["vs_resident"], h2d_GBps=sm["h2d_GBps"]) for sm in line["streamed"]}
+            if latency:
+                cfgd["latency_ms_single_image"] = {lt["workload"].split(" (")[-1].split(",")[0]: lt["latency_ms"] for lt in latency}
+            if line.get("also"):
+                cfgd["also_summary"] = [dict(workload=a_["config"]["workload"], images_per_s=a_["value"], golden_match=a_["check"].get("golden_match"), all_ok=a_["check"].get("all_ok"),
+                                             roofline_frac=(a_.get("roofline") or {}).get("frac"), vs_published=(a_.get("vs_published") or {}).get("vs_published"),
+                                             streamed=[dict(mode=sm["mode"], images_per_s=round(sm["images_per_s"], 2), vs_resident=sm["vs_resident"]) for sm in (a_.get("streamed") or [])] or None)
+                                        for a_ in line["also"]]
         if ranks:
             ranks.close()
     else:

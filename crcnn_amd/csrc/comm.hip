@@ -15,6 +15,7 @@
 #include <cstring>
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/random.h>
 #include <sys/stat.h>
 #include <thread>
 #include <unistd.h>
@@ -84,8 +85,15 @@ extern "C" int crc_comm_unique_id(uint8_t *h_id)
     if (shm_wanted()) {                           // the "id" names a fresh shared-memory segment
         std::memset(h_id, 0, CRC_COMM_ID_BYTES);
         std::memcpy(h_id, kShmMagic, sizeof kShmMagic);
-        std::snprintf((char *)h_id + 8, 48, "/crc_comm_%ld_%llx", (long)getpid(),
-            (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count());
+        // an unguessable name, and the segment itself made HERE, exclusively (O_EXCL: a name somebody else pre-created is an error, never adopted) and sized; the
+        // ranks -- this one included -- open it without O_CREAT in crc_comm_create.  A fresh segment reads as zeros, which is the barrier's initial state
+        unsigned long long rnd[2] = {0, 0};
+        if (getrandom(rnd, sizeof rnd, 0) != (ssize_t)sizeof rnd) return CRC_ERR_COMM;
+        std::snprintf((char *)h_id + 8, 48, "/crc_comm_%016llx%016llx", rnd[0], rnd[1]);
+        const int fd = shm_open((const char *)h_id + 8, O_CREAT | O_EXCL | O_RDWR, 0600);
+        const bool ok = fd >= 0 && ftruncate(fd, (off_t)(sizeof(ShmSeg) + kShmStage)) == 0;
+        if (fd >= 0) close(fd);
+        if (!ok) { if (fd >= 0) shm_unlink((const char *)h_id + 8); return CRC_ERR_COMM; }
         return CRC_OK;
     }
     ncclUniqueId id;
@@ -110,9 +118,9 @@ extern "C" int crc_comm_create(crc_ctx *c, int world, int rank, const uint8_t *h
         crc_comm *cm = new crc_comm(); cm->world = world; cm->rank = rank; cm->device = c->device;
         std::snprintf(cm->shm_name, sizeof cm->shm_name, "%s", (const char *)h_id + 8);
         const size_t bytes = sizeof(ShmSeg) + kShmStage;
-        // every rank opens (creating if it is first) and sizes the segment: a fresh one reads as zeros, which is the barrier's initial state
-        const int fd = shm_open(cm->shm_name, O_CREAT | O_RDWR, 0600);
-        void *p = fd >= 0 && ftruncate(fd, (off_t)bytes) == 0 ? mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
+        // the segment exists (crc_comm_unique_id made and sized it): no rank creates it here
+        const int fd = shm_open(cm->shm_name, O_RDWR, 0);
+        void *p = fd >= 0 ? mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
         if (fd >= 0) close(fd);
         if (p == MAP_FAILED) { delete cm; return CRC_ERR_COMM; }
         cm->shm = (ShmSeg *)p;

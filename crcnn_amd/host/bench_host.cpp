@@ -4,24 +4,33 @@
 // Network::forward runs it.
 //
 //   bench_host model=<name> h5=<model.h5> n=<n> k=<k> t=<t> [q=<p0>,<p1>,..] inputs=<file> distinct=<D> batch=<B> chunk=<C> group=<G> steps=<K> warmup=<W>
-//   outputs=<file> [fuse=1]
+//              outputs=<file> [fuse=1] [matrix_cores=1] [reenc=<layer>]
 //
-// inputs  D encrypted images ([D][784][2][k][n] u64, coefficient form: bench.py's client side writes them), tiled to one launch of C * G images that every
-// chunk
-//          of the batch re-reads (the same bytes per image as a resident batch; bench.py states it under "data")
-// group    > 1: two-level chunking -- Network::forward gets C * G images with head_chunk = C: the layers in front of the first dense layer per chunk, the dense
-//          layers once per group
-// timing   W untimed passes over the batch, then K timed ones bracketed by stream synchronisations; per-layer times from HIP events on the launch stream
-//          (Network::time_with_events: no synchronisation between layers)
-// outputs  the 10 output ciphertexts of the first D images of an untimed launch ([D][10][2][k][n] u64): bench.py hashes them against the reference's goldens
-// and
-//          decrypts them Several ranks (world=<N> rank=<r> rendezvous=<file>; one process per GPU, started by bench.py -- the reference's driver has no
-//          counterpart: mainparams.cpp:64-116 runs one process): rank 0 makes the RCCL rendezvous id (crc_comm_unique_id) and writes it to <file>, every rank
-//          joins (crc_comm_create), the encoded model goes out once with Network::broadcastParameters (the ONE collective of the path), then every rank
-//          evaluates its own batch: no data-path collective.  The timed region is bracketed on every rank by an all-gather (the barrier) + stream
-//          synchronisation, the elapsed times are gathered and the line carries the MAX over ranks and the whole-job rate (all ranks' images / that time).
-//          launch_check=1: rendezvous through the file only (no GPU, no RCCL): the CPU-side test of the launcher. stream_inputs=ciphertext|plaintext: the input
-//          launch is not resident -- see stream_inputs below. Prints ONE JSON line on stdout.
+// inputs        D encrypted images ([D][784][2][k][n] u64, coefficient form: bench.py's client side writes them), tiled to one launch of C * G images that
+//               every chunk of the batch re-reads (the same bytes per image as a resident batch; bench.py states it under "data")
+// group         > 1: two-level chunking -- Network::forward gets C * G images with head_chunk = C: the layers in front of the first dense layer per chunk, the
+//               dense layers once per group
+// timing        W untimed passes over the batch, then K timed ones bracketed by stream synchronisations; per-layer times from HIP events on the launch stream
+//               (Network::time_with_events: no synchronisation between layers)
+// outputs       the 10 output ciphertexts of the first D images of an untimed launch ([D][10][2][k][n] u64): bench.py hashes them against the reference's
+//               goldens and decrypts them
+// matrix_cores  0: Network::matrix_cores = false -- every conv / dense layer on the vector-ALU kernel (mac3_kernel) and the row NTT: north_star's "no MFMA" path
+// reenc         >= 0: Network::layer_before_reenc (counted on the unfused network, as network.cpp:23 counts): the client-side refresh of network.cpp:30-34, on
+//               the device (refreshImages), under this process' seeded client keys; its time is reported as T_REENC (mainparams.cpp:81).  The re-encryption is
+//               randomised, so launches are compared through their DECRYPTED outputs
+// Several ranks (world=<N> rank=<r> rendezvous=<file>; one process per GPU, started by bench.py -- the reference's driver has no counterpart:
+//               mainparams.cpp:64-116 runs one process): rank 0 makes the RCCL rendezvous id (crc_comm_unique_id) and writes it to <file>, every rank joins
+//               (crc_comm_create), the encoded model goes out once with Network::broadcastParameters (the ONE collective of the path), then every rank
+//               evaluates its own batch: no data-path collective.  The timed region is bracketed on every rank by an all-gather (the barrier) + stream
+//               synchronisation, the elapsed times are gathered and the line carries the MAX over ranks and the whole-job rate (all ranks' images / that time).
+// weights_via   (world > 1) broadcast: rank 0 encodes + transforms the weights and Network::broadcastParameters sends them (default); floats: every rank
+//               encodes + transforms its own copy from the model file's floats, nothing but the evaluation keys' checksum crosses the wire (SURVEY 8e's
+//               "cheaper alternative to measure against")
+// sync_each     1: the stream is synchronised after every Network::forward and the wall time of forward + wait is reported (ms_per_image_sync_each): with
+//               batch=1 chunk=1 the single-image latency of mainparams.cpp:85-112's usage (one image at a time)
+// launch_check  1: rendezvous through the file only (no GPU, no RCCL): the CPU-side test of the launcher
+// stream_inputs ciphertext|plaintext: the input launch is not resident -- see stream_inputs below
+// Prints ONE JSON line on stdout.
 #include "crcnn_host.h"
 #include <chrono>
 #include <cstdio>
@@ -31,6 +40,8 @@
 #include <iostream>
 #include <map>
 #include <thread>
+#include <cerrno>
+#include <fcntl.h>
 #include <unistd.h>
 using namespace std;
 
@@ -41,8 +52,12 @@ static void rendezvous_id(const string &path, int rank, uint8_t *id, bool make_n
         if (make_nccl_id) { if (crc_comm_unique_id(id)) throw runtime_error("crc_comm_unique_id failed (rccl error " + to_string(crc_last_comm_error()) +
             ")"); }
         else { ifstream r("/dev/urandom", ios::binary); r.read((char *)id, CRC_COMM_ID_BYTES); }
+        // a fresh file nobody else can read, never through a symlink somebody planted (O_EXCL | O_NOFOLLOW, mode 0600); bench.py puts it into a 0700 directory
         const string tmp = path + ".tmp";
-        { ofstream o(tmp, ios::binary); o.write((const char *)id, CRC_COMM_ID_BYTES); if (!o) throw runtime_error("cannot write " + tmp); }
+        const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+        if (fd < 0) throw runtime_error("cannot create " + tmp + ": " + strerror(errno));
+        const bool wrote = write(fd, id, CRC_COMM_ID_BYTES) == CRC_COMM_ID_BYTES;
+        if (close(fd) || !wrote) throw runtime_error("cannot write " + tmp);
         if (rename(tmp.c_str(), path.c_str())) throw runtime_error("cannot rename " + tmp);
         return;
     }
@@ -84,6 +99,10 @@ int main(int argc, char **argv)
     const int n = (int)geti("n", 0), k = (int)geti("k", 0); const uint64_t t = strtoull(need("t").c_str(), 0, 0);
     const int distinct = (int)geti("distinct", 1), batch = (int)geti("batch", 1), head = (int)geti("chunk", 1), group = max(1, (int)geti("group", 1));
     const int steps = (int)geti("steps", 1), warmup = (int)geti("warmup", 0), fuse = (int)geti("fuse", 1);
+    const int reenc = (int)geti("reenc", -1), matrix_cores = (int)geti("matrix_cores", 1);
+    const int sync_each = (int)geti("sync_each", 0);
+    const string weights_via = a.count("weights_via") ? a["weights_via"] : "broadcast";
+    if (weights_via != "broadcast" && weights_via != "floats") { fprintf(stderr, "bench_host: weights_via= broadcast | floats\n"); return 1; }
     const int launch = head * group;                          // images per Network::forward
     // stream_inputs: after the resident measurement, `stream_steps` more passes in which every launch's images come over PCIe while the previous launch is
     // evaluated (mainparams.cpp:85-112 encrypts, evaluates and decrypts image after image).  ciphertext: 784 ciphertexts per image from page-locked host
@@ -131,6 +150,8 @@ int main(int argc, char **argv)
         if (world > 1) {
             uint8_t id[CRC_COMM_ID_BYTES];
             rendezvous_id(need("rendezvous"), rank, id, true);
+            // (tests: CRC_TEST_BREAK_COMM_RANK=<r> spoils rank r's copy of the id, so that its crc_comm_create fails while the others wait for it)
+            if (getenv("CRC_TEST_BREAK_COMM_RANK") && atoi(getenv("CRC_TEST_BREAK_COMM_RANK")) == rank) for (int i = 8; i < 40; i++) id[i] ^= 0x15;
             if (crc_comm_create(context, world, rank, id, &comm)) throw runtime_error("crc_comm_create failed (rccl error " +
                 to_string(crc_last_comm_error()) + ")");
         }
@@ -141,10 +162,12 @@ int main(int argc, char **argv)
             allgather(0, 0, 0, 0);
             const auto tb = chrono::high_resolution_clock::now();
             // rank 0 lifts + transforms the weights, everybody else receives them (checksums compared inside)
-            bcast_bytes = net.broadcastParameters(comm, 0);
+            bcast_bytes = net.broadcastParameters(comm, 0, weights_via == "floats");
             allgather(0, 0, 0, 0);
             bcast_s = chrono::duration<double>(chrono::high_resolution_clock::now() - tb).count();
         }
+        net.layer_before_reenc = reenc;                       // (before fuse(): the index follows the layers it counts)
+        net.matrix_cores = matrix_cores != 0;
         if (fuse) net.fuse();
         if (group > 1) net.head_chunk = head;
         net.time_with_events = true;
@@ -161,10 +184,18 @@ int main(int argc, char **argv)
             x = stackImages(tiled);
         }
         if (stream_mode.find("ciphertext") == string::npos) { h.clear(); h.shrink_to_fit(); }
+        // with a refresh in the network every launch draws fresh randomness: two launches are "the same" when their outputs DECRYPT to the same plaintexts
+        auto decrypted = [&](const vector<uint64_t> &cts) {
+            vector<uint64_t> pl((size_t)distinct * 10 * n);
+            if (crc_decrypt(context, secret_key.data(), cts.data(), (size_t)distinct * 10, 2, pl.data())) throw runtime_error("crc_decrypt");
+            return pl;
+        };
+        vector<uint64_t> first_dec;
         // untimed first launch: operand forms, module load; the distinct images' outputs
         {
             ciphertext3D y = net.forward(x);
             vector<uint64_t> yh = y.toHost();
+            if (reenc >= 0) first_dec = decrypted(yh);
             ofstream o(outputs, ios::binary); o.write((const char *)yh.data(), (streamsize)((size_t)distinct * 10 * ctw * 8));
             if (!o) throw runtime_error("cannot write " + outputs);
         }
@@ -182,13 +213,21 @@ int main(int argc, char **argv)
         const int launches = batch / launch;
         for (int s = 0; s < warmup; s++) for (int c = 0; c < launches; c++) net.forward(x);
         vector<double> tl(L, 0.0); vector<long long> calls(L, 0);
+        double t_reenc = 0.0;
+        double t_sync = 0.0;
         allgather(0, 0, 0, 0);                                    // barrier + stream synchronisation on every rank
         const auto t0 = chrono::high_resolution_clock::now();
         ciphertext3D y_last;
         for (int s = 0; s < steps; s++)
             for (int c = 0; c < launches; c++) {
+                const auto tf = chrono::high_resolution_clock::now();
                 y_last = net.forward(x);
+                if (sync_each) {                                  // latency of ONE launch as a caller sees it: forward + the wait for its last kernel
+                    if (crc_stream_sync(context, compute) < 0) throw runtime_error("crc_stream_sync");
+                    t_sync += chrono::duration<double, milli>(chrono::high_resolution_clock::now() - tf).count();
+                }
                 for (int i = 0; i < L; i++) { tl[i] += net.last_layer_ms[i]; calls[i] += net.last_layer_launches[i]; }
+                t_reenc += net.last_reenc_ms;
             }
         if (crc_stream_sync(context, compute) < 0) throw runtime_error("crc_stream_sync");
         const double dt = chrono::duration<double>(chrono::high_resolution_clock::now() - t0).count();
@@ -199,6 +238,7 @@ int main(int argc, char **argv)
             vector<uint64_t> yh = y_last.toHost(), ref((size_t)distinct * 10 * ctw);
             ifstream f(outputs, ios::binary); f.read((char *)ref.data(), (streamsize)(ref.size() * 8));
             timed_same = f && memcmp(yh.data(), ref.data(), ref.size() * 8) == 0;
+            if (reenc >= 0) timed_same = f && decrypted(yh) == first_dec && memcmp(yh.data(), ref.data(), ref.size() * 8) != 0;
             y_last = ciphertext3D();
         }
         const double images = (double)steps * launches * launch;
@@ -218,11 +258,15 @@ int main(int argc, char **argv)
             const bool pt = mode == "plaintext";
             const size_t unit = pt ? (size_t)784 * n : imgw;                       // words uploaded per image
             uint64_t *pinned = nullptr;
-            if (crc_host_alloc(context, (size_t)distinct * unit * 8, (void **)&pinned)) throw runtime_error("crc_host_alloc");
+            if (crc_host_alloc(context, (size_t)distinct * unit * 8, (void **)&pinned))
+                throw runtime_error("crc_host_alloc: " + to_string((size_t)distinct * unit * 8) + " bytes of page-locked host memory for the streamed inputs");
             if (pt) {
                 ifstream f(need("plain_inputs"), ios::binary); if (!f) throw runtime_error("cannot open plain_inputs");
                 f.read((char *)pinned, (streamsize)((size_t)distinct * unit * 8)); if (!f) throw runtime_error("short read: plain_inputs");
-            } else memcpy(pinned, h.data(), (size_t)distinct * unit * 8);
+            } else {
+                memcpy(pinned, h.data(), (size_t)distinct * unit * 8);
+                h.clear(); h.shrink_to_fit();                      // one copy of the distinct images in host memory, not two (ciphertext mode runs once)
+            }
             // (plaintext mode: the device encryptor leaves NTT-form ciphertexts -- crc_encrypt_dev_forms: three forward transforms per modulus, none back --
             // and the first layer skips the transform it runs on a coefficient-form image)
             const int xform = pt ? CRC_NTT : CRC_COEFF;
@@ -315,11 +359,13 @@ int main(int argc, char **argv)
                    (unsigned long long)per_rank[(size_t)r * 4 + 1], (unsigned long long)per_rank[(size_t)r * 4 + 2],
                        (unsigned long long)per_rank[(size_t)r * 4 + 3]);
         printf("], ");
-        if (comm) printf("\"weight_broadcast\": {\"via\": \"Network::broadcastParameters (crc_broadcast_weights: %s; per-rank checksums compared with the "
-            "root's)\", \"bytes\": %zu, "
+        if (comm) printf("\"weight_broadcast\": {\"weights_via\": %s, \"via\": \"Network::broadcastParameters (crc_broadcast_weights: %s; per-rank checksums "
+            "compared with the root's)\", \"bytes\": %zu, "
                          "\"seconds\": %.3f, \"GBps\": %.2f, \"seconds_include\": \"the root's lift + NTT of its plaintext weights, the per-rank checksums "
                              "and their all-gather\", "
-                         "\"host_threads_per_rank\": %d}, ", getenv("CRC_COMM_TRANSPORT") &&
+                         "\"host_threads_per_rank\": %d}, ", jstr(weights_via == "floats" ? "floats: every rank encodes + transforms the weights itself, only "
+                             "the evaluation keys are sent" : "broadcast: the root's encoded weights and the evaluation keys are sent").c_str(),
+                             getenv("CRC_COMM_TRANSPORT") &&
                              !strcmp(getenv("CRC_COMM_TRANSPORT"), "shm") ?
                          "shared-memory rehearsal transport" : "ncclBroadcast over RCCL in <= 1 GiB pieces", bcast_bytes, bcast_s, bcast_s > 0 ?
                              bcast_bytes / bcast_s / 1e9 : 0.0, crc_host_thread_limit());
@@ -335,7 +381,10 @@ int main(int argc, char **argv)
         for (int i = 0; i < L; i++) printf("%s%.4f", i ? ", " : "", calls[i] ? tl[i] / calls[i] : 0.0);
         printf("], \"layer_launches\": [");
         for (int i = 0; i < L; i++) printf("%s%lld", i ? ", " : "", calls[i]);
-        printf("], \"layer_timing\": \"HIP events on the launch stream around every Layer::forward inside the timed region\", ");
+        printf("], \"layer_before_reenc\": %d, \"T_REENC_ms_per_image\": %.4f, \"matrix_cores\": %s", net.layer_before_reenc, t_reenc / images, matrix_cores ? "true" :
+            "false");
+        if (sync_each) printf(", \"ms_per_image_sync_each\": %.4f", t_sync / images);
+        printf(", \"layer_timing\": \"HIP events on the launch stream around every Layer::forward inside the timed region\", ");
         printf("\"hbm\": {\"total_bytes\": %zu, \"free_before_build\": %zu, \"free_after_first_launch\": %zu, \"parameters\": %zu, \"activation_slots\": %zu, "
             "\"work_buffer\": %zu, "
                "\"evaluation_keys\": %zu, \"input_launch\": %zu}}\n", total, free0, free1, plan.parameters, plan.activations, plan.work, plan.keys,
@@ -344,6 +393,8 @@ int main(int argc, char **argv)
         if (comm) crc_comm_destroy(comm);
         setStream(nullptr);
         delParameters();
+        if (!st_same) fprintf(stderr, "bench_host: a streamed launch's outputs differ from the resident launch's\n");
+        if (!timed_same) fprintf(stderr, "bench_host: the last timed launch's outputs differ from the first launch's\n");
         return st_same && timed_same ? 0 : 4;
     } catch (const exception &e) {
         fprintf(stderr, "bench_host: %s\n", e.what());

@@ -1187,7 +1187,7 @@ Network::HbmPlan Network::hbmPlan() const
 }
 Network::EventPool::~EventPool() { if (context) for (void *e : ev) crc_event_destroy(context, e); }
 
-size_t Network::broadcastParameters(crc_comm *comm, int root)
+size_t Network::broadcastParameters(crc_comm *comm, int root, bool encode_locally)
 {
     if (!comm) throw invalid_argument("broadcastParameters: no communicator");
     const int rank = crc_comm_rank(comm), world = crc_comm_world(comm);
@@ -1202,18 +1202,22 @@ size_t Network::broadcastParameters(crc_comm *comm, int root)
         if (rank != root) for (size_t i = 0; i < L; i++) layers[i]->adoptPlacement((int)all_pl[(size_t)root * L + i]);
     }
     vector<shared_ptr<DeviceBuffer>> bufs;
-    for (auto &l : layers) l->deviceParameters(bufs, rank != root);
+    // encode_locally: every rank lifts + transforms its own plaintext parameters (it read the same model file) and only the evaluation keys travel; the
+    // checksums below then prove that the ranks' encoders agree bit for bit
+    for (auto &l : layers) l->deviceParameters(bufs, rank != root && !encode_locally);
     if (!ev_keys16) throw logic_error("setParameters() must be called first");
+    const size_t own = encode_locally ? bufs.size() : 0;    // buffers that stay off the wire
     bufs.push_back(ev_keys16);                              // the evaluation keys come from the client through the root
     size_t bytes = 0;
     uint64_t mine[2] = {0, 0};
-    for (auto &b : bufs) {
+    for (size_t bi = 0; bi < bufs.size(); bi++) {
+        auto &b = bufs[bi];
         const size_t words = b->bytes / 8;
-        chk(crc_broadcast_weights(comm, (uint64_t *)b->ptr, words, root, stream()), "crc_broadcast_weights");
+        if (bi >= own) chk(crc_broadcast_weights(comm, (uint64_t *)b->ptr, words, root, stream()), "crc_broadcast_weights");
         uint64_t cs[2];
         chk(crc_checksum64(ctx(), (const uint64_t *)b->ptr, words, cs, stream()), "crc_checksum64");
         mine[0] ^= cs[0]; mine[1] = mine[1] * 0x9E3779B97F4A7C15ULL + cs[1];
-        bytes += b->bytes;
+        if (bi >= own) bytes += b->bytes;
     }
     vector<uint64_t> all((size_t)2 * world);
     chk(crc_comm_allgather_u64(comm, mine, 2, all.data(), stream()), "crc_comm_allgather_u64");

@@ -346,7 +346,9 @@ public:
     // (crc_broadcast_weights: ncclBroadcast in <= 1 GiB pieces), without encoding anything.  Every rank then checksums what it holds
     // (crc_checksum64) and the sums are compared with the root's; a mismatch throws std::runtime_error.  Call it before fuse() and
     // before the first forward() on the receiving ranks.  Returns the bytes received per rank.
-    size_t broadcastParameters(crc_comm *comm, int root = 0);
+    // encode_locally = true is SURVEY 8e's alternative: nothing but the evaluation keys is sent, every rank encodes + transforms the weights itself from the
+    // model file it read (the 2 MB of floats instead of 35-200 GB of residues on the wire; the same placement agreement and the same checksum comparison).
+    size_t broadcastParameters(crc_comm *comm, int root = 0, bool encode_locally = false);
 };
 
 // ---- model loader + builder (CrCNN/src/cnnBuilder.h:16-44) ----------------------------------------------------------

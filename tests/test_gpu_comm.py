@@ -160,3 +160,51 @@ def test_bench_two_ranks_over_rccl():
     _assert_cpp_ranks(line, 2)
     assert "ncclBroadcast" in line["weight_broadcast"]["via"]
     assert line["hbm_plan"]["parameters"] > 0
+
+
+def test_bench_two_cpp_ranks_encode_their_own_weights():
+    """--weights-via floats (SURVEY 8e's alternative to the residue broadcast): every rank lifts + transforms the model's weights itself, Network::broadcastParameters sends
+    only the evaluation keys -- and still compares every rank's parameter checksum with the root's, so two ranks that encoded differently could not pass"""
+    line = _run_bench(["--gpus", "2", "--weights-via", "floats"], {"CRC_COMM_TRANSPORT": "shm"})
+    _assert_cpp_ranks(line, 2)
+    b = line["weight_broadcast"]
+    assert b["weights_via"].startswith("floats")
+    other = _run_bench(["--gpus", "2"], {"CRC_COMM_TRANSPORT": "shm"})
+    assert other["weight_broadcast"]["weights_via"].startswith("broadcast") and other["weight_broadcast"]["bytes"] > 20 * b["bytes"]     # only the keys travelled
+
+
+def test_bench_a_failing_rank_stops_the_job_with_a_readable_line():
+    """crc_comm_create failing on one rank (here: a rendezvous id that names a shared-memory segment nobody created) must surface as a non-zero exit of that rank's
+    bench_host with a line a person can read, and the sibling rank must stop too instead of waiting in a collective (never a re-exec, never a hang)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update({"CRC_COMM_TRANSPORT": "shm", "CRC_TEST_BREAK_COMM_RANK": "1"})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "tiny1024", "--steps", "1", "--cpu-seconds", "0", "--also", "none", "--gpus", "2"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode != 0
+    assert "crc_comm_create failed" in out.stderr and "bench_host failed on rank 1" in out.stderr, out.stderr[-2000:]
+
+
+def test_bench_latency_published_and_valu_lines():
+    """the new lines of the default invocation on the small ring: single-image latency (batch 1, a synchronisation per image), the no-matrix-core pass (every conv / dense
+    layer on mac3_kernel) with the same golden ciphertexts"""
+    line = _run_bench(["--gpus", "1", "--latency", "on"])
+    assert line["check"]["all_ok"] is True
+    lat = line["latency"][0]
+    assert lat["latency_ms"] > 0 and lat["check"]["golden_match"] is True and set(lat["ms_per_layer"]) == set(line["ms_per_layer"]) and lat["images_timed"] >= 5
+    assert abs(sum(lat["ms_per_layer"].values()) - lat["latency_ms"]) < 0.5 * lat["latency_ms"]
+    assert line["config"]["latency_ms_single_image"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    for cfg, extra in (("tiny2048r", []), ("approx4096r", ["--batch", "128"]), ("tiny4096_valu", ["--batch", "64", "--distinct", "2"])):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--steps", "1", "--cpu-seconds", "0", "--also", "none", "--gpus", "1"] + extra,
+                             capture_output=True, text=True, env=env, timeout=900)
+        assert out.returncode == 0, (cfg, out.stdout[-1500:], out.stderr[-3000:])
+        ln = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        c = ln["check"]
+        assert c["golden_match"] is True and c["all_ok"] is True and c["last_timed_launch_identical_to_first"] is True, (cfg, c)
+        if cfg.endswith("r"):
+            vp = ln["vs_published"]
+            assert "T_REENC" in ln["ms_per_layer"] and ln["ms_per_layer"]["T_REENC"] > 0 and vp["vs_published"] > 100 and 0 < vp["refresh_share_of_image"] < 0.5
+            assert [r_["columns"] for r_ in vp["per_column"]].count("T_REENC") == 1
+        else:
+            assert all(k.startswith("mac3_kernel") or k.startswith("mac") for k in ln["mac_kernel_per_layer"].values()), ln["mac_kernel_per_layer"]
+            assert "mfma" not in json.dumps(ln["mac_kernel_per_layer"])

@@ -86,3 +86,17 @@ def test_bench_self_launches_its_ranks():
     bad = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                           os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launch-check"], capture_output=True, text=True, env=env, timeout=300)
     assert bad.returncode != 0
+
+
+def test_bench_launches_eight_ranks():
+    """the first 8-GPU contact of the launcher, rehearsed on CPU: `python bench.py --gpus 8 --launch-check` starts eight harness ranks, each starts its bench_host child,
+    rank 0's rendezvous id reaches the other seven through the file in the 0700 directory rank 0 made, and the ranks split the host cores eight ways"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--launch-check"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert (line["launch_check"], line["n_gpus"], line["ranks_seen"], line["self_launched"]) == (True, 8, 8, True)
+    assert line["same_rendezvous_id_on_every_rank"] is True
+    assert line["host_threads_per_rank"] == [max(1, min(16, (os.cpu_count() or 1) // 8))]

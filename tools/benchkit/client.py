@@ -93,7 +93,8 @@ class Client:
         """outs: [D][10][2][k][n] output ciphertexts of the D distinct images.  Returns the "check" dictionary of the bench line and whether everything held."""
         E, cfg = self.E, self.cfg
         D = len(imgs)
-        gold_ok, gold_name = golden_check(cfg_name, cfg, self.q, self.rank, x0_sha, sha(outs[0])) if golden else (None, None)
+        dec0_sha = sha(E.decrypt(self.sk, outs[0]))
+        gold_ok, gold_name = golden_check(cfg_name, cfg, self.q, self.rank, x0_sha, sha(outs[0]), dec0_sha) if golden else (None, None)
         # BASELINE configs[0] in full (tests/golden/c1_tiny4096_t32.json: 32 images through the compiled reference): this run's distinct images ARE its first
         # images
         c1_ok = None
@@ -114,6 +115,8 @@ class Client:
             preds_ok += int(np.argmax(logits) == np.argmax(want))
             preds.append(int(np.argmax(logits)))
         self.last_predictions = preds
-        ok = bool(preds_ok == D and gold_ok is not False and (c1_ok is None or c1_ok.split("/")[0] == c1_ok.split("/")[1]))
+        # (the reference's published parameter sets trade a little accuracy for speed -- t = 2^18 at n = 2048: 89.85 % against the float model's 90 %, Tesi.lyx:14929 --
+        # so there the bar is the reference's own decrypted outputs, and the agreement with the float model is reported, not required)
+        ok = bool((preds_ok == D or cfg.get("lossy")) and gold_ok is not False and (c1_ok is None or c1_ok.split("/")[0] == c1_ok.split("/")[1]))
         return {"predictions_match_plain_model": f"{preds_ok}/{D}", "max_logit_abs_err": round(max_err, 6), "noise_budget_bits": budgets, "golden_match": gold_ok, "golden": gold_name,
                 "c1_images_match_reference": c1_ok}, ok

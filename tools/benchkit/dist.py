@@ -59,15 +59,25 @@ def launch_check(args):
     ok = ok and all(recs) and len(ids) == 1 and sorted(r["rank"] for r in recs) == list(range(ranks.world))
     seen = sum(1 for r in recs if r)
     if ranks.rank == 0:
-        try:
-            os.remove(ranks.rendezvous_path("check"))
-        except OSError:
-            pass
         print(json.dumps({"launch_check": True, "n_gpus": ranks.world, "ranks_seen": seen, "self_launched": bool(os.environ.get("CRC_SELF_LAUNCHED")),
                           "host": "C++ bench_host (one child per rank, file rendezvous)", "same_rendezvous_id_on_every_rank": len(ids) == 1,
                           "host_threads_per_rank": sorted({r["host_threads"] for r in recs if r})}), flush=True)
     ranks.close()
     return 0 if ok and seen == args.gpus else 1
+
+
+def gpu_count_without_hip():
+    """GPUs of this node from the KFD topology in sysfs (a node with SIMDs is a GPU): no HIP call, so the harness ranks stay off the devices.  torch.cuda.device_count()
+    may initialise the runtime where the amdsmi path is unavailable"""
+    import glob
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(ln.split()[:2] for ln in open(f).read().splitlines() if len(ln.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+        except OSError:
+            pass
+    return n
 
 
 class HostRanks:
@@ -82,17 +92,20 @@ class HostRanks:
         self.local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(self.world)))
         if self.world != args.gpus and self.world > 1:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
-        self.token = "solo"
+        # the rendezvous files (RCCL's 128-byte id, failure markers) live in a directory only this user can enter: rank 0 makes it (mkdtemp: mode 0700, an
+        # unpredictable name) and tells the others its path over gloo -- nobody else on the host can pre-create, symlink or read what the ranks exchange there
+        import tempfile
+        base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+        self.dir = tempfile.mkdtemp(prefix="crc_rdv_", dir=base) if self.rank == 0 else None
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=30))
-            obj = [f"{os.getpid()}_{int(time.time() * 1e3)}" if self.rank == 0 else None]
+            obj = [self.dir]
             dist.broadcast_object_list(obj, src=0)
-            self.token = obj[0]
+            self.dir = obj[0]
 
     def rendezvous_path(self, tag):
-        d = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
-        return os.path.join(d, f"crc_rendezvous_{self.token}_{tag}")
+        return os.path.join(self.dir, f"rendezvous_{tag}")
 
     def gather(self, obj):
         if self.world == 1:
@@ -112,12 +125,8 @@ class HostRanks:
             self.dist.barrier()
             self.dist.destroy_process_group()
         if self.rank == 0:                                           # the rendezvous ids (and failure markers) of this job
-            import glob
-            for f in glob.glob(self.rendezvous_path("*")):
-                try:
-                    os.remove(f)
-                except OSError:
-                    pass
+            import shutil
+            shutil.rmtree(self.dir, ignore_errors=True)
 
 
 class Dist:
