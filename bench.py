@@ -320,7 +320,7 @@ def run_host(args, cfg_name, steps, warmup, batch=None, device=0, ranks=None, st
             cpu_line["c1_in_full"] = dict(images=len(c1f["images"]), images_per_s=full_ips, total_wall_s=c1f.get("total_wall_s_adjusted", c1f["total_wall_s"]),
                                           threads=c1f["ref_threads"], where="build container (8 cores), the compiled reference on 32 images: tests/golden/c1_tiny4096_t32.json")
             # both figures side by side: the one measured in full (other machine, 8 cores) and this run's sample scaled to the same core count
-            cpu_line["value_measured_in_full_elsewhere"] = dict(images_per_s=full_ips, cores=c1f["ref_threads"], per_core=round(full_ips / c1f["ref_threads"], 7))
+            cpu_line["value_measured_in_full_elsewhere"] = dict(images_per_s=full_ips, cores=8, per_core=round(full_ips / 8, 7), threads=c1f["ref_threads"])
             cpu_line["value_per_core"] = round(cpu_line["value"] / max(1, cpu_line["cores"]), 7)
     hbm = r["hbm"]
     line = {

@@ -479,20 +479,24 @@ extern "C" int crc_encode_dev_f64(crc_ctx *c, const double *d_values, size_t cou
     CHECK_CTX(c); if (!d_values || !d_plain) return CRC_ERR_INVALID_ARGUMENT;
     return k_fra_encode(c, d_values, 1, count, d_plain, nullptr, S(stream));
 }
-// work of a refresh: [plaintexts [count][n]: decrypted, then re-encoded in place][the decryptor's rows, then the encryptor's samples]
+// work of a refresh: [compact plaintexts [count][96]][dense plaintexts [count][n]: coefficient-form results only][the decryptor's rows, then the encryptor's samples]
 extern "C" size_t crc_refresh_dev_work_bytes(const crc_ctx *c, size_t count, int in_form)
 {
     if (!c || !ct_form_ok(in_form)) return 0;
     const size_t dec = k_decrypt_work_words(c, count, 2, in_form == CRC_NTT), enc = k_encrypt_work_words(c, count);
-    return 8 * (count * (size_t)c->n + (dec > enc ? dec : enc)) + 256;
+    return 8 * (count * ((size_t)c->n + CRC_PLAIN_COMPACT_WORDS) + (dec > enc ? dec : enc)) + 256;
 }
 static int refresh_impl(crc_ctx *c, const u64 *d_sk, const u64 *d_pk, const u64 *d_in, size_t count, int in_form, const ChaChaKey &key, u64 stream_base,
                         int out_form, u64 *d_out, float *d_vals, void *d_work, hipStream_t st)
 {
-    u64 *plain = (u64 *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255), *w = plain + count * (size_t)c->n;
-    RUN(k_decrypt(c, d_sk, d_in, count, 2, in_form == CRC_NTT, plain, w, st));
-    RUN(k_fra_encode(c, plain, 2, count, plain, d_vals, st));            // decode -> float -> encode, row by row in place
-    return k_encrypt(c, d_pk, plain, count, key, stream_base, d_out, w, st, out_form == CRC_NTT);
+    u64 *compact = (u64 *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255), *dense = compact + count * (size_t)CRC_PLAIN_COMPACT_WORDS;
+    u64 *w = dense + count * (size_t)c->n;
+    // decrypt -> decode -> float -> encode leaves the 96-word compact plaintexts (only the 96 coefficients the decoder reads are ever scaled) ...
+    RUN(k_decrypt_recode(c, d_sk, d_in, count, in_form == CRC_NTT, compact, d_vals, w, st));
+    // ... which the NTT-form encryptor reads as they are; the coefficient-form one adds Delta m from dense rows
+    if (out_form == CRC_NTT) return k_encrypt(c, d_pk, compact, count, key, stream_base, d_out, w, st, true, true);
+    RUN(k_plain_expand(c, compact, count, dense, st));
+    return k_encrypt(c, d_pk, dense, count, key, stream_base, d_out, w, st, false);
 }
 extern "C" int crc_refresh_dev(crc_ctx *c, const uint64_t *d_sk, const uint64_t *d_pk, const uint64_t *d_ct_in, size_t count, int in_form, uint64_t seed,
                                int out_form, uint64_t *d_ct_out, float *d_values_out, void *d_work, void *stream)

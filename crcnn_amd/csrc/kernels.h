@@ -51,11 +51,13 @@ int k_fold_pool(crc_ctx *c, const u64 *w, const u64 *bias, const u64 *div, u64 *
                 int pxf, int pyf, hipStream_t st);
 size_t k_encrypt_work_words(const crc_ctx *c, size_t cnt);
 struct ChaChaKey;
-int k_encrypt(crc_ctx *c, const u64 *pk, const u64 *plain, size_t cnt, const ChaChaKey &key, u64 stream_base, u64 *ct, u64 *work, hipStream_t st, bool out_ntt = false);
+int k_encrypt(crc_ctx *c, const u64 *pk, const u64 *plain, size_t cnt, const ChaChaKey &key, u64 stream_base, u64 *ct, u64 *work, hipStream_t st, bool out_ntt = false,
+              bool plain_compact = false);
 void k_encrypt_cdt(u64 *out19);                 // the 19 thresholds of the device encryptor's noise magnitudes (tests)
 // kernels_decrypt.hip: Decryptor::decrypt and the fractional encoder on the device (the refresh of Network::forward)
 size_t k_decrypt_work_words(const crc_ctx *c, size_t cnt, int size, bool in_ntt);
 int k_decrypt(crc_ctx *c, const u64 *sk, const u64 *ct, size_t cnt, int size, bool in_ntt, u64 *plain, u64 *work, hipStream_t st);
+int k_decrypt_recode(crc_ctx *c, const u64 *sk, const u64 *ct, size_t cnt, bool in_ntt, u64 *compact, float *vals_out, u64 *work, hipStream_t st);
 int k_fra_decode(crc_ctx *c, const u64 *plain, size_t cnt, double *out, hipStream_t st);
 int k_fra_encode(crc_ctx *c, const void *src, int mode, size_t cnt, u64 *plain, float *vals_out, hipStream_t st);
 

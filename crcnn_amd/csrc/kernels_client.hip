@@ -40,7 +40,8 @@ __device__ __forceinline__ u32 ternary_field(u32 lo, u32 hi)
 // U: [count][k][n] ternary polynomial in RNS form (coefficient domain).  ROWS = false: E [count][2][n] signed noise bytes (the coefficient-form pipeline adds
 // them after its inverse transforms); ROWS = true: the rows e1 + Delta m (+ q mod t on the upper half, evaluator.cpp:1168-1191) and e2 of every ciphertext, as
 // residues in ct [count][2][k][n] -- what the NTT-form pipeline transforms next
-template <bool ROWS>
+// COMPACT: `plain` holds the 96-word compact plaintexts of the fractional encoder (crc_plain_expand's layout) instead of dense rows
+template <bool ROWS, bool COMPACT = false>
 __global__ void __launch_bounds__(256) enc_sample_kernel(u64 *U, signed char *E, u64 *ct, const u64 *plain, const ModParams *mods, int n, int k, ChaChaKey key,
                                                          u64 stream_base, EncCdt cdt, PlainParams pp)
 {
@@ -69,7 +70,11 @@ __global__ void __launch_bounds__(256) enc_sample_kernel(u64 *U, signed char *E,
 #pragma unroll
         for (int p = 0; p < 2; p++) *reinterpret_cast<char2 *>(E + (m * 2 + p) * (size_t)n + s) = char2{(signed char)e[0][p], (signed char)e[1][p]};
     } else {
-        const ulonglong2 pl = *reinterpret_cast<const ulonglong2 *>(plain + m * (size_t)n + s);
+        ulonglong2 pl = make_ulonglong2(0, 0);
+        if (!COMPACT) pl = *reinterpret_cast<const ulonglong2 *>(plain + m * (size_t)n + s);
+        else if (s < CRC_PLAIN_COMPACT_LOW) pl = *reinterpret_cast<const ulonglong2 *>(plain + m * (size_t)CRC_PLAIN_COMPACT_WORDS + s);
+        else if (s >= n - CRC_PLAIN_COMPACT_HIGH)
+            pl = *reinterpret_cast<const ulonglong2 *>(plain + m * (size_t)CRC_PLAIN_COMPACT_WORDS + CRC_PLAIN_COMPACT_LOW + (s - (n - CRC_PLAIN_COMPACT_HIGH)));
         const u64 pc[2] = {pl.x, pl.y};
         for (int i = 0; i < k; i++) {
             const ModParams md = mods[i];
@@ -166,9 +171,11 @@ static const EncCdt &enc_cdt()
 }
 void k_encrypt_cdt(u64 *out19) { const EncCdt &T = enc_cdt(); for (int a = 0; a < 19; a++) out19[a] = T.t[a]; }
 
-int k_encrypt(crc_ctx *c, const u64 *pk, const u64 *plain, size_t cnt, const ChaChaKey &key, u64 stream_base, u64 *ct, u64 *work, hipStream_t st, bool out_ntt)
+int k_encrypt(crc_ctx *c, const u64 *pk, const u64 *plain, size_t cnt, const ChaChaKey &key, u64 stream_base, u64 *ct, u64 *work, hipStream_t st, bool out_ntt,
+              bool plain_compact)
 {
     if (cnt == 0) return CRC_OK;
+    if (plain_compact && !out_ntt) return CRC_ERR_INVALID_ARGUMENT;       // (the coefficient-form pipeline adds Delta m from dense rows: expand first)
     const int n = c->n, k = c->k;
     u64 *U = work; signed char *E = reinterpret_cast<signed char *>(U + cnt * (size_t)n * k);
     const int pairs = n / 2, threads = pairs < 256 ? pairs : 256, pblocks = (pairs + threads - 1) / threads;
@@ -177,9 +184,12 @@ int k_encrypt(crc_ctx *c, const u64 *pk, const u64 *plain, size_t cnt, const Cha
     if (out_ntt) {
         // c_p = NTT(e_p (+ Delta m)) + pk_p . NTT(u): three forward transforms per modulus and no inverse one -- the same residues as transforming the
         // coefficient form
-        hipLaunchKernelGGL(enc_sample_kernel<true>, dim3((unsigned)(cnt * pblocks)), dim3(threads), 0, st, U, E, ct, plain, c->d_mods, n, k, key, stream_base,
-            enc_cdt(),
-                           c->plain);
+        if (plain_compact)
+            hipLaunchKernelGGL((enc_sample_kernel<true, true>), dim3((unsigned)(cnt * pblocks)), dim3(threads), 0, st, U, E, ct, plain, c->d_mods, n, k, key,
+                               stream_base, enc_cdt(), c->plain);
+        else
+            hipLaunchKernelGGL((enc_sample_kernel<true, false>), dim3((unsigned)(cnt * pblocks)), dim3(threads), 0, st, U, E, ct, plain, c->d_mods, n, k, key,
+                               stream_base, enc_cdt(), c->plain);
         HIPCHK(hipGetLastError());
         if ((rc = k_ntt_ct(c, false, U, U, cnt, 1, false, st, nullptr, 0, 0, 0))) return rc;
         // (the product joins in the transform's last loop where the ring has the wave-local kernel; else as a pass of its own)
@@ -190,7 +200,7 @@ int k_encrypt(crc_ctx *c, const u64 *pk, const u64 *plain, size_t cnt, const Cha
         HIPCHK(hipGetLastError());
         return CRC_OK;
     }
-    hipLaunchKernelGGL(enc_sample_kernel<false>, dim3((unsigned)(cnt * pblocks)), dim3(threads), 0, st, U, E, ct, plain, c->d_mods, n, k, key, stream_base,
+    hipLaunchKernelGGL((enc_sample_kernel<false, false>), dim3((unsigned)(cnt * pblocks)), dim3(threads), 0, st, U, E, ct, plain, c->d_mods, n, k, key, stream_base,
         enc_cdt(),
                        c->plain);
     HIPCHK(hipGetLastError());

@@ -48,13 +48,9 @@ __device__ __forceinline__ void acc128(u64 &lo, u64 &hi, u64 a, u64 b)
     const u64 l2 = lo + pl; hi += ph + (l2 < lo); lo = l2;
 }
 
-// plain[m][s] from the coefficient-form rows V[m][i][s]: the gamma-corrected scaling by t / q
-__global__ void __launch_bounds__(256) dec_gamma_kernel(const u64 *V, u64 *plain, const ModParams *mods, int n, DecParams dp)
+// one plaintext coefficient from the k coefficient-form residues v[i n] of c0 + c1 s: the gamma-corrected scaling by t / q
+__device__ __forceinline__ u64 dec_gamma_one(const u64 *v, const ModParams *mods, int n, const DecParams &dp)
 {
-    const size_t m = blockIdx.y;
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n) return;
-    const u64 *v = V + m * (size_t)dp.k * n + s;
     u64 tl = 0, th = 0, gl = 0, gh = 0;
     for (int i = 0; i < dp.k; i++) {
         const u64 y = mulmod_shoup(v[(size_t)i * n], dp.yc[i], dp.yc_s[i], mods[i].q);
@@ -64,7 +60,16 @@ __global__ void __launch_bounds__(256) dec_gamma_kernel(const u64 *V, u64 *plain
     const u64 rt = mulmod(barrett128(tl, th, dp.tmod), dp.ninv_q_t, dp.tmod), rg = mulmod(barrett128(gl, gh, dp.gmod), dp.ninv_q_g, dp.gmod);
     // centred correction (decryptor.cpp:193-215)
     const u64 w = rg > (g >> 1) ? addmod(rt, barrett128(g - rg, 0, dp.tmod), t) : submod(rt, barrett128(rg, 0, dp.tmod), t);
-    plain[m * (size_t)n + s] = mulmod(w, dp.inv_gamma_t, dp.tmod);
+    return mulmod(w, dp.inv_gamma_t, dp.tmod);
+}
+
+// plain[m][s] for every coefficient of every ciphertext
+__global__ void __launch_bounds__(256) dec_gamma_kernel(const u64 *V, u64 *plain, const ModParams *mods, int n, DecParams dp)
+{
+    const size_t m = blockIdx.y;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    plain[m * (size_t)n + s] = dec_gamma_one(V + m * (size_t)dp.k * n + s, mods, n, dp);
 }
 
 // ---- FractionalEncoder(t, x^n + 1, 64, 32, base 3) -------------------------------------------------------------------
@@ -148,6 +153,28 @@ __global__ void __launch_bounds__(256) fra_encode_kernel(const void *src, u64 *p
     }
 }
 
+// The middle of a refresh, one workgroup (128 lanes) per ciphertext: FractionalEncoder::decode reads coefficients 0..63 and n-32..n-1 only, so only those 96 are
+// scaled (96 lanes, one each, into LDS); lane 0 decodes, rounds to float (globals.cpp:221) and encodes again; the workgroup writes the new plaintext in the compact
+// form (96 words: crc_plain_expand's layout), which the encryptor's sampling kernel reads directly -- no dense plaintext row is written or read
+__global__ void __launch_bounds__(128) dec_recode_kernel(const u64 *V, u64 *compact, float *vals_out, const ModParams *mods, int n, DecParams dp)
+{
+    __shared__ u64 co[CRC_PLAIN_COMPACT_WORDS], enc[CRC_PLAIN_COMPACT_WORDS];
+    const size_t m = blockIdx.x;
+    const int l = threadIdx.x;
+    if (l < CRC_PLAIN_COMPACT_WORDS) {
+        const int s = l < CRC_PLAIN_COMPACT_LOW ? l : n - CRC_PLAIN_COMPACT_HIGH + (l - CRC_PLAIN_COMPACT_LOW);
+        co[l] = dec_gamma_one(V + m * (size_t)dp.k * n + s, mods, n, dp);
+    }
+    __syncthreads();
+    if (l == 0) {
+        const float fv = (float)dev_fra_decode(co, co + CRC_PLAIN_COMPACT_LOW, dp.tmod.q);
+        if (vals_out) vals_out[m] = fv;
+        dev_fra_encode((double)fv, dp.tmod.q, enc);
+    }
+    __syncthreads();
+    if (l < CRC_PLAIN_COMPACT_WORDS) compact[m * (size_t)CRC_PLAIN_COMPACT_WORDS + l] = enc[l];
+}
+
 static DecParams dec_params(const crc_ctx *c)
 {
     DecParams dp{};
@@ -168,9 +195,9 @@ size_t k_decrypt_work_words(const crc_ctx *c, size_t cnt, int size, bool in_ntt)
     return cnt * (size_t)c->k * c->n * (in_ntt ? 1 : 1 + (size_t)size);
 }
 
-int k_decrypt(crc_ctx *c, const u64 *sk, const u64 *ct, size_t cnt, int size, bool in_ntt, u64 *plain, u64 *work, hipStream_t st)
+// V = work [cnt][k][n]: c0 + c1 s (+ c2 s^2) in coefficient form
+static int decrypt_rows(crc_ctx *c, const u64 *sk, const u64 *ct, size_t cnt, int size, bool in_ntt, u64 *work, hipStream_t st)
 {
-    if (cnt == 0) return CRC_OK;
     const int n = c->n, k = c->k;
     if (size < 2 || size > 3 || cnt * (size_t)k > 0x7fffffffULL || cnt > 65535u * 4096ull) return CRC_ERR_INVALID_ARGUMENT;
     u64 *V = work;
@@ -183,7 +210,16 @@ int k_decrypt(crc_ctx *c, const u64 *sk, const u64 *ct, size_t cnt, int size, bo
     }
     hipLaunchKernelGGL(dec_dot_kernel, dim3((unsigned)(cnt * k)), dim3(n / 2 < 256 ? n / 2 : 256), 0, st, hat, sk, V, c->d_mods, n, k, size);
     HIPCHK(hipGetLastError());
-    if ((rc = k_ntt_ct(c, true, V, V, cnt, 1, false, st, nullptr, 0, 0, 0))) return rc;
+    return k_ntt_ct(c, true, V, V, cnt, 1, false, st, nullptr, 0, 0, 0);
+}
+
+int k_decrypt(crc_ctx *c, const u64 *sk, const u64 *ct, size_t cnt, int size, bool in_ntt, u64 *plain, u64 *work, hipStream_t st)
+{
+    if (cnt == 0) return CRC_OK;
+    const int n = c->n, k = c->k;
+    int rc;
+    if ((rc = decrypt_rows(c, sk, ct, cnt, size, in_ntt, work, st))) return rc;
+    u64 *V = work;
     const DecParams dp = dec_params(c);
     const int threads = n < 256 ? n : 256;
     for (size_t o = 0; o < cnt; o += 65535) {     // grid.y limit
@@ -213,6 +249,18 @@ int k_fra_encode(crc_ctx *c, const void *src, int mode, size_t cnt, u64 *plain, 
     if (mode == 0) hipLaunchKernelGGL(fra_encode_kernel<0>, g, b, 0, st, src, plain, vals_out, c->n, c->t);
     else if (mode == 1) hipLaunchKernelGGL(fra_encode_kernel<1>, g, b, 0, st, src, plain, vals_out, c->n, c->t);
     else hipLaunchKernelGGL(fra_encode_kernel<2>, g, b, 0, st, src, plain, vals_out, c->n, c->t);
+    HIPCHK(hipGetLastError());
+    return CRC_OK;
+}
+
+// decrypt -> decode -> float -> encode for the refresh: compact plaintexts [cnt][96] (and the floats) out; work as k_decrypt
+int k_decrypt_recode(crc_ctx *c, const u64 *sk, const u64 *ct, size_t cnt, bool in_ntt, u64 *compact, float *vals_out, u64 *work, hipStream_t st)
+{
+    if (cnt == 0) return CRC_OK;
+    if (cnt > 0x7fffffffULL || c->n <= CRC_PLAIN_COMPACT_WORDS) return CRC_ERR_INVALID_ARGUMENT;
+    int rc;
+    if ((rc = decrypt_rows(c, sk, ct, cnt, 2, in_ntt, work, st))) return rc;
+    hipLaunchKernelGGL(dec_recode_kernel, dim3((unsigned)cnt), dim3(128), 0, st, work, compact, vals_out, c->d_mods, c->n, dec_params(c));
     HIPCHK(hipGetLastError());
     return CRC_OK;
 }
