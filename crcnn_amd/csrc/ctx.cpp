@@ -174,6 +174,7 @@ static void read_tuning(CrcTuning &t)
     t.mac2_cfg = (int)geti("CRC_MAC2_CFG", 0);
     t.mac_order = (int)geti("CRC_MAC_ORDER", -1);
     t.mac_regstage = (int)geti("CRC_MAC_REGSTAGE", 0);
+    t.mac_stream = (int)geti("CRC_MAC_STREAM", 1);
     t.mac2_dbg = (int)geti("CRC_MAC2_DBG", 0);
     t.relin_path = (int)geti("CRC_RELIN_PATH", 0);
     t.sq_path = (int)geti("CRC_SQ_PATH", 0);
@@ -201,6 +202,7 @@ extern "C" int crc_ctx_set_tuning(crc_ctx *c, const char *name, long long value)
     else if (s == "mac2_cfg") t.mac2_cfg = (int)value;
     else if (s == "mac_order") t.mac_order = (int)value;
     else if (s == "mac_regstage") t.mac_regstage = (int)value;
+    else if (s == "mac_stream") t.mac_stream = (int)value;
     else if (s == "ntt_inv61_loose") t.ntt_inv61_loose = value ? 1 : 0;
     else if (s == "relin_path") t.relin_path = (int)value;
     else if (s == "sq_path") t.sq_path = (int)value;

@@ -112,6 +112,7 @@ struct CrcTuning {
     int mac2_cfg = 0;             // CRC_MAC2_CFG=16|8: force a tile shape (mac2_kernel)
     int mac_order = -1;           // CRC_MAC_ORDER=0|1
     int mac_regstage = 0;         // CRC_MAC_REGSTAGE=1: register-staged mac2_kernel instead of the LDS-DMA mac3_kernel
+    int mac_stream = 1;           // CRC_MAC_STREAM=0: batch-1 dense layers on mac3_kernel (round 5) instead of the weight-stream kernel; 1..4: its shape (FT, SL)
     int mac2_dbg = 0;             // CRC_MAC2_DBG (only in -DCRC_TUNING builds)
     int ntt_split = 1;            // CRC_NTT_SPLIT=0: rows of n = 16384 as one 128-KiB LDS image (one workgroup per CU) instead of two 64-KiB halves
     int relin_mac_ct = 0;         // CRC_RELIN_MAC_CT=8: eight ciphertexts per thread in relin_mac_f64_kernel for k >= 4 (default 4)

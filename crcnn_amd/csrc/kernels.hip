@@ -5,6 +5,7 @@
 // Integer modular arithmetic only -- no MFMA.  Lane <-> coefficient/slot, so every global access is a coalesced
 // 512 B (8 B/lane) or 1 KiB (16 B/lane) wave transaction.
 #include "kernels.h"
+#include <type_traits>
 #include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1429,6 +1430,112 @@ static int mac3_launch(crc_ctx *c, MacArgs &a, hipStream_t st)
     return CRC_OK;
 }
 
+// mac_stream_kernel (round 6): ONE image, ONE output position -- a dense layer at batch 1, the reference's whole usage model (mainparams.cpp:85-112 evaluates one
+// image at a time).  Two rows (c0, c1) per weight: every weight residue is read for two multiply-adds, so the layer is a weight STREAM (PlainModelTiny's fc3 at
+// n = 4096: 34 GB for 1024 outputs), the one place where north_star's HBM roofline is the bound.  mac3_kernel serves it with 64-slot workgroups, eleven of whose
+// twelve pixel rows are padding, at 0.42 of 8 TB/s; here a workgroup owns SL * 256 consecutive slots of one residue row and FT filters, every lane SL adjacent
+// slots (16-byte loads at SL = 2), and walks the T terms with the next term's operands requested before the current ones are multiplied.  The x rows -- the same
+// for every filter group -- are shared through L2: the filter groups of a slot block run on ONE XCD next to each other (blockIdx -> (XCD, slot block, group)).
+// Same limb products, same lazy sums and the same folding reduction as mac3_kernel, hence the same residues.
+template <int FT, int SL, bool XP, bool WP>
+__global__ void __launch_bounds__(256) mac_stream_kernel(MacArgs a)
+{
+    typedef typename std::conditional<SL == 2, ulonglong2, u64>::type vec_t;
+    const int n = a.n, k = a.k;
+    const int per_row = n / (256 * SL), sbt = per_row * k, nfg = (a.F + FT - 1) / FT;
+    int g = blockIdx.x, sb, fg;
+    if ((sbt & 7) == 0) { const int xcd = g & 7, r = g >> 3, per = sbt >> 3; sb = xcd * per + r / nfg; fg = r % nfg; }
+    else { sb = g / nfg; fg = g % nfg; }
+    const int i = sb / per_row, s = (sb % per_row) * 256 * SL + threadIdx.x * SL;
+    const size_t rown = (size_t)i * n + s, kn = (size_t)k * n, ctw = 2 * kn;
+    const ModParams m = a.mods[i];
+    const int f0 = fg * FT;
+    const u64 *xb = a.x + (size_t)a.xoff[0] * ctw + rown;
+    const u64 *wb[FT];
+#pragma unroll
+    for (int f = 0; f < FT; f++) wb[f] = a.w + (size_t)min(f0 + f, a.F - 1) * a.T * kn + rown;        // filters past F: a clamped copy, never stored
+
+    u64 A0[SL][2][FT], A1[SL][2][FT], A2[SL][2][FT]; u32 OV[SL][2][FT];
+#pragma unroll
+    for (int e = 0; e < SL; e++)
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int f = 0; f < FT; f++) { A0[e][c][f] = 0; A1[e][c][f] = 0; A2[e][c][f] = 0; OV[e][c][f] = 0; }
+
+    auto load = [&](int t, vec_t (&xv)[2], vec_t (&wv)[FT]) {
+        const u64 *xt = xb + a.toffw[t];
+        xv[0] = *reinterpret_cast<const vec_t *>(xt); xv[1] = *reinterpret_cast<const vec_t *>(xt + kn);
+#pragma unroll
+        for (int f = 0; f < FT; f++) wv[f] = *reinterpret_cast<const vec_t *>(wb[f] + (size_t)t * kn);
+    };
+    auto lane_of = [](const vec_t &v, int e) -> u64 { if constexpr (SL == 2) return e ? v.y : v.x; else return v; };
+    auto compute = [&](const vec_t (&xv)[2], const vec_t (&wv)[FT]) {
+#pragma unroll
+        for (int e = 0; e < SL; e++) {
+            u32 w0[FT], w1[FT], ws[FT];
+#pragma unroll
+            for (int f = 0; f < FT; f++) { const u64 wr = lane_of(wv[f], e); const u64 wp = WP ? wr : split28(wr); w0[f] = (u32)wp; w1[f] = (u32)(wp >> 32);
+                ws[f] = w0[f] + w1[f]; }
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const u64 xr = lane_of(xv[c], e); const u64 xp = XP ? xr : split28(xr);
+                const u32 x0 = (u32)xp, x1 = (u32)(xp >> 32), xs = x0 + x1;
+#pragma unroll
+                for (int f = 0; f < FT; f++) { A0[e][c][f] += (u64)x0 * w0[f]; A2[e][c][f] += (u64)x1 * w1[f]; A1[e][c][f] += (u64)xs * ws[f]; }
+            }
+        }
+    };
+    vec_t xc[2], wc[FT], xn[2], wn[FT];
+    load(0, xc, wc);
+    for (int t = 0; t < a.T; t++) {
+        if (t + 1 < a.T) load(t + 1, xn, wn);
+        compute(xc, wc);
+        if ((t & 31) == 31) {                            // at most every 32 terms: park bit 63 of each accumulator in the overflow word (as mac3_kernel)
+#pragma unroll
+            for (int e = 0; e < SL; e++)
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+#pragma unroll
+                    for (int f = 0; f < FT; f++) {
+                        OV[e][c][f] += (u32)(A0[e][c][f] >> 63) + ((u32)(A1[e][c][f] >> 63) << 10) + ((u32)(A2[e][c][f] >> 63) << 20);
+                        A0[e][c][f] &= ~(1ULL << 63); A1[e][c][f] &= ~(1ULL << 63); A2[e][c][f] &= ~(1ULL << 63);
+                    }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; c++) xc[c] = xn[c];
+#pragma unroll
+        for (int f = 0; f < FT; f++) wc[f] = wn[f];
+    }
+#pragma unroll
+    for (int f = 0; f < FT; f++) {
+        const int ff = f0 + f;
+        if (ff >= a.F) continue;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            u64 v[SL];
+#pragma unroll
+            for (int e = 0; e < SL; e++) {
+                v[e] = mac_reduce_fold(A0[e][c][f], A1[e][c][f], A2[e][c][f], OV[e][c][f], m);
+                if (c == 0 && a.bias) v[e] = addmod(v[e], a.bias[(size_t)ff * kn + rown + e], m.q);
+                if (a.yp) v[e] = split28(v[e]);
+            }
+            u64 *dst = a.y + (size_t)ff * ctw + (size_t)c * kn + rown;       // B = P = 1: y[f][c][i][s]
+            if constexpr (SL == 2) *reinterpret_cast<ulonglong2 *>(dst) = ulonglong2{v[0], v[1]}; else *dst = v[0];
+        }
+    }
+}
+
+template <int FT, int SL, bool XP, bool WP>
+static int mac_stream_launch(crc_ctx *c, MacArgs &a, hipStream_t st)
+{
+    const size_t grid = (size_t)(c->n / (256 * SL)) * c->k * (size_t)((a.F + FT - 1) / FT);
+    if (grid > 0x7fffffffULL) return CRC_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL((mac_stream_kernel<FT, SL, XP, WP>), dim3((unsigned)grid), dim3(256), 0, st, a);
+    HIPCHK(hipGetLastError());
+    return CRC_OK;
+}
+
 template <int PX, int FT, int WM, int WN, int S, int DEPTH = 2>
 static int mac2_launch(crc_ctx *c, MacArgs &a, hipStream_t st)
 {
@@ -1481,6 +1588,21 @@ int k_mac2(crc_ctx *c, const u64 *x, const u64 *w, u64 *y, const int *d_xoff, co
     const int regstage = c->tune.mac_regstage;
     bool foldable = true;                          // mac3's epilogue is the folding reduction: needs q = 2^b - d, 50 <= b <= 55
     for (int i = 0; i < c->k; i++) if (!c->tabs[i].m.fold || c->tabs[i].m.bits < 50 || c->tabs[i].m.bits > 55) foldable = false;
+    // one image, one output position (a dense layer at batch 1): the weight stream (mac_stream_kernel).  CRC_MAC_STREAM=0 keeps mac3_kernel; 1..4 pick a shape
+    if (!regstage && !cfg && foldable && (long long)B * P == 1 && T >= 8 && c->tune.mac_stream != 0 && c->n >= 512) {
+        // measured (profiles/r06_ab_mac_stream.txt): four filters x two slots per lane streams fc3 at 6.1-6.2 TB/s; a layer of a few filters (fc4: 10) fills the chip
+        // better with two filters per workgroup
+        const int shape = c->tune.mac_stream > 1 ? c->tune.mac_stream : (F >= 16 ? 1 : 2);
+#define STREAM_GO(FTV, SLV) (a.xp && a.wp ? mac_stream_launch<FTV, SLV, true, true>(c, a, st) : a.xp ? mac_stream_launch<FTV, SLV, true, false>(c, a, st) \
+                             : a.wp ? mac_stream_launch<FTV, SLV, false, true>(c, a, st) : mac_stream_launch<FTV, SLV, false, false>(c, a, st))
+        switch (shape) {                               // (CRC_MAC_STREAM=5 forces the default shape for every F)
+        case 2: return STREAM_GO(2, 2);
+        case 3: return STREAM_GO(4, 1);
+        case 4: return STREAM_GO(8, 1);
+        default: return STREAM_GO(4, 2);
+        }
+#undef STREAM_GO
+    }
     if (!regstage && !cfg && foldable) {
         int rc;
 #define MAC3_GO(XPV, WPV) (pick == 8 ? mac3_launch<3, 4, 4, 2, 4, XPV, WPV>(c, a, st) : mac3_launch<3, 4, 2, 4, 4, XPV, WPV>(c, a, st))

@@ -313,3 +313,43 @@ def test_packed_operand_forms(gl):
     y = E.download(d_y, (B, nf, xo, yo, 2, E.k, E.n))
     for b in range(B):
         assert np.array_equal(y[b], g["ref_conv"])
+
+
+@pytest.mark.parametrize("n,k,in_dim,out_dim", [(1024, 2, 70, 7), (512, 3, 33, 10), (4096, 2, 200, 5)])
+def test_dense_at_batch_one_streams_its_weights(n, k, in_dim, out_dim):
+    """mac_stream_kernel (a dense layer on ONE image: two rows per weight, the weight stream of the single-image latency line) against exact integer arithmetic on
+    random residues -- sums past 2^64 per limb (in_dim > 32), a filter count that is no multiple of the filter group, every shape of the kernel (CRC_MAC_STREAM
+    1..4) and mac3_kernel (0), canonical and packed operands in and out"""
+    import crcnn_amd as ca
+    q = ca.default_coeff_modulus_128(8192)[:k] if k == 3 else ca.default_coeff_modulus_128(4096)
+    E = ca.Engine(n, q, 1 << 20, device=0)
+    rng = np.random.default_rng(n + in_dim)
+    qa = np.array(q, dtype=np.uint64).reshape(1, k, 1)
+    x = rng.integers(0, 1 << 62, size=(in_dim, 2, k, n), dtype=np.uint64) % qa.reshape(1, 1, k, 1)
+    w = rng.integers(0, 1 << 62, size=(out_dim * in_dim, k, n), dtype=np.uint64) % qa
+    x[0] = (qa - 1).reshape(1, k, 1); w[:in_dim] = qa - 1                 # the largest products on filter 0
+    bias = rng.integers(0, 1 << 62, size=(out_dim, k, n), dtype=np.uint64) % qa
+    qo = [int(v) for v in q]
+    xo, wo = x.astype(object), w.reshape(out_dim, in_dim, k, n).astype(object)
+    want = np.zeros((out_dim, 2, k, n), dtype=np.uint64)
+    for f in range(out_dim):
+        acc = (xo * wo[f][:, None]).sum(axis=0)                            # [2][k][n] exact integers
+        acc[0] = acc[0] + bias[f].astype(object)
+        for m in range(k):
+            want[f, :, m] = np.array([int(v) % qo[m] for v in acc[:, m].reshape(-1)], dtype=np.uint64).reshape(2, n)
+    d_x = E.upload(x); d_w = E.upload(w); d_b = E.upload(bias)
+    d_y = E.alloc(out_dim * 2 * k * n * 8)
+    d_work = E.alloc(E.dense_work_bytes(1, in_dim, out_dim, ca.NTT))
+    for shape in (1, 2, 3, 4, 0):
+        E.set_tuning("mac_stream", shape)
+        E.L.crc_memset(E.c, E.p(d_y), 0xff, out_dim * 2 * k * n * 8, E.stream)
+        E.dense(d_x, d_w, d_b, 1, in_dim, out_dim, ca.NTT, ca.NTT, d_y, d_work)
+        assert np.array_equal(E.download(d_y, want.shape), want), shape
+    # packed operands (CRC_NTTP: what Network::forward hands a dense layer that follows another one) in, packed out
+    E.set_tuning("mac_stream", 1)
+    d_xp = E.upload(x); E.pack28(d_xp, in_dim * 2 * k)
+    d_wp = E.upload(w); E.pack28(d_wp, out_dim * in_dim * k)
+    E.dense(d_xp, d_wp, d_b, 1, in_dim, out_dim, ca.NTTP, ca.NTTP, d_y, d_work, w_form=ca.NTTP)
+    E.pack28(d_y, out_dim * 2 * k, unpack=True)
+    assert np.array_equal(E.download(d_y, want.shape), want)
+    E.close()
