@@ -328,7 +328,8 @@ def run_host(args, cfg_name, steps, warmup, batch=None, device=0, ranks=None, st
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
         "data": f"synthetic ({D} distinct MNIST-like encrypted images tiled to the batch: one launch of {C * G} images resident in HBM, re-read by every launch of the step; "
                 f"trained weights from {cfg['model']}.h5)",
-        "config": {"workload": f"{cfg['model']}.h5 n={cfg['n']} k={cfg['k']} t=2^{cfg['t'].bit_length() - 1} batch={B}/GPU chunk={C}" + (f" (dense layers: {C * G})" if G > 1 else "") + f" ({cfg_name}, BASELINE configs)",
+        # (the batch actually evaluated per step: whole launches of C * G images -- 1020, not 1024, for wopad16384's launches of 30)
+        "config": {"workload": f"{cfg['model']}.h5 n={cfg['n']} k={cfg['k']} t=2^{cfg['t'].bit_length() - 1} batch={r.get('batch', B)}/GPU chunk={C}" + (f" (dense layers: {C * G})" if G > 1 else "") + f" ({cfg_name}, BASELINE configs)",
                    "host": r["host"], "mode": "NTT-resident" + ("" if args.no_fuse else " + Network::fuse (conv/pool and batch-norm folding)") +
                    ("" if r.get("matrix_cores", True) else "; matrix_cores = false: every conv / dense layer on the vector-ALU kernel (north_star's no-MFMA path)") +
                    (f"; client-side refresh in front of layer {cfg['reenc']} on the device (crc_refresh_dev)" if "reenc" in cfg else ""), "parallelism": f"image-sharded x{world}"},

@@ -401,10 +401,10 @@ extern "C" int crc_plan_fold_pool(const crc_ctx *c, int zd, int xd, int yd, int 
     return CRC_OK;
 }
 
-// ---- square + relinearize ----------------------------------------------------------------------------------------- ciphertexts per internal pass (bounds the
-// scratch footprint: ~10 GB at every ring size -- 512 up to n k = 65536, 256 at n = 16384 with all eight primes) ciphertexts per internal pass of square +
-// relinearise.  (Round 5: 1024 up to n k = 32768 -- the eight kernels of a pass each end in a partly filled last wave of workgroups; at (8192, 3) twice the
-// pass is 2 % faster, at (16384, 4) it changes nothing: profiles/r05_square_chunk_sweep.txt)
+// ---- square + relinearize -----------------------------------------------------------------------------------------
+// ciphertexts per internal pass of square + relinearise: bounds the scratch footprint at ~10 GB for every ring size -- 1024 up to n k = 32768, 512 up to 65536,
+// 256 at n = 16384 with all eight primes.  (Round 5: 1024 instead of 512 on the small rings -- the eight kernels of a pass each end in a partly filled last
+// wave of workgroups; at (8192, 3) twice the pass is 2 % faster, at (16384, 4) it changes nothing: profiles/r05_square_chunk_sweep.txt)
 static size_t square_chunk(const crc_ctx *c)
 {
     if (c->tune.sq_chunk > 0) return (size_t)c->tune.sq_chunk;

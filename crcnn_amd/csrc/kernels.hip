@@ -30,21 +30,21 @@ struct NttArgs {
     int prologue;
     // prologue 3 (forward): row = ((ct*D + g)*k + j); the source row is the premultiplied third polynomial c2 (q/q_i)^-1 mod q_i of ciphertext ct under
     //   modulus i = dig_i[g] (src = size-`src_size` ciphertexts, poly `src_poly`); the value fed to the transform is its digit (v >> dig_shift[g]) & dig_mask
-    //   (relinearize_one_step, evaluator.cpp:984-1001) -- the digit polynomials never exist in memory prologue 4 (inverse): row = ((ct*3 + p)*mod_count + j);
-    //   sources are the NTT-form rows a, b of polys 0 and 1 of ciphertext ct in `src` ([ct][2][mod_count][n]);
-    //   the value fed to the transform is a^2, 2ab or b^2 (Evaluator::square's dyadic products, evaluator.cpp:798-852)
-    //   (prologue 4: the three products of one (ciphertext, modulus) pair run on ONE XCD, blockIdx -> row through xcd_group; `pairs` = ciphertexts x mod_count)
+    //   (relinearize_one_step, evaluator.cpp:984-1001) -- the digit polynomials never exist in memory
+    // prologue 4 (inverse): row = ((ct*3 + p)*mod_count + j); sources are the NTT-form rows a, b of polys 0 and 1 of ciphertext ct in `src`
+    //   ([ct][2][mod_count][n]); the value fed to the transform is a^2, 2ab or b^2 (Evaluator::square's dyadic products, evaluator.cpp:798-852).
+    //   The three products of one (ciphertext, modulus) pair run on ONE XCD, blockIdx -> row through xcd_group; `pairs` = ciphertexts x mod_count
     // prologue 5 (inverse): the result leaves multiplied by the per-modulus constant post_mul (Shoup companion post_mul_s) -- the square's lift wants
     //   x m~ (q/q_i)^-1 mod q_i (baseconverter.cpp:686-696), and the Shoup multiplication takes the lazy value in place of the final reduction
     int D, src_size, src_poly; unsigned long long dig_mask;
     size_t pairs;
     u64 post_mul[CRC_MAXK], post_mul_s[CRC_MAXK];
-    // forward transforms of size-2 ciphertexts that leave as  NTT(row) + fma_u[ct][i] . fma_k[p][i]  (the device encryptor: noise rows + pk . NTT(u)); null:
-    // off
+    // forward transforms of size-2 ciphertexts that leave as  NTT(row) + fma_u[ct][i] . fma_k[p][i]  (the device encryptor: noise rows + pk . NTT(u));
+    // null: off
     const u64 *fma_u, *fma_k;
     unsigned long long fma_group;                              // fma_u null, fma_k set: the rows leave multiplied by the plaintext row fma_k[ct / fma_group][i]
-    // host side only, prologue 4: 1 = post_mul is OFFERED -- a kernel that closes with a multiplication anyway takes it in (and says so: 2), the others ignore
-    // it
+    // host side only, prologue 4: 1 = post_mul is OFFERED -- a kernel that closes with a multiplication anyway takes it in (and says so: 2), the others
+    // ignore it
     int opt_mul;
     unsigned char dig_i[48], dig_shift[48];
     const u64 *addend; int add_sign; int rows_per_ct; long long add_group;   // epilogue (inverse only)

@@ -444,11 +444,10 @@ int crc_refresh_dev_key(crc_ctx *ctx, const uint64_t *d_sk_ntt, const uint64_t *
  *   crc_checksum64        position-sensitive checksum of a device buffer: h_out[0] = xor of all words, h_out[1] =
  *                         sum_i w_i * (2i+1) mod 2^64; synchronises `stream`.  Every rank checks what it received against the
  *                         root's pair.
- * Rehearsal on one GPU: RCCL refuses two ranks on the same device.  With CRC_COMM_TRANSPORT=shm in the environment crc_comm_unique_id names a POSIX
- * shared-memory
- * segment instead of an RCCL rendezvous and the same calls stage their bytes through it (hipMemcpy, a process-shared barrier): the multi-rank HOST code above
- * this
- * header runs unchanged with several processes on one device.  A transport for tests only; never the default.
+ * Rehearsal on one GPU: RCCL refuses two ranks on the same device.  With CRC_COMM_TRANSPORT=shm in the environment crc_comm_unique_id makes a POSIX
+ * shared-memory segment (an unguessable name, created exclusively, mode 0600) instead of an RCCL rendezvous, names it in the id, and the same calls stage their
+ * bytes through it (hipMemcpy, a process-shared barrier): the multi-rank HOST code above this header runs unchanged with several processes on one device.
+ * A transport for tests only; never the default.
  * ------------------------------------------------------------------------------------------------------------- */
 typedef struct crc_comm crc_comm;
 #define CRC_COMM_ID_BYTES 128

@@ -340,7 +340,7 @@ def test_dense_at_batch_one_streams_its_weights(n, k, in_dim, out_dim):
     d_x = E.upload(x); d_w = E.upload(w); d_b = E.upload(bias)
     d_y = E.alloc(out_dim * 2 * k * n * 8)
     d_work = E.alloc(E.dense_work_bytes(1, in_dim, out_dim, ca.NTT))
-    for shape in (1, 2, 3, 4, 0):
+    for shape in (1, 2, 3, 4, 5, 0):
         E.set_tuning("mac_stream", shape)
         E.L.crc_memset(E.c, E.p(d_y), 0xff, out_dim * 2 * k * n * 8, E.stream)
         E.dense(d_x, d_w, d_b, 1, in_dim, out_dim, ca.NTT, ca.NTT, d_y, d_work)
