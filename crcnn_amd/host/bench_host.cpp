@@ -155,6 +155,7 @@ int main(int argc, char **argv)
             if (crc_comm_create(context, world, rank, id, &comm)) throw runtime_error("crc_comm_create failed (rccl error " +
                 to_string(crc_last_comm_error()) + ")");
         }
+        setExpectedBatch(launch);                             // (one image per forward: dense weights stay canonical and are streamed)
         CnnBuilder build(h5);
         Network net = build.buildNetworkByName(model);
         double bcast_s = 0.0; size_t bcast_bytes = 0;

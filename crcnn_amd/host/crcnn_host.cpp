@@ -482,6 +482,8 @@ ciphertext3D refreshImages(const ciphertext3D &t, int out_form, vector<float> *v
     return out;
 }
 
+static int g_expected_batch = 0;                            // images per Network::forward the caller announced (0: unknown)
+void setExpectedBatch(int images_per_forward) { g_expected_batch = images_per_forward > 0 ? images_per_forward : 0; }
 static bool tooLargeForHbm(size_t weights)
 {
     size_t free_b = 0, total_b = 0;
@@ -734,7 +736,9 @@ void FullyConnectedLayer::upload()
     }
     streamed = forced_placement >= 0 ? forced_placement == 1 : tooLargeForHbm(w.size());
     if (forced_placement >= 0) tilewise = forced_placement == 2;
-    else if (!streamed && plannedForm(in_dim, 1, 1, 1, 1, 1, 1, out_dim, 0) == CRC_NTTL) {
+    // (g_expected_batch: a deployment that evaluates one image at a time -- setExpectedBatch(1) -- never takes the limb GEMM for a dense layer, so its canonical
+    // weights stay resident and the layer runs as a weight stream (mac_stream_kernel) instead of being built tile-wise in limb form)
+    else if (!streamed && plannedForm(in_dim, 1, 1, 1, 1, 1, 1, out_dim, g_expected_batch) == CRC_NTTL) {
         // canonical + limb copy beyond what HBM has left, the limb copy alone within it: build the limb weights tile by tile at the first forward
         // (buildTilewise)
         size_t free_b = 0, total_b = 0;
@@ -804,7 +808,9 @@ void FullyConnectedLayer::buildTilewise()
 }
 size_t FullyConnectedLayer::deviceBytes() const { return bytesOf(d_w) + bytesOf(d_b[0]) + bytesOf(d_b[1]) + bytesOf(d_plain) + bytesOf(d_wtile) +
     bytesOf(d_ytile); }
-string FullyConnectedLayer::kernelName() const { return macKernelName(streamed ? stream_form : w_form, streamed) + (tilewise ?
+string FullyConnectedLayer::kernelName() const { if (last_B == 1 && !streamed && (w_form == CRC_NTTP || w_form == CRC_NTT)) return w_form == CRC_NTTP ?
+    "mac_stream_kernel (weight stream: one image, two rows per weight; v_mad_u64_u32, CRC_NTTP)" : "mac_stream_kernel (weight stream: one image; canonical residues)";
+    return macKernelName(streamed ? stream_form : w_form, streamed) + (tilewise ?
     ", limb weights built tile by tile" : ""); }
 int FullyConnectedLayer::placement() { upload(); return streamed ? 1 : tilewise ? 2 : 0; }
 bool FullyConnectedLayer::streamsOnMatrixCores(int B) { upload(); return streamed && plannedForm(in_dim, 1, 1, 1, 1, 1, 1, out_dim, B) == CRC_NTTL; }
@@ -867,6 +873,7 @@ ciphertext3D FullyConnectedLayer::forward(ciphertext3D input)
     // a tile-wise layer has no canonical weights: whoever reaches it first -- Network::forward through limbWeights, a direct call, a network with matrix_cores
     // off -- builds the limb tensor, the only form its weights exist in (the layer then runs on the limb GEMM whatever the plan would have been)
     if (tilewise && !tile_built) buildTilewise();
+    last_B = input.B;
     ciphertext3D out(input.B, 1, out_dim, 1, out_form);
     if (streamed) { stream_form = forwardStreamed(input, out, in_dim, 1, 1, 1, 1, 1, 1, out_dim, out_form, d_plain, d_b, d_wtile, d_ytile, g_scratch);
         return out; }

@@ -61,6 +61,10 @@ ciphertext3D deepCopyImage(const ciphertext3D &image);                  // globa
 extern crc_ctx *context;                                    // the engine context (SEALContext + Evaluator tables)
 // the HIP stream (hipStream_t behind void*; crc_stream_create makes one) all layer calls, copies and synchronisations of these classes go to; NULL = the
 // default stream.  Install it before the first forward(); the caller keeps ownership and orders its own streams against it with events
+// Announce the number of images a Network::forward will get (0 = unknown, the default) BEFORE the layers' weights are placed (fuse(), broadcastParameters(),
+// the first forward()): a deployment that evaluates one image at a time keeps every dense layer's canonical weights resident and streams them, where a batched
+// one may drop them for the matrix-core form (PlainModelWoPad's fc3 at n = 16384 has room for one of the two)
+void setExpectedBatch(int images_per_forward);
 void setStream(void *stream);
 void *getStream();
 extern std::vector<uint64_t> secret_key, public_key, ev_keys16_host;
@@ -187,6 +191,7 @@ private:
     // gets a canonical copy: its limb weights are built a tile of output rows at a time straight from the plaintexts (lift + NTT -> batch-norm fold of the tile
     // -> pack), a batch-norm layer that Network::fuse() folds into it being applied to every tile (same ciphertexts; netrun.py does the same)
     bool tilewise = false, tile_built = false;
+    int last_B = 0;                                         // images of the last forward (kernelName: one image runs as a weight stream)
     int forced_placement = -1;
     std::shared_ptr<BatchNormLayer> fold_bn;
     void buildTilewise();
