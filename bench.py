@@ -140,7 +140,7 @@ def run_host(args, cfg_name, steps, warmup, batch=None, device=0, ranks=None, st
     q = cfg.get("q") or ca.default_coeff_modulus_128(cfg["n"])[:cfg["k"]]
     D = max(1, min(over.get("distinct") or args.distinct or cfg.get("distinct", 4), C * G, B))
     rank, world = (ranks.rank, ranks.world) if ranks else (0, 1)
-    cores = max(1, cpu.host_cores() // (ranks.local_world if ranks else 1))
+    cores = cpu.host_cores(ranks.local_world if ranks else 1)
     keep_dir = os.environ.get("CRC_BENCH_KEEP")
     ci, reused = client_inputs(args, cfg_name, cfg, q, D, rank, cores)
     client, imgs, mnist, work, x0_sha = ci["client"], ci["imgs"][:D], ci["mnist"], ci["work"], ci["x0_sha"]
@@ -387,12 +387,16 @@ def main():
     if also == "auto":
         # the default invocation also measures BASELINE configs[2] (ApproxPlainModel, n = 8192, k = 3) and configs[4]'s per-GPU share (PlainModelWoPad, n = 16384, k = 4,
         # 1024 images) in the same process
-        also = ",".join(nm for nm, _ in AUTO_ALSO) if args.config == "tiny4096" and args.batch is None else "none"
+        # (N > 1: the two BASELINE configurations that are quoted on eight GPUs -- configs[3] and configs[4] -- and nothing else: the single-GPU lines would only make
+        # every rank encrypt more inputs on its share of the host cores)
+        auto_names = [nm for nm, _ in AUTO_ALSO] if world == 1 else ["approx8192", "wopad16384"]
+        also = ",".join(auto_names) if args.config == "tiny4096" and args.batch is None else "none"
     names = [] if also == "none" else also.split(",")
     auto = dict(AUTO_ALSO) if args.also == "auto" else {}
     latency_on = args.latency == "on" or (args.latency == "auto" and args.also == "auto" and args.config == "tiny4096" and args.batch is None and world == 1)
     if args.stream_inputs == "auto":
-        args.stream_inputs = "both" if args.config == "tiny4096" and args.batch is None else "none"
+        # (N = 1 only: eight ranks streaming at once would pin ~10 GB of host memory each and share one host's PCIe root -- a figure about the host, not the engine)
+        args.stream_inputs = "both" if args.config == "tiny4096" and args.batch is None and world == 1 else "none"
     line, ok = None, True
     if world == 1 or not args.python_twin:
         ranks = bdist.HostRanks(args) if world > 1 else None

@@ -9,9 +9,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def host_cores():
+def host_cores(ranks_on_node=1):
     """CPU cores this process may really use: scheduler affinity capped by the cgroup CPU quota (a GPU box gives one GPU's
-    share of the host, not all of its hardware threads)"""
+    share of the host, not all of its hardware threads), shared evenly by the ranks of the node, at most 16 (CRC_CPU_THREADS) per rank -- the same split
+    crc_host::thread_limit makes for the C++ side: eight ranks on a 128-thread host get 16 each, on a 16-thread one 2 each"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -19,7 +20,7 @@ def host_cores():
             n = min(n, max(1, int(int(quota) / int(period))))
     except Exception:
         pass
-    return max(1, min(n, int(os.environ.get("CRC_CPU_THREADS", "16"))))
+    return max(1, min(n // max(1, ranks_on_node), int(os.environ.get("CRC_CPU_THREADS", "16"))))
 
 
 def _ref_net(harness, d, cfg, q, dims, cts, topo_lines, floats, evk=None, timeout=900):
