@@ -95,10 +95,18 @@ _INPUTS = {}        # the client side of the configuration measured last: keys, 
 
 
 def drop_inputs():
+    # (CRC_BENCH_KEEP: the command lines stay; the encrypted inputs -- gigabytes per configuration -- stay only for the configurations CRC_BENCH_KEEP_CONFIGS names)
     keep_dir = os.environ.get("CRC_BENCH_KEEP")
+    keep_cfgs = [c_ for c_ in os.environ.get("CRC_BENCH_KEEP_CONFIGS", "").split(",") if c_]
     for c in _INPUTS.values():
         if not keep_dir:
             shutil.rmtree(c["work"], ignore_errors=True)
+        elif keep_cfgs and os.path.basename(c["work"]) not in keep_cfgs:
+            for f in ("inputs.u64", "plain_inputs.u64", "outputs.u64", "outputs.u64.streamed"):
+                try:
+                    os.remove(os.path.join(c["work"], f))
+                except OSError:
+                    pass
     _INPUTS.clear()
 
 

@@ -79,7 +79,7 @@ def layer_bytes_and_macs(E, kind, a, ishape, oshape, images):
 def offline_traffic(cfg_name, kind, kernel_label, cts_per_launch):
     """HBM traffic of the dominant launch from the PMC counters: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes collected OFFLINE (tools/pmc_square.sh, tools/pmc_mac.sh) and
     committed under profiles/ -- bench.py cannot run the profiler on itself, so this is never measured in the run that quotes it.  Returns (bytes or None, source or None)."""
-    for pf in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for pf in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", pf))).get(cfg_name)
             if pm and pm.get("per_ciphertext") and kind == "square":      # the Square + relinearise sequence: PMC bytes per ciphertext x the launch's ciphertexts
