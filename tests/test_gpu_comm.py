@@ -208,3 +208,12 @@ def test_bench_latency_published_and_valu_lines():
         else:
             assert all(k.startswith("mac3_kernel") or k.startswith("mac") for k in ln["mac_kernel_per_layer"].values()), ln["mac_kernel_per_layer"]
             assert "mfma" not in json.dumps(ln["mac_kernel_per_layer"])
+
+
+def test_bench_four_cpp_ranks_rehearsed_on_one_device():
+    """the same rehearsal with FOUR ranks (the box allows six GPU processes): the all-gathered placement / checksum / timing arrays, the rendezvous directory and the
+    failure markers are sized by the world, and a two-rank run exercises none of the indexing beyond rank 1.  Both weight-distribution strategies."""
+    for extra in ([], ["--weights-via", "floats"]):
+        line = _run_bench(["--gpus", "4"] + extra, {"CRC_COMM_TRANSPORT": "shm"})
+        _assert_cpp_ranks(line, 4)
+        assert line["config"]["parallelism"] == "image-sharded x4"
