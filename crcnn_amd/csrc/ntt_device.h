@@ -18,7 +18,14 @@ __device__ __forceinline__ bool xcd_group(unsigned b, unsigned G, size_t groups,
 // LDS index swizzle (XOR, no padding): conflict-free ds_read/write_b64 for the contiguous staging accesses AND for every strided
 // register-tile pattern of the radix-8 passes at n = 4096 (at most 2-way in the short tail pass of n = 8192 / 16384); found by
 // enumerating the access patterns (bank = index mod 32 per 32-lane group)
+#ifndef CRC_SWZ_KEEP_BIT0
 __device__ __forceinline__ int lpad(int i) { return i ^ ((i >> 3) & 7) ^ (((i >> 6) & 3) << 3); }
+#else
+// Experiment (round 6, -DCRC_SWZ_KEEP_BIT0): a swizzle that leaves bit 0 alone -- bits 5..7 into bits 1..3, bit 7 also into bit 4 -- so that the pair (s, s + 1), s
+// even, always sits in its 16-byte slot in order and the four v_cndmask of every pair access fold away.  Conflict-free for the radix-8 passes with element strides
+// 2, 16, 128 and 1024 (enumerated like the original); the 8-byte accesses of the wave-local kernels' cross passes (index 2 t + e) become two-way conflicts.
+__device__ __forceinline__ int lpad(int i) { return i ^ (((i >> 5) & 7) << 1) ^ (((i >> 7) & 1) << 4); }
+#endif
 // the same idea for passes of 16 / 32 values per thread (the fp64 transforms of kernels_relin64.hip): XOR of higher index bits into the low four = the sixteen
 // 8-byte slots of a 128-byte LDS row; found by enumerating every pass's access pattern in groups of 16 lanes (forward and inverse, n = 4096 / 8192 / 16384):
 // conflict-free for their own radix, at most 2-way in one pass of the radix-8 transforms below when those run on an image laid out this way (s, s + 1), s even,
