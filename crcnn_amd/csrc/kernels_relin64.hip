@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_digits_pool_f64
 // cut straight into the registers the cross pass works on (no fill), and the transformed block leaves through the wave's own drain.  POOL: one workgroup per
 // (pooled ciphertext, i); otherwise per (ciphertext, i).
 template <int CS, bool POOL>
-__global__ void __launch_bounds__(CS == 3 ? 512 : 1024, 4) relin_digits_wave_kernel(const u64 *src, int src_size, int src_poly, double *E, const double *Wf,
+__global__ void __launch_bounds__(CS == 2 ? 256 : CS == 3 ? 512 : 1024, 4) relin_digits_wave_kernel(const u64 *src, int src_size, int src_poly, double *E, const double *Wf,
     F64Params fp, int n,
                                                                                 int k, int D, int dbc, Relin64Tab tab, PoolGeom pg, int F)
 {
@@ -180,10 +180,10 @@ __global__ void __launch_bounds__(CS == 3 ? 512 : 1024, 4) relin_digits_wave_ker
     const int L = tab.L[i], g0 = tab.g0[i];
     u64 r[16];
     auto load_row = [&](const u64 *row, bool first) {
-        if (CS == 3) {
+        if (CS == 2 || CS == 3) {                                   // pairs: 16-byte loads (CS = 2: two pairs per block offset)
 #pragma unroll
             for (int c = 0; c < 8; c++) {
-                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(row + f64_cross_point<3>(2 * c));
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(row + f64_cross_point<CS == 2 ? 2 : 3>(2 * c));
                 if (!POOL) { r[2 * c] = v.x; r[2 * c + 1] = v.y; continue; }
                 const bool four = 3 * F < 64;
                 auto spread = [&](u64 x) {
@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(RB == 5 ? 512 : 1024, 4) relin_inv_crt_kernel(
 // memory). U64W: the forward transform over q_j that follows the CRT runs wave-locally too -- its cross pass works on the CRT's results where they are made, in
 // registers
 template <int CS, bool OUT_NTT, bool LAZY, bool U64W>
-__global__ void __launch_bounds__(CS == 3 ? 512 : 1024, 4) relin_inv_crt_wave_kernel(const double *A, const u64 *x3, int add_size, u64 *y,
+__global__ void __launch_bounds__(CS == 2 ? 256 : CS == 3 ? 512 : 1024, 4) relin_inv_crt_wave_kernel(const double *A, const u64 *x3, int add_size, u64 *y,
     const ModParams *mods, const double *Wi,
                                                                                  const ulonglong2 *Wq, F64Params fp, int n, int logn, int k, const u64 *mul,
                                                                                      PoolGeom pg)
@@ -442,10 +442,10 @@ __global__ void __launch_bounds__(CS == 3 ? 512 : 1024, 4) relin_inv_crt_wave_ke
     const int nw = pg.xf > 0 ? pg.xf * pg.yf : 1;
     u64 *sm = reinterpret_cast<u64 *>(smd);
     if (OUT_NTT) __syncthreads();                             // every wave has read its part of the image in the cross pass: the canonical sums go into it now
-    if constexpr (CS == 3) {
+    if constexpr (CS == 2 || CS == 3) {                        // pairs (CS = 2: two per block offset; the cross layout's registers 2 c, 2 c + 1 are neighbours either way)
 #pragma unroll
         for (int c = 0; c < 8; c++) {
-            const int s = f64_cross_point<3>(2 * c);
+            const int s = f64_cross_point<CS == 2 ? 2 : 3>(2 * c);
             ulonglong2 av = *reinterpret_cast<const ulonglong2 *>(add + s);
             for (int w = 1; w < nw; w++) {
                 const int kx = w / pg.yf, ky = w - kx * pg.yf;
@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(CS == 3 ? 512 : 1024, 4) relin_inv_crt_wave_ke
         int t2 = tid;
         // (... nor are the sixteen image addresses of the lifts kept alive for it: they are computed again)
         asm volatile("" : "+v"(t2));
-        auto own = [&](int c, int e) { return swz<3>(CS == 3 ? 2 * t2 + e + CRC_F64_BLOCK * c : t2 + CRC_F64_BLOCK * c); };
+        auto own = [&](int c, int e) { return swz<3>(CS == 2 ? 4 * t2 + e + CRC_F64_BLOCK * c : CS == 3 ? 2 * t2 + e + CRC_F64_BLOCK * c : t2 + CRC_F64_BLOCK * c); };
 #pragma unroll
         for (int e = 0; e < E; e++) {
             u64 x[C];
@@ -623,7 +623,7 @@ static int relin64_mac(crc_ctx *c, const double *E, const double *Kf, double *A,
 // prime's result in scratch, -0.3 % / -1.5 % of the whole sequence now -- its 64-bit forward transform is untouched: profiles/r05_square_pool_wave_local_*.txt)
 static bool f64_wave_path(const crc_ctx *c, int RB, int bit)
 {
-    if (RB != 3 || (c->logn != 13 && c->logn != 14)) return false;
+    if (RB != 3 || (c->logn != 12 && c->logn != 13 && c->logn != 14)) return false;      // (n = 4096 since round 6: CS = 2)
     const int sel = c->tune.f64_wave < 0 ? 7 : c->tune.f64_wave;
     return (sel >> bit) & 1;
 }
@@ -636,12 +636,11 @@ static int relin64_tail(crc_ctx *c, const double *A, const u64 *x3, int add_size
     for (int i = 0; i < c->k; i++) if (c->tabs[i].m.bits > 57 || c->tabs[i].m.bits < 45) lazy = false;
     const size_t lds = (size_t)c->n * 8;
     if (f64_wave_path(c, RB, 2)) {
-        const bool cs3 = c->logn == 13;
+        const int cs = c->logn - 10;
         const bool u64w = f64_wave_path(c, RB, 4);           // (bit 4: the 64-bit forward transform behind the CRT wave-local as well)
-        auto kern = !out_ntt ? (cs3 ? relin_inv_crt_wave_kernel<3, false, false, false> : relin_inv_crt_wave_kernel<4, false, false, false>)
-                  : lazy ? (u64w ? (cs3 ? relin_inv_crt_wave_kernel<3, true, true, true> : relin_inv_crt_wave_kernel<4, true, true, true>)
-                                 : (cs3 ? relin_inv_crt_wave_kernel<3, true, true, false> : relin_inv_crt_wave_kernel<4, true, true, false>))
-                         : (cs3 ? relin_inv_crt_wave_kernel<3, true, false, false> : relin_inv_crt_wave_kernel<4, true, false, false>);
+#define K3W(A, B, C) (cs == 2 ? relin_inv_crt_wave_kernel<2, A, B, C> : cs == 3 ? relin_inv_crt_wave_kernel<3, A, B, C> : relin_inv_crt_wave_kernel<4, A, B, C>)
+        auto kern = !out_ntt ? K3W(false, false, false) : lazy ? (u64w ? K3W(true, true, true) : K3W(true, true, false)) : K3W(true, false, false);
+#undef K3W
         { const int rc = crc_ctx_ensure_lds(c, (const void *)kern, lds); if (rc) return rc; }
         hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * 2 * c->k)), dim3(c->n / 16), lds, st, A, x3, add_size, y, c->d_mods, c->d_f64_irp,
                            reinterpret_cast<const ulonglong2 *>(c->d_rp), c->f64, c->n, c->logn, c->k, mul, pool ? *pool : PoolGeom{0, 0, 0, 0, 0, 0, 0, 0});
@@ -684,7 +683,7 @@ int k_relinearize64(crc_ctx *c, const u64 *src, int src_size, int src_poly, cons
         for (int i = 0; i < c->k; i++) { const int L = tab.L[i]; if ((L - 1) * F + ((int)c->tabs[i].m.bits - (L - 1) * dbc + wbits) > 64 || F > 32) one =
             false; }
         if (one && f64_wave_path(c, RB, 1)) {
-            auto kw = c->logn == 13 ? relin_digits_wave_kernel<3, true> : relin_digits_wave_kernel<4, true>;
+            auto kw = c->logn == 12 ? relin_digits_wave_kernel<2, true> : c->logn == 13 ? relin_digits_wave_kernel<3, true> : relin_digits_wave_kernel<4, true>;
             const int r3 = crc_ctx_ensure_lds(c, (const void *)kw, lds); if (r3) return r3;
             hipLaunchKernelGGL(kw, dim3((unsigned)(cnt * k)), dim3(c->n / 16), lds, st, src, src_size, src_poly, E, c->d_f64_rp, c->f64, c->n, c->k, D, dbc,
                 tab, *pool, F);
@@ -699,7 +698,7 @@ int k_relinearize64(crc_ctx *c, const u64 *src, int src_size, int src_poly, cons
         HIPCHK(hipGetLastError());
         }
     } else if (f64_wave_path(c, RB, 1)) {
-        auto kw = c->logn == 13 ? relin_digits_wave_kernel<3, false> : relin_digits_wave_kernel<4, false>;
+        auto kw = c->logn == 12 ? relin_digits_wave_kernel<2, false> : c->logn == 13 ? relin_digits_wave_kernel<3, false> : relin_digits_wave_kernel<4, false>;
         const int r3 = crc_ctx_ensure_lds(c, (const void *)kw, lds); if (r3) return r3;
         hipLaunchKernelGGL(kw, dim3((unsigned)(cnt * k)), dim3(c->n / 16), lds, st, src, src_size, src_poly, E, c->d_f64_rp, c->f64, c->n, c->k, D, dbc, tab,
                            PoolGeom{0, 0, 0, 0, 0, 0, 0, 0}, dbc);

@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(CS == 3 ? 512 : 1024, 4) sq64_liftfwd_wave_ker
 }
 // sq64_inv_kernel: a / b are held in the block-local layout the fills read them in; every product's transform ends in the cross pass and leaves from registers.
 template <int CS>
-__global__ void __launch_bounds__(CS == 3 ? 512 : 1024, 4) sq64_inv_wave_kernel(const double *in, double *out, const double *Wi, const Sq64Params *sp, int n,
+__global__ void __launch_bounds__(CS == 2 ? 256 : CS == 3 ? 512 : 1024, 4) sq64_inv_wave_kernel(const double *in, double *out, const double *Wi, const Sq64Params *sp, int n,
     int kf)
 {
     extern __shared__ double smd[];
@@ -357,7 +357,8 @@ static int sq64_threads(const crc_ctx *c, int RB) { int nt = c->n >> RB; if (nt 
 // eight waves per SIMD; off by default)
 static bool sq64_wave_path(const crc_ctx *c, int RB, int bit)
 {
-    if (RB != 3 || (c->logn != 13 && c->logn != 14)) return false;
+    // (n = 4096 since round 6: CS = 2; the lifting forward kernel -- bit 3, off by default -- exists for n = 8192 / 16384 only)
+    if (RB != 3 || (c->logn != 12 && c->logn != 13 && c->logn != 14) || (bit == 3 && c->logn == 12)) return false;
     const int sel = c->tune.f64_wave < 0 ? 7 : c->tune.f64_wave;
     return (sel >> bit) & 1;
 }
@@ -439,7 +440,7 @@ int k_square64(crc_ctx *c, const u64 *x, size_t cnt, u64 *y3, u64 *work, hipStre
     bool dq_scaled = false;
     if ((rc = k_square_intt(c, xn, DQ, cnt, false, st, c->behz.t_inv_qhat, &dq_scaled))) return rc;
     if (sq64_wave_path(c, RB, 0)) {
-        auto kern = c->logn == 13 ? sq64_inv_wave_kernel<3> : sq64_inv_wave_kernel<4>;
+        auto kern = c->logn == 12 ? sq64_inv_wave_kernel<2> : c->logn == 13 ? sq64_inv_wave_kernel<3> : sq64_inv_wave_kernel<4>;
         if ((rc = crc_ctx_ensure_lds(c, (const void *)kern, lds))) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * kf)), dim3(c->n / 16), lds, st, LB, DB, Wi, c->d_sq64, c->n, (int)kf);
         HIPCHK(hipGetLastError());

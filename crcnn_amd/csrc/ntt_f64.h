@@ -213,7 +213,7 @@ __device__ __forceinline__ void ntt_row_passes_f64(double *sm, const double *W, 
 
 // ---- ONE workgroup barrier per transform: wave-local passes (round 5) ---------------------------------------------------------------------------------------
 // A workgroup of n / 16 threads has n / 1024 waves; give wave w the 1024-point block [1024 w, 1024 w + 1024).  Only the CS = log2 n - 10 stages with gaps of
-// 1024 and more cross the blocks.  A thread that owns, at every block offset c 1024, the same position(s) inside the block -- the PAIR (2 t, 2 t + 1) for n =
+// 1024 and more cross the blocks (round 6: also CS = 2, n = 4096 -- the ring of the reference's published ApproxPlainModel run).  A thread that owns, at every block offset c 1024, the same position(s) inside the block -- the PAIR (2 t, 2 t + 1) for n =
 // 8192 (CS = 3: 8 offsets x 2 points), the single point t for n = 16384 (CS = 4: 16 offsets) -- runs those stages in registers, straight from (forward) or to
 // (inverse) memory: the fill and the first pass, or the last pass and the drain, are one step without an LDS round trip.  The other ten stages never leave a
 // block: three radix-8 passes in which wave w works on the 128 groups of ITS block (in every pass with a gap below 1024 the block of group g is g >> 7) and the
@@ -224,21 +224,26 @@ __device__ __forceinline__ void ntt_row_passes_f64(double *sm, const double *W, 
 //   cross layout of a thread's 16 points:  CS = 3: v[2 c + e] = point 2 t + e + 1024 c;  CS = 4: v[c] = point t + 1024 c
 //   block-local layout (fill / drain):     pair u of a thread = points 1024 w + 2 lane + 128 u and the next one, u < 8
 #define CRC_F64_BLOCK 1024
-__device__ __forceinline__ bool f64_wave_geometry(int n, int logn) { return (logn == 13 || logn == 14) && (int)blockDim.x * 16 == n; }
+__device__ __forceinline__ bool f64_wave_geometry(int n, int logn) { return (logn == 12 || logn == 13 || logn == 14) && (int)blockDim.x * 16 == n; }
 __device__ __forceinline__ void f64_wave_sync()
 {
     // the compiler must not move this wave's LDS reads above its own earlier LDS writes (the hardware never does)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// (round 6: CS = 2, n = 4096 on 256 threads: v[4 c + e] = point 4 t + e + 1024 c -- four block offsets x four points, two 16-byte accesses per offset)
 template <int CS> __device__ __forceinline__ int f64_cross_point(int i)
 {
-    return CS == 3 ? 2 * (int)threadIdx.x + (i & 1) + CRC_F64_BLOCK * (i >> 1) : (int)threadIdx.x + CRC_F64_BLOCK * i;
+    return CS == 2 ? 4 * (int)threadIdx.x + (i & 3) + CRC_F64_BLOCK * (i >> 2)
+         : CS == 3 ? 2 * (int)threadIdx.x + (i & 1) + CRC_F64_BLOCK * (i >> 1) : (int)threadIdx.x + CRC_F64_BLOCK * i;
 }
 __device__ __forceinline__ int f64_local_pair(int u) { return CRC_F64_BLOCK * (int)(threadIdx.x >> 6) + 2 * (int)(threadIdx.x & 63) + 128 * u; }
 // a row of doubles in memory <-> the cross layout (16-byte accesses for CS = 3, 8-byte ones -- 512 contiguous bytes per wave instruction -- for CS = 4)
 template <int CS> __device__ __forceinline__ void f64_cross_load(const double *row, double (&v)[16])
 {
-    if (CS == 3) {
+    if (CS == 2) {
+#pragma unroll
+        for (int h = 0; h < 8; h++) { const d2 x = *reinterpret_cast<const d2 *>(row + f64_cross_point<2>(2 * h)); v[2 * h] = x.x; v[2 * h + 1] = x.y; }
+    } else if (CS == 3) {
 #pragma unroll
         for (int c = 0; c < 8; c++) { const d2 x = *reinterpret_cast<const d2 *>(row + f64_cross_point<3>(2 * c)); v[2 * c] = x.x; v[2 * c + 1] = x.y; }
     } else {
@@ -248,7 +253,10 @@ template <int CS> __device__ __forceinline__ void f64_cross_load(const double *r
 }
 template <int CS> __device__ __forceinline__ void f64_cross_store(double *row, const double (&v)[16])
 {
-    if (CS == 3) {
+    if (CS == 2) {
+#pragma unroll
+        for (int h = 0; h < 8; h++) *reinterpret_cast<d2 *>(row + f64_cross_point<2>(2 * h)) = d2{v[2 * h], v[2 * h + 1]};
+    } else if (CS == 3) {
 #pragma unroll
         for (int c = 0; c < 8; c++) *reinterpret_cast<d2 *>(row + f64_cross_point<3>(2 * c)) = d2{v[2 * c], v[2 * c + 1]};
     } else {
@@ -274,7 +282,18 @@ __device__ __forceinline__ void f64_cross_fwd_to_image(double *sm, const double 
     load_tw_fwd<CS>(tw, W, 1, 0);
 #pragma unroll
     for (int i = 0; i < (1 << CS) - 1; i++) tw[i] = f64_uniform(tw[i]);
-    if constexpr (CS == 3) {
+    if constexpr (CS == 2) {
+        // two radix-4 groups at a time: the points (4 t + 2 h, 4 t + 2 h + 1) at the four block offsets -- a pair per offset, stored with ONE 16-byte access
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            double x0[4], x1[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) { x0[c] = get(4 * c + 2 * h); x1[c] = get(4 * c + 2 * h + 1); }
+            fwd_stages_f64<2>(x0, tw, md); fwd_stages_f64<2>(x1, tw, md);
+#pragma unroll
+            for (int c = 0; c < 4; c++) sm_store_pair<RB>(sm, f64_cross_point<2>(4 * c + 2 * h), x0[c], x1[c]);
+        }
+    } else if constexpr (CS == 3) {
 #pragma unroll
         for (int e = 0; e < 2; e++) {
             double x[8];
@@ -300,7 +319,18 @@ __device__ __forceinline__ void f64_cross_inv_from_image(const double *sm, const
     load_tw_inv<CS>(tw, W, n >> 11, 0);                        // the first of these stages has gap 1024: table index n / 2048
 #pragma unroll
     for (int i = 0; i < (1 << CS) - 1; i++) tw[i] = f64_uniform(tw[i]);
-    if constexpr (CS == 3) {
+    if constexpr (CS == 2) {
+        // (two stages of sums on inputs below 1.75 p: differences below 7 p, inside the multiplier's range -- no reduction on the way in)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            double x0[4], x1[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) { const d2 v = sm_load_pair<RB>(sm, f64_cross_point<2>(4 * c + 2 * h)); x0[c] = v.x; x1[c] = v.y; }
+            inv_stages_f64<2>(x0, tw, md); inv_stages_f64<2>(x1, tw, md);
+#pragma unroll
+            for (int c = 0; c < 4; c++) { put(4 * c + 2 * h, x0[c]); put(4 * c + 2 * h + 1, x1[c]); }
+        }
+    } else if constexpr (CS == 3) {
 #pragma unroll
         for (int e = 0; e < 2; e++) {
             double x[8];

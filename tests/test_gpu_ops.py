@@ -422,9 +422,9 @@ def test_square_over_fp64_auxiliary_base_equals_reference_base(n, k, t, cnt):
             E.square_relin(d_x, N, d_evk, d_y, d_w, in_form=ca.NTT, out_form=ca.NTT)
             assert np.array_equal(E.download(d_y, x.shape), res[(1, ca.NTT, ca.NTT)]), ("sq_fuse", fuse, "radix", radix)
     E.set_tuning("sq_fuse", -1); E.set_tuning("f64_radix", 0)
-    # round 5: the fp64 row kernels with one workgroup barrier per transform (wave-local passes; n = 8192 / 16384) -- every kernel of the family switched off
+    # round 5: the fp64 row kernels with one workgroup barrier per transform (wave-local passes; n = 4096 / 8192 / 16384) -- every kernel of the family switched off
     # (0: the round-4 kernels) and on (15: including the lifting forward kernel the default leaves alone): the reference base's ciphertexts both ways
-    if n in (8192, 16384):
+    if n in (4096, 8192, 16384):                          # (n = 4096 since round 6: two cross stages)
         for wave in (0, 15):
             E.set_tuning("f64_wave", wave)
             for fin, fout in [(ca.COEFF, ca.COEFF), (ca.NTT, ca.NTT)]:
