@@ -122,7 +122,8 @@ struct CrcTuning {
     // CRC_SQ_FUSE=1: an NTT-resident square lifts inside its forward fp64 transforms, 0: in a kernel of its own (round 3), -1: by k (fused up to k = 4)
     int sq_fuse = -1;
     // CRC_NTT_WAVE: the lazy 64-bit row transforms with one workgroup barrier per transform (ntt_rows_wave_kernel): bit 0 n = 8192, 1 n = 4096,
-    // 2 n = 16384, 3 n = 16384 with the Square prologues, 4 inverse butterflies that halve per stage (round 4) instead of scaling once; -1: measured (15)
+    // 2 n = 16384, 3 n = 16384 with the Square prologues, 4 inverse butterflies that halve per stage (round 4) instead of scaling once, 5 n = 2048 (round 6);
+    // -1: measured (47 = bits 0 to 3 and 5)
     int ntt_wave = -1;
     int f64_wave = -1;
                                   // 2 K3, 3 the lifting forward kernel, 4 K3's 64-bit forward transform (with bit 2); -1: what measured faster

@@ -176,9 +176,10 @@ __global__ void __launch_bounds__(1024) ntt_rows_kernel(NttArgs a) { ntt_rows_bo
 // wave-local passes | barrier | the cross stages from the image to registers -> final reduction (PRO 5: the scaled result) -> 16-byte stores.  Same butterflies
 // on the same values as ntt_rows_body, hence the same results.  Prologues 0 / 4 / 5 without an addend; everything else stays with ntt_rows_kernel.
 template <bool INV, int PRO, int CS, bool UNS, int FMA = 0>
-__global__ void __launch_bounds__(CS == 2 ? 256 : CS == 3 ? 512 : 1024, 4) ntt_rows_wave_kernel(NttArgs a)
+__global__ void __launch_bounds__(CS == 1 ? 128 : CS == 2 ? 256 : CS == 3 ? 512 : 1024, 4) ntt_rows_wave_kernel(NttArgs a)
 {
-    // CS = log2 n - 10 stages cross the 1024-point blocks (n = 4096 / 8192 / 16384: 2 / 3 / 4); a thread owns E = 16 >> CS neighbouring points of every block
+    // CS = log2 n - 10 stages cross the 1024-point blocks (n = 2048 / 4096 / 8192 / 16384: 1 / 2 / 3 / 4; n = 2048 -- the ring of the reference's published
+    // PlainModelTiny run -- since round 6); a thread owns E = 16 >> CS neighbouring points of every block
     constexpr int E = 16 >> CS, C = 1 << CS;
     extern __shared__ u64 sm[];
     const int n = a.n, tid = threadIdx.x;
@@ -551,10 +552,11 @@ static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t
     // wave-local passes (ntt_rows_wave_kernel): CRC_NTT_WAVE bit 0 n = 8192, bit 1 n = 4096, bit 2 n = 16384 (plain transforms), bit 3 n = 16384 with the
     // Square prologues (slower than the split kernel with the halving butterflies, 11.9 against 11.7 us per squared ciphertext, faster with the ones that do
     // not halve: 11.27 against 11.6 -- profiles/r05_ntt_u64_wave_local_ab.txt, r05_ntt_inverse_unscaled_ab.txt), bit 4: keep the halving butterflies; -1: bits
-    // 0 to 3
+    // 0 to 3 and 5
     {
-        const int sel = c->tune.ntt_wave < 0 ? 15 : c->tune.ntt_wave;
-        const int bit = c->n == 8192 ? 0 : c->n == 4096 ? 1 : c->n == 16384 ? (a.prologue ? 3 : 2) : -1;
+        // (bit 5, round 6: n = 2048 -- one cross stage, two waves per workgroup)
+        const int sel = c->tune.ntt_wave < 0 ? 47 : c->tune.ntt_wave;
+        const int bit = c->n == 8192 ? 0 : c->n == 4096 ? 1 : c->n == 16384 ? (a.prologue ? 3 : 2) : c->n == 2048 ? 5 : -1;
         if (bit >= 0 && ((sel >> bit) & 1) && lazy && !a.addend && (a.prologue == 0 || a.prologue == 4 || a.prologue == 5)) {
             lds = (size_t)c->n * 8;
             // inverse transforms over moduli below 2^55 take the butterflies that do not halve (inv_stages_unscaled; CRC_NTT_WAVE bit 4 switches them off): the
@@ -570,17 +572,19 @@ static int ntt_launch(crc_ctx *c, bool inv, NttArgs &a, size_t rows, hipStream_t
                 }
                 if (a.opt_mul) a.opt_mul = 2;
             }
+            const int cs = c->logn - 10;
 #define WAVEK(CSV, U) (a.prologue == 4 ? ntt_rows_wave_kernel<true, 4, CSV, U> : a.prologue == 5 ? ntt_rows_wave_kernel<true, 5, CSV, U> \
                        : inv ? ntt_rows_wave_kernel<true, 0, CSV, U> : ntt_rows_wave_kernel<false, 0, CSV, false>)
-            auto kw = uns ? (bit == 0 ? WAVEK(3, true) : bit == 1 ? WAVEK(2, true) : WAVEK(4, true)) : (bit == 0 ? WAVEK(3, false) : bit == 1 ? WAVEK(2,
-                false) : WAVEK(4, false));
+#define WAVECS(U) (cs == 1 ? WAVEK(1, U) : cs == 2 ? WAVEK(2, U) : cs == 3 ? WAVEK(3, U) : WAVEK(4, U))
+#define WAVEF(FV) (cs == 1 ? ntt_rows_wave_kernel<false, 0, 1, false, FV> : cs == 2 ? ntt_rows_wave_kernel<false, 0, 2, false, FV> \
+                   : cs == 3 ? ntt_rows_wave_kernel<false, 0, 3, false, FV> : ntt_rows_wave_kernel<false, 0, 4, false, FV>)
+            auto kw = uns ? WAVECS(true) : WAVECS(false);
             if (a.fma_u || a.fma_k) {
                 if (inv || a.prologue || a.pack_out) return CRC_ERR_INVALID_ARGUMENT;
-                if (a.fma_u) kw = bit == 0 ? ntt_rows_wave_kernel<false, 0, 3, false, 1> : bit == 1 ? ntt_rows_wave_kernel<false, 0, 2, false, 1>
-                                                                                                    : ntt_rows_wave_kernel<false, 0, 4, false, 1>;
-                else kw = bit == 0 ? ntt_rows_wave_kernel<false, 0, 3, false, 2> : bit == 1 ? ntt_rows_wave_kernel<false, 0, 2, false, 2>
-                                                                                            : ntt_rows_wave_kernel<false, 0, 4, false, 2>;
+                kw = a.fma_u ? WAVEF(1) : WAVEF(2);
             }
+#undef WAVEF
+#undef WAVECS
 #undef WAVEK
             { const int rc = crc_ctx_ensure_lds(c, (const void *)kw, lds); if (rc) return rc; }
             hipLaunchKernelGGL(kw, dim3((unsigned)rows), dim3(c->n / 16), lds, st, a);

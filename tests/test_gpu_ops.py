@@ -222,7 +222,7 @@ def test_baseline_ring_sizes_vs_oracle(n, q, t):
     want_edge = np.stack([O.ct_to_ntt(c) for c in edge])
     # the row transforms both ways round: the round-4 kernels (ntt_wave 0), the ones with one workgroup barrier per transform (15: every ring size
     # that has them, round 5; 31: with inverse butterflies that halve at every stage instead of scaling once) and the engine's own choice (-1)
-    for wave in (0, 15, 31, -1):
+    for wave in (0, 15, 31, 47, 63, -1):                   # (bit 5, round 6: n = 2048)
         E.set_tuning("ntt_wave", wave)
         d = E.upload(cts)
         E.ntt_fwd(d, 3)
