@@ -361,10 +361,10 @@ ALSO_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_ste
              "roofline", "cpu_baseline", "check", "vs_published", "setup_s", "weight_broadcast", "per_rank", "streamed", "hbm_plan", "python_twin")
 
 # what the default invocation measures beside the tiny4096 headline, in this order (configurations that share a parameter set follow each other: they share the
-# encrypted inputs), with the steps / batch of each: the BASELINE configs ([2], [4]'s per-GPU share), CrCNN's own coefficient modulus at n = 8192 (k = 4), north_star's
+# encrypted inputs), with the steps / batch of each: the BASELINE configs ([2], [4]'s per-GPU share), CrCNN's own coefficient moduli (k = 4 at n = 8192, all eight primes at n = 16384: fc3 streams its weights), north_star's
 # no-MFMA path, and the reference's two PUBLISHED configurations with their client-side refresh
 AUTO_ALSO = [("tiny4096_valu", dict(steps=2)), ("approx8192", dict()), ("wopad16384", dict()), ("approx8192k4", dict(steps=1, batch=512, distinct=8, cpu=False)),
-             ("tiny2048r", dict(steps=2, cpu=False)), ("approx4096r", dict(steps=2, cpu=False))]
+             ("wopad16384k8", dict(steps=1, distinct=4, cpu=False)), ("tiny2048r", dict(steps=2, cpu=False)), ("approx4096r", dict(steps=2, cpu=False))]
 # single-image latency (mainparams.cpp:85-112: the reference's whole usage model is one image at a time): bench_host batch=1 chunk=1, a synchronisation per image
 LATENCY_STEPS = {"tiny4096": 20, "approx8192": 20, "wopad16384": 5}
 
